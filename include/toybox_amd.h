@@ -1,0 +1,227 @@
+/*
+ * toybox_amd.h -- C-ABI boundary of the MI355X-native batched Toybox engine.
+ *
+ * What this replaces.  In the reference (toybox-rs/Toybox) every game-step call goes
+ * through the Python module `ctoybox` (cffi over the Rust cdylib of ctoybox==0.5.0,
+ * /root/reference/REQUIREMENTS.txt:12), one opaque pointer per env, one FFI call per
+ * operation.  The call sites that define the contract are cited per entry point below
+ * (paths relative to /root/reference).  This header is the batched, device-resident
+ * replacement of that per-env FFI: one engine handle owns N envs of one game on one GPU.
+ *
+ * Conventions (all entry points):
+ *   - return int: 0 = TBX_OK, <0 = error (never abort / throw across the ABI);
+ *     tbx_last_error() returns an engine-owned message valid until the next call;
+ *   - plain pointers and sizes only; buffers are caller-allocated;
+ *   - "_host" arguments are host pointers (call is synchronous), "_dev" arguments are
+ *     device (HBM) pointers (call is asynchronous on the given hipStream_t, passed as void*);
+ *   - a handle is not thread-safe; different handles may be used concurrently;
+ *   - there is NO CPU fallback: tbx_create fails with TBX_E_NO_DEVICE when no gfx950
+ *     device is visible.
+ *
+ * The POD structs below are the lossless per-env state/config records that the Python
+ * host turns into the interventions JSON schema
+ * (toybox/interventions/{core,breakout,amidar,space_invaders}.py) and back.
+ */
+#ifndef TOYBOX_AMD_H
+#define TOYBOX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ constants */
+
+#define TBX_ABI_VERSION 1
+
+#define TBX_GAME_BREAKOUT       0
+#define TBX_GAME_AMIDAR         1
+#define TBX_GAME_SPACE_INVADERS 2
+#define TBX_NUM_GAMES           3
+
+#define TBX_OK            0
+#define TBX_E_INVALID    -1   /* bad argument (range, NULL, size mismatch)          */
+#define TBX_E_NO_DEVICE  -2   /* no usable gfx950 device / HIP runtime error        */
+#define TBX_E_NOMEM      -3
+#define TBX_E_UNSUPPORTED -4  /* state/config outside what the device engine holds  */
+#define TBX_E_ACTION     -5   /* an illegal ALE action id was seen (treated as NOOP) */
+
+/* Input buttons bitmask == ctoybox.Input fields
+ * (scripts/utils/test_games.py:13, test/interventions/test_breakout_interventions.py:12-15). */
+#define TBX_BTN_LEFT    1u
+#define TBX_BTN_RIGHT   2u
+#define TBX_BTN_UP      4u
+#define TBX_BTN_DOWN    8u
+#define TBX_BTN_BUTTON1 16u
+#define TBX_BTN_BUTTON2 32u
+
+/* tbx_step flags */
+#define TBX_STEP_AUTO_RESET 1u  /* VecEnv semantics: a done env is reset inside the step
+                                   (baselines/common/vec_env/dummy_vec_env.py:51-54) */
+
+/* device buffers addressable with tbx_device_buffer() */
+#define TBX_BUF_REWARD  0   /* int32[N]  max(score - prev_score, 0) of the last step (envs/atari/base.py:136-138) */
+#define TBX_BUF_DONE    1   /* uint8[N]  lives <= 0 after the last step (envs/atari/base.py:25-27,142)          */
+#define TBX_BUF_LIVES   2   /* int32[N]  (pre-reset value when auto-reset fired)                                */
+#define TBX_BUF_SCORE   3   /* int32[N]  (pre-reset value when auto-reset fired)                                */
+#define TBX_BUF_FRAME   4   /* uint8[N,H,W,C] last tbx_render_device() into the engine-owned frame buffer       */
+#define TBX_BUF_PACKED  5   /* uint64[N] {reward:i32, done:u8, lives:u8, pad:u16} record for the multi-GPU gather */
+
+/* RGBA colour, memory order r,g,b,a (interventions/core.py:179-187) */
+typedef struct tbx_color { uint8_t r, g, b, a; } tbx_color_t;
+
+/* ------------------------------------------------------------------ Breakout POD */
+
+#define TBX_BRK_MAX_BALLS    4
+#define TBX_BRK_COLS         18
+#define TBX_BRK_MAX_ROWS     14
+#define TBX_BRK_MAX_BRICKS   256   /* >= 18 * 14 */
+#define TBX_BRK_MAX_STARTS   8
+#define TBX_BRK_MAX_SEGMENTS 16
+
+/* Breakout world (pixels == world units).  Anchored on the golden dump
+ * toybox/interventions/defaults/breakout_state_default.json: bricks at (12+12c, 43+4r),
+ * paddle (120,143), 18 columns => field x in [12,228). */
+#define TBX_BRK_W            240
+#define TBX_BRK_H            160
+#define TBX_BRK_LEFT         12.0
+#define TBX_BRK_RIGHT        228.0
+#define TBX_BRK_TOP          25.0
+#define TBX_BRK_BOTTOM       160.0
+#define TBX_BRK_WALL_Y0      13
+#define TBX_BRK_BRICK_Y0     43.0
+#define TBX_BRK_BRICK_W      12.0
+#define TBX_BRK_BRICK_H      4.0
+#define TBX_BRK_PADDLE_H     3.0
+
+typedef struct tbx_breakout_config {
+    uint64_t rand[2];                 /* simulator RNG == config_to_json()['rand']['state'] */
+    int32_t  start_lives;
+    int32_t  n_rows;                  /* len(row_scores) == len(row_colors) */
+    int32_t  row_scores[TBX_BRK_MAX_ROWS];
+    tbx_color_t row_colors[TBX_BRK_MAX_ROWS];
+    int32_t  ball_speed_row_depth;
+    int32_t  n_starts;
+    double   ball_speed_slow, ball_speed_fast;
+    double   start_x[TBX_BRK_MAX_STARTS], start_y[TBX_BRK_MAX_STARTS];
+    double   start_angle_deg[TBX_BRK_MAX_STARTS];
+    /* host-evaluated trig (libm), so that no transcendental runs on the device:
+       start_dir = (cos a, sin a) of start_angle_deg */
+    double   start_dir_x[TBX_BRK_MAX_STARTS], start_dir_y[TBX_BRK_MAX_STARTS];
+    int32_t  paddle_discrete_segments;   /* 1..16 */
+    int32_t  _pad0;
+    /* paddle_dir[i] = (cos a_i, -sin a_i), a_i = 150 - i*120/(S-1) degrees (S==1: 90) */
+    double   paddle_dir_x[TBX_BRK_MAX_SEGMENTS], paddle_dir_y[TBX_BRK_MAX_SEGMENTS];
+    tbx_color_t bg_color, frame_color, paddle_color, ball_color;
+} tbx_breakout_config_t;
+
+typedef struct tbx_brick {
+    double   x, y, w, h;              /* position, size */
+    int32_t  points, depth, row, col;
+    tbx_color_t color;
+    uint8_t  alive, destructible, _pad[2];
+} tbx_brick_t;
+
+typedef struct tbx_breakout_state {
+    uint64_t rand[2];
+    int32_t  score, lives, level;
+    uint8_t  is_dead, reset, _pad0[2];
+    double   paddle_x, paddle_y, paddle_vx, paddle_vy;
+    double   paddle_width, paddle_speed, ball_radius;
+    int32_t  n_balls, n_bricks;
+    double   ball_x[TBX_BRK_MAX_BALLS], ball_y[TBX_BRK_MAX_BALLS];
+    double   ball_vx[TBX_BRK_MAX_BALLS], ball_vy[TBX_BRK_MAX_BALLS];
+    tbx_brick_t bricks[TBX_BRK_MAX_BRICKS];
+} tbx_breakout_state_t;
+
+/* ------------------------------------------------------------------ engine */
+
+typedef struct tbx_engine tbx_engine;
+
+/* ABI version of the loaded library. */
+int tbx_abi_version(void);
+
+/* Last error text; engine may be NULL (errors of tbx_create). */
+const char* tbx_last_error(const tbx_engine* engine);
+
+/* Static game metadata.
+ * replaces Toybox.get_height/get_width (envs/atari/base.py:64-65) and
+ * Toybox.get_legal_action_set (envs/atari/base.py:57, test/benchmark.py:48). */
+int tbx_frame_dims(int game, int* height, int* width);
+int tbx_legal_actions(int game, int32_t* out_actions, int cap);   /* returns count or <0 */
+/* ALE action id (envs/atari/constants.py:16-35) -> TBX_BTN_* mask; <0 if out of 0..17. */
+int tbx_ale_action_to_buttons(int ale_action);
+size_t tbx_state_size(int game);
+size_t tbx_config_size(int game);
+
+/* Create an engine of n_envs envs of one game on HIP device `device`.
+ * config_pod may be NULL (game defaults == interventions/defaults/<game>_config_default.json).
+ * Every env's simulator RNG starts at config.rand; all envs are then given a first game.
+ * replaces ctoybox.Toybox(name) (envs/atari/breakout.py:8, interventions/breakout.py:38). */
+int tbx_create(int game, int n_envs, int device, const void* config_pod, size_t config_size,
+               tbx_engine** out_engine);
+int tbx_destroy(tbx_engine* engine);
+int tbx_num_envs(const tbx_engine* engine);
+int tbx_game(const tbx_engine* engine);
+
+/* Re-seed the simulator RNG: env >= 0 -> that env gets `seed`; env == -1 -> env i gets seed+i.
+ * Takes effect at the next new game, as in the reference (envs/atari/base.py:95-97).
+ * replaces Toybox.set_seed (envs/atari/base.py:95, scripts/utils/test_games.py:30). */
+int tbx_seed(tbx_engine* engine, int env, uint32_t seed);
+int tbx_get_sim_rng(tbx_engine* engine, int env, uint64_t out_state[2]);
+int tbx_set_sim_rng(tbx_engine* engine, int env, const uint64_t state[2]);
+
+/* Start a new game in the envs whose mask byte is non-zero (mask_host == NULL: all).
+ * replaces Toybox.new_game (envs/atari/base.py:97,153; test/benchmark.py:54). */
+int tbx_new_game(tbx_engine* engine, const uint8_t* mask_host);
+
+/* One game frame for every env.  actions are ALE action ids.  Host-pointer form: synchronous,
+ * any output pointer may be NULL.
+ * replaces Toybox.apply_ale_action + get_score/get_lives/game_over
+ * (envs/atari/base.py:126,136,142,145; test/benchmark.py:52-56). */
+int tbx_step(tbx_engine* engine, const int32_t* ale_actions_host, uint32_t flags,
+             int32_t* reward_host, uint8_t* done_host, int32_t* lives_host, int32_t* score_host);
+/* Device-pointer form: asynchronous on `stream`; results land in the TBX_BUF_* buffers. */
+int tbx_step_device(tbx_engine* engine, const int32_t* ale_actions_dev, uint32_t flags, void* stream);
+/* Same, with the actions generated on the device: env e at time t plays
+ * legal[ splitmix64(action_seed ^ (e_global << 32) ^ t) mod n_legal ], e_global = env_offset + e. */
+int tbx_step_synthetic(tbx_engine* engine, uint64_t action_seed, uint64_t t, uint64_t env_offset,
+                       uint32_t flags, void* stream);
+/* One frame for one env with a raw button mask.
+ * replaces Toybox.apply_action(Input) (scripts/utils/test_games.py:13). */
+int tbx_apply_input(tbx_engine* engine, int env, uint32_t buttons);
+
+/* Scalar reads for every env (any pointer may be NULL).
+ * replaces get_score/get_lives/get_level/game_over (envs/atari/base.py:20-27). */
+int tbx_get_scalars(tbx_engine* engine, int32_t* score_host, int32_t* lives_host,
+                    int32_t* level_host, uint8_t* game_over_host);
+
+/* Rasterise every env's current state: out[N][H][W][channels], channels 1 (gray), 3 (RGB), 4 (RGBA).
+ * replaces Toybox.get_state / get_rgb_frame (envs/atari/base.py:109,164). */
+int tbx_render(tbx_engine* engine, uint8_t* out_host, int channels);
+/* out_dev == NULL renders into the engine-owned TBX_BUF_FRAME buffer. */
+int tbx_render_device(tbx_engine* engine, uint8_t* out_dev, int channels, void* stream);
+/* Rasterise one env (host pointer, synchronous). */
+int tbx_render_env(tbx_engine* engine, int env, uint8_t* out_host, int channels);
+
+/* Per-env lossless state record (tbx_<game>_state_t).
+ * replaces Toybox.to_state_json / write_state_json (interventions/base.py:391,406). */
+int tbx_get_state(tbx_engine* engine, int env, void* pod_out, size_t size);
+int tbx_set_state(tbx_engine* engine, int env, const void* pod, size_t size);
+/* Batch-wide config record (tbx_<game>_config_t); `rand` is env 0's simulator RNG on get and
+ * is written to every env on set.  Does not start a new game.
+ * replaces Toybox.config_to_json / write_config_json (interventions/base.py:390,402). */
+int tbx_get_config(tbx_engine* engine, void* pod_out, size_t size);
+int tbx_set_config(tbx_engine* engine, const void* pod, size_t size);
+
+/* Address of an engine-owned device buffer (TBX_BUF_*). */
+int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out_bytes);
+/* Block until all work queued by this engine has finished; reports a pending TBX_E_ACTION. */
+int tbx_sync(tbx_engine* engine);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOYBOX_AMD_H */

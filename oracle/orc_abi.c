@@ -1,0 +1,328 @@
+/* orc_abi.c -- the C-ABI of include/toybox_amd.h restated over the CPU oracle.
+ * TEST INFRASTRUCTURE ONLY (see oracle.h): it lets tests/ drive the product's Python host
+ * (toybox_amd.Engine, Toybox, envs) over the oracle on a machine without a GPU, and lets the
+ * GPU parity tests run the very same call sequence against both libraries.  "Device" pointers
+ * are host pointers here and streams are ignored.  The product never loads this library. */
+#include "oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct tbx_engine {
+    int game, n;
+    size_t ssz, csz;
+    void* cfg;
+    char* states;
+    uint64_t* sim;        /* [n][2] */
+    int32_t* prev;
+    int32_t *reward, *lives, *score;
+    uint8_t* done;
+    uint64_t* packed;
+    uint8_t* frame;
+    size_t frame_bytes;
+    int pending_action_error;
+    int threads;
+    char err[256];
+};
+
+static char g_err[256];
+
+static int fail(tbx_engine* e, int code, const char* msg)
+{
+    snprintf(e ? e->err : g_err, 256, "%s", msg);
+    return code;
+}
+
+int tbx_abi_version(void) { return TBX_ABI_VERSION; }
+const char* tbx_last_error(const tbx_engine* e) { return e ? e->err : g_err; }
+int tbx_frame_dims(int game, int* h, int* w) { return orc_frame_dims(game, h, w) ? TBX_E_INVALID : TBX_OK; }
+int tbx_legal_actions(int game, int32_t* out, int cap) { int n = orc_legal_actions(game, out, cap); return n < 0 ? TBX_E_INVALID : n; }
+int tbx_ale_action_to_buttons(int a) { int b = orc_ale_action_to_buttons(a); return b < 0 ? TBX_E_INVALID : b; }
+
+size_t tbx_state_size(int game)
+{
+    switch (game) {
+    case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_state_t);
+    default: return 0;
+    }
+}
+size_t tbx_config_size(int game)
+{
+    switch (game) {
+    case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_config_t);
+    default: return 0;
+    }
+}
+
+int tbx_destroy(tbx_engine* e)
+{
+    if (!e) return TBX_OK;
+    free(e->cfg); free(e->states); free(e->sim); free(e->prev); free(e->reward); free(e->lives);
+    free(e->score); free(e->done); free(e->packed); free(e->frame);
+    free(e);
+    return TBX_OK;
+}
+
+int tbx_create(int game, int n, int device, const void* cfg, size_t cfg_size, tbx_engine** out)
+{
+    (void)device;
+    if (!out) return TBX_E_INVALID;
+    *out = NULL;
+    if (n < 1) return fail(NULL, TBX_E_INVALID, "n_envs must be >= 1");
+    size_t ssz = tbx_state_size(game), csz = tbx_config_size(game);
+    if (!ssz) return fail(NULL, TBX_E_INVALID, "unknown game id");
+    if (cfg && cfg_size != csz) return fail(NULL, TBX_E_INVALID, "config size mismatch");
+    tbx_engine* e = (tbx_engine*)calloc(1, sizeof *e);
+    e->game = game; e->n = n; e->ssz = ssz; e->csz = csz;
+    e->cfg = calloc(1, csz);
+    e->states = (char*)calloc((size_t)n, ssz);
+    e->sim = (uint64_t*)calloc((size_t)n * 2, 8);
+    e->prev = (int32_t*)calloc((size_t)n, 4);
+    e->reward = (int32_t*)calloc((size_t)n, 4);
+    e->lives = (int32_t*)calloc((size_t)n, 4);
+    e->score = (int32_t*)calloc((size_t)n, 4);
+    e->done = (uint8_t*)calloc((size_t)n, 1);
+    e->packed = (uint64_t*)calloc((size_t)n, 8);
+    const char* th = getenv("TBX_ORACLE_THREADS");
+    e->threads = th ? atoi(th) : 1;
+    if (cfg) memcpy(e->cfg, cfg, csz);
+    else switch (game) {
+        case TBX_GAME_BREAKOUT: orc_breakout_default_config((tbx_breakout_config_t*)e->cfg); break;
+    }
+    for (int i = 0; i < n; i++) memcpy(e->sim + 2 * (size_t)i, e->cfg, 16);
+    orc_new_game_batch(game, e->cfg, e->states, e->sim, e->prev, n, NULL);
+    *out = e;
+    return TBX_OK;
+}
+
+int tbx_num_envs(const tbx_engine* e) { return e ? e->n : TBX_E_INVALID; }
+int tbx_game(const tbx_engine* e) { return e ? e->game : TBX_E_INVALID; }
+
+int tbx_seed(tbx_engine* e, int env, uint32_t seed)
+{
+    if (!e) return TBX_E_INVALID;
+    if (env < -1 || env >= e->n) return fail(e, TBX_E_INVALID, "env index out of range");
+    for (int i = 0; i < e->n; i++) {
+        if (env >= 0 && i != env) continue;
+        orc_rng_seed(e->sim + 2 * (size_t)i, env >= 0 ? seed : seed + (uint32_t)i);
+    }
+    return TBX_OK;
+}
+
+int tbx_get_sim_rng(tbx_engine* e, int env, uint64_t out[2])
+{
+    if (!e) return TBX_E_INVALID;
+    if (env < 0 || env >= e->n || !out) return fail(e, TBX_E_INVALID, "env index out of range");
+    out[0] = e->sim[2 * (size_t)env]; out[1] = e->sim[2 * (size_t)env + 1];
+    return TBX_OK;
+}
+
+int tbx_set_sim_rng(tbx_engine* e, int env, const uint64_t st[2])
+{
+    if (!e) return TBX_E_INVALID;
+    if (env < -1 || env >= e->n || !st) return fail(e, TBX_E_INVALID, "env index out of range");
+    for (int i = 0; i < e->n; i++) {
+        if (env >= 0 && i != env) continue;
+        e->sim[2 * (size_t)i] = st[0]; e->sim[2 * (size_t)i + 1] = st[1];
+    }
+    return TBX_OK;
+}
+
+int tbx_new_game(tbx_engine* e, const uint8_t* mask)
+{
+    if (!e) return TBX_E_INVALID;
+    orc_new_game_batch(e->game, e->cfg, e->states, e->sim, e->prev, e->n, mask);
+    return TBX_OK;
+}
+
+static void pack_outputs(tbx_engine* e)
+{
+    for (int i = 0; i < e->n; i++) {
+        int32_t lv = e->lives[i];
+        uint32_t l8 = lv < 0 ? 0u : lv > 255 ? 255u : (uint32_t)lv;
+        e->packed[i] = (uint64_t)(uint32_t)e->reward[i] | ((uint64_t)(e->done[i] ? 1u : 0u) << 32) | ((uint64_t)l8 << 40);
+    }
+}
+
+int tbx_step_device(tbx_engine* e, const int32_t* actions, uint32_t flags, void* stream)
+{
+    (void)stream;
+    if (!e) return TBX_E_INVALID;
+    if (!actions) return fail(e, TBX_E_INVALID, "actions pointer is NULL");
+    int rc = orc_step_batch(e->game, e->cfg, e->states, e->sim, e->prev, e->n, actions, flags,
+                            e->reward, e->done, e->lives, e->score, e->threads);
+    pack_outputs(e);
+    if (rc == TBX_E_ACTION) e->pending_action_error = 1;
+    return TBX_OK;
+}
+
+int tbx_step_synthetic(tbx_engine* e, uint64_t seed, uint64_t t, uint64_t env_offset, uint32_t flags, void* stream)
+{
+    if (!e) return TBX_E_INVALID;
+    int32_t* a = (int32_t*)malloc((size_t)e->n * 4);
+    for (int i = 0; i < e->n; i++) a[i] = orc_synthetic_action(e->game, seed, env_offset + (uint64_t)i, t);
+    int rc = tbx_step_device(e, a, flags, stream);
+    free(a);
+    return rc;
+}
+
+static int take_action_error(tbx_engine* e)
+{
+    if (e->pending_action_error) {
+        e->pending_action_error = 0;
+        return fail(e, TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
+    }
+    return TBX_OK;
+}
+
+int tbx_step(tbx_engine* e, const int32_t* actions, uint32_t flags, int32_t* reward, uint8_t* done,
+             int32_t* lives, int32_t* score)
+{
+    int rc = tbx_step_device(e, actions, flags, NULL);
+    if (rc) return rc;
+    size_t n = (size_t)e->n;
+    if (reward) memcpy(reward, e->reward, n * 4);
+    if (done) memcpy(done, e->done, n);
+    if (lives) memcpy(lives, e->lives, n * 4);
+    if (score) memcpy(score, e->score, n * 4);
+    return take_action_error(e);
+}
+
+int tbx_apply_input(tbx_engine* e, int env, uint32_t buttons)
+{
+    if (!e) return TBX_E_INVALID;
+    if (env < 0 || env >= e->n) return fail(e, TBX_E_INVALID, "env index out of range");
+    void* st = e->states + e->ssz * (size_t)env;
+    switch (e->game) {
+    case TBX_GAME_BREAKOUT:
+        orc_breakout_step((const tbx_breakout_config_t*)e->cfg, (tbx_breakout_state_t*)st, buttons & 0x3Fu);
+        break;
+    }
+    int32_t sc, lv, le;
+    orc_get_scalars(e->game, st, 1, &sc, &lv, &le);
+    int32_t r = sc - e->prev[env];
+    if (r < 0) r = 0;
+    e->prev[env] = sc;
+    e->reward[env] = r; e->done[env] = lv <= 0; e->lives[env] = lv; e->score[env] = sc;
+    pack_outputs(e);
+    return TBX_OK;
+}
+
+int tbx_get_scalars(tbx_engine* e, int32_t* score, int32_t* lives, int32_t* level, uint8_t* over)
+{
+    if (!e) return TBX_E_INVALID;
+    int32_t* lv = (int32_t*)malloc((size_t)e->n * 4);
+    orc_get_scalars(e->game, e->states, e->n, score, lv, level);
+    for (int i = 0; i < e->n; i++) {
+        if (lives) lives[i] = lv[i];
+        if (over) over[i] = lv[i] <= 0;
+    }
+    free(lv);
+    return TBX_OK;
+}
+
+int tbx_render_device(tbx_engine* e, uint8_t* out, int channels, void* stream)
+{
+    (void)stream;
+    if (!e) return TBX_E_INVALID;
+    if (channels != 1 && channels != 3 && channels != 4) return fail(e, TBX_E_INVALID, "channels must be 1, 3 or 4");
+    int h, w;
+    orc_frame_dims(e->game, &h, &w);
+    if (!out) {
+        size_t bytes = (size_t)e->n * h * w * channels;
+        if (e->frame_bytes < bytes) { free(e->frame); e->frame = (uint8_t*)malloc(bytes); e->frame_bytes = bytes; }
+        out = e->frame;
+    }
+    orc_render_batch(e->game, e->cfg, e->states, e->n, out, channels, e->threads);
+    return TBX_OK;
+}
+
+int tbx_render(tbx_engine* e, uint8_t* out, int channels)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!out) return fail(e, TBX_E_INVALID, "output pointer is NULL");
+    return tbx_render_device(e, out, channels, NULL);
+}
+
+int tbx_render_env(tbx_engine* e, int env, uint8_t* out, int channels)
+{
+    if (!e) return TBX_E_INVALID;
+    if (env < 0 || env >= e->n || !out) return fail(e, TBX_E_INVALID, "env index out of range");
+    if (channels != 1 && channels != 3 && channels != 4) return fail(e, TBX_E_INVALID, "channels must be 1, 3 or 4");
+    orc_render_batch(e->game, e->cfg, e->states + e->ssz * (size_t)env, 1, out, channels, 1);
+    return TBX_OK;
+}
+
+int tbx_get_state(tbx_engine* e, int env, void* pod, size_t size)
+{
+    if (!e) return TBX_E_INVALID;
+    if (env < 0 || env >= e->n || !pod) return fail(e, TBX_E_INVALID, "env index out of range");
+    if (size != e->ssz) return fail(e, TBX_E_INVALID, "state record size mismatch");
+    memcpy(pod, e->states + e->ssz * (size_t)env, size);
+    return TBX_OK;
+}
+
+int tbx_set_state(tbx_engine* e, int env, const void* pod, size_t size)
+{
+    if (!e) return TBX_E_INVALID;
+    if (env < 0 || env >= e->n || !pod) return fail(e, TBX_E_INVALID, "env index out of range");
+    if (size != e->ssz) return fail(e, TBX_E_INVALID, "state record size mismatch");
+    if (e->game == TBX_GAME_BREAKOUT) {
+        const tbx_breakout_state_t* s = (const tbx_breakout_state_t*)pod;
+        if (s->n_balls < 0 || s->n_balls > TBX_BRK_MAX_BALLS) return fail(e, TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 4 balls per env");
+        if (s->n_bricks < 0 || s->n_bricks > TBX_BRK_MAX_BRICKS) return fail(e, TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 256 bricks per env");
+    }
+    memcpy(e->states + e->ssz * (size_t)env, pod, size);
+    return TBX_OK;
+}
+
+int tbx_get_config(tbx_engine* e, void* pod, size_t size)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!pod || size != e->csz) return fail(e, TBX_E_INVALID, "config record size mismatch");
+    memcpy(pod, e->cfg, size);
+    memcpy(pod, e->sim, 16);
+    return TBX_OK;
+}
+
+int tbx_set_config(tbx_engine* e, const void* pod, size_t size)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!pod || size != e->csz) return fail(e, TBX_E_INVALID, "config record size mismatch");
+    if (e->game == TBX_GAME_BREAKOUT) {
+        const tbx_breakout_config_t* k = (const tbx_breakout_config_t*)pod;
+        if (k->n_rows < 1 || k->n_rows > TBX_BRK_MAX_ROWS) return fail(e, TBX_E_UNSUPPORTED, "breakout: n_rows must be 1..14");
+        if (k->n_starts < 1 || k->n_starts > TBX_BRK_MAX_STARTS) return fail(e, TBX_E_UNSUPPORTED, "breakout: 1..8 ball_start_positions");
+        if (k->paddle_discrete_segments < 1 || k->paddle_discrete_segments > TBX_BRK_MAX_SEGMENTS)
+            return fail(e, TBX_E_UNSUPPORTED, "breakout: paddle_discrete_segments must be 1..16");
+    }
+    memcpy(e->cfg, pod, size);
+    for (int i = 0; i < e->n; i++) memcpy(e->sim + 2 * (size_t)i, pod, 16);
+    return TBX_OK;
+}
+
+int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_bytes)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!out_ptr) return fail(e, TBX_E_INVALID, "out_ptr is NULL");
+    size_t n = (size_t)e->n, b = 0;
+    void* p = NULL;
+    switch (which) {
+    case TBX_BUF_REWARD: p = e->reward; b = n * 4; break;
+    case TBX_BUF_DONE: p = e->done; b = n; break;
+    case TBX_BUF_LIVES: p = e->lives; b = n * 4; break;
+    case TBX_BUF_SCORE: p = e->score; b = n * 4; break;
+    case TBX_BUF_FRAME: p = e->frame; b = e->frame_bytes; break;
+    case TBX_BUF_PACKED: p = e->packed; b = n * 8; break;
+    default: return fail(e, TBX_E_INVALID, "unknown buffer id");
+    }
+    *out_ptr = p;
+    if (out_bytes) *out_bytes = b;
+    return TBX_OK;
+}
+
+int tbx_sync(tbx_engine* e)
+{
+    if (!e) return TBX_E_INVALID;
+    return take_action_error(e);
+}

@@ -1,0 +1,901 @@
+// breakout.hip -- Breakout on gfx950: one 64-lane wavefront per env.
+//
+// Replaces the per-env Rust transition + rasteriser behind ctoybox.Toybox.apply_ale_action /
+// get_state (call sites: /root/reference/toybox/envs/atari/base.py:126,109).  Semantics are the
+// ones stated in DESIGN.md "Breakout" and restated independently (scalar C) in oracle/orc_breakout.c;
+// the two are compared bit for bit by tests/test_gpu_parity.py.
+//
+// Layout in HBM: struct-of-arrays over the env batch for every scalar field (field f of env e at
+// base_f[e]); brick liveness as 4 x uint64 bit-words per env ([4][N]).  Brick geometry / colour /
+// points are canonical functions of the brick index and the config unless an intervention wrote a
+// non-canonical brick, in which case the engine switches to per-env brick tables ([N][field][256],
+// brick index fastest so that the 64 lanes of an env's wave read them coalesced).
+//
+// Lane roles: every lane carries the (wave-uniform) scalar state; lane l owns bricks l, l+64,
+// l+128, l+192 for the collision test (ballot -> lowest index) and pixels 4l..4l+3 of each
+// scanline in the rasteriser.
+//
+// Arithmetic is IEEE binary64 with -ffp-contract=off: + - * / sqrt ceil fabs only, all trig is
+// host-evaluated into the config tables, so results equal the CPU oracle's bit for bit.
+
+#include "tbx_common.hpp"
+
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int MAXB = TBX_BRK_MAX_BALLS;
+constexpr int MAXK = TBX_BRK_MAX_BRICKS / 64;   // brick slots per lane
+
+// per-env custom brick table: [field][256]
+struct BrkCustom {
+    double x[TBX_BRK_MAX_BRICKS], y[TBX_BRK_MAX_BRICKS], w[TBX_BRK_MAX_BRICKS], h[TBX_BRK_MAX_BRICKS];
+    int32_t points[TBX_BRK_MAX_BRICKS], depth[TBX_BRK_MAX_BRICKS], row[TBX_BRK_MAX_BRICKS], col[TBX_BRK_MAX_BRICKS];
+    uint32_t color[TBX_BRK_MAX_BRICKS];
+    uint8_t destructible[TBX_BRK_MAX_BRICKS];
+};
+
+// device view of the SoA state (passed by value as kernel argument)
+struct BrkDev {
+    int n;
+    // engine-common
+    uint64_t* sim_rng;      // [2][N]
+    int32_t* prev_score;
+    int32_t* reward;
+    uint8_t* done;
+    int32_t* lives_out;
+    int32_t* score_out;
+    uint64_t* packed;
+    uint32_t* err_flag;
+    // game state
+    uint64_t* rng;          // [2][N]
+    int32_t* score;
+    int32_t* lives;
+    int32_t* level;
+    int32_t* flags;         // bit0 is_dead, bit1 reset
+    double* paddle;         // [7][N]: x y vx vy width speed ball_radius
+    int32_t* n_balls;
+    double* balls;          // [16][N]: x[4] y[4] vx[4] vy[4]
+    int32_t* n_bricks;
+    uint64_t* alive;        // [4][N]
+    BrkCustom* custom;      // [N] or nullptr
+};
+
+// config as the kernels see it (kernel argument, scalar loads)
+struct BrkCfg {
+    int32_t start_lives, n_rows, ball_speed_row_depth, n_starts, segments;
+    int32_t row_scores[TBX_BRK_MAX_ROWS];
+    uint32_t row_colors[TBX_BRK_MAX_ROWS];
+    double speed_slow, speed_fast;
+    double start_x[TBX_BRK_MAX_STARTS], start_y[TBX_BRK_MAX_STARTS];
+    double start_dx[TBX_BRK_MAX_STARTS], start_dy[TBX_BRK_MAX_STARTS];
+    double pad_dx[TBX_BRK_MAX_SEGMENTS], pad_dy[TBX_BRK_MAX_SEGMENTS];
+    uint32_t bg, frame, paddle, ball;
+};
+
+// wave-uniform register copy of one env
+struct BrkRegs {
+    Rng rng;
+    int32_t score, lives, level, flags;
+    double px, py, pvx, pvy, pw, pspeed, radius;
+    int32_t n_balls, n_bricks;
+    double bx[MAXB], by[MAXB], bvx[MAXB], bvy[MAXB];
+    uint32_t mybits;   // per lane: bit k = brick (lane + 64k) alive
+};
+
+__device__ __forceinline__ void brk_load(const BrkDev& d, int env, int lane, BrkRegs& s)
+{
+    const size_t N = (size_t)d.n;
+    s.rng.s0 = d.rng[env];
+    s.rng.s1 = d.rng[N + env];
+    s.score = d.score[env];
+    s.lives = d.lives[env];
+    s.level = d.level[env];
+    s.flags = d.flags[env];
+    s.px = d.paddle[0 * N + env];
+    s.py = d.paddle[1 * N + env];
+    s.pvx = d.paddle[2 * N + env];
+    s.pvy = d.paddle[3 * N + env];
+    s.pw = d.paddle[4 * N + env];
+    s.pspeed = d.paddle[5 * N + env];
+    s.radius = d.paddle[6 * N + env];
+    s.n_balls = d.n_balls[env];
+    s.n_bricks = d.n_bricks[env];
+#pragma unroll
+    for (int b = 0; b < MAXB; b++) {
+        s.bx[b] = d.balls[(size_t)(0 * MAXB + b) * N + env];
+        s.by[b] = d.balls[(size_t)(1 * MAXB + b) * N + env];
+        s.bvx[b] = d.balls[(size_t)(2 * MAXB + b) * N + env];
+        s.bvy[b] = d.balls[(size_t)(3 * MAXB + b) * N + env];
+    }
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) {
+        uint64_t w = d.alive[(size_t)k * N + env];
+        bits |= (uint32_t)((w >> lane) & 1ull) << k;
+    }
+    s.mybits = bits;
+}
+
+__device__ __forceinline__ void brk_store(const BrkDev& d, int env, int lane, const BrkRegs& s)
+{
+    const size_t N = (size_t)d.n;
+    uint64_t words[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) words[k] = __ballot((s.mybits >> k) & 1u);
+    if (lane == 0) {
+        d.rng[env] = s.rng.s0;
+        d.rng[N + env] = s.rng.s1;
+        d.score[env] = s.score;
+        d.lives[env] = s.lives;
+        d.level[env] = s.level;
+        d.flags[env] = s.flags;
+        d.paddle[0 * N + env] = s.px;
+        d.paddle[1 * N + env] = s.py;
+        d.paddle[2 * N + env] = s.pvx;
+        d.paddle[3 * N + env] = s.pvy;
+        d.paddle[4 * N + env] = s.pw;
+        d.paddle[5 * N + env] = s.pspeed;
+        d.paddle[6 * N + env] = s.radius;
+        d.n_balls[env] = s.n_balls;
+        d.n_bricks[env] = s.n_bricks;
+#pragma unroll
+        for (int b = 0; b < MAXB; b++) {
+            d.balls[(size_t)(0 * MAXB + b) * N + env] = s.bx[b];
+            d.balls[(size_t)(1 * MAXB + b) * N + env] = s.by[b];
+            d.balls[(size_t)(2 * MAXB + b) * N + env] = s.bvx[b];
+            d.balls[(size_t)(3 * MAXB + b) * N + env] = s.bvy[b];
+        }
+#pragma unroll
+        for (int k = 0; k < MAXK; k++) d.alive[(size_t)k * N + env] = words[k];
+    }
+}
+
+__device__ __forceinline__ void brk_start_ball(const BrkCfg& c, BrkRegs& s)
+{
+    uint64_t i = s.rng.range((uint64_t)c.n_starts);
+    int k = s.n_balls;
+    if (k >= MAXB) return;
+    double x = c.start_x[i], y = c.start_y[i];
+    double vx = c.speed_slow * c.start_dx[i], vy = c.speed_slow * c.start_dy[i];
+#pragma unroll
+    for (int b = 0; b < MAXB; b++)
+        if (b == k) { s.bx[b] = x; s.by[b] = y; s.bvx[b] = vx; s.bvy[b] = vy; }
+    s.n_balls = k + 1;
+}
+
+// canonical brick j of an n_rows wall
+__device__ __forceinline__ void brk_canon(int j, int rows, int& row, int& col, double& x, double& y)
+{
+    col = j / rows;
+    row = j - col * rows;
+    x = TBX_BRK_LEFT + TBX_BRK_BRICK_W * (double)col;
+    y = TBX_BRK_BRICK_Y0 + TBX_BRK_BRICK_H * (double)row;
+}
+
+template <bool CUSTOM>
+__device__ __forceinline__ void brk_new_game(const BrkDev& d, const BrkCfg& c, int env, int lane, Rng& sim, BrkRegs& s)
+{
+    s.rng = sim.child();
+    s.score = 0;
+    s.lives = c.start_lives;
+    s.level = 1;
+    s.flags = 3;
+    s.px = 120.0; s.py = 143.0; s.pvx = 0.0; s.pvy = 0.0;
+    s.pw = 24.0; s.pspeed = 4.0; s.radius = 2.0;
+    s.n_bricks = TBX_BRK_COLS * c.n_rows;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) {
+        int j = lane + 64 * k;
+        if (j < s.n_bricks) bits |= 1u << k;
+        if (CUSTOM) {
+            BrkCustom& t = d.custom[env];
+            if (j < s.n_bricks) {
+                int row, col; double x, y;
+                brk_canon(j, c.n_rows, row, col, x, y);
+                t.x[j] = x; t.y[j] = y; t.w[j] = TBX_BRK_BRICK_W; t.h[j] = TBX_BRK_BRICK_H;
+                t.points[j] = c.row_scores[row]; t.depth[j] = c.n_rows - 1 - row;
+                t.row[j] = row; t.col[j] = col; t.color[j] = c.row_colors[row]; t.destructible[j] = 1;
+            } else {
+                t.x[j] = t.y[j] = t.w[j] = t.h[j] = 0.0;
+                t.points[j] = t.depth[j] = t.row[j] = t.col[j] = 0; t.color[j] = 0; t.destructible[j] = 0;
+            }
+        }
+    }
+    s.mybits = bits;
+    s.n_balls = 0;
+#pragma unroll
+    for (int b = 0; b < MAXB; b++) { s.bx[b] = 0.0; s.by[b] = 0.0; s.bvx[b] = 0.0; s.bvy[b] = 0.0; }
+    brk_start_ball(c, s);
+}
+
+// ------------------------------------------------------------------ new game
+
+template <bool CUSTOM>
+__global__ __launch_bounds__(TBX_BLOCK) void brk_new_game_kernel(BrkDev d, BrkCfg c, const uint8_t* mask)
+{
+    const int lane = threadIdx.x & 63;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (env >= d.n) return;
+    if (mask && !mask[env]) return;
+    const size_t N = (size_t)d.n;
+    Rng sim;
+    sim.s0 = d.sim_rng[env];
+    sim.s1 = d.sim_rng[N + env];
+    BrkRegs s;
+    brk_new_game<CUSTOM>(d, c, env, lane, sim, s);
+    brk_store(d, env, lane, s);
+    if (lane == 0) {
+        d.sim_rng[env] = sim.s0;
+        d.sim_rng[N + env] = sim.s1;
+        d.prev_score[env] = s.score;
+    }
+}
+
+// ------------------------------------------------------------------ step
+
+template <bool CUSTOM>
+__global__ __launch_bounds__(TBX_BLOCK) void brk_step_kernel(BrkDev d, BrkCfg c, ActionSource src, uint32_t flags,
+                                                             int first_env, int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (rel >= count) return;
+    const int env = first_env + rel;
+    const size_t N = (size_t)d.n;
+
+    // ---- action -> buttons
+    uint32_t buttons;
+    if (src.single_env >= 0) {
+        buttons = src.single_buttons;
+    } else {
+        int a;
+        if (src.actions) a = src.actions[env];
+        else {
+            uint64_t h = tbx_splitmix64(src.seed ^ ((src.env_offset + (uint64_t)env) << 32) ^ src.t);
+            a = tbx_legal_action(TBX_GAME_BREAKOUT, (int)(h % 4ull));
+        }
+        buttons = tbx_ale_buttons(a);
+        if (buttons == 0xFFu) {
+            buttons = 0;
+            if (lane == 0) atomicOr(d.err_flag, 1u);
+        }
+    }
+
+    BrkRegs s;
+    brk_load(d, env, lane, s);
+
+    // ---- lane-owned brick rectangles
+    double kx[MAXK], ky[MAXK], kw[MAXK], kh[MAXK];
+    const int nk = (s.n_bricks + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) {
+        int j = lane + 64 * k;
+        kx[k] = ky[k] = kw[k] = kh[k] = 0.0;
+        if (k < nk && j < s.n_bricks) {
+            if (CUSTOM) {
+                const BrkCustom& t = d.custom[env];
+                kx[k] = t.x[j]; ky[k] = t.y[j]; kw[k] = t.w[j]; kh[k] = t.h[j];
+            } else {
+                int row, col;
+                brk_canon(j, c.n_rows, row, col, kx[k], ky[k]);
+                kw[k] = TBX_BRK_BRICK_W; kh[k] = TBX_BRK_BRICK_H;
+            }
+        }
+    }
+
+    // 1. paddle intent
+    if (buttons & TBX_BTN_LEFT) s.pvx = -s.pspeed;
+    else if (buttons & TBX_BTN_RIGHT) s.pvx = s.pspeed;
+    else s.pvx = 0.0;
+    s.pvy = 0.0;
+
+    // 2. launch
+    if ((s.flags & 1) && (buttons & TBX_BTN_BUTTON1)) s.flags = 0;
+    const bool launched = !(s.flags & 1);
+
+    // 3. slices
+    const double r = s.radius;
+    int nsl = 1;
+    if (launched && r > 0.0) {
+        double vmax = 0.0;
+#pragma unroll
+        for (int b = 0; b < MAXB; b++)
+            if (b < s.n_balls) {
+                double m = sqrt(s.bvx[b] * s.bvx[b] + s.bvy[b] * s.bvy[b]);
+                if (m > vmax) vmax = m;
+            }
+        double q = ceil(vmax / r);
+        if (q > 16.0) q = 16.0;
+        if (q >= 1.0) nsl = (int)q;
+    }
+    nsl = wave_uniform(nsl);
+    const double dt = 1.0 / (double)nsl;
+    const double half = s.pw * 0.5;
+    bool gone[MAXB] = {false, false, false, false};
+
+    for (int sl = 0; sl < nsl; sl++) {
+        s.px = s.px + s.pvx * dt;
+        if (s.px - half < TBX_BRK_LEFT) s.px = TBX_BRK_LEFT + half;
+        else if (s.px + half > TBX_BRK_RIGHT) s.px = TBX_BRK_RIGHT - half;
+        if (!launched) continue;
+        const double pl = s.px - half, pr = s.px + half;
+#pragma unroll
+        for (int b = 0; b < MAXB; b++) {
+            if (b >= s.n_balls || gone[b]) continue;
+            double x = s.bx[b] + s.bvx[b] * dt;
+            double y = s.by[b] + s.bvy[b] * dt;
+            double vx = s.bvx[b], vy = s.bvy[b];
+            if (x - r < TBX_BRK_LEFT) vx = fabs(vx);
+            if (x + r > TBX_BRK_RIGHT) vx = -fabs(vx);
+            if (y - r < TBX_BRK_TOP) vy = fabs(vy);
+            if (vy > 0.0 && y + r >= s.py && y - r <= s.py + TBX_BRK_PADDLE_H && x + r >= pl && x - r <= pr) {
+                const int S = c.segments;
+                double t = (x - pl) / s.pw;
+                if (t < 0.0) t = 0.0;
+                if (t > 1.0) t = 1.0;
+                int seg = (int)(t * (double)S);
+                if (seg > S - 1) seg = S - 1;
+                seg = wave_uniform(seg);
+                double sp = sqrt(vx * vx + vy * vy);
+                vx = sp * c.pad_dx[seg];
+                vy = sp * c.pad_dy[seg];
+            }
+            // bricks: every lane tests its own; lowest index wins
+            int hit = -1;
+#pragma unroll
+            for (int k = 0; k < MAXK; k++) {
+                if (k < nk && hit < 0) {
+                    bool o = ((s.mybits >> k) & 1u) && x + r > kx[k] && x - r < kx[k] + kw[k] &&
+                             y + r > ky[k] && y - r < ky[k] + kh[k];
+                    uint64_t m = __ballot(o);
+                    if (m) hit = 64 * k + (int)__builtin_ctzll(m);
+                }
+            }
+            if (hit >= 0) {
+                double hx, hy, hw, hh;
+                int points, depth, destr;
+                if (CUSTOM) {
+                    const BrkCustom& t = d.custom[env];
+                    hx = t.x[hit]; hy = t.y[hit]; hw = t.w[hit]; hh = t.h[hit];
+                    points = t.points[hit]; depth = t.depth[hit]; destr = t.destructible[hit];
+                } else {
+                    int row, col;
+                    brk_canon(hit, c.n_rows, row, col, hx, hy);
+                    hw = TBX_BRK_BRICK_W; hh = TBX_BRK_BRICK_H;
+                    points = c.row_scores[row]; depth = c.n_rows - 1 - row; destr = 1;
+                }
+                bool cx_in = (x >= hx && x <= hx + hw);
+                bool cy_in = (y >= hy && y <= hy + hh);
+                if (cy_in && !cx_in) vx = (x < hx) ? -fabs(vx) : fabs(vx);
+                else vy = (y < hy + hh * 0.5) ? -fabs(vy) : fabs(vy);
+                if (destr) {
+                    if (lane == (hit & 63)) s.mybits &= ~(1u << (hit >> 6));
+                    s.score += points;
+                }
+                if (depth >= c.ball_speed_row_depth) {
+                    double m = sqrt(vx * vx + vy * vy);
+                    if (m < c.speed_fast && m > 0.0) {
+                        double f = c.speed_fast / m;
+                        vx = vx * f; vy = vy * f;
+                    }
+                }
+            }
+            if (y - r > TBX_BRK_BOTTOM) gone[b] = true;
+            s.bx[b] = x; s.by[b] = y; s.bvx[b] = vx; s.bvy[b] = vy;
+        }
+    }
+
+    // 4. compaction of lost balls, life lost
+    if (launched) {
+        int kdst = 0;
+#pragma unroll
+        for (int b = 0; b < MAXB; b++) {
+            if (b < s.n_balls && !gone[b]) {
+                double x = s.bx[b], y = s.by[b], vx = s.bvx[b], vy = s.bvy[b];
+#pragma unroll
+                for (int kk = 0; kk < MAXB; kk++)
+                    if (kk == kdst) { s.bx[kk] = x; s.by[kk] = y; s.bvx[kk] = vx; s.bvy[kk] = vy; }
+                kdst++;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < MAXB; b++)
+            if (b >= kdst) { s.bx[b] = 0.0; s.by[b] = 0.0; s.bvx[b] = 0.0; s.bvy[b] = 0.0; }
+        s.n_balls = kdst;
+        if (kdst == 0) {
+            s.lives -= 1;
+            s.flags = 3;
+            brk_start_ball(c, s);
+        }
+    }
+
+    // 5. wall cleared -> next level
+    {
+        int n_d = 0, n_alive = 0;
+        uint32_t dbits = 0;
+#pragma unroll
+        for (int k = 0; k < MAXK; k++) {
+            int j = lane + 64 * k;
+            bool valid = k < nk && j < s.n_bricks;
+            bool destr = valid && (CUSTOM ? d.custom[env].destructible[j] != 0 : true);
+            if (destr) dbits |= 1u << k;
+            n_d += __popcll(__ballot(destr));
+            n_alive += __popcll(__ballot(destr && ((s.mybits >> k) & 1u)));
+        }
+        if (n_d > 0 && n_alive == 0) {
+            s.level += 1;
+            s.mybits |= dbits;
+        }
+    }
+
+    // ---- outputs, auto-reset
+    int32_t rew = s.score - d.prev_score[env];
+    if (rew < 0) rew = 0;
+    const int32_t out_lives = s.lives, out_score = s.score;
+    const bool is_done = s.lives <= 0;
+    int32_t prev = s.score;
+    if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+        Rng sim;
+        sim.s0 = d.sim_rng[env];
+        sim.s1 = d.sim_rng[N + env];
+        brk_new_game<CUSTOM>(d, c, env, lane, sim, s);
+        if (lane == 0) { d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1; }
+        prev = s.score;
+    }
+    brk_store(d, env, lane, s);
+    if (lane == 0) {
+        d.prev_score[env] = prev;
+        d.reward[env] = rew;
+        d.done[env] = is_done ? 1 : 0;
+        d.lives_out[env] = out_lives;
+        d.score_out[env] = out_score;
+        uint32_t lv = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
+        d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv << 40);
+    }
+}
+
+// ------------------------------------------------------------------ render
+
+__constant__ uint16_t BRK_DIGITS[10] = {0x7B6F, 0x749A, 0x73E7, 0x79E7, 0x49ED, 0x79CF, 0x7BCF, 0x4927, 0x7BEF, 0x79EF};
+
+// One wave rasterises one env, scanline by scanline; lane l produces pixels 4l..4l+3
+// (60 active lanes, one 12/16/4-byte store per lane per line => each store instruction writes
+// one contiguous W*C-byte row).
+template <int C, bool CUSTOM>
+__global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(BrkDev d, BrkCfg c, uint8_t* out, int first_env, int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (rel >= count) return;
+    const int env = first_env + rel;
+    const size_t N = (size_t)d.n;
+    constexpr int W = TBX_BRK_W, H = TBX_BRK_H;
+
+    // ---- wave-uniform env data
+    const int n_bricks = d.n_bricks[env];
+    const int rows = c.n_rows;
+    uint64_t aw[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) aw[k] = d.alive[(size_t)k * N + env];
+    const double radius = d.paddle[6 * N + env];
+    const double pw_d = d.paddle[4 * N + env];
+    const int pad_x0 = f2i(d.paddle[0 * N + env] - pw_d * 0.5);
+    const int pad_y0 = f2i(d.paddle[1 * N + env]);
+    const int pad_w = f2i(pw_d);
+    const int n_balls = d.n_balls[env];
+    int ball_x0[MAXB], ball_y0[MAXB];
+    const int ball_s = f2i(radius * 2.0);
+#pragma unroll
+    for (int b = 0; b < MAXB; b++) {
+        ball_x0[b] = f2i(d.balls[(size_t)(0 * MAXB + b) * N + env] - radius);
+        ball_y0[b] = f2i(d.balls[(size_t)(1 * MAXB + b) * N + env] - radius);
+    }
+    int sc = d.score[env];
+    if (sc < 0) sc = 0;
+    sc %= 100000;
+    int lv = d.lives[env];
+    lv = lv < 0 ? 0 : lv > 9 ? 9 : lv;
+    int le = d.level[env];
+    if (le < 0) le = 0;
+    le %= 10;
+    // HUD glyphs: 5 score digits, lives, level
+    uint32_t glyph[7];
+    {
+        int div = 10000;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { glyph[i] = BRK_DIGITS[(sc / div) % 10]; div /= 10; }
+        glyph[5] = BRK_DIGITS[lv];
+        glyph[6] = BRK_DIGITS[le];
+    }
+    const int hud_x0[7] = {36, 44, 52, 60, 68, 148, 196};
+
+    // lane-owned brick rows for the custom path
+    const int nk = (n_bricks + 63) >> 6;
+
+    uint8_t* frame = out + (size_t)rel * H * W * C;
+    const int x0 = lane * 4;
+    const bool active = x0 < W;
+
+    for (int y = 0; y < H; y++) {
+        uint32_t px[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = x0 + i;
+            uint32_t col = c.bg;
+            if (y >= TBX_BRK_WALL_Y0 && (y < TBX_BRK_WALL_Y0 + 12 || x < 12 || x >= 228)) col = c.frame;
+            px[i] = col;
+        }
+        // bricks
+        if (!CUSTOM) {
+            const int by = y - 43;
+            if (by >= 0 && by < 4 * rows) {
+                const int row = by >> 2;
+                const uint32_t rc = c.row_colors[row];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int bxp = x0 + i - 12;
+                    if (bxp >= 0 && bxp < 216) {
+                        const int j = (bxp / 12) * rows + row;
+                        // j < 256 always (18*14=252)
+                        uint64_t w = (j < 64) ? aw[0] : (j < 128) ? aw[1] : (j < 192) ? aw[2] : aw[3];
+                        if ((w >> (j & 63)) & 1ull) px[i] = rc;
+                    }
+                }
+            }
+        } else {
+            const BrkCustom& t = d.custom[env];
+            for (int k = 0; k < nk; k++) {
+                const int j = lane + 64 * k;
+                bool on = false;
+                int rx0 = 0, rw = 0; uint32_t rc = 0;
+                if (j < n_bricks && ((aw[k] >> lane) & 1ull)) {
+                    const int ry0 = f2i(t.y[j]), rh = f2i(t.h[j]);
+                    on = y >= ry0 && y < ry0 + rh;
+                    rx0 = f2i(t.x[j]); rw = f2i(t.w[j]); rc = t.color[j];
+                }
+                uint64_t m = __ballot(on);
+                while (m) {   // ascending brick index == the oracle's paint order
+                    const int src = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const int sx0 = __shfl(rx0, src), sw = __shfl(rw, src);
+                    const uint32_t scol = __shfl(rc, src);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int x = x0 + i;
+                        if (x >= sx0 && x < sx0 + sw) px[i] = scol;
+                    }
+                }
+            }
+        }
+        // paddle
+        if (y >= pad_y0 && y < pad_y0 + 3) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int x = x0 + i;
+                if (x >= pad_x0 && x < pad_x0 + pad_w) px[i] = c.paddle;
+            }
+        }
+        // balls
+#pragma unroll
+        for (int b = 0; b < MAXB; b++) {
+            if (b < n_balls && y >= ball_y0[b] && y < ball_y0[b] + ball_s) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int x = x0 + i;
+                    if (x >= ball_x0[b] && x < ball_x0[b] + ball_s) px[i] = c.ball;
+                }
+            }
+        }
+        // HUD
+        if (y >= 2 && y < 12) {
+            const int gr = ((y - 2) >> 1) * 3;
+#pragma unroll
+            for (int g = 0; g < 7; g++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int dx = x0 + i - hud_x0[g];
+                    if (dx >= 0 && dx < 6 && ((glyph[g] >> (gr + (dx >> 1))) & 1u)) px[i] = c.frame;
+                }
+            }
+        }
+        if (active) store_px4<C>(frame + ((size_t)y * W + x0) * C, px[0], px[1], px[2], px[3]);
+    }
+}
+
+// ------------------------------------------------------------------ state pack / unpack, scalars
+
+template <bool CUSTOM>
+__global__ void brk_pack_kernel(BrkDev d, BrkCfg c, int env, tbx_breakout_state_t* out)
+{
+    const int lane = threadIdx.x & 63;
+    BrkRegs s;
+    brk_load(d, env, lane, s);
+    if (lane == 0) {
+        out->rand[0] = s.rng.s0; out->rand[1] = s.rng.s1;
+        out->score = s.score; out->lives = s.lives; out->level = s.level;
+        out->is_dead = (s.flags & 1) ? 1 : 0; out->reset = (s.flags & 2) ? 1 : 0;
+        out->_pad0[0] = out->_pad0[1] = 0;
+        out->paddle_x = s.px; out->paddle_y = s.py; out->paddle_vx = s.pvx; out->paddle_vy = s.pvy;
+        out->paddle_width = s.pw; out->paddle_speed = s.pspeed; out->ball_radius = s.radius;
+        out->n_balls = s.n_balls; out->n_bricks = s.n_bricks;
+        for (int b = 0; b < MAXB; b++) {
+            out->ball_x[b] = s.bx[b]; out->ball_y[b] = s.by[b]; out->ball_vx[b] = s.bvx[b]; out->ball_vy[b] = s.bvy[b];
+        }
+    }
+    for (int k = 0; k < MAXK; k++) {
+        const int j = lane + 64 * k;
+        tbx_brick_t b;
+        memset(&b, 0, sizeof b);
+        if (j < s.n_bricks) {
+            if (CUSTOM) {
+                const BrkCustom& t = d.custom[env];
+                b.x = t.x[j]; b.y = t.y[j]; b.w = t.w[j]; b.h = t.h[j];
+                b.points = t.points[j]; b.depth = t.depth[j]; b.row = t.row[j]; b.col = t.col[j];
+                b.color = unpack_color(t.color[j]); b.destructible = t.destructible[j];
+            } else {
+                int row, col;
+                brk_canon(j, c.n_rows, row, col, b.x, b.y);
+                b.w = TBX_BRK_BRICK_W; b.h = TBX_BRK_BRICK_H;
+                b.points = c.row_scores[row]; b.depth = c.n_rows - 1 - row; b.row = row; b.col = col;
+                b.color = unpack_color(c.row_colors[row]); b.destructible = 1;
+            }
+            b.alive = (s.mybits >> k) & 1u;
+        }
+        out->bricks[j] = b;
+    }
+}
+
+template <bool CUSTOM>
+__global__ void brk_unpack_kernel(BrkDev d, int env, const tbx_breakout_state_t* in)
+{
+    const int lane = threadIdx.x & 63;
+    BrkRegs s;
+    s.rng.s0 = in->rand[0]; s.rng.s1 = in->rand[1];
+    s.score = in->score; s.lives = in->lives; s.level = in->level;
+    s.flags = (in->is_dead ? 1 : 0) | (in->reset ? 2 : 0);
+    s.px = in->paddle_x; s.py = in->paddle_y; s.pvx = in->paddle_vx; s.pvy = in->paddle_vy;
+    s.pw = in->paddle_width; s.pspeed = in->paddle_speed; s.radius = in->ball_radius;
+    s.n_balls = in->n_balls; s.n_bricks = in->n_bricks;
+    for (int b = 0; b < MAXB; b++) {
+        const bool v = b < s.n_balls;
+        s.bx[b] = v ? in->ball_x[b] : 0.0; s.by[b] = v ? in->ball_y[b] : 0.0;
+        s.bvx[b] = v ? in->ball_vx[b] : 0.0; s.bvy[b] = v ? in->ball_vy[b] : 0.0;
+    }
+    uint32_t bits = 0;
+    for (int k = 0; k < MAXK; k++) {
+        const int j = lane + 64 * k;
+        const tbx_brick_t& b = in->bricks[j];
+        if (j < s.n_bricks && b.alive) bits |= 1u << k;
+        if (CUSTOM) {
+            BrkCustom& t = d.custom[env];
+            const bool v = j < s.n_bricks;
+            t.x[j] = v ? b.x : 0.0; t.y[j] = v ? b.y : 0.0; t.w[j] = v ? b.w : 0.0; t.h[j] = v ? b.h : 0.0;
+            t.points[j] = v ? b.points : 0; t.depth[j] = v ? b.depth : 0; t.row[j] = v ? b.row : 0; t.col[j] = v ? b.col : 0;
+            t.color[j] = v ? pack_color(b.color) : 0u; t.destructible[j] = v ? (b.destructible ? 1 : 0) : 0;
+        }
+    }
+    s.mybits = bits;
+    brk_store(d, env, lane, s);
+}
+
+// fills every env's custom table with the canonical wall (when the engine switches to custom mode)
+__global__ __launch_bounds__(TBX_BLOCK) void brk_fill_custom_kernel(BrkDev d, BrkCfg c)
+{
+    const int lane = threadIdx.x & 63;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (env >= d.n) return;
+    const int n_bricks = d.n_bricks[env];
+    BrkCustom& t = d.custom[env];
+    for (int k = 0; k < MAXK; k++) {
+        const int j = lane + 64 * k;
+        if (j < n_bricks) {
+            int row, col; double x, y;
+            brk_canon(j, c.n_rows, row, col, x, y);
+            t.x[j] = x; t.y[j] = y; t.w[j] = TBX_BRK_BRICK_W; t.h[j] = TBX_BRK_BRICK_H;
+            t.points[j] = c.row_scores[row]; t.depth[j] = c.n_rows - 1 - row;
+            t.row[j] = row; t.col[j] = col; t.color[j] = c.row_colors[row]; t.destructible[j] = 1;
+        } else {
+            t.x[j] = t.y[j] = t.w[j] = t.h[j] = 0.0;
+            t.points[j] = t.depth[j] = t.row[j] = t.col[j] = 0; t.color[j] = 0; t.destructible[j] = 0;
+        }
+    }
+}
+
+__global__ void brk_scalars_kernel(BrkDev d, int32_t* score, int32_t* lives, int32_t* level)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    if (score) score[i] = d.score[i];
+    if (lives) lives[i] = d.lives[i];
+    if (level) level[i] = d.level[i];
+}
+
+// ------------------------------------------------------------------ host ops
+
+struct BreakoutOps : GameOps {
+    BrkDev d{};
+    BrkCfg c{};
+    tbx_breakout_config_t cfg{};
+    bool custom = false;
+
+    static void default_config(tbx_breakout_config_t* k);
+
+    int height() const override { return TBX_BRK_H; }
+    int width() const override { return TBX_BRK_W; }
+    size_t state_size() const override { return sizeof(tbx_breakout_state_t); }
+    size_t config_size() const override { return sizeof(tbx_breakout_config_t); }
+
+    int load_cfg(tbx_engine* e, const tbx_breakout_config_t& k)
+    {
+        if (k.n_rows < 1 || k.n_rows > TBX_BRK_MAX_ROWS) return e->fail(TBX_E_UNSUPPORTED, "breakout: n_rows must be 1..14");
+        if (k.n_starts < 1 || k.n_starts > TBX_BRK_MAX_STARTS) return e->fail(TBX_E_UNSUPPORTED, "breakout: 1..8 ball_start_positions");
+        if (k.paddle_discrete_segments < 1 || k.paddle_discrete_segments > TBX_BRK_MAX_SEGMENTS)
+            return e->fail(TBX_E_UNSUPPORTED, "breakout: paddle_discrete_segments must be 1..16 (continuous bounce needs device trig)");
+        cfg = k;
+        c.start_lives = k.start_lives; c.n_rows = k.n_rows; c.ball_speed_row_depth = k.ball_speed_row_depth;
+        c.n_starts = k.n_starts; c.segments = k.paddle_discrete_segments;
+        for (int i = 0; i < TBX_BRK_MAX_ROWS; i++) { c.row_scores[i] = k.row_scores[i]; c.row_colors[i] = pack_color(k.row_colors[i]); }
+        c.speed_slow = k.ball_speed_slow; c.speed_fast = k.ball_speed_fast;
+        for (int i = 0; i < TBX_BRK_MAX_STARTS; i++) {
+            c.start_x[i] = k.start_x[i]; c.start_y[i] = k.start_y[i];
+            c.start_dx[i] = k.start_dir_x[i]; c.start_dy[i] = k.start_dir_y[i];
+        }
+        for (int i = 0; i < TBX_BRK_MAX_SEGMENTS; i++) { c.pad_dx[i] = k.paddle_dir_x[i]; c.pad_dy[i] = k.paddle_dir_y[i]; }
+        c.bg = pack_color(k.bg_color); c.frame = pack_color(k.frame_color);
+        c.paddle = pack_color(k.paddle_color); c.ball = pack_color(k.ball_color);
+        return TBX_OK;
+    }
+
+    template <typename T>
+    static hipError_t dalloc(T** p, size_t count) { return hipMalloc((void**)p, count * sizeof(T)); }
+
+    int init(tbx_engine* e, const void* cfg_pod, size_t cfg_size) override
+    {
+        tbx_breakout_config_t k;
+        if (cfg_pod) {
+            if (cfg_size != sizeof k) return e->fail(TBX_E_INVALID, "breakout: config size mismatch");
+            memcpy(&k, cfg_pod, sizeof k);
+        } else {
+            return e->fail(TBX_E_INVALID, "breakout: a config record is required");
+        }
+        int rc = load_cfg(e, k);
+        if (rc) return rc;
+        const size_t N = (size_t)e->n;
+        d.n = e->n;
+        d.sim_rng = e->sim_rng; d.prev_score = e->prev_score; d.reward = e->reward; d.done = e->done;
+        d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed; d.err_flag = e->err_flag;
+        TBX_HIP(dalloc(&d.rng, 2 * N));
+        TBX_HIP(dalloc(&d.score, N));
+        TBX_HIP(dalloc(&d.lives, N));
+        TBX_HIP(dalloc(&d.level, N));
+        TBX_HIP(dalloc(&d.flags, N));
+        TBX_HIP(dalloc(&d.paddle, 7 * N));
+        TBX_HIP(dalloc(&d.n_balls, N));
+        TBX_HIP(dalloc(&d.balls, 16 * N));
+        TBX_HIP(dalloc(&d.n_bricks, N));
+        TBX_HIP(dalloc(&d.alive, 4 * N));
+        d.custom = nullptr;
+        return TBX_OK;
+    }
+
+    void destroy(tbx_engine*) override
+    {
+        hipFree(d.rng); hipFree(d.score); hipFree(d.lives); hipFree(d.level); hipFree(d.flags);
+        hipFree(d.paddle); hipFree(d.n_balls); hipFree(d.balls); hipFree(d.n_bricks); hipFree(d.alive);
+        if (d.custom) hipFree(d.custom);
+    }
+
+    int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
+    int set_config(tbx_engine* e, const void* pod) override
+    {
+        tbx_breakout_config_t k;
+        memcpy(&k, pod, sizeof k);
+        return load_cfg(e, k);
+    }
+
+    static dim3 grid_for(int count) { return dim3((count + TBX_WAVES_PER_BLOCK - 1) / TBX_WAVES_PER_BLOCK); }
+
+    int new_game(tbx_engine* e, const uint8_t* mask_dev, hipStream_t s) override
+    {
+        if (custom) hipLaunchKernelGGL(brk_new_game_kernel<true>, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, c, mask_dev);
+        else hipLaunchKernelGGL(brk_new_game_kernel<false>, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, c, mask_dev);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
+    {
+        int first = 0, count = e->n;
+        if (src.single_env >= 0) { first = src.single_env; count = 1; }
+        if (custom) hipLaunchKernelGGL(brk_step_kernel<true>, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count);
+        else hipLaunchKernelGGL(brk_step_kernel<false>, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    template <int C>
+    void launch_render(uint8_t* out, int first, int count, hipStream_t s)
+    {
+        if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true>), grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, out, first, count);
+        else hipLaunchKernelGGL((brk_render_kernel<C, false>), grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, out, first, count);
+    }
+
+    int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
+    {
+        switch (channels) {
+        case 1: launch_render<1>(out_dev, first_env, n_envs, s); break;
+        case 3: launch_render<3>(out_dev, first_env, n_envs, s); break;
+        case 4: launch_render<4>(out_dev, first_env, n_envs, s); break;
+        default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+        }
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int pack_state(tbx_engine* e, int env, hipStream_t s) override
+    {
+        auto* out = (tbx_breakout_state_t*)e->staging;
+        if (custom) hipLaunchKernelGGL(brk_pack_kernel<true>, dim3(1), dim3(64), 0, s, d, c, env, out);
+        else hipLaunchKernelGGL(brk_pack_kernel<false>, dim3(1), dim3(64), 0, s, d, c, env, out);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    bool is_canonical(const tbx_breakout_state_t& st) const
+    {
+        if (st.n_bricks != TBX_BRK_COLS * cfg.n_rows) return false;
+        for (int j = 0; j < st.n_bricks; j++) {
+            const tbx_brick_t& b = st.bricks[j];
+            const int col = j / cfg.n_rows, row = j % cfg.n_rows;
+            if (b.x != TBX_BRK_LEFT + TBX_BRK_BRICK_W * col || b.y != TBX_BRK_BRICK_Y0 + TBX_BRK_BRICK_H * row ||
+                b.w != TBX_BRK_BRICK_W || b.h != TBX_BRK_BRICK_H || b.points != cfg.row_scores[row] ||
+                b.depth != cfg.n_rows - 1 - row || b.row != row || b.col != col || !b.destructible ||
+                pack_color(b.color) != pack_color(cfg.row_colors[row]))
+                return false;
+        }
+        return true;
+    }
+
+    int enable_custom(tbx_engine* e, hipStream_t s)
+    {
+        if (custom) return TBX_OK;
+        TBX_HIP(hipMalloc((void**)&d.custom, sizeof(BrkCustom) * (size_t)e->n));
+        hipLaunchKernelGGL(brk_fill_custom_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, c);
+        TBX_HIP(hipGetLastError());
+        custom = true;
+        return TBX_OK;
+    }
+
+    int unpack_state(tbx_engine* e, int env, const void* pod_host, hipStream_t s) override
+    {
+        const auto& st = *(const tbx_breakout_state_t*)pod_host;
+        if (st.n_balls < 0 || st.n_balls > TBX_BRK_MAX_BALLS)
+            return e->fail(TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 4 balls per env");
+        if (st.n_bricks < 0 || st.n_bricks > TBX_BRK_MAX_BRICKS)
+            return e->fail(TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 256 bricks per env");
+        if (!custom && !is_canonical(st)) {
+            int rc = enable_custom(e, s);
+            if (rc) return rc;
+        }
+        TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof st, hipMemcpyHostToDevice, s));
+        auto* in = (const tbx_breakout_state_t*)e->staging;
+        if (custom) hipLaunchKernelGGL(brk_unpack_kernel<true>, dim3(1), dim3(64), 0, s, d, env, in);
+        else hipLaunchKernelGGL(brk_unpack_kernel<false>, dim3(1), dim3(64), 0, s, d, env, in);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int scalars(tbx_engine* e, int32_t* score_dev, int32_t* lives_dev, int32_t* level_dev, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(brk_scalars_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, score_dev, lives_dev, level_dev);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+};
+
+}  // namespace
+
+GameOps* tbx_make_breakout_ops() { return new BreakoutOps(); }

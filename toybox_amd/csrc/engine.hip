@@ -1,0 +1,517 @@
+// engine.hip -- the C-ABI of include/toybox_amd.h over the per-game gfx950 kernels.
+// No CPU fallback: every entry point that computes needs a visible gfx950 device.
+
+#include "tbx_common.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define CHECK_ENGINE(e) \
+    if (!(e)) return TBX_E_INVALID
+
+int hip_fail(tbx_engine* e, const char* what, hipError_t err)
+{
+    return e->fail(TBX_E_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(err));
+}
+
+#define EHIP(call)                                        \
+    do {                                                  \
+        hipError_t _e = (call);                           \
+        if (_e != hipSuccess) return hip_fail(e, #call, _e); \
+    } while (0)
+
+void breakout_default_config(tbx_breakout_config_t* c)
+{
+    memset(c, 0, sizeof *c);
+    tbx_seed_state(13, c->rand[0], c->rand[1]);
+    c->start_lives = 5;
+    c->n_rows = 6;
+    const int scores[6] = {7, 7, 4, 4, 1, 1};
+    const uint8_t cols[6][3] = {{200, 72, 72}, {198, 108, 58}, {180, 122, 48}, {162, 162, 42}, {72, 160, 72}, {66, 72, 200}};
+    for (int i = 0; i < 6; i++) {
+        c->row_scores[i] = scores[i];
+        c->row_colors[i] = tbx_color_t{cols[i][0], cols[i][1], cols[i][2], 255};
+    }
+    c->ball_speed_row_depth = 3;
+    c->ball_speed_slow = 2.0;
+    c->ball_speed_fast = 4.0;
+    c->n_starts = 4;
+    const double sx[4] = {24.0, 120.0, 120.0, 216.0}, sa[4] = {30.0, 30.0, 150.0, 150.0};
+    for (int i = 0; i < 4; i++) {
+        c->start_x[i] = sx[i]; c->start_y[i] = 80.0; c->start_angle_deg[i] = sa[i];
+        const double rad = sa[i] * (M_PI / 180.0);
+        c->start_dir_x[i] = std::cos(rad);   // host libm: the device never evaluates trig
+        c->start_dir_y[i] = std::sin(rad);
+    }
+    c->paddle_discrete_segments = 5;
+    for (int i = 0; i < 5; i++) {
+        const double rad = (150.0 - (double)i * (120.0 / 4.0)) * (M_PI / 180.0);
+        c->paddle_dir_x[i] = std::cos(rad);
+        c->paddle_dir_y[i] = -std::sin(rad);
+    }
+    c->bg_color = tbx_color_t{0, 0, 0, 255};
+    c->frame_color = tbx_color_t{144, 144, 144, 255};
+    c->paddle_color = tbx_color_t{200, 72, 72, 255};
+    c->ball_color = tbx_color_t{200, 72, 72, 255};
+}
+
+__global__ void seed_kernel(uint64_t* sim_rng, int n, int env, uint32_t seed)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (env >= 0 && i != env) return;
+    uint64_t s0, s1;
+    tbx_seed_state(env >= 0 ? seed : seed + (uint32_t)i, s0, s1);
+    sim_rng[i] = s0;
+    sim_rng[(size_t)n + i] = s1;
+}
+
+__global__ void fill_rng_kernel(uint64_t* sim_rng, int n, uint64_t s0, uint64_t s1)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sim_rng[i] = s0;
+    sim_rng[(size_t)n + i] = s1;
+}
+
+int ensure_frame(tbx_engine* e, size_t bytes)
+{
+    if (e->frame_bytes >= bytes) return TBX_OK;
+    if (e->frame) hipFree(e->frame);
+    e->frame = nullptr;
+    e->frame_bytes = 0;
+    EHIP(hipMalloc((void**)&e->frame, bytes));
+    e->frame_bytes = bytes;
+    return TBX_OK;
+}
+
+int check_err_flag(tbx_engine* e)
+{
+    uint32_t f = 0;
+    EHIP(hipMemcpyAsync(&f, e->err_flag, sizeof f, hipMemcpyDeviceToHost, e->stream));
+    EHIP(hipStreamSynchronize(e->stream));
+    if (f) {
+        EHIP(hipMemsetAsync(e->err_flag, 0, sizeof f, e->stream));
+        return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
+    }
+    return TBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tbx_abi_version(void) { return TBX_ABI_VERSION; }
+
+const char* tbx_last_error(const tbx_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int tbx_frame_dims(int game, int* h, int* w)
+{
+    if (!h || !w) return TBX_E_INVALID;
+    switch (game) {
+    case TBX_GAME_BREAKOUT: *h = TBX_BRK_H; *w = TBX_BRK_W; return TBX_OK;
+    default: return TBX_E_INVALID;
+    }
+}
+
+int tbx_legal_actions(int game, int32_t* out, int cap)
+{
+    if (game < 0 || game >= TBX_NUM_GAMES) return TBX_E_INVALID;
+    const int n = tbx_legal_count(game);
+    for (int i = 0; i < n && i < cap; i++) out[i] = tbx_legal_action(game, i);
+    return n;
+}
+
+int tbx_ale_action_to_buttons(int a)
+{
+    const uint32_t b = tbx_ale_buttons(a);
+    return b == 0xFFu ? TBX_E_INVALID : (int)b;
+}
+
+size_t tbx_state_size(int game)
+{
+    switch (game) {
+    case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_state_t);
+    default: return 0;
+    }
+}
+
+size_t tbx_config_size(int game)
+{
+    switch (game) {
+    case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_config_t);
+    default: return 0;
+    }
+}
+
+int tbx_destroy(tbx_engine* e)
+{
+    if (!e) return TBX_OK;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->ops) { e->ops->destroy(e); delete e->ops; }
+    hipFree(e->sim_rng); hipFree(e->prev_score); hipFree(e->reward); hipFree(e->done);
+    hipFree(e->lives_out); hipFree(e->score_out); hipFree(e->packed); hipFree(e->actions);
+    hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame); hipFree(e->staging);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return TBX_OK;
+}
+
+int tbx_create(int game, int n_envs, int device, const void* config_pod, size_t config_size, tbx_engine** out)
+{
+    if (!out) return TBX_E_INVALID;
+    *out = nullptr;
+    if (n_envs < 1) { g_create_error = "n_envs must be >= 1"; return TBX_E_INVALID; }
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev < 1) {
+        g_create_error = std::string("no HIP device visible (the engine has no CPU fallback): ") + hipGetErrorString(he);
+        return TBX_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return TBX_E_INVALID; }
+    hipDeviceProp_t prop;
+    he = hipGetDeviceProperties(&prop, device);
+    if (he != hipSuccess) { g_create_error = hipGetErrorString(he); return TBX_E_NO_DEVICE; }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return TBX_E_NO_DEVICE;
+    }
+    tbx_engine* e = new (std::nothrow) tbx_engine();
+    if (!e) { g_create_error = "out of host memory"; return TBX_E_NOMEM; }
+    e->game = game;
+    e->n = n_envs;
+    e->device = device;
+    int rc = TBX_OK;
+    auto bail = [&](int code) {
+        g_create_error = e->err;
+        tbx_destroy(e);
+        return code;
+    };
+    switch (game) {
+    case TBX_GAME_BREAKOUT: e->ops = tbx_make_breakout_ops(); break;
+    default: e->err = "unknown game id"; return bail(TBX_E_INVALID);
+    }
+    const size_t N = (size_t)n_envs;
+#define CHIP(call)                                                                 \
+    do {                                                                           \
+        hipError_t _e = (call);                                                    \
+        if (_e != hipSuccess) { hip_fail(e, #call, _e); return bail(_e == hipErrorOutOfMemory ? TBX_E_NOMEM : TBX_E_NO_DEVICE); } \
+    } while (0)
+    CHIP(hipSetDevice(device));
+    CHIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    CHIP(hipMalloc((void**)&e->sim_rng, 2 * N * sizeof(uint64_t)));
+    CHIP(hipMalloc((void**)&e->prev_score, N * sizeof(int32_t)));
+    CHIP(hipMalloc((void**)&e->reward, N * sizeof(int32_t)));
+    CHIP(hipMalloc((void**)&e->done, N));
+    CHIP(hipMalloc((void**)&e->lives_out, N * sizeof(int32_t)));
+    CHIP(hipMalloc((void**)&e->score_out, N * sizeof(int32_t)));
+    CHIP(hipMalloc((void**)&e->packed, N * sizeof(uint64_t)));
+    CHIP(hipMalloc((void**)&e->actions, N * sizeof(int32_t)));
+    CHIP(hipMalloc((void**)&e->mask, N));
+    CHIP(hipMalloc((void**)&e->err_flag, sizeof(uint32_t)));
+    CHIP(hipMemsetAsync(e->err_flag, 0, sizeof(uint32_t), e->stream));
+    CHIP(hipMemsetAsync(e->reward, 0, N * sizeof(int32_t), e->stream));
+    CHIP(hipMemsetAsync(e->done, 0, N, e->stream));
+    CHIP(hipMemsetAsync(e->packed, 0, N * sizeof(uint64_t), e->stream));
+    e->staging_bytes = e->ops->state_size();
+    CHIP(hipMalloc(&e->staging, e->staging_bytes));
+
+    // config: NULL -> game defaults
+    std::vector<uint8_t> cfg(e->ops->config_size());
+    if (config_pod) {
+        if (config_size != cfg.size()) { e->err = "config size mismatch"; return bail(TBX_E_INVALID); }
+        memcpy(cfg.data(), config_pod, cfg.size());
+    } else {
+        switch (game) {
+        case TBX_GAME_BREAKOUT: breakout_default_config((tbx_breakout_config_t*)cfg.data()); break;
+        }
+    }
+    rc = e->ops->init(e, cfg.data(), cfg.size());
+    if (rc) return bail(rc);
+    // every env's simulator RNG starts at config.rand (first 16 bytes of every config record)
+    uint64_t r[2];
+    memcpy(r, cfg.data(), sizeof r);
+    hipLaunchKernelGGL(fill_rng_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, e->stream, e->sim_rng, n_envs, r[0], r[1]);
+    CHIP(hipGetLastError());
+    rc = e->ops->new_game(e, nullptr, e->stream);
+    if (rc) return bail(rc);
+    CHIP(hipStreamSynchronize(e->stream));
+#undef CHIP
+    *out = e;
+    return TBX_OK;
+}
+
+int tbx_num_envs(const tbx_engine* e) { return e ? e->n : TBX_E_INVALID; }
+int tbx_game(const tbx_engine* e) { return e ? e->game : TBX_E_INVALID; }
+
+int tbx_seed(tbx_engine* e, int env, uint32_t seed)
+{
+    CHECK_ENGINE(e);
+    if (env < -1 || env >= e->n) return e->fail(TBX_E_INVALID, "env index out of range");
+    EHIP(hipSetDevice(e->device));
+    hipLaunchKernelGGL(seed_kernel, dim3((e->n + 255) / 256), dim3(256), 0, e->stream, e->sim_rng, e->n, env, seed);
+    EHIP(hipGetLastError());
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_get_sim_rng(tbx_engine* e, int env, uint64_t out[2])
+{
+    CHECK_ENGINE(e);
+    if (env < 0 || env >= e->n || !out) return e->fail(TBX_E_INVALID, "env index out of range");
+    EHIP(hipSetDevice(e->device));
+    EHIP(hipMemcpyAsync(&out[0], e->sim_rng + env, 8, hipMemcpyDeviceToHost, e->stream));
+    EHIP(hipMemcpyAsync(&out[1], e->sim_rng + (size_t)e->n + env, 8, hipMemcpyDeviceToHost, e->stream));
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_set_sim_rng(tbx_engine* e, int env, const uint64_t st[2])
+{
+    CHECK_ENGINE(e);
+    if (env < -1 || env >= e->n || !st) return e->fail(TBX_E_INVALID, "env index out of range");
+    EHIP(hipSetDevice(e->device));
+    if (env == -1) {
+        hipLaunchKernelGGL(fill_rng_kernel, dim3((e->n + 255) / 256), dim3(256), 0, e->stream, e->sim_rng, e->n, st[0], st[1]);
+        EHIP(hipGetLastError());
+    } else {
+        EHIP(hipMemcpyAsync(e->sim_rng + env, &st[0], 8, hipMemcpyHostToDevice, e->stream));
+        EHIP(hipMemcpyAsync(e->sim_rng + (size_t)e->n + env, &st[1], 8, hipMemcpyHostToDevice, e->stream));
+    }
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_new_game(tbx_engine* e, const uint8_t* mask_host)
+{
+    CHECK_ENGINE(e);
+    EHIP(hipSetDevice(e->device));
+    const uint8_t* m = nullptr;
+    if (mask_host) {
+        EHIP(hipMemcpyAsync(e->mask, mask_host, (size_t)e->n, hipMemcpyHostToDevice, e->stream));
+        m = e->mask;
+    }
+    int rc = e->ops->new_game(e, m, e->stream);
+    if (rc) return rc;
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_step_device(tbx_engine* e, const int32_t* actions_dev, uint32_t flags, void* stream)
+{
+    CHECK_ENGINE(e);
+    if (!actions_dev) return e->fail(TBX_E_INVALID, "actions pointer is NULL");
+    EHIP(hipSetDevice(e->device));
+    ActionSource src{};
+    src.actions = actions_dev;
+    src.single_env = -1;
+    return e->ops->step(e, src, flags, (hipStream_t)stream);
+}
+
+int tbx_step_synthetic(tbx_engine* e, uint64_t action_seed, uint64_t t, uint64_t env_offset, uint32_t flags, void* stream)
+{
+    CHECK_ENGINE(e);
+    EHIP(hipSetDevice(e->device));
+    ActionSource src{};
+    src.actions = nullptr;
+    src.seed = action_seed;
+    src.t = t;
+    src.env_offset = env_offset;
+    src.single_env = -1;
+    return e->ops->step(e, src, flags, (hipStream_t)stream);
+}
+
+int tbx_step(tbx_engine* e, const int32_t* actions_host, uint32_t flags, int32_t* reward, uint8_t* done,
+             int32_t* lives, int32_t* score)
+{
+    CHECK_ENGINE(e);
+    if (!actions_host) return e->fail(TBX_E_INVALID, "actions pointer is NULL");
+    EHIP(hipSetDevice(e->device));
+    const size_t N = (size_t)e->n;
+    EHIP(hipMemcpyAsync(e->actions, actions_host, N * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    ActionSource src{};
+    src.actions = e->actions;
+    src.single_env = -1;
+    int rc = e->ops->step(e, src, flags, e->stream);
+    if (rc) return rc;
+    if (reward) EHIP(hipMemcpyAsync(reward, e->reward, N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (done) EHIP(hipMemcpyAsync(done, e->done, N, hipMemcpyDeviceToHost, e->stream));
+    if (lives) EHIP(hipMemcpyAsync(lives, e->lives_out, N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (score) EHIP(hipMemcpyAsync(score, e->score_out, N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    return check_err_flag(e);
+}
+
+int tbx_apply_input(tbx_engine* e, int env, uint32_t buttons)
+{
+    CHECK_ENGINE(e);
+    if (env < 0 || env >= e->n) return e->fail(TBX_E_INVALID, "env index out of range");
+    EHIP(hipSetDevice(e->device));
+    ActionSource src{};
+    src.single_env = env;
+    src.single_buttons = buttons & 0x3Fu;
+    int rc = e->ops->step(e, src, 0, e->stream);
+    if (rc) return rc;
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_get_scalars(tbx_engine* e, int32_t* score, int32_t* lives, int32_t* level, uint8_t* game_over)
+{
+    CHECK_ENGINE(e);
+    EHIP(hipSetDevice(e->device));
+    const size_t N = (size_t)e->n;
+    // reuse reward-sized scratch: allocate a temporary device block of 3N ints
+    int32_t* tmp = nullptr;
+    EHIP(hipMalloc((void**)&tmp, 3 * N * sizeof(int32_t)));
+    int rc = e->ops->scalars(e, tmp, tmp + N, tmp + 2 * N, e->stream);
+    if (rc) { hipFree(tmp); return rc; }
+    std::vector<int32_t> host(3 * N);
+    hipError_t he = hipMemcpyAsync(host.data(), tmp, 3 * N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    hipFree(tmp);
+    if (he != hipSuccess) return hip_fail(e, "tbx_get_scalars copy", he);
+    for (size_t i = 0; i < N; i++) {
+        if (score) score[i] = host[i];
+        if (lives) lives[i] = host[N + i];
+        if (level) level[i] = host[2 * N + i];
+        if (game_over) game_over[i] = host[N + i] <= 0;
+    }
+    return TBX_OK;
+}
+
+int tbx_render_device(tbx_engine* e, uint8_t* out_dev, int channels, void* stream)
+{
+    CHECK_ENGINE(e);
+    if (channels != 1 && channels != 3 && channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+    EHIP(hipSetDevice(e->device));
+    if (!out_dev) {
+        const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
+        int rc = ensure_frame(e, bytes);
+        if (rc) return rc;
+        out_dev = e->frame;
+    }
+    return e->ops->render(e, out_dev, channels, 0, e->n, (hipStream_t)stream);
+}
+
+int tbx_render(tbx_engine* e, uint8_t* out_host, int channels)
+{
+    CHECK_ENGINE(e);
+    if (!out_host) return e->fail(TBX_E_INVALID, "output pointer is NULL");
+    int rc = tbx_render_device(e, nullptr, channels, e->stream);
+    if (rc) return rc;
+    const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
+    EHIP(hipMemcpyAsync(out_host, e->frame, bytes, hipMemcpyDeviceToHost, e->stream));
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_render_env(tbx_engine* e, int env, uint8_t* out_host, int channels)
+{
+    CHECK_ENGINE(e);
+    if (env < 0 || env >= e->n || !out_host) return e->fail(TBX_E_INVALID, "env index out of range");
+    if (channels != 1 && channels != 3 && channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+    EHIP(hipSetDevice(e->device));
+    const size_t bytes = (size_t)e->ops->height() * e->ops->width() * channels;
+    uint8_t* tmp = nullptr;
+    EHIP(hipMalloc((void**)&tmp, bytes));
+    int rc = e->ops->render(e, tmp, channels, env, 1, e->stream);
+    hipError_t he = hipSuccess;
+    if (!rc) {
+        he = hipMemcpyAsync(out_host, tmp, bytes, hipMemcpyDeviceToHost, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    }
+    hipFree(tmp);
+    if (rc) return rc;
+    if (he != hipSuccess) return hip_fail(e, "tbx_render_env copy", he);
+    return TBX_OK;
+}
+
+int tbx_get_state(tbx_engine* e, int env, void* pod, size_t size)
+{
+    CHECK_ENGINE(e);
+    if (env < 0 || env >= e->n || !pod) return e->fail(TBX_E_INVALID, "env index out of range");
+    if (size != e->ops->state_size()) return e->fail(TBX_E_INVALID, "state record size mismatch");
+    EHIP(hipSetDevice(e->device));
+    int rc = e->ops->pack_state(e, env, e->stream);
+    if (rc) return rc;
+    EHIP(hipMemcpyAsync(pod, e->staging, size, hipMemcpyDeviceToHost, e->stream));
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_set_state(tbx_engine* e, int env, const void* pod, size_t size)
+{
+    CHECK_ENGINE(e);
+    if (env < 0 || env >= e->n || !pod) return e->fail(TBX_E_INVALID, "env index out of range");
+    if (size != e->ops->state_size()) return e->fail(TBX_E_INVALID, "state record size mismatch");
+    EHIP(hipSetDevice(e->device));
+    int rc = e->ops->unpack_state(e, env, pod, e->stream);
+    if (rc) return rc;
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_get_config(tbx_engine* e, void* pod, size_t size)
+{
+    CHECK_ENGINE(e);
+    if (!pod || size != e->ops->config_size()) return e->fail(TBX_E_INVALID, "config record size mismatch");
+    int rc = e->ops->get_config(e, pod);
+    if (rc) return rc;
+    uint64_t r[2];
+    rc = tbx_get_sim_rng(e, 0, r);
+    if (rc) return rc;
+    memcpy(pod, r, sizeof r);
+    return TBX_OK;
+}
+
+int tbx_set_config(tbx_engine* e, const void* pod, size_t size)
+{
+    CHECK_ENGINE(e);
+    if (!pod || size != e->ops->config_size()) return e->fail(TBX_E_INVALID, "config record size mismatch");
+    EHIP(hipSetDevice(e->device));
+    EHIP(hipStreamSynchronize(e->stream));
+    int rc = e->ops->set_config(e, pod);
+    if (rc) return rc;
+    uint64_t r[2];
+    memcpy(r, pod, sizeof r);
+    return tbx_set_sim_rng(e, -1, r);
+}
+
+int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_bytes)
+{
+    CHECK_ENGINE(e);
+    if (!out_ptr) return e->fail(TBX_E_INVALID, "out_ptr is NULL");
+    const size_t N = (size_t)e->n;
+    void* p = nullptr;
+    size_t b = 0;
+    switch (which) {
+    case TBX_BUF_REWARD: p = e->reward; b = N * 4; break;
+    case TBX_BUF_DONE: p = e->done; b = N; break;
+    case TBX_BUF_LIVES: p = e->lives_out; b = N * 4; break;
+    case TBX_BUF_SCORE: p = e->score_out; b = N * 4; break;
+    case TBX_BUF_FRAME: p = e->frame; b = e->frame_bytes; break;
+    case TBX_BUF_PACKED: p = e->packed; b = N * 8; break;
+    default: return e->fail(TBX_E_INVALID, "unknown buffer id");
+    }
+    *out_ptr = p;
+    if (out_bytes) *out_bytes = b;
+    return TBX_OK;
+}
+
+int tbx_sync(tbx_engine* e)
+{
+    CHECK_ENGINE(e);
+    EHIP(hipSetDevice(e->device));
+    EHIP(hipDeviceSynchronize());
+    return check_err_flag(e);
+}
+
+}  // extern "C"

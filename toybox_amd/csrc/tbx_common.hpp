@@ -1,0 +1,218 @@
+// tbx_common.hpp -- shared pieces of the gfx950 engine: RNG, action tables, wave helpers,
+// the engine object and the per-game operations table.  gfx950 (CDNA4, wave64) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/toybox_amd.h"
+
+#define TBX_WAVE 64
+#define TBX_WAVES_PER_BLOCK 4
+#define TBX_BLOCK (TBX_WAVE * TBX_WAVES_PER_BLOCK)
+
+#define TBX_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (call);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            return e->fail(TBX_E_NO_DEVICE, std::string(#call) + ": " + hipGetErrorString(_e)); \
+        }                                                                                  \
+    } while (0)
+
+// ------------------------------------------------------------------ device helpers
+
+// xoroshiro128+ (55,14,36); pinned by tests/golden/rng_kat.json
+struct Rng {
+    uint64_t s0, s1;
+    __device__ __forceinline__ uint64_t next()
+    {
+        uint64_t r = s0 + s1;
+        uint64_t t = s1 ^ s0;
+        s0 = ((s0 << 55) | (s0 >> 9)) ^ t ^ (t << 14);
+        s1 = (t << 36) | (t >> 28);
+        return r;
+    }
+    __device__ __forceinline__ Rng child()
+    {
+        Rng c;
+        c.s0 = next();
+        c.s1 = next();
+        return c;
+    }
+    // uniform in [0,n): widening multiply + rejection zone (rand's UniformInt::sample_single)
+    __device__ __forceinline__ uint64_t range(uint64_t n)
+    {
+        if (n <= 1) return 0;
+        uint64_t zone = (n << __clzll((long long)n)) - 1;
+        for (;;) {
+            uint64_t v = next();
+            uint64_t lo = v * n;
+            if (lo <= zone) return __umul64hi(v, n);
+        }
+    }
+};
+
+__host__ __device__ __forceinline__ void tbx_seed_state(uint32_t seed, uint64_t& s0, uint64_t& s1)
+{
+    s0 = 0x193a6754a8a7d469ULL ^ (uint64_t)seed;
+    s1 = 0x97830e05113ba7bbULL;
+}
+
+__host__ __device__ __forceinline__ uint64_t tbx_splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+// ALE action id -> button mask (envs/atari/constants.py:16-35); 0xFF = illegal id
+__host__ __device__ __forceinline__ uint32_t tbx_ale_buttons(int a)
+{
+    // packed table, one byte per action
+    const uint8_t L = TBX_BTN_LEFT, R = TBX_BTN_RIGHT, U = TBX_BTN_UP, D = TBX_BTN_DOWN, F = TBX_BTN_BUTTON1;
+    switch (a) {
+    case 0: return 0;
+    case 1: return F;
+    case 2: return U;
+    case 3: return R;
+    case 4: return L;
+    case 5: return D;
+    case 6: return U | R;
+    case 7: return U | L;
+    case 8: return D | R;
+    case 9: return D | L;
+    case 10: return U | F;
+    case 11: return R | F;
+    case 12: return L | F;
+    case 13: return D | F;
+    case 14: return U | R | F;
+    case 15: return U | L | F;
+    case 16: return D | R | F;
+    case 17: return D | L | F;
+    default: return 0xFFu;
+    }
+}
+
+__host__ __device__ __forceinline__ int tbx_legal_count(int game)
+{
+    return game == TBX_GAME_BREAKOUT ? 4 : 6;
+}
+__host__ __device__ __forceinline__ int tbx_legal_action(int game, int i)
+{
+    // Breakout [0,1,3,4]; Amidar [0..5]; SpaceInvaders [0,1,3,4,11,12]
+    if (game == TBX_GAME_BREAKOUT) return i == 0 ? 0 : i == 1 ? 1 : i == 2 ? 3 : 4;
+    if (game == TBX_GAME_AMIDAR) return i;
+    return i == 0 ? 0 : i == 1 ? 1 : i == 2 ? 3 : i == 3 ? 4 : i == 4 ? 11 : 12;
+}
+
+// how the step kernels obtain their action
+struct ActionSource {
+    const int32_t* actions;   // device array, or nullptr for synthetic
+    uint64_t seed, t, env_offset;
+    int single_env;           // >= 0: only this env steps, with buttons `single_buttons`
+    uint32_t single_buttons;
+};
+
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ uint32_t gray_of(uint32_t rgba)
+{
+    uint32_t r = rgba & 255u, g = (rgba >> 8) & 255u, b = (rgba >> 16) & 255u;
+    return (77u * r + 150u * g + 29u * b + 128u) >> 8;
+}
+
+__host__ __device__ __forceinline__ uint32_t pack_color(tbx_color_t c)
+{
+    return (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16) | ((uint32_t)c.a << 24);
+}
+__host__ __device__ __forceinline__ tbx_color_t unpack_color(uint32_t v)
+{
+    tbx_color_t c;
+    c.r = (uint8_t)v; c.g = (uint8_t)(v >> 8); c.b = (uint8_t)(v >> 16); c.a = (uint8_t)(v >> 24);
+    return c;
+}
+
+// double -> pixel coordinate: clamp, then truncate toward zero (matches the oracle's f2i)
+__device__ __forceinline__ int f2i(double v)
+{
+    if (!(v > -1.0e6)) v = -1.0e6;
+    if (v > 1.0e6) v = 1.0e6;
+    return (int)v;
+}
+
+// store 4 consecutive pixels (packed 0xAABBGGRR each) of one lane in C channels
+template <int C>
+__device__ __forceinline__ void store_px4(uint8_t* p, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
+{
+    if (C == 4) {
+        uint4 v = make_uint4(c0 | 0xFF000000u, c1 | 0xFF000000u, c2 | 0xFF000000u, c3 | 0xFF000000u);
+        *reinterpret_cast<uint4*>(p) = v;
+    } else if (C == 3) {
+        c0 &= 0xFFFFFFu; c1 &= 0xFFFFFFu; c2 &= 0xFFFFFFu; c3 &= 0xFFFFFFu;
+        struct alignas(4) U3 { uint32_t a, b, c; };
+        U3 v;
+        v.a = c0 | (c1 << 24);
+        v.b = (c1 >> 8) | (c2 << 16);
+        v.c = (c2 >> 16) | (c3 << 8);
+        *reinterpret_cast<U3*>(p) = v;
+    } else {
+        uint32_t v = gray_of(c0) | (gray_of(c1) << 8) | (gray_of(c2) << 16) | (gray_of(c3) << 24);
+        *reinterpret_cast<uint32_t*>(p) = v;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+
+struct GameOps;
+
+struct tbx_engine {
+    int game = -1, n = 0, device = 0;
+    mutable std::string err;
+    hipStream_t stream = nullptr;   // engine-owned stream used by the host-pointer entry points
+    // common device buffers (SoA over envs)
+    uint64_t* sim_rng = nullptr;    // [2][N] simulator RNG
+    int32_t* prev_score = nullptr;  // [N]
+    int32_t* reward = nullptr;      // [N]
+    uint8_t* done = nullptr;        // [N]
+    int32_t* lives_out = nullptr;   // [N]
+    int32_t* score_out = nullptr;   // [N]
+    uint64_t* packed = nullptr;     // [N]
+    int32_t* actions = nullptr;     // [N] staging for host actions
+    uint8_t* mask = nullptr;        // [N] staging for new_game masks
+    uint32_t* err_flag = nullptr;   // device word: bit0 = illegal action seen
+    uint8_t* frame = nullptr;       // engine-owned frame buffer (lazy)
+    size_t frame_bytes = 0;
+    void* staging = nullptr;        // device POD staging for get/set state
+    size_t staging_bytes = 0;
+    GameOps* ops = nullptr;
+
+    int fail(int code, const std::string& msg) const
+    {
+        err = msg;
+        return code;
+    }
+};
+
+// per-game operations; all launches are asynchronous on `s`
+struct GameOps {
+    virtual ~GameOps() {}
+    virtual int init(tbx_engine* e, const void* cfg, size_t cfg_size) = 0;
+    virtual void destroy(tbx_engine* e) = 0;
+    virtual int height() const = 0;
+    virtual int width() const = 0;
+    virtual size_t state_size() const = 0;
+    virtual size_t config_size() const = 0;
+    virtual int get_config(tbx_engine* e, void* pod) = 0;
+    virtual int set_config(tbx_engine* e, const void* pod) = 0;
+    virtual int new_game(tbx_engine* e, const uint8_t* mask_dev, hipStream_t s) = 0;
+    virtual int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) = 0;
+    virtual int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) = 0;
+    // pack env -> e->staging (device), unpack e->staging -> env
+    virtual int pack_state(tbx_engine* e, int env, hipStream_t s) = 0;
+    virtual int unpack_state(tbx_engine* e, int env, const void* pod_host, hipStream_t s) = 0;
+    virtual int scalars(tbx_engine* e, int32_t* score_dev, int32_t* lives_dev, int32_t* level_dev, hipStream_t s) = 0;
+};
+
+GameOps* tbx_make_breakout_ops();

@@ -1,0 +1,165 @@
+"""Engine: thin Python view of one tbx_engine handle (N envs of one game on one MI355X).
+
+All compute happens behind the C-ABI of include/toybox_amd.h; this class only marshals numpy
+buffers and POD records.  The library is the in-tree HIP build (toybox_amd/_lib.py) -- the `lib`
+argument exists so that the test-suite can drive the same host code over the CPU oracle's
+restatement of the ABI (oracle/liboracle.so); product code never passes it.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import ToyboxAmdError, load
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine:
+    def __init__(self, game, n_envs=1, device=0, config=None, lib=None):
+        self._lib = lib if lib is not None else load()
+        self.game_id = _abi.GAME_IDS[game] if isinstance(game, str) else int(game)
+        self.game = _abi.GAME_NAMES[self.game_id]
+        self.n_envs = int(n_envs)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        self.state_type = _abi.STATE_TYPES[self.game_id]
+        self.config_type = _abi.CONFIG_TYPES[self.game_id]
+        cfg_ptr, cfg_size = None, 0
+        if config is not None:
+            if not isinstance(config, self.config_type):
+                raise TypeError("config must be a %s" % self.config_type.__name__)
+            cfg_ptr, cfg_size = C.cast(C.pointer(config), C.c_void_p), C.sizeof(config)
+        rc = self._lib.tbx_create(self.game_id, self.n_envs, self.device, cfg_ptr, cfg_size, C.byref(self._h))
+        if rc != _abi.OK:
+            msg = self._lib.tbx_last_error(None)
+            self._h = C.c_void_p()
+            raise ToyboxAmdError(rc, msg.decode() if msg else "tbx_create failed")
+        h, w = C.c_int(), C.c_int()
+        self._check(self._lib.tbx_frame_dims(self.game_id, C.byref(h), C.byref(w)))
+        self.height, self.width = h.value, w.value
+        buf = (C.c_int32 * 18)()
+        n = self._lib.tbx_legal_actions(self.game_id, buf, 18)
+        self.legal_actions = [int(buf[i]) for i in range(n)]
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != _abi.OK:
+            msg = self._lib.tbx_last_error(self._h)
+            raise ToyboxAmdError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if self._h:
+            self._lib.tbx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ------------------------------------------------------------------ seeding / RNG
+    def seed(self, seed, env=-1):
+        self._check(self._lib.tbx_seed(self._h, int(env), int(seed) & 0xFFFFFFFF))
+
+    def get_sim_rng(self, env=0):
+        out = (C.c_uint64 * 2)()
+        self._check(self._lib.tbx_get_sim_rng(self._h, int(env), out))
+        return int(out[0]), int(out[1])
+
+    def set_sim_rng(self, state, env=-1):
+        st = (C.c_uint64 * 2)(int(state[0]), int(state[1]))
+        self._check(self._lib.tbx_set_sim_rng(self._h, int(env), st))
+
+    # ------------------------------------------------------------------ game control
+    def new_game(self, mask=None):
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert m.shape == (self.n_envs,)
+        self._check(self._lib.tbx_new_game(self._h, _ptr(m)))
+
+    def step(self, actions, auto_reset=False):
+        """One frame for every env.  Returns (reward int32[N], done bool[N], lives int32[N], score int32[N])."""
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        if a.shape != (self.n_envs,):
+            raise ValueError("actions must have shape (%d,)" % self.n_envs)
+        n = self.n_envs
+        reward, lives, score = (np.empty(n, np.int32) for _ in range(3))
+        done = np.empty(n, np.uint8)
+        flags = _abi.STEP_AUTO_RESET if auto_reset else 0
+        self._check(self._lib.tbx_step(self._h, _ptr(a), flags, _ptr(reward), _ptr(done), _ptr(lives), _ptr(score)))
+        return reward, done.astype(bool), lives, score
+
+    def apply_input(self, env, buttons):
+        self._check(self._lib.tbx_apply_input(self._h, int(env), int(buttons)))
+
+    def scalars(self):
+        n = self.n_envs
+        score, lives, level = (np.empty(n, np.int32) for _ in range(3))
+        over = np.empty(n, np.uint8)
+        self._check(self._lib.tbx_get_scalars(self._h, _ptr(score), _ptr(lives), _ptr(level), _ptr(over)))
+        return score, lives, level, over.astype(bool)
+
+    # ------------------------------------------------------------------ frames
+    def render(self, channels=3):
+        out = np.empty((self.n_envs, self.height, self.width, channels), np.uint8)
+        self._check(self._lib.tbx_render(self._h, _ptr(out), int(channels)))
+        return out
+
+    def render_env(self, env, channels=3):
+        out = np.empty((self.height, self.width, channels), np.uint8)
+        self._check(self._lib.tbx_render_env(self._h, int(env), _ptr(out), int(channels)))
+        return out
+
+    # ------------------------------------------------------------------ state / config records
+    def get_state(self, env=0):
+        st = self.state_type()
+        self._check(self._lib.tbx_get_state(self._h, int(env), C.byref(st), C.sizeof(st)))
+        return st
+
+    def set_state(self, env, st):
+        if not isinstance(st, self.state_type):
+            raise TypeError("state must be a %s" % self.state_type.__name__)
+        self._check(self._lib.tbx_set_state(self._h, int(env), C.byref(st), C.sizeof(st)))
+
+    def get_config(self):
+        cfg = self.config_type()
+        self._check(self._lib.tbx_get_config(self._h, C.byref(cfg), C.sizeof(cfg)))
+        return cfg
+
+    def set_config(self, cfg):
+        if not isinstance(cfg, self.config_type):
+            raise TypeError("config must be a %s" % self.config_type.__name__)
+        self._check(self._lib.tbx_set_config(self._h, C.byref(cfg), C.sizeof(cfg)))
+
+    # ------------------------------------------------------------------ device-resident path
+    def step_device(self, actions_ptr, auto_reset=False, stream=0):
+        flags = _abi.STEP_AUTO_RESET if auto_reset else 0
+        self._check(self._lib.tbx_step_device(self._h, C.c_void_p(int(actions_ptr)), flags, C.c_void_p(int(stream))))
+
+    def step_synthetic(self, action_seed, t, env_offset=0, auto_reset=True, stream=0):
+        flags = _abi.STEP_AUTO_RESET if auto_reset else 0
+        self._check(self._lib.tbx_step_synthetic(self._h, int(action_seed), int(t), int(env_offset), flags,
+                                                 C.c_void_p(int(stream))))
+
+    def render_device(self, out_ptr=0, channels=3, stream=0):
+        self._check(self._lib.tbx_render_device(self._h, C.c_void_p(int(out_ptr)) if out_ptr else None,
+                                                int(channels), C.c_void_p(int(stream))))
+
+    def device_buffer(self, which):
+        p, b = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.tbx_device_buffer(self._h, int(which), C.byref(p), C.byref(b)))
+        return (p.value or 0), b.value
+
+    def sync(self):
+        self._check(self._lib.tbx_sync(self._h))
