@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched game-step hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: the step kernel (transition + auto-reset,
+actions generated on the device by the counter-based rule of SURVEY 8d) followed by the frame
+rasteriser writing uint8[N,H,W,3] into HBM.  Workload at every N: Breakout, 65536 envs PER GPU
+(weak scaling: the batch shards embarrassingly, envs never interact), env seeds 1234 + global env
+index.  For N > 1 the driver launches one process per GPU through torch.distributed.run; the only
+exchange is the per-step all_gather of the packed {reward, done, lives} record over RCCL.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the dominant kernel (the rasteriser) priced against HBM bandwidth with HIP events
+                  recorded around every render launch of the timed region, and
+  cpu_baseline -- the CPU oracle (oracle/, a port: ctoybox itself cannot be built offline) timed on
+                  this box's host cores on a bounded sample of the same workload (N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+# algorithmic bytes per env-step: 2*S_game + A + O + F
+S_GAME = {"breakout": 72, "space_invaders": 248, "amidar": 420}
+A_BYTES, O_BYTES = 1, 5
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--game", default="breakout")
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--channels", type=int, default=3)
+    ap.add_argument("--no-render", action="store_true", help="step-only mode (reported separately, no roofline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=4096)
+    ap.add_argument("--cpu-steps", type=int, default=40)
+    return ap.parse_args()
+
+
+def cpu_baseline(game, channels, n_envs, steps):
+    """Times the CPU oracle (step + render, auto-reset, same action rule) on all host cores."""
+    from toybox_amd import Engine, _abi
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(path):
+        return None
+    cores = os.cpu_count() or 1
+    os.environ["TBX_ORACLE_THREADS"] = str(cores)
+    lib = ctypes.CDLL(path)
+    _abi.bind(lib)
+    e = Engine(game, n_envs, lib=lib)
+    e.seed(1234)
+    e.new_game()
+    for t in range(3):
+        e.step_synthetic(1337, t)
+        e.render_device(0, channels)
+    t0 = time.perf_counter()
+    for t in range(3, 3 + steps):
+        e.step_synthetic(1337, t)
+        e.render_device(0, channels)
+    dt = time.perf_counter() - t0
+    e.close()
+    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%s step+render(%dch), %d envs x %d steps, OpenMP static partition over envs, %.1f s" %
+                      (game, channels, n_envs, steps, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print("bench.py: --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus),
+              file=sys.stderr)
+        return 2
+
+    from toybox_amd import Engine, _abi, hip
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    hip.set_device(local_rank)
+
+    n = args.envs
+    game = args.game
+    eng = Engine(game, n, device=local_rank)
+    eng.seed(1234 + rank * n)            # env i of this rank: seed 1234 + global index
+    eng.new_game()
+    env_offset = rank * n
+    H, W, C = eng.height, eng.width, args.channels
+    render = not args.no_render
+
+    if world > 1:
+        stream_ptr = torch.cuda.current_stream().cuda_stream
+        packed_local = torch.zeros(n, dtype=torch.int64, device="cuda")
+        gathered = torch.zeros(n * world, dtype=torch.int64, device="cuda")
+        packed_src, _ = eng.device_buffer(_abi.BUF_PACKED)
+    else:
+        stream = hip.Stream()
+        stream_ptr = stream.ptr
+
+    K, Wm = args.steps, args.warmup
+    ev = [(hip.Event(), hip.Event()) for _ in range(K)] if render else []
+    pending = None
+
+    def one_step(t, events=None):
+        nonlocal pending
+        eng.step_synthetic(1337, t, env_offset=env_offset, auto_reset=True, stream=stream_ptr)
+        if world > 1:
+            if pending is not None:
+                pending.wait()
+            hip.memcpy_dtod_async(packed_local.data_ptr(), packed_src, 8 * n, stream_ptr)
+            pending = dist.all_gather_into_tensor(gathered, packed_local, async_op=True)
+        if render:
+            if events:
+                events[0].record(stream_ptr)
+            eng.render_device(0, C, stream=stream_ptr)
+            if events:
+                events[1].record(stream_ptr)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        hip.synchronize()
+
+    for t in range(Wm):
+        one_step(t)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        one_step(Wm + i, ev[i] if render else None)
+    if pending is not None:
+        pending.wait()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.sync()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    render_ms = None
+    if render:
+        render_ms = float(np.mean([a.elapsed_ms(b) for a, b in ev]))
+
+    # sanity: the rollout really played (scores move, episodes end)
+    score, lives, level, over = eng.scalars()
+    frame_bytes = H * W * C if render else 0
+    bytes_per_step = 2 * S_GAME[game] + A_BYTES + O_BYTES + frame_bytes
+
+    if rank == 0:
+        value = world * n * K / elapsed
+        out = {
+            "metric": "env steps/sec (whole node), Breakout 64k-env batch" if game == "breakout" else "env steps/sec (whole node), %s" % game,
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": 1000.0 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if game == "breakout" else "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s %s, %d envs/GPU, uniform random legal actions generated on device "
+                            "(splitmix64 counter rule, seed 1337), env seeds 1234+global index, auto-reset on done"
+                            % (game, "step + %dx%dx%d uint8 frame render" % (H, W, C) if render else "step-only", n),
+                "envs_per_gpu": n, "envs_total": n * world, "frame_hwc": [H, W, C] if render else None,
+                "parallelism": "env-sharded x%d, per-step RCCL all_gather of 8 B/env records" % world if world > 1 else "single GPU",
+                "algorithmic_bytes_per_env_step": bytes_per_step,
+            },
+        }
+        if render:
+            achieved = n * frame_bytes / (render_ms * 1e-3) / 1e9    # GB/s, algorithmic frame bytes of one launch
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tp):
+                try:
+                    rec = json.load(open(tp)).get("%s_render_%dch_%d" % (game, C, n))
+                    traffic = rec["hbm_bytes_per_launch"] if rec else None
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "%s render (%d ch)" % (game, C),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": n * frame_bytes, "avg_launch_ms": render_ms,
+            }
+        else:
+            out["roofline"] = None
+        out["check"] = {"mean_score": float(score.mean()), "mean_lives": float(lives.mean()), "max_level": int(level.max())}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(game, C, args.cpu_envs, args.cpu_steps)
+            except Exception as ex:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,71 @@
+"""Multi-rank path on CPU: world_size-2 gloo run of toybox_amd.parallel over the oracle's ABI must equal a
+single-process run over the whole batch (results independent of the number of ranks)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import ROOT
+from toybox_amd.parallel import pack_records, shard_range, unpack_records
+
+WORKER = r"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch.distributed as dist
+from toybox_amd import Engine, _abi
+from toybox_amd.parallel import ShardedBatch
+from support import synthetic_actions
+lib = ctypes.CDLL(os.path.join({root!r}, "oracle", "liboracle.so")); _abi.bind(lib)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+sb = ShardedBatch(lambda n: Engine("breakout", n, lib=lib), {n}, dist=dist)
+tot = np.zeros({n}, np.int64); dn = np.zeros({n}, np.int64)
+for t in range({steps}):
+    r, d, l = sb.step_host(synthetic_actions("breakout", {n}, t))
+    tot += r; dn += d
+if dist.get_rank() == 0:
+    np.save({out!r}, np.stack([tot, dn, l.astype(np.int64)]))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_shard_range_partition():
+    for n, w in ((10, 3), (65536, 8), (7, 8), (262144, 8)):
+        spans = [shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_record_packing_roundtrip():
+    r = np.array([0, 7, 2**31 - 1, 4], np.int32)
+    d = np.array([0, 1, 0, 1], bool)
+    l = np.array([5, 0, 255, 3])
+    rr, dd, ll = unpack_records(pack_records(r, d, l))
+    assert np.array_equal(rr, r) and np.array_equal(dd, d) and np.array_equal(ll, l)
+
+
+def test_two_rank_gloo_equals_single_process(oracle_lib, tmp_path):
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from support import synthetic_actions
+    from toybox_amd import Engine
+    from toybox_amd.parallel import ShardedBatch
+    n, steps, port = 37, 700, 29000 + os.getpid() % 2000
+    out = str(tmp_path / "r0.npy")
+    src = WORKER.format(root=ROOT, port=port, n=n, steps=steps, out=out)
+    script = tmp_path / "worker.py"
+    script.write_text(src)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = np.load(out)
+    sb = ShardedBatch(lambda k: Engine("breakout", k, lib=oracle_lib), n, dist=None)
+    tot = np.zeros(n, np.int64)
+    dn = np.zeros(n, np.int64)
+    for t in range(steps):
+        r, d, l = sb.step_host(synthetic_actions("breakout", n, t))
+        tot += r
+        dn += d
+    assert np.array_equal(got[0], tot) and np.array_equal(got[1], dn) and np.array_equal(got[2], l.astype(np.int64))
+    assert tot.sum() > 0

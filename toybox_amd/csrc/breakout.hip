@@ -2,7 +2,7 @@
 //
 // Replaces the per-env Rust transition + rasteriser behind ctoybox.Toybox.apply_ale_action /
 // get_state (call sites: /root/reference/toybox/envs/atari/base.py:126,109).  Semantics are the
-// ones stated in DESIGN.md "Breakout" and restated independently (scalar C) in oracle/orc_breakout.c;
+// ones stated in DESIGN.md "Breakout" and restated independently (scalar C) by the CPU checker under oracle/;
 // the two are compared bit for bit by tests/test_gpu_parity.py.
 //
 // Layout in HBM: struct-of-arrays over the env batch for every scalar field (field f of env e at

@@ -1,9 +1,9 @@
 """Engine: thin Python view of one tbx_engine handle (N envs of one game on one MI355X).
 
 All compute happens behind the C-ABI of include/toybox_amd.h; this class only marshals numpy
-buffers and POD records.  The library is the in-tree HIP build (toybox_amd/_lib.py) -- the `lib`
-argument exists so that the test-suite can drive the same host code over the CPU oracle's
-restatement of the ABI (oracle/liboracle.so); product code never passes it.
+buffers and POD records.  The library is the in-tree HIP build (toybox_amd/_lib.py).  The `lib`
+argument takes any bound library that exports the same ABI; product code never passes it (the
+test-suite uses it to drive this host code over its CPU checker).
 """
 import ctypes as C
 
