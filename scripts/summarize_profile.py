@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (scripts/profile_gpu.sh) into profiles/<tag>_*.{csv,md}
+and update profiles/traffic.json (HBM bytes per launch of the dominant kernel from the PMC passes).
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE/WRITE_SIZE are in KiB;
+FETCH_SIZE under-reports wide coalesced streaming reads by 2x (doubled here, flagged as an upper
+bound for non-streaming reads); WRITE_SIZE is exact for 16-byte-per-lane streaming stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name.split("(")[0]
+
+
+def main():
+    tag = sys.argv[1]
+    key = sys.argv[2] if len(sys.argv) > 2 else None        # e.g. breakout_render_3ch_65536
+    kernel_sub = sys.argv[3] if len(sys.argv) > 3 else "render_kernel<3"
+    src = os.path.join(ROOT, "gpurun_out", "prof_%s" % tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    lines = ["# rocprofv3 summary `%s`" % tag, ""]
+    host = os.path.join(src, "host.txt")
+    if os.path.exists(host):
+        lines += ["host: " + open(host).read().strip(), ""]
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
+        lines += ["## kernel-trace --stats (bench.py --steps 100 --warmup 10)", "",
+                  "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
+        for r in csv.DictReader(open(stats[0])):
+            lines.append("| `%s` | %s | %.1f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                             float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+        lines.append("")
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            per[k]["_dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Grid_Size"], r["Workgroup_Size"])
+    traffic = {}
+    if per:
+        lines += ["## PMC passes (separate runs, --pmc with --kernel-trace only)", "",
+                  "| kernel | grid | wg | VGPR | SGPR | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes/launch (fetch x2 corrected) | avg us (profiled) |",
+                  "|---|---|---|---|---|---|---|---|---|"]
+        for k, c in sorted(per.items()):
+            if "kernel" not in k:
+                continue
+            mean = lambda n: sum(c[n]) / len(c[n]) if c.get(n) else None
+            fs, ws = mean("FETCH_SIZE"), mean("WRITE_SIZE")
+            hbm = None
+            if fs is not None and ws is not None:
+                hbm = (2.0 * fs + ws) * 1024.0
+            v, s, l, g, w = meta[k]
+            lines.append("| `%s` | %s | %s | %s | %s | %s | %s | %s | %.1f |" % (
+                k, g, w, v, s, "%.0f" % fs if fs is not None else "-", "%.0f" % ws if ws is not None else "-",
+                "%.4g" % hbm if hbm else "-", mean("_dur_us")))
+            if kernel_sub in k and hbm:
+                traffic = {"hbm_bytes_per_launch": hbm, "fetch_kib_raw": fs, "write_kib_raw": ws,
+                           "correction": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE exact",
+                           "source": "profiles/%s_summary.md" % tag}
+            extra = {n: mean(n) for n in c if n not in ("FETCH_SIZE", "WRITE_SIZE", "_dur_us")}
+            if extra:
+                lines.append("|  | | | | | " + ", ".join("%s=%.4g" % kv for kv in sorted(extra.items())) + " | | | |")
+        lines.append("")
+    open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
+    if key and traffic:
+        tp = os.path.join(dst, "traffic.json")
+        db = json.load(open(tp)) if os.path.exists(tp) else {}
+        db[key] = traffic
+        json.dump(db, open(tp, "w"), indent=1, sort_keys=True)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()

@@ -398,6 +398,7 @@ int tbx_render_device(tbx_engine* e, uint8_t* out_dev, int channels, void* strea
         if (rc) return rc;
         out_dev = e->frame;
     }
+    if (((uintptr_t)out_dev & 15u) != 0) return e->fail(TBX_E_INVALID, "frame buffer must be 16-byte aligned");
     return e->ops->render(e, out_dev, channels, 0, e->n, (hipStream_t)stream);
 }
 
