@@ -1,0 +1,102 @@
+"""Batched env with the VecEnv contract of the reference's vendored baselines
+(/root/reference/baselines/baselines/common/vec_env/__init__.py:26-131): reset() -> obs[N,...];
+step_async(actions[N]); step_wait() -> (obs, rews float32, dones bool, infos); a done env is reset and
+the returned obs is the reset obs (dummy_vec_env.py:51-54, subproc_vec_env.py:11-15).  The N worker
+processes + pipes of SubprocVecEnv collapse into one device batch: one step kernel + one render kernel."""
+import numpy as np
+
+from .. import _abi
+from ..engine import Engine
+from ..games import codec
+from ..toybox import _make_engine
+from .base import hash_seed
+from .spaces import Box, Discrete
+
+
+class ToyboxVecEnv:
+    def __init__(self, game, num_envs, grayscale=True, alpha=False, seed=None, cache_terminal_state=False, engine=None):
+        self.game = {"spaceinvaders": "space_invaders"}.get(game, game)
+        self.num_envs = int(num_envs)
+        self.engine = engine if engine is not None else _make_engine(self.game, self.num_envs)
+        self._channels = 1 if grayscale else 4 if alpha else 3
+        self._action_set = sorted(self.engine.legal_actions)
+        self._lut = np.asarray(self._action_set, dtype=np.int32)
+        self.action_space = Discrete(len(self._action_set))
+        self.observation_space = Box(0, 255, (self.engine.height, self.engine.width, self._channels), "uint8")
+        self.cache_terminal_state = bool(cache_terminal_state)
+        self._codec = codec(self.game)
+        self._pending = None
+        self.closed = False
+        if seed is not None:
+            self.seed(seed)
+
+    # ------------------------------------------------------------------ seeding
+    def seed(self, seed):
+        """env i gets the reference's per-env derivation (cmd_util.py:31: seed + rank), each pushed through
+        ToyboxBaseEnv.seed's hash (envs/atari/base.py:84-98); returns [[seed1, seed2], ...]."""
+        out = []
+        for i in range(self.num_envs):
+            seed1 = int(seed) + i
+            seed2 = hash_seed(seed1 + 1) % 2 ** 31
+            self.engine.seed(seed2, env=i)
+            out.append([seed1, seed2])
+        self.engine.new_game()
+        return out
+
+    # ------------------------------------------------------------------ VecEnv
+    def reset(self):
+        self.engine.new_game()
+        return self.engine.render(self._channels)
+
+    def step_async(self, actions):
+        a = np.asarray(actions)
+        if a.shape != (self.num_envs,):
+            raise ValueError("actions must have shape (%d,)" % self.num_envs)
+        if a.min() < 0 or a.max() >= len(self._action_set):
+            raise AssertionError("action index out of range")   # assert action_index < len(action_set) (base.py:123)
+        self._pending = self._lut[a.astype(np.int64)]
+
+    def step_wait(self):
+        assert self._pending is not None, "step_wait without step_async"
+        actions, self._pending = self._pending, None
+        infos = [{} for _ in range(self.num_envs)]
+        if self.cache_terminal_state:
+            reward, done, lives, score = self.engine.step(actions, auto_reset=False)
+            idx = np.nonzero(done)[0]
+            for i in idx:
+                infos[i]["cached_state"] = self._codec.state_to_json(self.engine.get_state(int(i)))
+            if len(idx):
+                self.engine.new_game(done.astype(np.uint8))
+        else:
+            reward, done, lives, score = self.engine.step(actions, auto_reset=True)
+        obs = self.engine.render(self._channels)
+        for i in range(self.num_envs):
+            infos[i]["lives"] = int(lives[i])
+            infos[i]["score"] = 0 if done[i] else int(score[i])
+        return obs, reward.astype(np.float32), done, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def get_images(self):
+        return self.engine.render(3)
+
+    def render(self, mode="rgb_array"):
+        imgs = self.get_images()
+        if mode == "rgb_array":
+            return imgs
+        raise NotImplementedError("only rgb_array rendering is provided")
+
+    def close(self):
+        if not self.closed:
+            self.engine.close()
+            self.closed = True
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def get_action_meanings(self):
+        from .constants import ACTION_MEANING
+        return list(ACTION_MEANING.values())

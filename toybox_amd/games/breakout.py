@@ -200,3 +200,24 @@ def schema_for_state():
 def schema_for_config():
     return {"$schema": "http://json-schema.org/draft-07/schema#", "title": "BreakoutConfig", "type": "object",
             "required": list(CONFIG_KEYS), "properties": {}}
+
+
+def query(tb, name, args):
+    """State queries of the Breakout core (slow path, evaluated from the state JSON)."""
+    js = tb.state_to_json()
+    bricks = js["bricks"]
+    rows = max((b["row"] for b in bricks), default=-1) + 1
+    cols = max((b["col"] for b in bricks), default=-1) + 1
+    if name == "bricks_remaining":
+        return sum(1 for b in bricks if b["alive"])
+    if name in ("count_channels", "channel_count"):
+        return sum(1 for c in range(cols) if all(not b["alive"] for b in bricks if b["col"] == c))
+    if name == "num_columns":
+        return cols
+    if name == "num_rows":
+        return rows
+    if name == "channels":
+        return [c for c in range(cols) if all(not b["alive"] for b in bricks if b["col"] == c)]
+    if name == "brick_live_by_index":
+        return bool(bricks[int(args)]["alive"])
+    raise ValueError("unknown breakout query %r" % (name,))
