@@ -136,6 +136,66 @@ typedef struct tbx_breakout_state {
     tbx_brick_t bricks[TBX_BRK_MAX_BRICKS];
 } tbx_breakout_state_t;
 
+/* ------------------------------------------------------------------ SpaceInvaders POD */
+
+#define TBX_SI_W            320
+#define TBX_SI_H            210
+#define TBX_SI_COLS         6
+#define TBX_SI_MAX_ROWS     10
+#define TBX_SI_MAX_ENEMIES  64    /* one lane per enemy; 6 x 10 = 60 */
+#define TBX_SI_MAX_SHIELDS  3
+#define TBX_SI_SHIELD_W     16
+#define TBX_SI_SHIELD_H     18
+#define TBX_SI_MAX_LASERS   8
+
+/* interventions/core.py:125-135 Direction.directions order */
+#define TBX_DIR_UP    0
+#define TBX_DIR_DOWN  1
+#define TBX_DIR_LEFT  2
+#define TBX_DIR_RIGHT 3
+
+typedef struct tbx_si_config {
+    uint64_t rand[2];
+    double   jitter;                  /* probability of a random (vs player-targeted) firing column */
+    int32_t  start_lives, n_rows, n_shields;
+    int32_t  enemy_protocol;          /* 0 = "TargetPlayer" */
+    int32_t  row_scores[TBX_SI_MAX_ROWS];
+    int32_t  shield_x[TBX_SI_MAX_SHIELDS], shield_y[TBX_SI_MAX_SHIELDS];
+} tbx_si_config_t;
+
+typedef struct tbx_si_laser {
+    int32_t  x, y, w, h, t, movement, speed;
+    tbx_color_t color;
+} tbx_si_laser_t;
+
+typedef struct tbx_si_enemy {
+    int32_t  x, y, row, col, id, points;
+    int32_t  death_counter;           /* -1 == None */
+    uint8_t  alive, _pad[3];
+} tbx_si_enemy_t;
+
+typedef struct tbx_si_state {
+    uint64_t rand[2];
+    int32_t  score, lives, level;
+    int32_t  life_display_timer, enemy_shot_delay;
+    int32_t  n_enemies, n_enemy_lasers, has_ship_laser;
+    int32_t  ship_x, ship_y, ship_w, ship_h, ship_speed;
+    int32_t  ship_death_counter;      /* -1 == None */
+    tbx_color_t ship_color;
+    uint8_t  ship_alive, ship_death_hit_1, _pad0[2];
+    int32_t  ufo_x, ufo_y, ufo_appearance_counter;
+    int32_t  ufo_death_counter;       /* -1 == None */
+    int32_t  move_counter, move_dir;
+    uint8_t  visual_orientation, _pad1[3];
+    int32_t  n_shields;
+    int32_t  shield_x[TBX_SI_MAX_SHIELDS], shield_y[TBX_SI_MAX_SHIELDS];
+    tbx_color_t shield_color[TBX_SI_MAX_SHIELDS];
+    uint16_t shield_rows[TBX_SI_MAX_SHIELDS][TBX_SI_SHIELD_H];   /* bit c of row r = pixel (c,r) present */
+    tbx_si_laser_t ship_laser;
+    tbx_si_laser_t enemy_lasers[TBX_SI_MAX_LASERS];
+    tbx_si_enemy_t enemies[TBX_SI_MAX_ENEMIES];
+} tbx_si_state_t;
+
 /* ------------------------------------------------------------------ engine */
 
 typedef struct tbx_engine tbx_engine;

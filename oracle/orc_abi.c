@@ -43,6 +43,7 @@ size_t tbx_state_size(int game)
 {
     switch (game) {
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_state_t);
+    case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_state_t);
     default: return 0;
     }
 }
@@ -50,6 +51,7 @@ size_t tbx_config_size(int game)
 {
     switch (game) {
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_config_t);
+    case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_config_t);
     default: return 0;
     }
 }
@@ -88,6 +90,7 @@ int tbx_create(int game, int n, int device, const void* cfg, size_t cfg_size, tb
     if (cfg) memcpy(e->cfg, cfg, csz);
     else switch (game) {
         case TBX_GAME_BREAKOUT: orc_breakout_default_config((tbx_breakout_config_t*)e->cfg); break;
+        case TBX_GAME_SPACE_INVADERS: orc_si_default_config((tbx_si_config_t*)e->cfg); break;
     }
     for (int i = 0; i < n; i++) memcpy(e->sim + 2 * (size_t)i, e->cfg, 16);
     orc_new_game_batch(game, e->cfg, e->states, e->sim, e->prev, n, NULL);
@@ -197,6 +200,9 @@ int tbx_apply_input(tbx_engine* e, int env, uint32_t buttons)
     case TBX_GAME_BREAKOUT:
         orc_breakout_step((const tbx_breakout_config_t*)e->cfg, (tbx_breakout_state_t*)st, buttons & 0x3Fu);
         break;
+    case TBX_GAME_SPACE_INVADERS:
+        orc_si_step((const tbx_si_config_t*)e->cfg, (tbx_si_state_t*)st, buttons & 0x3Fu);
+        break;
     }
     int32_t sc, lv, le;
     orc_get_scalars(e->game, st, 1, &sc, &lv, &le);
@@ -272,6 +278,12 @@ int tbx_set_state(tbx_engine* e, int env, const void* pod, size_t size)
         if (s->n_balls < 0 || s->n_balls > TBX_BRK_MAX_BALLS) return fail(e, TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 4 balls per env");
         if (s->n_bricks < 0 || s->n_bricks > TBX_BRK_MAX_BRICKS) return fail(e, TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 256 bricks per env");
     }
+    if (e->game == TBX_GAME_SPACE_INVADERS) {
+        const tbx_si_state_t* s = (const tbx_si_state_t*)pod;
+        if (s->n_enemies < 0 || s->n_enemies > TBX_SI_MAX_ENEMIES) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 64 enemies per env");
+        if (s->n_enemy_lasers < 0 || s->n_enemy_lasers > TBX_SI_MAX_LASERS) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 8 enemy lasers per env");
+        if (s->n_shields < 0 || s->n_shields > TBX_SI_MAX_SHIELDS) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 3 shields per env");
+    }
     memcpy(e->states + e->ssz * (size_t)env, pod, size);
     return TBX_OK;
 }
@@ -295,6 +307,12 @@ int tbx_set_config(tbx_engine* e, const void* pod, size_t size)
         if (k->n_starts < 1 || k->n_starts > TBX_BRK_MAX_STARTS) return fail(e, TBX_E_UNSUPPORTED, "breakout: 1..8 ball_start_positions");
         if (k->paddle_discrete_segments < 1 || k->paddle_discrete_segments > TBX_BRK_MAX_SEGMENTS)
             return fail(e, TBX_E_UNSUPPORTED, "breakout: paddle_discrete_segments must be 1..16");
+    }
+    if (e->game == TBX_GAME_SPACE_INVADERS) {
+        const tbx_si_config_t* k = (const tbx_si_config_t*)pod;
+        if (k->n_rows < 1 || k->n_rows > TBX_SI_MAX_ROWS) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: n_rows must be 1..10");
+        if (k->n_shields < 0 || k->n_shields > TBX_SI_MAX_SHIELDS) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: at most 3 shields");
+        if (k->enemy_protocol != 0) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: only the TargetPlayer firing protocol is implemented");
     }
     memcpy(e->cfg, pod, size);
     for (int i = 0; i < e->n; i++) memcpy(e->sim + 2 * (size_t)i, pod, 16);

@@ -231,8 +231,13 @@ static void put(uint8_t* out, int ch, int x, int y, tbx_color_t c)
 
 static void rect(uint8_t* out, int ch, int x0, int y0, int w, int h, tbx_color_t c)
 {
-    for (int y = y0; y < y0 + h; y++)
-        for (int x = x0; x < x0 + w; x++) put(out, ch, x, y, c);
+    long xa = x0, xb = (long)x0 + w, ya = y0, yb = (long)y0 + h;   /* clip first: sizes come from state records */
+    if (xa < 0) xa = 0;
+    if (ya < 0) ya = 0;
+    if (xb > TBX_BRK_W) xb = TBX_BRK_W;
+    if (yb > TBX_BRK_H) yb = TBX_BRK_H;
+    for (long y = ya; y < yb; y++)
+        for (long x = xa; x < xb; x++) put(out, ch, (int)x, (int)y, c);
 }
 
 static void digit(uint8_t* out, int ch, int x0, int y0, int d, tbx_color_t c)

@@ -96,6 +96,7 @@ int orc_frame_dims(int game, int* h, int* w)
 {
     switch (game) {
     case TBX_GAME_BREAKOUT: *h = TBX_BRK_H; *w = TBX_BRK_W; return 0;
+    case TBX_GAME_SPACE_INVADERS: *h = TBX_SI_H; *w = TBX_SI_W; return 0;
     default: return -1;
     }
 }
@@ -114,6 +115,7 @@ static size_t state_size(int game)
 {
     switch (game) {
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_state_t);
+    case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_state_t);
     default: return 0;
     }
 }
@@ -124,6 +126,9 @@ static void one_new_game(int game, const void* cfg, void* st, uint64_t* sim)
     case TBX_GAME_BREAKOUT:
         orc_breakout_new_game((const tbx_breakout_config_t*)cfg, sim, (tbx_breakout_state_t*)st);
         break;
+    case TBX_GAME_SPACE_INVADERS:
+        orc_si_new_game((const tbx_si_config_t*)cfg, sim, (tbx_si_state_t*)st);
+        break;
     }
 }
 
@@ -132,6 +137,9 @@ static void one_step(int game, const void* cfg, void* st, uint32_t buttons)
     switch (game) {
     case TBX_GAME_BREAKOUT:
         orc_breakout_step((const tbx_breakout_config_t*)cfg, (tbx_breakout_state_t*)st, buttons);
+        break;
+    case TBX_GAME_SPACE_INVADERS:
+        orc_si_step((const tbx_si_config_t*)cfg, (tbx_si_state_t*)st, buttons);
         break;
     }
 }
@@ -142,6 +150,10 @@ static void one_scalars(int game, const void* st, int32_t* score, int32_t* lives
     switch (game) {
     case TBX_GAME_BREAKOUT: {
         const tbx_breakout_state_t* s = (const tbx_breakout_state_t*)st;
+        *score = s->score; *lives = s->lives; *level = s->level;
+        break; }
+    case TBX_GAME_SPACE_INVADERS: {
+        const tbx_si_state_t* s = (const tbx_si_state_t*)st;
         *score = s->score; *lives = s->lives; *level = s->level;
         break; }
     }
@@ -222,6 +234,9 @@ int orc_render_batch(int game, const void* cfg, const void* states, int n, uint8
         case TBX_GAME_BREAKOUT:
             orc_breakout_render((const tbx_breakout_config_t*)cfg, (const tbx_breakout_state_t*)st,
                                 out + fsz * (size_t)i, channels);
+            break;
+        case TBX_GAME_SPACE_INVADERS:
+            orc_si_render((const tbx_si_config_t*)cfg, (const tbx_si_state_t*)st, out + fsz * (size_t)i, channels);
             break;
         }
     }

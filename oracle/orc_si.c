@@ -1,0 +1,374 @@
+/* orc_si.c -- CPU restatement of SpaceInvaders.  TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Pinned by /root/reference/toybox/interventions/defaults/space_invaders_{config,state}_default.json
+ * (tests/golden/space_invaders_state.json): new_game() -- 36 enemies id = row*6+col at
+ * (44+32c, 31+18r) with points by row, three 16x18 shields with the golden pixel mask and colour,
+ * ship (68,185) 16x10 speed 3 not yet alive, life_display_timer 128, ufo (-2,12) appearance 500,
+ * enemy_shot_delay 50, lives 3, RNG bookkeeping (KAT-C).
+ * The per-frame rules and the pixels are PARITY UNPINNED: they follow DESIGN.md "SpaceInvaders".
+ * All arithmetic is int32 except the jitter test, a binary64 compare of (draw >> 11) * 2^-53. */
+#include "oracle.h"
+#include "../include/toybox_amd_spec.h"
+#include <string.h>
+
+static tbx_color_t rgb3(int r, int g, int b) { tbx_color_t c = {(uint8_t)r, (uint8_t)g, (uint8_t)b, 255}; return c; }
+
+static const uint16_t SHIELD_DEFAULT[TBX_SI_SHIELD_H] = {
+    0x0FF0, 0x0FF0, 0x3FFC, 0x3FFC, 0x3FFC, 0x3FFC, 0x3FFC, 0x3FFC, 0x3FFC, 0x3FFC,
+    0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xF00F, 0xF00F};
+
+void orc_si_default_config(tbx_si_config_t* c)
+{
+    memset(c, 0, sizeof *c);
+    orc_rng_seed(c->rand, 17);
+    c->jitter = 0.5;
+    c->start_lives = 3;
+    c->n_rows = 6;
+    c->n_shields = 3;
+    c->enemy_protocol = 0;
+    static const int sc[6] = {30, 30, 20, 20, 10, 10};
+    for (int i = 0; i < 6; i++) c->row_scores[i] = sc[i];
+    static const int sx[3] = {84, 148, 212};
+    for (int i = 0; i < 3; i++) { c->shield_x[i] = sx[i]; c->shield_y[i] = 157; }
+}
+
+static void reset_formation(tbx_si_state_t* s)
+{
+    for (int i = 0; i < s->n_enemies; i++) {
+        tbx_si_enemy_t* e = &s->enemies[i];
+        e->x = TBX_SI_ENEMY_X0 + TBX_SI_ENEMY_DX * e->col;
+        e->y = TBX_SI_ENEMY_Y0 + TBX_SI_ENEMY_DY * e->row;
+        e->alive = 1;
+        e->death_counter = -1;
+    }
+    s->move_counter = TBX_SI_MOVE_PERIOD;
+    s->move_dir = TBX_DIR_RIGHT;
+    s->visual_orientation = 1;
+    s->n_enemy_lasers = 0;
+    s->has_ship_laser = 0;
+    memset(&s->ship_laser, 0, sizeof s->ship_laser);
+    memset(s->enemy_lasers, 0, sizeof s->enemy_lasers);
+}
+
+void orc_si_new_game(const tbx_si_config_t* c, uint64_t sim_rng[2], tbx_si_state_t* s)
+{
+    memset(s, 0, sizeof *s);
+    orc_rng_child(sim_rng, s->rand);
+    s->score = 0;
+    s->lives = c->start_lives;
+    s->level = 1;
+    s->life_display_timer = TBX_SI_NEW_LIFE_TIME;
+    s->enemy_shot_delay = TBX_SI_SHOT_DELAY;
+    s->n_enemies = TBX_SI_COLS * c->n_rows;
+    for (int i = 0; i < s->n_enemies; i++) {
+        tbx_si_enemy_t* e = &s->enemies[i];
+        e->row = i / TBX_SI_COLS; e->col = i % TBX_SI_COLS; e->id = i;
+        e->points = c->row_scores[e->row];
+    }
+    reset_formation(s);
+    s->ship_x = TBX_SI_SHIP_X0; s->ship_y = TBX_SI_SHIP_Y; s->ship_w = TBX_SI_SHIP_W; s->ship_h = TBX_SI_SHIP_H;
+    s->ship_speed = TBX_SI_SHIP_SPEED; s->ship_death_counter = -1;
+    s->ship_color = rgb3(TBX_SI_COL_SHIP);
+    s->ship_alive = 0; s->ship_death_hit_1 = 1;
+    s->ufo_x = TBX_SI_UFO_X0; s->ufo_y = TBX_SI_UFO_Y; s->ufo_appearance_counter = TBX_SI_UFO_PERIOD; s->ufo_death_counter = -1;
+    s->n_shields = c->n_shields;
+    for (int k = 0; k < c->n_shields; k++) {
+        s->shield_x[k] = c->shield_x[k]; s->shield_y[k] = c->shield_y[k];
+        s->shield_color[k] = rgb3(TBX_SI_COL_SHIELD);
+        for (int r = 0; r < TBX_SI_SHIELD_H; r++) s->shield_rows[k][r] = SHIELD_DEFAULT[r];
+    }
+}
+
+static int overlap(int ax, int ay, int aw, int ah, int bx, int by, int bw, int bh)
+{
+    return ax < bx + bw && bx < ax + aw && ay < by + bh && by < ay + ah;
+}
+
+static void move_laser(tbx_si_laser_t* l)
+{
+    switch (l->movement) {
+    case TBX_DIR_UP: l->y -= l->speed; break;
+    case TBX_DIR_DOWN: l->y += l->speed; break;
+    case TBX_DIR_LEFT: l->x -= l->speed; break;
+    default: l->x += l->speed; break;
+    }
+    l->t += 1;
+}
+
+/* returns 1 and erodes the shield when the laser rect covers a live shield pixel */
+static int shield_hit(tbx_si_state_t* s, const tbx_si_laser_t* l)
+{
+    for (int k = 0; k < s->n_shields; k++) {
+        int cx0 = l->x - s->shield_x[k], cx1 = l->x + l->w - s->shield_x[k];
+        int cy0 = l->y - s->shield_y[k], cy1 = l->y + l->h - s->shield_y[k];
+        if (cx0 < 0) cx0 = 0;
+        if (cy0 < 0) cy0 = 0;
+        if (cx1 > TBX_SI_SHIELD_W) cx1 = TBX_SI_SHIELD_W;
+        if (cy1 > TBX_SI_SHIELD_H) cy1 = TBX_SI_SHIELD_H;
+        if (cx0 >= cx1 || cy0 >= cy1) continue;
+        uint32_t colmask = ((1u << cx1) - 1u) & ~((1u << cx0) - 1u);
+        int hit = 0;
+        for (int r = cy0; r < cy1; r++) if (s->shield_rows[k][r] & colmask) hit = 1;
+        if (!hit) continue;
+        int dx0 = cx0 > 0 ? cx0 - 1 : 0, dx1 = cx1 < TBX_SI_SHIELD_W ? cx1 + 1 : TBX_SI_SHIELD_W;
+        uint32_t dmask = ((1u << dx1) - 1u) & ~((1u << dx0) - 1u);
+        for (int r = cy0; r < cy1; r++) s->shield_rows[k][r] &= (uint16_t)~dmask;
+        return 1;
+    }
+    return 0;
+}
+
+static int dec_counter(int32_t* c)   /* Some(n) -> Some(n-1) ... -> None; returns 1 when it just became None */
+{
+    if (*c < 0) return 0;
+    *c -= 1;
+    if (*c <= 0) { *c = -1; return 1; }
+    return 0;
+}
+
+void orc_si_step(const tbx_si_config_t* c, tbx_si_state_t* s, uint32_t buttons)
+{
+    /* A. "get ready" phase of a life */
+    if (s->life_display_timer > 0) {
+        s->life_display_timer -= 1;
+        if (s->life_display_timer == 0) { s->ship_alive = 1; s->ship_death_hit_1 = 1; s->ship_death_counter = -1; }
+        return;
+    }
+    /* B. ship explosion: the rest of the world is frozen */
+    if (s->ship_death_counter >= 0) {
+        if (dec_counter(&s->ship_death_counter)) {
+            s->lives -= 1;
+            s->ship_death_hit_1 = 1;
+            if (s->lives > 0) {
+                s->life_display_timer = TBX_SI_NEW_LIFE_TIME;
+                s->ship_x = TBX_SI_SHIP_X0;
+                s->n_enemy_lasers = 0; s->has_ship_laser = 0;
+                memset(&s->ship_laser, 0, sizeof s->ship_laser);
+                memset(s->enemy_lasers, 0, sizeof s->enemy_lasers);
+            }
+        } else {
+            s->ship_death_hit_1 = ((s->ship_death_counter >> 2) & 1) == 0;
+        }
+        return;
+    }
+    if (!s->ship_alive) return;
+
+    /* C. ship */
+    if (buttons & TBX_BTN_LEFT) s->ship_x -= s->ship_speed;
+    else if (buttons & TBX_BTN_RIGHT) s->ship_x += s->ship_speed;
+    if (s->ship_x < TBX_SI_SHIP_X_MIN) s->ship_x = TBX_SI_SHIP_X_MIN;
+    if (s->ship_x > TBX_SI_SHIP_X_MAX) s->ship_x = TBX_SI_SHIP_X_MAX;
+
+    /* D. fire */
+    if ((buttons & TBX_BTN_BUTTON1) && !s->has_ship_laser) {
+        tbx_si_laser_t* l = &s->ship_laser;
+        l->x = s->ship_x + s->ship_w / 2 - 1; l->y = s->ship_y - TBX_SI_LASER_H;
+        l->w = TBX_SI_LASER_W; l->h = TBX_SI_LASER_H; l->t = 0; l->movement = TBX_DIR_UP;
+        l->speed = TBX_SI_SHIP_LASER_V; l->color = rgb3(TBX_SI_COL_SHIP_LASER);
+        s->has_ship_laser = 1;
+    }
+
+    /* E. ship laser */
+    if (s->has_ship_laser) {
+        tbx_si_laser_t* l = &s->ship_laser;
+        move_laser(l);
+        if (l->y + l->h <= 0 || l->y >= TBX_SI_GROUND_Y || l->x + l->w <= 0 || l->x >= TBX_SI_W) s->has_ship_laser = 0;
+        if (s->has_ship_laser)
+            for (int i = 0; i < s->n_enemies; i++) {
+                tbx_si_enemy_t* e = &s->enemies[i];
+                if (e->alive && overlap(l->x, l->y, l->w, l->h, e->x, e->y, TBX_SI_ENEMY_W, TBX_SI_ENEMY_H)) {
+                    e->alive = 0; e->death_counter = TBX_SI_ENEMY_DEATH_T;
+                    s->score += e->points;
+                    s->has_ship_laser = 0;
+                    break;
+                }
+            }
+        if (s->has_ship_laser && s->ufo_appearance_counter == 0 && s->ufo_death_counter < 0 &&
+            overlap(l->x, l->y, l->w, l->h, s->ufo_x, s->ufo_y, TBX_SI_UFO_W, TBX_SI_UFO_H)) {
+            s->ufo_death_counter = TBX_SI_UFO_DEATH_T;
+            s->score += TBX_SI_UFO_BONUS;
+            s->has_ship_laser = 0;
+        }
+        if (s->has_ship_laser && shield_hit(s, l)) s->has_ship_laser = 0;
+        if (!s->has_ship_laser) memset(l, 0, sizeof *l);
+    }
+
+    /* F. enemy explosions */
+    for (int i = 0; i < s->n_enemies; i++) dec_counter(&s->enemies[i].death_counter);
+
+    /* G. formation march */
+    s->move_counter -= 1;
+    if (s->move_counter <= 0) {
+        int n_alive = 0;
+        for (int i = 0; i < s->n_enemies; i++) n_alive += s->enemies[i].alive != 0;
+        const int dx = s->move_dir == TBX_DIR_RIGHT ? TBX_SI_STEP_X : -TBX_SI_STEP_X;
+        int edge = 0;
+        for (int i = 0; i < s->n_enemies; i++) {
+            const tbx_si_enemy_t* e = &s->enemies[i];
+            if (!e->alive) continue;
+            if (dx > 0 ? e->x + TBX_SI_ENEMY_W + dx > TBX_SI_FIELD_X_MAX : e->x + dx < TBX_SI_FIELD_X_MIN) edge = 1;
+        }
+        for (int i = 0; i < s->n_enemies; i++) {
+            if (edge) s->enemies[i].y += TBX_SI_STEP_Y;
+            else s->enemies[i].x += dx;
+        }
+        if (edge) s->move_dir = s->move_dir == TBX_DIR_RIGHT ? TBX_DIR_LEFT : TBX_DIR_RIGHT;
+        s->visual_orientation = !s->visual_orientation;
+        s->move_counter = TBX_SI_MOVE_PERIOD_MIN +
+                          (s->n_enemies > 0 ? ((TBX_SI_MOVE_PERIOD - TBX_SI_MOVE_PERIOD_MIN) * n_alive) / s->n_enemies : 0);
+        for (int i = 0; i < s->n_enemies; i++)
+            if (s->enemies[i].alive && s->enemies[i].y + TBX_SI_ENEMY_H >= s->ship_y) s->lives = 0;   /* invasion */
+    }
+
+    /* H. enemy fire */
+    s->enemy_shot_delay -= 1;
+    if (s->enemy_shot_delay <= 0) {
+        s->enemy_shot_delay = TBX_SI_SHOT_DELAY;
+        uint64_t colmask = 0;
+        for (int i = 0; i < s->n_enemies; i++) if (s->enemies[i].alive) colmask |= 1ull << (s->enemies[i].col & 63);
+        if (colmask && s->n_enemy_lasers < TBX_SI_MAX_LASERS) {
+            uint64_t draw = orc_rng_next(s->rand);
+            double u = (double)(draw >> 11) * (1.0 / 9007199254740992.0);
+            int col = -1;
+            if (u < c->jitter) {
+                int k = (int)orc_rng_range(s->rand, (uint64_t)__builtin_popcountll(colmask));
+                for (int b = 0; b < 64; b++)
+                    if ((colmask >> b) & 1) { if (k == 0) { col = b; break; } k--; }
+            } else {
+                int best = 1 << 30;
+                const int target = s->ship_x + s->ship_w / 2;
+                for (int b = 0; b < 64; b++) {
+                    if (!((colmask >> b) & 1)) continue;
+                    /* the column's shooter: lowest on screen (max y), ties lowest index */
+                    int sh = -1;
+                    for (int i = 0; i < s->n_enemies; i++) {
+                        const tbx_si_enemy_t* e = &s->enemies[i];
+                        if (e->alive && (e->col & 63) == b && (sh < 0 || e->y > s->enemies[sh].y)) sh = i;
+                    }
+                    int d = s->enemies[sh].x + TBX_SI_ENEMY_W / 2 - target;
+                    if (d < 0) d = -d;
+                    if (d < best) { best = d; col = b; }
+                }
+            }
+            int sh = -1;
+            for (int i = 0; i < s->n_enemies; i++) {
+                const tbx_si_enemy_t* e = &s->enemies[i];
+                if (e->alive && (e->col & 63) == col && (sh < 0 || e->y > s->enemies[sh].y)) sh = i;
+            }
+            tbx_si_laser_t* l = &s->enemy_lasers[s->n_enemy_lasers++];
+            l->x = s->enemies[sh].x + TBX_SI_ENEMY_W / 2 - 1; l->y = s->enemies[sh].y + TBX_SI_ENEMY_H;
+            l->w = TBX_SI_LASER_W; l->h = TBX_SI_LASER_H; l->t = 0; l->movement = TBX_DIR_DOWN;
+            l->speed = TBX_SI_ENEMY_LASER_V; l->color = rgb3(TBX_SI_COL_ENEMY_LASER);
+        }
+    }
+
+    /* I. enemy lasers */
+    {
+        int keep = 0;
+        for (int i = 0; i < s->n_enemy_lasers; i++) {
+            tbx_si_laser_t l = s->enemy_lasers[i];
+            move_laser(&l);
+            int gone = 0;
+            if (l.y + l.h >= TBX_SI_GROUND_Y || l.y + l.h <= 0 || l.x + l.w <= 0 || l.x >= TBX_SI_W) gone = 1;
+            else if (shield_hit(s, &l)) gone = 1;
+            else if (s->ship_alive && overlap(l.x, l.y, l.w, l.h, s->ship_x, s->ship_y, s->ship_w, s->ship_h)) {
+                s->ship_alive = 0; s->ship_death_counter = TBX_SI_SHIP_DEATH_T; s->ship_death_hit_1 = 1;
+                gone = 1;
+            }
+            if (!gone) s->enemy_lasers[keep++] = l;
+        }
+        for (int i = keep; i < TBX_SI_MAX_LASERS; i++) memset(&s->enemy_lasers[i], 0, sizeof s->enemy_lasers[i]);
+        s->n_enemy_lasers = keep;
+    }
+
+    /* J. ufo */
+    if (s->ufo_death_counter >= 0) {
+        if (dec_counter(&s->ufo_death_counter)) { s->ufo_x = TBX_SI_UFO_X0; s->ufo_appearance_counter = TBX_SI_UFO_PERIOD; }
+    } else if (s->ufo_appearance_counter > 0) {
+        s->ufo_appearance_counter -= 1;
+    } else if (s->ufo_appearance_counter == 0) {
+        s->ufo_x += TBX_SI_UFO_STEP;
+        if (s->ufo_x >= TBX_SI_W) { s->ufo_x = TBX_SI_UFO_X0; s->ufo_appearance_counter = TBX_SI_UFO_PERIOD; }
+    }
+
+    /* K. wave cleared */
+    {
+        int busy = 0;
+        for (int i = 0; i < s->n_enemies; i++) busy |= s->enemies[i].alive || s->enemies[i].death_counter >= 0;
+        if (!busy && s->n_enemies > 0) { s->level += 1; reset_formation(s); }
+    }
+}
+
+/* ---------------------------------------------------------------- render */
+
+static const uint16_t DIGITS[10] = TBX_DIGIT_FONT;
+static const uint32_t SPR_A[TBX_SI_ENEMY_H] = TBX_SI_SPRITE_ENEMY_A, SPR_B[TBX_SI_ENEMY_H] = TBX_SI_SPRITE_ENEMY_B;
+static const uint32_t SPR_BOOM[TBX_SI_ENEMY_H] = TBX_SI_SPRITE_BOOM, SPR_SHIP[TBX_SI_SHIP_H] = TBX_SI_SPRITE_SHIP;
+static const uint32_t SPR_D1[TBX_SI_SHIP_H] = TBX_SI_SPRITE_SHIP_D1, SPR_D2[TBX_SI_SHIP_H] = TBX_SI_SPRITE_SHIP_D2;
+static const uint32_t SPR_UFO[TBX_SI_UFO_H] = TBX_SI_SPRITE_UFO;
+
+static void put(uint8_t* out, int ch, int x, int y, tbx_color_t c)
+{
+    if (x < 0 || y < 0 || x >= TBX_SI_W || y >= TBX_SI_H) return;
+    uint8_t* p = out + ((size_t)y * TBX_SI_W + x) * ch;
+    if (ch == 1) p[0] = (uint8_t)((77 * c.r + 150 * c.g + 29 * c.b + 128) >> 8);
+    else { p[0] = c.r; p[1] = c.g; p[2] = c.b; if (ch == 4) p[3] = 255; }
+}
+
+static void rect(uint8_t* out, int ch, int x0, int y0, int w, int h, tbx_color_t c)
+{
+    long xa = x0, xb = (long)x0 + w, ya = y0, yb = (long)y0 + h;   /* clip first: sizes come from state records */
+    if (xa < 0) xa = 0;
+    if (ya < 0) ya = 0;
+    if (xb > TBX_SI_W) xb = TBX_SI_W;
+    if (yb > TBX_SI_H) yb = TBX_SI_H;
+    for (long y = ya; y < yb; y++)
+        for (long x = xa; x < xb; x++) put(out, ch, (int)x, (int)y, c);
+}
+
+static void sprite(uint8_t* out, int ch, int x0, int y0, const uint32_t* rows, int w, int h, tbx_color_t c)
+{
+    for (int r = 0; r < h; r++)
+        for (int k = 0; k < w; k++)
+            if ((rows[r] >> k) & 1u) put(out, ch, x0 + k, y0 + r, c);
+}
+
+static void digit(uint8_t* out, int ch, int x0, int y0, int d, tbx_color_t c)
+{
+    for (int py = 0; py < 10; py++)
+        for (int px = 0; px < 6; px++)
+            if ((DIGITS[d] >> ((py / 2) * 3 + (px / 2))) & 1) put(out, ch, x0 + px, y0 + py, c);
+}
+
+void orc_si_render(const tbx_si_config_t* c, const tbx_si_state_t* s, uint8_t* out, int ch)
+{
+    (void)c;
+    rect(out, ch, 0, 0, TBX_SI_W, TBX_SI_H, rgb3(0, 0, 0));
+    rect(out, ch, 0, TBX_SI_GROUND_Y, TBX_SI_W, 1, rgb3(TBX_SI_COL_GROUND));
+    for (int k = 0; k < s->n_shields; k++)
+        for (int r = 0; r < TBX_SI_SHIELD_H; r++)
+            for (int x = 0; x < TBX_SI_SHIELD_W; x++)
+                if ((s->shield_rows[k][r] >> x) & 1) put(out, ch, s->shield_x[k] + x, s->shield_y[k] + r, s->shield_color[k]);
+    for (int i = 0; i < s->n_enemies; i++) {
+        const tbx_si_enemy_t* e = &s->enemies[i];
+        if (e->alive) sprite(out, ch, e->x, e->y, s->visual_orientation ? SPR_A : SPR_B, TBX_SI_ENEMY_W, TBX_SI_ENEMY_H, rgb3(TBX_SI_COL_ENEMY));
+        else if (e->death_counter >= 0) sprite(out, ch, e->x, e->y, SPR_BOOM, TBX_SI_ENEMY_W, TBX_SI_ENEMY_H, rgb3(TBX_SI_COL_ENEMY));
+    }
+    if (s->ufo_appearance_counter == 0 || s->ufo_death_counter >= 0)
+        sprite(out, ch, s->ufo_x, s->ufo_y, SPR_UFO, TBX_SI_UFO_W, TBX_SI_UFO_H, rgb3(TBX_SI_COL_UFO));
+    if (s->ship_alive) sprite(out, ch, s->ship_x, s->ship_y, SPR_SHIP, 16, TBX_SI_SHIP_H, s->ship_color);
+    else if (s->ship_death_counter >= 0)
+        sprite(out, ch, s->ship_x, s->ship_y, s->ship_death_hit_1 ? SPR_D1 : SPR_D2, 16, TBX_SI_SHIP_H, s->ship_color);
+    if (s->has_ship_laser) rect(out, ch, s->ship_laser.x, s->ship_laser.y, s->ship_laser.w, s->ship_laser.h, s->ship_laser.color);
+    for (int i = 0; i < s->n_enemy_lasers; i++) {
+        const tbx_si_laser_t* l = &s->enemy_lasers[i];
+        rect(out, ch, l->x, l->y, l->w, l->h, l->color);
+    }
+    int sc = s->score; if (sc < 0) sc = 0; sc %= 100000;
+    int div = 10000;
+    for (int i = 0; i < 5; i++) { digit(out, ch, 36 + 8 * i, 2, (sc / div) % 10, rgb3(TBX_SI_COL_HUD)); div /= 10; }
+    int lv = s->lives; if (lv < 0) lv = 0; if (lv > 9) lv = 9;
+    digit(out, ch, 148, 2, lv, rgb3(TBX_SI_COL_HUD));
+    int le = s->level; if (le < 0) le = 0;
+    digit(out, ch, 196, 2, le % 10, rgb3(TBX_SI_COL_HUD));
+}

@@ -32,7 +32,7 @@ def _assert_states_equal(g, o, envs):
             raise AssertionError("env %d differs: %r" % (i, diff))
 
 
-@pytest.mark.parametrize("game", ["breakout"])
+@pytest.mark.parametrize("game", ["breakout", "space_invaders"])
 def test_rollout_parity(game, hip_lib, oracle_lib):
     """4096 envs, seeds 1234+i, 1500 random-action frames with auto-reset: outputs equal every step,
     full state records equal at checkpoints and at the end."""
@@ -58,7 +58,7 @@ def test_rollout_parity(game, hip_lib, oracle_lib):
         assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("game", ["breakout"])
+@pytest.mark.parametrize("game", ["breakout", "space_invaders"])
 @pytest.mark.parametrize("channels", [1, 3, 4])
 def test_frame_parity(game, channels, hip_lib, oracle_lib):
     n = 256
@@ -76,7 +76,7 @@ def test_frame_parity(game, channels, hip_lib, oracle_lib):
     assert np.array_equal(g.render_env(3, channels), o.render_env(3, channels))
 
 
-@pytest.mark.parametrize("game", ["breakout"])
+@pytest.mark.parametrize("game", ["breakout", "space_invaders"])
 def test_synthetic_device_path(game, hip_lib, oracle_lib):
     """tbx_step_synthetic (actions generated in-kernel) == host-generated actions with the same rule."""
     n = 1024

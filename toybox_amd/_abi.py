@@ -84,8 +84,54 @@ class BreakoutState(C.Structure):
     ]
 
 
-STATE_TYPES = {GAME_BREAKOUT: BreakoutState}
-CONFIG_TYPES = {GAME_BREAKOUT: BreakoutConfig}
+SI_COLS, SI_MAX_ROWS, SI_MAX_ENEMIES, SI_MAX_SHIELDS, SI_SHIELD_W, SI_SHIELD_H, SI_MAX_LASERS = 6, 10, 64, 3, 16, 18, 8
+DIR_NAMES = ["Up", "Down", "Left", "Right"]       # interventions/core.py:125-135
+
+
+class SIConfig(C.Structure):
+    _fields_ = [
+        ("rand", C.c_uint64 * 2),
+        ("jitter", C.c_double),
+        ("start_lives", C.c_int32), ("n_rows", C.c_int32), ("n_shields", C.c_int32), ("enemy_protocol", C.c_int32),
+        ("row_scores", C.c_int32 * SI_MAX_ROWS),
+        ("shield_x", C.c_int32 * SI_MAX_SHIELDS), ("shield_y", C.c_int32 * SI_MAX_SHIELDS),
+    ]
+
+
+class SILaser(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("t", C.c_int32),
+                ("movement", C.c_int32), ("speed", C.c_int32), ("color", Color)]
+
+
+class SIEnemy(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("row", C.c_int32), ("col", C.c_int32), ("id", C.c_int32),
+                ("points", C.c_int32), ("death_counter", C.c_int32), ("alive", C.c_uint8), ("_pad", C.c_uint8 * 3)]
+
+
+class SIState(C.Structure):
+    _fields_ = [
+        ("rand", C.c_uint64 * 2),
+        ("score", C.c_int32), ("lives", C.c_int32), ("level", C.c_int32),
+        ("life_display_timer", C.c_int32), ("enemy_shot_delay", C.c_int32),
+        ("n_enemies", C.c_int32), ("n_enemy_lasers", C.c_int32), ("has_ship_laser", C.c_int32),
+        ("ship_x", C.c_int32), ("ship_y", C.c_int32), ("ship_w", C.c_int32), ("ship_h", C.c_int32), ("ship_speed", C.c_int32),
+        ("ship_death_counter", C.c_int32), ("ship_color", Color),
+        ("ship_alive", C.c_uint8), ("ship_death_hit_1", C.c_uint8), ("_pad0", C.c_uint8 * 2),
+        ("ufo_x", C.c_int32), ("ufo_y", C.c_int32), ("ufo_appearance_counter", C.c_int32), ("ufo_death_counter", C.c_int32),
+        ("move_counter", C.c_int32), ("move_dir", C.c_int32),
+        ("visual_orientation", C.c_uint8), ("_pad1", C.c_uint8 * 3),
+        ("n_shields", C.c_int32),
+        ("shield_x", C.c_int32 * SI_MAX_SHIELDS), ("shield_y", C.c_int32 * SI_MAX_SHIELDS),
+        ("shield_color", Color * SI_MAX_SHIELDS),
+        ("shield_rows", (C.c_uint16 * SI_SHIELD_H) * SI_MAX_SHIELDS),
+        ("ship_laser", SILaser),
+        ("enemy_lasers", SILaser * SI_MAX_LASERS),
+        ("enemies", SIEnemy * SI_MAX_ENEMIES),
+    ]
+
+
+STATE_TYPES = {GAME_BREAKOUT: BreakoutState, GAME_SPACE_INVADERS: SIState}
+CONFIG_TYPES = {GAME_BREAKOUT: BreakoutConfig, GAME_SPACE_INVADERS: SIConfig}
 
 _p = C.POINTER
 _vp, _i, _u32, _u64, _sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_size_t

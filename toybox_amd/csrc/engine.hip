@@ -62,6 +62,20 @@ void breakout_default_config(tbx_breakout_config_t* c)
     c->ball_color = tbx_color_t{200, 72, 72, 255};
 }
 
+void si_default_config(tbx_si_config_t* c)
+{
+    memset(c, 0, sizeof *c);
+    tbx_seed_state(17, c->rand[0], c->rand[1]);
+    c->jitter = 0.5;
+    c->start_lives = 3;
+    c->n_rows = 6;
+    c->n_shields = 3;
+    c->enemy_protocol = 0;
+    const int sc[6] = {30, 30, 20, 20, 10, 10}, sx[3] = {84, 148, 212};
+    for (int i = 0; i < 6; i++) c->row_scores[i] = sc[i];
+    for (int i = 0; i < 3; i++) { c->shield_x[i] = sx[i]; c->shield_y[i] = 157; }
+}
+
 __global__ void seed_kernel(uint64_t* sim_rng, int n, int env, uint32_t seed)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,6 +131,7 @@ int tbx_frame_dims(int game, int* h, int* w)
     if (!h || !w) return TBX_E_INVALID;
     switch (game) {
     case TBX_GAME_BREAKOUT: *h = TBX_BRK_H; *w = TBX_BRK_W; return TBX_OK;
+    case TBX_GAME_SPACE_INVADERS: *h = TBX_SI_H; *w = TBX_SI_W; return TBX_OK;
     default: return TBX_E_INVALID;
     }
 }
@@ -139,6 +154,7 @@ size_t tbx_state_size(int game)
 {
     switch (game) {
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_state_t);
+    case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_state_t);
     default: return 0;
     }
 }
@@ -147,6 +163,7 @@ size_t tbx_config_size(int game)
 {
     switch (game) {
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_config_t);
+    case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_config_t);
     default: return 0;
     }
 }
@@ -197,6 +214,7 @@ int tbx_create(int game, int n_envs, int device, const void* config_pod, size_t 
     };
     switch (game) {
     case TBX_GAME_BREAKOUT: e->ops = tbx_make_breakout_ops(); break;
+    case TBX_GAME_SPACE_INVADERS: e->ops = tbx_make_si_ops(); break;
     default: e->err = "unknown game id"; return bail(TBX_E_INVALID);
     }
     const size_t N = (size_t)n_envs;
@@ -232,6 +250,7 @@ int tbx_create(int game, int n_envs, int device, const void* config_pod, size_t 
     } else {
         switch (game) {
         case TBX_GAME_BREAKOUT: breakout_default_config((tbx_breakout_config_t*)cfg.data()); break;
+        case TBX_GAME_SPACE_INVADERS: si_default_config((tbx_si_config_t*)cfg.data()); break;
         }
     }
     rc = e->ops->init(e, cfg.data(), cfg.size());

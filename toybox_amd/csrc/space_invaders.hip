@@ -1,0 +1,946 @@
+// space_invaders.hip -- SpaceInvaders on gfx950: one 64-lane wavefront per env.
+//
+// Replaces the per-env Rust transition + rasteriser behind ctoybox.Toybox.apply_ale_action /
+// get_state (call sites: /root/reference/toybox/envs/atari/base.py:126,109) for the game the
+// reference registers as SpaceInvadersToyboxNoFrameskip-v4 (toybox/__init__.py:20-24).  Rules:
+// DESIGN.md "SpaceInvaders"; independently restated in scalar C by the CPU checker under oracle/
+// and compared bit for bit by tests/test_gpu_parity.py.  All arithmetic is int32 except the
+// jitter test (one binary64 compare).
+//
+// Layout in HBM: scalar fields struct-of-arrays over envs ([field][N] int32); the per-entity
+// tables are env-major so that the 64 lanes of an env's wave read them coalesced:
+//   enemies  [N][7][64] int32   lane = enemy index (x y row col id points status)
+//   shields  [N][64]    uint32  lane = shield*18 + row (16-bit pixel mask)
+//   lasers   [N][8][16] int32   lane (0..8) = laser slot (8 = the ship's laser), field-major
+//
+// Lane roles in the step: lane = enemy for the march / hit tests / shooter election (ballots and
+// wave reductions), lane = shield row for laser erosion, lanes 0..8 = laser slots.
+
+#include "tbx_common.hpp"
+#include "raster.hpp"
+#include "../../include/toybox_amd_spec.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+enum SiField {
+    F_SCORE, F_LIVES, F_LEVEL, F_LIFE_TIMER, F_SHOT_DELAY, F_N_ENEMIES, F_N_LASERS, F_HAS_SHIP_LASER,
+    F_SHIP_X, F_SHIP_Y, F_SHIP_W, F_SHIP_H, F_SHIP_SPEED, F_SHIP_DC, F_SHIP_COLOR, F_SHIP_FLAGS,
+    F_UFO_X, F_UFO_Y, F_UFO_APP, F_UFO_DC, F_MOVE_COUNTER, F_MOVE_DIR, F_ORIENT, F_N_SHIELDS,
+    F_SHIELD_X0, F_SHIELD_X1, F_SHIELD_X2, F_SHIELD_Y0, F_SHIELD_Y1, F_SHIELD_Y2,
+    F_SHIELD_C0, F_SHIELD_C1, F_SHIELD_C2, NF
+};
+enum { EF_X, EF_Y, EF_ROW, EF_COL, EF_ID, EF_POINTS, EF_STATUS, NEF };   // status: bit0 alive, bits 8.. death_counter+1
+enum { LF_X, LF_Y, LF_W, LF_H, LF_T, LF_MOV, LF_SPEED, LF_COLOR, NLF };
+constexpr int SHIP_SLOT = TBX_SI_MAX_LASERS;   // lane 8 carries the ship's laser
+
+struct SiDev {
+    int n;
+    uint64_t* sim_rng; int32_t* prev_score; int32_t* reward; uint8_t* done; int32_t* lives_out; int32_t* score_out;
+    uint64_t* packed; uint32_t* err_flag;
+    uint64_t* rng;        // [2][N]
+    int32_t* sc;          // [NF][N]
+    int32_t* enemies;     // [N][NEF][64]
+    uint32_t* shields;    // [N][64]
+    int32_t* lasers;      // [N][NLF][16]
+};
+
+struct SiCfg {
+    double jitter;
+    int32_t start_lives, n_rows, n_shields;
+    int32_t row_scores[TBX_SI_MAX_ROWS];
+    int32_t shield_x[TBX_SI_MAX_SHIELDS], shield_y[TBX_SI_MAX_SHIELDS];
+};
+
+__constant__ uint16_t SI_SHIELD_DEFAULT[TBX_SI_SHIELD_H] = {
+    0x0FF0, 0x0FF0, 0x3FFC, 0x3FFC, 0x3FFC, 0x3FFC, 0x3FFC, 0x3FFC, 0x3FFC, 0x3FFC,
+    0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xF00F, 0xF00F};
+
+__host__ __device__ constexpr uint32_t rgb_u32(int r, int g, int b) { return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | 0xFF000000u; }
+
+// wave-uniform scalars + per-lane entity slices of one env
+struct SiRegs {
+    Rng rng;
+    int32_t f[NF];
+    // lane = enemy
+    int32_t ex, ey, erow, ecol, eid, epoints, estatus;
+    // lane = shield row
+    uint32_t srow;
+    // lanes 0..8 = laser slots
+    int32_t lf[NLF];
+};
+
+__device__ __forceinline__ void si_load(const SiDev& d, int env, int lane, SiRegs& s)
+{
+    const size_t N = (size_t)d.n;
+    s.rng.s0 = d.rng[env];
+    s.rng.s1 = d.rng[N + env];
+#pragma unroll
+    for (int i = 0; i < NF; i++) s.f[i] = d.sc[(size_t)i * N + env];
+    const int32_t* e = d.enemies + (size_t)env * NEF * 64;
+    s.ex = e[EF_X * 64 + lane]; s.ey = e[EF_Y * 64 + lane]; s.erow = e[EF_ROW * 64 + lane]; s.ecol = e[EF_COL * 64 + lane];
+    s.eid = e[EF_ID * 64 + lane]; s.epoints = e[EF_POINTS * 64 + lane]; s.estatus = e[EF_STATUS * 64 + lane];
+    s.srow = d.shields[(size_t)env * 64 + lane];
+    const int32_t* l = d.lasers + (size_t)env * NLF * 16;
+#pragma unroll
+    for (int i = 0; i < NLF; i++) s.lf[i] = l[i * 16 + (lane & 15)];
+}
+
+__device__ __forceinline__ void si_store(const SiDev& d, int env, int lane, const SiRegs& s)
+{
+    const size_t N = (size_t)d.n;
+    if (lane == 0) {
+        d.rng[env] = s.rng.s0;
+        d.rng[N + env] = s.rng.s1;
+#pragma unroll
+        for (int i = 0; i < NF; i++) d.sc[(size_t)i * N + env] = s.f[i];
+    }
+    int32_t* e = d.enemies + (size_t)env * NEF * 64;
+    e[EF_X * 64 + lane] = s.ex; e[EF_Y * 64 + lane] = s.ey; e[EF_ROW * 64 + lane] = s.erow; e[EF_COL * 64 + lane] = s.ecol;
+    e[EF_ID * 64 + lane] = s.eid; e[EF_POINTS * 64 + lane] = s.epoints; e[EF_STATUS * 64 + lane] = s.estatus;
+    d.shields[(size_t)env * 64 + lane] = s.srow;
+    if (lane < 16) {
+        int32_t* l = d.lasers + (size_t)env * NLF * 16;
+#pragma unroll
+        for (int i = 0; i < NLF; i++) l[i * 16 + lane] = s.lf[i];
+    }
+}
+
+__device__ __forceinline__ bool e_alive(const SiRegs& s) { return (s.estatus & 1) != 0; }
+__device__ __forceinline__ int e_dc(const SiRegs& s) { return (s.estatus >> 8) - 1; }
+__device__ __forceinline__ int32_t mk_status(bool alive, int dc) { return (alive ? 1 : 0) | ((dc + 1) << 8); }
+
+__device__ __forceinline__ void si_reset_formation(SiRegs& s, int lane)
+{
+    if (lane < s.f[F_N_ENEMIES]) {
+        s.ex = TBX_SI_ENEMY_X0 + TBX_SI_ENEMY_DX * s.ecol;
+        s.ey = TBX_SI_ENEMY_Y0 + TBX_SI_ENEMY_DY * s.erow;
+        s.estatus = mk_status(true, -1);
+    }
+    s.f[F_MOVE_COUNTER] = TBX_SI_MOVE_PERIOD;
+    s.f[F_MOVE_DIR] = TBX_DIR_RIGHT;
+    s.f[F_ORIENT] = 1;
+    s.f[F_N_LASERS] = 0;
+    s.f[F_HAS_SHIP_LASER] = 0;
+#pragma unroll
+    for (int i = 0; i < NLF; i++) s.lf[i] = 0;
+}
+
+__device__ __forceinline__ void si_new_game(const SiCfg& c, int lane, Rng& sim, SiRegs& s)
+{
+    s.rng = sim.child();
+#pragma unroll
+    for (int i = 0; i < NF; i++) s.f[i] = 0;
+    s.f[F_LIVES] = c.start_lives;
+    s.f[F_LEVEL] = 1;
+    s.f[F_LIFE_TIMER] = TBX_SI_NEW_LIFE_TIME;
+    s.f[F_SHOT_DELAY] = TBX_SI_SHOT_DELAY;
+    const int ne = TBX_SI_COLS * c.n_rows;
+    s.f[F_N_ENEMIES] = ne;
+    s.ex = s.ey = s.erow = s.ecol = s.eid = s.epoints = 0;
+    s.estatus = 0;   // slots beyond n_enemies are all-zero records
+    if (lane < ne) {
+        s.erow = lane / TBX_SI_COLS; s.ecol = lane % TBX_SI_COLS; s.eid = lane;
+        s.epoints = c.row_scores[s.erow];
+    }
+    si_reset_formation(s, lane);
+    if (lane >= ne) s.estatus = 0;
+    s.f[F_SHIP_X] = TBX_SI_SHIP_X0; s.f[F_SHIP_Y] = TBX_SI_SHIP_Y; s.f[F_SHIP_W] = TBX_SI_SHIP_W; s.f[F_SHIP_H] = TBX_SI_SHIP_H;
+    s.f[F_SHIP_SPEED] = TBX_SI_SHIP_SPEED; s.f[F_SHIP_DC] = -1; s.f[F_SHIP_COLOR] = (int32_t)rgb_u32(TBX_SI_COL_SHIP);
+    s.f[F_SHIP_FLAGS] = 2;   // alive = 0, death_hit_1 = 1
+    s.f[F_UFO_X] = TBX_SI_UFO_X0; s.f[F_UFO_Y] = TBX_SI_UFO_Y; s.f[F_UFO_APP] = TBX_SI_UFO_PERIOD; s.f[F_UFO_DC] = -1;
+    s.f[F_N_SHIELDS] = c.n_shields;
+#pragma unroll
+    for (int k = 0; k < TBX_SI_MAX_SHIELDS; k++) {
+        const bool on = k < c.n_shields;
+        s.f[F_SHIELD_X0 + k] = on ? c.shield_x[k] : 0;
+        s.f[F_SHIELD_Y0 + k] = on ? c.shield_y[k] : 0;
+        s.f[F_SHIELD_C0 + k] = on ? (int32_t)rgb_u32(TBX_SI_COL_SHIELD) : 0;
+    }
+    {
+        const int k = lane / TBX_SI_SHIELD_H, r = lane - k * TBX_SI_SHIELD_H;
+        s.srow = (lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H && k < c.n_shields) ? SI_SHIELD_DEFAULT[r] : 0u;
+    }
+}
+
+__device__ __forceinline__ bool overlap(int ax, int ay, int aw, int ah, int bx, int by, int bw, int bh)
+{
+    return ax < bx + bw && bx < ax + aw && ay < by + bh && by < ay + ah;
+}
+
+struct Laser { int32_t x, y, w, h, t, mov, speed, color; };
+
+__device__ __forceinline__ Laser get_laser(const SiRegs& s, int slot)
+{
+    Laser l;
+    l.x = __builtin_amdgcn_readlane(s.lf[LF_X], slot); l.y = __builtin_amdgcn_readlane(s.lf[LF_Y], slot);
+    l.w = __builtin_amdgcn_readlane(s.lf[LF_W], slot); l.h = __builtin_amdgcn_readlane(s.lf[LF_H], slot);
+    l.t = __builtin_amdgcn_readlane(s.lf[LF_T], slot); l.mov = __builtin_amdgcn_readlane(s.lf[LF_MOV], slot);
+    l.speed = __builtin_amdgcn_readlane(s.lf[LF_SPEED], slot); l.color = __builtin_amdgcn_readlane(s.lf[LF_COLOR], slot);
+    return l;
+}
+
+__device__ __forceinline__ void put_laser(SiRegs& s, int lane, int slot, const Laser& l)
+{
+    if (lane == slot) {
+        s.lf[LF_X] = l.x; s.lf[LF_Y] = l.y; s.lf[LF_W] = l.w; s.lf[LF_H] = l.h;
+        s.lf[LF_T] = l.t; s.lf[LF_MOV] = l.mov; s.lf[LF_SPEED] = l.speed; s.lf[LF_COLOR] = l.color;
+    }
+}
+
+__device__ __forceinline__ void clear_laser(SiRegs& s, int lane, int slot)
+{
+    if (lane == slot) {
+#pragma unroll
+        for (int i = 0; i < NLF; i++) s.lf[i] = 0;
+    }
+}
+
+__device__ __forceinline__ void move_laser(Laser& l)
+{
+    if (l.mov == TBX_DIR_UP) l.y -= l.speed;
+    else if (l.mov == TBX_DIR_DOWN) l.y += l.speed;
+    else if (l.mov == TBX_DIR_LEFT) l.x -= l.speed;
+    else l.x += l.speed;
+    l.t += 1;
+}
+
+// lane = shield row.  Returns true (wave-uniform) and erodes the first shield, in index order,
+// that has a live pixel under the laser rect.
+__device__ __forceinline__ bool shield_hit(SiRegs& s, int lane, const Laser& l)
+{
+    const int k = lane / TBX_SI_SHIELD_H, r = lane - k * TBX_SI_SHIELD_H;
+    const bool valid = lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H && k < s.f[F_N_SHIELDS];
+    const int sx = k == 0 ? s.f[F_SHIELD_X0] : k == 1 ? s.f[F_SHIELD_X1] : s.f[F_SHIELD_X2];
+    const int sy = k == 0 ? s.f[F_SHIELD_Y0] : k == 1 ? s.f[F_SHIELD_Y1] : s.f[F_SHIELD_Y2];
+    int cx0 = l.x - sx, cx1 = l.x + l.w - sx, cy0 = l.y - sy, cy1 = l.y + l.h - sy;
+    if (cx0 < 0) cx0 = 0;
+    if (cy0 < 0) cy0 = 0;
+    if (cx1 > TBX_SI_SHIELD_W) cx1 = TBX_SI_SHIELD_W;
+    if (cy1 > TBX_SI_SHIELD_H) cy1 = TBX_SI_SHIELD_H;
+    const bool inside = valid && cx0 < cx1 && r >= cy0 && r < cy1;
+    uint32_t colmask = 0, dmask = 0;
+    if (inside) {
+        colmask = ((1u << cx1) - 1u) & ~((1u << cx0) - 1u);
+        const int dx0 = cx0 > 0 ? cx0 - 1 : 0, dx1 = cx1 < TBX_SI_SHIELD_W ? cx1 + 1 : TBX_SI_SHIELD_W;
+        dmask = ((1u << dx1) - 1u) & ~((1u << dx0) - 1u);
+    }
+    const uint64_t hits = __ballot(inside && (s.srow & colmask) != 0);
+    if (!hits) return false;
+    const int kh = (int)__builtin_ctzll(hits) / TBX_SI_SHIELD_H;   // first shield in index order
+    if (inside && k == kh) s.srow &= ~dmask;
+    return true;
+}
+
+__device__ __forceinline__ bool dec_counter(int32_t& c)
+{
+    if (c < 0) return false;
+    c -= 1;
+    if (c <= 0) { c = -1; return true; }
+    return false;
+}
+
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)v, o), hi = __shfl_xor((uint32_t)(v >> 32), o);
+        v |= (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    return v;
+}
+
+__device__ __forceinline__ int64_t wave_max64(int64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)v, o), hi = __shfl_xor((uint32_t)((uint64_t)v >> 32), o);
+        int64_t w = (int64_t)((uint64_t)lo | ((uint64_t)hi << 32));
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// lowest-on-screen alive enemy of column `col` (max y, ties lowest index); -1 if none
+__device__ __forceinline__ int column_shooter(const SiRegs& s, int lane, int col)
+{
+    const bool cand = lane < s.f[F_N_ENEMIES] && e_alive(s) && (s.ecol & 63) == col;
+    const int64_t key = cand ? ((int64_t)s.ey * 256 + (int64_t)(63 - lane)) : INT64_MIN;
+    const int64_t best = wave_max64(key);
+    if (best == INT64_MIN) return -1;
+    return 63 - (int)(best & 0xFF);
+}
+
+__device__ __forceinline__ void si_step(const SiCfg& c, int lane, uint32_t buttons, SiRegs& s)
+{
+    int32_t* f = s.f;
+    // A. "get ready" phase of a life
+    if (f[F_LIFE_TIMER] > 0) {
+        f[F_LIFE_TIMER] -= 1;
+        if (f[F_LIFE_TIMER] == 0) { f[F_SHIP_FLAGS] = 3; f[F_SHIP_DC] = -1; }
+        return;
+    }
+    // B. ship explosion: the rest of the world is frozen
+    if (f[F_SHIP_DC] >= 0) {
+        if (dec_counter(f[F_SHIP_DC])) {
+            f[F_LIVES] -= 1;
+            f[F_SHIP_FLAGS] |= 2;
+            if (f[F_LIVES] > 0) {
+                f[F_LIFE_TIMER] = TBX_SI_NEW_LIFE_TIME;
+                f[F_SHIP_X] = TBX_SI_SHIP_X0;
+                f[F_N_LASERS] = 0; f[F_HAS_SHIP_LASER] = 0;
+#pragma unroll
+                for (int i = 0; i < NLF; i++) s.lf[i] = 0;
+            }
+        } else {
+            const bool h1 = ((f[F_SHIP_DC] >> 2) & 1) == 0;
+            f[F_SHIP_FLAGS] = (f[F_SHIP_FLAGS] & 1) | (h1 ? 2 : 0);
+        }
+        return;
+    }
+    if (!(f[F_SHIP_FLAGS] & 1)) return;
+
+    const int ne = f[F_N_ENEMIES];
+    // C. ship
+    if (buttons & TBX_BTN_LEFT) f[F_SHIP_X] -= f[F_SHIP_SPEED];
+    else if (buttons & TBX_BTN_RIGHT) f[F_SHIP_X] += f[F_SHIP_SPEED];
+    if (f[F_SHIP_X] < TBX_SI_SHIP_X_MIN) f[F_SHIP_X] = TBX_SI_SHIP_X_MIN;
+    if (f[F_SHIP_X] > TBX_SI_SHIP_X_MAX) f[F_SHIP_X] = TBX_SI_SHIP_X_MAX;
+
+    // D. fire
+    if ((buttons & TBX_BTN_BUTTON1) && !f[F_HAS_SHIP_LASER]) {
+        Laser l;
+        l.x = f[F_SHIP_X] + f[F_SHIP_W] / 2 - 1; l.y = f[F_SHIP_Y] - TBX_SI_LASER_H;
+        l.w = TBX_SI_LASER_W; l.h = TBX_SI_LASER_H; l.t = 0; l.mov = TBX_DIR_UP;
+        l.speed = TBX_SI_SHIP_LASER_V; l.color = (int32_t)rgb_u32(TBX_SI_COL_SHIP_LASER);
+        put_laser(s, lane, SHIP_SLOT, l);
+        f[F_HAS_SHIP_LASER] = 1;
+    }
+
+    // E. ship laser
+    if (f[F_HAS_SHIP_LASER]) {
+        Laser l = get_laser(s, SHIP_SLOT);
+        move_laser(l);
+        bool has = true;
+        if (l.y + l.h <= 0 || l.y >= TBX_SI_GROUND_Y || l.x + l.w <= 0 || l.x >= TBX_SI_W) has = false;
+        if (has) {
+            const uint64_t m = __ballot(lane < ne && e_alive(s) && overlap(l.x, l.y, l.w, l.h, s.ex, s.ey, TBX_SI_ENEMY_W, TBX_SI_ENEMY_H));
+            if (m) {
+                const int idx = (int)__builtin_ctzll(m);
+                f[F_SCORE] += __builtin_amdgcn_readlane(s.epoints, idx);
+                if (lane == idx) s.estatus = mk_status(false, TBX_SI_ENEMY_DEATH_T);
+                has = false;
+            }
+        }
+        if (has && f[F_UFO_APP] == 0 && f[F_UFO_DC] < 0 &&
+            overlap(l.x, l.y, l.w, l.h, f[F_UFO_X], f[F_UFO_Y], TBX_SI_UFO_W, TBX_SI_UFO_H)) {
+            f[F_UFO_DC] = TBX_SI_UFO_DEATH_T;
+            f[F_SCORE] += TBX_SI_UFO_BONUS;
+            has = false;
+        }
+        if (has && shield_hit(s, lane, l)) has = false;
+        if (has) put_laser(s, lane, SHIP_SLOT, l);
+        else { clear_laser(s, lane, SHIP_SLOT); f[F_HAS_SHIP_LASER] = 0; }
+    }
+
+    // F. enemy explosions
+    if (lane < ne) {
+        int dc = e_dc(s);
+        dec_counter(dc);
+        s.estatus = mk_status(e_alive(s), dc);
+    }
+
+    // G. formation march
+    f[F_MOVE_COUNTER] -= 1;
+    if (f[F_MOVE_COUNTER] <= 0) {
+        const bool alive = lane < ne && e_alive(s);
+        const int n_alive = __popcll(__ballot(alive));
+        const int dx = f[F_MOVE_DIR] == TBX_DIR_RIGHT ? TBX_SI_STEP_X : -TBX_SI_STEP_X;
+        const bool at_edge = alive && (dx > 0 ? s.ex + TBX_SI_ENEMY_W + dx > TBX_SI_FIELD_X_MAX : s.ex + dx < TBX_SI_FIELD_X_MIN);
+        const bool edge = __ballot(at_edge) != 0;
+        if (lane < ne) {
+            if (edge) s.ey += TBX_SI_STEP_Y;
+            else s.ex += dx;
+        }
+        if (edge) f[F_MOVE_DIR] = f[F_MOVE_DIR] == TBX_DIR_RIGHT ? TBX_DIR_LEFT : TBX_DIR_RIGHT;
+        f[F_ORIENT] = f[F_ORIENT] ? 0 : 1;
+        f[F_MOVE_COUNTER] = TBX_SI_MOVE_PERIOD_MIN + (ne > 0 ? ((TBX_SI_MOVE_PERIOD - TBX_SI_MOVE_PERIOD_MIN) * n_alive) / ne : 0);
+        if (__ballot(alive && s.ey + TBX_SI_ENEMY_H >= f[F_SHIP_Y])) f[F_LIVES] = 0;   // invasion
+    }
+
+    // H. enemy fire
+    f[F_SHOT_DELAY] -= 1;
+    if (f[F_SHOT_DELAY] <= 0) {
+        f[F_SHOT_DELAY] = TBX_SI_SHOT_DELAY;
+        const bool alive = lane < ne && e_alive(s);
+        const uint64_t colmask = wave_or64(alive ? 1ull << (s.ecol & 63) : 0ull);
+        if (colmask && f[F_N_LASERS] < TBX_SI_MAX_LASERS) {
+            const uint64_t draw = s.rng.next();
+            const double u = (double)(draw >> 11) * (1.0 / 9007199254740992.0);
+            int col = -1;
+            if (u < c.jitter) {
+                int k = (int)s.rng.range((uint64_t)__popcll(colmask));
+                uint64_t m = colmask;
+                while (k > 0) { m &= m - 1; k--; }
+                col = (int)__builtin_ctzll(m);
+            } else {
+                int best = 1 << 30;
+                const int target = f[F_SHIP_X] + f[F_SHIP_W] / 2;
+                uint64_t m = colmask;
+                while (m) {
+                    const int b = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const int sh = column_shooter(s, lane, b);
+                    int dd = __builtin_amdgcn_readlane(s.ex, sh) + TBX_SI_ENEMY_W / 2 - target;
+                    if (dd < 0) dd = -dd;
+                    if (dd < best) { best = dd; col = b; }
+                }
+            }
+            const int sh = column_shooter(s, lane, col);
+            Laser l;
+            l.x = __builtin_amdgcn_readlane(s.ex, sh) + TBX_SI_ENEMY_W / 2 - 1;
+            l.y = __builtin_amdgcn_readlane(s.ey, sh) + TBX_SI_ENEMY_H;
+            l.w = TBX_SI_LASER_W; l.h = TBX_SI_LASER_H; l.t = 0; l.mov = TBX_DIR_DOWN;
+            l.speed = TBX_SI_ENEMY_LASER_V; l.color = (int32_t)rgb_u32(TBX_SI_COL_ENEMY_LASER);
+            put_laser(s, lane, f[F_N_LASERS], l);
+            f[F_N_LASERS] += 1;
+        }
+    }
+
+    // I. enemy lasers, in slot order
+    {
+        const int nl = f[F_N_LASERS];
+        uint32_t keepmask = 0;
+#pragma unroll
+        for (int i = 0; i < TBX_SI_MAX_LASERS; i++) {
+            if (i < nl) {
+                Laser l = get_laser(s, i);
+                move_laser(l);
+                bool gone = false;
+                if (l.y + l.h >= TBX_SI_GROUND_Y || l.y + l.h <= 0 || l.x + l.w <= 0 || l.x >= TBX_SI_W) gone = true;
+                else if (shield_hit(s, lane, l)) gone = true;
+                else if ((f[F_SHIP_FLAGS] & 1) && overlap(l.x, l.y, l.w, l.h, f[F_SHIP_X], f[F_SHIP_Y], f[F_SHIP_W], f[F_SHIP_H])) {
+                    f[F_SHIP_FLAGS] = 2; f[F_SHIP_DC] = TBX_SI_SHIP_DEATH_T;
+                    gone = true;
+                }
+                if (!gone) { keepmask |= 1u << i; put_laser(s, lane, i, l); }
+            }
+        }
+        // compaction: slot j takes the j-th kept laser; freed slots are zeroed
+        const int keep = __popc(keepmask);
+        int src = -1;
+        if (lane < TBX_SI_MAX_LASERS && lane < keep) {
+            uint32_t m = keepmask;
+            for (int j = 0; j < lane; j++) m &= m - 1;
+            src = __builtin_ctz(m);
+        }
+        const int from = src < 0 ? lane : src;
+#pragma unroll
+        for (int i = 0; i < NLF; i++) {
+            const int32_t v = __shfl(s.lf[i], from);
+            if (lane < TBX_SI_MAX_LASERS) s.lf[i] = src >= 0 ? v : 0;
+        }
+        f[F_N_LASERS] = keep;
+    }
+
+    // J. ufo
+    if (f[F_UFO_DC] >= 0) {
+        if (dec_counter(f[F_UFO_DC])) { f[F_UFO_X] = TBX_SI_UFO_X0; f[F_UFO_APP] = TBX_SI_UFO_PERIOD; }
+    } else if (f[F_UFO_APP] > 0) {
+        f[F_UFO_APP] -= 1;
+    } else if (f[F_UFO_APP] == 0) {
+        f[F_UFO_X] += TBX_SI_UFO_STEP;
+        if (f[F_UFO_X] >= TBX_SI_W) { f[F_UFO_X] = TBX_SI_UFO_X0; f[F_UFO_APP] = TBX_SI_UFO_PERIOD; }
+    }
+
+    // K. wave cleared
+    {
+        const bool busy = lane < ne && (e_alive(s) || e_dc(s) >= 0);
+        if (!__ballot(busy) && ne > 0) { f[F_LEVEL] += 1; si_reset_formation(s, lane); }
+    }
+}
+
+// ------------------------------------------------------------------ kernels
+
+__global__ __launch_bounds__(TBX_BLOCK) void si_new_game_kernel(SiDev d, SiCfg c, const uint8_t* mask)
+{
+    const int lane = threadIdx.x & 63;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (env >= d.n) return;
+    if (mask && !mask[env]) return;
+    const size_t N = (size_t)d.n;
+    Rng sim;
+    sim.s0 = d.sim_rng[env];
+    sim.s1 = d.sim_rng[N + env];
+    SiRegs s;
+    si_new_game(c, lane, sim, s);
+    si_store(d, env, lane, s);
+    if (lane == 0) {
+        d.sim_rng[env] = sim.s0;
+        d.sim_rng[N + env] = sim.s1;
+        d.prev_score[env] = s.f[F_SCORE];
+    }
+}
+
+__global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (rel >= count) return;
+    const int env = first_env + rel;
+    const size_t N = (size_t)d.n;
+
+    uint32_t buttons;
+    if (src.single_env >= 0) {
+        buttons = src.single_buttons;
+    } else {
+        int a;
+        if (src.actions) a = src.actions[env];
+        else {
+            uint64_t h = tbx_splitmix64(src.seed ^ ((src.env_offset + (uint64_t)env) << 32) ^ src.t);
+            a = tbx_legal_action(TBX_GAME_SPACE_INVADERS, (int)(h % 6ull));
+        }
+        buttons = tbx_ale_buttons(a);
+        if (buttons == 0xFFu) {
+            buttons = 0;
+            if (lane == 0) atomicOr(d.err_flag, 1u);
+        }
+    }
+
+    SiRegs s;
+    si_load(d, env, lane, s);
+    si_step(c, lane, buttons, s);
+
+    int32_t rew = s.f[F_SCORE] - d.prev_score[env];
+    if (rew < 0) rew = 0;
+    const int32_t out_lives = s.f[F_LIVES], out_score = s.f[F_SCORE];
+    const bool is_done = out_lives <= 0;
+    int32_t prev = out_score;
+    if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+        Rng sim;
+        sim.s0 = d.sim_rng[env];
+        sim.s1 = d.sim_rng[N + env];
+        si_new_game(c, lane, sim, s);
+        if (lane == 0) { d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1; }
+        prev = s.f[F_SCORE];
+    }
+    si_store(d, env, lane, s);
+    if (lane == 0) {
+        d.prev_score[env] = prev;
+        d.reward[env] = rew;
+        d.done[env] = is_done ? 1 : 0;
+        d.lives_out[env] = out_lives;
+        d.score_out[env] = out_score;
+        uint32_t lv = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
+        d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv << 40);
+    }
+}
+
+// ------------------------------------------------------------------ render
+
+__constant__ uint16_t SI_DIGITS[10] = TBX_DIGIT_FONT;
+__constant__ uint32_t SI_SPR_A[TBX_SI_ENEMY_H] = TBX_SI_SPRITE_ENEMY_A;
+__constant__ uint32_t SI_SPR_B[TBX_SI_ENEMY_H] = TBX_SI_SPRITE_ENEMY_B;
+__constant__ uint32_t SI_SPR_BOOM[TBX_SI_ENEMY_H] = TBX_SI_SPRITE_BOOM;
+__constant__ uint32_t SI_SPR_SHIP[TBX_SI_SHIP_H] = TBX_SI_SPRITE_SHIP;
+__constant__ uint32_t SI_SPR_D1[TBX_SI_SHIP_H] = TBX_SI_SPRITE_SHIP_D1;
+__constant__ uint32_t SI_SPR_D2[TBX_SI_SHIP_H] = TBX_SI_SPRITE_SHIP_D2;
+__constant__ uint32_t SI_SPR_UFO[TBX_SI_UFO_H] = TBX_SI_SPRITE_UFO;
+
+constexpr int SI_UNIT_ROWS = 6;   // 210 = 35 units; 6 x 960 B (RGB) = 5760 B of LDS per wave
+
+// paints sprite row bits (bit k = column k, `w` columns) at x position sx into the lane's pixel groups
+template <int NG>
+__device__ __forceinline__ void paint_bits(uint32_t (&px)[NG][4], const int (&gx)[NG], int sx, uint32_t bits, int w, uint32_t col)
+{
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = gx[g] + i - sx;
+            if (k >= 0 && k < w && ((bits >> k) & 1u)) px[g][i] = col;
+        }
+    }
+}
+
+template <int NG>
+__device__ __forceinline__ void paint_span(uint32_t (&px)[NG][4], const int (&gx)[NG], long rx0, long rx1, uint32_t col)
+{
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const long x = gx[g] + i;
+            if (x >= rx0 && x < rx1) px[g][i] = col;
+        }
+    }
+}
+
+// One wave rasterises one env: scanline by scanline, lane l makes the 4-pixel groups l and l+64
+// (320 px = 80 groups); entities intersecting the scanline are found by ballot over lanes
+// (lane = enemy / shield row / laser slot) and painted in the checker's order.
+template <int C>
+__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count)
+{
+    constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = 2;
+    using Stager = RowStager<C, W, SI_UNIT_ROWS>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (rel >= count) return;
+    const int env = first_env + rel;
+    Stager st{lds_all + wave * Stager::UNIT_BYTES};
+
+    SiRegs s;
+    si_load(d, env, lane, s);
+    const int32_t* f = s.f;
+    const int ne = f[F_N_ENEMIES];
+    const int gx[NG] = {lane * 4, (lane + 64) * 4};
+    const bool gact[NG] = {true, lane + 64 < W / 4};
+
+    // HUD bits per pixel: bit 3*r = lit in glyph row r
+    uint32_t hud[NG][4];
+    {
+        int sc = f[F_SCORE];
+        if (sc < 0) sc = 0;
+        sc %= 100000;
+        int lv = f[F_LIVES];
+        lv = lv < 0 ? 0 : lv > 9 ? 9 : lv;
+        int le = f[F_LEVEL];
+        if (le < 0) le = 0;
+        le %= 10;
+        const int hud_x0[7] = {36, 44, 52, 60, 68, 148, 196};
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) hud[g][i] = 0;
+        int div = 10000;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            int digit;
+            if (q < 5) { digit = (sc / div) % 10; div /= 10; }
+            else digit = q == 5 ? lv : le;
+            const uint32_t glyph = SI_DIGITS[digit];
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int dx = gx[g] + i - hud_x0[q];
+                    if (dx >= 0 && dx < 6) hud[g][i] = (glyph >> (dx >> 1)) & 0x1249u;
+                }
+        }
+    }
+    const uint32_t c_enemy = rgb_u32(TBX_SI_COL_ENEMY), c_ufo = rgb_u32(TBX_SI_COL_UFO), c_ground = rgb_u32(TBX_SI_COL_GROUND);
+    const uint32_t c_hud = rgb_u32(TBX_SI_COL_HUD);
+    const bool ufo_on = f[F_UFO_APP] == 0 || f[F_UFO_DC] >= 0;
+    const int sk = lane / TBX_SI_SHIELD_H, sr = lane - sk * TBX_SI_SHIELD_H;
+    const bool s_valid = lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H && sk < f[F_N_SHIELDS];
+    const int s_x = sk == 0 ? f[F_SHIELD_X0] : sk == 1 ? f[F_SHIELD_X1] : f[F_SHIELD_X2];
+    const int s_y = (sk == 0 ? f[F_SHIELD_Y0] : sk == 1 ? f[F_SHIELD_Y1] : f[F_SHIELD_Y2]) + sr;
+    const uint32_t s_c = (uint32_t)(sk == 0 ? f[F_SHIELD_C0] : sk == 1 ? f[F_SHIELD_C1] : f[F_SHIELD_C2]);
+    const bool e_vis = lane < ne && (e_alive(s) || e_dc(s) >= 0);
+
+    uint8_t* frame = out + (size_t)rel * H * W * C;
+    constexpr int NUNITS = H / SI_UNIT_ROWS;
+    const int u0 = (int)(((uint32_t)env * 11u) % (uint32_t)NUNITS);
+    for (int k = 0; k < NUNITS; k++) {
+        int u = u0 + k;
+        if (u >= NUNITS) u -= NUNITS;
+#pragma unroll 1
+        for (int r = 0; r < SI_UNIT_ROWS; r++) {
+            const int y = u * SI_UNIT_ROWS + r;
+            uint32_t px[NG][4];
+            const uint32_t base = y == TBX_SI_GROUND_Y ? c_ground : 0xFF000000u;
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) px[g][i] = base;
+            // shields (ascending shield index, then row: one row per shield can match y)
+            {
+                uint64_t m = __ballot(s_valid && s_y == y && s.srow != 0);
+                while (m) {
+                    const int src = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    paint_bits<NG>(px, gx, __shfl(s_x, src), __shfl(s.srow, src), TBX_SI_SHIELD_W, __shfl(s_c, src));
+                }
+            }
+            // enemies in index order
+            {
+                uint64_t m = __ballot(e_vis && y >= s.ey && y < s.ey + TBX_SI_ENEMY_H);
+                while (m) {
+                    const int src = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const int ey = __builtin_amdgcn_readlane(s.ey, src);
+                    const int st_ = __builtin_amdgcn_readlane(s.estatus, src);
+                    const uint32_t* spr = (st_ & 1) ? (f[F_ORIENT] ? SI_SPR_A : SI_SPR_B) : SI_SPR_BOOM;
+                    paint_bits<NG>(px, gx, __builtin_amdgcn_readlane(s.ex, src), spr[y - ey], TBX_SI_ENEMY_W, c_enemy);
+                }
+            }
+            if (ufo_on && y >= f[F_UFO_Y] && y < f[F_UFO_Y] + TBX_SI_UFO_H)
+                paint_bits<NG>(px, gx, f[F_UFO_X], SI_SPR_UFO[y - f[F_UFO_Y]], TBX_SI_UFO_W, c_ufo);
+            if (y >= f[F_SHIP_Y] && y < f[F_SHIP_Y] + TBX_SI_SHIP_H) {
+                const int ry = y - f[F_SHIP_Y];
+                if (f[F_SHIP_FLAGS] & 1) paint_bits<NG>(px, gx, f[F_SHIP_X], SI_SPR_SHIP[ry], 16, (uint32_t)f[F_SHIP_COLOR]);
+                else if (f[F_SHIP_DC] >= 0)
+                    paint_bits<NG>(px, gx, f[F_SHIP_X], (f[F_SHIP_FLAGS] & 2) ? SI_SPR_D1[ry] : SI_SPR_D2[ry], 16, (uint32_t)f[F_SHIP_COLOR]);
+            }
+            // lasers: the ship's first, then enemy lasers in slot order
+            {
+                const bool mine = lane == SHIP_SLOT ? f[F_HAS_SHIP_LASER] != 0 : lane < f[F_N_LASERS];
+                const long ly0 = s.lf[LF_Y], ly1 = (long)s.lf[LF_Y] + s.lf[LF_H];
+                uint64_t m = __ballot(mine && y >= ly0 && y < ly1);
+                if ((m >> SHIP_SLOT) & 1) {
+                    const Laser l = get_laser(s, SHIP_SLOT);
+                    paint_span<NG>(px, gx, l.x, (long)l.x + l.w, (uint32_t)l.color);
+                }
+                m &= (1ull << SHIP_SLOT) - 1;
+                while (m) {
+                    const int src = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const long lx = __shfl(s.lf[LF_X], src), lw = __shfl(s.lf[LF_W], src);
+                    paint_span<NG>(px, gx, lx, lx + lw, (uint32_t)__shfl(s.lf[LF_COLOR], src));
+                }
+            }
+            if (y >= 2 && y < 12) {
+                const int gr = ((y - 2) >> 1) * 3;
+#pragma unroll
+                for (int g = 0; g < NG; g++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if ((hud[g][i] >> gr) & 1u) px[g][i] = c_hud;
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+                if (gact[g]) st.put4(r, lane + 64 * g, px[g][0], px[g][1], px[g][2], px[g][3]);
+        }
+        st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
+    }
+}
+
+// ------------------------------------------------------------------ state pack / unpack, scalars
+
+__global__ void si_pack_kernel(SiDev d, int env, tbx_si_state_t* out)
+{
+    const int lane = threadIdx.x & 63;
+    SiRegs s;
+    si_load(d, env, lane, s);
+    const int32_t* f = s.f;
+    if (lane == 0) {
+        out->rand[0] = s.rng.s0; out->rand[1] = s.rng.s1;
+        out->score = f[F_SCORE]; out->lives = f[F_LIVES]; out->level = f[F_LEVEL];
+        out->life_display_timer = f[F_LIFE_TIMER]; out->enemy_shot_delay = f[F_SHOT_DELAY];
+        out->n_enemies = f[F_N_ENEMIES]; out->n_enemy_lasers = f[F_N_LASERS]; out->has_ship_laser = f[F_HAS_SHIP_LASER];
+        out->ship_x = f[F_SHIP_X]; out->ship_y = f[F_SHIP_Y]; out->ship_w = f[F_SHIP_W]; out->ship_h = f[F_SHIP_H];
+        out->ship_speed = f[F_SHIP_SPEED]; out->ship_death_counter = f[F_SHIP_DC];
+        out->ship_color = unpack_color((uint32_t)f[F_SHIP_COLOR]);
+        out->ship_alive = f[F_SHIP_FLAGS] & 1; out->ship_death_hit_1 = (f[F_SHIP_FLAGS] >> 1) & 1;
+        out->_pad0[0] = out->_pad0[1] = 0;
+        out->ufo_x = f[F_UFO_X]; out->ufo_y = f[F_UFO_Y]; out->ufo_appearance_counter = f[F_UFO_APP]; out->ufo_death_counter = f[F_UFO_DC];
+        out->move_counter = f[F_MOVE_COUNTER]; out->move_dir = f[F_MOVE_DIR];
+        out->visual_orientation = f[F_ORIENT] ? 1 : 0;
+        out->_pad1[0] = out->_pad1[1] = out->_pad1[2] = 0;
+        out->n_shields = f[F_N_SHIELDS];
+        for (int k = 0; k < TBX_SI_MAX_SHIELDS; k++) {
+            out->shield_x[k] = f[F_SHIELD_X0 + k]; out->shield_y[k] = f[F_SHIELD_Y0 + k];
+            out->shield_color[k] = unpack_color((uint32_t)f[F_SHIELD_C0 + k]);
+        }
+    }
+    if (lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H) out->shield_rows[lane / TBX_SI_SHIELD_H][lane % TBX_SI_SHIELD_H] = (uint16_t)s.srow;
+    {
+        tbx_si_enemy_t e;
+        memset(&e, 0, sizeof e);
+        if (lane < f[F_N_ENEMIES]) {
+            e.x = s.ex; e.y = s.ey; e.row = s.erow; e.col = s.ecol; e.id = s.eid; e.points = s.epoints;
+            e.death_counter = e_dc(s); e.alive = e_alive(s) ? 1 : 0;
+        }
+        out->enemies[lane] = e;
+    }
+    if (lane <= SHIP_SLOT) {
+        tbx_si_laser_t l;
+        memset(&l, 0, sizeof l);
+        const bool on = lane == SHIP_SLOT ? f[F_HAS_SHIP_LASER] != 0 : lane < f[F_N_LASERS];
+        if (on) {
+            l.x = s.lf[LF_X]; l.y = s.lf[LF_Y]; l.w = s.lf[LF_W]; l.h = s.lf[LF_H]; l.t = s.lf[LF_T];
+            l.movement = s.lf[LF_MOV]; l.speed = s.lf[LF_SPEED]; l.color = unpack_color((uint32_t)s.lf[LF_COLOR]);
+        }
+        if (lane == SHIP_SLOT) out->ship_laser = l;
+        else out->enemy_lasers[lane] = l;
+    }
+}
+
+__global__ void si_unpack_kernel(SiDev d, int env, const tbx_si_state_t* in)
+{
+    const int lane = threadIdx.x & 63;
+    SiRegs s;
+    int32_t* f = s.f;
+    s.rng.s0 = in->rand[0]; s.rng.s1 = in->rand[1];
+    f[F_SCORE] = in->score; f[F_LIVES] = in->lives; f[F_LEVEL] = in->level;
+    f[F_LIFE_TIMER] = in->life_display_timer; f[F_SHOT_DELAY] = in->enemy_shot_delay;
+    f[F_N_ENEMIES] = in->n_enemies; f[F_N_LASERS] = in->n_enemy_lasers; f[F_HAS_SHIP_LASER] = in->has_ship_laser ? 1 : 0;
+    f[F_SHIP_X] = in->ship_x; f[F_SHIP_Y] = in->ship_y; f[F_SHIP_W] = in->ship_w; f[F_SHIP_H] = in->ship_h;
+    f[F_SHIP_SPEED] = in->ship_speed; f[F_SHIP_DC] = in->ship_death_counter < 0 ? -1 : in->ship_death_counter;
+    f[F_SHIP_COLOR] = (int32_t)pack_color(in->ship_color);
+    f[F_SHIP_FLAGS] = (in->ship_alive ? 1 : 0) | (in->ship_death_hit_1 ? 2 : 0);
+    f[F_UFO_X] = in->ufo_x; f[F_UFO_Y] = in->ufo_y; f[F_UFO_APP] = in->ufo_appearance_counter;
+    f[F_UFO_DC] = in->ufo_death_counter < 0 ? -1 : in->ufo_death_counter;
+    f[F_MOVE_COUNTER] = in->move_counter; f[F_MOVE_DIR] = in->move_dir & 3; f[F_ORIENT] = in->visual_orientation ? 1 : 0;
+    f[F_N_SHIELDS] = in->n_shields;
+    for (int k = 0; k < TBX_SI_MAX_SHIELDS; k++) {
+        const bool on = k < in->n_shields;
+        f[F_SHIELD_X0 + k] = on ? in->shield_x[k] : 0; f[F_SHIELD_Y0 + k] = on ? in->shield_y[k] : 0;
+        f[F_SHIELD_C0 + k] = on ? (int32_t)pack_color(in->shield_color[k]) : 0;
+    }
+    {
+        const int k = lane / TBX_SI_SHIELD_H, r = lane % TBX_SI_SHIELD_H;
+        s.srow = (lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H && k < in->n_shields) ? in->shield_rows[k][r] : 0u;
+    }
+    {
+        const tbx_si_enemy_t& e = in->enemies[lane];
+        const bool on = lane < in->n_enemies;
+        s.ex = on ? e.x : 0; s.ey = on ? e.y : 0; s.erow = on ? e.row : 0; s.ecol = on ? e.col : 0;
+        s.eid = on ? e.id : 0; s.epoints = on ? e.points : 0;
+        s.estatus = on ? mk_status(e.alive != 0, e.death_counter < 0 ? -1 : e.death_counter) : 0;
+    }
+    for (int i = 0; i < NLF; i++) s.lf[i] = 0;
+    {
+        const int slot = lane & 15;
+        const bool on = slot == SHIP_SLOT ? in->has_ship_laser != 0 : slot < in->n_enemy_lasers;
+        if (slot <= SHIP_SLOT && on) {
+            const tbx_si_laser_t& l = slot == SHIP_SLOT ? in->ship_laser : in->enemy_lasers[slot];
+            s.lf[LF_X] = l.x; s.lf[LF_Y] = l.y; s.lf[LF_W] = l.w; s.lf[LF_H] = l.h; s.lf[LF_T] = l.t;
+            s.lf[LF_MOV] = l.movement & 3; s.lf[LF_SPEED] = l.speed; s.lf[LF_COLOR] = (int32_t)pack_color(l.color);
+        }
+    }
+    si_store(d, env, lane, s);
+}
+
+__global__ void si_scalars_kernel(SiDev d, int32_t* score, int32_t* lives, int32_t* level)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    const size_t N = (size_t)d.n;
+    if (score) score[i] = d.sc[(size_t)F_SCORE * N + i];
+    if (lives) lives[i] = d.sc[(size_t)F_LIVES * N + i];
+    if (level) level[i] = d.sc[(size_t)F_LEVEL * N + i];
+}
+
+// ------------------------------------------------------------------ host ops
+
+struct SiOps : GameOps {
+    SiDev d{};
+    SiCfg c{};
+    tbx_si_config_t cfg{};
+
+    int height() const override { return TBX_SI_H; }
+    int width() const override { return TBX_SI_W; }
+    size_t state_size() const override { return sizeof(tbx_si_state_t); }
+    size_t config_size() const override { return sizeof(tbx_si_config_t); }
+
+    int load_cfg(tbx_engine* e, const tbx_si_config_t& k)
+    {
+        if (k.n_rows < 1 || k.n_rows > TBX_SI_MAX_ROWS) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: n_rows must be 1..10");
+        if (k.n_shields < 0 || k.n_shields > TBX_SI_MAX_SHIELDS) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: at most 3 shields");
+        if (k.enemy_protocol != 0) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: only the TargetPlayer firing protocol is implemented");
+        cfg = k;
+        c.jitter = k.jitter; c.start_lives = k.start_lives; c.n_rows = k.n_rows; c.n_shields = k.n_shields;
+        for (int i = 0; i < TBX_SI_MAX_ROWS; i++) c.row_scores[i] = k.row_scores[i];
+        for (int i = 0; i < TBX_SI_MAX_SHIELDS; i++) { c.shield_x[i] = k.shield_x[i]; c.shield_y[i] = k.shield_y[i]; }
+        return TBX_OK;
+    }
+
+    int init(tbx_engine* e, const void* cfg_pod, size_t cfg_size) override
+    {
+        if (!cfg_pod || cfg_size != sizeof(tbx_si_config_t)) return e->fail(TBX_E_INVALID, "space_invaders: config size mismatch");
+        tbx_si_config_t k;
+        memcpy(&k, cfg_pod, sizeof k);
+        int rc = load_cfg(e, k);
+        if (rc) return rc;
+        const size_t N = (size_t)e->n;
+        d.n = e->n;
+        d.sim_rng = e->sim_rng; d.prev_score = e->prev_score; d.reward = e->reward; d.done = e->done;
+        d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed; d.err_flag = e->err_flag;
+        TBX_HIP(hipMalloc((void**)&d.rng, 2 * N * sizeof(uint64_t)));
+        TBX_HIP(hipMalloc((void**)&d.sc, (size_t)NF * N * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&d.enemies, N * NEF * 64 * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&d.shields, N * 64 * sizeof(uint32_t)));
+        TBX_HIP(hipMalloc((void**)&d.lasers, N * NLF * 16 * sizeof(int32_t)));
+        return TBX_OK;
+    }
+
+    void destroy(tbx_engine*) override
+    {
+        hipFree(d.rng); hipFree(d.sc); hipFree(d.enemies); hipFree(d.shields); hipFree(d.lasers);
+    }
+
+    int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
+    int set_config(tbx_engine* e, const void* pod) override
+    {
+        tbx_si_config_t k;
+        memcpy(&k, pod, sizeof k);
+        return load_cfg(e, k);
+    }
+
+    static dim3 grid_for(int count) { return dim3((count + TBX_WAVES_PER_BLOCK - 1) / TBX_WAVES_PER_BLOCK); }
+
+    int new_game(tbx_engine* e, const uint8_t* mask_dev, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(si_new_game_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, c, mask_dev);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
+    {
+        int first = 0, count = e->n;
+        if (src.single_env >= 0) { first = src.single_env; count = 1; }
+        hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
+    {
+        switch (channels) {
+        case 1: hipLaunchKernelGGL(si_render_kernel<1>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        case 3: hipLaunchKernelGGL(si_render_kernel<3>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        case 4: hipLaunchKernelGGL(si_render_kernel<4>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+        }
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int pack_state(tbx_engine* e, int env, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(si_pack_kernel, dim3(1), dim3(64), 0, s, d, env, (tbx_si_state_t*)e->staging);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int unpack_state(tbx_engine* e, int env, const void* pod_host, hipStream_t s) override
+    {
+        const auto& st = *(const tbx_si_state_t*)pod_host;
+        if (st.n_enemies < 0 || st.n_enemies > TBX_SI_MAX_ENEMIES) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 64 enemies per env");
+        if (st.n_enemy_lasers < 0 || st.n_enemy_lasers > TBX_SI_MAX_LASERS) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 8 enemy lasers per env");
+        if (st.n_shields < 0 || st.n_shields > TBX_SI_MAX_SHIELDS) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 3 shields per env");
+        TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof st, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(si_unpack_kernel, dim3(1), dim3(64), 0, s, d, env, (const tbx_si_state_t*)e->staging);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int scalars(tbx_engine* e, int32_t* score_dev, int32_t* lives_dev, int32_t* level_dev, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(si_scalars_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, score_dev, lives_dev, level_dev);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+};
+
+}  // namespace
+
+GameOps* tbx_make_si_ops() { return new SiOps(); }

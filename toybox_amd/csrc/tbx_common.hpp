@@ -216,3 +216,4 @@ struct GameOps {
 };
 
 GameOps* tbx_make_breakout_ops();
+GameOps* tbx_make_si_ops();

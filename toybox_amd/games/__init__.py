@@ -1,7 +1,7 @@
 """Per-game POD <-> interventions-JSON codecs (slow path; the hot path never touches JSON)."""
-from . import breakout
+from . import breakout, space_invaders
 
-CODECS = {"breakout": breakout}
+CODECS = {"breakout": breakout, "space_invaders": space_invaders}
 
 
 def codec(game_name):
