@@ -196,6 +196,80 @@ typedef struct tbx_si_state {
     tbx_si_enemy_t enemies[TBX_SI_MAX_ENEMIES];
 } tbx_si_state_t;
 
+/* ------------------------------------------------------------------ Amidar POD */
+
+#define TBX_AMI_W             160
+#define TBX_AMI_H             250
+#define TBX_AMI_BOARD_W       32
+#define TBX_AMI_BOARD_H       31
+#define TBX_AMI_MAX_ENEMIES   8
+#define TBX_AMI_MAX_BOXES     64
+#define TBX_AMI_MAX_HISTORY   16
+#define TBX_AMI_MAX_CHASE_J   8
+#define TBX_AMI_TILE_WX       64    /* world units per tile: player_start {31,15} <-> position {1984,1200} in the goldens */
+#define TBX_AMI_TILE_WY       80
+
+/* tile tags (interventions/amidar.py:55-59) */
+#define TBX_TILE_EMPTY        0
+#define TBX_TILE_UNPAINTED    1
+#define TBX_TILE_PAINTED      2
+#define TBX_TILE_CHASE_MARKER 3
+
+/* movement protocols (interventions/amidar.py:101-112) */
+#define TBX_AI_PLAYER          0
+#define TBX_AI_LOOKUP          1   /* EnemyLookupAI     {next, default_route_index}                       */
+#define TBX_AI_PERIMETER       2   /* EnemyPerimeterAI  {start}                                           */
+#define TBX_AI_AMIDAR          3   /* EnemyAmidarMvmt   {vert, horiz, start_vert, start_horiz, start}     */
+#define TBX_AI_TARGET_PLAYER   4   /* EnemyTargetPlayer {start, start_dir, vision_distance, dir, player_seen} */
+#define TBX_AI_RANDOM          5   /* EnemyRandomMvmt   {start, start_dir, dir}                           */
+
+typedef struct tbx_amidar_ai {
+    int32_t kind;
+    int32_t next, default_route_index;
+    int32_t start_tx, start_ty;
+    int32_t vert, horiz, start_vert, start_horiz;
+    int32_t start_dir, dir;
+    int32_t vision_distance;
+    int32_t seen_tx, seen_ty;          /* player_seen; -1,-1 == None */
+} tbx_amidar_ai_t;
+
+typedef struct tbx_amidar_mover {
+    int32_t x, y, speed;
+    int32_t step_tx, step_ty;          /* step; -1,-1 == None */
+    int32_t n_history;
+    int32_t history[TBX_AMI_MAX_HISTORY];
+    int32_t caught;
+    tbx_amidar_ai_t ai;
+} tbx_amidar_mover_t;
+
+typedef struct tbx_amidar_box {
+    int32_t tl_tx, tl_ty, br_tx, br_ty;
+    uint8_t painted, triggers_chase, _pad[2];
+} tbx_amidar_box_t;
+
+typedef struct tbx_amidar_config {
+    uint64_t rand[2];
+    int32_t  start_lives, start_jumps, jump_time, chase_time, box_bonus, chase_score_bonus;
+    int32_t  player_start_tx, player_start_ty;
+    int32_t  n_enemies;
+    uint8_t  render_images, default_board_bugs, _pad0[2];
+    tbx_amidar_ai_t enemies[TBX_AMI_MAX_ENEMIES];
+    tbx_color_t bg_color, player_color, unpainted_color, painted_color, enemy_color, inner_painted_color;
+    uint8_t  board[TBX_AMI_BOARD_H][TBX_AMI_BOARD_W];   /* tile tags */
+} tbx_amidar_config_t;
+
+typedef struct tbx_amidar_state {
+    uint64_t rand[2];
+    int32_t  score, lives, level;
+    int32_t  jumps, jump_timer, chase_timer;
+    int32_t  n_enemies, n_boxes, n_chase_junctions;
+    int32_t  chase_junctions[TBX_AMI_MAX_CHASE_J];
+    tbx_amidar_mover_t player;
+    tbx_amidar_mover_t enemies[TBX_AMI_MAX_ENEMIES];
+    tbx_amidar_box_t boxes[TBX_AMI_MAX_BOXES];
+    uint8_t  tiles[TBX_AMI_BOARD_H][TBX_AMI_BOARD_W];
+} tbx_amidar_state_t;
+
 /* ------------------------------------------------------------------ engine */
 
 typedef struct tbx_engine tbx_engine;
@@ -275,6 +349,12 @@ int tbx_set_state(tbx_engine* engine, int env, const void* pod, size_t size);
  * replaces Toybox.config_to_json / write_config_json (interventions/base.py:390,402). */
 int tbx_get_config(tbx_engine* engine, void* pod_out, size_t size);
 int tbx_set_config(tbx_engine* engine, const void* pod, size_t size);
+
+/* Integer state queries.  Amidar: TBX_QUERY_TILE_TO_WORLD {tx,ty} -> {x,y}, TBX_QUERY_WORLD_TO_TILE {x,y} -> {tx,ty}.
+ * replaces Toybox.query_state_json('tile_to_world' / 'world_to_tile') (interventions/amidar.py:510,518). */
+#define TBX_QUERY_TILE_TO_WORLD 1
+#define TBX_QUERY_WORLD_TO_TILE 2
+int tbx_query(tbx_engine* engine, int env, int query_id, const int32_t* args, int n_args, int32_t* out, int n_out);
 
 /* Address of an engine-owned device buffer (TBX_BUF_*). */
 int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out_bytes);

@@ -71,4 +71,23 @@
 #define TBX_SI_COL_GROUND     80, 89, 22
 #define TBX_SI_COL_HUD        50, 132, 50
 
+/* ---- Amidar ---- */
+#define TBX_AMI_BOARD_OX       16    /* board origin on screen; one tile = 4 x 5 px = 64 x 80 world units (scale 16) */
+#define TBX_AMI_BOARD_OY       37
+#define TBX_AMI_TILE_PW        4
+#define TBX_AMI_TILE_PH        5
+#define TBX_AMI_WORLD_SCALE    16
+#define TBX_AMI_MOVER_W        6
+#define TBX_AMI_MOVER_H        7
+#define TBX_AMI_SPEED          8     /* [golden] speed of every mover */
+#define TBX_AMI_HIT_DX         48    /* collision box, world units */
+#define TBX_AMI_HIT_DY         60
+#define TBX_AMI_HUD_Y          204
+#define TBX_AMI_N_ROUTES       5
+#define TBX_AMI_ROUTE_LEN      5
+/* default EnemyLookupAI routes: tile ids ty*32+tx, -1 terminated; entry 0 is the start tile, which matches the
+   golden enemy positions (0,0) (0,0) (448,0) (0,2000) (576,2400) */
+#define TBX_AMI_ROUTES { {0, 31, 991, 960, -1}, {0, 192, 223, 31, -1}, {7, 10, 202, 198, 6}, \
+                         {800, 768, 774, 966, 960}, {969, 972, 780, 774, 966} }
+
 #endif

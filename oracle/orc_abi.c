@@ -44,6 +44,7 @@ size_t tbx_state_size(int game)
     switch (game) {
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_state_t);
     case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_state_t);
+    case TBX_GAME_AMIDAR: return sizeof(tbx_amidar_state_t);
     default: return 0;
     }
 }
@@ -52,6 +53,7 @@ size_t tbx_config_size(int game)
     switch (game) {
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_config_t);
     case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_config_t);
+    case TBX_GAME_AMIDAR: return sizeof(tbx_amidar_config_t);
     default: return 0;
     }
 }
@@ -91,6 +93,7 @@ int tbx_create(int game, int n, int device, const void* cfg, size_t cfg_size, tb
     else switch (game) {
         case TBX_GAME_BREAKOUT: orc_breakout_default_config((tbx_breakout_config_t*)e->cfg); break;
         case TBX_GAME_SPACE_INVADERS: orc_si_default_config((tbx_si_config_t*)e->cfg); break;
+        case TBX_GAME_AMIDAR: orc_amidar_default_config((tbx_amidar_config_t*)e->cfg); break;
     }
     for (int i = 0; i < n; i++) memcpy(e->sim + 2 * (size_t)i, e->cfg, 16);
     orc_new_game_batch(game, e->cfg, e->states, e->sim, e->prev, n, NULL);
@@ -203,6 +206,9 @@ int tbx_apply_input(tbx_engine* e, int env, uint32_t buttons)
     case TBX_GAME_SPACE_INVADERS:
         orc_si_step((const tbx_si_config_t*)e->cfg, (tbx_si_state_t*)st, buttons & 0x3Fu);
         break;
+    case TBX_GAME_AMIDAR:
+        orc_amidar_step((const tbx_amidar_config_t*)e->cfg, (tbx_amidar_state_t*)st, buttons & 0x3Fu);
+        break;
     }
     int32_t sc, lv, le;
     orc_get_scalars(e->game, st, 1, &sc, &lv, &le);
@@ -278,6 +284,11 @@ int tbx_set_state(tbx_engine* e, int env, const void* pod, size_t size)
         if (s->n_balls < 0 || s->n_balls > TBX_BRK_MAX_BALLS) return fail(e, TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 4 balls per env");
         if (s->n_bricks < 0 || s->n_bricks > TBX_BRK_MAX_BRICKS) return fail(e, TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 256 bricks per env");
     }
+    if (e->game == TBX_GAME_AMIDAR) {
+        const tbx_amidar_state_t* s = (const tbx_amidar_state_t*)pod;
+        if (s->n_enemies < 0 || s->n_enemies > TBX_AMI_MAX_ENEMIES) return fail(e, TBX_E_UNSUPPORTED, "amidar: the device engine holds at most 8 enemies per env");
+        if (s->n_boxes < 0 || s->n_boxes > TBX_AMI_MAX_BOXES) return fail(e, TBX_E_UNSUPPORTED, "amidar: the device engine holds at most 64 boxes per env");
+    }
     if (e->game == TBX_GAME_SPACE_INVADERS) {
         const tbx_si_state_t* s = (const tbx_si_state_t*)pod;
         if (s->n_enemies < 0 || s->n_enemies > TBX_SI_MAX_ENEMIES) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 64 enemies per env");
@@ -308,6 +319,10 @@ int tbx_set_config(tbx_engine* e, const void* pod, size_t size)
         if (k->paddle_discrete_segments < 1 || k->paddle_discrete_segments > TBX_BRK_MAX_SEGMENTS)
             return fail(e, TBX_E_UNSUPPORTED, "breakout: paddle_discrete_segments must be 1..16");
     }
+    if (e->game == TBX_GAME_AMIDAR) {
+        const tbx_amidar_config_t* k = (const tbx_amidar_config_t*)pod;
+        if (k->n_enemies < 0 || k->n_enemies > TBX_AMI_MAX_ENEMIES) return fail(e, TBX_E_UNSUPPORTED, "amidar: at most 8 enemies");
+    }
     if (e->game == TBX_GAME_SPACE_INVADERS) {
         const tbx_si_config_t* k = (const tbx_si_config_t*)pod;
         if (k->n_rows < 1 || k->n_rows > TBX_SI_MAX_ROWS) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: n_rows must be 1..10");
@@ -317,6 +332,14 @@ int tbx_set_config(tbx_engine* e, const void* pod, size_t size)
     memcpy(e->cfg, pod, size);
     for (int i = 0; i < e->n; i++) memcpy(e->sim + 2 * (size_t)i, pod, 16);
     return TBX_OK;
+}
+
+int tbx_query(tbx_engine* e, int env, int query_id, const int32_t* args, int n_args, int32_t* out, int n_out)
+{
+    if (!e) return TBX_E_INVALID;
+    if (env < 0 || env >= e->n || !args || !out) return fail(e, TBX_E_INVALID, "bad query arguments");
+    if (e->game == TBX_GAME_AMIDAR && n_args >= 2 && n_out >= 2 && orc_amidar_query(query_id, args, out) == 0) return TBX_OK;
+    return fail(e, TBX_E_INVALID, "unknown query for this game");
 }
 
 int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_bytes)

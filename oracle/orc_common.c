@@ -97,6 +97,7 @@ int orc_frame_dims(int game, int* h, int* w)
     switch (game) {
     case TBX_GAME_BREAKOUT: *h = TBX_BRK_H; *w = TBX_BRK_W; return 0;
     case TBX_GAME_SPACE_INVADERS: *h = TBX_SI_H; *w = TBX_SI_W; return 0;
+    case TBX_GAME_AMIDAR: *h = TBX_AMI_H; *w = TBX_AMI_W; return 0;
     default: return -1;
     }
 }
@@ -116,6 +117,7 @@ static size_t state_size(int game)
     switch (game) {
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_state_t);
     case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_state_t);
+    case TBX_GAME_AMIDAR: return sizeof(tbx_amidar_state_t);
     default: return 0;
     }
 }
@@ -129,6 +131,9 @@ static void one_new_game(int game, const void* cfg, void* st, uint64_t* sim)
     case TBX_GAME_SPACE_INVADERS:
         orc_si_new_game((const tbx_si_config_t*)cfg, sim, (tbx_si_state_t*)st);
         break;
+    case TBX_GAME_AMIDAR:
+        orc_amidar_new_game((const tbx_amidar_config_t*)cfg, sim, (tbx_amidar_state_t*)st);
+        break;
     }
 }
 
@@ -140,6 +145,9 @@ static void one_step(int game, const void* cfg, void* st, uint32_t buttons)
         break;
     case TBX_GAME_SPACE_INVADERS:
         orc_si_step((const tbx_si_config_t*)cfg, (tbx_si_state_t*)st, buttons);
+        break;
+    case TBX_GAME_AMIDAR:
+        orc_amidar_step((const tbx_amidar_config_t*)cfg, (tbx_amidar_state_t*)st, buttons);
         break;
     }
 }
@@ -154,6 +162,10 @@ static void one_scalars(int game, const void* st, int32_t* score, int32_t* lives
         break; }
     case TBX_GAME_SPACE_INVADERS: {
         const tbx_si_state_t* s = (const tbx_si_state_t*)st;
+        *score = s->score; *lives = s->lives; *level = s->level;
+        break; }
+    case TBX_GAME_AMIDAR: {
+        const tbx_amidar_state_t* s = (const tbx_amidar_state_t*)st;
         *score = s->score; *lives = s->lives; *level = s->level;
         break; }
     }
@@ -237,6 +249,9 @@ int orc_render_batch(int game, const void* cfg, const void* states, int n, uint8
             break;
         case TBX_GAME_SPACE_INVADERS:
             orc_si_render((const tbx_si_config_t*)cfg, (const tbx_si_state_t*)st, out + fsz * (size_t)i, channels);
+            break;
+        case TBX_GAME_AMIDAR:
+            orc_amidar_render((const tbx_amidar_config_t*)cfg, (const tbx_amidar_state_t*)st, out + fsz * (size_t)i, channels);
             break;
         }
     }

@@ -32,7 +32,7 @@ def _assert_states_equal(g, o, envs):
             raise AssertionError("env %d differs: %r" % (i, diff))
 
 
-@pytest.mark.parametrize("game", ["breakout", "space_invaders"])
+@pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar"])
 def test_rollout_parity(game, hip_lib, oracle_lib):
     """4096 envs, seeds 1234+i, 1500 random-action frames with auto-reset: outputs equal every step,
     full state records equal at checkpoints and at the end."""
@@ -58,7 +58,7 @@ def test_rollout_parity(game, hip_lib, oracle_lib):
         assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("game", ["breakout", "space_invaders"])
+@pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar"])
 @pytest.mark.parametrize("channels", [1, 3, 4])
 def test_frame_parity(game, channels, hip_lib, oracle_lib):
     n = 256
@@ -76,7 +76,7 @@ def test_frame_parity(game, channels, hip_lib, oracle_lib):
     assert np.array_equal(g.render_env(3, channels), o.render_env(3, channels))
 
 
-@pytest.mark.parametrize("game", ["breakout", "space_invaders"])
+@pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar"])
 def test_synthetic_device_path(game, hip_lib, oracle_lib):
     """tbx_step_synthetic (actions generated in-kernel) == host-generated actions with the same rule."""
     n = 1024
@@ -202,3 +202,52 @@ def test_full_size_properties(hip_lib):
         assert np.array_equal(a_eng.render_env(i, 3), b_eng.render_env(i, 3))
     a_eng.close()
     b_eng.close()
+
+
+def test_amidar_protocols_parity(hip_lib, oracle_lib):
+    """Every enemy movement protocol of interventions/amidar.py:101-112 (incl. EnemyRandomMvmt, which draws from the
+    state RNG in enemy order), a 6th enemy, chase / jump modes and painted boxes, stepped on both engines."""
+    import json
+    from toybox_amd.games import amidar as am
+    n = 16
+    g, o = _pair("amidar", n, hip_lib, oracle_lib)
+    for t in range(50):
+        a = synthetic_actions("amidar", n, t, seed=2)
+        g.step(a), o.step(a)
+    js = am.state_to_json(o.get_state(3))
+    tp = lambda x, y: {"tx": x, "ty": y}
+    js["enemies"][0]["ai"] = {"EnemyPerimeterAI": {"start": tp(0, 0)}}
+    js["enemies"][1]["ai"] = {"EnemyAmidarMvmt": {"vert": "Down", "horiz": "Right", "start_vert": "Down", "start_horiz": "Right", "start": tp(6, 0)}}
+    js["enemies"][2]["ai"] = {"EnemyTargetPlayer": {"start": tp(0, 30), "start_dir": "Right", "vision_distance": 12, "dir": "Right"}}
+    js["enemies"][3]["ai"] = {"EnemyRandomMvmt": {"start": tp(31, 30), "start_dir": "Up", "dir": "Up"}}
+    js["enemies"].append(json.loads(json.dumps(js["enemies"][3])))
+    js["enemies"][5]["ai"] = {"EnemyRandomMvmt": {"start": tp(12, 12), "start_dir": "Left", "dir": "Left"}}
+    js["enemies"][5]["position"] = {"x": 12 * 64, "y": 12 * 80}
+    js["enemies"][5]["step"] = None
+    for env in (3, 4, 5, 6):
+        st = am.state_from_json(js)
+        st.chase_timer = 40 * (env - 3)
+        for e in (g, o):
+            e.set_state(env, st)
+    _assert_states_equal(g, o, range(n))
+    for t in range(2500):
+        a = synthetic_actions("amidar", n, t, seed=9)
+        rg, ro = g.step(a, auto_reset=(t % 2 == 0)), o.step(a, auto_reset=(t % 2 == 0))
+        for x, y in zip(rg, ro):
+            assert np.array_equal(x, y), "step %d" % t
+        if t % 500 == 0:
+            assert np.array_equal(g.render(3), o.render(3))
+            _assert_states_equal(g, o, range(n))
+    _assert_states_equal(g, o, range(n))
+    # a painted board: every box painted, inner fill rendered
+    st = o.get_state(0)
+    for y in range(31):
+        for x in range(32):
+            if st.tiles[y][x]:
+                st.tiles[y][x] = 2
+    for b in range(st.n_boxes):
+        st.boxes[b].painted = 1
+    for e in (g, o):
+        e.set_state(0, st)
+    for ch in (1, 3, 4):
+        assert np.array_equal(g.render(ch), o.render(ch))

@@ -130,8 +130,58 @@ class SIState(C.Structure):
     ]
 
 
-STATE_TYPES = {GAME_BREAKOUT: BreakoutState, GAME_SPACE_INVADERS: SIState}
-CONFIG_TYPES = {GAME_BREAKOUT: BreakoutConfig, GAME_SPACE_INVADERS: SIConfig}
+AMI_BOARD_W, AMI_BOARD_H, AMI_MAX_ENEMIES, AMI_MAX_BOXES, AMI_MAX_HISTORY, AMI_MAX_CHASE_J = 32, 31, 8, 64, 16, 8
+AMI_TILE_WX, AMI_TILE_WY = 64, 80
+TILE_NAMES = ["Empty", "Unpainted", "Painted", "ChaseMarker"]          # interventions/amidar.py:55-59
+AI_NAMES = ["Player", "EnemyLookupAI", "EnemyPerimeterAI", "EnemyAmidarMvmt", "EnemyTargetPlayer", "EnemyRandomMvmt"]
+QUERY_TILE_TO_WORLD, QUERY_WORLD_TO_TILE = 1, 2
+
+
+class AmidarAI(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "next", "default_route_index", "start_tx", "start_ty", "vert", "horiz",
+                                         "start_vert", "start_horiz", "start_dir", "dir", "vision_distance", "seen_tx", "seen_ty")]
+
+
+class AmidarMover(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("speed", C.c_int32), ("step_tx", C.c_int32), ("step_ty", C.c_int32),
+                ("n_history", C.c_int32), ("history", C.c_int32 * AMI_MAX_HISTORY), ("caught", C.c_int32), ("ai", AmidarAI)]
+
+
+class AmidarBox(C.Structure):
+    _fields_ = [("tl_tx", C.c_int32), ("tl_ty", C.c_int32), ("br_tx", C.c_int32), ("br_ty", C.c_int32),
+                ("painted", C.c_uint8), ("triggers_chase", C.c_uint8), ("_pad", C.c_uint8 * 2)]
+
+
+class AmidarConfig(C.Structure):
+    _fields_ = [
+        ("rand", C.c_uint64 * 2),
+        ("start_lives", C.c_int32), ("start_jumps", C.c_int32), ("jump_time", C.c_int32), ("chase_time", C.c_int32),
+        ("box_bonus", C.c_int32), ("chase_score_bonus", C.c_int32),
+        ("player_start_tx", C.c_int32), ("player_start_ty", C.c_int32), ("n_enemies", C.c_int32),
+        ("render_images", C.c_uint8), ("default_board_bugs", C.c_uint8), ("_pad0", C.c_uint8 * 2),
+        ("enemies", AmidarAI * AMI_MAX_ENEMIES),
+        ("bg_color", Color), ("player_color", Color), ("unpainted_color", Color), ("painted_color", Color),
+        ("enemy_color", Color), ("inner_painted_color", Color),
+        ("board", (C.c_uint8 * AMI_BOARD_W) * AMI_BOARD_H),
+    ]
+
+
+class AmidarState(C.Structure):
+    _fields_ = [
+        ("rand", C.c_uint64 * 2),
+        ("score", C.c_int32), ("lives", C.c_int32), ("level", C.c_int32),
+        ("jumps", C.c_int32), ("jump_timer", C.c_int32), ("chase_timer", C.c_int32),
+        ("n_enemies", C.c_int32), ("n_boxes", C.c_int32), ("n_chase_junctions", C.c_int32),
+        ("chase_junctions", C.c_int32 * AMI_MAX_CHASE_J),
+        ("player", AmidarMover),
+        ("enemies", AmidarMover * AMI_MAX_ENEMIES),
+        ("boxes", AmidarBox * AMI_MAX_BOXES),
+        ("tiles", (C.c_uint8 * AMI_BOARD_W) * AMI_BOARD_H),
+    ]
+
+
+STATE_TYPES = {GAME_BREAKOUT: BreakoutState, GAME_SPACE_INVADERS: SIState, GAME_AMIDAR: AmidarState}
+CONFIG_TYPES = {GAME_BREAKOUT: BreakoutConfig, GAME_SPACE_INVADERS: SIConfig, GAME_AMIDAR: AmidarConfig}
 
 _p = C.POINTER
 _vp, _i, _u32, _u64, _sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_size_t
@@ -165,6 +215,7 @@ PROTOTYPES = {
     "tbx_set_state": (_i, [_vp, _i, _vp, _sz]),
     "tbx_get_config": (_i, [_vp, _vp, _sz]),
     "tbx_set_config": (_i, [_vp, _vp, _sz]),
+    "tbx_query": (_i, [_vp, _i, _i, _p(C.c_int32), _i, _p(C.c_int32), _i]),
     "tbx_device_buffer": (_i, [_vp, _i, _p(_vp), _p(_sz)]),
     "tbx_sync": (_i, [_vp]),
 }

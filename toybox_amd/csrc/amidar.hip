@@ -1,0 +1,995 @@
+// amidar.hip -- Amidar on gfx950: one 64-lane wavefront per env.
+//
+// Replaces the per-env Rust transition + rasteriser behind ctoybox.Toybox.apply_ale_action /
+// get_state (call sites: /root/reference/toybox/envs/atari/base.py:126,109) for the game the
+// reference registers as AmidarToyboxNoFrameskip-v4 (toybox/__init__.py:14-18).  Rules: DESIGN.md
+// "Amidar"; independently restated in scalar C by the CPU checker under oracle/ and compared bit
+// for bit by tests/test_gpu_parity.py.  Integer arithmetic only.
+//
+// Layout in HBM (env-major tables, so a wave reads its env coalesced):
+//   scalars [field][N] int32 (struct-of-arrays over envs)
+//   tiles   [N][32] uint64   lane = board row, 2 bits per tile (32 tiles)
+//   boxes   [N][2][64] uint32 lane = box (packed corners, flags)
+//   movers  [N][NMF][16] int32 lane = mover slot (0..7 enemies, 8 the player), field-major
+//
+// The maze chase is control-flow heavy and serial per mover (movement protocols, RNG draws in
+// enemy order), so the wave runs the movers one after the other with wave-uniform control flow and
+// uses its lanes for the data-parallel parts: the 31 board rows (segment painting, level-complete
+// test), the <= 64 boxes (perimeter check), and the scanline pixels in the rasteriser.
+
+#include "tbx_common.hpp"
+#include "raster.hpp"
+#include "../../include/toybox_amd_spec.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int BW = TBX_AMI_BOARD_W, BH = TBX_AMI_BOARD_H;
+constexpr int PLAYER_SLOT = TBX_AMI_MAX_ENEMIES;   // lane 8
+
+enum AmiField {
+    A_SCORE, A_LIVES, A_LEVEL, A_JUMPS, A_JUMP_TIMER, A_CHASE_TIMER, A_N_ENEMIES, A_N_BOXES, A_N_CHASE,
+    A_CJ0, A_CJ1, A_CJ2, A_CJ3, A_CJ4, A_CJ5, A_CJ6, A_CJ7, ANF
+};
+enum MoverField {
+    M_X, M_Y, M_SPEED, M_STEP_TX, M_STEP_TY, M_NHIST, M_CAUGHT,
+    M_KIND, M_NEXT, M_ROUTE, M_START_TX, M_START_TY, M_VERT, M_HORIZ, M_SVERT, M_SHORIZ, M_SDIR, M_DIR, M_VISION,
+    M_SEEN_TX, M_SEEN_TY, M_HIST0, NMF = M_HIST0 + TBX_AMI_MAX_HISTORY
+};
+
+// batch-wide tables derived from the config on the host
+struct AmiTables {
+    uint64_t board_rows[32];
+    uint32_t box_geom[TBX_AMI_MAX_BOXES];     // tl_tx | tl_ty << 8 | br_tx << 16 | br_ty << 24
+    uint32_t box_flags[TBX_AMI_MAX_BOXES];    // bit0 painted, bit1 triggers_chase, bit2 valid
+    int32_t n_boxes, n_chase, chase_j[TBX_AMI_MAX_CHASE_J];
+    int32_t n_enemies;
+    int32_t ai[TBX_AMI_MAX_ENEMIES][14];      // tbx_amidar_ai_t fields in declaration order
+    int32_t player_start_tx, player_start_ty, player_hist0;   // player_hist0 < 0: empty history
+    int32_t start_lives, start_jumps, jump_time, chase_time, box_bonus, chase_score_bonus;
+    uint32_t bg, player, unpainted, painted, enemy, inner;
+};
+
+struct AmiDev {
+    int n;
+    uint64_t* sim_rng; int32_t* prev_score; int32_t* reward; uint8_t* done; int32_t* lives_out; int32_t* score_out;
+    uint64_t* packed; uint32_t* err_flag;
+    uint64_t* rng;       // [2][N]
+    int32_t* sc;         // [ANF][N]
+    uint64_t* tiles;     // [N][32]
+    uint32_t* boxes;     // [N][2][64]
+    int32_t* movers;     // [N][NMF][16]
+    const AmiTables* tab;
+};
+
+__constant__ int AMI_ROUTES[TBX_AMI_N_ROUTES][TBX_AMI_ROUTE_LEN] = TBX_AMI_ROUTES;
+
+struct AmiRegs {
+    Rng rng;
+    int32_t f[ANF];
+    uint64_t trow;        // lane = board row
+    uint32_t bgeom, bflags;   // lane = box
+    int32_t mv[NMF];      // lane = mover slot
+};
+
+__device__ __forceinline__ void ami_load(const AmiDev& d, int env, int lane, AmiRegs& s)
+{
+    const size_t N = (size_t)d.n;
+    s.rng.s0 = d.rng[env];
+    s.rng.s1 = d.rng[N + env];
+#pragma unroll
+    for (int i = 0; i < ANF; i++) s.f[i] = d.sc[(size_t)i * N + env];
+    s.trow = d.tiles[(size_t)env * 32 + (lane & 31)];
+    s.bgeom = d.boxes[(size_t)env * 128 + lane];
+    s.bflags = d.boxes[(size_t)env * 128 + 64 + lane];
+    const int32_t* m = d.movers + (size_t)env * NMF * 16;
+#pragma unroll
+    for (int i = 0; i < NMF; i++) s.mv[i] = m[i * 16 + (lane & 15)];
+}
+
+__device__ __forceinline__ void ami_store(const AmiDev& d, int env, int lane, const AmiRegs& s)
+{
+    const size_t N = (size_t)d.n;
+    if (lane == 0) {
+        d.rng[env] = s.rng.s0;
+        d.rng[N + env] = s.rng.s1;
+#pragma unroll
+        for (int i = 0; i < ANF; i++) d.sc[(size_t)i * N + env] = s.f[i];
+    }
+    if (lane < 32) d.tiles[(size_t)env * 32 + lane] = s.trow;
+    d.boxes[(size_t)env * 128 + lane] = s.bgeom;
+    d.boxes[(size_t)env * 128 + 64 + lane] = s.bflags;
+    if (lane < 16) {
+        int32_t* m = d.movers + (size_t)env * NMF * 16;
+#pragma unroll
+        for (int i = 0; i < NMF; i++) m[i * 16 + lane] = s.mv[i];
+    }
+}
+
+// ------------------------------------------------------------------ board helpers (wave-uniform arguments)
+
+__device__ __forceinline__ uint64_t row_of(const AmiRegs& s, int ty)
+{
+    const uint32_t lo = __shfl((uint32_t)s.trow, ty), hi = __shfl((uint32_t)(s.trow >> 32), ty);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+__device__ __forceinline__ int tile_at(const AmiRegs& s, int tx, int ty)
+{
+    if (tx < 0 || ty < 0 || tx >= BW || ty >= BH) return TBX_TILE_EMPTY;
+    return (int)((row_of(s, ty) >> (2 * tx)) & 3ull);
+}
+
+__device__ __forceinline__ bool walkable(const AmiRegs& s, int tx, int ty) { return tile_at(s, tx, ty) != TBX_TILE_EMPTY; }
+
+__device__ __forceinline__ bool is_junction(const AmiRegs& s, int tx, int ty)
+{
+    if (!walkable(s, tx, ty)) return false;
+    const bool h = walkable(s, tx - 1, ty) || walkable(s, tx + 1, ty);
+    const bool v = walkable(s, tx, ty - 1) || walkable(s, tx, ty + 1);
+    return h && v;
+}
+
+__device__ __forceinline__ void dir_delta(int dir, int& dx, int& dy)
+{
+    dx = dir == TBX_DIR_LEFT ? -1 : dir == TBX_DIR_RIGHT ? 1 : 0;
+    dy = dir == TBX_DIR_UP ? -1 : dir == TBX_DIR_DOWN ? 1 : 0;
+}
+
+__device__ __forceinline__ bool can_go(const AmiRegs& s, int tx, int ty, int dir)
+{
+    int dx, dy;
+    dir_delta(dir, dx, dy);
+    return walkable(s, tx + dx, ty + dy);
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------ mover slots
+
+__device__ __forceinline__ int mget(const AmiRegs& s, int field, int slot) { return __shfl(s.mv[field], slot); }
+__device__ __forceinline__ void mset(AmiRegs& s, int lane, int field, int slot, int v)
+{
+    if (lane == slot) s.mv[field] = v;
+}
+
+__device__ __forceinline__ void reset_mover(AmiRegs& s, int lane, int slot, int tx, int ty)
+{
+    if (lane == slot) {
+        s.mv[M_X] = tx * TBX_AMI_TILE_WX; s.mv[M_Y] = ty * TBX_AMI_TILE_WY;
+        s.mv[M_STEP_TX] = -1; s.mv[M_STEP_TY] = -1;
+        s.mv[M_NHIST] = 0;
+#pragma unroll
+        for (int i = 0; i < TBX_AMI_MAX_HISTORY; i++) s.mv[M_HIST0 + i] = 0;
+        s.mv[M_CAUGHT] = 0;
+    }
+}
+
+__device__ __forceinline__ void reset_enemy(AmiRegs& s, int lane, int slot)
+{
+    const int kind = mget(s, M_KIND, slot);
+    int tx, ty;
+    if (kind == TBX_AI_LOOKUP) {
+        const int r = mget(s, M_ROUTE, slot);
+        const int id = (r >= 0 && r < TBX_AMI_N_ROUTES) ? AMI_ROUTES[r][0] : 0;
+        tx = id % BW; ty = id / BW;
+    } else { tx = mget(s, M_START_TX, slot); ty = mget(s, M_START_TY, slot); }
+    if (lane == slot) {
+        if (kind == TBX_AI_LOOKUP) s.mv[M_NEXT] = 0;
+        s.mv[M_VERT] = s.mv[M_SVERT]; s.mv[M_HORIZ] = s.mv[M_SHORIZ]; s.mv[M_DIR] = s.mv[M_SDIR];
+        s.mv[M_SEEN_TX] = -1; s.mv[M_SEEN_TY] = -1;
+    }
+    reset_mover(s, lane, slot, tx, ty);
+}
+
+__device__ __forceinline__ void reset_player(const AmiTables& t, AmiRegs& s, int lane)
+{
+    reset_mover(s, lane, PLAYER_SLOT, t.player_start_tx, t.player_start_ty);
+    // the first junction below the start tile, found on the CURRENT board like the checker does
+    int found = -1;
+    for (int ty = t.player_start_ty + 1; ty < BH; ty++)
+        if (is_junction(s, t.player_start_tx, ty)) { found = ty * BW + t.player_start_tx; break; }
+    if (found >= 0 && lane == PLAYER_SLOT) { s.mv[M_HIST0] = found; s.mv[M_NHIST] = 1; }
+}
+
+__device__ __forceinline__ void reset_board(const AmiTables& t, AmiRegs& s, int lane)
+{
+    s.trow = lane < BH ? t.board_rows[lane] : 0ull;
+    s.f[A_N_CHASE] = t.n_chase;
+#pragma unroll
+    for (int k = 0; k < TBX_AMI_MAX_CHASE_J; k++) s.f[A_CJ0 + k] = k < t.n_chase ? t.chase_j[k] : 0;
+    s.f[A_N_BOXES] = t.n_boxes;
+    s.bgeom = t.box_geom[lane];
+    s.bflags = t.box_flags[lane];
+}
+
+__device__ __forceinline__ void reset_positions(const AmiTables& t, AmiRegs& s, int lane)
+{
+    reset_player(t, s, lane);
+    for (int i = 0; i < s.f[A_N_ENEMIES]; i++) reset_enemy(s, lane, i);
+    s.f[A_JUMP_TIMER] = 0;
+    s.f[A_CHASE_TIMER] = 0;
+}
+
+__device__ __forceinline__ void ami_new_game(const AmiTables& t, int lane, Rng& sim, AmiRegs& s)
+{
+    s.rng = sim.child();
+#pragma unroll
+    for (int i = 0; i < ANF; i++) s.f[i] = 0;
+    s.f[A_LIVES] = t.start_lives;
+    s.f[A_LEVEL] = 1;
+    s.f[A_JUMPS] = t.start_jumps;
+    reset_board(t, s, lane);
+#pragma unroll
+    for (int i = 0; i < NMF; i++) s.mv[i] = 0;
+    s.f[A_N_ENEMIES] = t.n_enemies;
+    if (lane == PLAYER_SLOT) {
+        s.mv[M_SPEED] = TBX_AMI_SPEED; s.mv[M_KIND] = TBX_AI_PLAYER; s.mv[M_SEEN_TX] = -1; s.mv[M_SEEN_TY] = -1;
+    }
+    if (lane < t.n_enemies) {
+        s.mv[M_SPEED] = TBX_AMI_SPEED;
+#pragma unroll
+        for (int k = 0; k < 14; k++) s.mv[M_KIND + k] = t.ai[lane][k];
+    }
+    reset_player(t, s, lane);
+    for (int i = 0; i < t.n_enemies; i++) reset_enemy(s, lane, i);
+}
+
+// ------------------------------------------------------------------ movement
+
+// advance slot toward its step; true when the target tile was reached this frame
+__device__ __forceinline__ bool advance(AmiRegs& s, int lane, int slot)
+{
+    const int stx = mget(s, M_STEP_TX, slot);
+    if (stx < 0) return false;
+    const int sty = mget(s, M_STEP_TY, slot);
+    int x = mget(s, M_X, slot), y = mget(s, M_Y, slot), sp = mget(s, M_SPEED, slot);
+    const int gx = stx * TBX_AMI_TILE_WX, gy = sty * TBX_AMI_TILE_WY;
+    if (sp < 0) sp = 0;
+    if (x < gx) { x += sp; if (x > gx) x = gx; }
+    else if (x > gx) { x -= sp; if (x < gx) x = gx; }
+    else if (y < gy) { y += sp; if (y > gy) y = gy; }
+    else if (y > gy) { y -= sp; if (y < gy) y = gy; }
+    mset(s, lane, M_X, slot, x);
+    mset(s, lane, M_Y, slot, y);
+    if (x == gx && y == gy) {
+        mset(s, lane, M_STEP_TX, slot, -1);
+        mset(s, lane, M_STEP_TY, slot, -1);
+        return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ void set_step(AmiRegs& s, int lane, int slot, int tx, int ty, int dir)
+{
+    int dx, dy;
+    dir_delta(dir, dx, dy);
+    mset(s, lane, M_STEP_TX, slot, tx + dx);
+    mset(s, lane, M_STEP_TY, slot, ty + dy);
+}
+
+__device__ __forceinline__ void push_history(AmiRegs& s, int lane, int slot, int id)
+{
+    int n = mget(s, M_NHIST, slot);
+    if (n >= TBX_AMI_MAX_HISTORY) {
+        if (lane == slot) {
+#pragma unroll
+            for (int i = 1; i < TBX_AMI_MAX_HISTORY; i++) s.mv[M_HIST0 + i - 1] = s.mv[M_HIST0 + i];
+        }
+        n = TBX_AMI_MAX_HISTORY - 1;
+    }
+    if (lane == slot) {
+#pragma unroll
+        for (int i = 0; i < TBX_AMI_MAX_HISTORY; i++)
+            if (i == n) s.mv[M_HIST0 + i] = id;
+        s.mv[M_NHIST] = n + 1;
+    }
+}
+
+__device__ __forceinline__ int last_history(const AmiRegs& s, int slot, int n)
+{
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < TBX_AMI_MAX_HISTORY; i++) {
+        const int h = mget(s, M_HIST0 + i, slot);
+        if (i == n - 1) v = h;
+    }
+    return v;
+}
+
+// lane = box: perimeter test against the rows broadcast one by one
+__device__ __forceinline__ void check_boxes(const AmiTables& t, AmiRegs& s, int lane)
+{
+    const int tl_tx = s.bgeom & 255, tl_ty = (s.bgeom >> 8) & 255, br_tx = (s.bgeom >> 16) & 255, br_ty = (s.bgeom >> 24) & 255;
+    const bool cand = lane < s.f[A_N_BOXES] && !(s.bflags & 1u);
+    bool ok = cand && tl_tx < BW && br_tx < BW && tl_tx <= br_tx;
+    // 2-bit fields tl_tx..br_tx all == PAINTED (binary 10)
+    uint64_t span = 0, want = 0;
+    if (ok) {
+        const int nb = 2 * (br_tx - tl_tx + 1);
+        span = (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull)) << (2 * tl_tx);
+        want = 0xAAAAAAAAAAAAAAAAull & span;
+    }
+    for (int y = 0; y < BH; y++) {
+        const uint64_t row = row_of(s, y);
+        if (ok && y >= tl_ty && y <= br_ty) {
+            if (y == tl_ty || y == br_ty) { if ((row & span) != want) ok = false; }
+            else if (((row >> (2 * tl_tx)) & 3ull) != TBX_TILE_PAINTED || ((row >> (2 * br_tx)) & 3ull) != TBX_TILE_PAINTED) ok = false;
+        }
+    }
+    if (ok && (tl_ty >= BH || br_ty >= BH || tl_ty > br_ty)) ok = false;
+    const uint64_t newly = __ballot(ok);
+    if (!newly) return;
+    if (ok) s.bflags |= 1u;
+    s.f[A_SCORE] += t.box_bonus * __popcll(newly);
+    const bool trig = lane < s.f[A_N_BOXES] && (s.bflags & 2u);
+    if (__ballot(ok && trig) && !__ballot(trig && !(s.bflags & 1u))) s.f[A_CHASE_TIMER] = t.chase_time;
+}
+
+__device__ __forceinline__ void player_arrived(const AmiTables& t, AmiRegs& s, int lane)
+{
+    const int px = mget(s, M_X, PLAYER_SLOT), py = mget(s, M_Y, PLAYER_SLOT);
+    const int tx = px / TBX_AMI_TILE_WX, ty = py / TBX_AMI_TILE_WY;
+    if (!is_junction(s, tx, ty)) return;
+    const int id = ty * BW + tx;
+    int newly = 0;
+    const int nh = mget(s, M_NHIST, PLAYER_SLOT);
+    if (nh > 0) {
+        const int prev = last_history(s, PLAYER_SLOT, nh);
+        const int qx = prev % BW, qy = prev / BW;
+        if (prev != id && prev >= 0 && prev < BW * BH && (qx == tx || qy == ty)) {
+            const int x0 = qx < tx ? qx : tx, x1 = qx < tx ? tx : qx, y0 = qy < ty ? qy : ty, y1 = qy < ty ? ty : qy;
+            const int nb = 2 * (x1 - x0 + 1);
+            const uint64_t span = (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull)) << (2 * x0);
+            const bool mine = lane >= y0 && lane <= y1;
+            // a tile is walkable when its 2-bit tag is non-zero
+            const uint64_t nz = (s.trow | (s.trow >> 1)) & 0x5555555555555555ull;
+            const bool blocked = mine && (nz & span) != (0x5555555555555555ull & span);
+            if (!__ballot(blocked)) {
+                // count tiles not yet PAINTED (tag != 10b), then paint
+                const uint64_t painted = (s.trow >> 1) & ~s.trow & 0x5555555555555555ull;
+                const int cnt = mine ? __popcll((0x5555555555555555ull & span) & ~painted) : 0;
+                newly = wave_sum(cnt);
+                if (mine) s.trow = (s.trow & ~span) | (0xAAAAAAAAAAAAAAAAull & span);
+            }
+        }
+    }
+    push_history(s, lane, PLAYER_SLOT, id);
+    if (newly > 0) {
+        s.f[A_SCORE] += newly;
+        check_boxes(t, s, lane);
+        const bool left = lane < BH && (s.trow & 0x5555555555555555ull) != 0;   // tags 01 / 11 remain
+        if (!__ballot(left)) {
+            s.f[A_LEVEL] += 1;
+            reset_board(t, s, lane);
+            reset_positions(t, s, lane);
+            s.f[A_JUMPS] = t.start_jumps;
+        }
+    }
+}
+
+__device__ __forceinline__ int first_open(const AmiRegs& s, int tx, int ty, int avoid)
+{
+    for (int dd = 0; dd < 4; dd++)
+        if (dd != avoid && can_go(s, tx, ty, dd)) return dd;
+    return (avoid >= 0 && can_go(s, tx, ty, avoid)) ? avoid : -1;
+}
+
+__device__ __forceinline__ void enemy_decide(AmiRegs& s, int lane, int slot)
+{
+    const int x = mget(s, M_X, slot), y = mget(s, M_Y, slot);
+    const int tx = x / TBX_AMI_TILE_WX, ty = y / TBX_AMI_TILE_WY;
+    const int kind = mget(s, M_KIND, slot);
+    int dir = -1;
+    if (kind == TBX_AI_LOOKUP) {
+        const int r = mget(s, M_ROUTE, slot);
+        if (r < 0 || r >= TBX_AMI_N_ROUTES) return;
+        int len = 0;
+        while (len < TBX_AMI_ROUTE_LEN && AMI_ROUTES[r][len] >= 0) len++;
+        int next = mget(s, M_NEXT, slot);
+        if (next < 0 || next >= len) next = 0;
+        if (AMI_ROUTES[r][next] == ty * BW + tx) next = (next + 1) % len;
+        mset(s, lane, M_NEXT, slot, next);
+        const int gx = AMI_ROUTES[r][next] % BW, gy = AMI_ROUTES[r][next] / BW;
+        if (gx > tx && can_go(s, tx, ty, TBX_DIR_RIGHT)) dir = TBX_DIR_RIGHT;
+        else if (gx < tx && can_go(s, tx, ty, TBX_DIR_LEFT)) dir = TBX_DIR_LEFT;
+        else if (gy > ty && can_go(s, tx, ty, TBX_DIR_DOWN)) dir = TBX_DIR_DOWN;
+        else if (gy < ty && can_go(s, tx, ty, TBX_DIR_UP)) dir = TBX_DIR_UP;
+    } else if (kind == TBX_AI_PERIMETER) {
+        if (ty == 0 && tx < BW - 1 && can_go(s, tx, ty, TBX_DIR_RIGHT)) dir = TBX_DIR_RIGHT;
+        else if (tx == BW - 1 && ty < BH - 1 && can_go(s, tx, ty, TBX_DIR_DOWN)) dir = TBX_DIR_DOWN;
+        else if (ty == BH - 1 && tx > 0 && can_go(s, tx, ty, TBX_DIR_LEFT)) dir = TBX_DIR_LEFT;
+        else if (tx == 0 && ty > 0 && can_go(s, tx, ty, TBX_DIR_UP)) dir = TBX_DIR_UP;
+        else {
+            const int order[4] = {TBX_DIR_UP, TBX_DIR_LEFT, TBX_DIR_DOWN, TBX_DIR_RIGHT};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (dir < 0 && can_go(s, tx, ty, order[k])) dir = order[k];
+        }
+    } else if (kind == TBX_AI_AMIDAR) {
+        int vert = mget(s, M_VERT, slot) & 1;
+        int horiz = 2 | (mget(s, M_HORIZ, slot) & 1);
+        bool came_vertically = true;
+        const int nh = mget(s, M_NHIST, slot);
+        if (nh > 0) came_vertically = (last_history(s, slot, nh) % BW) == tx;
+        const bool can_h = can_go(s, tx, ty, horiz), can_v = can_go(s, tx, ty, vert);
+        if (came_vertically && can_h) dir = horiz;
+        else if (can_v) dir = vert;
+        else if (can_h) dir = horiz;
+        else {
+            vert ^= 1; horiz ^= 1;
+            if (can_go(s, tx, ty, vert)) dir = vert;
+            else if (can_go(s, tx, ty, horiz)) dir = horiz;
+        }
+        mset(s, lane, M_VERT, slot, vert);
+        mset(s, lane, M_HORIZ, slot, horiz);
+    } else if (kind == TBX_AI_TARGET_PLAYER) {
+        const int ptx = mget(s, M_X, PLAYER_SLOT) / TBX_AMI_TILE_WX, pty = mget(s, M_Y, PLAYER_SLOT) / TBX_AMI_TILE_WY;
+        const int ddx = ptx - tx, ddy = pty - ty;
+        const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
+        int cur = mget(s, M_DIR, slot) & 3;
+        if (adx + ady <= mget(s, M_VISION, slot)) {
+            mset(s, lane, M_SEEN_TX, slot, ptx);
+            mset(s, lane, M_SEEN_TY, slot, pty);
+            const int hd = ddx > 0 ? TBX_DIR_RIGHT : TBX_DIR_LEFT, vd = ddy > 0 ? TBX_DIR_DOWN : TBX_DIR_UP;
+            const int first = adx >= ady ? hd : vd, second = adx >= ady ? vd : hd;
+            const int fz = adx >= ady ? adx : ady, sz = adx >= ady ? ady : adx;
+            if (fz > 0 && can_go(s, tx, ty, first)) dir = first;
+            else if (sz > 0 && can_go(s, tx, ty, second)) dir = second;
+        } else {
+            mset(s, lane, M_SEEN_TX, slot, -1);
+            mset(s, lane, M_SEEN_TY, slot, -1);
+        }
+        if (dir < 0) dir = can_go(s, tx, ty, cur) ? cur : first_open(s, tx, ty, cur ^ 1);
+        if (dir >= 0) cur = dir;
+        mset(s, lane, M_DIR, slot, cur);
+    } else if (kind == TBX_AI_RANDOM) {
+        int cur = mget(s, M_DIR, slot) & 3;
+        int opts[4], n = 0;
+#pragma unroll
+        for (int dd = 0; dd < 4; dd++)
+            if (dd != (cur ^ 1) && can_go(s, tx, ty, dd)) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (k == n) opts[k] = dd;
+                n++;
+            }
+        if (n == 0) dir = can_go(s, tx, ty, cur ^ 1) ? (cur ^ 1) : -1;
+        else {
+            const int k = (int)s.rng.range((uint64_t)n);
+            dir = k == 0 ? opts[0] : k == 1 ? opts[1] : k == 2 ? opts[2] : opts[3];
+        }
+        if (dir >= 0) cur = dir;
+        mset(s, lane, M_DIR, slot, cur);
+    } else {
+        return;
+    }
+    if (dir >= 0) set_step(s, lane, slot, tx, ty, dir);
+}
+
+__device__ __forceinline__ bool at_tile(const AmiRegs& s, int slot)
+{
+    return mget(s, M_X, slot) % TBX_AMI_TILE_WX == 0 && mget(s, M_Y, slot) % TBX_AMI_TILE_WY == 0;
+}
+
+__device__ __forceinline__ void ami_step(const AmiTables& t, int lane, uint32_t buttons, AmiRegs& s)
+{
+    int32_t* f = s.f;
+    // 1. timers
+    if (f[A_JUMP_TIMER] > 0) f[A_JUMP_TIMER] -= 1;
+    if (f[A_CHASE_TIMER] > 0) {
+        f[A_CHASE_TIMER] -= 1;
+        if (f[A_CHASE_TIMER] == 0)
+            for (int i = 0; i < f[A_N_ENEMIES]; i++)
+                if (mget(s, M_CAUGHT, i)) reset_enemy(s, lane, i);
+    }
+    // 2. jump
+    if ((buttons & TBX_BTN_BUTTON1) && f[A_JUMPS] > 0 && f[A_JUMP_TIMER] == 0) { f[A_JUMPS] -= 1; f[A_JUMP_TIMER] = t.jump_time; }
+
+    // 3. player
+    if (mget(s, M_STEP_TX, PLAYER_SLOT) < 0 && at_tile(s, PLAYER_SLOT)) {
+        const int tx = mget(s, M_X, PLAYER_SLOT) / TBX_AMI_TILE_WX, ty = mget(s, M_Y, PLAYER_SLOT) / TBX_AMI_TILE_WY;
+        const int dir = (buttons & TBX_BTN_UP) ? TBX_DIR_UP : (buttons & TBX_BTN_DOWN) ? TBX_DIR_DOWN :
+                        (buttons & TBX_BTN_LEFT) ? TBX_DIR_LEFT : (buttons & TBX_BTN_RIGHT) ? TBX_DIR_RIGHT : -1;
+        if (dir >= 0 && can_go(s, tx, ty, dir)) set_step(s, lane, PLAYER_SLOT, tx, ty, dir);
+    }
+    const int level_before = f[A_LEVEL];
+    if (advance(s, lane, PLAYER_SLOT)) player_arrived(t, s, lane);
+    if (f[A_LEVEL] != level_before) return;
+
+    // 4. enemies, in index order
+    for (int i = 0; i < f[A_N_ENEMIES]; i++) {
+        if (mget(s, M_CAUGHT, i)) continue;
+        if (mget(s, M_STEP_TX, i) < 0 && at_tile(s, i)) enemy_decide(s, lane, i);
+        if (advance(s, lane, i)) {
+            if (mget(s, M_KIND, i) != TBX_AI_LOOKUP) {
+                const int id = (mget(s, M_Y, i) / TBX_AMI_TILE_WY) * BW + mget(s, M_X, i) / TBX_AMI_TILE_WX;
+                mset(s, lane, M_NHIST, i, 0);
+                push_history(s, lane, i, id);
+            }
+        }
+    }
+
+    // 5. collisions
+    const int px = mget(s, M_X, PLAYER_SLOT), py = mget(s, M_Y, PLAYER_SLOT);
+    for (int i = 0; i < f[A_N_ENEMIES]; i++) {
+        if (mget(s, M_CAUGHT, i)) continue;
+        int dx = mget(s, M_X, i) - px, dy = mget(s, M_Y, i) - py;
+        if (dx < 0) dx = -dx;
+        if (dy < 0) dy = -dy;
+        if (dx >= TBX_AMI_HIT_DX || dy >= TBX_AMI_HIT_DY) continue;
+        if (f[A_JUMP_TIMER] > 0) continue;
+        if (f[A_CHASE_TIMER] > 0) { mset(s, lane, M_CAUGHT, i, 1); f[A_SCORE] += t.chase_score_bonus; continue; }
+        f[A_LIVES] -= 1;
+        reset_positions(t, s, lane);
+        break;
+    }
+}
+
+// ------------------------------------------------------------------ kernels
+
+__global__ __launch_bounds__(TBX_BLOCK) void ami_new_game_kernel(AmiDev d, const uint8_t* mask)
+{
+    const int lane = threadIdx.x & 63;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (env >= d.n) return;
+    if (mask && !mask[env]) return;
+    const size_t N = (size_t)d.n;
+    Rng sim;
+    sim.s0 = d.sim_rng[env];
+    sim.s1 = d.sim_rng[N + env];
+    AmiRegs s;
+    ami_new_game(*d.tab, lane, sim, s);
+    ami_store(d, env, lane, s);
+    if (lane == 0) {
+        d.sim_rng[env] = sim.s0;
+        d.sim_rng[N + env] = sim.s1;
+        d.prev_score[env] = s.f[A_SCORE];
+    }
+}
+
+__global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, ActionSource src, uint32_t flags, int first_env, int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (rel >= count) return;
+    const int env = first_env + rel;
+    const size_t N = (size_t)d.n;
+
+    uint32_t buttons;
+    if (src.single_env >= 0) {
+        buttons = src.single_buttons;
+    } else {
+        int a;
+        if (src.actions) a = src.actions[env];
+        else {
+            uint64_t h = tbx_splitmix64(src.seed ^ ((src.env_offset + (uint64_t)env) << 32) ^ src.t);
+            a = tbx_legal_action(TBX_GAME_AMIDAR, (int)(h % 6ull));
+        }
+        buttons = tbx_ale_buttons(a);
+        if (buttons == 0xFFu) {
+            buttons = 0;
+            if (lane == 0) atomicOr(d.err_flag, 1u);
+        }
+    }
+
+    AmiRegs s;
+    ami_load(d, env, lane, s);
+    ami_step(*d.tab, lane, buttons, s);
+
+    int32_t rew = s.f[A_SCORE] - d.prev_score[env];
+    if (rew < 0) rew = 0;
+    const int32_t out_lives = s.f[A_LIVES], out_score = s.f[A_SCORE];
+    const bool is_done = out_lives <= 0;
+    int32_t prev = out_score;
+    if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+        Rng sim;
+        sim.s0 = d.sim_rng[env];
+        sim.s1 = d.sim_rng[N + env];
+        ami_new_game(*d.tab, lane, sim, s);
+        if (lane == 0) { d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1; }
+        prev = s.f[A_SCORE];
+    }
+    ami_store(d, env, lane, s);
+    if (lane == 0) {
+        d.prev_score[env] = prev;
+        d.reward[env] = rew;
+        d.done[env] = is_done ? 1 : 0;
+        d.lives_out[env] = out_lives;
+        d.score_out[env] = out_score;
+        uint32_t lv = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
+        d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv << 40);
+    }
+}
+
+// ------------------------------------------------------------------ render
+
+__constant__ uint16_t AMI_DIGITS[10] = TBX_DIGIT_FONT;
+constexpr int AMI_UNIT_ROWS = 10;   // 250 = 25 units; 10 x 480 B (RGB) of LDS per wave
+
+__device__ __forceinline__ int world_to_px(int v)
+{
+    return v >= 0 ? v / TBX_AMI_WORLD_SCALE : -((-v + TBX_AMI_WORLD_SCALE - 1) / TBX_AMI_WORLD_SCALE);
+}
+
+// One wave rasterises one env; lane l makes pixels 4l..4l+3 of each scanline (160 px = 40 lanes).
+// In the board band a lane's 4 pixels are exactly one tile (tile = 4x5 px, board origin x = 16).
+template <int C>
+__global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t* out, int first_env, int count)
+{
+    constexpr int W = TBX_AMI_W, H = TBX_AMI_H;
+    using Stager = RowStager<C, W, AMI_UNIT_ROWS>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (rel >= count) return;
+    const int env = first_env + rel;
+    Stager st{lds_all + wave * Stager::UNIT_BYTES};
+    const AmiTables& t = *d.tab;
+
+    AmiRegs s;
+    ami_load(d, env, lane, s);
+    const int32_t* f = s.f;
+    const int x0 = lane * 4;
+    const bool active = x0 < W;
+    const int tx = lane - TBX_AMI_BOARD_OX / 4;          // tile column of this lane in the board band
+    const bool in_board_x = tx >= 0 && tx < BW;
+
+    // lane = board row: which tiles lie strictly inside a painted box
+    uint32_t inner = 0;
+    for (int b = 0; b < f[A_N_BOXES]; b++) {
+        const uint32_t g = __shfl(s.bgeom, b), fl = __shfl(s.bflags, b);
+        if (!(fl & 1u)) continue;
+        const int tl_tx = g & 255, tl_ty = (g >> 8) & 255, br_tx = (g >> 16) & 255, br_ty = (g >> 24) & 255;
+        if (lane > tl_ty && lane < br_ty && br_tx - tl_tx >= 2) {
+            const int lo = tl_tx + 1, hi = br_tx - 1;   // inclusive
+            if (lo < 32) {
+                const int h2 = hi > 31 ? 31 : hi;
+                if (h2 >= lo) inner |= (h2 - lo + 1 >= 32 ? ~0u : ((1u << (h2 - lo + 1)) - 1u)) << lo;
+            }
+        }
+    }
+    // lane = mover slot: screen rects
+    const bool m_on = lane == PLAYER_SLOT || (lane < f[A_N_ENEMIES] && !s.mv[M_CAUGHT]);
+    const int m_x0 = TBX_AMI_BOARD_OX + world_to_px(s.mv[M_X]) - 1, m_y0 = TBX_AMI_BOARD_OY + world_to_px(s.mv[M_Y]) - 1;
+
+    // HUD bits per pixel
+    uint32_t hud[4] = {0, 0, 0, 0};
+    {
+        int sc = f[A_SCORE];
+        if (sc < 0) sc = 0;
+        sc %= 100000;
+        int lv = f[A_LIVES];
+        lv = lv < 0 ? 0 : lv > 9 ? 9 : lv;
+        int jp = f[A_JUMPS];
+        jp = jp < 0 ? 0 : jp > 9 ? 9 : jp;
+        int le = f[A_LEVEL];
+        if (le < 0) le = 0;
+        le %= 10;
+        const int hud_x0[8] = {20, 28, 36, 44, 52, 84, 108, 132};
+        int div = 10000;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            int digit;
+            if (q < 5) { digit = (sc / div) % 10; div /= 10; }
+            else digit = q == 5 ? lv : q == 6 ? jp : le;
+            const uint32_t glyph = AMI_DIGITS[digit];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int dx = x0 + i - hud_x0[q];
+                if (dx >= 0 && dx < 6) hud[i] = (glyph >> (dx >> 1)) & 0x1249u;
+            }
+        }
+    }
+
+    uint8_t* frame = out + (size_t)rel * H * W * C;
+    constexpr int NUNITS = H / AMI_UNIT_ROWS;
+    const int u0 = (int)(((uint32_t)env * 7u) % (uint32_t)NUNITS);
+    for (int k = 0; k < NUNITS; k++) {
+        int u = u0 + k;
+        if (u >= NUNITS) u -= NUNITS;
+#pragma unroll 1
+        for (int r = 0; r < AMI_UNIT_ROWS; r++) {
+            const int y = u * AMI_UNIT_ROWS + r;
+            uint32_t px[4] = {t.bg, t.bg, t.bg, t.bg};
+            const int by = y - TBX_AMI_BOARD_OY;
+            if (by >= 0 && by < BH * TBX_AMI_TILE_PH) {
+                const int ty = by / TBX_AMI_TILE_PH;
+                const uint64_t row = row_of(s, ty);
+                const uint32_t inn = __shfl(inner, ty);
+                if (in_board_x) {
+                    const int tag = (int)((row >> (2 * tx)) & 3ull);
+                    uint32_t col = t.bg;
+                    if (tag == TBX_TILE_EMPTY) { if ((inn >> tx) & 1u) col = t.inner; }
+                    else col = tag == TBX_TILE_PAINTED ? t.painted : t.unpainted;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) px[i] = col;
+                }
+            }
+            // movers: enemies in index order, then the player
+            {
+                uint64_t m = __ballot(m_on && y >= m_y0 && y < m_y0 + TBX_AMI_MOVER_H);
+                const bool player_here = (m >> PLAYER_SLOT) & 1;
+                m &= (1ull << PLAYER_SLOT) - 1;
+                while (m) {
+                    const int src = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const int sx = __shfl(m_x0, src);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = t.enemy;
+                }
+                if (player_here) {
+                    const int sx = __shfl(m_x0, PLAYER_SLOT);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = t.player;
+                }
+            }
+            if (y >= TBX_AMI_HUD_Y && y < TBX_AMI_HUD_Y + 10) {
+                const int gr = ((y - TBX_AMI_HUD_Y) >> 1) * 3;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if ((hud[i] >> gr) & 1u) px[i] = t.player;
+            }
+            if (active) st.put4(r, lane, px[0], px[1], px[2], px[3]);
+        }
+        st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
+    }
+}
+
+// ------------------------------------------------------------------ state pack / unpack, scalars
+
+__device__ __forceinline__ void mover_out(const AmiRegs& s, tbx_amidar_mover_t& m)
+{
+    m.x = s.mv[M_X]; m.y = s.mv[M_Y]; m.speed = s.mv[M_SPEED]; m.step_tx = s.mv[M_STEP_TX]; m.step_ty = s.mv[M_STEP_TY];
+    m.n_history = s.mv[M_NHIST];
+    for (int i = 0; i < TBX_AMI_MAX_HISTORY; i++) m.history[i] = s.mv[M_HIST0 + i];
+    m.caught = s.mv[M_CAUGHT];
+    int32_t* a = &m.ai.kind;
+    for (int k = 0; k < 14; k++) a[k] = s.mv[M_KIND + k];
+}
+
+__global__ void ami_pack_kernel(AmiDev d, int env, tbx_amidar_state_t* out)
+{
+    const int lane = threadIdx.x & 63;
+    AmiRegs s;
+    ami_load(d, env, lane, s);
+    const int32_t* f = s.f;
+    if (lane == 0) {
+        out->rand[0] = s.rng.s0; out->rand[1] = s.rng.s1;
+        out->score = f[A_SCORE]; out->lives = f[A_LIVES]; out->level = f[A_LEVEL];
+        out->jumps = f[A_JUMPS]; out->jump_timer = f[A_JUMP_TIMER]; out->chase_timer = f[A_CHASE_TIMER];
+        out->n_enemies = f[A_N_ENEMIES]; out->n_boxes = f[A_N_BOXES]; out->n_chase_junctions = f[A_N_CHASE];
+        for (int k = 0; k < TBX_AMI_MAX_CHASE_J; k++) out->chase_junctions[k] = f[A_CJ0 + k];
+    }
+    if (lane == PLAYER_SLOT) mover_out(s, out->player);
+    if (lane < TBX_AMI_MAX_ENEMIES) {
+        if (lane < f[A_N_ENEMIES]) mover_out(s, out->enemies[lane]);
+        else memset(&out->enemies[lane], 0, sizeof(tbx_amidar_mover_t));
+    }
+    {
+        tbx_amidar_box_t b;
+        memset(&b, 0, sizeof b);
+        if (lane < f[A_N_BOXES]) {
+            b.tl_tx = s.bgeom & 255; b.tl_ty = (s.bgeom >> 8) & 255; b.br_tx = (s.bgeom >> 16) & 255; b.br_ty = (s.bgeom >> 24) & 255;
+            b.painted = s.bflags & 1u; b.triggers_chase = (s.bflags >> 1) & 1u;
+        }
+        out->boxes[lane] = b;
+    }
+    if (lane < BH)
+        for (int x = 0; x < BW; x++) out->tiles[lane][x] = (uint8_t)((s.trow >> (2 * x)) & 3ull);
+}
+
+__device__ __forceinline__ void mover_in(const tbx_amidar_mover_t& m, AmiRegs& s)
+{
+    s.mv[M_X] = m.x; s.mv[M_Y] = m.y; s.mv[M_SPEED] = m.speed; s.mv[M_STEP_TX] = m.step_tx; s.mv[M_STEP_TY] = m.step_ty;
+    s.mv[M_NHIST] = m.n_history;
+    for (int i = 0; i < TBX_AMI_MAX_HISTORY; i++) s.mv[M_HIST0 + i] = m.history[i];
+    s.mv[M_CAUGHT] = m.caught;
+    const int32_t* a = &m.ai.kind;
+    for (int k = 0; k < 14; k++) s.mv[M_KIND + k] = a[k];
+}
+
+__global__ void ami_unpack_kernel(AmiDev d, int env, const tbx_amidar_state_t* in)
+{
+    const int lane = threadIdx.x & 63;
+    AmiRegs s;
+    int32_t* f = s.f;
+    s.rng.s0 = in->rand[0]; s.rng.s1 = in->rand[1];
+    f[A_SCORE] = in->score; f[A_LIVES] = in->lives; f[A_LEVEL] = in->level;
+    f[A_JUMPS] = in->jumps; f[A_JUMP_TIMER] = in->jump_timer; f[A_CHASE_TIMER] = in->chase_timer;
+    f[A_N_ENEMIES] = in->n_enemies; f[A_N_BOXES] = in->n_boxes; f[A_N_CHASE] = in->n_chase_junctions;
+    for (int k = 0; k < TBX_AMI_MAX_CHASE_J; k++) f[A_CJ0 + k] = in->chase_junctions[k];
+    for (int i = 0; i < NMF; i++) s.mv[i] = 0;
+    const int slot = lane & 15;
+    if (slot == PLAYER_SLOT) mover_in(in->player, s);
+    else if (slot < in->n_enemies) mover_in(in->enemies[slot], s);
+    s.bgeom = 0; s.bflags = 0;
+    if (lane < in->n_boxes) {
+        const tbx_amidar_box_t& b = in->boxes[lane];
+        s.bgeom = (uint32_t)(b.tl_tx & 255) | ((uint32_t)(b.tl_ty & 255) << 8) | ((uint32_t)(b.br_tx & 255) << 16) | ((uint32_t)(b.br_ty & 255) << 24);
+        s.bflags = (b.painted ? 1u : 0u) | (b.triggers_chase ? 2u : 0u) | 4u;
+    }
+    s.trow = 0;
+    if (lane < BH)
+        for (int x = 0; x < BW; x++) s.trow |= (uint64_t)(in->tiles[lane][x] & 3) << (2 * x);
+    ami_store(d, env, lane, s);
+}
+
+__global__ void ami_scalars_kernel(AmiDev d, int32_t* score, int32_t* lives, int32_t* level)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    const size_t N = (size_t)d.n;
+    if (score) score[i] = d.sc[(size_t)A_SCORE * N + i];
+    if (lives) lives[i] = d.sc[(size_t)A_LIVES * N + i];
+    if (level) level[i] = d.sc[(size_t)A_LEVEL * N + i];
+}
+
+// ------------------------------------------------------------------ host ops
+
+struct AmiOps : GameOps {
+    AmiDev d{};
+    tbx_amidar_config_t cfg{};
+    AmiTables tab{};
+    AmiTables* tab_dev = nullptr;
+
+    int height() const override { return TBX_AMI_H; }
+    int width() const override { return TBX_AMI_W; }
+    size_t state_size() const override { return sizeof(tbx_amidar_state_t); }
+    size_t config_size() const override { return sizeof(tbx_amidar_config_t); }
+
+    static bool walk(const tbx_amidar_config_t& k, int tx, int ty)
+    {
+        return tx >= 0 && ty >= 0 && tx < BW && ty < BH && k.board[ty][tx] != TBX_TILE_EMPTY;
+    }
+
+    // board-derived tables (boxes = maximal empty rectangles recorded by their track corners, row-major scan)
+    int build_tables(tbx_engine* e, const tbx_amidar_config_t& k)
+    {
+        if (k.n_enemies < 0 || k.n_enemies > TBX_AMI_MAX_ENEMIES) return e->fail(TBX_E_UNSUPPORTED, "amidar: at most 8 enemies");
+        AmiTables t;
+        memset(&t, 0, sizeof t);
+        for (int y = 0; y < BH; y++)
+            for (int x = 0; x < BW; x++) t.board_rows[y] |= (uint64_t)(k.board[y][x] & 3) << (2 * x);
+        for (int y = 0; y < BH; y++)
+            for (int x = 0; x < BW; x++)
+                if (k.board[y][x] == TBX_TILE_CHASE_MARKER && t.n_chase < TBX_AMI_MAX_CHASE_J) t.chase_j[t.n_chase++] = y * BW + x;
+        for (int ty = 0; ty < BH - 1; ty++)
+            for (int tx = 0; tx < BW - 1; tx++) {
+                if (!walk(k, tx, ty) || !walk(k, tx + 1, ty) || !walk(k, tx, ty + 1) || walk(k, tx + 1, ty + 1)) continue;
+                int x1 = tx + 1, y1 = ty + 1;
+                while (x1 < BW && !walk(k, x1, ty + 1)) x1++;
+                while (y1 < BH && !walk(k, tx + 1, y1)) y1++;
+                if (x1 >= BW || y1 >= BH || t.n_boxes >= TBX_AMI_MAX_BOXES) continue;
+                uint32_t fl = 4u;
+                for (int q = 0; q < t.n_chase; q++)
+                    if (t.chase_j[q] == ty * BW + tx) fl |= 2u;
+                t.box_geom[t.n_boxes] = (uint32_t)tx | ((uint32_t)ty << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
+                t.box_flags[t.n_boxes] = fl;
+                t.n_boxes++;
+            }
+        t.n_enemies = k.n_enemies;
+        for (int i = 0; i < k.n_enemies; i++) memcpy(t.ai[i], &k.enemies[i], sizeof(int32_t) * 14);
+        t.player_start_tx = k.player_start_tx; t.player_start_ty = k.player_start_ty; t.player_hist0 = -1;
+        t.start_lives = k.start_lives; t.start_jumps = k.start_jumps; t.jump_time = k.jump_time; t.chase_time = k.chase_time;
+        t.box_bonus = k.box_bonus; t.chase_score_bonus = k.chase_score_bonus;
+        t.bg = pack_color(k.bg_color); t.player = pack_color(k.player_color); t.unpainted = pack_color(k.unpainted_color);
+        t.painted = pack_color(k.painted_color); t.enemy = pack_color(k.enemy_color); t.inner = pack_color(k.inner_painted_color);
+        cfg = k;
+        tab = t;
+        return TBX_OK;
+    }
+
+    int upload(tbx_engine* e)
+    {
+        TBX_HIP(hipMemcpy(tab_dev, &tab, sizeof tab, hipMemcpyHostToDevice));
+        return TBX_OK;
+    }
+
+    int init(tbx_engine* e, const void* cfg_pod, size_t cfg_size) override
+    {
+        static_assert(sizeof(tbx_amidar_ai_t) == 14 * sizeof(int32_t), "tbx_amidar_ai_t is 14 int32 fields");
+        if (!cfg_pod || cfg_size != sizeof(tbx_amidar_config_t)) return e->fail(TBX_E_INVALID, "amidar: config size mismatch");
+        tbx_amidar_config_t k;
+        memcpy(&k, cfg_pod, sizeof k);
+        int rc = build_tables(e, k);
+        if (rc) return rc;
+        const size_t N = (size_t)e->n;
+        d.n = e->n;
+        d.sim_rng = e->sim_rng; d.prev_score = e->prev_score; d.reward = e->reward; d.done = e->done;
+        d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed; d.err_flag = e->err_flag;
+        TBX_HIP(hipMalloc((void**)&d.rng, 2 * N * sizeof(uint64_t)));
+        TBX_HIP(hipMalloc((void**)&d.sc, (size_t)ANF * N * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&d.tiles, N * 32 * sizeof(uint64_t)));
+        TBX_HIP(hipMalloc((void**)&d.boxes, N * 128 * sizeof(uint32_t)));
+        TBX_HIP(hipMalloc((void**)&d.movers, N * NMF * 16 * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&tab_dev, sizeof(AmiTables)));
+        d.tab = tab_dev;
+        return upload(e);
+    }
+
+    void destroy(tbx_engine*) override
+    {
+        hipFree(d.rng); hipFree(d.sc); hipFree(d.tiles); hipFree(d.boxes); hipFree(d.movers); hipFree(tab_dev);
+    }
+
+    int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
+    int set_config(tbx_engine* e, const void* pod) override
+    {
+        tbx_amidar_config_t k;
+        memcpy(&k, pod, sizeof k);
+        int rc = build_tables(e, k);
+        if (rc) return rc;
+        return upload(e);
+    }
+
+    static dim3 grid_for(int count) { return dim3((count + TBX_WAVES_PER_BLOCK - 1) / TBX_WAVES_PER_BLOCK); }
+
+    int new_game(tbx_engine* e, const uint8_t* mask_dev, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(ami_new_game_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, mask_dev);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
+    {
+        int first = 0, count = e->n;
+        if (src.single_env >= 0) { first = src.single_env; count = 1; }
+        hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
+    {
+        switch (channels) {
+        case 1: hipLaunchKernelGGL(ami_render_kernel<1>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        case 3: hipLaunchKernelGGL(ami_render_kernel<3>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        case 4: hipLaunchKernelGGL(ami_render_kernel<4>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+        }
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int pack_state(tbx_engine* e, int env, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(ami_pack_kernel, dim3(1), dim3(64), 0, s, d, env, (tbx_amidar_state_t*)e->staging);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int unpack_state(tbx_engine* e, int env, const void* pod_host, hipStream_t s) override
+    {
+        const auto& st = *(const tbx_amidar_state_t*)pod_host;
+        if (st.n_enemies < 0 || st.n_enemies > TBX_AMI_MAX_ENEMIES) return e->fail(TBX_E_UNSUPPORTED, "amidar: the device engine holds at most 8 enemies per env");
+        if (st.n_boxes < 0 || st.n_boxes > TBX_AMI_MAX_BOXES) return e->fail(TBX_E_UNSUPPORTED, "amidar: the device engine holds at most 64 boxes per env");
+        TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof st, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(ami_unpack_kernel, dim3(1), dim3(64), 0, s, d, env, (const tbx_amidar_state_t*)e->staging);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int scalars(tbx_engine* e, int32_t* score_dev, int32_t* lives_dev, int32_t* level_dev, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(ami_scalars_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, score_dev, lives_dev, level_dev);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+};
+
+}  // namespace
+
+GameOps* tbx_make_amidar_ops() { return new AmiOps(); }

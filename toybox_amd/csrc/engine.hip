@@ -76,6 +76,41 @@ void si_default_config(tbx_si_config_t* c)
     for (int i = 0; i < 3; i++) { c->shield_x[i] = sx[i]; c->shield_y[i] = 157; }
 }
 
+void amidar_default_config(tbx_amidar_config_t* c)
+{
+    static const char* board[TBX_AMI_BOARD_H] = {
+        "c========================c======", "=     =   =   =  =   =   =     =", "=     =   =   =  =   =   =     =",
+        "=     =   =   =  =   =   =     =", "=     =   =   =  =   =   =     =", "=     =   =   =  =   =   =     =",
+        "================================", "=   =    =  =      =  =    =   =", "=   =    =  =      =  =    =   =",
+        "=   =    =  =      =  =    =   =", "=   =    =  =      =  =    =   =", "=   =    =  =      =  =    =   =",
+        "================================", "=  =       =        =       =  p", "=  =       =        =       =  p",
+        "=  =       =        =       =  p", "=  =       =        =       =  p", "=  =       =        =       =  p",
+        "===============================p", "=    =        =  =        =    =", "=    =        =  =        =    =",
+        "=    =        =  =        =    =", "=    =        =  =        =    =", "=    =        =  =        =    =",
+        "c========================c======", "=     =     =      =     =     =", "=     =     =      =     =     =",
+        "=     =     =      =     =     =", "=     =     =      =     =     =", "=     =     =      =     =     =",
+        "================================"};
+    memset(c, 0, sizeof *c);
+    tbx_seed_state(13, c->rand[0], c->rand[1]);
+    c->start_lives = 3; c->start_jumps = 4; c->jump_time = 75; c->chase_time = 300;
+    c->box_bonus = 50; c->chase_score_bonus = 100;
+    c->player_start_tx = 31; c->player_start_ty = 15;
+    c->n_enemies = 5;
+    c->render_images = 1; c->default_board_bugs = 1;
+    for (int i = 0; i < 5; i++) {
+        c->enemies[i].kind = TBX_AI_LOOKUP; c->enemies[i].default_route_index = i;
+        c->enemies[i].seen_tx = c->enemies[i].seen_ty = -1;
+    }
+    c->bg_color = tbx_color_t{0, 0, 0, 255}; c->player_color = tbx_color_t{255, 255, 153, 255};
+    c->unpainted_color = tbx_color_t{148, 0, 211, 255}; c->painted_color = tbx_color_t{255, 255, 30, 255};
+    c->enemy_color = tbx_color_t{255, 50, 100, 255}; c->inner_painted_color = tbx_color_t{255, 255, 0, 255};
+    for (int y = 0; y < TBX_AMI_BOARD_H; y++)
+        for (int x = 0; x < TBX_AMI_BOARD_W; x++) {
+            const char ch = board[y][x];
+            c->board[y][x] = ch == '=' ? TBX_TILE_UNPAINTED : ch == 'p' ? TBX_TILE_PAINTED : ch == 'c' ? TBX_TILE_CHASE_MARKER : TBX_TILE_EMPTY;
+        }
+}
+
 __global__ void seed_kernel(uint64_t* sim_rng, int n, int env, uint32_t seed)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -132,6 +167,7 @@ int tbx_frame_dims(int game, int* h, int* w)
     switch (game) {
     case TBX_GAME_BREAKOUT: *h = TBX_BRK_H; *w = TBX_BRK_W; return TBX_OK;
     case TBX_GAME_SPACE_INVADERS: *h = TBX_SI_H; *w = TBX_SI_W; return TBX_OK;
+    case TBX_GAME_AMIDAR: *h = TBX_AMI_H; *w = TBX_AMI_W; return TBX_OK;
     default: return TBX_E_INVALID;
     }
 }
@@ -155,6 +191,7 @@ size_t tbx_state_size(int game)
     switch (game) {
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_state_t);
     case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_state_t);
+    case TBX_GAME_AMIDAR: return sizeof(tbx_amidar_state_t);
     default: return 0;
     }
 }
@@ -164,6 +201,7 @@ size_t tbx_config_size(int game)
     switch (game) {
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_config_t);
     case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_config_t);
+    case TBX_GAME_AMIDAR: return sizeof(tbx_amidar_config_t);
     default: return 0;
     }
 }
@@ -215,6 +253,7 @@ int tbx_create(int game, int n_envs, int device, const void* config_pod, size_t 
     switch (game) {
     case TBX_GAME_BREAKOUT: e->ops = tbx_make_breakout_ops(); break;
     case TBX_GAME_SPACE_INVADERS: e->ops = tbx_make_si_ops(); break;
+    case TBX_GAME_AMIDAR: e->ops = tbx_make_amidar_ops(); break;
     default: e->err = "unknown game id"; return bail(TBX_E_INVALID);
     }
     const size_t N = (size_t)n_envs;
@@ -251,6 +290,7 @@ int tbx_create(int game, int n_envs, int device, const void* config_pod, size_t 
         switch (game) {
         case TBX_GAME_BREAKOUT: breakout_default_config((tbx_breakout_config_t*)cfg.data()); break;
         case TBX_GAME_SPACE_INVADERS: si_default_config((tbx_si_config_t*)cfg.data()); break;
+        case TBX_GAME_AMIDAR: amidar_default_config((tbx_amidar_config_t*)cfg.data()); break;
         }
     }
     rc = e->ops->init(e, cfg.data(), cfg.size());
@@ -503,6 +543,22 @@ int tbx_set_config(tbx_engine* e, const void* pod, size_t size)
     uint64_t r[2];
     memcpy(r, pod, sizeof r);
     return tbx_set_sim_rng(e, -1, r);
+}
+
+int tbx_query(tbx_engine* e, int env, int query_id, const int32_t* args, int n_args, int32_t* out, int n_out)
+{
+    CHECK_ENGINE(e);
+    if (env < 0 || env >= e->n || !args || !out) return e->fail(TBX_E_INVALID, "bad query arguments");
+    if (e->game == TBX_GAME_AMIDAR && n_args >= 2 && n_out >= 2) {
+        // pure functions of the arguments (world = tile * (64, 80)); floor division for negative world coordinates
+        if (query_id == TBX_QUERY_TILE_TO_WORLD) { out[0] = args[0] * TBX_AMI_TILE_WX; out[1] = args[1] * TBX_AMI_TILE_WY; return TBX_OK; }
+        if (query_id == TBX_QUERY_WORLD_TO_TILE) {
+            out[0] = args[0] >= 0 ? args[0] / TBX_AMI_TILE_WX : -((-args[0] + TBX_AMI_TILE_WX - 1) / TBX_AMI_TILE_WX);
+            out[1] = args[1] >= 0 ? args[1] / TBX_AMI_TILE_WY : -((-args[1] + TBX_AMI_TILE_WY - 1) / TBX_AMI_TILE_WY);
+            return TBX_OK;
+        }
+    }
+    return e->fail(TBX_E_INVALID, "unknown query for this game");
 }
 
 int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_bytes)

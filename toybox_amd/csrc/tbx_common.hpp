@@ -217,3 +217,4 @@ struct GameOps {
 
 GameOps* tbx_make_breakout_ops();
 GameOps* tbx_make_si_ops();
+GameOps* tbx_make_amidar_ops();

@@ -142,6 +142,12 @@ class Engine:
             raise TypeError("config must be a %s" % self.config_type.__name__)
         self._check(self._lib.tbx_set_config(self._h, C.byref(cfg), C.sizeof(cfg)))
 
+    def query(self, env, query_id, args, n_out=2):
+        a = (C.c_int32 * len(args))(*[int(v) for v in args])
+        out = (C.c_int32 * n_out)()
+        self._check(self._lib.tbx_query(self._h, int(env), int(query_id), a, len(args), out, n_out))
+        return [int(v) for v in out]
+
     # ------------------------------------------------------------------ device-resident path
     def step_device(self, actions_ptr, auto_reset=False, stream=0):
         flags = _abi.STEP_AUTO_RESET if auto_reset else 0
