@@ -50,13 +50,26 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU boxes report 256
+    logical CPUs but run the job under a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(game, channels, n_envs, steps):
     """Times the CPU oracle (step + render, auto-reset, same action rule) on all host cores."""
     from toybox_amd import Engine, _abi
     path = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(path):
         return None
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     os.environ["TBX_ORACLE_THREADS"] = str(cores)
     lib = ctypes.CDLL(path)
     _abi.bind(lib)

@@ -31,10 +31,11 @@ OPTIONAL_AI_PARAMS = {"player_seen"}
 
 
 def _strict(d, keys, what):
-    actual, expected = set(d.keys()), set(keys)
-    if actual != expected:
-        raise ValueError("%s: key mismatch, missing %s, unexpected %s" %
-                         (what, sorted(expected - actual), sorted(actual - expected)))
+    """Required keys must be present; unknown keys are ignored, as serde does on the Rust side (the reference's own
+    MovementAI.encode leaks `_in_init` / `schema` into the AI parameters, interventions/amidar.py:159-164)."""
+    missing = set(keys) - set(d.keys())
+    if missing:
+        raise ValueError("%s: missing keys %s" % (what, sorted(missing)))
 
 
 def _dir(v):
@@ -54,10 +55,9 @@ def ai_from_json(d):
     name, p = next(iter(d.items()))
     if name not in AI_PARAMS:
         raise ValueError("amidar: unknown movement protocol %r" % (name,))
-    allowed = set(AI_PARAMS[name])
-    extra, missing = set(p) - allowed, allowed - set(p) - OPTIONAL_AI_PARAMS
-    if extra or missing:
-        raise ValueError("amidar %s: missing %s, unexpected %s" % (name, sorted(missing), sorted(extra)))
+    missing = set(AI_PARAMS[name]) - set(p) - OPTIONAL_AI_PARAMS
+    if missing:
+        raise ValueError("amidar %s: missing parameters %s" % (name, sorted(missing)))
     ai.kind = _abi.AI_NAMES.index(name)
     if "next" in p:
         ai.next, ai.default_route_index = int(p["next"]), int(p["default_route_index"])

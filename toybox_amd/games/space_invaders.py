@@ -22,10 +22,11 @@ PROTOCOLS = {"TargetPlayer": 0}
 
 
 def _strict(d, keys, what):
-    actual, expected = set(d.keys()), set(keys)
-    if actual != expected:
-        raise ValueError("%s: key mismatch, missing %s, unexpected %s" %
-                         (what, sorted(expected - actual), sorted(actual - expected)))
+    """Required keys must be present; unknown keys are ignored, as serde does on the Rust side (the reference's own
+    MovementAI.encode leaks `_in_init` / `schema` into the AI parameters, interventions/amidar.py:159-164)."""
+    missing = set(keys) - set(d.keys())
+    if missing:
+        raise ValueError("%s: missing keys %s" % (what, sorted(missing)))
 
 
 def _opt(v):
