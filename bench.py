@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--no-render", action="store_true", help="step-only mode (reported separately, no roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed/RCCL gather path even at world size 1")
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=40)
     return ap.parse_args()
@@ -63,8 +64,9 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(game, channels, n_envs, steps):
-    """Times the CPU oracle (step + render, auto-reset, same action rule) on all host cores."""
+def cpu_baseline(game, channels, n_envs, steps, target_seconds=12.0):
+    """Times the CPU oracle (step + render, auto-reset, same action rule) on all usable host cores for about
+    `target_seconds` of wall time (a bounded sample: the step count is calibrated from a short probe)."""
     from toybox_amd import Engine, _abi
     path = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(path):
@@ -76,14 +78,17 @@ def cpu_baseline(game, channels, n_envs, steps):
     e = Engine(game, n_envs, lib=lib)
     e.seed(1234)
     e.new_game()
-    for t in range(3):
-        e.step_synthetic(1337, t)
-        e.render_device(0, channels)
-    t0 = time.perf_counter()
-    for t in range(3, 3 + steps):
-        e.step_synthetic(1337, t)
-        e.render_device(0, channels)
-    dt = time.perf_counter() - t0
+    def run(t_from, count):
+        t0 = time.perf_counter()
+        for t in range(t_from, t_from + count):
+            e.step_synthetic(1337, t)
+            e.render_device(0, channels)
+        return time.perf_counter() - t0
+
+    run(0, 4)                                           # warm-up (thread pool, page faults)
+    probe = run(4, 8) + 1e-9                            # calibration
+    steps = int(max(steps, min(20000, target_seconds / max(probe / 8, 1e-6))))
+    dt = run(12, steps)
     e.close()
     return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%s step+render(%dch), %d envs x %d steps, OpenMP static partition over envs, %.1f s" %
@@ -102,7 +107,8 @@ def main():
 
     from toybox_amd import Engine, _abi, hip
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -118,7 +124,7 @@ def main():
     H, W, C = eng.height, eng.width, args.channels
     render = not args.no_render
 
-    if world > 1:
+    if use_dist:
         stream_ptr = torch.cuda.current_stream().cuda_stream
         packed_local = torch.zeros(n, dtype=torch.int64, device="cuda")
         gathered = torch.zeros(n * world, dtype=torch.int64, device="cuda")
@@ -134,7 +140,7 @@ def main():
     def one_step(t, events=None):
         nonlocal pending
         eng.step_synthetic(1337, t, env_offset=env_offset, auto_reset=True, stream=stream_ptr)
-        if world > 1:
+        if use_dist:
             if pending is not None:
                 pending.wait()
             hip.memcpy_dtod_async(packed_local.data_ptr(), packed_src, 8 * n, stream_ptr)
@@ -147,7 +153,7 @@ def main():
                 events[1].record(stream_ptr)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         hip.synchronize()
 
@@ -162,7 +168,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     eng.sync()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -227,7 +233,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0
