@@ -1,0 +1,138 @@
+"""Edge cases of the boundary, run against the CPU restatement of the ABI here (host logic) and against the HIP library
+on the GPU box (same assertions): ragged batch sizes, masks, single-env calls, error codes, capacity limits."""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from support import synthetic_actions
+from toybox_amd import Engine, ToyboxAmdError, _abi
+from toybox_amd.games import codec
+
+GAMES = ["breakout", "space_invaders", "amidar"]
+
+
+def _libs(request, hip_lib, oracle_lib):
+    return hip_lib if request.param == "hip" else oracle_lib
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def lib(request, oracle_lib):
+    if request.param == "oracle":
+        return oracle_lib
+    from toybox_amd import _lib
+    return _lib.load()
+
+
+@pytest.mark.parametrize("game", GAMES)
+@pytest.mark.parametrize("n", [1, 3, 5, 67])
+def test_ragged_batch_sizes(game, n, lib, oracle_lib):
+    """Batch sizes that do not fill a 4-env block / a 64-lane wave behave like any other: every env steps, renders and
+    round-trips, and equals the oracle (trivially so when lib IS the oracle)."""
+    e, o = Engine(game, n, lib=lib), Engine(game, n, lib=oracle_lib)
+    for x in (e, o):
+        x.seed(77)
+        x.new_game()
+    for t in range(120):
+        a = synthetic_actions(game, n, t)
+        r1, r2 = e.step(a, auto_reset=True), o.step(a, auto_reset=True)
+        for p, q in zip(r1, r2):
+            assert np.array_equal(p, q)
+    assert np.array_equal(e.render(3), o.render(3))
+    assert np.array_equal(e.render_env(n - 1, 1), o.render_env(n - 1, 1))
+    for i in range(n):
+        assert bytes(e.get_state(i)) == bytes(o.get_state(i))
+
+
+@pytest.mark.parametrize("game", GAMES)
+def test_masked_new_game_and_single_env_input(game, lib):
+    n = 6
+    e = Engine(game, n, lib=lib)
+    e.seed(5)
+    e.new_game()
+    for t in range(40):
+        e.step(synthetic_actions(game, n, t))
+    before = [bytes(e.get_state(i)) for i in range(n)]
+    mask = np.array([0, 1, 0, 0, 1, 0], np.uint8)
+    e.new_game(mask)
+    cd = codec(game)
+    for i in range(n):
+        if mask[i]:
+            js = cd.state_to_json(e.get_state(i))
+            assert js["score"] == 0 and bytes(e.get_state(i)) != before[i]
+        else:
+            assert bytes(e.get_state(i)) == before[i], "unmasked env %d was touched" % i
+    e.apply_input(2, _abi.BTN_BUTTON1)
+    for i in (0, 3, 5):
+        assert bytes(e.get_state(i)) == before[i]
+    assert bytes(e.get_state(2)) != before[2]
+
+
+def test_error_codes(lib):
+    with pytest.raises(ToyboxAmdError) as ei:
+        Engine("breakout", 0, lib=lib)
+    assert ei.value.code == _abi.E_INVALID
+    e = Engine("breakout", 2, lib=lib)
+    for bad_call in (lambda: e.get_state(2), lambda: e.get_state(-1), lambda: e.render_env(5, 3),
+                     lambda: e.render(2), lambda: e.apply_input(9, 0), lambda: e.seed(1, env=7),
+                     lambda: e.query(0, 1, [1, 2])):
+        with pytest.raises(ToyboxAmdError) as ei:
+            bad_call()
+        assert ei.value.code == _abi.E_INVALID
+    with pytest.raises(ValueError):
+        e.step([0])                      # wrong batch shape is caught on the host
+    e.step([0, 1])                       # the engine is still usable afterwards
+
+
+def test_capacity_limits_are_reported(lib):
+    """States outside what the device engine holds are refused loudly (TBX_E_UNSUPPORTED), never truncated."""
+    e = Engine("breakout", 1, lib=lib)
+    st = e.get_state(0)
+    st.n_balls = 5
+    with pytest.raises(ToyboxAmdError) as ei:
+        e.set_state(0, st)
+    assert ei.value.code == _abi.E_UNSUPPORTED
+    st.n_balls = 4                       # the maximum is fine
+    for b in range(4):
+        st.ball_x[b], st.ball_y[b], st.ball_vx[b], st.ball_vy[b] = 60.0 + 20 * b, 100.0, 1.0, -1.5
+    st.is_dead = 0
+    e.set_state(0, st)
+    for t in range(300):
+        e.step([3 + t % 2])
+    assert e.get_state(0).n_balls <= 4
+    cfg = e.get_config()
+    cfg.paddle_discrete_segments = 0
+    with pytest.raises(ToyboxAmdError) as ei:
+        e.set_config(cfg)
+    assert ei.value.code == _abi.E_UNSUPPORTED
+    s = Engine("space_invaders", 1, lib=lib)
+    st = s.get_state(0)
+    st.n_enemy_lasers = 9
+    with pytest.raises(ToyboxAmdError) as ei:
+        s.set_state(0, st)
+    assert ei.value.code == _abi.E_UNSUPPORTED
+    a = Engine("amidar", 1, lib=lib)
+    st = a.get_state(0)
+    st.n_enemies = 9
+    with pytest.raises(ToyboxAmdError) as ei:
+        a.set_state(0, st)
+    assert ei.value.code == _abi.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("game", GAMES)
+def test_seed_semantics(game, lib):
+    """set_seed takes effect at the next new_game (envs/atari/base.py:95-97); equal seeds give equal games, env i of a
+    batch seeded with s equals a single env seeded with s+i."""
+    e = Engine(game, 3, lib=lib)
+    before = bytes(e.get_state(1))
+    e.seed(900)
+    assert bytes(e.get_state(1)) == before           # nothing changes until the new game
+    e.new_game()
+    single = Engine(game, 1, lib=lib)
+    single.seed(901)
+    single.new_game()
+    assert bytes(single.get_state(0)) == bytes(e.get_state(1))
+    acts = [synthetic_actions(game, 3, t) for t in range(200)]
+    for a in acts:
+        e.step(a)
+        single.step(a[1:2])
+    assert bytes(single.get_state(0)) == bytes(e.get_state(1))
