@@ -824,16 +824,14 @@ struct BrkPalette {
     uint32_t row_colors[TBX_BRK_MAX_ROWS];
 };
 
-// The rasteriser.  Work item = one unit of BRK_UNIT_ROWS scanlines of one env's frame; items are
-// numbered in output-address order and dealt round-robin to the waves of a persistent grid
-// (wave w takes items w, w+NW, ...), so at any instant the chip writes one contiguous window of
-// the frame batch -- the access shape of a device memset, which on MI355X sustains ~15 % more write
-// bandwidth than one private stream per wave (scripts/ubench/write_bw4.hip, stage_bw.hip).
-// Per item a wave loads the env's 64-byte record (scalar), composes each scanline per lane as 4
-// packed pixels (lane l -> pixels 4l..4l+3) from wave-uniform row classes (HUD / top bar / side
-// walls / brick band / paddle / balls), stages the unit in its LDS slice and flushes it as
-// 1 KiB-per-instruction stores.
-template <int C, bool CUSTOM, bool ORDERED>
+// The rasteriser: one wave per env.  Per env the wave loads the 64-byte record (scalar), composes each scanline
+// per lane as 4 packed pixels (lane l -> pixels 4l..4l+3) from wave-uniform row classes (HUD / top bar / side
+// walls / brick band / paddle / balls), stages BRK_UNIT_ROWS scanlines in its LDS slice and flushes them as
+// 1 KiB-per-instruction stores.  Units are visited in an env-rotated order so that co-resident waves do not
+// march through the same frame offsets in lockstep.  Measured alternatives (scripts/ubench/): a persistent
+// grid over address-ordered units reaches 6.1 TB/s as bare stores but 4.7-4.9 TB/s with record loads and LDS
+// staging, against 5.2 TB/s for this form (hipMemset on the same box: 6.3 TB/s).
+template <int C, bool CUSTOM>
 __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
                                                                BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count)
 {
@@ -845,7 +843,6 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
-    const int total_waves = gridDim.x * TBX_WAVES_PER_BLOCK;
     const int x0 = lane * 4;
     const bool active = x0 < W;
     const int rows = pal.rows;
@@ -868,15 +865,10 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
         hud_sel[i] = sel;
     }
 
-    // ORDERED: items in output-address order over a persistent grid; otherwise one wave per env,
-    // units visited in an env-rotated order
-    const int n_items = ORDERED ? count * NUNITS : NUNITS;
-    const int w0 = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
-    if (!ORDERED && w0 >= count) return;
-    for (int q = ORDERED ? w0 : 0; q < n_items; q += ORDERED ? total_waves : 1) {
-        int rel, u;
-        if (ORDERED) { rel = q / NUNITS; u = q - rel * NUNITS; }
-        else { rel = w0; u = (int)(((uint32_t)(first_env + w0) * 7u + (uint32_t)q) % (uint32_t)NUNITS); }
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (rel >= count) return;
+    for (int q = 0; q < NUNITS; q++) {
+        const int u = (int)(((uint32_t)(first_env + rel) * 7u + (uint32_t)q) % (uint32_t)NUNITS);
         const BrkRenderRec rec = recs[first_env + rel];   // by value: scalar loads up front, none inside the row loop
         const int env = first_env + rel;
         uint8_t* dst = out + ((size_t)rel * H + (size_t)u * BRK_UNIT_ROWS) * W * C;
@@ -1134,14 +1126,7 @@ struct BreakoutOps : GameOps {
         int rc = load_cfg(e, k);
         if (rc) return rc;
         const size_t N = (size_t)e->n;
-        {
-            hipDeviceProp_t prop;
-            int per_cu = 6;
-            if (const char* v = getenv("TBX_RENDER_BLOCKS_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;
-            if (const char* v = getenv("TBX_RENDER_ORDERED")) render_ordered = atoi(v) != 0;
-            if (const char* v = getenv("TBX_BRK_STEP_TPE")) use_tpe = atoi(v) != 0;
-            if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) render_blocks = prop.multiProcessorCount * per_cu;
-        }
+        if (const char* v = getenv("TBX_BRK_STEP_TPE")) use_tpe = atoi(v) != 0;
         d.n = e->n;
         d.sim_rng = e->sim_rng; d.prev_score = e->prev_score; d.reward = e->reward; d.done = e->done;
         d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed; d.err_flag = e->err_flag;
@@ -1205,16 +1190,7 @@ struct BreakoutOps : GameOps {
         return TBX_OK;
     }
 
-    // persistent rasteriser grid: blocks_per_cu x CUs blocks, each wave strides over the envs
-    int render_blocks = 2048;
     bool use_tpe = true;            // thread-per-env step for the canonical wall (TBX_BRK_STEP_TPE=0 keeps the wave kernel)
-    bool render_ordered = false;   // measured: one wave per env (5.2 TB/s) beats address-ordered items (4.7-4.9 TB/s) at 64k envs
-    dim3 render_grid(int count) const
-    {
-        const long items = (long)count * (TBX_BRK_H / BRK_UNIT_ROWS);
-        const long need = (items + TBX_WAVES_PER_BLOCK - 1) / TBX_WAVES_PER_BLOCK;
-        return dim3((unsigned)(need < render_blocks ? need : render_blocks));
-    }
 
     template <int C>
     void launch_render(uint8_t* out, int first, int count, hipStream_t s)
@@ -1223,9 +1199,8 @@ struct BreakoutOps : GameOps {
         pal.bg = c.bg; pal.frame = c.frame; pal.paddle = c.paddle; pal.ball = c.ball; pal.rows = c.n_rows;
         for (int i = 0; i < TBX_BRK_MAX_ROWS; i++) pal.row_colors[i] = c.row_colors[i];
         if (!recs_valid) hipLaunchKernelGGL(brk_render_prep_kernel, dim3((count + 255) / 256), dim3(256), 0, s, d, recs, first, count);
-        if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true, false>), grid_for(count), dim3(TBX_BLOCK), 0, s, recs, d.custom, pal, out, first, count);
-        else if (render_ordered) hipLaunchKernelGGL((brk_render_kernel<C, false, true>), render_grid(count), dim3(TBX_BLOCK), 0, s, recs, d.custom, pal, out, first, count);
-        else hipLaunchKernelGGL((brk_render_kernel<C, false, false>), grid_for(count), dim3(TBX_BLOCK), 0, s, recs, d.custom, pal, out, first, count);
+        if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true>), grid_for(count), dim3(TBX_BLOCK), 0, s, recs, d.custom, pal, out, first, count);
+        else hipLaunchKernelGGL((brk_render_kernel<C, false>), grid_for(count), dim3(TBX_BLOCK), 0, s, recs, d.custom, pal, out, first, count);
     }
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override

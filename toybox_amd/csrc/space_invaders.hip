@@ -20,6 +20,7 @@
 #include "raster.hpp"
 #include "../../include/toybox_amd_spec.h"
 
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -552,16 +553,19 @@ __constant__ uint32_t SI_SPR_UFO[TBX_SI_UFO_H] = TBX_SI_SPRITE_UFO;
 
 constexpr int SI_UNIT_ROWS = 6;   // 210 = 35 units; 6 x 960 B (RGB) = 5760 B of LDS per wave
 
-// paints sprite row bits (bit k = column k, `w` columns) at x position sx into the lane's pixel groups
+// paints sprite row bits (bit k = column k, `w` <= 32 columns) at x position sx into the lane's pixel groups
 template <int NG>
 __device__ __forceinline__ void paint_bits(uint32_t (&px)[NG][4], const int (&gx)[NG], int sx, uint32_t bits, int w, uint32_t col)
 {
+    const uint64_t live = (uint64_t)(w >= 32 ? bits : (bits & ((1u << w) - 1u))) << 4;   // 4 guard bits below column 0
 #pragma unroll
     for (int g = 0; g < NG; g++) {
+        const int k = gx[g] - sx + 4;                       // bit index of this group's first pixel in `live`
+        if (k >= 0 && k < 40) {
+            const uint32_t four = (uint32_t)(live >> k) & 15u;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int k = gx[g] + i - sx;
-            if (k >= 0 && k < w && ((bits >> k) & 1u)) px[g][i] = col;
+            for (int i = 0; i < 4; i++)
+                if ((four >> i) & 1u) px[g][i] = col;
         }
     }
 }
@@ -643,6 +647,21 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
     const int s_y = (sk == 0 ? f[F_SHIELD_Y0] : sk == 1 ? f[F_SHIELD_Y1] : f[F_SHIELD_Y2]) + sr;
     const uint32_t s_c = (uint32_t)(sk == 0 ? f[F_SHIELD_C0] : sk == 1 ? f[F_SHIELD_C1] : f[F_SHIELD_C2]);
     const bool e_vis = lane < ne && (e_alive(s) || e_dc(s) >= 0);
+    // scanline ranges that can contain enemies / shields / lasers at all (wave-uniform), so that most scanlines
+    // skip the ballots
+    int e_y0 = e_vis ? s.ey : INT32_MAX, e_y1 = e_vis ? s.ey + TBX_SI_ENEMY_H : INT32_MIN;
+    const bool l_on = lane == SHIP_SLOT ? f[F_HAS_SHIP_LASER] != 0 : lane < f[F_N_LASERS];
+    long l_lo = l_on ? (long)s.lf[LF_Y] : LONG_MAX, l_hi = l_on ? (long)s.lf[LF_Y] + s.lf[LF_H] : LONG_MIN;
+    int s_y0 = s_valid && s.srow ? s_y : INT32_MAX, s_y1 = s_valid && s.srow ? s_y + 1 : INT32_MIN;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        e_y0 = min(e_y0, __shfl_xor(e_y0, o)); e_y1 = max(e_y1, __shfl_xor(e_y1, o));
+        s_y0 = min(s_y0, __shfl_xor(s_y0, o)); s_y1 = max(s_y1, __shfl_xor(s_y1, o));
+        const long a = ((long)__shfl_xor((int)(l_lo >> 32), o) << 32) | (uint32_t)__shfl_xor((int)l_lo, o);
+        const long b = ((long)__shfl_xor((int)(l_hi >> 32), o) << 32) | (uint32_t)__shfl_xor((int)l_hi, o);
+        l_lo = a < l_lo ? a : l_lo; l_hi = b > l_hi ? b : l_hi;
+    }
+    e_y0 = wave_uniform(e_y0); e_y1 = wave_uniform(e_y1); s_y0 = wave_uniform(s_y0); s_y1 = wave_uniform(s_y1);
 
     uint8_t* frame = out + (size_t)rel * H * W * C;
     constexpr int NUNITS = H / SI_UNIT_ROWS;
@@ -660,7 +679,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
 #pragma unroll
                 for (int i = 0; i < 4; i++) px[g][i] = base;
             // shields (ascending shield index, then row: one row per shield can match y)
-            {
+            if (y >= s_y0 && y < s_y1) {
                 uint64_t m = __ballot(s_valid && s_y == y && s.srow != 0);
                 while (m) {
                     const int src = (int)__builtin_ctzll(m);
@@ -669,7 +688,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
                 }
             }
             // enemies in index order
-            {
+            if (y >= e_y0 && y < e_y1) {
                 uint64_t m = __ballot(e_vis && y >= s.ey && y < s.ey + TBX_SI_ENEMY_H);
                 while (m) {
                     const int src = (int)__builtin_ctzll(m);
@@ -689,10 +708,9 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
                     paint_bits<NG>(px, gx, f[F_SHIP_X], (f[F_SHIP_FLAGS] & 2) ? SI_SPR_D1[ry] : SI_SPR_D2[ry], 16, (uint32_t)f[F_SHIP_COLOR]);
             }
             // lasers: the ship's first, then enemy lasers in slot order
-            {
-                const bool mine = lane == SHIP_SLOT ? f[F_HAS_SHIP_LASER] != 0 : lane < f[F_N_LASERS];
+            if (y >= l_lo && y < l_hi) {
                 const long ly0 = s.lf[LF_Y], ly1 = (long)s.lf[LF_Y] + s.lf[LF_H];
-                uint64_t m = __ballot(mine && y >= ly0 && y < ly1);
+                uint64_t m = __ballot(l_on && y >= ly0 && y < ly1);
                 if ((m >> SHIP_SLOT) & 1) {
                     const Laser l = get_laser(s, SHIP_SLOT);
                     paint_span<NG>(px, gx, l.x, (long)l.x + l.w, (uint32_t)l.color);

@@ -142,27 +142,6 @@ __device__ __forceinline__ int f2i(double v)
     return (int)v;
 }
 
-// store 4 consecutive pixels (packed 0xAABBGGRR each) of one lane in C channels
-template <int C>
-__device__ __forceinline__ void store_px4(uint8_t* p, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
-{
-    if (C == 4) {
-        uint4 v = make_uint4(c0 | 0xFF000000u, c1 | 0xFF000000u, c2 | 0xFF000000u, c3 | 0xFF000000u);
-        *reinterpret_cast<uint4*>(p) = v;
-    } else if (C == 3) {
-        c0 &= 0xFFFFFFu; c1 &= 0xFFFFFFu; c2 &= 0xFFFFFFu; c3 &= 0xFFFFFFu;
-        struct alignas(4) U3 { uint32_t a, b, c; };
-        U3 v;
-        v.a = c0 | (c1 << 24);
-        v.b = (c1 >> 8) | (c2 << 16);
-        v.c = (c2 >> 16) | (c3 << 8);
-        *reinterpret_cast<U3*>(p) = v;
-    } else {
-        uint32_t v = gray_of(c0) | (gray_of(c1) << 8) | (gray_of(c2) << 16) | (gray_of(c3) << 24);
-        *reinterpret_cast<uint32_t*>(p) = v;
-    }
-}
-
 // ------------------------------------------------------------------ host side
 
 struct GameOps;
