@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--no-render", action="store_true", help="step-only mode (reported separately, no roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--protocol", default="batch", choices=["batch", "reference"],
+                    help="'reference' = the raw single-env loop of the reference's harness (test/benchmark.py:44-58)")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed/RCCL gather path even at world size 1")
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=40)
@@ -95,8 +97,107 @@ def cpu_baseline(game, channels, n_envs, steps, target_seconds=12.0):
                       (game, channels, n_envs, steps, dt)}
 
 
+def bench_mixed(args, world, rank, local_rank, use_dist, dist):
+    """BASELINE config 5: Breakout + Amidar + SpaceInvaders, args.envs envs per GPU split in three contiguous segments,
+    three homogeneous launches per phase on three streams."""
+    from toybox_amd import hip
+    from toybox_amd.parallel import MixedBatch
+    games = ["breakout", "amidar", "space_invaders"]
+    per = args.envs // 3
+    mb = MixedBatch(games, per, device=local_rank, global_offset=rank * per * 3)
+    streams = [hip.Stream() for _ in games]
+    mb.attach_streams([s.ptr for s in streams])
+    C, K, Wm = args.channels, args.steps, args.warmup
+    render = not args.no_render
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        hip.synchronize()
+
+    def one(t):
+        mb.step_synthetic(1337, t)
+        if render:
+            mb.render_device(C)
+
+    for t in range(Wm):
+        one(t)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        one(Wm + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    mb.sync()
+    if use_dist:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        total = world * mb.n_envs
+        fb = mb.frame_bytes(C) if render else 0
+        out = {"metric": "env steps/sec (whole node), mixed Breakout+Amidar+SpaceInvaders batch", "value": total * K / elapsed,
+               "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * elapsed / K,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+int32", "data": "synthetic",
+               "config": {"workload": "mixed batch, %d envs/GPU = 3 x %d (breakout, amidar, space_invaders), %s, three streams"
+                                      % (mb.n_envs, per, "step + RGB render" if render else "step-only"),
+                          "envs_per_gpu": mb.n_envs, "envs_total": total},
+               "roofline": ({"bound": "hbm", "kernel": "the three rasterisers together (whole-step time, not per kernel)",
+                             "achieved": fb / (elapsed / K) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": fb / (elapsed / K) / 1e9 / HBM_PEAK_GBS, "traffic": None} if render else None)}
+        print(json.dumps(out), flush=True)
+    mb.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def bench_reference_protocol(args):
+    """Protocol A: test/benchmark.py:44-58 verbatim -- one env, action = legal[i % len(legal)],
+    new_game() when game_over() else apply_ale_action(move), no rendering, FPS = steps / elapsed.  One FFI round trip
+    per step, so on the GPU this measures launch + sync latency, not throughput; the CPU oracle runs the same loop."""
+    from toybox_amd import Engine, _abi
+    from toybox_amd import toybox as tbmod
+    from toybox_amd.toybox import Toybox
+    nsteps = max(args.steps, 1000)
+
+    def raw_loop(tb):
+        actions = tb.get_legal_action_set()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            move = actions[i % len(actions)]
+            if tb.game_over():
+                tb.new_game()
+            else:
+                tb.apply_ale_action(move)
+        return nsteps / (time.perf_counter() - t0)
+
+    out = {"metric": "raw single-env steps/sec, reference harness protocol (test/benchmark.py:44-58)", "unit": "env-steps/s",
+           "n_gpus": 1, "steps": nsteps, "warmup": 0, "higher_is_better": True, "vs_baseline": None, "data": "synthetic",
+           "scaling": "weak", "config": {"workload": "%s single env, cycling legal actions, new_game on game over, no render" % args.game}}
+    with Toybox(args.game) as tb:
+        raw_loop(tb)
+        out["value"] = raw_loop(tb)
+    out["ms_per_step"] = 1000.0 / out["value"]
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if os.path.exists(path) and not args.no_cpu_baseline:
+        lib = ctypes.CDLL(path)
+        _abi.bind(lib)
+        tbmod.set_engine_factory(lambda game, n: Engine(game, n, lib=lib))
+        with Toybox(args.game) as tb:
+            out["cpu_baseline"] = {"value": raw_loop(tb), "unit": "env-steps/s", "cores": 1, "kind": "port",
+                                   "sample": "same loop over the CPU oracle, %d steps" % nsteps}
+        tbmod.set_engine_factory(None)
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    if args.protocol == "reference":
+        return bench_reference_protocol(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -117,6 +218,8 @@ def main():
 
     n = args.envs
     game = args.game
+    if game == "mixed":
+        return bench_mixed(args, world, rank, local_rank, use_dist, dist)
     eng = Engine(game, n, device=local_rank)
     eng.seed(1234 + rank * n)            # env i of this rank: seed 1234 + global index
     eng.new_game()

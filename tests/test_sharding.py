@@ -69,3 +69,27 @@ def test_two_rank_gloo_equals_single_process(oracle_lib, tmp_path):
         dn += d
     assert np.array_equal(got[0], tot) and np.array_equal(got[1], dn) and np.array_equal(got[2], l.astype(np.int64))
     assert tot.sum() > 0
+
+
+def test_mixed_batch_matches_separate_engines(oracle_lib):
+    """BASELINE config 5 shape: a mixed Breakout + Amidar + SpaceInvaders batch is three homogeneous segments whose
+    seeds / synthetic actions use the global env index."""
+    from support import synthetic_actions
+    from toybox_amd import Engine
+    from toybox_amd.parallel import MixedBatch
+    games, per = ["breakout", "amidar", "space_invaders"], 5
+    mb = MixedBatch(games, per, engine_factory=lambda g, n: Engine(g, n, lib=oracle_lib))
+    singles = []
+    for i, g in enumerate(games):
+        e = Engine(g, per, lib=oracle_lib)
+        e.seed(1234 + i * per)
+        e.new_game()
+        singles.append(e)
+    for t in range(300):
+        mb.step_synthetic(1337, t)
+        for i, (g, e) in enumerate(zip(games, singles)):
+            e.step(synthetic_actions(g, per, t, seed=1337, env_offset=i * per), auto_reset=True)
+    for me, se in zip(mb.engines, singles):
+        for k in range(per):
+            assert bytes(me.get_state(k)) == bytes(se.get_state(k))
+    assert mb.n_envs == 15 and mb.frame_bytes(3) == per * 3 * (160 * 240 + 250 * 160 + 210 * 320)

@@ -71,3 +71,52 @@ class ShardedBatch:
         self.dist.all_gather(out, buf)
         parts = [o.numpy().view(np.uint64)[: e - s] for o, (s, e) in zip(out, self.counts)]
         return np.concatenate(parts)
+
+
+class MixedBatch:
+    """A batch made of several games (BASELINE config 5: Breakout + Amidar + SpaceInvaders): envs are sorted by game so
+    that every launch is homogeneous -- one engine per game, each on its own HIP stream so the three step / render
+    launches of a batch step overlap on the device.  Global env order: games in the order given, contiguous per game."""
+
+    def __init__(self, games, n_per_game, device=0, seed_base=1234, engine_factory=None, global_offset=0):
+        from .engine import Engine
+        self.games = list(games)
+        self.n_per_game = int(n_per_game)
+        make = engine_factory or (lambda game, n: Engine(game, n, device=device))
+        self.engines = [make(g, self.n_per_game) for g in self.games]
+        self.offsets = [global_offset + i * self.n_per_game for i in range(len(self.games))]
+        for e, off in zip(self.engines, self.offsets):
+            e.seed(seed_base + off)
+            e.new_game()
+        self.n_envs = self.n_per_game * len(self.games)
+        self.streams = None
+
+    def attach_streams(self, streams):
+        """One stream handle (int) per game; without it everything runs on the null stream."""
+        self.streams = list(streams)
+
+    def _stream(self, i):
+        return self.streams[i] if self.streams else 0
+
+    def step_synthetic(self, action_seed, t, auto_reset=True):
+        for i, (e, off) in enumerate(zip(self.engines, self.offsets)):
+            e.step_synthetic(action_seed, t, env_offset=off, auto_reset=auto_reset, stream=self._stream(i))
+
+    def render_device(self, channels=3):
+        for i, e in enumerate(self.engines):
+            e.render_device(0, channels, stream=self._stream(i))
+
+    def step_host(self, actions_by_game, auto_reset=True):
+        """actions_by_game: list of int arrays (ALE ids), one per game.  Returns per-game (reward, done, lives, score)."""
+        return [e.step(a, auto_reset=auto_reset) for e, a in zip(self.engines, actions_by_game)]
+
+    def frame_bytes(self, channels=3):
+        return sum(e.n_envs * e.height * e.width * channels for e in self.engines)
+
+    def sync(self):
+        for e in self.engines:
+            e.sync()
+
+    def close(self):
+        for e in self.engines:
+            e.close()
