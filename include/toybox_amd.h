@@ -356,6 +356,39 @@ int tbx_set_config(tbx_engine* engine, const void* pod, size_t size);
 #define TBX_QUERY_WORLD_TO_TILE 2
 int tbx_query(tbx_engine* engine, int env, int query_id, const int32_t* args, int n_args, int32_t* out, int n_out);
 
+/* ------------------------------------------------------------------ agent-side preprocessing
+ * The per-env wrapper stack that the reference's vendored baselines put between the env and the learner, fused on
+ * the device so that only the small stacked observation ever leaves the chip:
+ *   MaxAndSkipEnv(skip)   baselines/baselines/common/atari_wrappers.py:193-219  repeat the action `skip` frames, sum the
+ *                         rewards, observation = per-pixel max of the frames at i = skip-2 and i = skip-1
+ *   WarpFrame             atari_wrappers.py:230-244  gray frame (Toybox frames are already gray, :241-242) resized to
+ *                         out_w x out_h by area averaging (exact rational weights, round half up)
+ *   ClipRewardEnv         atari_wrappers.py:221-227  sign(reward)
+ *   VecFrameStack(stack)  common/vec_env/vec_frame_stack.py:17-30  roll the channel axis, zero the stack of envs that
+ *                         finished, write the new frame last
+ * plus the VecEnv auto-reset (dummy_vec_env.py:51-54): an env whose game ended during the `skip` frames is reset and its
+ * observation is the warped reset frame.  obs = uint8[N][out_h][out_w][stack], reward float32[N], done uint8[N]. */
+typedef struct tbx_agent_config {
+    int32_t skip;          /* >= 1 (4) */
+    int32_t out_h, out_w;  /* 84, 84 */
+    int32_t stack;         /* 1..4 (4) */
+    int32_t clip_reward;   /* 0 / 1 */
+} tbx_agent_config_t;
+
+int tbx_agent_init(tbx_engine* engine, const tbx_agent_config_t* cfg);
+/* new game in every env; stack = zeros with the warped first frame last (VecFrameStack.reset).  obs_host may be NULL. */
+int tbx_agent_reset(tbx_engine* engine, uint8_t* obs_host);
+/* one agent step with host pointers (synchronous); any output pointer may be NULL */
+int tbx_agent_step(tbx_engine* engine, const int32_t* ale_actions_host, float* reward_host, uint8_t* done_host, uint8_t* obs_host);
+/* device-resident forms: actions in HBM, or generated on the device like tbx_step_synthetic with t = agent step index
+ * (every sub-frame of an agent step repeats the same action); results in TBX_BUF_AGENT_* */
+int tbx_agent_step_device(tbx_engine* engine, const int32_t* ale_actions_dev, void* stream);
+int tbx_agent_step_synthetic(tbx_engine* engine, uint64_t action_seed, uint64_t t, uint64_t env_offset, void* stream);
+
+#define TBX_BUF_AGENT_OBS    6   /* uint8[N][out_h][out_w][stack] */
+#define TBX_BUF_AGENT_REWARD 7   /* float32[N] */
+#define TBX_BUF_AGENT_DONE   8   /* uint8[N] */
+
 /* Address of an engine-owned device buffer (TBX_BUF_*). */
 int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out_bytes);
 /* Block until all work queued by this engine has finished; reports a pending TBX_E_ACTION. */

@@ -23,6 +23,11 @@ struct tbx_engine {
     int pending_action_error;
     int threads;
     char err[256];
+    /* agent-side preprocessing */
+    int agent_on;
+    tbx_agent_config_t acfg;
+    uint8_t *gray_a, *gray_b, *aobs, *afin, *adone;
+    float* areward;
 };
 
 static char g_err[256];
@@ -63,6 +68,7 @@ int tbx_destroy(tbx_engine* e)
     if (!e) return TBX_OK;
     free(e->cfg); free(e->states); free(e->sim); free(e->prev); free(e->reward); free(e->lives);
     free(e->score); free(e->done); free(e->packed); free(e->frame);
+    free(e->gray_a); free(e->gray_b); free(e->aobs); free(e->afin); free(e->adone); free(e->areward);
     free(e);
     return TBX_OK;
 }
@@ -355,6 +361,12 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     case TBX_BUF_SCORE: p = e->score; b = n * 4; break;
     case TBX_BUF_FRAME: p = e->frame; b = e->frame_bytes; break;
     case TBX_BUF_PACKED: p = e->packed; b = n * 8; break;
+    case TBX_BUF_AGENT_OBS: case TBX_BUF_AGENT_REWARD: case TBX_BUF_AGENT_DONE:
+        if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
+        if (which == TBX_BUF_AGENT_OBS) { p = e->aobs; b = n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack; }
+        else if (which == TBX_BUF_AGENT_REWARD) { p = e->areward; b = n * 4; }
+        else { p = e->adone; b = n; }
+        break;
     default: return fail(e, TBX_E_INVALID, "unknown buffer id");
     }
     *out_ptr = p;
@@ -365,5 +377,110 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
 int tbx_sync(tbx_engine* e)
 {
     if (!e) return TBX_E_INVALID;
+    return take_action_error(e);
+}
+
+/* ---------------------------------------------------------------- agent-side preprocessing */
+
+int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!cfg) return fail(e, TBX_E_INVALID, "agent config is NULL");
+    int H, W;
+    orc_frame_dims(e->game, &H, &W);
+    if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
+        cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128)
+        return fail(e, TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128)");
+    if ((H + cfg->out_h - 1) / cfg->out_h + 1 > 8 || (W + cfg->out_w - 1) / cfg->out_w + 1 > 8)
+        return fail(e, TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
+    free(e->gray_a); free(e->gray_b); free(e->aobs); free(e->afin); free(e->adone); free(e->areward);
+    size_t n = (size_t)e->n;
+    e->acfg = *cfg;
+    e->gray_a = (uint8_t*)calloc(n, (size_t)H * W);
+    e->gray_b = (uint8_t*)calloc(n, (size_t)H * W);
+    e->aobs = (uint8_t*)calloc(n, (size_t)cfg->out_h * cfg->out_w * cfg->stack);
+    e->afin = (uint8_t*)calloc(n, 1);
+    e->adone = (uint8_t*)calloc(n, 1);
+    e->areward = (float*)calloc(n, sizeof(float));
+    e->agent_on = 1;
+    return TBX_OK;
+}
+
+static void agent_observe(tbx_engine* e, int all_fresh)
+{
+    int H, W;
+    orc_frame_dims(e->game, &H, &W);
+    const int oh = e->acfg.out_h, ow = e->acfg.out_w, st = e->acfg.stack;
+    uint8_t* mx = (uint8_t*)malloc((size_t)H * W);
+    uint8_t* small = (uint8_t*)malloc((size_t)oh * ow);
+    for (int i = 0; i < e->n; i++) {
+        const uint8_t* a = (e->acfg.skip >= 2 ? e->gray_a : e->gray_b) + (size_t)i * H * W;
+        const uint8_t* b = e->gray_b + (size_t)i * H * W;
+        const int fresh = all_fresh || e->afin[i];
+        for (int p = 0; p < H * W; p++) mx[p] = fresh ? b[p] : (a[p] > b[p] ? a[p] : b[p]);
+        orc_warp_area(mx, H, W, small, oh, ow);
+        orc_stack_push(e->aobs + (size_t)i * oh * ow * st, small, oh, ow, st, fresh);
+    }
+    free(mx); free(small);
+}
+
+int tbx_agent_reset(tbx_engine* e, uint8_t* obs)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
+    orc_new_game_batch(e->game, e->cfg, e->states, e->sim, e->prev, e->n, NULL);
+    orc_render_batch(e->game, e->cfg, e->states, e->n, e->gray_b, 1, e->threads);
+    agent_observe(e, 1);
+    if (obs) memcpy(obs, e->aobs, (size_t)e->n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack);
+    return TBX_OK;
+}
+
+int tbx_agent_step_device(tbx_engine* e, const int32_t* actions, void* stream)
+{
+    (void)stream;
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (!actions) return fail(e, TBX_E_INVALID, "actions pointer is NULL");
+    const int n = e->n;
+    int32_t* racc = (int32_t*)calloc((size_t)n, 4);
+    memset(e->afin, 0, (size_t)n);
+    for (int i = 0; i < e->acfg.skip; i++) {
+        int rc = orc_step_batch(e->game, e->cfg, e->states, e->sim, e->prev, n, actions, 0,
+                                e->reward, e->done, e->lives, e->score, e->threads);
+        if (rc == TBX_E_ACTION) e->pending_action_error = 1;
+        for (int k = 0; k < n; k++)
+            if (!e->afin[k]) { racc[k] += e->reward[k]; if (e->done[k]) e->afin[k] = 1; }
+        if (i == e->acfg.skip - 2) orc_render_batch(e->game, e->cfg, e->states, n, e->gray_a, 1, e->threads);
+    }
+    pack_outputs(e);
+    orc_new_game_batch(e->game, e->cfg, e->states, e->sim, e->prev, n, e->afin);
+    orc_render_batch(e->game, e->cfg, e->states, n, e->gray_b, 1, e->threads);
+    agent_observe(e, 0);
+    for (int k = 0; k < n; k++) {
+        e->areward[k] = e->acfg.clip_reward ? (float)((racc[k] > 0) - (racc[k] < 0)) : (float)racc[k];
+        e->adone[k] = e->afin[k];
+    }
+    free(racc);
+    return TBX_OK;
+}
+
+int tbx_agent_step_synthetic(tbx_engine* e, uint64_t seed, uint64_t t, uint64_t env_offset, void* stream)
+{
+    if (!e) return TBX_E_INVALID;
+    int32_t* a = (int32_t*)malloc((size_t)e->n * 4);
+    for (int i = 0; i < e->n; i++) a[i] = orc_synthetic_action(e->game, seed, env_offset + (uint64_t)i, t);
+    int rc = tbx_agent_step_device(e, a, stream);
+    free(a);
+    return rc;
+}
+
+int tbx_agent_step(tbx_engine* e, const int32_t* actions, float* reward, uint8_t* done, uint8_t* obs)
+{
+    int rc = tbx_agent_step_device(e, actions, NULL);
+    if (rc) return rc;
+    size_t n = (size_t)e->n;
+    if (reward) memcpy(reward, e->areward, n * 4);
+    if (done) memcpy(done, e->adone, n);
+    if (obs) memcpy(obs, e->aobs, n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack);
     return take_action_error(e);
 }

@@ -1,0 +1,181 @@
+"""Agent-side preprocessing: the fused device path against (a) a frame-by-frame numpy restatement of
+the reference's wrapper stack (atari_wrappers.py:193-244, vec_frame_stack.py:17-30) driven through the plain per-frame
+API, and (b) on the GPU box, the HIP library against the CPU restatement, bit for bit."""
+import ctypes as C
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from support import synthetic_actions
+from toybox_amd import Engine, _abi
+
+GAMES = ["breakout", "space_invaders", "amidar"]
+
+
+def area_resize_exact(img, oh, ow):
+    """INTER_AREA by its definition, in exact rational arithmetic, round half up."""
+    H, W = img.shape
+    out = np.zeros((oh, ow), np.uint8)
+    for oy in range(oh):
+        y0, y1 = Fraction(oy * H, oh), Fraction((oy + 1) * H, oh)
+        for ox in range(ow):
+            x0, x1 = Fraction(ox * W, ow), Fraction((ox + 1) * W, ow)
+            acc = Fraction(0)
+            sy = int(y0)
+            while sy < y1:
+                wy = min(y1, sy + 1) - max(y0, sy)
+                sx = int(x0)
+                while sx < x1:
+                    acc += wy * (min(x1, sx + 1) - max(x0, sx)) * int(img[sy, sx])
+                    sx += 1
+                sy += 1
+            mean = acc / ((y1 - y0) * (x1 - x0))
+            out[oy, ox] = int(mean + Fraction(1, 2))      # floor(mean + 1/2)
+    return out
+
+
+def overlap_matrix(src, out):
+    """M[o, s] = length of the overlap of output cell o with source pixel s, in units of 1/out source pixels."""
+    m = np.zeros((out, src), np.int64)
+    for o in range(out):
+        lo, hi = o * src, (o + 1) * src
+        for s_ in range(lo // out, src):
+            if s_ * out >= hi:
+                break
+            m[o, s_] = min(hi, (s_ + 1) * out) - max(lo, s_ * out)
+    return m
+
+
+def area_resize_int(img, oh, ow):
+    """The same definition as two integer matrix products (fast enough for whole rollouts)."""
+    H, W = img.shape
+    acc = overlap_matrix(H, oh) @ img.astype(np.int64) @ overlap_matrix(W, ow).T
+    return ((acc + (H * W) // 2) // (H * W)).astype(np.uint8)
+
+
+def test_warp_area_matches_definition(oracle_lib):
+    oracle_lib.orc_warp_area.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    rng = np.random.default_rng(3)
+    for (H, W, oh, ow) in ((16, 24, 7, 9), (160, 240, 84, 84), (21, 32, 21, 32), (10, 10, 5, 2)):
+        img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        if (H, W) == (160, 240):
+            img[:80] = 0                                       # big flat areas + noise
+        got = np.zeros((oh, ow), np.uint8)
+        oracle_lib.orc_warp_area(img.ctypes.data, H, W, got.ctypes.data, oh, ow)
+        assert np.array_equal(got, area_resize_int(img, oh, ow)), (H, W, oh, ow)
+        if H * W <= 1000:
+            assert np.array_equal(got, area_resize_exact(img, oh, ow)), (H, W, oh, ow)
+    flat = np.full((160, 240), 137, np.uint8)
+    got = np.zeros((84, 84), np.uint8)
+    oracle_lib.orc_warp_area(flat.ctypes.data, 160, 240, got.ctypes.data, 84, 84)
+    assert (got == 137).all()
+
+
+class WrapperStack:
+    """numpy restatement of MaxAndSkipEnv + WarpFrame + ClipRewardEnv + VecFrameStack + VecEnv auto-reset over the
+    plain per-frame engine API."""
+
+    def __init__(self, engine, skip, oh, ow, stack, clip):
+        self.e, self.skip, self.oh, self.ow, self.stack, self.clip = engine, skip, oh, ow, stack, clip
+        self.obs = np.zeros((engine.n_envs, oh, ow, stack), np.uint8)
+
+    def _warp(self, frames):
+        return np.stack([area_resize_int(f[:, :, 0], self.oh, self.ow) for f in frames])
+
+    def reset(self):
+        self.e.new_game()
+        self.obs[...] = 0
+        self.obs[..., -1] = self._warp(self.e.render(1))
+        return self.obs.copy()
+
+    def step(self, actions):
+        n = self.e.n_envs
+        total = np.zeros(n, np.int64)
+        fin = np.zeros(n, bool)
+        buf = [None, None]
+        for i in range(self.skip):
+            r, d, _, _ = self.e.step(actions, auto_reset=False)
+            total += np.where(fin, 0, r)
+            fin |= d
+            if i == self.skip - 2:
+                buf[0] = self.e.render(1)
+            if i == self.skip - 1:
+                buf[1] = self.e.render(1)
+        if fin.any():
+            self.e.new_game(fin.astype(np.uint8))
+            reset_frames = self.e.render(1)
+        mx = buf[1] if buf[0] is None else np.maximum(buf[0], buf[1])
+        if fin.any():
+            mx = np.where(fin[:, None, None, None], reset_frames, mx)
+        small = self._warp(mx)
+        self.obs = np.roll(self.obs, -1, axis=-1)
+        self.obs[fin] = 0
+        self.obs[..., -1] = small
+        rew = np.sign(total).astype(np.float32) if self.clip else total.astype(np.float32)
+        return self.obs.copy(), rew, fin
+
+
+@pytest.mark.parametrize("game,oh,ow,skip,stack,clip", [("breakout", 42, 42, 4, 4, True), ("amidar", 50, 40, 3, 2, False),
+                                                       ("space_invaders", 42, 64, 1, 4, True)])
+def test_fused_equals_wrapper_composition(game, oh, ow, skip, stack, clip, oracle_lib):
+    n, steps = 3, 260
+    fused = Engine(game, n, lib=oracle_lib)
+    plain = Engine(game, n, lib=oracle_lib)
+    for e in (fused, plain):
+        e.seed(31)
+    fused.agent_init(skip=skip, out_h=oh, out_w=ow, stack=stack, clip_reward=clip)
+    ws = WrapperStack(plain, skip, oh, ow, stack, clip)
+    assert np.array_equal(fused.agent_reset(), ws.reset())
+    dones = 0
+    for t in range(steps):
+        a = synthetic_actions(game, n, t, seed=4)
+        o1, r1, d1 = fused.agent_step(a)
+        o2, r2, d2 = ws.step(a)
+        assert np.array_equal(d1, d2) and np.array_equal(r1, r2), t
+        assert np.array_equal(o1, o2), t
+        dones += int(d1.sum())
+    for i in range(n):
+        assert bytes(fused.get_state(i)) == bytes(plain.get_state(i))
+    if game == "breakout":
+        assert dones > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", GAMES)
+def test_gpu_fused_preprocessing_parity(game, hip_lib, oracle_lib):
+    """HIP fused path == CPU restatement, bit for bit: 84x84x4 stacks, clipped rewards, dones, through episode ends."""
+    n = 192
+    g, o = Engine(game, n, lib=hip_lib), Engine(game, n, lib=oracle_lib)
+    for e in (g, o):
+        e.seed(1234)
+        e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True)
+    assert np.array_equal(g.agent_reset(), o.agent_reset())
+    ends = 0
+    for t in range(400):
+        a = synthetic_actions(game, n, t)
+        og, rg, dg = g.agent_step(a)
+        oo, ro, do = o.agent_step(a)
+        assert np.array_equal(dg, do) and np.array_equal(rg, ro), t
+        if t % 20 == 0 or dg.any():
+            assert np.array_equal(og, oo), t
+        ends += int(dg.sum())
+    assert np.array_equal(og, oo)
+    for i in range(0, n, 7):
+        assert bytes(g.get_state(i)) == bytes(o.get_state(i))
+    if game == "breakout":
+        assert ends > 0
+    # device-resident form with in-kernel actions, other output geometry
+    g2, o2 = Engine(game, 64, lib=hip_lib), Engine(game, 64, lib=oracle_lib)
+    for e in (g2, o2):
+        e.seed(9)
+        e.agent_init(skip=2, out_h=40, out_w=52, stack=3, clip_reward=False)
+        e.agent_reset()
+    for t in range(100):
+        g2.agent_step_synthetic(1337, t, env_offset=5)
+        o2.agent_step_synthetic(1337, t, env_offset=5)
+    g2.sync()
+    a = synthetic_actions(game, 64, 100, seed=1337, env_offset=5)
+    x, y = g2.agent_step(a), o2.agent_step(a)
+    for p, q in zip(x, y):
+        assert np.array_equal(p, q)

@@ -18,6 +18,7 @@ OK, E_INVALID, E_NO_DEVICE, E_NOMEM, E_UNSUPPORTED, E_ACTION = 0, -1, -2, -3, -4
 BTN_LEFT, BTN_RIGHT, BTN_UP, BTN_DOWN, BTN_BUTTON1, BTN_BUTTON2 = 1, 2, 4, 8, 16, 32
 STEP_AUTO_RESET = 1
 BUF_REWARD, BUF_DONE, BUF_LIVES, BUF_SCORE, BUF_FRAME, BUF_PACKED = 0, 1, 2, 3, 4, 5
+BUF_AGENT_OBS, BUF_AGENT_REWARD, BUF_AGENT_DONE = 6, 7, 8
 
 BRK_MAX_BALLS, BRK_COLS, BRK_MAX_ROWS, BRK_MAX_BRICKS, BRK_MAX_STARTS, BRK_MAX_SEGMENTS = 4, 18, 14, 256, 8, 16
 
@@ -183,6 +184,10 @@ class AmidarState(C.Structure):
 STATE_TYPES = {GAME_BREAKOUT: BreakoutState, GAME_SPACE_INVADERS: SIState, GAME_AMIDAR: AmidarState}
 CONFIG_TYPES = {GAME_BREAKOUT: BreakoutConfig, GAME_SPACE_INVADERS: SIConfig, GAME_AMIDAR: AmidarConfig}
 
+class AgentConfig(C.Structure):
+    _fields_ = [("skip", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32), ("stack", C.c_int32), ("clip_reward", C.c_int32)]
+
+
 _p = C.POINTER
 _vp, _i, _u32, _u64, _sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_size_t
 
@@ -216,6 +221,11 @@ PROTOTYPES = {
     "tbx_get_config": (_i, [_vp, _vp, _sz]),
     "tbx_set_config": (_i, [_vp, _vp, _sz]),
     "tbx_query": (_i, [_vp, _i, _i, _p(C.c_int32), _i, _p(C.c_int32), _i]),
+    "tbx_agent_init": (_i, [_vp, _p(AgentConfig)]),
+    "tbx_agent_reset": (_i, [_vp, _vp]),
+    "tbx_agent_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "tbx_agent_step_device": (_i, [_vp, _vp, _vp]),
+    "tbx_agent_step_synthetic": (_i, [_vp, _u64, _u64, _u64, _vp]),
     "tbx_device_buffer": (_i, [_vp, _i, _p(_vp), _p(_sz)]),
     "tbx_sync": (_i, [_vp]),
 }

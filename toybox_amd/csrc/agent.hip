@@ -1,0 +1,329 @@
+// agent.hip -- the agent-side wrapper stack fused on the device: frame-skip with reward
+// sum, max over the last two frames, area resize of the gray frame, reward clipping and the rolling frame stack
+// (baselines/baselines/common/atari_wrappers.py:193-244, common/vec_env/vec_frame_stack.py:17-30), with the VecEnv
+// auto-reset.  Generic over the games: it drives the game's own step / new_game / gray render launches and adds
+// three small kernels of its own.  Only the stacked observation (out_h x out_w x stack bytes per env, 28 KB at
+// 84x84x4) is ever meant to leave the chip; the two full-resolution gray frames are scratch in HBM.
+
+#include "tbx_common.hpp"
+
+#include <cstring>
+#include <vector>
+
+struct AgentTaps {          // area-resize taps of one output row / column
+    int32_t start, n;
+    uint8_t w[8];           // overlap lengths in units of 1/out of a source pixel; their sum is the source extent
+};
+
+struct AgentState {
+    tbx_agent_config_t cfg{};
+    int H = 0, W = 0;
+    uint8_t *gray_a = nullptr, *gray_b = nullptr, *obs = nullptr, *fin = nullptr, *done_out = nullptr;
+    int32_t* racc = nullptr;
+    float* reward_out = nullptr;
+    AgentTaps *ty = nullptr, *tx = nullptr;
+};
+
+namespace {
+
+constexpr int MAX_TAPS = 8;
+
+__global__ void agent_acc_init_kernel(int32_t* racc, uint8_t* fin, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { racc[i] = 0; fin[i] = 0; }
+}
+
+// after every sub-frame: rewards count until (and including) the frame that ends the game (MaxAndSkipEnv breaks there)
+__global__ void agent_acc_kernel(const int32_t* reward, const uint8_t* done, int32_t* racc, uint8_t* fin, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || fin[i]) return;
+    racc[i] += reward[i];
+    if (done[i]) fin[i] = 1;
+}
+
+__device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t x = (a >> (8 * k)) & 255u, y = (b >> (8 * k)) & 255u;
+        r |= (x > y ? x : y) << (8 * k);
+    }
+    return r;
+}
+
+// One wave per env.  Per output row: the <= 8 source rows it overlaps are loaded as dwords (max of the two frames
+// unless the env was just reset), staged in LDS, and every lane reduces the taps of its output columns; the result
+// is rolled into the env's frame stack.
+template <int S>
+__global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+                                                               const uint8_t* __restrict__ fin, const int32_t* __restrict__ racc,
+                                                               const AgentTaps* __restrict__ ty, const AgentTaps* __restrict__ tx,
+                                                               uint8_t* __restrict__ obs, float* __restrict__ reward_out,
+                                                               uint8_t* __restrict__ done_out, int H, int W, int oh, int ow,
+                                                               int clip, int reset_mode, int n)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK][MAX_TAPS * 320];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (env >= n) return;
+    uint8_t* lds = lds_all[wave];
+    const bool fresh = reset_mode || fin[env];          // the observation is the (warped) reset frame alone
+    const uint8_t* fa = A + (size_t)env * H * W;
+    const uint8_t* fb = B + (size_t)env * H * W;
+    uint8_t* o = obs + (size_t)env * oh * ow * S;
+    const int words = W >> 2;
+    const int area = H * W;
+
+    for (int oy = 0; oy < oh; oy++) {
+        const AgentTaps rowt = ty[oy];
+        for (int k = 0; k < rowt.n; k++) {
+            const size_t off = (size_t)(rowt.start + k) * W;
+            for (int w4 = lane; w4 < words; w4 += 64) {
+                const uint32_t b = *reinterpret_cast<const uint32_t*>(fb + off + 4 * w4);
+                uint32_t v = b;
+                if (!fresh) v = bytemax4(*reinterpret_cast<const uint32_t*>(fa + off + 4 * w4), b);
+                *reinterpret_cast<uint32_t*>(lds + k * 320 + 4 * w4) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int ox = lane; ox < ow; ox += 64) {
+            const AgentTaps colt = tx[ox];
+            int sum = 0;
+            for (int k = 0; k < rowt.n; k++) {
+                int rs = 0;
+                for (int j = 0; j < colt.n; j++) rs += (int)colt.w[j] * (int)lds[k * 320 + colt.start + j];
+                sum += (int)rowt.w[k] * rs;
+            }
+            // weights are in 1/ow and 1/oh pixel units: sum = ow*oh * (area-weighted sum); normalise and round half up
+            const long num = (long)sum;
+            const long den = (long)area * 1;   // sum of all weights = W * H
+            const uint32_t val = (uint32_t)((num + den / 2) / den);
+            uint8_t* px = o + ((size_t)oy * ow + ox) * S;
+            if (S == 4) {
+                const uint32_t old = fresh ? 0u : *reinterpret_cast<uint32_t*>(px);
+                *reinterpret_cast<uint32_t*>(px) = (old >> 8) | (val << 24);
+            } else {
+#pragma unroll
+                for (int c = 0; c + 1 < S; c++) px[c] = fresh ? (uint8_t)0 : px[c + 1];
+                px[S - 1] = (uint8_t)val;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!reset_mode && lane == 0) {
+        const int r = racc[env];
+        reward_out[env] = clip ? (float)((r > 0) - (r < 0)) : (float)r;
+        done_out[env] = fin[env];
+    }
+}
+
+int agent_fail(tbx_engine* e, const char* what, hipError_t err)
+{
+    return e->fail(TBX_E_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(err));
+}
+
+#define AHIP(call)                                           \
+    do {                                                     \
+        hipError_t _e = (call);                              \
+        if (_e != hipSuccess) return agent_fail(e, #call, _e); \
+    } while (0)
+
+// overlap of output cell o (extent `src` in 1/out units) with the source pixels (extent `out` each)
+std::vector<AgentTaps> make_taps(int src, int out)
+{
+    std::vector<AgentTaps> t((size_t)out);
+    for (int o = 0; o < out; o++) {
+        const long lo = (long)o * src, hi = (long)(o + 1) * src;
+        AgentTaps a;
+        memset(&a, 0, sizeof a);
+        a.start = (int)(lo / out);
+        for (long s = a.start; s * out < hi && a.n < MAX_TAPS; s++) {
+            const long l = s * out > lo ? s * out : lo, h = (s + 1) * out < hi ? (s + 1) * out : hi;
+            a.w[a.n++] = (uint8_t)(h - l);
+        }
+        t[(size_t)o] = a;
+    }
+    return t;
+}
+
+int launch_warp(tbx_engine* e, int reset_mode, hipStream_t s)
+{
+    AgentState& a = *e->agent;
+    const dim3 grid((e->n + TBX_WAVES_PER_BLOCK - 1) / TBX_WAVES_PER_BLOCK), block(TBX_BLOCK);
+    const uint8_t* A = a.cfg.skip >= 2 ? a.gray_a : a.gray_b;
+#define WARP(S) hipLaunchKernelGGL(agent_warp_kernel<S>, grid, block, 0, s, A, a.gray_b, a.fin, a.racc, a.ty, a.tx, a.obs, \
+                                   a.reward_out, a.done_out, a.H, a.W, a.cfg.out_h, a.cfg.out_w, a.cfg.clip_reward, reset_mode, e->n)
+    switch (a.cfg.stack) {
+    case 1: WARP(1); break;
+    case 2: WARP(2); break;
+    case 3: WARP(3); break;
+    default: WARP(4); break;
+    }
+#undef WARP
+    AHIP(hipGetLastError());
+    return TBX_OK;
+}
+
+// the whole agent step, asynchronous on `s`
+int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s)
+{
+    AgentState& a = *e->agent;
+    const int n = e->n, tb = 256, gb = (n + tb - 1) / tb;
+    hipLaunchKernelGGL(agent_acc_init_kernel, dim3(gb), dim3(tb), 0, s, a.racc, a.fin, n);
+    for (int i = 0; i < a.cfg.skip; i++) {
+        int rc = e->ops->step(e, src, 0, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(agent_acc_kernel, dim3(gb), dim3(tb), 0, s, e->reward, e->done, a.racc, a.fin, n);
+        if (i == a.cfg.skip - 2) {
+            rc = e->ops->render(e, a.gray_a, 1, 0, n, s);
+            if (rc) return rc;
+        }
+    }
+    int rc = e->ops->new_game(e, a.fin, s);        // VecEnv auto-reset of the envs whose game ended
+    if (rc) return rc;
+    rc = e->ops->render(e, a.gray_b, 1, 0, n, s);
+    if (rc) return rc;
+    AHIP(hipGetLastError());
+    return launch_warp(e, 0, s);
+}
+
+}  // namespace
+
+void tbx_agent_free(tbx_engine* e)
+{
+    if (!e->agent) return;
+    AgentState* a = e->agent;
+    hipFree(a->gray_a); hipFree(a->gray_b); hipFree(a->obs); hipFree(a->fin); hipFree(a->done_out);
+    hipFree(a->racc); hipFree(a->reward_out); hipFree(a->ty); hipFree(a->tx);
+    delete a;
+    e->agent = nullptr;
+}
+
+int tbx_agent_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_bytes)
+{
+    if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    AgentState& a = *e->agent;
+    const size_t N = (size_t)e->n;
+    void* p = nullptr;
+    size_t b = 0;
+    if (which == TBX_BUF_AGENT_OBS) { p = a.obs; b = N * a.cfg.out_h * a.cfg.out_w * a.cfg.stack; }
+    else if (which == TBX_BUF_AGENT_REWARD) { p = a.reward_out; b = N * sizeof(float); }
+    else { p = a.done_out; b = N; }
+    *out_ptr = p;
+    if (out_bytes) *out_bytes = b;
+    return TBX_OK;
+}
+
+extern "C" {
+
+int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!cfg) return e->fail(TBX_E_INVALID, "agent config is NULL");
+    const int H = e->ops->height(), W = e->ops->width();
+    if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
+        cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128)
+        return e->fail(TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128)");
+    if ((H + cfg->out_h - 1) / cfg->out_h + 1 > MAX_TAPS || (W + cfg->out_w - 1) / cfg->out_w + 1 > MAX_TAPS)
+        return e->fail(TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
+    AHIP(hipSetDevice(e->device));
+    tbx_agent_free(e);
+    AgentState* a = new AgentState();
+    e->agent = a;
+    a->cfg = *cfg;
+    a->H = H; a->W = W;
+    const size_t N = (size_t)e->n;
+    AHIP(hipMalloc((void**)&a->gray_a, N * H * W));
+    AHIP(hipMalloc((void**)&a->gray_b, N * H * W));
+    AHIP(hipMalloc((void**)&a->obs, N * cfg->out_h * cfg->out_w * cfg->stack));
+    AHIP(hipMalloc((void**)&a->fin, N));
+    AHIP(hipMalloc((void**)&a->done_out, N));
+    AHIP(hipMalloc((void**)&a->racc, N * sizeof(int32_t)));
+    AHIP(hipMalloc((void**)&a->reward_out, N * sizeof(float)));
+    const std::vector<AgentTaps> ty = make_taps(H, cfg->out_h), tx = make_taps(W, cfg->out_w);
+    AHIP(hipMalloc((void**)&a->ty, ty.size() * sizeof(AgentTaps)));
+    AHIP(hipMalloc((void**)&a->tx, tx.size() * sizeof(AgentTaps)));
+    AHIP(hipMemcpy(a->ty, ty.data(), ty.size() * sizeof(AgentTaps), hipMemcpyHostToDevice));
+    AHIP(hipMemcpy(a->tx, tx.data(), tx.size() * sizeof(AgentTaps), hipMemcpyHostToDevice));
+    AHIP(hipMemset(a->obs, 0, N * cfg->out_h * cfg->out_w * cfg->stack));
+    AHIP(hipMemset(a->fin, 0, N));
+    AHIP(hipMemset(a->done_out, 0, N));
+    AHIP(hipMemset(a->racc, 0, N * sizeof(int32_t)));
+    AHIP(hipMemset(a->reward_out, 0, N * sizeof(float)));
+    return TBX_OK;
+}
+
+int tbx_agent_reset(tbx_engine* e, uint8_t* obs_host)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    AgentState& a = *e->agent;
+    AHIP(hipSetDevice(e->device));
+    int rc = e->ops->new_game(e, nullptr, e->stream);
+    if (rc) return rc;
+    rc = e->ops->render(e, a.gray_b, 1, 0, e->n, e->stream);
+    if (rc) return rc;
+    rc = launch_warp(e, 1, e->stream);
+    if (rc) return rc;
+    if (obs_host)
+        AHIP(hipMemcpyAsync(obs_host, a.obs, (size_t)e->n * a.cfg.out_h * a.cfg.out_w * a.cfg.stack, hipMemcpyDeviceToHost, e->stream));
+    AHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_agent_step_device(tbx_engine* e, const int32_t* actions_dev, void* stream)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (!actions_dev) return e->fail(TBX_E_INVALID, "actions pointer is NULL");
+    AHIP(hipSetDevice(e->device));
+    ActionSource src{};
+    src.actions = actions_dev;
+    src.single_env = -1;
+    return agent_step_async(e, src, (hipStream_t)stream);
+}
+
+int tbx_agent_step_synthetic(tbx_engine* e, uint64_t action_seed, uint64_t t, uint64_t env_offset, void* stream)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    AHIP(hipSetDevice(e->device));
+    ActionSource src{};
+    src.seed = action_seed; src.t = t; src.env_offset = env_offset;
+    src.single_env = -1;
+    return agent_step_async(e, src, (hipStream_t)stream);
+}
+
+int tbx_agent_step(tbx_engine* e, const int32_t* actions_host, float* reward_host, uint8_t* done_host, uint8_t* obs_host)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (!actions_host) return e->fail(TBX_E_INVALID, "actions pointer is NULL");
+    AgentState& a = *e->agent;
+    AHIP(hipSetDevice(e->device));
+    const size_t N = (size_t)e->n;
+    AHIP(hipMemcpyAsync(e->actions, actions_host, N * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    ActionSource src{};
+    src.actions = e->actions;
+    src.single_env = -1;
+    int rc = agent_step_async(e, src, e->stream);
+    if (rc) return rc;
+    if (reward_host) AHIP(hipMemcpyAsync(reward_host, a.reward_out, N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (done_host) AHIP(hipMemcpyAsync(done_host, a.done_out, N, hipMemcpyDeviceToHost, e->stream));
+    if (obs_host) AHIP(hipMemcpyAsync(obs_host, a.obs, N * a.cfg.out_h * a.cfg.out_w * a.cfg.stack, hipMemcpyDeviceToHost, e->stream));
+    AHIP(hipStreamSynchronize(e->stream));
+    // an illegal action id is reported like tbx_step does
+    uint32_t f = 0;
+    AHIP(hipMemcpy(&f, e->err_flag, sizeof f, hipMemcpyDeviceToHost));
+    if (f) {
+        AHIP(hipMemset(e->err_flag, 0, sizeof f));
+        return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
+    }
+    return TBX_OK;
+}
+
+}  // extern "C"

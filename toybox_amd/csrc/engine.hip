@@ -9,6 +9,8 @@
 #include <new>
 #include <vector>
 
+int tbx_agent_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_bytes);
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -211,6 +213,7 @@ int tbx_destroy(tbx_engine* e)
     if (!e) return TBX_OK;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    tbx_agent_free(e);
     if (e->ops) { e->ops->destroy(e); delete e->ops; }
     hipFree(e->sim_rng); hipFree(e->prev_score); hipFree(e->reward); hipFree(e->done);
     hipFree(e->lives_out); hipFree(e->score_out); hipFree(e->packed); hipFree(e->actions);
@@ -575,6 +578,8 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     case TBX_BUF_SCORE: p = e->score_out; b = N * 4; break;
     case TBX_BUF_FRAME: p = e->frame; b = e->frame_bytes; break;
     case TBX_BUF_PACKED: p = e->packed; b = N * 8; break;
+    case TBX_BUF_AGENT_OBS: case TBX_BUF_AGENT_REWARD: case TBX_BUF_AGENT_DONE:
+        return tbx_agent_buffer(e, which, out_ptr, out_bytes);
     default: return e->fail(TBX_E_INVALID, "unknown buffer id");
     }
     *out_ptr = p;

@@ -166,6 +166,7 @@ struct tbx_engine {
     void* staging = nullptr;        // device POD staging for get/set state
     size_t staging_bytes = 0;
     GameOps* ops = nullptr;
+    struct AgentState* agent = nullptr;   // fused agent-side preprocessing (agent.hip), lazily created
 
     int fail(int code, const std::string& msg) const
     {
@@ -194,6 +195,7 @@ struct GameOps {
     virtual int scalars(tbx_engine* e, int32_t* score_dev, int32_t* lives_dev, int32_t* level_dev, hipStream_t s) = 0;
 };
 
+void tbx_agent_free(tbx_engine* e);
 GameOps* tbx_make_breakout_ops();
 GameOps* tbx_make_si_ops();
 GameOps* tbx_make_amidar_ops();

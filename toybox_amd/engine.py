@@ -148,6 +148,34 @@ class Engine:
         self._check(self._lib.tbx_query(self._h, int(env), int(query_id), a, len(args), out, n_out))
         return [int(v) for v in out]
 
+    # ------------------------------------------------------------------ agent-side preprocessing (fused wrapper stack)
+    def agent_init(self, skip=4, out_h=84, out_w=84, stack=4, clip_reward=True):
+        cfg = _abi.AgentConfig(int(skip), int(out_h), int(out_w), int(stack), int(bool(clip_reward)))
+        self._check(self._lib.tbx_agent_init(self._h, C.byref(cfg)))
+        self._agent_shape = (self.n_envs, int(out_h), int(out_w), int(stack))
+
+    def agent_reset(self):
+        obs = np.empty(self._agent_shape, np.uint8)
+        self._check(self._lib.tbx_agent_reset(self._h, _ptr(obs)))
+        return obs
+
+    def agent_step(self, actions):
+        """actions: ALE ids.  Returns (obs uint8[N,oh,ow,stack], reward float32[N], done bool[N])."""
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        if a.shape != (self.n_envs,):
+            raise ValueError("actions must have shape (%d,)" % self.n_envs)
+        obs = np.empty(self._agent_shape, np.uint8)
+        reward = np.empty(self.n_envs, np.float32)
+        done = np.empty(self.n_envs, np.uint8)
+        self._check(self._lib.tbx_agent_step(self._h, _ptr(a), _ptr(reward), _ptr(done), _ptr(obs)))
+        return obs, reward, done.astype(bool)
+
+    def agent_step_synthetic(self, action_seed, t, env_offset=0, stream=0):
+        self._check(self._lib.tbx_agent_step_synthetic(self._h, int(action_seed), int(t), int(env_offset), C.c_void_p(int(stream))))
+
+    def agent_step_device(self, actions_ptr, stream=0):
+        self._check(self._lib.tbx_agent_step_device(self._h, C.c_void_p(int(actions_ptr)), C.c_void_p(int(stream))))
+
     # ------------------------------------------------------------------ device-resident path
     def step_device(self, actions_ptr, auto_reset=False, stream=0):
         flags = _abi.STEP_AUTO_RESET if auto_reset else 0
