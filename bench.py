@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--no-render", action="store_true", help="step-only mode (reported separately, no roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--protocol", default="batch", choices=["batch", "reference"],
+    ap.add_argument("--protocol", default="batch", choices=["batch", "reference", "agent"],
                     help="'reference' = the raw single-env loop of the reference's harness (test/benchmark.py:44-58)")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed/RCCL gather path even at world size 1")
     ap.add_argument("--cpu-envs", type=int, default=4096)
@@ -194,10 +194,40 @@ def bench_reference_protocol(args):
     return 0
 
 
+def bench_agent_protocol(args):
+    """agent steps/s of the fused wrapper stack (skip 4, 84x84 gray, stack 4, clipped reward): one agent
+    step = 4 game frames + 2 gray renders + max/warp/stack; only 28 KB per env leave the pass."""
+    from toybox_amd import Engine, hip
+    n, K, Wm = args.envs, args.steps, args.warmup
+    eng = Engine(args.game, n, device=0)
+    eng.seed(1234)
+    eng.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True)
+    eng.agent_reset()
+    stream = hip.Stream()
+    for t in range(Wm):
+        eng.agent_step_synthetic(1337, t, stream=stream.ptr)
+    hip.synchronize()
+    t0 = time.perf_counter()
+    for t in range(Wm, Wm + K):
+        eng.agent_step_synthetic(1337, t, stream=stream.ptr)
+    hip.synchronize()
+    dt = time.perf_counter() - t0
+    eng.sync()
+    out = {"metric": "agent steps/sec (skip-4, 84x84x4 obs), %s" % args.game, "value": n * K / dt, "unit": "agent-steps/s",
+           "env_frames_per_s": 4 * n * K / dt, "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": 1000 * dt / K,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "%s fused MaxAndSkip(4)+WarpFrame(84)+ClipReward+FrameStack(4), %d envs, device actions" % (args.game, n)}}
+    print(json.dumps(out), flush=True)
+    eng.close()
+    return 0
+
+
 def main():
     args = parse()
     if args.protocol == "reference":
         return bench_reference_protocol(args)
+    if args.protocol == "agent":
+        return bench_agent_protocol(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

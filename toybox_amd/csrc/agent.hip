@@ -54,65 +54,95 @@ __device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
     return r;
 }
 
-// One wave per env.  Per output row: the <= 8 source rows it overlaps are loaded as dwords (max of the two frames
-// unless the env was just reset), staged in LDS, and every lane reduces the taps of its output columns; the result
-// is rolled into the env's frame stack.
+// this lane's taps for one output column: first source pixel and 8 byte weights (zero padded)
+struct ColTaps { int start; uint32_t wlo, whi; };
+
+__device__ __forceinline__ ColTaps load_col(const AgentTaps* tx, int ox, int ow)
+{
+    const AgentTaps t = tx[ox < ow ? ox : 0];
+    ColTaps c;
+    c.start = t.start;
+    c.wlo = (uint32_t)t.w[0] | ((uint32_t)t.w[1] << 8) | ((uint32_t)t.w[2] << 16) | ((uint32_t)t.w[3] << 24);
+    c.whi = (uint32_t)t.w[4] | ((uint32_t)t.w[5] << 8) | ((uint32_t)t.w[6] << 16) | ((uint32_t)t.w[7] << 24);
+    return c;
+}
+
+// horizontal area sum of one staged source row for one output column: 8 bytes from `start`, dotted with the weights
+__device__ __forceinline__ uint32_t hsum(const uint8_t* row, const ColTaps& c)
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(row + (c.start & ~3));
+    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+    const uint32_t sh = (uint32_t)(c.start & 3);
+    const uint32_t b0 = __builtin_amdgcn_alignbyte(d1, d0, sh), b1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return __builtin_amdgcn_udot4(b0, c.wlo, __builtin_amdgcn_udot4(b1, c.whi, 0u, false), false);
+}
+
+// One wave per env, one pass over the SOURCE rows: each row (max of the two frames unless the env was just reset)
+// is staged in LDS once, every lane takes the horizontal area sums of its (up to two) output columns with two
+// v_dot4_u32_u8, and adds them with the row's vertical weights into the current / next output-row accumulators
+// (a source row overlaps at most two output rows because out_h <= H).  A finished output row is normalised with a
+// multiply-shift reciprocal (exact for sums < 2^25) and rolled into the env's frame stack.
 template <int S>
 __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                                const uint8_t* __restrict__ fin, const int32_t* __restrict__ racc,
-                                                               const AgentTaps* __restrict__ ty, const AgentTaps* __restrict__ tx,
+                                                               const AgentTaps* __restrict__ tx,
                                                                uint8_t* __restrict__ obs, float* __restrict__ reward_out,
                                                                uint8_t* __restrict__ done_out, int H, int W, int oh, int ow,
-                                                               int clip, int reset_mode, int n)
+                                                               uint64_t magic, int clip, int reset_mode, int n)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK][MAX_TAPS * 320];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK][352];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
     if (env >= n) return;
-    uint8_t* lds = lds_all[wave];
+    uint8_t* row = lds_all[wave];
     const bool fresh = reset_mode || fin[env];          // the observation is the (warped) reset frame alone
     const uint8_t* fa = A + (size_t)env * H * W;
     const uint8_t* fb = B + (size_t)env * H * W;
     uint8_t* o = obs + (size_t)env * oh * ow * S;
     const int words = W >> 2;
-    const int area = H * W;
+    const uint32_t half = (uint32_t)(H * W) / 2u;
+    const ColTaps c0 = load_col(tx, lane, ow), c1 = load_col(tx, lane + 64, ow);
+    const bool on0 = lane < ow, on1 = lane + 64 < ow;
+    if (lane < 8) reinterpret_cast<uint32_t*>(row)[80 + lane] = 0u;   // padding read by the 12-byte windows
 
-    for (int oy = 0; oy < oh; oy++) {
-        const AgentTaps rowt = ty[oy];
-        for (int k = 0; k < rowt.n; k++) {
-            const size_t off = (size_t)(rowt.start + k) * W;
-            for (int w4 = lane; w4 < words; w4 += 64) {
-                const uint32_t b = *reinterpret_cast<const uint32_t*>(fb + off + 4 * w4);
-                uint32_t v = b;
-                if (!fresh) v = bytemax4(*reinterpret_cast<const uint32_t*>(fa + off + 4 * w4), b);
-                *reinterpret_cast<uint32_t*>(lds + k * 320 + 4 * w4) = v;
-            }
+    uint32_t acc0[2] = {0, 0}, acc1[2] = {0, 0};        // [column slot]: current / next output row
+    for (int sy = 0; sy < H; sy++) {
+        for (int w4 = lane; w4 < words; w4 += 64) {
+            const uint32_t b = *reinterpret_cast<const uint32_t*>(fb + (size_t)sy * W + 4 * w4);
+            uint32_t v = b;
+            if (!fresh) v = bytemax4(*reinterpret_cast<const uint32_t*>(fa + (size_t)sy * W + 4 * w4), b);
+            reinterpret_cast<uint32_t*>(row)[w4] = v;
         }
         __builtin_amdgcn_wave_barrier();
-        for (int ox = lane; ox < ow; ox += 64) {
-            const AgentTaps colt = tx[ox];
-            int sum = 0;
-            for (int k = 0; k < rowt.n; k++) {
-                int rs = 0;
-                for (int j = 0; j < colt.n; j++) rs += (int)colt.w[j] * (int)lds[k * 320 + colt.start + j];
-                sum += (int)rowt.w[k] * rs;
-            }
-            // weights are in 1/ow and 1/oh pixel units: sum = ow*oh * (area-weighted sum); normalise and round half up
-            const long num = (long)sum;
-            const long den = (long)area * 1;   // sum of all weights = W * H
-            const uint32_t val = (uint32_t)((num + den / 2) / den);
-            uint8_t* px = o + ((size_t)oy * ow + ox) * S;
-            if (S == 4) {
-                const uint32_t old = fresh ? 0u : *reinterpret_cast<uint32_t*>(px);
-                *reinterpret_cast<uint32_t*>(px) = (old >> 8) | (val << 24);
-            } else {
+        // vertical split of this source row (extent oh in refined units) over output rows oy and oy+1 (extent H each)
+        const int oy = (sy * oh) / H;
+        const int top = (oy + 1) * H;
+        const int w_cur = min((sy + 1) * oh, top) - sy * oh, w_next = oh - w_cur;
+        const uint32_t h0 = on0 ? hsum(row, c0) : 0u, h1 = on1 ? hsum(row, c1) : 0u;
+        acc0[0] += (uint32_t)w_cur * h0; acc0[1] += (uint32_t)w_cur * h1;
+        acc1[0] += (uint32_t)w_next * h0; acc1[1] += (uint32_t)w_next * h1;
+        __builtin_amdgcn_wave_barrier();
+        if ((sy + 1) * oh >= top) {                      // output row oy is complete
 #pragma unroll
-                for (int c = 0; c + 1 < S; c++) px[c] = fresh ? (uint8_t)0 : px[c + 1];
-                px[S - 1] = (uint8_t)val;
+            for (int q = 0; q < 2; q++) {
+                const int ox = lane + 64 * q;
+                if (q == 0 ? on0 : on1) {
+                    const uint32_t val = (uint32_t)(((uint64_t)(acc0[q] + half) * magic) >> 42);   // (sum + area/2) / area
+                    uint8_t* px = o + ((size_t)oy * ow + ox) * S;
+                    if (S == 4) {
+                        const uint32_t old = fresh ? 0u : *reinterpret_cast<uint32_t*>(px);
+                        *reinterpret_cast<uint32_t*>(px) = (old >> 8) | (val << 24);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c + 1 < S; c++) px[c] = fresh ? (uint8_t)0 : px[c + 1];
+                        px[S - 1] = (uint8_t)val;
+                    }
+                }
+                acc0[q] = acc1[q];
+                acc1[q] = 0;
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
     if (!reset_mode && lane == 0) {
         const int r = racc[env];
@@ -155,8 +185,9 @@ int launch_warp(tbx_engine* e, int reset_mode, hipStream_t s)
     AgentState& a = *e->agent;
     const dim3 grid((e->n + TBX_WAVES_PER_BLOCK - 1) / TBX_WAVES_PER_BLOCK), block(TBX_BLOCK);
     const uint8_t* A = a.cfg.skip >= 2 ? a.gray_a : a.gray_b;
-#define WARP(S) hipLaunchKernelGGL(agent_warp_kernel<S>, grid, block, 0, s, A, a.gray_b, a.fin, a.racc, a.ty, a.tx, a.obs, \
-                                   a.reward_out, a.done_out, a.H, a.W, a.cfg.out_h, a.cfg.out_w, a.cfg.clip_reward, reset_mode, e->n)
+    const uint64_t magic = (1ull << 42) / (uint64_t)(a.H * a.W) + 1ull;   // exact for numerators < 2^42 / area >= 2^25
+#define WARP(S) hipLaunchKernelGGL(agent_warp_kernel<S>, grid, block, 0, s, A, a.gray_b, a.fin, a.racc, a.tx, a.obs, \
+                                   a.reward_out, a.done_out, a.H, a.W, a.cfg.out_h, a.cfg.out_w, magic, a.cfg.clip_reward, reset_mode, e->n)
     switch (a.cfg.stack) {
     case 1: WARP(1); break;
     case 2: WARP(2); break;

@@ -100,3 +100,50 @@ class ToyboxVecEnv:
     def get_action_meanings(self):
         from .constants import ACTION_MEANING
         return list(ACTION_MEANING.values())
+
+
+class ToyboxPreprocVecEnv:
+    """The DeepMind-style pipeline of the reference's baselines fork -- MaxAndSkipEnv(skip) -> WarpFrame(84x84 gray) ->
+    ClipRewardEnv -> VecFrameStack(stack) (atari_wrappers.py:193-244,324-360; vec_frame_stack.py:17-30) -- as ONE device
+    pass per agent step (tbx_agent_step): the learner only ever sees uint8[N, size, size, stack]."""
+
+    def __init__(self, game, num_envs, skip=4, size=84, stack=4, clip_rewards=True, seed=None, engine=None):
+        self.game = {"spaceinvaders": "space_invaders"}.get(game, game)
+        self.num_envs = int(num_envs)
+        self.engine = engine if engine is not None else _make_engine(self.game, self.num_envs)
+        self._action_set = sorted(self.engine.legal_actions)
+        self._lut = np.asarray(self._action_set, dtype=np.int32)
+        self.action_space = Discrete(len(self._action_set))
+        self.observation_space = Box(0, 255, (size, size, stack), "uint8")
+        if seed is not None:
+            for i in range(self.num_envs):
+                self.engine.seed(hash_seed(int(seed) + i + 1) % 2 ** 31, env=i)
+        self.engine.agent_init(skip=skip, out_h=size, out_w=size, stack=stack, clip_reward=clip_rewards)
+        self._pending = None
+        self.closed = False
+
+    def reset(self):
+        return self.engine.agent_reset()
+
+    def step_async(self, actions):
+        a = np.asarray(actions)
+        if a.shape != (self.num_envs,):
+            raise ValueError("actions must have shape (%d,)" % self.num_envs)
+        if a.min() < 0 or a.max() >= len(self._action_set):
+            raise AssertionError("action index out of range")
+        self._pending = self._lut[a.astype(np.int64)]
+
+    def step_wait(self):
+        assert self._pending is not None, "step_wait without step_async"
+        actions, self._pending = self._pending, None
+        obs, reward, done = self.engine.agent_step(actions)
+        return obs, reward, done, [{} for _ in range(self.num_envs)]
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        if not self.closed:
+            self.engine.close()
+            self.closed = True
