@@ -389,8 +389,8 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     int H, W;
     orc_frame_dims(e->game, &H, &W);
     if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
-        cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128)
-        return fail(e, TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128)");
+        cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > 84 * 84)
+        return fail(e, TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056)");
     if ((H + cfg->out_h - 1) / cfg->out_h + 1 > 8 || (W + cfg->out_w - 1) / cfg->out_w + 1 > 8)
         return fail(e, TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
     free(e->gray_a); free(e->gray_b); free(e->aobs); free(e->afin); free(e->adone); free(e->areward);

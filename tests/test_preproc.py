@@ -179,3 +179,23 @@ def test_gpu_fused_preprocessing_parity(game, hip_lib, oracle_lib):
     x, y = g2.agent_step(a), o2.agent_step(a)
     for p, q in zip(x, y):
         assert np.array_equal(p, q)
+
+
+@pytest.mark.gpu
+def test_gpu_breakout_fused_observation_equals_generic_path(hip_lib, monkeypatch):
+    """Breakout's record-based observation kernel (no full-resolution frames) == the generic render + warp path."""
+    n = 512
+    monkeypatch.setenv("TBX_AGENT_GENERIC", "1")
+    gen = Engine("breakout", n, lib=hip_lib)
+    gen.seed(77)
+    gen.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=False)
+    monkeypatch.setenv("TBX_AGENT_GENERIC", "0")
+    fus = Engine("breakout", n, lib=hip_lib)
+    fus.seed(77)
+    fus.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=False)
+    assert np.array_equal(gen.agent_reset(), fus.agent_reset())
+    for t in range(500):
+        a = synthetic_actions("breakout", n, t, seed=8)
+        x, y = gen.agent_step(a), fus.agent_step(a)
+        for p, q in zip(x, y):
+            assert np.array_equal(p, q), t

@@ -6,14 +6,11 @@
 // 84x84x4) is ever meant to leave the chip; the two full-resolution gray frames are scratch in HBM.
 
 #include "tbx_common.hpp"
+#include "agent_device.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
-
-struct AgentTaps {          // area-resize taps of one output row / column
-    int32_t start, n;
-    uint8_t w[8];           // overlap lengths in units of 1/out of a source pixel; their sum is the source extent
-};
 
 struct AgentState {
     tbx_agent_config_t cfg{};
@@ -22,6 +19,7 @@ struct AgentState {
     int32_t* racc = nullptr;
     float* reward_out = nullptr;
     AgentTaps *ty = nullptr, *tx = nullptr;
+    bool force_generic = false;   // TBX_AGENT_GENERIC=1: always go through full-resolution gray frames
 };
 
 namespace {
@@ -41,40 +39,6 @@ __global__ void agent_acc_kernel(const int32_t* reward, const uint8_t* done, int
     if (i >= n || fin[i]) return;
     racc[i] += reward[i];
     if (done[i]) fin[i] = 1;
-}
-
-__device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
-{
-    uint32_t r = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t x = (a >> (8 * k)) & 255u, y = (b >> (8 * k)) & 255u;
-        r |= (x > y ? x : y) << (8 * k);
-    }
-    return r;
-}
-
-// this lane's taps for one output column: first source pixel and 8 byte weights (zero padded)
-struct ColTaps { int start; uint32_t wlo, whi; };
-
-__device__ __forceinline__ ColTaps load_col(const AgentTaps* tx, int ox, int ow)
-{
-    const AgentTaps t = tx[ox < ow ? ox : 0];
-    ColTaps c;
-    c.start = t.start;
-    c.wlo = (uint32_t)t.w[0] | ((uint32_t)t.w[1] << 8) | ((uint32_t)t.w[2] << 16) | ((uint32_t)t.w[3] << 24);
-    c.whi = (uint32_t)t.w[4] | ((uint32_t)t.w[5] << 8) | ((uint32_t)t.w[6] << 16) | ((uint32_t)t.w[7] << 24);
-    return c;
-}
-
-// horizontal area sum of one staged source row for one output column: 8 bytes from `start`, dotted with the weights
-__device__ __forceinline__ uint32_t hsum(const uint8_t* row, const ColTaps& c)
-{
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(row + (c.start & ~3));
-    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
-    const uint32_t sh = (uint32_t)(c.start & 3);
-    const uint32_t b0 = __builtin_amdgcn_alignbyte(d1, d0, sh), b1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    return __builtin_amdgcn_udot4(b0, c.wlo, __builtin_amdgcn_udot4(b1, c.whi, 0u, false), false);
 }
 
 // One wave per env, one pass over the SOURCE rows: each row (max of the two frames unless the env was just reset)
@@ -128,16 +92,9 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
             for (int q = 0; q < 2; q++) {
                 const int ox = lane + 64 * q;
                 if (q == 0 ? on0 : on1) {
-                    const uint32_t val = (uint32_t)(((uint64_t)(acc0[q] + half) * magic) >> 42);   // (sum + area/2) / area
-                    uint8_t* px = o + ((size_t)oy * ow + ox) * S;
-                    if (S == 4) {
-                        const uint32_t old = fresh ? 0u : *reinterpret_cast<uint32_t*>(px);
-                        *reinterpret_cast<uint32_t*>(px) = (old >> 8) | (val << 24);
-                    } else {
-#pragma unroll
-                        for (int c = 0; c + 1 < S; c++) px[c] = fresh ? (uint8_t)0 : px[c + 1];
-                        px[S - 1] = (uint8_t)val;
-                    }
+                    // (sum + area/2) / area by multiply-shift; this kernel is bound by re-reading the two gray frames, so the
+                    // stack is rolled row by row (the record-based Breakout kernel stages it in LDS instead)
+                    stack_push<S>(o + ((size_t)oy * ow + ox) * S, (uint32_t)(((uint64_t)(acc0[q] + half) * magic) >> 42), fresh);
                 }
                 acc0[q] = acc1[q];
                 acc1[q] = 0;
@@ -199,27 +156,52 @@ int launch_warp(tbx_engine* e, int reset_mode, hipStream_t s)
     return TBX_OK;
 }
 
+AgentWarpArgs warp_args(tbx_engine* e, int reset_mode)
+{
+    AgentState& a = *e->agent;
+    AgentWarpArgs w;
+    w.fin = a.fin; w.racc = a.racc; w.tx = a.tx; w.obs = a.obs; w.reward_out = a.reward_out; w.done_out = a.done_out;
+    w.H = a.H; w.W = a.W; w.oh = a.cfg.out_h; w.ow = a.cfg.out_w; w.stack = a.cfg.stack; w.clip = a.cfg.clip_reward;
+    w.reset_mode = reset_mode;
+    w.two_frames = a.cfg.skip >= 2;
+    w.magic = (1ull << 42) / (uint64_t)(a.H * a.W) + 1ull;
+    return w;
+}
+
+// frame B (and the observation) once the sub-frames and the auto-reset are done
+int observe(tbx_engine* e, int reset_mode, hipStream_t s)
+{
+    AgentState& a = *e->agent;
+    if (e->ops->agent_fused() && !a.force_generic) {
+        int rc = e->ops->agent_snapshot(e, 1, s);
+        if (rc) return rc;
+        return e->ops->agent_warp(e, warp_args(e, reset_mode), s);
+    }
+    int rc = e->ops->render(e, a.gray_b, 1, 0, e->n, s);
+    if (rc) return rc;
+    return launch_warp(e, reset_mode, s);
+}
+
 // the whole agent step, asynchronous on `s`
 int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s)
 {
     AgentState& a = *e->agent;
     const int n = e->n, tb = 256, gb = (n + tb - 1) / tb;
+    const bool fused = e->ops->agent_fused() && !a.force_generic;
     hipLaunchKernelGGL(agent_acc_init_kernel, dim3(gb), dim3(tb), 0, s, a.racc, a.fin, n);
     for (int i = 0; i < a.cfg.skip; i++) {
         int rc = e->ops->step(e, src, 0, s);
         if (rc) return rc;
         hipLaunchKernelGGL(agent_acc_kernel, dim3(gb), dim3(tb), 0, s, e->reward, e->done, a.racc, a.fin, n);
         if (i == a.cfg.skip - 2) {
-            rc = e->ops->render(e, a.gray_a, 1, 0, n, s);
+            rc = fused ? e->ops->agent_snapshot(e, 0, s) : e->ops->render(e, a.gray_a, 1, 0, n, s);
             if (rc) return rc;
         }
     }
     int rc = e->ops->new_game(e, a.fin, s);        // VecEnv auto-reset of the envs whose game ended
     if (rc) return rc;
-    rc = e->ops->render(e, a.gray_b, 1, 0, n, s);
-    if (rc) return rc;
     AHIP(hipGetLastError());
-    return launch_warp(e, 0, s);
+    return observe(e, 0, s);
 }
 
 }  // namespace
@@ -257,8 +239,8 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     if (!cfg) return e->fail(TBX_E_INVALID, "agent config is NULL");
     const int H = e->ops->height(), W = e->ops->width();
     if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
-        cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128)
-        return e->fail(TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128)");
+        cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > AGENT_MAX_OUT_PX)
+        return e->fail(TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056)");
     if ((H + cfg->out_h - 1) / cfg->out_h + 1 > MAX_TAPS || (W + cfg->out_w - 1) / cfg->out_w + 1 > MAX_TAPS)
         return e->fail(TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
     AHIP(hipSetDevice(e->device));
@@ -267,6 +249,7 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     e->agent = a;
     a->cfg = *cfg;
     a->H = H; a->W = W;
+    if (const char* v = getenv("TBX_AGENT_GENERIC")) a->force_generic = atoi(v) != 0;
     const size_t N = (size_t)e->n;
     AHIP(hipMalloc((void**)&a->gray_a, N * H * W));
     AHIP(hipMalloc((void**)&a->gray_b, N * H * W));
@@ -296,9 +279,7 @@ int tbx_agent_reset(tbx_engine* e, uint8_t* obs_host)
     AHIP(hipSetDevice(e->device));
     int rc = e->ops->new_game(e, nullptr, e->stream);
     if (rc) return rc;
-    rc = e->ops->render(e, a.gray_b, 1, 0, e->n, e->stream);
-    if (rc) return rc;
-    rc = launch_warp(e, 1, e->stream);
+    rc = observe(e, 1, e->stream);
     if (rc) return rc;
     if (obs_host)
         AHIP(hipMemcpyAsync(obs_host, a.obs, (size_t)e->n * a.cfg.out_h * a.cfg.out_w * a.cfg.stack, hipMemcpyDeviceToHost, e->stream));

@@ -20,6 +20,7 @@
 
 #include "tbx_common.hpp"
 #include "raster.hpp"
+#include "agent_device.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -962,6 +963,197 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
     }
 }
 
+// ------------------------------------------------------------------ fused agent observation
+//
+// max(frame A, frame B) -> gray -> area warp -> frame stack, straight from the two 64-byte render records: the
+// full-resolution frames are never materialised.  One wave per env walks the 160 source scanlines; a scanline is
+// composed as one packed-gray dword per lane (4 pixels) for each record, max'd bytewise, staged in LDS and reduced
+// with the column taps (agent_device.hpp).  A scanline that neither starts a new row class (host-built boundary
+// mask: HUD glyph rows, top bar, side walls, each brick row) nor holds a paddle / ball of either record (per-env
+// overlay masks built from the packed rects) equals the previous one, so its horizontal sums are reused: ~130 of
+// the 160 lines of a Breakout frame cost a handful of scalar instructions.
+
+struct BrkGrayPal {
+    uint32_t bg, frame, paddle, ball;   // gray byte values
+    int32_t rows;
+    uint32_t row[TBX_BRK_MAX_ROWS];
+    uint64_t boundary[3];               // bit y: scanline y may differ from y-1 even without moving objects
+};
+
+// sets bits y0..y1-1 (clipped to 0..159) of a 160-bit row mask
+__device__ __forceinline__ void brk_mark_rows(uint64_t (&m)[3], int y0, int y1)
+{
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+        const int lo = max(y0 - 64 * w, 0), hi = min(y1 - 64 * w, 64);
+        if (hi > lo) m[w] |= (hi - lo >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+    }
+}
+
+__device__ __forceinline__ void brk_overlay_rows(const BrkRenderRec& rec, uint64_t (&m)[3])
+{
+#pragma unroll
+    for (int k = 0; k < 1 + MAXB; k++) {
+        const uint32_t rc = k == 0 ? rec.paddle : rec.ball[k - 1];
+        if ((rc & 255u) < ((rc >> 8) & 255u)) brk_mark_rows(m, (int)((rc >> 16) & 255u), (int)(rc >> 24));
+    }
+}
+
+struct BrkLineCache { int row; uint32_t dw; };
+
+// one scanline of one record as 4 gray bytes
+__device__ __forceinline__ uint32_t brk_gray_line(const BrkRenderRec& rec, const BrkGrayPal& pal, int y, int x0, uint32_t side_dw,
+                                                  const uint32_t (&hud)[4], BrkLineCache& bc)
+{
+    uint32_t d;
+    if (y < TBX_BRK_WALL_Y0) d = pal.bg * 0x01010101u;
+    else if (y < TBX_BRK_WALL_Y0 + 12) d = pal.frame * 0x01010101u;
+    else d = side_dw;
+    const int by = y - 43;
+    if (by >= 0 && by < 4 * pal.rows) {
+        const int row = by >> 2;
+        if (row != bc.row) {
+            bc.row = row;
+            uint32_t b = side_dw;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int bxp = x0 + i - 12;
+                if (bxp >= 0 && bxp < 216) {
+                    const int j = (bxp / 12) * pal.rows + row;
+                    const uint64_t w = (j < 64) ? rec.alive[0] : (j < 128) ? rec.alive[1] : (j < 192) ? rec.alive[2] : rec.alive[3];
+                    if ((w >> (j & 63)) & 1ull) b = (b & ~(0xFFu << (8 * i))) | (pal.row[row] << (8 * i));
+                }
+            }
+            bc.dw = b;
+        }
+        d = bc.dw;
+    }
+    // paddle, balls: packed clipped rects of the record
+#pragma unroll
+    for (int k = 0; k < 1 + MAXB; k++) {
+        const uint32_t rc = k == 0 ? rec.paddle : rec.ball[k - 1];
+        const int ry0 = (int)((rc >> 16) & 255u), ry1 = (int)(rc >> 24);
+        if (y >= ry0 && y < ry1) {
+            const int rx0 = (int)(rc & 255u), rx1 = (int)((rc >> 8) & 255u);
+            const uint32_t col = (k == 0 ? pal.paddle : pal.ball) * 0x01010101u;
+            uint32_t m = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (x0 + i >= rx0 && x0 + i < rx1) m |= 0xFFu << (8 * i);
+            d = (d & ~m) | (col & m);
+        }
+    }
+    if (y >= 2 && y < 12) {
+        const int gr = ((y - 2) >> 1) * 3;
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if ((hud[i] >> gr) & 1u) m |= 0xFFu << (8 * i);
+        d = (d & ~m) | ((pal.frame * 0x01010101u) & m);
+    }
+    return d;
+}
+
+template <int S>
+__global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRenderRec* __restrict__ recsA, const BrkRenderRec* __restrict__ recsB,
+                                                                   BrkGrayPal pal, AgentWarpArgs a, int n)
+{
+    constexpr int W = TBX_BRK_W, H = TBX_BRK_H;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK][352];
+    __shared__ __attribute__((aligned(16))) uint8_t vals_all[TBX_WAVES_PER_BLOCK][AGENT_MAX_OUT_PX];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (env >= n) return;
+    uint8_t* row = lds_all[wave];
+    uint8_t* vals = vals_all[wave];
+    const bool fresh = a.reset_mode || a.fin[env];
+    const BrkRenderRec recA = recsA[env], recB = recsB[env];
+    const int x0 = lane * 4;
+    const bool active = x0 < W;
+    uint8_t* o = a.obs + (size_t)env * a.oh * a.ow * S;
+    const uint32_t half = (uint32_t)(H * W) / 2u;
+    const ColTaps c0 = load_col(a.tx, lane, a.ow), c1 = load_col(a.tx, lane + 64, a.ow);
+    const bool on0 = lane < a.ow, on1 = lane + 64 < a.ow;
+    if (lane < 8) reinterpret_cast<uint32_t*>(row)[80 + lane] = 0u;
+    if (lane >= 60 && lane < 64) reinterpret_cast<uint32_t*>(row)[lane] = 0u;   // words 60..79 are never pixels
+    if (lane < 16) reinterpret_cast<uint32_t*>(row)[64 + lane] = 0u;
+
+    uint32_t side_dw = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) side_dw |= ((x0 + i < 12 || x0 + i >= 228) ? pal.frame : pal.bg) << (8 * i);
+    // HUD column bits of this lane's pixels for both records: bit 3*r = lit in glyph row r
+    uint32_t hudA[4], hudB[4];
+    {
+        const int hud_x0[7] = {36, 44, 52, 60, 68, 148, 196};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t sel = 7u << 2;
+#pragma unroll
+            for (int g = 0; g < 7; g++) {
+                const int dx = x0 + i - hud_x0[g];
+                if (dx >= 0 && dx < 6) sel = ((uint32_t)g << 2) | (uint32_t)(dx >> 1);
+            }
+            const uint32_t g = sel >> 2;
+            const uint32_t ga = g < 7 ? (uint32_t)BRK_DIGITS[(recA.hud >> (4 * g)) & 15u] : 0u;
+            const uint32_t gb = g < 7 ? (uint32_t)BRK_DIGITS[(recB.hud >> (4 * g)) & 15u] : 0u;
+            hudA[i] = (ga >> (sel & 3u)) & 0x1249u;
+            hudB[i] = (gb >> (sel & 3u)) & 0x1249u;
+        }
+    }
+
+    BrkLineCache bcA{-1, 0}, bcB{-1, 0};
+    uint64_t need[3] = {pal.boundary[0], pal.boundary[1], pal.boundary[2]};   // scanlines that must be composed
+    {
+        uint64_t ov[3] = {0, 0, 0};
+        brk_overlay_rows(recB, ov);
+        if (!fresh) brk_overlay_rows(recA, ov);
+#pragma unroll
+        for (int w = 0; w < 3; w++) need[w] |= ov[w];
+        // the line after a run of overlay lines differs from it as well
+        need[2] |= (ov[2] << 1) | (ov[1] >> 63);
+        need[1] |= (ov[1] << 1) | (ov[0] >> 63);
+        need[0] |= (ov[0] << 1) | 1ull;
+    }
+    uint32_t h0 = 0, h1 = 0;
+    uint32_t acc0[2] = {0, 0}, acc1[2] = {0, 0};
+    for (int sy = 0; sy < H; sy++) {
+        const uint64_t nw = sy < 64 ? need[0] : sy < 128 ? need[1] : need[2];
+        if ((nw >> (sy & 63)) & 1ull) {
+            const uint32_t dB = brk_gray_line(recB, pal, sy, x0, side_dw, hudB, bcB);
+            uint32_t v = dB;
+            if (!fresh) v = bytemax4(brk_gray_line(recA, pal, sy, x0, side_dw, hudA, bcA), dB);
+            if (active) reinterpret_cast<uint32_t*>(row)[lane] = v;
+            __builtin_amdgcn_wave_barrier();
+            h0 = on0 ? hsum(row, c0) : 0u;
+            h1 = on1 ? hsum(row, c1) : 0u;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int oy = (sy * a.oh) / H;
+        const int top = (oy + 1) * H;
+        const int w_cur = min((sy + 1) * a.oh, top) - sy * a.oh, w_next = a.oh - w_cur;
+        acc0[0] += (uint32_t)w_cur * h0; acc0[1] += (uint32_t)w_cur * h1;
+        acc1[0] += (uint32_t)w_next * h0; acc1[1] += (uint32_t)w_next * h1;
+        if ((sy + 1) * a.oh >= top) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int ox = lane + 64 * q;
+                if (q == 0 ? on0 : on1) {
+                    vals[oy * a.ow + ox] = (uint8_t)(((uint64_t)(acc0[q] + half) * a.magic) >> 42);
+                }
+                acc0[q] = acc1[q];
+                acc1[q] = 0;
+            }
+        }
+    }
+    stack_commit<S>(vals, o, a.oh * a.ow, lane, fresh);
+    if (!a.reset_mode && lane == 0) {
+        const int r = a.racc[env];
+        a.reward_out[env] = a.clip ? (float)((r > 0) - (r < 0)) : (float)r;
+        a.done_out[env] = a.fin[env];
+    }
+}
+
 // ------------------------------------------------------------------ state pack / unpack, scalars
 
 template <bool CUSTOM>
@@ -1151,6 +1343,7 @@ struct BreakoutOps : GameOps {
         hipFree(d.paddle); hipFree(d.n_balls); hipFree(d.balls); hipFree(d.n_bricks); hipFree(d.alive);
         if (d.custom) hipFree(d.custom);
         hipFree(recs);
+        hipFree(recsA);
         hipFree(cfg_dev);
     }
 
@@ -1210,6 +1403,55 @@ struct BreakoutOps : GameOps {
         case 3: launch_render<3>(out_dev, first_env, n_envs, s); break;
         case 4: launch_render<4>(out_dev, first_env, n_envs, s); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+        }
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    // ---- fused agent observation: frame A / B are copies of the 64-byte render records
+    BrkRenderRec* recsA = nullptr;
+
+    bool agent_fused() const override { return !custom; }
+
+    int agent_snapshot(tbx_engine* e, int which, hipStream_t s) override
+    {
+        if (!recs_valid) {
+            hipLaunchKernelGGL(brk_render_prep_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, recs, 0, e->n);
+            TBX_HIP(hipGetLastError());
+            recs_valid = true;
+        }
+        if (which == 0) {
+            if (!recsA) TBX_HIP(hipMalloc((void**)&recsA, sizeof(BrkRenderRec) * (size_t)e->n));
+            TBX_HIP(hipMemcpyAsync(recsA, recs, sizeof(BrkRenderRec) * (size_t)e->n, hipMemcpyDeviceToDevice, s));
+        }
+        return TBX_OK;
+    }
+
+    static uint32_t host_gray(uint32_t rgba)
+    {
+        const uint32_t r = rgba & 255u, g = (rgba >> 8) & 255u, b = (rgba >> 16) & 255u;
+        return (77u * r + 150u * g + 29u * b + 128u) >> 8;
+    }
+
+    int agent_warp(tbx_engine* e, const AgentWarpArgs& a, hipStream_t s) override
+    {
+        BrkGrayPal pal;
+        pal.bg = host_gray(c.bg); pal.frame = host_gray(c.frame); pal.paddle = host_gray(c.paddle); pal.ball = host_gray(c.ball);
+        pal.rows = c.n_rows;
+        for (int i = 0; i < TBX_BRK_MAX_ROWS; i++) pal.row[i] = host_gray(c.row_colors[i]);
+        pal.boundary[0] = pal.boundary[1] = pal.boundary[2] = 0;
+        auto mark = [&](int y) { if (y >= 0 && y < TBX_BRK_H) pal.boundary[y >> 6] |= 1ull << (y & 63); };
+        mark(0);
+        for (int y = 2; y <= 12; y += 2) mark(y);           // HUD glyph rows are 2 px tall, HUD ends at 12
+        mark(TBX_BRK_WALL_Y0); mark(TBX_BRK_WALL_Y0 + 12);  // top bar
+        for (int r = 0; r <= c.n_rows; r++) mark(43 + 4 * r); // each brick row and the line after the wall
+        const BrkRenderRec* A = (a.reset_mode || !a.two_frames || !recsA) ? recs : recsA;
+        const dim3 grid = grid_for(e->n), block(TBX_BLOCK);
+        switch (a.stack) {
+        case 1: hipLaunchKernelGGL(brk_agent_warp_kernel<1>, grid, block, 0, s, A, recs, pal, a, e->n); break;
+        case 2: hipLaunchKernelGGL(brk_agent_warp_kernel<2>, grid, block, 0, s, A, recs, pal, a, e->n); break;
+        case 3: hipLaunchKernelGGL(brk_agent_warp_kernel<3>, grid, block, 0, s, A, recs, pal, a, e->n); break;
+        default: hipLaunchKernelGGL(brk_agent_warp_kernel<4>, grid, block, 0, s, A, recs, pal, a, e->n); break;
         }
         TBX_HIP(hipGetLastError());
         return TBX_OK;

@@ -193,6 +193,11 @@ struct GameOps {
     virtual int pack_state(tbx_engine* e, int env, hipStream_t s) = 0;
     virtual int unpack_state(tbx_engine* e, int env, const void* pod_host, hipStream_t s) = 0;
     virtual int scalars(tbx_engine* e, int32_t* score_dev, int32_t* lives_dev, int32_t* level_dev, hipStream_t s) = 0;
+    // optional fused observation path of the agent layer (agent.hip): snapshot what the rasteriser needs of the current
+    // state as frame A (which = 0) or frame B (1), then produce the warped, max'd, stacked observation from the two
+    virtual bool agent_fused() const { return false; }
+    virtual int agent_snapshot(tbx_engine*, int /*which*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    virtual int agent_warp(tbx_engine*, const struct AgentWarpArgs&, hipStream_t) { return TBX_E_UNSUPPORTED; }
 };
 
 void tbx_agent_free(tbx_engine* e);
