@@ -344,6 +344,10 @@ int tbx_render_env(tbx_engine* engine, int env, uint8_t* out_host, int channels)
  * replaces Toybox.to_state_json / write_state_json (interventions/base.py:391,406). */
 int tbx_get_state(tbx_engine* engine, int env, void* pod_out, size_t size);
 int tbx_set_state(tbx_engine* engine, int env, const void* pod, size_t size);
+/* Batched forms for intervention sweeps over many envs: `count` consecutive records of
+ * record_size bytes for envs [first_env, first_env + count), one pack/unpack launch and one copy. */
+int tbx_get_states(tbx_engine* engine, int first_env, int count, void* pods_out, size_t record_size);
+int tbx_set_states(tbx_engine* engine, int first_env, int count, const void* pods, size_t record_size);
 /* Batch-wide config record (tbx_<game>_config_t); `rand` is env 0's simulator RNG on get and
  * is written to every env on set.  Does not start a new game.
  * replaces Toybox.config_to_json / write_config_json (interventions/base.py:390,402). */

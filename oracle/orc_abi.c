@@ -305,6 +305,28 @@ int tbx_set_state(tbx_engine* e, int env, const void* pod, size_t size)
     return TBX_OK;
 }
 
+int tbx_get_states(tbx_engine* e, int first, int count, void* pods, size_t size)
+{
+    if (!e) return TBX_E_INVALID;
+    if (first < 0 || count < 1 || first + count > e->n || !pods) return fail(e, TBX_E_INVALID, "env range out of bounds");
+    for (int i = 0; i < count; i++) {
+        int rc = tbx_get_state(e, first + i, (char*)pods + size * (size_t)i, size);
+        if (rc) return rc;
+    }
+    return TBX_OK;
+}
+
+int tbx_set_states(tbx_engine* e, int first, int count, const void* pods, size_t size)
+{
+    if (!e) return TBX_E_INVALID;
+    if (first < 0 || count < 1 || first + count > e->n || !pods) return fail(e, TBX_E_INVALID, "env range out of bounds");
+    for (int i = 0; i < count; i++) {
+        int rc = tbx_set_state(e, first + i, (const char*)pods + size * (size_t)i, size);
+        if (rc) return rc;
+    }
+    return TBX_OK;
+}
+
 int tbx_get_config(tbx_engine* e, void* pod, size_t size)
 {
     if (!e) return TBX_E_INVALID;

@@ -1,0 +1,77 @@
+"""Batched interventions (8f rank 3): vectorised state get/set over env ranges on both libraries; the batched path must
+equal env-by-env get_state/set_state, and engines driven through it must stay bit-identical to the oracle."""
+import numpy as np
+import pytest
+
+from support import synthetic_actions
+from toybox_amd import Engine
+from toybox_amd.interventions import BatchIntervention
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def lib(request, oracle_lib):
+    if request.param == "oracle":
+        return oracle_lib
+    from toybox_amd import _lib
+    return _lib.load()
+
+
+@pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar"])
+def test_batched_get_set_equals_single(game, lib):
+    n = 37
+    e = Engine(game, n, lib=lib)
+    e.seed(3)
+    e.new_game()
+    for t in range(60):
+        e.step(synthetic_actions(game, n, t))
+    arr = e.get_states(5, 20)
+    for k in range(20):
+        assert bytes(arr[k]) == bytes(e.get_state(5 + k))
+    rec = e.get_states_np()
+    assert rec.shape == (n,) and int(rec["lives"][0]) == e.get_state(0).lives
+    # write a shifted copy back: env i takes the state of env i+1
+    e.set_states(0, e.get_states(1, n - 1))
+    for k in range(n - 1):
+        assert bytes(e.get_state(k)) == bytes(rec[k + 1].tobytes())
+
+
+def test_breakout_channel_sweep(lib, oracle_lib):
+    """add_channel in 64 envs with one vectorised write (the reference does this one env and one JSON round-trip at a
+    time, test_breakout_interventions.py:60-76), then play on both engines."""
+    n = 64
+    e, o = Engine("breakout", n, lib=lib), Engine("breakout", n, lib=oracle_lib)
+    for x in (e, o):
+        x.seed(11)
+        x.new_game()
+        with BatchIntervention(x) as bi:
+            before = bi.breakout_bricks_remaining()
+            bi.breakout_add_channel(np.arange(n) % 18 if False else 4)
+            bi.states["lives"] = 2
+            assert bi.dirty_state
+            assert (bi.breakout_bricks_remaining() == before - 6).all()
+        with BatchIntervention(x) as bi:
+            assert not bi.dirty_state and (bi.states["lives"] == 2).all()
+            js = bi.json(7)
+            assert sum(1 for b in js["bricks"] if b["col"] == 4 and b["alive"]) == 0
+    for t in range(400):
+        a = synthetic_actions("breakout", n, t)
+        r1, r2 = e.step(a, auto_reset=True), o.step(a, auto_reset=True)
+        for p, q in zip(r1, r2):
+            assert np.array_equal(p, q)
+    assert bytes(e.get_states()) == bytes(o.get_states())
+
+
+def test_mode_sweeps(lib):
+    a = Engine("amidar", 9, lib=lib)
+    with BatchIntervention(a, 2, 5) as bi:
+        bi.amidar_set_mode("jump")
+    jt = a.get_states_np()["jump_timer"]
+    assert (jt[2:7] == 75).all() and (jt[:2] == 0).all() and (jt[7:] == 0).all()
+    s = Engine("space_invaders", 4, lib=lib)
+    with BatchIntervention(s) as bi:
+        bi.space_invaders_remove_mothership()
+    for t in range(700):
+        s.step([0] * 4)
+    assert (s.get_states_np()["ufo_appearance_counter"] == -1).all()
+    with pytest.raises(Exception):
+        s.get_states(2, 5)

@@ -218,6 +218,8 @@ PROTOTYPES = {
     "tbx_render_env": (_i, [_vp, _i, _vp, _i]),
     "tbx_get_state": (_i, [_vp, _i, _vp, _sz]),
     "tbx_set_state": (_i, [_vp, _i, _vp, _sz]),
+    "tbx_get_states": (_i, [_vp, _i, _i, _vp, _sz]),
+    "tbx_set_states": (_i, [_vp, _i, _i, _vp, _sz]),
     "tbx_get_config": (_i, [_vp, _vp, _sz]),
     "tbx_set_config": (_i, [_vp, _vp, _sz]),
     "tbx_query": (_i, [_vp, _i, _i, _p(C.c_int32), _i, _p(C.c_int32), _i]),

@@ -761,6 +761,8 @@ __device__ __forceinline__ void mover_out(const AmiRegs& s, tbx_amidar_mover_t& 
 
 __global__ void ami_pack_kernel(AmiDev d, int env, tbx_amidar_state_t* out)
 {
+    env += blockIdx.x;      // one block per env of the requested range
+    out += blockIdx.x;
     const int lane = threadIdx.x & 63;
     AmiRegs s;
     ami_load(d, env, lane, s);
@@ -802,6 +804,8 @@ __device__ __forceinline__ void mover_in(const tbx_amidar_mover_t& m, AmiRegs& s
 
 __global__ void ami_unpack_kernel(AmiDev d, int env, const tbx_amidar_state_t* in)
 {
+    env += blockIdx.x;
+    in += blockIdx.x;
     const int lane = threadIdx.x & 63;
     AmiRegs s;
     int32_t* f = s.f;
@@ -964,20 +968,23 @@ struct AmiOps : GameOps {
         return TBX_OK;
     }
 
-    int pack_state(tbx_engine* e, int env, hipStream_t s) override
+    int pack_state(tbx_engine* e, int env, int count, hipStream_t s) override
     {
-        hipLaunchKernelGGL(ami_pack_kernel, dim3(1), dim3(64), 0, s, d, env, (tbx_amidar_state_t*)e->staging);
+        hipLaunchKernelGGL(ami_pack_kernel, dim3(count), dim3(64), 0, s, d, env, (tbx_amidar_state_t*)e->staging);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 
-    int unpack_state(tbx_engine* e, int env, const void* pod_host, hipStream_t s) override
+    int unpack_state(tbx_engine* e, int env, int count, const void* pod_host, hipStream_t s) override
     {
-        const auto& st = *(const tbx_amidar_state_t*)pod_host;
-        if (st.n_enemies < 0 || st.n_enemies > TBX_AMI_MAX_ENEMIES) return e->fail(TBX_E_UNSUPPORTED, "amidar: the device engine holds at most 8 enemies per env");
-        if (st.n_boxes < 0 || st.n_boxes > TBX_AMI_MAX_BOXES) return e->fail(TBX_E_UNSUPPORTED, "amidar: the device engine holds at most 64 boxes per env");
-        TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof st, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(ami_unpack_kernel, dim3(1), dim3(64), 0, s, d, env, (const tbx_amidar_state_t*)e->staging);
+        const auto* sts = (const tbx_amidar_state_t*)pod_host;
+        for (int i = 0; i < count; i++) {
+            const auto& st = sts[i];
+            if (st.n_enemies < 0 || st.n_enemies > TBX_AMI_MAX_ENEMIES) return e->fail(TBX_E_UNSUPPORTED, "amidar: the device engine holds at most 8 enemies per env");
+            if (st.n_boxes < 0 || st.n_boxes > TBX_AMI_MAX_BOXES) return e->fail(TBX_E_UNSUPPORTED, "amidar: the device engine holds at most 64 boxes per env");
+        }
+        TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof(tbx_amidar_state_t) * (size_t)count, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(ami_unpack_kernel, dim3(count), dim3(64), 0, s, d, env, (const tbx_amidar_state_t*)e->staging);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

@@ -1159,6 +1159,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
 template <bool CUSTOM>
 __global__ void brk_pack_kernel(BrkDev d, BrkCfg c, int env, tbx_breakout_state_t* out)
 {
+    env += blockIdx.x;      // one block per env of the requested range
+    out += blockIdx.x;
     const int lane = threadIdx.x & 63;
     BrkRegs s;
     brk_load(d, env, lane, s);
@@ -1200,6 +1202,8 @@ __global__ void brk_pack_kernel(BrkDev d, BrkCfg c, int env, tbx_breakout_state_
 template <bool CUSTOM>
 __global__ void brk_unpack_kernel(BrkDev d, int env, const tbx_breakout_state_t* in)
 {
+    env += blockIdx.x;
+    in += blockIdx.x;
     const int lane = threadIdx.x & 63;
     BrkRegs s;
     s.rng.s0 = in->rand[0]; s.rng.s1 = in->rand[1];
@@ -1457,11 +1461,11 @@ struct BreakoutOps : GameOps {
         return TBX_OK;
     }
 
-    int pack_state(tbx_engine* e, int env, hipStream_t s) override
+    int pack_state(tbx_engine* e, int env, int count, hipStream_t s) override
     {
         auto* out = (tbx_breakout_state_t*)e->staging;
-        if (custom) hipLaunchKernelGGL(brk_pack_kernel<true>, dim3(1), dim3(64), 0, s, d, c, env, out);
-        else hipLaunchKernelGGL(brk_pack_kernel<false>, dim3(1), dim3(64), 0, s, d, c, env, out);
+        if (custom) hipLaunchKernelGGL(brk_pack_kernel<true>, dim3(count), dim3(64), 0, s, d, c, env, out);
+        else hipLaunchKernelGGL(brk_pack_kernel<false>, dim3(count), dim3(64), 0, s, d, c, env, out);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
@@ -1491,21 +1495,26 @@ struct BreakoutOps : GameOps {
         return TBX_OK;
     }
 
-    int unpack_state(tbx_engine* e, int env, const void* pod_host, hipStream_t s) override
+    int unpack_state(tbx_engine* e, int env, int count, const void* pod_host, hipStream_t s) override
     {
-        const auto& st = *(const tbx_breakout_state_t*)pod_host;
-        if (st.n_balls < 0 || st.n_balls > TBX_BRK_MAX_BALLS)
-            return e->fail(TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 4 balls per env");
-        if (st.n_bricks < 0 || st.n_bricks > TBX_BRK_MAX_BRICKS)
-            return e->fail(TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 256 bricks per env");
-        if (!custom && !is_canonical(st)) {
+        const auto* sts = (const tbx_breakout_state_t*)pod_host;
+        bool all_canonical = true;
+        for (int i = 0; i < count; i++) {
+            const auto& st = sts[i];
+            if (st.n_balls < 0 || st.n_balls > TBX_BRK_MAX_BALLS)
+                return e->fail(TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 4 balls per env");
+            if (st.n_bricks < 0 || st.n_bricks > TBX_BRK_MAX_BRICKS)
+                return e->fail(TBX_E_UNSUPPORTED, "breakout: the device engine holds at most 256 bricks per env");
+            if (!custom && all_canonical && !is_canonical(st)) all_canonical = false;
+        }
+        if (!custom && !all_canonical) {
             int rc = enable_custom(e, s);
             if (rc) return rc;
         }
-        TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof st, hipMemcpyHostToDevice, s));
+        TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof(tbx_breakout_state_t) * (size_t)count, hipMemcpyHostToDevice, s));
         auto* in = (const tbx_breakout_state_t*)e->staging;
-        if (custom) hipLaunchKernelGGL(brk_unpack_kernel<true>, dim3(1), dim3(64), 0, s, d, env, in);
-        else hipLaunchKernelGGL(brk_unpack_kernel<false>, dim3(1), dim3(64), 0, s, d, env, in);
+        if (custom) hipLaunchKernelGGL(brk_unpack_kernel<true>, dim3(count), dim3(64), 0, s, d, env, in);
+        else hipLaunchKernelGGL(brk_unpack_kernel<false>, dim3(count), dim3(64), 0, s, d, env, in);
         TBX_HIP(hipGetLastError());
         recs_valid = false;
         return TBX_OK;

@@ -497,29 +497,59 @@ int tbx_render_env(tbx_engine* e, int env, uint8_t* out_host, int channels)
     return TBX_OK;
 }
 
+static int ensure_staging(tbx_engine* e, size_t bytes)
+{
+    if (e->staging_bytes >= bytes) return TBX_OK;
+    EHIP(hipStreamSynchronize(e->stream));
+    if (e->staging) hipFree(e->staging);
+    e->staging = nullptr;
+    e->staging_bytes = 0;
+    EHIP(hipMalloc(&e->staging, bytes));
+    e->staging_bytes = bytes;
+    return TBX_OK;
+}
+
+int tbx_get_states(tbx_engine* e, int first_env, int count, void* pods, size_t record_size)
+{
+    CHECK_ENGINE(e);
+    if (first_env < 0 || count < 1 || first_env + count > e->n || !pods) return e->fail(TBX_E_INVALID, "env range out of bounds");
+    if (record_size != e->ops->state_size()) return e->fail(TBX_E_INVALID, "state record size mismatch");
+    EHIP(hipSetDevice(e->device));
+    int rc = ensure_staging(e, record_size * (size_t)count);
+    if (rc) return rc;
+    rc = e->ops->pack_state(e, first_env, count, e->stream);
+    if (rc) return rc;
+    EHIP(hipMemcpyAsync(pods, e->staging, record_size * (size_t)count, hipMemcpyDeviceToHost, e->stream));
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_set_states(tbx_engine* e, int first_env, int count, const void* pods, size_t record_size)
+{
+    CHECK_ENGINE(e);
+    if (first_env < 0 || count < 1 || first_env + count > e->n || !pods) return e->fail(TBX_E_INVALID, "env range out of bounds");
+    if (record_size != e->ops->state_size()) return e->fail(TBX_E_INVALID, "state record size mismatch");
+    EHIP(hipSetDevice(e->device));
+    int rc = ensure_staging(e, record_size * (size_t)count);
+    if (rc) return rc;
+    rc = e->ops->unpack_state(e, first_env, count, pods, e->stream);
+    if (rc) return rc;
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
 int tbx_get_state(tbx_engine* e, int env, void* pod, size_t size)
 {
     CHECK_ENGINE(e);
     if (env < 0 || env >= e->n || !pod) return e->fail(TBX_E_INVALID, "env index out of range");
-    if (size != e->ops->state_size()) return e->fail(TBX_E_INVALID, "state record size mismatch");
-    EHIP(hipSetDevice(e->device));
-    int rc = e->ops->pack_state(e, env, e->stream);
-    if (rc) return rc;
-    EHIP(hipMemcpyAsync(pod, e->staging, size, hipMemcpyDeviceToHost, e->stream));
-    EHIP(hipStreamSynchronize(e->stream));
-    return TBX_OK;
+    return tbx_get_states(e, env, 1, pod, size);
 }
 
 int tbx_set_state(tbx_engine* e, int env, const void* pod, size_t size)
 {
     CHECK_ENGINE(e);
     if (env < 0 || env >= e->n || !pod) return e->fail(TBX_E_INVALID, "env index out of range");
-    if (size != e->ops->state_size()) return e->fail(TBX_E_INVALID, "state record size mismatch");
-    EHIP(hipSetDevice(e->device));
-    int rc = e->ops->unpack_state(e, env, pod, e->stream);
-    if (rc) return rc;
-    EHIP(hipStreamSynchronize(e->stream));
-    return TBX_OK;
+    return tbx_set_states(e, env, 1, pod, size);
 }
 
 int tbx_get_config(tbx_engine* e, void* pod, size_t size)

@@ -743,6 +743,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
 
 __global__ void si_pack_kernel(SiDev d, int env, tbx_si_state_t* out)
 {
+    env += blockIdx.x;      // one block per env of the requested range
+    out += blockIdx.x;
     const int lane = threadIdx.x & 63;
     SiRegs s;
     si_load(d, env, lane, s);
@@ -792,6 +794,8 @@ __global__ void si_pack_kernel(SiDev d, int env, tbx_si_state_t* out)
 
 __global__ void si_unpack_kernel(SiDev d, int env, const tbx_si_state_t* in)
 {
+    env += blockIdx.x;
+    in += blockIdx.x;
     const int lane = threadIdx.x & 63;
     SiRegs s;
     int32_t* f = s.f;
@@ -932,21 +936,24 @@ struct SiOps : GameOps {
         return TBX_OK;
     }
 
-    int pack_state(tbx_engine* e, int env, hipStream_t s) override
+    int pack_state(tbx_engine* e, int env, int count, hipStream_t s) override
     {
-        hipLaunchKernelGGL(si_pack_kernel, dim3(1), dim3(64), 0, s, d, env, (tbx_si_state_t*)e->staging);
+        hipLaunchKernelGGL(si_pack_kernel, dim3(count), dim3(64), 0, s, d, env, (tbx_si_state_t*)e->staging);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 
-    int unpack_state(tbx_engine* e, int env, const void* pod_host, hipStream_t s) override
+    int unpack_state(tbx_engine* e, int env, int count, const void* pod_host, hipStream_t s) override
     {
-        const auto& st = *(const tbx_si_state_t*)pod_host;
-        if (st.n_enemies < 0 || st.n_enemies > TBX_SI_MAX_ENEMIES) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 64 enemies per env");
-        if (st.n_enemy_lasers < 0 || st.n_enemy_lasers > TBX_SI_MAX_LASERS) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 8 enemy lasers per env");
-        if (st.n_shields < 0 || st.n_shields > TBX_SI_MAX_SHIELDS) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 3 shields per env");
-        TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof st, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(si_unpack_kernel, dim3(1), dim3(64), 0, s, d, env, (const tbx_si_state_t*)e->staging);
+        const auto* sts = (const tbx_si_state_t*)pod_host;
+        for (int i = 0; i < count; i++) {
+            const auto& st = sts[i];
+            if (st.n_enemies < 0 || st.n_enemies > TBX_SI_MAX_ENEMIES) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 64 enemies per env");
+            if (st.n_enemy_lasers < 0 || st.n_enemy_lasers > TBX_SI_MAX_LASERS) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 8 enemy lasers per env");
+            if (st.n_shields < 0 || st.n_shields > TBX_SI_MAX_SHIELDS) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 3 shields per env");
+        }
+        TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof(tbx_si_state_t) * (size_t)count, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(si_unpack_kernel, dim3(count), dim3(64), 0, s, d, env, (const tbx_si_state_t*)e->staging);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

@@ -189,9 +189,9 @@ struct GameOps {
     virtual int new_game(tbx_engine* e, const uint8_t* mask_dev, hipStream_t s) = 0;
     virtual int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) = 0;
     virtual int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) = 0;
-    // pack env -> e->staging (device), unpack e->staging -> env
-    virtual int pack_state(tbx_engine* e, int env, hipStream_t s) = 0;
-    virtual int unpack_state(tbx_engine* e, int env, const void* pod_host, hipStream_t s) = 0;
+    // pack envs [env, env+count) -> e->staging (device, count records), unpack host records -> those envs
+    virtual int pack_state(tbx_engine* e, int env, int count, hipStream_t s) = 0;
+    virtual int unpack_state(tbx_engine* e, int env, int count, const void* pod_host, hipStream_t s) = 0;
     virtual int scalars(tbx_engine* e, int32_t* score_dev, int32_t* lives_dev, int32_t* level_dev, hipStream_t s) = 0;
     // optional fused observation path of the agent layer (agent.hip): snapshot what the rasteriser needs of the current
     // state as frame A (which = 0) or frame B (1), then produce the warped, max'd, stacked observation from the two

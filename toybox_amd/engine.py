@@ -132,6 +132,30 @@ class Engine:
             raise TypeError("state must be a %s" % self.state_type.__name__)
         self._check(self._lib.tbx_set_state(self._h, int(env), C.byref(st), C.sizeof(st)))
 
+    def get_states(self, first=0, count=None):
+        """Records of envs [first, first+count) as a ctypes array (one pack launch, one copy)."""
+        count = self.n_envs - first if count is None else int(count)
+        arr = (self.state_type * count)()
+        self._check(self._lib.tbx_get_states(self._h, int(first), count, C.cast(arr, C.c_void_p), C.sizeof(self.state_type)))
+        return arr
+
+    def set_states(self, first, arr):
+        count = len(arr)
+        if not isinstance(arr, C.Array) or arr._type_ is not self.state_type:
+            raise TypeError("states must be a ctypes array of %s" % self.state_type.__name__)
+        self._check(self._lib.tbx_set_states(self._h, int(first), count, C.cast(arr, C.c_void_p), C.sizeof(self.state_type)))
+
+    def get_states_np(self, first=0, count=None):
+        """The same records as a numpy structured array (fields named like the C struct): vectorised interventions,
+        e.g. `st = e.get_states_np(); st['lives'] = 1; e.set_states_np(0, st)`."""
+        arr = self.get_states(first, count)
+        return np.frombuffer(arr, dtype=np.dtype(self.state_type)).copy()
+
+    def set_states_np(self, first, records):
+        rec = np.ascontiguousarray(records, dtype=np.dtype(self.state_type))
+        arr = (self.state_type * len(rec)).from_buffer_copy(rec.tobytes())
+        self.set_states(first, arr)
+
     def get_config(self):
         cfg = self.config_type()
         self._check(self._lib.tbx_get_config(self._h, C.byref(cfg), C.sizeof(cfg)))
