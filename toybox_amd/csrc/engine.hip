@@ -217,7 +217,7 @@ int tbx_destroy(tbx_engine* e)
     if (e->ops) { e->ops->destroy(e); delete e->ops; }
     hipFree(e->sim_rng); hipFree(e->prev_score); hipFree(e->reward); hipFree(e->done);
     hipFree(e->lives_out); hipFree(e->score_out); hipFree(e->packed); hipFree(e->actions);
-    hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame); hipFree(e->staging);
+    hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame); hipFree(e->staging); hipFree(e->scal); hipFree(e->one_frame);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return TBX_OK;
@@ -277,6 +277,7 @@ int tbx_create(int game, int n_envs, int device, const void* config_pod, size_t 
     CHIP(hipMalloc((void**)&e->actions, N * sizeof(int32_t)));
     CHIP(hipMalloc((void**)&e->mask, N));
     CHIP(hipMalloc((void**)&e->err_flag, sizeof(uint32_t)));
+    CHIP(hipMalloc((void**)&e->scal, 3 * N * sizeof(int32_t)));
     CHIP(hipMemsetAsync(e->err_flag, 0, sizeof(uint32_t), e->stream));
     CHIP(hipMemsetAsync(e->reward, 0, N * sizeof(int32_t), e->stream));
     CHIP(hipMemsetAsync(e->done, 0, N, e->stream));
@@ -430,16 +431,12 @@ int tbx_get_scalars(tbx_engine* e, int32_t* score, int32_t* lives, int32_t* leve
     CHECK_ENGINE(e);
     EHIP(hipSetDevice(e->device));
     const size_t N = (size_t)e->n;
-    // reuse reward-sized scratch: allocate a temporary device block of 3N ints
-    int32_t* tmp = nullptr;
-    EHIP(hipMalloc((void**)&tmp, 3 * N * sizeof(int32_t)));
+    int32_t* tmp = e->scal;
     int rc = e->ops->scalars(e, tmp, tmp + N, tmp + 2 * N, e->stream);
-    if (rc) { hipFree(tmp); return rc; }
+    if (rc) return rc;
     std::vector<int32_t> host(3 * N);
-    hipError_t he = hipMemcpyAsync(host.data(), tmp, 3 * N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
-    hipFree(tmp);
-    if (he != hipSuccess) return hip_fail(e, "tbx_get_scalars copy", he);
+    EHIP(hipMemcpyAsync(host.data(), tmp, 3 * N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    EHIP(hipStreamSynchronize(e->stream));
     for (size_t i = 0; i < N; i++) {
         if (score) score[i] = host[i];
         if (lives) lives[i] = host[N + i];
@@ -483,17 +480,11 @@ int tbx_render_env(tbx_engine* e, int env, uint8_t* out_host, int channels)
     if (channels != 1 && channels != 3 && channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
     EHIP(hipSetDevice(e->device));
     const size_t bytes = (size_t)e->ops->height() * e->ops->width() * channels;
-    uint8_t* tmp = nullptr;
-    EHIP(hipMalloc((void**)&tmp, bytes));
-    int rc = e->ops->render(e, tmp, channels, env, 1, e->stream);
-    hipError_t he = hipSuccess;
-    if (!rc) {
-        he = hipMemcpyAsync(out_host, tmp, bytes, hipMemcpyDeviceToHost, e->stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
-    }
-    hipFree(tmp);
+    if (!e->one_frame) EHIP(hipMalloc((void**)&e->one_frame, (size_t)e->ops->height() * e->ops->width() * 4));
+    int rc = e->ops->render(e, e->one_frame, channels, env, 1, e->stream);
     if (rc) return rc;
-    if (he != hipSuccess) return hip_fail(e, "tbx_render_env copy", he);
+    EHIP(hipMemcpyAsync(out_host, e->one_frame, bytes, hipMemcpyDeviceToHost, e->stream));
+    EHIP(hipStreamSynchronize(e->stream));
     return TBX_OK;
 }
 

@@ -161,6 +161,8 @@ struct tbx_engine {
     int32_t* actions = nullptr;     // [N] staging for host actions
     uint8_t* mask = nullptr;        // [N] staging for new_game masks
     uint32_t* err_flag = nullptr;   // device word: bit0 = illegal action seen
+    int32_t* scal = nullptr;        // [3][N] scratch of tbx_get_scalars
+    uint8_t* one_frame = nullptr;   // H*W*4 scratch of tbx_render_env
     uint8_t* frame = nullptr;       // engine-owned frame buffer (lazy)
     size_t frame_bytes = 0;
     void* staging = nullptr;        // device POD staging for get/set state
