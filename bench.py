@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--protocol", default="batch", choices=["batch", "reference", "agent"],
                     help="'reference' = the raw single-env loop of the reference's harness (test/benchmark.py:44-58)")
+    ap.add_argument("--deepmind", action="store_true",
+                    help="agent protocol: also EpisodicLife + FireReset + NoopReset(30) + episode monitor (wrap_deepmind)")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed/RCCL gather path even at world size 1")
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=40)
@@ -201,7 +203,9 @@ def bench_agent_protocol(args):
     n, K, Wm = args.envs, args.steps, args.warmup
     eng = Engine(args.game, n, device=0)
     eng.seed(1234)
-    eng.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True)
+    dm = bool(args.deepmind)
+    eng.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=dm, fire_reset=dm,
+                   noop_max=30 if dm else 0, noop_seed=2024)
     eng.agent_reset()
     stream = hip.Stream()
     for t in range(Wm):
@@ -216,7 +220,8 @@ def bench_agent_protocol(args):
     out = {"metric": "agent steps/sec (skip-4, 84x84x4 obs), %s" % args.game, "value": n * K / dt, "unit": "agent-steps/s",
            "env_frames_per_s": 4 * n * K / dt, "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": 1000 * dt / K,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": "%s fused MaxAndSkip(4)+WarpFrame(84)+ClipReward+FrameStack(4), %d envs, device actions" % (args.game, n)}}
+           "config": {"workload": "%s fused %sMaxAndSkip(4)+WarpFrame(84)+ClipReward+FrameStack(4), %d envs, device actions"
+                                  % (args.game, "NoopReset(30)+EpisodicLife+FireReset+Monitor+" if dm else "", n)}}
     print(json.dumps(out), flush=True)
     eng.close()
     return 0

@@ -377,6 +377,14 @@ typedef struct tbx_agent_config {
     int32_t out_h, out_w;  /* 84, 84 */
     int32_t stack;         /* 1..4 (4) */
     int32_t clip_reward;   /* 0 / 1 */
+    /* the reset-time wrappers and the episode monitor of the same stack */
+    int32_t episodic_life; /* EpisodicLifeEnv (atari_wrappers.py:157-191): a lost life ends the agent's episode; the game is
+                              only restarted on a real game over, otherwise it is advanced by one no-op agent step */
+    int32_t fire_reset;    /* FireResetEnv (:137-155): after every reset press action #1 (FIRE) then action #2 */
+    int32_t noop_max;      /* NoopResetEnv (:108-135): 1..noop_max no-op frames after a real reset; 0 = off */
+    uint64_t noop_seed;    /* the reference draws that number from numpy's RNG; here it is the counter-based
+                              1 + splitmix64(noop_seed ^ (global env << 32) ^ episode index) % noop_max */
+    uint64_t env_offset;   /* global index of env 0 of this engine (sharded batches) */
 } tbx_agent_config_t;
 
 int tbx_agent_init(tbx_engine* engine, const tbx_agent_config_t* cfg);
@@ -392,6 +400,12 @@ int tbx_agent_step_synthetic(tbx_engine* engine, uint64_t action_seed, uint64_t 
 #define TBX_BUF_AGENT_OBS    6   /* uint8[N][out_h][out_w][stack] */
 #define TBX_BUF_AGENT_REWARD 7   /* float32[N] */
 #define TBX_BUF_AGENT_DONE   8   /* uint8[N] */
+/* episode monitor (bench.Monitor / VecMonitor: baselines/bench/monitor.py:51-76, common/vec_env/vec_monitor.py:21-37) */
+#define TBX_BUF_AGENT_EP_DONE   9    /* uint8[N]   a real episode (game over) ended during the last agent step */
+#define TBX_BUF_AGENT_EP_RETURN 10   /* float32[N] its unclipped return 'r' (valid where EP_DONE) */
+#define TBX_BUF_AGENT_EP_LENGTH 11   /* int32[N]   its length 'l' in agent steps (valid where EP_DONE) */
+/* host copy of the three episode-monitor arrays of the last agent step (any pointer may be NULL) */
+int tbx_agent_episodes(tbx_engine* engine, uint8_t* ep_done_host, float* ep_return_host, int32_t* ep_length_host);
 
 /* Address of an engine-owned device buffer (TBX_BUF_*). */
 int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out_bytes);

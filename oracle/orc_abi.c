@@ -28,6 +28,10 @@ struct tbx_engine {
     tbx_agent_config_t acfg;
     uint8_t *gray_a, *gray_b, *aobs, *afin, *adone;
     float* areward;
+    /* Monitor / EpisodicLifeEnv state and this step's episode records */
+    int32_t *ep_ret, *ep_len, *ep_index, *prev_lives, *ep_len_out;
+    uint8_t* ep_done;
+    float* ep_ret_out;
 };
 
 static char g_err[256];
@@ -63,12 +67,14 @@ size_t tbx_config_size(int game)
     }
 }
 
+static void agent_free(tbx_engine* e);
+
 int tbx_destroy(tbx_engine* e)
 {
     if (!e) return TBX_OK;
     free(e->cfg); free(e->states); free(e->sim); free(e->prev); free(e->reward); free(e->lives);
     free(e->score); free(e->done); free(e->packed); free(e->frame);
-    free(e->gray_a); free(e->gray_b); free(e->aobs); free(e->afin); free(e->adone); free(e->areward);
+    agent_free(e);
     free(e);
     return TBX_OK;
 }
@@ -384,10 +390,14 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     case TBX_BUF_FRAME: p = e->frame; b = e->frame_bytes; break;
     case TBX_BUF_PACKED: p = e->packed; b = n * 8; break;
     case TBX_BUF_AGENT_OBS: case TBX_BUF_AGENT_REWARD: case TBX_BUF_AGENT_DONE:
+    case TBX_BUF_AGENT_EP_DONE: case TBX_BUF_AGENT_EP_RETURN: case TBX_BUF_AGENT_EP_LENGTH:
         if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
         if (which == TBX_BUF_AGENT_OBS) { p = e->aobs; b = n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack; }
         else if (which == TBX_BUF_AGENT_REWARD) { p = e->areward; b = n * 4; }
-        else { p = e->adone; b = n; }
+        else if (which == TBX_BUF_AGENT_DONE) { p = e->adone; b = n; }
+        else if (which == TBX_BUF_AGENT_EP_DONE) { p = e->ep_done; b = n; }
+        else if (which == TBX_BUF_AGENT_EP_RETURN) { p = e->ep_ret_out; b = n * 4; }
+        else { p = e->ep_len_out; b = n * 4; }
         break;
     default: return fail(e, TBX_E_INVALID, "unknown buffer id");
     }
@@ -404,6 +414,16 @@ int tbx_sync(tbx_engine* e)
 
 /* ---------------------------------------------------------------- agent-side preprocessing */
 
+static void agent_free(tbx_engine* e)
+{
+    free(e->gray_a); free(e->gray_b); free(e->aobs); free(e->afin); free(e->adone); free(e->areward);
+    free(e->ep_ret); free(e->ep_len); free(e->ep_index); free(e->prev_lives); free(e->ep_len_out); free(e->ep_done);
+    free(e->ep_ret_out);
+    e->gray_a = e->gray_b = e->aobs = e->afin = e->adone = e->ep_done = NULL;
+    e->areward = e->ep_ret_out = NULL;
+    e->ep_ret = e->ep_len = e->ep_index = e->prev_lives = e->ep_len_out = NULL;
+}
+
 int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
 {
     if (!e) return TBX_E_INVALID;
@@ -411,11 +431,12 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     int H, W;
     orc_frame_dims(e->game, &H, &W);
     if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
-        cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > 84 * 84)
-        return fail(e, TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056)");
+        cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > 84 * 84 || cfg->noop_max < 0 ||
+        cfg->noop_max > 1000)
+        return fail(e, TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000)");
     if ((H + cfg->out_h - 1) / cfg->out_h + 1 > 8 || (W + cfg->out_w - 1) / cfg->out_w + 1 > 8)
         return fail(e, TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
-    free(e->gray_a); free(e->gray_b); free(e->aobs); free(e->afin); free(e->adone); free(e->areward);
+    agent_free(e);
     size_t n = (size_t)e->n;
     e->acfg = *cfg;
     e->gray_a = (uint8_t*)calloc(n, (size_t)H * W);
@@ -424,6 +445,10 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     e->afin = (uint8_t*)calloc(n, 1);
     e->adone = (uint8_t*)calloc(n, 1);
     e->areward = (float*)calloc(n, sizeof(float));
+    e->ep_ret = (int32_t*)calloc(n, 4); e->ep_len = (int32_t*)calloc(n, 4); e->ep_index = (int32_t*)calloc(n, 4);
+    e->prev_lives = (int32_t*)calloc(n, 4); e->ep_len_out = (int32_t*)calloc(n, 4);
+    e->ep_done = (uint8_t*)calloc(n, 1);
+    e->ep_ret_out = (float*)calloc(n, sizeof(float));
     e->agent_on = 1;
     return TBX_OK;
 }
@@ -438,7 +463,7 @@ static void agent_observe(tbx_engine* e, int all_fresh)
     for (int i = 0; i < e->n; i++) {
         const uint8_t* a = (e->acfg.skip >= 2 ? e->gray_a : e->gray_b) + (size_t)i * H * W;
         const uint8_t* b = e->gray_b + (size_t)i * H * W;
-        const int fresh = all_fresh || e->afin[i];
+        const int fresh = all_fresh || e->adone[i];
         for (int p = 0; p < H * W; p++) mx[p] = fresh ? b[p] : (a[p] > b[p] ? a[p] : b[p]);
         orc_warp_area(mx, H, W, small, oh, ow);
         orc_stack_push(e->aobs + (size_t)i * oh * ow * st, small, oh, ow, st, fresh);
@@ -446,14 +471,137 @@ static void agent_observe(tbx_engine* e, int all_fresh)
     free(mx); free(small);
 }
 
+/* ---- the reset path of the wrapper stack, one env at a time.
+ * NoopResetEnv -> MaxAndSkipEnv -> Monitor -> EpisodicLifeEnv -> FireResetEnv
+ * (baselines/baselines/common/atari_wrappers.py:12-36 noop reset, :99-130 max-and-skip, :58-96 episodic life,
+ *  :38-56 fire reset; baselines/baselines/bench/monitor.py:51-76 episode records).  Each wrapper is a function
+ * over the one below it, as in the Python. */
+typedef struct {
+    tbx_engine* e;
+    int i;
+    int was_real_done;      /* EpisodicLifeEnv.was_real_done */
+} wrap_t;
+
+static void* env_state(tbx_engine* e, int i) { return e->states + (size_t)i * e->ssz; }
+
+static void raw_step(tbx_engine* e, int i, uint32_t buttons)
+{
+    switch (e->game) {
+    case TBX_GAME_BREAKOUT: orc_breakout_step((const tbx_breakout_config_t*)e->cfg, (tbx_breakout_state_t*)env_state(e, i), buttons); break;
+    case TBX_GAME_SPACE_INVADERS: orc_si_step((const tbx_si_config_t*)e->cfg, (tbx_si_state_t*)env_state(e, i), buttons); break;
+    default: orc_amidar_step((const tbx_amidar_config_t*)e->cfg, (tbx_amidar_state_t*)env_state(e, i), buttons); break;
+    }
+}
+static void raw_new_game(tbx_engine* e, int i)
+{
+    uint64_t* sim = e->sim + 2 * (size_t)i;
+    switch (e->game) {
+    case TBX_GAME_BREAKOUT: orc_breakout_new_game((const tbx_breakout_config_t*)e->cfg, sim, (tbx_breakout_state_t*)env_state(e, i)); break;
+    case TBX_GAME_SPACE_INVADERS: orc_si_new_game((const tbx_si_config_t*)e->cfg, sim, (tbx_si_state_t*)env_state(e, i)); break;
+    default: orc_amidar_new_game((const tbx_amidar_config_t*)e->cfg, sim, (tbx_amidar_state_t*)env_state(e, i)); break;
+    }
+}
+static void raw_scalars(tbx_engine* e, int i, int32_t* score, int32_t* lives)
+{
+    int32_t level;
+    orc_get_scalars(e->game, env_state(e, i), 1, score, lives, &level);
+}
+static int raw_lives(tbx_engine* e, int i) { int32_t sc, lv; raw_scalars(e, i, &sc, &lv); return lv; }
+
+/* Monitor.reset over NoopResetEnv.reset */
+static void noop_monitor_reset(wrap_t* w)
+{
+    tbx_engine* e = w->e;
+    const int i = w->i;
+    e->ep_ret[i] = 0; e->ep_len[i] = 0; e->ep_index[i] += 1;
+    raw_new_game(e, i);
+    if (e->acfg.noop_max > 0) {
+        const uint64_t env_global = e->acfg.env_offset + (uint64_t)i;
+        const int k = 1 + (int)(orc_splitmix64(e->acfg.noop_seed ^ (env_global << 32) ^ (uint64_t)(uint32_t)e->ep_index[i]) %
+                                (uint64_t)e->acfg.noop_max);
+        for (int j = 0; j < k; j++) {
+            raw_step(e, i, 0);
+            if (raw_lives(e, i) <= 0) raw_new_game(e, i);
+        }
+    }
+}
+/* Monitor.step over MaxAndSkipEnv.step; returns done */
+static int skip_monitor_step(wrap_t* w, uint32_t buttons)
+{
+    tbx_engine* e = w->e;
+    const int i = w->i;
+    int total = 0, done = 0;
+    for (int f = 0; f < e->acfg.skip && !done; f++) {
+        int32_t s0, s1, lv;
+        raw_scalars(e, i, &s0, &lv);
+        raw_step(e, i, buttons);
+        raw_scalars(e, i, &s1, &lv);
+        if (s1 > s0) total += s1 - s0;
+        done = lv <= 0;
+    }
+    e->ep_ret[i] += total; e->ep_len[i] += 1;
+    if (done) { e->ep_done[i] = 1; e->ep_ret_out[i] = (float)e->ep_ret[i]; e->ep_len_out[i] = e->ep_len[i]; }
+    return done;
+}
+static void episodic_reset(wrap_t* w)
+{
+    if (w->was_real_done || !w->e->acfg.episodic_life) noop_monitor_reset(w);
+    else if (skip_monitor_step(w, 0)) noop_monitor_reset(w);    /* own rule: a game that ends in the no-op step starts over */
+    w->e->prev_lives[w->i] = raw_lives(w->e, w->i);
+}
+static int episodic_step(wrap_t* w, uint32_t buttons)
+{
+    int done = skip_monitor_step(w, buttons);
+    w->was_real_done = done;
+    const int lives = raw_lives(w->e, w->i);
+    if (w->e->acfg.episodic_life && lives < w->e->prev_lives[w->i] && lives > 0) done = 1;
+    w->e->prev_lives[w->i] = lives;
+    return done;
+}
+static void fire_reset(tbx_engine* e, int i, int game_over)
+{
+    wrap_t w = {e, i, game_over};
+    episodic_reset(&w);
+    if (e->acfg.fire_reset) {
+        int32_t legal[18];
+        orc_legal_actions(e->game, legal, 18);
+        if (episodic_step(&w, (uint32_t)orc_ale_action_to_buttons(legal[1]))) episodic_reset(&w);
+        if (episodic_step(&w, (uint32_t)orc_ale_action_to_buttons(legal[2]))) episodic_reset(&w);
+    }
+    int32_t sc, lv;
+    raw_scalars(e, i, &sc, &lv);
+    e->prev[i] = sc;
+}
+
+static int agent_has_wrappers(const tbx_engine* e) { return e->acfg.episodic_life || e->acfg.fire_reset || e->acfg.noop_max > 0; }
+
 int tbx_agent_reset(tbx_engine* e, uint8_t* obs)
 {
     if (!e) return TBX_E_INVALID;
     if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
-    orc_new_game_batch(e->game, e->cfg, e->states, e->sim, e->prev, e->n, NULL);
-    orc_render_batch(e->game, e->cfg, e->states, e->n, e->gray_b, 1, e->threads);
+    const int n = e->n;
+    memset(e->ep_ret, 0, (size_t)n * 4);
+    memset(e->ep_len, 0, (size_t)n * 4);
+    if (agent_has_wrappers(e)) {
+        for (int i = 0; i < n; i++) fire_reset(e, i, 1);
+    } else {
+        orc_new_game_batch(e->game, e->cfg, e->states, e->sim, e->prev, n, NULL);
+    }
+    memset(e->ep_done, 0, (size_t)n);
+    orc_render_batch(e->game, e->cfg, e->states, n, e->gray_b, 1, e->threads);
     agent_observe(e, 1);
-    if (obs) memcpy(obs, e->aobs, (size_t)e->n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack);
+    if (obs) memcpy(obs, e->aobs, (size_t)n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack);
+    return TBX_OK;
+}
+
+int tbx_agent_episodes(tbx_engine* e, uint8_t* ep_done, float* ep_return, int32_t* ep_length)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
+    const size_t n = (size_t)e->n;
+    if (ep_done) memcpy(ep_done, e->ep_done, n);
+    if (ep_return) memcpy(ep_return, e->ep_ret_out, n * 4);
+    if (ep_length) memcpy(ep_length, e->ep_len_out, n * 4);
     return TBX_OK;
 }
 
@@ -475,13 +623,27 @@ int tbx_agent_step_device(tbx_engine* e, const int32_t* actions, void* stream)
         if (i == e->acfg.skip - 2) orc_render_batch(e->game, e->cfg, e->states, n, e->gray_a, 1, e->threads);
     }
     pack_outputs(e);
-    orc_new_game_batch(e->game, e->cfg, e->states, e->sim, e->prev, n, e->afin);
+    /* Monitor.step, EpisodicLifeEnv.step, ClipRewardEnv, then VecEnv's reset of the envs that are done */
+    const int wrappers = agent_has_wrappers(e);
+    for (int k = 0; k < n; k++) {
+        e->ep_ret[k] += racc[k]; e->ep_len[k] += 1;
+        const int real = e->afin[k];
+        const int lives = e->lives[k];
+        const int life_lost = e->acfg.episodic_life && !real && lives < e->prev_lives[k] && lives > 0;
+        e->prev_lives[k] = lives;
+        e->ep_done[k] = (uint8_t)real;
+        if (real) { e->ep_ret_out[k] = (float)e->ep_ret[k]; e->ep_len_out[k] = e->ep_len[k]; }
+        e->areward[k] = e->acfg.clip_reward ? (float)((racc[k] > 0) - (racc[k] < 0)) : (float)racc[k];
+        e->adone[k] = (uint8_t)(real || life_lost);
+        if (wrappers) {
+            if (e->adone[k]) fire_reset(e, k, real);
+        } else if (real) {
+            e->ep_ret[k] = 0; e->ep_len[k] = 0; e->ep_index[k] += 1;
+        }
+    }
+    if (!wrappers) orc_new_game_batch(e->game, e->cfg, e->states, e->sim, e->prev, n, e->afin);
     orc_render_batch(e->game, e->cfg, e->states, n, e->gray_b, 1, e->threads);
     agent_observe(e, 0);
-    for (int k = 0; k < n; k++) {
-        e->areward[k] = e->acfg.clip_reward ? (float)((racc[k] > 0) - (racc[k] < 0)) : (float)racc[k];
-        e->adone[k] = e->afin[k];
-    }
     free(racc);
     return TBX_OK;
 }

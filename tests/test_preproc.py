@@ -199,3 +199,277 @@ def test_gpu_breakout_fused_observation_equals_generic_path(hip_lib, monkeypatch
         x, y = gen.agent_step(a), fus.agent_step(a)
         for p, q in zip(x, y):
             assert np.array_equal(p, q), t
+
+
+# ------------------------------------------------------------------ reset-time wrappers + episode monitor (8f rank 2)
+# A literal, one-env-at-a-time restatement of the wrapper classes the reference's agents train under
+# (baselines/baselines/common/atari_wrappers.py: NoopResetEnv :12-36, FireResetEnv :38-56, EpisodicLifeEnv :58-96,
+#  MaxAndSkipEnv :99-130, ClipRewardEnv :132-139, WarpFrame :141-190; bench/monitor.py :51-76; DummyVecEnv's reset-on-done
+#  vec_env/dummy_vec_env.py:45-60; VecFrameStack vec_frame_stack.py:17-30).  Two documented choices of this repo replace
+# host randomness / host frames: the no-op count is a hash of (seed, global env index, episode index), and the
+# observation returned by a reset is the frame after the reset procedure (not the max over its last two sub-frames).
+from support import splitmix64  # noqa: E402
+
+
+class _Raw:
+    """ToyboxBaseEnv semantics over one env of the per-frame engine API (envs/atari/base.py:113-157)."""
+
+    def __init__(self, eng):
+        self.e = eng
+
+    def frame(self):
+        return self.e.render(1)[0, :, :, 0]
+
+    def lives(self):
+        return int(self.e.scalars()[1][0])
+
+    def reset(self):
+        self.e.new_game()
+        return self.frame()
+
+    def step(self, ale_action):
+        r, d, _, _ = self.e.step(np.array([ale_action], np.int32))
+        return self.frame(), int(r[0]), bool(d[0]), {}
+
+
+class _NoopReset:
+    def __init__(self, env, noop_max, seed, env_global):
+        self.env, self.noop_max, self.seed, self.env_global, self.resets = env, noop_max, seed, env_global, 0
+
+    def lives(self):
+        return self.env.lives()
+
+    def reset(self):
+        self.resets += 1
+        obs = self.env.reset()
+        if self.noop_max > 0:
+            k = 1 + splitmix64(self.seed ^ (self.env_global << 32) ^ self.resets) % self.noop_max
+            for _ in range(k):
+                obs, _, done, _ = self.env.step(0)
+                if done:
+                    obs = self.env.reset()
+        return obs
+
+    def step(self, a):
+        return self.env.step(a)
+
+
+class _MaxAndSkip:
+    def __init__(self, env, skip):
+        self.env, self.skip = env, skip
+
+    def lives(self):
+        return self.env.lives()
+
+    def reset(self):
+        return self.env.reset()
+
+    def step(self, a):
+        total, done, buf = 0, False, [None, None]
+        for i in range(self.skip):
+            obs, r, done, info = self.env.step(a)
+            if i == self.skip - 2:
+                buf[0] = obs
+            if i == self.skip - 1:
+                buf[1] = obs
+            total += r
+            if done:
+                break
+        if buf[1] is None:
+            mx = obs                                # cut short by the end of the game: the caller resets anyway
+        else:
+            mx = buf[1] if buf[0] is None else np.maximum(buf[0], buf[1])
+        return mx, total, done, info
+
+
+class _Monitor:
+    def __init__(self, env):
+        self.env, self.rewards, self.episodes = env, [], []
+
+    def lives(self):
+        return self.env.lives()
+
+    def reset(self):
+        self.rewards = []
+        return self.env.reset()
+
+    def step(self, a):
+        obs, r, done, info = self.env.step(a)
+        self.rewards.append(r)
+        if done:
+            info = dict(info, episode={"r": float(sum(self.rewards)), "l": len(self.rewards)})
+            self.episodes.append((float(sum(self.rewards)), len(self.rewards)))
+        return obs, r, done, info
+
+
+class _EpisodicLife:
+    def __init__(self, env, on):
+        self.env, self.on, self.lives_, self.was_real_done = env, on, 0, True
+
+    def lives(self):
+        return self.env.lives()
+
+    def step(self, a):
+        obs, r, done, info = self.env.step(a)
+        self.was_real_done = done
+        lives = self.env.lives()
+        if self.on and lives < self.lives_ and lives > 0:
+            done = True
+        self.lives_ = lives
+        return obs, r, done, info
+
+    def reset(self):
+        if self.was_real_done or not self.on:
+            obs = self.env.reset()
+        else:
+            obs, _, d, _ = self.env.step(0)
+            if d:
+                obs = self.env.reset()              # this repo's rule for a game that ends inside the no-op step
+        self.lives_ = self.env.lives()
+        return obs
+
+
+class _FireReset:
+    def __init__(self, env, on, legal):
+        self.env, self.on, self.legal = env, on, legal
+
+    def reset(self):
+        obs = self.env.reset()
+        if self.on:
+            obs, _, done, _ = self.env.step(self.legal[1])
+            if done:
+                self.env.reset()
+            obs, _, done, _ = self.env.step(self.legal[2])
+            if done:
+                self.env.reset()
+        return obs
+
+    def step(self, a):
+        return self.env.step(a)
+
+
+def _build_stack(eng, skip, episodic, fire, noop_max, noop_seed, env_global):
+    raw = _Raw(eng)
+    mon = _Monitor(_MaxAndSkip(_NoopReset(raw, noop_max, noop_seed, env_global), skip))
+    top = _FireReset(_EpisodicLife(mon, episodic), fire, sorted(eng.legal_actions))
+    return raw, mon, top
+
+
+@pytest.mark.parametrize("game,episodic,fire,noop_max", [("breakout", True, True, 30), ("breakout", True, False, 0),
+                                                         ("space_invaders", True, True, 7), ("amidar", False, True, 30),
+                                                         ("amidar", True, False, 5)])
+def test_reset_wrappers_equal_wrapper_classes(game, episodic, fire, noop_max, oracle_lib):
+    n, steps, skip, oh, ow, stack = 3, 220, 4, 42, 42, 4
+    if game == "amidar":
+        oh, ow = 50, 40
+    if game == "space_invaders":
+        oh, ow = 42, 64
+    fused = Engine(game, n, lib=oracle_lib)
+    fused.seed(77)
+    singles = [Engine(game, 1, lib=oracle_lib) for _ in range(n)]
+    for i, s in enumerate(singles):
+        s.set_state(0, fused.get_state(i))
+        s.set_sim_rng(fused.get_sim_rng(i), 0)
+    fused.agent_init(skip=skip, out_h=oh, out_w=ow, stack=stack, clip_reward=True, episodic_life=episodic, fire_reset=fire,
+                     noop_max=noop_max, noop_seed=99, env_offset=1000)
+    stacks = [_build_stack(s, skip, episodic, fire, noop_max, 99, 1000 + i) for i, s in enumerate(singles)]
+    obs = np.zeros((n, oh, ow, stack), np.uint8)
+    for i, (raw, mon, top) in enumerate(stacks):
+        top.reset()
+        obs[i, ..., -1] = area_resize_int(raw.frame(), oh, ow)
+    assert np.array_equal(fused.agent_reset(), obs)
+    fused_eps = [[] for _ in range(n)]
+    n_done = n_real = 0
+    for t in range(steps):
+        a = synthetic_actions(game, n, t, seed=21)
+        o1, r1, d1 = fused.agent_step(a)
+        ended, ret, length = fused.agent_episodes()
+        obs = np.roll(obs, -1, axis=-1)
+        for i, (raw, mon, top) in enumerate(stacks):
+            ob, r, done, info = top.step(int(a[i]))
+            if done:
+                top.reset()
+                ob = raw.frame()
+                obs[i] = 0
+            obs[i, ..., -1] = area_resize_int(ob, oh, ow)
+            assert r1[i] == float(np.sign(r)), (t, i)
+            assert bool(d1[i]) == done, (t, i)
+            n_done += done
+            if ended[i]:
+                fused_eps[i].append((float(ret[i]), int(length[i])))
+        assert np.array_equal(o1, obs), t
+    for i, (raw, mon, top) in enumerate(stacks):
+        assert fused_eps[i] == mon.episodes, i
+        assert bytes(fused.get_state(i)) == bytes(singles[i].get_state(0))
+        assert fused.get_sim_rng(i) == singles[i].get_sim_rng(0)
+        n_real += len(mon.episodes)
+    if game == "breakout":
+        assert n_done > 0 and (not episodic or n_done > n_real)
+
+
+def test_preproc_vec_env_reports_episodes(oracle_lib):
+    from toybox_amd.envs import ToyboxPreprocVecEnv
+    env = ToyboxPreprocVecEnv("breakout", 4, size=42, seed=5, episode_life=True, fire_reset=True, noop_max=30,
+                              engine=Engine("breakout", 4, lib=oracle_lib))
+    obs = env.reset()
+    assert obs.shape == (4, 42, 42, 4) and obs[..., :3].max() == 0 and obs[..., 3].max() > 0
+    rng = np.random.default_rng(0)
+    eps = lost = 0
+    for _ in range(600):
+        obs, rew, done, infos = env.step(rng.integers(0, env.action_space.n, 4))
+        for d, info in zip(done, infos):
+            if "episode" in info:
+                assert d and info["episode"]["l"] > 0 and info["episode"]["r"] >= 0
+                eps += 1
+            elif d:
+                lost += 1
+    assert eps > 0 and lost > eps            # five lives per game: most dones are lost lives
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game,episodic,fire,noop_max", [("breakout", True, True, 30), ("breakout", False, False, 30),
+                                                         ("space_invaders", True, True, 30), ("amidar", True, True, 30)])
+def test_gpu_reset_wrappers_parity(game, episodic, fire, noop_max, hip_lib, oracle_lib):
+    """HIP in-kernel reset procedure + monitor == CPU restatement, bit for bit, through lost lives and game ends."""
+    n = 160
+    g, o = Engine(game, n, lib=hip_lib), Engine(game, n, lib=oracle_lib)
+    for e in (g, o):
+        e.seed(4321)
+        e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=episodic, fire_reset=fire,
+                     noop_max=noop_max, noop_seed=7, env_offset=123456)
+    assert np.array_equal(g.agent_reset(), o.agent_reset())
+    dones = eps = 0
+    for t in range(500):
+        a = synthetic_actions(game, n, t, seed=3)
+        og, rg, dg = g.agent_step(a)
+        oo, ro, do = o.agent_step(a)
+        assert np.array_equal(dg, do) and np.array_equal(rg, ro), t
+        eg, eo = g.agent_episodes(), o.agent_episodes()
+        assert np.array_equal(eg[0], eo[0]), t
+        assert np.array_equal(eg[1][eg[0]], eo[1][eo[0]]) and np.array_equal(eg[2][eg[0]], eo[2][eo[0]]), t
+        if t % 25 == 0 or dg.any():
+            assert np.array_equal(og, oo), t
+        dones += int(dg.sum())
+        eps += int(eg[0].sum())
+    assert np.array_equal(og, oo)
+    for i in range(0, n, 5):
+        assert bytes(g.get_state(i)) == bytes(o.get_state(i))
+        assert g.get_sim_rng(i) == o.get_sim_rng(i)
+    if game == "breakout":
+        assert dones > 0 and eps > 0
+        if episodic:
+            assert dones > eps
+
+
+@pytest.mark.gpu
+def test_gpu_reset_wrappers_unsupported_for_custom_bricks(hip_lib):
+    from toybox_amd import ToyboxAmdError
+    from toybox_amd.games import breakout as bk
+    e = Engine("breakout", 8, lib=hip_lib)
+    js = bk.state_to_json(e.get_state(0))
+    js["bricks"][0]["size"]["x"] += 1.0          # a wall that is no longer the canonical grid
+    e.set_state(0, bk.state_from_json(js))
+    e.agent_init(skip=4, episodic_life=True)
+    with pytest.raises(ToyboxAmdError):
+        e.agent_reset()

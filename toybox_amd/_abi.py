@@ -19,6 +19,7 @@ BTN_LEFT, BTN_RIGHT, BTN_UP, BTN_DOWN, BTN_BUTTON1, BTN_BUTTON2 = 1, 2, 4, 8, 16
 STEP_AUTO_RESET = 1
 BUF_REWARD, BUF_DONE, BUF_LIVES, BUF_SCORE, BUF_FRAME, BUF_PACKED = 0, 1, 2, 3, 4, 5
 BUF_AGENT_OBS, BUF_AGENT_REWARD, BUF_AGENT_DONE = 6, 7, 8
+BUF_AGENT_EP_DONE, BUF_AGENT_EP_RETURN, BUF_AGENT_EP_LENGTH = 9, 10, 11
 
 BRK_MAX_BALLS, BRK_COLS, BRK_MAX_ROWS, BRK_MAX_BRICKS, BRK_MAX_STARTS, BRK_MAX_SEGMENTS = 4, 18, 14, 256, 8, 16
 
@@ -185,7 +186,9 @@ STATE_TYPES = {GAME_BREAKOUT: BreakoutState, GAME_SPACE_INVADERS: SIState, GAME_
 CONFIG_TYPES = {GAME_BREAKOUT: BreakoutConfig, GAME_SPACE_INVADERS: SIConfig, GAME_AMIDAR: AmidarConfig}
 
 class AgentConfig(C.Structure):
-    _fields_ = [("skip", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32), ("stack", C.c_int32), ("clip_reward", C.c_int32)]
+    _fields_ = [("skip", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32), ("stack", C.c_int32), ("clip_reward", C.c_int32),
+                ("episodic_life", C.c_int32), ("fire_reset", C.c_int32), ("noop_max", C.c_int32),
+                ("noop_seed", C.c_uint64), ("env_offset", C.c_uint64)]
 
 
 _p = C.POINTER
@@ -225,6 +228,7 @@ PROTOTYPES = {
     "tbx_query": (_i, [_vp, _i, _i, _p(C.c_int32), _i, _p(C.c_int32), _i]),
     "tbx_agent_init": (_i, [_vp, _p(AgentConfig)]),
     "tbx_agent_reset": (_i, [_vp, _vp]),
+    "tbx_agent_episodes": (_i, [_vp, _vp, _vp, _vp]),
     "tbx_agent_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "tbx_agent_step_device": (_i, [_vp, _vp, _vp]),
     "tbx_agent_step_synthetic": (_i, [_vp, _u64, _u64, _u64, _vp]),

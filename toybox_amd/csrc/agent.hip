@@ -19,6 +19,10 @@ struct AgentState {
     int32_t* racc = nullptr;
     float* reward_out = nullptr;
     AgentTaps *ty = nullptr, *tx = nullptr;
+    // reset-time wrappers + episode monitor
+    uint8_t *kind = nullptr, *ep_done = nullptr;
+    int32_t *ep_ret = nullptr, *ep_len = nullptr, *ep_index = nullptr, *prev_lives = nullptr, *ep_len_out = nullptr;
+    float* ep_ret_out = nullptr;
     bool force_generic = false;   // TBX_AGENT_GENERIC=1: always go through full-resolution gray frames
 };
 
@@ -39,6 +43,38 @@ __global__ void agent_acc_kernel(const int32_t* reward, const uint8_t* done, int
     if (i >= n || fin[i]) return;
     racc[i] += reward[i];
     if (done[i]) fin[i] = 1;
+}
+
+// after the `skip` frames: Monitor bookkeeping, EpisodicLifeEnv's done rule, clipped reward, and what kind of reset the
+// env needs (0 none, 1 life lost, 2 game over).  simple: no in-kernel reset follows, so a finished episode's counters
+// are cleared here.
+__global__ void agent_monitor_kernel(const int32_t* racc, const uint8_t* fin, const int32_t* lives, int32_t* ep_ret, int32_t* ep_len,
+                                     int32_t* ep_index, int32_t* prev_lives, uint8_t* kind, uint8_t* ep_done, float* ep_ret_out,
+                                     int32_t* ep_len_out, float* reward_out, uint8_t* done_out, int episodic, int clip, int simple, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = racc[i];
+    int er = ep_ret[i] + r, el = ep_len[i] + 1;
+    const bool real = fin[i] != 0;
+    const int l = lives[i];
+    const bool life_lost = episodic && !real && l < prev_lives[i] && l > 0;
+    kind[i] = real ? 2 : life_lost ? 1 : 0;
+    done_out[i] = (real || life_lost) ? 1 : 0;
+    reward_out[i] = clip ? (float)((r > 0) - (r < 0)) : (float)r;
+    ep_done[i] = real ? 1 : 0;
+    if (real) {
+        ep_ret_out[i] = (float)er; ep_len_out[i] = el;
+        if (simple) { er = 0; el = 0; ep_index[i] += 1; }
+    }
+    ep_ret[i] = er; ep_len[i] = el;
+    prev_lives[i] = l;
+}
+
+__global__ void agent_fill_u8_kernel(uint8_t* p, uint8_t v, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 // One wave per env, one pass over the SOURCE rows: each row (max of the two frames unless the env was just reset)
@@ -101,11 +137,6 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
             }
         }
     }
-    if (!reset_mode && lane == 0) {
-        const int r = racc[env];
-        reward_out[env] = clip ? (float)((r > 0) - (r < 0)) : (float)r;
-        done_out[env] = fin[env];
-    }
 }
 
 int agent_fail(tbx_engine* e, const char* what, hipError_t err)
@@ -143,7 +174,8 @@ int launch_warp(tbx_engine* e, int reset_mode, hipStream_t s)
     const dim3 grid((e->n + TBX_WAVES_PER_BLOCK - 1) / TBX_WAVES_PER_BLOCK), block(TBX_BLOCK);
     const uint8_t* A = a.cfg.skip >= 2 ? a.gray_a : a.gray_b;
     const uint64_t magic = (1ull << 42) / (uint64_t)(a.H * a.W) + 1ull;   // exact for numerators < 2^42 / area >= 2^25
-#define WARP(S) hipLaunchKernelGGL(agent_warp_kernel<S>, grid, block, 0, s, A, a.gray_b, a.fin, a.racc, a.tx, a.obs, \
+    // fresh = the env was reset during this agent step (game over, or a lost life in episodic-life mode)
+#define WARP(S) hipLaunchKernelGGL(agent_warp_kernel<S>, grid, block, 0, s, A, a.gray_b, a.done_out, a.racc, a.tx, a.obs, \
                                    a.reward_out, a.done_out, a.H, a.W, a.cfg.out_h, a.cfg.out_w, magic, a.cfg.clip_reward, reset_mode, e->n)
     switch (a.cfg.stack) {
     case 1: WARP(1); break;
@@ -160,7 +192,7 @@ AgentWarpArgs warp_args(tbx_engine* e, int reset_mode)
 {
     AgentState& a = *e->agent;
     AgentWarpArgs w;
-    w.fin = a.fin; w.racc = a.racc; w.tx = a.tx; w.obs = a.obs; w.reward_out = a.reward_out; w.done_out = a.done_out;
+    w.fin = a.done_out; w.racc = a.racc; w.tx = a.tx; w.obs = a.obs; w.reward_out = a.reward_out; w.done_out = a.done_out;
     w.H = a.H; w.W = a.W; w.oh = a.cfg.out_h; w.ow = a.cfg.out_w; w.stack = a.cfg.stack; w.clip = a.cfg.clip_reward;
     w.reset_mode = reset_mode;
     w.two_frames = a.cfg.skip >= 2;
@@ -168,7 +200,24 @@ AgentWarpArgs warp_args(tbx_engine* e, int reset_mode)
     return w;
 }
 
-// frame B (and the observation) once the sub-frames and the auto-reset are done
+bool needs_reset_kernel(const AgentState& a) { return a.cfg.episodic_life || a.cfg.fire_reset || a.cfg.noop_max > 0; }
+
+AgentResetArgs reset_args(tbx_engine* e)
+{
+    AgentState& a = *e->agent;
+    AgentResetArgs r;
+    r.kind = a.kind;
+    r.skip = a.cfg.skip; r.episodic_life = a.cfg.episodic_life; r.fire_reset = a.cfg.fire_reset; r.noop_max = a.cfg.noop_max;
+    r.noop_seed = a.cfg.noop_seed; r.env_offset = a.cfg.env_offset;
+    // action #1 and #2 of the game's (sorted) legal action set: FIRE and the next one (atari_wrappers.py:146-149)
+    r.fire_buttons = tbx_ale_buttons(tbx_legal_action(e->game, 1));
+    r.third_buttons = tbx_ale_buttons(tbx_legal_action(e->game, 2));
+    r.ep_ret = a.ep_ret; r.ep_len = a.ep_len; r.ep_index = a.ep_index; r.prev_lives = a.prev_lives;
+    r.ep_done = a.ep_done; r.ep_ret_out = a.ep_ret_out; r.ep_len_out = a.ep_len_out;
+    return r;
+}
+
+// frame B (and the observation) once the sub-frames and the resets are done
 int observe(tbx_engine* e, int reset_mode, hipStream_t s)
 {
     AgentState& a = *e->agent;
@@ -188,6 +237,7 @@ int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s)
     AgentState& a = *e->agent;
     const int n = e->n, tb = 256, gb = (n + tb - 1) / tb;
     const bool fused = e->ops->agent_fused() && !a.force_generic;
+    const bool in_kernel_reset = needs_reset_kernel(a);
     hipLaunchKernelGGL(agent_acc_init_kernel, dim3(gb), dim3(tb), 0, s, a.racc, a.fin, n);
     for (int i = 0; i < a.cfg.skip; i++) {
         int rc = e->ops->step(e, src, 0, s);
@@ -198,9 +248,13 @@ int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s)
             if (rc) return rc;
         }
     }
-    int rc = e->ops->new_game(e, a.fin, s);        // VecEnv auto-reset of the envs whose game ended
-    if (rc) return rc;
+    hipLaunchKernelGGL(agent_monitor_kernel, dim3(gb), dim3(tb), 0, s, a.racc, a.fin, e->lives_out, a.ep_ret, a.ep_len, a.ep_index,
+                       a.prev_lives, a.kind, a.ep_done, a.ep_ret_out, a.ep_len_out, a.reward_out, a.done_out,
+                       a.cfg.episodic_life, a.cfg.clip_reward, in_kernel_reset ? 0 : 1, n);
     AHIP(hipGetLastError());
+    // VecEnv auto-reset: plain new game of the finished envs, or the reset-time wrappers run in-kernel
+    int rc = in_kernel_reset ? e->ops->agent_reset_envs(e, reset_args(e), s) : e->ops->new_game(e, a.fin, s);
+    if (rc) return rc;
     return observe(e, 0, s);
 }
 
@@ -212,6 +266,8 @@ void tbx_agent_free(tbx_engine* e)
     AgentState* a = e->agent;
     hipFree(a->gray_a); hipFree(a->gray_b); hipFree(a->obs); hipFree(a->fin); hipFree(a->done_out);
     hipFree(a->racc); hipFree(a->reward_out); hipFree(a->ty); hipFree(a->tx);
+    hipFree(a->kind); hipFree(a->ep_done); hipFree(a->ep_ret); hipFree(a->ep_len); hipFree(a->ep_index);
+    hipFree(a->prev_lives); hipFree(a->ep_len_out); hipFree(a->ep_ret_out);
     delete a;
     e->agent = nullptr;
 }
@@ -223,9 +279,14 @@ int tbx_agent_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_bytes
     const size_t N = (size_t)e->n;
     void* p = nullptr;
     size_t b = 0;
-    if (which == TBX_BUF_AGENT_OBS) { p = a.obs; b = N * a.cfg.out_h * a.cfg.out_w * a.cfg.stack; }
-    else if (which == TBX_BUF_AGENT_REWARD) { p = a.reward_out; b = N * sizeof(float); }
-    else { p = a.done_out; b = N; }
+    switch (which) {
+    case TBX_BUF_AGENT_OBS: p = a.obs; b = N * a.cfg.out_h * a.cfg.out_w * a.cfg.stack; break;
+    case TBX_BUF_AGENT_REWARD: p = a.reward_out; b = N * sizeof(float); break;
+    case TBX_BUF_AGENT_DONE: p = a.done_out; b = N; break;
+    case TBX_BUF_AGENT_EP_DONE: p = a.ep_done; b = N; break;
+    case TBX_BUF_AGENT_EP_RETURN: p = a.ep_ret_out; b = N * sizeof(float); break;
+    default: p = a.ep_len_out; b = N * sizeof(int32_t); break;
+    }
     *out_ptr = p;
     if (out_bytes) *out_bytes = b;
     return TBX_OK;
@@ -239,8 +300,9 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     if (!cfg) return e->fail(TBX_E_INVALID, "agent config is NULL");
     const int H = e->ops->height(), W = e->ops->width();
     if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
-        cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > AGENT_MAX_OUT_PX)
-        return e->fail(TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056)");
+        cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > AGENT_MAX_OUT_PX || cfg->noop_max < 0 ||
+        cfg->noop_max > 1000)
+        return e->fail(TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000)");
     if ((H + cfg->out_h - 1) / cfg->out_h + 1 > MAX_TAPS || (W + cfg->out_w - 1) / cfg->out_w + 1 > MAX_TAPS)
         return e->fail(TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
     AHIP(hipSetDevice(e->device));
@@ -258,6 +320,14 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     AHIP(hipMalloc((void**)&a->done_out, N));
     AHIP(hipMalloc((void**)&a->racc, N * sizeof(int32_t)));
     AHIP(hipMalloc((void**)&a->reward_out, N * sizeof(float)));
+    AHIP(hipMalloc((void**)&a->kind, N));
+    AHIP(hipMalloc((void**)&a->ep_done, N));
+    AHIP(hipMalloc((void**)&a->ep_ret, N * sizeof(int32_t)));
+    AHIP(hipMalloc((void**)&a->ep_len, N * sizeof(int32_t)));
+    AHIP(hipMalloc((void**)&a->ep_index, N * sizeof(int32_t)));
+    AHIP(hipMalloc((void**)&a->prev_lives, N * sizeof(int32_t)));
+    AHIP(hipMalloc((void**)&a->ep_len_out, N * sizeof(int32_t)));
+    AHIP(hipMalloc((void**)&a->ep_ret_out, N * sizeof(float)));
     const std::vector<AgentTaps> ty = make_taps(H, cfg->out_h), tx = make_taps(W, cfg->out_w);
     AHIP(hipMalloc((void**)&a->ty, ty.size() * sizeof(AgentTaps)));
     AHIP(hipMalloc((void**)&a->tx, tx.size() * sizeof(AgentTaps)));
@@ -268,6 +338,14 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     AHIP(hipMemset(a->done_out, 0, N));
     AHIP(hipMemset(a->racc, 0, N * sizeof(int32_t)));
     AHIP(hipMemset(a->reward_out, 0, N * sizeof(float)));
+    AHIP(hipMemset(a->kind, 0, N));
+    AHIP(hipMemset(a->ep_done, 0, N));
+    AHIP(hipMemset(a->ep_ret, 0, N * sizeof(int32_t)));
+    AHIP(hipMemset(a->ep_len, 0, N * sizeof(int32_t)));
+    AHIP(hipMemset(a->ep_index, 0, N * sizeof(int32_t)));
+    AHIP(hipMemset(a->prev_lives, 0, N * sizeof(int32_t)));
+    AHIP(hipMemset(a->ep_len_out, 0, N * sizeof(int32_t)));
+    AHIP(hipMemset(a->ep_ret_out, 0, N * sizeof(float)));
     return TBX_OK;
 }
 
@@ -277,12 +355,40 @@ int tbx_agent_reset(tbx_engine* e, uint8_t* obs_host)
     if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
     AgentState& a = *e->agent;
     AHIP(hipSetDevice(e->device));
-    int rc = e->ops->new_game(e, nullptr, e->stream);
-    if (rc) return rc;
+    const int n = e->n, tb = 256, gb = (n + tb - 1) / tb;
+    const size_t N = (size_t)n;
+    AHIP(hipMemsetAsync(a.ep_ret, 0, N * sizeof(int32_t), e->stream));
+    AHIP(hipMemsetAsync(a.ep_len, 0, N * sizeof(int32_t), e->stream));
+    AHIP(hipMemsetAsync(a.ep_done, 0, N, e->stream));
+    int rc;
+    if (needs_reset_kernel(a)) {
+        // env.reset() of the whole wrapper stack == the game-over reset path for every env
+        hipLaunchKernelGGL(agent_fill_u8_kernel, dim3(gb), dim3(tb), 0, e->stream, a.kind, (uint8_t)2, n);
+        rc = e->ops->agent_reset_envs(e, reset_args(e), e->stream);
+        if (rc) return rc;
+        AHIP(hipMemsetAsync(a.ep_done, 0, N, e->stream));
+    } else {
+        rc = e->ops->new_game(e, nullptr, e->stream);
+        if (rc) return rc;
+    }
     rc = observe(e, 1, e->stream);
     if (rc) return rc;
     if (obs_host)
-        AHIP(hipMemcpyAsync(obs_host, a.obs, (size_t)e->n * a.cfg.out_h * a.cfg.out_w * a.cfg.stack, hipMemcpyDeviceToHost, e->stream));
+        AHIP(hipMemcpyAsync(obs_host, a.obs, N * a.cfg.out_h * a.cfg.out_w * a.cfg.stack, hipMemcpyDeviceToHost, e->stream));
+    AHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_agent_episodes(tbx_engine* e, uint8_t* ep_done_host, float* ep_return_host, int32_t* ep_length_host)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    AgentState& a = *e->agent;
+    AHIP(hipSetDevice(e->device));
+    const size_t N = (size_t)e->n;
+    if (ep_done_host) AHIP(hipMemcpyAsync(ep_done_host, a.ep_done, N, hipMemcpyDeviceToHost, e->stream));
+    if (ep_return_host) AHIP(hipMemcpyAsync(ep_return_host, a.ep_ret_out, N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (ep_length_host) AHIP(hipMemcpyAsync(ep_length_host, a.ep_len_out, N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     AHIP(hipStreamSynchronize(e->stream));
     return TBX_OK;
 }

@@ -98,3 +98,89 @@ __device__ __forceinline__ void stack_commit(const uint8_t* vals, uint8_t* o, in
         for (int i = lane; i < n_px; i += 64) stack_push<S>(o + (size_t)i * S, vals[i], fresh);
     }
 }
+
+// ------------------------------------------------------------------ reset-time wrappers + episode monitor (8f rank 2)
+
+// what a game's agent-reset kernel needs (see tbx_agent_config_t)
+struct AgentResetArgs {
+    const uint8_t* kind;        // [N] 0 = nothing to do, 1 = a life was lost (episodic life), 2 = game over
+    int skip, episodic_life, fire_reset, noop_max;
+    uint64_t noop_seed, env_offset;
+    uint32_t fire_buttons, third_buttons;   // buttons of action #1 and action #2 of the game's action set
+    int32_t *ep_ret, *ep_len, *ep_index, *prev_lives;   // [N] monitor / episodic-life state
+    uint8_t* ep_done;           // [N] episode records of this agent step
+    float* ep_ret_out;
+    int32_t* ep_len_out;
+};
+
+struct AgentMonitor {
+    int32_t ep_ret, ep_len, ep_index, prev_lives;
+    bool emitted;
+    int32_t out_ret, out_len;
+};
+
+// The reset path of the wrapper stack NoopResetEnv -> MaxAndSkipEnv -> Monitor -> EpisodicLifeEnv -> FireResetEnv
+// (baselines/baselines/common/atari_wrappers.py:108-191, bench/monitor.py:51-76), run in-kernel for one env.
+// Env provides step(buttons), new_game(), lives(), score(); every call is wave-uniform for wave-per-env games.
+template <class Env>
+struct AgentResetProc {
+    Env& env;
+    const AgentResetArgs& r;
+    AgentMonitor& m;
+    uint64_t env_global;
+    bool was_real_done;
+
+    __device__ __forceinline__ void inner_real_reset()      // Monitor.reset + NoopResetEnv.reset
+    {
+        m.ep_ret = 0; m.ep_len = 0; m.ep_index += 1;
+        env.new_game();
+        if (r.noop_max > 0) {
+            const int k = 1 + (int)(tbx_splitmix64(r.noop_seed ^ (env_global << 32) ^ (uint64_t)(uint32_t)m.ep_index) % (uint64_t)r.noop_max);
+            for (int j = 0; j < k; j++) {
+                env.step(0u);
+                if (env.lives() <= 0) env.new_game();
+            }
+        }
+    }
+    __device__ __forceinline__ bool mstep(uint32_t buttons)  // MaxAndSkipEnv.step under Monitor
+    {
+        int rsum = 0;
+        bool done = false;
+        for (int i = 0; i < r.skip && !done; i++) {
+            const int s0 = env.score();
+            env.step(buttons);
+            const int dsc = env.score() - s0;
+            rsum += dsc > 0 ? dsc : 0;
+            if (env.lives() <= 0) done = true;
+        }
+        m.ep_ret += rsum; m.ep_len += 1;
+        if (done) { m.emitted = true; m.out_ret = m.ep_ret; m.out_len = m.ep_len; }
+        return done;
+    }
+    __device__ __forceinline__ void elife_reset()            // EpisodicLifeEnv.reset
+    {
+        if (was_real_done || !r.episodic_life) inner_real_reset();
+        else if (mstep(0u)) inner_real_reset();              // no-op step to advance from the lost-life state
+                                                             // (a game that ends inside it starts over: own rule,
+                                                             // the wrapper stack would raise on its next step)
+        m.prev_lives = env.lives();
+    }
+    __device__ __forceinline__ bool elife_step(uint32_t buttons)   // EpisodicLifeEnv.step
+    {
+        bool d = mstep(buttons);
+        was_real_done = d;
+        const int l = env.lives();
+        if (r.episodic_life && l < m.prev_lives && l > 0) d = true;
+        m.prev_lives = l;
+        return d;
+    }
+    __device__ __forceinline__ void run(int kind)            // FireResetEnv.reset (or the reset below it)
+    {
+        was_real_done = kind == 2;
+        elife_reset();
+        if (r.fire_reset) {
+            if (elife_step(r.fire_buttons)) elife_reset();
+            if (elife_step(r.third_buttons)) elife_reset();
+        }
+    }
+};

@@ -19,6 +19,7 @@
 
 #include "tbx_common.hpp"
 #include "raster.hpp"
+#include "agent_device.hpp"
 #include "../../include/toybox_amd_spec.h"
 
 #include <cstdlib>
@@ -610,6 +611,43 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, ActionSou
     }
 }
 
+// reset-time wrappers of the agent layer for the envs flagged in r.kind (agent_device.hpp, AgentResetProc)
+struct AmiAgentEnv {
+    const AmiTables& c;
+    int lane;
+    AmiRegs& s;
+    Rng& sim;
+    __device__ __forceinline__ void step(uint32_t buttons) { ami_step(c, lane, buttons, s); }
+    __device__ __forceinline__ void new_game() { ami_new_game(c, lane, sim, s); }
+    __device__ __forceinline__ int lives() const { return wave_uniform(s.f[A_LIVES]); }
+    __device__ __forceinline__ int score() const { return wave_uniform(s.f[A_SCORE]); }
+};
+
+__global__ __launch_bounds__(TBX_BLOCK) void ami_agent_reset_kernel(AmiDev d, AgentResetArgs r)
+{
+    const int lane = threadIdx.x & 63;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (env >= d.n) return;
+    const int kind = wave_uniform((int)r.kind[env]);
+    if (kind == 0) return;
+    const size_t N = (size_t)d.n;
+    AmiRegs s;
+    ami_load(d, env, lane, s);
+    Rng sim;
+    sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
+    AgentMonitor m{r.ep_ret[env], r.ep_len[env], r.ep_index[env], r.prev_lives[env], false, 0, 0};
+    AmiAgentEnv ops{*d.tab, lane, s, sim};
+    AgentResetProc<AmiAgentEnv> proc{ops, r, m, r.env_offset + (uint64_t)env, false};
+    proc.run(kind);
+    ami_store(d, env, lane, s);
+    if (lane == 0) {
+        d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
+        d.prev_score[env] = s.f[A_SCORE];
+        r.ep_ret[env] = m.ep_ret; r.ep_len[env] = m.ep_len; r.ep_index[env] = m.ep_index; r.prev_lives[env] = m.prev_lives;
+        if (m.emitted) { r.ep_done[env] = 1; r.ep_ret_out[env] = (float)m.out_ret; r.ep_len_out[env] = m.out_len; }
+    }
+}
+
 // ------------------------------------------------------------------ render
 
 __constant__ uint16_t AMI_DIGITS[10] = TBX_DIGIT_FONT;
@@ -952,6 +990,13 @@ struct AmiOps : GameOps {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int agent_reset_envs(tbx_engine* e, const AgentResetArgs& r, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(ami_agent_reset_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, r);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

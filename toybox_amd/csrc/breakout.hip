@@ -566,23 +566,9 @@ __device__ __forceinline__ void t_new_game(const BrkCfg& c, Rng& sim, BrkT& s)
     t_start_ball(c, s);
 }
 
-__global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, ActionSource src, uint32_t flags, BrkRenderRec* recs)
+__device__ __forceinline__ void t_load(const BrkDev& d, int env, BrkT& s)
 {
-    const BrkCfg& c = *cp;   // tables are indexed per thread: read them from memory, not from the kernel arguments
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= d.n) return;
     const size_t N = (size_t)d.n;
-
-    int a;
-    if (src.actions) a = src.actions[env];
-    else {
-        const uint64_t h = tbx_splitmix64(src.seed ^ ((src.env_offset + (uint64_t)env) << 32) ^ src.t);
-        a = tbx_legal_action(TBX_GAME_BREAKOUT, (int)(h % 4ull));
-    }
-    uint32_t buttons = tbx_ale_buttons(a);
-    if (buttons == 0xFFu) { buttons = 0; atomicOr(d.err_flag, 1u); }
-
-    BrkT s;
     s.rng.s0 = d.rng[env]; s.rng.s1 = d.rng[N + env];
     s.score = d.score[env]; s.lives = d.lives[env]; s.level = d.level[env]; s.flags = d.flags[env];
     s.px = d.paddle[0 * N + env]; s.py = d.paddle[1 * N + env]; s.pvx = d.paddle[2 * N + env]; s.pvy = d.paddle[3 * N + env];
@@ -595,8 +581,46 @@ __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCf
     }
 #pragma unroll
     for (int k = 0; k < MAXK; k++) s.alive[k] = d.alive[(size_t)k * N + env];
-    const int rows = c.n_rows;
+}
 
+__device__ __forceinline__ void t_store(const BrkDev& d, int env, const BrkT& s)
+{
+    const size_t N = (size_t)d.n;
+    d.rng[env] = s.rng.s0; d.rng[N + env] = s.rng.s1;
+    d.score[env] = s.score; d.lives[env] = s.lives; d.level[env] = s.level; d.flags[env] = s.flags;
+    d.paddle[0 * N + env] = s.px; d.paddle[1 * N + env] = s.py; d.paddle[2 * N + env] = s.pvx; d.paddle[3 * N + env] = s.pvy;
+    d.paddle[4 * N + env] = s.pw; d.paddle[5 * N + env] = s.pspeed; d.paddle[6 * N + env] = s.radius;
+    d.n_balls[env] = s.n_balls; d.n_bricks[env] = s.n_bricks;
+#pragma unroll
+    for (int b = 0; b < MAXB; b++) {
+        d.balls[(size_t)(0 * MAXB + b) * N + env] = s.bx[b]; d.balls[(size_t)(1 * MAXB + b) * N + env] = s.by[b];
+        d.balls[(size_t)(2 * MAXB + b) * N + env] = s.bvx[b]; d.balls[(size_t)(3 * MAXB + b) * N + env] = s.bvy[b];
+    }
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) d.alive[(size_t)k * N + env] = s.alive[k];
+}
+
+// the rasteriser's record of one env
+__device__ __forceinline__ BrkRenderRec t_record(const BrkT& s)
+{
+    BrkRenderRec rec;
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) rec.alive[k] = s.alive[k];
+    rec.paddle = pack_rect(f2i(s.px - s.pw * 0.5), f2i(s.py), f2i(s.pw), 3);
+    const int ball_s = f2i(s.radius * 2.0);
+#pragma unroll
+    for (int b = 0; b < MAXB; b++)
+        rec.ball[b] = b < s.n_balls ? pack_rect(f2i(s.bx[b] - s.radius), f2i(s.by[b] - s.radius), ball_s, ball_s) : 0u;
+    rec.n_bricks = s.n_bricks;
+    rec.hud = brk_hud_word(s.score, s.lives, s.level);
+    rec._pad = 0;
+    return rec;
+}
+
+// one frame of one env (the transition of DESIGN.md "Breakout" for the canonical wall)
+__device__ __forceinline__ void brk_t_step(const BrkCfg& c, BrkT& s, uint32_t buttons)
+{
+    const int rows = c.n_rows;
     // 1. paddle intent
     if (buttons & TBX_BTN_LEFT) s.pvx = -s.pspeed;
     else if (buttons & TBX_BTN_RIGHT) s.pvx = s.pspeed;
@@ -714,7 +738,28 @@ __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCf
     // 5. wall cleared
     if (s.n_bricks > 0 && (s.alive[0] | s.alive[1] | s.alive[2] | s.alive[3]) == 0ull) { s.level += 1; t_fill_wall(s); }
 
-    // outputs, auto-reset
+}
+
+__global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, ActionSource src, uint32_t flags, BrkRenderRec* recs)
+{
+    const BrkCfg& c = *cp;   // tables are indexed per thread: read them from memory, not from the kernel arguments
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n) return;
+    const size_t N = (size_t)d.n;
+
+    int a;
+    if (src.actions) a = src.actions[env];
+    else {
+        const uint64_t h = tbx_splitmix64(src.seed ^ ((src.env_offset + (uint64_t)env) << 32) ^ src.t);
+        a = tbx_legal_action(TBX_GAME_BREAKOUT, (int)(h % 4ull));
+    }
+    uint32_t buttons = tbx_ale_buttons(a);
+    if (buttons == 0xFFu) { buttons = 0; atomicOr(d.err_flag, 1u); }
+
+    BrkT s;
+    t_load(d, env, s);
+    brk_t_step(c, s, buttons);
+
     int32_t rew = s.score - d.prev_score[env];
     if (rew < 0) rew = 0;
     const int32_t out_lives = s.lives, out_score = s.score;
@@ -727,18 +772,7 @@ __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCf
         d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
         prev = s.score;
     }
-    d.rng[env] = s.rng.s0; d.rng[N + env] = s.rng.s1;
-    d.score[env] = s.score; d.lives[env] = s.lives; d.level[env] = s.level; d.flags[env] = s.flags;
-    d.paddle[0 * N + env] = s.px; d.paddle[1 * N + env] = s.py; d.paddle[2 * N + env] = s.pvx; d.paddle[3 * N + env] = s.pvy;
-    d.paddle[4 * N + env] = s.pw; d.paddle[5 * N + env] = s.pspeed; d.paddle[6 * N + env] = s.radius;
-    d.n_balls[env] = s.n_balls; d.n_bricks[env] = s.n_bricks;
-#pragma unroll
-    for (int b = 0; b < MAXB; b++) {
-        d.balls[(size_t)(0 * MAXB + b) * N + env] = s.bx[b]; d.balls[(size_t)(1 * MAXB + b) * N + env] = s.by[b];
-        d.balls[(size_t)(2 * MAXB + b) * N + env] = s.bvx[b]; d.balls[(size_t)(3 * MAXB + b) * N + env] = s.bvy[b];
-    }
-#pragma unroll
-    for (int k = 0; k < MAXK; k++) d.alive[(size_t)k * N + env] = s.alive[k];
+    t_store(d, env, s);
     d.prev_score[env] = prev;
     d.reward[env] = rew;
     d.done[env] = is_done ? 1 : 0;
@@ -746,20 +780,42 @@ __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCf
     d.score_out[env] = out_score;
     const uint32_t lv8 = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
     d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv8 << 40);
+    recs[env] = t_record(s);
+}
 
-    // the rasteriser's record of the (possibly re-started) env
-    BrkRenderRec rec;
-#pragma unroll
-    for (int k = 0; k < MAXK; k++) rec.alive[k] = s.alive[k];
-    rec.paddle = pack_rect(f2i(s.px - s.pw * 0.5), f2i(s.py), f2i(s.pw), 3);
-    const int ball_s = f2i(s.radius * 2.0);
-#pragma unroll
-    for (int b = 0; b < MAXB; b++)
-        rec.ball[b] = b < s.n_balls ? pack_rect(f2i(s.bx[b] - s.radius), f2i(s.by[b] - s.radius), ball_s, ball_s) : 0u;
-    rec.n_bricks = s.n_bricks;
-    rec.hud = brk_hud_word(s.score, s.lives, s.level);
-    rec._pad = 0;
-    recs[env] = rec;
+// reset-time wrappers of the agent layer for the envs flagged in r.kind (agent_device.hpp, AgentResetProc)
+struct BrkTEnv {
+    const BrkCfg& c;
+    BrkT& s;
+    Rng& sim;
+    __device__ __forceinline__ void step(uint32_t buttons) { brk_t_step(c, s, buttons); }
+    __device__ __forceinline__ void new_game() { t_new_game(c, sim, s); }
+    __device__ __forceinline__ int lives() const { return s.lives; }
+    __device__ __forceinline__ int score() const { return s.score; }
+};
+
+__global__ __launch_bounds__(128) void brk_agent_reset_kernel(BrkDev d, const BrkCfg* __restrict__ cp, AgentResetArgs r, BrkRenderRec* recs)
+{
+    const BrkCfg& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n) return;
+    const int kind = r.kind[env];
+    if (kind == 0) return;
+    const size_t N = (size_t)d.n;
+    BrkT s;
+    t_load(d, env, s);
+    Rng sim;
+    sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
+    AgentMonitor m{r.ep_ret[env], r.ep_len[env], r.ep_index[env], r.prev_lives[env], false, 0, 0};
+    BrkTEnv env_ops{c, s, sim};
+    AgentResetProc<BrkTEnv> proc{env_ops, r, m, r.env_offset + (uint64_t)env, false};
+    proc.run(kind);
+    t_store(d, env, s);
+    d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
+    d.prev_score[env] = s.score;
+    r.ep_ret[env] = m.ep_ret; r.ep_len[env] = m.ep_len; r.ep_index[env] = m.ep_index; r.prev_lives[env] = m.prev_lives;
+    if (m.emitted) { r.ep_done[env] = 1; r.ep_ret_out[env] = (float)m.out_ret; r.ep_len_out[env] = m.out_len; }
+    recs[env] = t_record(s);
 }
 
 // ------------------------------------------------------------------ render
@@ -1147,11 +1203,6 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
         }
     }
     stack_commit<S>(vals, o, a.oh * a.ow, lane, fresh);
-    if (!a.reset_mode && lane == 0) {
-        const int r = a.racc[env];
-        a.reward_out[env] = a.clip ? (float)((r > 0) - (r < 0)) : (float)r;
-        a.done_out[env] = a.fin[env];
-    }
 }
 
 // ------------------------------------------------------------------ state pack / unpack, scalars
@@ -1428,6 +1479,15 @@ struct BreakoutOps : GameOps {
             if (!recsA) TBX_HIP(hipMalloc((void**)&recsA, sizeof(BrkRenderRec) * (size_t)e->n));
             TBX_HIP(hipMemcpyAsync(recsA, recs, sizeof(BrkRenderRec) * (size_t)e->n, hipMemcpyDeviceToDevice, s));
         }
+        return TBX_OK;
+    }
+
+    int agent_reset_envs(tbx_engine* e, const AgentResetArgs& r, hipStream_t s) override
+    {
+        if (custom) return e->fail(TBX_E_UNSUPPORTED, "breakout: episodic-life / fire-reset / no-op-reset need the canonical brick wall");
+        hipLaunchKernelGGL(brk_agent_reset_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, r, recs);
+        TBX_HIP(hipGetLastError());
+        // every other env's record is still current if it was; the flagged envs' records were just rewritten
         return TBX_OK;
     }
 

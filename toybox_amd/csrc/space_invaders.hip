@@ -18,6 +18,7 @@
 
 #include "tbx_common.hpp"
 #include "raster.hpp"
+#include "agent_device.hpp"
 #include "../../include/toybox_amd_spec.h"
 
 #include <climits>
@@ -540,6 +541,43 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiCfg c, Ac
     }
 }
 
+// reset-time wrappers of the agent layer for the envs flagged in r.kind (agent_device.hpp, AgentResetProc)
+struct SiAgentEnv {
+    const SiCfg& c;
+    int lane;
+    SiRegs& s;
+    Rng& sim;
+    __device__ __forceinline__ void step(uint32_t buttons) { si_step(c, lane, buttons, s); }
+    __device__ __forceinline__ void new_game() { si_new_game(c, lane, sim, s); }
+    __device__ __forceinline__ int lives() const { return wave_uniform(s.f[F_LIVES]); }
+    __device__ __forceinline__ int score() const { return wave_uniform(s.f[F_SCORE]); }
+};
+
+__global__ __launch_bounds__(TBX_BLOCK) void si_agent_reset_kernel(SiDev d, SiCfg c, AgentResetArgs r)
+{
+    const int lane = threadIdx.x & 63;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (env >= d.n) return;
+    const int kind = wave_uniform((int)r.kind[env]);
+    if (kind == 0) return;
+    const size_t N = (size_t)d.n;
+    SiRegs s;
+    si_load(d, env, lane, s);
+    Rng sim;
+    sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
+    AgentMonitor m{r.ep_ret[env], r.ep_len[env], r.ep_index[env], r.prev_lives[env], false, 0, 0};
+    SiAgentEnv ops{c, lane, s, sim};
+    AgentResetProc<SiAgentEnv> proc{ops, r, m, r.env_offset + (uint64_t)env, false};
+    proc.run(kind);
+    si_store(d, env, lane, s);
+    if (lane == 0) {
+        d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
+        d.prev_score[env] = s.f[F_SCORE];
+        r.ep_ret[env] = m.ep_ret; r.ep_len[env] = m.ep_len; r.ep_index[env] = m.ep_index; r.prev_lives[env] = m.prev_lives;
+        if (m.emitted) { r.ep_done[env] = 1; r.ep_ret_out[env] = (float)m.out_ret; r.ep_len_out[env] = m.out_len; }
+    }
+}
+
 // ------------------------------------------------------------------ render
 
 __constant__ uint16_t SI_DIGITS[10] = TBX_DIGIT_FONT;
@@ -920,6 +958,13 @@ struct SiOps : GameOps {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int agent_reset_envs(tbx_engine* e, const AgentResetArgs& r, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(si_agent_reset_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, c, r);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

@@ -200,6 +200,8 @@ struct GameOps {
     virtual bool agent_fused() const { return false; }
     virtual int agent_snapshot(tbx_engine*, int /*which*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
     virtual int agent_warp(tbx_engine*, const struct AgentWarpArgs&, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    // reset-time wrappers (episodic life / fire reset / no-op reset) for the envs flagged in AgentResetArgs::kind
+    virtual int agent_reset_envs(tbx_engine*, const struct AgentResetArgs&, hipStream_t) { return TBX_E_UNSUPPORTED; }
 };
 
 void tbx_agent_free(tbx_engine* e);

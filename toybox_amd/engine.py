@@ -173,8 +173,10 @@ class Engine:
         return [int(v) for v in out]
 
     # ------------------------------------------------------------------ agent-side preprocessing (fused wrapper stack)
-    def agent_init(self, skip=4, out_h=84, out_w=84, stack=4, clip_reward=True):
-        cfg = _abi.AgentConfig(int(skip), int(out_h), int(out_w), int(stack), int(bool(clip_reward)))
+    def agent_init(self, skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=False, fire_reset=False,
+                   noop_max=0, noop_seed=0, env_offset=0):
+        cfg = _abi.AgentConfig(int(skip), int(out_h), int(out_w), int(stack), int(bool(clip_reward)), int(bool(episodic_life)),
+                               int(bool(fire_reset)), int(noop_max), int(noop_seed), int(env_offset))
         self._check(self._lib.tbx_agent_init(self._h, C.byref(cfg)))
         self._agent_shape = (self.n_envs, int(out_h), int(out_w), int(stack))
 
@@ -193,6 +195,13 @@ class Engine:
         done = np.empty(self.n_envs, np.uint8)
         self._check(self._lib.tbx_agent_step(self._h, _ptr(a), _ptr(reward), _ptr(done), _ptr(obs)))
         return obs, reward, done.astype(bool)
+
+    def agent_episodes(self):
+        """Episode monitor of the last agent step: (ended bool[N], return float32[N], length int32[N])."""
+        n = self.n_envs
+        ended, ret, length = np.empty(n, np.uint8), np.empty(n, np.float32), np.empty(n, np.int32)
+        self._check(self._lib.tbx_agent_episodes(self._h, _ptr(ended), _ptr(ret), _ptr(length)))
+        return ended.astype(bool), ret, length
 
     def agent_step_synthetic(self, action_seed, t, env_offset=0, stream=0):
         self._check(self._lib.tbx_agent_step_synthetic(self._h, int(action_seed), int(t), int(env_offset), C.c_void_p(int(stream))))

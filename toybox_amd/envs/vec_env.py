@@ -105,9 +105,15 @@ class ToyboxVecEnv:
 class ToyboxPreprocVecEnv:
     """The DeepMind-style pipeline of the reference's baselines fork -- MaxAndSkipEnv(skip) -> WarpFrame(84x84 gray) ->
     ClipRewardEnv -> VecFrameStack(stack) (atari_wrappers.py:193-244,324-360; vec_frame_stack.py:17-30) -- as ONE device
-    pass per agent step (tbx_agent_step): the learner only ever sees uint8[N, size, size, stack]."""
+    pass per agent step (tbx_agent_step): the learner only ever sees uint8[N, size, size, stack].
 
-    def __init__(self, game, num_envs, skip=4, size=84, stack=4, clip_rewards=True, seed=None, engine=None):
+    episode_life / fire_reset / noop_max switch on the reset-time wrappers of wrap_deepmind / make_atari
+    (EpisodicLifeEnv :58-96, FireResetEnv :38-56, NoopResetEnv :12-36), run inside the reset kernel; the Monitor
+    record of a finished game arrives as info["episode"] = {"r", "l"} like bench/monitor.py:68-76.  env_offset is the
+    global index of env 0 (multi-GPU sharding) so no-op counts do not depend on the shard layout."""
+
+    def __init__(self, game, num_envs, skip=4, size=84, stack=4, clip_rewards=True, seed=None, engine=None,
+                 episode_life=False, fire_reset=False, noop_max=0, noop_seed=0, env_offset=0):
         self.game = {"spaceinvaders": "space_invaders"}.get(game, game)
         self.num_envs = int(num_envs)
         self.engine = engine if engine is not None else _make_engine(self.game, self.num_envs)
@@ -118,7 +124,9 @@ class ToyboxPreprocVecEnv:
         if seed is not None:
             for i in range(self.num_envs):
                 self.engine.seed(hash_seed(int(seed) + i + 1) % 2 ** 31, env=i)
-        self.engine.agent_init(skip=skip, out_h=size, out_w=size, stack=stack, clip_reward=clip_rewards)
+        self.engine.agent_init(skip=skip, out_h=size, out_w=size, stack=stack, clip_reward=clip_rewards,
+                               episodic_life=episode_life, fire_reset=fire_reset, noop_max=noop_max, noop_seed=noop_seed,
+                               env_offset=env_offset)
         self._pending = None
         self.closed = False
 
@@ -137,7 +145,11 @@ class ToyboxPreprocVecEnv:
         assert self._pending is not None, "step_wait without step_async"
         actions, self._pending = self._pending, None
         obs, reward, done = self.engine.agent_step(actions)
-        return obs, reward, done, [{} for _ in range(self.num_envs)]
+        infos = [{} for _ in range(self.num_envs)]
+        ended, ret, length = self.engine.agent_episodes()
+        for i in np.flatnonzero(ended):
+            infos[int(i)]["episode"] = {"r": float(ret[i]), "l": int(length[i])}
+        return obs, reward, done, infos
 
     def step(self, actions):
         self.step_async(actions)
