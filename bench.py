@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 # algorithmic bytes per env-step: 2*S_game + A + O + F
-S_GAME = {"breakout": 72, "space_invaders": 248, "amidar": 420}
+S_GAME = {"breakout": 72, "space_invaders": 248, "amidar": 420, "gridworld": 17}   # gridworld: player 8 + score 4 + over 4 + one cell
 A_BYTES, O_BYTES = 1, 5
 
 

@@ -39,7 +39,8 @@ extern "C" {
 #define TBX_GAME_BREAKOUT       0
 #define TBX_GAME_AMIDAR         1
 #define TBX_GAME_SPACE_INVADERS 2
-#define TBX_NUM_GAMES           3
+#define TBX_GAME_GRIDWORLD      3   /* toybox/envs/atari/gridworld.py:8-13; not gym-registered by the reference */
+#define TBX_NUM_GAMES           4
 
 #define TBX_OK            0
 #define TBX_E_INVALID    -1   /* bad argument (range, NULL, size mismatch)          */
@@ -269,6 +270,45 @@ typedef struct tbx_amidar_state {
     tbx_amidar_box_t boxes[TBX_AMI_MAX_BOXES];
     uint8_t  tiles[TBX_AMI_BOARD_H][TBX_AMI_BOARD_W];
 } tbx_amidar_state_t;
+
+/* ------------------------------------------------------------------ GridWorld POD */
+
+/* The reference only ships this game's two golden dumps (toybox/interventions/defaults/gridworld_{config,state}_default.json)
+ * and the env class envs/atari/gridworld.py:8-13; the records below hold exactly the fields of those dumps.  The rules
+ * and the picture are this repo's own ("GridWorld"): a fixed 160x128 frame divided into
+ * game_size cells of floor(160/w) x floor(128/h) pixels. */
+#define TBX_GW_W          160
+#define TBX_GW_H          128
+#define TBX_GW_MAX_DIM    32    /* game_size <= 32 x 32; grid rows have a stride of 32 cells */
+#define TBX_GW_MAX_TILES  16
+
+typedef struct tbx_gw_tile {
+    tbx_color_t color;
+    int32_t  reward;
+    uint8_t  goal, walkable, _pad[2];
+} tbx_gw_tile_t;
+
+typedef struct tbx_gridworld_config {
+    uint64_t rand[2];                 /* simulator RNG words (kept for a uniform seeding surface; the rules draw nothing) */
+    int32_t  width, height;           /* "game_size" */
+    int32_t  n_tiles;
+    int32_t  player_start_x, player_start_y;
+    int32_t  reward_becomes;          /* tile index a collected reward cell turns into */
+    tbx_color_t player_color;
+    uint8_t  tile_keys[TBX_GW_MAX_TILES];   /* the one-character names the JSON config gives the tiles */
+    tbx_gw_tile_t tiles[TBX_GW_MAX_TILES];
+    uint8_t  grid[TBX_GW_MAX_DIM * TBX_GW_MAX_DIM];   /* tile index of cell (x, y) at [y * 32 + x] */
+} tbx_gridworld_config_t;
+
+typedef struct tbx_gridworld_state {
+    int32_t  score, game_over;
+    int32_t  player_x, player_y;
+    int32_t  reward_becomes;
+    int32_t  width, height, n_tiles;
+    tbx_color_t player_color;
+    tbx_gw_tile_t tiles[TBX_GW_MAX_TILES];
+    uint8_t  grid[TBX_GW_MAX_DIM * TBX_GW_MAX_DIM];
+} tbx_gridworld_state_t;
 
 /* ------------------------------------------------------------------ engine */
 

@@ -54,6 +54,7 @@ size_t tbx_state_size(int game)
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_state_t);
     case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_state_t);
     case TBX_GAME_AMIDAR: return sizeof(tbx_amidar_state_t);
+    case TBX_GAME_GRIDWORLD: return sizeof(tbx_gridworld_state_t);
     default: return 0;
     }
 }
@@ -63,6 +64,7 @@ size_t tbx_config_size(int game)
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_config_t);
     case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_config_t);
     case TBX_GAME_AMIDAR: return sizeof(tbx_amidar_config_t);
+    case TBX_GAME_GRIDWORLD: return sizeof(tbx_gridworld_config_t);
     default: return 0;
     }
 }
@@ -106,6 +108,7 @@ int tbx_create(int game, int n, int device, const void* cfg, size_t cfg_size, tb
         case TBX_GAME_BREAKOUT: orc_breakout_default_config((tbx_breakout_config_t*)e->cfg); break;
         case TBX_GAME_SPACE_INVADERS: orc_si_default_config((tbx_si_config_t*)e->cfg); break;
         case TBX_GAME_AMIDAR: orc_amidar_default_config((tbx_amidar_config_t*)e->cfg); break;
+        case TBX_GAME_GRIDWORLD: orc_gridworld_default_config((tbx_gridworld_config_t*)e->cfg); break;
     }
     for (int i = 0; i < n; i++) memcpy(e->sim + 2 * (size_t)i, e->cfg, 16);
     orc_new_game_batch(game, e->cfg, e->states, e->sim, e->prev, n, NULL);
@@ -221,6 +224,9 @@ int tbx_apply_input(tbx_engine* e, int env, uint32_t buttons)
     case TBX_GAME_AMIDAR:
         orc_amidar_step((const tbx_amidar_config_t*)e->cfg, (tbx_amidar_state_t*)st, buttons & 0x3Fu);
         break;
+    case TBX_GAME_GRIDWORLD:
+        orc_gridworld_step((const tbx_gridworld_config_t*)e->cfg, (tbx_gridworld_state_t*)st, buttons & 0x3Fu);
+        break;
     }
     int32_t sc, lv, le;
     orc_get_scalars(e->game, st, 1, &sc, &lv, &le);
@@ -307,6 +313,12 @@ int tbx_set_state(tbx_engine* e, int env, const void* pod, size_t size)
         if (s->n_enemy_lasers < 0 || s->n_enemy_lasers > TBX_SI_MAX_LASERS) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 8 enemy lasers per env");
         if (s->n_shields < 0 || s->n_shields > TBX_SI_MAX_SHIELDS) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 3 shields per env");
     }
+    if (e->game == TBX_GAME_GRIDWORLD) {
+        const tbx_gridworld_state_t* s = (const tbx_gridworld_state_t*)pod;
+        if (s->width < 1 || s->width > TBX_GW_MAX_DIM || s->height < 1 || s->height > TBX_GW_MAX_DIM)
+            return fail(e, TBX_E_UNSUPPORTED, "gridworld: game_size must be 1..32 x 1..32");
+        if (s->n_tiles < 1 || s->n_tiles > TBX_GW_MAX_TILES) return fail(e, TBX_E_UNSUPPORTED, "gridworld: 1..16 tiles");
+    }
     memcpy(e->states + e->ssz * (size_t)env, pod, size);
     return TBX_OK;
 }
@@ -362,6 +374,12 @@ int tbx_set_config(tbx_engine* e, const void* pod, size_t size)
         if (k->n_rows < 1 || k->n_rows > TBX_SI_MAX_ROWS) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: n_rows must be 1..10");
         if (k->n_shields < 0 || k->n_shields > TBX_SI_MAX_SHIELDS) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: at most 3 shields");
         if (k->enemy_protocol != 0) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: only the TargetPlayer firing protocol is implemented");
+    }
+    if (e->game == TBX_GAME_GRIDWORLD) {
+        const tbx_gridworld_config_t* k = (const tbx_gridworld_config_t*)pod;
+        if (k->width < 1 || k->width > TBX_GW_MAX_DIM || k->height < 1 || k->height > TBX_GW_MAX_DIM)
+            return fail(e, TBX_E_UNSUPPORTED, "gridworld: game_size must be 1..32 x 1..32");
+        if (k->n_tiles < 1 || k->n_tiles > TBX_GW_MAX_TILES) return fail(e, TBX_E_UNSUPPORTED, "gridworld: 1..16 tiles");
     }
     memcpy(e->cfg, pod, size);
     for (int i = 0; i < e->n; i++) memcpy(e->sim + 2 * (size_t)i, pod, 16);
@@ -489,6 +507,7 @@ static void raw_step(tbx_engine* e, int i, uint32_t buttons)
     switch (e->game) {
     case TBX_GAME_BREAKOUT: orc_breakout_step((const tbx_breakout_config_t*)e->cfg, (tbx_breakout_state_t*)env_state(e, i), buttons); break;
     case TBX_GAME_SPACE_INVADERS: orc_si_step((const tbx_si_config_t*)e->cfg, (tbx_si_state_t*)env_state(e, i), buttons); break;
+    case TBX_GAME_GRIDWORLD: orc_gridworld_step((const tbx_gridworld_config_t*)e->cfg, (tbx_gridworld_state_t*)env_state(e, i), buttons); break;
     default: orc_amidar_step((const tbx_amidar_config_t*)e->cfg, (tbx_amidar_state_t*)env_state(e, i), buttons); break;
     }
 }
@@ -498,6 +517,7 @@ static void raw_new_game(tbx_engine* e, int i)
     switch (e->game) {
     case TBX_GAME_BREAKOUT: orc_breakout_new_game((const tbx_breakout_config_t*)e->cfg, sim, (tbx_breakout_state_t*)env_state(e, i)); break;
     case TBX_GAME_SPACE_INVADERS: orc_si_new_game((const tbx_si_config_t*)e->cfg, sim, (tbx_si_state_t*)env_state(e, i)); break;
+    case TBX_GAME_GRIDWORLD: orc_gridworld_new_game((const tbx_gridworld_config_t*)e->cfg, sim, (tbx_gridworld_state_t*)env_state(e, i)); break;
     default: orc_amidar_new_game((const tbx_amidar_config_t*)e->cfg, sim, (tbx_amidar_state_t*)env_state(e, i)); break;
     }
 }

@@ -81,11 +81,13 @@ int orc_legal_actions(int game, int32_t* out, int cap)
     static const int32_t brk[] = {0, 1, 3, 4};
     static const int32_t ami[] = {0, 1, 2, 3, 4, 5};
     static const int32_t spi[] = {0, 1, 3, 4, 11, 12};
+    static const int32_t grd[] = {0, 2, 3, 4, 5};
     const int32_t* src; int n;
     switch (game) {
     case TBX_GAME_BREAKOUT: src = brk; n = 4; break;
     case TBX_GAME_AMIDAR: src = ami; n = 6; break;
     case TBX_GAME_SPACE_INVADERS: src = spi; n = 6; break;
+    case TBX_GAME_GRIDWORLD: src = grd; n = 5; break;
     default: return -1;
     }
     for (int i = 0; i < n && i < cap; i++) out[i] = src[i];
@@ -98,6 +100,7 @@ int orc_frame_dims(int game, int* h, int* w)
     case TBX_GAME_BREAKOUT: *h = TBX_BRK_H; *w = TBX_BRK_W; return 0;
     case TBX_GAME_SPACE_INVADERS: *h = TBX_SI_H; *w = TBX_SI_W; return 0;
     case TBX_GAME_AMIDAR: *h = TBX_AMI_H; *w = TBX_AMI_W; return 0;
+    case TBX_GAME_GRIDWORLD: *h = TBX_GW_H; *w = TBX_GW_W; return 0;
     default: return -1;
     }
 }
@@ -118,6 +121,7 @@ static size_t state_size(int game)
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_state_t);
     case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_state_t);
     case TBX_GAME_AMIDAR: return sizeof(tbx_amidar_state_t);
+    case TBX_GAME_GRIDWORLD: return sizeof(tbx_gridworld_state_t);
     default: return 0;
     }
 }
@@ -134,6 +138,9 @@ static void one_new_game(int game, const void* cfg, void* st, uint64_t* sim)
     case TBX_GAME_AMIDAR:
         orc_amidar_new_game((const tbx_amidar_config_t*)cfg, sim, (tbx_amidar_state_t*)st);
         break;
+    case TBX_GAME_GRIDWORLD:
+        orc_gridworld_new_game((const tbx_gridworld_config_t*)cfg, sim, (tbx_gridworld_state_t*)st);
+        break;
     }
 }
 
@@ -148,6 +155,9 @@ static void one_step(int game, const void* cfg, void* st, uint32_t buttons)
         break;
     case TBX_GAME_AMIDAR:
         orc_amidar_step((const tbx_amidar_config_t*)cfg, (tbx_amidar_state_t*)st, buttons);
+        break;
+    case TBX_GAME_GRIDWORLD:
+        orc_gridworld_step((const tbx_gridworld_config_t*)cfg, (tbx_gridworld_state_t*)st, buttons);
         break;
     }
 }
@@ -167,6 +177,10 @@ static void one_scalars(int game, const void* st, int32_t* score, int32_t* lives
     case TBX_GAME_AMIDAR: {
         const tbx_amidar_state_t* s = (const tbx_amidar_state_t*)st;
         *score = s->score; *lives = s->lives; *level = s->level;
+        break; }
+    case TBX_GAME_GRIDWORLD: {                  /* one life, spent on reaching a goal cell; a single level */
+        const tbx_gridworld_state_t* s = (const tbx_gridworld_state_t*)st;
+        *score = s->score; *lives = s->game_over ? 0 : 1; *level = 1;
         break; }
     }
 }
@@ -252,6 +266,9 @@ int orc_render_batch(int game, const void* cfg, const void* states, int n, uint8
             break;
         case TBX_GAME_AMIDAR:
             orc_amidar_render((const tbx_amidar_config_t*)cfg, (const tbx_amidar_state_t*)st, out + fsz * (size_t)i, channels);
+            break;
+        case TBX_GAME_GRIDWORLD:
+            orc_gridworld_render((const tbx_gridworld_config_t*)cfg, (const tbx_gridworld_state_t*)st, out + fsz * (size_t)i, channels);
             break;
         }
     }

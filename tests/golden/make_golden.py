@@ -164,6 +164,10 @@ def main():
             json.dump(load(game, "config"), f, separators=(",", ":"), sort_keys=True)
         with open(os.path.join(OUT, "%s_state.json" % game), "w") as f:
             json.dump(mp(load(game, "state")), f, separators=(",", ":"), sort_keys=True)
+    # GridWorld: the two dumps as they are (the reference has no intervention classes for this game)
+    for kind in ("config", "state"):
+        with open(os.path.join(OUT, "gridworld_%s.json" % kind), "w") as f:
+            json.dump(load("gridworld", kind), f, separators=(",", ":"), sort_keys=True)
     print("golden fixtures written to", OUT)
 
 

@@ -7,6 +7,7 @@ LEGAL = {
     "breakout": [0, 1, 3, 4],
     "amidar": [0, 1, 2, 3, 4, 5],
     "space_invaders": [0, 1, 3, 4, 11, 12],
+    "gridworld": [0, 2, 3, 4, 5],
 }
 
 

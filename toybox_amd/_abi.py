@@ -8,10 +8,11 @@ import ctypes as C
 
 ABI_VERSION = 1
 
-GAME_BREAKOUT, GAME_AMIDAR, GAME_SPACE_INVADERS = 0, 1, 2
+GAME_BREAKOUT, GAME_AMIDAR, GAME_SPACE_INVADERS, GAME_GRIDWORLD = 0, 1, 2, 3
 GAME_IDS = {"breakout": GAME_BREAKOUT, "amidar": GAME_AMIDAR, "space_invaders": GAME_SPACE_INVADERS,
-            "spaceinvaders": GAME_SPACE_INVADERS}
-GAME_NAMES = {GAME_BREAKOUT: "breakout", GAME_AMIDAR: "amidar", GAME_SPACE_INVADERS: "space_invaders"}
+            "spaceinvaders": GAME_SPACE_INVADERS, "gridworld": GAME_GRIDWORLD}
+GAME_NAMES = {GAME_BREAKOUT: "breakout", GAME_AMIDAR: "amidar", GAME_SPACE_INVADERS: "space_invaders",
+              GAME_GRIDWORLD: "gridworld"}
 
 OK, E_INVALID, E_NO_DEVICE, E_NOMEM, E_UNSUPPORTED, E_ACTION = 0, -1, -2, -3, -4, -5
 
@@ -182,8 +183,39 @@ class AmidarState(C.Structure):
     ]
 
 
-STATE_TYPES = {GAME_BREAKOUT: BreakoutState, GAME_SPACE_INVADERS: SIState, GAME_AMIDAR: AmidarState}
-CONFIG_TYPES = {GAME_BREAKOUT: BreakoutConfig, GAME_SPACE_INVADERS: SIConfig, GAME_AMIDAR: AmidarConfig}
+GW_MAX_DIM, GW_MAX_TILES = 32, 16
+
+
+class GridWorldTile(C.Structure):
+    _fields_ = [("color", Color), ("reward", C.c_int32), ("goal", C.c_uint8), ("walkable", C.c_uint8), ("_pad", C.c_uint8 * 2)]
+
+
+class GridWorldConfig(C.Structure):
+    _fields_ = [
+        ("rand", C.c_uint64 * 2),
+        ("width", C.c_int32), ("height", C.c_int32), ("n_tiles", C.c_int32),
+        ("player_start_x", C.c_int32), ("player_start_y", C.c_int32), ("reward_becomes", C.c_int32),
+        ("player_color", Color),
+        ("tile_keys", C.c_uint8 * GW_MAX_TILES),
+        ("tiles", GridWorldTile * GW_MAX_TILES),
+        ("grid", C.c_uint8 * (GW_MAX_DIM * GW_MAX_DIM)),
+    ]
+
+
+class GridWorldState(C.Structure):
+    _fields_ = [
+        ("score", C.c_int32), ("game_over", C.c_int32), ("player_x", C.c_int32), ("player_y", C.c_int32),
+        ("reward_becomes", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("n_tiles", C.c_int32),
+        ("player_color", Color),
+        ("tiles", GridWorldTile * GW_MAX_TILES),
+        ("grid", C.c_uint8 * (GW_MAX_DIM * GW_MAX_DIM)),
+    ]
+
+
+STATE_TYPES = {GAME_BREAKOUT: BreakoutState, GAME_SPACE_INVADERS: SIState, GAME_AMIDAR: AmidarState,
+               GAME_GRIDWORLD: GridWorldState}
+CONFIG_TYPES = {GAME_BREAKOUT: BreakoutConfig, GAME_SPACE_INVADERS: SIConfig, GAME_AMIDAR: AmidarConfig,
+                GAME_GRIDWORLD: GridWorldConfig}
 
 class AgentConfig(C.Structure):
     _fields_ = [("skip", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32), ("stack", C.c_int32), ("clip_reward", C.c_int32),

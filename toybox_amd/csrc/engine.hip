@@ -78,6 +78,31 @@ void si_default_config(tbx_si_config_t* c)
     for (int i = 0; i < 3; i++) { c->shield_x[i] = sx[i]; c->shield_y[i] = 157; }
 }
 
+// toybox/interventions/defaults/gridworld_config_default.json (tiles in the order of the dump's keys)
+void gridworld_default_config(tbx_gridworld_config_t* c)
+{
+    static const char* const rows[7] = {"111111111", "1000R0001", "101111101", "100010001", "10001R111", "1000100G1", "111111111"};
+    memset(c, 0, sizeof *c);
+    c->width = 9; c->height = 7; c->n_tiles = 4;
+    c->player_start_x = 2; c->player_start_y = 4;
+    c->reward_becomes = 0;
+    c->player_color = tbx_color_t{255, 0, 0, 255};
+    const char keys[4] = {'0', '1', 'G', 'R'};
+    const tbx_color_t colors[4] = {{255, 255, 255, 255}, {0, 0, 0, 255}, {0, 255, 0, 255}, {255, 255, 0, 255}};
+    const int rewards[4] = {0, 0, 10, 1};
+    for (int i = 0; i < 4; i++) {
+        c->tile_keys[i] = (uint8_t)keys[i];
+        c->tiles[i].color = colors[i];
+        c->tiles[i].reward = rewards[i];
+        c->tiles[i].goal = keys[i] == 'G';
+        c->tiles[i].walkable = keys[i] != '1';
+    }
+    for (int y = 0; y < 7; y++)
+        for (int x = 0; x < 9; x++)
+            for (int i = 0; i < 4; i++)
+                if (keys[i] == rows[y][x]) c->grid[y * TBX_GW_MAX_DIM + x] = (uint8_t)i;
+}
+
 void amidar_default_config(tbx_amidar_config_t* c)
 {
     static const char* board[TBX_AMI_BOARD_H] = {
@@ -170,6 +195,7 @@ int tbx_frame_dims(int game, int* h, int* w)
     case TBX_GAME_BREAKOUT: *h = TBX_BRK_H; *w = TBX_BRK_W; return TBX_OK;
     case TBX_GAME_SPACE_INVADERS: *h = TBX_SI_H; *w = TBX_SI_W; return TBX_OK;
     case TBX_GAME_AMIDAR: *h = TBX_AMI_H; *w = TBX_AMI_W; return TBX_OK;
+    case TBX_GAME_GRIDWORLD: *h = TBX_GW_H; *w = TBX_GW_W; return TBX_OK;
     default: return TBX_E_INVALID;
     }
 }
@@ -194,6 +220,7 @@ size_t tbx_state_size(int game)
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_state_t);
     case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_state_t);
     case TBX_GAME_AMIDAR: return sizeof(tbx_amidar_state_t);
+    case TBX_GAME_GRIDWORLD: return sizeof(tbx_gridworld_state_t);
     default: return 0;
     }
 }
@@ -204,6 +231,7 @@ size_t tbx_config_size(int game)
     case TBX_GAME_BREAKOUT: return sizeof(tbx_breakout_config_t);
     case TBX_GAME_SPACE_INVADERS: return sizeof(tbx_si_config_t);
     case TBX_GAME_AMIDAR: return sizeof(tbx_amidar_config_t);
+    case TBX_GAME_GRIDWORLD: return sizeof(tbx_gridworld_config_t);
     default: return 0;
     }
 }
@@ -257,6 +285,7 @@ int tbx_create(int game, int n_envs, int device, const void* config_pod, size_t 
     case TBX_GAME_BREAKOUT: e->ops = tbx_make_breakout_ops(); break;
     case TBX_GAME_SPACE_INVADERS: e->ops = tbx_make_si_ops(); break;
     case TBX_GAME_AMIDAR: e->ops = tbx_make_amidar_ops(); break;
+    case TBX_GAME_GRIDWORLD: e->ops = tbx_make_gridworld_ops(); break;
     default: e->err = "unknown game id"; return bail(TBX_E_INVALID);
     }
     const size_t N = (size_t)n_envs;
@@ -295,6 +324,7 @@ int tbx_create(int game, int n_envs, int device, const void* config_pod, size_t 
         case TBX_GAME_BREAKOUT: breakout_default_config((tbx_breakout_config_t*)cfg.data()); break;
         case TBX_GAME_SPACE_INVADERS: si_default_config((tbx_si_config_t*)cfg.data()); break;
         case TBX_GAME_AMIDAR: amidar_default_config((tbx_amidar_config_t*)cfg.data()); break;
+        case TBX_GAME_GRIDWORLD: gridworld_default_config((tbx_gridworld_config_t*)cfg.data()); break;
         }
     }
     rc = e->ops->init(e, cfg.data(), cfg.size());

@@ -1,0 +1,438 @@
+// gridworld.hip -- GridWorld on gfx950: thread-per-env step, wave-per-env rasteriser.
+//
+// The reference holds this game's env class (toybox/envs/atari/gridworld.py:8-13) and two golden dumps
+// (toybox/interventions/defaults/gridworld_config_default.json, gridworld_state_default.json); the rules are in the
+// absent ctoybox core, so movement, reward bookkeeping and the picture are this repo's specification (DESIGN.md
+// section 3, "GridWorld"), restated independently in the CPU checker.
+//
+// HBM layout: nine int32 scalars as SoA [field][N]; the tile table env-major [N][16][3 words]; the board env-major
+// [N][32*32] bytes.  A step touches the scalars (coalesced), one board byte and one tile record, so it is one thread
+// per env; the rasteriser is one wavefront per env with 8-scanline LDS units like the other games.
+#include "tbx_common.hpp"
+#include "raster.hpp"
+#include "agent_device.hpp"
+
+#include <cstring>
+
+namespace {
+
+enum { G_SCORE, G_OVER, G_PX, G_PY, G_BECOMES, G_W, G_H, G_NT, G_PCOL, GF };
+constexpr int GD = TBX_GW_MAX_DIM, GT = TBX_GW_MAX_TILES, CELLS = GD * GD;
+
+struct GwDev {
+    int n;
+    int32_t* sc;        // [GF][N]
+    uint32_t* tiles;    // [N][GT][3]: colour, reward, goal | walkable << 8
+    uint8_t* grid;      // [N][CELLS]
+    const tbx_gridworld_config_t* cfg;   // device copy of the engine's config
+    uint64_t* sim_rng;
+    int32_t *prev_score, *reward, *lives_out, *score_out;
+    uint8_t* done;
+    uint64_t* packed;
+    uint32_t* err_flag;
+};
+
+struct GwT { int32_t score, over, px, py, becomes, w, h, nt; };
+
+__device__ __forceinline__ void gw_load(const GwDev& d, int env, GwT& s)
+{
+    const size_t N = (size_t)d.n;
+    s.score = d.sc[G_SCORE * N + env]; s.over = d.sc[G_OVER * N + env];
+    s.px = d.sc[G_PX * N + env]; s.py = d.sc[G_PY * N + env];
+    s.becomes = d.sc[G_BECOMES * N + env];
+    s.w = d.sc[G_W * N + env]; s.h = d.sc[G_H * N + env]; s.nt = d.sc[G_NT * N + env];
+}
+__device__ __forceinline__ void gw_store(const GwDev& d, int env, const GwT& s)
+{
+    const size_t N = (size_t)d.n;
+    d.sc[G_SCORE * N + env] = s.score; d.sc[G_OVER * N + env] = s.over;
+    d.sc[G_PX * N + env] = s.px; d.sc[G_PY * N + env] = s.py;
+    d.sc[G_BECOMES * N + env] = s.becomes;
+    d.sc[G_W * N + env] = s.w; d.sc[G_H * N + env] = s.h; d.sc[G_NT * N + env] = s.nt;
+}
+
+__host__ __device__ __forceinline__ uint32_t tile_flags(const tbx_gw_tile_t& t) { return (t.goal ? 1u : 0u) | (t.walkable ? 256u : 0u); }
+
+// the board and tile table of the config, copied by `lanes` cooperating lanes (1 for the thread-per-env callers)
+__device__ __forceinline__ void gw_copy_board(const GwDev& d, int env, int lane, int lanes)
+{
+    const tbx_gridworld_config_t& c = *d.cfg;
+    uint32_t* tiles = d.tiles + (size_t)env * GT * 3;
+    for (int t = lane; t < GT; t += lanes) {
+        tiles[t * 3 + 0] = pack_color(c.tiles[t].color);
+        tiles[t * 3 + 1] = (uint32_t)c.tiles[t].reward;
+        tiles[t * 3 + 2] = tile_flags(c.tiles[t]);
+    }
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(c.grid);   // 4-byte aligned in the record
+    uint32_t* dst = reinterpret_cast<uint32_t*>(d.grid + (size_t)env * CELLS);
+    for (int i = lane; i < CELLS / 4; i += lanes) dst[i] = src[i];
+}
+
+__device__ __forceinline__ void gw_new_scalars(const GwDev& d, GwT& s)
+{
+    const tbx_gridworld_config_t& c = *d.cfg;
+    s.score = 0; s.over = 0;
+    s.px = c.player_start_x; s.py = c.player_start_y;
+    s.becomes = c.reward_becomes;
+    s.w = c.width; s.h = c.height; s.nt = c.n_tiles;
+}
+
+// one frame of one env: at most one cell in the held direction (up, down, left, right in that priority)
+__device__ __forceinline__ void gw_step(const GwDev& d, int env, GwT& s, uint32_t buttons)
+{
+    if (s.over) return;
+    int dx = 0, dy = 0;
+    if (buttons & TBX_BTN_UP) dy = -1;
+    else if (buttons & TBX_BTN_DOWN) dy = 1;
+    else if (buttons & TBX_BTN_LEFT) dx = -1;
+    else if (buttons & TBX_BTN_RIGHT) dx = 1;
+    else return;
+    const int nx = s.px + dx, ny = s.py + dy;
+    if (nx < 0 || ny < 0 || nx >= s.w || ny >= s.h || nx >= GD || ny >= GD) return;
+    uint8_t* cell = d.grid + (size_t)env * CELLS + ny * GD + nx;
+    const int id = *cell;
+    if (id >= s.nt || id >= GT) return;
+    const uint32_t* t = d.tiles + ((size_t)env * GT + id) * 3;
+    const uint32_t fl = t[2];
+    if (!(fl & 256u)) return;
+    const int32_t reward = (int32_t)t[1];
+    s.px = nx; s.py = ny;
+    s.score += reward;
+    if (reward != 0) *cell = (uint8_t)s.becomes;
+    if (fl & 1u) s.over = 1;
+}
+
+__global__ __launch_bounds__(TBX_BLOCK) void gw_new_game_kernel(GwDev d, const uint8_t* mask)
+{
+    const int lane = threadIdx.x & 63;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (env >= d.n) return;
+    if (mask && !mask[env]) return;
+    gw_copy_board(d, env, lane, 64);
+    if (lane == 0) {
+        GwT s;
+        gw_new_scalars(d, s);
+        gw_store(d, env, s);
+        d.sc[G_PCOL * (size_t)d.n + env] = (int32_t)pack_color(d.cfg->player_color);
+        d.prev_score[env] = 0;
+    }
+}
+
+__global__ __launch_bounds__(128) void gw_step_kernel(GwDev d, ActionSource src, uint32_t flags, int first_env, int count)
+{
+    const int rel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rel >= count) return;
+    const int env = first_env + rel;
+    uint32_t buttons;
+    if (src.single_env >= 0) {
+        buttons = src.single_buttons;
+    } else {
+        int a;
+        if (src.actions) a = src.actions[env];
+        else {
+            const uint64_t h = tbx_splitmix64(src.seed ^ ((src.env_offset + (uint64_t)env) << 32) ^ src.t);
+            a = tbx_legal_action(TBX_GAME_GRIDWORLD, (int)(h % 5ull));
+        }
+        buttons = tbx_ale_buttons(a);
+        if (buttons == 0xFFu) { buttons = 0; atomicOr(d.err_flag, 1u); }
+    }
+    GwT s;
+    gw_load(d, env, s);
+    gw_step(d, env, s, buttons);
+    int32_t rew = s.score - d.prev_score[env];
+    if (rew < 0) rew = 0;
+    const int32_t out_lives = s.over ? 0 : 1, out_score = s.score;
+    const bool is_done = out_lives <= 0;
+    int32_t prev = s.score;
+    if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+        gw_copy_board(d, env, 0, 1);
+        gw_new_scalars(d, s);
+        d.sc[G_PCOL * (size_t)d.n + env] = (int32_t)pack_color(d.cfg->player_color);
+        prev = 0;
+    }
+    gw_store(d, env, s);
+    d.prev_score[env] = prev;
+    d.reward[env] = rew;
+    d.done[env] = is_done ? 1 : 0;
+    d.lives_out[env] = out_lives;
+    d.score_out[env] = out_score;
+    d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)(uint32_t)out_lives << 40);
+}
+
+// reset-time wrappers of the agent layer (agent_device.hpp, AgentResetProc), thread per flagged env
+struct GwAgentEnv {
+    const GwDev& d;
+    int env;
+    GwT& s;
+    __device__ __forceinline__ void step(uint32_t buttons) { gw_step(d, env, s, buttons); }
+    __device__ __forceinline__ void new_game()
+    {
+        gw_copy_board(d, env, 0, 1);
+        gw_new_scalars(d, s);
+        d.sc[G_PCOL * (size_t)d.n + env] = (int32_t)pack_color(d.cfg->player_color);
+    }
+    __device__ __forceinline__ int lives() const { return s.over ? 0 : 1; }
+    __device__ __forceinline__ int score() const { return s.score; }
+};
+
+__global__ __launch_bounds__(128) void gw_agent_reset_kernel(GwDev d, AgentResetArgs r)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n) return;
+    const int kind = r.kind[env];
+    if (kind == 0) return;
+    GwT s;
+    gw_load(d, env, s);
+    AgentMonitor m{r.ep_ret[env], r.ep_len[env], r.ep_index[env], r.prev_lives[env], false, 0, 0};
+    GwAgentEnv ops{d, env, s};
+    AgentResetProc<GwAgentEnv> proc{ops, r, m, r.env_offset + (uint64_t)env, false};
+    proc.run(kind);
+    gw_store(d, env, s);
+    d.prev_score[env] = s.score;
+    r.ep_ret[env] = m.ep_ret; r.ep_len[env] = m.ep_len; r.ep_index[env] = m.ep_index; r.prev_lives[env] = m.prev_lives;
+    if (m.emitted) { r.ep_done[env] = 1; r.ep_ret_out[env] = (float)m.out_ret; r.ep_len_out[env] = m.out_len; }
+}
+
+// ------------------------------------------------------------------ render
+
+constexpr int GW_UNIT_ROWS = 8;
+
+// lane l -> pixels 4l..4l+3 (lanes 0..39); lane t < 16 also keeps tile t's colour for the board lookups (ds_bpermute).
+// A scanline only changes when it enters the next cell row, so the four colours are rebuilt once per cell row.
+template <int C>
+__global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* out, int first_env, int count)
+{
+    constexpr int W = TBX_GW_W, H = TBX_GW_H, UNITS = H / GW_UNIT_ROWS;
+    using Stager = RowStager<C, W, GW_UNIT_ROWS>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (rel >= count) return;
+    const int env = first_env + rel;
+    Stager st{lds_all + wave * Stager::UNIT_BYTES};
+    const size_t N = (size_t)d.n;
+
+    int gw = wave_uniform(d.sc[G_W * N + env]), gh = wave_uniform(d.sc[G_H * N + env]);
+    gw = gw < 1 ? 1 : gw > GD ? GD : gw;
+    gh = gh < 1 ? 1 : gh > GD ? GD : gh;
+    const int tw = W / gw, th = H / gh;
+    const int px = wave_uniform(d.sc[G_PX * N + env]), py = wave_uniform(d.sc[G_PY * N + env]);
+    const int nt = wave_uniform(d.sc[G_NT * N + env]);
+    const uint32_t pcol = (uint32_t)wave_uniform(d.sc[G_PCOL * N + env]);
+    const uint32_t black = 0xFF000000u;
+    const uint32_t tcol = (lane < GT && lane < nt) ? d.tiles[((size_t)env * GT + lane) * 3] : black;
+    const uint8_t* g = d.grid + (size_t)env * CELLS;
+    const bool active = lane < W / 4;
+    int cx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cx[k] = (lane * 4 + k) / tw;
+
+    uint8_t* dst = out + (size_t)rel * H * W * C;
+    uint32_t c[4] = {black, black, black, black};
+    int last_cy = -1;
+    for (int u = 0; u < UNITS; u++) {
+        const int unit = (u + env) % UNITS;                  // rotate the start so waves do not march in lockstep
+        for (int r = 0; r < GW_UNIT_ROWS; r++) {
+            const int cy = (unit * GW_UNIT_ROWS + r) / th;
+            if (cy != last_cy) {
+                last_cy = cy;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool inside = active && cx[k] < gw && cy < gh;
+                    const int id = inside ? g[cy * GD + cx[k]] : 255;
+                    const uint32_t tc = __shfl(tcol, id & 15);
+                    c[k] = !inside ? black : (cx[k] == px && cy == py) ? pcol : id < GT ? tc : black;
+                }
+            }
+            if (active) st.put4(r, lane, c[0], c[1], c[2], c[3]);
+        }
+        st.flush(dst + (size_t)unit * Stager::UNIT_BYTES, lane);
+    }
+}
+
+// ------------------------------------------------------------------ state records
+
+__global__ void gw_pack_kernel(GwDev d, int env0, tbx_gridworld_state_t* out)
+{
+    const int env = env0 + blockIdx.x, lane = threadIdx.x;
+    const size_t N = (size_t)d.n;
+    tbx_gridworld_state_t& o = out[blockIdx.x];
+    if (lane == 0) {
+        o.score = d.sc[G_SCORE * N + env]; o.game_over = d.sc[G_OVER * N + env];
+        o.player_x = d.sc[G_PX * N + env]; o.player_y = d.sc[G_PY * N + env];
+        o.reward_becomes = d.sc[G_BECOMES * N + env];
+        o.width = d.sc[G_W * N + env]; o.height = d.sc[G_H * N + env]; o.n_tiles = d.sc[G_NT * N + env];
+        o.player_color = unpack_color((uint32_t)d.sc[G_PCOL * N + env]);
+    }
+    if (lane < GT) {
+        const uint32_t* t = d.tiles + ((size_t)env * GT + lane) * 3;
+        tbx_gw_tile_t tile;
+        tile.color = unpack_color(t[0]);
+        tile.reward = (int32_t)t[1];
+        tile.goal = (t[2] & 1u) ? 1 : 0; tile.walkable = (t[2] & 256u) ? 1 : 0;
+        tile._pad[0] = tile._pad[1] = 0;
+        o.tiles[lane] = tile;
+    }
+    for (int i = lane; i < CELLS; i += 64) o.grid[i] = d.grid[(size_t)env * CELLS + i];
+}
+
+__global__ void gw_unpack_kernel(GwDev d, int env0, const tbx_gridworld_state_t* in)
+{
+    const int env = env0 + blockIdx.x, lane = threadIdx.x;
+    const size_t N = (size_t)d.n;
+    const tbx_gridworld_state_t& o = in[blockIdx.x];
+    if (lane == 0) {
+        d.sc[G_SCORE * N + env] = o.score; d.sc[G_OVER * N + env] = o.game_over ? 1 : 0;
+        d.sc[G_PX * N + env] = o.player_x; d.sc[G_PY * N + env] = o.player_y;
+        d.sc[G_BECOMES * N + env] = o.reward_becomes;
+        d.sc[G_W * N + env] = o.width; d.sc[G_H * N + env] = o.height; d.sc[G_NT * N + env] = o.n_tiles;
+        d.sc[G_PCOL * N + env] = (int32_t)pack_color(o.player_color);
+        d.prev_score[env] = o.score;
+    }
+    if (lane < GT) {
+        uint32_t* t = d.tiles + ((size_t)env * GT + lane) * 3;
+        t[0] = pack_color(o.tiles[lane].color);
+        t[1] = (uint32_t)o.tiles[lane].reward;
+        t[2] = tile_flags(o.tiles[lane]);
+    }
+    for (int i = lane; i < CELLS; i += 64) d.grid[(size_t)env * CELLS + i] = o.grid[i];
+}
+
+__global__ void gw_scalars_kernel(GwDev d, int32_t* score, int32_t* lives, int32_t* level)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    const size_t N = (size_t)d.n;
+    score[i] = d.sc[G_SCORE * N + i];
+    lives[i] = d.sc[G_OVER * N + i] ? 0 : 1;
+    level[i] = 1;
+}
+
+int check_dims(tbx_engine* e, int w, int h, int nt)
+{
+    if (w < 1 || w > GD || h < 1 || h > GD) return e->fail(TBX_E_UNSUPPORTED, "gridworld: game_size must be 1..32 x 1..32");
+    if (nt < 1 || nt > GT) return e->fail(TBX_E_UNSUPPORTED, "gridworld: 1..16 tiles");
+    return TBX_OK;
+}
+
+struct GridWorldOps : GameOps {
+    GwDev d{};
+    tbx_gridworld_config_t cfg{};
+    tbx_gridworld_config_t* cfg_dev = nullptr;
+
+    int height() const override { return TBX_GW_H; }
+    int width() const override { return TBX_GW_W; }
+    size_t state_size() const override { return sizeof(tbx_gridworld_state_t); }
+    size_t config_size() const override { return sizeof(tbx_gridworld_config_t); }
+
+    int load_cfg(tbx_engine* e, const tbx_gridworld_config_t& k)
+    {
+        int rc = check_dims(e, k.width, k.height, k.n_tiles);
+        if (rc) return rc;
+        cfg = k;
+        TBX_HIP(hipMemcpy(cfg_dev, &cfg, sizeof cfg, hipMemcpyHostToDevice));
+        return TBX_OK;
+    }
+
+    int init(tbx_engine* e, const void* cfg_pod, size_t cfg_size) override
+    {
+        if (!cfg_pod || cfg_size != sizeof(tbx_gridworld_config_t)) return e->fail(TBX_E_INVALID, "gridworld: config size mismatch");
+        const size_t N = (size_t)e->n;
+        TBX_HIP(hipMalloc((void**)&cfg_dev, sizeof(tbx_gridworld_config_t)));
+        tbx_gridworld_config_t k;
+        memcpy(&k, cfg_pod, sizeof k);
+        int rc = load_cfg(e, k);
+        if (rc) return rc;
+        d.n = e->n;
+        d.cfg = cfg_dev;
+        d.sim_rng = e->sim_rng; d.prev_score = e->prev_score; d.reward = e->reward; d.done = e->done;
+        d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed; d.err_flag = e->err_flag;
+        TBX_HIP(hipMalloc((void**)&d.sc, (size_t)GF * N * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&d.tiles, N * GT * 3 * sizeof(uint32_t)));
+        TBX_HIP(hipMalloc((void**)&d.grid, N * CELLS));
+        return TBX_OK;
+    }
+
+    void destroy(tbx_engine*) override
+    {
+        hipFree(d.sc); hipFree(d.tiles); hipFree(d.grid); hipFree(cfg_dev);
+    }
+
+    int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
+    int set_config(tbx_engine* e, const void* pod) override
+    {
+        tbx_gridworld_config_t k;
+        memcpy(&k, pod, sizeof k);
+        TBX_HIP(hipStreamSynchronize(e->stream));     // kernels in flight still read the old table
+        return load_cfg(e, k);
+    }
+
+    static dim3 wave_grid(int count) { return dim3((count + TBX_WAVES_PER_BLOCK - 1) / TBX_WAVES_PER_BLOCK); }
+
+    int new_game(tbx_engine* e, const uint8_t* mask_dev, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(gw_new_game_kernel, wave_grid(e->n), dim3(TBX_BLOCK), 0, s, d, mask_dev);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
+    {
+        int first = 0, count = e->n;
+        if (src.single_env >= 0) { first = src.single_env; count = 1; }
+        hipLaunchKernelGGL(gw_step_kernel, dim3((count + 127) / 128), dim3(128), 0, s, d, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int agent_reset_envs(tbx_engine* e, const AgentResetArgs& r, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(gw_agent_reset_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, r);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
+    {
+        switch (channels) {
+        case 1: hipLaunchKernelGGL(gw_render_kernel<1>, wave_grid(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        case 3: hipLaunchKernelGGL(gw_render_kernel<3>, wave_grid(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        case 4: hipLaunchKernelGGL(gw_render_kernel<4>, wave_grid(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+        }
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int pack_state(tbx_engine* e, int env, int count, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(gw_pack_kernel, dim3(count), dim3(64), 0, s, d, env, (tbx_gridworld_state_t*)e->staging);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int unpack_state(tbx_engine* e, int env, int count, const void* pod_host, hipStream_t s) override
+    {
+        const auto* sts = (const tbx_gridworld_state_t*)pod_host;
+        for (int i = 0; i < count; i++) {
+            int rc = check_dims(e, sts[i].width, sts[i].height, sts[i].n_tiles);
+            if (rc) return rc;
+        }
+        TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof(tbx_gridworld_state_t) * (size_t)count, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(gw_unpack_kernel, dim3(count), dim3(64), 0, s, d, env, (const tbx_gridworld_state_t*)e->staging);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int scalars(tbx_engine* e, int32_t* score_dev, int32_t* lives_dev, int32_t* level_dev, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(gw_scalars_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, score_dev, lives_dev, level_dev);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+};
+
+}  // namespace
+
+GameOps* tbx_make_gridworld_ops() { return new GridWorldOps(); }

@@ -97,12 +97,13 @@ __host__ __device__ __forceinline__ uint32_t tbx_ale_buttons(int a)
 
 __host__ __device__ __forceinline__ int tbx_legal_count(int game)
 {
-    return game == TBX_GAME_BREAKOUT ? 4 : 6;
+    return game == TBX_GAME_BREAKOUT ? 4 : game == TBX_GAME_GRIDWORLD ? 5 : 6;
 }
 __host__ __device__ __forceinline__ int tbx_legal_action(int game, int i)
 {
-    // Breakout [0,1,3,4]; Amidar [0..5]; SpaceInvaders [0,1,3,4,11,12]
+    // Breakout [0,1,3,4]; Amidar [0..5]; SpaceInvaders [0,1,3,4,11,12]; GridWorld [0,2,3,4,5]
     if (game == TBX_GAME_BREAKOUT) return i == 0 ? 0 : i == 1 ? 1 : i == 2 ? 3 : 4;
+    if (game == TBX_GAME_GRIDWORLD) return i == 0 ? 0 : i + 1;
     if (game == TBX_GAME_AMIDAR) return i;
     return i == 0 ? 0 : i == 1 ? 1 : i == 2 ? 3 : i == 3 ? 4 : i == 4 ? 11 : 12;
 }
@@ -208,3 +209,4 @@ void tbx_agent_free(tbx_engine* e);
 GameOps* tbx_make_breakout_ops();
 GameOps* tbx_make_si_ops();
 GameOps* tbx_make_amidar_ops();
+GameOps* tbx_make_gridworld_ops();

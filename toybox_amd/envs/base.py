@@ -156,6 +156,15 @@ class SpaceInvadersEnv(ToyboxBaseEnv):
                          grayscale=grayscale, alpha=alpha)
 
 
+class GridWorldEnv(ToyboxBaseEnv):
+    """envs/atari/gridworld.py:8-13 (frameskip (0, 0) there; neither exported nor gym-registered by the reference)."""
+    game_name = "gridworld"
+
+    def __init__(self, frameskip=(0, 0), repeat_action_probability=0.0, grayscale=True, alpha=False):
+        super().__init__(Toybox("gridworld", grayscale), "gridworld", frameskip, repeat_action_probability,
+                         grayscale=grayscale, alpha=alpha)
+
+
 ENV_IDS = {
     # gym ids of the reference (toybox/__init__.py:8-24)
     "BreakoutToyboxNoFrameskip-v4": BreakoutEnv,

@@ -18,7 +18,7 @@ from .engine import Engine
 from .games import codec
 
 GAME_ALIASES = {"breakout": "breakout", "amidar": "amidar", "space_invaders": "space_invaders",
-                "spaceinvaders": "space_invaders"}
+                "spaceinvaders": "space_invaders", "gridworld": "gridworld"}
 
 _engine_factory = None
 
