@@ -39,6 +39,31 @@ struct PixBytes<1> {
     }
 };
 
+// a palette colour in the form put4p() takes: the gray byte for C == 1, RGBA otherwise (convert once, not per pixel)
+template <int C>
+__device__ __forceinline__ uint32_t pix_of(uint32_t rgba) { return C == 1 ? gray_of(rgba) : rgba; }
+
+// rows [a, b) of a frame as bits of 64-row word k (rows outside 0..255 fall away)
+__device__ __forceinline__ uint64_t row_range_bits(long a, long b, int k)
+{
+    const long lo = a > 64L * k ? a : 64L * k, hi = b < 64L * k + 64 ? b : 64L * k + 64;
+    if (hi <= lo) return 0ull;
+    const int n = (int)(hi - lo), sh = (int)(lo - 64L * k);
+    return (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << sh;
+}
+
+// R consecutive row bits starting at row `pos` of a 256-row mask held as four wave-uniform words
+template <int R>
+__device__ __forceinline__ uint32_t row_mask_chunk(const uint64_t (&m)[4], int pos)
+{
+    const int w = pos >> 6, b = pos & 63;
+    const uint64_t cur = w == 0 ? m[0] : w == 1 ? m[1] : w == 2 ? m[2] : m[3];
+    const uint64_t nxt = w == 0 ? m[1] : w == 1 ? m[2] : w == 2 ? m[3] : 0ull;
+    uint64_t v = cur >> b;
+    if (b > 64 - R) v |= nxt << (64 - b);
+    return (uint32_t)v & ((1u << R) - 1u);
+}
+
 // W: frame width (multiple of 4), C: channels, R: scanlines per unit.
 template <int C, int W, int R>
 struct RowStager {
@@ -53,6 +78,43 @@ struct RowStager {
     __device__ __forceinline__ void put4(int row_in_unit, int group, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) const
     {
         PixBytes<C>::write(lds + row_in_unit * ROW_BYTES + group * 4 * C, c0, c1, c2, c3);
+    }
+
+    // the same for colours that went through pix_of<C>() already
+    __device__ __forceinline__ void put4p(int row_in_unit, int group, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) const
+    {
+        if (C == 1)
+            *reinterpret_cast<uint32_t*>(lds + row_in_unit * ROW_BYTES + group * 4) = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        else
+            PixBytes<C>::write(lds + row_in_unit * ROW_BYTES + group * 4 * C, c0, c1, c2, c3);
+    }
+
+    // a whole unit of one colour (already through pix_of<C>()) straight to dst, without staging.  RGB: the byte stream
+    // has period 3, a 16-byte chunk c starts at phase c % 3 and holds the dwords d[ph], d[ph+1], d[ph+2], d[ph]
+    static __device__ __forceinline__ void fill_unit(uint8_t* dst, int lane, uint32_t p)
+    {
+        uint4* out = reinterpret_cast<uint4*>(dst);
+        constexpr int chunks = UNIT_BYTES / 16;
+        if (C == 3) {
+            const uint32_t q = p & 0xFFFFFFu;
+            const uint32_t d0 = q | (q << 24), d1 = (q >> 8) | (q << 16), d2 = (q >> 16) | (q << 8);
+            const int ph0 = lane % 3;
+#pragma unroll
+            for (int i = 0; i < (chunks + 63) / 64; i++) {
+                const int c = lane + 64 * i;
+                const int ph = (ph0 + i) % 3;               // (lane + 64 i) % 3
+                const uint4 v = ph == 0 ? make_uint4(d0, d1, d2, d0) : ph == 1 ? make_uint4(d1, d2, d0, d1) : make_uint4(d2, d0, d1, d2);
+                if (c < chunks) out[c] = v;
+            }
+        } else {
+            const uint32_t q = C == 1 ? p * 0x01010101u : (p | 0xFF000000u);
+            const uint4 v = make_uint4(q, q, q, q);
+#pragma unroll
+            for (int i = 0; i < (chunks + 63) / 64; i++) {
+                const int c = lane + 64 * i;
+                if (c < chunks) out[c] = v;
+            }
+        }
     }
 
     // write `rows` staged scanlines to dst (16-byte aligned, contiguous)

@@ -625,11 +625,18 @@ __device__ __forceinline__ void paint_span(uint32_t (&px)[NG][4], const int (&gx
 // (320 px = 80 groups); entities intersecting the scanline are found by ballot over lanes
 // (lane = enemy / shield row / laser slot) and painted in the checker's order.
 template <int C>
-__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count)
+__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank)
 {
     constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = 2;
     using Stager = RowStager<C, W, SI_UNIT_ROWS>;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
+    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][8];
+    __shared__ uint32_t spr_lds[3 * TBX_SI_ENEMY_H];        // enemy sprite rows: pose A, pose B, explosion
+    if (threadIdx.x < 3 * TBX_SI_ENEMY_H) {
+        const int t = threadIdx.x;
+        spr_lds[t] = t < TBX_SI_ENEMY_H ? SI_SPR_A[t] : t < 2 * TBX_SI_ENEMY_H ? SI_SPR_B[t - TBX_SI_ENEMY_H] : SI_SPR_BOOM[t - 2 * TBX_SI_ENEMY_H];
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
@@ -676,14 +683,17 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
                 }
         }
     }
-    const uint32_t c_enemy = rgb_u32(TBX_SI_COL_ENEMY), c_ufo = rgb_u32(TBX_SI_COL_UFO), c_ground = rgb_u32(TBX_SI_COL_GROUND);
-    const uint32_t c_hud = rgb_u32(TBX_SI_COL_HUD);
+    // every colour goes through pix_of<C>() once here; the scanline loop only moves finished pixel values
+    const uint32_t c_enemy = pix_of<C>(rgb_u32(TBX_SI_COL_ENEMY)), c_ufo = pix_of<C>(rgb_u32(TBX_SI_COL_UFO));
+    const uint32_t c_ground = pix_of<C>(rgb_u32(TBX_SI_COL_GROUND)), c_hud = pix_of<C>(rgb_u32(TBX_SI_COL_HUD));
+    const uint32_t c_black = pix_of<C>(0xFF000000u), c_ship = pix_of<C>((uint32_t)f[F_SHIP_COLOR]);
+    const uint32_t l_col = pix_of<C>((uint32_t)s.lf[LF_COLOR]);
     const bool ufo_on = f[F_UFO_APP] == 0 || f[F_UFO_DC] >= 0;
     const int sk = lane / TBX_SI_SHIELD_H, sr = lane - sk * TBX_SI_SHIELD_H;
     const bool s_valid = lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H && sk < f[F_N_SHIELDS];
     const int s_x = sk == 0 ? f[F_SHIELD_X0] : sk == 1 ? f[F_SHIELD_X1] : f[F_SHIELD_X2];
     const int s_y = (sk == 0 ? f[F_SHIELD_Y0] : sk == 1 ? f[F_SHIELD_Y1] : f[F_SHIELD_Y2]) + sr;
-    const uint32_t s_c = (uint32_t)(sk == 0 ? f[F_SHIELD_C0] : sk == 1 ? f[F_SHIELD_C1] : f[F_SHIELD_C2]);
+    const uint32_t s_c = pix_of<C>((uint32_t)(sk == 0 ? f[F_SHIELD_C0] : sk == 1 ? f[F_SHIELD_C1] : f[F_SHIELD_C2]));
     const bool e_vis = lane < ne && (e_alive(s) || e_dc(s) >= 0);
     // scanline ranges that can contain enemies / shields / lasers at all (wave-uniform), so that most scanlines
     // skip the ballots
@@ -701,17 +711,69 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
     }
     e_y0 = wave_uniform(e_y0); e_y1 = wave_uniform(e_y1); s_y0 = wave_uniform(s_y0); s_y1 = wave_uniform(s_y1);
 
+    // per pixel group: the visible enemies whose columns overlap it (bit e), and per enemy lane its sprite table base
+    uint64_t cand[NG] = {0ull, 0ull};
+    for (uint64_t m = __ballot(e_vis); m; m &= m - 1) {
+        const int e = (int)__builtin_ctzll(m);
+        const int ex = __builtin_amdgcn_readlane(s.ex, e);
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+            if (gx[g] + 3 >= ex && gx[g] < ex + TBX_SI_ENEMY_W) cand[g] |= 1ull << e;
+    }
+    const int e_tab = (s.estatus & 1) ? (f[F_ORIENT] ? 0 : TBX_SI_ENEMY_H) : 2 * TBX_SI_ENEMY_H;
+
+    // Which scanlines show anything but the black background: every lane ORs the rows of the entities it holds (enemy,
+    // shield row, laser) into the wave's 256-bit mask in LDS; ufo, ship, HUD and ground come from wave-uniform fields.
+    uint64_t busy[4];
+    {
+        uint32_t* bm = lds_mask[wave];
+        if (lane < 8) bm[lane] = 0u;
+        const long ly0 = s.lf[LF_Y];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint64_t w = 0;
+            if (e_vis) w |= row_range_bits(s.ey, (long)s.ey + TBX_SI_ENEMY_H, k);
+            if (s_valid && s.srow != 0) w |= row_range_bits(s_y, (long)s_y + 1, k);
+            if (l_on) w |= row_range_bits(ly0, ly0 + s.lf[LF_H], k);
+            if (lane == 0) {
+                w |= row_range_bits(2, 12, k) | row_range_bits(TBX_SI_GROUND_Y, TBX_SI_GROUND_Y + 1, k);
+                if (ufo_on) w |= row_range_bits(f[F_UFO_Y], (long)f[F_UFO_Y] + TBX_SI_UFO_H, k);
+                if ((f[F_SHIP_FLAGS] & 1) || f[F_SHIP_DC] >= 0) w |= row_range_bits(f[F_SHIP_Y], (long)f[F_SHIP_Y] + TBX_SI_SHIP_H, k);
+            }
+            if ((uint32_t)w) atomicOr(&bm[2 * k], (uint32_t)w);
+            if ((uint32_t)(w >> 32)) atomicOr(&bm[2 * k + 1], (uint32_t)(w >> 32));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(bm[2 * k]), hi = __builtin_amdgcn_readfirstlane(bm[2 * k + 1]);
+            busy[k] = (uint64_t)lo | ((uint64_t)hi << 32);
+        }
+    }
+
     uint8_t* frame = out + (size_t)rel * H * W * C;
     constexpr int NUNITS = H / SI_UNIT_ROWS;
     const int u0 = (int)(((uint32_t)env * 11u) % (uint32_t)NUNITS);
     for (int k = 0; k < NUNITS; k++) {
         int u = u0 + k;
         if (u >= NUNITS) u -= NUNITS;
+        const uint32_t rows_busy = skip_blank ? row_mask_chunk<SI_UNIT_ROWS>(busy, u * SI_UNIT_ROWS) : (1u << SI_UNIT_ROWS) - 1u;
+        if (rows_busy == 0 && C != 4) {                      // nothing but background: no staging (for RGBA the
+            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, c_black);   // staged path measured faster)
+            continue;
+        }
 #pragma unroll 1
         for (int r = 0; r < SI_UNIT_ROWS; r++) {
             const int y = u * SI_UNIT_ROWS + r;
+            if (!((rows_busy >> r) & 1u)) {
+#pragma unroll
+                for (int g = 0; g < NG; g++)
+                    if (gact[g]) st.put4p(r, lane + 64 * g, c_black, c_black, c_black, c_black);
+                continue;
+            }
             uint32_t px[NG][4];
-            const uint32_t base = y == TBX_SI_GROUND_Y ? c_ground : 0xFF000000u;
+            const uint32_t base = y == TBX_SI_GROUND_Y ? c_ground : c_black;
 #pragma unroll
             for (int g = 0; g < NG; g++)
 #pragma unroll
@@ -725,25 +787,34 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
                     paint_bits<NG>(px, gx, __shfl(s_x, src), __shfl(s.srow, src), TBX_SI_SHIELD_W, __shfl(s_c, src));
                 }
             }
-            // enemies in index order
+            // enemies in index order: each lane walks the (usually one) enemy that overlaps its pixel group and this scanline
             if (y >= e_y0 && y < e_y1) {
-                uint64_t m = __ballot(e_vis && y >= s.ey && y < s.ey + TBX_SI_ENEMY_H);
-                while (m) {
-                    const int src = (int)__builtin_ctzll(m);
-                    m &= m - 1;
-                    const int ey = __builtin_amdgcn_readlane(s.ey, src);
-                    const int st_ = __builtin_amdgcn_readlane(s.estatus, src);
-                    const uint32_t* spr = (st_ & 1) ? (f[F_ORIENT] ? SI_SPR_A : SI_SPR_B) : SI_SPR_BOOM;
-                    paint_bits<NG>(px, gx, __builtin_amdgcn_readlane(s.ex, src), spr[y - ey], TBX_SI_ENEMY_W, c_enemy);
+                const uint64_t ym = __ballot(e_vis && y >= s.ey && y < s.ey + TBX_SI_ENEMY_H);
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    uint64_t c = cand[g] & ym;
+                    while (__ballot(c != 0)) {
+                        const bool on = c != 0;
+                        const int e = on ? (int)__builtin_ctzll(c) : 0;
+                        const int ex = __shfl(s.ex, e), ey = __shfl(s.ey, e), tab = __shfl(e_tab, e);
+                        if (on) {
+                            const uint32_t bits = spr_lds[tab + (y - ey)] & ((1u << TBX_SI_ENEMY_W) - 1u);
+                            const uint32_t four = ((bits << 4) >> (gx[g] - ex + 4)) & 15u;    // shift in [1, 19]
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                if ((four >> i) & 1u) px[g][i] = c_enemy;
+                            c &= c - 1;
+                        }
+                    }
                 }
             }
             if (ufo_on && y >= f[F_UFO_Y] && y < f[F_UFO_Y] + TBX_SI_UFO_H)
                 paint_bits<NG>(px, gx, f[F_UFO_X], SI_SPR_UFO[y - f[F_UFO_Y]], TBX_SI_UFO_W, c_ufo);
             if (y >= f[F_SHIP_Y] && y < f[F_SHIP_Y] + TBX_SI_SHIP_H) {
                 const int ry = y - f[F_SHIP_Y];
-                if (f[F_SHIP_FLAGS] & 1) paint_bits<NG>(px, gx, f[F_SHIP_X], SI_SPR_SHIP[ry], 16, (uint32_t)f[F_SHIP_COLOR]);
+                if (f[F_SHIP_FLAGS] & 1) paint_bits<NG>(px, gx, f[F_SHIP_X], SI_SPR_SHIP[ry], 16, c_ship);
                 else if (f[F_SHIP_DC] >= 0)
-                    paint_bits<NG>(px, gx, f[F_SHIP_X], (f[F_SHIP_FLAGS] & 2) ? SI_SPR_D1[ry] : SI_SPR_D2[ry], 16, (uint32_t)f[F_SHIP_COLOR]);
+                    paint_bits<NG>(px, gx, f[F_SHIP_X], (f[F_SHIP_FLAGS] & 2) ? SI_SPR_D1[ry] : SI_SPR_D2[ry], 16, c_ship);
             }
             // lasers: the ship's first, then enemy lasers in slot order
             if (y >= l_lo && y < l_hi) {
@@ -751,14 +822,14 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
                 uint64_t m = __ballot(l_on && y >= ly0 && y < ly1);
                 if ((m >> SHIP_SLOT) & 1) {
                     const Laser l = get_laser(s, SHIP_SLOT);
-                    paint_span<NG>(px, gx, l.x, (long)l.x + l.w, (uint32_t)l.color);
+                    paint_span<NG>(px, gx, l.x, (long)l.x + l.w, __shfl(l_col, SHIP_SLOT));
                 }
                 m &= (1ull << SHIP_SLOT) - 1;
                 while (m) {
                     const int src = (int)__builtin_ctzll(m);
                     m &= m - 1;
                     const long lx = __shfl(s.lf[LF_X], src), lw = __shfl(s.lf[LF_W], src);
-                    paint_span<NG>(px, gx, lx, lx + lw, (uint32_t)__shfl(s.lf[LF_COLOR], src));
+                    paint_span<NG>(px, gx, lx, lx + lw, __shfl(l_col, src));
                 }
             }
             if (y >= 2 && y < 12) {
@@ -771,7 +842,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
             }
 #pragma unroll
             for (int g = 0; g < NG; g++)
-                if (gact[g]) st.put4(r, lane + 64 * g, px[g][0], px[g][1], px[g][2], px[g][3]);
+                if (gact[g]) st.put4p(r, lane + 64 * g, px[g][0], px[g][1], px[g][2], px[g][3]);
         }
         st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
     }
@@ -971,10 +1042,11 @@ struct SiOps : GameOps {
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
     {
+        static const int skip_blank = getenv("TBX_SI_NO_SKIP") ? 0 : 1;   // diagnostic A/B switch
         switch (channels) {
-        case 1: hipLaunchKernelGGL(si_render_kernel<1>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
-        case 3: hipLaunchKernelGGL(si_render_kernel<3>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
-        case 4: hipLaunchKernelGGL(si_render_kernel<4>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        case 1: hipLaunchKernelGGL(si_render_kernel<1>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank); break;
+        case 3: hipLaunchKernelGGL(si_render_kernel<3>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank); break;
+        case 4: hipLaunchKernelGGL(si_render_kernel<4>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
         TBX_HIP(hipGetLastError());
