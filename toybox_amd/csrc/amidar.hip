@@ -666,6 +666,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
     constexpr int W = TBX_AMI_W, H = TBX_AMI_H;
     using Stager = RowStager<C, W, AMI_UNIT_ROWS>;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
+    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][8];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
@@ -729,32 +730,70 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
         }
     }
 
+    // palette through pix_of<C>() once; the scanline loop only moves finished pixel values
+    const uint32_t c_bg = pix_of<C>(t.bg), c_inner = pix_of<C>(t.inner), c_painted = pix_of<C>(t.painted);
+    const uint32_t c_unpainted = pix_of<C>(t.unpainted), c_enemy = pix_of<C>(t.enemy), c_player = pix_of<C>(t.player);
+
+    // scanlines crossed by a mover: every mover lane ORs its rows into the wave's 256-bit mask in LDS
+    uint64_t mv_rows[4];
+    {
+        uint32_t* bm = lds_mask[wave];
+        if (lane < 8) bm[lane] = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t w = m_on ? row_range_bits(m_y0, (long)m_y0 + TBX_AMI_MOVER_H, k) : 0ull;
+            if ((uint32_t)w) atomicOr(&bm[2 * k], (uint32_t)w);
+            if ((uint32_t)(w >> 32)) atomicOr(&bm[2 * k + 1], (uint32_t)(w >> 32));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(bm[2 * k]), hi = __builtin_amdgcn_readfirstlane(bm[2 * k + 1]);
+            mv_rows[k] = (uint64_t)lo | ((uint64_t)hi << 32);
+        }
+    }
+
     uint8_t* frame = out + (size_t)rel * H * W * C;
     constexpr int NUNITS = H / AMI_UNIT_ROWS;
+    constexpr int BOARD_Y1 = TBX_AMI_BOARD_OY + BH * TBX_AMI_TILE_PH;
     const int u0 = (int)(((uint32_t)env * 7u) % (uint32_t)NUNITS);
+    int ty_cached = -1;
+    uint32_t board_col = c_bg;                               // this lane's tile colour in tile row ty_cached
     for (int k = 0; k < NUNITS; k++) {
         int u = u0 + k;
         if (u >= NUNITS) u -= NUNITS;
+        const int y_first = u * AMI_UNIT_ROWS;
+        const uint32_t mv_chunk = row_mask_chunk<AMI_UNIT_ROWS>(mv_rows, y_first);
+        const bool board_unit = y_first + AMI_UNIT_ROWS > TBX_AMI_BOARD_OY && y_first < BOARD_Y1;
+        const bool hud_unit = y_first + AMI_UNIT_ROWS > TBX_AMI_HUD_Y && y_first < TBX_AMI_HUD_Y + 10;
+        if (!board_unit && !hud_unit && mv_chunk == 0 && C != 4) {   // background only: no staging (RGBA: staged is faster)
+            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, c_bg);
+            continue;
+        }
 #pragma unroll 1
         for (int r = 0; r < AMI_UNIT_ROWS; r++) {
-            const int y = u * AMI_UNIT_ROWS + r;
-            uint32_t px[4] = {t.bg, t.bg, t.bg, t.bg};
+            const int y = y_first + r;
+            uint32_t px[4] = {c_bg, c_bg, c_bg, c_bg};
             const int by = y - TBX_AMI_BOARD_OY;
             if (by >= 0 && by < BH * TBX_AMI_TILE_PH) {
                 const int ty = by / TBX_AMI_TILE_PH;
-                const uint64_t row = row_of(s, ty);
-                const uint32_t inn = __shfl(inner, ty);
-                if (in_board_x) {
-                    const int tag = (int)((row >> (2 * tx)) & 3ull);
-                    uint32_t col = t.bg;
-                    if (tag == TBX_TILE_EMPTY) { if ((inn >> tx) & 1u) col = t.inner; }
-                    else col = tag == TBX_TILE_PAINTED ? t.painted : t.unpainted;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) px[i] = col;
+                if (ty != ty_cached) {                       // five scanlines share a tile row
+                    ty_cached = ty;
+                    const uint64_t row = row_of(s, ty);
+                    const uint32_t inn = __shfl(inner, ty);
+                    board_col = c_bg;
+                    if (in_board_x) {
+                        const int tag = (int)((row >> (2 * tx)) & 3ull);
+                        if (tag == TBX_TILE_EMPTY) { if ((inn >> tx) & 1u) board_col = c_inner; }
+                        else board_col = tag == TBX_TILE_PAINTED ? c_painted : c_unpainted;
+                    }
                 }
+#pragma unroll
+                for (int i = 0; i < 4; i++) px[i] = board_col;
             }
             // movers: enemies in index order, then the player
-            {
+            if ((mv_chunk >> r) & 1u) {
                 uint64_t m = __ballot(m_on && y >= m_y0 && y < m_y0 + TBX_AMI_MOVER_H);
                 const bool player_here = (m >> PLAYER_SLOT) & 1;
                 m &= (1ull << PLAYER_SLOT) - 1;
@@ -764,22 +803,22 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
                     const int sx = __shfl(m_x0, src);
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = t.enemy;
+                        if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = c_enemy;
                 }
                 if (player_here) {
                     const int sx = __shfl(m_x0, PLAYER_SLOT);
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = t.player;
+                        if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = c_player;
                 }
             }
             if (y >= TBX_AMI_HUD_Y && y < TBX_AMI_HUD_Y + 10) {
                 const int gr = ((y - TBX_AMI_HUD_Y) >> 1) * 3;
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    if ((hud[i] >> gr) & 1u) px[i] = t.player;
+                    if ((hud[i] >> gr) & 1u) px[i] = c_player;
             }
-            if (active) st.put4(r, lane, px[0], px[1], px[2], px[3]);
+            if (active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
         }
         st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
     }

@@ -874,6 +874,25 @@ __device__ __forceinline__ void overlay4(uint32_t (&px)[4], int x0, int rx0, int
     }
 }
 
+// sets bits y0..y1-1 (clipped to 0..159) of a 160-bit row mask
+__device__ __forceinline__ void brk_mark_rows(uint64_t (&m)[3], int y0, int y1)
+{
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+        const int lo = max(y0 - 64 * w, 0), hi = min(y1 - 64 * w, 64);
+        if (hi > lo) m[w] |= (hi - lo >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+    }
+}
+
+__device__ __forceinline__ void brk_overlay_rows(const BrkRenderRec& rec, uint64_t (&m)[3])
+{
+#pragma unroll
+    for (int k = 0; k < 1 + MAXB; k++) {
+        const uint32_t rc = k == 0 ? rec.paddle : rec.ball[k - 1];
+        if ((rc & 255u) < ((rc >> 8) & 255u)) brk_mark_rows(m, (int)((rc >> 16) & 255u), (int)(rc >> 24));
+    }
+}
+
 // colours and wall geometry the rasteriser needs from the config
 struct BrkPalette {
     uint32_t bg, frame, paddle, ball;
@@ -903,11 +922,13 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
     const int x0 = lane * 4;
     const bool active = x0 < W;
     const int rows = pal.rows;
+    // palette through pix_of<C>() once; the scanline loop only moves finished pixel values
+    const uint32_t c_bg = pix_of<C>(pal.bg), c_frame = pix_of<C>(pal.frame), c_paddle = pix_of<C>(pal.paddle), c_ball = pix_of<C>(pal.ball);
 
     // per-lane base pattern of a side-wall row
     uint32_t side[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) side[i] = (x0 + i < 12 || x0 + i >= 228) ? pal.frame : pal.bg;
+    for (int i = 0; i < 4; i++) side[i] = (x0 + i < 12 || x0 + i >= 228) ? c_frame : c_bg;
     // per-lane HUD slots: which glyph (0..6, 7 = none) and which glyph column covers pixel x0+i
     uint32_t hud_sel[4];
 #pragma unroll
@@ -944,6 +965,11 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
         }
         uint32_t brick4[4] = {0, 0, 0, 0};
         int brick_row_cached = -1;
+        // scanlines of this unit crossed by the paddle or a ball
+        uint64_t ov[3] = {0ull, 0ull, 0ull};
+        brk_overlay_rows(rec, ov);
+        const int ow = y_first >> 6, ob = y_first & 63;      // units are 8 rows at multiples of 8: never straddle a word
+        const uint32_t ov_chunk = (uint32_t)((ow == 0 ? ov[0] : ow == 1 ? ov[1] : ov[2]) >> ob) & ((1u << BRK_UNIT_ROWS) - 1u);
 
 #pragma unroll 1
         for (int r = 0; r < BRK_UNIT_ROWS; r++) {
@@ -951,10 +977,10 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
             uint32_t px[4];
             if (y < TBX_BRK_WALL_Y0) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) px[i] = pal.bg;
+                for (int i = 0; i < 4; i++) px[i] = c_bg;
             } else if (y < TBX_BRK_WALL_Y0 + 12) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) px[i] = pal.frame;
+                for (int i = 0; i < 4; i++) px[i] = c_frame;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; i++) px[i] = side[i];
@@ -966,7 +992,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
                     const int row = by >> 2;
                     if (row != brick_row_cached) {
                         brick_row_cached = row;
-                        const uint32_t rc = pal.row_colors[row];
+                        const uint32_t rc = pix_of<C>(pal.row_colors[row]);
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             brick4[i] = side[i];
@@ -992,7 +1018,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
                     if (j < n_bricks && ((rec.alive[kk] >> lane) & 1ull)) {
                         const int ry0 = f2i(t.y[j]), rh = f2i(t.h[j]);
                         on = y >= ry0 && y < ry0 + rh;
-                        rx0 = f2i(t.x[j]); rw = f2i(t.w[j]); rc = t.color[j];
+                        rx0 = f2i(t.x[j]); rw = f2i(t.w[j]); rc = pix_of<C>(t.color[j]);
                     }
                     uint64_t m = __ballot(on);
                     while (m) {   // ascending brick index == the oracle's paint order
@@ -1003,17 +1029,19 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
                 }
             }
             // paddle, balls
-            overlay_rect(px, x0, y, rec.paddle, pal.paddle);
+            if ((ov_chunk >> r) & 1u) {
+                overlay_rect(px, x0, y, rec.paddle, c_paddle);
 #pragma unroll
-            for (int b = 0; b < MAXB; b++) overlay_rect(px, x0, y, rec.ball[b], pal.ball);
+                for (int b = 0; b < MAXB; b++) overlay_rect(px, x0, y, rec.ball[b], c_ball);
+            }
             // HUD
             if (y >= 2 && y < 12) {
                 const int gr = ((y - 2) >> 1) * 3;
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    if ((hud[i] >> gr) & 1u) px[i] = pal.frame;
+                    if ((hud[i] >> gr) & 1u) px[i] = c_frame;
             }
-            if (active) st.put4(r, lane, px[0], px[1], px[2], px[3]);
+            if (active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
         }
         st.flush(dst, lane);
     }
@@ -1035,25 +1063,6 @@ struct BrkGrayPal {
     uint32_t row[TBX_BRK_MAX_ROWS];
     uint64_t boundary[3];               // bit y: scanline y may differ from y-1 even without moving objects
 };
-
-// sets bits y0..y1-1 (clipped to 0..159) of a 160-bit row mask
-__device__ __forceinline__ void brk_mark_rows(uint64_t (&m)[3], int y0, int y1)
-{
-#pragma unroll
-    for (int w = 0; w < 3; w++) {
-        const int lo = max(y0 - 64 * w, 0), hi = min(y1 - 64 * w, 64);
-        if (hi > lo) m[w] |= (hi - lo >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
-    }
-}
-
-__device__ __forceinline__ void brk_overlay_rows(const BrkRenderRec& rec, uint64_t (&m)[3])
-{
-#pragma unroll
-    for (int k = 0; k < 1 + MAXB; k++) {
-        const uint32_t rc = k == 0 ? rec.paddle : rec.ball[k - 1];
-        if ((rc & 255u) < ((rc >> 8) & 255u)) brk_mark_rows(m, (int)((rc >> 16) & 255u), (int)(rc >> 24));
-    }
-}
 
 struct BrkLineCache { int row; uint32_t dw; };
 

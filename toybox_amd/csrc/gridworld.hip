@@ -219,9 +219,9 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* 
     const int tw = W / gw, th = H / gh;
     const int px = wave_uniform(d.sc[G_PX * N + env]), py = wave_uniform(d.sc[G_PY * N + env]);
     const int nt = wave_uniform(d.sc[G_NT * N + env]);
-    const uint32_t pcol = (uint32_t)wave_uniform(d.sc[G_PCOL * N + env]);
-    const uint32_t black = 0xFF000000u;
-    const uint32_t tcol = (lane < GT && lane < nt) ? d.tiles[((size_t)env * GT + lane) * 3] : black;
+    const uint32_t pcol = pix_of<C>((uint32_t)wave_uniform(d.sc[G_PCOL * N + env]));
+    const uint32_t black = pix_of<C>(0xFF000000u);
+    const uint32_t tcol = (lane < GT && lane < nt) ? pix_of<C>(d.tiles[((size_t)env * GT + lane) * 3]) : black;
     const uint8_t* g = d.grid + (size_t)env * CELLS;
     const bool active = lane < W / 4;
     int cx[4];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* 
                     c[k] = !inside ? black : (cx[k] == px && cy == py) ? pcol : id < GT ? tc : black;
                 }
             }
-            if (active) st.put4(r, lane, c[0], c[1], c[2], c[3]);
+            if (active) st.put4p(r, lane, c[0], c[1], c[2], c[3]);
         }
         st.flush(dst + (size_t)unit * Stager::UNIT_BYTES, lane);
     }
