@@ -106,36 +106,76 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
     const bool on0 = lane < ow, on1 = lane + 64 < ow;
     if (lane < 8) reinterpret_cast<uint32_t*>(row)[80 + lane] = 0u;   // padding read by the 12-byte windows
 
-    uint32_t acc0[2] = {0, 0}, acc1[2] = {0, 0};        // [column slot]: current / next output row
-    for (int sy = 0; sy < H; sy++) {
-        for (int w4 = lane; w4 < words; w4 += 64) {
-            const uint32_t b = *reinterpret_cast<const uint32_t*>(fb + (size_t)sy * W + 4 * w4);
-            uint32_t v = b;
-            if (!fresh) v = bytemax4(*reinterpret_cast<const uint32_t*>(fa + (size_t)sy * W + 4 * w4), b);
-            reinterpret_cast<uint32_t*>(row)[w4] = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // vertical split of this source row (extent oh in refined units) over output rows oy and oy+1 (extent H each)
-        const int oy = (sy * oh) / H;
-        const int top = (oy + 1) * H;
-        const int w_cur = min((sy + 1) * oh, top) - sy * oh, w_next = oh - w_cur;
-        const uint32_t h0 = on0 ? hsum(row, c0) : 0u, h1 = on1 ? hsum(row, c1) : 0u;
-        acc0[0] += (uint32_t)w_cur * h0; acc0[1] += (uint32_t)w_cur * h1;
-        acc1[0] += (uint32_t)w_next * h0; acc1[1] += (uint32_t)w_next * h1;
-        __builtin_amdgcn_wave_barrier();
-        if ((sy + 1) * oh >= top) {                      // output row oy is complete
+    // The kernel is bound by the latency of re-reading the two gray frames, so source rows are fetched PF at a time, one
+    // group ahead of the group being reduced, and the frame-stack word of the NEXT output row is fetched while the
+    // current one accumulates (S == 4; other depths roll byte-wise in stack_push).
+    constexpr int PF = 4;
+    uint32_t cur_a[PF][2], cur_b[PF][2], nxt_a[PF][2], nxt_b[PF][2];
+    auto fetch = [&](int sy0, uint32_t (&va)[PF][2], uint32_t (&vb)[PF][2]) {
+#pragma unroll
+        for (int p = 0; p < PF; p++)
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                const int ox = lane + 64 * q;
-                if (q == 0 ? on0 : on1) {
-                    // (sum + area/2) / area by multiply-shift; this kernel is bound by re-reading the two gray frames, so the
-                    // stack is rolled row by row (the record-based Breakout kernel stages it in LDS instead)
-                    stack_push<S>(o + ((size_t)oy * ow + ox) * S, (uint32_t)(((uint64_t)(acc0[q] + half) * magic) >> 42), fresh);
+                const int w4 = lane + 64 * q, sy = sy0 + p;
+                va[p][q] = 0u; vb[p][q] = 0u;
+                if (sy < H && w4 < words) {
+                    vb[p][q] = *reinterpret_cast<const uint32_t*>(fb + (size_t)sy * W + 4 * w4);
+                    if (!fresh) va[p][q] = *reinterpret_cast<const uint32_t*>(fa + (size_t)sy * W + 4 * w4);
                 }
-                acc0[q] = acc1[q];
-                acc1[q] = 0;
+            }
+    };
+    uint32_t old[2] = {0u, 0u};                          // stack words of the output row being accumulated
+    auto fetch_old = [&](int oy) {
+        if (S == 4 && !fresh && oy < oh) {
+            if (on0) old[0] = *reinterpret_cast<const uint32_t*>(o + ((size_t)oy * ow + lane) * 4);
+            if (on1) old[1] = *reinterpret_cast<const uint32_t*>(o + ((size_t)oy * ow + lane + 64) * 4);
+        }
+    };
+    fetch(0, cur_a, cur_b);
+    fetch_old(0);
+
+    uint32_t acc0[2] = {0, 0}, acc1[2] = {0, 0};        // [column slot]: current / next output row
+    for (int sy0 = 0; sy0 < H; sy0 += PF) {
+        fetch(sy0 + PF, nxt_a, nxt_b);
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            const int sy = sy0 + p;
+            if (sy >= H) break;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int w4 = lane + 64 * q;
+                if (w4 < words) reinterpret_cast<uint32_t*>(row)[w4] = fresh ? cur_b[p][q] : bytemax4(cur_a[p][q], cur_b[p][q]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // vertical split of this source row (extent oh in refined units) over output rows oy and oy+1 (extent H each)
+            const int oy = (sy * oh) / H;
+            const int top = (oy + 1) * H;
+            const int w_cur = min((sy + 1) * oh, top) - sy * oh, w_next = oh - w_cur;
+            const uint32_t h0 = on0 ? hsum(row, c0) : 0u, h1 = on1 ? hsum(row, c1) : 0u;
+            acc0[0] += (uint32_t)w_cur * h0; acc0[1] += (uint32_t)w_cur * h1;
+            acc1[0] += (uint32_t)w_next * h0; acc1[1] += (uint32_t)w_next * h1;
+            __builtin_amdgcn_wave_barrier();
+            if ((sy + 1) * oh >= top) {                  // output row oy is complete
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int ox = lane + 64 * q;
+                    if (q == 0 ? on0 : on1) {
+                        // (sum + area/2) / area by multiply-shift
+                        const uint32_t val = (uint32_t)(((uint64_t)(acc0[q] + half) * magic) >> 42);
+                        uint8_t* px = o + ((size_t)oy * ow + ox) * S;
+                        if (S == 4) *reinterpret_cast<uint32_t*>(px) = ((fresh ? 0u : old[q]) >> 8) | (val << 24);
+                        else stack_push<S>(px, val, fresh);
+                    }
+                    acc0[q] = acc1[q];
+                    acc1[q] = 0;
+                }
+                fetch_old(oy + 1);
             }
         }
+#pragma unroll
+        for (int p = 0; p < PF; p++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) { cur_a[p][q] = nxt_a[p][q]; cur_b[p][q] = nxt_b[p][q]; }
     }
 }
 
