@@ -906,7 +906,8 @@ struct BrkPalette {
 // 1 KiB-per-instruction stores.  Units are visited in an env-rotated order so that co-resident waves do not
 // march through the same frame offsets in lockstep.  Measured alternatives (scripts/ubench/): a persistent
 // grid over address-ordered units reaches 6.1 TB/s as bare stores but 4.7-4.9 TB/s with record loads and LDS
-// staging, against 5.2 TB/s for this form (hipMemset on the same box: 6.3 TB/s).
+// staging; one-shot address-ordered waves of 1, 2, 4 or 10 units each measured 5.3-5.5 TB/s against 5.5-5.9 TB/s for
+// this form in the same session (hipMemset on the same box: 6.3 TB/s).
 template <int C, bool CUSTOM>
 __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
                                                                BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count)
