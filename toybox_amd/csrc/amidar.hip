@@ -289,8 +289,8 @@ __device__ __forceinline__ void push_history(AmiRegs& s, int lane, int slot, int
     }
     if (lane == slot) {
 #pragma unroll
-        for (int i = 0; i < TBX_AMI_MAX_HISTORY; i++)
-            if (i == n) s.mv[M_HIST0 + i] = id;
+        for (int i = 0; i < TBX_AMI_MAX_HISTORY; i++)     // selects of values: an `if (i == n) a[i] = id` chain is folded
+            s.mv[M_HIST0 + i] = i == n ? id : s.mv[M_HIST0 + i];   // into a[n] = id, which sends the array to scratch
         s.mv[M_NHIST] = n + 1;
     }
 }

@@ -111,6 +111,9 @@ __device__ __forceinline__ void si_store(const SiDev& d, int env, int lane, cons
     }
 }
 
+// k == 0 ? a : k == 1 ? b : c over VALUES
+__device__ __forceinline__ int32_t sel3(int k, int32_t a, int32_t b, int32_t c) { return k == 0 ? a : k == 1 ? b : c; }
+
 __device__ __forceinline__ bool e_alive(const SiRegs& s) { return (s.estatus & 1) != 0; }
 __device__ __forceinline__ int e_dc(const SiRegs& s) { return (s.estatus >> 8) - 1; }
 __device__ __forceinline__ int32_t mk_status(bool alive, int dc) { return (alive ? 1 : 0) | ((dc + 1) << 8); }
@@ -216,8 +219,10 @@ __device__ __forceinline__ bool shield_hit(SiRegs& s, int lane, const Laser& l)
 {
     const int k = lane / TBX_SI_SHIELD_H, r = lane - k * TBX_SI_SHIELD_H;
     const bool valid = lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H && k < s.f[F_N_SHIELDS];
-    const int sx = k == 0 ? s.f[F_SHIELD_X0] : k == 1 ? s.f[F_SHIELD_X1] : s.f[F_SHIELD_X2];
-    const int sy = k == 0 ? s.f[F_SHIELD_Y0] : k == 1 ? s.f[F_SHIELD_Y1] : s.f[F_SHIELD_Y2];
+    // (values, not lvalues, in the selects: a conditional over array elements becomes a select of addresses and pushes
+    // the whole register array into scratch)
+    const int sx = sel3(k, s.f[F_SHIELD_X0], s.f[F_SHIELD_X1], s.f[F_SHIELD_X2]);
+    const int sy = sel3(k, s.f[F_SHIELD_Y0], s.f[F_SHIELD_Y1], s.f[F_SHIELD_Y2]);
     int cx0 = l.x - sx, cx1 = l.x + l.w - sx, cy0 = l.y - sy, cy1 = l.y + l.h - sy;
     if (cx0 < 0) cx0 = 0;
     if (cy0 < 0) cy0 = 0;
@@ -691,9 +696,9 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
     const bool ufo_on = f[F_UFO_APP] == 0 || f[F_UFO_DC] >= 0;
     const int sk = lane / TBX_SI_SHIELD_H, sr = lane - sk * TBX_SI_SHIELD_H;
     const bool s_valid = lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H && sk < f[F_N_SHIELDS];
-    const int s_x = sk == 0 ? f[F_SHIELD_X0] : sk == 1 ? f[F_SHIELD_X1] : f[F_SHIELD_X2];
-    const int s_y = (sk == 0 ? f[F_SHIELD_Y0] : sk == 1 ? f[F_SHIELD_Y1] : f[F_SHIELD_Y2]) + sr;
-    const uint32_t s_c = pix_of<C>((uint32_t)(sk == 0 ? f[F_SHIELD_C0] : sk == 1 ? f[F_SHIELD_C1] : f[F_SHIELD_C2]));
+    const int s_x = sel3(sk, f[F_SHIELD_X0], f[F_SHIELD_X1], f[F_SHIELD_X2]);
+    const int s_y = sel3(sk, f[F_SHIELD_Y0], f[F_SHIELD_Y1], f[F_SHIELD_Y2]) + sr;
+    const uint32_t s_c = pix_of<C>((uint32_t)sel3(sk, f[F_SHIELD_C0], f[F_SHIELD_C1], f[F_SHIELD_C2]));
     const bool e_vis = lane < ne && (e_alive(s) || e_dc(s) >= 0);
     // scanline ranges that can contain enemies / shields / lasers at all (wave-uniform), so that most scanlines
     // skip the ballots
