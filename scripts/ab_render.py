@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""A/B timing of render launches of several builds of the library on ONE box, interleaved (run-to-run drift on a box is a
+few per cent, so variants are only comparable within one session).  usage: ab_render.py game channels lib1.so lib2.so ..."""
+import ctypes as C
+import sys
+import time
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from toybox_amd import Engine, _abi, hip  # noqa: E402
+
+game, ch = sys.argv[1], int(sys.argv[2])
+libs = []
+for p in sys.argv[3:]:
+    lib = C.CDLL(p)
+    _abi.bind(lib)
+    libs.append((p, lib))
+n = 65536
+for rnd in range(3):
+    for p, lib in libs:
+        e = Engine(game, n, lib=lib)
+        e.seed(1234)
+        for t in range(30):
+            e.step_synthetic(1337, t)
+        e.render_device(channels=ch)
+        hip.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            e.render_device(channels=ch)
+        hip.synchronize()
+        dt = (time.perf_counter() - t0) / 40
+        print("round %d %-40s %.4f ms  %.0f GB/s" % (rnd, p.split("/")[-1], dt * 1e3, n * e.height * e.width * ch / dt / 1e9), flush=True)
+        e.close()
