@@ -10,6 +10,10 @@
 
 #include "tbx_common.hpp"
 
+// the frame stores are plain 16-byte stores: non-temporal (`nt`) stores measured within run-to-run noise of them (A/B on one
+// box, scripts/ab_render.py)
+__device__ __forceinline__ void tbx_store16(uint4* p, const uint4& v) { *p = v; }
+
 template <int C>
 struct PixBytes;   // bytes of a 4-pixel group
 
@@ -104,7 +108,7 @@ struct RowStager {
                 const int c = lane + 64 * i;
                 const int ph = (ph0 + i) % 3;               // (lane + 64 i) % 3
                 const uint4 v = ph == 0 ? make_uint4(d0, d1, d2, d0) : ph == 1 ? make_uint4(d1, d2, d0, d1) : make_uint4(d2, d0, d1, d2);
-                if (c < chunks) out[c] = v;
+                if (c < chunks) tbx_store16(out + c, v);
             }
         } else {
             const uint32_t q = C == 1 ? p * 0x01010101u : (p | 0xFF000000u);
@@ -112,7 +116,7 @@ struct RowStager {
 #pragma unroll
             for (int i = 0; i < (chunks + 63) / 64; i++) {
                 const int c = lane + 64 * i;
-                if (c < chunks) out[c] = v;
+                if (c < chunks) tbx_store16(out + c, v);
             }
         }
     }
@@ -125,7 +129,7 @@ struct RowStager {
         uint4* out = reinterpret_cast<uint4*>(dst);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
-        for (int i = lane; i < chunks; i += 64) out[i] = src[i];
+        for (int i = lane; i < chunks; i += 64) tbx_store16(out + i, src[i]);
         __builtin_amdgcn_wave_barrier();
     }
 };
