@@ -2,6 +2,7 @@
 #pragma once
 
 #include "tbx_common.hpp"
+#include "raster.hpp"
 
 struct AgentTaps {          // area-resize taps of one output row / column
     int32_t start, n;
@@ -22,15 +23,15 @@ struct AgentWarpArgs {
     uint64_t magic;            // floor(2^42 / (H*W)) + 1
 };
 
+// per-byte max of two packed dwords: even and odd bytes as two packed-u16 maxima (v_pk_max_u16)
 __device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
 {
-    uint32_t r = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t x = (a >> (8 * k)) & 255u, y = (b >> (8 * k)) & 255u;
-        r |= (x > y ? x : y) << (8 * k);
-    }
-    return r;
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t m = 0x00FF00FFu;
+    const uint32_t ae = a & m, be = b & m, ao = (a >> 8) & m, bo = (b >> 8) & m;
+    const u16x2 e = __builtin_elementwise_max(__builtin_bit_cast(u16x2, ae), __builtin_bit_cast(u16x2, be));
+    const u16x2 o = __builtin_elementwise_max(__builtin_bit_cast(u16x2, ao), __builtin_bit_cast(u16x2, bo));
+    return __builtin_bit_cast(uint32_t, e) | (__builtin_bit_cast(uint32_t, o) << 8);
 }
 
 // this lane's taps for one output column: first source pixel and 8 byte weights (zero padded)
@@ -184,3 +185,144 @@ struct AgentResetProc {
         }
     }
 };
+
+
+// ------------------------------------------------------------------ fused observation from two painters
+//
+// max(frame A, frame B) -> area warp -> frame stack for games whose rasteriser is a "painter" (a struct that is set up once
+// per frame from the SoA state and then composes any scanline as packed gray dwords), without the two full-resolution
+// gray frames ever reaching HBM.  One wave per env holds both painters: A = a snapshot of the state after frame skip-2,
+// B = the live state.  A painter sorts what it draws into NCLS classes (enemies, shields, lasers, HUD ...) and records
+// each class's scanlines as a 256-bit mask in LDS; the game supplies diff_classes(A, B), the classes whose entities are
+// not identical in the two states.  A scanline is then
+//   * skipped when it is blank in B and holds no differing class (its horizontal sums are a per-column constant),
+//   * painted from B alone when no differing class touches it (frame A shows the same pixels there),
+//   * painted from both and maxed otherwise
+// -- consecutive frames differ in a few moving objects, so most scanlines take the first two forms.
+// (A two-wave variant, one painter per wave with a block barrier per chunk of scanlines, measured 18 % slower: fewer envs
+// in flight and barrier stalls outweighed the lower register count.)
+//
+// Painter P: static W, H, NG (4-pixel groups per lane), NCLS; type Dev; setup(dev, env, lane, cls) with cls = this wave's
+// [NCLS][8] dwords of LDS (the painter fills them and keeps their union in busy[4]); row_dwords(y, v[NG]); blank_dword();
+// static diff_classes(const P& a, const P& b) -> wave-uniform bit mask.
+template <class P>
+struct AgentFusedLds {
+    static constexpr int ROWB = ((P::W + 32 + 15) / 16) * 16;
+    uint8_t row[ROWB] __attribute__((aligned(16)));
+    uint32_t cls[2][P::NCLS][8];
+    uint32_t masks[2][8];       // need / need_a
+};
+
+template <int S, class P>
+__device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P::Dev& dA, const typename P::Dev& dB, const AgentWarpArgs& a,
+                                                 int env, int lane, AgentFusedLds<P>& L)
+{
+    constexpr int W = P::W, H = P::H, NG = P::NG, NCLS = P::NCLS;
+    static_assert(W % 4 == 0 && W / 4 <= 64 * NG && H <= 256, "painter geometry");
+    const bool fresh = a.reset_mode || a.fin[env];                     // the observation is the (warped) reset frame alone
+    const bool two = a.two_frames && !fresh;
+    uint8_t* row = L.row;
+    pb.setup(dB, env, lane, &L.cls[1][0][0]);
+    uint64_t need[4], need_a[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+    for (int k = 0; k < 4; k++) need[k] = pb.busy[k];
+    if (two) {
+        pa.setup(dA, env, lane, &L.cls[0][0][0]);
+        const uint32_t diff = P::diff_classes(pa, pb);
+        if (lane < 8) {
+            uint32_t na = 0u;
+            for (int c = 0; c < NCLS; c++)
+                if ((diff >> c) & 1u) na |= L.cls[0][c][lane] | L.cls[1][c][lane];
+            L.masks[1][lane] = na;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(L.masks[1][2 * k]), hi = __builtin_amdgcn_readfirstlane(L.masks[1][2 * k + 1]);
+            need_a[k] = (uint64_t)lo | ((uint64_t)hi << 32);
+            need[k] |= need_a[k];
+        }
+    }
+    uint8_t* o = a.obs + (size_t)env * a.oh * a.ow * S;
+    const uint32_t half = (uint32_t)(H * W) / 2u;
+    const ColTaps c0 = load_col(a.tx, lane, a.ow), c1 = load_col(a.tx, lane + 64, a.ow);
+    const bool on0 = lane < a.ow, on1 = lane + 64 < a.ow;
+    const uint32_t blank = P::blank_dword();
+    for (int i = lane; i < (AgentFusedLds<P>::ROWB - W) / 4; i += 64) reinterpret_cast<uint32_t*>(row + W)[i] = 0u;   // window padding
+    uint32_t hb0, hb1;                                                 // horizontal sums of a blank scanline
+    {
+        for (int i = lane; i < W / 4; i += 64) reinterpret_cast<uint32_t*>(row)[i] = blank;
+        __builtin_amdgcn_wave_barrier();
+        hb0 = on0 ? hsum(row, c0) : 0u;
+        hb1 = on1 ? hsum(row, c1) : 0u;
+        __builtin_amdgcn_wave_barrier();
+    }
+    uint32_t old[2] = {0u, 0u};                                        // stack words of the output row being accumulated
+    auto fetch_old = [&](int oy) {
+        if (S == 4 && !fresh && oy < a.oh) {
+            if (on0) old[0] = *reinterpret_cast<const uint32_t*>(o + ((size_t)oy * a.ow + lane) * 4);
+            if (on1) old[1] = *reinterpret_cast<const uint32_t*>(o + ((size_t)oy * a.ow + lane + 64) * 4);
+        }
+    };
+    fetch_old(0);
+
+    uint32_t acc0[2] = {0, 0}, acc1[2] = {0, 0};                       // [column slot]: current / next output row
+    // source row sy covers [sy*oh, (sy+1)*oh) and output row oy covers [oy*H, (oy+1)*H) in refined units; both walk
+    // incrementally (no division), and the three row masks are consumed one bit per scanline, 64 scanlines per word
+    int oy = 0, top = H, pos = 0;
+#pragma unroll 1
+    for (int wi = 0; wi < (H + 63) / 64; wi++) {
+        uint64_t nw = wi == 0 ? need[0] : wi == 1 ? need[1] : wi == 2 ? need[2] : need[3];
+        uint64_t bw = wi == 0 ? pb.busy[0] : wi == 1 ? pb.busy[1] : wi == 2 ? pb.busy[2] : pb.busy[3];
+        uint64_t aw = wi == 0 ? need_a[0] : wi == 1 ? need_a[1] : wi == 2 ? need_a[2] : need_a[3];
+        const int sy_end = min(H, 64 * wi + 64);
+#pragma unroll 1
+        for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, bw >>= 1, aw >>= 1) {
+            uint32_t h0 = hb0, h1 = hb1;
+            if (nw & 1ull) {
+                uint32_t v[NG];
+                if (bw & 1ull) pb.row_dwords(sy, v);
+                else {
+#pragma unroll
+                    for (int g = 0; g < NG; g++) v[g] = blank;
+                }
+                if (aw & 1ull) {                                       // only then can frame A show different pixels
+                    uint32_t va[NG];
+                    pa.row_dwords(sy, va);
+#pragma unroll
+                    for (int g = 0; g < NG; g++) v[g] = bytemax4(v[g], va[g]);
+                }
+#pragma unroll
+                for (int g = 0; g < NG; g++)
+                    if (lane + 64 * g < W / 4) reinterpret_cast<uint32_t*>(row)[lane + 64 * g] = v[g];
+                __builtin_amdgcn_wave_barrier();
+                h0 = on0 ? hsum(row, c0) : 0u;
+                h1 = on1 ? hsum(row, c1) : 0u;
+                __builtin_amdgcn_wave_barrier();
+            }
+            const int pos_next = pos + a.oh;
+            const int w_cur = min(pos_next, top) - pos, w_next = a.oh - w_cur;
+            acc0[0] += (uint32_t)w_cur * h0; acc0[1] += (uint32_t)w_cur * h1;
+            acc1[0] += (uint32_t)w_next * h0; acc1[1] += (uint32_t)w_next * h1;
+            pos = pos_next;
+            if (pos_next >= top) {                                     // output row oy is complete
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int ox = lane + 64 * q;
+                    if (q == 0 ? on0 : on1) {
+                        const uint32_t val = (uint32_t)(((uint64_t)(acc0[q] + half) * a.magic) >> 42);
+                        uint8_t* px = o + ((size_t)oy * a.ow + ox) * S;
+                        if (S == 4) *reinterpret_cast<uint32_t*>(px) = ((fresh ? 0u : old[q]) >> 8) | (val << 24);
+                        else stack_push<S>(px, val, fresh);
+                    }
+                    acc0[q] = acc1[q];
+                    acc1[q] = 0;
+                }
+                oy += 1;
+                top += H;
+                fetch_old(oy);
+            }
+        }
+    }
+}

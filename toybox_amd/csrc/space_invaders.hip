@@ -626,136 +626,291 @@ __device__ __forceinline__ void paint_span(uint32_t (&px)[NG][4], const int (&gx
     }
 }
 
-// One wave rasterises one env: scanline by scanline, lane l makes the 4-pixel groups l and l+64
-// (320 px = 80 groups); entities intersecting the scanline are found by ballot over lanes
-// (lane = enemy / shield row / laser slot) and painted in the checker's order.
+// Everything one wave needs to paint scanlines of one env: lane l makes the 4-pixel groups l and l+64 (320 px = 80
+// groups); lanes also hold the entities (lane = enemy / shield row / laser slot).  Built once per frame by setup();
+// paint_row() then composes one busy scanline in the checker's order (shields, enemies, ufo, ship, lasers, HUD).
+constexpr int SI_NG = 2;
+
 template <int C>
-__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank)
+struct SiPainter {
+    typedef SiDev Dev;
+    static constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
+    enum { CLS_ENEMY, CLS_SHIELD, CLS_LASER, CLS_HUD, CLS_UFO, CLS_SHIP, NCLS };
+    SiRegs s;
+    int lane;
+    int gx[SI_NG];
+    bool gact[SI_NG];
+    uint32_t hud[SI_NG][4];                 // bit 3*r = lit in glyph row r
+    uint32_t c_enemy, c_ufo, c_ground, c_hud, c_black, c_ship, l_col, s_c;
+    bool ufo_on, s_valid, e_vis, l_on;
+    int s_x, s_y;
+    int e_y0, e_y1, s_y0, s_y1;             // scanline ranges that can hold enemies / shield rows at all (wave-uniform)
+    long l_lo, l_hi;                        // ... lasers
+    uint64_t cand[SI_NG];                   // per pixel group: visible enemies whose columns overlap it (bit e)
+    int e_tab;                              // lane = enemy: its sprite table base in spr_lds
+    uint64_t busy[4];                       // scanlines that show anything but black (wave-uniform, 256 bits)
+    const uint32_t* spr_lds;
+
+    // spr_lds (set by the caller first): the block's copy of the three enemy sprites (si_fill_sprites); cls: [NCLS][8]
+    // dwords of LDS private to this wave
+    __device__ __forceinline__ void setup(const SiDev& d, int env, int lane_, uint32_t* cls)
+    {
+        lane = lane_;
+        si_load(d, env, lane, s);
+        const int32_t* f = s.f;
+        const int ne = f[F_N_ENEMIES];
+        gx[0] = lane * 4; gx[1] = (lane + 64) * 4;
+        gact[0] = true; gact[1] = lane + 64 < TBX_SI_W / 4;
+        {
+            int sc = f[F_SCORE];
+            if (sc < 0) sc = 0;
+            sc %= 100000;
+            int lv = f[F_LIVES];
+            lv = lv < 0 ? 0 : lv > 9 ? 9 : lv;
+            int le = f[F_LEVEL];
+            if (le < 0) le = 0;
+            le %= 10;
+            const int hud_x0[7] = {36, 44, 52, 60, 68, 148, 196};
+#pragma unroll
+            for (int g = 0; g < SI_NG; g++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) hud[g][i] = 0;
+            int div = 10000;
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+                int digit;
+                if (q < 5) { digit = (sc / div) % 10; div /= 10; }
+                else digit = q == 5 ? lv : le;
+                const uint32_t glyph = SI_DIGITS[digit];
+#pragma unroll
+                for (int g = 0; g < SI_NG; g++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int dx = gx[g] + i - hud_x0[q];
+                        if (dx >= 0 && dx < 6) hud[g][i] = (glyph >> (dx >> 1)) & 0x1249u;
+                    }
+            }
+        }
+        // every colour goes through pix_of<C>() once here; the scanline loop only moves finished pixel values
+        c_enemy = pix_of<C>(rgb_u32(TBX_SI_COL_ENEMY)); c_ufo = pix_of<C>(rgb_u32(TBX_SI_COL_UFO));
+        c_ground = pix_of<C>(rgb_u32(TBX_SI_COL_GROUND)); c_hud = pix_of<C>(rgb_u32(TBX_SI_COL_HUD));
+        c_black = pix_of<C>(0xFF000000u); c_ship = pix_of<C>((uint32_t)f[F_SHIP_COLOR]);
+        l_col = pix_of<C>((uint32_t)s.lf[LF_COLOR]);
+        ufo_on = f[F_UFO_APP] == 0 || f[F_UFO_DC] >= 0;
+        const int sk = lane / TBX_SI_SHIELD_H, sr = lane - sk * TBX_SI_SHIELD_H;
+        s_valid = lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H && sk < f[F_N_SHIELDS];
+        s_x = sel3(sk, f[F_SHIELD_X0], f[F_SHIELD_X1], f[F_SHIELD_X2]);
+        s_y = sel3(sk, f[F_SHIELD_Y0], f[F_SHIELD_Y1], f[F_SHIELD_Y2]) + sr;
+        s_c = pix_of<C>((uint32_t)sel3(sk, f[F_SHIELD_C0], f[F_SHIELD_C1], f[F_SHIELD_C2]));
+        e_vis = lane < ne && (e_alive(s) || e_dc(s) >= 0);
+        e_y0 = e_vis ? s.ey : INT32_MAX; e_y1 = e_vis ? s.ey + TBX_SI_ENEMY_H : INT32_MIN;
+        l_on = lane == SHIP_SLOT ? f[F_HAS_SHIP_LASER] != 0 : lane < f[F_N_LASERS];
+        l_lo = l_on ? (long)s.lf[LF_Y] : LONG_MAX; l_hi = l_on ? (long)s.lf[LF_Y] + s.lf[LF_H] : LONG_MIN;
+        s_y0 = s_valid && s.srow ? s_y : INT32_MAX; s_y1 = s_valid && s.srow ? s_y + 1 : INT32_MIN;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            e_y0 = min(e_y0, __shfl_xor(e_y0, o)); e_y1 = max(e_y1, __shfl_xor(e_y1, o));
+            s_y0 = min(s_y0, __shfl_xor(s_y0, o)); s_y1 = max(s_y1, __shfl_xor(s_y1, o));
+            const long a = ((long)__shfl_xor((int)(l_lo >> 32), o) << 32) | (uint32_t)__shfl_xor((int)l_lo, o);
+            const long b = ((long)__shfl_xor((int)(l_hi >> 32), o) << 32) | (uint32_t)__shfl_xor((int)l_hi, o);
+            l_lo = a < l_lo ? a : l_lo; l_hi = b > l_hi ? b : l_hi;
+        }
+        e_y0 = wave_uniform(e_y0); e_y1 = wave_uniform(e_y1); s_y0 = wave_uniform(s_y0); s_y1 = wave_uniform(s_y1);
+
+        cand[0] = cand[1] = 0ull;
+        for (uint64_t m = __ballot(e_vis); m; m &= m - 1) {
+            const int e = (int)__builtin_ctzll(m);
+            const int ex = __builtin_amdgcn_readlane(s.ex, e);
+#pragma unroll
+            for (int g = 0; g < SI_NG; g++)
+                if (gx[g] + 3 >= ex && gx[g] < ex + TBX_SI_ENEMY_W) cand[g] |= 1ull << e;
+        }
+        e_tab = (s.estatus & 1) ? (f[F_ORIENT] ? 0 : TBX_SI_ENEMY_H) : 2 * TBX_SI_ENEMY_H;
+
+        // scanline masks per class in LDS: every lane ORs the rows of the entities it holds (enemy, shield row, laser);
+        // HUD + ground, ufo and ship come from wave-uniform fields.  busy = their union.
+        for (int i = lane; i < NCLS * 8; i += 64) cls[i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const long ly0 = s.lf[LF_Y];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t we = e_vis ? row_range_bits(s.ey, (long)s.ey + TBX_SI_ENEMY_H, k) : 0ull;
+            const uint64_t ws = (s_valid && s.srow != 0) ? row_range_bits(s_y, (long)s_y + 1, k) : 0ull;
+            const uint64_t wl = l_on ? row_range_bits(ly0, ly0 + s.lf[LF_H], k) : 0ull;
+            if ((uint32_t)we) atomicOr(&cls[CLS_ENEMY * 8 + 2 * k], (uint32_t)we);
+            if ((uint32_t)(we >> 32)) atomicOr(&cls[CLS_ENEMY * 8 + 2 * k + 1], (uint32_t)(we >> 32));
+            if ((uint32_t)ws) atomicOr(&cls[CLS_SHIELD * 8 + 2 * k], (uint32_t)ws);
+            if ((uint32_t)(ws >> 32)) atomicOr(&cls[CLS_SHIELD * 8 + 2 * k + 1], (uint32_t)(ws >> 32));
+            if ((uint32_t)wl) atomicOr(&cls[CLS_LASER * 8 + 2 * k], (uint32_t)wl);
+            if ((uint32_t)(wl >> 32)) atomicOr(&cls[CLS_LASER * 8 + 2 * k + 1], (uint32_t)(wl >> 32));
+            if (lane == 0) {
+                const uint64_t wh = row_range_bits(2, 12, k) | row_range_bits(TBX_SI_GROUND_Y, TBX_SI_GROUND_Y + 1, k);
+                const uint64_t wu = ufo_on ? row_range_bits(f[F_UFO_Y], (long)f[F_UFO_Y] + TBX_SI_UFO_H, k) : 0ull;
+                const uint64_t wp = ((f[F_SHIP_FLAGS] & 1) || f[F_SHIP_DC] >= 0) ? row_range_bits(f[F_SHIP_Y], (long)f[F_SHIP_Y] + TBX_SI_SHIP_H, k) : 0ull;
+                cls[CLS_HUD * 8 + 2 * k] = (uint32_t)wh; cls[CLS_HUD * 8 + 2 * k + 1] = (uint32_t)(wh >> 32);
+                cls[CLS_UFO * 8 + 2 * k] = (uint32_t)wu; cls[CLS_UFO * 8 + 2 * k + 1] = (uint32_t)(wu >> 32);
+                cls[CLS_SHIP * 8 + 2 * k] = (uint32_t)wp; cls[CLS_SHIP * 8 + 2 * k + 1] = (uint32_t)(wp >> 32);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+            for (int c = 0; c < NCLS; c++) { lo |= cls[c * 8 + 2 * k]; hi |= cls[c * 8 + 2 * k + 1]; }
+            busy[k] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(lo) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(hi) << 32);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // the classes whose entities differ between two states of one env (wave-uniform bit mask)
+    static __device__ __forceinline__ uint32_t diff_classes(const SiPainter& a, const SiPainter& b)
+    {
+        uint32_t m = 0u;
+        if (__ballot(a.e_vis != b.e_vis || (b.e_vis && (a.s.ex != b.s.ex || a.s.ey != b.s.ey || a.e_tab != b.e_tab)))) m |= 1u << CLS_ENEMY;
+        if (__ballot(a.s_valid != b.s_valid || (b.s_valid && (a.s.srow != b.s.srow || a.s_x != b.s_x || a.s_y != b.s_y || a.s_c != b.s_c))))
+            m |= 1u << CLS_SHIELD;
+        if (__ballot(a.l_on != b.l_on || (b.l_on && (a.s.lf[LF_X] != b.s.lf[LF_X] || a.s.lf[LF_Y] != b.s.lf[LF_Y] || a.s.lf[LF_W] != b.s.lf[LF_W] ||
+                                                     a.s.lf[LF_H] != b.s.lf[LF_H] || a.l_col != b.l_col))))
+            m |= 1u << CLS_LASER;
+        bool hud_diff = false;
+#pragma unroll
+        for (int g = 0; g < SI_NG; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) hud_diff |= a.hud[g][i] != b.hud[g][i];
+        if (__ballot(hud_diff)) m |= 1u << CLS_HUD;
+        const int32_t *fa = a.s.f, *fb = b.s.f;
+        if (a.ufo_on != b.ufo_on || (b.ufo_on && (fa[F_UFO_X] != fb[F_UFO_X] || fa[F_UFO_Y] != fb[F_UFO_Y]))) m |= 1u << CLS_UFO;
+        const bool sa = (fa[F_SHIP_FLAGS] & 1) || fa[F_SHIP_DC] >= 0, sb = (fb[F_SHIP_FLAGS] & 1) || fb[F_SHIP_DC] >= 0;
+        if (sa != sb || (sb && (fa[F_SHIP_X] != fb[F_SHIP_X] || fa[F_SHIP_Y] != fb[F_SHIP_Y] || fa[F_SHIP_FLAGS] != fb[F_SHIP_FLAGS] ||
+                                (fa[F_SHIP_DC] >= 0) != (fb[F_SHIP_DC] >= 0) || a.c_ship != b.c_ship)))
+            m |= 1u << CLS_SHIP;
+        return wave_uniform((int)m);
+    }
+
+    // one busy scanline as finished pixel values
+    __device__ __forceinline__ void paint_row(int y, uint32_t (&px)[SI_NG][4]) const
+    {
+        constexpr int NG = SI_NG;
+        const int32_t* f = s.f;
+        const uint32_t base = y == TBX_SI_GROUND_Y ? c_ground : c_black;
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) px[g][i] = base;
+        // shields (ascending shield index, then row: one row per shield can match y)
+        if (y >= s_y0 && y < s_y1) {
+            uint64_t m = __ballot(s_valid && s_y == y && s.srow != 0);
+            while (m) {
+                const int src = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                paint_bits<NG>(px, gx, __shfl(s_x, src), __shfl(s.srow, src), TBX_SI_SHIELD_W, __shfl(s_c, src));
+            }
+        }
+        // enemies in index order: each lane walks the (usually one) enemy that overlaps its pixel group and this scanline
+        if (y >= e_y0 && y < e_y1) {
+            const uint64_t ym = __ballot(e_vis && y >= s.ey && y < s.ey + TBX_SI_ENEMY_H);
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                uint64_t c = cand[g] & ym;
+                while (__ballot(c != 0)) {
+                    const bool on = c != 0;
+                    const int e = on ? (int)__builtin_ctzll(c) : 0;
+                    const int ex = __shfl(s.ex, e), ey = __shfl(s.ey, e), tab = __shfl(e_tab, e);
+                    if (on) {
+                        const uint32_t bits = spr_lds[tab + (y - ey)] & ((1u << TBX_SI_ENEMY_W) - 1u);
+                        const uint32_t four = ((bits << 4) >> (gx[g] - ex + 4)) & 15u;    // shift in [1, 19]
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            if ((four >> i) & 1u) px[g][i] = c_enemy;
+                        c &= c - 1;
+                    }
+                }
+            }
+        }
+        if (ufo_on && y >= f[F_UFO_Y] && y < f[F_UFO_Y] + TBX_SI_UFO_H)
+            paint_bits<NG>(px, gx, f[F_UFO_X], SI_SPR_UFO[y - f[F_UFO_Y]], TBX_SI_UFO_W, c_ufo);
+        if (y >= f[F_SHIP_Y] && y < f[F_SHIP_Y] + TBX_SI_SHIP_H) {
+            const int ry = y - f[F_SHIP_Y];
+            if (f[F_SHIP_FLAGS] & 1) paint_bits<NG>(px, gx, f[F_SHIP_X], SI_SPR_SHIP[ry], 16, c_ship);
+            else if (f[F_SHIP_DC] >= 0)
+                paint_bits<NG>(px, gx, f[F_SHIP_X], (f[F_SHIP_FLAGS] & 2) ? SI_SPR_D1[ry] : SI_SPR_D2[ry], 16, c_ship);
+        }
+        // lasers: the ship's first, then enemy lasers in slot order
+        if (y >= l_lo && y < l_hi) {
+            const long ly0 = s.lf[LF_Y], ly1 = (long)s.lf[LF_Y] + s.lf[LF_H];
+            uint64_t m = __ballot(l_on && y >= ly0 && y < ly1);
+            if ((m >> SHIP_SLOT) & 1) {
+                const Laser l = get_laser(s, SHIP_SLOT);
+                paint_span<NG>(px, gx, l.x, (long)l.x + l.w, __shfl(l_col, SHIP_SLOT));
+            }
+            m &= (1ull << SHIP_SLOT) - 1;
+            while (m) {
+                const int src = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const long lx = __shfl(s.lf[LF_X], src), lw = __shfl(s.lf[LF_W], src);
+                paint_span<NG>(px, gx, lx, lx + lw, __shfl(l_col, src));
+            }
+        }
+        if (y >= 2 && y < 12) {
+            const int gr = ((y - 2) >> 1) * 3;
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if ((hud[g][i] >> gr) & 1u) px[g][i] = c_hud;
+        }
+    }
+};
+
+// (SiPainter, continued) packed gray bytes for the fused agent path
+template <int C>
+__device__ __forceinline__ void si_row_dwords(const SiPainter<C>& p, int y, uint32_t (&v)[SI_NG])
 {
-    constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = 2;
-    using Stager = RowStager<C, W, SI_UNIT_ROWS>;
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
-    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][8];
-    __shared__ uint32_t spr_lds[3 * TBX_SI_ENEMY_H];        // enemy sprite rows: pose A, pose B, explosion
+    uint32_t px[SI_NG][4];
+    p.paint_row(y, px);
+#pragma unroll
+    for (int g = 0; g < SI_NG; g++) v[g] = px[g][0] | (px[g][1] << 8) | (px[g][2] << 16) | (px[g][3] << 24);
+}
+
+struct SiGrayPainter : SiPainter<1> {
+    static __device__ __forceinline__ uint32_t diff_classes(const SiGrayPainter& a, const SiGrayPainter& b) { return SiPainter<1>::diff_classes(a, b); }
+    static __device__ __forceinline__ uint32_t blank_dword() { return 0u; }      // black is gray 0
+    __device__ __forceinline__ void row_dwords(int y, uint32_t (&v)[SI_NG]) const { si_row_dwords<1>(*this, y, v); }
+};
+
+// the block's LDS copy of the enemy sprite rows (pose A, pose B, explosion); ends with a block barrier
+__device__ __forceinline__ void si_fill_sprites(uint32_t* spr_lds)
+{
     if (threadIdx.x < 3 * TBX_SI_ENEMY_H) {
         const int t = threadIdx.x;
         spr_lds[t] = t < TBX_SI_ENEMY_H ? SI_SPR_A[t] : t < 2 * TBX_SI_ENEMY_H ? SI_SPR_B[t - TBX_SI_ENEMY_H] : SI_SPR_BOOM[t - 2 * TBX_SI_ENEMY_H];
     }
     __syncthreads();
+}
+
+// One wave rasterises one env, scanline by scanline; SI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte
+// stores, blank units are stored directly.
+template <int C>
+__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank)
+{
+    constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
+    using Stager = RowStager<C, W, SI_UNIT_ROWS>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
+    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][SiPainter<C>::NCLS * 8];
+    __shared__ uint32_t spr_lds[3 * TBX_SI_ENEMY_H];
+    si_fill_sprites(spr_lds);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
     if (rel >= count) return;
     const int env = first_env + rel;
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
-
-    SiRegs s;
-    si_load(d, env, lane, s);
-    const int32_t* f = s.f;
-    const int ne = f[F_N_ENEMIES];
-    const int gx[NG] = {lane * 4, (lane + 64) * 4};
-    const bool gact[NG] = {true, lane + 64 < W / 4};
-
-    // HUD bits per pixel: bit 3*r = lit in glyph row r
-    uint32_t hud[NG][4];
-    {
-        int sc = f[F_SCORE];
-        if (sc < 0) sc = 0;
-        sc %= 100000;
-        int lv = f[F_LIVES];
-        lv = lv < 0 ? 0 : lv > 9 ? 9 : lv;
-        int le = f[F_LEVEL];
-        if (le < 0) le = 0;
-        le %= 10;
-        const int hud_x0[7] = {36, 44, 52, 60, 68, 148, 196};
-#pragma unroll
-        for (int g = 0; g < NG; g++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) hud[g][i] = 0;
-        int div = 10000;
-#pragma unroll
-        for (int q = 0; q < 7; q++) {
-            int digit;
-            if (q < 5) { digit = (sc / div) % 10; div /= 10; }
-            else digit = q == 5 ? lv : le;
-            const uint32_t glyph = SI_DIGITS[digit];
-#pragma unroll
-            for (int g = 0; g < NG; g++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int dx = gx[g] + i - hud_x0[q];
-                    if (dx >= 0 && dx < 6) hud[g][i] = (glyph >> (dx >> 1)) & 0x1249u;
-                }
-        }
-    }
-    // every colour goes through pix_of<C>() once here; the scanline loop only moves finished pixel values
-    const uint32_t c_enemy = pix_of<C>(rgb_u32(TBX_SI_COL_ENEMY)), c_ufo = pix_of<C>(rgb_u32(TBX_SI_COL_UFO));
-    const uint32_t c_ground = pix_of<C>(rgb_u32(TBX_SI_COL_GROUND)), c_hud = pix_of<C>(rgb_u32(TBX_SI_COL_HUD));
-    const uint32_t c_black = pix_of<C>(0xFF000000u), c_ship = pix_of<C>((uint32_t)f[F_SHIP_COLOR]);
-    const uint32_t l_col = pix_of<C>((uint32_t)s.lf[LF_COLOR]);
-    const bool ufo_on = f[F_UFO_APP] == 0 || f[F_UFO_DC] >= 0;
-    const int sk = lane / TBX_SI_SHIELD_H, sr = lane - sk * TBX_SI_SHIELD_H;
-    const bool s_valid = lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H && sk < f[F_N_SHIELDS];
-    const int s_x = sel3(sk, f[F_SHIELD_X0], f[F_SHIELD_X1], f[F_SHIELD_X2]);
-    const int s_y = sel3(sk, f[F_SHIELD_Y0], f[F_SHIELD_Y1], f[F_SHIELD_Y2]) + sr;
-    const uint32_t s_c = pix_of<C>((uint32_t)sel3(sk, f[F_SHIELD_C0], f[F_SHIELD_C1], f[F_SHIELD_C2]));
-    const bool e_vis = lane < ne && (e_alive(s) || e_dc(s) >= 0);
-    // scanline ranges that can contain enemies / shields / lasers at all (wave-uniform), so that most scanlines
-    // skip the ballots
-    int e_y0 = e_vis ? s.ey : INT32_MAX, e_y1 = e_vis ? s.ey + TBX_SI_ENEMY_H : INT32_MIN;
-    const bool l_on = lane == SHIP_SLOT ? f[F_HAS_SHIP_LASER] != 0 : lane < f[F_N_LASERS];
-    long l_lo = l_on ? (long)s.lf[LF_Y] : LONG_MAX, l_hi = l_on ? (long)s.lf[LF_Y] + s.lf[LF_H] : LONG_MIN;
-    int s_y0 = s_valid && s.srow ? s_y : INT32_MAX, s_y1 = s_valid && s.srow ? s_y + 1 : INT32_MIN;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        e_y0 = min(e_y0, __shfl_xor(e_y0, o)); e_y1 = max(e_y1, __shfl_xor(e_y1, o));
-        s_y0 = min(s_y0, __shfl_xor(s_y0, o)); s_y1 = max(s_y1, __shfl_xor(s_y1, o));
-        const long a = ((long)__shfl_xor((int)(l_lo >> 32), o) << 32) | (uint32_t)__shfl_xor((int)l_lo, o);
-        const long b = ((long)__shfl_xor((int)(l_hi >> 32), o) << 32) | (uint32_t)__shfl_xor((int)l_hi, o);
-        l_lo = a < l_lo ? a : l_lo; l_hi = b > l_hi ? b : l_hi;
-    }
-    e_y0 = wave_uniform(e_y0); e_y1 = wave_uniform(e_y1); s_y0 = wave_uniform(s_y0); s_y1 = wave_uniform(s_y1);
-
-    // per pixel group: the visible enemies whose columns overlap it (bit e), and per enemy lane its sprite table base
-    uint64_t cand[NG] = {0ull, 0ull};
-    for (uint64_t m = __ballot(e_vis); m; m &= m - 1) {
-        const int e = (int)__builtin_ctzll(m);
-        const int ex = __builtin_amdgcn_readlane(s.ex, e);
-#pragma unroll
-        for (int g = 0; g < NG; g++)
-            if (gx[g] + 3 >= ex && gx[g] < ex + TBX_SI_ENEMY_W) cand[g] |= 1ull << e;
-    }
-    const int e_tab = (s.estatus & 1) ? (f[F_ORIENT] ? 0 : TBX_SI_ENEMY_H) : 2 * TBX_SI_ENEMY_H;
-
-    // Which scanlines show anything but the black background: every lane ORs the rows of the entities it holds (enemy,
-    // shield row, laser) into the wave's 256-bit mask in LDS; ufo, ship, HUD and ground come from wave-uniform fields.
-    uint64_t busy[4];
-    {
-        uint32_t* bm = lds_mask[wave];
-        if (lane < 8) bm[lane] = 0u;
-        const long ly0 = s.lf[LF_Y];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint64_t w = 0;
-            if (e_vis) w |= row_range_bits(s.ey, (long)s.ey + TBX_SI_ENEMY_H, k);
-            if (s_valid && s.srow != 0) w |= row_range_bits(s_y, (long)s_y + 1, k);
-            if (l_on) w |= row_range_bits(ly0, ly0 + s.lf[LF_H], k);
-            if (lane == 0) {
-                w |= row_range_bits(2, 12, k) | row_range_bits(TBX_SI_GROUND_Y, TBX_SI_GROUND_Y + 1, k);
-                if (ufo_on) w |= row_range_bits(f[F_UFO_Y], (long)f[F_UFO_Y] + TBX_SI_UFO_H, k);
-                if ((f[F_SHIP_FLAGS] & 1) || f[F_SHIP_DC] >= 0) w |= row_range_bits(f[F_SHIP_Y], (long)f[F_SHIP_Y] + TBX_SI_SHIP_H, k);
-            }
-            if ((uint32_t)w) atomicOr(&bm[2 * k], (uint32_t)w);
-            if ((uint32_t)(w >> 32)) atomicOr(&bm[2 * k + 1], (uint32_t)(w >> 32));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t lo = __builtin_amdgcn_readfirstlane(bm[2 * k]), hi = __builtin_amdgcn_readfirstlane(bm[2 * k + 1]);
-            busy[k] = (uint64_t)lo | ((uint64_t)hi << 32);
-        }
-    }
+    SiPainter<C> p;
+    p.spr_lds = spr_lds;
+    p.setup(d, env, lane, lds_mask[wave]);
 
     uint8_t* frame = out + (size_t)rel * H * W * C;
     constexpr int NUNITS = H / SI_UNIT_ROWS;
@@ -763,94 +918,47 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
     for (int k = 0; k < NUNITS; k++) {
         int u = u0 + k;
         if (u >= NUNITS) u -= NUNITS;
-        const uint32_t rows_busy = skip_blank ? row_mask_chunk<SI_UNIT_ROWS>(busy, u * SI_UNIT_ROWS) : (1u << SI_UNIT_ROWS) - 1u;
+        const uint32_t rows_busy = skip_blank ? row_mask_chunk<SI_UNIT_ROWS>(p.busy, u * SI_UNIT_ROWS) : (1u << SI_UNIT_ROWS) - 1u;
         if (rows_busy == 0 && C != 4) {                      // nothing but background: no staging (for RGBA the
-            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, c_black);   // staged path measured faster)
+            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_black);   // staged path measured faster)
             continue;
         }
 #pragma unroll 1
         for (int r = 0; r < SI_UNIT_ROWS; r++) {
             const int y = u * SI_UNIT_ROWS + r;
-            if (!((rows_busy >> r) & 1u)) {
-#pragma unroll
-                for (int g = 0; g < NG; g++)
-                    if (gact[g]) st.put4p(r, lane + 64 * g, c_black, c_black, c_black, c_black);
-                continue;
-            }
             uint32_t px[NG][4];
-            const uint32_t base = y == TBX_SI_GROUND_Y ? c_ground : c_black;
-#pragma unroll
-            for (int g = 0; g < NG; g++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) px[g][i] = base;
-            // shields (ascending shield index, then row: one row per shield can match y)
-            if (y >= s_y0 && y < s_y1) {
-                uint64_t m = __ballot(s_valid && s_y == y && s.srow != 0);
-                while (m) {
-                    const int src = (int)__builtin_ctzll(m);
-                    m &= m - 1;
-                    paint_bits<NG>(px, gx, __shfl(s_x, src), __shfl(s.srow, src), TBX_SI_SHIELD_W, __shfl(s_c, src));
-                }
-            }
-            // enemies in index order: each lane walks the (usually one) enemy that overlaps its pixel group and this scanline
-            if (y >= e_y0 && y < e_y1) {
-                const uint64_t ym = __ballot(e_vis && y >= s.ey && y < s.ey + TBX_SI_ENEMY_H);
-#pragma unroll
-                for (int g = 0; g < NG; g++) {
-                    uint64_t c = cand[g] & ym;
-                    while (__ballot(c != 0)) {
-                        const bool on = c != 0;
-                        const int e = on ? (int)__builtin_ctzll(c) : 0;
-                        const int ex = __shfl(s.ex, e), ey = __shfl(s.ey, e), tab = __shfl(e_tab, e);
-                        if (on) {
-                            const uint32_t bits = spr_lds[tab + (y - ey)] & ((1u << TBX_SI_ENEMY_W) - 1u);
-                            const uint32_t four = ((bits << 4) >> (gx[g] - ex + 4)) & 15u;    // shift in [1, 19]
-#pragma unroll
-                            for (int i = 0; i < 4; i++)
-                                if ((four >> i) & 1u) px[g][i] = c_enemy;
-                            c &= c - 1;
-                        }
-                    }
-                }
-            }
-            if (ufo_on && y >= f[F_UFO_Y] && y < f[F_UFO_Y] + TBX_SI_UFO_H)
-                paint_bits<NG>(px, gx, f[F_UFO_X], SI_SPR_UFO[y - f[F_UFO_Y]], TBX_SI_UFO_W, c_ufo);
-            if (y >= f[F_SHIP_Y] && y < f[F_SHIP_Y] + TBX_SI_SHIP_H) {
-                const int ry = y - f[F_SHIP_Y];
-                if (f[F_SHIP_FLAGS] & 1) paint_bits<NG>(px, gx, f[F_SHIP_X], SI_SPR_SHIP[ry], 16, c_ship);
-                else if (f[F_SHIP_DC] >= 0)
-                    paint_bits<NG>(px, gx, f[F_SHIP_X], (f[F_SHIP_FLAGS] & 2) ? SI_SPR_D1[ry] : SI_SPR_D2[ry], 16, c_ship);
-            }
-            // lasers: the ship's first, then enemy lasers in slot order
-            if (y >= l_lo && y < l_hi) {
-                const long ly0 = s.lf[LF_Y], ly1 = (long)s.lf[LF_Y] + s.lf[LF_H];
-                uint64_t m = __ballot(l_on && y >= ly0 && y < ly1);
-                if ((m >> SHIP_SLOT) & 1) {
-                    const Laser l = get_laser(s, SHIP_SLOT);
-                    paint_span<NG>(px, gx, l.x, (long)l.x + l.w, __shfl(l_col, SHIP_SLOT));
-                }
-                m &= (1ull << SHIP_SLOT) - 1;
-                while (m) {
-                    const int src = (int)__builtin_ctzll(m);
-                    m &= m - 1;
-                    const long lx = __shfl(s.lf[LF_X], src), lw = __shfl(s.lf[LF_W], src);
-                    paint_span<NG>(px, gx, lx, lx + lw, __shfl(l_col, src));
-                }
-            }
-            if (y >= 2 && y < 12) {
-                const int gr = ((y - 2) >> 1) * 3;
+            if ((rows_busy >> r) & 1u) p.paint_row(y, px);
+            else {
 #pragma unroll
                 for (int g = 0; g < NG; g++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if ((hud[g][i] >> gr) & 1u) px[g][i] = c_hud;
+                    for (int i = 0; i < 4; i++) px[g][i] = p.c_black;
             }
 #pragma unroll
             for (int g = 0; g < NG; g++)
-                if (gact[g]) st.put4p(r, lane + 64 * g, px[g][0], px[g][1], px[g][2], px[g][3]);
+                if (p.gact[g]) st.put4p(r, lane + 64 * g, px[g][0], px[g][1], px[g][2], px[g][3]);
         }
         st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
     }
+}
+
+// ------------------------------------------------------------------ fused agent observation
+//
+// max(frame A, frame B) -> gray -> area warp -> frame stack without the two full-resolution gray frames ever reaching
+// HBM: agent_fused_wave (agent_device.hpp) with two SiGrayPainters in one wave per env.
+template <int S>
+__global__ __launch_bounds__(TBX_BLOCK) void si_agent_warp_kernel(SiDev dA, SiDev dB, AgentWarpArgs a, int n)
+{
+    __shared__ AgentFusedLds<SiGrayPainter> lds[TBX_WAVES_PER_BLOCK];
+    __shared__ uint32_t spr_lds[3 * TBX_SI_ENEMY_H];
+    si_fill_sprites(spr_lds);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (env >= n) return;
+    SiGrayPainter pa, pb;
+    pa.spr_lds = spr_lds; pb.spr_lds = spr_lds;
+    agent_fused_wave<S, SiGrayPainter>(pa, pb, dA, dB, a, env, lane, lds[wave]);
 }
 
 // ------------------------------------------------------------------ state pack / unpack, scalars
@@ -1010,6 +1118,7 @@ struct SiOps : GameOps {
     void destroy(tbx_engine*) override
     {
         hipFree(d.rng); hipFree(d.sc); hipFree(d.enemies); hipFree(d.shields); hipFree(d.lasers);
+        hipFree(dA.sc); hipFree(dA.enemies); hipFree(dA.shields); hipFree(dA.lasers);
     }
 
     int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
@@ -1034,6 +1143,45 @@ struct SiOps : GameOps {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    // ---- fused agent observation: frame A is a snapshot of the dynamic SoA state, frame B the live state
+    SiDev dA{};
+    bool agent_fused() const override { return true; }
+
+    int agent_snapshot(tbx_engine* e, int which, hipStream_t s) override
+    {
+        if (which != 0) return TBX_OK;                       // frame B is read from the live state
+        const size_t N = (size_t)e->n;
+        if (!dA.sc) {
+            dA = d;
+            dA.sc = nullptr; dA.enemies = nullptr; dA.shields = nullptr; dA.lasers = nullptr;
+            TBX_HIP(hipMalloc((void**)&dA.sc, (size_t)NF * N * sizeof(int32_t)));
+            TBX_HIP(hipMalloc((void**)&dA.enemies, N * NEF * 64 * sizeof(int32_t)));
+            TBX_HIP(hipMalloc((void**)&dA.shields, N * 64 * sizeof(uint32_t)));
+            TBX_HIP(hipMalloc((void**)&dA.lasers, N * NLF * 16 * sizeof(int32_t)));
+        }
+        TBX_HIP(hipMemcpyAsync(dA.sc, d.sc, (size_t)NF * N * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        TBX_HIP(hipMemcpyAsync(dA.enemies, d.enemies, N * NEF * 64 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        TBX_HIP(hipMemcpyAsync(dA.shields, d.shields, N * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        TBX_HIP(hipMemcpyAsync(dA.lasers, d.lasers, N * NLF * 16 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        return TBX_OK;
+    }
+
+    int agent_warp(tbx_engine* e, const AgentWarpArgs& a, hipStream_t s) override
+    {
+        AgentWarpArgs w = a;
+        if (!dA.sc) w.two_frames = 0;                        // no snapshot yet (reset, or skip == 1): frame B alone
+        const SiDev& A = dA.sc ? dA : d;
+        const dim3 grid = grid_for(e->n), block(TBX_BLOCK);
+        switch (a.stack) {
+        case 1: hipLaunchKernelGGL(si_agent_warp_kernel<1>, grid, block, 0, s, A, d, w, e->n); break;
+        case 2: hipLaunchKernelGGL(si_agent_warp_kernel<2>, grid, block, 0, s, A, d, w, e->n); break;
+        case 3: hipLaunchKernelGGL(si_agent_warp_kernel<3>, grid, block, 0, s, A, d, w, e->n); break;
+        default: hipLaunchKernelGGL(si_agent_warp_kernel<4>, grid, block, 0, s, A, d, w, e->n); break;
+        }
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
