@@ -203,7 +203,8 @@ struct AgentResetProc {
 // in flight and barrier stalls outweighed the lower register count.)
 //
 // Painter P: static W, H, NG (4-pixel groups per lane), NCLS; type Dev; setup(dev, env, lane, cls) with cls = this wave's
-// [NCLS][8] dwords of LDS (the painter fills them and keeps their union in busy[4]); row_dwords(y, v[NG]); blank_dword();
+// [NCLS][8] dwords of LDS (the painter fills them and keeps their union in busy[4]); row_dwords(y, v[NG]); blank_dword()
+// (the packed value of a scanline outside busy);
 // static diff_classes(const P& a, const P& b) -> wave-uniform bit mask.
 template <class P>
 struct AgentFusedLds {
@@ -248,7 +249,7 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
     const uint32_t half = (uint32_t)(H * W) / 2u;
     const ColTaps c0 = load_col(a.tx, lane, a.ow), c1 = load_col(a.tx, lane + 64, a.ow);
     const bool on0 = lane < a.ow, on1 = lane + 64 < a.ow;
-    const uint32_t blank = P::blank_dword();
+    const uint32_t blank = pb.blank_dword();
     for (int i = lane; i < (AgentFusedLds<P>::ROWB - W) / 4; i += 64) reinterpret_cast<uint32_t*>(row + W)[i] = 0u;   // window padding
     uint32_t hb0, hb1;                                                 // horizontal sums of a blank scanline
     {
@@ -273,9 +274,9 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
     int oy = 0, top = H, pos = 0;
 #pragma unroll 1
     for (int wi = 0; wi < (H + 63) / 64; wi++) {
-        uint64_t nw = wi == 0 ? need[0] : wi == 1 ? need[1] : wi == 2 ? need[2] : need[3];
-        uint64_t bw = wi == 0 ? pb.busy[0] : wi == 1 ? pb.busy[1] : wi == 2 ? pb.busy[2] : pb.busy[3];
-        uint64_t aw = wi == 0 ? need_a[0] : wi == 1 ? need_a[1] : wi == 2 ? need_a[2] : need_a[3];
+        uint64_t nw = sel4(wi, need[0], need[1], need[2], need[3]);
+        uint64_t bw = sel4(wi, pb.busy[0], pb.busy[1], pb.busy[2], pb.busy[3]);
+        uint64_t aw = sel4(wi, need_a[0], need_a[1], need_a[2], need_a[3]);
         const int sy_end = min(H, 64 * wi + 64);
 #pragma unroll 1
         for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, bw >>= 1, aw >>= 1) {

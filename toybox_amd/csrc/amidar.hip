@@ -459,14 +459,13 @@ __device__ __forceinline__ void enemy_decide(AmiRegs& s, int lane, int slot)
         for (int dd = 0; dd < 4; dd++)
             if (dd != (cur ^ 1) && can_go(s, tx, ty, dd)) {
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (k == n) opts[k] = dd;
+                for (int k = 0; k < 4; k++) opts[k] = k == n ? dd : opts[k];   // value selects (see push_history)
                 n++;
             }
         if (n == 0) dir = can_go(s, tx, ty, cur ^ 1) ? (cur ^ 1) : -1;
         else {
             const int k = (int)s.rng.range((uint64_t)n);
-            dir = k == 0 ? opts[0] : k == 1 ? opts[1] : k == 2 ? opts[2] : opts[3];
+            dir = (int)sel4(k, (uint64_t)opts[0], (uint64_t)opts[1], (uint64_t)opts[2], (uint64_t)opts[3]);
         }
         if (dir >= 0) cur = dir;
         mset(s, lane, M_DIR, slot, cur);
@@ -658,170 +657,243 @@ __device__ __forceinline__ int world_to_px(int v)
     return v >= 0 ? v / TBX_AMI_WORLD_SCALE : -((-v + TBX_AMI_WORLD_SCALE - 1) / TBX_AMI_WORLD_SCALE);
 }
 
-// One wave rasterises one env; lane l makes pixels 4l..4l+3 of each scanline (160 px = 40 lanes).
-// In the board band a lane's 4 pixels are exactly one tile (tile = 4x5 px, board origin x = 16).
+// Everything one wave needs to paint scanlines of one env; lane l makes pixels 4l..4l+3 of each scanline (160 px = 40
+// lanes).  In the board band a lane's 4 pixels are exactly one tile (tile = 4x5 px, board origin x = 16).  Built once
+// per frame by setup(); paint_row() then composes one scanline (board, movers in index order then the player, HUD).
+template <int C>
+struct AmiPainter {
+    typedef AmiDev Dev;
+    static constexpr int W = TBX_AMI_W, H = TBX_AMI_H, NG = 1;
+    enum { CLS_BOARD, CLS_MOVER, CLS_HUD, NCLS };
+    static constexpr int BOARD_Y1 = TBX_AMI_BOARD_OY + BH * TBX_AMI_TILE_PH;
+    AmiRegs s;
+    int lane, x0, tx;
+    bool active, in_board_x, m_on;
+    uint32_t inner;                         // lane = board row: tiles strictly inside a painted box
+    int m_x0, m_y0;                         // lane = mover slot: screen rect origin
+    uint32_t hud[4];                        // bit 3*r = lit in glyph row r
+    uint32_t c_bg, c_inner, c_painted, c_unpainted, c_enemy, c_player;
+    uint64_t mv_rows[4];                    // scanlines crossed by a mover (wave-uniform)
+    uint64_t busy[4];                       // scanlines that are not plain background
+    mutable int ty_cached;
+    mutable uint32_t board_col;             // this lane's tile colour in tile row ty_cached
+
+    // cls: [NCLS][8] dwords of LDS private to this wave
+    __device__ __forceinline__ void setup(const AmiDev& d, int env, int lane_, uint32_t* cls)
+    {
+        lane = lane_;
+        const AmiTables& t = *d.tab;
+        ami_load(d, env, lane, s);
+        const int32_t* f = s.f;
+        x0 = lane * 4;
+        active = x0 < W;
+        tx = lane - TBX_AMI_BOARD_OX / 4;
+        in_board_x = tx >= 0 && tx < BW;
+        inner = 0;
+        for (int b = 0; b < f[A_N_BOXES]; b++) {
+            const uint32_t g = __shfl(s.bgeom, b), fl = __shfl(s.bflags, b);
+            if (!(fl & 1u)) continue;
+            const int tl_tx = g & 255, tl_ty = (g >> 8) & 255, br_tx = (g >> 16) & 255, br_ty = (g >> 24) & 255;
+            if (lane > tl_ty && lane < br_ty && br_tx - tl_tx >= 2) {
+                const int lo = tl_tx + 1, hi = br_tx - 1;   // inclusive
+                if (lo < 32) {
+                    const int h2 = hi > 31 ? 31 : hi;
+                    if (h2 >= lo) inner |= (h2 - lo + 1 >= 32 ? ~0u : ((1u << (h2 - lo + 1)) - 1u)) << lo;
+                }
+            }
+        }
+        m_on = lane == PLAYER_SLOT || (lane < f[A_N_ENEMIES] && !s.mv[M_CAUGHT]);
+        m_x0 = TBX_AMI_BOARD_OX + world_to_px(s.mv[M_X]) - 1; m_y0 = TBX_AMI_BOARD_OY + world_to_px(s.mv[M_Y]) - 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) hud[i] = 0;
+        {
+            int sc = f[A_SCORE];
+            if (sc < 0) sc = 0;
+            sc %= 100000;
+            int lv = f[A_LIVES];
+            lv = lv < 0 ? 0 : lv > 9 ? 9 : lv;
+            int jp = f[A_JUMPS];
+            jp = jp < 0 ? 0 : jp > 9 ? 9 : jp;
+            int le = f[A_LEVEL];
+            if (le < 0) le = 0;
+            le %= 10;
+            const int hud_x0[8] = {20, 28, 36, 44, 52, 84, 108, 132};
+            int div = 10000;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                int digit;
+                if (q < 5) { digit = (sc / div) % 10; div /= 10; }
+                else digit = q == 5 ? lv : q == 6 ? jp : le;
+                const uint32_t glyph = AMI_DIGITS[digit];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int dx = x0 + i - hud_x0[q];
+                    if (dx >= 0 && dx < 6) hud[i] = (glyph >> (dx >> 1)) & 0x1249u;
+                }
+            }
+        }
+        // palette through pix_of<C>() once; the scanline loop only moves finished pixel values
+        c_bg = pix_of<C>(t.bg); c_inner = pix_of<C>(t.inner); c_painted = pix_of<C>(t.painted);
+        c_unpainted = pix_of<C>(t.unpainted); c_enemy = pix_of<C>(t.enemy); c_player = pix_of<C>(t.player);
+        ty_cached = -1;
+        board_col = c_bg;
+
+        // scanline masks per class in LDS: every mover lane ORs its rows; board band and HUD rows are fixed
+        for (int i = lane; i < NCLS * 8; i += 64) cls[i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t w = m_on ? row_range_bits(m_y0, (long)m_y0 + TBX_AMI_MOVER_H, k) : 0ull;
+            if ((uint32_t)w) atomicOr(&cls[CLS_MOVER * 8 + 2 * k], (uint32_t)w);
+            if ((uint32_t)(w >> 32)) atomicOr(&cls[CLS_MOVER * 8 + 2 * k + 1], (uint32_t)(w >> 32));
+            if (lane == 0) {
+                const uint64_t wb = row_range_bits(TBX_AMI_BOARD_OY, BOARD_Y1, k), wh = row_range_bits(TBX_AMI_HUD_Y, TBX_AMI_HUD_Y + 10, k);
+                cls[CLS_BOARD * 8 + 2 * k] = (uint32_t)wb; cls[CLS_BOARD * 8 + 2 * k + 1] = (uint32_t)(wb >> 32);
+                cls[CLS_HUD * 8 + 2 * k] = (uint32_t)wh; cls[CLS_HUD * 8 + 2 * k + 1] = (uint32_t)(wh >> 32);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t mlo = __builtin_amdgcn_readfirstlane(cls[CLS_MOVER * 8 + 2 * k]), mhi = __builtin_amdgcn_readfirstlane(cls[CLS_MOVER * 8 + 2 * k + 1]);
+            mv_rows[k] = (uint64_t)mlo | ((uint64_t)mhi << 32);
+            busy[k] = mv_rows[k] | row_range_bits(TBX_AMI_BOARD_OY, BOARD_Y1, k) | row_range_bits(TBX_AMI_HUD_Y, TBX_AMI_HUD_Y + 10, k);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // the classes whose entities differ between two states of one env (wave-uniform bit mask)
+    static __device__ __forceinline__ uint32_t diff_classes(const AmiPainter& a, const AmiPainter& b)
+    {
+        uint32_t m = 0u;
+        if (__ballot(a.s.trow != b.s.trow || a.inner != b.inner)) m |= 1u << CLS_BOARD;
+        if (__ballot(a.m_on != b.m_on || (b.m_on && (a.m_x0 != b.m_x0 || a.m_y0 != b.m_y0)))) m |= 1u << CLS_MOVER;
+        if (__ballot(a.hud[0] != b.hud[0] || a.hud[1] != b.hud[1] || a.hud[2] != b.hud[2] || a.hud[3] != b.hud[3])) m |= 1u << CLS_HUD;
+        return (uint32_t)wave_uniform((int)m);
+    }
+
+    // one scanline as finished pixel values; mover_row: a mover crosses it (bit of mv_rows)
+    __device__ __forceinline__ void paint_row(int y, bool mover_row, uint32_t (&px)[4]) const
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) px[i] = c_bg;
+        const int by = y - TBX_AMI_BOARD_OY;
+        if (by >= 0 && by < BH * TBX_AMI_TILE_PH) {
+            const int ty = by / TBX_AMI_TILE_PH;
+            if (ty != ty_cached) {                       // five scanlines share a tile row
+                ty_cached = ty;
+                const uint64_t row = row_of(s, ty);
+                const uint32_t inn = __shfl(inner, ty);
+                board_col = c_bg;
+                if (in_board_x) {
+                    const int tag = (int)((row >> (2 * tx)) & 3ull);
+                    if (tag == TBX_TILE_EMPTY) { if ((inn >> tx) & 1u) board_col = c_inner; }
+                    else board_col = tag == TBX_TILE_PAINTED ? c_painted : c_unpainted;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) px[i] = board_col;
+        }
+        // movers: enemies in index order, then the player
+        if (mover_row) {
+            uint64_t m = __ballot(m_on && y >= m_y0 && y < m_y0 + TBX_AMI_MOVER_H);
+            const bool player_here = (m >> PLAYER_SLOT) & 1;
+            m &= (1ull << PLAYER_SLOT) - 1;
+            while (m) {
+                const int src = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const int sx = __shfl(m_x0, src);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = c_enemy;
+            }
+            if (player_here) {
+                const int sx = __shfl(m_x0, PLAYER_SLOT);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = c_player;
+            }
+        }
+        if (y >= TBX_AMI_HUD_Y && y < TBX_AMI_HUD_Y + 10) {
+            const int gr = ((y - TBX_AMI_HUD_Y) >> 1) * 3;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if ((hud[i] >> gr) & 1u) px[i] = c_player;
+        }
+    }
+};
+
+struct AmiGrayPainter : AmiPainter<1> {
+    static __device__ __forceinline__ uint32_t diff_classes(const AmiGrayPainter& a, const AmiGrayPainter& b) { return AmiPainter<1>::diff_classes(a, b); }
+    // the background colour comes from the config table, so the blank value is per engine, not a constant
+    __device__ __forceinline__ uint32_t blank_dword() const { return c_bg * 0x01010101u; }
+    __device__ __forceinline__ void row_dwords(int y, uint32_t (&v)[1]) const
+    {
+        const int wi = y >> 6;
+        const uint64_t mw = sel4(wi, mv_rows[0], mv_rows[1], mv_rows[2], mv_rows[3]);
+        uint32_t px[4];
+        paint_row(y, (mw >> (y & 63)) & 1ull, px);
+        v[0] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+    }
+};
+
+// One wave rasterises one env; AMI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte stores, background-only
+// units are stored directly.
 template <int C>
 __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t* out, int first_env, int count)
 {
     constexpr int W = TBX_AMI_W, H = TBX_AMI_H;
     using Stager = RowStager<C, W, AMI_UNIT_ROWS>;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
-    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][8];
+    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][AmiPainter<C>::NCLS * 8];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
     if (rel >= count) return;
     const int env = first_env + rel;
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
-    const AmiTables& t = *d.tab;
-
-    AmiRegs s;
-    ami_load(d, env, lane, s);
-    const int32_t* f = s.f;
-    const int x0 = lane * 4;
-    const bool active = x0 < W;
-    const int tx = lane - TBX_AMI_BOARD_OX / 4;          // tile column of this lane in the board band
-    const bool in_board_x = tx >= 0 && tx < BW;
-
-    // lane = board row: which tiles lie strictly inside a painted box
-    uint32_t inner = 0;
-    for (int b = 0; b < f[A_N_BOXES]; b++) {
-        const uint32_t g = __shfl(s.bgeom, b), fl = __shfl(s.bflags, b);
-        if (!(fl & 1u)) continue;
-        const int tl_tx = g & 255, tl_ty = (g >> 8) & 255, br_tx = (g >> 16) & 255, br_ty = (g >> 24) & 255;
-        if (lane > tl_ty && lane < br_ty && br_tx - tl_tx >= 2) {
-            const int lo = tl_tx + 1, hi = br_tx - 1;   // inclusive
-            if (lo < 32) {
-                const int h2 = hi > 31 ? 31 : hi;
-                if (h2 >= lo) inner |= (h2 - lo + 1 >= 32 ? ~0u : ((1u << (h2 - lo + 1)) - 1u)) << lo;
-            }
-        }
-    }
-    // lane = mover slot: screen rects
-    const bool m_on = lane == PLAYER_SLOT || (lane < f[A_N_ENEMIES] && !s.mv[M_CAUGHT]);
-    const int m_x0 = TBX_AMI_BOARD_OX + world_to_px(s.mv[M_X]) - 1, m_y0 = TBX_AMI_BOARD_OY + world_to_px(s.mv[M_Y]) - 1;
-
-    // HUD bits per pixel
-    uint32_t hud[4] = {0, 0, 0, 0};
-    {
-        int sc = f[A_SCORE];
-        if (sc < 0) sc = 0;
-        sc %= 100000;
-        int lv = f[A_LIVES];
-        lv = lv < 0 ? 0 : lv > 9 ? 9 : lv;
-        int jp = f[A_JUMPS];
-        jp = jp < 0 ? 0 : jp > 9 ? 9 : jp;
-        int le = f[A_LEVEL];
-        if (le < 0) le = 0;
-        le %= 10;
-        const int hud_x0[8] = {20, 28, 36, 44, 52, 84, 108, 132};
-        int div = 10000;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            int digit;
-            if (q < 5) { digit = (sc / div) % 10; div /= 10; }
-            else digit = q == 5 ? lv : q == 6 ? jp : le;
-            const uint32_t glyph = AMI_DIGITS[digit];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int dx = x0 + i - hud_x0[q];
-                if (dx >= 0 && dx < 6) hud[i] = (glyph >> (dx >> 1)) & 0x1249u;
-            }
-        }
-    }
-
-    // palette through pix_of<C>() once; the scanline loop only moves finished pixel values
-    const uint32_t c_bg = pix_of<C>(t.bg), c_inner = pix_of<C>(t.inner), c_painted = pix_of<C>(t.painted);
-    const uint32_t c_unpainted = pix_of<C>(t.unpainted), c_enemy = pix_of<C>(t.enemy), c_player = pix_of<C>(t.player);
-
-    // scanlines crossed by a mover: every mover lane ORs its rows into the wave's 256-bit mask in LDS
-    uint64_t mv_rows[4];
-    {
-        uint32_t* bm = lds_mask[wave];
-        if (lane < 8) bm[lane] = 0u;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint64_t w = m_on ? row_range_bits(m_y0, (long)m_y0 + TBX_AMI_MOVER_H, k) : 0ull;
-            if ((uint32_t)w) atomicOr(&bm[2 * k], (uint32_t)w);
-            if ((uint32_t)(w >> 32)) atomicOr(&bm[2 * k + 1], (uint32_t)(w >> 32));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t lo = __builtin_amdgcn_readfirstlane(bm[2 * k]), hi = __builtin_amdgcn_readfirstlane(bm[2 * k + 1]);
-            mv_rows[k] = (uint64_t)lo | ((uint64_t)hi << 32);
-        }
-    }
+    AmiPainter<C> p;
+    p.setup(d, env, lane, lds_mask[wave]);
 
     uint8_t* frame = out + (size_t)rel * H * W * C;
     constexpr int NUNITS = H / AMI_UNIT_ROWS;
-    constexpr int BOARD_Y1 = TBX_AMI_BOARD_OY + BH * TBX_AMI_TILE_PH;
     const int u0 = (int)(((uint32_t)env * 7u) % (uint32_t)NUNITS);
-    int ty_cached = -1;
-    uint32_t board_col = c_bg;                               // this lane's tile colour in tile row ty_cached
     for (int k = 0; k < NUNITS; k++) {
         int u = u0 + k;
         if (u >= NUNITS) u -= NUNITS;
         const int y_first = u * AMI_UNIT_ROWS;
-        const uint32_t mv_chunk = row_mask_chunk<AMI_UNIT_ROWS>(mv_rows, y_first);
-        const bool board_unit = y_first + AMI_UNIT_ROWS > TBX_AMI_BOARD_OY && y_first < BOARD_Y1;
-        const bool hud_unit = y_first + AMI_UNIT_ROWS > TBX_AMI_HUD_Y && y_first < TBX_AMI_HUD_Y + 10;
-        if (!board_unit && !hud_unit && mv_chunk == 0 && C != 4) {   // background only: no staging (RGBA: staged is faster)
-            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, c_bg);
+        const uint32_t mv_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.mv_rows, y_first);
+        const uint32_t busy_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.busy, y_first);
+        if (busy_chunk == 0 && C != 4) {                     // background only: no staging (RGBA: staged is faster)
+            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_bg);
             continue;
         }
 #pragma unroll 1
         for (int r = 0; r < AMI_UNIT_ROWS; r++) {
-            const int y = y_first + r;
-            uint32_t px[4] = {c_bg, c_bg, c_bg, c_bg};
-            const int by = y - TBX_AMI_BOARD_OY;
-            if (by >= 0 && by < BH * TBX_AMI_TILE_PH) {
-                const int ty = by / TBX_AMI_TILE_PH;
-                if (ty != ty_cached) {                       // five scanlines share a tile row
-                    ty_cached = ty;
-                    const uint64_t row = row_of(s, ty);
-                    const uint32_t inn = __shfl(inner, ty);
-                    board_col = c_bg;
-                    if (in_board_x) {
-                        const int tag = (int)((row >> (2 * tx)) & 3ull);
-                        if (tag == TBX_TILE_EMPTY) { if ((inn >> tx) & 1u) board_col = c_inner; }
-                        else board_col = tag == TBX_TILE_PAINTED ? c_painted : c_unpainted;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++) px[i] = board_col;
-            }
-            // movers: enemies in index order, then the player
-            if ((mv_chunk >> r) & 1u) {
-                uint64_t m = __ballot(m_on && y >= m_y0 && y < m_y0 + TBX_AMI_MOVER_H);
-                const bool player_here = (m >> PLAYER_SLOT) & 1;
-                m &= (1ull << PLAYER_SLOT) - 1;
-                while (m) {
-                    const int src = (int)__builtin_ctzll(m);
-                    m &= m - 1;
-                    const int sx = __shfl(m_x0, src);
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = c_enemy;
-                }
-                if (player_here) {
-                    const int sx = __shfl(m_x0, PLAYER_SLOT);
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = c_player;
-                }
-            }
-            if (y >= TBX_AMI_HUD_Y && y < TBX_AMI_HUD_Y + 10) {
-                const int gr = ((y - TBX_AMI_HUD_Y) >> 1) * 3;
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if ((hud[i] >> gr) & 1u) px[i] = c_player;
-            }
-            if (active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
+            uint32_t px[4];
+            p.paint_row(y_first + r, (mv_chunk >> r) & 1u, px);
+            if (p.active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
         }
         st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
     }
+}
+
+// ------------------------------------------------------------------ fused agent observation
+//
+// max(frame A, frame B) -> gray -> area warp -> frame stack without the two full-resolution gray frames ever reaching
+// HBM: agent_fused_wave (agent_device.hpp) with two AmiGrayPainters in one wave per env.
+template <int S>
+__global__ __launch_bounds__(TBX_BLOCK) void ami_agent_warp_kernel(AmiDev dA, AmiDev dB, AgentWarpArgs a, int n)
+{
+    __shared__ AgentFusedLds<AmiGrayPainter> lds[TBX_WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (env >= n) return;
+    AmiGrayPainter pa, pb;
+    agent_fused_wave<S, AmiGrayPainter>(pa, pb, dA, dB, a, env, lane, lds[wave]);
 }
 
 // ------------------------------------------------------------------ state pack / unpack, scalars
@@ -1003,6 +1075,7 @@ struct AmiOps : GameOps {
     void destroy(tbx_engine*) override
     {
         hipFree(d.rng); hipFree(d.sc); hipFree(d.tiles); hipFree(d.boxes); hipFree(d.movers); hipFree(tab_dev);
+        hipFree(dA.sc); hipFree(dA.tiles); hipFree(dA.boxes); hipFree(dA.movers);
     }
 
     int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
@@ -1029,6 +1102,46 @@ struct AmiOps : GameOps {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    // ---- fused agent observation: frame A is a snapshot of the dynamic SoA state, frame B the live state
+    AmiDev dA{};
+    bool agent_fused() const override { return true; }
+
+    int agent_snapshot(tbx_engine* e, int which, hipStream_t s) override
+    {
+        if (which != 0) return TBX_OK;                       // frame B is read from the live state
+        const size_t N = (size_t)e->n;
+        if (!dA.sc) {
+            dA = d;
+            dA.sc = nullptr; dA.tiles = nullptr; dA.boxes = nullptr; dA.movers = nullptr;
+            TBX_HIP(hipMalloc((void**)&dA.sc, (size_t)ANF * N * sizeof(int32_t)));
+            TBX_HIP(hipMalloc((void**)&dA.tiles, N * 32 * sizeof(uint64_t)));
+            TBX_HIP(hipMalloc((void**)&dA.boxes, N * 128 * sizeof(uint32_t)));
+            TBX_HIP(hipMalloc((void**)&dA.movers, N * NMF * 16 * sizeof(int32_t)));
+        }
+        dA.tab = d.tab;
+        TBX_HIP(hipMemcpyAsync(dA.sc, d.sc, (size_t)ANF * N * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        TBX_HIP(hipMemcpyAsync(dA.tiles, d.tiles, N * 32 * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+        TBX_HIP(hipMemcpyAsync(dA.boxes, d.boxes, N * 128 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        TBX_HIP(hipMemcpyAsync(dA.movers, d.movers, N * NMF * 16 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        return TBX_OK;
+    }
+
+    int agent_warp(tbx_engine* e, const AgentWarpArgs& a, hipStream_t s) override
+    {
+        AgentWarpArgs w = a;
+        if (!dA.sc) w.two_frames = 0;                        // no snapshot yet (reset, or skip == 1): frame B alone
+        const AmiDev& A = dA.sc ? dA : d;
+        const dim3 grid = grid_for(e->n), block(TBX_BLOCK);
+        switch (a.stack) {
+        case 1: hipLaunchKernelGGL(ami_agent_warp_kernel<1>, grid, block, 0, s, A, d, w, e->n); break;
+        case 2: hipLaunchKernelGGL(ami_agent_warp_kernel<2>, grid, block, 0, s, A, d, w, e->n); break;
+        case 3: hipLaunchKernelGGL(ami_agent_warp_kernel<3>, grid, block, 0, s, A, d, w, e->n); break;
+        default: hipLaunchKernelGGL(ami_agent_warp_kernel<4>, grid, block, 0, s, A, d, w, e->n); break;
+        }
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

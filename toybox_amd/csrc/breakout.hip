@@ -518,7 +518,7 @@ struct BrkT {
 
 __device__ __forceinline__ bool t_alive(const BrkT& s, int j)
 {
-    const uint64_t w = j < 64 ? s.alive[0] : j < 128 ? s.alive[1] : j < 192 ? s.alive[2] : s.alive[3];
+    const uint64_t w = sel4(j >> 6, s.alive[0], s.alive[1], s.alive[2], s.alive[3]);   // values, not lvalues (scratch)
     return (w >> (j & 63)) & 1ull;
 }
 
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
         uint64_t ov[3] = {0ull, 0ull, 0ull};
         brk_overlay_rows(rec, ov);
         const int ow = y_first >> 6, ob = y_first & 63;      // units are 8 rows at multiples of 8: never straddle a word
-        const uint32_t ov_chunk = (uint32_t)((ow == 0 ? ov[0] : ow == 1 ? ov[1] : ov[2]) >> ob) & ((1u << BRK_UNIT_ROWS) - 1u);
+        const uint32_t ov_chunk = (uint32_t)(sel4(ow, ov[0], ov[1], ov[2], 0ull) >> ob) & ((1u << BRK_UNIT_ROWS) - 1u);
 
 #pragma unroll 1
         for (int r = 0; r < BRK_UNIT_ROWS; r++) {
@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
                             const int bxp = x0 + i - 12;
                             if (bxp >= 0 && bxp < 216) {
                                 const int j = (bxp / 12) * rows + row;   // < 256 (18*14 = 252)
-                                const uint64_t w = (j < 64) ? rec.alive[0] : (j < 128) ? rec.alive[1] : (j < 192) ? rec.alive[2] : rec.alive[3];
+                                const uint64_t w = sel4(j >> 6, rec.alive[0], rec.alive[1], rec.alive[2], rec.alive[3]);
                                 if ((w >> (j & 63)) & 1ull) brick4[i] = rc;
                             }
                         }
@@ -1086,7 +1086,7 @@ __device__ __forceinline__ uint32_t brk_gray_line(const BrkRenderRec& rec, const
                 const int bxp = x0 + i - 12;
                 if (bxp >= 0 && bxp < 216) {
                     const int j = (bxp / 12) * pal.rows + row;
-                    const uint64_t w = (j < 64) ? rec.alive[0] : (j < 128) ? rec.alive[1] : (j < 192) ? rec.alive[2] : rec.alive[3];
+                    const uint64_t w = sel4(j >> 6, rec.alive[0], rec.alive[1], rec.alive[2], rec.alive[3]);
                     if ((w >> (j & 63)) & 1ull) b = (b & ~(0xFFu << (8 * i))) | (pal.row[row] << (8 * i));
                 }
             }
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
     uint32_t h0 = 0, h1 = 0;
     uint32_t acc0[2] = {0, 0}, acc1[2] = {0, 0};
     for (int sy = 0; sy < H; sy++) {
-        const uint64_t nw = sy < 64 ? need[0] : sy < 128 ? need[1] : need[2];
+        const uint64_t nw = sel4(sy >> 6, need[0], need[1], need[2], 0ull);
         if ((nw >> (sy & 63)) & 1ull) {
             const uint32_t dB = brk_gray_line(recB, pal, sy, x0, side_dw, hudB, bcB);
             uint32_t v = dB;

@@ -56,13 +56,17 @@ __device__ __forceinline__ uint64_t row_range_bits(long a, long b, int k)
     return (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << sh;
 }
 
+// m[w] for a run-time w by VALUE (a conditional over array elements is a select of addresses, which pushes the
+// enclosing object into scratch)
+__device__ __forceinline__ uint64_t sel4(int w, uint64_t a, uint64_t b, uint64_t c, uint64_t d) { return w == 0 ? a : w == 1 ? b : w == 2 ? c : d; }
+
 // R consecutive row bits starting at row `pos` of a 256-row mask held as four wave-uniform words
 template <int R>
 __device__ __forceinline__ uint32_t row_mask_chunk(const uint64_t (&m)[4], int pos)
 {
     const int w = pos >> 6, b = pos & 63;
-    const uint64_t cur = w == 0 ? m[0] : w == 1 ? m[1] : w == 2 ? m[2] : m[3];
-    const uint64_t nxt = w == 0 ? m[1] : w == 1 ? m[2] : w == 2 ? m[3] : 0ull;
+    const uint64_t cur = sel4(w, m[0], m[1], m[2], m[3]);
+    const uint64_t nxt = sel4(w, m[1], m[2], m[3], 0ull);
     uint64_t v = cur >> b;
     if (b > 64 - R) v |= nxt << (64 - b);
     return (uint32_t)v & ((1u << R) - 1u);

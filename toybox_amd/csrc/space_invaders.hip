@@ -877,7 +877,7 @@ __device__ __forceinline__ void si_row_dwords(const SiPainter<C>& p, int y, uint
 
 struct SiGrayPainter : SiPainter<1> {
     static __device__ __forceinline__ uint32_t diff_classes(const SiGrayPainter& a, const SiGrayPainter& b) { return SiPainter<1>::diff_classes(a, b); }
-    static __device__ __forceinline__ uint32_t blank_dword() { return 0u; }      // black is gray 0
+    __device__ __forceinline__ uint32_t blank_dword() const { return 0u; }       // black is gray 0
     __device__ __forceinline__ void row_dwords(int y, uint32_t (&v)[SI_NG]) const { si_row_dwords<1>(*this, y, v); }
 };
 
