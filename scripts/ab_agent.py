@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""A/B timing of the agent step of several library builds on ONE box, interleaved.  usage: ab_agent.py game lib1.so lib2.so ..."""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from toybox_amd import Engine, _abi, hip  # noqa: E402
+
+game = sys.argv[1]
+libs = []
+for p in sys.argv[2:]:
+    lib = C.CDLL(p)
+    _abi.bind(lib)
+    libs.append((p, lib))
+n = 65536
+for rnd in range(3):
+    for p, lib in libs:
+        e = Engine(game, n, lib=lib)
+        e.seed(1234)
+        e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True)
+        e.agent_reset()
+        for t in range(10):
+            e.agent_step_synthetic(1337, t)
+        hip.synchronize()
+        t0 = time.perf_counter()
+        for t in range(10, 70):
+            e.agent_step_synthetic(1337, t)
+        hip.synchronize()
+        dt = (time.perf_counter() - t0) / 60
+        print("round %d %-30s %.4f ms  %.2f M agent-steps/s" % (rnd, p.split("/")[-1], dt * 1e3, n / dt / 1e6), flush=True)
+        e.close()
