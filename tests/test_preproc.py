@@ -182,20 +182,23 @@ def test_gpu_fused_preprocessing_parity(game, hip_lib, oracle_lib):
 
 
 @pytest.mark.gpu
-def test_gpu_breakout_fused_observation_equals_generic_path(hip_lib, monkeypatch):
-    """Breakout's record-based observation kernel (no full-resolution frames) == the generic render + warp path."""
+@pytest.mark.parametrize("game,skip,oh,ow,stack", [("breakout", 4, 84, 84, 4), ("space_invaders", 4, 84, 84, 4), ("amidar", 4, 84, 84, 4),
+                                                  ("space_invaders", 3, 60, 100, 2), ("amidar", 2, 50, 40, 3), ("amidar", 1, 84, 84, 4)])
+def test_gpu_fused_observation_equals_generic_path(game, skip, oh, ow, stack, hip_lib, monkeypatch):
+    """The per-game fused observation kernels (Breakout: from render records; SpaceInvaders / Amidar: two painters per wave
+    with class-diff scanline skipping; no full-resolution frames) == the generic render + warp path, through episode ends."""
     n = 512
     monkeypatch.setenv("TBX_AGENT_GENERIC", "1")
-    gen = Engine("breakout", n, lib=hip_lib)
+    gen = Engine(game, n, lib=hip_lib)
     gen.seed(77)
-    gen.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=False)
+    gen.agent_init(skip=skip, out_h=oh, out_w=ow, stack=stack, clip_reward=False)
     monkeypatch.setenv("TBX_AGENT_GENERIC", "0")
-    fus = Engine("breakout", n, lib=hip_lib)
+    fus = Engine(game, n, lib=hip_lib)
     fus.seed(77)
-    fus.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=False)
+    fus.agent_init(skip=skip, out_h=oh, out_w=ow, stack=stack, clip_reward=False)
     assert np.array_equal(gen.agent_reset(), fus.agent_reset())
-    for t in range(500):
-        a = synthetic_actions("breakout", n, t, seed=8)
+    for t in range(500 if game == "breakout" else 300):
+        a = synthetic_actions(game, n, t, seed=8)
         x, y = gen.agent_step(a), fus.agent_step(a)
         for p, q in zip(x, y):
             assert np.array_equal(p, q), t
