@@ -525,10 +525,9 @@ __device__ __forceinline__ bool t_alive(const BrkT& s, int j)
 __device__ __forceinline__ void t_kill(BrkT& s, int j)
 {
     const uint64_t m = ~(1ull << (j & 63));
-    if (j < 64) s.alive[0] &= m;
-    else if (j < 128) s.alive[1] &= m;
-    else if (j < 192) s.alive[2] &= m;
-    else s.alive[3] &= m;
+    const int w = j >> 6;
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) s.alive[k] &= k == w ? m : ~0ull;   // every word written: no select of addresses
 }
 
 __device__ __forceinline__ void t_fill_wall(BrkT& s)
@@ -549,7 +548,10 @@ __device__ __forceinline__ void t_start_ball(const BrkCfg& c, BrkT& s)
     const double vx = c.speed_slow * c.start_dx[i], vy = c.speed_slow * c.start_dy[i];
 #pragma unroll
     for (int b = 0; b < MAXB; b++)
-        if (b == k) { s.bx[b] = x; s.by[b] = y; s.bvx[b] = vx; s.bvy[b] = vy; }
+{   // value selects: an `if (b == k) a[b] = v` chain is folded into a[k] = v, which sends the arrays to scratch
+            s.bx[b] = b == k ? x : s.bx[b]; s.by[b] = b == k ? y : s.by[b];
+            s.bvx[b] = b == k ? vx : s.bvx[b]; s.bvy[b] = b == k ? vy : s.bvy[b];
+        }
     s.n_balls = k + 1;
 }
 
@@ -725,7 +727,10 @@ __device__ __forceinline__ void brk_t_step(const BrkCfg& c, BrkT& s, uint32_t bu
                 const double x = s.bx[b], y = s.by[b], vx = s.bvx[b], vy = s.bvy[b];
 #pragma unroll
                 for (int kk = 0; kk < MAXB; kk++)
-                    if (kk == kdst) { s.bx[kk] = x; s.by[kk] = y; s.bvx[kk] = vx; s.bvy[kk] = vy; }
+{
+                        s.bx[kk] = kk == kdst ? x : s.bx[kk]; s.by[kk] = kk == kdst ? y : s.by[kk];
+                        s.bvx[kk] = kk == kdst ? vx : s.bvx[kk]; s.bvy[kk] = kk == kdst ? vy : s.bvy[kk];
+                    }
                 kdst++;
             }
         }
