@@ -1188,32 +1188,43 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
     }
     uint32_t h0 = 0, h1 = 0;
     uint32_t acc0[2] = {0, 0}, acc1[2] = {0, 0};
-    for (int sy = 0; sy < H; sy++) {
-        const uint64_t nw = sel4(sy >> 6, need[0], need[1], need[2], 0ull);
-        if ((nw >> (sy & 63)) & 1ull) {
-            const uint32_t dB = brk_gray_line(recB, pal, sy, x0, side_dw, hudB, bcB);
-            uint32_t v = dB;
-            if (!fresh) v = bytemax4(brk_gray_line(recA, pal, sy, x0, side_dw, hudA, bcA), dB);
-            if (active) reinterpret_cast<uint32_t*>(row)[lane] = v;
-            __builtin_amdgcn_wave_barrier();
-            h0 = on0 ? hsum(row, c0) : 0u;
-            h1 = on1 ? hsum(row, c1) : 0u;
-            __builtin_amdgcn_wave_barrier();
-        }
-        const int oy = (sy * a.oh) / H;
-        const int top = (oy + 1) * H;
-        const int w_cur = min((sy + 1) * a.oh, top) - sy * a.oh, w_next = a.oh - w_cur;
-        acc0[0] += (uint32_t)w_cur * h0; acc0[1] += (uint32_t)w_cur * h1;
-        acc1[0] += (uint32_t)w_next * h0; acc1[1] += (uint32_t)w_next * h1;
-        if ((sy + 1) * a.oh >= top) {
+    // source row sy covers [sy*oh, (sy+1)*oh), output row oy covers [oy*H, (oy+1)*H) in refined units: both walk
+    // incrementally (no division per scanline) and the need mask is consumed one bit per scanline -- this kernel was
+    // SALU-bound (86 % of issue slots) on exactly that bookkeeping
+    int oy = 0, top = H, pos = 0;
+#pragma unroll 1
+    for (int wi = 0; wi < 3; wi++) {
+        uint64_t nw = sel4(wi, need[0], need[1], need[2], 0ull);
+        const int sy_end = min(H, 64 * wi + 64);
+#pragma unroll 1
+        for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1) {
+            if (nw & 1ull) {
+                const uint32_t dB = brk_gray_line(recB, pal, sy, x0, side_dw, hudB, bcB);
+                uint32_t v = dB;
+                if (!fresh) v = bytemax4(brk_gray_line(recA, pal, sy, x0, side_dw, hudA, bcA), dB);
+                if (active) reinterpret_cast<uint32_t*>(row)[lane] = v;
+                __builtin_amdgcn_wave_barrier();
+                h0 = on0 ? hsum(row, c0) : 0u;
+                h1 = on1 ? hsum(row, c1) : 0u;
+                __builtin_amdgcn_wave_barrier();
+            }
+            const int pos_next = pos + a.oh;
+            const int w_cur = min(pos_next, top) - pos, w_next = a.oh - w_cur;
+            acc0[0] += (uint32_t)w_cur * h0; acc0[1] += (uint32_t)w_cur * h1;
+            acc1[0] += (uint32_t)w_next * h0; acc1[1] += (uint32_t)w_next * h1;
+            pos = pos_next;
+            if (pos_next >= top) {
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int ox = lane + 64 * q;
-                if (q == 0 ? on0 : on1) {
-                    vals[oy * a.ow + ox] = (uint8_t)(((uint64_t)(acc0[q] + half) * a.magic) >> 42);
+                for (int q = 0; q < 2; q++) {
+                    const int ox = lane + 64 * q;
+                    if (q == 0 ? on0 : on1) {
+                        vals[oy * a.ow + ox] = (uint8_t)(((uint64_t)(acc0[q] + half) * a.magic) >> 42);
+                    }
+                    acc0[q] = acc1[q];
+                    acc1[q] = 0;
                 }
-                acc0[q] = acc1[q];
-                acc1[q] = 0;
+                oy += 1;
+                top += H;
             }
         }
     }
