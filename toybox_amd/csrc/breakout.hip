@@ -1073,8 +1073,9 @@ struct BrkGrayPal {
 struct BrkLineCache { int row; uint32_t dw; };
 
 // one scanline of one record as 4 gray bytes
+// has_overlay: the paddle or a ball of this record crosses scanline y (bit of brk_overlay_rows)
 __device__ __forceinline__ uint32_t brk_gray_line(const BrkRenderRec& rec, const BrkGrayPal& pal, int y, int x0, uint32_t side_dw,
-                                                  const uint32_t (&hud)[4], BrkLineCache& bc)
+                                                  const uint32_t (&hud)[4], BrkLineCache& bc, bool has_overlay)
 {
     uint32_t d;
     if (y < TBX_BRK_WALL_Y0) d = pal.bg * 0x01010101u;
@@ -1102,6 +1103,7 @@ __device__ __forceinline__ uint32_t brk_gray_line(const BrkRenderRec& rec, const
     // paddle, balls: packed clipped rects of the record
 #pragma unroll
     for (int k = 0; k < 1 + MAXB; k++) {
+        if (!has_overlay) break;
         const uint32_t rc = k == 0 ? rec.paddle : rec.ball[k - 1];
         const int ry0 = (int)((rc >> 16) & 255u), ry1 = (int)(rc >> 24);
         if (y >= ry0 && y < ry1) {
@@ -1175,12 +1177,13 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
 
     BrkLineCache bcA{-1, 0}, bcB{-1, 0};
     uint64_t need[3] = {pal.boundary[0], pal.boundary[1], pal.boundary[2]};   // scanlines that must be composed
+    uint64_t ovA[3] = {0, 0, 0}, ovB[3] = {0, 0, 0};
     {
-        uint64_t ov[3] = {0, 0, 0};
-        brk_overlay_rows(recB, ov);
-        if (!fresh) brk_overlay_rows(recA, ov);
+        brk_overlay_rows(recB, ovB);
+        if (!fresh) brk_overlay_rows(recA, ovA);
+        uint64_t ov[3];
 #pragma unroll
-        for (int w = 0; w < 3; w++) need[w] |= ov[w];
+        for (int w = 0; w < 3; w++) { ov[w] = ovA[w] | ovB[w]; need[w] |= ov[w]; }
         // the line after a run of overlay lines differs from it as well
         need[2] |= (ov[2] << 1) | (ov[1] >> 63);
         need[1] |= (ov[1] << 1) | (ov[0] >> 63);
@@ -1195,13 +1198,14 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
 #pragma unroll 1
     for (int wi = 0; wi < 3; wi++) {
         uint64_t nw = sel4(wi, need[0], need[1], need[2], 0ull);
+        uint64_t oa = sel4(wi, ovA[0], ovA[1], ovA[2], 0ull), ob = sel4(wi, ovB[0], ovB[1], ovB[2], 0ull);
         const int sy_end = min(H, 64 * wi + 64);
 #pragma unroll 1
-        for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1) {
+        for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, oa >>= 1, ob >>= 1) {
             if (nw & 1ull) {
-                const uint32_t dB = brk_gray_line(recB, pal, sy, x0, side_dw, hudB, bcB);
+                const uint32_t dB = brk_gray_line(recB, pal, sy, x0, side_dw, hudB, bcB, ob & 1ull);
                 uint32_t v = dB;
-                if (!fresh) v = bytemax4(brk_gray_line(recA, pal, sy, x0, side_dw, hudA, bcA), dB);
+                if (!fresh) v = bytemax4(brk_gray_line(recA, pal, sy, x0, side_dw, hudA, bcA, oa & 1ull), dB);
                 if (active) reinterpret_cast<uint32_t*>(row)[lane] = v;
                 __builtin_amdgcn_wave_barrier();
                 h0 = on0 ? hsum(row, c0) : 0u;
