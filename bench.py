@@ -248,6 +248,8 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)                       # --force-dist without a launcher: a world of one
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     hip.set_device(local_rank)
 
