@@ -251,3 +251,29 @@ def test_amidar_protocols_parity(hip_lib, oracle_lib):
         e.set_state(0, st)
     for ch in (1, 3, 4):
         assert np.array_equal(g.render(ch), o.render(ch))
+
+
+@pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar"])
+def test_full_size_batch_parity(game, hip_lib, oracle_lib, monkeypatch):
+    """BASELINE's batch size (65 536 envs, seeds 1234+i): every per-step output of every env equals the CPU restatement for
+    1200 auto-resetting frames; full state records and frames are compared on a sample (the records alone would be ~1 GB),
+    and the score / lives / level vectors of the whole batch at the end."""
+    monkeypatch.setenv("TBX_ORACLE_THREADS", str(min(16, len(__import__("os").sched_getaffinity(0)))))
+    n, steps = 65536, 1200
+    g, o = _pair(game, n, hip_lib, oracle_lib)
+    sample = np.random.default_rng(1).choice(n, 96, replace=False)
+    acc = np.zeros(n, np.int64)
+    dones = 0
+    for t in range(steps):
+        a = synthetic_actions(game, n, t)
+        rg, ro = g.step(a, auto_reset=True), o.step(a, auto_reset=True)
+        for x, y, name in zip(rg, ro, ("reward", "done", "lives", "score")):
+            assert np.array_equal(x, y), "%s differs at step %d (envs %s)" % (name, t, np.nonzero(x != y)[0][:8])
+        acc += rg[0]
+        dones += int(rg[1].sum())
+    _assert_states_equal(g, o, sample)
+    for x, y in zip(g.scalars(), o.scalars()):
+        assert np.array_equal(x, y)
+    for i in sample[:24]:
+        assert np.array_equal(g.render_env(int(i), 3), o.render_env(int(i), 3)), i
+    assert acc.sum() > 0 and (game != "breakout" or dones > 0)      # rewards flowed; Breakout games ended and restarted
