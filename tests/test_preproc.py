@@ -183,7 +183,8 @@ def test_gpu_fused_preprocessing_parity(game, hip_lib, oracle_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("game,skip,oh,ow,stack", [("breakout", 4, 84, 84, 4), ("space_invaders", 4, 84, 84, 4), ("amidar", 4, 84, 84, 4),
-                                                  ("space_invaders", 3, 60, 100, 2), ("amidar", 2, 50, 40, 3), ("amidar", 1, 84, 84, 4)])
+                                                  ("space_invaders", 3, 60, 100, 2), ("amidar", 2, 50, 40, 3), ("amidar", 1, 84, 84, 4),
+                                                  ("gridworld", 4, 84, 84, 4), ("gridworld", 2, 64, 80, 1)])
 def test_gpu_fused_observation_equals_generic_path(game, skip, oh, ow, stack, hip_lib, monkeypatch):
     """The per-game fused observation kernels (Breakout: from render records; SpaceInvaders / Amidar: two painters per wave
     with class-diff scanline skipping; no full-resolution frames) == the generic render + warp path, through episode ends."""

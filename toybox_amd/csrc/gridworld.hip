@@ -197,58 +197,142 @@ __global__ __launch_bounds__(128) void gw_agent_reset_kernel(GwDev d, AgentReset
 
 constexpr int GW_UNIT_ROWS = 8;
 
-// lane l -> pixels 4l..4l+3 (lanes 0..39); lane t < 16 also keeps tile t's colour for the board lookups (ds_bpermute).
-// A scanline only changes when it enters the next cell row, so the four colours are rebuilt once per cell row.
+// Everything one wave needs to paint scanlines of one env: lane l -> pixels 4l..4l+3 (lanes 0..39); lane t < 16 also
+// keeps tile t's colour for the board lookups (ds_bpermute).  A scanline only changes when it enters the next cell row,
+// so the four colours are rebuilt once per cell row.
+template <int C>
+struct GwPainter {
+    typedef GwDev Dev;
+    static constexpr int W = TBX_GW_W, H = TBX_GW_H, NG = 1;
+    enum { CLS_BOARD, CLS_PLAYER, NCLS };
+    int lane, gw, gh, tw, th, px, py;
+    uint32_t pcol, black, tcol;
+    const uint8_t* g;
+    bool active;
+    int cx[4];
+    uint4 cells;                    // this lane's 16 board bytes (for diff_classes)
+    uint32_t tile_rec[3];           // lane t < 16: tile t's record
+    uint64_t busy[4];
+    mutable int last_cy;
+    mutable uint32_t c[4];
+
+    __device__ __forceinline__ void setup(const GwDev& d, int env, int lane_, uint32_t* cls)
+    {
+        lane = lane_;
+        const size_t N = (size_t)d.n;
+        gw = wave_uniform(d.sc[G_W * N + env]); gh = wave_uniform(d.sc[G_H * N + env]);
+        gw = gw < 1 ? 1 : gw > GD ? GD : gw;
+        gh = gh < 1 ? 1 : gh > GD ? GD : gh;
+        tw = W / gw; th = H / gh;
+        px = wave_uniform(d.sc[G_PX * N + env]); py = wave_uniform(d.sc[G_PY * N + env]);
+        const int nt = wave_uniform(d.sc[G_NT * N + env]);
+        pcol = pix_of<C>((uint32_t)wave_uniform(d.sc[G_PCOL * N + env]));
+        black = pix_of<C>(0xFF000000u);
+        const uint32_t* trec = d.tiles + ((size_t)env * GT + (lane < GT ? lane : 0)) * 3;
+        tile_rec[0] = trec[0]; tile_rec[1] = trec[1]; tile_rec[2] = trec[2];
+        tcol = (lane < GT && lane < nt) ? pix_of<C>(tile_rec[0]) : black;
+        g = d.grid + (size_t)env * CELLS;
+        cells = reinterpret_cast<const uint4*>(g)[lane];
+        active = lane < W / 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) cx[k] = (lane * 4 + k) / tw;
+        last_cy = -1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) c[k] = black;
+        // scanline masks per class (all wave-uniform): the board band and the player's cell row
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t wb = row_range_bits(0, (long)gh * th, k);
+                const bool p_in = px >= 0 && px < gw && py >= 0 && py < gh;
+                const uint64_t wp = p_in ? row_range_bits((long)py * th, (long)py * th + th, k) : 0ull;
+                cls[CLS_BOARD * 8 + 2 * k] = (uint32_t)wb; cls[CLS_BOARD * 8 + 2 * k + 1] = (uint32_t)(wb >> 32);
+                cls[CLS_PLAYER * 8 + 2 * k] = (uint32_t)wp; cls[CLS_PLAYER * 8 + 2 * k + 1] = (uint32_t)(wp >> 32);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) busy[k] = row_range_bits(0, (long)gh * th, k);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    static __device__ __forceinline__ uint32_t diff_classes(const GwPainter& a, const GwPainter& b)
+    {
+        uint32_t m = 0u;
+        const bool cell_diff = a.cells.x != b.cells.x || a.cells.y != b.cells.y || a.cells.z != b.cells.z || a.cells.w != b.cells.w;
+        const bool tile_diff = a.lane < GT && (a.tile_rec[0] != b.tile_rec[0] || a.tcol != b.tcol);
+        if (a.gw != b.gw || a.gh != b.gh || __ballot(cell_diff || tile_diff)) m |= 1u << CLS_BOARD;
+        if (a.px != b.px || a.py != b.py || a.pcol != b.pcol) m |= 1u << CLS_PLAYER;
+        return m;
+    }
+
+    __device__ __forceinline__ void paint_row(int y, uint32_t (&out)[4]) const
+    {
+        const int cy = y / th;
+        if (cy != last_cy) {
+            last_cy = cy;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool inside = active && cx[k] < gw && cy < gh;
+                const int id = inside ? g[cy * GD + cx[k]] : 255;
+                const uint32_t tc = __shfl(tcol, id & 15);
+                c[k] = !inside ? black : (cx[k] == px && cy == py) ? pcol : id < GT ? tc : black;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[k] = c[k];
+    }
+};
+
+struct GwGrayPainter : GwPainter<1> {
+    static __device__ __forceinline__ uint32_t diff_classes(const GwGrayPainter& a, const GwGrayPainter& b) { return GwPainter<1>::diff_classes(a, b); }
+    __device__ __forceinline__ uint32_t blank_dword() const { return black * 0x01010101u; }
+    __device__ __forceinline__ void row_dwords(int y, uint32_t (&v)[1]) const
+    {
+        uint32_t p[4];
+        paint_row(y, p);
+        v[0] = p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24);
+    }
+};
+
 template <int C>
 __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* out, int first_env, int count)
 {
     constexpr int W = TBX_GW_W, H = TBX_GW_H, UNITS = H / GW_UNIT_ROWS;
     using Stager = RowStager<C, W, GW_UNIT_ROWS>;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
+    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][GwPainter<C>::NCLS * 8];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
     if (rel >= count) return;
     const int env = first_env + rel;
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
-    const size_t N = (size_t)d.n;
-
-    int gw = wave_uniform(d.sc[G_W * N + env]), gh = wave_uniform(d.sc[G_H * N + env]);
-    gw = gw < 1 ? 1 : gw > GD ? GD : gw;
-    gh = gh < 1 ? 1 : gh > GD ? GD : gh;
-    const int tw = W / gw, th = H / gh;
-    const int px = wave_uniform(d.sc[G_PX * N + env]), py = wave_uniform(d.sc[G_PY * N + env]);
-    const int nt = wave_uniform(d.sc[G_NT * N + env]);
-    const uint32_t pcol = pix_of<C>((uint32_t)wave_uniform(d.sc[G_PCOL * N + env]));
-    const uint32_t black = pix_of<C>(0xFF000000u);
-    const uint32_t tcol = (lane < GT && lane < nt) ? pix_of<C>(d.tiles[((size_t)env * GT + lane) * 3]) : black;
-    const uint8_t* g = d.grid + (size_t)env * CELLS;
-    const bool active = lane < W / 4;
-    int cx[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) cx[k] = (lane * 4 + k) / tw;
-
+    GwPainter<C> p;
+    p.setup(d, env, lane, lds_mask[wave]);
     uint8_t* dst = out + (size_t)rel * H * W * C;
-    uint32_t c[4] = {black, black, black, black};
-    int last_cy = -1;
     for (int u = 0; u < UNITS; u++) {
         const int unit = (u + env) % UNITS;                  // rotate the start so waves do not march in lockstep
         for (int r = 0; r < GW_UNIT_ROWS; r++) {
-            const int cy = (unit * GW_UNIT_ROWS + r) / th;
-            if (cy != last_cy) {
-                last_cy = cy;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const bool inside = active && cx[k] < gw && cy < gh;
-                    const int id = inside ? g[cy * GD + cx[k]] : 255;
-                    const uint32_t tc = __shfl(tcol, id & 15);
-                    c[k] = !inside ? black : (cx[k] == px && cy == py) ? pcol : id < GT ? tc : black;
-                }
-            }
-            if (active) st.put4p(r, lane, c[0], c[1], c[2], c[3]);
+            uint32_t px[4];
+            p.paint_row(unit * GW_UNIT_ROWS + r, px);
+            if (p.active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
         }
         st.flush(dst + (size_t)unit * Stager::UNIT_BYTES, lane);
     }
+}
+
+// fused agent observation: agent_fused_wave (agent_device.hpp) with two GwGrayPainters per wave
+template <int S>
+__global__ __launch_bounds__(TBX_BLOCK) void gw_agent_warp_kernel(GwDev dA, GwDev dB, AgentWarpArgs a, int n)
+{
+    __shared__ AgentFusedLds<GwGrayPainter> lds[TBX_WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (env >= n) return;
+    GwGrayPainter pa, pb;
+    agent_fused_wave<S, GwGrayPainter>(pa, pb, dA, dB, a, env, lane, lds[wave]);
 }
 
 // ------------------------------------------------------------------ state records
@@ -357,6 +441,7 @@ struct GridWorldOps : GameOps {
     void destroy(tbx_engine*) override
     {
         hipFree(d.sc); hipFree(d.tiles); hipFree(d.grid); hipFree(cfg_dev);
+        hipFree(dA.sc); hipFree(dA.tiles); hipFree(dA.grid);
     }
 
     int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
@@ -382,6 +467,43 @@ struct GridWorldOps : GameOps {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         hipLaunchKernelGGL(gw_step_kernel, dim3((count + 127) / 128), dim3(128), 0, s, d, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    // ---- fused agent observation: frame A is a snapshot of the dynamic state, frame B the live state
+    GwDev dA{};
+    bool agent_fused() const override { return true; }
+
+    int agent_snapshot(tbx_engine* e, int which, hipStream_t s) override
+    {
+        if (which != 0) return TBX_OK;
+        const size_t N = (size_t)e->n;
+        if (!dA.sc) {
+            dA = d;
+            dA.sc = nullptr; dA.tiles = nullptr; dA.grid = nullptr;
+            TBX_HIP(hipMalloc((void**)&dA.sc, (size_t)GF * N * sizeof(int32_t)));
+            TBX_HIP(hipMalloc((void**)&dA.tiles, N * GT * 3 * sizeof(uint32_t)));
+            TBX_HIP(hipMalloc((void**)&dA.grid, N * CELLS));
+        }
+        TBX_HIP(hipMemcpyAsync(dA.sc, d.sc, (size_t)GF * N * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        TBX_HIP(hipMemcpyAsync(dA.tiles, d.tiles, N * GT * 3 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        TBX_HIP(hipMemcpyAsync(dA.grid, d.grid, N * CELLS, hipMemcpyDeviceToDevice, s));
+        return TBX_OK;
+    }
+
+    int agent_warp(tbx_engine* e, const AgentWarpArgs& a, hipStream_t s) override
+    {
+        AgentWarpArgs w = a;
+        if (!dA.sc) w.two_frames = 0;
+        const GwDev& A = dA.sc ? dA : d;
+        const dim3 grid = wave_grid(e->n), block(TBX_BLOCK);
+        switch (a.stack) {
+        case 1: hipLaunchKernelGGL(gw_agent_warp_kernel<1>, grid, block, 0, s, A, d, w, e->n); break;
+        case 2: hipLaunchKernelGGL(gw_agent_warp_kernel<2>, grid, block, 0, s, A, d, w, e->n); break;
+        case 3: hipLaunchKernelGGL(gw_agent_warp_kernel<3>, grid, block, 0, s, A, d, w, e->n); break;
+        default: hipLaunchKernelGGL(gw_agent_warp_kernel<4>, grid, block, 0, s, A, d, w, e->n); break;
+        }
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
