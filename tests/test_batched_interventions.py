@@ -75,3 +75,34 @@ def test_mode_sweeps(lib):
     assert (s.get_states_np()["ufo_appearance_counter"] == -1).all()
     with pytest.raises(Exception):
         s.get_states(2, 5)
+
+
+def test_set_eq_diff_and_partial_config(oracle_lib, tmp_path):
+    """SetEq for batches + set_partial_config (interventions/base.py:47-106, 409-419)."""
+    import json
+    from toybox_amd.interventions import diff_states
+    with Engine("breakout", 6, lib=oracle_lib) as e:
+        e.seed(3)
+        e.new_game()
+        base = e.get_states_np()
+        with BatchIntervention(e) as bi:
+            assert bi.differs(base) == []
+            bi.states["lives"][2] = 1
+            bi.states["bricks"]["alive"][4, 17] = 0
+            bi.states["paddle_x"][5] += 1e-13           # below the isclose tolerance: not a difference
+            bi.states["paddle_x"][1] += 0.5
+            d = dict((k, list(v)) for k, v in bi.differs(base))
+            assert d == {"lives": [2], "bricks.alive": [4], "paddle_x": [1]}
+        after = e.get_states_np()
+        assert [k for k, _ in diff_states(after, base, rel_tol=0.0)] == ["lives", "paddle_x", "bricks.alive"] or \
+            sorted(k for k, _ in diff_states(after, base, rel_tol=0.0)) == ["bricks.alive", "lives", "paddle_x"]
+        # partial config from a file: unknown keys are ignored, known ones replace; the batch restarts with it
+        f = tmp_path / "partial.json"
+        f.write_text(json.dumps({"start_lives": 2, "no_such_key": 1}))
+        with BatchIntervention(e) as bi:
+            bi.set_partial_config(str(f))
+            bi.set_partial_config({"ball_speed_slow": 1.5})
+            assert bi.dirty_config
+        cfg = e.get_config()
+        assert cfg.start_lives == 2 and cfg.ball_speed_slow == 1.5
+        assert (e.scalars()[1] == 2).all()

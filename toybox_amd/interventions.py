@@ -5,9 +5,36 @@ states come as a numpy structured array (one record per env, fields named like t
 include/toybox_amd.h), so an intervention is a vectorised array expression; per-env JSON views are available for code
 written against the interventions schema.
 """
+import json
+import os
+
 import numpy as np
 
 from .games import codec
+
+
+def diff_states(a, b, rel_tol=1e-9, prefix=""):
+    """SetEq for batches (interventions/base.py:47-106): where do two arrays of state records differ?  Returns
+    [(field path, env indices)], floats compared like math.isclose (rel_tol 1e-9), everything else exactly; nested
+    records and per-entity arrays are walked by name, e.g. 'bricks.alive' or 'ball_x'."""
+    assert a.dtype == b.dtype and a.shape == b.shape
+    out = []
+    for name in a.dtype.names:
+        if name.startswith("_"):
+            continue
+        x, y = a[name], b[name]
+        path = prefix + name
+        if x.dtype.names:
+            out.extend(diff_states(x, y, rel_tol, path + "."))
+            continue
+        if x.dtype.kind == "f":
+            neq = ~np.isclose(x, y, rtol=rel_tol, atol=0.0, equal_nan=True)
+        else:
+            neq = x != y
+        envs = np.flatnonzero(neq.reshape(neq.shape[0], -1).any(axis=1))
+        if len(envs):
+            out.append((path, envs))
+    return out
 
 
 class BatchIntervention:
@@ -18,17 +45,50 @@ class BatchIntervention:
         self.states = None
         self._before = None
         self._codec = codec(engine.game)
+        self.config = None
+        self._config_before = None
 
     def __enter__(self):
         self.states = self.engine.get_states_np(self.first, self.count)
         self._before = self.states.tobytes()
+        self.config = self._codec.config_to_json(self.engine.get_config())
+        self._config_before = json.dumps(self.config, sort_keys=True)
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        if exc_type is None and self.dirty_state:
-            self.engine.set_states_np(self.first, self.states)
+        # like Intervention.__exit__ (interventions/base.py:396-406): a changed config is written and a new game started
+        # (the config is batch-wide, so for every env of the engine); otherwise changed states are written back
+        if exc_type is None:
+            if self.dirty_config:
+                self.engine.set_config(self._codec.config_from_json(self.config))
+                self.engine.new_game()
+            elif self.dirty_state:
+                self.engine.set_states_np(self.first, self.states)
         self.states = None
+        self.config = None
         return False
+
+    @property
+    def dirty_config(self):
+        return self.config is not None and json.dumps(self.config, sort_keys=True) != self._config_before
+
+    def set_partial_config(self, source):
+        """Intervention.set_partial_config (interventions/base.py:409-419): keys of a JSON file (or a dict) that the config
+        has replace its values."""
+        if isinstance(source, dict):
+            data = source
+        elif os.path.isfile(source):
+            with open(source) as f:
+                data = json.load(f)
+        else:
+            return
+        for k, v in data.items():
+            if k in self.config:
+                self.config[k] = v
+
+    def differs(self, other_states, rel_tol=1e-9):
+        """SetEq-style report against another batch of records (see diff_states)."""
+        return diff_states(self.states, other_states, rel_tol)
 
     @property
     def dirty_state(self):
