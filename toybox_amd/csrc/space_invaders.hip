@@ -650,6 +650,9 @@ struct SiPainter {
     int e_tab;                              // lane = enemy: its sprite table base in spr_lds
     uint64_t busy[4];                       // scanlines that show anything but black (wave-uniform, 256 bits)
     const uint32_t* spr_lds;
+    mutable uint64_t ym_cached;             // enemy lookups of the current formation row (paint_row)
+    mutable int ec_shift[SI_NG], ec_row0[SI_NG];
+    mutable bool ec_multi;
 
     // spr_lds (set by the caller first): the block's copy of the three enemy sprites (si_fill_sprites); cls: [NCLS][8]
     // dwords of LDS private to this wave
@@ -726,6 +729,8 @@ struct SiPainter {
                 if (gx[g] + 3 >= ex && gx[g] < ex + TBX_SI_ENEMY_W) cand[g] |= 1ull << e;
         }
         e_tab = (s.estatus & 1) ? (f[F_ORIENT] ? 0 : TBX_SI_ENEMY_H) : 2 * TBX_SI_ENEMY_H;
+        ym_cached = 0ull; ec_multi = false;
+        ec_shift[0] = ec_shift[1] = 31; ec_row0[0] = ec_row0[1] = 0;
 
         // scanline masks per class in LDS: every lane ORs the rows of the entities it holds (enemy, shield row, laser);
         // HUD + ground, ufo and ship come from wave-uniform fields.  busy = their union.
@@ -809,23 +814,52 @@ struct SiPainter {
                 paint_bits<NG>(px, gx, __shfl(s_x, src), __shfl(s.srow, src), TBX_SI_SHIELD_W, __shfl(s_c, src));
             }
         }
-        // enemies in index order: each lane walks the (usually one) enemy that overlaps its pixel group and this scanline
+        // enemies in index order.  The set of enemies crossing a scanline (ym) is the same for the ten scanlines of a
+        // formation row, so what each lane needs of its (usually single) overlapping enemy is looked up once per set:
+        // the shift of the sprite row into its pixel group and the sprite-table offset.  A lane with two overlapping
+        // enemies in a group (only states written by hand) takes the general walk below.
         if (y >= e_y0 && y < e_y1) {
             const uint64_t ym = __ballot(e_vis && y >= s.ey && y < s.ey + TBX_SI_ENEMY_H);
+            if (ym != ym_cached) {
+                ym_cached = ym;
+                bool multi = false;
 #pragma unroll
-            for (int g = 0; g < NG; g++) {
-                uint64_t c = cand[g] & ym;
-                while (__ballot(c != 0)) {
-                    const bool on = c != 0;
-                    const int e = on ? (int)__builtin_ctzll(c) : 0;
+                for (int g = 0; g < NG; g++) {
+                    const uint64_t c = cand[g] & ym;
+                    const int e = c ? (int)__builtin_ctzll(c) : 0;
                     const int ex = __shfl(s.ex, e), ey = __shfl(s.ey, e), tab = __shfl(e_tab, e);
-                    if (on) {
-                        const uint32_t bits = spr_lds[tab + (y - ey)] & ((1u << TBX_SI_ENEMY_W) - 1u);
-                        const uint32_t four = ((bits << 4) >> (gx[g] - ex + 4)) & 15u;    // shift in [1, 19]
+                    ec_shift[g] = c ? gx[g] - ex + 4 : 31;        // 31: every sprite bit shifted out
+                    ec_row0[g] = tab - ey;
+                    multi |= (c & (c - 1)) != 0;
+                }
+                ec_multi = __ballot(multi) != 0;
+            }
+            if (!ec_multi) {
 #pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            if ((four >> i) & 1u) px[g][i] = c_enemy;
-                        c &= c - 1;
+                for (int g = 0; g < NG; g++) {
+                    const int idx = ec_row0[g] + y;
+                    const uint32_t bits = ec_shift[g] != 31 ? spr_lds[idx] & ((1u << TBX_SI_ENEMY_W) - 1u) : 0u;
+                    const uint32_t four = ((bits << 4) >> ec_shift[g]) & 15u;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if ((four >> i) & 1u) px[g][i] = c_enemy;
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    uint64_t c = cand[g] & ym;
+                    while (__ballot(c != 0)) {
+                        const bool on = c != 0;
+                        const int e = on ? (int)__builtin_ctzll(c) : 0;
+                        const int ex = __shfl(s.ex, e), ey = __shfl(s.ey, e), tab = __shfl(e_tab, e);
+                        if (on) {
+                            const uint32_t bits = spr_lds[tab + (y - ey)] & ((1u << TBX_SI_ENEMY_W) - 1u);
+                            const uint32_t four = ((bits << 4) >> (gx[g] - ex + 4)) & 15u;    // shift in [1, 19]
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                if ((four >> i) & 1u) px[g][i] = c_enemy;
+                            c &= c - 1;
+                        }
                     }
                 }
             }
