@@ -202,15 +202,16 @@ struct AgentResetProc {
 // (A two-wave variant, one painter per wave with a block barrier per chunk of scanlines, measured 18 % slower: fewer envs
 // in flight and barrier stalls outweighed the lower register count.)
 //
-// Painter P: static W, H, NG (4-pixel groups per lane), NCLS; type Dev; setup(dev, env, lane, cls) with cls = this wave's
+// Painter P: static W, H, NG (4-pixel groups per lane), NCLS, NLDS (>= NCLS: mask slots of LDS it uses); type Dev; setup(dev, env, lane, cls) with cls = this wave's
 // [NCLS][8] dwords of LDS (the painter fills them and keeps their union in busy[4]); row_dwords(y, v[NG]); blank_dword()
-// (the packed value of a scanline outside busy);
+// (the packed value of a scanline outside busy); rep[4]: wave-uniform mask of the scanlines that paint exactly as the one above them;
 // static diff_classes(const P& a, const P& b) -> wave-uniform bit mask.
 template <class P>
 struct AgentFusedLds {
     static constexpr int ROWB = ((P::W + 32 + 15) / 16) * 16;
     uint8_t row[ROWB] __attribute__((aligned(16)));
-    uint32_t cls[2][P::NCLS][8];
+    uint8_t vals[AGENT_MAX_OUT_PX] __attribute__((aligned(16)));   // the new observation plane, committed to the stack at the end
+    uint32_t cls[2][P::NLDS][8];   // per painter: NCLS class masks (+ painter-private scratch masks)
     uint32_t masks[2][8];       // need / need_a
 };
 
@@ -259,48 +260,52 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
         hb1 = on1 ? hsum(row, c1) : 0u;
         __builtin_amdgcn_wave_barrier();
     }
-    uint32_t old[2] = {0u, 0u};                                        // stack words of the output row being accumulated
-    auto fetch_old = [&](int oy) {
-        if (S == 4 && !fresh && oy < a.oh) {
-            if (on0) old[0] = *reinterpret_cast<const uint32_t*>(o + ((size_t)oy * a.ow + lane) * 4);
-            if (on1) old[1] = *reinterpret_cast<const uint32_t*>(o + ((size_t)oy * a.ow + lane + 64) * 4);
-        }
-    };
-    fetch_old(0);
-
     uint32_t acc0[2] = {0, 0}, acc1[2] = {0, 0};                       // [column slot]: current / next output row
     // source row sy covers [sy*oh, (sy+1)*oh) and output row oy covers [oy*H, (oy+1)*H) in refined units; both walk
     // incrementally (no division), and the three row masks are consumed one bit per scanline, 64 scanlines per word
     int oy = 0, top = H, pos = 0;
+    int prev_kind = 0;                                                 // 0: the scanline above was skipped; else 1 + B painted + 2 * A painted
+    uint32_t hl0 = 0u, hl1 = 0u;                                        // sums of the last composed scanline
 #pragma unroll 1
     for (int wi = 0; wi < (H + 63) / 64; wi++) {
         uint64_t nw = sel4(wi, need[0], need[1], need[2], need[3]);
         uint64_t bw = sel4(wi, pb.busy[0], pb.busy[1], pb.busy[2], pb.busy[3]);
         uint64_t aw = sel4(wi, need_a[0], need_a[1], need_a[2], need_a[3]);
+        uint64_t rb = sel4(wi, pb.rep[0], pb.rep[1], pb.rep[2], pb.rep[3]), ra = two ? sel4(wi, pa.rep[0], pa.rep[1], pa.rep[2], pa.rep[3]) : 0ull;
         const int sy_end = min(H, 64 * wi + 64);
 #pragma unroll 1
-        for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, bw >>= 1, aw >>= 1) {
+        for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, bw >>= 1, aw >>= 1, rb >>= 1, ra >>= 1) {
             uint32_t h0 = hb0, h1 = hb1;
             if (nw & 1ull) {
-                uint32_t v[NG];
-                if (bw & 1ull) pb.row_dwords(sy, v);
-                else {
+                const bool b_on = bw & 1ull, a_on = aw & 1ull;
+                // a scanline that paints exactly like the one above it (same tile / cell / glyph row, same objects) has
+                // the same horizontal sums: neither painted nor reduced again
+                const bool reuse = prev_kind == (1 + (b_on ? 1 : 0) + (a_on ? 2 : 0)) && (!b_on || (rb & 1ull)) && (!a_on || (ra & 1ull));
+                if (!reuse) {
+                    uint32_t v[NG];
+                    if (b_on) pb.row_dwords(sy, v);
+                    else {
 #pragma unroll
-                    for (int g = 0; g < NG; g++) v[g] = blank;
+                        for (int g = 0; g < NG; g++) v[g] = blank;
+                    }
+                    if (a_on) {                                        // only then can frame A show different pixels
+                        uint32_t va[NG];
+                        pa.row_dwords(sy, va);
+#pragma unroll
+                        for (int g = 0; g < NG; g++) v[g] = bytemax4(v[g], va[g]);
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; g++)
+                        if (lane + 64 * g < W / 4) reinterpret_cast<uint32_t*>(row)[lane + 64 * g] = v[g];
+                    __builtin_amdgcn_wave_barrier();
+                    hl0 = on0 ? hsum(row, c0) : 0u;
+                    hl1 = on1 ? hsum(row, c1) : 0u;
+                    __builtin_amdgcn_wave_barrier();
                 }
-                if (aw & 1ull) {                                       // only then can frame A show different pixels
-                    uint32_t va[NG];
-                    pa.row_dwords(sy, va);
-#pragma unroll
-                    for (int g = 0; g < NG; g++) v[g] = bytemax4(v[g], va[g]);
-                }
-#pragma unroll
-                for (int g = 0; g < NG; g++)
-                    if (lane + 64 * g < W / 4) reinterpret_cast<uint32_t*>(row)[lane + 64 * g] = v[g];
-                __builtin_amdgcn_wave_barrier();
-                h0 = on0 ? hsum(row, c0) : 0u;
-                h1 = on1 ? hsum(row, c1) : 0u;
-                __builtin_amdgcn_wave_barrier();
+                h0 = hl0; h1 = hl1;
+                prev_kind = 1 + (b_on ? 1 : 0) + (a_on ? 2 : 0);
+            } else {
+                prev_kind = 0;
             }
             const int pos_next = pos + a.oh;
             const int w_cur = min(pos_next, top) - pos, w_next = a.oh - w_cur;
@@ -311,19 +316,16 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const int ox = lane + 64 * q;
-                    if (q == 0 ? on0 : on1) {
-                        const uint32_t val = (uint32_t)(((uint64_t)(acc0[q] + half) * a.magic) >> 42);
-                        uint8_t* px = o + ((size_t)oy * a.ow + ox) * S;
-                        if (S == 4) *reinterpret_cast<uint32_t*>(px) = ((fresh ? 0u : old[q]) >> 8) | (val << 24);
-                        else stack_push<S>(px, val, fresh);
-                    }
+                    if (q == 0 ? on0 : on1) L.vals[oy * a.ow + ox] = (uint8_t)(((uint64_t)(acc0[q] + half) * a.magic) >> 42);
                     acc0[q] = acc1[q];
                     acc1[q] = 0;
                 }
                 oy += 1;
                 top += H;
-                fetch_old(oy);
             }
         }
     }
+    // the read-modify-write of the frame stack in one sweep with many loads in flight (a dependent load -> store per
+    // output row, even fetched a row ahead, left this kernel waiting on HBM latency 84 times per env)
+    stack_commit<S>(L.vals, o, a.oh * a.ow, lane, fresh);
 }

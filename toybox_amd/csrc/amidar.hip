@@ -664,7 +664,7 @@ template <int C>
 struct AmiPainter {
     typedef AmiDev Dev;
     static constexpr int W = TBX_AMI_W, H = TBX_AMI_H, NG = 1;
-    enum { CLS_BOARD, CLS_MOVER, CLS_HUD, NCLS };
+    enum { CLS_BOARD, CLS_MOVER, CLS_HUD, NCLS, SLOT_EDGE = NCLS, NLDS };
     static constexpr int BOARD_Y1 = TBX_AMI_BOARD_OY + BH * TBX_AMI_TILE_PH;
     AmiRegs s;
     int lane, x0, tx;
@@ -675,6 +675,7 @@ struct AmiPainter {
     uint32_t c_bg, c_inner, c_painted, c_unpainted, c_enemy, c_player;
     uint64_t mv_rows[4];                    // scanlines crossed by a mover (wave-uniform)
     uint64_t busy[4];                       // scanlines that are not plain background
+    uint64_t rep[4];                        // scanlines that paint exactly as the one above (same tile / glyph row, no mover edge)
     mutable int ty_cached;
     mutable uint32_t board_col;             // this lane's tile colour in tile row ty_cached
 
@@ -739,7 +740,7 @@ struct AmiPainter {
         board_col = c_bg;
 
         // scanline masks per class in LDS: every mover lane ORs its rows; board band and HUD rows are fixed
-        for (int i = lane; i < NCLS * 8; i += 64) cls[i] = 0u;
+        for (int i = lane; i < NLDS * 8; i += 64) cls[i] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -747,6 +748,10 @@ struct AmiPainter {
             const uint64_t w = m_on ? row_range_bits(m_y0, (long)m_y0 + TBX_AMI_MOVER_H, k) : 0ull;
             if ((uint32_t)w) atomicOr(&cls[CLS_MOVER * 8 + 2 * k], (uint32_t)w);
             if ((uint32_t)(w >> 32)) atomicOr(&cls[CLS_MOVER * 8 + 2 * k + 1], (uint32_t)(w >> 32));
+            // the scanlines where a mover starts, and the first one below it
+            const uint64_t we = m_on ? (row_range_bits(m_y0, (long)m_y0 + 1, k) | row_range_bits((long)m_y0 + TBX_AMI_MOVER_H, (long)m_y0 + TBX_AMI_MOVER_H + 1, k)) : 0ull;
+            if ((uint32_t)we) atomicOr(&cls[SLOT_EDGE * 8 + 2 * k], (uint32_t)we);
+            if ((uint32_t)(we >> 32)) atomicOr(&cls[SLOT_EDGE * 8 + 2 * k + 1], (uint32_t)(we >> 32));
             if (lane == 0) {
                 const uint64_t wb = row_range_bits(TBX_AMI_BOARD_OY, BOARD_Y1, k), wh = row_range_bits(TBX_AMI_HUD_Y, TBX_AMI_HUD_Y + 10, k);
                 cls[CLS_BOARD * 8 + 2 * k] = (uint32_t)wb; cls[CLS_BOARD * 8 + 2 * k + 1] = (uint32_t)(wb >> 32);
@@ -760,6 +765,12 @@ struct AmiPainter {
             const uint32_t mlo = __builtin_amdgcn_readfirstlane(cls[CLS_MOVER * 8 + 2 * k]), mhi = __builtin_amdgcn_readfirstlane(cls[CLS_MOVER * 8 + 2 * k + 1]);
             mv_rows[k] = (uint64_t)mlo | ((uint64_t)mhi << 32);
             busy[k] = mv_rows[k] | row_range_bits(TBX_AMI_BOARD_OY, BOARD_Y1, k) | row_range_bits(TBX_AMI_HUD_Y, TBX_AMI_HUD_Y + 10, k);
+            const uint32_t elo = __builtin_amdgcn_readfirstlane(cls[SLOT_EDGE * 8 + 2 * k]), ehi = __builtin_amdgcn_readfirstlane(cls[SLOT_EDGE * 8 + 2 * k + 1]);
+            uint64_t firsts = (uint64_t)elo | ((uint64_t)ehi << 32);     // + the first scanline of every tile row / glyph row
+            for (int ty = 0; ty < BH; ty++) firsts |= row_range_bits(TBX_AMI_BOARD_OY + ty * TBX_AMI_TILE_PH, TBX_AMI_BOARD_OY + ty * TBX_AMI_TILE_PH + 1, k);
+            for (int gr = 0; gr <= 5; gr++) firsts |= row_range_bits(TBX_AMI_HUD_Y + 2 * gr, TBX_AMI_HUD_Y + 2 * gr + 1, k);
+            firsts |= row_range_bits(BOARD_Y1, BOARD_Y1 + 1, k);       // the first scanline below the board band
+            rep[k] = busy[k] & ~firsts;
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -204,7 +204,7 @@ template <int C>
 struct GwPainter {
     typedef GwDev Dev;
     static constexpr int W = TBX_GW_W, H = TBX_GW_H, NG = 1;
-    enum { CLS_BOARD, CLS_PLAYER, NCLS };
+    enum { CLS_BOARD, CLS_PLAYER, NCLS, NLDS = NCLS };
     int lane, gw, gh, tw, th, px, py;
     uint32_t pcol, black, tcol;
     const uint8_t* g;
@@ -213,6 +213,7 @@ struct GwPainter {
     uint4 cells;                    // this lane's 16 board bytes (for diff_classes)
     uint32_t tile_rec[3];           // lane t < 16: tile t's record
     uint64_t busy[4];
+    uint64_t rep[4];                // scanlines in the same cell row as the one above them
     mutable int last_cy;
     mutable uint32_t c[4];
 
@@ -252,6 +253,14 @@ struct GwPainter {
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) busy[k] = row_range_bits(0, (long)gh * th, k);
+        {   // every scanline of the board band except the first of each cell row
+            uint64_t firsts[4] = {0ull, 0ull, 0ull, 0ull};
+            for (int r = 0; r < gh; r++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) firsts[k] |= row_range_bits((long)r * th, (long)r * th + 1, k);
+#pragma unroll
+            for (int k = 0; k < 4; k++) rep[k] = busy[k] & ~firsts[k];
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }

@@ -635,7 +635,7 @@ template <int C>
 struct SiPainter {
     typedef SiDev Dev;
     static constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
-    enum { CLS_ENEMY, CLS_SHIELD, CLS_LASER, CLS_HUD, CLS_UFO, CLS_SHIP, NCLS };
+    enum { CLS_ENEMY, CLS_SHIELD, CLS_LASER, CLS_HUD, CLS_UFO, CLS_SHIP, NCLS, NLDS = NCLS };
     SiRegs s;
     int lane;
     int gx[SI_NG];
@@ -913,6 +913,7 @@ struct SiGrayPainter : SiPainter<1> {
     static __device__ __forceinline__ uint32_t diff_classes(const SiGrayPainter& a, const SiGrayPainter& b) { return SiPainter<1>::diff_classes(a, b); }
     __device__ __forceinline__ uint32_t blank_dword() const { return 0u; }       // black is gray 0
     __device__ __forceinline__ void row_dwords(int y, uint32_t (&v)[SI_NG]) const { si_row_dwords<1>(*this, y, v); }
+    uint64_t rep[4] = {0ull, 0ull, 0ull, 0ull};                                   // sprite rows differ scanline by scanline
 };
 
 // the block's LDS copy of the enemy sprite rows (pose A, pose B, explosion); ends with a block barrier
