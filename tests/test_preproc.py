@@ -477,3 +477,38 @@ def test_gpu_reset_wrappers_unsupported_for_custom_bricks(hip_lib):
     e.agent_init(skip=4, episodic_life=True)
     with pytest.raises(ToyboxAmdError):
         e.agent_reset()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", GAMES + ["gridworld"])
+def test_gpu_agent_pipeline_survives_state_writes(game, hip_lib, oracle_lib):
+    """Interventions between agent steps (whole-batch state rewrites, single-env writes, a re-seed + new game): the fused
+    observation kernels must not keep anything stale (render records, state snapshots)."""
+    n = 96
+    g, o = Engine(game, n, lib=hip_lib), Engine(game, n, lib=oracle_lib)
+    for e in (g, o):
+        e.seed(5)
+        e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=True, fire_reset=True, noop_max=5)
+    assert np.array_equal(g.agent_reset(), o.agent_reset())
+
+    def run(t0, k):
+        for t in range(t0, t0 + k):
+            a = synthetic_actions(game, n, t, seed=12)
+            x, y = g.agent_step(a), o.agent_step(a)
+            for p, q in zip(x, y):
+                assert np.array_equal(p, q), t
+
+    run(0, 40)
+    recs = o.get_states_np()
+    recs[:] = recs[::-1].copy()                      # every env gets another env's state
+    for e in (g, o):
+        e.set_states_np(0, recs)
+    run(40, 30)
+    st = o.get_state(7)
+    for e in (g, o):
+        e.set_state(3, st)
+        e.seed(99, env=5)
+        e.new_game(np.eye(1, n, 5, dtype=np.uint8)[0])
+    run(70, 30)
+    for i in range(0, n, 5):
+        assert bytes(g.get_state(i)) == bytes(o.get_state(i))

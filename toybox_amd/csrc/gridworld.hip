@@ -381,7 +381,7 @@ __global__ void gw_unpack_kernel(GwDev d, int env0, const tbx_gridworld_state_t*
         d.sc[G_BECOMES * N + env] = o.reward_becomes;
         d.sc[G_W * N + env] = o.width; d.sc[G_H * N + env] = o.height; d.sc[G_NT * N + env] = o.n_tiles;
         d.sc[G_PCOL * N + env] = (int32_t)pack_color(o.player_color);
-        d.prev_score[env] = o.score;
+        // prev_score stays: like ToyboxBaseEnv.score (envs/atari/base.py:136-142) it follows steps, not state writes
     }
     if (lane < GT) {
         uint32_t* t = d.tiles + ((size_t)env * GT + lane) * 3;
