@@ -93,3 +93,39 @@ def test_mixed_batch_matches_separate_engines(oracle_lib):
         for k in range(per):
             assert bytes(me.get_state(k)) == bytes(se.get_state(k))
     assert mb.n_envs == 15 and mb.frame_bytes(3) == per * 3 * (160 * 240 + 250 * 160 + 210 * 320)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar"])
+def test_gpu_shard_decomposition_independence(game, hip_lib):
+    """The 8-GPU layout of BASELINE's headline config on one GPU: eight engines of 8192 envs, each seeded and fed in-kernel
+    actions by GLOBAL env index, end in exactly the states of one 65 536-env engine (no result depends on the rank count)."""
+    from toybox_amd import Engine
+    n, shards, steps = 65536, 8, 250
+    whole = Engine(game, n, lib=hip_lib)
+    whole.seed(1234)
+    whole.new_game()
+    per = n // shards
+    parts = []
+    for r in range(shards):
+        e = Engine(game, per, lib=hip_lib)
+        e.seed(1234 + r * per)
+        e.new_game()
+        parts.append(e)
+    for t in range(steps):
+        whole.step_synthetic(1337, t, env_offset=0, auto_reset=True)
+        for r, e in enumerate(parts):
+            e.step_synthetic(1337, t, env_offset=r * per, auto_reset=True)
+    whole.sync()
+    sw = whole.scalars()
+    for r, e in enumerate(parts):
+        e.sync()
+        for x, y in zip(e.scalars(), sw):
+            assert np.array_equal(x, y[r * per:(r + 1) * per]), (game, r)
+        for k in (0, 1, per // 2, per - 1):
+            assert bytes(e.get_state(k)) == bytes(whole.get_state(r * per + k)), (game, r, k)
+    for e in parts + [whole]:
+        e.close()
