@@ -156,7 +156,8 @@ __device__ __forceinline__ int wave_sum(int v)
 
 // ------------------------------------------------------------------ mover slots
 
-__device__ __forceinline__ int mget(const AmiRegs& s, int field, int slot) { return __shfl(s.mv[field], slot); }
+// slot is wave-uniform (movers are processed one after the other by the whole wave): v_readlane, not ds_bpermute
+__device__ __forceinline__ int mget(const AmiRegs& s, int field, int slot) { return __builtin_amdgcn_readlane(s.mv[field], slot); }
 __device__ __forceinline__ void mset(AmiRegs& s, int lane, int field, int slot, int v)
 {
     if (lane == slot) s.mv[field] = v;
