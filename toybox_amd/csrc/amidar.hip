@@ -114,7 +114,7 @@ __device__ __forceinline__ void ami_store(const AmiDev& d, int env, int lane, co
 
 __device__ __forceinline__ uint64_t row_of(const AmiRegs& s, int ty)
 {
-    const uint32_t lo = __shfl((uint32_t)s.trow, ty), hi = __shfl((uint32_t)(s.trow >> 32), ty);
+    const uint32_t lo = bcast((uint32_t)s.trow, ty), hi = bcast((uint32_t)(s.trow >> 32), ty);   // ty is wave-uniform everywhere
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
@@ -693,7 +693,7 @@ struct AmiPainter {
         in_board_x = tx >= 0 && tx < BW;
         inner = 0;
         for (int b = 0; b < f[A_N_BOXES]; b++) {
-            const uint32_t g = __shfl(s.bgeom, b), fl = __shfl(s.bflags, b);
+            const uint32_t g = bcast(s.bgeom, b), fl = bcast(s.bflags, b);
             if (!(fl & 1u)) continue;
             const int tl_tx = g & 255, tl_ty = (g >> 8) & 255, br_tx = (g >> 16) & 255, br_ty = (g >> 24) & 255;
             if (lane > tl_ty && lane < br_ty && br_tx - tl_tx >= 2) {
@@ -797,7 +797,7 @@ struct AmiPainter {
             if (ty != ty_cached) {                       // five scanlines share a tile row
                 ty_cached = ty;
                 const uint64_t row = row_of(s, ty);
-                const uint32_t inn = __shfl(inner, ty);
+                const uint32_t inn = bcast(inner, ty);
                 board_col = c_bg;
                 if (in_board_x) {
                     const int tag = (int)((row >> (2 * tx)) & 3ull);
@@ -816,13 +816,13 @@ struct AmiPainter {
             while (m) {
                 const int src = (int)__builtin_ctzll(m);
                 m &= m - 1;
-                const int sx = __shfl(m_x0, src);
+                const int sx = bcast(m_x0, src);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = c_enemy;
             }
             if (player_here) {
-                const int sx = __shfl(m_x0, PLAYER_SLOT);
+                const int sx = bcast(m_x0, PLAYER_SLOT);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     if (x0 + i >= sx && x0 + i < sx + TBX_AMI_MOVER_W) px[i] = c_player;

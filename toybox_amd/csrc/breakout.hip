@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
                     while (m) {   // ascending brick index == the oracle's paint order
                         const int src = (int)__builtin_ctzll(m);
                         m &= m - 1;
-                        overlay4(px, x0, __shfl(rx0, src), __shfl(rw, src), __shfl(rc, src));
+                        overlay4(px, x0, bcast(rx0, src), bcast(rw, src), bcast(rc, src));
                     }
                 }
             }

@@ -811,7 +811,7 @@ struct SiPainter {
             while (m) {
                 const int src = (int)__builtin_ctzll(m);
                 m &= m - 1;
-                paint_bits<NG>(px, gx, __shfl(s_x, src), __shfl(s.srow, src), TBX_SI_SHIELD_W, __shfl(s_c, src));
+                paint_bits<NG>(px, gx, bcast(s_x, src), bcast(s.srow, src), TBX_SI_SHIELD_W, bcast(s_c, src));
             }
         }
         // enemies in index order.  The set of enemies crossing a scanline (ym) is the same for the ten scanlines of a
@@ -878,14 +878,14 @@ struct SiPainter {
             uint64_t m = __ballot(l_on && y >= ly0 && y < ly1);
             if ((m >> SHIP_SLOT) & 1) {
                 const Laser l = get_laser(s, SHIP_SLOT);
-                paint_span<NG>(px, gx, l.x, (long)l.x + l.w, __shfl(l_col, SHIP_SLOT));
+                paint_span<NG>(px, gx, l.x, (long)l.x + l.w, bcast(l_col, SHIP_SLOT));
             }
             m &= (1ull << SHIP_SLOT) - 1;
             while (m) {
                 const int src = (int)__builtin_ctzll(m);
                 m &= m - 1;
-                const long lx = __shfl(s.lf[LF_X], src), lw = __shfl(s.lf[LF_W], src);
-                paint_span<NG>(px, gx, lx, lx + lw, __shfl(l_col, src));
+                const long lx = bcast(s.lf[LF_X], src), lw = bcast(s.lf[LF_W], src);
+                paint_span<NG>(px, gx, lx, lx + lw, bcast(l_col, src));
             }
         }
         if (y >= 2 && y < 12) {

@@ -118,6 +118,10 @@ struct ActionSource {
 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// value of lane `src` for a WAVE-UNIFORM src: v_readlane_b32 (a few cycles, result in an SGPR) instead of ds_bpermute_b32
+__device__ __forceinline__ int bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+
 __device__ __forceinline__ uint32_t gray_of(uint32_t rgba)
 {
     uint32_t r = rgba & 255u, g = (rgba >> 8) & 255u, b = (rgba >> 16) & 255u;
