@@ -84,11 +84,9 @@ __global__ void agent_fill_u8_kernel(uint8_t* p, uint8_t v, int n)
 // multiply-shift reciprocal (exact for sums < 2^25) and rolled into the env's frame stack.
 template <int S>
 __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
-                                                               const uint8_t* __restrict__ fin, const int32_t* __restrict__ racc,
-                                                               const AgentTaps* __restrict__ tx,
-                                                               uint8_t* __restrict__ obs, float* __restrict__ reward_out,
-                                                               uint8_t* __restrict__ done_out, int H, int W, int oh, int ow,
-                                                               uint64_t magic, int clip, int reset_mode, int n)
+                                                               const uint8_t* __restrict__ fin, const AgentTaps* __restrict__ tx,
+                                                               uint8_t* __restrict__ obs, int H, int W, int oh, int ow,
+                                                               uint64_t magic, int reset_mode, int n)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK][352];
     const int lane = threadIdx.x & 63;
@@ -215,8 +213,8 @@ int launch_warp(tbx_engine* e, int reset_mode, hipStream_t s)
     const uint8_t* A = a.cfg.skip >= 2 ? a.gray_a : a.gray_b;
     const uint64_t magic = (1ull << 42) / (uint64_t)(a.H * a.W) + 1ull;   // exact for numerators < 2^42 / area >= 2^25
     // fresh = the env was reset during this agent step (game over, or a lost life in episodic-life mode)
-#define WARP(S) hipLaunchKernelGGL(agent_warp_kernel<S>, grid, block, 0, s, A, a.gray_b, a.done_out, a.racc, a.tx, a.obs, \
-                                   a.reward_out, a.done_out, a.H, a.W, a.cfg.out_h, a.cfg.out_w, magic, a.cfg.clip_reward, reset_mode, e->n)
+#define WARP(S) hipLaunchKernelGGL(agent_warp_kernel<S>, grid, block, 0, s, A, a.gray_b, a.done_out, a.tx, a.obs, \
+                                   a.H, a.W, a.cfg.out_h, a.cfg.out_w, magic, reset_mode, e->n)
     switch (a.cfg.stack) {
     case 1: WARP(1); break;
     case 2: WARP(2); break;
@@ -232,8 +230,8 @@ AgentWarpArgs warp_args(tbx_engine* e, int reset_mode)
 {
     AgentState& a = *e->agent;
     AgentWarpArgs w;
-    w.fin = a.done_out; w.racc = a.racc; w.tx = a.tx; w.obs = a.obs; w.reward_out = a.reward_out; w.done_out = a.done_out;
-    w.H = a.H; w.W = a.W; w.oh = a.cfg.out_h; w.ow = a.cfg.out_w; w.stack = a.cfg.stack; w.clip = a.cfg.clip_reward;
+    w.fin = a.done_out; w.tx = a.tx; w.obs = a.obs;
+    w.H = a.H; w.W = a.W; w.oh = a.cfg.out_h; w.ow = a.cfg.out_w; w.stack = a.cfg.stack;
     w.reset_mode = reset_mode;
     w.two_frames = a.cfg.skip >= 2;
     w.magic = (1ull << 42) / (uint64_t)(a.H * a.W) + 1ull;

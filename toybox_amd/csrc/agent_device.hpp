@@ -12,13 +12,10 @@ struct AgentTaps {          // area-resize taps of one output row / column
 
 // what a game's fused observation kernel needs from the agent layer
 struct AgentWarpArgs {
-    const uint8_t* fin;        // [N] game ended during this agent step (observation = reset frame alone)
-    const int32_t* racc;       // [N] summed reward
+    const uint8_t* fin;        // [N] the env was reset during this agent step (observation = reset frame alone)
     const AgentTaps* tx;       // [out_w] column taps
     uint8_t* obs;              // [N][out_h][out_w][stack]
-    float* reward_out;         // [N]
-    uint8_t* done_out;         // [N]
-    int H, W, oh, ow, stack, clip, reset_mode;
+    int H, W, oh, ow, stack, reset_mode;
     int two_frames;            // skip >= 2: the observation is max(frame A, frame B); otherwise frame B alone
     uint64_t magic;            // floor(2^42 / (H*W)) + 1
 };
