@@ -30,21 +30,6 @@ namespace {
 
 constexpr int MAX_TAPS = 8;
 
-__global__ void agent_acc_init_kernel(int32_t* racc, uint8_t* fin, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { racc[i] = 0; fin[i] = 0; }
-}
-
-// after every sub-frame: rewards count until (and including) the frame that ends the game (MaxAndSkipEnv breaks there)
-__global__ void agent_acc_kernel(const int32_t* reward, const uint8_t* done, int32_t* racc, uint8_t* fin, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || fin[i]) return;
-    racc[i] += reward[i];
-    if (done[i]) fin[i] = 1;
-}
-
 // after the `skip` frames: Monitor bookkeeping, EpisodicLifeEnv's done rule, clipped reward, and what kind of reset the
 // env needs (0 none, 1 life lost, 2 game over).  simple: no in-kernel reset follows, so a finished episode's counters
 // are cleared here.
@@ -276,11 +261,12 @@ int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s)
     const int n = e->n, tb = 256, gb = (n + tb - 1) / tb;
     const bool fused = e->ops->agent_fused() && !a.force_generic;
     const bool in_kernel_reset = needs_reset_kernel(a);
-    hipLaunchKernelGGL(agent_acc_init_kernel, dim3(gb), dim3(tb), 0, s, a.racc, a.fin, n);
+    // the step kernels sum reward / latch done themselves (tbx_accumulate), so the skip loop is one launch per frame
+    src.acc_reward = a.racc; src.acc_done = a.fin;
     for (int i = 0; i < a.cfg.skip; i++) {
+        src.acc_first = i == 0;
         int rc = e->ops->step(e, src, 0, s);
         if (rc) return rc;
-        hipLaunchKernelGGL(agent_acc_kernel, dim3(gb), dim3(tb), 0, s, e->reward, e->done, a.racc, a.fin, n);
         if (i == a.cfg.skip - 2) {
             rc = fused ? e->ops->agent_snapshot(e, 0, s) : e->ops->render(e, a.gray_a, 1, 0, n, s);
             if (rc) return rc;

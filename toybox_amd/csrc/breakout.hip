@@ -495,6 +495,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_step_kernel(BrkDev d, BrkCfg c,
         d.score_out[env] = out_score;
         uint32_t lv = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
         d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv << 40);
+        tbx_accumulate(src, env, rew, is_done);
     }
 }
 
@@ -785,6 +786,7 @@ __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCf
     d.score_out[env] = out_score;
     const uint32_t lv8 = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
     d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv8 << 40);
+    tbx_accumulate(src, env, rew, is_done);
     recs[env] = t_record(s);
 }
 

@@ -157,6 +157,7 @@ __global__ __launch_bounds__(128) void gw_step_kernel(GwDev d, ActionSource src,
     d.lives_out[env] = out_lives;
     d.score_out[env] = out_score;
     d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)(uint32_t)out_lives << 40);
+    tbx_accumulate(src, env, rew, is_done);
 }
 
 // reset-time wrappers of the agent layer (agent_device.hpp, AgentResetProc), thread per flagged env

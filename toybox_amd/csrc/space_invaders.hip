@@ -543,6 +543,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiCfg c, Ac
         d.score_out[env] = out_score;
         uint32_t lv = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
         d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv << 40);
+        tbx_accumulate(src, env, rew, is_done);
     }
 }
 

@@ -114,7 +114,21 @@ struct ActionSource {
     uint64_t seed, t, env_offset;
     int single_env;           // >= 0: only this env steps, with buttons `single_buttons`
     uint32_t single_buttons;
+    // agent layer (MaxAndSkipEnv): sum this frame's reward into acc_reward[env] until the env is done (acc_done[env]);
+    // acc_first: the first of the `skip` frames starts the sums over
+    int32_t* acc_reward;
+    uint8_t* acc_done;
+    int acc_first;
 };
+
+__device__ __forceinline__ void tbx_accumulate(const ActionSource& src, int env, int32_t rew, bool is_done)
+{
+    if (!src.acc_reward) return;
+    const bool was_done = src.acc_first ? false : src.acc_done[env] != 0;
+    if (was_done) return;
+    src.acc_reward[env] = (src.acc_first ? 0 : src.acc_reward[env]) + rew;
+    src.acc_done[env] = is_done ? 1 : 0;
+}
 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
