@@ -1,0 +1,173 @@
+"""The gym / VecEnv surfaces: ToyboxBaseEnv's semantics as the reference states them
+(/root/reference/toybox/envs/atari/base.py:38-173) and the baselines VecEnv contract
+(baselines/baselines/common/vec_env/__init__.py:26-131, dummy_vec_env.py:45-60), over the CPU restatement here and over
+the HIP library on the GPU box."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from toybox_amd import Engine, _abi
+from toybox_amd import toybox as tbm
+from toybox_amd.envs import (ACTION_MEANING, AmidarEnv, BreakoutEnv, ENV_IDS, SpaceInvadersEnv, ToyboxPreprocVecEnv, ToyboxVecEnv,
+                             hash_seed, make)
+from toybox_amd.envs.vec_env import LazyInfos
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def factory(request, oracle_lib):
+    lib = oracle_lib if request.param == "oracle" else request.getfixturevalue("hip_lib")
+    tbm.set_engine_factory(lambda game, n: Engine(game, n, lib=lib))
+    yield lambda game, n: Engine(game, n, lib=lib)
+    tbm.set_engine_factory(None)
+
+
+def test_hash_seed_is_gyms():
+    # gym.utils.seeding.hash_seed(seed) = int.from_bytes(sha512(str(seed))[:8], 'little'); spot values computed by hand
+    import hashlib
+    for s in (0, 1, 14, 2 ** 31):
+        assert hash_seed(s) == int.from_bytes(hashlib.sha512(str(s).encode()).digest()[:8], "little")
+
+
+@pytest.mark.parametrize("cls,game,dims,n_act", [(BreakoutEnv, "breakout", (160, 240), 4), (AmidarEnv, "amidar", (250, 160), 6),
+                                                 (SpaceInvadersEnv, "space_invaders", (210, 320), 6)])
+def test_base_env_semantics(cls, game, dims, n_act, factory):
+    env = cls(grayscale=True)
+    assert env.observation_space.shape == dims + (1,) and env.observation_space.dtype == np.uint8
+    assert env.action_space.n == n_act and env.reward_range == (0, float("inf"))
+    assert env.get_action_meanings() == list(ACTION_MEANING.values()) and len(env.get_action_meanings()) == 18
+    s1, s2 = env.seed(13)
+    assert s1 == 13 and s2 == hash_seed(14) % 2 ** 31                  # base.py:84-98
+    obs = env.reset()
+    assert obs.shape == dims + (1,) and obs.dtype == np.uint8
+    assert env.cached_state is not None and env.score == 0
+    total, done, steps = 0, False, 0
+    rng = np.random.default_rng(0)
+    while not done and steps < 6000:
+        prev = env.toybox.get_score()
+        obs, r, done, info = env.step(int(rng.integers(0, n_act)))
+        assert r == max(env.toybox.get_score() - prev, 0)               # reward = max(score delta, 0)
+        assert info["lives"] == env.toybox.get_lives()
+        assert info["score"] == (0 if done else env.toybox.get_score())
+        assert done == (env.toybox.get_lives() <= 0) == env.ale.game_over()
+        assert ("cached_state" in info) == done                          # only on the game-over step
+        total += r
+        steps += 1
+    with pytest.raises(AssertionError):
+        env.step(n_act)                                                  # assert action_index < len(action_set)
+    rgb = cls(grayscale=False)
+    assert rgb.reset().shape == dims + (3,)
+    assert rgb.render("rgb_array").shape == dims + (3,)
+    rgba = cls(grayscale=False, alpha=True)
+    o4 = rgba.reset()
+    assert o4.shape == dims + (4,) and (o4[..., 3] == 255).all()
+    for e in (env, rgb, rgba):
+        e.close()
+    assert make([k for k, v in ENV_IDS.items() if v is cls][0]).action_space.n == n_act
+
+
+def test_seed_reproduces_rollout(factory):
+    def rollout(seed):
+        env = BreakoutEnv()
+        env.seed(seed)
+        env.reset()
+        out = []
+        for t in range(300):
+            o, r, d, info = env.step(1 if t % 7 == 0 else 2 + (t % 2))
+            out.append((r, d, info["lives"]))
+        js = env.toybox.to_state_json()
+        env.close()
+        return out, js
+    a, b, c = rollout(5), rollout(5), rollout(6)
+    assert a == b and a[1] != c[1]
+
+
+@pytest.mark.parametrize("game", ["breakout", "amidar", "space_invaders"])
+def test_vec_env_contract(game, factory):
+    n = 6
+    env = ToyboxVecEnv(game, n, grayscale=False, engine=factory(game, n))
+    seeds = env.seed(100)
+    assert [s[0] for s in seeds] == list(range(100, 100 + n)) and seeds[2][1] == hash_seed(103) % 2 ** 31   # cmd_util.py:31
+    obs = env.reset()
+    H, W = env.observation_space.shape[:2]
+    assert obs.shape == (n, H, W, 3) and obs.dtype == np.uint8
+    # the batch equals n single envs with the same seeds: obs, rewards, dones, infos, and the reset obs on done
+    singles = []
+    cls = {"breakout": BreakoutEnv, "amidar": AmidarEnv, "space_invaders": SpaceInvadersEnv}[game]
+    for i in range(n):
+        e = cls(grayscale=False)
+        e.seed(100 + i)
+        singles.append(e)
+    ref = np.stack([e.reset() for e in singles])
+    assert np.array_equal(obs, ref)
+    rng = np.random.default_rng(3)
+    ends = 0
+    for t in range(700 if game == "breakout" else 250):
+        a = rng.integers(0, env.action_space.n, n)
+        env.step_async(a)
+        obs, rew, done, infos = env.step_wait()
+        assert rew.dtype == np.float32 and done.dtype == bool and len(infos) == n
+        for i, e in enumerate(singles):
+            o, r, d, info = e.step(int(a[i]))
+            if d:
+                o = e.reset()                                            # DummyVecEnv: the obs of a done env is its reset obs
+                ends += 1
+            assert rew[i] == r and done[i] == d, (t, i)
+            assert infos[i]["lives"] == info["lives"] and infos[i]["score"] == info["score"], (t, i)
+            assert np.array_equal(obs[i], o), (t, i)
+    if game == "breakout":
+        assert ends > 0
+    assert env.get_images().shape == (n, H, W, 3)
+    with pytest.raises(ValueError):
+        env.step(np.zeros(n + 1, np.int64))
+    with pytest.raises(AssertionError):
+        env.step(np.full(n, 99))
+    env.close()
+    for e in singles:
+        e.close()
+
+
+def test_vec_env_cached_terminal_state(factory):
+    eng = factory("breakout", 4)
+    env = ToyboxVecEnv("breakout", 4, cache_terminal_state=True, engine=eng)
+    env.seed(1)
+    env.reset()
+    for i in range(4):                                   # one life left: the next lost ball ends the game
+        st = eng.get_state(i)
+        st.lives = 1
+        eng.set_state(i, st)
+    rng = np.random.default_rng(2)
+    seen = 0
+    for t in range(4000):
+        obs, rew, done, infos = env.step(rng.integers(0, 4, 4))
+        for i in np.flatnonzero(done):
+            st = infos[int(i)]["cached_state"]
+            assert st["lives"] == 0 and len(st["bricks"]) == 108   # the terminal state, not the reset one
+            assert infos[int(i)]["score"] == 0 and infos[int(i)]["lives"] == 0
+            seen += 1
+        if seen >= 2:
+            break
+    assert seen >= 2
+    assert eng.scalars()[1].max() == 5                   # the finished envs play a fresh game
+    env.close()
+
+
+def test_lazy_infos_behaves_like_a_list_of_dicts():
+    inf = LazyInfos(4, {"lives": np.array([3, 2, 1, 0]), "score": np.array([5, 0, 7, 0])}, {2: {"episode": {"r": 7.0, "l": 9}}})
+    assert len(inf) == 4 and inf[0] == {"lives": 3, "score": 5} and inf[-1]["lives"] == 0
+    assert [d.get("episode") for d in inf] == [None, None, {"r": 7.0, "l": 9}, None]
+    assert inf[1:3][1]["episode"]["l"] == 9 and inf.with_key("episode") == {2: {"r": 7.0, "l": 9}}
+    assert isinstance(inf[0]["lives"], int)
+    with pytest.raises(IndexError):
+        inf[4]
+
+
+def test_preproc_vec_env_defaults(factory):
+    env = ToyboxPreprocVecEnv("amidar", 3, engine=factory("amidar", 3))
+    assert env.observation_space.shape == (84, 84, 4) and env.action_space.n == 6
+    obs = env.reset()
+    assert obs.shape == (3, 84, 84, 4) and obs.dtype == np.uint8 and obs[..., :3].max() == 0
+    obs, rew, done, infos = env.step(np.array([1, 2, 3]))
+    assert rew.dtype == np.float32 and set(np.unique(rew)) <= {-1.0, 0.0, 1.0} and len(infos) == 3
+    assert obs[..., 2].max() > 0 and obs[..., 1].max() == 0               # the stack rolls by one frame per agent step
+    env.close()

@@ -13,6 +13,41 @@ from .base import hash_seed
 from .spaces import Box, Discrete
 
 
+class LazyInfos:
+    """The per-env info dicts of a VecEnv step as a read-only sequence that builds a dict only when one is asked for:
+    65 536 Python dicts per step would cost more host time than the whole device step.  Indexing, iteration and len()
+    behave like the list of dicts baselines expects (`for info in infos: info.get('episode')`)."""
+
+    def __init__(self, n, columns=None, extras=None):
+        self._n = int(n)
+        self._columns = columns or {}        # key -> array[N]
+        self._extras = extras or {}          # env index -> dict of additional keys
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(self._n))]
+        i = int(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        d = {k: v[i].item() for k, v in self._columns.items()}
+        d.update(self._extras.get(i, ()))
+        return d
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+    def with_key(self, key):
+        """{env index: value} of the envs whose info carries `key` -- e.g. infos.with_key('episode') -- without walking N dicts"""
+        if key in self._columns:
+            return {i: self._columns[key][i].item() for i in range(self._n)}
+        return {i: d[key] for i, d in self._extras.items() if key in d}
+
+
 class ToyboxVecEnv:
     def __init__(self, game, num_envs, grayscale=True, alpha=False, seed=None, cache_terminal_state=False, engine=None):
         self.game = {"spaceinvaders": "space_invaders"}.get(game, game)
@@ -59,20 +94,18 @@ class ToyboxVecEnv:
     def step_wait(self):
         assert self._pending is not None, "step_wait without step_async"
         actions, self._pending = self._pending, None
-        infos = [{} for _ in range(self.num_envs)]
+        extras = {}
         if self.cache_terminal_state:
             reward, done, lives, score = self.engine.step(actions, auto_reset=False)
             idx = np.nonzero(done)[0]
             for i in idx:
-                infos[i]["cached_state"] = self._codec.state_to_json(self.engine.get_state(int(i)))
+                extras[int(i)] = {"cached_state": self._codec.state_to_json(self.engine.get_state(int(i)))}
             if len(idx):
                 self.engine.new_game(done.astype(np.uint8))
         else:
             reward, done, lives, score = self.engine.step(actions, auto_reset=True)
         obs = self.engine.render(self._channels)
-        for i in range(self.num_envs):
-            infos[i]["lives"] = int(lives[i])
-            infos[i]["score"] = 0 if done[i] else int(score[i])
+        infos = LazyInfos(self.num_envs, {"lives": lives, "score": np.where(done, 0, score)}, extras)
         return obs, reward.astype(np.float32), done, infos
 
     def step(self, actions):
@@ -145,11 +178,9 @@ class ToyboxPreprocVecEnv:
         assert self._pending is not None, "step_wait without step_async"
         actions, self._pending = self._pending, None
         obs, reward, done = self.engine.agent_step(actions)
-        infos = [{} for _ in range(self.num_envs)]
         ended, ret, length = self.engine.agent_episodes()
-        for i in np.flatnonzero(ended):
-            infos[int(i)]["episode"] = {"r": float(ret[i]), "l": int(length[i])}
-        return obs, reward, done, infos
+        extras = {int(i): {"episode": {"r": float(ret[i]), "l": int(length[i])}} for i in np.flatnonzero(ended)}
+        return obs, reward, done, LazyInfos(self.num_envs, None, extras)
 
     def step(self, actions):
         self.step_async(actions)
