@@ -23,7 +23,7 @@ def lib(request, oracle_lib):
     return _lib.load()
 
 
-@pytest.mark.parametrize("game", GAMES)
+@pytest.mark.parametrize("game", GAMES + ["gridworld"])
 @pytest.mark.parametrize("n", [1, 3, 5, 67])
 def test_ragged_batch_sizes(game, n, lib, oracle_lib):
     """Batch sizes that do not fill a 4-env block / a 64-lane wave behave like any other: every env steps, renders and
@@ -32,7 +32,7 @@ def test_ragged_batch_sizes(game, n, lib, oracle_lib):
     for x in (e, o):
         x.seed(77)
         x.new_game()
-    for t in range(120):
+    for t in range(120 if game != "gridworld" else 900):     # long enough for GridWorld games to end (auto-reset in a partly empty wave)
         a = synthetic_actions(game, n, t)
         r1, r2 = e.step(a, auto_reset=True), o.step(a, auto_reset=True)
         for p, q in zip(r1, r2):

@@ -144,8 +144,15 @@ __global__ __launch_bounds__(128) void gw_step_kernel(GwDev d, ActionSource src,
     const int32_t out_lives = s.over ? 0 : 1, out_score = s.score;
     const bool is_done = out_lives <= 0;
     int32_t prev = s.score;
-    if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
-        gw_copy_board(d, env, 0, 1);
+    // auto-reset: the wave copies the 1 KB board of each of its finished envs together, one env at a time
+    const bool resets = is_done && (flags & TBX_STEP_AUTO_RESET);
+    const uint64_t act = __ballot(true);                 // the last wave of a launch may be partly empty
+    const int n_act = __popcll(act), rank = __popcll(act & ((1ull << (threadIdx.x & 63)) - 1ull));
+    for (uint64_t m = __ballot(resets); m; m &= m - 1) {
+        const int env_r = __builtin_amdgcn_readlane(env, (int)__builtin_ctzll(m));
+        gw_copy_board(d, env_r, rank, n_act);
+    }
+    if (resets) {
         gw_new_scalars(d, s);
         d.sc[G_PCOL * (size_t)d.n + env] = (int32_t)pack_color(d.cfg->player_color);
         prev = 0;
