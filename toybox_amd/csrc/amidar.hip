@@ -81,8 +81,11 @@ __device__ __forceinline__ void ami_load(const AmiDev& d, int env, int lane, Ami
     const size_t N = (size_t)d.n;
     s.rng.s0 = d.rng[env];
     s.rng.s1 = d.rng[N + env];
+    // the env's scalars with ONE load instruction (lane i fetches field i) and a v_readlane per field actually used
+    static_assert(ANF <= 64, "one lane per scalar field");
+    const int32_t fv = lane < ANF ? d.sc[(size_t)lane * N + env] : 0;
 #pragma unroll
-    for (int i = 0; i < ANF; i++) s.f[i] = d.sc[(size_t)i * N + env];
+    for (int i = 0; i < ANF; i++) s.f[i] = __builtin_amdgcn_readlane(fv, i);
     s.trow = d.tiles[(size_t)env * 32 + (lane & 31)];
     s.bgeom = d.boxes[(size_t)env * 128 + lane];
     s.bflags = d.boxes[(size_t)env * 128 + 64 + lane];
@@ -97,8 +100,12 @@ __device__ __forceinline__ void ami_store(const AmiDev& d, int env, int lane, co
     if (lane == 0) {
         d.rng[env] = s.rng.s0;
         d.rng[N + env] = s.rng.s1;
+    }
+    {   // lane i stores field i: one store instruction for the scalars
+        int32_t fv = 0;
 #pragma unroll
-        for (int i = 0; i < ANF; i++) d.sc[(size_t)i * N + env] = s.f[i];
+        for (int i = 0; i < ANF; i++) fv = lane == i ? s.f[i] : fv;
+        if (lane < ANF) d.sc[(size_t)lane * N + env] = fv;
     }
     if (lane < 32) d.tiles[(size_t)env * 32 + lane] = s.trow;
     d.boxes[(size_t)env * 128 + lane] = s.bgeom;

@@ -80,8 +80,12 @@ __device__ __forceinline__ void si_load(const SiDev& d, int env, int lane, SiReg
     const size_t N = (size_t)d.n;
     s.rng.s0 = d.rng[env];
     s.rng.s1 = d.rng[N + env];
+    // the env's NF scalars with ONE load instruction (lane i fetches field i) and a v_readlane per field actually used:
+    // they land in SGPRs instead of occupying NF VGPRs, and NF - 1 single-dword VMEM instructions disappear
+    static_assert(NF <= 64, "one lane per scalar field");
+    const int32_t fv = lane < NF ? d.sc[(size_t)lane * N + env] : 0;
 #pragma unroll
-    for (int i = 0; i < NF; i++) s.f[i] = d.sc[(size_t)i * N + env];
+    for (int i = 0; i < NF; i++) s.f[i] = __builtin_amdgcn_readlane(fv, i);
     const int32_t* e = d.enemies + (size_t)env * NEF * 64;
     s.ex = e[EF_X * 64 + lane]; s.ey = e[EF_Y * 64 + lane]; s.erow = e[EF_ROW * 64 + lane]; s.ecol = e[EF_COL * 64 + lane];
     s.eid = e[EF_ID * 64 + lane]; s.epoints = e[EF_POINTS * 64 + lane]; s.estatus = e[EF_STATUS * 64 + lane];
@@ -97,8 +101,12 @@ __device__ __forceinline__ void si_store(const SiDev& d, int env, int lane, cons
     if (lane == 0) {
         d.rng[env] = s.rng.s0;
         d.rng[N + env] = s.rng.s1;
+    }
+    {   // lane i stores field i: one store instruction for the NF scalars
+        int32_t fv = 0;
 #pragma unroll
-        for (int i = 0; i < NF; i++) d.sc[(size_t)i * N + env] = s.f[i];
+        for (int i = 0; i < NF; i++) fv = lane == i ? s.f[i] : fv;
+        if (lane < NF) d.sc[(size_t)lane * N + env] = fv;
     }
     int32_t* e = d.enemies + (size_t)env * NEF * 64;
     e[EF_X * 64 + lane] = s.ex; e[EF_Y * 64 + lane] = s.ey; e[EF_ROW * 64 + lane] = s.erow; e[EF_COL * 64 + lane] = s.ecol;
