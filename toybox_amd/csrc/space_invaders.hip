@@ -639,6 +639,9 @@ __device__ __forceinline__ void paint_span(uint32_t (&px)[NG][4], const int (&gx
 // groups); lanes also hold the entities (lane = enemy / shield row / laser slot).  Built once per frame by setup();
 // paint_row() then composes one busy scanline in the checker's order (shields, enemies, ufo, ship, lasers, HUD).
 constexpr int SI_NG = 2;
+// the block's LDS copy of every sprite row (si_fill_sprites): enemy pose A, pose B, explosion, ship, ship death 1 / 2, ufo
+constexpr int SPR_SHIP = 3 * TBX_SI_ENEMY_H, SPR_D1 = SPR_SHIP + TBX_SI_SHIP_H, SPR_D2 = SPR_D1 + TBX_SI_SHIP_H;
+constexpr int SPR_UFO = SPR_D2 + TBX_SI_SHIP_H, SPR_WORDS = SPR_UFO + TBX_SI_UFO_H;
 
 template <int C>
 struct SiPainter {
@@ -874,12 +877,12 @@ struct SiPainter {
             }
         }
         if (ufo_on && y >= f[F_UFO_Y] && y < f[F_UFO_Y] + TBX_SI_UFO_H)
-            paint_bits<NG>(px, gx, f[F_UFO_X], SI_SPR_UFO[y - f[F_UFO_Y]], TBX_SI_UFO_W, c_ufo);
+            paint_bits<NG>(px, gx, f[F_UFO_X], spr_lds[SPR_UFO + (y - f[F_UFO_Y])], TBX_SI_UFO_W, c_ufo);
         if (y >= f[F_SHIP_Y] && y < f[F_SHIP_Y] + TBX_SI_SHIP_H) {
             const int ry = y - f[F_SHIP_Y];
-            if (f[F_SHIP_FLAGS] & 1) paint_bits<NG>(px, gx, f[F_SHIP_X], SI_SPR_SHIP[ry], 16, c_ship);
+            if (f[F_SHIP_FLAGS] & 1) paint_bits<NG>(px, gx, f[F_SHIP_X], spr_lds[SPR_SHIP + ry], 16, c_ship);
             else if (f[F_SHIP_DC] >= 0)
-                paint_bits<NG>(px, gx, f[F_SHIP_X], (f[F_SHIP_FLAGS] & 2) ? SI_SPR_D1[ry] : SI_SPR_D2[ry], 16, c_ship);
+                paint_bits<NG>(px, gx, f[F_SHIP_X], spr_lds[((f[F_SHIP_FLAGS] & 2) ? SPR_D1 : SPR_D2) + ry], 16, c_ship);
         }
         // lasers: the ship's first, then enemy lasers in slot order
         if (y >= l_lo && y < l_hi) {
@@ -925,12 +928,20 @@ struct SiGrayPainter : SiPainter<1> {
     uint64_t rep[4] = {0ull, 0ull, 0ull, 0ull};                                   // sprite rows differ scanline by scanline
 };
 
-// the block's LDS copy of the enemy sprite rows (pose A, pose B, explosion); ends with a block barrier
+// fills the block's LDS copy of the sprite rows (scalar loads from constant memory inside the scanline loop stalled the
+// wave once per sprite row); ends with a block barrier
 __device__ __forceinline__ void si_fill_sprites(uint32_t* spr_lds)
 {
-    if (threadIdx.x < 3 * TBX_SI_ENEMY_H) {
-        const int t = threadIdx.x;
-        spr_lds[t] = t < TBX_SI_ENEMY_H ? SI_SPR_A[t] : t < 2 * TBX_SI_ENEMY_H ? SI_SPR_B[t - TBX_SI_ENEMY_H] : SI_SPR_BOOM[t - 2 * TBX_SI_ENEMY_H];
+    for (int t = threadIdx.x; t < SPR_WORDS; t += blockDim.x) {
+        uint32_t v;
+        if (t < TBX_SI_ENEMY_H) v = SI_SPR_A[t];
+        else if (t < 2 * TBX_SI_ENEMY_H) v = SI_SPR_B[t - TBX_SI_ENEMY_H];
+        else if (t < SPR_SHIP) v = SI_SPR_BOOM[t - 2 * TBX_SI_ENEMY_H];
+        else if (t < SPR_D1) v = SI_SPR_SHIP[t - SPR_SHIP];
+        else if (t < SPR_D2) v = SI_SPR_D1[t - SPR_D1];
+        else if (t < SPR_UFO) v = SI_SPR_D2[t - SPR_D2];
+        else v = SI_SPR_UFO[t - SPR_UFO];
+        spr_lds[t] = v;
     }
     __syncthreads();
 }
@@ -944,7 +955,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
     using Stager = RowStager<C, W, SI_UNIT_ROWS>;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
     __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][SiPainter<C>::NCLS * 8];
-    __shared__ uint32_t spr_lds[3 * TBX_SI_ENEMY_H];
+    __shared__ uint32_t spr_lds[SPR_WORDS];
     si_fill_sprites(spr_lds);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -994,7 +1005,7 @@ template <int S>
 __global__ __launch_bounds__(TBX_BLOCK) void si_agent_warp_kernel(SiDev dA, SiDev dB, AgentWarpArgs a, int n)
 {
     __shared__ AgentFusedLds<SiGrayPainter> lds[TBX_WAVES_PER_BLOCK];
-    __shared__ uint32_t spr_lds[3 * TBX_SI_ENEMY_H];
+    __shared__ uint32_t spr_lds[SPR_WORDS];
     si_fill_sprites(spr_lds);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
