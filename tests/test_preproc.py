@@ -512,3 +512,54 @@ def test_gpu_agent_pipeline_survives_state_writes(game, hip_lib, oracle_lib):
     run(70, 30)
     for i in range(0, n, 5):
         assert bytes(g.get_state(i)) == bytes(o.get_state(i))
+
+
+def _stress_config(game, lib):
+    """a config at the edges of what the device engine holds"""
+    with Engine(game, 1, lib=lib) as e:
+        cfg = e.get_config()
+    if game == "breakout":
+        cfg.n_rows = 14                                   # 252 bricks, the wall reaches further down
+        for i in range(14):
+            cfg.row_scores[i] = 1 + i % 7
+            cfg.row_colors[i].r, cfg.row_colors[i].g, cfg.row_colors[i].b, cfg.row_colors[i].a = 30 + 15 * i, 250 - 12 * i, (i * 53) % 256, 255
+        cfg.start_lives = 2
+    elif game == "space_invaders":
+        cfg.n_rows = 10                                   # 60 enemies
+        for i in range(10):
+            cfg.row_scores[i] = 10 * (10 - i)
+        cfg.n_shields = 2
+        cfg.shield_x[0], cfg.shield_x[1] = 60, 230
+        cfg.jitter = 0.9
+        cfg.start_lives = 2
+    return cfg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", ["breakout", "space_invaders"])
+def test_gpu_agent_pipeline_with_stress_configs(game, hip_lib, oracle_lib):
+    """Configs at the capacity edges (14 brick rows; 60 invaders, two moved shields, jittery fire): the fused agent path ==
+    the CPU restatement and == the generic render + warp path."""
+    import os
+    n = 128
+    cfg = _stress_config(game, oracle_lib)
+    g, o = Engine(game, n, lib=hip_lib, config=cfg), Engine(game, n, lib=oracle_lib, config=cfg)
+    os.environ["TBX_AGENT_GENERIC"] = "1"
+    try:
+        gen = Engine(game, n, lib=hip_lib, config=cfg)
+        gen.seed(3)
+        gen.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=False, episodic_life=True, fire_reset=True, noop_max=8)
+    finally:
+        os.environ["TBX_AGENT_GENERIC"] = "0"
+    for e in (g, o):
+        e.seed(3)
+        e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=False, episodic_life=True, fire_reset=True, noop_max=8)
+    r0 = g.agent_reset()
+    assert np.array_equal(r0, o.agent_reset()) and np.array_equal(r0, gen.agent_reset())
+    for t in range(350):
+        a = synthetic_actions(game, n, t, seed=31)
+        x, y, z = g.agent_step(a), o.agent_step(a), gen.agent_step(a)
+        for p, q, r in zip(x, y, z):
+            assert np.array_equal(p, q) and np.array_equal(p, r), t
+    for i in range(0, n, 9):
+        assert bytes(g.get_state(i)) == bytes(o.get_state(i))
