@@ -277,3 +277,57 @@ def test_full_size_batch_parity(game, hip_lib, oracle_lib, monkeypatch):
     for i in sample[:24]:
         assert np.array_equal(g.render_env(int(i), 3), o.render_env(int(i), 3)), i
     assert acc.sum() > 0 and (game != "breakout" or dones > 0)      # rewards flowed; Breakout games ended and restarted
+
+
+def test_space_invaders_interventions_parity(hip_lib, oracle_lib):
+    """Hand-written SpaceInvaders states: enemies stacked on top of each other (paint order, the multi-candidate path of the
+    rasteriser), eight enemy lasers over shields and ship, a chewed shield, a visible ufo, an exploding ship, out-of-frame
+    objects -- frames in every format, the fused observation, and the dynamics from there."""
+    n = 24
+    g, o = _pair("space_invaders", n, hip_lib, oracle_lib, seed=8)
+    for t in range(140):                                   # past the get-ready phase
+        a = synthetic_actions("space_invaders", n, t, seed=4)
+        g.step(a), o.step(a)
+    rng = np.random.default_rng(5)
+    for i in range(n):
+        st = o.get_state(i)
+        for k in range(0, 36, 3):                          # pile enemies up: same and overlapping columns
+            st.enemies[k].x = st.enemies[(k + 1) % 36].x + int(rng.integers(-14, 15))
+            st.enemies[k].y = st.enemies[(k + 1) % 36].y + int(rng.integers(-6, 7))
+        st.enemies[5].x, st.enemies[5].y = -9, 40          # partly outside the frame
+        st.enemies[7].x = 312
+        st.enemies[9].alive, st.enemies[9].death_counter = 0, 7   # exploding
+        st.n_enemy_lasers = 8
+        for k in range(8):
+            l = st.enemy_lasers[k]
+            l.x, l.y, l.w, l.h, l.t, l.movement, l.speed = 40 + 33 * k + i, 120 + 9 * k, 2, 8, 0, 1, 3
+            l.color.r, l.color.g, l.color.b, l.color.a = 200 - 20 * k, 30 * k, 255, 255
+        st.has_ship_laser = 1
+        st.ship_laser.x, st.ship_laser.y, st.ship_laser.w, st.ship_laser.h, st.ship_laser.movement, st.ship_laser.speed = 150, 100 + i, 2, 8, 0, 6
+        st.ship_laser.color.r, st.ship_laser.color.g, st.ship_laser.color.b, st.ship_laser.color.a = 255, 255, 0, 255
+        for r in range(18):
+            st.shield_rows[1][r] = int(rng.integers(0, 1 << 16))
+        st.shield_x[2], st.shield_y[2] = 150, 150 + i % 5   # overlaps shield 1's columns
+        st.ufo_x, st.ufo_appearance_counter = 100 + 3 * i, 0
+        if i % 3 == 0:
+            st.ship_alive, st.ship_death_counter, st.ship_death_hit_1 = 0, 20, i % 2
+        for e in (g, o):
+            e.set_state(i, st)
+    _assert_states_equal(g, o, range(n))
+    for ch in (1, 3, 4):
+        assert np.array_equal(g.render(ch), o.render(ch)), ch
+    for e in (g, o):
+        e.agent_init(skip=3, out_h=84, out_w=84, stack=2, clip_reward=False)
+    # the agent path reads the current states (no reset): step it and compare observations
+    for t in range(60):
+        a = synthetic_actions("space_invaders", n, t, seed=6)
+        x, y = g.agent_step(a), o.agent_step(a)
+        for p, q in zip(x, y):
+            assert np.array_equal(p, q), t
+    for t in range(200):
+        a = synthetic_actions("space_invaders", n, t, seed=7)
+        rg, ro = g.step(a, auto_reset=True), o.step(a, auto_reset=True)
+        for p, q in zip(rg, ro):
+            assert np.array_equal(p, q), t
+    _assert_states_equal(g, o, range(n))
+    assert np.array_equal(g.render(3), o.render(3))
