@@ -331,3 +331,50 @@ def test_space_invaders_interventions_parity(hip_lib, oracle_lib):
             assert np.array_equal(p, q), t
     _assert_states_equal(g, o, range(n))
     assert np.array_equal(g.render(3), o.render(3))
+
+
+def test_amidar_interventions_parity(hip_lib, oracle_lib):
+    """Hand-written Amidar states: movers on top of each other and of the player, at the board's edges and between tiles,
+    painted boxes (interior fill), repainted track, chase and jump modes, a caught enemy -- frames in every format, the
+    fused observation (movers differ between the two sub-frames, the board usually does not), and the dynamics from there."""
+    n = 24
+    g, o = _pair("amidar", n, hip_lib, oracle_lib, seed=8)
+    for t in range(60):
+        a = synthetic_actions("amidar", n, t, seed=4)
+        g.step(a), o.step(a)
+    rng = np.random.default_rng(6)
+    for i in range(n):
+        st = o.get_state(i)
+        for b in range(0, st.n_boxes, 3):
+            st.boxes[b].painted = 1
+        for ty in range(31):
+            for tx in range(32):
+                if st.tiles[ty][tx] == 1 and rng.random() < 0.3:      # Unpainted -> Painted
+                    st.tiles[ty][tx] = 2
+        st.enemies[1].x, st.enemies[1].y = st.enemies[0].x + 16 * (i % 4), st.enemies[0].y     # overlapping movers, off-tile x
+        st.enemies[2].x, st.enemies[2].y = st.player.x, st.player.y                              # under the player
+        st.enemies[3].x, st.enemies[3].y = 31 * 64, 30 * 80                                      # bottom-right corner
+        st.enemies[4].caught = 1
+        st.chase_timer = 40 if i % 2 else 0
+        st.jump_timer = 25 if i % 3 == 0 else 0
+        st.score = 98765 - i
+        st.lives = 1 + i % 3
+        for e in (g, o):
+            e.set_state(i, st)
+    _assert_states_equal(g, o, range(n))
+    for ch in (1, 3, 4):
+        assert np.array_equal(g.render(ch), o.render(ch)), ch
+    for e in (g, o):
+        e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=False)
+    for t in range(60):
+        a = synthetic_actions("amidar", n, t, seed=6)
+        x, y = g.agent_step(a), o.agent_step(a)
+        for p, q in zip(x, y):
+            assert np.array_equal(p, q), t
+    for t in range(200):
+        a = synthetic_actions("amidar", n, t, seed=7)
+        rg, ro = g.step(a, auto_reset=True), o.step(a, auto_reset=True)
+        for p, q in zip(rg, ro):
+            assert np.array_equal(p, q), t
+    _assert_states_equal(g, o, range(n))
+    assert np.array_equal(g.render(3), o.render(3))
