@@ -564,7 +564,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_new_game_kernel(AmiDev d, const
     }
 }
 
-__global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, ActionSource src, uint32_t flags, int first_env, int count)
+__global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, AmiDev shadow, ActionSource src, uint32_t flags, int first_env, int count)
 {
     const int lane = threadIdx.x & 63;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
@@ -607,6 +607,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, ActionSou
         prev = s.f[A_SCORE];
     }
     ami_store(d, env, lane, s);
+    if (shadow.sc) ami_store(shadow, env, lane, s);     // frame A of the agent observation (ActionSource::snapshot)
     if (lane == 0) {
         d.prev_score[env] = prev;
         d.reward[env] = rew;
@@ -1095,7 +1096,7 @@ struct AmiOps : GameOps {
     void destroy(tbx_engine*) override
     {
         hipFree(d.rng); hipFree(d.sc); hipFree(d.tiles); hipFree(d.boxes); hipFree(d.movers); hipFree(tab_dev);
-        hipFree(dA.sc); hipFree(dA.tiles); hipFree(dA.boxes); hipFree(dA.movers);
+        hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.tiles); hipFree(dA.boxes); hipFree(dA.movers);
     }
 
     int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
@@ -1121,7 +1122,13 @@ struct AmiOps : GameOps {
     {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
-        hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, src, flags, first, count);
+        AmiDev shadow{};
+        if (src.snapshot) {
+            int rc = ensure_shadow(e);
+            if (rc) return rc;
+            shadow = dA;
+        }
+        hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, shadow, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
@@ -1130,19 +1137,28 @@ struct AmiOps : GameOps {
     AmiDev dA{};
     bool agent_fused() const override { return true; }
 
+    bool snapshot_in_step() const override { return true; }
+
+    int ensure_shadow(tbx_engine* e)
+    {
+        if (dA.sc) { dA.tab = d.tab; return TBX_OK; }
+        const size_t N = (size_t)e->n;
+        dA = d;
+        dA.sc = nullptr; dA.tiles = nullptr; dA.boxes = nullptr; dA.movers = nullptr; dA.rng = nullptr;
+        TBX_HIP(hipMalloc((void**)&dA.rng, 2 * N * sizeof(uint64_t)));
+        TBX_HIP(hipMalloc((void**)&dA.sc, (size_t)ANF * N * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&dA.tiles, N * 32 * sizeof(uint64_t)));
+        TBX_HIP(hipMalloc((void**)&dA.boxes, N * 128 * sizeof(uint32_t)));
+        TBX_HIP(hipMalloc((void**)&dA.movers, N * NMF * 16 * sizeof(int32_t)));
+        return TBX_OK;
+    }
+
     int agent_snapshot(tbx_engine* e, int which, hipStream_t s) override
     {
         if (which != 0) return TBX_OK;                       // frame B is read from the live state
         const size_t N = (size_t)e->n;
-        if (!dA.sc) {
-            dA = d;
-            dA.sc = nullptr; dA.tiles = nullptr; dA.boxes = nullptr; dA.movers = nullptr;
-            TBX_HIP(hipMalloc((void**)&dA.sc, (size_t)ANF * N * sizeof(int32_t)));
-            TBX_HIP(hipMalloc((void**)&dA.tiles, N * 32 * sizeof(uint64_t)));
-            TBX_HIP(hipMalloc((void**)&dA.boxes, N * 128 * sizeof(uint32_t)));
-            TBX_HIP(hipMalloc((void**)&dA.movers, N * NMF * 16 * sizeof(int32_t)));
-        }
-        dA.tab = d.tab;
+        int rc = ensure_shadow(e);
+        if (rc) return rc;
         TBX_HIP(hipMemcpyAsync(dA.sc, d.sc, (size_t)ANF * N * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         TBX_HIP(hipMemcpyAsync(dA.tiles, d.tiles, N * 32 * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
         TBX_HIP(hipMemcpyAsync(dA.boxes, d.boxes, N * 128 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));

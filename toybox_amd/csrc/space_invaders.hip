@@ -500,7 +500,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_new_game_kernel(SiDev d, SiCfg c
     }
 }
 
-__global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
+__global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiDev shadow, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
 {
     const int lane = threadIdx.x & 63;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
@@ -543,6 +543,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiCfg c, Ac
         prev = s.f[F_SCORE];
     }
     si_store(d, env, lane, s);
+    if (shadow.sc) si_store(shadow, env, lane, s);      // frame A of the agent observation (ActionSource::snapshot)
     if (lane == 0) {
         d.prev_score[env] = prev;
         d.reward[env] = rew;
@@ -1173,7 +1174,7 @@ struct SiOps : GameOps {
     void destroy(tbx_engine*) override
     {
         hipFree(d.rng); hipFree(d.sc); hipFree(d.enemies); hipFree(d.shields); hipFree(d.lasers);
-        hipFree(dA.sc); hipFree(dA.enemies); hipFree(dA.shields); hipFree(dA.lasers);
+        hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.enemies); hipFree(dA.shields); hipFree(dA.lasers);
     }
 
     int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
@@ -1197,7 +1198,13 @@ struct SiOps : GameOps {
     {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
-        hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count);
+        SiDev shadow{};
+        if (src.snapshot) {
+            int rc = ensure_shadow(e);
+            if (rc) return rc;
+            shadow = dA;
+        }
+        hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, shadow, c, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
@@ -1206,18 +1213,28 @@ struct SiOps : GameOps {
     SiDev dA{};
     bool agent_fused() const override { return true; }
 
+    bool snapshot_in_step() const override { return true; }
+
+    int ensure_shadow(tbx_engine* e)
+    {
+        if (dA.sc) return TBX_OK;
+        const size_t N = (size_t)e->n;
+        dA = d;
+        dA.sc = nullptr; dA.enemies = nullptr; dA.shields = nullptr; dA.lasers = nullptr; dA.rng = nullptr;
+        TBX_HIP(hipMalloc((void**)&dA.rng, 2 * N * sizeof(uint64_t)));
+        TBX_HIP(hipMalloc((void**)&dA.sc, (size_t)NF * N * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&dA.enemies, N * NEF * 64 * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&dA.shields, N * 64 * sizeof(uint32_t)));
+        TBX_HIP(hipMalloc((void**)&dA.lasers, N * NLF * 16 * sizeof(int32_t)));
+        return TBX_OK;
+    }
+
     int agent_snapshot(tbx_engine* e, int which, hipStream_t s) override
     {
         if (which != 0) return TBX_OK;                       // frame B is read from the live state
         const size_t N = (size_t)e->n;
-        if (!dA.sc) {
-            dA = d;
-            dA.sc = nullptr; dA.enemies = nullptr; dA.shields = nullptr; dA.lasers = nullptr;
-            TBX_HIP(hipMalloc((void**)&dA.sc, (size_t)NF * N * sizeof(int32_t)));
-            TBX_HIP(hipMalloc((void**)&dA.enemies, N * NEF * 64 * sizeof(int32_t)));
-            TBX_HIP(hipMalloc((void**)&dA.shields, N * 64 * sizeof(uint32_t)));
-            TBX_HIP(hipMalloc((void**)&dA.lasers, N * NLF * 16 * sizeof(int32_t)));
-        }
+        int rc = ensure_shadow(e);
+        if (rc) return rc;
         TBX_HIP(hipMemcpyAsync(dA.sc, d.sc, (size_t)NF * N * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         TBX_HIP(hipMemcpyAsync(dA.enemies, d.enemies, N * NEF * 64 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         TBX_HIP(hipMemcpyAsync(dA.shields, d.shields, N * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));

@@ -119,6 +119,9 @@ struct ActionSource {
     int32_t* acc_reward;
     uint8_t* acc_done;
     int acc_first;
+    // agent layer: this frame's end state is frame A of the observation -- games that can, also store it to their shadow
+    // state arrays (GameOps::snapshot_in_step) instead of being copied afterwards
+    int snapshot;
 };
 
 __device__ __forceinline__ void tbx_accumulate(const ActionSource& src, int env, int32_t rew, bool is_done)
@@ -218,6 +221,7 @@ struct GameOps {
     // state as frame A (which = 0) or frame B (1), then produce the warped, max'd, stacked observation from the two
     virtual bool agent_fused() const { return false; }
     virtual int agent_snapshot(tbx_engine*, int /*which*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    virtual bool snapshot_in_step() const { return false; }   // frame A is written by step() when ActionSource::snapshot is set
     virtual int agent_warp(tbx_engine*, const struct AgentWarpArgs&, hipStream_t) { return TBX_E_UNSUPPORTED; }
     // reset-time wrappers (episodic life / fire reset / no-op reset) for the envs flagged in AgentResetArgs::kind
     virtual int agent_reset_envs(tbx_engine*, const struct AgentResetArgs&, hipStream_t) { return TBX_E_UNSUPPORTED; }
