@@ -263,15 +263,24 @@ int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s)
     const bool in_kernel_reset = needs_reset_kernel(a);
     // the step kernels sum reward / latch done themselves (tbx_accumulate), so the skip loop is one launch per frame
     src.acc_reward = a.racc; src.acc_done = a.fin;
-    const bool snap_in_step = fused && e->ops->snapshot_in_step();
-    for (int i = 0; i < a.cfg.skip; i++) {
-        src.acc_first = i == 0;
-        src.snapshot = snap_in_step && i == a.cfg.skip - 2;
+    if (e->ops->multi_frame_step() && fused) {
+        // the whole skip loop in one launch: state stays in registers, frame A's snapshot is stored on the way
+        src.acc_first = 1;
+        src.frames = a.cfg.skip;
+        src.snapshot_after = a.cfg.skip >= 2 ? a.cfg.skip - 1 : 0;
         int rc = e->ops->step(e, src, 0, s);
         if (rc) return rc;
-        if (i == a.cfg.skip - 2 && !snap_in_step) {
-            rc = fused ? e->ops->agent_snapshot(e, 0, s) : e->ops->render(e, a.gray_a, 1, 0, n, s);
+    } else {
+        src.frames = 1;
+        src.snapshot_after = 0;
+        for (int i = 0; i < a.cfg.skip; i++) {
+            src.acc_first = i == 0;
+            int rc = e->ops->step(e, src, 0, s);
             if (rc) return rc;
+            if (i == a.cfg.skip - 2) {
+                rc = fused ? e->ops->agent_snapshot(e, 0, s) : e->ops->render(e, a.gray_a, 1, 0, n, s);
+                if (rc) return rc;
+            }
         }
     }
     hipLaunchKernelGGL(agent_monitor_kernel, dim3(gb), dim3(tb), 0, s, a.racc, a.fin, e->lives_out, a.ep_ret, a.ep_len, a.ep_index,

@@ -527,23 +527,29 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiDev shado
 
     SiRegs s;
     si_load(d, env, lane, s);
-    si_step(c, lane, buttons, s);
-
-    int32_t rew = s.f[F_SCORE] - d.prev_score[env];
-    if (rew < 0) rew = 0;
-    const int32_t out_lives = s.f[F_LIVES], out_score = s.f[F_SCORE];
-    const bool is_done = out_lives <= 0;
-    int32_t prev = out_score;
-    if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
-        Rng sim;
-        sim.s0 = d.sim_rng[env];
-        sim.s1 = d.sim_rng[N + env];
-        si_new_game(c, lane, sim, s);
-        if (lane == 0) { d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1; }
-        prev = s.f[F_SCORE];
+    int32_t prev = d.prev_score[env];
+    const int frames = src.frames > 1 ? src.frames : 1;
+    int32_t rew = 0, out_lives = 0, out_score = 0;
+    bool is_done = false;
+    for (int fr = 0; fr < frames; fr++) {                  // > 1: the agent layer's action repeat, state stays in registers
+        si_step(c, lane, buttons, s);
+        rew = s.f[F_SCORE] - prev;
+        if (rew < 0) rew = 0;
+        out_lives = s.f[F_LIVES]; out_score = s.f[F_SCORE];
+        is_done = out_lives <= 0;
+        prev = out_score;
+        if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+            Rng sim;
+            sim.s0 = d.sim_rng[env];
+            sim.s1 = d.sim_rng[N + env];
+            si_new_game(c, lane, sim, s);
+            if (lane == 0) { d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1; }
+            prev = s.f[F_SCORE];
+        }
+        if (lane == 0) tbx_accumulate(src, env, rew, is_done, fr);
+        if (fr + 1 == src.snapshot_after && shadow.sc) si_store(shadow, env, lane, s);   // frame A of the agent observation
     }
     si_store(d, env, lane, s);
-    if (shadow.sc) si_store(shadow, env, lane, s);      // frame A of the agent observation (ActionSource::snapshot)
     if (lane == 0) {
         d.prev_score[env] = prev;
         d.reward[env] = rew;
@@ -552,7 +558,6 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiDev shado
         d.score_out[env] = out_score;
         uint32_t lv = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
         d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv << 40);
-        tbx_accumulate(src, env, rew, is_done);
     }
 }
 
@@ -1199,7 +1204,7 @@ struct SiOps : GameOps {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         SiDev shadow{};
-        if (src.snapshot) {
+        if (src.snapshot_after > 0) {
             int rc = ensure_shadow(e);
             if (rc) return rc;
             shadow = dA;
@@ -1213,7 +1218,7 @@ struct SiOps : GameOps {
     SiDev dA{};
     bool agent_fused() const override { return true; }
 
-    bool snapshot_in_step() const override { return true; }
+    bool multi_frame_step() const override { return true; }
 
     int ensure_shadow(tbx_engine* e)
     {

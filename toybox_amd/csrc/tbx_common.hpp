@@ -119,17 +119,21 @@ struct ActionSource {
     int32_t* acc_reward;
     uint8_t* acc_done;
     int acc_first;
-    // agent layer: this frame's end state is frame A of the observation -- games that can, also store it to their shadow
-    // state arrays (GameOps::snapshot_in_step) instead of being copied afterwards
-    int snapshot;
+    // agent layer (games with GameOps::multi_frame_step): run `frames` frames of the same action in ONE launch with the
+    // state held in registers (0 means 1), and store the state after `snapshot_after` frames (0 = never) to the game's
+    // shadow arrays as well: it is frame A of the observation
+    int frames;
+    int snapshot_after;
 };
 
-__device__ __forceinline__ void tbx_accumulate(const ActionSource& src, int env, int32_t rew, bool is_done)
+// frame: index of this frame inside a multi-frame launch
+__device__ __forceinline__ void tbx_accumulate(const ActionSource& src, int env, int32_t rew, bool is_done, int frame = 0)
 {
     if (!src.acc_reward) return;
-    const bool was_done = src.acc_first ? false : src.acc_done[env] != 0;
+    const bool first = src.acc_first && frame == 0;
+    const bool was_done = first ? false : src.acc_done[env] != 0;
     if (was_done) return;
-    src.acc_reward[env] = (src.acc_first ? 0 : src.acc_reward[env]) + rew;
+    src.acc_reward[env] = (first ? 0 : src.acc_reward[env]) + rew;
     src.acc_done[env] = is_done ? 1 : 0;
 }
 
@@ -221,7 +225,7 @@ struct GameOps {
     // state as frame A (which = 0) or frame B (1), then produce the warped, max'd, stacked observation from the two
     virtual bool agent_fused() const { return false; }
     virtual int agent_snapshot(tbx_engine*, int /*which*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
-    virtual bool snapshot_in_step() const { return false; }   // frame A is written by step() when ActionSource::snapshot is set
+    virtual bool multi_frame_step() const { return false; }   // step() honours ActionSource::frames / snapshot_after
     virtual int agent_warp(tbx_engine*, const struct AgentWarpArgs&, hipStream_t) { return TBX_E_UNSUPPORTED; }
     // reset-time wrappers (episodic life / fire reset / no-op reset) for the envs flagged in AgentResetArgs::kind
     virtual int agent_reset_envs(tbx_engine*, const struct AgentResetArgs&, hipStream_t) { return TBX_E_UNSUPPORTED; }
