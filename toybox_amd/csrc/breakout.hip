@@ -746,7 +746,8 @@ __device__ __forceinline__ void brk_t_step(const BrkCfg& c, BrkT& s, uint32_t bu
 
 }
 
-__global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, ActionSource src, uint32_t flags, BrkRenderRec* recs)
+__global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, ActionSource src, uint32_t flags, BrkRenderRec* recs,
+                                                           BrkRenderRec* recs_a)
 {
     const BrkCfg& c = *cp;   // tables are indexed per thread: read them from memory, not from the kernel arguments
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
@@ -764,19 +765,26 @@ __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCf
 
     BrkT s;
     t_load(d, env, s);
-    brk_t_step(c, s, buttons);
-
-    int32_t rew = s.score - d.prev_score[env];
-    if (rew < 0) rew = 0;
-    const int32_t out_lives = s.lives, out_score = s.score;
-    const bool is_done = s.lives <= 0;
-    int32_t prev = s.score;
-    if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
-        Rng sim;
-        sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
-        t_new_game(c, sim, s);
-        d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
+    int32_t prev = d.prev_score[env];
+    const int frames = src.frames > 1 ? src.frames : 1;
+    int32_t rew = 0, out_lives = 0, out_score = 0;
+    bool is_done = false;
+    for (int fr = 0; fr < frames; fr++) {                  // > 1: the agent layer's action repeat, state stays in registers
+        brk_t_step(c, s, buttons);
+        rew = s.score - prev;
+        if (rew < 0) rew = 0;
+        out_lives = s.lives; out_score = s.score;
+        is_done = s.lives <= 0;
         prev = s.score;
+        if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+            Rng sim;
+            sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
+            t_new_game(c, sim, s);
+            d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
+            prev = s.score;
+        }
+        tbx_accumulate(src, env, rew, is_done, fr);
+        if (fr + 1 == src.snapshot_after && recs_a) recs_a[env] = t_record(s);     // frame A of the agent observation
     }
     t_store(d, env, s);
     d.prev_score[env] = prev;
@@ -786,7 +794,6 @@ __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCf
     d.score_out[env] = out_score;
     const uint32_t lv8 = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
     d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv8 << 40);
-    tbx_accumulate(src, env, rew, is_done);
     recs[env] = t_record(s);
 }
 
@@ -1456,7 +1463,12 @@ struct BreakoutOps : GameOps {
     int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
     {
         if (!custom && src.single_env < 0 && use_tpe) {
-            hipLaunchKernelGGL(brk_step_tpe_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs);
+            BrkRenderRec* ra = nullptr;
+            if (src.snapshot_after > 0) {
+                if (!recsA) TBX_HIP(hipMalloc((void**)&recsA, sizeof(BrkRenderRec) * (size_t)e->n));
+                ra = recsA;
+            }
+            hipLaunchKernelGGL(brk_step_tpe_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs, ra);
             TBX_HIP(hipGetLastError());
             recs_valid = true;
             return TBX_OK;
@@ -1499,6 +1511,7 @@ struct BreakoutOps : GameOps {
     BrkRenderRec* recsA = nullptr;
 
     bool agent_fused() const override { return !custom; }
+    bool multi_frame_step() const override { return !custom && use_tpe; }
 
     int agent_snapshot(tbx_engine* e, int which, hipStream_t s) override
     {
