@@ -23,6 +23,9 @@ struct AgentState {
     uint8_t *kind = nullptr, *ep_done = nullptr;
     int32_t *ep_ret = nullptr, *ep_len = nullptr, *ep_index = nullptr, *prev_lives = nullptr, *ep_len_out = nullptr;
     float* ep_ret_out = nullptr;
+    int32_t* reset_list = nullptr;   // [N] envs the monitor kernel flagged for a reset
+    int32_t* reset_count = nullptr;  // [2] their number, double-buffered by step parity
+    int parity = 0;
     bool force_generic = false;   // TBX_AGENT_GENERIC=1: always go through full-resolution gray frames
 };
 
@@ -35,9 +38,11 @@ constexpr int MAX_TAPS = 8;
 // are cleared here.
 __global__ void agent_monitor_kernel(const int32_t* racc, const uint8_t* fin, const int32_t* lives, int32_t* ep_ret, int32_t* ep_len,
                                      int32_t* ep_index, int32_t* prev_lives, uint8_t* kind, uint8_t* ep_done, float* ep_ret_out,
-                                     int32_t* ep_len_out, float* reward_out, uint8_t* done_out, int episodic, int clip, int simple, int n)
+                                     int32_t* ep_len_out, float* reward_out, uint8_t* done_out, int32_t* list, int32_t* count,
+                                     int32_t* next_count, int episodic, int clip, int simple, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *next_count = 0;                         // the other step parity's counter: its readers ran a step ago
     if (i >= n) return;
     const int r = racc[i];
     int er = ep_ret[i] + r, el = ep_len[i] + 1;
@@ -45,6 +50,7 @@ __global__ void agent_monitor_kernel(const int32_t* racc, const uint8_t* fin, co
     const int l = lives[i];
     const bool life_lost = episodic && !real && l < prev_lives[i] && l > 0;
     kind[i] = real ? 2 : life_lost ? 1 : 0;
+    if (real || life_lost) list[atomicAdd(count, 1)] = i;  // order is irrelevant: the reset of one env touches nothing else
     done_out[i] = (real || life_lost) ? 1 : 0;
     reward_out[i] = clip ? (float)((r > 0) - (r < 0)) : (float)r;
     ep_done[i] = real ? 1 : 0;
@@ -230,6 +236,7 @@ AgentResetArgs reset_args(tbx_engine* e)
     AgentState& a = *e->agent;
     AgentResetArgs r;
     r.kind = a.kind;
+    r.list = nullptr; r.count = nullptr;
     r.skip = a.cfg.skip; r.episodic_life = a.cfg.episodic_life; r.fire_reset = a.cfg.fire_reset; r.noop_max = a.cfg.noop_max;
     r.noop_seed = a.cfg.noop_seed; r.env_offset = a.cfg.env_offset;
     // action #1 and #2 of the game's (sorted) legal action set: FIRE and the next one (atari_wrappers.py:146-149)
@@ -285,10 +292,14 @@ int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s)
     }
     hipLaunchKernelGGL(agent_monitor_kernel, dim3(gb), dim3(tb), 0, s, a.racc, a.fin, e->lives_out, a.ep_ret, a.ep_len, a.ep_index,
                        a.prev_lives, a.kind, a.ep_done, a.ep_ret_out, a.ep_len_out, a.reward_out, a.done_out,
+                       a.reset_list, a.reset_count + a.parity, a.reset_count + (a.parity ^ 1),
                        a.cfg.episodic_life, a.cfg.clip_reward, in_kernel_reset ? 0 : 1, n);
     AHIP(hipGetLastError());
     // VecEnv auto-reset: plain new game of the finished envs, or the reset-time wrappers run in-kernel
-    int rc = in_kernel_reset ? e->ops->agent_reset_envs(e, reset_args(e), s) : e->ops->new_game(e, a.fin, s);
+    AgentResetArgs ra = reset_args(e);
+    ra.list = a.reset_list; ra.count = a.reset_count + a.parity;
+    a.parity ^= 1;
+    int rc = in_kernel_reset ? e->ops->agent_reset_envs(e, ra, s) : e->ops->new_game(e, a.fin, s);
     if (rc) return rc;
     return observe(e, 0, s);
 }
@@ -302,7 +313,7 @@ void tbx_agent_free(tbx_engine* e)
     hipFree(a->gray_a); hipFree(a->gray_b); hipFree(a->obs); hipFree(a->fin); hipFree(a->done_out);
     hipFree(a->racc); hipFree(a->reward_out); hipFree(a->ty); hipFree(a->tx);
     hipFree(a->kind); hipFree(a->ep_done); hipFree(a->ep_ret); hipFree(a->ep_len); hipFree(a->ep_index);
-    hipFree(a->prev_lives); hipFree(a->ep_len_out); hipFree(a->ep_ret_out);
+    hipFree(a->prev_lives); hipFree(a->ep_len_out); hipFree(a->ep_ret_out); hipFree(a->reset_list); hipFree(a->reset_count);
     delete a;
     e->agent = nullptr;
 }
@@ -363,6 +374,9 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     AHIP(hipMalloc((void**)&a->prev_lives, N * sizeof(int32_t)));
     AHIP(hipMalloc((void**)&a->ep_len_out, N * sizeof(int32_t)));
     AHIP(hipMalloc((void**)&a->ep_ret_out, N * sizeof(float)));
+    AHIP(hipMalloc((void**)&a->reset_list, N * sizeof(int32_t)));
+    AHIP(hipMalloc((void**)&a->reset_count, 2 * sizeof(int32_t)));
+    AHIP(hipMemset(a->reset_count, 0, 2 * sizeof(int32_t)));
     const std::vector<AgentTaps> ty = make_taps(H, cfg->out_h), tx = make_taps(W, cfg->out_w);
     AHIP(hipMalloc((void**)&a->ty, ty.size() * sizeof(AgentTaps)));
     AHIP(hipMalloc((void**)&a->tx, tx.size() * sizeof(AgentTaps)));

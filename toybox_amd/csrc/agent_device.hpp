@@ -102,6 +102,10 @@ __device__ __forceinline__ void stack_commit(const uint8_t* vals, uint8_t* o, in
 // what a game's agent-reset kernel needs (see tbx_agent_config_t)
 struct AgentResetArgs {
     const uint8_t* kind;        // [N] 0 = nothing to do, 1 = a life was lost (episodic life), 2 = game over
+    // the flagged envs as a compact list (built by the monitor kernel) so that heavy wave-per-env reset kernels launch a
+    // small persistent grid instead of N waves that exit at once; nullptr: every env is flagged (tbx_agent_reset)
+    const int32_t* list;
+    const int32_t* count;
     int skip, episodic_life, fire_reset, noop_max;
     uint64_t noop_seed, env_offset;
     uint32_t fire_buttons, third_buttons;   // buttons of action #1 and action #2 of the game's action set

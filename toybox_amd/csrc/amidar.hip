@@ -23,6 +23,7 @@
 #include "../../include/toybox_amd_spec.h"
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -640,10 +641,13 @@ struct AmiAgentEnv {
 __global__ __launch_bounds__(TBX_BLOCK) void ami_agent_reset_kernel(AmiDev d, AgentResetArgs r)
 {
     const int lane = threadIdx.x & 63;
-    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-    if (env >= d.n) return;
+    // a persistent grid walks the compact list of flagged envs (or every env when there is no list)
+    const int wave_id = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6)), n_waves = gridDim.x * TBX_WAVES_PER_BLOCK;
+    const int total = r.list ? wave_uniform(*r.count) : d.n;
+    for (int it = wave_id; it < total; it += n_waves) {
+    const int env = r.list ? wave_uniform(r.list[it]) : it;
     const int kind = wave_uniform((int)r.kind[env]);
-    if (kind == 0) return;
+    if (kind == 0) continue;
     const size_t N = (size_t)d.n;
     AmiRegs s;
     ami_load(d, env, lane, s);
@@ -659,6 +663,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_agent_reset_kernel(AmiDev d, Ag
         d.prev_score[env] = s.f[A_SCORE];
         r.ep_ret[env] = m.ep_ret; r.ep_len[env] = m.ep_len; r.ep_index[env] = m.ep_index; r.prev_lives[env] = m.prev_lives;
         if (m.emitted) { r.ep_done[env] = 1; r.ep_ret_out[env] = (float)m.out_ret; r.ep_len_out[env] = m.out_len; }
+    }
     }
 }
 
@@ -1189,7 +1194,8 @@ struct AmiOps : GameOps {
 
     int agent_reset_envs(tbx_engine* e, const AgentResetArgs& r, hipStream_t s) override
     {
-        hipLaunchKernelGGL(ami_agent_reset_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, r);
+        const dim3 grid = r.list ? dim3(std::min<unsigned>(grid_for(e->n).x, 512u)) : grid_for(e->n);
+        hipLaunchKernelGGL(ami_agent_reset_kernel, grid, dim3(TBX_BLOCK), 0, s, d, r);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

@@ -23,6 +23,7 @@
 
 #include <climits>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -576,10 +577,13 @@ struct SiAgentEnv {
 __global__ __launch_bounds__(TBX_BLOCK) void si_agent_reset_kernel(SiDev d, SiCfg c, AgentResetArgs r)
 {
     const int lane = threadIdx.x & 63;
-    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-    if (env >= d.n) return;
+    // a persistent grid walks the compact list of flagged envs (or every env when there is no list)
+    const int wave_id = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6)), n_waves = gridDim.x * TBX_WAVES_PER_BLOCK;
+    const int total = r.list ? wave_uniform(*r.count) : d.n;
+    for (int it = wave_id; it < total; it += n_waves) {
+    const int env = r.list ? wave_uniform(r.list[it]) : it;
     const int kind = wave_uniform((int)r.kind[env]);
-    if (kind == 0) return;
+    if (kind == 0) continue;
     const size_t N = (size_t)d.n;
     SiRegs s;
     si_load(d, env, lane, s);
@@ -595,6 +599,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_agent_reset_kernel(SiDev d, SiCf
         d.prev_score[env] = s.f[F_SCORE];
         r.ep_ret[env] = m.ep_ret; r.ep_len[env] = m.ep_len; r.ep_index[env] = m.ep_index; r.prev_lives[env] = m.prev_lives;
         if (m.emitted) { r.ep_done[env] = 1; r.ep_ret_out[env] = (float)m.out_ret; r.ep_len_out[env] = m.out_len; }
+    }
     }
 }
 
@@ -1265,7 +1270,8 @@ struct SiOps : GameOps {
 
     int agent_reset_envs(tbx_engine* e, const AgentResetArgs& r, hipStream_t s) override
     {
-        hipLaunchKernelGGL(si_agent_reset_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, c, r);
+        const dim3 grid = r.list ? dim3(std::min<unsigned>(grid_for(e->n).x, 512u)) : grid_for(e->n);
+        hipLaunchKernelGGL(si_agent_reset_kernel, grid, dim3(TBX_BLOCK), 0, s, d, c, r);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
