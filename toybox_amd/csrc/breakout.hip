@@ -1186,13 +1186,21 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
 
     BrkLineCache bcA{-1, 0}, bcB{-1, 0};
     uint64_t need[3] = {pal.boundary[0], pal.boundary[1], pal.boundary[2]};   // scanlines that must be composed
-    uint64_t ovA[3] = {0, 0, 0}, ovB[3] = {0, 0, 0};
+    uint64_t ovA[3] = {0, 0, 0}, ovB[3] = {0, 0, 0}, diff_a[3] = {0, 0, 0};
     {
         brk_overlay_rows(recB, ovB);
         if (!fresh) brk_overlay_rows(recA, ovA);
         uint64_t ov[3];
 #pragma unroll
-        for (int w = 0; w < 3; w++) { ov[w] = ovA[w] | ovB[w]; need[w] |= ov[w]; }
+        for (int w = 0; w < 3; w++) { ov[w] = ovA[w] | ovB[w]; need[w] |= ov[w]; diff_a[w] = fresh ? 0ull : ov[w]; }
+        // frame A can only show other pixels than frame B where a paddle / ball of either frame lies, in the brick band if a
+        // brick went, and in the HUD if a digit changed: everywhere else the composed line of B is the max already
+        if (!fresh) {
+            if (recA.alive[0] != recB.alive[0] || recA.alive[1] != recB.alive[1] || recA.alive[2] != recB.alive[2] ||
+                recA.alive[3] != recB.alive[3] || recA.n_bricks != recB.n_bricks)
+                brk_mark_rows(diff_a, 43, 43 + 4 * pal.rows);
+            if (recA.hud != recB.hud) brk_mark_rows(diff_a, 2, 12);
+        }
         // the line after a run of overlay lines differs from it as well
         need[2] |= (ov[2] << 1) | (ov[1] >> 63);
         need[1] |= (ov[1] << 1) | (ov[0] >> 63);
@@ -1208,13 +1216,14 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
     for (int wi = 0; wi < 3; wi++) {
         uint64_t nw = sel4(wi, need[0], need[1], need[2], 0ull);
         uint64_t oa = sel4(wi, ovA[0], ovA[1], ovA[2], 0ull), ob = sel4(wi, ovB[0], ovB[1], ovB[2], 0ull);
+        uint64_t da = sel4(wi, diff_a[0], diff_a[1], diff_a[2], 0ull);
         const int sy_end = min(H, 64 * wi + 64);
 #pragma unroll 1
-        for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, oa >>= 1, ob >>= 1) {
+        for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, oa >>= 1, ob >>= 1, da >>= 1) {
             if (nw & 1ull) {
                 const uint32_t dB = brk_gray_line(recB, pal, sy, x0, side_dw, hudB, bcB, ob & 1ull);
                 uint32_t v = dB;
-                if (!fresh) v = bytemax4(brk_gray_line(recA, pal, sy, x0, side_dw, hudA, bcA, oa & 1ull), dB);
+                if (da & 1ull) v = bytemax4(brk_gray_line(recA, pal, sy, x0, side_dw, hudA, bcA, oa & 1ull), dB);   // diff_a is 0 when fresh
                 if (active) reinterpret_cast<uint32_t*>(row)[lane] = v;
                 __builtin_amdgcn_wave_barrier();
                 h0 = on0 ? hsum(row, c0) : 0u;
