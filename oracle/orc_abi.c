@@ -292,6 +292,72 @@ int tbx_get_state(tbx_engine* e, int env, void* pod, size_t size)
     return TBX_OK;
 }
 
+/* tbx_set_state stores the CANONICAL form of a record, the one tbx_get_state returns on both libraries: slots beyond
+ * the counts zeroed, flags 0 / 1, "no counter" = -1, directions two bits wide, tile tags two bits, paddings zero.  States a
+ * game produces itself are canonical already; this only matters for hand-written records (interventions). */
+static void normalize_state(int game, void* pod)
+{
+    if (game == TBX_GAME_BREAKOUT) {
+        tbx_breakout_state_t* s = (tbx_breakout_state_t*)pod;
+        s->is_dead = s->is_dead ? 1 : 0; s->reset = s->reset ? 1 : 0;
+        s->_pad0[0] = s->_pad0[1] = 0;
+        for (int b = s->n_balls; b < TBX_BRK_MAX_BALLS; b++) s->ball_x[b] = s->ball_y[b] = s->ball_vx[b] = s->ball_vy[b] = 0.0;
+        for (int j = 0; j < TBX_BRK_MAX_BRICKS; j++) {
+            if (j >= s->n_bricks) { memset(&s->bricks[j], 0, sizeof s->bricks[j]); continue; }
+            s->bricks[j].alive = s->bricks[j].alive ? 1 : 0;
+            s->bricks[j].destructible = s->bricks[j].destructible ? 1 : 0;
+            s->bricks[j]._pad[0] = s->bricks[j]._pad[1] = 0;
+        }
+    } else if (game == TBX_GAME_SPACE_INVADERS) {
+        tbx_si_state_t* s = (tbx_si_state_t*)pod;
+        s->has_ship_laser = s->has_ship_laser ? 1 : 0;
+        if (s->ship_death_counter < 0) s->ship_death_counter = -1;
+        s->ship_alive = s->ship_alive ? 1 : 0; s->ship_death_hit_1 = s->ship_death_hit_1 ? 1 : 0;
+        s->_pad0[0] = s->_pad0[1] = 0;
+        if (s->ufo_death_counter < 0) s->ufo_death_counter = -1;
+        s->move_dir &= 3;
+        s->visual_orientation = s->visual_orientation ? 1 : 0;
+        s->_pad1[0] = s->_pad1[1] = s->_pad1[2] = 0;
+        for (int k = s->n_shields; k < TBX_SI_MAX_SHIELDS; k++) {
+            s->shield_x[k] = s->shield_y[k] = 0;
+            memset(&s->shield_color[k], 0, sizeof s->shield_color[k]);
+            memset(s->shield_rows[k], 0, sizeof s->shield_rows[k]);
+        }
+        for (int j = 0; j < TBX_SI_MAX_ENEMIES; j++) {
+            tbx_si_enemy_t* e = &s->enemies[j];
+            if (j >= s->n_enemies) { memset(e, 0, sizeof *e); continue; }
+            e->alive = e->alive ? 1 : 0;
+            if (e->death_counter < 0) e->death_counter = -1;
+            e->_pad[0] = e->_pad[1] = e->_pad[2] = 0;
+        }
+        for (int j = 0; j < TBX_SI_MAX_LASERS; j++) {
+            if (j >= s->n_enemy_lasers) memset(&s->enemy_lasers[j], 0, sizeof s->enemy_lasers[j]);
+            else s->enemy_lasers[j].movement &= 3;
+        }
+        if (!s->has_ship_laser) memset(&s->ship_laser, 0, sizeof s->ship_laser);
+        else s->ship_laser.movement &= 3;
+    } else if (game == TBX_GAME_AMIDAR) {
+        tbx_amidar_state_t* s = (tbx_amidar_state_t*)pod;
+        for (int j = s->n_enemies; j < TBX_AMI_MAX_ENEMIES; j++) memset(&s->enemies[j], 0, sizeof s->enemies[j]);
+        for (int j = 0; j < TBX_AMI_MAX_BOXES; j++) {
+            tbx_amidar_box_t* b = &s->boxes[j];
+            if (j >= s->n_boxes) { memset(b, 0, sizeof *b); continue; }
+            b->tl_tx &= 255; b->tl_ty &= 255; b->br_tx &= 255; b->br_ty &= 255;
+            b->painted = b->painted ? 1 : 0; b->triggers_chase = b->triggers_chase ? 1 : 0;
+            b->_pad[0] = b->_pad[1] = 0;
+        }
+        for (int y = 0; y < TBX_AMI_BOARD_H; y++)
+            for (int x = 0; x < TBX_AMI_BOARD_W; x++) s->tiles[y][x] &= 3;
+    } else if (game == TBX_GAME_GRIDWORLD) {
+        tbx_gridworld_state_t* s = (tbx_gridworld_state_t*)pod;
+        s->game_over = s->game_over ? 1 : 0;
+        for (int t = 0; t < TBX_GW_MAX_TILES; t++) {
+            s->tiles[t].goal = s->tiles[t].goal ? 1 : 0; s->tiles[t].walkable = s->tiles[t].walkable ? 1 : 0;
+            s->tiles[t]._pad[0] = s->tiles[t]._pad[1] = 0;
+        }
+    }
+}
+
 int tbx_set_state(tbx_engine* e, int env, const void* pod, size_t size)
 {
     if (!e) return TBX_E_INVALID;
@@ -320,6 +386,7 @@ int tbx_set_state(tbx_engine* e, int env, const void* pod, size_t size)
         if (s->n_tiles < 1 || s->n_tiles > TBX_GW_MAX_TILES) return fail(e, TBX_E_UNSUPPORTED, "gridworld: 1..16 tiles");
     }
     memcpy(e->states + e->ssz * (size_t)env, pod, size);
+    normalize_state(e->game, e->states + e->ssz * (size_t)env);
     return TBX_OK;
 }
 

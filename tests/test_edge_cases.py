@@ -136,3 +136,57 @@ def test_seed_semantics(game, lib):
         e.step(a)
         single.step(a[1:2])
     assert bytes(single.get_state(0)) == bytes(e.get_state(1))
+
+
+@pytest.mark.parametrize("game", GAMES + ["gridworld"])
+def test_set_state_stores_the_canonical_record(game, lib, oracle_lib):
+    """Hand-written records with junk in unused slots, flags that are not 0 / 1 and wide direction fields come back from
+    tbx_get_state in ONE canonical form on both libraries, and writing that form back changes nothing."""
+    e, o = Engine(game, 2, lib=lib), Engine(game, 2, lib=oracle_lib)
+    st = o.get_state(0)
+    raw = bytearray(bytes(st))
+    if game == "breakout":
+        st.is_dead, st.reset = 7, 200
+        st.n_balls = 1
+        st.ball_x[3], st.ball_vy[2] = 1.5e9, -3.25
+        st.bricks[5].alive, st.bricks[6].destructible = 9, 77
+        st.bricks[200].x, st.bricks[200].alive = 123.0, 1          # beyond n_bricks
+    elif game == "space_invaders":
+        st.has_ship_laser, st.ship_alive, st.ship_death_hit_1, st.visual_orientation = 5, 3, 4, 9
+        st.ship_death_counter, st.ufo_death_counter = -7, -2
+        st.move_dir = 7
+        st.n_enemies = 30
+        st.enemies[40].x, st.enemies[40].alive = 999, 1               # beyond n_enemies
+        st.enemies[3].alive, st.enemies[3].death_counter = 8, -5
+        st.n_enemy_lasers = 1
+        st.enemy_lasers[0].movement = 6
+        st.enemy_lasers[5].x = 44
+        st.ship_laser.y = 55
+        st.has_ship_laser = 0
+        st.n_shields = 2
+        st.shield_rows[2][4] = 0xFFFF
+    elif game == "amidar":
+        st.n_enemies = 3
+        st.enemies[6].x, st.enemies[6].ai.kind = 5, 2
+        st.n_boxes = 20
+        st.boxes[40].tl_tx, st.boxes[40].painted = 9, 1
+        st.boxes[2].painted, st.boxes[2].triggers_chase = 6, 4
+        st.tiles[3][4] = 2 + 4 * 13                                     # only the low two bits are the tag
+    else:
+        st.game_over = 5
+        st.tiles[0].goal, st.tiles[1].walkable = 3, 200
+    assert bytes(st) != bytes(raw)
+    for x in (e, o):
+        x.set_state(1, st)
+    a, b = e.get_state(1), o.get_state(1)
+    assert bytes(a) == bytes(b)
+    assert bytes(a) != bytes(st)                                        # it was normalised
+    for x in (e, o):
+        x.set_state(0, a)
+    assert bytes(e.get_state(0)) == bytes(a) == bytes(o.get_state(0))   # the canonical form is a fixed point
+    for t in range(30):
+        act = synthetic_actions(game, 2, t)
+        for p, q in zip(e.step(act), o.step(act)):
+            assert np.array_equal(p, q)
+    for i in range(2):
+        assert bytes(e.get_state(i)) == bytes(o.get_state(i))

@@ -378,3 +378,78 @@ def test_amidar_interventions_parity(hip_lib, oracle_lib):
             assert np.array_equal(p, q), t
     _assert_states_equal(g, o, range(n))
     assert np.array_equal(g.render(3), o.render(3))
+
+
+def test_level_transitions_parity(hip_lib, oracle_lib):
+    """Level completion is out of reach of short random rollouts, so it is set up by hand in every game: the last brick / the
+    last invader / the last unpainted track, then the frames in which the level changes and the new wall / formation / board
+    appears -- identical on both sides, and the level counter really moves."""
+    n = 8
+    # Breakout: one brick left, a ball right under it flying up
+    g, o = _pair("breakout", n, hip_lib, oracle_lib, seed=3)
+    for e in (g, o):
+        e.step([1] * n)
+    for i in range(n):
+        st = o.get_state(i)
+        keep = 7 * i + 3
+        for j in range(st.n_bricks):
+            st.bricks[j].alive = 1 if j == keep else 0
+        b = st.bricks[keep]
+        st.n_balls = 1
+        st.ball_x[0], st.ball_y[0], st.ball_vx[0], st.ball_vy[0] = b.x + 6.0, b.y + b.h + 2.5, 0.25, -2.0
+        st.is_dead, st.reset = 0, 0
+        for e in (g, o):
+            e.set_state(i, st)
+    lv0 = o.scalars()[2].copy()
+    for t in range(40):
+        a = synthetic_actions("breakout", n, t, seed=9)
+        for x, y in zip(g.step(a), o.step(a)):
+            assert np.array_equal(x, y), t
+    _assert_states_equal(g, o, range(n))
+    assert (o.scalars()[2] == lv0 + 1).all() and np.array_equal(g.render(3), o.render(3))
+    assert all(sum(b.alive for b in list(o.get_state(i).bricks)[:108]) >= 95 for i in range(n))     # the wall is back (the ball keeps eating)
+
+    # SpaceInvaders: one invader left with the ship's laser right under it
+    g, o = _pair("space_invaders", n, hip_lib, oracle_lib, seed=3)
+    for t in range(140):
+        a = synthetic_actions("space_invaders", n, t, seed=4)
+        g.step(a), o.step(a)
+    for i in range(n):
+        st = o.get_state(i)
+        keep = (5 * i + 2) % 36
+        for j in range(36):
+            st.enemies[j].alive, st.enemies[j].death_counter = (1 if j == keep else 0), -1
+        en = st.enemies[keep]
+        st.has_ship_laser = 1
+        st.ship_laser.x, st.ship_laser.y, st.ship_laser.w, st.ship_laser.h = en.x + 7, en.y + 14, 2, 8
+        st.ship_laser.movement, st.ship_laser.speed, st.ship_laser.t = 0, 6, 0
+        st.n_enemy_lasers = 0
+        for e in (g, o):
+            e.set_state(i, st)
+    lv0 = o.scalars()[2].copy()
+    for t in range(60):
+        a = synthetic_actions("space_invaders", n, t, seed=9)
+        for x, y in zip(g.step(a), o.step(a)):
+            assert np.array_equal(x, y), t
+    _assert_states_equal(g, o, range(n))
+    assert (o.scalars()[2] == lv0 + 1).all() and np.array_equal(g.render(3), o.render(3))
+    assert all(sum(en.alive for en in list(o.get_state(i).enemies)[:36]) >= 30 for i in range(n))       # a fresh formation
+
+    # Amidar: every piece of track painted except the stretch of the right-hand column the player is about to close
+    g, o = _pair("amidar", n, hip_lib, oracle_lib, seed=3)
+    for i in range(n):
+        st = o.get_state(i)
+        for ty in range(31):
+            for tx in range(32):
+                if st.tiles[ty][tx] in (1, 3) and not (tx == 31 and ty <= 18):
+                    st.tiles[ty][tx] = 2
+        st.n_enemies = i % 3                              # with and without pursuers
+        for e in (g, o):
+            e.set_state(i, st)
+    lv0 = o.scalars()[2].copy()
+    for t in range(260):
+        a = np.full(n, 2, np.int32)                        # UP along the column, junction after junction
+        for x, y in zip(g.step(a), o.step(a)):
+            assert np.array_equal(x, y), t
+    _assert_states_equal(g, o, range(n))
+    assert (o.scalars()[2] > lv0).sum() >= n // 2 and np.array_equal(g.render(3), o.render(3))
