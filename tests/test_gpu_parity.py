@@ -453,3 +453,104 @@ def test_level_transitions_parity(hip_lib, oracle_lib):
             assert np.array_equal(x, y), t
     _assert_states_equal(g, o, range(n))
     assert (o.scalars()[2] > lv0).sum() >= n // 2 and np.array_equal(g.render(3), o.render(3))
+
+
+def _fuzz_breakout(st, rng):
+    st.score = int(rng.integers(0, 250000)); st.lives = int(rng.integers(1, 12)); st.level = int(rng.integers(0, 30))
+    st.paddle_x = float(rng.uniform(-40, 280)); st.paddle_width = float(rng.choice([0.0, 3.0, 24.0, 90.0, 400.0]))
+    st.paddle_speed = float(rng.choice([0.0, 4.0, 17.5]))
+    st.ball_radius = float(rng.choice([0.5, 2.0, 2.0, 5.5]))
+    st.n_balls = int(rng.integers(0, 5))
+    for b in range(st.n_balls):
+        st.ball_x[b], st.ball_y[b] = float(rng.uniform(-30, 270)), float(rng.uniform(-20, 190))
+        st.ball_vx[b], st.ball_vy[b] = float(rng.uniform(-9, 9)), float(rng.uniform(-9, 9))
+    st.is_dead, st.reset = int(st.n_balls == 0 or rng.random() < 0.2), int(rng.random() < 0.3)
+    for j in range(st.n_bricks):
+        st.bricks[j].alive = int(rng.random() < 0.6)
+
+
+def _fuzz_si(st, rng):
+    st.score = int(rng.integers(0, 250000)); st.lives = int(rng.integers(1, 12)); st.level = int(rng.integers(0, 30))
+    st.life_display_timer = int(rng.choice([0, 0, 0, 5])); st.enemy_shot_delay = int(rng.integers(0, 60))
+    st.ship_x = int(rng.integers(-20, 330)); st.ship_alive = int(rng.random() < 0.8)
+    st.ship_death_counter = -1 if st.ship_alive else int(rng.integers(0, 33))
+    st.ufo_x, st.ufo_appearance_counter = int(rng.integers(-40, 340)), int(rng.choice([0, 0, 7, 300]))
+    st.ufo_death_counter = int(rng.choice([-1, -1, 10]))
+    st.move_counter, st.move_dir = int(rng.integers(0, 33)), int(rng.integers(0, 2)) * 1
+    st.visual_orientation = int(rng.integers(0, 2))
+    for j in range(st.n_enemies):
+        en = st.enemies[j]
+        en.x += int(rng.integers(-30, 31)); en.y += int(rng.integers(-40, 90))
+        en.alive = int(rng.random() < 0.7)
+        en.death_counter = -1 if en.alive or rng.random() < 0.7 else int(rng.integers(0, 17))
+    st.n_enemy_lasers = int(rng.integers(0, 9))
+    for k in range(st.n_enemy_lasers):
+        l = st.enemy_lasers[k]
+        l.x, l.y, l.w, l.h = int(rng.integers(-5, 325)), int(rng.integers(-12, 215)), int(rng.integers(1, 5)), int(rng.integers(1, 12))
+        l.t, l.movement, l.speed = 0, 1, int(rng.integers(1, 6))
+        l.color.r, l.color.g, l.color.b, l.color.a = int(rng.integers(0, 256)), int(rng.integers(0, 256)), int(rng.integers(0, 256)), 255
+    st.has_ship_laser = int(rng.random() < 0.5)
+    if st.has_ship_laser:
+        l = st.ship_laser
+        l.x, l.y, l.w, l.h, l.t, l.movement, l.speed = int(rng.integers(0, 320)), int(rng.integers(-5, 200)), 2, 8, 0, 0, 6
+        l.color.r, l.color.g, l.color.b, l.color.a = 255, 200, 0, 255
+    for k in range(st.n_shields):
+        st.shield_x[k] += int(rng.integers(-60, 61)); st.shield_y[k] += int(rng.integers(-30, 31))
+        for r in range(18):
+            if rng.random() < 0.5:
+                st.shield_rows[k][r] = int(rng.integers(0, 1 << 16))
+
+
+def _fuzz_amidar(st, rng):
+    st.score = int(rng.integers(0, 250000)); st.lives = int(rng.integers(1, 12)); st.level = int(rng.integers(0, 30))
+    st.jumps, st.jump_timer, st.chase_timer = int(rng.integers(0, 12)), int(rng.choice([0, 0, 30])), int(rng.choice([0, 0, 50]))
+    track = [(tx, ty) for ty in range(31) for tx in range(32) if st.tiles[ty][tx] != 0]
+    for m in [st.player] + [st.enemies[k] for k in range(st.n_enemies)]:
+        tx, ty = track[int(rng.integers(0, len(track)))]
+        m.x, m.y = 64 * tx, 80 * ty                       # on a track tile, so the movement code has a defined start
+        m.step_tx, m.step_ty = tx, ty
+        m.caught = int(rng.random() < 0.15)
+    st.player.caught = 0
+    for ty in range(31):
+        for tx in range(32):
+            if st.tiles[ty][tx] == 1 and rng.random() < 0.4:
+                st.tiles[ty][tx] = 2
+    for b in range(st.n_boxes):
+        st.boxes[b].painted = int(rng.random() < 0.3)
+
+
+@pytest.mark.parametrize("fuzz_seed", [12345, 777])
+@pytest.mark.parametrize("game,fuzz", [("breakout", _fuzz_breakout), ("space_invaders", _fuzz_si), ("amidar", _fuzz_amidar)])
+def test_fuzzed_states_parity(game, fuzz, fuzz_seed, hip_lib, oracle_lib):
+    """Randomised hand-written states -- out-of-frame and overlapping objects, degenerate sizes, odd counters, scores
+    beyond the HUD's digits -- written to both libraries: every frame format, then 120 frames of dynamics (auto-reset on)
+    and the agent pipeline, all equal to the CPU restatement."""
+    n = 96
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=21)
+    for t in range(30):
+        a = synthetic_actions(game, n, t, seed=1)
+        g.step(a), o.step(a)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("TBX_FUZZ_SEED", fuzz_seed)))
+    for i in range(n):
+        st = o.get_state(i)
+        fuzz(st, rng)
+        for e in (g, o):
+            e.set_state(i, st)
+    _assert_states_equal(g, o, range(n))
+    for ch in (1, 3, 4):
+        fg, fo = g.render(ch), o.render(ch)
+        assert np.array_equal(fg, fo), (ch, np.argwhere(fg != fo)[:3])
+    for t in range(120):
+        a = synthetic_actions(game, n, t, seed=2)
+        for x, y, name in zip(g.step(a, auto_reset=True), o.step(a, auto_reset=True), ("reward", "done", "lives", "score")):
+            assert np.array_equal(x, y), (name, t, np.nonzero(x != y)[0][:5])
+        if t % 30 == 7:
+            assert np.array_equal(g.render(3), o.render(3)), t
+    _assert_states_equal(g, o, range(n))
+    for e in (g, o):
+        e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=False, episodic_life=True, fire_reset=True, noop_max=4)
+    for t in range(25):
+        a = synthetic_actions(game, n, t, seed=3)
+        for p, q in zip(g.agent_step(a), o.agent_step(a)):
+            assert np.array_equal(p, q), t
