@@ -149,6 +149,17 @@ __global__ void seed_kernel(uint64_t* sim_rng, int n, int env, uint32_t seed)
     sim_rng[(size_t)n + i] = s1;
 }
 
+// step outputs into one block for the host: [reward N | lives N | score N | err 1 | done N bytes]
+__global__ void gather_outputs_kernel(const int32_t* reward, const int32_t* lives, const int32_t* score, const uint8_t* done,
+                                      uint32_t* err_flag, int32_t* out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { out[3 * (size_t)n] = (int32_t)*err_flag; *err_flag = 0u; }
+    if (i >= n) return;
+    out[i] = reward[i]; out[(size_t)n + i] = lives[i]; out[2 * (size_t)n + i] = score[i];
+    reinterpret_cast<uint8_t*>(out + 3 * (size_t)n + 1)[i] = done[i];
+}
+
 __global__ void fill_rng_kernel(uint64_t* sim_rng, int n, uint64_t s0, uint64_t s1)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -245,7 +256,8 @@ int tbx_destroy(tbx_engine* e)
     if (e->ops) { e->ops->destroy(e); delete e->ops; }
     hipFree(e->sim_rng); hipFree(e->prev_score); hipFree(e->reward); hipFree(e->done);
     hipFree(e->lives_out); hipFree(e->score_out); hipFree(e->packed); hipFree(e->actions);
-    hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame); hipFree(e->staging); hipFree(e->scal); hipFree(e->one_frame);
+    hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame); hipFree(e->staging); hipFree(e->scal); hipFree(e->one_frame); hipFree(e->io_dev);
+    if (e->io_host) hipHostFree(e->io_host);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return TBX_OK;
@@ -429,17 +441,31 @@ int tbx_step(tbx_engine* e, const int32_t* actions_host, uint32_t flags, int32_t
     if (!actions_host) return e->fail(TBX_E_INVALID, "actions pointer is NULL");
     EHIP(hipSetDevice(e->device));
     const size_t N = (size_t)e->n;
-    EHIP(hipMemcpyAsync(e->actions, actions_host, N * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    const size_t out_bytes = (3 * N + 1) * sizeof(int32_t) + N;
+    if (!e->io_dev) {
+        EHIP(hipMalloc((void**)&e->io_dev, out_bytes));
+        EHIP(hipHostMalloc((void**)&e->io_host, N * sizeof(int32_t) + out_bytes, hipHostMallocDefault));
+    }
+    int32_t* host_actions = e->io_host;
+    int32_t* host_out = e->io_host + N;
+    memcpy(host_actions, actions_host, N * sizeof(int32_t));
+    EHIP(hipMemcpyAsync(e->actions, host_actions, N * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     ActionSource src{};
     src.actions = e->actions;
     src.single_env = -1;
     int rc = e->ops->step(e, src, flags, e->stream);
     if (rc) return rc;
-    if (reward) EHIP(hipMemcpyAsync(reward, e->reward, N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-    if (done) EHIP(hipMemcpyAsync(done, e->done, N, hipMemcpyDeviceToHost, e->stream));
-    if (lives) EHIP(hipMemcpyAsync(lives, e->lives_out, N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-    if (score) EHIP(hipMemcpyAsync(score, e->score_out, N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-    return check_err_flag(e);
+    hipLaunchKernelGGL(gather_outputs_kernel, dim3((e->n + 255) / 256), dim3(256), 0, e->stream, e->reward, e->lives_out, e->score_out,
+                       e->done, e->err_flag, e->io_dev, e->n);
+    EHIP(hipGetLastError());
+    EHIP(hipMemcpyAsync(host_out, e->io_dev, out_bytes, hipMemcpyDeviceToHost, e->stream));
+    EHIP(hipStreamSynchronize(e->stream));
+    if (reward) memcpy(reward, host_out, N * sizeof(int32_t));
+    if (lives) memcpy(lives, host_out + N, N * sizeof(int32_t));
+    if (score) memcpy(score, host_out + 2 * N, N * sizeof(int32_t));
+    if (done) memcpy(done, host_out + 3 * N + 1, N);
+    if (host_out[3 * N]) return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
+    return TBX_OK;
 }
 
 int tbx_apply_input(tbx_engine* e, int env, uint32_t buttons)

@@ -189,6 +189,10 @@ struct tbx_engine {
     uint32_t* err_flag = nullptr;   // device word: bit0 = illegal action seen
     int32_t* scal = nullptr;        // [3][N] scratch of tbx_get_scalars
     uint8_t* one_frame = nullptr;   // H*W*4 scratch of tbx_render_env
+    // host-pointer step path: one device block [reward | lives | score | err | done] gathered by a kernel and ONE copy
+    // into pinned host memory (five pageable copies cost ~100 us per call); actions go up through the pinned block too
+    int32_t* io_dev = nullptr;      // 3N + 1 dwords + N bytes
+    int32_t* io_host = nullptr;     // pinned mirror (+ N action dwords in front)
     uint8_t* frame = nullptr;       // engine-owned frame buffer (lazy)
     size_t frame_bytes = 0;
     void* staging = nullptr;        // device POD staging for get/set state
