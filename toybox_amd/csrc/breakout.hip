@@ -924,7 +924,7 @@ struct BrkPalette {
 // this form in the same session (hipMemset on the same box: 6.3 TB/s).
 template <int C, bool CUSTOM>
 __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
-                                                               BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count)
+                                                               BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split)
 {
     constexpr int W = TBX_BRK_W, H = TBX_BRK_H;
     using Stager = RowStager<C, W, BRK_UNIT_ROWS>;
@@ -958,9 +958,11 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
         hud_sel[i] = sel;
     }
 
-    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    // `split` waves share a frame, wave `part` taking units part, part + split, ...
+    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    const int rel = wid / split, part = wid - rel * split;
     if (rel >= count) return;
-    for (int q = 0; q < NUNITS; q++) {
+    for (int q = part; q < NUNITS; q += split) {
         const int u = (int)(((uint32_t)(first_env + rel) * 7u + (uint32_t)q) % (uint32_t)NUNITS);
         const BrkRenderRec rec = recs[first_env + rel];   // by value: scalar loads up front, none inside the row loop
         const int env = first_env + rel;
@@ -1500,8 +1502,13 @@ struct BreakoutOps : GameOps {
         pal.bg = c.bg; pal.frame = c.frame; pal.paddle = c.paddle; pal.ball = c.ball; pal.rows = c.n_rows;
         for (int i = 0; i < TBX_BRK_MAX_ROWS; i++) pal.row_colors[i] = c.row_colors[i];
         if (!recs_valid) hipLaunchKernelGGL(brk_render_prep_kernel, dim3((count + 255) / 256), dim3(256), 0, s, d, recs, first, count);
-        if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true>), grid_for(count), dim3(TBX_BLOCK), 0, s, recs, d.custom, pal, out, first, count);
-        else hipLaunchKernelGGL((brk_render_kernel<C, false>), grid_for(count), dim3(TBX_BLOCK), 0, s, recs, d.custom, pal, out, first, count);
+        // ten waves per frame, each doing unit p and unit p + 10 (one from the busy upper half of the screen, one from the
+        // lower): measured 6.05-6.25 TB/s against 5.4-5.7 for one wave per frame and for every other split from 1 to 20
+        // except 9..12 (scripts/ab_render.py with TBX_BRK_SPLIT); also what keeps small batches from under-filling the chip
+        static const int split_env = getenv("TBX_BRK_SPLIT") ? atoi(getenv("TBX_BRK_SPLIT")) : 0;
+        const int split = split_env > 0 ? split_env : C == 3 ? 10 : count <= 8192 ? 4 : count <= 32768 ? 2 : 1;   // gray / RGBA: no such effect
+        if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, recs, d.custom, pal, out, first, count, split);
+        else hipLaunchKernelGGL((brk_render_kernel<C, false>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, recs, d.custom, pal, out, first, count, split);
     }
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
