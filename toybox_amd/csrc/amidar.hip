@@ -873,7 +873,7 @@ struct AmiGrayPainter : AmiPainter<1> {
 // One wave rasterises one env; AMI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte stores, background-only
 // units are stored directly.
 template <int C>
-__global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t* out, int first_env, int count)
+__global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t* out, int first_env, int count, int split)
 {
     constexpr int W = TBX_AMI_W, H = TBX_AMI_H;
     using Stager = RowStager<C, W, AMI_UNIT_ROWS>;
@@ -881,7 +881,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
     __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][AmiPainter<C>::NCLS * 8];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);   // `split` waves share a frame (see breakout.hip)
+    const int rel = wid / split, part = wid - rel * split;
     if (rel >= count) return;
     const int env = first_env + rel;
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
@@ -890,8 +891,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
 
     uint8_t* frame = out + (size_t)rel * H * W * C;
     constexpr int NUNITS = H / AMI_UNIT_ROWS;
-    const int u0 = (int)(((uint32_t)env * 7u) % (uint32_t)NUNITS);
-    for (int k = 0; k < NUNITS; k++) {
+    const int u0 = split > 1 ? 0 : (int)(((uint32_t)env * 7u) % (uint32_t)NUNITS);
+    for (int k = part; k < NUNITS; k += split) {
         int u = u0 + k;
         if (u >= NUNITS) u -= NUNITS;
         const int y_first = u * AMI_UNIT_ROWS;
@@ -1202,10 +1203,14 @@ struct AmiOps : GameOps {
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
     {
+        static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
+        // RGB: nine waves per frame (2-3 of the 25 units each) measured 5.45-5.55 TB/s against 4.9 for one wave per frame;
+        // gray and RGBA show no such effect (scripts/ab_render.py with TBX_RENDER_SPLIT)
+        const int split = split_env > 0 ? split_env : channels == 3 ? 9 : 1;
         switch (channels) {
-        case 1: hipLaunchKernelGGL(ami_render_kernel<1>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
-        case 3: hipLaunchKernelGGL(ami_render_kernel<3>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
-        case 4: hipLaunchKernelGGL(ami_render_kernel<4>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        case 1: hipLaunchKernelGGL(ami_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
+        case 3: hipLaunchKernelGGL(ami_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
+        case 4: hipLaunchKernelGGL(ami_render_kernel<4>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
         TBX_HIP(hipGetLastError());

@@ -12,6 +12,7 @@
 #include "raster.hpp"
 #include "agent_device.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -313,7 +314,7 @@ struct GwGrayPainter : GwPainter<1> {
 };
 
 template <int C>
-__global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* out, int first_env, int count)
+__global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* out, int first_env, int count, int split)
 {
     constexpr int W = TBX_GW_W, H = TBX_GW_H, UNITS = H / GW_UNIT_ROWS;
     using Stager = RowStager<C, W, GW_UNIT_ROWS>;
@@ -321,15 +322,16 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* 
     __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][GwPainter<C>::NCLS * 8];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);   // `split` waves share a frame (see breakout.hip)
+    const int rel = wid / split, part = wid - rel * split;
     if (rel >= count) return;
     const int env = first_env + rel;
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
     GwPainter<C> p;
     p.setup(d, env, lane, lds_mask[wave]);
     uint8_t* dst = out + (size_t)rel * H * W * C;
-    for (int u = 0; u < UNITS; u++) {
-        const int unit = (u + env) % UNITS;                  // rotate the start so waves do not march in lockstep
+    for (int u = part; u < UNITS; u += split) {
+        const int unit = split > 1 ? u : (u + env) % UNITS;  // one wave per frame: rotate the start so waves do not march in lockstep
         for (int r = 0; r < GW_UNIT_ROWS; r++) {
             uint32_t px[4];
             p.paint_row(unit * GW_UNIT_ROWS + r, px);
@@ -534,10 +536,12 @@ struct GridWorldOps : GameOps {
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
     {
+        static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
+        const int split = split_env > 0 ? split_env : 1;
         switch (channels) {
-        case 1: hipLaunchKernelGGL(gw_render_kernel<1>, wave_grid(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
-        case 3: hipLaunchKernelGGL(gw_render_kernel<3>, wave_grid(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
-        case 4: hipLaunchKernelGGL(gw_render_kernel<4>, wave_grid(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs); break;
+        case 1: hipLaunchKernelGGL(gw_render_kernel<1>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
+        case 3: hipLaunchKernelGGL(gw_render_kernel<3>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
+        case 4: hipLaunchKernelGGL(gw_render_kernel<4>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
         TBX_HIP(hipGetLastError());

@@ -960,7 +960,7 @@ __device__ __forceinline__ void si_fill_sprites(uint32_t* spr_lds)
 // One wave rasterises one env, scanline by scanline; SI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte
 // stores, blank units are stored directly.
 template <int C>
-__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank)
+__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank, int split)
 {
     constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
     using Stager = RowStager<C, W, SI_UNIT_ROWS>;
@@ -970,7 +970,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
     si_fill_sprites(spr_lds);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);   // `split` waves share a frame (see breakout.hip)
+    const int rel = wid / split, part = wid - rel * split;
     if (rel >= count) return;
     const int env = first_env + rel;
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
@@ -980,8 +981,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
 
     uint8_t* frame = out + (size_t)rel * H * W * C;
     constexpr int NUNITS = H / SI_UNIT_ROWS;
-    const int u0 = (int)(((uint32_t)env * 11u) % (uint32_t)NUNITS);
-    for (int k = 0; k < NUNITS; k++) {
+    const int u0 = split > 1 ? 0 : (int)(((uint32_t)env * 11u) % (uint32_t)NUNITS);
+    for (int k = part; k < NUNITS; k += split) {
         int u = u0 + k;
         if (u >= NUNITS) u -= NUNITS;
         const uint32_t rows_busy = skip_blank ? row_mask_chunk<SI_UNIT_ROWS>(p.busy, u * SI_UNIT_ROWS) : (1u << SI_UNIT_ROWS) - 1u;
@@ -1279,10 +1280,12 @@ struct SiOps : GameOps {
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
     {
         static const int skip_blank = getenv("TBX_SI_NO_SKIP") ? 0 : 1;   // diagnostic A/B switch
+        static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
+        const int split = split_env > 0 ? split_env : 1;
         switch (channels) {
-        case 1: hipLaunchKernelGGL(si_render_kernel<1>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank); break;
-        case 3: hipLaunchKernelGGL(si_render_kernel<3>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank); break;
-        case 4: hipLaunchKernelGGL(si_render_kernel<4>, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank); break;
+        case 1: hipLaunchKernelGGL(si_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank, split); break;
+        case 3: hipLaunchKernelGGL(si_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank, split); break;
+        case 4: hipLaunchKernelGGL(si_render_kernel<4>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank, split); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
         TBX_HIP(hipGetLastError());
