@@ -836,6 +836,8 @@ __global__ __launch_bounds__(128) void brk_agent_reset_kernel(BrkDev d, const Br
 
 __constant__ uint16_t BRK_DIGITS[10] = {0x7B6F, 0x749A, 0x73E7, 0x79E7, 0x49ED, 0x79CF, 0x7BCF, 0x4927, 0x7BEF, 0x79EF};
 
+// 8 scanlines = 5 760 B (RGB) = 45 x 128 B: units whose size is not a multiple of 128 B (5, 10, 20 rows) measured 15-40 %
+// slower, 16 rows no better
 constexpr int BRK_UNIT_ROWS = 8;    // scanlines per work item, staged in LDS (160 = 20 units)
 
 __global__ __launch_bounds__(256) void brk_render_prep_kernel(BrkDev d, BrkRenderRec* recs, int first_env, int count)
@@ -985,8 +987,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
         // scanlines of this unit crossed by the paddle or a ball
         uint64_t ov[3] = {0ull, 0ull, 0ull};
         brk_overlay_rows(rec, ov);
-        const int ow = y_first >> 6, ob = y_first & 63;      // units are 8 rows at multiples of 8: never straddle a word
-        const uint32_t ov_chunk = (uint32_t)(sel4(ow, ov[0], ov[1], ov[2], 0ull) >> ob) & ((1u << BRK_UNIT_ROWS) - 1u);
+        const uint64_t ov4[4] = {ov[0], ov[1], ov[2], 0ull};
+        const uint32_t ov_chunk = row_mask_chunk<BRK_UNIT_ROWS>(ov4, y_first);
 
 #pragma unroll 1
         for (int r = 0; r < BRK_UNIT_ROWS; r++) {
