@@ -1281,7 +1281,9 @@ struct SiOps : GameOps {
     {
         static const int skip_blank = getenv("TBX_SI_NO_SKIP") ? 0 : 1;   // diagnostic A/B switch
         static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
-        const int split = split_env > 0 ? split_env : 1;
+        // the painter set-up is too heavy to repeat many times per frame, so one wave per frame -- except for batches that
+        // would leave the chip under-filled (measured +10 % at 4 096 envs, +5 % at 16 384 with five waves per frame)
+        const int split = split_env > 0 ? split_env : (channels != 1 && n_envs <= 32768) ? 5 : 1;
         switch (channels) {
         case 1: hipLaunchKernelGGL(si_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank, split); break;
         case 3: hipLaunchKernelGGL(si_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank, split); break;
