@@ -916,14 +916,16 @@ struct BrkPalette {
     uint32_t row_colors[TBX_BRK_MAX_ROWS];
 };
 
-// The rasteriser: one wave per env.  Per env the wave loads the 64-byte record (scalar), composes each scanline
-// per lane as 4 packed pixels (lane l -> pixels 4l..4l+3) from wave-uniform row classes (HUD / top bar / side
-// walls / brick band / paddle / balls), stages BRK_UNIT_ROWS scanlines in its LDS slice and flushes them as
-// 1 KiB-per-instruction stores.  Units are visited in an env-rotated order so that co-resident waves do not
-// march through the same frame offsets in lockstep.  Measured alternatives (scripts/ubench/): a persistent
-// grid over address-ordered units reaches 6.1 TB/s as bare stores but 4.7-4.9 TB/s with record loads and LDS
-// staging; one-shot address-ordered waves of 1, 2, 4 or 10 units each measured 5.3-5.5 TB/s against 5.5-5.9 TB/s for
-// this form in the same session (hipMemset on the same box: 6.3 TB/s).
+// The rasteriser.  A wave loads the env's 64-byte record (scalar loads), composes each scanline per lane as 4 packed
+// pixels (lane l -> pixels 4l..4l+3) from wave-uniform row classes (HUD / top bar / side walls / brick band / paddle /
+// balls), stages BRK_UNIT_ROWS scanlines in its LDS slice and flushes them as 1 KiB-per-instruction stores.  `split`
+// waves share a frame: wave `part` takes units part, part + split, ...  RGB launches use split = 10 (two units per
+// wave, one from the busy upper half of the screen and one from the lower): 6.05-6.25 TB/s, against 5.4-5.7 TB/s for
+// one wave per frame (units then visited in an env-rotated order so that co-resident waves do not march in lockstep)
+// and for every other split except 9..12; 4.6 TB/s at one unit per wave.  Other measured alternatives
+// (scripts/ubench/): a persistent grid over address-ordered units reaches 6.1 TB/s as bare stores but 4.7-4.9 TB/s with
+// record loads and LDS staging; one-shot address-ordered waves of 1, 2, 4 or 10 CONSECUTIVE units 5.3-5.5 TB/s
+// (hipMemset on the same boxes: 6.3-6.5 TB/s).
 template <int C, bool CUSTOM>
 __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
                                                                BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split)
