@@ -14,6 +14,9 @@
  *   - plain pointers and sizes only; buffers are caller-allocated;
  *   - "_host" arguments are host pointers (call is synchronous), "_dev" arguments are
  *     device (HBM) pointers (call is asynchronous on the given hipStream_t, passed as void*);
+ *   - calls on one handle take effect in program order whatever streams they name: when an entry point uses another stream
+ *     than the previous one did (the host-pointer forms run on an engine-owned non-blocking stream), the new stream first
+ *     waits for an event recorded on the old one -- no tbx_sync is needed between the two API families;
  *   - a handle is not thread-safe; different handles may be used concurrently;
  *   - there is NO CPU fallback: tbx_create fails with TBX_E_NO_DEVICE when no gfx950
  *     device is visible.
@@ -344,6 +347,10 @@ int tbx_game(const tbx_engine* engine);
  * Takes effect at the next new game, as in the reference (envs/atari/base.py:95-97).
  * replaces Toybox.set_seed (envs/atari/base.py:95, scripts/utils/test_games.py:30). */
 int tbx_seed(tbx_engine* engine, int env, uint32_t seed);
+/* Per-env seeds in one upload + one launch: env i gets seeds_host[i].  This is how a vectorised env applies the reference's
+ * per-worker derivation seed2_i = hash_seed(seed + rank_i + 1) % 2**31 (envs/atari/base.py:84-98 under
+ * baselines/common/cmd_util.py:31) without N calls. */
+int tbx_seed_array(tbx_engine* engine, const uint32_t* seeds_host);
 int tbx_get_sim_rng(tbx_engine* engine, int env, uint64_t out_state[2]);
 int tbx_set_sim_rng(tbx_engine* engine, int env, const uint64_t state[2]);
 
@@ -391,8 +398,10 @@ int tbx_set_state(tbx_engine* engine, int env, const void* pod, size_t size);
  * record_size bytes for envs [first_env, first_env + count), one pack/unpack launch and one copy. */
 int tbx_get_states(tbx_engine* engine, int first_env, int count, void* pods_out, size_t record_size);
 int tbx_set_states(tbx_engine* engine, int first_env, int count, const void* pods, size_t record_size);
-/* Batch-wide config record (tbx_<game>_config_t); `rand` is env 0's simulator RNG on get and
- * is written to every env on set.  Does not start a new game.
+/* Batch-wide config record (tbx_<game>_config_t).  `rand` is env 0's simulator RNG on get.  On set, a `rand` equal to
+ * env 0's current simulator RNG (i.e. the caller did not edit it) leaves every env's simulator RNG untouched -- a config
+ * edit must not put a seeded batch onto one random stream; any other value is written to every env.  For a one-env engine
+ * both cases coincide with the reference.  Does not start a new game.
  * replaces Toybox.config_to_json / write_config_json (interventions/base.py:390,402). */
 int tbx_get_config(tbx_engine* engine, void* pod_out, size_t size);
 int tbx_set_config(tbx_engine* engine, const void* pod, size_t size);
@@ -449,6 +458,32 @@ int tbx_agent_step_synthetic(tbx_engine* engine, uint64_t action_seed, uint64_t 
 #define TBX_BUF_AGENT_EP_LENGTH 11   /* int32[N]   its length 'l' in agent steps (valid where EP_DONE) */
 /* host copy of the three episode-monitor arrays of the last agent step (any pointer may be NULL) */
 int tbx_agent_episodes(tbx_engine* engine, uint8_t* ep_done_host, float* ep_return_host, int32_t* ep_length_host);
+
+/* ------------------------------------------------------------------ multi-GPU record gather
+ * One process per GPU, one engine per process = one contiguous shard of the env batch; envs never interact, so the only
+ * exchange is one all-gather per step of the packed TBX_BUF_PACKED records (8 B/env: reward i32, done u8, lives u8) over
+ * RCCL / xGMI.  replaces the pipes of pickled (ob, rew, done, info) tuples between the reference's worker processes and
+ * the learner (baselines/baselines/common/vec_env/subproc_vec_env.py:63-74); frames stay on their GPU.
+ * librccl is resolved with dlopen inside these calls (no link-time dependency, no PyTorch); without it they return
+ * TBX_E_UNSUPPORTED and a caller may fall back to gathering the records on the host. */
+#define TBX_GATHER_ID_BYTES 128
+/* rank 0: a fresh communicator id (ncclGetUniqueId) to hand to every rank out of band (file, env var, pipe).
+ * Errors are reported through tbx_last_error(NULL). */
+int tbx_gather_unique_id(void* id_out, size_t id_bytes);
+/* Collective over all ranks (ncclCommInitRank).  records_per_rank >= this engine's env count is the per-rank slot width of
+ * the gathered layout [nranks][records_per_rank] (ranks may hold unequal shards; unused slots read 0). */
+int tbx_gather_init(tbx_engine* engine, int nranks, int rank, int records_per_rank, const void* id, size_t id_bytes);
+/* Queue the all-gather of the last step's records into out_dev (NULL: the engine-owned TBX_BUF_GATHERED).  Asynchronous: it
+ * is ordered after everything queued through this handle so far, runs on an engine-owned communication stream, and the next
+ * step on this handle is ordered after it -- what the caller queues in between (the rasteriser) overlaps with it. */
+int tbx_gather(tbx_engine* engine, uint64_t* out_dev, void* stream);
+/* Make `stream` wait for the last queued gather (device-side consumers of the gathered records). */
+int tbx_gather_wait(tbx_engine* engine, void* stream);
+/* Block until the last queued gather has finished and copy TBX_BUF_GATHERED to the host: uint64[nranks * records_per_rank]. */
+int tbx_gather_host(tbx_engine* engine, uint64_t* out_host);
+/* Blocking max-reduction of one double over all ranks (barrier + "slowest rank" timing of bench.py). */
+int tbx_gather_reduce_max(tbx_engine* engine, double* inout_host);
+#define TBX_BUF_GATHERED 12   /* uint64[nranks][records_per_rank] result of tbx_gather(out_dev = NULL) */
 
 /* Address of an engine-owned device buffer (TBX_BUF_*). */
 int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out_bytes);

@@ -28,6 +28,9 @@ struct tbx_engine {
     tbx_agent_config_t acfg;
     uint8_t *gray_a, *gray_b, *aobs, *afin, *adone;
     float* areward;
+    /* record gather: the oracle restates the one-rank case only (there is no second process to talk to) */
+    int gather_on, gather_width;
+    uint64_t* gathered;
     /* Monitor / EpisodicLifeEnv state and this step's episode records */
     int32_t *ep_ret, *ep_len, *ep_index, *prev_lives, *ep_len_out;
     uint8_t* ep_done;
@@ -75,7 +78,7 @@ int tbx_destroy(tbx_engine* e)
 {
     if (!e) return TBX_OK;
     free(e->cfg); free(e->states); free(e->sim); free(e->prev); free(e->reward); free(e->lives);
-    free(e->score); free(e->done); free(e->packed); free(e->frame);
+    free(e->score); free(e->done); free(e->packed); free(e->frame); free(e->gathered);
     agent_free(e);
     free(e);
     return TBX_OK;
@@ -127,6 +130,14 @@ int tbx_seed(tbx_engine* e, int env, uint32_t seed)
         if (env >= 0 && i != env) continue;
         orc_rng_seed(e->sim + 2 * (size_t)i, env >= 0 ? seed : seed + (uint32_t)i);
     }
+    return TBX_OK;
+}
+
+int tbx_seed_array(tbx_engine* e, const uint32_t* seeds)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!seeds) return fail(e, TBX_E_INVALID, "seeds pointer is NULL");
+    for (int i = 0; i < e->n; i++) orc_rng_seed(e->sim + 2 * (size_t)i, seeds[i]);
     return TBX_OK;
 }
 
@@ -449,7 +460,9 @@ int tbx_set_config(tbx_engine* e, const void* pod, size_t size)
         if (k->n_tiles < 1 || k->n_tiles > TBX_GW_MAX_TILES) return fail(e, TBX_E_UNSUPPORTED, "gridworld: 1..16 tiles");
     }
     memcpy(e->cfg, pod, size);
-    for (int i = 0; i < e->n; i++) memcpy(e->sim + 2 * (size_t)i, pod, 16);
+    /* `rand` unchanged from what tbx_get_config reports (env 0's words): the per-env simulator RNGs stay (toybox_amd.h) */
+    if (memcmp(e->sim, pod, 16) != 0)
+        for (int i = 0; i < e->n; i++) memcpy(e->sim + 2 * (size_t)i, pod, 16);
     return TBX_OK;
 }
 
@@ -484,10 +497,74 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
         else if (which == TBX_BUF_AGENT_EP_RETURN) { p = e->ep_ret_out; b = n * 4; }
         else { p = e->ep_len_out; b = n * 4; }
         break;
+    case TBX_BUF_GATHERED:
+        if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
+        p = e->gathered; b = (size_t)e->gather_width * 8;
+        break;
     default: return fail(e, TBX_E_INVALID, "unknown buffer id");
     }
     *out_ptr = p;
     if (out_bytes) *out_bytes = b;
+    return TBX_OK;
+}
+
+/* ---------------------------------------------------------------- record gather (one rank) */
+
+int tbx_gather_unique_id(void* id_out, size_t id_bytes)
+{
+    if (!id_out || id_bytes != TBX_GATHER_ID_BYTES) return fail(NULL, TBX_E_INVALID, "id buffer must be TBX_GATHER_ID_BYTES long");
+    memset(id_out, 0, id_bytes);
+    memcpy(id_out, "oracle-one-rank", 16);
+    return TBX_OK;
+}
+
+int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, const void* id, size_t id_bytes)
+{
+    if (!e) return TBX_E_INVALID;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(e, TBX_E_INVALID, "gather: rank / nranks out of range");
+    if (records_per_rank < e->n) return fail(e, TBX_E_INVALID, "gather: records_per_rank must be >= the engine's env count");
+    if (!id || id_bytes != TBX_GATHER_ID_BYTES) return fail(e, TBX_E_INVALID, "gather: id must be TBX_GATHER_ID_BYTES long");
+    if (nranks != 1) return fail(e, TBX_E_UNSUPPORTED, "gather: the CPU checker restates the one-rank case only");
+    free(e->gathered);
+    e->gathered = (uint64_t*)calloc((size_t)records_per_rank, 8);
+    e->gather_width = records_per_rank;
+    e->gather_on = 1;
+    return TBX_OK;
+}
+
+int tbx_gather(tbx_engine* e, uint64_t* out, void* stream)
+{
+    (void)stream;
+    if (!e) return TBX_E_INVALID;
+    if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
+    uint64_t* dst = out ? out : e->gathered;
+    memset(dst, 0, (size_t)e->gather_width * 8);
+    memcpy(dst, e->packed, (size_t)e->n * 8);
+    return TBX_OK;
+}
+
+int tbx_gather_wait(tbx_engine* e, void* stream)
+{
+    (void)stream;
+    if (!e) return TBX_E_INVALID;
+    if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
+    return TBX_OK;
+}
+
+int tbx_gather_host(tbx_engine* e, uint64_t* out)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
+    if (!out) return fail(e, TBX_E_INVALID, "output pointer is NULL");
+    memcpy(out, e->gathered, (size_t)e->gather_width * 8);
+    return TBX_OK;
+}
+
+int tbx_gather_reduce_max(tbx_engine* e, double* inout)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
+    if (!inout) return fail(e, TBX_E_INVALID, "value pointer is NULL");
     return TBX_OK;
 }
 

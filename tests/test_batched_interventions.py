@@ -106,3 +106,44 @@ def test_set_eq_diff_and_partial_config(oracle_lib, tmp_path):
         cfg = e.get_config()
         assert cfg.start_lives == 2 and cfg.ball_speed_slow == 1.5
         assert (e.scalars()[1] == 2).all()
+
+
+@pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar"])
+def test_config_intervention_keeps_per_env_rngs(game, lib):
+    """A batch-wide config edit (Intervention.set_partial_config + the new game of interventions/base.py:401-403) must not put
+    every env on env 0's random stream: `rand` as tbx_get_config reported it means "not edited"; an edited `rand` is
+    written to every env (the one-env case of both is the reference's behaviour)."""
+    n = 9
+    e = Engine(game, n, lib=lib)
+    e.seed(500)
+    e.new_game()
+    before = [e.get_sim_rng(i) for i in range(n)]
+    assert len(set(before)) == n
+    key = {"breakout": "start_lives", "space_invaders": "start_lives", "amidar": "start_lives"}[game]
+    with BatchIntervention(e) as bi:
+        bi.set_partial_config({key: 2})
+    assert (e.get_states_np()["lives"] == 2).all()
+    # the new game drew one child from every env's own stream: all distinct, none equal to env 0's
+    after = [e.get_sim_rng(i) for i in range(n)]
+    assert len(set(after)) == n and all(a != b for a, b in zip(after, before))
+    rngs = {tuple(int(v) for v in r) for r in e.get_states_np()["rand"]}
+    assert len(rngs) == n, "envs share a state RNG after a config intervention"
+    # an edited `rand` IS a request to re-seed every env
+    with BatchIntervention(e) as bi:
+        bi.config["rand"] = {"state": [123, 456]}
+    assert len({e.get_sim_rng(i) for i in range(n)}) == 1
+
+
+def test_seed_array_equals_per_env_seed(lib):
+    n = 11
+    a, b = Engine("space_invaders", n, lib=lib), Engine("space_invaders", n, lib=lib)
+    seeds = [(977 * i * i + 13) % 2 ** 31 for i in range(n)]
+    a.seed_array(seeds)
+    for i, s in enumerate(seeds):
+        b.seed(s, env=i)
+    a.new_game()
+    b.new_game()
+    for i in range(n):
+        assert a.get_sim_rng(i) == b.get_sim_rng(i) and bytes(a.get_state(i)) == bytes(b.get_state(i))
+    with pytest.raises(ValueError):
+        a.seed_array(seeds[:-1])

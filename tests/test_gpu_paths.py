@@ -1,0 +1,393 @@
+"""HIP code paths that the main parity file does not reach, each held to the CPU oracle bit for bit:
+
+* tbx_apply_input (Toybox.apply_action(Input), /root/reference/scripts/utils/test_games.py:13) on every game, mixed with
+  batch steps -- for Breakout this is the wave-per-env kernel brk_step_kernel<false>;
+* the whole batch protocol with TBX_BRK_STEP_TPE=0 (wave-per-env Breakout step instead of thread-per-env);
+* the several-waves-per-frame rasteriser launches at other split factors than the default (TBX_RENDER_SPLIT / TBX_BRK_SPLIT);
+* BASELINE config 5's per-GPU share: three games x 10 922 envs on three HIP streams (toybox_amd.parallel.MixedBatch);
+* every TBX_BUF_* id of tbx_device_buffer on both libraries;
+* the cross-stream ordering rule of the C-ABI (async "_device" calls on the NULL stream, then host-pointer calls).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from support import LEGAL, synthetic_actions
+from toybox_amd import Engine, ToyboxAmdError, _abi
+
+GAMES = ["breakout", "space_invaders", "amidar", "gridworld"]
+
+BUTTONS = {0: 0, 1: 16, 2: 4, 3: 2, 4: 1, 5: 8, 11: 2 | 16, 12: 1 | 16}   # ALE id -> TBX_BTN_* mask (constants.py:16-35)
+
+
+def _pair(game, n, hip_lib, oracle_lib, seed=1234):
+    g, o = Engine(game, n, lib=hip_lib), Engine(game, n, lib=oracle_lib)
+    for e in (g, o):
+        e.seed(seed)
+        e.new_game()
+    return g, o
+
+
+def _same_states(g, o, envs, what=""):
+    for i in envs:
+        assert bytes(g.get_state(int(i))) == bytes(o.get_state(int(i))), "%s env %d" % (what, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", GAMES)
+def test_apply_input_rollout_parity(game, hip_lib, oracle_lib):
+    """One env at a time through tbx_apply_input (raw button masks, including BUTTON2 and opposing directions), with a
+    batch step every 16th frame: states, the step outputs the call leaves in TBX_BUF_*, and frames equal the oracle."""
+    n, frames = 6, 700
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=31)
+    rng = np.random.default_rng(7)
+    for t in range(frames):
+        if t % 16 == 15:
+            a = synthetic_actions(game, n, t)
+            rg, ro = g.step(a), o.step(a)
+            for x, y in zip(rg, ro):
+                assert np.array_equal(x, y), t
+            over = rg[1].astype(np.uint8)
+            if over.any():
+                g.new_game(over)
+                o.new_game(over)
+        else:
+            a = synthetic_actions(game, n, t, seed=99)
+            for i in range(n):
+                b = BUTTONS[int(a[i])]
+                if rng.random() < 0.1:
+                    b = int(rng.integers(0, 64))          # any mask the Input struct can express
+                g.apply_input(i, b)
+                o.apply_input(i, b)
+        if t % 50 == 49 or t < 3:
+            _same_states(g, o, range(n), "frame %d" % t)
+            assert np.array_equal(g.render(3), o.render(3))
+            for x, y in zip(g.scalars(), o.scalars()):
+                assert np.array_equal(x, y)
+    _same_states(g, o, range(n), "end")
+
+
+@pytest.mark.gpu
+def test_apply_input_many_envs_long(hip_lib, oracle_lib):
+    """Breakout's wave-per-env step over a long horizon (lives lost, new balls from the RNG, levels): every env of a
+    64-env engine driven only through tbx_apply_input."""
+    n = 64
+    g, o = _pair("breakout", n, hip_lib, oracle_lib, seed=5)
+    for t in range(1500):
+        a = synthetic_actions("breakout", n, t)
+        for i in range(n):
+            g.apply_input(i, BUTTONS[int(a[i])])
+            o.apply_input(i, BUTTONS[int(a[i])])
+        if t % 300 == 299:
+            _same_states(g, o, range(n), "frame %d" % t)
+            over = g.scalars()[3].astype(np.uint8)
+            assert np.array_equal(over, o.scalars()[3].astype(np.uint8))
+            if over.any():
+                g.new_game(over)
+                o.new_game(over)
+    lives = g.scalars()[1]
+    assert (lives < 5).any(), "no life was ever lost: the reset-ball path was not reached"
+
+
+_SUB = r"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from toybox_amd import Engine, _abi, _lib
+from support import synthetic_actions
+orc = ctypes.CDLL(os.path.join({root!r}, "oracle", "liboracle.so")); _abi.bind(orc)
+hip = _lib.load()
+{body}
+print("SUB_OK")
+"""
+
+
+def _run_sub(body, env, timeout=900):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _SUB.format(root=ROOT, body=body)], env=e, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0 and "SUB_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_breakout_wave_per_env_step_kernel_parity(oracle_lib):
+    """TBX_BRK_STEP_TPE=0: the batch protocol and the agent pipeline run on brk_step_kernel<false> (one wavefront per env)
+    instead of the thread-per-env kernel; same bar as test_rollout_parity."""
+    body = r"""
+n, steps = 2048, 900
+g, o = Engine("breakout", n, lib=hip), Engine("breakout", n, lib=orc)
+for e in (g, o):
+    e.seed(1234); e.new_game()
+done = 0
+for t in range(steps):
+    a = synthetic_actions("breakout", n, t)
+    rg, ro = g.step(a, auto_reset=True), o.step(a, auto_reset=True)
+    for x, y in zip(rg, ro):
+        assert np.array_equal(x, y), t
+    done += int(rg[1].sum())
+    if t % 300 == 299:
+        assert np.array_equal(g.render(3)[::64], o.render(3)[::64])
+for i in range(n):
+    assert bytes(g.get_state(i)) == bytes(o.get_state(i)), i
+assert done > 0
+# device-generated actions and the agent pipeline on the same kernel
+for t in range(200):
+    g.step_synthetic(1337, t, env_offset=3, auto_reset=True)
+    o.step(synthetic_actions("breakout", n, t, seed=1337, env_offset=3), auto_reset=True)
+g.sync()
+for i in range(0, n, 5):
+    assert bytes(g.get_state(i)) == bytes(o.get_state(i)), i
+for e in (g, o):
+    e.agent_init(skip=4, episodic_life=True, fire_reset=True, noop_max=8, noop_seed=3)
+assert np.array_equal(g.agent_reset(), o.agent_reset())
+for t in range(120):
+    a = synthetic_actions("breakout", n, t, seed=11)
+    xg, xo = g.agent_step(a), o.agent_step(a)
+    for x, y in zip(xg, xo):
+        assert np.array_equal(x, y), t
+"""
+    _run_sub(body, {"TBX_BRK_STEP_TPE": "0"})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", ["1", "2", "3", "5", "7", "16"])
+def test_render_split_factors_parity(split, oracle_lib):
+    """The rasterisers take `split` waves per frame (launch-time choice, by default a function of game, channels and batch
+    size).  Every factor must paint the same bytes: all games, all channel counts, batch sizes that do not fill a block."""
+    body = r"""
+for game in ("breakout", "space_invaders", "amidar", "gridworld"):
+    for n in (3, 130):
+        g, o = Engine(game, n, lib=hip), Engine(game, n, lib=orc)
+        for e in (g, o):
+            e.seed(9); e.new_game()
+        for t in range(260):
+            a = synthetic_actions(game, n, t)
+            g.step(a, auto_reset=True); o.step(a, auto_reset=True)
+            if t in (0, 129, 259):
+                for c in (1, 3, 4):
+                    assert np.array_equal(g.render(c), o.render(c)), (game, n, t, c)
+        assert np.array_equal(g.render_env(n - 1, 3), o.render_env(n - 1, 3))
+"""
+    _run_sub(body, {"TBX_RENDER_SPLIT": split, "TBX_BRK_SPLIT": split})
+
+
+@pytest.mark.gpu
+def test_mixed_batch_config5_share_on_three_streams(hip_lib, oracle_lib):
+    """BASELINE config 5, one GPU's share: Breakout + Amidar + SpaceInvaders, 10 922 envs each, stepped with in-kernel
+    actions by GLOBAL env index and rendered on three HIP streams -- equal to three oracle engines fed the same rule:
+    per-step outputs (through the packed gather record), full states of a sample, frames of a sample."""
+    from toybox_amd import hip
+    from toybox_amd.parallel import MixedBatch, unpack_records
+    games, per, steps, off = ["breakout", "amidar", "space_invaders"], 10922, 150, 32768
+    old = os.environ.get("TBX_ORACLE_THREADS")
+    os.environ["TBX_ORACLE_THREADS"] = str(min(16, os.cpu_count() or 1))
+    try:
+        mb = MixedBatch(games, per, engine_factory=lambda g, n: Engine(g, n, lib=hip_lib), global_offset=off)
+        ref = MixedBatch(games, per, engine_factory=lambda g, n: Engine(g, n, lib=oracle_lib), global_offset=off)
+    finally:
+        if old is None:
+            os.environ.pop("TBX_ORACLE_THREADS")
+        else:
+            os.environ["TBX_ORACLE_THREADS"] = old
+    streams = [hip.Stream() for _ in games]
+    mb.attach_streams([s.ptr for s in streams])
+    rec = np.empty(per, np.uint64)
+    n_done = 0
+    for t in range(steps):
+        mb.step_synthetic(1337, t)
+        mb.render_device(3)
+        ref.step_synthetic(1337, t)
+        if t % 10 == 9 or t == steps - 1:
+            for s in streams:
+                s.synchronize()
+            for ge, oe in zip(mb.engines, ref.engines):
+                p, nbytes = ge.device_buffer(_abi.BUF_PACKED)
+                assert nbytes == 8 * per
+                hip.memcpy_dtoh(rec, p, nbytes)
+                q, _ = oe.device_buffer(_abi.BUF_PACKED)
+                want = np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_uint64)), (per,))
+                assert np.array_equal(rec, want), (ge.game, t)
+                n_done += int(unpack_records(rec)[1].sum())
+    for s in streams:
+        s.synchronize()
+    sample = list(range(0, per, 97)) + [per - 1]
+    one = None
+    for ge, oe in zip(mb.engines, ref.engines):
+        for x, y in zip(ge.scalars(), oe.scalars()):
+            assert np.array_equal(x, y), ge.game
+        _same_states(ge, oe, sample, ge.game)
+        # frames of the last render_device, straight out of the engine-owned frame batch
+        p, nbytes = ge.device_buffer(_abi.BUF_FRAME)
+        fb = ge.height * ge.width * 3
+        assert nbytes >= per * fb
+        one = np.empty(fb, np.uint8)
+        for i in sample[::8]:
+            hip.memcpy_dtoh(one, p + i * fb, fb)
+            assert np.array_equal(one.reshape(ge.height, ge.width, 3), oe.render_env(i, 3)), (ge.game, i)
+    assert mb.n_envs == 3 * per
+    mb.close()
+    ref.close()
+    for s in streams:
+        s.close()
+
+
+ALL_BUFS = ["BUF_REWARD", "BUF_DONE", "BUF_LIVES", "BUF_SCORE", "BUF_FRAME", "BUF_PACKED", "BUF_AGENT_OBS", "BUF_AGENT_REWARD",
+            "BUF_AGENT_DONE", "BUF_AGENT_EP_DONE", "BUF_AGENT_EP_RETURN", "BUF_AGENT_EP_LENGTH", "BUF_GATHERED"]
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def lib(request, oracle_lib):
+    if request.param == "oracle":
+        return oracle_lib
+    from toybox_amd import _lib
+    return _lib.load()
+
+
+def test_every_device_buffer_id(lib):
+    """Every TBX_BUF_* the header declares is addressable once its producer ran, with the documented size; agent buffers
+    before tbx_agent_init and unknown ids are TBX_E_INVALID on both libraries."""
+    import re
+    text = open(os.path.join(ROOT, "include", "toybox_amd.h")).read()
+    declared = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+TBX_(BUF_[A-Z_]+)\s+(\d+)", text)}
+    assert sorted(declared) == sorted(ALL_BUFS)
+    for name, v in declared.items():
+        assert getattr(_abi, name) == v
+    n = 5
+    e = Engine("breakout", n, lib=lib)
+    for name in ALL_BUFS:
+        if "AGENT" in name or name == "BUF_GATHERED":
+            with pytest.raises(ToyboxAmdError) as ei:
+                e.device_buffer(declared[name])
+            assert ei.value.code == _abi.E_INVALID, name
+    for bad in (-1, 13, 99):
+        with pytest.raises(ToyboxAmdError) as ei:
+            e.device_buffer(bad)
+        assert ei.value.code == _abi.E_INVALID
+    e.step([1] * n)
+    e.render_device(0, 3)
+    e.sync()
+    e.agent_init(skip=2, out_h=42, out_w=60, stack=3)
+    e.agent_reset()
+    e.agent_step([1] * n)
+    e.gather_init(1, 0, e.gather_unique_id(), records_per_rank=n + 3)
+    want = {"BUF_GATHERED": 8 * (n + 3),"BUF_REWARD": 4 * n, "BUF_DONE": n, "BUF_LIVES": 4 * n, "BUF_SCORE": 4 * n, "BUF_FRAME": n * 160 * 240 * 3,
+            "BUF_PACKED": 8 * n, "BUF_AGENT_OBS": n * 42 * 60 * 3, "BUF_AGENT_REWARD": 4 * n, "BUF_AGENT_DONE": n,
+            "BUF_AGENT_EP_DONE": n, "BUF_AGENT_EP_RETURN": 4 * n, "BUF_AGENT_EP_LENGTH": 4 * n}
+    seen = set()
+    for name in ALL_BUFS:
+        p, b = e.device_buffer(declared[name])
+        assert p and b == want[name], (name, p, b)
+        seen.add(p)
+    assert len(seen) == len(ALL_BUFS), "two buffer ids share an address"
+    e.close()
+
+
+@pytest.mark.gpu
+def test_device_buffer_contents_match_host_outputs(hip_lib):
+    """What the ids point at is what the host-pointer calls return."""
+    from toybox_amd import hip
+    n = 300
+    e = Engine("amidar", n, lib=hip_lib)
+    e.seed(3)
+    e.new_game()
+    for t in range(200):
+        out = e.step(synthetic_actions("amidar", n, t), auto_reset=True)
+    for which, host, dt in ((_abi.BUF_REWARD, out[0], np.int32), (_abi.BUF_DONE, out[1].astype(np.uint8), np.uint8),
+                            (_abi.BUF_LIVES, out[2], np.int32), (_abi.BUF_SCORE, out[3], np.int32)):
+        p, b = e.device_buffer(which)
+        got = np.empty(n, dt)
+        hip.memcpy_dtoh(got, p, b)
+        assert np.array_equal(got, host), which
+    e.agent_init(skip=4)
+    e.agent_reset()
+    for t in range(60):
+        obs, rew, done = e.agent_step(synthetic_actions("amidar", n, t))
+    ended, ret, length = e.agent_episodes()
+    for which, host in ((_abi.BUF_AGENT_OBS, obs), (_abi.BUF_AGENT_REWARD, rew), (_abi.BUF_AGENT_DONE, done.astype(np.uint8)),
+                        (_abi.BUF_AGENT_EP_DONE, ended.astype(np.uint8)), (_abi.BUF_AGENT_EP_RETURN, ret),
+                        (_abi.BUF_AGENT_EP_LENGTH, length)):
+        p, b = e.device_buffer(which)
+        got = np.empty(host.shape, host.dtype)
+        assert b == got.nbytes
+        hip.memcpy_dtoh(got, p, b)
+        assert np.array_equal(got, host), which
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar"])
+def test_null_stream_async_then_host_calls_are_ordered(game, hip_lib, oracle_lib):
+    """The "_device" entry points run on the caller's stream (here the NULL stream, the Python default), the host-pointer
+    ones on the engine's own non-blocking stream.  Calls on one handle take effect in program order without an explicit
+    tbx_sync in between (include/toybox_amd.h, conventions)."""
+    n = 20000
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=8)
+    for rnd in range(6):
+        for t in range(25):
+            g.step_synthetic(1337, 25 * rnd + t, auto_reset=True)                  # async, NULL stream
+            o.step(synthetic_actions(game, n, 25 * rnd + t, seed=1337), auto_reset=True)
+        a = synthetic_actions(game, n, rnd, seed=4)
+        rg, ro = g.step(a, auto_reset=True), o.step(a, auto_reset=True)           # engine stream, no sync in between
+        for x, y in zip(rg, ro):
+            assert np.array_equal(x, y), rnd
+        g.render_device(0, 1)                                                      # async again ...
+        _same_states(g, o, range(0, n, 1999), "round %d" % rnd)                    # ... then a host-pointer read
+
+
+def test_gather_one_rank_equals_local_records(lib):
+    """tbx_gather over a one-rank communicator (RCCL on the GPU box): the gathered block is the engine's own packed
+    records, padded to the slot width; a step queued after a gather does not overtake it; the max-reduction returns its
+    argument.  The N > 1 case differs only in the communicator (same code path, same kernels)."""
+    from toybox_amd.parallel import pack_records
+    n, width = 1000, 1024
+    e = Engine("breakout", n, lib=lib)
+    e.seed(77)
+    e.new_game()
+    with pytest.raises(ToyboxAmdError):
+        e.gather()
+    e.gather_init(1, 0, e.gather_unique_id(), records_per_rank=width)
+    with pytest.raises(ToyboxAmdError):
+        e.gather_init(1, 0, e.gather_unique_id(), records_per_rank=n - 1)
+    for t in range(120):
+        a = synthetic_actions("breakout", n, t)
+        reward, done, lives, _ = e.step(a, auto_reset=True)
+        e.gather()
+        if t % 3 == 0:
+            e.step_synthetic(5, t, auto_reset=True)       # queued right behind the gather: must not change what it sends
+        got = e.gather_host()
+        assert got.shape == (1, width)
+        assert np.array_equal(got[0, :n], pack_records(reward, done, lives)), t
+        assert not got[0, n:].any()
+    assert e.gather_reduce_max(3.25) == 3.25
+    e.close()
+
+
+@pytest.mark.gpu
+def test_gather_overlaps_with_render_and_keeps_parity(hip_lib, oracle_lib):
+    """The bench loop shape: step -> gather -> render on the caller's stream, 8 192 envs (the 8-GPU strong-scaling share):
+    gathered records and final states equal the oracle's."""
+    from toybox_amd import hip
+    from toybox_amd.parallel import unpack_records
+    n = 8192
+    g, o = _pair("breakout", n, hip_lib, oracle_lib)
+    g.gather_init(1, 0, g.gather_unique_id())
+    st = hip.Stream()
+    tot = np.zeros(n, np.int64)
+    want = np.zeros(n, np.int64)
+    for t in range(300):
+        g.step_synthetic(1337, t, auto_reset=True, stream=st.ptr)
+        g.gather(stream=st.ptr)
+        g.render_device(0, 3, stream=st.ptr)
+        r, d, l, _ = o.step(synthetic_actions("breakout", n, t), auto_reset=True)
+        if t % 7 == 0 or t > 290:
+            rr, dd, ll = unpack_records(g.gather_host()[0])
+            assert np.array_equal(rr, r) and np.array_equal(dd, d) and np.array_equal(ll, np.clip(l, 0, 255)), t
+    st.synchronize()
+    _same_states(g, o, range(0, n, 211), "end")
+    st.close()

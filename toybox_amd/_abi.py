@@ -21,6 +21,8 @@ STEP_AUTO_RESET = 1
 BUF_REWARD, BUF_DONE, BUF_LIVES, BUF_SCORE, BUF_FRAME, BUF_PACKED = 0, 1, 2, 3, 4, 5
 BUF_AGENT_OBS, BUF_AGENT_REWARD, BUF_AGENT_DONE = 6, 7, 8
 BUF_AGENT_EP_DONE, BUF_AGENT_EP_RETURN, BUF_AGENT_EP_LENGTH = 9, 10, 11
+BUF_GATHERED = 12
+GATHER_ID_BYTES = 128
 
 BRK_MAX_BALLS, BRK_COLS, BRK_MAX_ROWS, BRK_MAX_BRICKS, BRK_MAX_STARTS, BRK_MAX_SEGMENTS = 4, 18, 14, 256, 8, 16
 
@@ -240,6 +242,7 @@ PROTOTYPES = {
     "tbx_num_envs": (_i, [_vp]),
     "tbx_game": (_i, [_vp]),
     "tbx_seed": (_i, [_vp, _i, _u32]),
+    "tbx_seed_array": (_i, [_vp, _vp]),
     "tbx_get_sim_rng": (_i, [_vp, _i, _p(_u64)]),
     "tbx_set_sim_rng": (_i, [_vp, _i, _p(_u64)]),
     "tbx_new_game": (_i, [_vp, _vp]),
@@ -264,6 +267,12 @@ PROTOTYPES = {
     "tbx_agent_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "tbx_agent_step_device": (_i, [_vp, _vp, _vp]),
     "tbx_agent_step_synthetic": (_i, [_vp, _u64, _u64, _u64, _vp]),
+    "tbx_gather_unique_id": (_i, [_vp, _sz]),
+    "tbx_gather_init": (_i, [_vp, _i, _i, _i, _vp, _sz]),
+    "tbx_gather": (_i, [_vp, _vp, _vp]),
+    "tbx_gather_wait": (_i, [_vp, _vp]),
+    "tbx_gather_host": (_i, [_vp, _vp]),
+    "tbx_gather_reduce_max": (_i, [_vp, _p(C.c_double)]),
     "tbx_device_buffer": (_i, [_vp, _i, _p(_vp), _p(_sz)]),
     "tbx_sync": (_i, [_vp]),
 }

@@ -331,7 +331,8 @@ int tbx_agent_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_bytes
     case TBX_BUF_AGENT_DONE: p = a.done_out; b = N; break;
     case TBX_BUF_AGENT_EP_DONE: p = a.ep_done; b = N; break;
     case TBX_BUF_AGENT_EP_RETURN: p = a.ep_ret_out; b = N * sizeof(float); break;
-    default: p = a.ep_len_out; b = N * sizeof(int32_t); break;
+    case TBX_BUF_AGENT_EP_LENGTH: p = a.ep_len_out; b = N * sizeof(int32_t); break;
+    default: return e->fail(TBX_E_INVALID, "unknown buffer id");
     }
     *out_ptr = p;
     if (out_bytes) *out_bytes = b;
@@ -404,6 +405,7 @@ int tbx_agent_reset(tbx_engine* e, uint8_t* obs_host)
     if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
     AgentState& a = *e->agent;
     AHIP(hipSetDevice(e->device));
+    AHIP(tbx_use_stream(e, e->stream));
     const int n = e->n, tb = 256, gb = (n + tb - 1) / tb;
     const size_t N = (size_t)n;
     AHIP(hipMemsetAsync(a.ep_ret, 0, N * sizeof(int32_t), e->stream));
@@ -434,6 +436,7 @@ int tbx_agent_episodes(tbx_engine* e, uint8_t* ep_done_host, float* ep_return_ho
     if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
     AgentState& a = *e->agent;
     AHIP(hipSetDevice(e->device));
+    AHIP(tbx_use_stream(e, e->stream));
     const size_t N = (size_t)e->n;
     if (ep_done_host) AHIP(hipMemcpyAsync(ep_done_host, a.ep_done, N, hipMemcpyDeviceToHost, e->stream));
     if (ep_return_host) AHIP(hipMemcpyAsync(ep_return_host, a.ep_ret_out, N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
@@ -448,6 +451,8 @@ int tbx_agent_step_device(tbx_engine* e, const int32_t* actions_dev, void* strea
     if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
     if (!actions_dev) return e->fail(TBX_E_INVALID, "actions pointer is NULL");
     AHIP(hipSetDevice(e->device));
+    AHIP(tbx_use_stream(e, (hipStream_t)stream));
+    AHIP(tbx_gather_before_step(e, (hipStream_t)stream));
     ActionSource src{};
     src.actions = actions_dev;
     src.single_env = -1;
@@ -459,6 +464,8 @@ int tbx_agent_step_synthetic(tbx_engine* e, uint64_t action_seed, uint64_t t, ui
     if (!e) return TBX_E_INVALID;
     if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
     AHIP(hipSetDevice(e->device));
+    AHIP(tbx_use_stream(e, (hipStream_t)stream));
+    AHIP(tbx_gather_before_step(e, (hipStream_t)stream));
     ActionSource src{};
     src.seed = action_seed; src.t = t; src.env_offset = env_offset;
     src.single_env = -1;
@@ -472,6 +479,8 @@ int tbx_agent_step(tbx_engine* e, const int32_t* actions_host, float* reward_hos
     if (!actions_host) return e->fail(TBX_E_INVALID, "actions pointer is NULL");
     AgentState& a = *e->agent;
     AHIP(hipSetDevice(e->device));
+    AHIP(tbx_use_stream(e, e->stream));
+    AHIP(tbx_gather_before_step(e, e->stream));
     const size_t N = (size_t)e->n;
     AHIP(hipMemcpyAsync(e->actions, actions_host, N * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     ActionSource src{};

@@ -18,6 +18,12 @@ thread_local std::string g_create_error;
 #define CHECK_ENGINE(e) \
     if (!(e)) return TBX_E_INVALID
 
+}  // namespace
+
+void tbx_set_create_error(const std::string& msg) { g_create_error = msg; }
+
+namespace {
+
 int hip_fail(tbx_engine* e, const char* what, hipError_t err)
 {
     return e->fail(TBX_E_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(err));
@@ -149,6 +155,16 @@ __global__ void seed_kernel(uint64_t* sim_rng, int n, int env, uint32_t seed)
     sim_rng[(size_t)n + i] = s1;
 }
 
+__global__ void seed_array_kernel(uint64_t* sim_rng, int n, const uint32_t* seeds)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s0, s1;
+    tbx_seed_state(seeds[i], s0, s1);
+    sim_rng[i] = s0;
+    sim_rng[(size_t)n + i] = s1;
+}
+
 // step outputs into one block for the host: [reward N | lives N | score N | err 1 | done N bytes]
 __global__ void gather_outputs_kernel(const int32_t* reward, const int32_t* lives, const int32_t* score, const uint8_t* done,
                                       uint32_t* err_flag, int32_t* out, int n)
@@ -252,12 +268,15 @@ int tbx_destroy(tbx_engine* e)
     if (!e) return TBX_OK;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    tbx_gather_free(e);
     tbx_agent_free(e);
     if (e->ops) { e->ops->destroy(e); delete e->ops; }
     hipFree(e->sim_rng); hipFree(e->prev_score); hipFree(e->reward); hipFree(e->done);
     hipFree(e->lives_out); hipFree(e->score_out); hipFree(e->packed); hipFree(e->actions);
     hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame); hipFree(e->staging); hipFree(e->scal); hipFree(e->one_frame); hipFree(e->io_dev);
     if (e->io_host) hipHostFree(e->io_host);
+    if (e->scal_host) hipHostFree(e->scal_host);
+    if (e->order_ev) hipEventDestroy(e->order_ev);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return TBX_OK;
@@ -362,7 +381,23 @@ int tbx_seed(tbx_engine* e, int env, uint32_t seed)
     CHECK_ENGINE(e);
     if (env < -1 || env >= e->n) return e->fail(TBX_E_INVALID, "env index out of range");
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
     hipLaunchKernelGGL(seed_kernel, dim3((e->n + 255) / 256), dim3(256), 0, e->stream, e->sim_rng, e->n, env, seed);
+    EHIP(hipGetLastError());
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_seed_array(tbx_engine* e, const uint32_t* seeds_host)
+{
+    CHECK_ENGINE(e);
+    if (!seeds_host) return e->fail(TBX_E_INVALID, "seeds pointer is NULL");
+    EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
+    // e->actions is the engine's N-dword upload staging
+    EHIP(hipMemcpyAsync(e->actions, seeds_host, (size_t)e->n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(seed_array_kernel, dim3((e->n + 255) / 256), dim3(256), 0, e->stream, e->sim_rng, e->n,
+                       reinterpret_cast<const uint32_t*>(e->actions));
     EHIP(hipGetLastError());
     EHIP(hipStreamSynchronize(e->stream));
     return TBX_OK;
@@ -373,6 +408,7 @@ int tbx_get_sim_rng(tbx_engine* e, int env, uint64_t out[2])
     CHECK_ENGINE(e);
     if (env < 0 || env >= e->n || !out) return e->fail(TBX_E_INVALID, "env index out of range");
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
     EHIP(hipMemcpyAsync(&out[0], e->sim_rng + env, 8, hipMemcpyDeviceToHost, e->stream));
     EHIP(hipMemcpyAsync(&out[1], e->sim_rng + (size_t)e->n + env, 8, hipMemcpyDeviceToHost, e->stream));
     EHIP(hipStreamSynchronize(e->stream));
@@ -384,6 +420,7 @@ int tbx_set_sim_rng(tbx_engine* e, int env, const uint64_t st[2])
     CHECK_ENGINE(e);
     if (env < -1 || env >= e->n || !st) return e->fail(TBX_E_INVALID, "env index out of range");
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
     if (env == -1) {
         hipLaunchKernelGGL(fill_rng_kernel, dim3((e->n + 255) / 256), dim3(256), 0, e->stream, e->sim_rng, e->n, st[0], st[1]);
         EHIP(hipGetLastError());
@@ -399,6 +436,7 @@ int tbx_new_game(tbx_engine* e, const uint8_t* mask_host)
 {
     CHECK_ENGINE(e);
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
     const uint8_t* m = nullptr;
     if (mask_host) {
         EHIP(hipMemcpyAsync(e->mask, mask_host, (size_t)e->n, hipMemcpyHostToDevice, e->stream));
@@ -415,6 +453,8 @@ int tbx_step_device(tbx_engine* e, const int32_t* actions_dev, uint32_t flags, v
     CHECK_ENGINE(e);
     if (!actions_dev) return e->fail(TBX_E_INVALID, "actions pointer is NULL");
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, (hipStream_t)stream));
+    EHIP(tbx_gather_before_step(e, (hipStream_t)stream));
     ActionSource src{};
     src.actions = actions_dev;
     src.single_env = -1;
@@ -425,6 +465,8 @@ int tbx_step_synthetic(tbx_engine* e, uint64_t action_seed, uint64_t t, uint64_t
 {
     CHECK_ENGINE(e);
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, (hipStream_t)stream));
+    EHIP(tbx_gather_before_step(e, (hipStream_t)stream));
     ActionSource src{};
     src.actions = nullptr;
     src.seed = action_seed;
@@ -440,6 +482,8 @@ int tbx_step(tbx_engine* e, const int32_t* actions_host, uint32_t flags, int32_t
     CHECK_ENGINE(e);
     if (!actions_host) return e->fail(TBX_E_INVALID, "actions pointer is NULL");
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
+    EHIP(tbx_gather_before_step(e, e->stream));
     const size_t N = (size_t)e->n;
     const size_t out_bytes = (3 * N + 1) * sizeof(int32_t) + N;
     if (!e->io_dev) {
@@ -473,6 +517,8 @@ int tbx_apply_input(tbx_engine* e, int env, uint32_t buttons)
     CHECK_ENGINE(e);
     if (env < 0 || env >= e->n) return e->fail(TBX_E_INVALID, "env index out of range");
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
+    EHIP(tbx_gather_before_step(e, e->stream));
     ActionSource src{};
     src.single_env = env;
     src.single_buttons = buttons & 0x3Fu;
@@ -486,12 +532,14 @@ int tbx_get_scalars(tbx_engine* e, int32_t* score, int32_t* lives, int32_t* leve
 {
     CHECK_ENGINE(e);
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
     const size_t N = (size_t)e->n;
     int32_t* tmp = e->scal;
     int rc = e->ops->scalars(e, tmp, tmp + N, tmp + 2 * N, e->stream);
     if (rc) return rc;
-    std::vector<int32_t> host(3 * N);
-    EHIP(hipMemcpyAsync(host.data(), tmp, 3 * N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (!e->scal_host) EHIP(hipHostMalloc((void**)&e->scal_host, 3 * N * sizeof(int32_t), hipHostMallocDefault));
+    const int32_t* host = e->scal_host;
+    EHIP(hipMemcpyAsync(e->scal_host, tmp, 3 * N * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     EHIP(hipStreamSynchronize(e->stream));
     for (size_t i = 0; i < N; i++) {
         if (score) score[i] = host[i];
@@ -507,6 +555,7 @@ int tbx_render_device(tbx_engine* e, uint8_t* out_dev, int channels, void* strea
     CHECK_ENGINE(e);
     if (channels != 1 && channels != 3 && channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, (hipStream_t)stream));
     if (!out_dev) {
         const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
         int rc = ensure_frame(e, bytes);
@@ -535,6 +584,7 @@ int tbx_render_env(tbx_engine* e, int env, uint8_t* out_host, int channels)
     if (env < 0 || env >= e->n || !out_host) return e->fail(TBX_E_INVALID, "env index out of range");
     if (channels != 1 && channels != 3 && channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
     const size_t bytes = (size_t)e->ops->height() * e->ops->width() * channels;
     if (!e->one_frame) EHIP(hipMalloc((void**)&e->one_frame, (size_t)e->ops->height() * e->ops->width() * 4));
     int rc = e->ops->render(e, e->one_frame, channels, env, 1, e->stream);
@@ -562,6 +612,7 @@ int tbx_get_states(tbx_engine* e, int first_env, int count, void* pods, size_t r
     if (first_env < 0 || count < 1 || first_env + count > e->n || !pods) return e->fail(TBX_E_INVALID, "env range out of bounds");
     if (record_size != e->ops->state_size()) return e->fail(TBX_E_INVALID, "state record size mismatch");
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
     int rc = ensure_staging(e, record_size * (size_t)count);
     if (rc) return rc;
     rc = e->ops->pack_state(e, first_env, count, e->stream);
@@ -577,6 +628,7 @@ int tbx_set_states(tbx_engine* e, int first_env, int count, const void* pods, si
     if (first_env < 0 || count < 1 || first_env + count > e->n || !pods) return e->fail(TBX_E_INVALID, "env range out of bounds");
     if (record_size != e->ops->state_size()) return e->fail(TBX_E_INVALID, "state record size mismatch");
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
     int rc = ensure_staging(e, record_size * (size_t)count);
     if (rc) return rc;
     rc = e->ops->unpack_state(e, first_env, count, pods, e->stream);
@@ -617,11 +669,17 @@ int tbx_set_config(tbx_engine* e, const void* pod, size_t size)
     CHECK_ENGINE(e);
     if (!pod || size != e->ops->config_size()) return e->fail(TBX_E_INVALID, "config record size mismatch");
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
     EHIP(hipStreamSynchronize(e->stream));
     int rc = e->ops->set_config(e, pod);
     if (rc) return rc;
-    uint64_t r[2];
+    // `rand` as tbx_get_config reported it (env 0's words) means "not edited": the per-env simulator RNGs stay as they are,
+    // so a config edit does not collapse a seeded batch onto one stream.  Any other value is written to every env.
+    uint64_t r[2], cur[2];
     memcpy(r, pod, sizeof r);
+    rc = tbx_get_sim_rng(e, 0, cur);
+    if (rc) return rc;
+    if (r[0] == cur[0] && r[1] == cur[1]) return TBX_OK;
     return tbx_set_sim_rng(e, -1, r);
 }
 
@@ -656,7 +714,9 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     case TBX_BUF_FRAME: p = e->frame; b = e->frame_bytes; break;
     case TBX_BUF_PACKED: p = e->packed; b = N * 8; break;
     case TBX_BUF_AGENT_OBS: case TBX_BUF_AGENT_REWARD: case TBX_BUF_AGENT_DONE:
+    case TBX_BUF_AGENT_EP_DONE: case TBX_BUF_AGENT_EP_RETURN: case TBX_BUF_AGENT_EP_LENGTH:
         return tbx_agent_buffer(e, which, out_ptr, out_bytes);
+    case TBX_BUF_GATHERED: return tbx_gather_buffer(e, out_ptr, out_bytes);
     default: return e->fail(TBX_E_INVALID, "unknown buffer id");
     }
     *out_ptr = p;

@@ -176,6 +176,10 @@ struct tbx_engine {
     int game = -1, n = 0, device = 0;
     mutable std::string err;
     hipStream_t stream = nullptr;   // engine-owned stream used by the host-pointer entry points
+    // cross-stream ordering of everything queued through this handle (tbx_use_stream)
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
+    hipEvent_t order_ev = nullptr;
     // common device buffers (SoA over envs)
     uint64_t* sim_rng = nullptr;    // [2][N] simulator RNG
     int32_t* prev_score = nullptr;  // [N]
@@ -188,6 +192,7 @@ struct tbx_engine {
     uint8_t* mask = nullptr;        // [N] staging for new_game masks
     uint32_t* err_flag = nullptr;   // device word: bit0 = illegal action seen
     int32_t* scal = nullptr;        // [3][N] scratch of tbx_get_scalars
+    int32_t* scal_host = nullptr;   // pinned mirror of it
     uint8_t* one_frame = nullptr;   // H*W*4 scratch of tbx_render_env
     // host-pointer step path: one device block [reward | lives | score | err | done] gathered by a kernel and ONE copy
     // into pinned host memory (five pageable copies cost ~100 us per call); actions go up through the pinned block too
@@ -199,6 +204,7 @@ struct tbx_engine {
     size_t staging_bytes = 0;
     GameOps* ops = nullptr;
     struct AgentState* agent = nullptr;   // fused agent-side preprocessing (agent.hip), lazily created
+    struct GatherState* gather = nullptr; // multi-GPU record gather over RCCL (gather.hip), created by tbx_gather_init
 
     int fail(int code, const std::string& msg) const
     {
@@ -206,6 +212,27 @@ struct tbx_engine {
         return code;
     }
 };
+
+// Every entry point that queues work names the stream it is about to use.  When that differs from the stream the previous
+// entry point used (the "_device" forms run on the caller's stream -- including the NULL stream, which does not order itself
+// against the engine's non-blocking stream -- the host-pointer forms on the engine's own), the new stream first waits for an
+// event recorded on the old one, so calls on one handle take effect in program order whatever streams they name.
+inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s)
+{
+    if (e->has_last && e->last_stream != s) {
+        if (!e->order_ev) {
+            hipError_t r = hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming);
+            if (r != hipSuccess) return r;
+        }
+        hipError_t r = hipEventRecord(e->order_ev, e->last_stream);
+        if (r != hipSuccess) return r;
+        r = hipStreamWaitEvent(s, e->order_ev, 0);
+        if (r != hipSuccess) return r;
+    }
+    e->last_stream = s;
+    e->has_last = true;
+    return hipSuccess;
+}
 
 // per-game operations; all launches are asynchronous on `s`
 struct GameOps {
@@ -236,6 +263,10 @@ struct GameOps {
 };
 
 void tbx_agent_free(tbx_engine* e);
+void tbx_gather_free(tbx_engine* e);
+hipError_t tbx_gather_before_step(tbx_engine* e, hipStream_t s);   // a step must not overwrite records a queued gather still reads
+void tbx_set_create_error(const std::string& msg);                 // text behind tbx_last_error(NULL)
+int tbx_gather_buffer(tbx_engine* e, void** out_ptr, size_t* out_bytes);
 GameOps* tbx_make_breakout_ops();
 GameOps* tbx_make_si_ops();
 GameOps* tbx_make_amidar_ops();

@@ -71,6 +71,13 @@ class Engine:
     def seed(self, seed, env=-1):
         self._check(self._lib.tbx_seed(self._h, int(env), int(seed) & 0xFFFFFFFF))
 
+    def seed_array(self, seeds):
+        """env i gets seeds[i] (one upload, one launch)."""
+        a = np.ascontiguousarray(seeds, dtype=np.uint32)
+        if a.shape != (self.n_envs,):
+            raise ValueError("seeds must have shape (%d,)" % self.n_envs)
+        self._check(self._lib.tbx_seed_array(self._h, _ptr(a)))
+
     def get_sim_rng(self, env=0):
         out = (C.c_uint64 * 2)()
         self._check(self._lib.tbx_get_sim_rng(self._h, int(env), out))
@@ -227,6 +234,39 @@ class Engine:
         p, b = C.c_void_p(), C.c_size_t()
         self._check(self._lib.tbx_device_buffer(self._h, int(which), C.byref(p), C.byref(b)))
         return (p.value or 0), b.value
+
+    # ------------------------------------------------------------------ multi-GPU record gather (RCCL behind the C-ABI)
+    def gather_unique_id(self):
+        """rank 0: bytes of a fresh communicator id, to be handed to every rank out of band."""
+        buf = (C.c_uint8 * _abi.GATHER_ID_BYTES)()
+        rc = self._lib.tbx_gather_unique_id(buf, _abi.GATHER_ID_BYTES)
+        if rc != _abi.OK:
+            msg = self._lib.tbx_last_error(None)
+            raise ToyboxAmdError(rc, msg.decode() if msg else "tbx_gather_unique_id failed")
+        return bytes(buf)
+
+    def gather_init(self, nranks, rank, unique_id, records_per_rank=None):
+        width = self.n_envs if records_per_rank is None else int(records_per_rank)
+        buf = (C.c_uint8 * _abi.GATHER_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._check(self._lib.tbx_gather_init(self._h, int(nranks), int(rank), width, buf, _abi.GATHER_ID_BYTES))
+        self._gather_shape = (int(nranks), width)
+
+    def gather(self, out_ptr=0, stream=0):
+        self._check(self._lib.tbx_gather(self._h, C.c_void_p(int(out_ptr)) if out_ptr else None, C.c_void_p(int(stream))))
+
+    def gather_wait(self, stream=0):
+        self._check(self._lib.tbx_gather_wait(self._h, C.c_void_p(int(stream))))
+
+    def gather_host(self):
+        """uint64[nranks, records_per_rank] of the last queued gather (blocks until it has finished)."""
+        out = np.empty(self._gather_shape, np.uint64)
+        self._check(self._lib.tbx_gather_host(self._h, _ptr(out)))
+        return out
+
+    def gather_reduce_max(self, value):
+        v = C.c_double(float(value))
+        self._check(self._lib.tbx_gather_reduce_max(self._h, C.byref(v)))
+        return v.value
 
     def sync(self):
         self._check(self._lib.tbx_sync(self._h))

@@ -69,12 +69,8 @@ class ToyboxVecEnv:
     def seed(self, seed):
         """env i gets the reference's per-env derivation (cmd_util.py:31: seed + rank), each pushed through
         ToyboxBaseEnv.seed's hash (envs/atari/base.py:84-98); returns [[seed1, seed2], ...]."""
-        out = []
-        for i in range(self.num_envs):
-            seed1 = int(seed) + i
-            seed2 = hash_seed(seed1 + 1) % 2 ** 31
-            self.engine.seed(seed2, env=i)
-            out.append([seed1, seed2])
+        out = [[int(seed) + i, hash_seed(int(seed) + i + 1) % 2 ** 31] for i in range(self.num_envs)]
+        self.engine.seed_array([s2 for _, s2 in out])      # one upload + one launch, not N
         self.engine.new_game()
         return out
 
@@ -155,8 +151,7 @@ class ToyboxPreprocVecEnv:
         self.action_space = Discrete(len(self._action_set))
         self.observation_space = Box(0, 255, (size, size, stack), "uint8")
         if seed is not None:
-            for i in range(self.num_envs):
-                self.engine.seed(hash_seed(int(seed) + i + 1) % 2 ** 31, env=i)
+            self.engine.seed_array([hash_seed(int(seed) + i + 1) % 2 ** 31 for i in range(self.num_envs)])
         self.engine.agent_init(skip=skip, out_h=size, out_w=size, stack=stack, clip_reward=clip_rewards,
                                episodic_life=episode_life, fire_reset=fire_reset, noop_max=noop_max, noop_seed=noop_seed,
                                env_offset=env_offset)
