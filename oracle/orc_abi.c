@@ -3,7 +3,13 @@
  * (toybox_amd.Engine, Toybox, envs) over the oracle on a machine without a GPU, and lets the
  * GPU parity tests run the very same call sequence against both libraries.  "Device" pointers
  * are host pointers here and streams are ignored.  The product never loads this library. */
+#define _GNU_SOURCE
 #include "oracle.h"
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -29,8 +35,12 @@ struct tbx_engine {
     uint8_t *gray_a, *gray_b, *aobs, *afin, *adone;
     float* areward;
     /* record gather: the oracle restates the one-rank case only (there is no second process to talk to) */
-    int gather_on, gather_width;
+    int gather_on, gather_width, gather_ranks, gather_rank;
     uint64_t* gathered;
+    void* gshm;
+    size_t gshm_len;
+    char gshm_name[TBX_GATHER_ID_BYTES];
+    uint64_t gather_calls[2];
     /* Monitor / EpisodicLifeEnv state and this step's episode records */
     int32_t *ep_ret, *ep_len, *ep_index, *prev_lives, *ep_len_out;
     uint8_t* ep_done;
@@ -73,12 +83,14 @@ size_t tbx_config_size(int game)
 }
 
 static void agent_free(tbx_engine* e);
+static void gather_close(tbx_engine* e);
 
 int tbx_destroy(tbx_engine* e)
 {
     if (!e) return TBX_OK;
     free(e->cfg); free(e->states); free(e->sim); free(e->prev); free(e->reward); free(e->lives);
-    free(e->score); free(e->done); free(e->packed); free(e->frame); free(e->gathered);
+    free(e->score); free(e->done); free(e->packed); free(e->frame);
+    gather_close(e);
     agent_free(e);
     free(e);
     return TBX_OK;
@@ -499,7 +511,7 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
         break;
     case TBX_BUF_GATHERED:
         if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
-        p = e->gathered; b = (size_t)e->gather_width * 8;
+        p = e->gathered; b = (size_t)e->gather_ranks * e->gather_width * 8;
         break;
     default: return fail(e, TBX_E_INVALID, "unknown buffer id");
     }
@@ -508,14 +520,35 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     return TBX_OK;
 }
 
-/* ---------------------------------------------------------------- record gather (one rank) */
+/* ---------------------------------------------------------------- record gather
+ * The product does this with RCCL over xGMI (toybox_amd/csrc/gather.hip).  The checker restates the same calls over a POSIX
+ * shared-memory segment named by the "unique id", so that the multi-process CPU tests (world size 2) drive the real control
+ * flow -- id made by rank 0, handed over out of band, collective init, one all-gather per step, max-reduction -- through the
+ * same C-ABI.  Layout of the segment: seq[2][64] call counters (records / scalar), then two parity buffers of
+ * nranks * width records, then two parity buffers of nranks doubles. */
+
+typedef struct {
+    volatile uint64_t seq[3][64];   /* records, scalar, init barrier */
+} gshm_head_t;
+
+static size_t gshm_bytes(int nranks, int width) { return sizeof(gshm_head_t) + 2 * (size_t)nranks * width * 8 + 2 * (size_t)nranks * 8; }
 
 int tbx_gather_unique_id(void* id_out, size_t id_bytes)
 {
     if (!id_out || id_bytes != TBX_GATHER_ID_BYTES) return fail(NULL, TBX_E_INVALID, "id buffer must be TBX_GATHER_ID_BYTES long");
     memset(id_out, 0, id_bytes);
-    memcpy(id_out, "oracle-one-rank", 16);
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    snprintf((char*)id_out, id_bytes, "/tbx_orc_%ld_%lld_%ld", (long)getpid(), (long long)ts.tv_sec, (long)ts.tv_nsec);
     return TBX_OK;
+}
+
+static void gather_close(tbx_engine* e)
+{
+    if (e->gshm) munmap(e->gshm, e->gshm_len);
+    if (e->gather_on && e->gather_rank == 0 && e->gshm_name[0]) shm_unlink(e->gshm_name);
+    free(e->gathered);
+    e->gshm = NULL; e->gathered = NULL; e->gather_on = 0;
 }
 
 int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, const void* id, size_t id_bytes)
@@ -524,12 +557,45 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(e, TBX_E_INVALID, "gather: rank / nranks out of range");
     if (records_per_rank < e->n) return fail(e, TBX_E_INVALID, "gather: records_per_rank must be >= the engine's env count");
     if (!id || id_bytes != TBX_GATHER_ID_BYTES) return fail(e, TBX_E_INVALID, "gather: id must be TBX_GATHER_ID_BYTES long");
-    if (nranks != 1) return fail(e, TBX_E_UNSUPPORTED, "gather: the CPU checker restates the one-rank case only");
-    free(e->gathered);
-    e->gathered = (uint64_t*)calloc((size_t)records_per_rank, 8);
-    e->gather_width = records_per_rank;
+    if (nranks > 64) return fail(e, TBX_E_UNSUPPORTED, "gather: the CPU checker handles at most 64 ranks");
+    gather_close(e);
+    e->gather_ranks = nranks; e->gather_rank = rank; e->gather_width = records_per_rank;
+    e->gather_calls[0] = e->gather_calls[1] = 0;
+    e->gathered = (uint64_t*)calloc((size_t)nranks * records_per_rank, 8);
+    snprintf(e->gshm_name, sizeof e->gshm_name, "%s", (const char*)id);
+    e->gshm_len = gshm_bytes(nranks, records_per_rank);
+    if (nranks > 1) {
+        if (e->gshm_name[0] != '/') return fail(e, TBX_E_INVALID, "gather: not an id made by tbx_gather_unique_id");
+        int fd = shm_open(e->gshm_name, O_CREAT | O_RDWR, 0600);
+        if (fd < 0) return fail(e, TBX_E_NO_DEVICE, "gather: shm_open failed");
+        if (ftruncate(fd, (off_t)e->gshm_len) != 0) { close(fd); return fail(e, TBX_E_NO_DEVICE, "gather: ftruncate failed"); }
+        e->gshm = mmap(NULL, e->gshm_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);   /* a fresh segment reads as zeros */
+        close(fd);
+        if (e->gshm == MAP_FAILED) { e->gshm = NULL; return fail(e, TBX_E_NO_DEVICE, "gather: mmap failed"); }
+        /* collective like ncclCommInitRank: returns once every rank has attached */
+        gshm_head_t* h = (gshm_head_t*)e->gshm;
+        __atomic_store_n(&h->seq[2][rank], 1, __ATOMIC_RELEASE);
+        for (int r = 0; r < nranks; r++)
+            while (__atomic_load_n(&h->seq[2][r], __ATOMIC_ACQUIRE) < 1) sched_yield();
+    } else {
+        e->gshm = NULL;
+    }
     e->gather_on = 1;
     return TBX_OK;
+}
+
+/* one collective step over the segment: publish `bytes` at slot `rank` of parity buffer `base`, wait for every rank's
+ * counter to reach this call's number, copy all slots out */
+static void gshm_exchange(tbx_engine* e, int which, char* base, size_t slot, const void* mine, void* all)
+{
+    gshm_head_t* h = (gshm_head_t*)e->gshm;
+    const uint64_t call = ++e->gather_calls[which];
+    char* buf = base + (call & 1u) * (size_t)e->gather_ranks * slot;
+    memcpy(buf + (size_t)e->gather_rank * slot, mine, slot);
+    __atomic_store_n(&h->seq[which][e->gather_rank], call, __ATOMIC_RELEASE);
+    for (int r = 0; r < e->gather_ranks; r++)
+        while (__atomic_load_n(&h->seq[which][r], __ATOMIC_ACQUIRE) < call) sched_yield();
+    memcpy(all, buf, (size_t)e->gather_ranks * slot);
 }
 
 int tbx_gather(tbx_engine* e, uint64_t* out, void* stream)
@@ -537,9 +603,13 @@ int tbx_gather(tbx_engine* e, uint64_t* out, void* stream)
     (void)stream;
     if (!e) return TBX_E_INVALID;
     if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
+    const size_t slot = (size_t)e->gather_width * 8;
     uint64_t* dst = out ? out : e->gathered;
-    memset(dst, 0, (size_t)e->gather_width * 8);
-    memcpy(dst, e->packed, (size_t)e->n * 8);
+    uint64_t* mine = (uint64_t*)calloc(1, slot);
+    memcpy(mine, e->packed, (size_t)e->n * 8);
+    if (e->gather_ranks == 1) memcpy(dst, mine, slot);
+    else gshm_exchange(e, 0, (char*)e->gshm + sizeof(gshm_head_t), slot, mine, dst);
+    free(mine);
     return TBX_OK;
 }
 
@@ -556,7 +626,7 @@ int tbx_gather_host(tbx_engine* e, uint64_t* out)
     if (!e) return TBX_E_INVALID;
     if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
     if (!out) return fail(e, TBX_E_INVALID, "output pointer is NULL");
-    memcpy(out, e->gathered, (size_t)e->gather_width * 8);
+    memcpy(out, e->gathered, (size_t)e->gather_ranks * e->gather_width * 8);
     return TBX_OK;
 }
 
@@ -565,6 +635,12 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout)
     if (!e) return TBX_E_INVALID;
     if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
     if (!inout) return fail(e, TBX_E_INVALID, "value pointer is NULL");
+    if (e->gather_ranks > 1) {
+        double all[64];
+        char* base = (char*)e->gshm + sizeof(gshm_head_t) + 2 * (size_t)e->gather_ranks * e->gather_width * 8;
+        gshm_exchange(e, 1, base, sizeof(double), inout, all);
+        for (int r = 0; r < e->gather_ranks; r++) if (all[r] > *inout) *inout = all[r];
+    }
     return TBX_OK;
 }
 

@@ -1,5 +1,9 @@
-"""Multi-rank path on CPU: world_size-2 gloo run of toybox_amd.parallel over the oracle's ABI must equal a
-single-process run over the whole batch (results independent of the number of ranks)."""
+"""Multi-rank path on CPU, world size 2, over the oracle's ABI; both must equal a single-process run over the whole batch
+(results independent of the number of ranks):
+  * the product path: communicator id made by rank 0, handed over through toybox_amd.parallel.exchange_unique_id, collective
+    tbx_gather_init, one tbx_gather per step, tbx_gather_reduce_max (the oracle restates these calls over shared memory, the
+    HIP library over RCCL);
+  * the host fallback: the same records through a gloo process group."""
 import os
 import subprocess
 import sys
@@ -19,7 +23,7 @@ from toybox_amd.parallel import ShardedBatch
 from support import synthetic_actions
 lib = ctypes.CDLL(os.path.join({root!r}, "oracle", "liboracle.so")); _abi.bind(lib)
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
-sb = ShardedBatch(lambda n: Engine("breakout", n, lib=lib), {n}, dist=dist)
+sb = ShardedBatch(lambda n: Engine("breakout", n, lib=lib), {n}, rank=dist.get_rank(), world=2, host_dist=dist)
 tot = np.zeros({n}, np.int64); dn = np.zeros({n}, np.int64)
 for t in range({steps}):
     r, d, l = sb.step_host(synthetic_actions("breakout", {n}, t))
@@ -60,7 +64,7 @@ def test_two_rank_gloo_equals_single_process(oracle_lib, tmp_path):
     for p in procs:
         assert p.wait(timeout=300) == 0
     got = np.load(out)
-    sb = ShardedBatch(lambda k: Engine("breakout", k, lib=oracle_lib), n, dist=None)
+    sb = ShardedBatch(lambda k: Engine("breakout", k, lib=oracle_lib), n)
     tot = np.zeros(n, np.int64)
     dn = np.zeros(n, np.int64)
     for t in range(steps):
@@ -69,6 +73,69 @@ def test_two_rank_gloo_equals_single_process(oracle_lib, tmp_path):
         dn += d
     assert np.array_equal(got[0], tot) and np.array_equal(got[1], dn) and np.array_equal(got[2], l.astype(np.int64))
     assert tot.sum() > 0
+
+
+ABI_WORKER = r"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from toybox_amd import Engine, _abi
+from toybox_amd.parallel import ShardedBatch, world_from_env
+from support import synthetic_actions
+lib = ctypes.CDLL(os.path.join({root!r}, "oracle", "liboracle.so")); _abi.bind(lib)
+rank, world, _ = world_from_env()
+sb = ShardedBatch(lambda n: Engine({game!r}, n, lib=lib), {n}, rank=rank, world=world)
+tot = np.zeros({n}, np.int64); dn = np.zeros({n}, np.int64)
+for t in range({steps}):
+    if t % 2:
+        r, d, l = sb.step_host(synthetic_actions({game!r}, {n}, t))
+    else:                                   # device-resident form: in-kernel actions by global index + asynchronous gather
+        sb.step_synthetic(1337, t)
+        r, d, l = sb.gathered()
+    tot += r; dn += d
+slowest = sb.max_over_ranks(10.0 + rank)
+assert slowest == 10.0 + world - 1, slowest
+if rank == 0:
+    np.save({out!r}, np.stack([tot, dn, l.astype(np.int64)]))
+sb.close()
+"""
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("game,world", [("breakout", 2), ("amidar", 3)])
+def test_multi_rank_gather_through_the_abi_equals_single_process(game, world, oracle_lib, tmp_path):
+    """n = 37 does not divide: shards of unequal size, padded slots in the gathered layout."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from support import synthetic_actions
+    from toybox_amd import Engine
+    from toybox_amd.parallel import ShardedBatch
+    n, steps = 37, 400
+    out = str(tmp_path / "r0.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(ABI_WORKER.format(root=ROOT, n=n, steps=steps, out=out, game=game))
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="1", TBX_RDZV_DIR=str(tmp_path))
+    env.pop("TBX_RDZV_KEY", None)           # the default key (port + run id + parent pid) must do
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = np.load(out)
+    sb = ShardedBatch(lambda k: Engine(game, k, lib=oracle_lib), n)
+    tot = np.zeros(n, np.int64)
+    dn = np.zeros(n, np.int64)
+    for t in range(steps):
+        r, d, l = sb.step_host(synthetic_actions(game, n, t, seed=1337 if t % 2 == 0 else 1337))
+        tot += r
+        dn += d
+    assert np.array_equal(got[0], tot) and np.array_equal(got[1], dn) and np.array_equal(got[2], l.astype(np.int64))
+    assert not os.listdir(str(tmp_path)) or all(not f.startswith("tbx_rccl_id_") for f in os.listdir(str(tmp_path))), "id file left behind"
+
+
+def test_exchange_unique_id_times_out(tmp_path):
+    from toybox_amd.parallel import exchange_unique_id
+    with pytest.raises(TimeoutError):
+        exchange_unique_id(1, 2, lambda: b"", key="nobody", timeout=0.2, directory=str(tmp_path))
 
 
 def test_mixed_batch_matches_separate_engines(oracle_lib):
@@ -93,9 +160,6 @@ def test_mixed_batch_matches_separate_engines(oracle_lib):
         for k in range(per):
             assert bytes(me.get_state(k)) == bytes(se.get_state(k))
     assert mb.n_envs == 15 and mb.frame_bytes(3) == per * 3 * (160 * 240 + 250 * 160 + 210 * 320)
-
-
-import pytest  # noqa: E402
 
 
 @pytest.mark.gpu

@@ -1,13 +1,23 @@
 """Sharding of one env batch over the GPUs of a node: one process per GPU, contiguous env ranges,
 no data-path collective (envs never interact -- the reference runs one OS process per env,
 /root/reference/baselines/baselines/common/vec_env/subproc_vec_env.py:49-56).  The only exchange is
-the per-step gather of the packed {reward:i32, done:u8, lives:u8} record (8 bytes/env), carried by
-torch.distributed -- backend "nccl" is RCCL over xGMI on MI355X, "gloo" in the CPU tests.
+the per-step all-gather of the packed {reward:i32, done:u8, lives:u8} record (8 bytes/env), which
+lives BEHIND the C-ABI (tbx_gather_*, toybox_amd/csrc/gather.hip: RCCL over xGMI, resolved with
+dlopen) -- no PyTorch anywhere on this path.  The ranks only have to hand the 128-byte communicator
+id from rank 0 to the others; `exchange_unique_id` does that through a file, keyed so that any
+launcher that sets RANK / WORLD_SIZE / MASTER_PORT (torch.distributed.run, mpirun wrappers, bench.py's
+own spawner) works.
 
 Seeds and synthetic actions are functions of the GLOBAL env index, so results do not depend on
 the number of ranks.
 """
+import os
+import tempfile
+import time
+
 import numpy as np
+
+from . import _abi
 
 
 def shard_range(n_global, world_size, rank):
@@ -33,44 +43,137 @@ def pack_records(reward, done, lives):
     return r | (d << np.uint64(32)) | (l << np.uint64(40))
 
 
+# ---------------------------------------------------------------------- rendezvous (no torch)
+
+def world_from_env(env=None):
+    """(rank, world_size, local_rank) as any one-process-per-GPU launcher exports them."""
+    env = os.environ if env is None else env
+    return int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1")), int(env.get("LOCAL_RANK", env.get("RANK", "0")))
+
+
+def rendezvous_key(env=None):
+    """A name all ranks of ONE launch agree on and no other launch shares: an explicit TBX_RDZV_KEY, else the launcher's
+    master port + run id + the pid of the common parent (all workers of torch.distributed.run / of bench.py's spawner are
+    children of one process)."""
+    env = os.environ if env is None else env
+    if env.get("TBX_RDZV_KEY"):
+        return env["TBX_RDZV_KEY"]
+    return "%s_%s_%s_%d" % (env.get("MASTER_ADDR", "127.0.0.1").replace("/", "_"), env.get("MASTER_PORT", "0"),
+                            env.get("TORCHELASTIC_RUN_ID", "none").replace("/", "_"), os.getppid())
+
+
+def exchange_unique_id(rank, world, make_id, tag="", key=None, timeout=180.0, directory=None):
+    """Rank 0 calls make_id() (tbx_gather_unique_id) and publishes the bytes atomically as a file; the other ranks poll for
+    it.  One node, so the temp directory is shared.  Returns the id bytes on every rank.  The file is left for the
+    launcher's temp cleaning (rank 0 cannot know when the last rank has read it before the collective init returns);
+    `forget_unique_id` removes it afterwards."""
+    if world == 1:
+        return make_id()
+    path = _id_path(tag, key, directory)
+    if rank == 0:
+        data = make_id()
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, path)
+        return data
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with open(path, "rb") as f:
+                data = f.read()
+            if len(data) == _abi.GATHER_ID_BYTES:
+                return data
+        except FileNotFoundError:
+            pass
+        if time.monotonic() > deadline:
+            raise TimeoutError("rank %d: no communicator id at %s after %.0f s" % (rank, path, timeout))
+        time.sleep(0.01)
+
+
+def _id_path(tag, key, directory):
+    d = directory or os.environ.get("TBX_RDZV_DIR") or tempfile.gettempdir()
+    return os.path.join(d, "tbx_rccl_id_%s%s" % (key or rendezvous_key(), ("_" + tag) if tag else ""))
+
+
+def forget_unique_id(rank, tag="", key=None, directory=None):
+    if rank == 0:
+        try:
+            os.unlink(_id_path(tag, key, directory))
+        except OSError:
+            pass
+
+
+class HostGather:
+    """Fallback exchange when RCCL is not available: the 8-byte records are gathered on the host through a
+    torch.distributed process group with a CPU backend (gloo)."""
+
+    def __init__(self, dist, counts):
+        self.dist, self.counts = dist, counts
+        self.width = max(e - s for s, e in counts)
+
+    def all_gather(self, local_records):
+        import torch
+        buf = torch.zeros(self.width, dtype=torch.int64)
+        n = len(local_records)
+        buf[:n] = torch.from_numpy(np.asarray(local_records, dtype=np.uint64).view(np.int64).copy())
+        out = [torch.zeros(self.width, dtype=torch.int64) for _ in self.counts]
+        self.dist.all_gather(out, buf)
+        return np.stack([o.numpy().view(np.uint64) for o in out])
+
+
 class ShardedBatch:
     """One rank's shard of a global env batch plus the gather of per-step records.
 
-    engine_factory(n_local) -> Engine.  `dist` is torch.distributed (initialised by the caller) or
-    None for a single process.
+    engine_factory(n_local) -> Engine.  rank / world come from the launcher (world_from_env()).  The records travel through
+    the engine's own tbx_gather (RCCL on the GPU) unless `host_dist` names a torch.distributed module whose CPU process
+    group should carry them instead.
     """
 
-    def __init__(self, engine_factory, n_global, dist=None, seed_base=1234):
-        self.dist = dist
-        self.world = dist.get_world_size() if dist is not None else 1
-        self.rank = dist.get_rank() if dist is not None else 0
+    def __init__(self, engine_factory, n_global, rank=0, world=1, seed_base=1234, host_dist=None, rdzv_tag="", rdzv_key=None):
+        self.rank, self.world = int(rank), int(world)
         self.n_global = int(n_global)
         self.start, self.end = shard_range(n_global, self.world, self.rank)
         self.n_local = self.end - self.start
+        self.counts = [shard_range(n_global, self.world, r) for r in range(self.world)]
+        self.width = max(e - s for s, e in self.counts)
         self.engine = engine_factory(self.n_local)
         self.engine.seed(seed_base + self.start)      # env i gets seed_base + global index
         self.engine.new_game()
-        self.counts = [shard_range(n_global, self.world, r) for r in range(self.world)]
+        self.host = HostGather(host_dist, self.counts) if (host_dist is not None and self.world > 1) else None
+        if self.host is None:
+            uid = exchange_unique_id(self.rank, self.world, self.engine.gather_unique_id, tag=rdzv_tag, key=rdzv_key)
+            self.engine.gather_init(self.world, self.rank, uid, records_per_rank=self.width)   # collective
+            forget_unique_id(self.rank, tag=rdzv_tag, key=rdzv_key)
+
+    def _global_order(self, gathered):
+        """[world][width] -> records in global env order (drops the padding of short shards)."""
+        return np.concatenate([gathered[r, : e - s] for r, (s, e) in enumerate(self.counts)])
 
     def step_host(self, actions_global, auto_reset=True):
         """Steps the local shard with its slice of the global action vector; returns the gathered
         (reward, done, lives) over all ranks, in global env order."""
         a = np.asarray(actions_global, dtype=np.int32)[self.start:self.end]
         reward, done, lives, _ = self.engine.step(a, auto_reset=auto_reset)
-        local = pack_records(reward, done, lives)
-        return unpack_records(self.gather(local))
+        if self.host is not None:
+            return unpack_records(self._global_order(self.host.all_gather(pack_records(reward, done, lives))))
+        self.engine.gather()
+        return unpack_records(self._global_order(self.engine.gather_host()))
 
-    def gather(self, local_records):
-        if self.dist is None or self.world == 1:
-            return np.asarray(local_records, dtype=np.uint64)
-        import torch
-        width = max(e - s for s, e in self.counts)
-        buf = torch.zeros(width, dtype=torch.int64)
-        buf[: self.n_local] = torch.from_numpy(np.asarray(local_records, dtype=np.uint64).view(np.int64).copy())
-        out = [torch.zeros(width, dtype=torch.int64) for _ in range(self.world)]
-        self.dist.all_gather(out, buf)
-        parts = [o.numpy().view(np.uint64)[: e - s] for o, (s, e) in zip(out, self.counts)]
-        return np.concatenate(parts)
+    def step_synthetic(self, action_seed, t, auto_reset=True, stream=0):
+        """Device-resident form: in-kernel actions by global env index, then the asynchronous gather (results in
+        TBX_BUF_GATHERED; `gathered()` fetches them)."""
+        self.engine.step_synthetic(action_seed, t, env_offset=self.start, auto_reset=auto_reset, stream=stream)
+        self.engine.gather(stream=stream)
+
+    def gathered(self):
+        return unpack_records(self._global_order(self.engine.gather_host()))
+
+    def max_over_ranks(self, value):
+        return self.engine.gather_reduce_max(value) if self.host is None else value
+
+    def close(self):
+        self.engine.close()
 
 
 class MixedBatch:
@@ -90,6 +193,7 @@ class MixedBatch:
             e.new_game()
         self.n_envs = self.n_per_game * len(self.games)
         self.streams = None
+        self.gathering = False
 
     def attach_streams(self, streams):
         """One stream handle (int) per game; without it everything runs on the null stream."""
@@ -98,9 +202,19 @@ class MixedBatch:
     def _stream(self, i):
         return self.streams[i] if self.streams else 0
 
+    def gather_init(self, rank, world, rdzv_key=None):
+        """One communicator per game segment (every rank holds the same three segments)."""
+        for g, e in zip(self.games, self.engines):
+            uid = exchange_unique_id(rank, world, e.gather_unique_id, tag=g, key=rdzv_key)
+            e.gather_init(world, rank, uid)
+            forget_unique_id(rank, tag=g, key=rdzv_key)
+        self.gathering = True
+
     def step_synthetic(self, action_seed, t, auto_reset=True):
         for i, (e, off) in enumerate(zip(self.engines, self.offsets)):
             e.step_synthetic(action_seed, t, env_offset=off, auto_reset=auto_reset, stream=self._stream(i))
+            if self.gathering:
+                e.gather(stream=self._stream(i))
 
     def render_device(self, channels=3):
         for i, e in enumerate(self.engines):
