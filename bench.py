@@ -162,6 +162,22 @@ def cpu_config1(game, channels):
     return out
 
 
+class quiet_stdout:
+    """librccl prints a version banner on STDOUT when a communicator is created; this script's stdout carries exactly one JSON
+    line, so fd 1 points at stderr while a communicator is being set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 # ---------------------------------------------------------------------------------------------- timed regions
 
 class Region:
@@ -203,7 +219,8 @@ def bench_mixed(args, world, rank, local_rank):
     mb.attach_streams([s.ptr for s in streams])
     gather = world > 1 or args.with_gather
     if gather:
-        mb.gather_init(rank, world)
+        with quiet_stdout():
+            mb.gather_init(rank, world)
     C, K, Wm, R = args.channels, args.steps, args.warmup, args.repeats
     render = not args.no_render
     lead = mb.engines[0]
@@ -369,8 +386,9 @@ def main():
     render = not args.no_render
     gather = world > 1 or args.with_gather
     if gather:
-        uid = exchange_unique_id(rank, world, eng.gather_unique_id)
-        eng.gather_init(world, rank, uid, records_per_rank=width)       # collective (ncclCommInitRank)
+        with quiet_stdout():
+            uid = exchange_unique_id(rank, world, eng.gather_unique_id)
+            eng.gather_init(world, rank, uid, records_per_rank=width)   # collective (ncclCommInitRank)
         forget_unique_id(rank)
     stream = hip.Stream()
     sp = stream.ptr
@@ -510,7 +528,8 @@ def strong_share_probe(args, game, C, n_single):
     eng = Engine(game, n, device=0)
     eng.seed(SEED_BASE)
     eng.new_game()
-    eng.gather_init(1, 0, eng.gather_unique_id())
+    with quiet_stdout():
+        eng.gather_init(1, 0, eng.gather_unique_id())
     st = hip.Stream()
 
     def one(t):
