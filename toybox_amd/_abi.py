@@ -14,7 +14,7 @@ GAME_IDS = {"breakout": GAME_BREAKOUT, "amidar": GAME_AMIDAR, "space_invaders": 
 GAME_NAMES = {GAME_BREAKOUT: "breakout", GAME_AMIDAR: "amidar", GAME_SPACE_INVADERS: "space_invaders",
               GAME_GRIDWORLD: "gridworld"}
 
-OK, E_INVALID, E_NO_DEVICE, E_NOMEM, E_UNSUPPORTED, E_ACTION = 0, -1, -2, -3, -4, -5
+OK, E_INVALID, E_NO_DEVICE, E_NOMEM, E_UNSUPPORTED, E_ACTION, E_NEEDS_RESET = 0, -1, -2, -3, -4, -5, -6
 
 BTN_LEFT, BTN_RIGHT, BTN_UP, BTN_DOWN, BTN_BUTTON1, BTN_BUTTON2 = 1, 2, 4, 8, 16, 32
 STEP_AUTO_RESET = 1
@@ -262,6 +262,7 @@ PROTOTYPES = {
     "tbx_set_config": (_i, [_vp, _vp, _sz]),
     "tbx_query": (_i, [_vp, _i, _i, _p(C.c_int32), _i, _p(C.c_int32), _i]),
     "tbx_agent_init": (_i, [_vp, _p(AgentConfig)]),
+    "tbx_agent_set_noops": (_i, [_vp, _vp]),
     "tbx_agent_reset": (_i, [_vp, _vp]),
     "tbx_agent_episodes": (_i, [_vp, _vp, _vp, _vp]),
     "tbx_agent_step": (_i, [_vp, _vp, _vp, _vp, _vp]),

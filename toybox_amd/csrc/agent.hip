@@ -15,51 +15,66 @@
 struct AgentState {
     tbx_agent_config_t cfg{};
     int H = 0, W = 0;
-    uint8_t *gray_a = nullptr, *gray_b = nullptr, *obs = nullptr, *fin = nullptr, *done_out = nullptr;
+    uint8_t *gray_a = nullptr, *gray_b = nullptr;   // generic path only: full-resolution gray frames of the two buffer slots
+    uint8_t *obs = nullptr, *fin = nullptr, *done_out = nullptr;
     int32_t* racc = nullptr;
     float* reward_out = nullptr;
     AgentTaps *ty = nullptr, *tx = nullptr;
-    // reset-time wrappers + episode monitor
-    uint8_t *kind = nullptr, *ep_done = nullptr;
+    // per-env state of the wrapper classes: Monitor (return, length, needs_reset), EpisodicLifeEnv (lives, was_real_done),
+    // the episode counter behind the no-op count, MaxAndSkipEnv's buffer validity; and this step's outputs
+    uint8_t *kind = nullptr, *ep_done = nullptr, *was_real_done = nullptr, *needs_reset = nullptr;
+    uint8_t *mode = nullptr, *buf_valid = nullptr, *exec_flag = nullptr;
     int32_t *ep_ret = nullptr, *ep_len = nullptr, *ep_index = nullptr, *prev_lives = nullptr, *ep_len_out = nullptr;
+    int32_t* noop_override = nullptr;   // [N] or nullptr
     float* ep_ret_out = nullptr;
     int32_t* reset_list = nullptr;   // [N] envs the monitor kernel flagged for a reset
     int32_t* reset_count = nullptr;  // [2] their number, double-buffered by step parity
     int parity = 0;
-    bool force_generic = false;   // TBX_AGENT_GENERIC=1: always go through full-resolution gray frames
+    bool force_generic = false;   // TBX_AGENT_GENERIC=1: observations through full-resolution gray frames
 };
 
 namespace {
 
 constexpr int MAX_TAPS = 8;
 
-// after the `skip` frames: Monitor bookkeeping, EpisodicLifeEnv's done rule, clipped reward, and what kind of reset the
-// env needs (0 none, 1 life lost, 2 game over).  simple: no in-kernel reset follows, so a finished episode's counters
-// are cleared here.
+// after MaxAndSkipEnv.step: Monitor.step (bench/monitor.py:51-76), EpisodicLifeEnv.step (atari_wrappers.py:166-178),
+// ClipRewardEnv, and DummyVecEnv's decision to reset (dummy_vec_env.py:51-52): kind = 1 for envs that report done.
+// simple: no in-kernel reset procedure follows (custom-brick Breakout): a finished game is restarted by a plain new game and
+// Monitor.reset's bookkeeping happens here.
 __global__ void agent_monitor_kernel(const int32_t* racc, const uint8_t* fin, const int32_t* lives, int32_t* ep_ret, int32_t* ep_len,
-                                     int32_t* ep_index, int32_t* prev_lives, uint8_t* kind, uint8_t* ep_done, float* ep_ret_out,
-                                     int32_t* ep_len_out, float* reward_out, uint8_t* done_out, int32_t* list, int32_t* count,
-                                     int32_t* next_count, int episodic, int clip, int simple, int n)
+                                     int32_t* ep_index, int32_t* prev_lives, uint8_t* was_real_done, uint8_t* needs_reset, uint8_t* kind,
+                                     uint8_t* mode, uint8_t* ep_done, float* ep_ret_out, int32_t* ep_len_out, float* reward_out,
+                                     uint8_t* done_out, int32_t* list, int32_t* count, int32_t* next_count, uint32_t* err_flag,
+                                     int episodic, int clip, int simple, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *next_count = 0;                         // the other step parity's counter: its readers ran a step ago
     if (i >= n) return;
     const int r = racc[i];
-    int er = ep_ret[i] + r, el = ep_len[i] + 1;
     const bool real = fin[i] != 0;
-    const int l = lives[i];
-    const bool life_lost = episodic && !real && l < prev_lives[i] && l > 0;
-    kind[i] = real ? 2 : life_lost ? 1 : 0;
-    if (real || life_lost) list[atomicAdd(count, 1)] = i;  // order is irrelevant: the reset of one env touches nothing else
-    done_out[i] = (real || life_lost) ? 1 : 0;
-    reward_out[i] = clip ? (float)((r > 0) - (r < 0)) : (float)r;
-    ep_done[i] = real ? 1 : 0;
-    if (real) {
-        ep_ret_out[i] = (float)er; ep_len_out[i] = el;
-        if (simple) { er = 0; el = 0; ep_index[i] += 1; }
+    bool emitted = false;
+    int er = ep_ret[i], el = ep_len[i];
+    if (needs_reset[i]) atomicOr(err_flag, 2u);          // Monitor raises "Tried to step environment that needs reset"
+    else {
+        er += r; el += 1;
+        if (real) { emitted = true; needs_reset[i] = 1; }
     }
+    bool done = real;
+    const int l = lives[i];
+    if (episodic) {
+        was_real_done[i] = real ? 1 : 0;
+        if (l < prev_lives[i] && l > 0) done = true;
+        prev_lives[i] = l;
+    }
+    kind[i] = done ? 1 : 0;
+    mode[i] = (simple && done) ? 1 : 0;                  // a plain new game: the observation is its raw frame
+    if (done) list[atomicAdd(count, 1)] = i;             // order is irrelevant: the reset of one env touches nothing else
+    done_out[i] = done ? 1 : 0;
+    reward_out[i] = clip ? (float)((r > 0) - (r < 0)) : (float)r;
+    ep_done[i] = emitted ? 1 : 0;
+    if (emitted) { ep_ret_out[i] = (float)er; ep_len_out[i] = el; }
+    if (simple && real) { er = 0; el = 0; ep_index[i] += 1; needs_reset[i] = 0; }
     ep_ret[i] = er; ep_len[i] = el;
-    prev_lives[i] = l;
 }
 
 __global__ void agent_fill_u8_kernel(uint8_t* p, uint8_t v, int n)
@@ -74,18 +89,22 @@ __global__ void agent_fill_u8_kernel(uint8_t* p, uint8_t v, int n)
 // (a source row overlaps at most two output rows because out_h <= H).  A finished output row is normalised with a
 // multiply-shift reciprocal (exact for sums < 2^25) and rolled into the env's frame stack.
 template <int S>
-__global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
-                                                               const uint8_t* __restrict__ fin, const AgentTaps* __restrict__ tx,
-                                                               uint8_t* __restrict__ obs, int H, int W, int oh, int ow,
-                                                               uint64_t magic, int reset_mode, int n)
+__global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B, AgentWarpArgs wa, int n)
 {
+    const AgentTaps* __restrict__ tx = wa.tx;
+    uint8_t* __restrict__ obs = wa.obs;
+    const int H = wa.H, W = wa.W, oh = wa.oh, ow = wa.ow;
+    const uint64_t magic = wa.magic;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK][352];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
     if (env >= n) return;
     uint8_t* row = lds_all[wave];
-    const bool fresh = reset_mode || fin[env];          // the observation is the (warped) reset frame alone
+    // B holds slot B, or the live frame where the env's observation is a raw frame; A holds slot A
+    const ObsSel sel = agent_obs_sel(wa, env);
+    const bool use_a = !sel.none && (sel.two || sel.single == 1), use_b = !sel.none && (sel.two || sel.single != 1);
+    const bool fresh = sel.zero;                        // VecFrameStack: older slots become zero
     const uint8_t* fa = A + (size_t)env * H * W;
     const uint8_t* fb = B + (size_t)env * H * W;
     uint8_t* o = obs + (size_t)env * oh * ow * S;
@@ -108,8 +127,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
                 const int w4 = lane + 64 * q, sy = sy0 + p;
                 va[p][q] = 0u; vb[p][q] = 0u;
                 if (sy < H && w4 < words) {
-                    vb[p][q] = *reinterpret_cast<const uint32_t*>(fb + (size_t)sy * W + 4 * w4);
-                    if (!fresh) va[p][q] = *reinterpret_cast<const uint32_t*>(fa + (size_t)sy * W + 4 * w4);
+                    if (use_b) vb[p][q] = *reinterpret_cast<const uint32_t*>(fb + (size_t)sy * W + 4 * w4);
+                    if (use_a) va[p][q] = *reinterpret_cast<const uint32_t*>(fa + (size_t)sy * W + 4 * w4);
                 }
             }
     };
@@ -133,7 +152,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const int w4 = lane + 64 * q;
-                if (w4 < words) reinterpret_cast<uint32_t*>(row)[w4] = fresh ? cur_b[p][q] : bytemax4(cur_a[p][q], cur_b[p][q]);
+                if (w4 < words) reinterpret_cast<uint32_t*>(row)[w4] = bytemax4(cur_a[p][q], cur_b[p][q]);   // an unused slot reads 0
             }
             __builtin_amdgcn_wave_barrier();
             // vertical split of this source row (extent oh in refined units) over output rows oy and oy+1 (extent H each)
@@ -197,15 +216,23 @@ std::vector<AgentTaps> make_taps(int src, int out)
     return t;
 }
 
+AgentWarpArgs warp_args(tbx_engine* e, int reset_mode)
+{
+    AgentState& a = *e->agent;
+    AgentWarpArgs w;
+    w.zero = a.done_out; w.mode = a.mode; w.valid = a.buf_valid; w.tx = a.tx; w.obs = a.obs;
+    w.H = a.H; w.W = a.W; w.oh = a.cfg.out_h; w.ow = a.cfg.out_w; w.stack = a.cfg.stack;
+    w.reset_mode = reset_mode;
+    w.magic = (1ull << 42) / (uint64_t)(a.H * a.W) + 1ull;   // exact for numerators < 2^42 / area >= 2^25
+    return w;
+}
+
 int launch_warp(tbx_engine* e, int reset_mode, hipStream_t s)
 {
     AgentState& a = *e->agent;
     const dim3 grid((e->n + TBX_WAVES_PER_BLOCK - 1) / TBX_WAVES_PER_BLOCK), block(TBX_BLOCK);
-    const uint8_t* A = a.cfg.skip >= 2 ? a.gray_a : a.gray_b;
-    const uint64_t magic = (1ull << 42) / (uint64_t)(a.H * a.W) + 1ull;   // exact for numerators < 2^42 / area >= 2^25
-    // fresh = the env was reset during this agent step (game over, or a lost life in episodic-life mode)
-#define WARP(S) hipLaunchKernelGGL(agent_warp_kernel<S>, grid, block, 0, s, A, a.gray_b, a.done_out, a.tx, a.obs, \
-                                   a.H, a.W, a.cfg.out_h, a.cfg.out_w, magic, reset_mode, e->n)
+    const AgentWarpArgs w = warp_args(e, reset_mode);
+#define WARP(S) hipLaunchKernelGGL(agent_warp_kernel<S>, grid, block, 0, s, a.gray_a, a.gray_b, w, e->n)
     switch (a.cfg.stack) {
     case 1: WARP(1); break;
     case 2: WARP(2); break;
@@ -217,19 +244,7 @@ int launch_warp(tbx_engine* e, int reset_mode, hipStream_t s)
     return TBX_OK;
 }
 
-AgentWarpArgs warp_args(tbx_engine* e, int reset_mode)
-{
-    AgentState& a = *e->agent;
-    AgentWarpArgs w;
-    w.fin = a.done_out; w.tx = a.tx; w.obs = a.obs;
-    w.H = a.H; w.W = a.W; w.oh = a.cfg.out_h; w.ow = a.cfg.out_w; w.stack = a.cfg.stack;
-    w.reset_mode = reset_mode;
-    w.two_frames = a.cfg.skip >= 2;
-    w.magic = (1ull << 42) / (uint64_t)(a.H * a.W) + 1ull;
-    return w;
-}
-
-bool needs_reset_kernel(const AgentState& a) { return a.cfg.episodic_life || a.cfg.fire_reset || a.cfg.noop_max > 0; }
+bool wants_wrappers(const AgentState& a) { return a.cfg.episodic_life || a.cfg.fire_reset || a.cfg.noop_max > 0 || a.noop_override; }
 
 AgentResetArgs reset_args(tbx_engine* e)
 {
@@ -239,24 +254,26 @@ AgentResetArgs reset_args(tbx_engine* e)
     r.list = nullptr; r.count = nullptr;
     r.skip = a.cfg.skip; r.episodic_life = a.cfg.episodic_life; r.fire_reset = a.cfg.fire_reset; r.noop_max = a.cfg.noop_max;
     r.noop_seed = a.cfg.noop_seed; r.env_offset = a.cfg.env_offset;
+    r.noop_override = a.noop_override;
     // action #1 and #2 of the game's (sorted) legal action set: FIRE and the next one (atari_wrappers.py:146-149)
     r.fire_buttons = tbx_ale_buttons(tbx_legal_action(e->game, 1));
     r.third_buttons = tbx_ale_buttons(tbx_legal_action(e->game, 2));
     r.ep_ret = a.ep_ret; r.ep_len = a.ep_len; r.ep_index = a.ep_index; r.prev_lives = a.prev_lives;
+    r.was_real_done = a.was_real_done; r.needs_reset = a.needs_reset;
     r.ep_done = a.ep_done; r.ep_ret_out = a.ep_ret_out; r.ep_len_out = a.ep_len_out;
+    r.mode = a.mode; r.buf_valid = a.buf_valid; r.err_flag = e->err_flag;
     return r;
 }
 
-// frame B (and the observation) once the sub-frames and the resets are done
+// the observation, once the frames and the resets of the agent step are done
 int observe(tbx_engine* e, int reset_mode, hipStream_t s)
 {
     AgentState& a = *e->agent;
-    if (e->ops->agent_fused() && !a.force_generic) {
-        int rc = e->ops->agent_snapshot(e, 1, s);
-        if (rc) return rc;
-        return e->ops->agent_warp(e, warp_args(e, reset_mode), s);
-    }
-    int rc = e->ops->render(e, a.gray_b, 1, 0, e->n, s);
+    if (e->ops->agent_fused() && !a.force_generic) return e->ops->agent_warp(e, warp_args(e, reset_mode), s);
+    // generic path: the two buffer slots (and the live frame where a reset returned one) as full-resolution gray frames
+    int rc = e->ops->render_from(e, 1, nullptr, a.gray_a, 1, s);
+    if (rc) return rc;
+    rc = e->ops->render_from(e, 2, a.mode, a.gray_b, 1, s);
     if (rc) return rc;
     return launch_warp(e, reset_mode, s);
 }
@@ -266,42 +283,59 @@ int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s)
 {
     AgentState& a = *e->agent;
     const int n = e->n, tb = 256, gb = (n + tb - 1) / tb;
-    const bool fused = e->ops->agent_fused() && !a.force_generic;
-    const bool in_kernel_reset = needs_reset_kernel(a);
-    // the step kernels sum reward / latch done themselves (tbx_accumulate), so the skip loop is one launch per frame
+    const bool in_kernel_reset = e->ops->agent_reset_supported();
+    if (!in_kernel_reset && wants_wrappers(a))
+        return e->fail(TBX_E_UNSUPPORTED, "agent: episodic-life / fire-reset / no-op-reset are not available for this engine state");
+    // MaxAndSkipEnv.step: the step kernels sum reward / latch done themselves (tbx_accumulate) and write the buffer slots
     src.acc_reward = a.racc; src.acc_done = a.fin;
-    if (e->ops->multi_frame_step() && fused) {
-        // the whole skip loop in one launch: state stays in registers, frame A's snapshot is stored on the way
-        src.acc_first = 1;
-        src.frames = a.cfg.skip;
-        src.snapshot_after = a.cfg.skip >= 2 ? a.cfg.skip - 1 : 0;
+    src.snap_a_after = a.cfg.skip >= 2 ? a.cfg.skip - 1 : 0;
+    src.snap_b_after = a.cfg.skip;
+    src.buf_valid = a.buf_valid;
+    if (e->ops->multi_frame_step()) {
+        // the whole skip loop in one launch: state stays in registers, the slots are stored on the way
+        src.frames = a.cfg.skip; src.frame0 = 0; src.exec_flag = nullptr;
         int rc = e->ops->step(e, src, 0, s);
         if (rc) return rc;
     } else {
         src.frames = 1;
-        src.snapshot_after = 0;
+        src.exec_flag = a.exec_flag;
         for (int i = 0; i < a.cfg.skip; i++) {
-            src.acc_first = i == 0;
+            src.frame0 = i;
             int rc = e->ops->step(e, src, 0, s);
             if (rc) return rc;
-            if (i == a.cfg.skip - 2) {
-                rc = fused ? e->ops->agent_snapshot(e, 0, s) : e->ops->render(e, a.gray_a, 1, 0, n, s);
-                if (rc) return rc;
-            }
+            if (i + 1 == src.snap_a_after) rc = e->ops->agent_snapshot(e, 0, a.exec_flag, a.buf_valid, s);
+            if (rc) return rc;
+            if (i + 1 == src.snap_b_after) rc = e->ops->agent_snapshot(e, 1, a.exec_flag, a.buf_valid, s);
+            if (rc) return rc;
         }
     }
     hipLaunchKernelGGL(agent_monitor_kernel, dim3(gb), dim3(tb), 0, s, a.racc, a.fin, e->lives_out, a.ep_ret, a.ep_len, a.ep_index,
-                       a.prev_lives, a.kind, a.ep_done, a.ep_ret_out, a.ep_len_out, a.reward_out, a.done_out,
-                       a.reset_list, a.reset_count + a.parity, a.reset_count + (a.parity ^ 1),
+                       a.prev_lives, a.was_real_done, a.needs_reset, a.kind, a.mode, a.ep_done, a.ep_ret_out, a.ep_len_out,
+                       a.reward_out, a.done_out, a.reset_list, a.reset_count + a.parity, a.reset_count + (a.parity ^ 1), e->err_flag,
                        a.cfg.episodic_life, a.cfg.clip_reward, in_kernel_reset ? 0 : 1, n);
     AHIP(hipGetLastError());
-    // VecEnv auto-reset: plain new game of the finished envs, or the reset-time wrappers run in-kernel
+    // DummyVecEnv: obs = env.reset() for the envs that reported done -- the whole reset path of the stack in-kernel, or (engines
+    // without one) a plain new game
     AgentResetArgs ra = reset_args(e);
     ra.list = a.reset_list; ra.count = a.reset_count + a.parity;
     a.parity ^= 1;
     int rc = in_kernel_reset ? e->ops->agent_reset_envs(e, ra, s) : e->ops->new_game(e, a.fin, s);
     if (rc) return rc;
     return observe(e, 0, s);
+}
+
+// the error word of the device: bit 0 illegal action id, bit 1 a step on an env whose Monitor needed a reset
+int report_flags(tbx_engine* e)
+{
+    uint32_t f = 0;
+    AHIP(hipMemcpy(&f, e->err_flag, sizeof f, hipMemcpyDeviceToHost));
+    if (f) {
+        AHIP(hipMemset(e->err_flag, 0, sizeof f));
+        if (f & 2u)
+            return e->fail(TBX_E_NEEDS_RESET, "an env was stepped after its game ended inside EpisodicLifeEnv's no-op step (bench.Monitor raises here)");
+        return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
+    }
+    return TBX_OK;
 }
 
 }  // namespace
@@ -312,6 +346,8 @@ void tbx_agent_free(tbx_engine* e)
     AgentState* a = e->agent;
     hipFree(a->gray_a); hipFree(a->gray_b); hipFree(a->obs); hipFree(a->fin); hipFree(a->done_out);
     hipFree(a->racc); hipFree(a->reward_out); hipFree(a->ty); hipFree(a->tx);
+    hipFree(a->was_real_done); hipFree(a->needs_reset); hipFree(a->mode); hipFree(a->buf_valid); hipFree(a->exec_flag);
+    hipFree(a->noop_override);
     hipFree(a->kind); hipFree(a->ep_done); hipFree(a->ep_ret); hipFree(a->ep_len); hipFree(a->ep_index);
     hipFree(a->prev_lives); hipFree(a->ep_len_out); hipFree(a->ep_ret_out); hipFree(a->reset_list); hipFree(a->reset_count);
     delete a;
@@ -360,8 +396,24 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     a->H = H; a->W = W;
     if (const char* v = getenv("TBX_AGENT_GENERIC")) a->force_generic = atoi(v) != 0;
     const size_t N = (size_t)e->n;
-    AHIP(hipMalloc((void**)&a->gray_a, N * H * W));
-    AHIP(hipMalloc((void**)&a->gray_b, N * H * W));
+    if (a->force_generic || !e->ops->agent_fused()) {
+        AHIP(hipMalloc((void**)&a->gray_a, N * H * W));
+        AHIP(hipMalloc((void**)&a->gray_b, N * H * W));
+    }
+    AHIP(hipMalloc((void**)&a->was_real_done, N));
+    AHIP(hipMalloc((void**)&a->needs_reset, N));
+    AHIP(hipMalloc((void**)&a->mode, N));
+    AHIP(hipMalloc((void**)&a->buf_valid, N));
+    AHIP(hipMalloc((void**)&a->exec_flag, N));
+    AHIP(hipMemset(a->was_real_done, 1, N));         // EpisodicLifeEnv.__init__: was_real_done = True
+    AHIP(hipMemset(a->needs_reset, 0, N));
+    AHIP(hipMemset(a->mode, 0, N));
+    AHIP(hipMemset(a->buf_valid, 0, N));             // MaxAndSkipEnv.__init__: _obs_buffer = np.zeros
+    AHIP(hipMemset(a->exec_flag, 0, N));
+    {
+        int rc = e->ops->agent_prepare(e);
+        if (rc) return rc;
+    }
     AHIP(hipMalloc((void**)&a->obs, N * cfg->out_h * cfg->out_w * cfg->stack));
     AHIP(hipMalloc((void**)&a->fin, N));
     AHIP(hipMalloc((void**)&a->done_out, N));
@@ -399,6 +451,26 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     return TBX_OK;
 }
 
+int tbx_agent_set_noops(tbx_engine* e, const int32_t* counts_host)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    AgentState& a = *e->agent;
+    AHIP(hipSetDevice(e->device));
+    AHIP(tbx_use_stream(e, e->stream));
+    AHIP(hipStreamSynchronize(e->stream));
+    if (!counts_host) {
+        hipFree(a.noop_override);
+        a.noop_override = nullptr;
+        return TBX_OK;
+    }
+    if (!e->ops->agent_reset_supported())
+        return e->fail(TBX_E_UNSUPPORTED, "agent: no-op resets are not available for this engine state");
+    if (!a.noop_override) AHIP(hipMalloc((void**)&a.noop_override, (size_t)e->n * sizeof(int32_t)));
+    AHIP(hipMemcpy(a.noop_override, counts_host, (size_t)e->n * sizeof(int32_t), hipMemcpyHostToDevice));
+    return TBX_OK;
+}
+
 int tbx_agent_reset(tbx_engine* e, uint8_t* obs_host)
 {
     if (!e) return TBX_E_INVALID;
@@ -408,20 +480,24 @@ int tbx_agent_reset(tbx_engine* e, uint8_t* obs_host)
     AHIP(tbx_use_stream(e, e->stream));
     const int n = e->n, tb = 256, gb = (n + tb - 1) / tb;
     const size_t N = (size_t)n;
-    AHIP(hipMemsetAsync(a.ep_ret, 0, N * sizeof(int32_t), e->stream));
-    AHIP(hipMemsetAsync(a.ep_len, 0, N * sizeof(int32_t), e->stream));
-    AHIP(hipMemsetAsync(a.ep_done, 0, N, e->stream));
     int rc;
-    if (needs_reset_kernel(a)) {
-        // env.reset() of the whole wrapper stack == the game-over reset path for every env
-        hipLaunchKernelGGL(agent_fill_u8_kernel, dim3(gb), dim3(tb), 0, e->stream, a.kind, (uint8_t)2, n);
+    if (e->ops->agent_reset_supported()) {
+        // reset() of every env's wrapper stack (AgentResetProc::run)
+        hipLaunchKernelGGL(agent_fill_u8_kernel, dim3(gb), dim3(tb), 0, e->stream, a.kind, (uint8_t)1, n);
         rc = e->ops->agent_reset_envs(e, reset_args(e), e->stream);
         if (rc) return rc;
-        AHIP(hipMemsetAsync(a.ep_done, 0, N, e->stream));
     } else {
+        if (wants_wrappers(a))
+            return e->fail(TBX_E_UNSUPPORTED, "agent: episodic-life / fire-reset / no-op-reset are not available for this engine state");
+        // Monitor.reset + a plain new game; the observation is its raw frame
+        AHIP(hipMemsetAsync(a.ep_ret, 0, N * sizeof(int32_t), e->stream));
+        AHIP(hipMemsetAsync(a.ep_len, 0, N * sizeof(int32_t), e->stream));
+        AHIP(hipMemsetAsync(a.needs_reset, 0, N, e->stream));
+        hipLaunchKernelGGL(agent_fill_u8_kernel, dim3(gb), dim3(tb), 0, e->stream, a.mode, (uint8_t)1, n);
         rc = e->ops->new_game(e, nullptr, e->stream);
         if (rc) return rc;
     }
+    AHIP(hipMemsetAsync(a.ep_done, 0, N, e->stream));   // records of games that ended inside the reset procedure are not reported here
     rc = observe(e, 1, e->stream);
     if (rc) return rc;
     if (obs_host)
@@ -492,14 +568,8 @@ int tbx_agent_step(tbx_engine* e, const int32_t* actions_host, float* reward_hos
     if (done_host) AHIP(hipMemcpyAsync(done_host, a.done_out, N, hipMemcpyDeviceToHost, e->stream));
     if (obs_host) AHIP(hipMemcpyAsync(obs_host, a.obs, N * a.cfg.out_h * a.cfg.out_w * a.cfg.stack, hipMemcpyDeviceToHost, e->stream));
     AHIP(hipStreamSynchronize(e->stream));
-    // an illegal action id is reported like tbx_step does
-    uint32_t f = 0;
-    AHIP(hipMemcpy(&f, e->err_flag, sizeof f, hipMemcpyDeviceToHost));
-    if (f) {
-        AHIP(hipMemset(e->err_flag, 0, sizeof f));
-        return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
-    }
-    return TBX_OK;
+    // an illegal action id is reported like tbx_step does; so is a step that bench.Monitor would have refused
+    return report_flags(e);
 }
 
 }  // extern "C"

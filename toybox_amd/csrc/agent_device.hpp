@@ -10,15 +10,39 @@ struct AgentTaps {          // area-resize taps of one output row / column
 };
 
 
-// what a game's fused observation kernel needs from the agent layer
+// what a game's observation kernel needs from the agent layer
 struct AgentWarpArgs {
-    const uint8_t* fin;        // [N] the env was reset during this agent step (observation = reset frame alone)
+    const uint8_t* zero;       // [N] the env reported done in this agent step: VecFrameStack zeroes its older slots
+    const uint8_t* mode;       // [N] 1: the observation is the raw frame of the live state (what a reset without FireResetEnv
+                               //     returns after a new game); 0: the max over the two-frame buffer (MaxAndSkipEnv.step)
+    const uint8_t* valid;      // [N] bit 0 / 1: buffer slot A / B has been written since construction (else a zero frame)
     const AgentTaps* tx;       // [out_w] column taps
     uint8_t* obs;              // [N][out_h][out_w][stack]
-    int H, W, oh, ow, stack, reset_mode;
-    int two_frames;            // skip >= 2: the observation is max(frame A, frame B); otherwise frame B alone
+    int H, W, oh, ow, stack;
+    int reset_mode;            // venv.reset(): every stack starts from zeros
     uint64_t magic;            // floor(2^42 / (H*W)) + 1
 };
+
+// which frames make up this env's observation (wave-uniform)
+struct ObsSel {
+    bool zero;    // zero the older stack slots
+    bool none;    // both buffer slots still hold np.zeros: the observation is black
+    bool two;     // max(slot A, slot B)
+    int single;   // !two: the one source -- 0 live state, 1 slot A, 2 slot B
+};
+
+__device__ __forceinline__ ObsSel agent_obs_sel(const AgentWarpArgs& a, int env)
+{
+    ObsSel s;
+    const uint32_t mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.mode[env]);
+    const uint32_t valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.valid[env]);
+    s.zero = a.reset_mode || __builtin_amdgcn_readfirstlane((int)a.zero[env]) != 0;
+    const bool raw = (mode & 1u) != 0;
+    s.none = !raw && (valid & 3u) == 0u;
+    s.two = !raw && (valid & 3u) == 3u;
+    s.single = raw ? 0 : (valid & 2u) ? 2 : 1;
+    return s;
+}
 
 // per-byte max of two packed dwords: even and odd bytes as two packed-u16 maxima (v_pk_max_u16)
 __device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
@@ -101,88 +125,149 @@ __device__ __forceinline__ void stack_commit(const uint8_t* vals, uint8_t* o, in
 
 // what a game's agent-reset kernel needs (see tbx_agent_config_t)
 struct AgentResetArgs {
-    const uint8_t* kind;        // [N] 0 = nothing to do, 1 = a life was lost (episodic life), 2 = game over
+    const uint8_t* kind;        // [N] 0 = nothing to do, else the env reported done and DummyVecEnv calls reset()
     // the flagged envs as a compact list (built by the monitor kernel) so that heavy wave-per-env reset kernels launch a
     // small persistent grid instead of N waves that exit at once; nullptr: every env is flagged (tbx_agent_reset)
     const int32_t* list;
     const int32_t* count;
     int skip, episodic_life, fire_reset, noop_max;
     uint64_t noop_seed, env_offset;
+    const int32_t* noop_override;            // [N] or nullptr: NoopResetEnv.override_num_noops (> 0 overrides)
     uint32_t fire_buttons, third_buttons;   // buttons of action #1 and action #2 of the game's action set
-    int32_t *ep_ret, *ep_len, *ep_index, *prev_lives;   // [N] monitor / episodic-life state
+    int32_t *ep_ret, *ep_len, *ep_index, *prev_lives;   // [N] Monitor.rewards (sum, count), episode counter, EpisodicLifeEnv.lives
+    uint8_t *was_real_done, *needs_reset;   // [N] EpisodicLifeEnv.was_real_done, Monitor.needs_reset
     uint8_t* ep_done;           // [N] episode records of this agent step
     float* ep_ret_out;
     int32_t* ep_len_out;
+    uint8_t *mode, *buf_valid;  // [N] see AgentWarpArgs
+    uint32_t* err_flag;         // bit 1: an env was stepped although Monitor.needs_reset (TBX_E_NEEDS_RESET)
 };
 
 struct AgentMonitor {
     int32_t ep_ret, ep_len, ep_index, prev_lives;
-    bool emitted;
+    bool was_real_done, needs_reset;
+    bool emitted, stale;
     int32_t out_ret, out_len;
 };
 
-// The reset path of the wrapper stack NoopResetEnv -> MaxAndSkipEnv -> Monitor -> EpisodicLifeEnv -> FireResetEnv
-// (baselines/baselines/common/atari_wrappers.py:108-191, bench/monitor.py:51-76), run in-kernel for one env.
-// Env provides step(buttons), new_game(), lives(), score(); every call is wave-uniform for wave-per-env games.
+__device__ __forceinline__ AgentMonitor agent_monitor_load(const AgentResetArgs& r, int env)
+{
+    AgentMonitor m;
+    m.ep_ret = r.ep_ret[env]; m.ep_len = r.ep_len[env]; m.ep_index = r.ep_index[env]; m.prev_lives = r.prev_lives[env];
+    m.was_real_done = r.was_real_done[env] != 0; m.needs_reset = r.needs_reset[env] != 0;
+    m.emitted = false; m.stale = false; m.out_ret = 0; m.out_len = 0;
+    return m;
+}
+
+// (one lane / thread per env calls this)
+__device__ __forceinline__ void agent_monitor_store(const AgentResetArgs& r, int env, const AgentMonitor& m, uint32_t valid, bool obs_raw)
+{
+    r.ep_ret[env] = m.ep_ret; r.ep_len[env] = m.ep_len; r.ep_index[env] = m.ep_index; r.prev_lives[env] = m.prev_lives;
+    r.was_real_done[env] = m.was_real_done ? 1 : 0; r.needs_reset[env] = m.needs_reset ? 1 : 0;
+    if (m.emitted) { r.ep_done[env] = 1; r.ep_ret_out[env] = (float)m.out_ret; r.ep_len_out[env] = m.out_len; }
+    if (m.stale) atomicOr(r.err_flag, 2u);
+    r.buf_valid[env] = (uint8_t)valid;
+    r.mode[env] = obs_raw ? 1 : 0;
+}
+
+// reset() of one env's wrapper stack, class by class (baselines/baselines/common/atari_wrappers.py, bench/monitor.py):
+//   FireResetEnv.reset :144-152 -> EpisodicLifeEnv.reset / .step :166-191 -> Monitor.reset / .step (monitor.py:36-76)
+//   -> MaxAndSkipEnv.step :201-216 / .reset :218-219 -> NoopResetEnv.reset :117-132 -> ToyboxBaseEnv.step / .reset
+// run in-kernel for one env.  Env provides step(buttons), new_game(), lives(), score(), snapshot(slot); every call is
+// wave-uniform for wave-per-env games.  `prev` is ToyboxBaseEnv.score, `valid` the written slots of the frame buffer,
+// `obs_raw` what the last wrapper call returned: a raw frame of the live state (true) or the buffer max (false).
 template <class Env>
 struct AgentResetProc {
     Env& env;
     const AgentResetArgs& r;
     AgentMonitor& m;
     uint64_t env_global;
-    bool was_real_done;
+    int32_t prev;
+    uint32_t valid;
+    int32_t noop_override;
+    bool obs_raw;
 
-    __device__ __forceinline__ void inner_real_reset()      // Monitor.reset + NoopResetEnv.reset
+    __device__ __forceinline__ bool base_step(uint32_t buttons, int& reward)   // ToyboxBaseEnv.step
     {
-        m.ep_ret = 0; m.ep_len = 0; m.ep_index += 1;
+        env.step(buttons);
+        const int sc = env.score();
+        reward = sc - prev > 0 ? sc - prev : 0;
+        prev = sc;
+        return env.lives() <= 0;
+    }
+    __device__ __forceinline__ void base_reset()                               // ToyboxBaseEnv.reset
+    {
         env.new_game();
-        if (r.noop_max > 0) {
-            const int k = 1 + (int)(tbx_splitmix64(r.noop_seed ^ (env_global << 32) ^ (uint64_t)(uint32_t)m.ep_index) % (uint64_t)r.noop_max);
-            for (int j = 0; j < k; j++) {
-                env.step(0u);
-                if (env.lives() <= 0) env.new_game();
-            }
+        prev = env.score();
+    }
+    __device__ __forceinline__ void noop_reset()                               // NoopResetEnv.reset
+    {
+        base_reset();
+        obs_raw = true;
+        int k = 0;
+        if (noop_override > 0) k = noop_override;
+        else if (r.noop_max > 0)
+            k = 1 + (int)(tbx_splitmix64(r.noop_seed ^ (env_global << 32) ^ (uint64_t)(uint32_t)m.ep_index) % (uint64_t)r.noop_max);
+        for (int j = 0; j < k; j++) {
+            int rew;
+            if (base_step(0u, rew)) base_reset();
         }
     }
-    __device__ __forceinline__ bool mstep(uint32_t buttons)  // MaxAndSkipEnv.step under Monitor
+    __device__ __forceinline__ bool skip_step(uint32_t buttons, int& total)    // MaxAndSkipEnv.step
     {
-        int rsum = 0;
         bool done = false;
-        for (int i = 0; i < r.skip && !done; i++) {
-            const int s0 = env.score();
-            env.step(buttons);
-            const int dsc = env.score() - s0;
-            rsum += dsc > 0 ? dsc : 0;
-            if (env.lives() <= 0) done = true;
+        total = 0;
+        for (int i = 0; i < r.skip; i++) {
+            int rew;
+            done = base_step(buttons, rew);
+            if (i == r.skip - 2) { env.snapshot(0); valid |= 1u; }
+            if (i == r.skip - 1) { env.snapshot(1); valid |= 2u; }
+            total += rew;
+            if (done) break;
         }
-        m.ep_ret += rsum; m.ep_len += 1;
-        if (done) { m.emitted = true; m.out_ret = m.ep_ret; m.out_len = m.ep_len; }
+        obs_raw = false;
         return done;
     }
-    __device__ __forceinline__ void elife_reset()            // EpisodicLifeEnv.reset
+    __device__ __forceinline__ bool monitor_step(uint32_t buttons)            // Monitor.step
     {
-        if (was_real_done || !r.episodic_life) inner_real_reset();
-        else if (mstep(0u)) inner_real_reset();              // no-op step to advance from the lost-life state
-                                                             // (a game that ends inside it starts over: own rule,
-                                                             // the wrapper stack would raise on its next step)
-        m.prev_lives = env.lives();
+        const bool stale = m.needs_reset;
+        int total;
+        const bool done = skip_step(buttons, total);
+        if (stale) { m.stale = true; return done; }                            // Monitor raises here: reported, and carried on
+        m.ep_ret += total; m.ep_len += 1;
+        if (done) { m.needs_reset = true; m.emitted = true; m.out_ret = m.ep_ret; m.out_len = m.ep_len; }
+        return done;
     }
-    __device__ __forceinline__ bool elife_step(uint32_t buttons)   // EpisodicLifeEnv.step
+    __device__ __forceinline__ void monitor_reset()                            // Monitor.reset (allow_early_resets)
     {
-        bool d = mstep(buttons);
-        was_real_done = d;
+        m.ep_ret = 0; m.ep_len = 0; m.needs_reset = false; m.ep_index += 1;
+        noop_reset();
+    }
+    __device__ __forceinline__ bool episodic_step(uint32_t buttons)           // EpisodicLifeEnv.step
+    {
+        bool d = monitor_step(buttons);
+        if (!r.episodic_life) return d;
+        m.was_real_done = d;
         const int l = env.lives();
-        if (r.episodic_life && l < m.prev_lives && l > 0) d = true;
+        if (l < m.prev_lives && l > 0) d = true;
         m.prev_lives = l;
         return d;
     }
-    __device__ __forceinline__ void run(int kind)            // FireResetEnv.reset (or the reset below it)
+    __device__ __forceinline__ void episodic_reset()                           // EpisodicLifeEnv.reset
     {
-        was_real_done = kind == 2;
-        elife_reset();
+        if (!r.episodic_life) { monitor_reset(); return; }
+        if (m.was_real_done) monitor_reset();
+        else monitor_step(0u);                   // no-op step to advance from the lost-life state; its `done` is ignored
+        m.prev_lives = env.lives();
+    }
+    __device__ __forceinline__ void run()                                      // FireResetEnv.reset (or the reset below it)
+    {
+        episodic_reset();
         if (r.fire_reset) {
-            if (elife_step(r.fire_buttons)) elife_reset();
-            if (elife_step(r.third_buttons)) elife_reset();
+            if (episodic_step(r.fire_buttons)) episodic_reset();
+            const bool d = episodic_step(r.third_buttons);
+            if (d) episodic_reset();
+            obs_raw = false;                     // the observation is the one step(2) returned, whatever followed
         }
     }
 };
@@ -217,15 +302,22 @@ struct AgentFusedLds {
 };
 
 template <int S, class P>
-__device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P::Dev& dA, const typename P::Dev& dB, const AgentWarpArgs& a,
-                                                 int env, int lane, AgentFusedLds<P>& L)
+__device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P::Dev& dLive, const typename P::Dev& dA, const typename P::Dev& dB,
+                                                 const AgentWarpArgs& a, int env, int lane, AgentFusedLds<P>& L)
 {
     constexpr int W = P::W, H = P::H, NG = P::NG, NCLS = P::NCLS;
     static_assert(W % 4 == 0 && W / 4 <= 64 * NG && H <= 256, "painter geometry");
-    const bool fresh = a.reset_mode || a.fin[env];                     // the observation is the (warped) reset frame alone
-    const bool two = a.two_frames && !fresh;
+    const ObsSel sel = agent_obs_sel(a, env);
+    uint8_t* o = a.obs + (size_t)env * a.oh * a.ow * S;
+    if (sel.none) {                                                    // max over two zero frames
+        for (int i = lane; i < a.oh * a.ow; i += 64) L.vals[i] = 0;
+        stack_commit<S>(L.vals, o, a.oh * a.ow, lane, sel.zero);
+        return;
+    }
+    const bool two = sel.two;
     uint8_t* row = L.row;
-    pb.setup(dB, env, lane, &L.cls[1][0][0]);
+    // painter B is the one that is always set up: slot B, or the single source of a one-frame observation
+    pb.setup(sel.single == 0 ? dLive : sel.single == 1 ? dA : dB, env, lane, &L.cls[1][0][0]);
     uint64_t need[4], need_a[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
     for (int k = 0; k < 4; k++) need[k] = pb.busy[k];
@@ -247,7 +339,6 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
             need[k] |= need_a[k];
         }
     }
-    uint8_t* o = a.obs + (size_t)env * a.oh * a.ow * S;
     const uint32_t half = (uint32_t)(H * W) / 2u;
     const ColTaps c0 = load_col(a.tx, lane, a.ow), c1 = load_col(a.tx, lane + 64, a.ow);
     const bool on0 = lane < a.ow, on1 = lane + 64 < a.ow;
@@ -328,5 +419,5 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
     }
     // the read-modify-write of the frame stack in one sweep with many loads in flight (a dependent load -> store per
     // output row, even fetched a row ahead, left this kernel waiting on HBM latency 84 times per env)
-    stack_commit<S>(L.vals, o, a.oh * a.ow, lane, fresh);
+    stack_commit<S>(L.vals, o, a.oh * a.ow, lane, sel.zero);
 }

@@ -565,13 +565,15 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_new_game_kernel(AmiDev d, const
     }
 }
 
-__global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, AmiDev shadow, ActionSource src, uint32_t flags, int first_env, int count)
+__global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, AmiDev slot_a, AmiDev slot_b, ActionSource src, uint32_t flags, int first_env, int count)
 {
     const int lane = threadIdx.x & 63;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     if (rel >= count) return;
     const int env = first_env + rel;
     const size_t N = (size_t)d.n;
+    if (src.exec_flag && lane == 0) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
+    if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
 
     uint32_t buttons;
     if (src.single_env >= 0) {
@@ -612,7 +614,13 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, AmiDev sh
             prev = s.f[A_SCORE];
         }
         if (lane == 0) tbx_accumulate(src, env, rew, is_done, fr);
-        if (fr + 1 == src.snapshot_after && shadow.sc) ami_store(shadow, env, lane, s);  // frame A of the agent observation
+        if (src.buf_valid) {                                 // MaxAndSkipEnv's frame buffer: slot A after frame skip-2, B after skip-1
+            const uint32_t slots = tbx_snap_slots(src, fr);
+            if (slots & 1u) ami_store(slot_a, env, lane, s);
+            if (slots & 2u) ami_store(slot_b, env, lane, s);
+            if (slots && lane == 0) src.buf_valid[env] |= (uint8_t)slots;
+            if (is_done) break;                              // ... and its loop ends with the game
+        }
     }
     ami_store(d, env, lane, s);
     if (lane == 0) {
@@ -632,38 +640,41 @@ struct AmiAgentEnv {
     int lane;
     AmiRegs& s;
     Rng& sim;
+    const AmiDev& slot_a;
+    const AmiDev& slot_b;
+    int env;
+    __device__ __forceinline__ void snapshot(int slot) { ami_store(slot ? slot_b : slot_a, env, lane, s); }
     __device__ __forceinline__ void step(uint32_t buttons) { ami_step(c, lane, buttons, s); }
     __device__ __forceinline__ void new_game() { ami_new_game(c, lane, sim, s); }
     __device__ __forceinline__ int lives() const { return wave_uniform(s.f[A_LIVES]); }
     __device__ __forceinline__ int score() const { return wave_uniform(s.f[A_SCORE]); }
 };
 
-__global__ __launch_bounds__(TBX_BLOCK) void ami_agent_reset_kernel(AmiDev d, AgentResetArgs r)
+__global__ __launch_bounds__(TBX_BLOCK) void ami_agent_reset_kernel(AmiDev d, AmiDev slot_a, AmiDev slot_b, AgentResetArgs r)
 {
     const int lane = threadIdx.x & 63;
     // a persistent grid walks the compact list of flagged envs (or every env when there is no list)
     const int wave_id = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6)), n_waves = gridDim.x * TBX_WAVES_PER_BLOCK;
     const int total = r.list ? wave_uniform(*r.count) : d.n;
     for (int it = wave_id; it < total; it += n_waves) {
-    const int env = r.list ? wave_uniform(r.list[it]) : it;
-    const int kind = wave_uniform((int)r.kind[env]);
-    if (kind == 0) continue;
-    const size_t N = (size_t)d.n;
-    AmiRegs s;
-    ami_load(d, env, lane, s);
-    Rng sim;
-    sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
-    AgentMonitor m{r.ep_ret[env], r.ep_len[env], r.ep_index[env], r.prev_lives[env], false, 0, 0};
-    AmiAgentEnv ops{*d.tab, lane, s, sim};
-    AgentResetProc<AmiAgentEnv> proc{ops, r, m, r.env_offset + (uint64_t)env, false};
-    proc.run(kind);
-    ami_store(d, env, lane, s);
-    if (lane == 0) {
-        d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
-        d.prev_score[env] = s.f[A_SCORE];
-        r.ep_ret[env] = m.ep_ret; r.ep_len[env] = m.ep_len; r.ep_index[env] = m.ep_index; r.prev_lives[env] = m.prev_lives;
-        if (m.emitted) { r.ep_done[env] = 1; r.ep_ret_out[env] = (float)m.out_ret; r.ep_len_out[env] = m.out_len; }
-    }
+        const int env = r.list ? wave_uniform(r.list[it]) : it;
+        if (wave_uniform((int)r.kind[env]) == 0) continue;
+        const size_t N = (size_t)d.n;
+        AmiRegs s;
+        ami_load(d, env, lane, s);
+        Rng sim;
+        sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
+        AgentMonitor m = agent_monitor_load(r, env);
+        AmiAgentEnv ops{*d.tab, lane, s, sim, slot_a, slot_b, env};
+        AgentResetProc<AmiAgentEnv> proc{ops, r, m, r.env_offset + (uint64_t)env, wave_uniform(d.prev_score[env]),
+                                         (uint32_t)wave_uniform((int)r.buf_valid[env]), r.noop_override ? wave_uniform(r.noop_override[env]) : 0, false};
+        proc.run();
+        ami_store(d, env, lane, s);
+        if (lane == 0) {
+            d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
+            d.prev_score[env] = proc.prev;
+            agent_monitor_store(r, env, m, proc.valid, proc.obs_raw);
+        }
     }
 }
 
@@ -873,7 +884,8 @@ struct AmiGrayPainter : AmiPainter<1> {
 // One wave rasterises one env; AMI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte stores, background-only
 // units are stored directly.
 template <int C>
-__global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t* out, int first_env, int count, int split)
+__global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t* out, int first_env, int count, int split, AmiDev d_alt,
+                                                               const uint8_t* __restrict__ pick_alt)
 {
     constexpr int W = TBX_AMI_W, H = TBX_AMI_H;
     using Stager = RowStager<C, W, AMI_UNIT_ROWS>;
@@ -887,7 +899,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
     const int env = first_env + rel;
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
     AmiPainter<C> p;
-    p.setup(d, env, lane, lds_mask[wave]);
+    // (agent layer, generic path: flagged envs are painted from d_alt)
+    p.setup((pick_alt && wave_uniform((int)pick_alt[env])) ? d_alt : d, env, lane, lds_mask[wave]);
 
     uint8_t* frame = out + (size_t)rel * H * W * C;
     constexpr int NUNITS = H / AMI_UNIT_ROWS;
@@ -917,7 +930,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
 // max(frame A, frame B) -> gray -> area warp -> frame stack without the two full-resolution gray frames ever reaching
 // HBM: agent_fused_wave (agent_device.hpp) with two AmiGrayPainters in one wave per env.
 template <int S>
-__global__ __launch_bounds__(TBX_BLOCK) void ami_agent_warp_kernel(AmiDev dA, AmiDev dB, AgentWarpArgs a, int n)
+__global__ __launch_bounds__(TBX_BLOCK) void ami_agent_warp_kernel(AmiDev dLive, AmiDev dA, AmiDev dB, AgentWarpArgs a, int n)
 {
     __shared__ AgentFusedLds<AmiGrayPainter> lds[TBX_WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
@@ -925,7 +938,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_agent_warp_kernel(AmiDev dA, Am
     const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
     if (env >= n) return;
     AmiGrayPainter pa, pb;
-    agent_fused_wave<S, AmiGrayPainter>(pa, pb, dA, dB, a, env, lane, lds[wave]);
+    agent_fused_wave<S, AmiGrayPainter>(pa, pb, dLive, dA, dB, a, env, lane, lds[wave]);
 }
 
 // ------------------------------------------------------------------ state pack / unpack, scalars
@@ -1108,6 +1121,7 @@ struct AmiOps : GameOps {
     {
         hipFree(d.rng); hipFree(d.sc); hipFree(d.tiles); hipFree(d.boxes); hipFree(d.movers); hipFree(tab_dev);
         hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.tiles); hipFree(dA.boxes); hipFree(dA.movers);
+        hipFree(dB.rng); hipFree(dB.sc); hipFree(dB.tiles); hipFree(dB.boxes); hipFree(dB.movers);
     }
 
     int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
@@ -1133,61 +1147,48 @@ struct AmiOps : GameOps {
     {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
-        AmiDev shadow{};
-        if (src.snapshot_after > 0) {
-            int rc = ensure_shadow(e);
-            if (rc) return rc;
-            shadow = dA;
-        }
-        hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, shadow, src, flags, first, count);
+        dA.tab = dB.tab = d.tab;
+        hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 
-    // ---- fused agent observation: frame A is a snapshot of the dynamic SoA state, frame B the live state
-    AmiDev dA{};
+    // ---- agent layer: MaxAndSkipEnv's two-frame buffer is two snapshots of the dynamic SoA state per env
+    AmiDev dA{}, dB{};
     bool agent_fused() const override { return true; }
-
     bool multi_frame_step() const override { return true; }
+    bool agent_reset_supported() const override { return true; }
 
-    int ensure_shadow(tbx_engine* e)
+    int alloc_slot(tbx_engine* e, AmiDev& x)
     {
-        if (dA.sc) { dA.tab = d.tab; return TBX_OK; }
+        if (x.sc) { x.tab = d.tab; return TBX_OK; }
         const size_t N = (size_t)e->n;
-        dA = d;
-        dA.sc = nullptr; dA.tiles = nullptr; dA.boxes = nullptr; dA.movers = nullptr; dA.rng = nullptr;
-        TBX_HIP(hipMalloc((void**)&dA.rng, 2 * N * sizeof(uint64_t)));
-        TBX_HIP(hipMalloc((void**)&dA.sc, (size_t)ANF * N * sizeof(int32_t)));
-        TBX_HIP(hipMalloc((void**)&dA.tiles, N * 32 * sizeof(uint64_t)));
-        TBX_HIP(hipMalloc((void**)&dA.boxes, N * 128 * sizeof(uint32_t)));
-        TBX_HIP(hipMalloc((void**)&dA.movers, N * NMF * 16 * sizeof(int32_t)));
+        x = d;
+        x.sc = nullptr; x.tiles = nullptr; x.boxes = nullptr; x.movers = nullptr; x.rng = nullptr;
+        TBX_HIP(hipMalloc((void**)&x.rng, 2 * N * sizeof(uint64_t)));
+        TBX_HIP(hipMalloc((void**)&x.sc, (size_t)ANF * N * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&x.tiles, N * 32 * sizeof(uint64_t)));
+        TBX_HIP(hipMalloc((void**)&x.boxes, N * 128 * sizeof(uint32_t)));
+        TBX_HIP(hipMalloc((void**)&x.movers, N * NMF * 16 * sizeof(int32_t)));
         return TBX_OK;
     }
 
-    int agent_snapshot(tbx_engine* e, int which, hipStream_t s) override
+    int agent_prepare(tbx_engine* e) override
     {
-        if (which != 0) return TBX_OK;                       // frame B is read from the live state
-        const size_t N = (size_t)e->n;
-        int rc = ensure_shadow(e);
+        int rc = alloc_slot(e, dA);
         if (rc) return rc;
-        TBX_HIP(hipMemcpyAsync(dA.sc, d.sc, (size_t)ANF * N * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        TBX_HIP(hipMemcpyAsync(dA.tiles, d.tiles, N * 32 * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
-        TBX_HIP(hipMemcpyAsync(dA.boxes, d.boxes, N * 128 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        TBX_HIP(hipMemcpyAsync(dA.movers, d.movers, N * NMF * 16 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        return TBX_OK;
+        return alloc_slot(e, dB);
     }
 
     int agent_warp(tbx_engine* e, const AgentWarpArgs& a, hipStream_t s) override
     {
-        AgentWarpArgs w = a;
-        if (!dA.sc) w.two_frames = 0;                        // no snapshot yet (reset, or skip == 1): frame B alone
-        const AmiDev& A = dA.sc ? dA : d;
+        dA.tab = dB.tab = d.tab;
         const dim3 grid = grid_for(e->n), block(TBX_BLOCK);
         switch (a.stack) {
-        case 1: hipLaunchKernelGGL(ami_agent_warp_kernel<1>, grid, block, 0, s, A, d, w, e->n); break;
-        case 2: hipLaunchKernelGGL(ami_agent_warp_kernel<2>, grid, block, 0, s, A, d, w, e->n); break;
-        case 3: hipLaunchKernelGGL(ami_agent_warp_kernel<3>, grid, block, 0, s, A, d, w, e->n); break;
-        default: hipLaunchKernelGGL(ami_agent_warp_kernel<4>, grid, block, 0, s, A, d, w, e->n); break;
+        case 1: hipLaunchKernelGGL(ami_agent_warp_kernel<1>, grid, block, 0, s, d, dA, dB, a, e->n); break;
+        case 2: hipLaunchKernelGGL(ami_agent_warp_kernel<2>, grid, block, 0, s, d, dA, dB, a, e->n); break;
+        case 3: hipLaunchKernelGGL(ami_agent_warp_kernel<3>, grid, block, 0, s, d, dA, dB, a, e->n); break;
+        default: hipLaunchKernelGGL(ami_agent_warp_kernel<4>, grid, block, 0, s, d, dA, dB, a, e->n); break;
         }
         TBX_HIP(hipGetLastError());
         return TBX_OK;
@@ -1195,22 +1196,36 @@ struct AmiOps : GameOps {
 
     int agent_reset_envs(tbx_engine* e, const AgentResetArgs& r, hipStream_t s) override
     {
+        dA.tab = dB.tab = d.tab;
         const dim3 grid = r.list ? dim3(std::min<unsigned>(grid_for(e->n).x, 512u)) : grid_for(e->n);
-        hipLaunchKernelGGL(ami_agent_reset_kernel, grid, dim3(TBX_BLOCK), 0, s, d, r);
+        hipLaunchKernelGGL(ami_agent_reset_kernel, grid, dim3(TBX_BLOCK), 0, s, d, dA, dB, r);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 
+    int render_from(tbx_engine* e, int source, const uint8_t* pick_live, uint8_t* out_dev, int channels, hipStream_t s) override
+    {
+        dA.tab = dB.tab = d.tab;
+        const AmiDev& src = source == 1 ? dA : source == 2 ? dB : d;
+        return render_impl(e, src, d, source ? pick_live : nullptr, out_dev, channels, 0, e->n, s);
+    }
+
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
+    {
+        return render_impl(e, d, d, nullptr, out_dev, channels, first_env, n_envs, s);
+    }
+
+    int render_impl(tbx_engine* e, const AmiDev& src, const AmiDev& alt, const uint8_t* pick_alt, uint8_t* out_dev, int channels, int first_env,
+                    int n_envs, hipStream_t s)
     {
         static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
         // RGB: nine waves per frame (2-3 of the 25 units each) measured 5.45-5.55 TB/s against 4.9 for one wave per frame;
         // gray and RGBA show no such effect (scripts/ab_render.py with TBX_RENDER_SPLIT)
         const int split = split_env > 0 ? split_env : channels == 3 ? 9 : 1;
         switch (channels) {
-        case 1: hipLaunchKernelGGL(ami_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
-        case 3: hipLaunchKernelGGL(ami_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
-        case 4: hipLaunchKernelGGL(ami_render_kernel<4>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
+        case 1: hipLaunchKernelGGL(ami_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
+        case 3: hipLaunchKernelGGL(ami_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
+        case 4: hipLaunchKernelGGL(ami_render_kernel<4>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
         TBX_HIP(hipGetLastError());

@@ -286,6 +286,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_step_kernel(BrkDev d, BrkCfg c,
     if (rel >= count) return;
     const int env = first_env + rel;
     const size_t N = (size_t)d.n;
+    if (src.exec_flag && lane == 0) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
+    if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
 
     // ---- action -> buttons
     uint32_t buttons;
@@ -747,12 +749,14 @@ __device__ __forceinline__ void brk_t_step(const BrkCfg& c, BrkT& s, uint32_t bu
 }
 
 __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, ActionSource src, uint32_t flags, BrkRenderRec* recs,
-                                                           BrkRenderRec* recs_a)
+                                                           BrkRenderRec* recs_a, BrkRenderRec* recs_b)
 {
     const BrkCfg& c = *cp;   // tables are indexed per thread: read them from memory, not from the kernel arguments
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= d.n) return;
     const size_t N = (size_t)d.n;
+    if (src.exec_flag) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
+    if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
 
     int a;
     if (src.actions) a = src.actions[env];
@@ -784,7 +788,16 @@ __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCf
             prev = s.score;
         }
         tbx_accumulate(src, env, rew, is_done, fr);
-        if (fr + 1 == src.snapshot_after && recs_a) recs_a[env] = t_record(s);     // frame A of the agent observation
+        if (src.buf_valid) {                                 // MaxAndSkipEnv's frame buffer: slot A after frame skip-2, B after skip-1
+            const uint32_t slots = tbx_snap_slots(src, fr);
+            if (slots) {
+                const BrkRenderRec rec = t_record(s);
+                if (slots & 1u) recs_a[env] = rec;
+                if (slots & 2u) recs_b[env] = rec;
+                src.buf_valid[env] |= (uint8_t)slots;
+            }
+            if (is_done) break;                              // ... and its loop ends with the game
+        }
     }
     t_store(d, env, s);
     d.prev_score[env] = prev;
@@ -802,33 +815,36 @@ struct BrkTEnv {
     const BrkCfg& c;
     BrkT& s;
     Rng& sim;
+    BrkRenderRec* slot_a;
+    BrkRenderRec* slot_b;
+    __device__ __forceinline__ void snapshot(int slot) { *(slot ? slot_b : slot_a) = t_record(s); }
     __device__ __forceinline__ void step(uint32_t buttons) { brk_t_step(c, s, buttons); }
     __device__ __forceinline__ void new_game() { t_new_game(c, sim, s); }
     __device__ __forceinline__ int lives() const { return s.lives; }
     __device__ __forceinline__ int score() const { return s.score; }
 };
 
-__global__ __launch_bounds__(128) void brk_agent_reset_kernel(BrkDev d, const BrkCfg* __restrict__ cp, AgentResetArgs r, BrkRenderRec* recs)
+__global__ __launch_bounds__(128) void brk_agent_reset_kernel(BrkDev d, const BrkCfg* __restrict__ cp, AgentResetArgs r, BrkRenderRec* recs,
+                                                              BrkRenderRec* recs_a, BrkRenderRec* recs_b)
 {
     const BrkCfg& c = *cp;
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= d.n) return;
-    const int kind = r.kind[env];
-    if (kind == 0) return;
+    if (r.kind[env] == 0) return;
     const size_t N = (size_t)d.n;
     BrkT s;
     t_load(d, env, s);
     Rng sim;
     sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
-    AgentMonitor m{r.ep_ret[env], r.ep_len[env], r.ep_index[env], r.prev_lives[env], false, 0, 0};
-    BrkTEnv env_ops{c, s, sim};
-    AgentResetProc<BrkTEnv> proc{env_ops, r, m, r.env_offset + (uint64_t)env, false};
-    proc.run(kind);
+    AgentMonitor m = agent_monitor_load(r, env);
+    BrkTEnv env_ops{c, s, sim, recs_a + env, recs_b + env};
+    AgentResetProc<BrkTEnv> proc{env_ops, r, m, r.env_offset + (uint64_t)env, d.prev_score[env], (uint32_t)r.buf_valid[env],
+                                 r.noop_override ? r.noop_override[env] : 0, false};
+    proc.run();
     t_store(d, env, s);
     d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
-    d.prev_score[env] = s.score;
-    r.ep_ret[env] = m.ep_ret; r.ep_len[env] = m.ep_len; r.ep_index[env] = m.ep_index; r.prev_lives[env] = m.prev_lives;
-    if (m.emitted) { r.ep_done[env] = 1; r.ep_ret_out[env] = (float)m.out_ret; r.ep_len_out[env] = m.out_len; }
+    d.prev_score[env] = proc.prev;
+    agent_monitor_store(r, env, m, proc.valid, proc.obs_raw);
     recs[env] = t_record(s);
 }
 
@@ -840,11 +856,17 @@ __constant__ uint16_t BRK_DIGITS[10] = {0x7B6F, 0x749A, 0x73E7, 0x79E7, 0x49ED, 
 // slower, 16 rows no better
 constexpr int BRK_UNIT_ROWS = 8;    // scanlines per work item, staged in LDS (160 = 20 units)
 
-__global__ __launch_bounds__(256) void brk_render_prep_kernel(BrkDev d, BrkRenderRec* recs, int first_env, int count)
+// exec_flag (agent layer, single-frame launches): only the envs that ran the frame write their record, and set `bit` of buf_valid
+__global__ __launch_bounds__(256) void brk_render_prep_kernel(BrkDev d, BrkRenderRec* recs, int first_env, int count,
+                                                              const uint8_t* exec_flag = nullptr, uint8_t* buf_valid = nullptr, int bit = 0)
 {
     const int rel = blockIdx.x * blockDim.x + threadIdx.x;
     if (rel >= count) return;
     const int env = first_env + rel;
+    if (exec_flag) {
+        if (!exec_flag[env]) return;
+        buf_valid[env] |= (uint8_t)bit;
+    }
     const size_t N = (size_t)d.n;
     BrkRenderRec r;
 #pragma unroll
@@ -928,7 +950,8 @@ struct BrkPalette {
 // (hipMemset on the same boxes: 6.3-6.5 TB/s).
 template <int C, bool CUSTOM>
 __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
-                                                               BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split)
+                                                               BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split,
+                                                               const BrkRenderRec* __restrict__ recs_alt = nullptr, const uint8_t* __restrict__ pick_alt = nullptr)
 {
     constexpr int W = TBX_BRK_W, H = TBX_BRK_H;
     using Stager = RowStager<C, W, BRK_UNIT_ROWS>;
@@ -968,7 +991,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
     if (rel >= count) return;
     for (int q = part; q < NUNITS; q += split) {
         const int u = (int)(((uint32_t)(first_env + rel) * 7u + (uint32_t)q) % (uint32_t)NUNITS);
-        const BrkRenderRec rec = recs[first_env + rel];   // by value: scalar loads up front, none inside the row loop
+        // by value: scalar loads up front, none inside the row loop (agent layer, generic path: flagged envs paint recs_alt)
+        const BrkRenderRec rec = (pick_alt && pick_alt[first_env + rel]) ? recs_alt[first_env + rel] : recs[first_env + rel];
         const int env = first_env + rel;
         uint8_t* dst = out + ((size_t)rel * H + (size_t)u * BRK_UNIT_ROWS) * W * C;
         const int y_first = u * BRK_UNIT_ROWS;
@@ -1143,8 +1167,8 @@ __device__ __forceinline__ uint32_t brk_gray_line(const BrkRenderRec& rec, const
 }
 
 template <int S>
-__global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRenderRec* __restrict__ recsA, const BrkRenderRec* __restrict__ recsB,
-                                                                   BrkGrayPal pal, AgentWarpArgs a, int n)
+__global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRenderRec* __restrict__ recsLive, const BrkRenderRec* __restrict__ recsA,
+                                                                   const BrkRenderRec* __restrict__ recsB, BrkGrayPal pal, AgentWarpArgs a, int n)
 {
     constexpr int W = TBX_BRK_W, H = TBX_BRK_H;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK][352];
@@ -1155,11 +1179,18 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
     if (env >= n) return;
     uint8_t* row = lds_all[wave];
     uint8_t* vals = vals_all[wave];
-    const bool fresh = a.reset_mode || a.fin[env];
-    const BrkRenderRec recA = recsA[env], recB = recsB[env];
+    const ObsSel sel = agent_obs_sel(a, env);
+    uint8_t* o = a.obs + (size_t)env * a.oh * a.ow * S;
+    if (sel.none) {                                        // max over two zero frames
+        for (int i = lane; i < a.oh * a.ow; i += 64) vals[i] = 0;
+        stack_commit<S>(vals, o, a.oh * a.ow, lane, sel.zero);
+        return;
+    }
+    const bool fresh = !sel.two;                           // one frame alone: record B is its source, record A is not composed
+    const BrkRenderRec recA = recsA[env];
+    const BrkRenderRec recB = sel.single == 0 ? recsLive[env] : sel.single == 1 ? recA : recsB[env];
     const int x0 = lane * 4;
     const bool active = x0 < W;
-    uint8_t* o = a.obs + (size_t)env * a.oh * a.ow * S;
     const uint32_t half = (uint32_t)(H * W) / 2u;
     const ColTaps c0 = load_col(a.tx, lane, a.ow), c1 = load_col(a.tx, lane + 64, a.ow);
     const bool on0 = lane < a.ow, on1 = lane + 64 < a.ow;
@@ -1256,7 +1287,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
             }
         }
     }
-    stack_commit<S>(vals, o, a.oh * a.ow, lane, fresh);
+    stack_commit<S>(vals, o, a.oh * a.ow, lane, sel.zero);
 }
 
 // ------------------------------------------------------------------ state pack / unpack, scalars
@@ -1453,6 +1484,7 @@ struct BreakoutOps : GameOps {
         if (d.custom) hipFree(d.custom);
         hipFree(recs);
         hipFree(recsA);
+        hipFree(recsB);
         hipFree(cfg_dev);
     }
 
@@ -1478,12 +1510,7 @@ struct BreakoutOps : GameOps {
     int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
     {
         if (!custom && src.single_env < 0 && use_tpe) {
-            BrkRenderRec* ra = nullptr;
-            if (src.snapshot_after > 0) {
-                if (!recsA) TBX_HIP(hipMalloc((void**)&recsA, sizeof(BrkRenderRec) * (size_t)e->n));
-                ra = recsA;
-            }
-            hipLaunchKernelGGL(brk_step_tpe_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs, ra);
+            hipLaunchKernelGGL(brk_step_tpe_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs, recsA, recsB);
             TBX_HIP(hipGetLastError());
             recs_valid = true;
             return TBX_OK;
@@ -1500,19 +1527,24 @@ struct BreakoutOps : GameOps {
     bool use_tpe = true;            // thread-per-env step for the canonical wall (TBX_BRK_STEP_TPE=0 keeps the wave kernel)
 
     template <int C>
-    void launch_render(uint8_t* out, int first, int count, hipStream_t s)
+    void launch_render(uint8_t* out, int first, int count, hipStream_t s, const BrkRenderRec* src_recs = nullptr,
+                       const BrkRenderRec* alt = nullptr, const uint8_t* pick_alt = nullptr)
     {
         BrkPalette pal;
         pal.bg = c.bg; pal.frame = c.frame; pal.paddle = c.paddle; pal.ball = c.ball; pal.rows = c.n_rows;
         for (int i = 0; i < TBX_BRK_MAX_ROWS; i++) pal.row_colors[i] = c.row_colors[i];
-        if (!recs_valid) hipLaunchKernelGGL(brk_render_prep_kernel, dim3((count + 255) / 256), dim3(256), 0, s, d, recs, first, count);
+        if (!recs_valid && (!src_recs || alt)) {           // the live records are read
+            hipLaunchKernelGGL(brk_render_prep_kernel, dim3((count + 255) / 256), dim3(256), 0, s, d, recs, first, count);
+            if (first == 0 && count == d.n) recs_valid = true;
+        }
+        const BrkRenderRec* rr = src_recs ? src_recs : recs;
         // ten waves per frame, each doing unit p and unit p + 10 (one from the busy upper half of the screen, one from the
         // lower): measured 6.05-6.25 TB/s against 5.4-5.7 for one wave per frame and for every other split from 1 to 20
         // except 9..12 (scripts/ab_render.py with TBX_BRK_SPLIT); also what keeps small batches from under-filling the chip
         static const int split_env = getenv("TBX_BRK_SPLIT") ? atoi(getenv("TBX_BRK_SPLIT")) : 0;
         const int split = split_env > 0 ? split_env : C == 3 ? 10 : count <= 8192 ? 4 : count <= 32768 ? 2 : 1;   // gray / RGBA: no such effect
-        if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, recs, d.custom, pal, out, first, count, split);
-        else hipLaunchKernelGGL((brk_render_kernel<C, false>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, recs, d.custom, pal, out, first, count, split);
+        if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
+        else hipLaunchKernelGGL((brk_render_kernel<C, false>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
     }
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
@@ -1527,32 +1559,51 @@ struct BreakoutOps : GameOps {
         return TBX_OK;
     }
 
-    // ---- fused agent observation: frame A / B are copies of the 64-byte render records
+    // ---- agent layer: MaxAndSkipEnv's two-frame buffer is two 64-byte render records per env
     BrkRenderRec* recsA = nullptr;
+    BrkRenderRec* recsB = nullptr;
 
     bool agent_fused() const override { return !custom; }
     bool multi_frame_step() const override { return !custom && use_tpe; }
+    bool agent_reset_supported() const override { return !custom; }
 
-    int agent_snapshot(tbx_engine* e, int which, hipStream_t s) override
+    int agent_prepare(tbx_engine* e) override
     {
-        if (!recs_valid) {
-            hipLaunchKernelGGL(brk_render_prep_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, recs, 0, e->n);
-            TBX_HIP(hipGetLastError());
-            recs_valid = true;
+        if (!recsA) TBX_HIP(hipMalloc((void**)&recsA, sizeof(BrkRenderRec) * (size_t)e->n));
+        if (!recsB) TBX_HIP(hipMalloc((void**)&recsB, sizeof(BrkRenderRec) * (size_t)e->n));
+        TBX_HIP(hipMemset(recsA, 0, sizeof(BrkRenderRec) * (size_t)e->n));
+        TBX_HIP(hipMemset(recsB, 0, sizeof(BrkRenderRec) * (size_t)e->n));
+        return TBX_OK;
+    }
+
+    int agent_snapshot(tbx_engine* e, int slot, const uint8_t* exec_flag, uint8_t* buf_valid, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(brk_render_prep_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, slot ? recsB : recsA, 0, e->n, exec_flag,
+                           buf_valid, slot ? 2 : 1);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int render_from(tbx_engine* e, int source, const uint8_t* pick_live, uint8_t* out_dev, int channels, hipStream_t s) override
+    {
+        const BrkRenderRec* src_recs = source == 1 ? recsA : source == 2 ? recsB : nullptr;
+        const BrkRenderRec* alt = (src_recs && pick_live) ? recs : nullptr;
+        switch (channels) {
+        case 1: launch_render<1>(out_dev, 0, e->n, s, src_recs, alt, alt ? pick_live : nullptr); break;
+        case 3: launch_render<3>(out_dev, 0, e->n, s, src_recs, alt, alt ? pick_live : nullptr); break;
+        case 4: launch_render<4>(out_dev, 0, e->n, s, src_recs, alt, alt ? pick_live : nullptr); break;
+        default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
-        if (which == 0) {
-            if (!recsA) TBX_HIP(hipMalloc((void**)&recsA, sizeof(BrkRenderRec) * (size_t)e->n));
-            TBX_HIP(hipMemcpyAsync(recsA, recs, sizeof(BrkRenderRec) * (size_t)e->n, hipMemcpyDeviceToDevice, s));
-        }
+        TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 
     int agent_reset_envs(tbx_engine* e, const AgentResetArgs& r, hipStream_t s) override
     {
         if (custom) return e->fail(TBX_E_UNSUPPORTED, "breakout: episodic-life / fire-reset / no-op-reset need the canonical brick wall");
-        hipLaunchKernelGGL(brk_agent_reset_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, r, recs);
+        hipLaunchKernelGGL(brk_agent_reset_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, r, recs, recsA, recsB);
         TBX_HIP(hipGetLastError());
-        // every other env's record is still current if it was; the flagged envs' records were just rewritten
+        // every other env's live record is still current if it was; the flagged envs' records were just rewritten
         return TBX_OK;
     }
 
@@ -1574,13 +1625,17 @@ struct BreakoutOps : GameOps {
         for (int y = 2; y <= 12; y += 2) mark(y);           // HUD glyph rows are 2 px tall, HUD ends at 12
         mark(TBX_BRK_WALL_Y0); mark(TBX_BRK_WALL_Y0 + 12);  // top bar
         for (int r = 0; r <= c.n_rows; r++) mark(43 + 4 * r); // each brick row and the line after the wall
-        const BrkRenderRec* A = (a.reset_mode || !a.two_frames || !recsA) ? recs : recsA;
+        if (!recs_valid) {                                   // envs whose observation is the raw live frame read `recs`
+            hipLaunchKernelGGL(brk_render_prep_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, recs, 0, e->n);
+            TBX_HIP(hipGetLastError());
+            recs_valid = true;
+        }
         const dim3 grid = grid_for(e->n), block(TBX_BLOCK);
         switch (a.stack) {
-        case 1: hipLaunchKernelGGL(brk_agent_warp_kernel<1>, grid, block, 0, s, A, recs, pal, a, e->n); break;
-        case 2: hipLaunchKernelGGL(brk_agent_warp_kernel<2>, grid, block, 0, s, A, recs, pal, a, e->n); break;
-        case 3: hipLaunchKernelGGL(brk_agent_warp_kernel<3>, grid, block, 0, s, A, recs, pal, a, e->n); break;
-        default: hipLaunchKernelGGL(brk_agent_warp_kernel<4>, grid, block, 0, s, A, recs, pal, a, e->n); break;
+        case 1: hipLaunchKernelGGL(brk_agent_warp_kernel<1>, grid, block, 0, s, recs, recsA, recsB, pal, a, e->n); break;
+        case 2: hipLaunchKernelGGL(brk_agent_warp_kernel<2>, grid, block, 0, s, recs, recsA, recsB, pal, a, e->n); break;
+        case 3: hipLaunchKernelGGL(brk_agent_warp_kernel<3>, grid, block, 0, s, recs, recsA, recsB, pal, a, e->n); break;
+        default: hipLaunchKernelGGL(brk_agent_warp_kernel<4>, grid, block, 0, s, recs, recsA, recsB, pal, a, e->n); break;
         }
         TBX_HIP(hipGetLastError());
         return TBX_OK;

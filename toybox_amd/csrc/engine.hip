@@ -202,6 +202,8 @@ int check_err_flag(tbx_engine* e)
     EHIP(hipStreamSynchronize(e->stream));
     if (f) {
         EHIP(hipMemsetAsync(e->err_flag, 0, sizeof f, e->stream));
+        if (f & 2u)
+            return e->fail(TBX_E_NEEDS_RESET, "an env was stepped after its game ended inside EpisodicLifeEnv's no-op step (bench.Monitor raises here)");
         return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
     }
     return TBX_OK;
@@ -508,6 +510,7 @@ int tbx_step(tbx_engine* e, const int32_t* actions_host, uint32_t flags, int32_t
     if (lives) memcpy(lives, host_out + N, N * sizeof(int32_t));
     if (score) memcpy(score, host_out + 2 * N, N * sizeof(int32_t));
     if (done) memcpy(done, host_out + 3 * N + 1, N);
+    if (host_out[3 * N] & 2) return e->fail(TBX_E_NEEDS_RESET, "an env was stepped after its game ended inside EpisodicLifeEnv's no-op step (bench.Monitor raises here)");
     if (host_out[3 * N]) return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
     return TBX_OK;
 }

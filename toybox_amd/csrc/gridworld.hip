@@ -124,6 +124,8 @@ __global__ __launch_bounds__(128) void gw_step_kernel(GwDev d, ActionSource src,
     const int rel = blockIdx.x * blockDim.x + threadIdx.x;
     if (rel >= count) return;
     const int env = first_env + rel;
+    if (src.exec_flag) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
+    if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
     uint32_t buttons;
     if (src.single_env >= 0) {
         buttons = src.single_buttons;
@@ -169,10 +171,42 @@ __global__ __launch_bounds__(128) void gw_step_kernel(GwDev d, ActionSource src,
 }
 
 // reset-time wrappers of the agent layer (agent_device.hpp, AgentResetProc), thread per flagged env
+// the dynamic state of one env (scalars, tile table, board) copied live -> slot by `lanes` cooperating lanes
+__device__ __forceinline__ void gw_copy_env(const GwDev& dst, const GwDev& src, int env, int lane, int lanes)
+{
+    const size_t N = (size_t)src.n;
+    for (int f = lane; f < GF; f += lanes) dst.sc[(size_t)f * N + env] = src.sc[(size_t)f * N + env];
+    const uint32_t* ts = src.tiles + (size_t)env * GT * 3;
+    uint32_t* td = dst.tiles + (size_t)env * GT * 3;
+    for (int i = lane; i < GT * 3; i += lanes) td[i] = ts[i];
+    const uint32_t* gs = reinterpret_cast<const uint32_t*>(src.grid + (size_t)env * CELLS);
+    uint32_t* gd = reinterpret_cast<uint32_t*>(dst.grid + (size_t)env * CELLS);
+    for (int i = lane; i < CELLS / 4; i += lanes) gd[i] = gs[i];
+}
+
+// agent layer, single-frame launches: the envs that ran the frame copy their state into a buffer slot
+__global__ __launch_bounds__(TBX_BLOCK) void gw_snapshot_kernel(GwDev dst, GwDev src, const uint8_t* exec_flag, uint8_t* buf_valid, int bit)
+{
+    const int lane = threadIdx.x & 63;
+    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (env >= src.n) return;
+    if (!wave_uniform((int)exec_flag[env])) return;
+    gw_copy_env(dst, src, env, lane, 64);
+    if (lane == 0) buf_valid[env] |= (uint8_t)bit;
+}
+
 struct GwAgentEnv {
     const GwDev& d;
+    const GwDev& slot_a;
+    const GwDev& slot_b;
     int env;
     GwT& s;
+    __device__ __forceinline__ void snapshot(int slot)
+    {
+        const GwDev& dst = slot ? slot_b : slot_a;
+        gw_copy_env(dst, d, env, 0, 1);      // board, tile table, player colour; the scalars held in registers follow
+        gw_store(dst, env, s);
+    }
     __device__ __forceinline__ void step(uint32_t buttons) { gw_step(d, env, s, buttons); }
     __device__ __forceinline__ void new_game()
     {
@@ -184,22 +218,21 @@ struct GwAgentEnv {
     __device__ __forceinline__ int score() const { return s.score; }
 };
 
-__global__ __launch_bounds__(128) void gw_agent_reset_kernel(GwDev d, AgentResetArgs r)
+__global__ __launch_bounds__(128) void gw_agent_reset_kernel(GwDev d, GwDev slot_a, GwDev slot_b, AgentResetArgs r)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= d.n) return;
-    const int kind = r.kind[env];
-    if (kind == 0) return;
+    if (r.kind[env] == 0) return;
     GwT s;
     gw_load(d, env, s);
-    AgentMonitor m{r.ep_ret[env], r.ep_len[env], r.ep_index[env], r.prev_lives[env], false, 0, 0};
-    GwAgentEnv ops{d, env, s};
-    AgentResetProc<GwAgentEnv> proc{ops, r, m, r.env_offset + (uint64_t)env, false};
-    proc.run(kind);
+    AgentMonitor m = agent_monitor_load(r, env);
+    GwAgentEnv ops{d, slot_a, slot_b, env, s};
+    AgentResetProc<GwAgentEnv> proc{ops, r, m, r.env_offset + (uint64_t)env, d.prev_score[env], (uint32_t)r.buf_valid[env],
+                                    r.noop_override ? r.noop_override[env] : 0, false};
+    proc.run();
     gw_store(d, env, s);
-    d.prev_score[env] = s.score;
-    r.ep_ret[env] = m.ep_ret; r.ep_len[env] = m.ep_len; r.ep_index[env] = m.ep_index; r.prev_lives[env] = m.prev_lives;
-    if (m.emitted) { r.ep_done[env] = 1; r.ep_ret_out[env] = (float)m.out_ret; r.ep_len_out[env] = m.out_len; }
+    d.prev_score[env] = proc.prev;
+    agent_monitor_store(r, env, m, proc.valid, proc.obs_raw);
 }
 
 // ------------------------------------------------------------------ render
@@ -314,7 +347,8 @@ struct GwGrayPainter : GwPainter<1> {
 };
 
 template <int C>
-__global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* out, int first_env, int count, int split)
+__global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* out, int first_env, int count, int split, GwDev d_alt,
+                                                              const uint8_t* __restrict__ pick_alt)
 {
     constexpr int W = TBX_GW_W, H = TBX_GW_H, UNITS = H / GW_UNIT_ROWS;
     using Stager = RowStager<C, W, GW_UNIT_ROWS>;
@@ -328,7 +362,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* 
     const int env = first_env + rel;
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
     GwPainter<C> p;
-    p.setup(d, env, lane, lds_mask[wave]);
+    // (agent layer, generic path: flagged envs are painted from d_alt)
+    p.setup((pick_alt && wave_uniform((int)pick_alt[env])) ? d_alt : d, env, lane, lds_mask[wave]);
     uint8_t* dst = out + (size_t)rel * H * W * C;
     for (int u = part; u < UNITS; u += split) {
         const int unit = split > 1 ? u : (u + env) % UNITS;  // one wave per frame: rotate the start so waves do not march in lockstep
@@ -343,7 +378,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* 
 
 // fused agent observation: agent_fused_wave (agent_device.hpp) with two GwGrayPainters per wave
 template <int S>
-__global__ __launch_bounds__(TBX_BLOCK) void gw_agent_warp_kernel(GwDev dA, GwDev dB, AgentWarpArgs a, int n)
+__global__ __launch_bounds__(TBX_BLOCK) void gw_agent_warp_kernel(GwDev dLive, GwDev dA, GwDev dB, AgentWarpArgs a, int n)
 {
     __shared__ AgentFusedLds<GwGrayPainter> lds[TBX_WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
@@ -351,7 +386,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_agent_warp_kernel(GwDev dA, GwDe
     const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
     if (env >= n) return;
     GwGrayPainter pa, pb;
-    agent_fused_wave<S, GwGrayPainter>(pa, pb, dA, dB, a, env, lane, lds[wave]);
+    agent_fused_wave<S, GwGrayPainter>(pa, pb, dLive, dA, dB, a, env, lane, lds[wave]);
 }
 
 // ------------------------------------------------------------------ state records
@@ -461,6 +496,7 @@ struct GridWorldOps : GameOps {
     {
         hipFree(d.sc); hipFree(d.tiles); hipFree(d.grid); hipFree(cfg_dev);
         hipFree(dA.sc); hipFree(dA.tiles); hipFree(dA.grid);
+        hipFree(dB.sc); hipFree(dB.tiles); hipFree(dB.grid);
     }
 
     int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
@@ -490,38 +526,47 @@ struct GridWorldOps : GameOps {
         return TBX_OK;
     }
 
-    // ---- fused agent observation: frame A is a snapshot of the dynamic state, frame B the live state
-    GwDev dA{};
+    // ---- agent layer: MaxAndSkipEnv's two-frame buffer is two snapshots of the dynamic state per env
+    GwDev dA{}, dB{};
     bool agent_fused() const override { return true; }
+    bool agent_reset_supported() const override { return true; }
 
-    int agent_snapshot(tbx_engine* e, int which, hipStream_t s) override
+    int alloc_slot(tbx_engine* e, GwDev& x)
     {
-        if (which != 0) return TBX_OK;
+        if (x.sc) { x.cfg = d.cfg; return TBX_OK; }
         const size_t N = (size_t)e->n;
-        if (!dA.sc) {
-            dA = d;
-            dA.sc = nullptr; dA.tiles = nullptr; dA.grid = nullptr;
-            TBX_HIP(hipMalloc((void**)&dA.sc, (size_t)GF * N * sizeof(int32_t)));
-            TBX_HIP(hipMalloc((void**)&dA.tiles, N * GT * 3 * sizeof(uint32_t)));
-            TBX_HIP(hipMalloc((void**)&dA.grid, N * CELLS));
-        }
-        TBX_HIP(hipMemcpyAsync(dA.sc, d.sc, (size_t)GF * N * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        TBX_HIP(hipMemcpyAsync(dA.tiles, d.tiles, N * GT * 3 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        TBX_HIP(hipMemcpyAsync(dA.grid, d.grid, N * CELLS, hipMemcpyDeviceToDevice, s));
+        x = d;
+        x.sc = nullptr; x.tiles = nullptr; x.grid = nullptr;
+        TBX_HIP(hipMalloc((void**)&x.sc, (size_t)GF * N * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&x.tiles, N * GT * 3 * sizeof(uint32_t)));
+        TBX_HIP(hipMalloc((void**)&x.grid, N * CELLS));
+        return TBX_OK;
+    }
+
+    int agent_prepare(tbx_engine* e) override
+    {
+        int rc = alloc_slot(e, dA);
+        if (rc) return rc;
+        return alloc_slot(e, dB);
+    }
+
+    int agent_snapshot(tbx_engine* e, int slot, const uint8_t* exec_flag, uint8_t* buf_valid, hipStream_t s) override
+    {
+        dA.cfg = dB.cfg = d.cfg;
+        hipLaunchKernelGGL(gw_snapshot_kernel, wave_grid(e->n), dim3(TBX_BLOCK), 0, s, slot ? dB : dA, d, exec_flag, buf_valid, slot ? 2 : 1);
+        TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 
     int agent_warp(tbx_engine* e, const AgentWarpArgs& a, hipStream_t s) override
     {
-        AgentWarpArgs w = a;
-        if (!dA.sc) w.two_frames = 0;
-        const GwDev& A = dA.sc ? dA : d;
+        dA.cfg = dB.cfg = d.cfg;
         const dim3 grid = wave_grid(e->n), block(TBX_BLOCK);
         switch (a.stack) {
-        case 1: hipLaunchKernelGGL(gw_agent_warp_kernel<1>, grid, block, 0, s, A, d, w, e->n); break;
-        case 2: hipLaunchKernelGGL(gw_agent_warp_kernel<2>, grid, block, 0, s, A, d, w, e->n); break;
-        case 3: hipLaunchKernelGGL(gw_agent_warp_kernel<3>, grid, block, 0, s, A, d, w, e->n); break;
-        default: hipLaunchKernelGGL(gw_agent_warp_kernel<4>, grid, block, 0, s, A, d, w, e->n); break;
+        case 1: hipLaunchKernelGGL(gw_agent_warp_kernel<1>, grid, block, 0, s, d, dA, dB, a, e->n); break;
+        case 2: hipLaunchKernelGGL(gw_agent_warp_kernel<2>, grid, block, 0, s, d, dA, dB, a, e->n); break;
+        case 3: hipLaunchKernelGGL(gw_agent_warp_kernel<3>, grid, block, 0, s, d, dA, dB, a, e->n); break;
+        default: hipLaunchKernelGGL(gw_agent_warp_kernel<4>, grid, block, 0, s, d, dA, dB, a, e->n); break;
         }
         TBX_HIP(hipGetLastError());
         return TBX_OK;
@@ -529,19 +574,33 @@ struct GridWorldOps : GameOps {
 
     int agent_reset_envs(tbx_engine* e, const AgentResetArgs& r, hipStream_t s) override
     {
-        hipLaunchKernelGGL(gw_agent_reset_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, r);
+        dA.cfg = dB.cfg = d.cfg;
+        hipLaunchKernelGGL(gw_agent_reset_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, dA, dB, r);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 
+    int render_from(tbx_engine* e, int source, const uint8_t* pick_live, uint8_t* out_dev, int channels, hipStream_t s) override
+    {
+        dA.cfg = dB.cfg = d.cfg;
+        const GwDev& src = source == 1 ? dA : source == 2 ? dB : d;
+        return render_impl(e, src, d, source ? pick_live : nullptr, out_dev, channels, 0, e->n, s);
+    }
+
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
+    {
+        return render_impl(e, d, d, nullptr, out_dev, channels, first_env, n_envs, s);
+    }
+
+    int render_impl(tbx_engine* e, const GwDev& src, const GwDev& alt, const uint8_t* pick_alt, uint8_t* out_dev, int channels, int first_env,
+                    int n_envs, hipStream_t s)
     {
         static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
         const int split = split_env > 0 ? split_env : 1;
         switch (channels) {
-        case 1: hipLaunchKernelGGL(gw_render_kernel<1>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
-        case 3: hipLaunchKernelGGL(gw_render_kernel<3>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
-        case 4: hipLaunchKernelGGL(gw_render_kernel<4>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, split); break;
+        case 1: hipLaunchKernelGGL(gw_render_kernel<1>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
+        case 3: hipLaunchKernelGGL(gw_render_kernel<3>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
+        case 4: hipLaunchKernelGGL(gw_render_kernel<4>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
         TBX_HIP(hipGetLastError());

@@ -501,13 +501,15 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_new_game_kernel(SiDev d, SiCfg c
     }
 }
 
-__global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiDev shadow, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
+__global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiDev slot_a, SiDev slot_b, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
 {
     const int lane = threadIdx.x & 63;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     if (rel >= count) return;
     const int env = first_env + rel;
     const size_t N = (size_t)d.n;
+    if (src.exec_flag && lane == 0) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
+    if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
 
     uint32_t buttons;
     if (src.single_env >= 0) {
@@ -548,7 +550,13 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiDev shado
             prev = s.f[F_SCORE];
         }
         if (lane == 0) tbx_accumulate(src, env, rew, is_done, fr);
-        if (fr + 1 == src.snapshot_after && shadow.sc) si_store(shadow, env, lane, s);   // frame A of the agent observation
+        if (src.buf_valid) {                                 // MaxAndSkipEnv's frame buffer: slot A after frame skip-2, B after skip-1
+            const uint32_t slots = tbx_snap_slots(src, fr);
+            if (slots & 1u) si_store(slot_a, env, lane, s);
+            if (slots & 2u) si_store(slot_b, env, lane, s);
+            if (slots && lane == 0) src.buf_valid[env] |= (uint8_t)slots;
+            if (is_done) break;                              // ... and its loop ends with the game
+        }
     }
     si_store(d, env, lane, s);
     if (lane == 0) {
@@ -568,38 +576,41 @@ struct SiAgentEnv {
     int lane;
     SiRegs& s;
     Rng& sim;
+    const SiDev& slot_a;
+    const SiDev& slot_b;
+    int env;
+    __device__ __forceinline__ void snapshot(int slot) { si_store(slot ? slot_b : slot_a, env, lane, s); }
     __device__ __forceinline__ void step(uint32_t buttons) { si_step(c, lane, buttons, s); }
     __device__ __forceinline__ void new_game() { si_new_game(c, lane, sim, s); }
     __device__ __forceinline__ int lives() const { return wave_uniform(s.f[F_LIVES]); }
     __device__ __forceinline__ int score() const { return wave_uniform(s.f[F_SCORE]); }
 };
 
-__global__ __launch_bounds__(TBX_BLOCK) void si_agent_reset_kernel(SiDev d, SiCfg c, AgentResetArgs r)
+__global__ __launch_bounds__(TBX_BLOCK) void si_agent_reset_kernel(SiDev d, SiDev slot_a, SiDev slot_b, SiCfg c, AgentResetArgs r)
 {
     const int lane = threadIdx.x & 63;
     // a persistent grid walks the compact list of flagged envs (or every env when there is no list)
     const int wave_id = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6)), n_waves = gridDim.x * TBX_WAVES_PER_BLOCK;
     const int total = r.list ? wave_uniform(*r.count) : d.n;
     for (int it = wave_id; it < total; it += n_waves) {
-    const int env = r.list ? wave_uniform(r.list[it]) : it;
-    const int kind = wave_uniform((int)r.kind[env]);
-    if (kind == 0) continue;
-    const size_t N = (size_t)d.n;
-    SiRegs s;
-    si_load(d, env, lane, s);
-    Rng sim;
-    sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
-    AgentMonitor m{r.ep_ret[env], r.ep_len[env], r.ep_index[env], r.prev_lives[env], false, 0, 0};
-    SiAgentEnv ops{c, lane, s, sim};
-    AgentResetProc<SiAgentEnv> proc{ops, r, m, r.env_offset + (uint64_t)env, false};
-    proc.run(kind);
-    si_store(d, env, lane, s);
-    if (lane == 0) {
-        d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
-        d.prev_score[env] = s.f[F_SCORE];
-        r.ep_ret[env] = m.ep_ret; r.ep_len[env] = m.ep_len; r.ep_index[env] = m.ep_index; r.prev_lives[env] = m.prev_lives;
-        if (m.emitted) { r.ep_done[env] = 1; r.ep_ret_out[env] = (float)m.out_ret; r.ep_len_out[env] = m.out_len; }
-    }
+        const int env = r.list ? wave_uniform(r.list[it]) : it;
+        if (wave_uniform((int)r.kind[env]) == 0) continue;
+        const size_t N = (size_t)d.n;
+        SiRegs s;
+        si_load(d, env, lane, s);
+        Rng sim;
+        sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
+        AgentMonitor m = agent_monitor_load(r, env);
+        SiAgentEnv ops{c, lane, s, sim, slot_a, slot_b, env};
+        AgentResetProc<SiAgentEnv> proc{ops, r, m, r.env_offset + (uint64_t)env, wave_uniform(d.prev_score[env]),
+                                        (uint32_t)wave_uniform((int)r.buf_valid[env]), r.noop_override ? wave_uniform(r.noop_override[env]) : 0, false};
+        proc.run();
+        si_store(d, env, lane, s);
+        if (lane == 0) {
+            d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
+            d.prev_score[env] = proc.prev;
+            agent_monitor_store(r, env, m, proc.valid, proc.obs_raw);
+        }
     }
 }
 
@@ -960,7 +971,8 @@ __device__ __forceinline__ void si_fill_sprites(uint32_t* spr_lds)
 // One wave rasterises one env, scanline by scanline; SI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte
 // stores, blank units are stored directly.
 template <int C>
-__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank, int split)
+__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank, int split,
+                                                              SiDev d_alt, const uint8_t* __restrict__ pick_alt)
 {
     constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
     using Stager = RowStager<C, W, SI_UNIT_ROWS>;
@@ -977,7 +989,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
     SiPainter<C> p;
     p.spr_lds = spr_lds;
-    p.setup(d, env, lane, lds_mask[wave]);
+    // (agent layer, generic path: flagged envs are painted from d_alt)
+    p.setup((pick_alt && wave_uniform((int)pick_alt[env])) ? d_alt : d, env, lane, lds_mask[wave]);
 
     uint8_t* frame = out + (size_t)rel * H * W * C;
     constexpr int NUNITS = H / SI_UNIT_ROWS;
@@ -1014,7 +1027,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
 // max(frame A, frame B) -> gray -> area warp -> frame stack without the two full-resolution gray frames ever reaching
 // HBM: agent_fused_wave (agent_device.hpp) with two SiGrayPainters in one wave per env.
 template <int S>
-__global__ __launch_bounds__(TBX_BLOCK) void si_agent_warp_kernel(SiDev dA, SiDev dB, AgentWarpArgs a, int n)
+__global__ __launch_bounds__(TBX_BLOCK) void si_agent_warp_kernel(SiDev dLive, SiDev dA, SiDev dB, AgentWarpArgs a, int n)
 {
     __shared__ AgentFusedLds<SiGrayPainter> lds[TBX_WAVES_PER_BLOCK];
     __shared__ uint32_t spr_lds[SPR_WORDS];
@@ -1025,7 +1038,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_agent_warp_kernel(SiDev dA, SiDe
     if (env >= n) return;
     SiGrayPainter pa, pb;
     pa.spr_lds = spr_lds; pb.spr_lds = spr_lds;
-    agent_fused_wave<S, SiGrayPainter>(pa, pb, dA, dB, a, env, lane, lds[wave]);
+    agent_fused_wave<S, SiGrayPainter>(pa, pb, dLive, dA, dB, a, env, lane, lds[wave]);
 }
 
 // ------------------------------------------------------------------ state pack / unpack, scalars
@@ -1186,6 +1199,7 @@ struct SiOps : GameOps {
     {
         hipFree(d.rng); hipFree(d.sc); hipFree(d.enemies); hipFree(d.shields); hipFree(d.lasers);
         hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.enemies); hipFree(dA.shields); hipFree(dA.lasers);
+        hipFree(dB.rng); hipFree(dB.sc); hipFree(dB.enemies); hipFree(dB.shields); hipFree(dB.lasers);
     }
 
     int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
@@ -1209,61 +1223,46 @@ struct SiOps : GameOps {
     {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
-        SiDev shadow{};
-        if (src.snapshot_after > 0) {
-            int rc = ensure_shadow(e);
-            if (rc) return rc;
-            shadow = dA;
-        }
-        hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, shadow, c, src, flags, first, count);
+        hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, c, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 
-    // ---- fused agent observation: frame A is a snapshot of the dynamic SoA state, frame B the live state
-    SiDev dA{};
+    // ---- agent layer: MaxAndSkipEnv's two-frame buffer is two snapshots of the dynamic SoA state per env
+    SiDev dA{}, dB{};
     bool agent_fused() const override { return true; }
-
     bool multi_frame_step() const override { return true; }
+    bool agent_reset_supported() const override { return true; }
 
-    int ensure_shadow(tbx_engine* e)
+    int alloc_slot(tbx_engine* e, SiDev& x)
     {
-        if (dA.sc) return TBX_OK;
+        if (x.sc) return TBX_OK;
         const size_t N = (size_t)e->n;
-        dA = d;
-        dA.sc = nullptr; dA.enemies = nullptr; dA.shields = nullptr; dA.lasers = nullptr; dA.rng = nullptr;
-        TBX_HIP(hipMalloc((void**)&dA.rng, 2 * N * sizeof(uint64_t)));
-        TBX_HIP(hipMalloc((void**)&dA.sc, (size_t)NF * N * sizeof(int32_t)));
-        TBX_HIP(hipMalloc((void**)&dA.enemies, N * NEF * 64 * sizeof(int32_t)));
-        TBX_HIP(hipMalloc((void**)&dA.shields, N * 64 * sizeof(uint32_t)));
-        TBX_HIP(hipMalloc((void**)&dA.lasers, N * NLF * 16 * sizeof(int32_t)));
+        x = d;
+        x.sc = nullptr; x.enemies = nullptr; x.shields = nullptr; x.lasers = nullptr; x.rng = nullptr;
+        TBX_HIP(hipMalloc((void**)&x.rng, 2 * N * sizeof(uint64_t)));
+        TBX_HIP(hipMalloc((void**)&x.sc, (size_t)NF * N * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&x.enemies, N * NEF * 64 * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&x.shields, N * 64 * sizeof(uint32_t)));
+        TBX_HIP(hipMalloc((void**)&x.lasers, N * NLF * 16 * sizeof(int32_t)));
         return TBX_OK;
     }
 
-    int agent_snapshot(tbx_engine* e, int which, hipStream_t s) override
+    int agent_prepare(tbx_engine* e) override
     {
-        if (which != 0) return TBX_OK;                       // frame B is read from the live state
-        const size_t N = (size_t)e->n;
-        int rc = ensure_shadow(e);
+        int rc = alloc_slot(e, dA);
         if (rc) return rc;
-        TBX_HIP(hipMemcpyAsync(dA.sc, d.sc, (size_t)NF * N * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        TBX_HIP(hipMemcpyAsync(dA.enemies, d.enemies, N * NEF * 64 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        TBX_HIP(hipMemcpyAsync(dA.shields, d.shields, N * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        TBX_HIP(hipMemcpyAsync(dA.lasers, d.lasers, N * NLF * 16 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        return TBX_OK;
+        return alloc_slot(e, dB);
     }
 
     int agent_warp(tbx_engine* e, const AgentWarpArgs& a, hipStream_t s) override
     {
-        AgentWarpArgs w = a;
-        if (!dA.sc) w.two_frames = 0;                        // no snapshot yet (reset, or skip == 1): frame B alone
-        const SiDev& A = dA.sc ? dA : d;
         const dim3 grid = grid_for(e->n), block(TBX_BLOCK);
         switch (a.stack) {
-        case 1: hipLaunchKernelGGL(si_agent_warp_kernel<1>, grid, block, 0, s, A, d, w, e->n); break;
-        case 2: hipLaunchKernelGGL(si_agent_warp_kernel<2>, grid, block, 0, s, A, d, w, e->n); break;
-        case 3: hipLaunchKernelGGL(si_agent_warp_kernel<3>, grid, block, 0, s, A, d, w, e->n); break;
-        default: hipLaunchKernelGGL(si_agent_warp_kernel<4>, grid, block, 0, s, A, d, w, e->n); break;
+        case 1: hipLaunchKernelGGL(si_agent_warp_kernel<1>, grid, block, 0, s, d, dA, dB, a, e->n); break;
+        case 2: hipLaunchKernelGGL(si_agent_warp_kernel<2>, grid, block, 0, s, d, dA, dB, a, e->n); break;
+        case 3: hipLaunchKernelGGL(si_agent_warp_kernel<3>, grid, block, 0, s, d, dA, dB, a, e->n); break;
+        default: hipLaunchKernelGGL(si_agent_warp_kernel<4>, grid, block, 0, s, d, dA, dB, a, e->n); break;
         }
         TBX_HIP(hipGetLastError());
         return TBX_OK;
@@ -1272,12 +1271,24 @@ struct SiOps : GameOps {
     int agent_reset_envs(tbx_engine* e, const AgentResetArgs& r, hipStream_t s) override
     {
         const dim3 grid = r.list ? dim3(std::min<unsigned>(grid_for(e->n).x, 512u)) : grid_for(e->n);
-        hipLaunchKernelGGL(si_agent_reset_kernel, grid, dim3(TBX_BLOCK), 0, s, d, c, r);
+        hipLaunchKernelGGL(si_agent_reset_kernel, grid, dim3(TBX_BLOCK), 0, s, d, dA, dB, c, r);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 
+    int render_from(tbx_engine* e, int source, const uint8_t* pick_live, uint8_t* out_dev, int channels, hipStream_t s) override
+    {
+        const SiDev& src = source == 1 ? dA : source == 2 ? dB : d;
+        return render_impl(e, src, d, source ? pick_live : nullptr, out_dev, channels, 0, e->n, s);
+    }
+
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
+    {
+        return render_impl(e, d, d, nullptr, out_dev, channels, first_env, n_envs, s);
+    }
+
+    int render_impl(tbx_engine* e, const SiDev& src, const SiDev& alt, const uint8_t* pick_alt, uint8_t* out_dev, int channels, int first_env,
+                    int n_envs, hipStream_t s)
     {
         static const int skip_blank = getenv("TBX_SI_NO_SKIP") ? 0 : 1;   // diagnostic A/B switch
         static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
@@ -1285,9 +1296,9 @@ struct SiOps : GameOps {
         // would leave the chip under-filled (measured +10 % at 4 096 envs, +5 % at 16 384 with five waves per frame)
         const int split = split_env > 0 ? split_env : (channels != 1 && n_envs <= 32768) ? 5 : 1;
         switch (channels) {
-        case 1: hipLaunchKernelGGL(si_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank, split); break;
-        case 3: hipLaunchKernelGGL(si_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank, split); break;
-        case 4: hipLaunchKernelGGL(si_render_kernel<4>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, d, out_dev, first_env, n_envs, skip_blank, split); break;
+        case 1: hipLaunchKernelGGL(si_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); break;
+        case 3: hipLaunchKernelGGL(si_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); break;
+        case 4: hipLaunchKernelGGL(si_render_kernel<4>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
         TBX_HIP(hipGetLastError());

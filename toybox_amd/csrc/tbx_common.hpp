@@ -114,27 +114,45 @@ struct ActionSource {
     uint64_t seed, t, env_offset;
     int single_env;           // >= 0: only this env steps, with buttons `single_buttons`
     uint32_t single_buttons;
-    // agent layer (MaxAndSkipEnv): sum this frame's reward into acc_reward[env] until the env is done (acc_done[env]);
-    // acc_first: the first of the `skip` frames starts the sums over
+    // agent layer (MaxAndSkipEnv.step, atari_wrappers.py:201-216): sum the rewards of the agent step's frames into
+    // acc_reward[env] and latch acc_done[env]; an env whose game has ended does not run the remaining frames
     int32_t* acc_reward;
     uint8_t* acc_done;
-    int acc_first;
-    // agent layer (games with GameOps::multi_frame_step): run `frames` frames of the same action in ONE launch with the
-    // state held in registers (0 means 1), and store the state after `snapshot_after` frames (0 = never) to the game's
-    // shadow arrays as well: it is frame A of the observation
+    // one launch runs `frames` frames of the same action with the state held in registers (0 means 1; games with
+    // GameOps::multi_frame_step run the whole action repeat in ONE launch); frame0 = frames of this agent step that earlier
+    // launches already ran
     int frames;
-    int snapshot_after;
+    int frame0;
+    // MaxAndSkipEnv._obs_buffer, kept as two persistent state snapshots per env ("slot A" / "slot B", what the rasteriser
+    // needs to repaint the frame): written after snap_a_after / snap_b_after frames of the agent step (0 = never), i.e. by
+    // frame skip-2 and frame skip-1, and only by envs that get that far.  buf_valid[env] bit 0 / 1: the slot has been written
+    // since construction (until then it is the zero frame of np.zeros).
+    int snap_a_after, snap_b_after;
+    uint8_t* buf_valid;
+    // single-frame launches (games without multi_frame_step): 1 if the env ran this frame, for the snapshot kernel that follows
+    uint8_t* exec_flag;
 };
 
-// frame: index of this frame inside a multi-frame launch
+// this env's game ended in an earlier launch of the same agent step: MaxAndSkipEnv has left its loop
+__device__ __forceinline__ bool tbx_agent_env_finished(const ActionSource& src, int env)
+{
+    return src.acc_done && src.frame0 > 0 && src.acc_done[env] != 0;
+}
+
+// frame: index of this frame inside the launch
 __device__ __forceinline__ void tbx_accumulate(const ActionSource& src, int env, int32_t rew, bool is_done, int frame = 0)
 {
     if (!src.acc_reward) return;
-    const bool first = src.acc_first && frame == 0;
-    const bool was_done = first ? false : src.acc_done[env] != 0;
-    if (was_done) return;
+    const bool first = src.frame0 + frame == 0;
     src.acc_reward[env] = (first ? 0 : src.acc_reward[env]) + rew;
     src.acc_done[env] = is_done ? 1 : 0;
+}
+
+// which buffer slots frame number `done_frames` (1-based count of frames run in this agent step) writes: bit 0 = A, bit 1 = B
+__device__ __forceinline__ uint32_t tbx_snap_slots(const ActionSource& src, int frame)
+{
+    const int g = src.frame0 + frame + 1;
+    return (g == src.snap_a_after ? 1u : 0u) | (g == src.snap_b_after ? 2u : 0u);
 }
 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -252,13 +270,19 @@ struct GameOps {
     virtual int pack_state(tbx_engine* e, int env, int count, hipStream_t s) = 0;
     virtual int unpack_state(tbx_engine* e, int env, int count, const void* pod_host, hipStream_t s) = 0;
     virtual int scalars(tbx_engine* e, int32_t* score_dev, int32_t* lives_dev, int32_t* level_dev, hipStream_t s) = 0;
-    // optional fused observation path of the agent layer (agent.hip): snapshot what the rasteriser needs of the current
-    // state as frame A (which = 0) or frame B (1), then produce the warped, max'd, stacked observation from the two
+    // ---- agent layer (agent.hip).  The two-frame buffer of MaxAndSkipEnv lives with the game as two snapshot slots.
+    virtual int agent_prepare(tbx_engine*) { return TBX_OK; }  // allocate the slots
+    virtual bool multi_frame_step() const { return false; }   // step() honours ActionSource::frames and writes the slots itself
+    // single-frame launches: copy the live state of the envs with exec_flag set into slot 0 (A) / 1 (B), set their valid bit
+    virtual int agent_snapshot(tbx_engine*, int /*slot*/, const uint8_t* /*exec_flag*/, uint8_t* /*buf_valid*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    // fused observation kernels (no full-resolution frame leaves the chip)
     virtual bool agent_fused() const { return false; }
-    virtual int agent_snapshot(tbx_engine*, int /*which*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
-    virtual bool multi_frame_step() const { return false; }   // step() honours ActionSource::frames / snapshot_after
     virtual int agent_warp(tbx_engine*, const struct AgentWarpArgs&, hipStream_t) { return TBX_E_UNSUPPORTED; }
-    // reset-time wrappers (episodic life / fire reset / no-op reset) for the envs flagged in AgentResetArgs::kind
+    // generic path: full-resolution gray frames of slot A (source 1), slot B (2) or the live state (0); envs whose
+    // pick_live byte is non-zero are painted from the live state instead
+    virtual int render_from(tbx_engine*, int /*source*/, const uint8_t* /*pick_live*/, uint8_t* /*out_dev*/, int /*channels*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    // the reset path of the wrapper stack, run in-kernel for the envs flagged in AgentResetArgs::kind
+    virtual bool agent_reset_supported() const { return false; }
     virtual int agent_reset_envs(tbx_engine*, const struct AgentResetArgs&, hipStream_t) { return TBX_E_UNSUPPORTED; }
 };
 

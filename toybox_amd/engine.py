@@ -187,20 +187,34 @@ class Engine:
         self._check(self._lib.tbx_agent_init(self._h, C.byref(cfg)))
         self._agent_shape = (self.n_envs, int(out_h), int(out_w), int(stack))
 
+    def agent_set_noops(self, counts):
+        """NoopResetEnv.override_num_noops per env (counts[i] > 0 overrides, 0 keeps the default rule); None removes it."""
+        if counts is None:
+            self._check(self._lib.tbx_agent_set_noops(self._h, None))
+            return
+        a = np.ascontiguousarray(counts, dtype=np.int32)
+        if a.shape != (self.n_envs,):
+            raise ValueError("counts must have shape (%d,)" % self.n_envs)
+        self._check(self._lib.tbx_agent_set_noops(self._h, _ptr(a)))
+
     def agent_reset(self):
         obs = np.empty(self._agent_shape, np.uint8)
         self._check(self._lib.tbx_agent_reset(self._h, _ptr(obs)))
         return obs
 
-    def agent_step(self, actions):
-        """actions: ALE ids.  Returns (obs uint8[N,oh,ow,stack], reward float32[N], done bool[N])."""
+    def agent_step(self, actions, tolerate_needs_reset=False):
+        """actions: ALE ids.  Returns (obs uint8[N,oh,ow,stack], reward float32[N], done bool[N]).
+        TBX_E_NEEDS_RESET (where bench.Monitor raises) is raised like every other error unless tolerate_needs_reset: the step
+        has been carried out either way and the outputs are valid."""
         a = np.ascontiguousarray(actions, dtype=np.int32)
         if a.shape != (self.n_envs,):
             raise ValueError("actions must have shape (%d,)" % self.n_envs)
         obs = np.empty(self._agent_shape, np.uint8)
         reward = np.empty(self.n_envs, np.float32)
         done = np.empty(self.n_envs, np.uint8)
-        self._check(self._lib.tbx_agent_step(self._h, _ptr(a), _ptr(reward), _ptr(done), _ptr(obs)))
+        rc = self._lib.tbx_agent_step(self._h, _ptr(a), _ptr(reward), _ptr(done), _ptr(obs))
+        if not (tolerate_needs_reset and rc == _abi.E_NEEDS_RESET):
+            self._check(rc)
         return obs, reward, done.astype(bool)
 
     def agent_episodes(self):
