@@ -1187,8 +1187,11 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
         return;
     }
     const bool fresh = !sel.two;                           // one frame alone: record B is its source, record A is not composed
+    // the SOURCE ARRAY is selected (wave-uniform pointer), then one scalar load: a select between loaded records would
+    // move them into vector registers
+    const BrkRenderRec* __restrict__ srcB = sel.single == 0 ? recsLive : sel.single == 1 ? recsA : recsB;
     const BrkRenderRec recA = recsA[env];
-    const BrkRenderRec recB = sel.single == 0 ? recsLive[env] : sel.single == 1 ? recA : recsB[env];
+    const BrkRenderRec recB = srcB[env];
     const int x0 = lane * 4;
     const bool active = x0 < W;
     const uint32_t half = (uint32_t)(H * W) / 2u;
