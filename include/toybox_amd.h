@@ -374,6 +374,14 @@ int tbx_step_device(tbx_engine* engine, const int32_t* ale_actions_dev, uint32_t
  * legal[ splitmix64(action_seed ^ (e_global << 32) ^ t) mod n_legal ], e_global = env_offset + e. */
 int tbx_step_synthetic(tbx_engine* engine, uint64_t action_seed, uint64_t t, uint64_t env_offset,
                        uint32_t flags, void* stream);
+/* One frame for ONE env by ALE action id, with the outputs of tbx_step: out[4] = {reward, done, lives, score} (may be NULL).
+ * replaces the reference's per-frame call sequence Toybox.apply_ale_action + get_score / get_lives / game_over on a single
+ * env (envs/atari/base.py:126-145, test/benchmark.py:50-56).  On a ONE-env engine this call does not launch anything: a
+ * resident kernel (one wave) waits on a mailbox in host-coherent pinned memory, steps env 0 and posts the outputs back --
+ * two PCIe hops per frame.  The wave leaves after 50 ms without a request and every other entry point of the handle stops it
+ * first, so the two never run side by side.  On batch engines it is tbx_apply_input plus a read-back of the outputs.
+ * TBX_NO_SERVER=1 in the environment forces that second form everywhere. */
+int tbx_step1(tbx_engine* engine, int env, int32_t ale_action, uint32_t flags, int32_t out[4]);
 /* One frame for one env with a raw button mask.
  * replaces Toybox.apply_action(Input) (scripts/utils/test_games.py:13). */
 int tbx_apply_input(tbx_engine* engine, int env, uint32_t buttons);

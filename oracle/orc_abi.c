@@ -269,6 +269,24 @@ int tbx_apply_input(tbx_engine* e, int env, uint32_t buttons)
     return TBX_OK;
 }
 
+int tbx_step1(tbx_engine* e, int env, int32_t ale_action, uint32_t flags, int32_t out[4])
+{
+    if (!e) return TBX_E_INVALID;
+    if (env < 0 || env >= e->n) return fail(e, TBX_E_INVALID, "env index out of range");
+    int b = orc_ale_action_to_buttons(ale_action);
+    const int bad = b < 0;
+    int rc = tbx_apply_input(e, env, bad ? 0u : (uint32_t)b);
+    if (rc) return rc;
+    if (out) { out[0] = e->reward[env]; out[1] = e->done[env]; out[2] = e->lives[env]; out[3] = e->score[env]; }
+    if ((flags & TBX_STEP_AUTO_RESET) && e->done[env]) {
+        uint8_t* mask = (uint8_t*)calloc((size_t)e->n, 1);
+        mask[env] = 1;
+        orc_new_game_batch(e->game, e->cfg, e->states, e->sim, e->prev, e->n, mask);
+        free(mask);
+    }
+    return bad ? fail(e, TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)") : TBX_OK;
+}
+
 int tbx_get_scalars(tbx_engine* e, int32_t* score, int32_t* lives, int32_t* level, uint8_t* over)
 {
     if (!e) return TBX_E_INVALID;

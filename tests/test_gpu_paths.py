@@ -391,3 +391,61 @@ def test_gather_overlaps_with_render_and_keeps_parity(hip_lib, oracle_lib):
     st.synchronize()
     _same_states(g, o, range(0, n, 211), "end")
     st.close()
+
+
+@pytest.mark.parametrize("game", GAMES)
+def test_step1_equals_batch_step(game, lib, oracle_lib):
+    """tbx_step1 (one frame of one env by ALE id, outputs included) == tbx_step on a twin engine -- on a one-env engine of
+    the HIP library this is the resident step kernel (mailbox in pinned memory, no launch per frame), interleaved here with
+    calls that stop it (frames, state reads and writes, new games), idle pauses that let it leave, and an illegal action."""
+    import time
+    a1, ref = Engine(game, 1, lib=lib), Engine(game, 1, lib=oracle_lib)
+    for e in (a1, ref):
+        e.seed(21)
+        e.new_game()
+    rng = np.random.default_rng(3)
+    for t in range(2500):
+        a = int(synthetic_actions(game, 1, t)[0])
+        r, d, l, s = a1.step1(0, a, auto_reset=True)
+        rr, dd, ll, ss = ref.step([a], auto_reset=True)
+        assert (r, d, l, s) == (int(rr[0]), bool(dd[0]), int(ll[0]), int(ss[0])), t
+        k = rng.random()
+        if k < 0.01:
+            assert np.array_equal(a1.render_env(0, 3), ref.render_env(0, 3)), t
+        elif k < 0.02:
+            assert bytes(a1.get_state(0)) == bytes(ref.get_state(0)), t
+        elif k < 0.025:
+            st = ref.get_state(0)
+            a1.set_state(0, st)
+            ref.set_state(0, st)
+        elif k < 0.03:
+            a1.new_game()
+            ref.new_game()
+        elif k < 0.032:
+            time.sleep(0.08)                      # longer than the resident kernel's idle time: it leaves, the next call restarts it
+    assert bytes(a1.get_state(0)) == bytes(ref.get_state(0))
+    with pytest.raises(ToyboxAmdError) as ei:
+        a1.step1(0, 99)
+    assert ei.value.code == _abi.E_ACTION
+    a1.step1(0, 0)
+    ref.step([0])
+    ref.step([0])
+    assert bytes(a1.get_state(0)) == bytes(ref.get_state(0))
+    a1.close()
+
+
+def test_step1_on_a_batch_engine(lib, oracle_lib):
+    n = 5
+    e, ref = Engine("breakout", n, lib=lib), Engine("breakout", n, lib=oracle_lib)
+    for x in (e, ref):
+        x.seed(2)
+        x.new_game()
+    for t in range(200):
+        env = t % n
+        a = int(synthetic_actions("breakout", n, t)[env])
+        out = e.step1(env, a)
+        ref.apply_input(env, BUTTONS[a])
+        sc, lv, _, _ = ref.scalars()
+        assert out[2] == int(lv[env]) and out[3] == int(sc[env])
+    for i in range(n):
+        assert bytes(e.get_state(i)) == bytes(ref.get_state(i))

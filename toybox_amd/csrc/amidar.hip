@@ -565,12 +565,9 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_new_game_kernel(AmiDev d, const
     }
 }
 
-__global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, AmiDev slot_a, AmiDev slot_b, ActionSource src, uint32_t flags, int first_env, int count)
+// one frame (or the agent layer's whole action repeat) of one env on one wave
+__device__ __forceinline__ void ami_step_body(const AmiDev& d, const AmiDev& slot_a, const AmiDev& slot_b, const ActionSource& src, uint32_t flags, int env, int lane)
 {
-    const int lane = threadIdx.x & 63;
-    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-    if (rel >= count) return;
-    const int env = first_env + rel;
     const size_t N = (size_t)d.n;
     if (src.exec_flag && lane == 0) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
     if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
@@ -632,6 +629,23 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, AmiDev sl
         uint32_t lv = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
         d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv << 40);
     }
+}
+
+
+__global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, AmiDev slot_a, AmiDev slot_b, ActionSource src, uint32_t flags, int first_env, int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (rel >= count) return;
+    ami_step_body(d, slot_a, slot_b, src, flags, first_env + rel, lane);
+}
+
+// resident single-env form (tbx_serve_loop, tbx_common.hpp): one wave, env 0
+__global__ __launch_bounds__(64) void ami_serve_kernel(AmiDev d, TbxServeCtl* ctl)
+{
+    const int lane = threadIdx.x & 63;
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { ami_step_body(d, d, d, src, flags, 0, lane); },
+                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
 // reset-time wrappers of the agent layer for the envs flagged in r.kind (agent_device.hpp, AgentResetProc)
@@ -1149,6 +1163,13 @@ struct AmiOps : GameOps {
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         dA.tab = dB.tab = d.tab;
         hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int serve(tbx_engine* e, TbxServeCtl* ctl_dev, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(ami_serve_kernel, dim3(1), dim3(64), 0, s, d, ctl_dev);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

@@ -277,14 +277,10 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_new_game_kernel(BrkDev d, BrkCf
 
 // ------------------------------------------------------------------ step
 
+// one frame of one env on one wave
 template <bool CUSTOM>
-__global__ __launch_bounds__(TBX_BLOCK) void brk_step_kernel(BrkDev d, BrkCfg c, ActionSource src, uint32_t flags,
-                                                             int first_env, int count)
+__device__ __forceinline__ void brk_step_body(const BrkDev& d, const BrkCfg& c, const ActionSource& src, uint32_t flags, int env, int lane)
 {
-    const int lane = threadIdx.x & 63;
-    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-    if (rel >= count) return;
-    const int env = first_env + rel;
     const size_t N = (size_t)d.n;
     if (src.exec_flag && lane == 0) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
     if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
@@ -499,6 +495,25 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_step_kernel(BrkDev d, BrkCfg c,
         d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv << 40);
         tbx_accumulate(src, env, rew, is_done);
     }
+}
+
+
+template <bool CUSTOM>
+__global__ __launch_bounds__(TBX_BLOCK) void brk_step_kernel(BrkDev d, BrkCfg c, ActionSource src, uint32_t flags, int first_env, int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (rel >= count) return;
+    brk_step_body<CUSTOM>(d, c, src, flags, first_env + rel, lane);
+}
+
+// resident single-env form (tbx_serve_loop, tbx_common.hpp): one wave, env 0
+template <bool CUSTOM>
+__global__ __launch_bounds__(64) void brk_serve_kernel(BrkDev d, BrkCfg c, TbxServeCtl* ctl)
+{
+    const int lane = threadIdx.x & 63;
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { brk_step_body<CUSTOM>(d, c, src, flags, 0, lane); },
+                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
 // ------------------------------------------------------------------ step, thread per env (canonical wall)
@@ -748,24 +763,26 @@ __device__ __forceinline__ void brk_t_step(const BrkCfg& c, BrkT& s, uint32_t bu
 
 }
 
-__global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, ActionSource src, uint32_t flags, BrkRenderRec* recs,
-                                                           BrkRenderRec* recs_a, BrkRenderRec* recs_b)
+// one frame (or the agent layer's whole action repeat) of one env on one THREAD
+__device__ __forceinline__ void brk_step_tpe_body(const BrkDev& d, const BrkCfg& c, const ActionSource& src, uint32_t flags, BrkRenderRec* recs,
+                                                  BrkRenderRec* recs_a, BrkRenderRec* recs_b, int env)
 {
-    const BrkCfg& c = *cp;   // tables are indexed per thread: read them from memory, not from the kernel arguments
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= d.n) return;
     const size_t N = (size_t)d.n;
     if (src.exec_flag) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
     if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
 
-    int a;
-    if (src.actions) a = src.actions[env];
+    uint32_t buttons;
+    if (src.single_env >= 0) buttons = src.single_buttons;
     else {
-        const uint64_t h = tbx_splitmix64(src.seed ^ ((src.env_offset + (uint64_t)env) << 32) ^ src.t);
-        a = tbx_legal_action(TBX_GAME_BREAKOUT, (int)(h % 4ull));
+        int a;
+        if (src.actions) a = src.actions[env];
+        else {
+            const uint64_t h = tbx_splitmix64(src.seed ^ ((src.env_offset + (uint64_t)env) << 32) ^ src.t);
+            a = tbx_legal_action(TBX_GAME_BREAKOUT, (int)(h % 4ull));
+        }
+        buttons = tbx_ale_buttons(a);
+        if (buttons == 0xFFu) { buttons = 0; atomicOr(d.err_flag, 1u); }
     }
-    uint32_t buttons = tbx_ale_buttons(a);
-    if (buttons == 0xFFu) { buttons = 0; atomicOr(d.err_flag, 1u); }
 
     BrkT s;
     t_load(d, env, s);
@@ -808,6 +825,23 @@ __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCf
     const uint32_t lv8 = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
     d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv8 << 40);
     recs[env] = t_record(s);
+}
+
+
+__global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, ActionSource src, uint32_t flags, BrkRenderRec* recs,
+                                                           BrkRenderRec* recs_a, BrkRenderRec* recs_b)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n) return;
+    brk_step_tpe_body(d, *cp, src, flags, recs, recs_a, recs_b, env);   // tables are indexed per thread: read from memory, not from kernel arguments
+}
+
+// resident single-env form (tbx_serve_loop, tbx_common.hpp): lane 0 of one wave, env 0
+__global__ __launch_bounds__(64) void brk_serve_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, BrkRenderRec* recs, TbxServeCtl* ctl)
+{
+    const int lane = threadIdx.x & 63;
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { if (lane == 0) brk_step_tpe_body(d, *cp, src, flags, recs, nullptr, nullptr, 0); },
+                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
 // reset-time wrappers of the agent layer for the envs flagged in r.kind (agent_device.hpp, AgentResetProc)
@@ -1524,6 +1558,16 @@ struct BreakoutOps : GameOps {
         else hipLaunchKernelGGL(brk_step_kernel<false>, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         recs_valid = false;
+        return TBX_OK;
+    }
+
+    int serve(tbx_engine* e, TbxServeCtl* ctl_dev, hipStream_t s) override
+    {
+        if (custom) hipLaunchKernelGGL(brk_serve_kernel<true>, dim3(1), dim3(64), 0, s, d, c, ctl_dev);
+        else if (use_tpe) hipLaunchKernelGGL(brk_serve_tpe_kernel, dim3(1), dim3(64), 0, s, d, cfg_dev, recs, ctl_dev);
+        else hipLaunchKernelGGL(brk_serve_kernel<false>, dim3(1), dim3(64), 0, s, d, c, ctl_dev);
+        TBX_HIP(hipGetLastError());
+        recs_valid = false;         // (the thread-per-env form keeps env 0's record current, but nothing here relies on it)
         return TBX_OK;
     }
 

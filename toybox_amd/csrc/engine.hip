@@ -269,6 +269,9 @@ int tbx_destroy(tbx_engine* e)
 {
     if (!e) return TBX_OK;
     hipSetDevice(e->device);
+    tbx_serve_stop(e);
+    if (e->serve_stream) hipStreamDestroy(e->serve_stream);
+    if (e->serve_ctl) hipHostFree(e->serve_ctl);
     if (e->stream) hipStreamSynchronize(e->stream);
     tbx_gather_free(e);
     tbx_agent_free(e);
@@ -515,6 +518,119 @@ int tbx_step(tbx_engine* e, const int32_t* actions_host, uint32_t flags, int32_t
     return TBX_OK;
 }
 
+// ---- resident single-env step (TbxServeCtl, tbx_common.hpp)
+
+static int serve_start(tbx_engine* e)
+{
+    if (!e->serve_ctl) {
+        EHIP(hipHostMalloc((void**)&e->serve_ctl, sizeof(TbxServeCtl), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(e->serve_ctl, 0, sizeof(TbxServeCtl));
+        EHIP(hipHostGetDevicePointer((void**)&e->serve_ctl_dev, e->serve_ctl, 0));
+        EHIP(hipStreamCreateWithFlags(&e->serve_stream, hipStreamNonBlocking));
+    }
+    TbxServeCtl* c = e->serve_ctl;
+    c->exited = 0;
+    c->ack_seq = e->serve_seq;
+    c->req = (uint64_t)e->serve_seq;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    // ordered after everything queued through the handle so far
+    EHIP(tbx_use_stream(e, e->serve_stream));
+    int rc = e->ops->serve(e, e->serve_ctl_dev, e->serve_stream);
+    if (rc) return rc;
+    e->serve_running = true;
+    return TBX_OK;
+}
+
+}  // extern "C"
+
+hipError_t tbx_serve_stop(tbx_engine* e)
+{
+    if (!e->serve_running) return hipSuccess;
+    __atomic_store_n(&e->serve_ctl->req, (uint64_t)e->serve_seq | TBX_SERVE_STOP, __ATOMIC_RELEASE);
+    hipError_t r = hipStreamSynchronize(e->serve_stream);     // the wave leaves at its next poll
+    e->serve_running = false;
+    return r;
+}
+
+extern "C" {
+
+int tbx_step1(tbx_engine* e, int env, int32_t ale_action, uint32_t flags, int32_t out[4])
+{
+    CHECK_ENGINE(e);
+    if (env < 0 || env >= e->n) return e->fail(TBX_E_INVALID, "env index out of range");
+    EHIP(hipSetDevice(e->device));
+    static const bool no_server = getenv("TBX_NO_SERVER") != nullptr;
+    if (e->n == 1 && !no_server && !e->gather) {
+        // the resident kernel: post the request, spin on the acknowledgement (no launch, no copy, no synchronisation)
+        TbxServeCtl* c = e->serve_ctl;
+        if (!e->serve_running || __atomic_load_n(&c->exited, __ATOMIC_ACQUIRE)) {
+            if (e->serve_running) { EHIP(hipStreamSynchronize(e->serve_stream)); e->serve_running = false; }
+            int rc = serve_start(e);
+            if (rc == TBX_E_UNSUPPORTED) goto slow;
+            if (rc) return rc;
+            c = e->serve_ctl;
+        }
+        {
+            const uint32_t seq = ++e->serve_seq;
+            const uint64_t word = tbx_serve_word(seq, ale_action, flags);
+            __atomic_store_n(&c->req, word, __ATOMIC_RELEASE);
+            unsigned long spins = 0;
+            while (__atomic_load_n(&c->ack_seq, __ATOMIC_ACQUIRE) != seq) {
+                if ((++spins & 0xFFFul) == 0) {
+                    if (__atomic_load_n(&c->exited, __ATOMIC_ACQUIRE) && __atomic_load_n(&c->ack_seq, __ATOMIC_ACQUIRE) != seq) {
+                        // the wave went idle and left just as the request arrived: start another, it serves the pending request
+                        EHIP(hipStreamSynchronize(e->serve_stream));
+                        e->serve_running = false;
+                        e->serve_seq = seq - 1;
+                        int rc = serve_start(e);
+                        if (rc) return rc;
+                        e->serve_seq = seq;
+                        __atomic_store_n(&c->req, word, __ATOMIC_RELEASE);
+                    }
+                    if (spins > (1ul << 33)) return e->fail(TBX_E_NO_DEVICE, "the resident step kernel does not answer");
+                }
+                __builtin_ia32_pause();
+            }
+            const uint32_t de = c->done_err;
+            if (out) { out[0] = c->reward; out[1] = (int32_t)(de & 1u); out[2] = c->lives; out[3] = c->score; }
+            if (de & 2u) return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
+            return TBX_OK;
+        }
+    }
+slow:
+    {
+        // any env of a batch engine: the single-env launch of tbx_apply_input, then its outputs
+        const uint32_t b = tbx_ale_buttons(ale_action);
+        int rc = tbx_apply_input(e, env, b == 0xFFu ? 0u : b);
+        if (rc) return rc;
+        if (flags & TBX_STEP_AUTO_RESET) {
+            // (rare on this path) a finished game starts over, as in tbx_step
+            int32_t lv = 0;
+            EHIP(hipMemcpy(&lv, e->lives_out + env, 4, hipMemcpyDeviceToHost));
+            if (lv <= 0) {
+                std::vector<uint8_t> mask((size_t)e->n, 0);
+                mask[(size_t)env] = 1;
+                int32_t o[4];
+                EHIP(hipMemcpy(&o[0], e->reward + env, 4, hipMemcpyDeviceToHost));
+                EHIP(hipMemcpy(&o[3], e->score_out + env, 4, hipMemcpyDeviceToHost));
+                rc = tbx_new_game(e, mask.data());
+                if (rc) return rc;
+                if (out) { out[0] = o[0]; out[1] = 1; out[2] = lv; out[3] = o[3]; }
+                return b == 0xFFu ? e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)") : TBX_OK;
+            }
+        }
+        if (out) {
+            uint8_t dn = 0;
+            EHIP(hipMemcpy(&out[0], e->reward + env, 4, hipMemcpyDeviceToHost));
+            EHIP(hipMemcpy(&dn, e->done + env, 1, hipMemcpyDeviceToHost));
+            EHIP(hipMemcpy(&out[2], e->lives_out + env, 4, hipMemcpyDeviceToHost));
+            EHIP(hipMemcpy(&out[3], e->score_out + env, 4, hipMemcpyDeviceToHost));
+            out[1] = dn;
+        }
+        return b == 0xFFu ? e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)") : TBX_OK;
+    }
+}
+
 int tbx_apply_input(tbx_engine* e, int env, uint32_t buttons)
 {
     CHECK_ENGINE(e);
@@ -731,6 +847,7 @@ int tbx_sync(tbx_engine* e)
 {
     CHECK_ENGINE(e);
     EHIP(hipSetDevice(e->device));
+    EHIP(tbx_serve_stop(e));
     EHIP(hipDeviceSynchronize());
     return check_err_flag(e);
 }

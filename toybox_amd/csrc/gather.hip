@@ -139,6 +139,7 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
     if (records_per_rank < e->n) return e->fail(TBX_E_INVALID, "gather: records_per_rank must be >= the engine's env count");
     if (!id || id_bytes != TBX_GATHER_ID_BYTES) return e->fail(TBX_E_INVALID, "gather: id must be TBX_GATHER_ID_BYTES long");
     GHIP(hipSetDevice(e->device));
+    GHIP(tbx_serve_stop(e));
     tbx_gather_free(e);
     e->gather = new GatherState();
     GatherState& g = *e->gather;

@@ -119,11 +119,9 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_new_game_kernel(GwDev d, const u
     }
 }
 
-__global__ __launch_bounds__(128) void gw_step_kernel(GwDev d, ActionSource src, uint32_t flags, int first_env, int count)
+// one frame of one env on one thread
+__device__ __forceinline__ void gw_step_body(const GwDev& d, const ActionSource& src, uint32_t flags, int env)
 {
-    const int rel = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rel >= count) return;
-    const int env = first_env + rel;
     if (src.exec_flag) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
     if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
     uint32_t buttons;
@@ -168,6 +166,22 @@ __global__ __launch_bounds__(128) void gw_step_kernel(GwDev d, ActionSource src,
     d.score_out[env] = out_score;
     d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)(uint32_t)out_lives << 40);
     tbx_accumulate(src, env, rew, is_done);
+}
+
+
+__global__ __launch_bounds__(128) void gw_step_kernel(GwDev d, ActionSource src, uint32_t flags, int first_env, int count)
+{
+    const int rel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rel >= count) return;
+    gw_step_body(d, src, flags, first_env + rel);
+}
+
+// resident single-env form (tbx_serve_loop, tbx_common.hpp): lane 0 of one wave, env 0
+__global__ __launch_bounds__(64) void gw_serve_kernel(GwDev d, TbxServeCtl* ctl)
+{
+    const int lane = threadIdx.x & 63;
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { if (lane == 0) gw_step_body(d, src, flags, 0); },
+                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
 // reset-time wrappers of the agent layer (agent_device.hpp, AgentResetProc), thread per flagged env
@@ -522,6 +536,13 @@ struct GridWorldOps : GameOps {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         hipLaunchKernelGGL(gw_step_kernel, dim3((count + 127) / 128), dim3(128), 0, s, d, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int serve(tbx_engine* e, TbxServeCtl* ctl_dev, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(gw_serve_kernel, dim3(1), dim3(64), 0, s, d, ctl_dev);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

@@ -501,12 +501,9 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_new_game_kernel(SiDev d, SiCfg c
     }
 }
 
-__global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiDev slot_a, SiDev slot_b, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
+// one frame (or the agent layer's whole action repeat) of one env on one wave
+__device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a, const SiDev& slot_b, const SiCfg& c, const ActionSource& src, uint32_t flags, int env, int lane)
 {
-    const int lane = threadIdx.x & 63;
-    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-    if (rel >= count) return;
-    const int env = first_env + rel;
     const size_t N = (size_t)d.n;
     if (src.exec_flag && lane == 0) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
     if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
@@ -568,6 +565,23 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiDev slot_
         uint32_t lv = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
         d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv << 40);
     }
+}
+
+
+__global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiDev slot_a, SiDev slot_b, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (rel >= count) return;
+    si_step_body(d, slot_a, slot_b, c, src, flags, first_env + rel, lane);
+}
+
+// resident single-env form (tbx_serve_loop, tbx_common.hpp): one wave, env 0
+__global__ __launch_bounds__(64) void si_serve_kernel(SiDev d, SiCfg c, TbxServeCtl* ctl)
+{
+    const int lane = threadIdx.x & 63;
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { si_step_body(d, d, d, c, src, flags, 0, lane); },
+                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
 // reset-time wrappers of the agent layer for the envs flagged in r.kind (agent_device.hpp, AgentResetProc)
@@ -1360,6 +1374,13 @@ struct SiOps : GameOps {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, c, src, flags, first, count);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    int serve(tbx_engine* e, TbxServeCtl* ctl_dev, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(si_serve_kernel, dim3(1), dim3(64), 0, s, d, c, ctl_dev);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

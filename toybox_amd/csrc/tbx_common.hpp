@@ -186,6 +186,85 @@ __device__ __forceinline__ int f2i(double v)
     return (int)v;
 }
 
+// ------------------------------------------------------------------ resident single-env step ("server" kernel)
+//
+// The reference's whole user-facing surface is single-env: Toybox.apply_ale_action + get_score / get_lives / game_over, one FFI
+// round trip per frame (test/benchmark.py:50-56).  On a GPU that loop is pure latency: a launch, a host-device copy each
+// way and a stream synchronisation are ~30 us.  For a one-env engine tbx_step1 therefore talks to a RESIDENT kernel
+// instead: one wave that waits on a mailbox in host-coherent pinned memory, runs the game's ordinary step body for env 0
+// and posts the outputs back -- two PCIe hops per frame, no launch, no copy, no synchronisation.  The wave leaves by
+// itself after TBX_SERVE_IDLE_TICKS without a request (or when told to), and every other entry point of the handle stops
+// it first, so nothing else ever runs beside it on the env's state.
+struct TbxServeCtl {
+    // host -> device: ONE 64-bit word, so that a single PCIe read per poll brings the whole request:
+    //   bits 0..31 request number, 32..47 ALE action id (int16), 48..55 TBX_STEP_* flags, 63 "leave now"
+    uint64_t req;
+    uint64_t _pad0[7];
+    // device -> host (its own cache line): outputs, then the request number they belong to (written last)
+    int32_t reward, lives, score;
+    uint32_t done_err;       // bit 0 done, bit 1 illegal action id
+    uint32_t ack_seq;
+    uint32_t exited;
+    uint32_t _pad1[10];
+};
+constexpr unsigned long long TBX_SERVE_IDLE_TICKS = 5000000ull;   // 50 ms of the 100 MHz s_memrealtime clock
+constexpr uint64_t TBX_SERVE_STOP = 1ull << 63;
+
+__host__ __device__ __forceinline__ uint64_t tbx_serve_word(uint32_t seq, int action, uint32_t flags)
+{
+    // ids outside int16 are all illegal anyway: clamp them onto one illegal id
+    const int a = action < -32768 || action > 32767 ? 32767 : action;
+    return (uint64_t)seq | ((uint64_t)(uint16_t)(int16_t)a << 32) | ((uint64_t)(flags & 0xFFu) << 48);
+}
+
+// step(src, flags) runs one frame of env 0 on the calling wave (every lane calls it; outputs land in out_* [0])
+template <class StepFn>
+__device__ __forceinline__ void tbx_serve_loop(TbxServeCtl* ctl, int lane, StepFn step, const int32_t* out_reward, const uint8_t* out_done,
+                                               const int32_t* out_lives, const int32_t* out_score, uint32_t* err_flag)
+{
+    uint32_t last = __hip_atomic_load(&ctl->ack_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (;;) {
+        uint64_t w = last;
+        bool idle_out = false;
+        if (lane == 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned polls = 0;
+            for (;;) {
+                w = __hip_atomic_load(&ctl->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((uint32_t)w != last || (w & TBX_SERVE_STOP)) break;
+                if ((++polls & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > TBX_SERVE_IDLE_TICKS) { idle_out = true; break; }
+            }
+        }
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32));
+        idle_out = __builtin_amdgcn_readfirstlane((int)idle_out) != 0;
+        const uint32_t seq = lo;
+        if (seq == last) {                                   // nothing to serve: told to leave, or idle for too long
+            if ((hi >> 31) || idle_out) {                    // (a request that raced with the stop bit is served first)
+                if (lane == 0) __hip_atomic_store(&ctl->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+            continue;
+        }
+        const int action = (int)(int16_t)(hi & 0xFFFFu);
+        const uint32_t flags = (hi >> 16) & 0xFFu;
+        ActionSource src{};
+        uint32_t buttons = tbx_ale_buttons(action);
+        uint32_t err = 0;
+        if (buttons == 0xFFu) { buttons = 0; err = 2; }      // illegal id: NOOP + TBX_E_ACTION, as in the batch kernels
+        src.single_env = 0;
+        src.single_buttons = buttons;
+        step(src, flags);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (lane == 0) {
+            ctl->reward = out_reward[0]; ctl->lives = out_lives[0]; ctl->score = out_score[0];
+            ctl->done_err = (out_done[0] ? 1u : 0u) | err;
+            __hip_atomic_store(&ctl->ack_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        last = seq;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 
 struct GameOps;
@@ -223,6 +302,12 @@ struct tbx_engine {
     GameOps* ops = nullptr;
     struct AgentState* agent = nullptr;   // fused agent-side preprocessing (agent.hip), lazily created
     struct GatherState* gather = nullptr; // multi-GPU record gather over RCCL (gather.hip), created by tbx_gather_init
+    // resident single-env step kernel (tbx_step1 on one-env engines)
+    TbxServeCtl* serve_ctl = nullptr;     // host-coherent pinned mailbox (host address)
+    TbxServeCtl* serve_ctl_dev = nullptr; // its device address
+    hipStream_t serve_stream = nullptr;
+    bool serve_running = false;           // a server kernel has been launched and not yet been seen to exit
+    uint32_t serve_seq = 0;
 
     int fail(int code, const std::string& msg) const
     {
@@ -235,8 +320,14 @@ struct tbx_engine {
 // entry point used (the "_device" forms run on the caller's stream -- including the NULL stream, which does not order itself
 // against the engine's non-blocking stream -- the host-pointer forms on the engine's own), the new stream first waits for an
 // event recorded on the old one, so calls on one handle take effect in program order whatever streams they name.
+hipError_t tbx_serve_stop(tbx_engine* e);   // engine.hip
+
 inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s)
 {
+    if (e->serve_running) {                    // nothing else runs beside the resident step kernel
+        hipError_t r = tbx_serve_stop(e);
+        if (r != hipSuccess) return r;
+    }
     if (e->has_last && e->last_stream != s) {
         if (!e->order_ev) {
             hipError_t r = hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming);
@@ -270,6 +361,8 @@ struct GameOps {
     virtual int pack_state(tbx_engine* e, int env, int count, hipStream_t s) = 0;
     virtual int unpack_state(tbx_engine* e, int env, int count, const void* pod_host, hipStream_t s) = 0;
     virtual int scalars(tbx_engine* e, int32_t* score_dev, int32_t* lives_dev, int32_t* level_dev, hipStream_t s) = 0;
+    // launch the resident single-env step kernel for env 0 on `s` (tbx_serve_loop); optional
+    virtual int serve(tbx_engine*, TbxServeCtl* /*ctl_dev*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
     // ---- agent layer (agent.hip).  The two-frame buffer of MaxAndSkipEnv lives with the game as two snapshot slots.
     virtual int agent_prepare(tbx_engine*) { return TBX_OK; }  // allocate the slots
     virtual bool multi_frame_step() const { return false; }   // step() honours ActionSource::frames and writes the slots itself

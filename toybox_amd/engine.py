@@ -43,6 +43,7 @@ class Engine:
         buf = (C.c_int32 * 18)()
         n = self._lib.tbx_legal_actions(self.game_id, buf, 18)
         self.legal_actions = [int(buf[i]) for i in range(n)]
+        self._out4 = (C.c_int32 * 4)()
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -106,6 +107,15 @@ class Engine:
         flags = _abi.STEP_AUTO_RESET if auto_reset else 0
         self._check(self._lib.tbx_step(self._h, _ptr(a), flags, _ptr(reward), _ptr(done), _ptr(lives), _ptr(score)))
         return reward, done.astype(bool), lives, score
+
+    def step1(self, env, ale_action, auto_reset=False):
+        """One frame for one env: (reward, done, lives, score) as Python ints.  On a one-env engine this is the resident-kernel
+        path of tbx_step1 (no launch, no copy)."""
+        out = self._out4
+        rc = self._lib.tbx_step1(self._h, env, ale_action, _abi.STEP_AUTO_RESET if auto_reset else 0, out)
+        if rc != _abi.OK:
+            self._check(rc)
+        return out[0], out[1] != 0, out[2], out[3]
 
     def apply_input(self, env, buttons):
         self._check(self._lib.tbx_apply_input(self._h, int(env), int(buttons)))

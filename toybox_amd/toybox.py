@@ -174,13 +174,14 @@ class Toybox(object):
     def apply_ale_action(self, action_int):
         if int(action_int) not in self._engine.legal_actions:
             raise ValueError("Expected to apply action, but failed: {0}".format(action_int))
+        # one round trip per frame: the step call hands back score and lives, so the get_score / get_lives / game_over
+        # calls that follow every action in the reference's loops (test/benchmark.py:50-56) cost nothing.  A one-env engine
+        # answers from its resident step kernel (tbx_step1): no launch, no copy, no synchronisation.
         if self._engine.n_envs == 1:
-            # one round trip per frame: the step call hands back score and lives, so the get_score / get_lives /
-            # game_over calls that follow every action in the reference's loops (test/benchmark.py:50-56) cost nothing
-            a = np.array([int(action_int)], np.int32)
+            step1 = self._engine.step1
             for _ in range(self.frames_per_action):
-                _, _, lives, score = self._engine.step(a)
-            self._scal = (int(score[0]), int(lives[0]))
+                _, _, lives, score = step1(0, action_int)
+            self._scal = (score, lives)
             return
         self._scal = None
         buttons = self._engine._lib.tbx_ale_action_to_buttons(int(action_int))
