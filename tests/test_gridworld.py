@@ -24,12 +24,20 @@ def _resolved(js):
     return [[json.dumps(js["tiles"][v], sort_keys=True) for v in row] for row in js["grid"]]
 
 
-def test_golden_dumps_round_trip_and_defaults(oracle_lib):
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def lib(request, oracle_lib):
+    if request.param == "oracle":
+        return oracle_lib
+    from toybox_amd import _lib
+    return _lib.load()
+
+
+def test_golden_dumps_round_trip_and_defaults(lib):
     gc, gs = _load("gridworld_config.json"), _load("gridworld_state.json")
     assert gw.config_to_json(gw.config_from_json(gc)) == gc
     assert gw.state_to_json(gw.state_from_json(gs)) == gs
     assert gw.default_config() == gc
-    with Engine("gridworld", 2, lib=oracle_lib) as e:
+    with Engine("gridworld", 2, lib=lib) as e:
         assert gw.config_to_json(e.get_config()) == gc           # library-side defaults
         js = gw.state_to_json(e.get_state(1))
         # a new game of the default config is the golden state up to the order of the tile table
