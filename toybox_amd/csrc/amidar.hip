@@ -914,7 +914,9 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
     AmiPainter<C> p;
     // (agent layer, generic path: flagged envs are painted from d_alt)
-    p.setup((pick_alt && wave_uniform((int)pick_alt[env])) ? d_alt : d, env, lane, lds_mask[wave]);
+    AmiDev src = d;                                             // by VALUE: a select between references to kernel arguments puts both into scratch
+    if (pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;
+    p.setup(src, env, lane, lds_mask[wave]);
 
     uint8_t* frame = out + (size_t)rel * H * W * C;
     constexpr int NUNITS = H / AMI_UNIT_ROWS;

@@ -377,7 +377,9 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* 
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
     GwPainter<C> p;
     // (agent layer, generic path: flagged envs are painted from d_alt)
-    p.setup((pick_alt && wave_uniform((int)pick_alt[env])) ? d_alt : d, env, lane, lds_mask[wave]);
+    GwDev src = d;                                             // by VALUE: a select between references to kernel arguments puts both into scratch
+    if (pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;
+    p.setup(src, env, lane, lds_mask[wave]);
     uint8_t* dst = out + (size_t)rel * H * W * C;
     for (int u = part; u < UNITS; u += split) {
         const int unit = split > 1 ? u : (u + env) % UNITS;  // one wave per frame: rotate the start so waves do not march in lockstep

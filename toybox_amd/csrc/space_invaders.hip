@@ -839,15 +839,19 @@ struct SiPainter {
         for (int q = 0; q < 5; q++) { digits |= (uint32_t)((sc / div) % 10) << (4 * q); div /= 10; }
         digits |= (uint32_t)lv << 20; digits |= (uint32_t)le << 24;
         auto clampy = [](long v) { return (uint32_t)(v < 0 ? 0 : v > H ? H : v); };
-        const uint32_t tail[11] = {(uint32_t)busy[0], (uint32_t)(busy[0] >> 32), (uint32_t)busy[1], (uint32_t)(busy[1] >> 32),
-                                   (uint32_t)busy[2], (uint32_t)(busy[2] >> 32), (uint32_t)busy[3],
-                                   clampy(e_y0) | (clampy(e_y1) << 16), clampy(s_y0) | (clampy(s_y1) << 16),
-                                   clampy(l_lo) | (clampy(l_hi) << 16), digits};
+        // lane i < NF carries field i, lanes NF .. NF+10 the wave-uniform painter words (selects by value, no indexed array:
+        // an array indexed in a select chain lands in scratch)
         int32_t fv = 0;
 #pragma unroll
         for (int i = 0; i < NF; i++) fv = lane == i ? f[i] : fv;
-#pragma unroll
-        for (int k = 0; k < 11; k++) fv = lane == NF + k ? (int32_t)tail[k] : fv;
+        fv = lane == NF + 0 ? (int32_t)(uint32_t)busy[0] : fv; fv = lane == NF + 1 ? (int32_t)(uint32_t)(busy[0] >> 32) : fv;
+        fv = lane == NF + 2 ? (int32_t)(uint32_t)busy[1] : fv; fv = lane == NF + 3 ? (int32_t)(uint32_t)(busy[1] >> 32) : fv;
+        fv = lane == NF + 4 ? (int32_t)(uint32_t)busy[2] : fv; fv = lane == NF + 5 ? (int32_t)(uint32_t)(busy[2] >> 32) : fv;
+        fv = lane == NF + 6 ? (int32_t)(uint32_t)busy[3] : fv;
+        fv = lane == NF + 7 ? (int32_t)(clampy(e_y0) | (clampy(e_y1) << 16)) : fv;
+        fv = lane == NF + 8 ? (int32_t)(clampy(s_y0) | (clampy(s_y1) << 16)) : fv;
+        fv = lane == NF + 9 ? (int32_t)(clampy(l_lo) | (clampy(l_hi) << 16)) : fv;
+        fv = lane == NF + 10 ? (int32_t)digits : fv;
         r[lane] = (uint32_t)fv;
         r[1 * 64 + lane] = (uint32_t)s.ex; r[2 * 64 + lane] = (uint32_t)s.ey;
         r[3 * 64 + lane] = (uint32_t)e_tab | (e_vis ? 0x100u : 0u) | (l_on ? 0x200u : 0u);
@@ -1114,7 +1118,9 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_prep_kernel(SiDev d, uint
     const int env = first_env + rel;
     SiPainter<1> p;
     p.spr_lds = nullptr;                                      // the set-up does not touch the sprite rows
-    p.setup((pick_alt && wave_uniform((int)pick_alt[env])) ? d_alt : d, env, lane, lds_mask[wave]);
+    SiDev src = d;                                             // by VALUE: a select between references to kernel arguments puts both into scratch
+    if (pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;
+    p.setup(src, env, lane, lds_mask[wave]);
     p.export_rec(recs + (size_t)env * SI_REC_WORDS);
 }
 
