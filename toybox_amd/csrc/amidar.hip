@@ -11,6 +11,7 @@
 //   tiles   [N][32] uint64   lane = board row, 2 bits per tile (32 tiles)
 //   boxes   [N][2][64] uint32 lane = box (packed corners, flags)
 //   movers  [N][NMF][16] int32 lane = mover slot (0..7 enemies, 8 the player), field-major
+//   mh      [6][9][N]   int32 the movers' per-frame fields (x, y, speed, step, caught), struct-of-arrays over envs
 //
 // The maze chase is control-flow heavy and serial per mover (movement protocols, RNG draws in
 // enemy order), so the wave runs the movers one after the other with wave-uniform control flow and
@@ -63,9 +64,18 @@ struct AmiDev {
     int32_t* sc;         // [ANF][N]
     uint64_t* tiles;     // [N][32]
     uint32_t* boxes;     // [N][2][64]
-    int32_t* movers;     // [N][NMF][16]
+    int32_t* movers;     // [N][NMF][16]  (the per-frame fields below live in `mh`, their table entries are unused)
+    int32_t* mh;         // [NMH][MSLOTS][N] the movers' per-frame fields (position, step, speed, caught), struct-of-arrays over envs:
+                         // the thread-per-env step reads and writes them coalesced; wave-per-env kernels fetch nine dwords each
     const AmiTables* tab;
 };
+
+// the movers' per-frame ("hot") fields and their row in AmiDev::mh; -1 for the fields that stay in the env-major table
+constexpr int NMH = 6, MSLOTS = TBX_AMI_MAX_ENEMIES + 1;
+__host__ __device__ constexpr int ami_hot_row(int field)
+{
+    return field == M_X ? 0 : field == M_Y ? 1 : field == M_SPEED ? 2 : field == M_STEP_TX ? 3 : field == M_STEP_TY ? 4 : field == M_CAUGHT ? 5 : -1;
+}
 
 __constant__ int AMI_ROUTES[TBX_AMI_N_ROUTES][TBX_AMI_ROUTE_LEN] = TBX_AMI_ROUTES;
 
@@ -91,8 +101,13 @@ __device__ __forceinline__ void ami_load(const AmiDev& d, int env, int lane, Ami
     s.bgeom = d.boxes[(size_t)env * 128 + lane];
     s.bflags = d.boxes[(size_t)env * 128 + 64 + lane];
     const int32_t* m = d.movers + (size_t)env * NMF * 16;
+    const int slot = lane & 15;
 #pragma unroll
-    for (int i = 0; i < NMF; i++) s.mv[i] = m[i * 16 + (lane & 15)];
+    for (int i = 0; i < NMF; i++) {
+        const int h = ami_hot_row(i);
+        if (h >= 0) s.mv[i] = slot < MSLOTS ? d.mh[((size_t)h * MSLOTS + slot) * N + env] : 0;
+        else s.mv[i] = m[i * 16 + slot];
+    }
 }
 
 __device__ __forceinline__ void ami_store(const AmiDev& d, int env, int lane, const AmiRegs& s)
@@ -114,7 +129,11 @@ __device__ __forceinline__ void ami_store(const AmiDev& d, int env, int lane, co
     if (lane < 16) {
         int32_t* m = d.movers + (size_t)env * NMF * 16;
 #pragma unroll
-        for (int i = 0; i < NMF; i++) m[i * 16 + lane] = s.mv[i];
+        for (int i = 0; i < NMF; i++) {
+            const int h = ami_hot_row(i);
+            if (h >= 0) { if (lane < MSLOTS) d.mh[((size_t)h * MSLOTS + lane) * N + env] = s.mv[i]; }
+            else m[i * 16 + lane] = s.mv[i];
+        }
     }
 }
 
@@ -540,6 +559,532 @@ __device__ __forceinline__ void ami_step(const AmiTables& t, int lane, uint32_t 
         f[A_LIVES] -= 1;
         reset_positions(t, s, lane);
         break;
+    }
+}
+
+// ------------------------------------------------------------------ step, thread per env
+//
+// The maze chase is scalar and branchy: in the wave-per-env form above one lane works and 63 idle through ~900 serial
+// instructions per frame, and 65 536 such waves queue three deep on every SIMD (145 us per frame of the batch).  Here ONE
+// THREAD steps one env, so the whole batch is 1 024 waves, one per SIMD, all running at once.  The rules are restated
+// statement by statement over the same arrays in HBM:
+//   * the env's scalars (struct-of-arrays over envs) are read coalesced into registers;
+//   * the 31 board rows of the wave's 64 envs are staged in LDS with one contiguous 16 KB read (env-major table) and looked
+//     up there by (row, column) -- the only indexed structure the rules touch all the time; written back only if some env
+//     of the wave painted;
+//   * the movers and boxes stay in their env-major tables and are read / written field by field (uncoalesced, but each
+//     64-byte line serves the same env's next accesses out of L2).
+// Lanes diverge where envs differ (a mover reaches a tile in one env and not in its neighbour); every branch is short.
+namespace tpe {
+
+constexpr int ROW_STRIDE = 33;   // 64-bit words per env in LDS: 32 rows + 1 pad (bank spread)
+
+struct Env {
+    const AmiDev& d;
+    const AmiTables& t;
+    int env;
+    uint64_t* rows;      // LDS: this env's board rows
+    int32_t* mv;         // HBM: this env's mover table [NMF][16] (AI parameters, history)
+    uint32_t* bx;        // HBM: this env's boxes, geometry [64] then flags [64]
+    Rng rng;
+    int32_t f[A_CJ0];    // the scalars the rules read every frame (the chase-junction list behind them stays in memory)
+    bool dirty;          // a board row changed
+
+    __device__ __forceinline__ int mg(int field, int slot) const
+    {
+        const int h = ami_hot_row(field);
+        return h >= 0 ? d.mh[((size_t)h * MSLOTS + slot) * (size_t)d.n + env] : mv[field * 16 + slot];
+    }
+    __device__ __forceinline__ void ms(int field, int slot, int v)
+    {
+        const int h = ami_hot_row(field);
+        if (h >= 0) d.mh[((size_t)h * MSLOTS + slot) * (size_t)d.n + env] = v;
+        else mv[field * 16 + slot] = v;
+    }
+    __device__ __forceinline__ int tile_at(int tx, int ty) const
+    {
+        if (tx < 0 || ty < 0 || tx >= BW || ty >= BH) return TBX_TILE_EMPTY;
+        return (int)((rows[ty] >> (2 * tx)) & 3ull);
+    }
+    __device__ __forceinline__ bool walkable(int tx, int ty) const { return tile_at(tx, ty) != TBX_TILE_EMPTY; }
+    __device__ __forceinline__ bool is_junction(int tx, int ty) const
+    {
+        if (!walkable(tx, ty)) return false;
+        const bool h = walkable(tx - 1, ty) || walkable(tx + 1, ty);
+        const bool v = walkable(tx, ty - 1) || walkable(tx, ty + 1);
+        return h && v;
+    }
+    __device__ __forceinline__ bool can_go(int tx, int ty, int dir) const
+    {
+        int dx, dy;
+        dir_delta(dir, dx, dy);
+        return walkable(tx + dx, ty + dy);
+    }
+
+    __device__ __forceinline__ void reset_mover(int slot, int tx, int ty)
+    {
+        ms(M_X, slot, tx * TBX_AMI_TILE_WX); ms(M_Y, slot, ty * TBX_AMI_TILE_WY);
+        ms(M_STEP_TX, slot, -1); ms(M_STEP_TY, slot, -1);
+        ms(M_NHIST, slot, 0);
+        for (int i = 0; i < TBX_AMI_MAX_HISTORY; i++) ms(M_HIST0 + i, slot, 0);
+        ms(M_CAUGHT, slot, 0);
+    }
+    __device__ __forceinline__ void reset_enemy(int slot)
+    {
+        const int kind = mg(M_KIND, slot);
+        int tx, ty;
+        if (kind == TBX_AI_LOOKUP) {
+            const int r = mg(M_ROUTE, slot);
+            const int id = (r >= 0 && r < TBX_AMI_N_ROUTES) ? AMI_ROUTES[r][0] : 0;
+            tx = id % BW; ty = id / BW;
+            ms(M_NEXT, slot, 0);
+        } else { tx = mg(M_START_TX, slot); ty = mg(M_START_TY, slot); }
+        ms(M_VERT, slot, mg(M_SVERT, slot)); ms(M_HORIZ, slot, mg(M_SHORIZ, slot)); ms(M_DIR, slot, mg(M_SDIR, slot));
+        ms(M_SEEN_TX, slot, -1); ms(M_SEEN_TY, slot, -1);
+        reset_mover(slot, tx, ty);
+    }
+    __device__ __forceinline__ void reset_player()
+    {
+        reset_mover(PLAYER_SLOT, t.player_start_tx, t.player_start_ty);
+        for (int ty = t.player_start_ty + 1; ty < BH; ty++)
+            if (is_junction(t.player_start_tx, ty)) { ms(M_HIST0, PLAYER_SLOT, ty * BW + t.player_start_tx); ms(M_NHIST, PLAYER_SLOT, 1); break; }
+    }
+    __device__ __forceinline__ void reset_board()
+    {
+        for (int y = 0; y < 32; y++) rows[y] = y < BH ? t.board_rows[y] : 0ull;
+        dirty = true;
+        f[A_N_CHASE] = t.n_chase;
+        // (the chase-junction list is not part of the per-frame register set: it goes straight to its arrays)
+        for (int k = 0; k < TBX_AMI_MAX_CHASE_J; k++) d.sc[(size_t)(A_CJ0 + k) * (size_t)d.n + env] = k < t.n_chase ? t.chase_j[k] : 0;
+        f[A_N_BOXES] = t.n_boxes;
+        for (int i = 0; i < 64; i++) { bx[i] = t.box_geom[i]; bx[64 + i] = t.box_flags[i]; }
+    }
+    __device__ __forceinline__ void reset_positions()
+    {
+        reset_player();
+        for (int i = 0; i < f[A_N_ENEMIES]; i++) reset_enemy(i);
+        f[A_JUMP_TIMER] = 0;
+        f[A_CHASE_TIMER] = 0;
+    }
+    __device__ __forceinline__ void new_game(Rng& sim)
+    {
+        rng = sim.child();
+        for (int i = 0; i < A_CJ0; i++) f[i] = 0;
+        f[A_LIVES] = t.start_lives;
+        f[A_LEVEL] = 1;
+        f[A_JUMPS] = t.start_jumps;
+        reset_board();
+        for (int i = 0; i < NMF * 16; i++) mv[i] = 0;
+        for (int h = 0; h < NMH * MSLOTS; h++) d.mh[(size_t)h * (size_t)d.n + env] = 0;
+        f[A_N_ENEMIES] = t.n_enemies;
+        ms(M_SPEED, PLAYER_SLOT, TBX_AMI_SPEED); ms(M_KIND, PLAYER_SLOT, TBX_AI_PLAYER);
+        ms(M_SEEN_TX, PLAYER_SLOT, -1); ms(M_SEEN_TY, PLAYER_SLOT, -1);
+        for (int e = 0; e < t.n_enemies; e++) {
+            ms(M_SPEED, e, TBX_AMI_SPEED);
+            for (int k = 0; k < 14; k++) ms(M_KIND + k, e, t.ai[e][k]);
+        }
+        reset_player();
+        for (int i = 0; i < t.n_enemies; i++) reset_enemy(i);
+    }
+
+    __device__ __forceinline__ bool at_tile(int slot) const { return mg(M_X, slot) % TBX_AMI_TILE_WX == 0 && mg(M_Y, slot) % TBX_AMI_TILE_WY == 0; }
+    __device__ __forceinline__ bool advance(int slot)
+    {
+        const int stx = mg(M_STEP_TX, slot);
+        if (stx < 0) return false;
+        const int sty = mg(M_STEP_TY, slot);
+        int x = mg(M_X, slot), y = mg(M_Y, slot), sp = mg(M_SPEED, slot);
+        const int gx = stx * TBX_AMI_TILE_WX, gy = sty * TBX_AMI_TILE_WY;
+        if (sp < 0) sp = 0;
+        if (x < gx) { x += sp; if (x > gx) x = gx; }
+        else if (x > gx) { x -= sp; if (x < gx) x = gx; }
+        else if (y < gy) { y += sp; if (y > gy) y = gy; }
+        else if (y > gy) { y -= sp; if (y < gy) y = gy; }
+        ms(M_X, slot, x); ms(M_Y, slot, y);
+        if (x == gx && y == gy) { ms(M_STEP_TX, slot, -1); ms(M_STEP_TY, slot, -1); return true; }
+        return false;
+    }
+    __device__ __forceinline__ void set_step(int slot, int tx, int ty, int dir)
+    {
+        int dx, dy;
+        dir_delta(dir, dx, dy);
+        ms(M_STEP_TX, slot, tx + dx); ms(M_STEP_TY, slot, ty + dy);
+    }
+    __device__ __forceinline__ void push_history(int slot, int id)
+    {
+        int n = mg(M_NHIST, slot);
+        if (n >= TBX_AMI_MAX_HISTORY) {
+            for (int i = 1; i < TBX_AMI_MAX_HISTORY; i++) ms(M_HIST0 + i - 1, slot, mg(M_HIST0 + i, slot));
+            n = TBX_AMI_MAX_HISTORY - 1;
+        }
+        if (n >= 0) ms(M_HIST0 + n, slot, id);          // (a negative count -- hand-written states -- matches no slot, as in the wave form)
+        ms(M_NHIST, slot, n + 1);
+    }
+    // M_NHIST outside 1..16 (hand-written states): like the wave form, no slot matches and the value is 0
+    __device__ __forceinline__ int last_history(int slot, int n) const { return (n >= 1 && n <= TBX_AMI_MAX_HISTORY) ? mg(M_HIST0 + n - 1, slot) : 0; }
+
+    __device__ __forceinline__ void check_boxes()
+    {
+        const int nb = f[A_N_BOXES];
+        int n_new = 0;
+        bool trig_new = false;
+        for (int i = 0; i < nb && i < 64; i++) {
+            const uint32_t fl = bx[64 + i];
+            if (fl & 1u) continue;
+            const uint32_t g = bx[i];
+            const int tl_tx = g & 255, tl_ty = (g >> 8) & 255, br_tx = (g >> 16) & 255, br_ty = (g >> 24) & 255;
+            if (!(tl_tx < BW && br_tx < BW && tl_tx <= br_tx) || tl_ty >= BH || br_ty >= BH || tl_ty > br_ty) continue;
+            const int nbits = 2 * (br_tx - tl_tx + 1);
+            const uint64_t span = (nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull)) << (2 * tl_tx);
+            const uint64_t want = 0xAAAAAAAAAAAAAAAAull & span;
+            bool ok = (rows[tl_ty] & span) == want && (rows[br_ty] & span) == want;
+            for (int y = tl_ty + 1; y < br_ty && ok; y++) {
+                const uint64_t row = rows[y];
+                if (((row >> (2 * tl_tx)) & 3ull) != TBX_TILE_PAINTED || ((row >> (2 * br_tx)) & 3ull) != TBX_TILE_PAINTED) ok = false;
+            }
+            if (!ok) continue;
+            bx[64 + i] = fl | 1u;
+            n_new += 1;
+            if (fl & 2u) trig_new = true;
+        }
+        if (!n_new) return;
+        f[A_SCORE] += t.box_bonus * n_new;
+        if (trig_new) {
+            bool all = true;
+            for (int k = 0; k < nb && k < 64; k++) {
+                const uint32_t fl = bx[64 + k];
+                if ((fl & 2u) && !(fl & 1u)) all = false;
+            }
+            if (all) f[A_CHASE_TIMER] = t.chase_time;
+        }
+    }
+
+    __device__ __forceinline__ void player_arrived()
+    {
+        const int tx = mg(M_X, PLAYER_SLOT) / TBX_AMI_TILE_WX, ty = mg(M_Y, PLAYER_SLOT) / TBX_AMI_TILE_WY;
+        if (!is_junction(tx, ty)) return;
+        const int id = ty * BW + tx;
+        int newly = 0;
+        const int nh = mg(M_NHIST, PLAYER_SLOT);
+        if (nh > 0) {
+            const int prev = last_history(PLAYER_SLOT, nh);
+            const int qx = prev % BW, qy = prev / BW;
+            if (prev != id && prev >= 0 && prev < BW * BH && (qx == tx || qy == ty)) {
+                const int x0 = qx < tx ? qx : tx, x1 = qx < tx ? tx : qx, y0 = qy < ty ? qy : ty, y1 = qy < ty ? ty : qy;
+                const int nbits = 2 * (x1 - x0 + 1);
+                const uint64_t span = (nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull)) << (2 * x0);
+                const uint64_t ones = 0x5555555555555555ull & span;
+                bool clear = true;
+                for (int y = y0; y <= y1; y++) {
+                    const uint64_t row = rows[y];
+                    if ((((row | (row >> 1)) & 0x5555555555555555ull) & span) != ones) clear = false;   // a 2-bit tag of 0 = not walkable
+                }
+                if (clear) {
+                    for (int y = y0; y <= y1; y++) {
+                        const uint64_t row = rows[y];
+                        const uint64_t painted = (row >> 1) & ~row & 0x5555555555555555ull;
+                        newly += __popcll(ones & ~painted);
+                        rows[y] = (row & ~span) | (0xAAAAAAAAAAAAAAAAull & span);
+                    }
+                    dirty = true;
+                }
+            }
+        }
+        push_history(PLAYER_SLOT, id);
+        if (newly > 0) {
+            f[A_SCORE] += newly;
+            check_boxes();
+            bool left = false;
+            for (int y = 0; y < BH; y++) if (rows[y] & 0x5555555555555555ull) left = true;   // tags 01 / 11 remain
+            if (!left) {
+                f[A_LEVEL] += 1;
+                reset_board();
+                reset_positions();
+                f[A_JUMPS] = t.start_jumps;
+            }
+        }
+    }
+
+    __device__ __forceinline__ int first_open(int tx, int ty, int avoid) const
+    {
+        for (int dd = 0; dd < 4; dd++)
+            if (dd != avoid && can_go(tx, ty, dd)) return dd;
+        return (avoid >= 0 && can_go(tx, ty, avoid)) ? avoid : -1;
+    }
+
+    __device__ __forceinline__ void enemy_decide(int slot)
+    {
+        const int tx = mg(M_X, slot) / TBX_AMI_TILE_WX, ty = mg(M_Y, slot) / TBX_AMI_TILE_WY;
+        const int kind = mg(M_KIND, slot);
+        int dir = -1;
+        if (kind == TBX_AI_LOOKUP) {
+            const int r = mg(M_ROUTE, slot);
+            if (r < 0 || r >= TBX_AMI_N_ROUTES) return;
+            int len = 0;
+            while (len < TBX_AMI_ROUTE_LEN && AMI_ROUTES[r][len] >= 0) len++;
+            int next = mg(M_NEXT, slot);
+            if (next < 0 || next >= len) next = 0;
+            if (AMI_ROUTES[r][next] == ty * BW + tx) next = (next + 1) % len;
+            ms(M_NEXT, slot, next);
+            const int gx = AMI_ROUTES[r][next] % BW, gy = AMI_ROUTES[r][next] / BW;
+            if (gx > tx && can_go(tx, ty, TBX_DIR_RIGHT)) dir = TBX_DIR_RIGHT;
+            else if (gx < tx && can_go(tx, ty, TBX_DIR_LEFT)) dir = TBX_DIR_LEFT;
+            else if (gy > ty && can_go(tx, ty, TBX_DIR_DOWN)) dir = TBX_DIR_DOWN;
+            else if (gy < ty && can_go(tx, ty, TBX_DIR_UP)) dir = TBX_DIR_UP;
+        } else if (kind == TBX_AI_PERIMETER) {
+            if (ty == 0 && tx < BW - 1 && can_go(tx, ty, TBX_DIR_RIGHT)) dir = TBX_DIR_RIGHT;
+            else if (tx == BW - 1 && ty < BH - 1 && can_go(tx, ty, TBX_DIR_DOWN)) dir = TBX_DIR_DOWN;
+            else if (ty == BH - 1 && tx > 0 && can_go(tx, ty, TBX_DIR_LEFT)) dir = TBX_DIR_LEFT;
+            else if (tx == 0 && ty > 0 && can_go(tx, ty, TBX_DIR_UP)) dir = TBX_DIR_UP;
+            else {
+                if (can_go(tx, ty, TBX_DIR_UP)) dir = TBX_DIR_UP;
+                else if (can_go(tx, ty, TBX_DIR_LEFT)) dir = TBX_DIR_LEFT;
+                else if (can_go(tx, ty, TBX_DIR_DOWN)) dir = TBX_DIR_DOWN;
+                else if (can_go(tx, ty, TBX_DIR_RIGHT)) dir = TBX_DIR_RIGHT;
+            }
+        } else if (kind == TBX_AI_AMIDAR) {
+            int vert = mg(M_VERT, slot) & 1;
+            int horiz = 2 | (mg(M_HORIZ, slot) & 1);
+            bool came_vertically = true;
+            const int nh = mg(M_NHIST, slot);
+            if (nh > 0) came_vertically = (last_history(slot, nh) % BW) == tx;
+            const bool can_h = can_go(tx, ty, horiz), can_v = can_go(tx, ty, vert);
+            if (came_vertically && can_h) dir = horiz;
+            else if (can_v) dir = vert;
+            else if (can_h) dir = horiz;
+            else {
+                vert ^= 1; horiz ^= 1;
+                if (can_go(tx, ty, vert)) dir = vert;
+                else if (can_go(tx, ty, horiz)) dir = horiz;
+            }
+            ms(M_VERT, slot, vert);
+            ms(M_HORIZ, slot, horiz);
+        } else if (kind == TBX_AI_TARGET_PLAYER) {
+            const int ptx = mg(M_X, PLAYER_SLOT) / TBX_AMI_TILE_WX, pty = mg(M_Y, PLAYER_SLOT) / TBX_AMI_TILE_WY;
+            const int ddx = ptx - tx, ddy = pty - ty;
+            const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
+            int cur = mg(M_DIR, slot) & 3;
+            if (adx + ady <= mg(M_VISION, slot)) {
+                ms(M_SEEN_TX, slot, ptx); ms(M_SEEN_TY, slot, pty);
+                const int hd = ddx > 0 ? TBX_DIR_RIGHT : TBX_DIR_LEFT, vd = ddy > 0 ? TBX_DIR_DOWN : TBX_DIR_UP;
+                const int first = adx >= ady ? hd : vd, second = adx >= ady ? vd : hd;
+                const int fz = adx >= ady ? adx : ady, sz = adx >= ady ? ady : adx;
+                if (fz > 0 && can_go(tx, ty, first)) dir = first;
+                else if (sz > 0 && can_go(tx, ty, second)) dir = second;
+            } else { ms(M_SEEN_TX, slot, -1); ms(M_SEEN_TY, slot, -1); }
+            if (dir < 0) dir = can_go(tx, ty, cur) ? cur : first_open(tx, ty, cur ^ 1);
+            if (dir >= 0) cur = dir;
+            ms(M_DIR, slot, cur);
+        } else if (kind == TBX_AI_RANDOM) {
+            int cur = mg(M_DIR, slot) & 3;
+            int o0 = 0, o1 = 0, o2 = 0, o3 = 0, n = 0;     // (no indexed array: it would live in scratch)
+            for (int dd = 0; dd < 4; dd++)
+                if (dd != (cur ^ 1) && can_go(tx, ty, dd)) {
+                    if (n == 0) o0 = dd; else if (n == 1) o1 = dd; else if (n == 2) o2 = dd; else o3 = dd;
+                    n++;
+                }
+            if (n == 0) dir = can_go(tx, ty, cur ^ 1) ? (cur ^ 1) : -1;
+            else {
+                const int k = (int)rng.range((uint64_t)n);
+                dir = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : o3;
+            }
+            if (dir >= 0) cur = dir;
+            ms(M_DIR, slot, cur);
+        } else {
+            return;
+        }
+        if (dir >= 0) set_step(slot, tx, ty, dir);
+    }
+
+    // a mover's per-frame fields, fetched with independent loads (one latency) and kept in registers while it moves
+    struct Hot { int x, y, stx, sty, caught, sp; };
+    __device__ __forceinline__ Hot load_hot(int slot) const
+    {
+        Hot h;
+        h.x = mg(M_X, slot); h.y = mg(M_Y, slot); h.stx = mg(M_STEP_TX, slot); h.sty = mg(M_STEP_TY, slot);
+        h.caught = mg(M_CAUGHT, slot); h.sp = mg(M_SPEED, slot);
+        return h;
+    }
+    // advance toward the step; true when the target tile was reached this frame (fields written back by the caller)
+    static __device__ __forceinline__ bool advance_hot(Hot& h)
+    {
+        if (h.stx < 0) return false;
+        const int gx = h.stx * TBX_AMI_TILE_WX, gy = h.sty * TBX_AMI_TILE_WY;
+        const int sp = h.sp < 0 ? 0 : h.sp;
+        if (h.x < gx) { h.x += sp; if (h.x > gx) h.x = gx; }
+        else if (h.x > gx) { h.x -= sp; if (h.x < gx) h.x = gx; }
+        else if (h.y < gy) { h.y += sp; if (h.y > gy) h.y = gy; }
+        else if (h.y > gy) { h.y -= sp; if (h.y < gy) h.y = gy; }
+        if (h.x == gx && h.y == gy) { h.stx = -1; h.sty = -1; return true; }
+        return false;
+    }
+
+    __device__ __forceinline__ void step(uint32_t buttons)
+    {
+        // 1. timers
+        if (f[A_JUMP_TIMER] > 0) f[A_JUMP_TIMER] -= 1;
+        if (f[A_CHASE_TIMER] > 0) {
+            f[A_CHASE_TIMER] -= 1;
+            if (f[A_CHASE_TIMER] == 0)
+                for (int i = 0; i < f[A_N_ENEMIES]; i++)
+                    if (mg(M_CAUGHT, i)) reset_enemy(i);
+        }
+        // 2. jump
+        if ((buttons & TBX_BTN_BUTTON1) && f[A_JUMPS] > 0 && f[A_JUMP_TIMER] == 0) { f[A_JUMPS] -= 1; f[A_JUMP_TIMER] = t.jump_time; }
+        // every mover's per-frame fields with independent loads up front: the walk below is a chain of short dependent steps,
+        // and with one wave per SIMD each round trip to L2 in that chain would be paid in full
+        const int ne = f[A_N_ENEMIES];
+        Hot p = load_hot(PLAYER_SLOT);
+        Hot hs[TBX_AMI_MAX_ENEMIES];
+#pragma unroll
+        for (int i = 0; i < TBX_AMI_MAX_ENEMIES; i++) {
+            hs[i] = Hot{0, 0, -1, -1, 1, 0};
+            if (i < ne) hs[i] = load_hot(i);
+        }
+        // 3. player
+        if (p.stx < 0 && p.x % TBX_AMI_TILE_WX == 0 && p.y % TBX_AMI_TILE_WY == 0) {
+            const int tx = p.x / TBX_AMI_TILE_WX, ty = p.y / TBX_AMI_TILE_WY;
+            const int dir = (buttons & TBX_BTN_UP) ? TBX_DIR_UP : (buttons & TBX_BTN_DOWN) ? TBX_DIR_DOWN :
+                            (buttons & TBX_BTN_LEFT) ? TBX_DIR_LEFT : (buttons & TBX_BTN_RIGHT) ? TBX_DIR_RIGHT : -1;
+            if (dir >= 0 && can_go(tx, ty, dir)) {
+                int dx, dy;
+                dir_delta(dir, dx, dy);
+                p.stx = tx + dx; p.sty = ty + dy;
+            }
+        }
+        const int level_before = f[A_LEVEL];
+        const bool p_arrived = advance_hot(p);
+        ms(M_X, PLAYER_SLOT, p.x); ms(M_Y, PLAYER_SLOT, p.y); ms(M_STEP_TX, PLAYER_SLOT, p.stx); ms(M_STEP_TY, PLAYER_SLOT, p.sty);
+        if (p_arrived) player_arrived();
+        if (f[A_LEVEL] != level_before) return;
+        // 4. enemies, in index order (unrolled: slot numbers are constants, the positions stay in registers for pass 5)
+#pragma unroll
+        for (int i = 0; i < TBX_AMI_MAX_ENEMIES; i++) {
+            if (i < ne && !hs[i].caught) {
+                Hot& h = hs[i];
+                // (the protocol's own fields live in the env-major table: only the lanes that decide / arrive touch it)
+                if (h.stx < 0 && h.x % TBX_AMI_TILE_WX == 0 && h.y % TBX_AMI_TILE_WY == 0) {
+                    if (mg(M_KIND, i) == TBX_AI_LOOKUP) {
+                        // EnemyLookupAI, the default protocol, with the step kept in registers
+                        const int tx = h.x / TBX_AMI_TILE_WX, ty = h.y / TBX_AMI_TILE_WY, r = mg(M_ROUTE, i);
+                        if (r >= 0 && r < TBX_AMI_N_ROUTES) {
+                            int len = 0;
+                            while (len < TBX_AMI_ROUTE_LEN && AMI_ROUTES[r][len] >= 0) len++;
+                            int next = mg(M_NEXT, i);
+                            if (next < 0 || next >= len) next = 0;
+                            if (AMI_ROUTES[r][next] == ty * BW + tx) next = (next + 1) % len;
+                            ms(M_NEXT, i, next);
+                            const int gx = AMI_ROUTES[r][next] % BW, gy = AMI_ROUTES[r][next] / BW;
+                            int dir = -1;
+                            if (gx > tx && can_go(tx, ty, TBX_DIR_RIGHT)) dir = TBX_DIR_RIGHT;
+                            else if (gx < tx && can_go(tx, ty, TBX_DIR_LEFT)) dir = TBX_DIR_LEFT;
+                            else if (gy > ty && can_go(tx, ty, TBX_DIR_DOWN)) dir = TBX_DIR_DOWN;
+                            else if (gy < ty && can_go(tx, ty, TBX_DIR_UP)) dir = TBX_DIR_UP;
+                            if (dir >= 0) {
+                                int dx, dy;
+                                dir_delta(dir, dx, dy);
+                                h.stx = tx + dx; h.sty = ty + dy;
+                                ms(M_STEP_TX, i, h.stx); ms(M_STEP_TY, i, h.sty);
+                            }
+                        }
+                    } else {
+                        enemy_decide(i);                    // writes the step (and the protocol's own fields) to the table
+                        h.stx = mg(M_STEP_TX, i); h.sty = mg(M_STEP_TY, i);
+                    }
+                }
+                const bool moved = h.stx >= 0;
+                const bool arrived = advance_hot(h);
+                if (moved) { ms(M_X, i, h.x); ms(M_Y, i, h.y); }
+                if (arrived) {
+                    ms(M_STEP_TX, i, -1); ms(M_STEP_TY, i, -1);
+                    if (mg(M_KIND, i) != TBX_AI_LOOKUP) {
+                        const int id = (h.y / TBX_AMI_TILE_WY) * BW + h.x / TBX_AMI_TILE_WX;
+                        ms(M_NHIST, i, 0);
+                        push_history(i, id);
+                    }
+                }
+            }
+        }
+        // 5. collisions
+        bool hit = false;
+#pragma unroll
+        for (int i = 0; i < TBX_AMI_MAX_ENEMIES; i++) {
+            if (i < ne && !hit && !hs[i].caught) {
+                int dx = hs[i].x - p.x, dy = hs[i].y - p.y;
+                if (dx < 0) dx = -dx;
+                if (dy < 0) dy = -dy;
+                if (dx < TBX_AMI_HIT_DX && dy < TBX_AMI_HIT_DY && f[A_JUMP_TIMER] <= 0) {
+                    if (f[A_CHASE_TIMER] > 0) { ms(M_CAUGHT, i, 1); f[A_SCORE] += t.chase_score_bonus; }
+                    else { f[A_LIVES] -= 1; reset_positions(); hit = true; }
+                }
+            }
+        }
+    }
+};
+
+}  // namespace tpe
+
+// one frame of the batch protocol (tbx_step / tbx_step_device / tbx_step_synthetic), one wave of 64 envs per block
+__global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, ActionSource src, uint32_t flags)
+{
+    __shared__ uint64_t lds_rows[64 * tpe::ROW_STRIDE];
+    const int lane = threadIdx.x;
+    const int env0 = blockIdx.x * 64;
+    const int env = env0 + lane;
+    const size_t N = (size_t)d.n;
+    const int n_here = min(64, d.n - env0);
+    // the board rows of this wave's envs: one contiguous read of the env-major table
+    for (int it = 0; it < 32; it++) {
+        const int g = it * 64 + lane;                   // (env_rel, row) = (g / 32, g % 32)
+        if ((g >> 5) < n_here) lds_rows[(g >> 5) * tpe::ROW_STRIDE + (g & 31)] = d.tiles[(size_t)env0 * 32 + g];
+    }
+    __syncthreads();
+    bool dirty = false;
+    if (env < d.n) {
+        int a;
+        if (src.actions) a = src.actions[env];
+        else {
+            const uint64_t h = tbx_splitmix64(src.seed ^ ((src.env_offset + (uint64_t)env) << 32) ^ src.t);
+            a = tbx_legal_action(TBX_GAME_AMIDAR, (int)(h % 6ull));
+        }
+        uint32_t buttons = tbx_ale_buttons(a);
+        if (buttons == 0xFFu) { buttons = 0; atomicOr(d.err_flag, 1u); }
+
+        tpe::Env e{d, *d.tab, env, lds_rows + lane * tpe::ROW_STRIDE, d.movers + (size_t)env * NMF * 16, d.boxes + (size_t)env * 128, Rng{}, {}, false};
+        e.rng.s0 = d.rng[env]; e.rng.s1 = d.rng[N + env];
+#pragma unroll
+        for (int i = 0; i < A_CJ0; i++) e.f[i] = d.sc[(size_t)i * N + env];
+        int32_t prev = d.prev_score[env];
+        e.step(buttons);
+        int32_t rew = e.f[A_SCORE] - prev;
+        if (rew < 0) rew = 0;
+        const int32_t out_lives = e.f[A_LIVES], out_score = e.f[A_SCORE];
+        const bool is_done = out_lives <= 0;
+        prev = out_score;
+        if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+            Rng sim;
+            sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
+            e.new_game(sim);
+            d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
+            prev = e.f[A_SCORE];
+        }
+        d.rng[env] = e.rng.s0; d.rng[N + env] = e.rng.s1;
+#pragma unroll
+        for (int i = 0; i < A_CJ0; i++) d.sc[(size_t)i * N + env] = e.f[i];
+        d.prev_score[env] = prev;
+        d.reward[env] = rew;
+        d.done[env] = is_done ? 1 : 0;
+        d.lives_out[env] = out_lives;
+        d.score_out[env] = out_score;
+        const uint32_t lv = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
+        d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv << 40);
+        dirty = e.dirty;
+    }
+    // only the envs that changed their board write it back: 32 lanes store the env's rows as one 256-byte run
+    __syncthreads();
+    for (uint64_t m = __ballot(dirty); m; m &= m - 1) {
+        const int r = (int)__builtin_ctzll(m);
+        if (lane < 32) d.tiles[(size_t)(env0 + r) * 32 + lane] = lds_rows[r * tpe::ROW_STRIDE + lane];
     }
 }
 
@@ -1128,6 +1673,7 @@ struct AmiOps : GameOps {
         TBX_HIP(hipMalloc((void**)&d.tiles, N * 32 * sizeof(uint64_t)));
         TBX_HIP(hipMalloc((void**)&d.boxes, N * 128 * sizeof(uint32_t)));
         TBX_HIP(hipMalloc((void**)&d.movers, N * NMF * 16 * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&d.mh, N * NMH * MSLOTS * sizeof(int32_t)));
         TBX_HIP(hipMalloc((void**)&tab_dev, sizeof(AmiTables)));
         d.tab = tab_dev;
         return upload(e);
@@ -1135,9 +1681,9 @@ struct AmiOps : GameOps {
 
     void destroy(tbx_engine*) override
     {
-        hipFree(d.rng); hipFree(d.sc); hipFree(d.tiles); hipFree(d.boxes); hipFree(d.movers); hipFree(tab_dev);
-        hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.tiles); hipFree(dA.boxes); hipFree(dA.movers);
-        hipFree(dB.rng); hipFree(dB.sc); hipFree(dB.tiles); hipFree(dB.boxes); hipFree(dB.movers);
+        hipFree(d.rng); hipFree(d.sc); hipFree(d.tiles); hipFree(d.boxes); hipFree(d.movers); hipFree(d.mh); hipFree(tab_dev);
+        hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.tiles); hipFree(dA.boxes); hipFree(dA.movers); hipFree(dA.mh);
+        hipFree(dB.rng); hipFree(dB.sc); hipFree(dB.tiles); hipFree(dB.boxes); hipFree(dB.movers); hipFree(dB.mh);
     }
 
     int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
@@ -1164,6 +1710,13 @@ struct AmiOps : GameOps {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         dA.tab = dB.tab = d.tab;
+        static const bool no_tpe = getenv("TBX_AMI_STEP_TPE") && atoi(getenv("TBX_AMI_STEP_TPE")) == 0;
+        if (!no_tpe && src.single_env < 0 && src.frames <= 1 && !src.acc_reward) {
+            // the batch protocol: one THREAD per env (the wave-per-env form stays for single-env calls and the agent layer)
+            hipLaunchKernelGGL(ami_step_tpe_kernel, dim3((e->n + 63) / 64), dim3(64), 0, s, d, src, flags);
+            TBX_HIP(hipGetLastError());
+            return TBX_OK;
+        }
         hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
@@ -1187,12 +1740,13 @@ struct AmiOps : GameOps {
         if (x.sc) { x.tab = d.tab; return TBX_OK; }
         const size_t N = (size_t)e->n;
         x = d;
-        x.sc = nullptr; x.tiles = nullptr; x.boxes = nullptr; x.movers = nullptr; x.rng = nullptr;
+        x.sc = nullptr; x.tiles = nullptr; x.boxes = nullptr; x.movers = nullptr; x.rng = nullptr; x.mh = nullptr;
         TBX_HIP(hipMalloc((void**)&x.rng, 2 * N * sizeof(uint64_t)));
         TBX_HIP(hipMalloc((void**)&x.sc, (size_t)ANF * N * sizeof(int32_t)));
         TBX_HIP(hipMalloc((void**)&x.tiles, N * 32 * sizeof(uint64_t)));
         TBX_HIP(hipMalloc((void**)&x.boxes, N * 128 * sizeof(uint32_t)));
         TBX_HIP(hipMalloc((void**)&x.movers, N * NMF * 16 * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&x.mh, N * NMH * MSLOTS * sizeof(int32_t)));
         return TBX_OK;
     }
 
