@@ -12,7 +12,10 @@ game, ch = sys.argv[1], int(sys.argv[2])
 libs = []
 for p in sys.argv[3:]:
     lib = C.CDLL(p)
-    _abi.bind(lib)
+    for name, (res, args) in _abi.PROTOTYPES.items():     # older builds lack the newest entry points: bind what is there
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
     libs.append((p, lib))
 n = 65536
 for rnd in range(3):

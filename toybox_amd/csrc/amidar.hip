@@ -1024,8 +1024,9 @@ struct Env {
 
 }  // namespace tpe
 
-// one frame of the batch protocol (tbx_step / tbx_step_device / tbx_step_synthetic), one wave of 64 envs per block
-__global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, ActionSource src, uint32_t flags)
+// the batch protocol (tbx_step / tbx_step_device / tbx_step_synthetic) and the agent layer's action repeat (`frames` frames of
+// one action with the reward summed, MaxAndSkipEnv's two buffer slots written on the way), one wave of 64 envs per block
+__global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, AmiDev slot_a, AmiDev slot_b, ActionSource src, uint32_t flags)
 {
     __shared__ uint64_t lds_rows[64 * tpe::ROW_STRIDE];
     const int lane = threadIdx.x;
@@ -1039,35 +1040,78 @@ __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, ActionSource
         if ((g >> 5) < n_here) lds_rows[(g >> 5) * tpe::ROW_STRIDE + (g & 31)] = d.tiles[(size_t)env0 * 32 + g];
     }
     __syncthreads();
-    bool dirty = false;
-    if (env < d.n) {
+    const bool agent = src.acc_reward != nullptr;
+    // an env whose game ended in an earlier launch of the same agent step sits this one out (MaxAndSkipEnv left its loop)
+    bool active = env < d.n && !(env < d.n && tbx_agent_env_finished(src, env));
+    if (src.exec_flag && env < d.n) src.exec_flag[env] = active ? 1 : 0;
+    uint32_t buttons = 0;
+    if (active) {
         int a;
         if (src.actions) a = src.actions[env];
         else {
             const uint64_t h = tbx_splitmix64(src.seed ^ ((src.env_offset + (uint64_t)env) << 32) ^ src.t);
             a = tbx_legal_action(TBX_GAME_AMIDAR, (int)(h % 6ull));
         }
-        uint32_t buttons = tbx_ale_buttons(a);
+        buttons = tbx_ale_buttons(a);
         if (buttons == 0xFFu) { buttons = 0; atomicOr(d.err_flag, 1u); }
-
-        tpe::Env e{d, *d.tab, env, lds_rows + lane * tpe::ROW_STRIDE, d.movers + (size_t)env * NMF * 16, d.boxes + (size_t)env * 128, Rng{}, {}, false};
+    }
+    const int ec = env < d.n ? env : 0;                 // (idle lanes of the last block point at a valid env and never step)
+    tpe::Env e{d, *d.tab, ec, lds_rows + lane * tpe::ROW_STRIDE, d.movers + (size_t)ec * NMF * 16, d.boxes + (size_t)ec * 128, Rng{}, {}, false};
+    int32_t prev = 0, rew = 0, out_lives = 0, out_score = 0;
+    bool is_done = false;
+    const bool loaded = active;
+    if (active) {
         e.rng.s0 = d.rng[env]; e.rng.s1 = d.rng[N + env];
 #pragma unroll
         for (int i = 0; i < A_CJ0; i++) e.f[i] = d.sc[(size_t)i * N + env];
-        int32_t prev = d.prev_score[env];
-        e.step(buttons);
-        int32_t rew = e.f[A_SCORE] - prev;
-        if (rew < 0) rew = 0;
-        const int32_t out_lives = e.f[A_LIVES], out_score = e.f[A_SCORE];
-        const bool is_done = out_lives <= 0;
-        prev = out_score;
-        if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
-            Rng sim;
-            sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
-            e.new_game(sim);
-            d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
-            prev = e.f[A_SCORE];
+        prev = d.prev_score[env];
+    }
+    const int frames = src.frames > 1 ? src.frames : 1;
+    for (int fr = 0; fr < frames; fr++) {
+        uint32_t slots = 0;
+        if (active) {
+            e.step(buttons);
+            rew = e.f[A_SCORE] - prev;
+            if (rew < 0) rew = 0;
+            out_lives = e.f[A_LIVES]; out_score = e.f[A_SCORE];
+            is_done = out_lives <= 0;
+            prev = out_score;
+            if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+                Rng sim;
+                sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
+                e.new_game(sim);
+                d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
+                prev = e.f[A_SCORE];
+            }
+            tbx_accumulate(src, env, rew, is_done, fr);
+            if (src.buf_valid) slots = tbx_snap_slots(src, fr);
         }
+        // MaxAndSkipEnv's frame buffer: the envs that ran frame skip-2 / skip-1 copy what the rasteriser reads of their
+        // state into slot A / B -- scalars and per-frame mover fields by the env's own thread (coalesced), board rows and
+        // boxes by the whole wave, one env at a time
+        if (agent && __syncthreads_or(slots != 0)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // box flags written by check_boxes are read below by other lanes
+            __syncthreads();
+            for (int which = 0; which < 2; which++) {
+                const bool mine = (slots >> which) & 1u;
+                const AmiDev& dst = which ? slot_b : slot_a;
+                if (mine) {
+#pragma unroll
+                    for (int i = 0; i < A_CJ0; i++) dst.sc[(size_t)i * N + env] = e.f[i];
+                    for (int h = 0; h < NMH * MSLOTS; h++) dst.mh[(size_t)h * N + env] = d.mh[(size_t)h * N + env];
+                    src.buf_valid[env] |= (uint8_t)(1u << which);
+                }
+                for (uint64_t m = __ballot(mine); m; m &= m - 1) {
+                    const int r = (int)__builtin_ctzll(m);
+                    if (lane < 32) dst.tiles[(size_t)(env0 + r) * 32 + lane] = lds_rows[r * tpe::ROW_STRIDE + lane];
+                    dst.boxes[(size_t)(env0 + r) * 128 + lane] = d.boxes[(size_t)(env0 + r) * 128 + lane];
+                    dst.boxes[(size_t)(env0 + r) * 128 + 64 + lane] = d.boxes[(size_t)(env0 + r) * 128 + 64 + lane];
+                }
+            }
+        }
+        if (agent && is_done) active = false;            // ... and its loop ends with the game
+    }
+    if (loaded) {
         d.rng[env] = e.rng.s0; d.rng[N + env] = e.rng.s1;
 #pragma unroll
         for (int i = 0; i < A_CJ0; i++) d.sc[(size_t)i * N + env] = e.f[i];
@@ -1078,11 +1122,10 @@ __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, ActionSource
         d.score_out[env] = out_score;
         const uint32_t lv = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
         d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv << 40);
-        dirty = e.dirty;
     }
     // only the envs that changed their board write it back: 32 lanes store the env's rows as one 256-byte run
     __syncthreads();
-    for (uint64_t m = __ballot(dirty); m; m &= m - 1) {
+    for (uint64_t m = __ballot(loaded && e.dirty); m; m &= m - 1) {
         const int r = (int)__builtin_ctzll(m);
         if (lane < 32) d.tiles[(size_t)(env0 + r) * 32 + lane] = lds_rows[r * tpe::ROW_STRIDE + lane];
     }
@@ -1711,9 +1754,9 @@ struct AmiOps : GameOps {
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         dA.tab = dB.tab = d.tab;
         static const bool no_tpe = getenv("TBX_AMI_STEP_TPE") && atoi(getenv("TBX_AMI_STEP_TPE")) == 0;
-        if (!no_tpe && src.single_env < 0 && src.frames <= 1 && !src.acc_reward) {
-            // the batch protocol: one THREAD per env (the wave-per-env form stays for single-env calls and the agent layer)
-            hipLaunchKernelGGL(ami_step_tpe_kernel, dim3((e->n + 63) / 64), dim3(64), 0, s, d, src, flags);
+        if (!no_tpe && src.single_env < 0) {
+            // batches: one THREAD per env (the wave-per-env form stays for single-env calls and the in-kernel reset procedure)
+            hipLaunchKernelGGL(ami_step_tpe_kernel, dim3((e->n + 63) / 64), dim3(64), 0, s, d, dA, dB, src, flags);
             TBX_HIP(hipGetLastError());
             return TBX_OK;
         }

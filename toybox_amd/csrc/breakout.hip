@@ -1023,10 +1023,13 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
     const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
     const int rel = wid / split, part = wid - rel * split;
     if (rel >= count) return;
+    // the env's record by value, ONCE, before the unit loop: scalar loads up front, none between the frame stores.  (agent
+    // layer, generic path: flagged envs paint recs_alt -- the ARRAY is selected; a select between two loaded records turns
+    // the scalar loads into vector loads, and a load left inside the loop is repeated per unit behind the stores)
+    const BrkRenderRec* __restrict__ rsrc = (pick_alt && wave_uniform((int)pick_alt[first_env + rel])) ? recs_alt : recs;
+    const BrkRenderRec rec = rsrc[first_env + rel];
     for (int q = part; q < NUNITS; q += split) {
         const int u = (int)(((uint32_t)(first_env + rel) * 7u + (uint32_t)q) % (uint32_t)NUNITS);
-        // by value: scalar loads up front, none inside the row loop (agent layer, generic path: flagged envs paint recs_alt)
-        const BrkRenderRec rec = (pick_alt && pick_alt[first_env + rel]) ? recs_alt[first_env + rel] : recs[first_env + rel];
         const int env = first_env + rel;
         uint8_t* dst = out + ((size_t)rel * H + (size_t)u * BRK_UNIT_ROWS) * W * C;
         const int y_first = u * BRK_UNIT_ROWS;
