@@ -201,8 +201,10 @@ class Region:
 
 
 def summarize(times, K):
-    ms = sorted(1000.0 * x / K for x in times)
-    return {"n": len(ms), "ms_per_step_median": statistics.median(ms), "ms_per_step_min": ms[0], "ms_per_step_max": ms[-1]}
+    in_order = [1000.0 * x / K for x in times]
+    ms = sorted(in_order)
+    return {"n": len(ms), "ms_per_step_median": statistics.median(ms), "ms_per_step_min": ms[0], "ms_per_step_max": ms[-1],
+            "ms_per_step_in_run_order": [round(v, 5) for v in in_order]}
 
 
 # ---------------------------------------------------------------------------------------------- other protocols

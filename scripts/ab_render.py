@@ -17,12 +17,13 @@ for p in sys.argv[3:]:
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
     libs.append((p, lib))
-n = 65536
+n = int(__import__("os").environ.get("AB_ENVS", "65536"))
+pre = int(__import__("os").environ.get("AB_PREROLL", "30"))     # frames played before timing (mid-game states paint more)
 for rnd in range(3):
     for p, lib in libs:
         e = Engine(game, n, lib=lib)
         e.seed(1234)
-        for t in range(30):
+        for t in range(pre):
             e.step_synthetic(1337, t)
         e.render_device(channels=ch)
         hip.synchronize()

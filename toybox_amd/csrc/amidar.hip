@@ -11,7 +11,7 @@
 //   tiles   [N][32] uint64   lane = board row, 2 bits per tile (32 tiles)
 //   boxes   [N][2][64] uint32 lane = box (packed corners, flags)
 //   movers  [N][NMF][16] int32 lane = mover slot (0..7 enemies, 8 the player), field-major
-//   mh      [6][9][N]   int32 the movers' per-frame fields (x, y, speed, step, caught), struct-of-arrays over envs
+//   mh      [6][9][N]   int32 mirror of the movers' per-frame fields (x, y, speed, step, caught), struct-of-arrays over envs
 //
 // The maze chase is control-flow heavy and serial per mover (movement protocols, RNG draws in
 // enemy order), so the wave runs the movers one after the other with wave-uniform control flow and
@@ -64,9 +64,10 @@ struct AmiDev {
     int32_t* sc;         // [ANF][N]
     uint64_t* tiles;     // [N][32]
     uint32_t* boxes;     // [N][2][64]
-    int32_t* movers;     // [N][NMF][16]  (the per-frame fields below live in `mh`, their table entries are unused)
-    int32_t* mh;         // [NMH][MSLOTS][N] the movers' per-frame fields (position, step, speed, caught), struct-of-arrays over envs:
-                         // the thread-per-env step reads and writes them coalesced; wave-per-env kernels fetch nine dwords each
+    int32_t* movers;     // [N][NMF][16]
+    int32_t* mh;         // [NMH][MSLOTS][N] MIRROR of the movers' per-frame fields (position, step, speed, caught) as
+                         // struct-of-arrays over envs: the thread-per-env step reads them coalesced from here; every writer
+                         // (ami_store, the thread form's ms) updates both copies, wave-per-env kernels read the table
     const AmiTables* tab;
 };
 
@@ -103,11 +104,7 @@ __device__ __forceinline__ void ami_load(const AmiDev& d, int env, int lane, Ami
     const int32_t* m = d.movers + (size_t)env * NMF * 16;
     const int slot = lane & 15;
 #pragma unroll
-    for (int i = 0; i < NMF; i++) {
-        const int h = ami_hot_row(i);
-        if (h >= 0) s.mv[i] = slot < MSLOTS ? d.mh[((size_t)h * MSLOTS + slot) * N + env] : 0;
-        else s.mv[i] = m[i * 16 + slot];
-    }
+    for (int i = 0; i < NMF; i++) s.mv[i] = m[i * 16 + slot];
 }
 
 __device__ __forceinline__ void ami_store(const AmiDev& d, int env, int lane, const AmiRegs& s)
@@ -130,9 +127,9 @@ __device__ __forceinline__ void ami_store(const AmiDev& d, int env, int lane, co
         int32_t* m = d.movers + (size_t)env * NMF * 16;
 #pragma unroll
         for (int i = 0; i < NMF; i++) {
-            const int h = ami_hot_row(i);
-            if (h >= 0) { if (lane < MSLOTS) d.mh[((size_t)h * MSLOTS + lane) * N + env] = s.mv[i]; }
-            else m[i * 16 + lane] = s.mv[i];
+            m[i * 16 + lane] = s.mv[i];
+            const int h = ami_hot_row(i);              // ... and the struct-of-arrays mirror of the per-frame fields
+            if (h >= 0 && lane < MSLOTS) d.mh[((size_t)h * MSLOTS + lane) * N + env] = s.mv[i];
         }
     }
 }
@@ -599,7 +596,7 @@ struct Env {
     {
         const int h = ami_hot_row(field);
         if (h >= 0) d.mh[((size_t)h * MSLOTS + slot) * (size_t)d.n + env] = v;
-        else mv[field * 16 + slot] = v;
+        mv[field * 16 + slot] = v;
     }
     __device__ __forceinline__ int tile_at(int tx, int ty) const
     {
@@ -1087,8 +1084,8 @@ __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, AmiDev slot_
             if (src.buf_valid) slots = tbx_snap_slots(src, fr);
         }
         // MaxAndSkipEnv's frame buffer: the envs that ran frame skip-2 / skip-1 copy what the rasteriser reads of their
-        // state into slot A / B -- scalars and per-frame mover fields by the env's own thread (coalesced), board rows and
-        // boxes by the whole wave, one env at a time
+        // state into slot A / B -- scalars by the env's own thread (coalesced), board rows, boxes and the movers' position
+        // rows by the whole wave, one env at a time
         if (agent && __syncthreads_or(slots != 0)) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // box flags written by check_boxes are read below by other lanes
             __syncthreads();
@@ -1098,7 +1095,6 @@ __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, AmiDev slot_
                 if (mine) {
 #pragma unroll
                     for (int i = 0; i < A_CJ0; i++) dst.sc[(size_t)i * N + env] = e.f[i];
-                    for (int h = 0; h < NMH * MSLOTS; h++) dst.mh[(size_t)h * N + env] = d.mh[(size_t)h * N + env];
                     src.buf_valid[env] |= (uint8_t)(1u << which);
                 }
                 for (uint64_t m = __ballot(mine); m; m &= m - 1) {
@@ -1106,6 +1102,13 @@ __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, AmiDev slot_
                     if (lane < 32) dst.tiles[(size_t)(env0 + r) * 32 + lane] = lds_rows[r * tpe::ROW_STRIDE + lane];
                     dst.boxes[(size_t)(env0 + r) * 128 + lane] = d.boxes[(size_t)(env0 + r) * 128 + lane];
                     dst.boxes[(size_t)(env0 + r) * 128 + 64 + lane] = d.boxes[(size_t)(env0 + r) * 128 + 64 + lane];
+                    // the movers' positions and caught flags: the three table rows the painter reads (the table is current:
+                    // the thread form writes it along with its struct-of-arrays mirror)
+                    if (lane < 48) {
+                        const int fld = lane < 16 ? M_X : lane < 32 ? M_Y : M_CAUGHT;
+                        const size_t at = (size_t)(env0 + r) * NMF * 16 + (size_t)fld * 16 + (lane & 15);
+                        dst.movers[at] = d.movers[at];
+                    }
                 }
             }
         }
@@ -1485,7 +1488,7 @@ struct AmiGrayPainter : AmiPainter<1> {
 
 // One wave rasterises one env; AMI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte stores, background-only
 // units are stored directly.
-template <int C>
+template <int C, bool ALT>
 __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t* out, int first_env, int count, int split, AmiDev d_alt,
                                                                const uint8_t* __restrict__ pick_alt)
 {
@@ -1503,7 +1506,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
     AmiPainter<C> p;
     // (agent layer, generic path: flagged envs are painted from d_alt)
     AmiDev src = d;                                             // by VALUE: a select between references to kernel arguments puts both into scratch
-    if (pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;
+    if (ALT && pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;   // (ALT: the agent layer's generic path only)
     p.setup(src, env, lane, lds_mask[wave]);
 
     uint8_t* frame = out + (size_t)rel * H * W * C;
@@ -1843,9 +1846,9 @@ struct AmiOps : GameOps {
         // gray and RGBA show no such effect (scripts/ab_render.py with TBX_RENDER_SPLIT)
         const int split = split_env > 0 ? split_env : channels == 3 ? 9 : 1;
         switch (channels) {
-        case 1: hipLaunchKernelGGL(ami_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
-        case 3: hipLaunchKernelGGL(ami_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
-        case 4: hipLaunchKernelGGL(ami_render_kernel<4>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
+        case 1: if (pick_alt) hipLaunchKernelGGL((ami_render_kernel<1, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((ami_render_kernel<1, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
+        case 3: if (pick_alt) hipLaunchKernelGGL((ami_render_kernel<3, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((ami_render_kernel<3, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
+        case 4: if (pick_alt) hipLaunchKernelGGL((ami_render_kernel<4, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((ami_render_kernel<4, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
         TBX_HIP(hipGetLastError());

@@ -982,7 +982,7 @@ struct BrkPalette {
 // (scripts/ubench/): a persistent grid over address-ordered units reaches 6.1 TB/s as bare stores but 4.7-4.9 TB/s with
 // record loads and LDS staging; one-shot address-ordered waves of 1, 2, 4 or 10 CONSECUTIVE units 5.3-5.5 TB/s
 // (hipMemset on the same boxes: 6.3-6.5 TB/s).
-template <int C, bool CUSTOM>
+template <int C, bool CUSTOM, bool ALT>
 __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
                                                                BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split,
                                                                const BrkRenderRec* __restrict__ recs_alt = nullptr, const uint8_t* __restrict__ pick_alt = nullptr)
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
     // the env's record by value, ONCE, before the unit loop: scalar loads up front, none between the frame stores.  (agent
     // layer, generic path: flagged envs paint recs_alt -- the ARRAY is selected; a select between two loaded records turns
     // the scalar loads into vector loads, and a load left inside the loop is repeated per unit behind the stores)
-    const BrkRenderRec* __restrict__ rsrc = (pick_alt && wave_uniform((int)pick_alt[first_env + rel])) ? recs_alt : recs;
+    const BrkRenderRec* __restrict__ rsrc = (ALT && pick_alt && wave_uniform((int)pick_alt[first_env + rel])) ? recs_alt : recs;
     const BrkRenderRec rec = rsrc[first_env + rel];
     for (int q = part; q < NUNITS; q += split) {
         const int u = (int)(((uint32_t)(first_env + rel) * 7u + (uint32_t)q) % (uint32_t)NUNITS);
@@ -1593,8 +1593,13 @@ struct BreakoutOps : GameOps {
         // except 9..12 (scripts/ab_render.py with TBX_BRK_SPLIT); also what keeps small batches from under-filling the chip
         static const int split_env = getenv("TBX_BRK_SPLIT") ? atoi(getenv("TBX_BRK_SPLIT")) : 0;
         const int split = split_env > 0 ? split_env : C == 3 ? 10 : count <= 8192 ? 4 : count <= 32768 ? 2 : 1;   // gray / RGBA: no such effect
-        if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
-        else hipLaunchKernelGGL((brk_render_kernel<C, false>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
+        if (pick_alt) {        // the agent layer's generic path: per-env choice between two record arrays
+            if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true, true>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
+            else hipLaunchKernelGGL((brk_render_kernel<C, false, true>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
+        } else {
+            if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true, false>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
+            else hipLaunchKernelGGL((brk_render_kernel<C, false, false>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
+        }
     }
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override

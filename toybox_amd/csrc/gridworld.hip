@@ -360,7 +360,7 @@ struct GwGrayPainter : GwPainter<1> {
     }
 };
 
-template <int C>
+template <int C, bool ALT>
 __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* out, int first_env, int count, int split, GwDev d_alt,
                                                               const uint8_t* __restrict__ pick_alt)
 {
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* 
     GwPainter<C> p;
     // (agent layer, generic path: flagged envs are painted from d_alt)
     GwDev src = d;                                             // by VALUE: a select between references to kernel arguments puts both into scratch
-    if (pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;
+    if (ALT && pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;   // (ALT: the agent layer's generic path only)
     p.setup(src, env, lane, lds_mask[wave]);
     uint8_t* dst = out + (size_t)rel * H * W * C;
     for (int u = part; u < UNITS; u += split) {
@@ -621,9 +621,9 @@ struct GridWorldOps : GameOps {
         static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
         const int split = split_env > 0 ? split_env : 1;
         switch (channels) {
-        case 1: hipLaunchKernelGGL(gw_render_kernel<1>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
-        case 3: hipLaunchKernelGGL(gw_render_kernel<3>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
-        case 4: hipLaunchKernelGGL(gw_render_kernel<4>, wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
+        case 1: if (pick_alt) hipLaunchKernelGGL((gw_render_kernel<1, true>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((gw_render_kernel<1, false>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
+        case 3: if (pick_alt) hipLaunchKernelGGL((gw_render_kernel<3, true>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((gw_render_kernel<3, false>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
+        case 4: if (pick_alt) hipLaunchKernelGGL((gw_render_kernel<4, true>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((gw_render_kernel<4, false>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
         TBX_HIP(hipGetLastError());

@@ -34,16 +34,6 @@ struct PixBytes<3> {
         p[1] = (c1 >> 8) | (c2 << 16);
         p[2] = (c2 >> 16) | (c3 << 8);
     }
-    // the same 12 bytes with three v_perm_b32 (selector bytes 0..3 = second operand, 4..7 = first) instead of four masks and
-    // six shift / or.  A/B on one box (scripts/ab_render.py): SpaceInvaders +4 %, Breakout +-0, Amidar -6 % -- the rasterisers
-    // are sensitive to how their waves fall into step, not only to instruction counts -- so each game picks its form.
-    static __device__ __forceinline__ void write_perm(uint8_t* lds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
-    {
-        uint32_t* p = reinterpret_cast<uint32_t*>(lds);
-        p[0] = __builtin_amdgcn_perm(c1, c0, 0x04020100u);   // c0.r c0.g c0.b c1.r
-        p[1] = __builtin_amdgcn_perm(c2, c1, 0x05040201u);   // c1.g c1.b c2.r c2.g
-        p[2] = __builtin_amdgcn_perm(c3, c2, 0x06050402u);   // c2.b c3.r c3.g c3.b
-    }
 };
 template <>
 struct PixBytes<1> {
@@ -105,13 +95,6 @@ struct RowStager {
             *reinterpret_cast<uint32_t*>(lds + row_in_unit * ROW_BYTES + group * 4) = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
         else
             PixBytes<C>::write(lds + row_in_unit * ROW_BYTES + group * 4 * C, c0, c1, c2, c3);
-    }
-
-    // put4p with the v_perm form of the RGB packing (PixBytes<3>::write_perm)
-    __device__ __forceinline__ void put4p_perm(int row_in_unit, int group, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) const
-    {
-        if (C == 3) PixBytes<3>::write_perm(lds + row_in_unit * ROW_BYTES + group * 12, c0, c1, c2, c3);
-        else put4p(row_in_unit, group, c0, c1, c2, c3);
     }
 
     // a whole unit of one colour (already through pix_of<C>()) straight to dst, without staging.  RGB: the byte stream

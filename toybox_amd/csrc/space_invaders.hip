@@ -640,6 +640,8 @@ __constant__ uint32_t SI_SPR_D2[TBX_SI_SHIP_H] = TBX_SI_SPRITE_SHIP_D2;
 __constant__ uint32_t SI_SPR_UFO[TBX_SI_UFO_H] = TBX_SI_SPRITE_UFO;
 
 
+constexpr int SI_UNIT_ROWS = 6;   // 210 = 35 units; 6 x 960 B (RGB) = 5760 B of LDS per wave
+
 // paints sprite row bits (bit k = column k, `w` <= 32 columns) at x position sx into the lane's pixel groups
 template <int NG>
 __device__ __forceinline__ void paint_bits(uint32_t (&px)[NG][4], const int (&gx)[NG], int sx, uint32_t bits, int w, uint32_t col)
@@ -677,16 +679,6 @@ constexpr int SI_NG = 2;
 // the block's LDS copy of every sprite row (si_fill_sprites): enemy pose A, pose B, explosion, ship, ship death 1 / 2, ufo
 constexpr int SPR_SHIP = 3 * TBX_SI_ENEMY_H, SPR_D1 = SPR_SHIP + TBX_SI_SHIP_H, SPR_D2 = SPR_D1 + TBX_SI_SHIP_H;
 constexpr int SPR_UFO = SPR_D2 + TBX_SI_SHIP_H, SPR_WORDS = SPR_UFO + TBX_SI_UFO_H;
-
-// A finished painter as a 3.5 KB record per env: SI_REC_FIELDS coalesced 256-byte rows, word [k][lane].  Stage 1 of the
-// rasteriser (si_render_prep_kernel) runs the painter's set-up once per env and writes it; the rasteriser's waves -- several
-// per frame -- rebuild their registers from it with SI_REC_FIELDS independent loads instead of ~1 500 instructions each.
-//   row 0: the env's scalars (word i = field i, i < NF); words NF.. : busy-row mask (7 words), row ranges of enemies /
-//          shield rows / lasers as lo | hi << 16 clamped to the frame (3 words), HUD digits as nibbles (1 word)
-//   rows 1..13: enemy x, enemy y, sprite-table base | flags << 8 (lane = enemy); shield row bits (lane = shield row);
-//          laser x, y, w, h, colour (lane = laser slot); candidate-enemy masks of the lane's two pixel groups (4 words)
-constexpr int SI_REC_FIELDS = 14, SI_REC_WORDS = SI_REC_FIELDS * 64;
-static_assert(NF + 11 <= 64, "the wave-uniform painter words share row 0 with the scalars");
 
 template <int C>
 struct SiPainter {
@@ -825,102 +817,6 @@ struct SiPainter {
             busy[k] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(lo) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(hi) << 32);
         }
         __builtin_amdgcn_wave_barrier();
-    }
-
-    // (stage 1, after setup) everything paint_row reads, as the env's painter record
-    __device__ __forceinline__ void export_rec(uint32_t* __restrict__ r) const
-    {
-        const int32_t* f = s.f;
-        int sc = f[F_SCORE]; if (sc < 0) sc = 0; sc %= 100000;
-        int lv = f[F_LIVES]; lv = lv < 0 ? 0 : lv > 9 ? 9 : lv;
-        int le = f[F_LEVEL]; if (le < 0) le = 0; le %= 10;
-        uint32_t digits = 0; int div = 10000;
-#pragma unroll
-        for (int q = 0; q < 5; q++) { digits |= (uint32_t)((sc / div) % 10) << (4 * q); div /= 10; }
-        digits |= (uint32_t)lv << 20; digits |= (uint32_t)le << 24;
-        auto clampy = [](long v) { return (uint32_t)(v < 0 ? 0 : v > H ? H : v); };
-        // lane i < NF carries field i, lanes NF .. NF+10 the wave-uniform painter words (selects by value, no indexed array:
-        // an array indexed in a select chain lands in scratch)
-        int32_t fv = 0;
-#pragma unroll
-        for (int i = 0; i < NF; i++) fv = lane == i ? f[i] : fv;
-        fv = lane == NF + 0 ? (int32_t)(uint32_t)busy[0] : fv; fv = lane == NF + 1 ? (int32_t)(uint32_t)(busy[0] >> 32) : fv;
-        fv = lane == NF + 2 ? (int32_t)(uint32_t)busy[1] : fv; fv = lane == NF + 3 ? (int32_t)(uint32_t)(busy[1] >> 32) : fv;
-        fv = lane == NF + 4 ? (int32_t)(uint32_t)busy[2] : fv; fv = lane == NF + 5 ? (int32_t)(uint32_t)(busy[2] >> 32) : fv;
-        fv = lane == NF + 6 ? (int32_t)(uint32_t)busy[3] : fv;
-        fv = lane == NF + 7 ? (int32_t)(clampy(e_y0) | (clampy(e_y1) << 16)) : fv;
-        fv = lane == NF + 8 ? (int32_t)(clampy(s_y0) | (clampy(s_y1) << 16)) : fv;
-        fv = lane == NF + 9 ? (int32_t)(clampy(l_lo) | (clampy(l_hi) << 16)) : fv;
-        fv = lane == NF + 10 ? (int32_t)digits : fv;
-        r[lane] = (uint32_t)fv;
-        r[1 * 64 + lane] = (uint32_t)s.ex; r[2 * 64 + lane] = (uint32_t)s.ey;
-        r[3 * 64 + lane] = (uint32_t)e_tab | (e_vis ? 0x100u : 0u) | (l_on ? 0x200u : 0u);
-        r[4 * 64 + lane] = s.srow;
-        r[5 * 64 + lane] = (uint32_t)s.lf[LF_X]; r[6 * 64 + lane] = (uint32_t)s.lf[LF_Y]; r[7 * 64 + lane] = (uint32_t)s.lf[LF_W];
-        r[8 * 64 + lane] = (uint32_t)s.lf[LF_H]; r[9 * 64 + lane] = (uint32_t)s.lf[LF_COLOR];
-        r[10 * 64 + lane] = (uint32_t)cand[0]; r[11 * 64 + lane] = (uint32_t)(cand[0] >> 32);
-        r[12 * 64 + lane] = (uint32_t)cand[1]; r[13 * 64 + lane] = (uint32_t)(cand[1] >> 32);
-    }
-
-    // (stage 2; spr_lds set by the caller first)  with_hud: this wave paints scanlines above y = 12.  Fields of `s` that
-    // paint_row does not read stay unset.
-    __device__ __forceinline__ void import_rec(const uint32_t* __restrict__ r, int lane_, bool with_hud)
-    {
-        lane = lane_;
-        uint32_t w[SI_REC_FIELDS];
-#pragma unroll
-        for (int k = 0; k < SI_REC_FIELDS; k++) w[k] = r[k * 64 + lane];          // independent loads, one latency
-        const int32_t fv = (int32_t)w[0];
-#pragma unroll
-        for (int i = 0; i < NF; i++) s.f[i] = __builtin_amdgcn_readlane(fv, i);
-        const int32_t* f = s.f;
-        gx[0] = lane * 4; gx[1] = (lane + 64) * 4;
-        gact[0] = true; gact[1] = lane + 64 < TBX_SI_W / 4;
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-            busy[k] = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(fv, NF + 2 * k) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(fv, NF + 2 * k + 1) << 32);
-        busy[3] = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(fv, NF + 6);
-        const uint32_t re = (uint32_t)__builtin_amdgcn_readlane(fv, NF + 7), rs = (uint32_t)__builtin_amdgcn_readlane(fv, NF + 8);
-        const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane(fv, NF + 9);
-        e_y0 = (int)(re & 0xFFFFu); e_y1 = (int)(re >> 16); s_y0 = (int)(rs & 0xFFFFu); s_y1 = (int)(rs >> 16);
-        l_lo = (long)(rl & 0xFFFFu); l_hi = (long)(rl >> 16);
-#pragma unroll
-        for (int g = 0; g < SI_NG; g++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) hud[g][i] = 0;
-        if (with_hud) {
-            const uint32_t digits = (uint32_t)__builtin_amdgcn_readlane(fv, NF + 10);
-            const int hud_x0[7] = {36, 44, 52, 60, 68, 148, 196};
-#pragma unroll
-            for (int q = 0; q < 7; q++) {
-                const uint32_t glyph = SI_DIGITS[(digits >> (4 * q)) & 15u];
-#pragma unroll
-                for (int g = 0; g < SI_NG; g++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int dx = gx[g] + i - hud_x0[q];
-                        if (dx >= 0 && dx < 6) hud[g][i] = (glyph >> (dx >> 1)) & 0x1249u;
-                    }
-            }
-        }
-        s.ex = (int32_t)w[1]; s.ey = (int32_t)w[2];
-        e_tab = (int)(w[3] & 0xFFu); e_vis = (w[3] & 0x100u) != 0; l_on = (w[3] & 0x200u) != 0;
-        s.srow = w[4];
-        s.lf[LF_X] = (int32_t)w[5]; s.lf[LF_Y] = (int32_t)w[6]; s.lf[LF_W] = (int32_t)w[7]; s.lf[LF_H] = (int32_t)w[8];
-        l_col = pix_of<C>(w[9]);
-        cand[0] = (uint64_t)w[10] | ((uint64_t)w[11] << 32);
-        cand[1] = (uint64_t)w[12] | ((uint64_t)w[13] << 32);
-        c_enemy = pix_of<C>(rgb_u32(TBX_SI_COL_ENEMY)); c_ufo = pix_of<C>(rgb_u32(TBX_SI_COL_UFO));
-        c_ground = pix_of<C>(rgb_u32(TBX_SI_COL_GROUND)); c_hud = pix_of<C>(rgb_u32(TBX_SI_COL_HUD));
-        c_black = pix_of<C>(0xFF000000u); c_ship = pix_of<C>((uint32_t)f[F_SHIP_COLOR]);
-        ufo_on = f[F_UFO_APP] == 0 || f[F_UFO_DC] >= 0;
-        const int sk = lane / TBX_SI_SHIELD_H, sr = lane - sk * TBX_SI_SHIELD_H;
-        s_valid = lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H && sk < f[F_N_SHIELDS];
-        s_x = sel3(sk, f[F_SHIELD_X0], f[F_SHIELD_X1], f[F_SHIELD_X2]);
-        s_y = sel3(sk, f[F_SHIELD_Y0], f[F_SHIELD_Y1], f[F_SHIELD_Y2]) + sr;
-        s_c = pix_of<C>((uint32_t)sel3(sk, f[F_SHIELD_C0], f[F_SHIELD_C1], f[F_SHIELD_C2]));
-        ym_cached = 0ull; ec_multi = false;
-        ec_shift[0] = ec_shift[1] = 31; ec_row0[0] = ec_row0[1] = 0;
     }
 
     // the classes whose entities differ between two states of one env (wave-uniform bit mask)
@@ -1087,53 +983,19 @@ __device__ __forceinline__ void si_fill_sprites(uint32_t* spr_lds)
     __syncthreads();
 }
 
-// the same for ONE wave's private copy (no block barrier: the rasteriser's waves start and finish independently)
-__device__ __forceinline__ void si_fill_sprites_wave(uint32_t* spr, int lane)
-{
-    for (int t = lane; t < SPR_WORDS; t += 64) {
-        uint32_t v;
-        if (t < TBX_SI_ENEMY_H) v = SI_SPR_A[t];
-        else if (t < 2 * TBX_SI_ENEMY_H) v = SI_SPR_B[t - TBX_SI_ENEMY_H];
-        else if (t < SPR_SHIP) v = SI_SPR_BOOM[t - 2 * TBX_SI_ENEMY_H];
-        else if (t < SPR_D1) v = SI_SPR_SHIP[t - SPR_SHIP];
-        else if (t < SPR_D2) v = SI_SPR_D1[t - SPR_D1];
-        else if (t < SPR_UFO) v = SI_SPR_D2[t - SPR_D2];
-        else v = SI_SPR_UFO[t - SPR_UFO];
-        spr[t] = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// stage 1 of the rasteriser: one wave per env runs the painter's set-up once and writes the painter record
-// (agent layer, generic path: envs flagged in pick_alt are set up from d_alt)
-__global__ __launch_bounds__(TBX_BLOCK) void si_render_prep_kernel(SiDev d, uint32_t* __restrict__ recs, int first_env, int count, SiDev d_alt,
-                                                                   const uint8_t* __restrict__ pick_alt)
-{
-    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][SiPainter<1>::NCLS * 8];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
-    if (rel >= count) return;
-    const int env = first_env + rel;
-    SiPainter<1> p;
-    p.spr_lds = nullptr;                                      // the set-up does not touch the sprite rows
-    SiDev src = d;                                             // by VALUE: a select between references to kernel arguments puts both into scratch
-    if (pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;
-    p.setup(src, env, lane, lds_mask[wave]);
-    p.export_rec(recs + (size_t)env * SI_REC_WORDS);
-}
-
-// stage 2: `split` waves per frame, wave `part` painting the units part, part + split, ...; UR scanlines (a "unit") are staged
-// in LDS and flushed as 16-byte stores, blank units are stored directly.
-template <int C, int UR>
-__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(const uint32_t* __restrict__ recs, uint8_t* out, int first_env, int count, int skip_blank,
-                                                              int split)
+// One wave rasterises one env, scanline by scanline; SI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte
+// stores, blank units are stored directly.  `split` > 1: that many waves share a frame (small batches).
+// (agent layer, generic path: envs flagged in pick_alt are painted from d_alt)
+template <int C, bool ALT>
+__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank, int split, SiDev d_alt,
+                                                              const uint8_t* __restrict__ pick_alt)
 {
     constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
-    using Stager = RowStager<C, W, UR>;
+    using Stager = RowStager<C, W, SI_UNIT_ROWS>;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
-    __shared__ uint32_t spr_all[TBX_WAVES_PER_BLOCK][SPR_WORDS];
+    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][SiPainter<C>::NCLS * 8];
+    __shared__ uint32_t spr_lds[SPR_WORDS];
+    si_fill_sprites(spr_lds);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);   // `split` waves share a frame (see breakout.hip)
@@ -1142,25 +1004,25 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(const uint32_t* __
     const int env = first_env + rel;
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
     SiPainter<C> p;
-    p.spr_lds = spr_all[wave];
-    si_fill_sprites_wave(spr_all[wave], lane);
-    p.import_rec(recs + (size_t)env * SI_REC_WORDS, lane, part * UR < 12);
+    p.spr_lds = spr_lds;
+    SiDev src = d;                                            // by VALUE: a select between references to kernel arguments puts both into scratch
+    if (ALT && pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;   // (ALT: the agent layer's generic path only)
+    p.setup(src, env, lane, lds_mask[wave]);
 
     uint8_t* frame = out + (size_t)rel * H * W * C;
-    constexpr int NUNITS = H / UR;
-    // one wave per frame: the start unit rotates with the env so that co-resident waves do not march in lockstep
+    constexpr int NUNITS = H / SI_UNIT_ROWS;
     const int u0 = split > 1 ? 0 : (int)(((uint32_t)env * 11u) % (uint32_t)NUNITS);
     for (int k = part; k < NUNITS; k += split) {
         int u = u0 + k;
         if (u >= NUNITS) u -= NUNITS;
-        const uint32_t rows_busy = (skip_blank & 1) ? row_mask_chunk<UR>(p.busy, u * UR) : (1u << UR) - 1u;
+        const uint32_t rows_busy = (skip_blank & 1) ? row_mask_chunk<SI_UNIT_ROWS>(p.busy, u * SI_UNIT_ROWS) : (1u << SI_UNIT_ROWS) - 1u;
         if (rows_busy == 0 && C != 4) {                      // nothing but background: no staging (for RGBA the
             Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_black);   // staged path measured faster)
             continue;
         }
 #pragma unroll 1
-        for (int r = 0; r < UR; r++) {
-            const int y = u * UR + r;
+        for (int r = 0; r < SI_UNIT_ROWS; r++) {
+            const int y = u * SI_UNIT_ROWS + r;
             uint32_t px[NG][4];
             if (((rows_busy >> r) & 1u) && !(skip_blank & 2)) p.paint_row(y, px);
             else {
@@ -1171,7 +1033,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(const uint32_t* __
             }
 #pragma unroll
             for (int g = 0; g < NG; g++)
-                if (p.gact[g]) st.put4p_perm(r, lane + 64 * g, px[g][0], px[g][1], px[g][2], px[g][3]);
+                if (p.gact[g]) st.put4p(r, lane + 64 * g, px[g][0], px[g][1], px[g][2], px[g][3]);
         }
         if (!(skip_blank & 4)) st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
     }
@@ -1355,7 +1217,6 @@ struct SiOps : GameOps {
         hipFree(d.rng); hipFree(d.sc); hipFree(d.enemies); hipFree(d.shields); hipFree(d.lasers);
         hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.enemies); hipFree(dA.shields); hipFree(dA.lasers);
         hipFree(dB.rng); hipFree(dB.sc); hipFree(dB.enemies); hipFree(dB.shields); hipFree(dB.lasers);
-        hipFree(recs);
     }
 
     int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
@@ -1450,8 +1311,6 @@ struct SiOps : GameOps {
         return render_impl(e, d, d, nullptr, out_dev, channels, first_env, n_envs, s);
     }
 
-    uint32_t* recs = nullptr;      // [N][SI_REC_WORDS] painter records, rewritten by every render launch
-
     int render_impl(tbx_engine* e, const SiDev& src, const SiDev& alt, const uint8_t* pick_alt, uint8_t* out_dev, int channels, int first_env,
                     int n_envs, hipStream_t s)
     {
@@ -1459,22 +1318,15 @@ struct SiOps : GameOps {
         // only), bit 1 = no stores (painting only)
         static const int skip_blank = (getenv("TBX_SI_NO_SKIP") ? 0 : 1) | (getenv("TBX_SI_DIAG") ? atoi(getenv("TBX_SI_DIAG")) << 1 : 0);
         static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
-        const int split = split_env > 0 ? split_env : channels == 3 ? 18 : 1;
-        if (!recs) TBX_HIP(hipMalloc((void**)&recs, (size_t)e->n * SI_REC_WORDS * sizeof(uint32_t)));
-        hipLaunchKernelGGL(si_render_prep_kernel, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, src, recs, first_env, n_envs, alt, pick_alt);
-        TBX_HIP(hipGetLastError());
-        static const int unit_env = getenv("TBX_SI_UNIT") ? atoi(getenv("TBX_SI_UNIT")) : 0;
-        const int ur = unit_env > 0 ? unit_env : 6;
-#define SI_RENDER(C, UR) hipLaunchKernelGGL((si_render_kernel<C, UR>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, out_dev, first_env, n_envs, skip_blank, split)
+        // the painter set-up (~1 500 instructions) is too heavy to repeat many times per frame, so one wave per frame -- except
+        // for batches that would leave the chip under-filled (five waves per frame up to 32 768 envs).  A two-stage form
+        // (set-up once per env into a 3.5 KB record, 9-18 light waves per frame rebuilding their registers from it) was
+        // built and measured this round: 10-12 % SLOWER than this kernel on four boxes out of four.
+        const int split = split_env > 0 ? split_env : (channels != 1 && n_envs <= 32768) ? 5 : 1;
         switch (channels) {
-        case 1: SI_RENDER(1, 6); break;
-        case 3:
-            if (ur == 10) SI_RENDER(3, 10);
-            else if (ur == 14) SI_RENDER(3, 14);
-            else if (ur == 2) SI_RENDER(3, 2);
-            else SI_RENDER(3, 6);
-            break;
-        case 4: SI_RENDER(4, 6); break;
+        case 1: if (pick_alt) hipLaunchKernelGGL((si_render_kernel<1, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); else hipLaunchKernelGGL((si_render_kernel<1, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); break;
+        case 3: if (pick_alt) hipLaunchKernelGGL((si_render_kernel<3, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); else hipLaunchKernelGGL((si_render_kernel<3, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); break;
+        case 4: if (pick_alt) hipLaunchKernelGGL((si_render_kernel<4, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); else hipLaunchKernelGGL((si_render_kernel<4, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
         TBX_HIP(hipGetLastError());
