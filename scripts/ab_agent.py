@@ -12,20 +12,24 @@ game = sys.argv[1]
 libs = []
 for p in sys.argv[2:]:
     lib = C.CDLL(p)
-    _abi.bind(lib)
+    for name, (res, args) in _abi.PROTOTYPES.items():     # older builds lack the newest entry points: bind what is there
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
     libs.append((p, lib))
 n = 65536
 for rnd in range(3):
     for p, lib in libs:
         e = Engine(game, n, lib=lib)
         e.seed(1234)
-        e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True)
+        dm = bool(int(os.environ.get("AB_DEEPMIND", "0")))
+        e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=dm, fire_reset=dm, noop_max=30 if dm else 0)
         e.agent_reset()
-        for t in range(10):
+        for t in range(int(os.environ.get("AB_PREROLL", "10"))):
             e.agent_step_synthetic(1337, t)
         hip.synchronize()
         t0 = time.perf_counter()
-        for t in range(10, 70):
+        for t in range(1000, 1060):
             e.agent_step_synthetic(1337, t)
         hip.synchronize()
         dt = (time.perf_counter() - t0) / 60
