@@ -403,7 +403,9 @@ int tbx_render_env(tbx_engine* engine, int env, uint8_t* out_host, int channels)
  * replaces Toybox.to_state_json / write_state_json (interventions/base.py:391,406).
  * tbx_set_state stores the CANONICAL form of the record and tbx_get_state returns it: slots beyond the counts (balls,
  * bricks, enemies, lasers, shields, boxes) zeroed, flags 0 / 1, an absent counter -1, direction fields two bits wide,
- * Amidar tile tags two bits wide, paddings zero.  Records a game produces itself are canonical already. */
+ * Amidar tile tags two bits wide, paddings zero.  Records a game produces itself are canonical already.
+ * Capacity: counts beyond the fixed tables (TBX_*_MAX_*) and SpaceInvaders enemies whose row / col leave 0..255 or whose id
+ * leaves 0..65535 (the device packs the three into one word) are refused with TBX_E_UNSUPPORTED, never truncated. */
 int tbx_get_state(tbx_engine* engine, int env, void* pod_out, size_t size);
 int tbx_set_state(tbx_engine* engine, int env, const void* pod, size_t size);
 /* Batched forms for intervention sweeps over many envs: `count` consecutive records of

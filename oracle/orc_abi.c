@@ -427,6 +427,11 @@ int tbx_set_state(tbx_engine* e, int env, const void* pod, size_t size)
         if (s->n_enemies < 0 || s->n_enemies > TBX_SI_MAX_ENEMIES) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 64 enemies per env");
         if (s->n_enemy_lasers < 0 || s->n_enemy_lasers > TBX_SI_MAX_LASERS) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 8 enemy lasers per env");
         if (s->n_shields < 0 || s->n_shields > TBX_SI_MAX_SHIELDS) return fail(e, TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 3 shields per env");
+        for (int k = 0; k < s->n_enemies; k++) {
+            const tbx_si_enemy_t* en = &s->enemies[k];
+            if (en->row < 0 || en->row > 255 || en->col < 0 || en->col > 255 || en->id < 0 || en->id > 65535)
+                return fail(e, TBX_E_UNSUPPORTED, "space_invaders: the device engine keeps an enemy's row, col (0..255) and id (0..65535) in one word");
+        }
     }
     if (e->game == TBX_GAME_GRIDWORLD) {
         const tbx_gridworld_state_t* s = (const tbx_gridworld_state_t*)pod;

@@ -110,6 +110,17 @@ def test_capacity_limits_are_reported(lib):
     with pytest.raises(ToyboxAmdError) as ei:
         s.set_state(0, st)
     assert ei.value.code == _abi.E_UNSUPPORTED
+    st = s.get_state(0)
+    for field, bad in (("row", 256), ("col", -1), ("id", 65536)):     # the enemy table packs these three into one word
+        st2 = type(st).from_buffer_copy(bytes(st))
+        setattr(st2.enemies[3], field, bad)
+        with pytest.raises(ToyboxAmdError) as ei:
+            s.set_state(0, st2)
+        assert ei.value.code == _abi.E_UNSUPPORTED
+    st.enemies[3].row, st.enemies[3].col, st.enemies[3].id = 255, 255, 65535      # the extremes round-trip
+    s.set_state(0, st)
+    back = s.get_state(0)
+    assert (back.enemies[3].row, back.enemies[3].col, back.enemies[3].id) == (255, 255, 65535)
     a = Engine("amidar", 1, lib=lib)
     st = a.get_state(0)
     st.n_enemies = 9

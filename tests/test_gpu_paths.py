@@ -156,6 +156,46 @@ for t in range(120):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tpe", ["0", "1"])
+def test_amidar_step_kernel_forms_parity(tpe, oracle_lib):
+    """Amidar's batch step has two forms, chosen by batch size (thread per env from 24 576 envs up, wavefront per env
+    below): TBX_AMI_STEP_TPE forces either one at a batch size the oracle finishes, through the batch protocol, device
+    actions and the agent pipeline with every reset-time wrapper on."""
+    body = r"""
+n, steps = 1100, 700      # not a multiple of 64: the thread form's last wave is ragged
+g, o = Engine("amidar", n, lib=hip), Engine("amidar", n, lib=orc)
+for e in (g, o):
+    e.seed(77); e.new_game()
+for t in range(steps):
+    a = synthetic_actions("amidar", n, t)
+    rg, ro = g.step(a, auto_reset=True), o.step(a, auto_reset=True)
+    for x, y in zip(rg, ro):
+        assert np.array_equal(x, y), t
+    if t % 233 == 232:
+        assert np.array_equal(g.render(3)[::37], o.render(3)[::37])
+for i in range(n):
+    assert bytes(g.get_state(i)) == bytes(o.get_state(i)), i
+for t in range(100):
+    g.step_synthetic(1337, t, env_offset=3, auto_reset=True)
+    o.step(synthetic_actions("amidar", n, t, seed=1337, env_offset=3), auto_reset=True)
+g.sync()
+for i in range(0, n, 3):
+    assert bytes(g.get_state(i)) == bytes(o.get_state(i)), i
+for e in (g, o):
+    e.agent_init(skip=4, episodic_life=True, fire_reset=True, noop_max=8, noop_seed=3)
+assert np.array_equal(g.agent_reset(), o.agent_reset())
+for t in range(150):
+    a = synthetic_actions("amidar", n, t, seed=11)
+    xg, xo = g.agent_step(a), o.agent_step(a)
+    for x, y in zip(xg, xo):
+        assert np.array_equal(x, y), t
+for i in range(0, n, 3):
+    assert bytes(g.get_state(i)) == bytes(o.get_state(i)), i
+"""
+    _run_sub(body, {"TBX_AMI_STEP_TPE": tpe})
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("split", ["1", "2", "3", "5", "7", "16"])
 def test_render_split_factors_parity(split, oracle_lib):
     """The rasterisers take `split` waves per frame (launch-time choice, by default a function of game, channels and batch

@@ -1097,18 +1097,27 @@ __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, AmiDev slot_
                     for (int i = 0; i < A_CJ0; i++) dst.sc[(size_t)i * N + env] = e.f[i];
                     src.buf_valid[env] |= (uint8_t)(1u << which);
                 }
-                for (uint64_t m = __ballot(mine); m; m &= m - 1) {
-                    const int r = (int)__builtin_ctzll(m);
-                    if (lane < 32) dst.tiles[(size_t)(env0 + r) * 32 + lane] = lds_rows[r * tpe::ROW_STRIDE + lane];
-                    dst.boxes[(size_t)(env0 + r) * 128 + lane] = d.boxes[(size_t)(env0 + r) * 128 + lane];
-                    dst.boxes[(size_t)(env0 + r) * 128 + 64 + lane] = d.boxes[(size_t)(env0 + r) * 128 + 64 + lane];
-                    // the movers' positions and caught flags: the three table rows the painter reads (the table is current:
-                    // the thread form writes it along with its struct-of-arrays mirror)
-                    if (lane < 48) {
-                        const int fld = lane < 16 ? M_X : lane < 32 ? M_Y : M_CAUGHT;
-                        const size_t at = (size_t)(env0 + r) * NMF * 16 + (size_t)fld * 16 + (lane & 15);
-                        dst.movers[at] = d.movers[at];
-                    }
+                // flat element loops over the wave's 64 envs (independent loads, so several are in flight at once; one env
+                // after the other was a chain of 64 load -> store round trips per slot)
+                const uint64_t want = __ballot(mine);
+#pragma unroll 4
+                for (int it = 0; it < 32; it++) {                      // board rows: 64 envs x 32 rows of 8 bytes, from LDS
+                    const int g = it * 64 + lane, r = g >> 5;
+                    if ((want >> r) & 1ull) dst.tiles[(size_t)env0 * 32 + g] = lds_rows[r * tpe::ROW_STRIDE + (g & 31)];
+                }
+#pragma unroll 4
+                for (int it = 0; it < 128; it++) {                     // boxes: 64 envs x 128 dwords
+                    const int g = it * 64 + lane, r = g >> 7;
+                    if ((want >> r) & 1ull) dst.boxes[(size_t)env0 * 128 + g] = d.boxes[(size_t)env0 * 128 + g];
+                }
+                // the movers' positions and caught flags: the three table rows the painter reads (the table is current: the
+                // thread form writes it along with its struct-of-arrays mirror)
+#pragma unroll 4
+                for (int it = 0; it < 48; it++) {                      // 64 envs x 3 rows x 16 slots
+                    const int g = it * 64 + lane, r = g / 48, w = g - r * 48;
+                    const int fld = w < 16 ? M_X : w < 32 ? M_Y : M_CAUGHT;
+                    const size_t at = (size_t)(env0 + r) * NMF * 16 + (size_t)fld * 16 + (w & 15);
+                    if ((want >> r) & 1ull) dst.movers[at] = d.movers[at];
                 }
             }
         }
@@ -1157,11 +1166,16 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_new_game_kernel(AmiDev d, const
 }
 
 // one frame (or the agent layer's whole action repeat) of one env on one wave
+// AGENT: the agent layer's whole action repeat with MaxAndSkipEnv's bookkeeping; the batch protocol's instantiation carries
+// neither the slot structs nor the frame loop and needs fewer registers (the kernel is bound by latency x occupancy)
+template <bool AGENT>
 __device__ __forceinline__ void ami_step_body(const AmiDev& d, const AmiDev& slot_a, const AmiDev& slot_b, const ActionSource& src, uint32_t flags, int env, int lane)
 {
     const size_t N = (size_t)d.n;
-    if (src.exec_flag && lane == 0) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
-    if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
+    if (AGENT) {
+        if (src.exec_flag && lane == 0) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
+        if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
+    }
 
     uint32_t buttons;
     if (src.single_env >= 0) {
@@ -1183,7 +1197,7 @@ __device__ __forceinline__ void ami_step_body(const AmiDev& d, const AmiDev& slo
     AmiRegs s;
     ami_load(d, env, lane, s);
     int32_t prev = d.prev_score[env];
-    const int frames = src.frames > 1 ? src.frames : 1;
+    const int frames = AGENT && src.frames > 1 ? src.frames : 1;
     int32_t rew = 0, out_lives = 0, out_score = 0;
     bool is_done = false;
     for (int fr = 0; fr < frames; fr++) {                  // > 1: the agent layer's action repeat, state stays in registers
@@ -1201,13 +1215,15 @@ __device__ __forceinline__ void ami_step_body(const AmiDev& d, const AmiDev& slo
             if (lane == 0) { d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1; }
             prev = s.f[A_SCORE];
         }
-        if (lane == 0) tbx_accumulate(src, env, rew, is_done, fr);
-        if (src.buf_valid) {                                 // MaxAndSkipEnv's frame buffer: slot A after frame skip-2, B after skip-1
-            const uint32_t slots = tbx_snap_slots(src, fr);
-            if (slots & 1u) ami_store(slot_a, env, lane, s);
-            if (slots & 2u) ami_store(slot_b, env, lane, s);
-            if (slots && lane == 0) src.buf_valid[env] |= (uint8_t)slots;
-            if (is_done) break;                              // ... and its loop ends with the game
+        if (AGENT) {
+            if (lane == 0) tbx_accumulate(src, env, rew, is_done, fr);
+            if (src.buf_valid) {                             // MaxAndSkipEnv's frame buffer: slot A after frame skip-2, B after skip-1
+                const uint32_t slots = tbx_snap_slots(src, fr);
+                if (slots & 1u) ami_store(slot_a, env, lane, s);
+                if (slots & 2u) ami_store(slot_b, env, lane, s);
+                if (slots && lane == 0) src.buf_valid[env] |= (uint8_t)slots;
+                if (is_done) break;                          // ... and its loop ends with the game
+            }
         }
     }
     ami_store(d, env, lane, s);
@@ -1223,19 +1239,27 @@ __device__ __forceinline__ void ami_step_body(const AmiDev& d, const AmiDev& slo
 }
 
 
-__global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, AmiDev slot_a, AmiDev slot_b, ActionSource src, uint32_t flags, int first_env, int count)
+__global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, ActionSource src, uint32_t flags, int first_env, int count)
 {
     const int lane = threadIdx.x & 63;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     if (rel >= count) return;
-    ami_step_body(d, slot_a, slot_b, src, flags, first_env + rel, lane);
+    ami_step_body<false>(d, d, d, src, flags, first_env + rel, lane);
+}
+
+__global__ __launch_bounds__(TBX_BLOCK) void ami_agent_step_kernel(AmiDev d, AmiDev slot_a, AmiDev slot_b, ActionSource src, uint32_t flags, int first_env, int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (rel >= count) return;
+    ami_step_body<true>(d, slot_a, slot_b, src, flags, first_env + rel, lane);
 }
 
 // resident single-env form (tbx_serve_loop, tbx_common.hpp): one wave, env 0
 __global__ __launch_bounds__(64) void ami_serve_kernel(AmiDev d, TbxServeCtl* ctl)
 {
     const int lane = threadIdx.x & 63;
-    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { ami_step_body(d, d, d, src, flags, 0, lane); },
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { ami_step_body<false>(d, d, d, src, flags, 0, lane); },
                    d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
@@ -1756,14 +1780,23 @@ struct AmiOps : GameOps {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         dA.tab = dB.tab = d.tab;
-        static const bool no_tpe = getenv("TBX_AMI_STEP_TPE") && atoi(getenv("TBX_AMI_STEP_TPE")) == 0;
-        if (!no_tpe && src.single_env < 0) {
-            // batches: one THREAD per env (the wave-per-env form stays for single-env calls and the in-kernel reset procedure)
+        // TBX_AMI_STEP_TPE: 0 = never, 1 = always, unset = by batch size.  The thread form is one wave per 64 envs with a long
+        // serial path per thread (~40 us whatever the batch), the wave form scales with the batch (~28 us at 12 288 envs, ~14 us
+        // at 4 096): below ~16 k envs the wave form is the faster one (measured)
+        static const int tpe_mode = getenv("TBX_AMI_STEP_TPE") ? atoi(getenv("TBX_AMI_STEP_TPE")) : -1;
+        static const int tpe_min = getenv("TBX_AMI_STEP_TPE_MIN") ? atoi(getenv("TBX_AMI_STEP_TPE_MIN")) : 16384;
+        const bool use_tpe = tpe_mode == 0 ? false : tpe_mode == 1 ? true : e->n >= tpe_min;
+        if (use_tpe && src.single_env < 0) {
+            // large batches: one THREAD per env (the wave-per-env form stays for small batches, single-env calls and the
+            // in-kernel reset procedure)
             hipLaunchKernelGGL(ami_step_tpe_kernel, dim3((e->n + 63) / 64), dim3(64), 0, s, d, dA, dB, src, flags);
             TBX_HIP(hipGetLastError());
             return TBX_OK;
         }
-        hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, src, flags, first, count);
+        if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1)      // an agent step's frames
+            hipLaunchKernelGGL(ami_agent_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, src, flags, first, count);
+        else
+            hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

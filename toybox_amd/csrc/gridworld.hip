@@ -209,44 +209,58 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_snapshot_kernel(GwDev dst, GwDev
     if (lane == 0) buf_valid[env] |= (uint8_t)bit;
 }
 
+// One WAVE per flagged env: every lane runs the (scalar) procedure redundantly -- same loads, same values, same stores -- so
+// that the 1 KB board copies of new_game() and of the frame-buffer snapshots are done by 64 lanes instead of one (a single
+// thread copying them was 166 us per agent step at 65 536 envs)
 struct GwAgentEnv {
     const GwDev& d;
     const GwDev& slot_a;
     const GwDev& slot_b;
     int env;
+    int lane;
     GwT& s;
     __device__ __forceinline__ void snapshot(int slot)
     {
         const GwDev& dst = slot ? slot_b : slot_a;
-        gw_copy_env(dst, d, env, 0, 1);      // board, tile table, player colour; the scalars held in registers follow
-        gw_store(dst, env, s);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the cell gw_step() wrote is read by another lane below
+        gw_copy_env(dst, d, env, lane, 64);  // board, tile table, player colour; the scalars held in registers follow
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // lane 0's scalars land after the copied ones
+        if (lane == 0) gw_store(dst, env, s);
     }
     __device__ __forceinline__ void step(uint32_t buttons) { gw_step(d, env, s, buttons); }
     __device__ __forceinline__ void new_game()
     {
-        gw_copy_board(d, env, 0, 1);
+        gw_copy_board(d, env, lane, 64);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // gw_step() reads cells other lanes wrote
         gw_new_scalars(d, s);
-        d.sc[G_PCOL * (size_t)d.n + env] = (int32_t)pack_color(d.cfg->player_color);
+        if (lane == 0) d.sc[G_PCOL * (size_t)d.n + env] = (int32_t)pack_color(d.cfg->player_color);
     }
     __device__ __forceinline__ int lives() const { return s.over ? 0 : 1; }
     __device__ __forceinline__ int score() const { return s.score; }
 };
 
-__global__ __launch_bounds__(128) void gw_agent_reset_kernel(GwDev d, GwDev slot_a, GwDev slot_b, AgentResetArgs r)
+__global__ __launch_bounds__(TBX_BLOCK) void gw_agent_reset_kernel(GwDev d, GwDev slot_a, GwDev slot_b, AgentResetArgs r)
 {
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= d.n) return;
-    if (r.kind[env] == 0) return;
-    GwT s;
-    gw_load(d, env, s);
-    AgentMonitor m = agent_monitor_load(r, env);
-    GwAgentEnv ops{d, slot_a, slot_b, env, s};
-    AgentResetProc<GwAgentEnv> proc{ops, r, m, r.env_offset + (uint64_t)env, d.prev_score[env], (uint32_t)r.buf_valid[env],
-                                    r.noop_override ? r.noop_override[env] : 0, false};
-    proc.run();
-    gw_store(d, env, s);
-    d.prev_score[env] = proc.prev;
-    agent_monitor_store(r, env, m, proc.valid, proc.obs_raw);
+    const int lane = threadIdx.x & 63;
+    // a persistent grid walks the compact list of flagged envs (or every env when there is no list)
+    const int wave_id = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6)), n_waves = gridDim.x * TBX_WAVES_PER_BLOCK;
+    const int total = r.list ? wave_uniform(*r.count) : d.n;
+    for (int it = wave_id; it < total; it += n_waves) {
+        const int env = r.list ? wave_uniform(r.list[it]) : it;
+        if (wave_uniform((int)r.kind[env]) == 0) continue;
+        GwT s;
+        gw_load(d, env, s);
+        AgentMonitor m = agent_monitor_load(r, env);
+        GwAgentEnv ops{d, slot_a, slot_b, env, lane, s};
+        AgentResetProc<GwAgentEnv> proc{ops, r, m, r.env_offset + (uint64_t)env, d.prev_score[env], (uint32_t)r.buf_valid[env],
+                                        r.noop_override ? r.noop_override[env] : 0, false};
+        proc.run();
+        if (lane == 0) {
+            gw_store(d, env, s);
+            d.prev_score[env] = proc.prev;
+            agent_monitor_store(r, env, m, proc.valid, proc.obs_raw);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ render
@@ -598,7 +612,8 @@ struct GridWorldOps : GameOps {
     int agent_reset_envs(tbx_engine* e, const AgentResetArgs& r, hipStream_t s) override
     {
         dA.cfg = dB.cfg = d.cfg;
-        hipLaunchKernelGGL(gw_agent_reset_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, dA, dB, r);
+        const unsigned blocks = (unsigned)((e->n + TBX_WAVES_PER_BLOCK - 1) / TBX_WAVES_PER_BLOCK);
+        hipLaunchKernelGGL(gw_agent_reset_kernel, dim3(r.list ? std::min(blocks, 1024u) : blocks), dim3(TBX_BLOCK), 0, s, d, dA, dB, r);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

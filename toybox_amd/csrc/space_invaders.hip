@@ -9,7 +9,7 @@
 //
 // Layout in HBM: scalar fields struct-of-arrays over envs ([field][N] int32); the per-entity
 // tables are env-major so that the 64 lanes of an env's wave read them coalesced:
-//   enemies  [N][7][64] int32   lane = enemy index (x y row col id points status)
+//   enemies  [N][5][64] int32   lane = enemy index (x, y, row | col << 8 | id << 16, points, status)
 //   shields  [N][64]    uint32  lane = shield*18 + row (16-bit pixel mask)
 //   lasers   [N][8][16] int32   lane (0..8) = laser slot (8 = the ship's laser), field-major
 //
@@ -36,7 +36,9 @@ enum SiField {
     F_SHIELD_X0, F_SHIELD_X1, F_SHIELD_X2, F_SHIELD_Y0, F_SHIELD_Y1, F_SHIELD_Y2,
     F_SHIELD_C0, F_SHIELD_C1, F_SHIELD_C2, NF
 };
-enum { EF_X, EF_Y, EF_ROW, EF_COL, EF_ID, EF_POINTS, EF_STATUS, NEF };   // status: bit0 alive, bits 8.. death_counter+1
+// rci: row | col << 8 | id << 16 (the three fields no rule ever writes; row, col <= 255 and id <= 65535 are checked where
+// states come in); status: bit0 alive, bits 8.. death_counter+1
+enum { EF_X, EF_Y, EF_RCI, EF_POINTS, EF_STATUS, NEF };
 enum { LF_X, LF_Y, LF_W, LF_H, LF_T, LF_MOV, LF_SPEED, LF_COLOR, NLF };
 constexpr int SHIP_SLOT = TBX_SI_MAX_LASERS;   // lane 8 carries the ship's laser
 
@@ -76,7 +78,17 @@ struct SiRegs {
     int32_t lf[NLF];
 };
 
-__device__ __forceinline__ void si_load(const SiDev& d, int env, int lane, SiRegs& s)
+// what si_load fetched, as it lies in memory: si_store_changed() writes back only the rows a frame changed
+struct SiLoaded {
+    int32_t fv;                                   // lane i = scalar field i
+    int32_t ex, ey, rci, epoints, estatus;
+    uint32_t srow;
+    int32_t lf[NLF];
+};
+
+__device__ __forceinline__ int32_t si_rci(const SiRegs& s) { return (int32_t)((uint32_t)(s.erow & 0xFF) | ((uint32_t)(s.ecol & 0xFF) << 8) | ((uint32_t)s.eid << 16)); }
+
+__device__ __forceinline__ void si_load(const SiDev& d, int env, int lane, SiRegs& s, SiLoaded& o)
 {
     const size_t N = (size_t)d.n;
     s.rng.s0 = d.rng[env];
@@ -84,16 +96,32 @@ __device__ __forceinline__ void si_load(const SiDev& d, int env, int lane, SiReg
     // the env's NF scalars with ONE load instruction (lane i fetches field i) and a v_readlane per field actually used:
     // they land in SGPRs instead of occupying NF VGPRs, and NF - 1 single-dword VMEM instructions disappear
     static_assert(NF <= 64, "one lane per scalar field");
-    const int32_t fv = lane < NF ? d.sc[(size_t)lane * N + env] : 0;
+    o.fv = lane < NF ? d.sc[(size_t)lane * N + env] : 0;
 #pragma unroll
-    for (int i = 0; i < NF; i++) s.f[i] = __builtin_amdgcn_readlane(fv, i);
+    for (int i = 0; i < NF; i++) s.f[i] = __builtin_amdgcn_readlane(o.fv, i);
     const int32_t* e = d.enemies + (size_t)env * NEF * 64;
-    s.ex = e[EF_X * 64 + lane]; s.ey = e[EF_Y * 64 + lane]; s.erow = e[EF_ROW * 64 + lane]; s.ecol = e[EF_COL * 64 + lane];
-    s.eid = e[EF_ID * 64 + lane]; s.epoints = e[EF_POINTS * 64 + lane]; s.estatus = e[EF_STATUS * 64 + lane];
-    s.srow = d.shields[(size_t)env * 64 + lane];
+    o.ex = e[EF_X * 64 + lane]; o.ey = e[EF_Y * 64 + lane]; o.rci = e[EF_RCI * 64 + lane];
+    o.epoints = e[EF_POINTS * 64 + lane]; o.estatus = e[EF_STATUS * 64 + lane];
+    s.ex = o.ex; s.ey = o.ey; s.epoints = o.epoints; s.estatus = o.estatus;
+    s.erow = o.rci & 0xFF; s.ecol = (o.rci >> 8) & 0xFF; s.eid = (int32_t)((uint32_t)o.rci >> 16);
+    s.srow = o.srow = d.shields[(size_t)env * 64 + lane];
     const int32_t* l = d.lasers + (size_t)env * NLF * 16;
 #pragma unroll
-    for (int i = 0; i < NLF; i++) s.lf[i] = l[i * 16 + (lane & 15)];
+    for (int i = 0; i < NLF; i++) s.lf[i] = o.lf[i] = l[i * 16 + (lane & 15)];
+}
+
+__device__ __forceinline__ void si_load(const SiDev& d, int env, int lane, SiRegs& s)
+{
+    SiLoaded o;
+    si_load(d, env, lane, s, o);
+}
+
+__device__ __forceinline__ int32_t si_scalar_row(int lane, const SiRegs& s)
+{
+    int32_t fv = 0;                               // v_writelane: one instruction per field (a select chain is two)
+#pragma unroll
+    for (int i = 0; i < NF; i++) asm("v_writelane_b32 %0, %1, %2" : "+v"(fv) : "s"(wave_uniform(s.f[i])), "n"(i));
+    return fv;
 }
 
 __device__ __forceinline__ void si_store(const SiDev& d, int env, int lane, const SiRegs& s)
@@ -103,21 +131,43 @@ __device__ __forceinline__ void si_store(const SiDev& d, int env, int lane, cons
         d.rng[env] = s.rng.s0;
         d.rng[N + env] = s.rng.s1;
     }
-    {   // lane i stores field i: one store instruction for the NF scalars
-        int32_t fv = 0;
-#pragma unroll
-        for (int i = 0; i < NF; i++) fv = lane == i ? s.f[i] : fv;
-        if (lane < NF) d.sc[(size_t)lane * N + env] = fv;
-    }
+    // lane i stores field i: one store instruction for the NF scalars
+    if (lane < NF) d.sc[(size_t)lane * N + env] = si_scalar_row(lane, s);
     int32_t* e = d.enemies + (size_t)env * NEF * 64;
-    e[EF_X * 64 + lane] = s.ex; e[EF_Y * 64 + lane] = s.ey; e[EF_ROW * 64 + lane] = s.erow; e[EF_COL * 64 + lane] = s.ecol;
-    e[EF_ID * 64 + lane] = s.eid; e[EF_POINTS * 64 + lane] = s.epoints; e[EF_STATUS * 64 + lane] = s.estatus;
+    e[EF_X * 64 + lane] = s.ex; e[EF_Y * 64 + lane] = s.ey; e[EF_RCI * 64 + lane] = si_rci(s);
+    e[EF_POINTS * 64 + lane] = s.epoints; e[EF_STATUS * 64 + lane] = s.estatus;
     d.shields[(size_t)env * 64 + lane] = s.srow;
     if (lane < 16) {
         int32_t* l = d.lasers + (size_t)env * NLF * 16;
 #pragma unroll
         for (int i = 0; i < NLF; i++) l[i * 16 + lane] = s.lf[i];
     }
+}
+
+// the same state back to where si_load(.., o) took it from: only the 256-byte rows (and scalar words) that differ.  A frame
+// moves the lasers and a few counters; the formation marches every TBX_SI_MOVE_PERIOD frames, shields and statuses change on
+// hits -- the step kernel is bound by its HBM bytes, and most of them were rows written back unchanged
+__device__ __forceinline__ void si_store_changed(const SiDev& d, int env, int lane, const SiRegs& s, const SiLoaded& o)
+{
+    const size_t N = (size_t)d.n;
+    if (lane == 0) {
+        d.rng[env] = s.rng.s0;
+        d.rng[N + env] = s.rng.s1;
+    }
+    const int32_t fv = si_scalar_row(lane, s);
+    if (lane < NF && fv != o.fv) d.sc[(size_t)lane * N + env] = fv;
+    int32_t* e = d.enemies + (size_t)env * NEF * 64;
+    const int32_t rci = si_rci(s);
+    if (__ballot(s.ex != o.ex)) e[EF_X * 64 + lane] = s.ex;
+    if (__ballot(s.ey != o.ey)) e[EF_Y * 64 + lane] = s.ey;
+    if (__ballot(rci != o.rci)) e[EF_RCI * 64 + lane] = rci;
+    if (__ballot(s.epoints != o.epoints)) e[EF_POINTS * 64 + lane] = s.epoints;
+    if (__ballot(s.estatus != o.estatus)) e[EF_STATUS * 64 + lane] = s.estatus;
+    if (__ballot(s.srow != o.srow)) d.shields[(size_t)env * 64 + lane] = s.srow;
+    int32_t* l = d.lasers + (size_t)env * NLF * 16;
+#pragma unroll
+    for (int i = 0; i < NLF; i++)
+        if (__ballot(lane < 16 && s.lf[i] != o.lf[i]) && lane < 16) l[i * 16 + lane] = s.lf[i];
 }
 
 // k == 0 ? a : k == 1 ? b : c over VALUES
@@ -501,12 +551,17 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_new_game_kernel(SiDev d, SiCfg c
     }
 }
 
-// one frame (or the agent layer's whole action repeat) of one env on one wave
+// one frame (AGENT: the agent layer's whole action repeat, with MaxAndSkipEnv's bookkeeping) of one env on one wave.  Two
+// instantiations because the kernel is bound by latency x occupancy: the batch protocol's form carries neither the slot
+// structs nor the frame loop and needs fewer registers
+template <bool AGENT>
 __device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a, const SiDev& slot_b, const SiCfg& c, const ActionSource& src, uint32_t flags, int env, int lane)
 {
     const size_t N = (size_t)d.n;
-    if (src.exec_flag && lane == 0) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
-    if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
+    if (AGENT) {
+        if (src.exec_flag && lane == 0) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
+        if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
+    }
 
     uint32_t buttons;
     if (src.single_env >= 0) {
@@ -526,9 +581,10 @@ __device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a
     }
 
     SiRegs s;
-    si_load(d, env, lane, s);
+    SiLoaded loaded;
+    si_load(d, env, lane, s, loaded);
     int32_t prev = d.prev_score[env];
-    const int frames = src.frames > 1 ? src.frames : 1;
+    const int frames = AGENT && src.frames > 1 ? src.frames : 1;
     int32_t rew = 0, out_lives = 0, out_score = 0;
     bool is_done = false;
     for (int fr = 0; fr < frames; fr++) {                  // > 1: the agent layer's action repeat, state stays in registers
@@ -546,16 +602,19 @@ __device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a
             if (lane == 0) { d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1; }
             prev = s.f[F_SCORE];
         }
-        if (lane == 0) tbx_accumulate(src, env, rew, is_done, fr);
-        if (src.buf_valid) {                                 // MaxAndSkipEnv's frame buffer: slot A after frame skip-2, B after skip-1
-            const uint32_t slots = tbx_snap_slots(src, fr);
-            if (slots & 1u) si_store(slot_a, env, lane, s);
-            if (slots & 2u) si_store(slot_b, env, lane, s);
-            if (slots && lane == 0) src.buf_valid[env] |= (uint8_t)slots;
-            if (is_done) break;                              // ... and its loop ends with the game
+        if (AGENT) {
+            if (lane == 0) tbx_accumulate(src, env, rew, is_done, fr);
+            if (src.buf_valid) {                             // MaxAndSkipEnv's frame buffer: slot A after frame skip-2, B after skip-1
+                const uint32_t slots = tbx_snap_slots(src, fr);
+                if (slots & 1u) si_store(slot_a, env, lane, s);
+                if (slots & 2u) si_store(slot_b, env, lane, s);
+                if (slots && lane == 0) src.buf_valid[env] |= (uint8_t)slots;
+                if (is_done) break;                          // ... and its loop ends with the game
+            }
         }
     }
-    si_store(d, env, lane, s);
+    if (AGENT) si_store(d, env, lane, s);                 // (the agent form keeps its registers for the frame loop)
+    else si_store_changed(d, env, lane, s, loaded);
     if (lane == 0) {
         d.prev_score[env] = prev;
         d.reward[env] = rew;
@@ -567,20 +626,27 @@ __device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a
     }
 }
 
-
-__global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiDev slot_a, SiDev slot_b, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
+__global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
 {
     const int lane = threadIdx.x & 63;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     if (rel >= count) return;
-    si_step_body(d, slot_a, slot_b, c, src, flags, first_env + rel, lane);
+    si_step_body<false>(d, d, d, c, src, flags, first_env + rel, lane);
+}
+
+__global__ __launch_bounds__(TBX_BLOCK) void si_agent_step_kernel(SiDev d, SiDev slot_a, SiDev slot_b, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (rel >= count) return;
+    si_step_body<true>(d, slot_a, slot_b, c, src, flags, first_env + rel, lane);
 }
 
 // resident single-env form (tbx_serve_loop, tbx_common.hpp): one wave, env 0
 __global__ __launch_bounds__(64) void si_serve_kernel(SiDev d, SiCfg c, TbxServeCtl* ctl)
 {
     const int lane = threadIdx.x & 63;
-    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { si_step_body(d, d, d, c, src, flags, 0, lane); },
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { si_step_body<false>(d, d, d, c, src, flags, 0, lane); },
                    d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
@@ -1240,7 +1306,10 @@ struct SiOps : GameOps {
     {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
-        hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, c, src, flags, first, count);
+        if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1)      // an agent step's frames
+            hipLaunchKernelGGL(si_agent_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, c, src, flags, first, count);
+        else
+            hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
@@ -1348,6 +1417,11 @@ struct SiOps : GameOps {
             if (st.n_enemies < 0 || st.n_enemies > TBX_SI_MAX_ENEMIES) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 64 enemies per env");
             if (st.n_enemy_lasers < 0 || st.n_enemy_lasers > TBX_SI_MAX_LASERS) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 8 enemy lasers per env");
             if (st.n_shields < 0 || st.n_shields > TBX_SI_MAX_SHIELDS) return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine holds at most 3 shields per env");
+            for (int k = 0; k < st.n_enemies; k++) {
+                const auto& en = st.enemies[k];
+                if (en.row < 0 || en.row > 255 || en.col < 0 || en.col > 255 || en.id < 0 || en.id > 65535)
+                    return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine keeps an enemy's row, col (0..255) and id (0..65535) in one word");
+            }
         }
         TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof(tbx_si_state_t) * (size_t)count, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(si_unpack_kernel, dim3(count), dim3(64), 0, s, d, env, (const tbx_si_state_t*)e->staging);
