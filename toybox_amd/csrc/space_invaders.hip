@@ -301,6 +301,21 @@ __device__ __forceinline__ bool shield_hit(SiRegs& s, int lane, const Laser& l)
     return true;
 }
 
+// the clipped rectangle shield_hit() builds is not empty for some shield (wave-uniform arithmetic: the cheap way to say no)
+__device__ __forceinline__ bool near_shield(const SiRegs& s, const Laser& l)
+{
+    bool near = false;
+#pragma unroll
+    for (int k = 0; k < TBX_SI_MAX_SHIELDS; k++) {
+        const int sx = sel3(k, s.f[F_SHIELD_X0], s.f[F_SHIELD_X1], s.f[F_SHIELD_X2]);
+        const int sy = sel3(k, s.f[F_SHIELD_Y0], s.f[F_SHIELD_Y1], s.f[F_SHIELD_Y2]);
+        const int cx0 = max(l.x - sx, 0), cx1 = min(l.x + l.w - sx, TBX_SI_SHIELD_W);
+        const int cy0 = max(l.y - sy, 0), cy1 = min(l.y + l.h - sy, TBX_SI_SHIELD_H);
+        near = near || (k < s.f[F_N_SHIELDS] && cx0 < cx1 && cy0 < cy1);
+    }
+    return near;
+}
+
 __device__ __forceinline__ bool dec_counter(int32_t& c)
 {
     if (c < 0) return false;
@@ -407,8 +422,8 @@ __device__ __forceinline__ void si_step(const SiCfg& c, int lane, uint32_t butto
             f[F_SCORE] += TBX_SI_UFO_BONUS;
             has = false;
         }
-        if (has && shield_hit(s, lane, l)) has = false;
-        if (has) put_laser(s, lane, SHIP_SLOT, l);
+        if (has && near_shield(s, l) && shield_hit(s, lane, l)) has = false;
+        if (has) { if (lane == SHIP_SLOT) { s.lf[LF_X] = l.x; s.lf[LF_Y] = l.y; s.lf[LF_T] = l.t; } }   // what move_laser() changes
         else { clear_laser(s, lane, SHIP_SLOT); f[F_HAS_SHIP_LASER] = 0; }
     }
 
@@ -476,40 +491,66 @@ __device__ __forceinline__ void si_step(const SiCfg& c, int lane, uint32_t butto
         }
     }
 
-    // I. enemy lasers, in slot order
+    // I. enemy lasers.  The rules take them in slot order (bounds, then shields, then the ship), but only two things carry
+    // from one laser to the next: the shields' pixels and whether the ship is still alive.  So lane = slot moves every laser
+    // and tests the bounds at once, only the lasers whose rectangle reaches a shield's box take the eroding shield test one
+    // after the other, and the first of the rest that overlaps the living ship kills it.
     {
         const int nl = f[F_N_LASERS];
+        const bool mine = lane < nl;                      // nl <= TBX_SI_MAX_LASERS; the ship's laser sits in the slot above
         uint32_t keepmask = 0;
+        if (nl > 0) {
+            int32_t lx = s.lf[LF_X], ly = s.lf[LF_Y];
+            const int32_t lw = s.lf[LF_W], lh = s.lf[LF_H], mov = s.lf[LF_MOV], sp = s.lf[LF_SPEED];
+            if (mov == TBX_DIR_UP) ly -= sp;
+            else if (mov == TBX_DIR_DOWN) ly += sp;
+            else if (mov == TBX_DIR_LEFT) lx -= sp;
+            else lx += sp;
+            bool gone = ly + lh >= TBX_SI_GROUND_Y || ly + lh <= 0 || lx + lw <= 0 || lx >= TBX_SI_W;
+            bool near = false;                            // the clipped rectangle shield_hit() would build is not empty
 #pragma unroll
-        for (int i = 0; i < TBX_SI_MAX_LASERS; i++) {
-            if (i < nl) {
-                Laser l = get_laser(s, i);
-                move_laser(l);
-                bool gone = false;
-                if (l.y + l.h >= TBX_SI_GROUND_Y || l.y + l.h <= 0 || l.x + l.w <= 0 || l.x >= TBX_SI_W) gone = true;
-                else if (shield_hit(s, lane, l)) gone = true;
-                else if ((f[F_SHIP_FLAGS] & 1) && overlap(l.x, l.y, l.w, l.h, f[F_SHIP_X], f[F_SHIP_Y], f[F_SHIP_W], f[F_SHIP_H])) {
-                    f[F_SHIP_FLAGS] = 2; f[F_SHIP_DC] = TBX_SI_SHIP_DEATH_T;
-                    gone = true;
-                }
-                if (!gone) { keepmask |= 1u << i; put_laser(s, lane, i, l); }
+            for (int k = 0; k < TBX_SI_MAX_SHIELDS; k++) {
+                const int sx = sel3(k, f[F_SHIELD_X0], f[F_SHIELD_X1], f[F_SHIELD_X2]);
+                const int sy = sel3(k, f[F_SHIELD_Y0], f[F_SHIELD_Y1], f[F_SHIELD_Y2]);
+                const int cx0 = max(lx - sx, 0), cx1 = min(lx + lw - sx, TBX_SI_SHIELD_W);
+                const int cy0 = max(ly - sy, 0), cy1 = min(ly + lh - sy, TBX_SI_SHIELD_H);
+                near = near || (k < f[F_N_SHIELDS] && cx0 < cx1 && cy0 < cy1);
             }
+            for (uint64_t todo = __ballot(mine && !gone && near); todo; todo &= todo - 1) {
+                const int i = (int)__builtin_ctzll(todo);
+                Laser l;
+                l.x = __builtin_amdgcn_readlane(lx, i); l.y = __builtin_amdgcn_readlane(ly, i);
+                l.w = __builtin_amdgcn_readlane(lw, i); l.h = __builtin_amdgcn_readlane(lh, i);
+                if (shield_hit(s, lane, l) && lane == i) gone = true;
+            }
+            if (f[F_SHIP_FLAGS] & 1) {
+                const uint64_t hit = __ballot(mine && !gone && overlap(lx, ly, lw, lh, f[F_SHIP_X], f[F_SHIP_Y], f[F_SHIP_W], f[F_SHIP_H]));
+                if (hit) {
+                    f[F_SHIP_FLAGS] = 2; f[F_SHIP_DC] = TBX_SI_SHIP_DEATH_T;
+                    if (lane == (int)__builtin_ctzll(hit)) gone = true;
+                }
+            }
+            if (mine) { s.lf[LF_X] = lx; s.lf[LF_Y] = ly; s.lf[LF_T] += 1; }
+            keepmask = (uint32_t)__ballot(mine && !gone);
         }
-        // compaction: slot j takes the j-th kept laser; freed slots are zeroed
+        // compaction: slot j takes the j-th kept laser; freed slots are zeroed (nothing to do while no laser went: the slots
+        // above the count are zero already)
         const int keep = __popc(keepmask);
-        int src = -1;
-        if (lane < TBX_SI_MAX_LASERS && lane < keep) {
-            uint32_t m = keepmask;
-            for (int j = 0; j < lane; j++) m &= m - 1;
-            src = __builtin_ctz(m);
-        }
-        const int from = src < 0 ? lane : src;
+        if (keep != nl) {
+            int src = -1;
+            if (lane < TBX_SI_MAX_LASERS && lane < keep) {
+                uint32_t m = keepmask;
+                for (int j = 0; j < lane; j++) m &= m - 1;
+                src = __builtin_ctz(m);
+            }
+            const int from = src < 0 ? lane : src;
 #pragma unroll
-        for (int i = 0; i < NLF; i++) {
-            const int32_t v = __shfl(s.lf[i], from);
-            if (lane < TBX_SI_MAX_LASERS) s.lf[i] = src >= 0 ? v : 0;
+            for (int i = 0; i < NLF; i++) {
+                const int32_t v = __shfl(s.lf[i], from);
+                if (lane < TBX_SI_MAX_LASERS) s.lf[i] = src >= 0 ? v : 0;
+            }
+            f[F_N_LASERS] = keep;
         }
-        f[F_N_LASERS] = keep;
     }
 
     // J. ufo
