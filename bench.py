@@ -367,6 +367,8 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         return 2
+    if os.environ.get("TBX_BENCH_ONE_DEVICE"):     # diagnostic: every rank on device 0 (exercises the N > 1 flow on a 1-GPU box)
+        local_rank = 0
     hip.set_device(local_rank)
 
     game = args.game
@@ -387,16 +389,31 @@ def main():
     H, W, C = eng.height, eng.width, args.channels
     render = not args.no_render
     gather = world > 1 or args.with_gather
+    gather_note = None
+    fw = None
     if gather:
-        with quiet_stdout():
-            uid = exchange_unique_id(rank, world, eng.gather_unique_id)
-            eng.gather_init(world, rank, uid, records_per_rank=width)   # collective (ncclCommInitRank)
-        forget_unique_id(rank)
+        try:
+            if os.environ.get("TBX_BENCH_NO_RCCL"):
+                raise RuntimeError("disabled by TBX_BENCH_NO_RCCL")
+            with quiet_stdout():
+                uid = exchange_unique_id(rank, world, eng.gather_unique_id)
+                eng.gather_init(world, rank, uid, records_per_rank=width)   # collective (ncclCommInitRank)
+            forget_unique_id(rank)
+        except Exception as ex:    # no usable RCCL: the shards still run; ranks start and stop together through files
+            from toybox_amd.parallel import FileWorld
+            gather_note = "RCCL communicator unavailable (%s): no per-step gather, file barrier between ranks" % (str(ex).splitlines()[0][:160],)
+            print("bench.py: " + gather_note, file=sys.stderr)
+            gather = False
+            fw = FileWorld(rank, world)
     stream = hip.Stream()
     sp = stream.ptr
     K, Wm, R = args.steps, args.warmup, max(1, args.repeats)
-    reg = Region(hip.synchronize, (lambda: eng.gather_reduce_max(0.0)) if gather else (lambda: None),
-                 (lambda v: eng.gather_reduce_max(v)) if gather else (lambda v: v))
+    if gather:
+        reg = Region(hip.synchronize, lambda: eng.gather_reduce_max(0.0), lambda v: eng.gather_reduce_max(v))
+    elif fw is not None:
+        reg = Region(hip.synchronize, fw.barrier, fw.allreduce_max)
+    else:
+        reg = Region(hip.synchronize, lambda: None, lambda v: v)
 
     # HIP events around every render launch of the timed regions, created up front (nothing is allocated inside a region)
     pool = [(hip.Event(), hip.Event()) for _ in range(K * R)] if render else []
@@ -480,7 +497,8 @@ def main():
                                args.envs, "per GPU" if args.scaling == "weak" else "in total", args.preroll),
                 "envs_per_gpu": n, "envs_total": n_total, "frame_hwc": [H, W, C] if render else None,
                 "parallelism": ("env-sharded x%d, per-step RCCL all-gather of 8 B/env records behind the C-ABI (tbx_gather), "
-                                "overlapped with the rasteriser" % world) if gather else "single GPU",
+                                "overlapped with the rasteriser" % world) if gather else
+                               ("env-sharded x%d, no collective (%s)" % (world, gather_note)) if gather_note else "single GPU",
                 "algorithmic_bytes_per_env_step": bytes_per_step,
             },
         }

@@ -35,7 +35,7 @@ def agent_summary(tag):
 
 def sq_counters(tag):
     out = ["# SQ counters (scripts/pmc_gpu.sh: rocprofv3 --pmc with --kernel-trace only), average PER LAUNCH of the kernel class:",
-           "# `render` = *_render_kernel, `step` = *_step_kernel (wave-per-env forms); divide by SQ_WAVES for per-wave figures", ""]
+           "# `render` = *_render_kernel, `step` = *_step*_kernel; divide by SQ_WAVES for per-wave figures", ""]
     for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, "pmc_*sq*.txt"))):
         out += ["## " + os.path.basename(f)[:-4], open(f).read().rstrip(), ""]
     return "\n".join(out)

@@ -32,4 +32,5 @@ BENCH_ARGS="--game amidar --envs 4096 --no-extras --repeats 1" bash scripts/pmc_
 for g in breakout space_invaders amidar gridworld; do
   cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_agent_$g" -- python3 $REPO/bench.py --protocol agent --deepmind --game $g --steps 60 --warmup 5 > /dev/null 2>&1
 done
-cd "$REPO"; find gpurun_out -size +8M -delete; du -sh gpurun_out/$TAG gpurun_out/prof_${TAG}* | tail -20
+cd "$REPO"; python scripts/ab_step.py space_invaders toybox_amd/csrc/libtoybox_amd.so > "$OUT/step_only_space_invaders.txt" 2>&1; python scripts/ab_step.py amidar toybox_amd/csrc/libtoybox_amd.so > "$OUT/step_only_amidar.txt" 2>&1; AB_ENVS=4096 python scripts/ab_step.py amidar toybox_amd/csrc/libtoybox_amd.so > "$OUT/step_only_amidar_4096.txt" 2>&1
+find gpurun_out -size +8M -delete; du -sh gpurun_out/$TAG gpurun_out/prof_${TAG}* | tail -20

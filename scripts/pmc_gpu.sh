@@ -15,7 +15,7 @@ agg=collections.defaultdict(list)
 for f in glob.glob(sys.argv[1]+'/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name']
-        k='render' if 'render' in k else 'step' if 'step_kernel' in k else None
+        k='render' if 'render' in k else 'step' if '_step' in k else None
         if k: agg[(k,r['Counter_Name'])].append(float(r['Counter_Value']))
 for k,v in sorted(agg.items()): print(k[0],k[1],'%.4g'%(sum(v)/len(v)))
 PY

@@ -193,3 +193,30 @@ def test_gpu_shard_decomposition_independence(game, hip_lib):
             assert bytes(e.get_state(k)) == bytes(whole.get_state(r * per + k)), (game, r, k)
     for e in parts + [whole]:
         e.close()
+
+
+def _file_world_worker(rank, world, key, q):
+    from toybox_amd.parallel import FileWorld
+    fw = FileWorld(rank, world, key=key)
+    out = []
+    for i in range(40):
+        fw.barrier()
+        out.append(fw.allreduce_max(rank * 10 + i))
+    q.put((rank, out))
+
+
+def test_file_world_barrier_and_max(tmp_path, monkeypatch):
+    """bench.py's fallback when no RCCL communicator can be made: ranks of one node meet through files."""
+    import multiprocessing as mp
+    monkeypatch.setenv("TBX_RDZV_DIR", str(tmp_path))
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    world = 3
+    ps = [ctx.Process(target=_file_world_worker, args=(r, world, "t%d" % os.getpid(), q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=30)
+    assert all(out == [10 * (world - 1) + i for i in range(40)] for _, out in res)
+    assert len(list(tmp_path.iterdir())) <= world          # only the last round's files are left

@@ -104,6 +104,50 @@ def forget_unique_id(rank, tag="", key=None, directory=None):
             pass
 
 
+class FileWorld:
+    """Barrier and max-reduction between the ranks of one node through small files in the rendezvous directory: what
+    bench.py falls back to when the RCCL communicator cannot be created (the timed path has no data-path collective, so the
+    measurement only needs the ranks to start and stop together)."""
+
+    def __init__(self, rank, world, key=None, directory=None, timeout=600.0):
+        self.rank, self.world, self.timeout = int(rank), int(world), timeout
+        d = directory or os.environ.get("TBX_RDZV_DIR") or tempfile.gettempdir()
+        self.base = os.path.join(d, "tbx_fw_%s" % (key or rendezvous_key()))
+        self.seq = 0
+
+    def allreduce_max(self, value):
+        if self.world == 1:
+            return float(value)
+        self.seq += 1
+        mine = "%s_%d_%d" % (self.base, self.seq, self.rank)
+        tmp = mine + ".tmp"
+        with open(tmp, "w") as f:
+            f.write(repr(float(value)))
+        os.replace(tmp, mine)
+        deadline = time.monotonic() + self.timeout
+        vals = []
+        for r in range(self.world):
+            path = "%s_%d_%d" % (self.base, self.seq, r)
+            while True:
+                try:
+                    with open(path) as f:
+                        vals.append(float(f.read()))
+                    break
+                except (FileNotFoundError, ValueError):
+                    if time.monotonic() > deadline:
+                        raise TimeoutError("rank %d: rank %d never reached step %d of the file barrier" % (self.rank, r, self.seq))
+                    time.sleep(0.0005)
+        if self.seq > 1:                                   # every rank wrote round seq, so every rank is done reading round seq-1
+            try:
+                os.unlink("%s_%d_%d" % (self.base, self.seq - 1, self.rank))
+            except OSError:
+                pass
+        return max(vals)
+
+    def barrier(self):
+        self.allreduce_max(0.0)
+
+
 class HostGather:
     """Fallback exchange when RCCL is not available: the 8-byte records are gathered on the host through a
     torch.distributed process group with a CPU backend (gloo)."""
