@@ -1,5 +1,6 @@
 #!/bin/bash
-# stores-only / painting-only render launches (TBX_*_DIAG) against waves per frame: what bounds a rasteriser
-# usage (GPU box): bash scripts/diag_sweep.sh amidar "0 1 2 3" "1 5 9 12"
-game=$1; var=TBX_AMI_DIAG; [ "$game" = space_invaders ] && var=TBX_SI_DIAG
-for sp in ${3:-0}; do for d in ${2:-0 1 2 3}; do env $var=$d TBX_RENDER_SPLIT=$sp python scripts/render_probe.py $game 3 ${4:-65536} 400; done; done
+# stores-only / painting-only SpaceInvaders render launches (TBX_SI_DIAG: 1 = no painting, 2 = no stores, 3 = neither) against
+# waves per frame: what bounds the rasteriser (the Amidar figures there came from a temporary build
+# with the same switch).
+# usage (GPU box): bash scripts/diag_sweep.sh "0 1 2 3" "1 5 9" [envs]
+for sp in ${2:-1 5 9}; do for d in ${1:-0 1 2 3}; do TBX_SI_DIAG=$d TBX_RENDER_SPLIT=$sp python scripts/render_probe.py space_invaders 3 ${3:-65536} 400; done; done
