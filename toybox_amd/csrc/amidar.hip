@@ -1023,6 +1023,8 @@ struct Env {
 
 // the batch protocol (tbx_step / tbx_step_device / tbx_step_synthetic) and the agent layer's action repeat (`frames` frames of
 // one action with the reward summed, MaxAndSkipEnv's two buffer slots written on the way), one wave of 64 envs per block
+// AGENT: the agent layer's action repeat and frame-buffer slots; the batch protocol's instantiation carries neither
+template <bool AGENT>
 __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, AmiDev slot_a, AmiDev slot_b, ActionSource src, uint32_t flags)
 {
     __shared__ uint64_t lds_rows[64 * tpe::ROW_STRIDE];
@@ -1037,10 +1039,10 @@ __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, AmiDev slot_
         if ((g >> 5) < n_here) lds_rows[(g >> 5) * tpe::ROW_STRIDE + (g & 31)] = d.tiles[(size_t)env0 * 32 + g];
     }
     __syncthreads();
-    const bool agent = src.acc_reward != nullptr;
+    const bool agent = AGENT && src.acc_reward != nullptr;
     // an env whose game ended in an earlier launch of the same agent step sits this one out (MaxAndSkipEnv left its loop)
-    bool active = env < d.n && !(env < d.n && tbx_agent_env_finished(src, env));
-    if (src.exec_flag && env < d.n) src.exec_flag[env] = active ? 1 : 0;
+    bool active = env < d.n && !(AGENT && env < d.n && tbx_agent_env_finished(src, env));
+    if (AGENT && src.exec_flag && env < d.n) src.exec_flag[env] = active ? 1 : 0;
     uint32_t buttons = 0;
     if (active) {
         int a;
@@ -1063,7 +1065,7 @@ __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, AmiDev slot_
         for (int i = 0; i < A_CJ0; i++) e.f[i] = d.sc[(size_t)i * N + env];
         prev = d.prev_score[env];
     }
-    const int frames = src.frames > 1 ? src.frames : 1;
+    const int frames = AGENT && src.frames > 1 ? src.frames : 1;
     for (int fr = 0; fr < frames; fr++) {
         uint32_t slots = 0;
         if (active) {
@@ -1080,8 +1082,8 @@ __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, AmiDev slot_
                 d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
                 prev = e.f[A_SCORE];
             }
-            tbx_accumulate(src, env, rew, is_done, fr);
-            if (src.buf_valid) slots = tbx_snap_slots(src, fr);
+            if (AGENT) tbx_accumulate(src, env, rew, is_done, fr);
+            if (AGENT && src.buf_valid) slots = tbx_snap_slots(src, fr);
         }
         // MaxAndSkipEnv's frame buffer: the envs that ran frame skip-2 / skip-1 copy what the rasteriser reads of their
         // state into slot A / B -- scalars by the env's own thread (coalesced), board rows, boxes and the movers' position
@@ -1789,7 +1791,10 @@ struct AmiOps : GameOps {
         if (use_tpe && src.single_env < 0) {
             // large batches: one THREAD per env (the wave-per-env form stays for small batches, single-env calls and the
             // in-kernel reset procedure)
-            hipLaunchKernelGGL(ami_step_tpe_kernel, dim3((e->n + 63) / 64), dim3(64), 0, s, d, dA, dB, src, flags);
+            if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1)      // an agent step's frames
+                hipLaunchKernelGGL(ami_step_tpe_kernel<true>, dim3((e->n + 63) / 64), dim3(64), 0, s, d, dA, dB, src, flags);
+            else
+                hipLaunchKernelGGL(ami_step_tpe_kernel<false>, dim3((e->n + 63) / 64), dim3(64), 0, s, d, d, d, src, flags);
             TBX_HIP(hipGetLastError());
             return TBX_OK;
         }
