@@ -764,12 +764,17 @@ __device__ __forceinline__ void brk_t_step(const BrkCfg& c, BrkT& s, uint32_t bu
 }
 
 // one frame (or the agent layer's whole action repeat) of one env on one THREAD
+// AGENT: the agent layer's action repeat with MaxAndSkipEnv's bookkeeping and frame-buffer records; the batch protocol's
+// instantiation carries neither (fewer registers, less spill code)
+template <bool AGENT>
 __device__ __forceinline__ void brk_step_tpe_body(const BrkDev& d, const BrkCfg& c, const ActionSource& src, uint32_t flags, BrkRenderRec* recs,
                                                   BrkRenderRec* recs_a, BrkRenderRec* recs_b, int env)
 {
     const size_t N = (size_t)d.n;
-    if (src.exec_flag) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
-    if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
+    if (AGENT) {
+        if (src.exec_flag) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
+        if (tbx_agent_env_finished(src, env)) return;     // MaxAndSkipEnv left its loop when this env's game ended
+    }
 
     uint32_t buttons;
     if (src.single_env >= 0) buttons = src.single_buttons;
@@ -787,7 +792,7 @@ __device__ __forceinline__ void brk_step_tpe_body(const BrkDev& d, const BrkCfg&
     BrkT s;
     t_load(d, env, s);
     int32_t prev = d.prev_score[env];
-    const int frames = src.frames > 1 ? src.frames : 1;
+    const int frames = AGENT && src.frames > 1 ? src.frames : 1;
     int32_t rew = 0, out_lives = 0, out_score = 0;
     bool is_done = false;
     for (int fr = 0; fr < frames; fr++) {                  // > 1: the agent layer's action repeat, state stays in registers
@@ -804,16 +809,18 @@ __device__ __forceinline__ void brk_step_tpe_body(const BrkDev& d, const BrkCfg&
             d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
             prev = s.score;
         }
-        tbx_accumulate(src, env, rew, is_done, fr);
-        if (src.buf_valid) {                                 // MaxAndSkipEnv's frame buffer: slot A after frame skip-2, B after skip-1
-            const uint32_t slots = tbx_snap_slots(src, fr);
-            if (slots) {
-                const BrkRenderRec rec = t_record(s);
-                if (slots & 1u) recs_a[env] = rec;
-                if (slots & 2u) recs_b[env] = rec;
-                src.buf_valid[env] |= (uint8_t)slots;
+        if (AGENT) {
+            tbx_accumulate(src, env, rew, is_done, fr);
+            if (src.buf_valid) {                             // MaxAndSkipEnv's frame buffer: slot A after frame skip-2, B after skip-1
+                const uint32_t slots = tbx_snap_slots(src, fr);
+                if (slots) {
+                    const BrkRenderRec rec = t_record(s);
+                    if (slots & 1u) recs_a[env] = rec;
+                    if (slots & 2u) recs_b[env] = rec;
+                    src.buf_valid[env] |= (uint8_t)slots;
+                }
+                if (is_done) break;                          // ... and its loop ends with the game
             }
-            if (is_done) break;                              // ... and its loop ends with the game
         }
     }
     t_store(d, env, s);
@@ -828,19 +835,20 @@ __device__ __forceinline__ void brk_step_tpe_body(const BrkDev& d, const BrkCfg&
 }
 
 
+template <bool AGENT>
 __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, ActionSource src, uint32_t flags, BrkRenderRec* recs,
                                                            BrkRenderRec* recs_a, BrkRenderRec* recs_b)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= d.n) return;
-    brk_step_tpe_body(d, *cp, src, flags, recs, recs_a, recs_b, env);   // tables are indexed per thread: read from memory, not from kernel arguments
+    brk_step_tpe_body<AGENT>(d, *cp, src, flags, recs, recs_a, recs_b, env);   // tables are indexed per thread: read from memory, not from kernel arguments
 }
 
 // resident single-env form (tbx_serve_loop, tbx_common.hpp): lane 0 of one wave, env 0
 __global__ __launch_bounds__(64) void brk_serve_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, BrkRenderRec* recs, TbxServeCtl* ctl)
 {
     const int lane = threadIdx.x & 63;
-    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { if (lane == 0) brk_step_tpe_body(d, *cp, src, flags, recs, nullptr, nullptr, 0); },
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { if (lane == 0) brk_step_tpe_body<false>(d, *cp, src, flags, recs, nullptr, nullptr, 0); },
                    d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
@@ -1550,7 +1558,10 @@ struct BreakoutOps : GameOps {
     int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
     {
         if (!custom && src.single_env < 0 && use_tpe) {
-            hipLaunchKernelGGL(brk_step_tpe_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs, recsA, recsB);
+            if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1)      // an agent step's frames
+                hipLaunchKernelGGL(brk_step_tpe_kernel<true>, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs, recsA, recsB);
+            else
+                hipLaunchKernelGGL(brk_step_tpe_kernel<false>, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs, recsA, recsB);
             TBX_HIP(hipGetLastError());
             recs_valid = true;
             return TBX_OK;
