@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, AmiDev slot_
             out_lives = e.f[A_LIVES]; out_score = e.f[A_SCORE];
             is_done = out_lives <= 0;
             prev = out_score;
-            if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+            if (!AGENT && is_done && (flags & TBX_STEP_AUTO_RESET)) {   // (the agent layer resets through its own procedure)
                 Rng sim;
                 sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
                 e.new_game(sim);
@@ -1209,7 +1209,7 @@ __device__ __forceinline__ void ami_step_body(const AmiDev& d, const AmiDev& slo
         out_lives = s.f[A_LIVES]; out_score = s.f[A_SCORE];
         is_done = out_lives <= 0;
         prev = out_score;
-        if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+        if (!AGENT && is_done && (flags & TBX_STEP_AUTO_RESET)) {   // (the agent layer resets through its own procedure)
             Rng sim;
             sim.s0 = d.sim_rng[env];
             sim.s1 = d.sim_rng[N + env];
@@ -1791,16 +1791,18 @@ struct AmiOps : GameOps {
         if (use_tpe && src.single_env < 0) {
             // large batches: one THREAD per env (the wave-per-env form stays for small batches, single-env calls and the
             // in-kernel reset procedure)
-            if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1)      // an agent step's frames
+            if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1) {    // an agent step's frames (never auto-reset)
+                if (flags & TBX_STEP_AUTO_RESET) return e->fail(TBX_E_INVALID, "an agent step cannot auto-reset");
                 hipLaunchKernelGGL(ami_step_tpe_kernel<true>, dim3((e->n + 63) / 64), dim3(64), 0, s, d, dA, dB, src, flags);
-            else
+            } else
                 hipLaunchKernelGGL(ami_step_tpe_kernel<false>, dim3((e->n + 63) / 64), dim3(64), 0, s, d, d, d, src, flags);
             TBX_HIP(hipGetLastError());
             return TBX_OK;
         }
-        if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1)      // an agent step's frames
+        if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1) {    // an agent step's frames (never auto-reset)
+            if (flags & TBX_STEP_AUTO_RESET) return e->fail(TBX_E_INVALID, "an agent step cannot auto-reset");
             hipLaunchKernelGGL(ami_agent_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, src, flags, first, count);
-        else
+        } else
             hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         return TBX_OK;

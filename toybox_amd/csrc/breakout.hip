@@ -802,7 +802,7 @@ __device__ __forceinline__ void brk_step_tpe_body(const BrkDev& d, const BrkCfg&
         out_lives = s.lives; out_score = s.score;
         is_done = s.lives <= 0;
         prev = s.score;
-        if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+        if (!AGENT && is_done && (flags & TBX_STEP_AUTO_RESET)) {   // (the agent layer resets through its own procedure)
             Rng sim;
             sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
             t_new_game(c, sim, s);
@@ -1558,9 +1558,10 @@ struct BreakoutOps : GameOps {
     int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
     {
         if (!custom && src.single_env < 0 && use_tpe) {
-            if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1)      // an agent step's frames
+            if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1) {    // an agent step's frames (never auto-reset)
+                if (flags & TBX_STEP_AUTO_RESET) return e->fail(TBX_E_INVALID, "an agent step cannot auto-reset");
                 hipLaunchKernelGGL(brk_step_tpe_kernel<true>, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs, recsA, recsB);
-            else
+            } else
                 hipLaunchKernelGGL(brk_step_tpe_kernel<false>, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs, recsA, recsB);
             TBX_HIP(hipGetLastError());
             recs_valid = true;

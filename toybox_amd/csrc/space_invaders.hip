@@ -635,7 +635,7 @@ __device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a
         out_lives = s.f[F_LIVES]; out_score = s.f[F_SCORE];
         is_done = out_lives <= 0;
         prev = out_score;
-        if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+        if (!AGENT && is_done && (flags & TBX_STEP_AUTO_RESET)) {   // (the agent layer resets through its own procedure)
             Rng sim;
             sim.s0 = d.sim_rng[env];
             sim.s1 = d.sim_rng[N + env];
@@ -1347,9 +1347,10 @@ struct SiOps : GameOps {
     {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
-        if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1)      // an agent step's frames
+        if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1) {    // an agent step's frames (never auto-reset)
+            if (flags & TBX_STEP_AUTO_RESET) return e->fail(TBX_E_INVALID, "an agent step cannot auto-reset");
             hipLaunchKernelGGL(si_agent_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, c, src, flags, first, count);
-        else
+        } else
             hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
