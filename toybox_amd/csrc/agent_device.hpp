@@ -343,6 +343,20 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
     const ColTaps c0 = load_col(a.tx, lane, a.ow), c1 = load_col(a.tx, lane + 64, a.ow);
     const bool on0 = lane < a.ow, on1 = lane + 64 < a.ow;
     const uint32_t blank = pb.blank_dword();
+    // scanlines whose horizontal sums the painter can give without painting (P::FAST_ROWS; SpaceInvaders: scanlines that hold
+    // nothing but enemies): those of B's that frame A cannot change
+    uint64_t fast[4] = {0ull, 0ull, 0ull, 0ull};
+    if (P::FAST_ROWS) {
+        if (lane < 8) L.masks[0][lane] = P::fast_row_word(&L.cls[1][0][0], lane) & ~(two ? L.masks[1][lane] : 0u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(L.masks[0][2 * k]), hi = __builtin_amdgcn_readfirstlane(L.masks[0][2 * k + 1]);
+            fast[k] = (uint64_t)lo | ((uint64_t)hi << 32);
+        }
+        pb.fast_init(c0, c1, on0, on1);
+    }
     for (int i = lane; i < (AgentFusedLds<P>::ROWB - W) / 4; i += 64) reinterpret_cast<uint32_t*>(row + W)[i] = 0u;   // window padding
     uint32_t hb0, hb1;                                                 // horizontal sums of a blank scanline
     {
@@ -364,11 +378,15 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
         uint64_t bw = sel4(wi, pb.busy[0], pb.busy[1], pb.busy[2], pb.busy[3]);
         uint64_t aw = sel4(wi, need_a[0], need_a[1], need_a[2], need_a[3]);
         uint64_t rb = sel4(wi, pb.rep[0], pb.rep[1], pb.rep[2], pb.rep[3]), ra = two ? sel4(wi, pa.rep[0], pa.rep[1], pa.rep[2], pa.rep[3]) : 0ull;
+        uint64_t fw = P::FAST_ROWS ? sel4(wi, fast[0], fast[1], fast[2], fast[3]) : 0ull;
         const int sy_end = min(H, 64 * wi + 64);
 #pragma unroll 1
-        for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, bw >>= 1, aw >>= 1, rb >>= 1, ra >>= 1) {
+        for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, bw >>= 1, aw >>= 1, rb >>= 1, ra >>= 1, fw >>= 1) {
             uint32_t h0 = hb0, h1 = hb1;
-            if (nw & 1ull) {
+            if (P::FAST_ROWS && (fw & 1ull) && pb.fast_ready(sy)) {
+                pb.fast_sums(sy, c0, c1, on0, on1, h0, h1);
+                prev_kind = 0;
+            } else if (nw & 1ull) {
                 const bool b_on = bw & 1ull, a_on = aw & 1ull;
                 // a scanline that paints exactly like the one above it (same tile / cell / glyph row, same objects) has
                 // the same horizontal sums: neither painted nor reduced again

@@ -1326,6 +1326,11 @@ template <int C>
 struct AmiPainter {
     typedef AmiDev Dev;
     static constexpr int W = TBX_AMI_W, H = TBX_AMI_H, NG = 1;
+    static constexpr bool FAST_ROWS = false;      // (agent_fused_wave: no scanline class with sums known without painting)
+    static __device__ __forceinline__ uint32_t fast_row_word(const uint32_t*, int) { return 0u; }
+    __device__ __forceinline__ void fast_init(const ColTaps&, const ColTaps&, bool, bool) {}
+    __device__ __forceinline__ bool fast_ready(int) const { return false; }
+    __device__ __forceinline__ void fast_sums(int, const ColTaps&, const ColTaps&, bool, bool, uint32_t&, uint32_t&) const {}
     enum { CLS_BOARD, CLS_MOVER, CLS_HUD, NCLS, SLOT_EDGE = NCLS, NLDS };
     static constexpr int BOARD_Y1 = TBX_AMI_BOARD_OY + BH * TBX_AMI_TILE_PH;
     AmiRegs s;

@@ -809,6 +809,13 @@ struct SiPainter {
     mutable uint64_t ym_cached;             // enemy lookups of the current formation row (paint_row)
     mutable int ec_shift[SI_NG], ec_row0[SI_NG];
     mutable bool ec_multi;
+    // fused agent observation, scanlines that hold nothing but enemies (fast_*): per output column of this lane the visible
+    // enemies whose columns reach its 8-pixel tap window, and the lookups of the current formation row
+    static constexpr bool FAST_ROWS = true;
+    int f_start[2];                         // first source pixel of this lane's two output columns (-1: column not in use)
+    mutable uint64_t fym_cached;
+    mutable uint32_t f_hit[2];              // (enemy x + 64) << 16 | (sprite-table row of scanline 0 + 1024); ~0u: no enemy under the window
+    mutable bool f_multi;
 
     // spr_lds (set by the caller first): the block's copy of the three enemy sprites (si_fill_sprites); cls: [NCLS][8]
     // dwords of LDS private to this wave
@@ -924,6 +931,69 @@ struct SiPainter {
             busy[k] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(lo) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(hi) << 32);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- agent_fused_wave's shortcut: on a scanline that shows only enemies the gray row is c_enemy where a sprite bit is set and
+    // 0 elsewhere, so an output column's horizontal sum is c_enemy x (tap weights . sprite bits under the window) -- no painting,
+    // no staging in LDS.  Exactly the sum hsum() takes of the painted row.
+    // dword w (of 8) of the scanline mask: enemy rows that no other class touches
+    static __device__ __forceinline__ uint32_t fast_row_word(const uint32_t* cls, int w)
+    {
+        uint32_t other = 0u;
+#pragma unroll
+        for (int c = 0; c < NCLS; c++)
+            if (c != CLS_ENEMY) other |= cls[c * 8 + w];
+        return cls[CLS_ENEMY * 8 + w] & ~other;
+    }
+
+    __device__ __forceinline__ void fast_init(const ColTaps& c0, const ColTaps& c1, bool on0, bool on1)
+    {
+        f_start[0] = on0 ? c0.start : -1; f_start[1] = on1 ? c1.start : -1;
+        fym_cached = 0ull; f_multi = false;
+        f_hit[0] = f_hit[1] = ~0u;
+    }
+
+    // looks up the enemies crossing scanline y under this lane's two windows (once per formation row: the set is the same
+    // for its ten scanlines); false if some window holds two of them (states written by hand): the scanline then takes the
+    // painted path
+    __device__ __forceinline__ bool fast_ready(int y) const
+    {
+        const uint64_t ym = __ballot(e_vis && y >= s.ey && y < s.ey + TBX_SI_ENEMY_H);
+        if (ym != fym_cached) {
+            fym_cached = ym;
+            f_hit[0] = f_hit[1] = ~0u;
+            bool multi = false;
+            for (uint64_t m = ym; m; m &= m - 1) {
+                const int e = (int)__builtin_ctzll(m);
+                const int ex = __builtin_amdgcn_readlane(s.ex, e);
+                const uint32_t hit = ((uint32_t)(ex + 64) << 16) | (uint32_t)(__builtin_amdgcn_readlane(e_tab, e) - __builtin_amdgcn_readlane(s.ey, e) + 1024);
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+                    if (f_start[q] >= 0 && f_start[q] + 8 > ex && f_start[q] < ex + TBX_SI_ENEMY_W) {
+                        multi |= f_hit[q] != ~0u;
+                        f_hit[q] = hit;
+                    }
+            }
+            f_multi = __ballot(multi) != 0;
+        }
+        return !f_multi;
+    }
+
+    __device__ __forceinline__ void fast_sums(int y, const ColTaps& c0, const ColTaps& c1, bool, bool, uint32_t& h0, uint32_t& h1) const
+    {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint32_t sum = 0u;
+            if (f_hit[q] != ~0u) {
+                const int ex = (int)(f_hit[q] >> 16) - 64, row0 = (int)(f_hit[q] & 0xFFFFu) - 1024;
+                const uint32_t bits = spr_lds[row0 + y] & ((1u << TBX_SI_ENEMY_W) - 1u);      // bit k = pixel ex + k
+                const int sh = f_start[q] - ex;                        // window pixel i is sprite bit sh + i; -8 < sh < 16
+                const uint32_t wb = (sh >= 0 ? bits >> sh : bits << -sh) & 0xFFu;
+                const uint32_t lo = ((wb & 15u) * 0x00204081u) & 0x01010101u, hi = ((wb >> 4) * 0x00204081u) & 0x01010101u;
+                sum = c_enemy * __builtin_amdgcn_udot4(lo, q ? c1.wlo : c0.wlo, __builtin_amdgcn_udot4(hi, q ? c1.whi : c0.whi, 0u, false), false);
+            }
+            (q ? h1 : h0) = sum;
+        }
     }
 
     // the classes whose entities differ between two states of one env (wave-uniform bit mask)
