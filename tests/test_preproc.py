@@ -804,3 +804,49 @@ def test_gpu_agent_pipeline_with_stress_configs(game, hip_lib, oracle_lib):
             assert np.array_equal(p, q) and np.array_equal(p, r), t
     for i in range(0, n, 9):
         assert bytes(g.get_state(i)) == bytes(o.get_state(i))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("oh,ow", [(84, 84), (50, 97), (100, 46)])
+def test_gpu_space_invaders_observation_of_handwritten_formations(oh, ow, hip_lib, oracle_lib):
+    """The fused SpaceInvaders observation takes scanlines that show only enemies straight from the sprite bits.  States a game
+    never produces -- two enemies of one row a few pixels apart (one tap window sees both), enemies hanging over the left and
+    right edge of the frame, a dying enemy next to a living one, rows at odd heights -- through several output geometries."""
+    n = 64
+    g, o = Engine("space_invaders", n, lib=hip_lib), Engine("space_invaders", n, lib=oracle_lib)
+    for e in (g, o):
+        e.seed(17)
+        e.new_game()
+    rng = np.random.default_rng(5)
+    for t in range(140):                              # past the get-ready phase, lasers in flight
+        a = synthetic_actions("space_invaders", n, t, seed=4)
+        g.step(a); o.step(a)
+    recs = o.get_states_np()
+    for i in range(n):
+        en = recs[i]["enemies"]
+        ne = int(recs[i]["n_enemies"])
+        k = i % 6
+        if k == 0:                                    # neighbours of a row pushed together: overlapping sprites
+            for j in range(1, ne):
+                if en[j]["row"] == en[j - 1]["row"]:
+                    en[j]["x"] = en[j - 1]["x"] + int(rng.integers(1, 9))
+        elif k == 1:                                  # the formation hangs over the left edge
+            en["x"][:ne] -= 52
+        elif k == 2:                                  # ... and over the right edge
+            en["x"][:ne] += 96
+        elif k == 3:                                  # every other enemy dying
+            for j in range(0, ne, 2):
+                en[j]["alive"] = 0
+                en[j]["death_counter"] = 9
+        elif k == 4:                                  # rows at odd heights, some touching the shields and the ship rows
+            en["y"][:ne] += int(rng.integers(1, 60))
+        # k == 5: as played
+    for e in (g, o):
+        e.set_states_np(0, recs)
+        e.agent_init(skip=4, out_h=oh, out_w=ow, stack=4, clip_reward=False)
+    assert np.array_equal(g.agent_reset(), o.agent_reset())
+    for t in range(12):
+        a = synthetic_actions("space_invaders", n, 200 + t, seed=4)
+        x, y = g.agent_step(a), o.agent_step(a)
+        for p, q in zip(x, y):
+            assert np.array_equal(p, q), t
