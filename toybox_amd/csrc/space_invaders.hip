@@ -1161,7 +1161,7 @@ __device__ __forceinline__ void si_fill_sprites(uint32_t* spr_lds)
 }
 
 // One wave rasterises one env, scanline by scanline; SI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte
-// stores, blank units are stored directly.  `split` > 1: that many waves share a frame (small batches).
+// stores, blank units are stored directly.  `split` > 1: that many waves share a frame.
 // (agent layer, generic path: envs flagged in pick_alt are painted from d_alt)
 template <int C, bool ALT>
 __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank, int split, SiDev d_alt,
@@ -1499,11 +1499,13 @@ struct SiOps : GameOps {
         // only), bit 1 = no stores (painting only)
         static const int skip_blank = (getenv("TBX_SI_NO_SKIP") ? 0 : 1) | (getenv("TBX_SI_DIAG") ? atoi(getenv("TBX_SI_DIAG")) << 1 : 0);
         static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
-        // the painter set-up (~1 500 instructions) is too heavy to repeat many times per frame, so one wave per frame -- except
-        // for batches that would leave the chip under-filled (five waves per frame up to 32 768 envs).  A two-stage form
-        // (set-up once per env into a 3.5 KB record, 9-18 light waves per frame rebuilding their registers from it) was
-        // built and measured this round: 10-12 % SLOWER than this kernel on four boxes out of four.
-        const int split = split_env > 0 ? split_env : (channels != 1 && n_envs <= 32768) ? 5 : 1;
+        // the painter set-up (~1 500 instructions behind a state load) is too heavy to repeat many times per frame: five waves
+        // per RGB frame (A/B on two boxes at 65 536 envs, scripts/ab_render.py: 2.41-2.43 ms in every round against 2.41-2.56
+        // for one wave per frame, which drops into the GPU's slower rate state more often; whole step 25.0 -> 25.8 M
+        // env-steps/s), five per RGBA frame only for batches that would leave the chip under-filled, one per gray frame.  A
+        // two-stage form (set-up once per env into a 3.5 KB record, 9-18 light waves per frame) and a set-up shared by a
+        // block's waves through LDS were built and measured this round: both slower.
+        const int split = split_env > 0 ? split_env : channels == 3 ? 5 : (channels == 4 && n_envs <= 32768) ? 5 : 1;
         switch (channels) {
         case 1: if (pick_alt) hipLaunchKernelGGL((si_render_kernel<1, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); else hipLaunchKernelGGL((si_render_kernel<1, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); break;
         case 3: if (pick_alt) hipLaunchKernelGGL((si_render_kernel<3, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); else hipLaunchKernelGGL((si_render_kernel<3, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); break;
