@@ -173,6 +173,11 @@ class quiet_stdout:
 
     def __exit__(self, *a):
         sys.stdout.flush()
+        try:                                   # the banner sits in libc's stdio buffer when stdout is a pipe: push it out
+            import ctypes                      # while fd 1 still points at stderr, not after the JSON line at exit
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False
