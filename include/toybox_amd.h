@@ -16,7 +16,10 @@
  *     device (HBM) pointers (call is asynchronous on the given hipStream_t, passed as void*);
  *   - calls on one handle take effect in program order whatever streams they name: when an entry point uses another stream
  *     than the previous one did (the host-pointer forms run on an engine-owned non-blocking stream), the new stream first
- *     waits for an event recorded on the old one -- no tbx_sync is needed between the two API families;
+ *     waits for an event recorded on the old one -- no tbx_sync is needed between the two API families.  Where two
+ *     consecutive calls cannot affect each other the library may run them side by side (a Breakout tbx_step_synthetic beside
+ *     the tbx_render_device queued before it, on an internal stream; the stream the call names still waits for it), which
+ *     no caller can observe except by the clock;
  *   - a handle is not thread-safe; different handles may be used concurrently;
  *   - there is NO CPU fallback: tbx_create fails with TBX_E_NO_DEVICE when no gfx950
  *     device is visible.
@@ -371,7 +374,8 @@ int tbx_step(tbx_engine* engine, const int32_t* ale_actions_host, uint32_t flags
 /* Device-pointer form: asynchronous on `stream`; results land in the TBX_BUF_* buffers. */
 int tbx_step_device(tbx_engine* engine, const int32_t* ale_actions_dev, uint32_t flags, void* stream);
 /* Same, with the actions generated on the device: env e at time t plays
- * legal[ splitmix64(action_seed ^ (e_global << 32) ^ t) mod n_legal ], e_global = env_offset + e. */
+ * legal[ splitmix64(action_seed ^ (e_global << 32) ^ t) mod n_legal ], e_global = env_offset + e.
+ * (Such a step depends on nothing a rasteriser produces; Breakout's runs beside the previous frame's tbx_render_device.) */
 int tbx_step_synthetic(tbx_engine* engine, uint64_t action_seed, uint64_t t, uint64_t env_offset,
                        uint32_t flags, void* stream);
 /* One frame for ONE env by ALE action id, with the outputs of tbx_step: out[4] = {reward, done, lives, score} (may be NULL).

@@ -1457,7 +1457,9 @@ struct BreakoutOps : GameOps {
     BrkCfg c{};
     tbx_breakout_config_t cfg{};
     bool custom = false;
-    BrkRenderRec* recs = nullptr;   // [N] rasteriser input records
+    BrkRenderRec* recs = nullptr;   // [N] rasteriser input records (the CURRENT of two buffers)
+    BrkRenderRec* recs_other = nullptr;   // the other one: a step that runs ahead of the previous frame's rasteriser writes
+    int recs_par = 0;               // here and the two swap (GameOps::step_ahead)
     bool recs_valid = false;        // records reflect the current state of every env
     BrkCfg* cfg_dev = nullptr;      // device copy of `c` for kernels that index the tables per thread
 
@@ -1521,6 +1523,7 @@ struct BreakoutOps : GameOps {
         TBX_HIP(dalloc(&d.n_bricks, N));
         TBX_HIP(dalloc(&d.alive, 4 * N));
         TBX_HIP(dalloc(&recs, N));
+        TBX_HIP(dalloc(&recs_other, N));
         d.custom = nullptr;
         return TBX_OK;
     }
@@ -1531,6 +1534,7 @@ struct BreakoutOps : GameOps {
         hipFree(d.paddle); hipFree(d.n_balls); hipFree(d.balls); hipFree(d.n_bricks); hipFree(d.alive);
         if (d.custom) hipFree(d.custom);
         hipFree(recs);
+        hipFree(recs_other);
         hipFree(recsA);
         hipFree(recsB);
         hipFree(cfg_dev);
@@ -1573,6 +1577,20 @@ struct BreakoutOps : GameOps {
         else hipLaunchKernelGGL(brk_step_kernel<false>, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         recs_valid = false;
+        return TBX_OK;
+    }
+
+    // the rasteriser reads nothing but the records, and there are two buffers of them: a batch step of the canonical wall
+    // can run while the previous frame is still being painted (engine.hip, tbx_step_ahead)
+    bool step_ahead_ok() const override { return !custom && use_tpe && recs_other != nullptr; }
+    int records_parity() const override { return recs_par; }
+    int step_ahead(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(brk_step_tpe_kernel<false>, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs_other, recsA, recsB);
+        TBX_HIP(hipGetLastError());
+        std::swap(recs, recs_other);
+        recs_par ^= 1;
+        recs_valid = true;
         return TBX_OK;
     }
 

@@ -273,6 +273,7 @@ int tbx_destroy(tbx_engine* e)
     if (e->serve_stream) hipStreamDestroy(e->serve_stream);
     if (e->serve_ctl) hipHostFree(e->serve_ctl);
     if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->step_stream) hipStreamSynchronize(e->step_stream);
     tbx_gather_free(e);
     tbx_agent_free(e);
     if (e->ops) { e->ops->destroy(e); delete e->ops; }
@@ -282,6 +283,10 @@ int tbx_destroy(tbx_engine* e)
     if (e->io_host) hipHostFree(e->io_host);
     if (e->scal_host) hipHostFree(e->scal_host);
     if (e->order_ev) hipEventDestroy(e->order_ev);
+    if (e->step_ev) hipEventDestroy(e->step_ev);
+    for (int p = 0; p < 2; p++)
+        if (e->render_ev[p]) hipEventDestroy(e->render_ev[p]);
+    if (e->step_stream) hipStreamDestroy(e->step_stream);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return TBX_OK;
@@ -466,18 +471,62 @@ int tbx_step_device(tbx_engine* e, const int32_t* actions_dev, uint32_t flags, v
     return e->ops->step(e, src, flags, (hipStream_t)stream);
 }
 
+// A step with in-kernel actions depends on nothing the previous frame's rasteriser produces, and for games whose rasteriser
+// reads double-buffered records (GameOps::step_ahead_ok) it disturbs nothing that rasteriser reads: it runs on the engine's
+// step stream BESIDE the render queued before it.  Measured on MI355X (scripts/interleave_probe.py): a 10 us step kernel
+// serialised between two 1.19 ms Breakout render launches costs 0.04-0.22 ms depending on the box, run beside the render it
+// costs 0.01-0.04 ms.  Program order is kept: the step waits for the previous step (same stream), for the render that read
+// the records buffer it rewrites, and -- the first time after any other call -- for everything; the caller's stream waits
+// for the step, so whatever the caller queues next (the render of this frame, a buffer read) sees it.
+static int tbx_step_ahead(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t user)
+{
+    if (e->serve_running) EHIP(tbx_serve_stop(e));
+    if (!e->step_stream) {
+        EHIP(hipStreamCreateWithFlags(&e->step_stream, hipStreamNonBlocking));
+        EHIP(hipEventCreateWithFlags(&e->step_ev, hipEventDisableTiming));
+        EHIP(hipEventCreateWithFlags(&e->render_ev[0], hipEventDisableTiming));
+        EHIP(hipEventCreateWithFlags(&e->render_ev[1], hipEventDisableTiming));
+    }
+    hipStream_t ss = e->step_stream;
+    const bool beside = !e->step_needs_join && e->has_last && (e->last_op_readonly || e->last_stream == ss);
+    if (!beside) {                                   // ordered behind everything, like any other call
+        if (e->has_last && e->last_stream != ss) {
+            if (!e->order_ev) EHIP(hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming));
+            EHIP(hipEventRecord(e->order_ev, e->last_stream));
+            EHIP(hipStreamWaitEvent(ss, e->order_ev, 0));
+        }
+        for (int p = 0; p < 2; p++)
+            if (e->render_pending[p]) { EHIP(hipStreamWaitEvent(ss, e->render_ev[p], 0)); e->render_pending[p] = false; }
+    } else {                                         // beside the last render: only the reader of the buffer about to be rewritten
+        const int wp = e->ops->records_parity() ^ 1;
+        if (e->render_pending[wp]) { EHIP(hipStreamWaitEvent(ss, e->render_ev[wp], 0)); e->render_pending[wp] = false; }
+    }
+    EHIP(tbx_gather_before_step(e, ss));
+    int rc = e->ops->step_ahead(e, src, flags, ss);
+    if (rc) return rc;
+    EHIP(hipEventRecord(e->step_ev, ss));
+    EHIP(hipStreamWaitEvent(user, e->step_ev, 0));
+    e->last_stream = ss;
+    e->has_last = true;
+    e->last_op_readonly = false;
+    e->step_needs_join = false;
+    return TBX_OK;
+}
+
 int tbx_step_synthetic(tbx_engine* e, uint64_t action_seed, uint64_t t, uint64_t env_offset, uint32_t flags, void* stream)
 {
     CHECK_ENGINE(e);
     EHIP(hipSetDevice(e->device));
-    EHIP(tbx_use_stream(e, (hipStream_t)stream));
-    EHIP(tbx_gather_before_step(e, (hipStream_t)stream));
     ActionSource src{};
     src.actions = nullptr;
     src.seed = action_seed;
     src.t = t;
     src.env_offset = env_offset;
     src.single_env = -1;
+    static const bool no_ahead = getenv("TBX_NO_STEP_AHEAD") != nullptr;
+    if (!no_ahead && e->ops->step_ahead_ok()) return tbx_step_ahead(e, src, flags, (hipStream_t)stream);
+    EHIP(tbx_use_stream(e, (hipStream_t)stream));
+    EHIP(tbx_gather_before_step(e, (hipStream_t)stream));
     return e->ops->step(e, src, flags, (hipStream_t)stream);
 }
 
@@ -674,7 +723,8 @@ int tbx_render_device(tbx_engine* e, uint8_t* out_dev, int channels, void* strea
     CHECK_ENGINE(e);
     if (channels != 1 && channels != 3 && channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
     EHIP(hipSetDevice(e->device));
-    EHIP(tbx_use_stream(e, (hipStream_t)stream));
+    const bool ahead = e->ops->step_ahead_ok() && e->step_stream;      // (the step stream exists once a step has run ahead)
+    EHIP(tbx_use_stream(e, (hipStream_t)stream, /*readonly=*/ahead));
     if (!out_dev) {
         const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
         int rc = ensure_frame(e, bytes);
@@ -682,7 +732,14 @@ int tbx_render_device(tbx_engine* e, uint8_t* out_dev, int channels, void* strea
         out_dev = e->frame;
     }
     if (((uintptr_t)out_dev & 15u) != 0) return e->fail(TBX_E_INVALID, "frame buffer must be 16-byte aligned");
-    return e->ops->render(e, out_dev, channels, 0, e->n, (hipStream_t)stream);
+    const int parity = e->ops->records_parity();
+    int rc = e->ops->render(e, out_dev, channels, 0, e->n, (hipStream_t)stream);
+    if (rc) return rc;
+    if (ahead) {                                     // the next step ahead must not rewrite these records before they are read
+        EHIP(hipEventRecord(e->render_ev[parity], (hipStream_t)stream));
+        e->render_pending[parity] = true;
+    }
+    return TBX_OK;
 }
 
 int tbx_render(tbx_engine* e, uint8_t* out_host, int channels)

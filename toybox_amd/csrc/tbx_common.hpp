@@ -277,6 +277,14 @@ struct tbx_engine {
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     hipEvent_t order_ev = nullptr;
+    // step-ahead (engine.hip, tbx_step_synthetic on games whose rasteriser reads double-buffered records -- GameOps::
+    // step_ahead_ok): the step kernel runs on an internal stream BESIDE the previous frame's rasteriser instead of behind it.
+    hipStream_t step_stream = nullptr;
+    hipEvent_t step_ev = nullptr;
+    hipEvent_t render_ev[2] = {nullptr, nullptr};   // behind the last tbx_render_device that read records buffer 0 / 1
+    bool render_pending[2] = {false, false};
+    bool last_op_readonly = false;                   // the last call through tbx_use_stream only read (a batch render)
+    bool step_needs_join = true;                     // something other than steps and batch renders came since the last step
     // common device buffers (SoA over envs)
     uint64_t* sim_rng = nullptr;    // [2][N] simulator RNG
     int32_t* prev_score = nullptr;  // [N]
@@ -322,7 +330,10 @@ struct tbx_engine {
 // event recorded on the old one, so calls on one handle take effect in program order whatever streams they name.
 hipError_t tbx_serve_stop(tbx_engine* e);   // engine.hip
 
-inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s)
+// Every entry point declares the stream it is about to use: the call is ordered behind whatever came last through this
+// handle, on whatever stream.  readonly: a batch render (it changes nothing a step reads or writes except through the
+// records buffer it was launched on -- what lets the next tbx_step_synthetic run beside it, see tbx_step_ahead in engine.hip).
+inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s, bool readonly = false)
 {
     if (e->serve_running) {                    // nothing else runs beside the resident step kernel
         hipError_t r = tbx_serve_stop(e);
@@ -338,8 +349,17 @@ inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s)
         r = hipStreamWaitEvent(s, e->order_ev, 0);
         if (r != hipSuccess) return r;
     }
+    // a step that ran ahead is `last`; the render it ran beside may still be going on another stream
+    for (int p = 0; p < 2; p++)
+        if (e->render_pending[p]) {
+            hipError_t r = hipStreamWaitEvent(s, e->render_ev[p], 0);
+            if (r != hipSuccess) return r;
+            if (!readonly) e->render_pending[p] = false;
+        }
     e->last_stream = s;
     e->has_last = true;
+    e->last_op_readonly = readonly;
+    if (!readonly) e->step_needs_join = true;
     return hipSuccess;
 }
 
@@ -371,6 +391,12 @@ struct GameOps {
     // fused observation kernels (no full-resolution frame leaves the chip)
     virtual bool agent_fused() const { return false; }
     virtual int agent_warp(tbx_engine*, const struct AgentWarpArgs&, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    // step-ahead: the rasteriser reads records the step kernel writes, and there are two buffers of them -- a batch step may
+    // then run while the previous frame is still being rasterised.  records_parity(): the buffer a render launched now reads;
+    // step_ahead(): one frame of every env on stream s, records into the OTHER buffer, which becomes the current one.
+    virtual bool step_ahead_ok() const { return false; }
+    virtual int records_parity() const { return 0; }
+    virtual int step_ahead(tbx_engine*, const ActionSource&, uint32_t, hipStream_t) { return TBX_E_UNSUPPORTED; }
     // generic path: full-resolution gray frames of slot A (source 1), slot B (2) or the live state (0); envs whose
     // pick_live byte is non-zero are painted from the live state instead
     virtual int render_from(tbx_engine*, int /*source*/, const uint8_t* /*pick_live*/, uint8_t* /*out_dev*/, int /*channels*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
