@@ -492,16 +492,16 @@ def test_step1_on_a_batch_engine(lib, oracle_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("game,n", [("breakout", 40000), ("breakout", 3000), ("amidar", 20000)])
 @pytest.mark.parametrize("same_stream", [True, False])
-def test_step_ahead_keeps_program_order(same_stream, hip_lib, oracle_lib):
-    """tbx_step_synthetic on Breakout runs on the engine's step stream BESIDE the rasteriser launch queued before it (two
-    record buffers).  What the caller sees must stay program order: every frame is the frame of the step before it, device
+def test_step_ahead_keeps_program_order(same_stream, game, n, hip_lib, oracle_lib):
+    """tbx_step_synthetic on Breakout runs on the engine's step stream BESIDE the rasteriser launch queued before it (two record
+    buffers; Amidar, whose step stays serialised, walks the same call pattern as the control).  What the caller sees must stay program order: every frame is the frame of the step before it, device
     buffers read behind the caller's stream are the step's, and calls of every other kind in between (state reads and writes,
     new games, host-pointer steps and renders, a device-action step, a second render of one frame, two steps in a row) join
     both streams.  Bench pattern, 40 000 envs so that a render launch is long enough to be overtaken."""
     from toybox_amd import hip
-    n = 40000
-    g, o = _pair("breakout", n, hip_lib, oracle_lib, seed=31)
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=31)
     s_step, s_render = hip.Stream(), hip.Stream()
     sp, rp = (s_render.ptr, s_render.ptr) if same_stream else (s_step.ptr, s_render.ptr)
     H, W = g.height, g.width
@@ -522,12 +522,12 @@ def test_step_ahead_keeps_program_order(same_stream, hip_lib, oracle_lib):
         for k in range(int(rng.integers(3, 30))):           # the bench loop: step, render, step, render ...
             g.step_synthetic(1337, t, auto_reset=True, stream=sp)
             g.render_device(0, 3, stream=rp)
-            o.step(synthetic_actions("breakout", n, t, seed=1337), auto_reset=True)
+            o.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
             t += 1
         check_frame("round %d" % rnd)
         # the step's outputs, read behind the stream the step call named
         g.step_synthetic(1337, t, auto_reset=True, stream=sp)
-        ro = o.step(synthetic_actions("breakout", n, t, seed=1337), auto_reset=True)
+        ro = o.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
         t += 1
         (s_render if same_stream else s_step).synchronize()
         p, nbytes = g.device_buffer(_abi.BUF_PACKED)
@@ -538,7 +538,7 @@ def test_step_ahead_keeps_program_order(same_stream, hip_lib, oracle_lib):
         if kind == 0:                                       # state read right behind a step that ran ahead of a render
             g.render_device(0, 3, stream=rp)
             g.step_synthetic(1337, t, auto_reset=True, stream=sp)
-            o.step(synthetic_actions("breakout", n, t, seed=1337), auto_reset=True)
+            o.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
             t += 1
             _same_states(g, o, sample, "read %d" % rnd)
         elif kind == 1:                                     # state write, then straight back into the loop
@@ -549,7 +549,7 @@ def test_step_ahead_keeps_program_order(same_stream, hip_lib, oracle_lib):
             m = (np.arange(n) % 7 == 0).astype(np.uint8)
             g.new_game(m); o.new_game(m)
         elif kind == 3:                                     # host-pointer step and render
-            a = synthetic_actions("breakout", n, t, seed=5)
+            a = synthetic_actions(game, n, t, seed=5)
             rg, ro = g.step(a, auto_reset=True), o.step(a, auto_reset=True)
             for x, y in zip(rg, ro):
                 assert np.array_equal(x, y)
@@ -560,7 +560,7 @@ def test_step_ahead_keeps_program_order(same_stream, hip_lib, oracle_lib):
             g.render_device(0, 3, stream=sp)
             for _ in range(2):
                 g.step_synthetic(1337, t, auto_reset=True, stream=sp)
-                o.step(synthetic_actions("breakout", n, t, seed=1337), auto_reset=True)
+                o.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
                 t += 1
         else:                                               # a render, then a step that must NOT overtake a state read
             g.render_device(0, 1, stream=rp)
