@@ -501,6 +501,8 @@ def test_step_ahead_keeps_program_order(same_stream, game, n, hip_lib, oracle_li
     new games, host-pointer steps and renders, a device-action step, a second render of one frame, two steps in a row) join
     both streams.  Bench pattern, 40 000 envs so that a render launch is long enough to be overtaken."""
     from toybox_amd import hip
+    if n < 12288:
+        os.environ["TBX_STEP_AHEAD_MIN"] = "1"        # read once per process: only effective if no larger engine came first
     g, o = _pair(game, n, hip_lib, oracle_lib, seed=31)
     s_step, s_render = hip.Stream(), hip.Stream()
     sp, rp = (s_render.ptr, s_render.ptr) if same_stream else (s_step.ptr, s_render.ptr)
