@@ -494,7 +494,7 @@ def test_step1_on_a_batch_engine(lib, oracle_lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("game,n", [("breakout", 40000), ("breakout", 3000), ("amidar", 20000)])
 @pytest.mark.parametrize("same_stream", [True, False])
-def test_step_ahead_keeps_program_order(same_stream, game, n, hip_lib, oracle_lib):
+def test_step_ahead_keeps_program_order(same_stream, game, n, hip_lib, oracle_lib, monkeypatch):
     """tbx_step_synthetic on Breakout runs on the engine's step stream BESIDE the rasteriser launch queued before it (two record
     buffers; Amidar, whose step stays serialised, walks the same call pattern as the control).  What the caller sees must stay program order: every frame is the frame of the step before it, device
     buffers read behind the caller's stream are the step's, and calls of every other kind in between (state reads and writes,
@@ -502,7 +502,7 @@ def test_step_ahead_keeps_program_order(same_stream, game, n, hip_lib, oracle_li
     both streams.  Bench pattern, 40 000 envs so that a render launch is long enough to be overtaken."""
     from toybox_amd import hip
     if n < 12288:
-        os.environ["TBX_STEP_AHEAD_MIN"] = "1"        # read once per process: only effective if no larger engine came first
+        monkeypatch.setenv("TBX_STEP_AHEAD_MIN", "1")  # small batches run the step serialised by default
     g, o = _pair(game, n, hip_lib, oracle_lib, seed=31)
     s_step, s_render = hip.Stream(), hip.Stream()
     sp, rp = (s_render.ptr, s_render.ptr) if same_stream else (s_step.ptr, s_render.ptr)

@@ -1586,7 +1586,8 @@ struct BreakoutOps : GameOps {
     // same, at 4 096 envs 37.3 against 39.7 -- a ~100 us step leaves no room for the extra event calls)
     bool step_ahead_ok() const override
     {
-        static const int min_n = getenv("TBX_STEP_AHEAD_MIN") ? atoi(getenv("TBX_STEP_AHEAD_MIN")) : 12288;
+        const char* v = getenv("TBX_STEP_AHEAD_MIN");       // (read per call: the tests move it)
+        const int min_n = v ? atoi(v) : 12288;
         return !custom && use_tpe && recs_other != nullptr && d.n >= min_n;
     }
     int records_parity() const override { return recs_par; }
