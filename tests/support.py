@@ -26,3 +26,24 @@ def synthetic_actions(game, n, t, seed=1337, env_offset=0):
     env = np.arange(env_offset, env_offset + n, dtype=np.uint64)
     h = splitmix64(np.uint64(seed) ^ (env << np.uint64(32)) ^ np.uint64(t))
     return legal[(h % np.uint64(len(legal))).astype(np.int64)]
+
+
+def noop_count(noop_seed, global_env, episode_index, noop_max):
+    """the engine's default no-op rule (include/toybox_amd.h, tbx_agent_init): 1 + splitmix64(seed ^ env << 32 ^ k) % noop_max"""
+    return 1 + int(splitmix64(int(noop_seed) ^ (int(global_env) << 32) ^ int(episode_index)) % np.uint64(noop_max))
+
+
+# ---------------------------------------------------------------- Amidar state edits of the wrapper corner cases
+# Shared by tests/golden/make_wrapper_golden.py (applied through the reference env's write_state_json) and by
+# tests/test_preproc.py (applied to the fused engine): inputs of the fixtures, not expected outputs.
+
+def amidar_edit_last_lives(js, lives, jump_timer, perimeter_from_start):
+    """every enemy parked on the player, a jump that runs out `jump_timer` frames from now: the life goes when the jump ends;
+    with perimeter_from_start the enemies respawn ON the player's start tile and the next frame costs another life"""
+    js["lives"], js["jump_timer"] = lives, jump_timer
+    for en in js["enemies"]:
+        en["position"] = dict(js["player"]["position"])
+        en["step"] = None
+        if perimeter_from_start:
+            en["ai"] = {"EnemyPerimeterAI": {"start": {"tx": 31, "ty": 15}}}
+    return js

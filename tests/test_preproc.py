@@ -1,6 +1,7 @@
-"""Agent-side preprocessing: the fused device path against (a) a frame-by-frame numpy restatement of
-the reference's wrapper stack (atari_wrappers.py:193-244, vec_frame_stack.py:17-30) driven through the plain per-frame
-API, and (b) on the GPU box, the HIP library against the CPU restatement, bit for bit."""
+"""Agent-side preprocessing: the fused path against (a) committed fixtures recorded from the reference's
+own wrapper classes (tests/golden/wrappers/, generator tests/golden/make_wrapper_golden.py) -- replayed through the CPU
+restatement here and through the HIP library on the GPU box -- and (b) on the GPU box, the HIP library against the CPU
+restatement on larger batches, bit for bit."""
 import ctypes as C
 from fractions import Fraction
 
@@ -72,338 +73,125 @@ def test_warp_area_matches_definition(oracle_lib):
     assert (got == 137).all()
 
 
-# ------------------------------------------------------------------ the reference's wrapper classes, restated literally
-# One class per class of the reference, same method bodies, over a one-env Engine driven through the plain per-frame API
-# (no gym here, so gym.Wrapper's attribute forwarding is the small `_Wrapper` base):
-#   ToyboxBaseEnv            toybox/envs/atari/base.py:115-156
-#   NoopResetEnv             baselines/baselines/common/atari_wrappers.py:108-135
-#   MaxAndSkipEnv            :193-219           (make_wrapper :324-335 builds Noop -> MaxAndSkip)
-#   bench.Monitor            baselines/bench/monitor.py:36-76   (cmd_util.py:32 puts it between make_atari and wrap_deepmind)
-#   EpisodicLifeEnv          :157-191
-#   FireResetEnv             :137-155
-#   WarpFrame, ClipRewardEnv :230-244, :221-227  (wrap_deepmind :346-360)
-#   DummyVecEnv              common/vec_env/dummy_vec_env.py:45-60
-#   VecFrameStack            common/vec_env/vec_frame_stack.py:17-33
-# The only line that is not the reference's: NoopResetEnv draws its count from `count_fn` (the engine's counter-based rule)
-# where the reference calls self.unwrapped.np_random.randint(1, noop_max + 1).
-from support import splitmix64  # noqa: E402
+# ------------------------------------------------------------------ the reference's wrapper stack, as committed fixtures
+# tests/golden/wrappers/*.npz hold what the reference's OWN classes return (NoopResetEnv, MaxAndSkipEnv, bench.Monitor,
+# EpisodicLifeEnv, FireResetEnv, WarpFrame, ClipRewardEnv, DummyVecEnv, VecFrameStack over ToyboxBaseEnv), recorded in the
+# build container by tests/golden/make_wrapper_golden.py from /root/reference's unmodified files.  Nothing of the reference
+# is restated here: the tests replay a fixture's inputs through the fused engine and compare with its outputs.
+import json  # noqa: E402
+import os  # noqa: E402
+
+from conftest import GOLDEN  # noqa: E402
+from support import LEGAL, amidar_edit_last_lives  # noqa: E402
+from toybox_amd.toybox import codec  # noqa: E402
 
 
-class _Raw:
-    """ToyboxBaseEnv over one env of an engine (grayscale=True: obs is the (H, W, 1) gray frame)."""
+class Case:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, "wrappers", name + ".npz"), allow_pickle=False)
+        self.name = name
+        self.a = {k: z[k] for k in z.files}
+        self.meta = json.loads(str(self.a["meta"]))
+        self.game, self.n = self.meta["game"], self.meta["n"]
+        self.legal = np.asarray(sorted(LEGAL[self.game]), np.int32)
 
-    def __init__(self, eng):
-        self.e = eng
-        self.score = 0
-        self.unwrapped = self
+    def __getitem__(self, k):
+        return self.a[k]
 
-    def lives(self):                                    # env.unwrapped.ale.lives()
-        return int(self.e.scalars()[1][0])
+    def engine(self, lib):
+        """the fused engine set up from the fixture's inputs: env i seeded seed + i, the wrapper options of the case"""
+        m = self.meta
+        e = Engine(self.game, self.n, lib=lib)
+        e.seed(m["seed"])
+        e.agent_init(skip=m["skip"], out_h=m["oh"], out_w=m["ow"], stack=m["stack"], clip_reward=m["clip"],
+                     episodic_life=m.get("episodic", False), fire_reset=m.get("fire", False), noop_max=m.get("noop_max", 0),
+                     noop_seed=m.get("noop_seed", 0), env_offset=m.get("env_offset", 0))
+        return e
 
-    def _get_obs(self):
-        return self.e.render(1)[0]
+    def ale(self, idx):
+        """the fixtures hold action INDICES (what a learner emits, envs/atari/base.py:123-126); the engine takes ALE ids"""
+        return self.legal[np.asarray(idx)]
 
-    def reset(self):
-        self.e.new_game()
-        self.score = int(self.e.scalars()[0][0])
-        return self._get_obs()
+    def replay(self, e, first=0, last=None, prefix="", episodes=True):
+        """steps [first, last) of the fixture through the fused engine; every output compared"""
+        idx = self.a[prefix + "action_idx"]
+        last = len(idx) if last is None else last
+        eps = [[] for _ in range(self.n)]
+        for t in range(first, last):
+            obs, rew, done = e.agent_step(self.ale(idx[t]), tolerate_needs_reset=bool(prefix))
+            assert np.array_equal(rew, self.a[prefix + "rew"][t]) and np.array_equal(done, self.a[prefix + "done"][t]), (self.name, t)
+            assert np.array_equal(obs, self.a[prefix + "obs"][t]), (self.name, t)
+            if episodes and not prefix:
+                ended, ret, length = e.agent_episodes()
+                assert np.array_equal(ended, self.a["ep_flag"][t]), (self.name, t)       # info["episode"] of bench.Monitor
+                assert np.array_equal(ret[ended], self.a["ep_r"][t][ended]) and np.array_equal(length[ended], self.a["ep_l"][t][ended])
+                for i in np.flatnonzero(ended):
+                    eps[i].append((float(ret[i]), int(length[i])))
+        return eps
 
-    def step(self, ale_action):
-        self.e.step(np.array([ale_action], np.int32))
-        obs = self._get_obs()
-        score = int(self.e.scalars()[0][0])
-        reward = max(score - self.score, 0)
-        self.score = score
-        done = self.lives() <= 0
-        return obs, reward, done, {"lives": self.lives(), "score": 0 if done else score}
+    def check_states(self, e, key="state_json", rng_key="sim_rng"):
+        cd = codec(self.game)
+        for i in range(self.n):
+            assert cd.state_to_json(e.get_state(i)) == json.loads(str(self.a[key][i])), (self.name, i)
+            if rng_key is not None:
+                assert list(e.get_sim_rng(i)) == [int(v) for v in self.a[rng_key][i]], (self.name, i)
 
-
-class _Wrapper:
-    def __init__(self, env):
-        self.env = env
-        self.unwrapped = env.unwrapped
-
-    def step(self, a):
-        return self.env.step(a)
-
-    def reset(self):
-        return self.env.reset()
-
-
-class _NoopResetEnv(_Wrapper):
-    def __init__(self, env, noop_max, count_fn):
-        super().__init__(env)
-        self.noop_max, self.count_fn = noop_max, count_fn
-        self.override_num_noops = None
-        self.noop_action = 0
-
-    def reset(self):
-        self.env.reset()
-        if self.override_num_noops is not None:
-            noops = self.override_num_noops
-        else:
-            noops = self.count_fn()
-        assert noops > 0
-        obs = None
-        for _ in range(noops):
-            obs, _, done, _ = self.env.step(self.noop_action)
-            if done:
-                obs = self.env.reset()
-        return obs
+    def check_monitor(self, eps):
+        """Monitor.episode_rewards / episode_lengths at the end of the run == the episodes the engine reported step by step"""
+        pos = 0
+        for i in range(self.n):
+            c = int(self.a["mon_count"][i])
+            want = list(zip([float(v) for v in self.a["mon_r"][pos:pos + c]], [int(v) for v in self.a["mon_l"][pos:pos + c]]))
+            assert eps[i] == want, (self.name, i)
+            pos += c
 
 
-class _MaxAndSkipEnv(_Wrapper):
-    def __init__(self, env, skip, shape):
-        super().__init__(env)
-        self._obs_buffer = np.zeros((2,) + shape, dtype=np.uint8)
-        self._skip = skip
-
-    def step(self, action):
-        total_reward = 0.0
-        done = None
-        for i in range(self._skip):
-            obs, reward, done, info = self.env.step(action)
-            if i == self._skip - 2:
-                self._obs_buffer[0] = obs
-            if i == self._skip - 1:
-                self._obs_buffer[1] = obs
-            total_reward += reward
-            if done:
-                break
-        max_frame = self._obs_buffer.max(axis=0)
-        return max_frame, total_reward, done, info
-
-
-class _Monitor(_Wrapper):
-    def __init__(self, env, strict=True):
-        super().__init__(env)
-        self.rewards, self.needs_reset, self.episodes, self.strict, self.stale_steps = None, False, [], strict, 0
-
-    def reset(self):                                    # allow_early_resets=True
-        self.rewards = []
-        self.needs_reset = False
-        return self.env.reset()
-
-    def step(self, action):
-        if self.needs_reset:
-            if self.strict:
-                raise RuntimeError("Tried to step environment that needs reset")
-            self.stale_steps += 1                       # what the engine reports as TBX_E_NEEDS_RESET and carries on
-            return self.env.step(action)
-        ob, rew, done, info = self.env.step(action)
-        self.rewards.append(rew)
-        if done:
-            self.needs_reset = True
-            epinfo = {"r": round(sum(self.rewards), 6), "l": len(self.rewards)}
-            self.episodes.append((float(epinfo["r"]), epinfo["l"]))
-            info = dict(info, episode=epinfo)
-        return ob, rew, done, info
-
-
-class _EpisodicLifeEnv(_Wrapper):
-    def __init__(self, env):
-        super().__init__(env)
-        self.lives = 0
-        self.was_real_done = True
-
-    def step(self, action):
-        obs, reward, done, info = self.env.step(action)
-        self.was_real_done = done
-        lives = self.unwrapped.lives()
-        if lives < self.lives and lives > 0:
-            done = True
-        self.lives = lives
-        return obs, reward, done, info
-
-    def reset(self):
-        if self.was_real_done:
-            obs = self.env.reset()
-        else:
-            obs, _, _, _ = self.env.step(0)
-        self.lives = self.unwrapped.lives()
-        return obs
-
-
-class _FireResetEnv(_Wrapper):
-    def reset(self):
-        self.env.reset()
-        obs, _, done, _ = self.env.step(1)
-        if done:
-            self.env.reset()
-        obs, _, done, _ = self.env.step(2)
-        if done:
-            self.env.reset()
-        return obs
-
-
-class _WarpFrame(_Wrapper):
-    def __init__(self, env, height, width):
-        super().__init__(env)
-        self.height, self.width = height, width
-
-    def observation(self, frame):
-        return area_resize_int(frame[:, :, 0], self.height, self.width)[:, :, None]     # cv2.resize(..., INTER_AREA)
-
-    def reset(self):
-        return self.observation(self.env.reset())
-
-    def step(self, a):
-        obs, r, d, info = self.env.step(a)
-        return self.observation(obs), r, d, info
-
-
-class _ClipRewardEnv(_Wrapper):
-    def step(self, a):
-        obs, r, d, info = self.env.step(a)
-        return obs, float(np.sign(r)), d, info
-
-
-class _ActionIndex(_Wrapper):
-    """ToyboxBaseEnv.step takes an INDEX into the sorted action set (base.py:123-126); the engines take ALE ids."""
-
-    def __init__(self, env, action_set):
-        super().__init__(env)
-        self.action_set = action_set
-
-    def step(self, index):
-        return self.env.step(self.action_set[index])
-
-
-class _DummyVecEnv:
-    def __init__(self, envs):
-        self.envs = envs
-        self.num_envs = len(envs)
-
-    def step(self, actions):
-        obs, rews, dones, infos = [], [], [], []
-        for e in range(self.num_envs):
-            ob, r, d, info = self.envs[e].step(int(actions[e]))
-            if d:
-                ob = self.envs[e].reset()
-            obs.append(ob); rews.append(r); dones.append(d); infos.append(info)
-        return np.stack(obs), np.asarray(rews, np.float32), np.asarray(dones, bool), infos
-
-    def reset(self):
-        return np.stack([e.reset() for e in self.envs])
-
-
-class _VecFrameStack:
-    def __init__(self, venv, nstack, shape):
-        self.venv, self.nstack = venv, nstack
-        self.stackedobs = np.zeros((venv.num_envs,) + shape[:-1] + (shape[-1] * nstack,), np.uint8)
-
-    def step(self, actions):
-        obs, rews, news, infos = self.venv.step(actions)
-        self.stackedobs = np.roll(self.stackedobs, shift=-1, axis=-1)
-        for (i, new) in enumerate(news):
-            if new:
-                self.stackedobs[i] = 0
-        self.stackedobs[..., -obs.shape[-1]:] = obs
-        return self.stackedobs, rews, news, infos
-
-    def reset(self):
-        obs = self.venv.reset()
-        self.stackedobs[...] = 0
-        self.stackedobs[..., -obs.shape[-1]:] = obs
-        return self.stackedobs
-
-
-class RefStack:
-    """make_atari + Monitor + wrap_deepmind + DummyVecEnv + VecFrameStack over N one-env engines."""
-
-    def __init__(self, engines, skip, oh, ow, stack, clip, episodic=False, fire=False, noop_max=0, noop_seed=0, env_offset=0,
-                 strict_monitor=True):
-        self.monitors, self.noops, self.raws = [], [], []
-        tops = []
-        for i, eng in enumerate(engines):
-            raw = _Raw(eng)
-            env = _ActionIndex(raw, sorted(eng.legal_actions))     # everything above speaks action INDICES, like the reference
-
-            def count_fn(i=i, holder=[0]):
-                holder[0] += 1
-                return 1 + int(splitmix64(noop_seed ^ ((env_offset + i) << 32) ^ holder[0]) % noop_max)
-
-            noop = None
-            if noop_max > 0:
-                env = noop = _NoopResetEnv(env, noop_max, count_fn)
-            env = _MaxAndSkipEnv(env, skip, (eng.height, eng.width, 1))
-            env = mon = _Monitor(env, strict=strict_monitor)
-            if episodic:
-                env = _EpisodicLifeEnv(env)
-            if fire:
-                env = _FireResetEnv(env)
-            env = _WarpFrame(env, oh, ow)
-            if clip:
-                env = _ClipRewardEnv(env)
-            tops.append(env)
-            self.monitors.append(mon); self.noops.append(noop); self.raws.append(raw)
-        self.venv = _VecFrameStack(_DummyVecEnv(tops), stack, (oh, ow, 1))
-
-    def reset(self):
-        return self.venv.reset().copy()
-
-    def step(self, action_indices):
-        obs, r, d, infos = self.venv.step(action_indices)
-        return obs.copy(), r, d, infos
+def test_wrapper_fixtures_are_what_the_generator_makes():
+    """build container only: regenerating the fixtures from /root/reference reproduces the committed files"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    if not os.path.isdir("/root/reference/baselines/baselines/common"):
+        pytest.skip("the reference tree is only present in the build container")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_wrapper_golden.py"), "--check"], cwd="/tmp",
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
 
 
 @pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
 def lib(request, oracle_lib):
-    """the library under the fused engine: the CPU restatement here, the HIP library on the GPU box; the reference's wrapper
-    classes always run over one-env engines of the CPU restatement"""
+    """the library under the fused engine: the CPU restatement here, the HIP library on the GPU box"""
     if request.param == "oracle":
         return oracle_lib
     from toybox_amd import _lib
     return _lib.load()
 
 
-def _pair_with_singles(game, n, lib, seed):
-    """a fused engine (on `lib`) and n one-env CPU engines holding the same states and simulator RNGs"""
-    import ctypes, os
-    from conftest import ROOT
-    fused = Engine(game, n, lib=lib)
-    fused.seed(seed)
-    fused.new_game()
-    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
-    _abi.bind(orc)
-    singles = [Engine(game, 1, lib=orc) for _ in range(n)]
-    for i, s_ in enumerate(singles):
-        s_.set_state(0, fused.get_state(i))
-        s_.set_sim_rng(fused.get_sim_rng(i), 0)
-    return fused, singles
-
-
-def _indices(game, n, t, seed):
-    """uniform action INDICES (what a learner emits) and the ALE ids they stand for"""
-    legal = np.asarray(sorted(LEGAL_SETS[game]), np.int32)
-    ale = synthetic_actions(game, n, t, seed=seed)
-    return np.searchsorted(legal, ale), ale
-
-
-LEGAL_SETS = {"breakout": [0, 1, 3, 4], "amidar": [0, 1, 2, 3, 4, 5], "space_invaders": [0, 1, 3, 4, 11, 12]}
-
-
-@pytest.mark.parametrize("game,oh,ow,skip,stack,clip", [("breakout", 42, 42, 4, 4, True), ("amidar", 50, 40, 3, 2, False),
-                                                       ("space_invaders", 42, 64, 1, 4, True)])
-def test_fused_equals_wrapper_composition(game, oh, ow, skip, stack, clip, lib):
-    """MaxAndSkip + Warp + Clip + DummyVecEnv + VecFrameStack (no reset-time wrappers)."""
-    n, steps = 3, 260
-    fused, singles = _pair_with_singles(game, n, lib, 31)
-    fused.agent_init(skip=skip, out_h=oh, out_w=ow, stack=stack, clip_reward=clip)
-    ref = RefStack(singles, skip, oh, ow, stack, clip)
-    assert np.array_equal(fused.agent_reset(), ref.reset())
-    dones = 0
-    for t in range(steps):
-        idx, ale = _indices(game, n, t, 4)
-        o1, r1, d1 = fused.agent_step(ale)
-        o2, r2, d2, _ = ref.step(idx)
-        assert np.array_equal(d1, d2) and np.array_equal(r1, r2), t
-        assert np.array_equal(o1, o2), t
-        dones += int(d1.sum())
-    for i in range(n):
-        assert bytes(fused.get_state(i)) == bytes(singles[i].get_state(0))
+@pytest.mark.parametrize("game", GAMES)
+def test_fused_equals_wrapper_composition(game, lib):
+    """MaxAndSkip + Monitor + Warp + Clip + DummyVecEnv + VecFrameStack (no reset-time wrappers); geometries 42x42 skip 4
+    stack 4, 50x40 skip 3 stack 2, 42x64 skip 1 stack 4."""
+    c = Case("composition_" + game)
+    e = c.engine(lib)
+    assert np.array_equal(e.agent_reset(), c["reset_obs"])
+    eps = c.replay(e)
+    c.check_states(e)
+    c.check_monitor(eps)
     if game == "breakout":
-        assert dones > 0
+        assert c["done"].sum() > 0
+
+
+@pytest.mark.parametrize("game", GAMES)
+def test_fused_equals_reference_factory_functions(game, lib):
+    """The reference's own make_atari + wrap_deepmind (their fixed options: TimeLimit, NoopResetEnv(30), MaxAndSkipEnv(4),
+    EpisodicLifeEnv, FireResetEnv, WarpFrame 84x84, ClipRewardEnv) + Monitor + VecFrameStack(4) -- baselines' Atari path
+    (atari_wrappers.py:324-360, cmd_util.py:32)."""
+    c = Case("default_path_" + game)
+    e = c.engine(lib)
+    assert np.array_equal(e.agent_reset(), c["reset_obs"])
+    eps = c.replay(e)
+    c.check_states(e)
+    c.check_monitor(eps)
 
 
 @pytest.mark.gpu
@@ -478,177 +266,108 @@ WRAPPER_CASES = [("breakout", True, True, 30), ("breakout", True, False, 0), ("b
 
 @pytest.mark.parametrize("game,episodic,fire,noop_max", WRAPPER_CASES)
 def test_reset_wrappers_equal_wrapper_classes(game, episodic, fire, noop_max, lib):
-    """The whole stack: what venv.reset() / venv.step() of the reference's classes return == the fused engine's outputs
+    """The whole stack: what venv.reset() / venv.step() of the reference's classes returned == the fused engine's outputs
     (observation stacks, rewards, dones, Monitor's episode records), and the games end in the same states."""
-    n, steps, skip, oh, ow, stack = 3, 220, 4, 42, 42, 4
-    if game == "amidar":
-        oh, ow = 50, 40
-    if game == "space_invaders":
-        oh, ow = 42, 64
-    fused, singles = _pair_with_singles(game, n, lib, 77)
-    fused.agent_init(skip=skip, out_h=oh, out_w=ow, stack=stack, clip_reward=True, episodic_life=episodic, fire_reset=fire,
-                     noop_max=noop_max, noop_seed=99, env_offset=1000)
-    ref = RefStack(singles, skip, oh, ow, stack, True, episodic, fire, noop_max, 99, 1000)
-    assert np.array_equal(fused.agent_reset(), ref.reset())
-    fused_eps = [[] for _ in range(n)]
-    info_eps = [[] for _ in range(n)]
-    n_done = n_real = 0
-    for t in range(steps):
-        idx, ale = _indices(game, n, t, 21)
-        o1, r1, d1 = fused.agent_step(ale)
-        ended, ret, length = fused.agent_episodes()
-        o2, r2, d2, infos = ref.step(idx)
-        assert np.array_equal(r1, r2) and np.array_equal(d1, d2), t
-        assert np.array_equal(o1, o2), t
-        n_done += int(d1.sum())
-        for i in range(n):
-            if ended[i]:
-                fused_eps[i].append((float(ret[i]), int(length[i])))
-            if "episode" in infos[i]:
-                info_eps[i].append((float(infos[i]["episode"]["r"]), infos[i]["episode"]["l"]))
-    for i in range(n):
-        assert fused_eps[i] == ref.monitors[i].episodes, i
-        assert info_eps[i] == fused_eps[i], i           # no game ended inside a reset procedure here, so info saw them all
-        assert bytes(fused.get_state(i)) == bytes(singles[i].get_state(0))
-        assert fused.get_sim_rng(i) == singles[i].get_sim_rng(0)
-        n_real += len(fused_eps[i])
+    c = Case("wrappers_%s_e%d_f%d_n%d" % (game, episodic, fire, noop_max))
+    e = c.engine(lib)
+    assert np.array_equal(e.agent_reset(), c["reset_obs"])
+    eps = c.replay(e)
+    c.check_states(e)
+    c.check_monitor(eps)            # no game ended inside a reset procedure here, so info["episode"] saw them all
+    n_done, n_real = int(c["done"].sum()), int(c["mon_count"].sum())
     if game == "breakout":
         assert n_done > 0 and (not episodic or n_done > n_real)
 
 
-def test_second_reset_in_mid_episode_is_a_noop_step_under_episodic_life(lib):
+@pytest.mark.parametrize("episodic", [True, False])
+def test_second_reset_in_mid_episode_is_a_noop_step_under_episodic_life(episodic, lib):
     """EpisodicLifeEnv.reset only restarts the game after a real game over (atari_wrappers.py:180-189): venv.reset() in the
     middle of an episode advances one no-op agent step.  Without the wrapper it is a real reset."""
-    for episodic in (True, False):
-        fused, singles = _pair_with_singles("breakout", 2, lib, 5)
-        fused.agent_init(skip=4, out_h=42, out_w=42, stack=2, clip_reward=True, episodic_life=episodic, fire_reset=True)
-        ref = RefStack(singles, 4, 42, 42, 2, True, episodic, True)
-        assert np.array_equal(fused.agent_reset(), ref.reset())
-        for t in range(30):
-            idx, ale = _indices("breakout", 2, t, 2)
-            o1, _, _ = fused.agent_step(ale)
-            o2, _, _, _ = ref.step(idx)
-            assert np.array_equal(o1, o2)
-        assert np.array_equal(fused.agent_reset(), ref.reset())
-        for i in range(2):
-            assert bytes(fused.get_state(i)) == bytes(singles[i].get_state(0))
-        score = fused.get_states_np()["score"]
-        assert (score == 0).all() != episodic or True
-        for t in range(30, 60):
-            idx, ale = _indices("breakout", 2, t, 2)
-            o1, _, _ = fused.agent_step(ale)
-            o2, _, _, _ = ref.step(idx)
-            assert np.array_equal(o1, o2)
+    c = Case("second_reset_" + ("episodic" if episodic else "plain"))
+    e = c.engine(lib)
+    assert np.array_equal(e.agent_reset(), c["reset_obs"])
+    c.replay(e, 0, 30)
+    assert np.array_equal(e.agent_reset(), c["second_reset_obs"])
+    c.check_states(e, "mid_state_json", "mid_sim_rng")
+    c.replay(e, 30, 60)
+    c.check_states(e)
 
 
 def test_injected_noop_counts(lib):
     """NoopResetEnv.override_num_noops (atari_wrappers.py:115-123) per env."""
-    n = 4
-    fused, singles = _pair_with_singles("space_invaders", n, lib, 8)
-    fused.agent_init(skip=2, out_h=42, out_w=64, stack=1, clip_reward=False, noop_max=30, noop_seed=1)
-    ref = RefStack(singles, 2, 42, 64, 1, False, noop_max=30, noop_seed=1)
-    counts = [3, 0, 17, 1]                               # 0: keep the default rule for that env
-    fused.agent_set_noops(counts)
-    for i, c in enumerate(counts):
-        ref.noops[i].override_num_noops = c if c > 0 else None
-    assert np.array_equal(fused.agent_reset(), ref.reset())
-    for i in range(n):
-        assert bytes(fused.get_state(i)) == bytes(singles[i].get_state(0))
+    c = Case("injected_noops")
+    e = c.engine(lib)
+    e.agent_set_noops(c["noop_counts"])                      # 0: keep the default rule for that env
+    assert np.array_equal(e.agent_reset(), c["reset_obs"])
+    c.check_states(e)
     # 3 no-op frames after the new game: SpaceInvaders' get-ready timer started at 128
-    assert fused.get_states_np()["life_display_timer"][0] == 128 - 3 and fused.get_states_np()["life_display_timer"][3] == 127
-    fused.agent_set_noops(None)
-    for nr in ref.noops:
-        nr.override_num_noops = None
+    assert e.get_states_np()["life_display_timer"][0] == 128 - 3 and e.get_states_np()["life_display_timer"][3] == 127
+    e.agent_set_noops(None)
     with pytest.raises(ValueError):
-        fused.agent_set_noops([1, 2])
+        e.agent_set_noops([1, 2])
 
 
-def _noop_step_game_over_case(lib, jump_timer, strict, tolerate):
-    """Amidar, two lives left, every enemy parked on the player with its respawn tile ON the player's start tile, and a jump
-    that runs out `jump_timer` frames from now: the life is lost when the jump ends, everyone respawns on the same tile and
-    the next frame costs the last life.  Returns None unless the first life goes in the LAST frame of the agent step (so that
-    the game ends inside EpisodicLifeEnv.reset's no-op step), else what happened next."""
-    from toybox_amd import ToyboxAmdError
-    from toybox_amd.games import amidar as am
-    fused, singles = _pair_with_singles("amidar", 1, lib, 3)
-    fused.agent_init(skip=4, out_h=50, out_w=40, stack=2, clip_reward=True, episodic_life=True)
-    ref = RefStack(singles, 4, 50, 40, 2, True, episodic=True, strict_monitor=strict)
-    assert np.array_equal(fused.agent_reset(), ref.reset())
-    js = am.state_to_json(fused.get_state(0))
-    js["lives"], js["jump_timer"] = 2, jump_timer
-    for en in js["enemies"]:
-        en["position"] = dict(js["player"]["position"])
-        en["step"] = None
-        en["ai"] = {"EnemyPerimeterAI": {"start": {"tx": 31, "ty": 15}}}
-    st = am.state_from_json(js)
-    fused.set_state(0, st)
-    singles[0].set_state(0, st)
-    o1, r1, d1 = fused.agent_step([0])
-    o2, r2, d2, _ = ref.step([0])
-    assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
-    assert bytes(fused.get_state(0)) == bytes(singles[0].get_state(0))
-    if not (d1[0] and fused.get_state(0).lives == 0 and ref.monitors[0].needs_reset):
-        return None
-    # the game is over, the wrapper stack thinks a life was lost; Monitor closed the episode inside the ignored step
-    assert fused.agent_episodes()[0][0] and ref.monitors[0].episodes == [(float(fused.agent_episodes()[1][0]), int(fused.agent_episodes()[2][0]))]
-    if strict:
-        with pytest.raises(RuntimeError):
-            ref.step([1])
-        with pytest.raises(ToyboxAmdError) as ei:
-            fused.agent_step([1])
-        assert ei.value.code == _abi.E_NEEDS_RESET
-        return "raised"
-    for t in range(12):                                # the stack without a Monitor: done at once, real reset, play on
-        a = [1 + t % 3]
-        o1, r1, d1 = fused.agent_step(a, tolerate_needs_reset=tolerate)
-        o2, r2, d2, _ = ref.step(a)
-        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2), t
-        assert bytes(fused.get_state(0)) == bytes(singles[0].get_state(0)), t
-        if t == 0:
-            assert d1[0] and fused.get_state(0).lives == 3 and not fused.agent_episodes()[0][0]
-    assert ref.monitors[0].stale_steps == 1
-    return "continued"
+def _edit_state(e, c, **kw):
+    cd = codec("amidar")
+    e.set_state(0, cd.state_from_json(amidar_edit_last_lives(cd.state_to_json(e.get_state(0)), **kw)))
 
 
 def test_game_over_inside_the_episodic_life_noop_step(lib):
     """EpisodicLifeEnv.reset ignores the `done` of its no-op step (atari_wrappers.py:186-187).  bench.Monitor then raises on
-    the next step ("Tried to step environment that needs reset", bench/monitor.py:52-53); the engine reports
-    TBX_E_NEEDS_RESET and has carried the step out exactly as the stack does without a Monitor: the finished game reports
-    done on its next frame and is reset for real."""
-    outcomes = set()
+    the next step ("Tried to step environment that needs reset", bench/monitor.py:52-53: recorded as `raised` in the
+    fixture); the engine reports TBX_E_NEEDS_RESET and has carried the step out exactly as the stack does without a Monitor
+    (the fixture's `cont_*` arrays, recorded from the same classes without the Monitor): the finished game reports done on
+    its next frame and is reset for real."""
+    from toybox_amd import ToyboxAmdError
+    hits = 0
     for j in range(1, 9):
+        c = Case("noop_step_game_over_j%d" % j)
         for strict in (True, False):
-            outcomes.add(_noop_step_game_over_case(lib, j, strict, tolerate=True))
-    assert "raised" in outcomes and "continued" in outcomes, outcomes
+            e = c.engine(lib)
+            assert np.array_equal(e.agent_reset(), c["reset_obs"])
+            _edit_state(e, c, lives=2, jump_timer=j, perimeter_from_start=True)
+            # a game that ends inside the ignored no-op step closes Monitor's episode there: info["episode"] of the step that
+            # the learner sees does not carry it (ep_flag False), Monitor's own list -- and the engine's report -- do
+            c.replay(e, episodes=False)
+            c.check_states(e)
+            ended, ret, length = e.agent_episodes()
+            c.check_monitor([[(float(ret[0]), int(length[0]))] if ended[0] else []])
+            assert bool(c["hit"]) == bool(c["done"][0][0] and e.get_state(0).lives == 0)
+            assert bool(ended[0]) == bool(c["hit"] or c["ep_flag"][0][0])
+            if not c["hit"]:
+                continue
+            hits += 1
+            assert bool(c["raised"]) and e.agent_episodes()[0][0]
+            if strict:
+                with pytest.raises(ToyboxAmdError) as ei:
+                    e.agent_step(c.ale([1]))
+                assert ei.value.code == _abi.E_NEEDS_RESET
+                continue
+            for t in range(len(c["cont_action_idx"])):
+                obs, rew, done = e.agent_step(c.ale(c["cont_action_idx"][t]), tolerate_needs_reset=True)
+                assert np.array_equal(obs, c["cont_obs"][t]) and np.array_equal(rew, c["cont_rew"][t]), (j, t)
+                assert np.array_equal(done, c["cont_done"][t]), (j, t)
+                if t == 0:
+                    assert done[0] and e.get_state(0).lives == 3 and not e.agent_episodes()[0][0]
+            c.check_states(e, "cont_state_json", "cont_sim_rng")
+    assert hits > 0
 
 
 def test_cut_short_step_keeps_the_stale_frame_buffer(lib):
     """Agent steps cut short by a game over at every possible sub-frame (the jump that protects the player runs out j frames
     from now, on the last life), with FireResetEnv on: MaxAndSkipEnv stops stepping at `done` and leaves the buffer slots it
     did not reach (atari_wrappers.py:196-214); the observation is the one FireResetEnv.reset returns (:144-152)."""
-    from toybox_amd.games import amidar as am
     hits = 0
+    cd = codec("amidar")
     for j in range(1, 14):
-        fused, singles = _pair_with_singles("amidar", 1, lib, 4)
-        fused.agent_init(skip=4, out_h=50, out_w=40, stack=2, clip_reward=False, episodic_life=False, fire_reset=True)
-        ref = RefStack(singles, 4, 50, 40, 2, False, fire=True)
-        assert np.array_equal(fused.agent_reset(), ref.reset())
-        js = am.state_to_json(fused.get_state(0))
-        js["lives"], js["jump_timer"] = 1, j
-        for en in js["enemies"]:
-            en["position"] = dict(js["player"]["position"])
-            en["step"] = None
-        st = am.state_from_json(js)
-        fused.set_state(0, st)
-        singles[0].set_state(0, st)
-        cut = False
+        c = Case("cut_short_j%d" % j)
+        e = c.engine(lib)
+        assert np.array_equal(e.agent_reset(), c["reset_obs"])
+        _edit_state(e, c, lives=1, jump_timer=j, perimeter_from_start=False)
         for t in range(4):
-            o1, r1, d1 = fused.agent_step([0])
-            o2, r2, d2, _ = ref.step([0])
-            assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2), (j, t)
-            assert bytes(fused.get_state(0)) == bytes(singles[0].get_state(0)), (j, t)
-            cut = cut or bool(d1[0])
-        hits += cut
+            c.replay(e, t, t + 1)
+            assert cd.state_to_json(e.get_state(0)) == json.loads(str(c["state_json_per_step"][t][0])), (j, t)
+        hits += bool(c["done"].any())
     assert hits > 0
 
 

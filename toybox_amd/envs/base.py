@@ -1,24 +1,44 @@
-"""Single-env gym-style surface with the semantics of the reference's ToyboxBaseEnv
-(/root/reference/toybox/envs/atari/base.py:38-173): obs = rendered frame (H,W,C) uint8 with
-C = 1 if grayscale else 4 if alpha else 3; reward = max(score - previous score, 0); done = lives <= 0;
-info = {lives, score (0 when done), cached_state on the game-over step}.  gym itself is optional."""
+"""One-env gym surface over an engine: the drop-in for the reference's `toybox.envs.atari` classes
+(/root/reference/toybox/envs/atari/base.py:38-173, breakout.py / amidar.py / space_invaders.py / gridworld.py).
+
+Contract kept from the reference (each line checked by tests/test_envs.py on both libraries, and -- through the reference's own
+wrapper classes -- by the fixtures of tests/golden/wrappers/):
+  step(i)  -> (frame, reward, done, info): i indexes the sorted legal action set; frame is (H, W, C) uint8 with C = 1 for
+              grayscale, 4 with alpha, else 3; reward = max(score - score at the previous step, 0); done = lives <= 0;
+              info = {"lives", "score" (0 once done), "cached_state" (state JSON, on the game-over step only)}
+  reset()  -> frame of a new game; the state before it is kept in `cached_state`
+  seed(s)  -> [s, hash_seed(s + 1) % 2**31]; the second value seeds the simulator and a new game is started
+  .ale     -> lives() / get_score() / game_over() / saveScreenPNG(name), what baselines' wrappers ask an ALE for
+  .toybox  -> the ctoybox-shaped Toybox (interventions take it from here)
+The class derives from gym.Env when a `gym` is importable and registers the reference's three ids with it (envs/__init__.py);
+without gym it is a plain class with the same methods and `toybox_amd.envs.make(id)`.
+"""
 import hashlib
+import os
 
 import numpy as np
 
 from ..toybox import Toybox
 from .constants import ACTION_MEANING
-from .spaces import Box, Discrete
+
+try:                                                    # gym is optional (absent from the ROCm image)
+    import gym as _gym
+    from gym.spaces import Box, Discrete
+    _EnvBase = _gym.Env
+except ImportError:                                     # pragma: no cover - depends on the installation
+    _gym = None
+    from .spaces import Box, Discrete
+    _EnvBase = object
 
 
 def hash_seed(seed, max_bytes=8):
     """gym.utils.seeding.hash_seed of the gym era the reference targets: little-endian int of sha512(str(seed))[:8]."""
-    h = hashlib.sha512(str(seed).encode("utf8")).digest()
-    return int.from_bytes(h[:max_bytes], "little")
+    digest = hashlib.sha512(str(seed).encode("utf8")).digest()
+    return int.from_bytes(digest[:max_bytes], "little")
 
 
 class MockALE:
-    """ALE-shaped view over a Toybox (envs/atari/base.py:15-35)."""
+    """What baselines' wrappers read from `env.unwrapped.ale` (EpisodicLifeEnv: lives(); envs/atari/base.py:15-35)."""
 
     def __init__(self, toybox):
         self.toybox = toybox
@@ -30,101 +50,85 @@ class MockALE:
         return self.toybox.get_score()
 
     def game_over(self):
-        # matches baselines / atari_py, not what videogames would expect (envs/atari/base.py:25-27)
-        return self.toybox.get_lives() <= 0
+        return self.lives() <= 0                        # "out of lives", the atari_py meaning, not the game's own flag
 
     def saveScreenPNG(self, name):
-        if isinstance(name, bytes):
-            name = name.decode("utf-8")
-        self.toybox.save_frame_image(name, grayscale=False)
+        path = name.decode("utf-8") if isinstance(name, bytes) else name
+        self.toybox.save_frame_image(path, grayscale=False)
 
 
-class ToyboxBaseEnv:
+class ToyboxBaseEnv(_EnvBase):
     metadata = {"render.modes": ["human", "rgb_array"]}
     reward_range = (0, float("inf"))
-    game_name = None
+    game_name = None                                    # set by the per-game subclasses
 
-    def __init__(self, toybox=None, game=None, frameskip=(2, 5), repeat_action_probability=0.0, grayscale=True,
-                 alpha=False, actions=None):
-        if toybox is None:
-            toybox = Toybox(game or self.game_name, grayscale)
-        assert toybox.rstate
-        self.toybox = toybox
-        self.cached_state = None
-        self.score = self.toybox.get_score()
-        self.viewer = None
-        self._np_random = None
-        self.ale = MockALE(toybox)
-        if actions is None:
-            actions = toybox.get_legal_action_set()
-        assert actions is not None
-        self._action_set = list(actions)
-        self._obs_type = "image"
-        self._rgba = 1 if grayscale else 4 if alpha else 3
-        self._pixel_high = 255
-        self._height = self.toybox.get_height()
-        self._width = self.toybox.get_width()
-        self._dim = (self._height, self._width, self._rgba)
+    def __init__(self, toybox=None, game=None, frameskip=(2, 5), repeat_action_probability=0.0, grayscale=True, alpha=False,
+                 actions=None):
+        # frameskip / repeat_action_probability: accepted for signature compatibility; like the reference's NoFrameskip
+        # envs, one step is one frame and actions are never repeated at random
+        tb = toybox if toybox is not None else Toybox(game or self.game_name, grayscale)
+        if not tb.rstate:
+            raise ValueError("the Toybox handed to %s has been closed" % type(self).__name__)
+        self.toybox = tb
+        self.ale = MockALE(tb)
+        self.channels = 1 if grayscale else (4 if alpha else 3)
+        self._action_set = list(tb.get_legal_action_set() if actions is None else actions)
         self.action_space = Discrete(len(self._action_set))
-        self.observation_space = Box(low=0, high=self._pixel_high, shape=self._dim, dtype="uint8")
+        self.observation_space = Box(low=0, high=255, shape=(tb.get_height(), tb.get_width(), self.channels), dtype=np.uint8)
+        self.score = tb.get_score()                     # the score one step ago: rewards are its increases
+        self.cached_state = None
+        self._np_random = None
 
+    # ------------------------------------------------------------------ gym.Env
     @property
     def unwrapped(self):
         return self
 
     @property
     def np_random(self):
+        """NoopResetEnv draws its no-op count here (atari_wrappers.py:124); seeded lazily like gym's envs"""
         if self._np_random is None:
             self.seed()
         return self._np_random
 
     def seed(self, seed=None):
-        """envs/atari/base.py:84-98: seed1 -> seed2 = hash_seed(seed1 + 1) % 2**31 -> set_seed -> new_game."""
-        if seed is None:
-            seed = int(np.random.SeedSequence().entropy % (2 ** 31))
-        seed1 = int(seed)
-        self._np_random = np.random.RandomState(seed1 % (2 ** 32))
-        seed2 = hash_seed(seed1 + 1) % 2 ** 31
-        self.toybox.set_seed(seed2)
-        self.toybox.new_game()
-        return [seed1, seed2]
+        first = int.from_bytes(os.urandom(4), "little") % 2 ** 31 if seed is None else int(seed)
+        second = hash_seed(first + 1) % 2 ** 31
+        self._np_random = np.random.RandomState(first % 2 ** 32)
+        self.toybox.set_seed(second)
+        self.toybox.new_game()                          # the simulator's seed only acts through a new game
+        return [first, second]
 
     def get_action_meanings(self):
-        # all 18 names regardless of the action set, as the reference does (envs/atari/base.py:102-104)
-        return list(ACTION_MEANING.values())
+        return list(ACTION_MEANING.values())            # all 18 ALE names whatever the action set, as the reference answers
 
-    def _get_obs(self):
-        if self._rgba == 1:
-            return self.toybox._engine.render_env(self.toybox._env, 1)
-        return self.toybox._engine.render_env(self.toybox._env, self._rgba)
+    def _frame(self):
+        return self.toybox._engine.render_env(self.toybox._env, self.channels)
 
     def step(self, action_index):
-        info = {}
-        assert action_index < len(self._action_set)
-        self.toybox.apply_ale_action(self._action_set[int(action_index)])
-        if self.ale.game_over():
-            info["cached_state"] = self.toybox.to_state_json()
-        obs = self._get_obs()
-        score = self.toybox.get_score()
-        reward = max(score - self.score, 0)
-        self.score = score
-        done = self.ale.game_over()
-        info["lives"] = self.toybox.get_lives()
-        info["score"] = 0 if done else self.score
-        return obs, reward, done, info
+        if not 0 <= action_index < len(self._action_set):
+            raise AssertionError("action index %r outside the %d legal actions" % (action_index, len(self._action_set)))
+        tb = self.toybox
+        tb.apply_ale_action(self._action_set[int(action_index)])
+        score, lives = tb.get_score(), tb.get_lives()
+        done = lives <= 0
+        info = {"lives": lives, "score": 0 if done else score}
+        if done:
+            info["cached_state"] = tb.to_state_json()
+        reward, self.score = max(score - self.score, 0), score
+        return self._frame(), reward, done, info
 
     def reset(self):
-        self.cached_state = self.toybox.to_state_json()
-        self.toybox.new_game()
-        self.score = self.toybox.get_score()
-        return self._get_obs()
+        tb = self.toybox
+        self.cached_state = tb.to_state_json()
+        tb.new_game()
+        self.score = tb.get_score()
+        return self._frame()
 
     def render(self, mode="human", close=False):
-        if mode == "rgb_array":
-            return self.toybox.get_rgb_frame()
-        if mode == "human":
-            return self.toybox.get_rgb_frame()   # no viewer dependency: hand the frame to the caller
-        raise ValueError("unknown render mode %r" % (mode,))
+        if mode not in ("human", "rgb_array"):
+            raise ValueError("unknown render mode %r" % (mode,))
+        return self.toybox.get_rgb_frame()              # headless: "human" hands the frame to the caller, no viewer window
 
     def close(self):
         if self.toybox is not None:
@@ -132,45 +136,33 @@ class ToyboxBaseEnv:
         self.toybox = None
 
 
-class BreakoutEnv(ToyboxBaseEnv):
-    game_name = "breakout"
+def _game_env(game, default_frameskip=(2, 5)):
+    """the per-game classes differ only in the game they open (envs/atari/breakout.py:7-12 and siblings)"""
 
-    def __init__(self, frameskip=(2, 5), repeat_action_probability=0.0, grayscale=True, alpha=False):
-        super().__init__(Toybox("breakout", grayscale), "breakout", frameskip, repeat_action_probability,
-                         grayscale=grayscale, alpha=alpha)
+    class GameEnv(ToyboxBaseEnv):
+        game_name = game
 
+        def __init__(self, frameskip=default_frameskip, repeat_action_probability=0.0, grayscale=True, alpha=False):
+            ToyboxBaseEnv.__init__(self, None, game, frameskip, repeat_action_probability, grayscale=grayscale, alpha=alpha)
 
-class AmidarEnv(ToyboxBaseEnv):
-    game_name = "amidar"
-
-    def __init__(self, frameskip=(2, 5), repeat_action_probability=0.0, grayscale=True, alpha=False):
-        super().__init__(Toybox("amidar", grayscale), "amidar", frameskip, repeat_action_probability,
-                         grayscale=grayscale, alpha=alpha)
+    return GameEnv
 
 
-class SpaceInvadersEnv(ToyboxBaseEnv):
-    game_name = "space_invaders"
+BreakoutEnv = _game_env("breakout")
+AmidarEnv = _game_env("amidar")
+SpaceInvadersEnv = _game_env("space_invaders")
+GridWorldEnv = _game_env("gridworld", (0, 0))           # envs/atari/gridworld.py:8-13: neither exported nor registered upstream
+for _name, _cls in (("BreakoutEnv", BreakoutEnv), ("AmidarEnv", AmidarEnv), ("SpaceInvadersEnv", SpaceInvadersEnv),
+                    ("GridWorldEnv", GridWorldEnv)):
+    _cls.__name__ = _cls.__qualname__ = _name
 
-    def __init__(self, frameskip=(2, 5), repeat_action_probability=0.0, grayscale=True, alpha=False):
-        super().__init__(Toybox("space_invaders", grayscale), "space_invaders", frameskip, repeat_action_probability,
-                         grayscale=grayscale, alpha=alpha)
-
-
-class GridWorldEnv(ToyboxBaseEnv):
-    """envs/atari/gridworld.py:8-13 (frameskip (0, 0) there; neither exported nor gym-registered by the reference)."""
-    game_name = "gridworld"
-
-    def __init__(self, frameskip=(0, 0), repeat_action_probability=0.0, grayscale=True, alpha=False):
-        super().__init__(Toybox("gridworld", grayscale), "gridworld", frameskip, repeat_action_probability,
-                         grayscale=grayscale, alpha=alpha)
-
-
+# gym ids of the reference (toybox/__init__.py:8-24) and their `nondeterministic` flags
 ENV_IDS = {
-    # gym ids of the reference (toybox/__init__.py:8-24)
     "BreakoutToyboxNoFrameskip-v4": BreakoutEnv,
     "AmidarToyboxNoFrameskip-v4": AmidarEnv,
     "SpaceInvadersToyboxNoFrameskip-v4": SpaceInvadersEnv,
 }
+_NONDETERMINISTIC = {"BreakoutToyboxNoFrameskip-v4": True}
 
 
 def make(env_id, **kwargs):
@@ -178,8 +170,15 @@ def make(env_id, **kwargs):
 
 
 def register_with_gym():
-    """Registers the three ids with gym when gym is installed (toybox/__init__.py:8-24)."""
+    """Puts the three ids into gym's registry (what `import toybox` does upstream); returns the ids it added."""
     from gym.envs.registration import register
-    register(id="BreakoutToyboxNoFrameskip-v4", entry_point="toybox_amd.envs:BreakoutEnv", nondeterministic=True)
-    register(id="AmidarToyboxNoFrameskip-v4", entry_point="toybox_amd.envs:AmidarEnv", nondeterministic=False)
-    register(id="SpaceInvadersToyboxNoFrameskip-v4", entry_point="toybox_amd.envs:SpaceInvadersEnv", nondeterministic=False)
+    added = []
+    for env_id, cls in ENV_IDS.items():
+        try:
+            register(id=env_id, entry_point="toybox_amd.envs:%s" % cls.__name__,
+                     nondeterministic=_NONDETERMINISTIC.get(env_id, False))
+            added.append(env_id)
+        except Exception as exc:                        # gym raises on a second registration of the same id
+            if "Cannot re-register" not in str(exc) and "already" not in str(exc).lower():
+                raise
+    return added
