@@ -16,10 +16,12 @@
  *     device (HBM) pointers (call is asynchronous on the given hipStream_t, passed as void*);
  *   - calls on one handle take effect in program order whatever streams they name: when an entry point uses another stream
  *     than the previous one did (the host-pointer forms run on an engine-owned non-blocking stream), the new stream first
- *     waits for an event recorded on the old one -- no tbx_sync is needed between the two API families.  Where two
- *     consecutive calls cannot affect each other the library may run them side by side (a Breakout tbx_step_synthetic beside
- *     the tbx_render_device queued before it, on an internal stream; the stream the call names still waits for it), which
- *     no caller can observe except by the clock;
+ *     waits for an event recorded on the old one -- no tbx_sync is needed between the two API families.  The library keeps
+ *     the handle of the stream the LAST call named until the next call (or tbx_sync) so that it can record that event; a
+ *     caller that destroys such a stream in between loses nothing: the stale handle is detected and the next call falls back
+ *     to a device-wide synchronisation.  The engine-owned output buffers (TBX_BUF_*) keep their addresses and a result in
+ *     them stays valid for whatever the caller queues on the stream of the call that produced it before its next call on the
+ *     handle -- unless the pipelined mode is switched on (TBX_OPT_PIPELINE below), which double-buffers them;
  *   - a handle is not thread-safe; different handles may be used concurrently;
  *   - there is NO CPU fallback: tbx_create fails with TBX_E_NO_DEVICE when no gfx950
  *     device is visible.
@@ -375,7 +377,8 @@ int tbx_step(tbx_engine* engine, const int32_t* ale_actions_host, uint32_t flags
 int tbx_step_device(tbx_engine* engine, const int32_t* ale_actions_dev, uint32_t flags, void* stream);
 /* Same, with the actions generated on the device: env e at time t plays
  * legal[ splitmix64(action_seed ^ (e_global << 32) ^ t) mod n_legal ], e_global = env_offset + e.
- * (Such a step depends on nothing a rasteriser produces; Breakout's runs beside the previous frame's tbx_render_device.) */
+ * (Such a step depends on nothing a rasteriser produces: with TBX_OPT_PIPELINE it runs beside the previous frame's
+ * tbx_render_device.) */
 int tbx_step_synthetic(tbx_engine* engine, uint64_t action_seed, uint64_t t, uint64_t env_offset,
                        uint32_t flags, void* stream);
 /* One frame for ONE env by ALE action id, with the outputs of tbx_step: out[4] = {reward, done, lives, score} (may be NULL).
@@ -383,8 +386,8 @@ int tbx_step_synthetic(tbx_engine* engine, uint64_t action_seed, uint64_t t, uin
  * env (envs/atari/base.py:126-145, test/benchmark.py:50-56).  On a ONE-env engine this call does not launch anything: a
  * resident kernel (one wave) waits on a mailbox in host-coherent pinned memory, steps env 0 and posts the outputs back --
  * two PCIe hops per frame.  The wave leaves after 50 ms without a request and every other entry point of the handle stops it
- * first, so the two never run side by side.  On batch engines it is tbx_apply_input plus a read-back of the outputs.
- * TBX_NO_SERVER=1 in the environment forces that second form everywhere. */
+ * first, so the two never run side by side.  On batch engines it is tbx_apply_input plus a read-back of the outputs
+ * (TBX_OPT_RESIDENT_STEP = 0 forces that second form everywhere). */
 int tbx_step1(tbx_engine* engine, int env, int32_t ale_action, uint32_t flags, int32_t out[4]);
 /* One frame for one env with a raw button mask.
  * replaces Toybox.apply_action(Input) (scripts/utils/test_games.py:13). */
@@ -507,6 +510,10 @@ int tbx_gather_unique_id(void* id_out, size_t id_bytes);
 /* Collective over all ranks (ncclCommInitRank).  records_per_rank >= this engine's env count is the per-rank slot width of
  * the gathered layout [nranks][records_per_rank] (ranks may hold unequal shards; unused slots read 0). */
 int tbx_gather_init(tbx_engine* engine, int nranks, int rank, int records_per_rank, const void* id, size_t id_bytes);
+/* What the communicator itself reports (ncclCommCount; == nranks after a successful tbx_gather_init) and the path of the
+ * librccl that was loaded -- so that a benchmark line can say which collective really ran over how many ranks. */
+int tbx_gather_nranks(tbx_engine* engine);
+const char* tbx_gather_library(tbx_engine* engine);
 /* Queue the all-gather of the last step's records into out_dev (NULL: the engine-owned TBX_BUF_GATHERED).  Asynchronous: it
  * is ordered after everything queued through this handle so far, runs on an engine-owned communication stream, and the next
  * step on this handle is ordered after it -- what the caller queues in between (the rasteriser) overlaps with it. */
@@ -519,8 +526,43 @@ int tbx_gather_host(tbx_engine* engine, uint64_t* out_host);
 int tbx_gather_reduce_max(tbx_engine* engine, double* inout_host);
 #define TBX_BUF_GATHERED 12   /* uint64[nranks][records_per_rank] result of tbx_gather(out_dev = NULL) */
 
-/* Address of an engine-owned device buffer (TBX_BUF_*). */
+/* Address of an engine-owned device buffer (TBX_BUF_*).  In pipelined mode (TBX_OPT_PIPELINE) the step outputs and the
+ * engine-owned frame buffer each alternate between two addresses: ask again after every step / render. */
 int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out_bytes);
+
+/* ------------------------------------------------------------------ engine options
+ * Launch-time choices that used to be environment variables.  Every non-default path they select has a parity test against
+ * the oracle (tests/test_gpu_paths.py, tests/test_preproc.py).  Unknown options / values: TBX_E_INVALID.
+ *
+ * TBX_OPT_PIPELINE -- random-rollout loops (tbx_step_synthetic + tbx_render_device) only; 0 = off (default).
+ *   A step whose actions are generated on the device depends on nothing the previous frame's rasteriser produces, and a
+ *   rasteriser that reads step-written render records (Breakout) disturbs nothing the next step touches.  With the option
+ *   on, such engines keep TWO sets of render records, of step outputs (TBX_BUF_REWARD / DONE / LIVES / SCORE / PACKED) and
+ *   -- for tbx_render_device(out_dev = NULL) -- of TBX_BUF_FRAME, and run the calls on internal streams:
+ *     value 2: tbx_step_synthetic N+1 runs beside the rasteriser of frame N;
+ *     value 3: additionally consecutive rasteriser launches alternate between two internal streams and the two frame
+ *              buffers, so that launch N+1 fills the ramp-down of launch N (small batches: BASELINE configs 2-4, the
+ *              per-GPU share of a strong-scaled batch);
+ *     value 1: the engine picks 0, 2 or 3 from game and batch size (what bench.py measured to pay).
+ *   Contract in this mode: the stream a call names still waits for the call's work, so anything queued on it afterwards sees
+ *   the result; the result of step N (render N) stays valid for readers queued on that stream BEFORE step N+1 (render N+1)
+ *   is issued -- the same rule as without the option -- but it lives at the address tbx_device_buffer reports after the
+ *   call, which alternates.  Every other call on the handle first joins the pipeline.  Engines whose rasteriser reads live
+ *   state (SpaceInvaders, Amidar, GridWorld, Breakout with intervention-written bricks) ignore the option. */
+#define TBX_OPT_PIPELINE      0
+/* batch step kernel form of Breakout and Amidar: 0 = the engine's choice (by batch size), 1 = one thread per env, 2 = one
+ * wavefront per env */
+#define TBX_OPT_STEP_FORM     1
+/* waves per frame of the rasteriser launches: 0 = the engine's choice (by game, channels and batch size) */
+#define TBX_OPT_RENDER_SPLIT  2
+/* 1: the agent observation goes through two full-resolution gray renders and the generic warp kernel instead of the per-game
+ * fused kernels (the cross-check path); read by tbx_agent_init */
+#define TBX_OPT_AGENT_GENERIC 3
+/* 1 (default): tbx_step1 on a one-env engine talks to the resident step kernel; 0: single-env launch + read-back */
+#define TBX_OPT_RESIDENT_STEP 4
+#define TBX_OPT_COUNT         5
+int tbx_set_option(tbx_engine* engine, int option, int value);
+int tbx_get_option(tbx_engine* engine, int option, int* value_out);
 /* Block until all work queued by this engine has finished; reports a pending TBX_E_ACTION. */
 int tbx_sync(tbx_engine* engine);
 

@@ -48,6 +48,7 @@ struct tbx_engine {
     uint8_t *was_real_done, *needs_reset;
     int32_t* noop_override;
     int pending_needs_reset;
+    int opt[TBX_OPT_COUNT];
 };
 
 static char g_err[256];
@@ -121,6 +122,7 @@ int tbx_create(int game, int n, int device, const void* cfg, size_t cfg_size, tb
     e->packed = (uint64_t*)calloc((size_t)n, 8);
     const char* th = getenv("TBX_ORACLE_THREADS");
     e->threads = th ? atoi(th) : 1;
+    e->opt[TBX_OPT_RESIDENT_STEP] = 1;
     if (cfg) memcpy(e->cfg, cfg, csz);
     else switch (game) {
         case TBX_GAME_BREAKOUT: orc_breakout_default_config((tbx_breakout_config_t*)e->cfg); break;
@@ -674,6 +676,34 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout)
     }
     return TBX_OK;
 }
+
+/* launch-time choices of the device engine: stored and reported, without effect on a scalar CPU restatement */
+int tbx_set_option(tbx_engine* e, int option, int value)
+{
+    static const int hi[TBX_OPT_COUNT] = {3, 2, 64, 1, 1};
+    if (!e) return TBX_E_INVALID;
+    if (option < 0 || option >= TBX_OPT_COUNT) return fail(e, TBX_E_INVALID, "unknown option");
+    if (value < 0 || value > hi[option]) return fail(e, TBX_E_INVALID, "option value out of range");
+    e->opt[option] = value;
+    return TBX_OK;
+}
+
+int tbx_get_option(tbx_engine* e, int option, int* value_out)
+{
+    if (!e) return TBX_E_INVALID;
+    if (option < 0 || option >= TBX_OPT_COUNT || !value_out) return fail(e, TBX_E_INVALID, "unknown option");
+    *value_out = e->opt[option];
+    return TBX_OK;
+}
+
+int tbx_gather_nranks(tbx_engine* e)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
+    return e->gather_ranks;
+}
+
+const char* tbx_gather_library(tbx_engine* e) { (void)e; return "oracle: POSIX shared memory"; }
 
 int tbx_sync(tbx_engine* e)
 {

@@ -2,8 +2,9 @@
 
 * tbx_apply_input (Toybox.apply_action(Input), /root/reference/scripts/utils/test_games.py:13) on every game, mixed with
   batch steps -- for Breakout this is the wave-per-env kernel brk_step_kernel<false>;
-* the whole batch protocol with TBX_BRK_STEP_TPE=0 (wave-per-env Breakout step instead of thread-per-env);
-* the several-waves-per-frame rasteriser launches at other split factors than the default (TBX_RENDER_SPLIT / TBX_BRK_SPLIT);
+* the whole batch protocol with TBX_OPT_STEP_FORM = 2 (wave-per-env Breakout step instead of thread-per-env);
+* the several-waves-per-frame rasteriser launches at other split factors than the default (TBX_OPT_RENDER_SPLIT);
+* the pipelined mode (TBX_OPT_PIPELINE: steps beside renders, overlapped renders, double-buffered outputs and frames);
 * BASELINE config 5's per-GPU share: three games x 10 922 envs on three HIP streams (toybox_amd.parallel.MixedBatch);
 * every TBX_BUF_* id of tbx_device_buffer on both libraries;
 * the cross-stream ordering rule of the C-ABI (async "_device" calls on the NULL stream, then host-pointer calls).
@@ -117,12 +118,13 @@ def _run_sub(body, env, timeout=900):
 
 @pytest.mark.gpu
 def test_breakout_wave_per_env_step_kernel_parity(oracle_lib):
-    """TBX_BRK_STEP_TPE=0: the batch protocol and the agent pipeline run on brk_step_kernel<false> (one wavefront per env)
+    """TBX_OPT_STEP_FORM = 2: the batch protocol and the agent pipeline run on brk_step_kernel<false> (one wavefront per env)
     instead of the thread-per-env kernel; same bar as test_rollout_parity."""
     body = r"""
 n, steps = 2048, 900
 g, o = Engine("breakout", n, lib=hip), Engine("breakout", n, lib=orc)
 for e in (g, o):
+    e.set_option(_abi.OPT_STEP_FORM, _abi.STEP_FORM_WAVE_PER_ENV)
     e.seed(1234); e.new_game()
 done = 0
 for t in range(steps):
@@ -152,19 +154,20 @@ for t in range(120):
     for x, y in zip(xg, xo):
         assert np.array_equal(x, y), t
 """
-    _run_sub(body, {"TBX_BRK_STEP_TPE": "0"})
+    _run_sub(body, {})
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tpe", ["0", "1"])
-def test_amidar_step_kernel_forms_parity(tpe, oracle_lib):
-    """Amidar's batch step has two forms, chosen by batch size (thread per env from 24 576 envs up, wavefront per env
-    below): TBX_AMI_STEP_TPE forces either one at a batch size the oracle finishes, through the batch protocol, device
+@pytest.mark.parametrize("form", [1, 2])
+def test_amidar_step_kernel_forms_parity(form, oracle_lib):
+    """Amidar's batch step has two forms, chosen by batch size (thread per env from 16 384 envs up, wavefront per env
+    below): TBX_OPT_STEP_FORM forces either one at a batch size the oracle finishes, through the batch protocol, device
     actions and the agent pipeline with every reset-time wrapper on."""
     body = r"""
 n, steps = 1100, 700      # not a multiple of 64: the thread form's last wave is ragged
 g, o = Engine("amidar", n, lib=hip), Engine("amidar", n, lib=orc)
 for e in (g, o):
+    e.set_option(_abi.OPT_STEP_FORM, FORM)
     e.seed(77); e.new_game()
 for t in range(steps):
     a = synthetic_actions("amidar", n, t)
@@ -192,11 +195,11 @@ for t in range(150):
 for i in range(0, n, 3):
     assert bytes(g.get_state(i)) == bytes(o.get_state(i)), i
 """
-    _run_sub(body, {"TBX_AMI_STEP_TPE": tpe})
+    _run_sub(body.replace("FORM", str(form)), {})
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("split", ["1", "2", "3", "5", "7", "16"])
+@pytest.mark.parametrize("split", [1, 2, 3, 5, 7, 16])
 def test_render_split_factors_parity(split, oracle_lib):
     """The rasterisers take `split` waves per frame (launch-time choice, by default a function of game, channels and batch
     size).  Every factor must paint the same bytes: all games, all channel counts, batch sizes that do not fill a block."""
@@ -205,6 +208,7 @@ for game in ("breakout", "space_invaders", "amidar", "gridworld"):
     for n in (3, 130):
         g, o = Engine(game, n, lib=hip), Engine(game, n, lib=orc)
         for e in (g, o):
+            e.set_option(_abi.OPT_RENDER_SPLIT, SPLIT)
             e.seed(9); e.new_game()
         for t in range(260):
             a = synthetic_actions(game, n, t)
@@ -214,7 +218,7 @@ for game in ("breakout", "space_invaders", "amidar", "gridworld"):
                     assert np.array_equal(g.render(c), o.render(c)), (game, n, t, c)
         assert np.array_equal(g.render_env(n - 1, 3), o.render_env(n - 1, 3))
 """
-    _run_sub(body, {"TBX_RENDER_SPLIT": split, "TBX_BRK_SPLIT": split})
+    _run_sub(body.replace("SPLIT", str(split)), {})
 
 
 @pytest.mark.gpu
@@ -492,18 +496,21 @@ def test_step1_on_a_batch_engine(lib, oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("game,n", [("breakout", 40000), ("breakout", 3000), ("amidar", 20000)])
+@pytest.mark.parametrize("game,n,mode", [("breakout", 40000, 2), ("breakout", 40000, 3), ("breakout", 3000, 3), ("breakout", 3000, 1),
+                                         ("amidar", 20000, 3)])
 @pytest.mark.parametrize("same_stream", [True, False])
-def test_step_ahead_keeps_program_order(same_stream, game, n, hip_lib, oracle_lib, monkeypatch):
-    """tbx_step_synthetic on Breakout runs on the engine's step stream BESIDE the rasteriser launch queued before it (two record
-    buffers; Amidar, whose step stays serialised, walks the same call pattern as the control).  What the caller sees must stay program order: every frame is the frame of the step before it, device
-    buffers read behind the caller's stream are the step's, and calls of every other kind in between (state reads and writes,
-    new games, host-pointer steps and renders, a device-action step, a second render of one frame, two steps in a row) join
-    both streams.  Bench pattern, 40 000 envs so that a render launch is long enough to be overtaken."""
+def test_pipelined_mode_keeps_program_order(same_stream, game, n, mode, hip_lib, oracle_lib):
+    """TBX_OPT_PIPELINE: tbx_step_synthetic on Breakout runs on the engine's step stream BESIDE the rasteriser launch queued
+    before it (two buffers of records and of step outputs); with value 3 consecutive rasteriser launches alternate between two
+    internal streams and two frame buffers (Amidar, which ignores the option, walks the same call pattern as the control).
+    What the caller sees must stay program order: every frame is the frame of the step before it, device buffers read behind
+    the caller's stream are the step's, and calls of every other kind in between (state reads and writes, new games,
+    host-pointer steps and renders, a device-action step, a second render of one frame, two steps in a row) join the
+    pipeline.  Bench pattern; 40 000 envs so that a render launch is long enough to be overtaken."""
     from toybox_amd import hip
-    if n < 12288:
-        monkeypatch.setenv("TBX_STEP_AHEAD_MIN", "1")  # small batches run the step serialised by default
     g, o = _pair(game, n, hip_lib, oracle_lib, seed=31)
+    g.set_option(_abi.OPT_PIPELINE, mode)
+    assert g.get_option(_abi.OPT_PIPELINE) == mode
     s_step, s_render = hip.Stream(), hip.Stream()
     sp, rp = (s_render.ptr, s_render.ptr) if same_stream else (s_step.ptr, s_render.ptr)
     H, W = g.height, g.width
@@ -572,3 +579,87 @@ def test_step_ahead_keeps_program_order(same_stream, game, n, hip_lib, oracle_li
     _same_states(g, o, sample, "end")
     for x, y in zip(g.scalars(), o.scalars()):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_results_stay_valid_for_readers_queued_before_the_next_call(mode, hip_lib, oracle_lib):
+    """The stream-ordering contract of the TBX_BUF_* outputs, with and without the pipelined mode: device-side copies of
+    TBX_BUF_PACKED queued on the caller's stream right behind a step AND behind the render that follows it, and copies of frames
+    queued behind the render -- nothing synchronised until the very end, so in pipelined mode the next step (beside the render)
+    and the next render (on the other internal stream) are in flight while the copies still wait their turn."""
+    from toybox_amd import hip
+    from toybox_amd.parallel import pack_records
+    n, T, game = 40000, 16, "breakout"
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=8)
+    g.set_option(_abi.OPT_PIPELINE, mode)
+    H, W = g.height, g.width
+    fb = H * W * 3
+    sample = [0, 1, n // 2, n - 1]
+    s = hip.Stream()
+    c1, c2, cf = hip.malloc(8 * n * T), hip.malloc(8 * n * T), hip.malloc(fb * len(sample) * T)
+    want = []
+    for t in range(T):
+        g.step_synthetic(1337, t, auto_reset=True, stream=s.ptr)
+        p, _ = g.device_buffer(_abi.BUF_PACKED)
+        hip.memcpy_dtod_async(c1 + 8 * n * t, p, 8 * n, s)
+        g.render_device(0, 3, stream=s.ptr)
+        assert g.device_buffer(_abi.BUF_PACKED)[0] == p          # a render does not move the step outputs
+        hip.memcpy_dtod_async(c2 + 8 * n * t, p, 8 * n, s)
+        f, _ = g.device_buffer(_abi.BUF_FRAME)
+        for k, i in enumerate(sample):
+            hip.memcpy_dtod_async(cf + fb * (len(sample) * t + k), f + fb * i, fb, s)
+        ro = o.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
+        want.append((pack_records(ro[0], ro[1], ro[2]), [o.render_env(i, 3) for i in sample]))
+    s.synchronize()
+    got, one = np.empty(n, np.uint64), np.empty((H, W, 3), np.uint8)
+    for t in range(T):
+        for c in (c1, c2):
+            hip.memcpy_dtoh(got, c + 8 * n * t, 8 * n)
+            assert np.array_equal(got, want[t][0]), (mode, t)
+        for k in range(len(sample)):
+            hip.memcpy_dtoh(one, cf + fb * (len(sample) * t + k), fb)
+            assert np.array_equal(one, want[t][1][k]), (mode, t, k)
+    for c in (c1, c2, cf):
+        hip.free(c)
+    g.sync()
+    _same_states(g, o, sample, "end")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 3])
+def test_a_caller_stream_destroyed_between_calls_is_tolerated(mode, hip_lib, oracle_lib):
+    """The library remembers the stream of the last call to order the next one behind it.  A caller may create a stream for one
+    pair of calls, synchronise and destroy it: the next call on the handle (on another stream, or a host-pointer call) must
+    neither fail nor lose its place in program order."""
+    from toybox_amd import hip
+    game, n = "breakout", 2048
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=3)
+    g.set_option(_abi.OPT_PIPELINE, mode)
+    for t in range(12):
+        s = hip.Stream()
+        g.step_synthetic(1337, t, auto_reset=True, stream=s.ptr)
+        g.render_device(0, 3, stream=s.ptr)
+        if t % 3:
+            s.synchronize()
+        s.close()
+        o.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
+        if t % 2:
+            for x, y in zip(g.scalars(), o.scalars()):
+                assert np.array_equal(x, y), t
+        if t % 4 == 3:
+            assert np.array_equal(g.render_env(t, 3), o.render_env(t, 3))
+    _same_states(g, o, range(0, n, 97), "end")
+
+
+@pytest.mark.gpu
+def test_options_are_validated_and_reported(hip_lib, oracle_lib):
+    for lib in (hip_lib, oracle_lib):
+        e = Engine("amidar", 8, lib=lib)
+        assert [e.get_option(k) for k in range(5)] == [0, 0, 0, 0, 1]
+        e.set_option(_abi.OPT_RENDER_SPLIT, 7)
+        assert e.get_option(_abi.OPT_RENDER_SPLIT) == 7
+        for opt, val in ((_abi.OPT_PIPELINE, 4), (_abi.OPT_STEP_FORM, 3), (_abi.OPT_RENDER_SPLIT, -1), (99, 0), (_abi.OPT_AGENT_GENERIC, 2)):
+            with pytest.raises(ToyboxAmdError):
+                e.set_option(opt, val)
+        e.close()

@@ -238,15 +238,14 @@ def test_gpu_fused_preprocessing_parity(game, hip_lib, oracle_lib):
 @pytest.mark.parametrize("game,skip,oh,ow,stack", [("breakout", 4, 84, 84, 4), ("space_invaders", 4, 84, 84, 4), ("amidar", 4, 84, 84, 4),
                                                   ("space_invaders", 3, 60, 100, 2), ("amidar", 2, 50, 40, 3), ("amidar", 1, 84, 84, 4),
                                                   ("gridworld", 4, 84, 84, 4), ("gridworld", 2, 64, 80, 1)])
-def test_gpu_fused_observation_equals_generic_path(game, skip, oh, ow, stack, hip_lib, monkeypatch):
+def test_gpu_fused_observation_equals_generic_path(game, skip, oh, ow, stack, hip_lib):
     """The per-game fused observation kernels (Breakout: from render records; SpaceInvaders / Amidar: two painters per wave
     with class-diff scanline skipping; no full-resolution frames) == the generic render + warp path, through episode ends."""
     n = 512
-    monkeypatch.setenv("TBX_AGENT_GENERIC", "1")
     gen = Engine(game, n, lib=hip_lib)
+    gen.set_option(_abi.OPT_AGENT_GENERIC, 1)
     gen.seed(77)
     gen.agent_init(skip=skip, out_h=oh, out_w=ow, stack=stack, clip_reward=False)
-    monkeypatch.setenv("TBX_AGENT_GENERIC", "0")
     fus = Engine(game, n, lib=hip_lib)
     fus.seed(77)
     fus.agent_init(skip=skip, out_h=oh, out_w=ow, stack=stack, clip_reward=False)
@@ -504,13 +503,10 @@ def test_gpu_agent_pipeline_with_stress_configs(game, hip_lib, oracle_lib):
     n = 128
     cfg = _stress_config(game, oracle_lib)
     g, o = Engine(game, n, lib=hip_lib, config=cfg), Engine(game, n, lib=oracle_lib, config=cfg)
-    os.environ["TBX_AGENT_GENERIC"] = "1"
-    try:
-        gen = Engine(game, n, lib=hip_lib, config=cfg)
-        gen.seed(3)
-        gen.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=False, episodic_life=True, fire_reset=True, noop_max=8)
-    finally:
-        os.environ["TBX_AGENT_GENERIC"] = "0"
+    gen = Engine(game, n, lib=hip_lib, config=cfg)
+    gen.set_option(_abi.OPT_AGENT_GENERIC, 1)
+    gen.seed(3)
+    gen.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=False, episodic_life=True, fire_reset=True, noop_max=8)
     for e in (g, o):
         e.seed(3)
         e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=False, episodic_life=True, fire_reset=True, noop_max=8)

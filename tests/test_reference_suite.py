@@ -24,9 +24,14 @@ def _env():
 
 
 def test_reference_intervention_suite(oracle_lib):
-    p = subprocess.run([sys.executable, "-m", "unittest", "discover", "-s", os.path.join(REF, "test", "interventions"),
-                        "-t", REF], cwd="/tmp", env=_env(), capture_output=True, text=True, timeout=900)
-    tail = (p.stdout + p.stderr)[-3000:]
+    for attempt in range(2):
+        p = subprocess.run([sys.executable, "-m", "unittest", "discover", "-s", os.path.join(REF, "test", "interventions"),
+                            "-t", REF], cwd="/tmp", env=_env(), capture_output=True, text=True, timeout=900)
+        tail = (p.stdout + p.stderr)[-3000:]
+        # the reference's test_random_starts draws an unseeded random tile (interventions/amidar.py:373-375) and fails when it
+        # draws the player's own: one in 992 runs.  Only that one failure is retried.
+        if p.returncode == 0 or "failures=1" not in tail or "FAIL: test_random_starts" not in tail:
+            break
     assert p.returncode == 0, tail
     assert "Ran 34 tests" in tail and "OK" in tail, tail
 

@@ -23,6 +23,10 @@ BUF_AGENT_OBS, BUF_AGENT_REWARD, BUF_AGENT_DONE = 6, 7, 8
 BUF_AGENT_EP_DONE, BUF_AGENT_EP_RETURN, BUF_AGENT_EP_LENGTH = 9, 10, 11
 BUF_GATHERED = 12
 GATHER_ID_BYTES = 128
+# engine options (tbx_set_option)
+OPT_PIPELINE, OPT_STEP_FORM, OPT_RENDER_SPLIT, OPT_AGENT_GENERIC, OPT_RESIDENT_STEP = 0, 1, 2, 3, 4
+PIPELINE_OFF, PIPELINE_AUTO, PIPELINE_STEP_BESIDE_RENDER, PIPELINE_OVERLAP_RENDERS = 0, 1, 2, 3
+STEP_FORM_AUTO, STEP_FORM_THREAD_PER_ENV, STEP_FORM_WAVE_PER_ENV = 0, 1, 2
 
 BRK_MAX_BALLS, BRK_COLS, BRK_MAX_ROWS, BRK_MAX_BRICKS, BRK_MAX_STARTS, BRK_MAX_SEGMENTS = 4, 18, 14, 256, 8, 16
 
@@ -275,7 +279,11 @@ PROTOTYPES = {
     "tbx_gather_wait": (_i, [_vp, _vp]),
     "tbx_gather_host": (_i, [_vp, _vp]),
     "tbx_gather_reduce_max": (_i, [_vp, _p(C.c_double)]),
+    "tbx_gather_nranks": (_i, [_vp]),
+    "tbx_gather_library": (C.c_char_p, [_vp]),
     "tbx_device_buffer": (_i, [_vp, _i, _p(_vp), _p(_sz)]),
+    "tbx_set_option": (_i, [_vp, _i, _i]),
+    "tbx_get_option": (_i, [_vp, _i, _p(_i)]),
     "tbx_sync": (_i, [_vp]),
 }
 

@@ -389,12 +389,16 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     if ((H + cfg->out_h - 1) / cfg->out_h + 1 > MAX_TAPS || (W + cfg->out_w - 1) / cfg->out_w + 1 > MAX_TAPS)
         return e->fail(TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
     AHIP(hipSetDevice(e->device));
+    // nothing of this handle may be in flight while the agent layer's buffers are freed and made anew: not a queued kernel,
+    // not the resident step kernel of tbx_step1 (tbx_use_stream stops it)
+    AHIP(tbx_use_stream(e, e->stream));
+    AHIP(hipStreamSynchronize(e->stream));
     tbx_agent_free(e);
     AgentState* a = new AgentState();
     e->agent = a;
     a->cfg = *cfg;
     a->H = H; a->W = W;
-    if (const char* v = getenv("TBX_AGENT_GENERIC")) a->force_generic = atoi(v) != 0;
+    a->force_generic = e->opt[TBX_OPT_AGENT_GENERIC] != 0;
     const size_t N = (size_t)e->n;
     if (a->force_generic || !e->ops->agent_fused()) {
         AHIP(hipMalloc((void**)&a->gray_a, N * H * W));

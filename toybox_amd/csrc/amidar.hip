@@ -1787,12 +1787,11 @@ struct AmiOps : GameOps {
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         dA.tab = dB.tab = d.tab;
-        // TBX_AMI_STEP_TPE: 0 = never, 1 = always, unset = by batch size.  The thread form is one wave per 64 envs with a long
+        // TBX_OPT_STEP_FORM: 2 = never, 1 = always, 0 = by batch size.  The thread form is one wave per 64 envs with a long
         // serial path per thread (~40 us whatever the batch), the wave form scales with the batch (~28 us at 12 288 envs, ~14 us
         // at 4 096): below ~16 k envs the wave form is the faster one (measured)
-        static const int tpe_mode = getenv("TBX_AMI_STEP_TPE") ? atoi(getenv("TBX_AMI_STEP_TPE")) : -1;
-        static const int tpe_min = getenv("TBX_AMI_STEP_TPE_MIN") ? atoi(getenv("TBX_AMI_STEP_TPE_MIN")) : 16384;
-        const bool use_tpe = tpe_mode == 0 ? false : tpe_mode == 1 ? true : e->n >= tpe_min;
+        const int form = e->opt[TBX_OPT_STEP_FORM];
+        const bool use_tpe = form == 2 ? false : form == 1 ? true : e->n >= 16384;
         if (use_tpe && src.single_env < 0) {
             // large batches: one THREAD per env (the wave-per-env form stays for small batches, single-env calls and the
             // in-kernel reset procedure)
@@ -1886,9 +1885,9 @@ struct AmiOps : GameOps {
     int render_impl(tbx_engine* e, const AmiDev& src, const AmiDev& alt, const uint8_t* pick_alt, uint8_t* out_dev, int channels, int first_env,
                     int n_envs, hipStream_t s)
     {
-        static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
+        const int split_env = e->opt[TBX_OPT_RENDER_SPLIT];
         // RGB: nine waves per frame (2-3 of the 25 units each) measured 5.45-5.55 TB/s against 4.9 for one wave per frame;
-        // gray and RGBA show no such effect (scripts/ab_render.py with TBX_RENDER_SPLIT)
+        // gray and RGBA show no such effect (scripts/ab_render.py over TBX_OPT_RENDER_SPLIT)
         const int split = split_env > 0 ? split_env : channels == 3 ? 9 : 1;
         switch (channels) {
         case 1: if (pick_alt) hipLaunchKernelGGL((ami_render_kernel<1, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((ami_render_kernel<1, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;

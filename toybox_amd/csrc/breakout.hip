@@ -1508,7 +1508,7 @@ struct BreakoutOps : GameOps {
         int rc = load_cfg(e, k);
         if (rc) return rc;
         const size_t N = (size_t)e->n;
-        if (const char* v = getenv("TBX_BRK_STEP_TPE")) use_tpe = atoi(v) != 0;
+        options_changed(e);
         d.n = e->n;
         d.sim_rng = e->sim_rng; d.prev_score = e->prev_score; d.reward = e->reward; d.done = e->done;
         d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed; d.err_flag = e->err_flag;
@@ -1581,14 +1581,16 @@ struct BreakoutOps : GameOps {
     }
 
     // the rasteriser reads nothing but the records, and there are two buffers of them: a batch step of the canonical wall
-    // can run while the previous frame is still being painted (engine.hip, tbx_step_ahead)
-    // (from 12 288 envs up: at 16 384 envs the overlapped loop measured 49.5 against 45.4 M env-steps/s, at 8 192 envs the
-    // same, at 4 096 envs 37.3 against 39.7 -- a ~100 us step leaves no room for the extra event calls)
-    bool step_ahead_ok() const override
+    // can run while the previous frame is still being painted (engine.hip, pipelined mode)
+    bool pipeline_ok() const override { return !custom && use_tpe && recs_other != nullptr; }
+    void rebind_outputs(tbx_engine* e) override
     {
-        const char* v = getenv("TBX_STEP_AHEAD_MIN");       // (read per call: the tests move it)
-        const int min_n = v ? atoi(v) : 12288;
-        return !custom && use_tpe && recs_other != nullptr && d.n >= min_n;
+        d.reward = e->reward; d.done = e->done; d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed;
+    }
+    void options_changed(tbx_engine* e) override
+    {
+        use_tpe = e->opt[TBX_OPT_STEP_FORM] != 2;     // thread per env unless the wave-per-env kernel is asked for
+        split_opt = e->opt[TBX_OPT_RENDER_SPLIT];
     }
     int records_parity() const override { return recs_par; }
     int step_ahead(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
@@ -1611,7 +1613,8 @@ struct BreakoutOps : GameOps {
         return TBX_OK;
     }
 
-    bool use_tpe = true;            // thread-per-env step for the canonical wall (TBX_BRK_STEP_TPE=0 keeps the wave kernel)
+    bool use_tpe = true;            // thread-per-env step for the canonical wall (TBX_OPT_STEP_FORM = 2 keeps the wave kernel)
+    int split_opt = 0;              // TBX_OPT_RENDER_SPLIT
 
     template <int C>
     void launch_render(uint8_t* out, int first, int count, hipStream_t s, const BrkRenderRec* src_recs = nullptr,
@@ -1627,9 +1630,8 @@ struct BreakoutOps : GameOps {
         const BrkRenderRec* rr = src_recs ? src_recs : recs;
         // ten waves per frame, each doing unit p and unit p + 10 (one from the busy upper half of the screen, one from the
         // lower): measured 6.05-6.25 TB/s against 5.4-5.7 for one wave per frame and for every other split from 1 to 20
-        // except 9..12 (scripts/ab_render.py with TBX_BRK_SPLIT); also what keeps small batches from under-filling the chip
-        static const int split_env = getenv("TBX_BRK_SPLIT") ? atoi(getenv("TBX_BRK_SPLIT")) : 0;
-        const int split = split_env > 0 ? split_env : C == 3 ? 10 : count <= 8192 ? 4 : count <= 32768 ? 2 : 1;   // gray / RGBA: no such effect
+        // except 9..12 (scripts/ab_render.py over TBX_OPT_RENDER_SPLIT); also what keeps small batches from under-filling the chip
+        const int split = split_opt > 0 ? split_opt : C == 3 ? 10 : count <= 8192 ? 4 : count <= 32768 ? 2 : 1;   // gray / RGBA: no such effect
         if (pick_alt) {        // the agent layer's generic path: per-env choice between two record arrays
             if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true, true>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
             else hipLaunchKernelGGL((brk_render_kernel<C, false, true>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);

@@ -22,6 +22,17 @@ thread_local std::string g_create_error;
 
 void tbx_set_create_error(const std::string& msg) { g_create_error = msg; }
 
+void tbx_set_out_parity(tbx_engine* e, int p)
+{
+    e->out_par = p;
+    e->reward = e->outs[p].reward;
+    e->done = e->outs[p].done;
+    e->lives_out = e->outs[p].lives;
+    e->score_out = e->outs[p].score;
+    e->packed = e->outs[p].packed;
+    if (e->ops) e->ops->rebind_outputs(e);
+}
+
 namespace {
 
 int hip_fail(tbx_engine* e, const char* what, hipError_t err)
@@ -186,12 +197,15 @@ __global__ void fill_rng_kernel(uint64_t* sim_rng, int n, uint64_t s0, uint64_t 
 
 int ensure_frame(tbx_engine* e, size_t bytes)
 {
-    if (e->frame_bytes >= bytes) return TBX_OK;
-    if (e->frame) hipFree(e->frame);
-    e->frame = nullptr;
-    e->frame_bytes = 0;
-    EHIP(hipMalloc((void**)&e->frame, bytes));
-    e->frame_bytes = bytes;
+    if (e->frame_own_bytes < bytes) {
+        if (e->frame_own) hipFree(e->frame_own);
+        e->frame_own = nullptr;
+        e->frame_own_bytes = 0;
+        EHIP(hipMalloc((void**)&e->frame_own, bytes));
+        e->frame_own_bytes = bytes;
+    }
+    e->frame = e->frame_own;
+    e->frame_bytes = e->frame_own_bytes;
     return TBX_OK;
 }
 
@@ -273,20 +287,29 @@ int tbx_destroy(tbx_engine* e)
     if (e->serve_stream) hipStreamDestroy(e->serve_stream);
     if (e->serve_ctl) hipHostFree(e->serve_ctl);
     if (e->stream) hipStreamSynchronize(e->stream);
-    if (e->step_stream) hipStreamSynchronize(e->step_stream);
+    TbxPipe& pp = e->pipe;
+    if (pp.step_stream) hipStreamSynchronize(pp.step_stream);
+    for (int k = 0; k < 2; k++)
+        if (pp.render_stream[k]) hipStreamSynchronize(pp.render_stream[k]);
     tbx_gather_free(e);
     tbx_agent_free(e);
     if (e->ops) { e->ops->destroy(e); delete e->ops; }
-    hipFree(e->sim_rng); hipFree(e->prev_score); hipFree(e->reward); hipFree(e->done);
-    hipFree(e->lives_out); hipFree(e->score_out); hipFree(e->packed); hipFree(e->actions);
-    hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame); hipFree(e->staging); hipFree(e->scal); hipFree(e->one_frame); hipFree(e->io_dev);
+    hipFree(e->sim_rng); hipFree(e->prev_score);
+    for (int k = 0; k < 2; k++) {
+        hipFree(e->outs[k].reward); hipFree(e->outs[k].done); hipFree(e->outs[k].lives); hipFree(e->outs[k].score); hipFree(e->outs[k].packed);
+        hipFree(pp.frame[k]);
+        if (pp.render_ev[k]) hipEventDestroy(pp.render_ev[k]);
+        if (pp.user_step_ev[k]) hipEventDestroy(pp.user_step_ev[k]);
+        if (pp.user_frame_ev[k]) hipEventDestroy(pp.user_frame_ev[k]);
+        if (pp.render_stream[k]) hipStreamDestroy(pp.render_stream[k]);
+    }
+    hipFree(e->actions);
+    hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame_own); hipFree(e->staging); hipFree(e->scal); hipFree(e->one_frame); hipFree(e->io_dev);
     if (e->io_host) hipHostFree(e->io_host);
     if (e->scal_host) hipHostFree(e->scal_host);
     if (e->order_ev) hipEventDestroy(e->order_ev);
-    if (e->step_ev) hipEventDestroy(e->step_ev);
-    for (int p = 0; p < 2; p++)
-        if (e->render_ev[p]) hipEventDestroy(e->render_ev[p]);
-    if (e->step_stream) hipStreamDestroy(e->step_stream);
+    if (pp.step_ev) hipEventDestroy(pp.step_ev);
+    if (pp.step_stream) hipStreamDestroy(pp.step_stream);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return TBX_OK;
@@ -339,11 +362,12 @@ int tbx_create(int game, int n_envs, int device, const void* config_pod, size_t 
     CHIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     CHIP(hipMalloc((void**)&e->sim_rng, 2 * N * sizeof(uint64_t)));
     CHIP(hipMalloc((void**)&e->prev_score, N * sizeof(int32_t)));
-    CHIP(hipMalloc((void**)&e->reward, N * sizeof(int32_t)));
-    CHIP(hipMalloc((void**)&e->done, N));
-    CHIP(hipMalloc((void**)&e->lives_out, N * sizeof(int32_t)));
-    CHIP(hipMalloc((void**)&e->score_out, N * sizeof(int32_t)));
-    CHIP(hipMalloc((void**)&e->packed, N * sizeof(uint64_t)));
+    CHIP(hipMalloc((void**)&e->outs[0].reward, N * sizeof(int32_t)));
+    CHIP(hipMalloc((void**)&e->outs[0].done, N));
+    CHIP(hipMalloc((void**)&e->outs[0].lives, N * sizeof(int32_t)));
+    CHIP(hipMalloc((void**)&e->outs[0].score, N * sizeof(int32_t)));
+    CHIP(hipMalloc((void**)&e->outs[0].packed, N * sizeof(uint64_t)));
+    tbx_set_out_parity(e, 0);
     CHIP(hipMalloc((void**)&e->actions, N * sizeof(int32_t)));
     CHIP(hipMalloc((void**)&e->mask, N));
     CHIP(hipMalloc((void**)&e->err_flag, sizeof(uint32_t)));
@@ -471,45 +495,147 @@ int tbx_step_device(tbx_engine* e, const int32_t* actions_dev, uint32_t flags, v
     return e->ops->step(e, src, flags, (hipStream_t)stream);
 }
 
+// ---- pipelined mode (TBX_OPT_PIPELINE; contract in include/toybox_amd.h)
+//
 // A step with in-kernel actions depends on nothing the previous frame's rasteriser produces, and for games whose rasteriser
-// reads double-buffered records (GameOps::step_ahead_ok) it disturbs nothing that rasteriser reads: it runs on the engine's
-// step stream BESIDE the render queued before it.  Measured on MI355X (scripts/interleave_probe.py): a 10 us step kernel
-// serialised between two 1.19 ms Breakout render launches costs 0.04-0.22 ms depending on the box, run beside the render it
-// costs 0.01-0.04 ms.  Program order is kept: the step waits for the previous step (same stream), for the render that read
-// the records buffer it rewrites, and -- the first time after any other call -- for everything; the caller's stream waits
-// for the step, so whatever the caller queues next (the render of this frame, a buffer read) sees it.
-static int tbx_step_ahead(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t user)
+// reads step-written records (GameOps::pipeline_ok) it disturbs nothing that rasteriser reads once there are two buffers of
+// records and of step outputs: it runs on the engine's step stream BESIDE the render queued before it.  Measured on MI355X
+// (scripts/interleave_probe.py): a 10 us step kernel serialised between two 1.19 ms Breakout render launches costs
+// 0.04-0.22 ms depending on the box, run beside the render it costs 0.01-0.04 ms.  With value 3 consecutive renders into the
+// engine-owned frame buffer alternate between two internal streams and two buffers as well, so that launch N+1 ramps up in
+// the ramp-down of launch N.
+//
+// Who waits for whom (p = buffer parity; the stream the caller names is U):
+//   step N+1 (step stream, writes records / outputs p')   <- step N (same stream), the render that read records p',
+//                                                             U's readers of outputs p' (fence recorded on U at step N's
+//                                                             call), the gather that read outputs p'
+//   render N (U, or render stream f for frame buffer f)   <- step N (U waits for every step; step_ev on a render stream),
+//                                                             render N-2 (same stream), U's readers of frame buffer f
+//                                                             (fence recorded on U at render N-1's call)
+//   U                                                      <- every step and every overlapped render (so whatever the caller
+//                                                             queues next sees them, and U is the tail other calls join)
+static int pipe_mode(const tbx_engine* e)
 {
+    const int v = e->opt[TBX_OPT_PIPELINE];
+    if (v == 0 || !e->ops->pipeline_ok()) return 0;
+    if (v == 1) return e->n >= 16384 ? 2 : 3;
+    return v;
+}
+
+static int pipe_prepare(tbx_engine* e)
+{
+    TbxPipe& p = e->pipe;
+    if (p.step_stream) return TBX_OK;
+    const size_t N = (size_t)e->n;
+    EHIP(hipMalloc((void**)&e->outs[1].reward, N * sizeof(int32_t)));
+    EHIP(hipMalloc((void**)&e->outs[1].done, N));
+    EHIP(hipMalloc((void**)&e->outs[1].lives, N * sizeof(int32_t)));
+    EHIP(hipMalloc((void**)&e->outs[1].score, N * sizeof(int32_t)));
+    EHIP(hipMalloc((void**)&e->outs[1].packed, N * sizeof(uint64_t)));
+    EHIP(hipMemset(e->outs[1].reward, 0, N * sizeof(int32_t)));
+    EHIP(hipMemset(e->outs[1].done, 0, N));
+    EHIP(hipMemset(e->outs[1].lives, 0, N * sizeof(int32_t)));
+    EHIP(hipMemset(e->outs[1].score, 0, N * sizeof(int32_t)));
+    EHIP(hipMemset(e->outs[1].packed, 0, N * sizeof(uint64_t)));
+    EHIP(hipEventCreateWithFlags(&p.step_ev, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) {
+        EHIP(hipStreamCreateWithFlags(&p.render_stream[k], hipStreamNonBlocking));
+        EHIP(hipEventCreateWithFlags(&p.render_ev[k], hipEventDisableTiming));
+        EHIP(hipEventCreateWithFlags(&p.user_step_ev[k], hipEventDisableTiming));
+        EHIP(hipEventCreateWithFlags(&p.user_frame_ev[k], hipEventDisableTiming));
+    }
+    EHIP(hipStreamCreateWithFlags(&p.step_stream, hipStreamNonBlocking));
+    return TBX_OK;
+}
+
+// the first pipelined call after a call of any other kind: every internal stream behind all that came before
+static int pipe_enter(tbx_engine* e)
+{
+    TbxPipe& p = e->pipe;
+    if (p.active) return TBX_OK;
     if (e->serve_running) EHIP(tbx_serve_stop(e));
-    if (!e->step_stream) {
-        EHIP(hipStreamCreateWithFlags(&e->step_stream, hipStreamNonBlocking));
-        EHIP(hipEventCreateWithFlags(&e->step_ev, hipEventDisableTiming));
-        EHIP(hipEventCreateWithFlags(&e->render_ev[0], hipEventDisableTiming));
-        EHIP(hipEventCreateWithFlags(&e->render_ev[1], hipEventDisableTiming));
-    }
-    hipStream_t ss = e->step_stream;
-    const bool beside = !e->step_needs_join && e->has_last && (e->last_op_readonly || e->last_stream == ss);
-    if (!beside) {                                   // ordered behind everything, like any other call
-        if (e->has_last && e->last_stream != ss) {
-            if (!e->order_ev) EHIP(hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming));
-            EHIP(hipEventRecord(e->order_ev, e->last_stream));
-            EHIP(hipStreamWaitEvent(ss, e->order_ev, 0));
-        }
-        for (int p = 0; p < 2; p++)
-            if (e->render_pending[p]) { EHIP(hipStreamWaitEvent(ss, e->render_ev[p], 0)); e->render_pending[p] = false; }
-    } else {                                         // beside the last render: only the reader of the buffer about to be rewritten
-        const int wp = e->ops->records_parity() ^ 1;
-        if (e->render_pending[wp]) { EHIP(hipStreamWaitEvent(ss, e->render_ev[wp], 0)); e->render_pending[wp] = false; }
-    }
-    EHIP(tbx_gather_before_step(e, ss));
-    int rc = e->ops->step_ahead(e, src, flags, ss);
+    int rc = pipe_prepare(e);
     if (rc) return rc;
-    EHIP(hipEventRecord(e->step_ev, ss));
-    EHIP(hipStreamWaitEvent(user, e->step_ev, 0));
-    e->last_stream = ss;
+    EHIP(tbx_wait_tail(e, p.step_stream));
+    EHIP(tbx_wait_tail(e, p.render_stream[0]));
+    EHIP(tbx_wait_tail(e, p.render_stream[1]));
+    for (int k = 0; k < 2; k++) p.render_pending[k] = p.user_step_rec[k] = p.user_frame_rec[k] = false;
+    p.step_outstanding = false;
+    p.active = true;
+    return TBX_OK;
+}
+
+static int pipe_step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t user)
+{
+    int rc = pipe_enter(e);
+    if (rc) return rc;
+    TbxPipe& p = e->pipe;
+    hipStream_t ss = p.step_stream;
+    const int cur = e->out_par, wp = cur ^ 1;                  // this step writes output set wp ...
+    const int rw = e->ops->records_parity() ^ 1;               // ... and records buffer rw
+    if (p.render_pending[rw]) { EHIP(hipStreamWaitEvent(ss, p.render_ev[rw], 0)); p.render_pending[rw] = false; }
+    if (p.user_step_rec[wp]) { EHIP(hipStreamWaitEvent(ss, p.user_step_ev[wp], 0)); p.user_step_rec[wp] = false; }
+    // whatever the caller has queued so far may read the current outputs: the step after this one waits for it
+    EHIP(hipEventRecord(p.user_step_ev[cur], user));
+    p.user_step_rec[cur] = true;
+    tbx_set_out_parity(e, wp);
+    EHIP(tbx_gather_before_step(e, ss));
+    rc = e->ops->step_ahead(e, src, flags, ss);
+    if (rc) return rc;
+    EHIP(hipEventRecord(p.step_ev, ss));
+    EHIP(hipStreamWaitEvent(user, p.step_ev, 0));
+    p.step_outstanding = true;
+    e->last_stream = user;
     e->has_last = true;
-    e->last_op_readonly = false;
-    e->step_needs_join = false;
+    return TBX_OK;
+}
+
+static int pipe_render(tbx_engine* e, uint8_t* out_dev, int channels, hipStream_t user, int mode)
+{
+    int rc = pipe_enter(e);
+    if (rc) return rc;
+    TbxPipe& p = e->pipe;
+    const int rp = e->ops->records_parity();
+    const bool overlap = mode == 3 && out_dev == nullptr;
+    const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
+    hipStream_t rs = user;                                     // (U already waits for the step: pipe_step made it)
+    int fp = p.frame_par;
+    if (overlap) {
+        fp ^= 1;
+        rs = p.render_stream[fp];
+        if (p.frame_bytes[fp] < bytes) {
+            EHIP(hipStreamSynchronize(rs));
+            if (p.frame[fp]) hipFree(p.frame[fp]);
+            p.frame[fp] = nullptr;
+            p.frame_bytes[fp] = 0;
+            EHIP(hipMalloc((void**)&p.frame[fp], bytes));
+            p.frame_bytes[fp] = bytes;
+        }
+        if (p.step_outstanding) EHIP(hipStreamWaitEvent(rs, p.step_ev, 0));
+        if (p.user_frame_rec[fp]) { EHIP(hipStreamWaitEvent(rs, p.user_frame_ev[fp], 0)); p.user_frame_rec[fp] = false; }
+        // readers of the frame the previous render wrote, queued so far: the render after this one waits for them
+        EHIP(hipEventRecord(p.user_frame_ev[p.frame_par], user));
+        p.user_frame_rec[p.frame_par] = true;
+        out_dev = p.frame[fp];
+    } else if (!out_dev) {
+        rc = ensure_frame(e, bytes);
+        if (rc) return rc;
+        out_dev = e->frame;
+    }
+    if (((uintptr_t)out_dev & 15u) != 0) return e->fail(TBX_E_INVALID, "frame buffer must be 16-byte aligned");
+    if (p.render_pending[rp]) EHIP(hipStreamWaitEvent(rs, p.render_ev[rp], 0));    // (another render of the same records)
+    rc = e->ops->render(e, out_dev, channels, 0, e->n, rs);
+    if (rc) return rc;
+    EHIP(hipEventRecord(p.render_ev[rp], rs));
+    p.render_pending[rp] = true;
+    if (overlap) {
+        EHIP(hipStreamWaitEvent(user, p.render_ev[rp], 0));
+        p.frame_par = fp;
+        e->frame = p.frame[fp];
+        e->frame_bytes = p.frame_bytes[fp];
+    }
+    e->last_stream = user;
+    e->has_last = true;
     return TBX_OK;
 }
 
@@ -523,8 +649,7 @@ int tbx_step_synthetic(tbx_engine* e, uint64_t action_seed, uint64_t t, uint64_t
     src.t = t;
     src.env_offset = env_offset;
     src.single_env = -1;
-    static const bool no_ahead = getenv("TBX_NO_STEP_AHEAD") != nullptr;
-    if (!no_ahead && e->ops->step_ahead_ok()) return tbx_step_ahead(e, src, flags, (hipStream_t)stream);
+    if (pipe_mode(e)) return pipe_step(e, src, flags, (hipStream_t)stream);
     EHIP(tbx_use_stream(e, (hipStream_t)stream));
     EHIP(tbx_gather_before_step(e, (hipStream_t)stream));
     return e->ops->step(e, src, flags, (hipStream_t)stream);
@@ -608,8 +733,7 @@ int tbx_step1(tbx_engine* e, int env, int32_t ale_action, uint32_t flags, int32_
     CHECK_ENGINE(e);
     if (env < 0 || env >= e->n) return e->fail(TBX_E_INVALID, "env index out of range");
     EHIP(hipSetDevice(e->device));
-    static const bool no_server = getenv("TBX_NO_SERVER") != nullptr;
-    if (e->n == 1 && !no_server && !e->gather) {
+    if (e->n == 1 && e->opt[TBX_OPT_RESIDENT_STEP] && !e->gather) {
         // the resident kernel: post the request, spin on the acknowledgement (no launch, no copy, no synchronisation)
         TbxServeCtl* c = e->serve_ctl;
         if (!e->serve_running || __atomic_load_n(&c->exited, __ATOMIC_ACQUIRE)) {
@@ -723,8 +847,8 @@ int tbx_render_device(tbx_engine* e, uint8_t* out_dev, int channels, void* strea
     CHECK_ENGINE(e);
     if (channels != 1 && channels != 3 && channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
     EHIP(hipSetDevice(e->device));
-    const bool ahead = e->ops->step_ahead_ok() && e->step_stream;      // (the step stream exists once a step has run ahead)
-    EHIP(tbx_use_stream(e, (hipStream_t)stream, /*readonly=*/ahead));
+    if (const int mode = pipe_mode(e)) return pipe_render(e, out_dev, channels, (hipStream_t)stream, mode);
+    EHIP(tbx_use_stream(e, (hipStream_t)stream));
     if (!out_dev) {
         const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
         int rc = ensure_frame(e, bytes);
@@ -732,14 +856,7 @@ int tbx_render_device(tbx_engine* e, uint8_t* out_dev, int channels, void* strea
         out_dev = e->frame;
     }
     if (((uintptr_t)out_dev & 15u) != 0) return e->fail(TBX_E_INVALID, "frame buffer must be 16-byte aligned");
-    const int parity = e->ops->records_parity();
-    int rc = e->ops->render(e, out_dev, channels, 0, e->n, (hipStream_t)stream);
-    if (rc) return rc;
-    if (ahead) {                                     // the next step ahead must not rewrite these records before they are read
-        EHIP(hipEventRecord(e->render_ev[parity], (hipStream_t)stream));
-        e->render_pending[parity] = true;
-    }
-    return TBX_OK;
+    return e->ops->render(e, out_dev, channels, 0, e->n, (hipStream_t)stream);
 }
 
 int tbx_render(tbx_engine* e, uint8_t* out_host, int channels)
@@ -900,12 +1017,44 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     return TBX_OK;
 }
 
+int tbx_set_option(tbx_engine* e, int option, int value)
+{
+    CHECK_ENGINE(e);
+    bool ok = false;
+    switch (option) {
+    case TBX_OPT_PIPELINE: ok = value >= 0 && value <= 3; break;
+    case TBX_OPT_STEP_FORM: ok = value >= 0 && value <= 2; break;
+    case TBX_OPT_RENDER_SPLIT: ok = value >= 0 && value <= 64; break;
+    case TBX_OPT_AGENT_GENERIC: case TBX_OPT_RESIDENT_STEP: ok = value == 0 || value == 1; break;
+    default: return e->fail(TBX_E_INVALID, "unknown option");
+    }
+    if (!ok) return e->fail(TBX_E_INVALID, "option value out of range");
+    if (e->opt[option] == value) return TBX_OK;
+    // a launch-time choice must not change under work that is in flight
+    EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
+    EHIP(hipStreamSynchronize(e->stream));
+    e->opt[option] = value;
+    e->ops->options_changed(e);
+    return TBX_OK;
+}
+
+int tbx_get_option(tbx_engine* e, int option, int* value_out)
+{
+    CHECK_ENGINE(e);
+    if (option < 0 || option >= TBX_OPT_COUNT || !value_out) return e->fail(TBX_E_INVALID, "unknown option");
+    *value_out = e->opt[option];
+    return TBX_OK;
+}
+
 int tbx_sync(tbx_engine* e)
 {
     CHECK_ENGINE(e);
     EHIP(hipSetDevice(e->device));
     EHIP(tbx_serve_stop(e));
     EHIP(hipDeviceSynchronize());
+    e->has_last = false;              // nothing is pending any more: the stream of the last call is no longer needed
+    e->pipe.active = false;
     return check_err_flag(e);
 }
 

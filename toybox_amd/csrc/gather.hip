@@ -12,36 +12,68 @@
 #include "tbx_common.hpp"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstring>
 
+// The handful of RCCL declarations this file needs, stated locally: the library is found with dlopen at run time and its
+// header is not a build dependency.  Values are NCCL's stable public ABI (nccl.h / rccl.h: ncclUint64 = 5, ncclFloat64 = 8,
+// ncclMax = 2, NCCL_UNIQUE_ID_BYTES = 128); where the header is present the build checks them.
+typedef struct tbxNcclComm* tbx_nccl_comm_t;
+typedef struct { char internal[TBX_GATHER_ID_BYTES]; } tbx_nccl_id_t;
+enum { TBX_NCCL_SUCCESS = 0, TBX_NCCL_UINT64 = 5, TBX_NCCL_FLOAT64 = 8, TBX_NCCL_MAX = 2 };
+typedef int (*tbx_nccl_get_unique_id_fn)(tbx_nccl_id_t*);
+typedef int (*tbx_nccl_comm_init_rank_fn)(tbx_nccl_comm_t*, int, tbx_nccl_id_t, int);
+typedef int (*tbx_nccl_comm_destroy_fn)(tbx_nccl_comm_t);
+typedef int (*tbx_nccl_comm_count_fn)(tbx_nccl_comm_t, int*);
+typedef int (*tbx_nccl_all_gather_fn)(const void*, void*, size_t, int, tbx_nccl_comm_t, hipStream_t);
+typedef int (*tbx_nccl_all_reduce_fn)(const void*, void*, size_t, int, int, tbx_nccl_comm_t, hipStream_t);
+typedef const char* (*tbx_nccl_error_string_fn)(int);
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+static_assert(TBX_GATHER_ID_BYTES == NCCL_UNIQUE_ID_BYTES && sizeof(tbx_nccl_id_t) == sizeof(ncclUniqueId), "unique id size");
+static_assert((int)ncclSuccess == TBX_NCCL_SUCCESS && (int)ncclUint64 == TBX_NCCL_UINT64 && (int)ncclFloat64 == TBX_NCCL_FLOAT64 &&
+              (int)ncclMax == TBX_NCCL_MAX, "RCCL enum values");
+#endif
+
 struct GatherState {
     void* dl = nullptr;
-    ncclComm_t comm = nullptr;
+    tbx_nccl_comm_t comm = nullptr;
     int nranks = 1, rank = 0, width = 0;      // width = records per rank in the gathered layout (>= N of every rank)
+    int comm_count = 0;                       // what ncclCommCount said after ncclCommInitRank
+    std::string lib_path;                     // the librccl that dlopen found
     hipStream_t stream = nullptr;             // communication stream
-    hipEvent_t ready = nullptr, done = nullptr;
-    bool pending = false;                     // a gather has been queued and nothing waited for it yet
+    hipEvent_t ready = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};  // behind the last gather that read output set p (tbx_engine::outs)
+    bool pending[2] = {false, false};         // ... and no step has waited for it yet
+    int last_par = 0;
     uint64_t* send = nullptr;                 // [width] padded copy of the local records when width != N
     uint64_t* out = nullptr;                  // [nranks][width] engine-owned result (TBX_BUF_GATHERED)
     double* scalar = nullptr;                 // device scalar for the max-reduction
-    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
-    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
-    decltype(&ncclCommDestroy) comm_destroy = nullptr;
-    decltype(&ncclAllGather) all_gather = nullptr;
-    decltype(&ncclAllReduce) all_reduce = nullptr;
-    decltype(&ncclGetErrorString) error_string = nullptr;
+    tbx_nccl_get_unique_id_fn get_unique_id = nullptr;
+    tbx_nccl_comm_init_rank_fn comm_init_rank = nullptr;
+    tbx_nccl_comm_destroy_fn comm_destroy = nullptr;
+    tbx_nccl_comm_count_fn comm_count_fn = nullptr;
+    tbx_nccl_all_gather_fn all_gather = nullptr;
+    tbx_nccl_all_reduce_fn all_reduce = nullptr;
+    tbx_nccl_error_string_fn error_string = nullptr;
 };
 
 namespace {
 
 const char* const RCCL_NAMES[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
 
-void* open_rccl(std::string& err)
+void* open_rccl(std::string& err, std::string* path = nullptr)
 {
     for (const char* name : RCCL_NAMES)
-        if (void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) return h;
+        if (void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+            if (path) {
+                *path = name;
+                Dl_info info;
+                if (void* f = dlsym(h, "ncclAllGather"))
+                    if (dladdr(f, &info) && info.dli_fname) *path = info.dli_fname;
+            }
+            return h;
+        }
     err = std::string("librccl.so not found (") + dlerror() + ")";
     return nullptr;
 }
@@ -57,7 +89,8 @@ bool sym(void* dl, const char* name, F& f, std::string& err)
 bool load_symbols(GatherState& g, std::string& err)
 {
     return sym(g.dl, "ncclGetUniqueId", g.get_unique_id, err) && sym(g.dl, "ncclCommInitRank", g.comm_init_rank, err) &&
-           sym(g.dl, "ncclCommDestroy", g.comm_destroy, err) && sym(g.dl, "ncclAllGather", g.all_gather, err) &&
+           sym(g.dl, "ncclCommDestroy", g.comm_destroy, err) && sym(g.dl, "ncclCommCount", g.comm_count_fn, err) &&
+           sym(g.dl, "ncclAllGather", g.all_gather, err) &&
            sym(g.dl, "ncclAllReduce", g.all_reduce, err) && sym(g.dl, "ncclGetErrorString", g.error_string, err);
 }
 
@@ -69,8 +102,8 @@ bool load_symbols(GatherState& g, std::string& err)
 
 #define GNCCL(call)                                                                                       \
     do {                                                                                                  \
-        ncclResult_t _r = (call);                                                                         \
-        if (_r != ncclSuccess) return e->fail(TBX_E_NO_DEVICE, std::string(#call) + ": " + g.error_string(_r)); \
+        int _r = (call);                                                                                  \
+        if (_r != TBX_NCCL_SUCCESS) return e->fail(TBX_E_NO_DEVICE, std::string(#call) + ": " + g.error_string(_r)); \
     } while (0)
 
 __global__ void pad_records_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int n, int width)
@@ -88,7 +121,8 @@ void tbx_gather_free(tbx_engine* e)
     if (g->stream) hipStreamSynchronize(g->stream);
     if (g->comm && g->comm_destroy) g->comm_destroy(g->comm);
     if (g->ready) hipEventDestroy(g->ready);
-    if (g->done) hipEventDestroy(g->done);
+    for (int k = 0; k < 2; k++)
+        if (g->done[k]) hipEventDestroy(g->done[k]);
     if (g->stream) hipStreamDestroy(g->stream);
     hipFree(g->send); hipFree(g->out); hipFree(g->scalar);
     if (g->dl) dlclose(g->dl);
@@ -96,13 +130,15 @@ void tbx_gather_free(tbx_engine* e)
     e->gather = nullptr;
 }
 
-// steps overwrite the records a queued gather still has to read
+// a step overwrites the records of the output set it writes (tbx_engine::out_par at the time of this call): a queued gather
+// that still has to read that set goes first
 hipError_t tbx_gather_before_step(tbx_engine* e, hipStream_t s)
 {
     GatherState* g = e->gather;
-    if (!g || !g->pending) return hipSuccess;
-    g->pending = false;
-    return hipStreamWaitEvent(s, g->done, 0);
+    const int p = e->out_par;
+    if (!g || !g->pending[p]) return hipSuccess;
+    g->pending[p] = false;
+    return hipStreamWaitEvent(s, g->done[p], 0);
 }
 
 int tbx_gather_buffer(tbx_engine* e, void** out_ptr, size_t* out_bytes)
@@ -119,14 +155,13 @@ int tbx_gather_unique_id(void* id_out, size_t id_bytes)
 {
     std::string err;
     if (!id_out || id_bytes != TBX_GATHER_ID_BYTES) { tbx_set_create_error("id buffer must be TBX_GATHER_ID_BYTES long"); return TBX_E_INVALID; }
-    static_assert(TBX_GATHER_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
     GatherState g;
     g.dl = open_rccl(err);
     if (!g.dl) { tbx_set_create_error(err); return TBX_E_UNSUPPORTED; }
     if (!load_symbols(g, err)) { dlclose(g.dl); tbx_set_create_error(err); return TBX_E_UNSUPPORTED; }
-    ncclUniqueId id;
-    const ncclResult_t r = g.get_unique_id(&id);
-    if (r != ncclSuccess) { tbx_set_create_error(std::string("ncclGetUniqueId: ") + g.error_string(r)); return TBX_E_NO_DEVICE; }
+    tbx_nccl_id_t id;
+    const int r = g.get_unique_id(&id);
+    if (r != TBX_NCCL_SUCCESS) { tbx_set_create_error(std::string("ncclGetUniqueId: ") + g.error_string(r)); return TBX_E_NO_DEVICE; }
     memcpy(id_out, &id, sizeof id);
     // the library stays loaded (the bootstrap listener of the id lives in it)
     return TBX_OK;
@@ -144,19 +179,22 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
     e->gather = new GatherState();
     GatherState& g = *e->gather;
     std::string err;
-    g.dl = open_rccl(err);
+    g.dl = open_rccl(err, &g.lib_path);
     if (!g.dl || !load_symbols(g, err)) { tbx_gather_free(e); return e->fail(TBX_E_UNSUPPORTED, err); }
     g.nranks = nranks; g.rank = rank; g.width = records_per_rank;
     GHIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     GHIP(hipEventCreateWithFlags(&g.ready, hipEventDisableTiming));
-    GHIP(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    GHIP(hipEventCreateWithFlags(&g.done[0], hipEventDisableTiming));
+    GHIP(hipEventCreateWithFlags(&g.done[1], hipEventDisableTiming));
     GHIP(hipMalloc((void**)&g.out, sizeof(uint64_t) * (size_t)nranks * (size_t)g.width));
     GHIP(hipMemset(g.out, 0, sizeof(uint64_t) * (size_t)nranks * (size_t)g.width));
     GHIP(hipMalloc((void**)&g.scalar, sizeof(double)));
     if (g.width != e->n) GHIP(hipMalloc((void**)&g.send, sizeof(uint64_t) * (size_t)g.width));
-    ncclUniqueId uid;
+    tbx_nccl_id_t uid;
     memcpy(&uid, id, sizeof uid);
     GNCCL(g.comm_init_rank(&g.comm, nranks, uid, rank));
+    GNCCL(g.comm_count_fn(g.comm, &g.comm_count));
+    if (g.comm_count != nranks) return e->fail(TBX_E_NO_DEVICE, "gather: the communicator does not span the ranks asked for");
     return TBX_OK;
 }
 
@@ -166,20 +204,23 @@ int tbx_gather(tbx_engine* e, uint64_t* out_dev, void* stream)
     if (!e->gather) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called");
     GatherState& g = *e->gather;
     GHIP(hipSetDevice(e->device));
-    // after everything queued through this handle so far (the step that wrote the records) ...
-    hipStream_t prev = e->has_last ? e->last_stream : (hipStream_t)stream;
-    GHIP(hipEventRecord(g.ready, prev));
-    GHIP(hipStreamWaitEvent(g.stream, g.ready, 0));
+    // after the step that wrote the records: in pipelined mode that is the step stream's event (the caller's stream, which the
+    // other calls order themselves behind, also waits for the previous frame's rasteriser), else the tail of whatever came last
+    (void)stream;
+    if (e->pipe.active && e->pipe.step_outstanding) GHIP(hipStreamWaitEvent(g.stream, e->pipe.step_ev, 0));
+    else GHIP(tbx_wait_tail(e, g.stream));
     const uint64_t* send = e->packed;
     if (g.send) {
         hipLaunchKernelGGL(pad_records_kernel, dim3((g.width + 255) / 256), dim3(256), 0, g.stream, e->packed, g.send, e->n, g.width);
         GHIP(hipGetLastError());
         send = g.send;
     }
-    GNCCL(g.all_gather(send, out_dev ? out_dev : g.out, (size_t)g.width, ncclUint64, g.comm, g.stream));
-    // ... and before the next step (tbx_gather_before_step); what the caller queues next on its own stream overlaps
-    GHIP(hipEventRecord(g.done, g.stream));
-    g.pending = true;
+    GNCCL(g.all_gather(send, out_dev ? out_dev : g.out, (size_t)g.width, TBX_NCCL_UINT64, g.comm, g.stream));
+    // ... and before the next step that rewrites these records (tbx_gather_before_step); what the caller queues next on its
+    // own stream overlaps
+    g.last_par = e->out_par;
+    GHIP(hipEventRecord(g.done[g.last_par], g.stream));
+    g.pending[g.last_par] = true;
     return TBX_OK;
 }
 
@@ -189,7 +230,7 @@ int tbx_gather_wait(tbx_engine* e, void* stream)
     if (!e->gather) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called");
     GatherState& g = *e->gather;
     GHIP(hipSetDevice(e->device));
-    GHIP(hipStreamWaitEvent((hipStream_t)stream, g.done, 0));
+    GHIP(hipStreamWaitEvent((hipStream_t)stream, g.done[g.last_par], 0));
     return TBX_OK;
 }
 
@@ -213,10 +254,24 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout_host)
     GatherState& g = *e->gather;
     GHIP(hipSetDevice(e->device));
     GHIP(hipMemcpyAsync(g.scalar, inout_host, sizeof(double), hipMemcpyHostToDevice, g.stream));
-    GNCCL(g.all_reduce(g.scalar, g.scalar, 1, ncclFloat64, ncclMax, g.comm, g.stream));
+    GNCCL(g.all_reduce(g.scalar, g.scalar, 1, TBX_NCCL_FLOAT64, TBX_NCCL_MAX, g.comm, g.stream));
     GHIP(hipMemcpyAsync(inout_host, g.scalar, sizeof(double), hipMemcpyDeviceToHost, g.stream));
     GHIP(hipStreamSynchronize(g.stream));
     return TBX_OK;
+}
+
+/* how many ranks the communicator spans as RCCL itself reports it (ncclCommCount), and the library that was loaded */
+int tbx_gather_nranks(tbx_engine* e)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->gather || !e->gather->comm) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called");
+    return e->gather->comm_count;
+}
+
+const char* tbx_gather_library(tbx_engine* e)
+{
+    if (!e || !e->gather) return "";
+    return e->gather->lib_path.c_str();
 }
 
 }  // extern "C"

@@ -638,9 +638,9 @@ struct GridWorldOps : GameOps {
     int render_impl(tbx_engine* e, const GwDev& src, const GwDev& alt, const uint8_t* pick_alt, uint8_t* out_dev, int channels, int first_env,
                     int n_envs, hipStream_t s)
     {
-        static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
+        const int split_env = e->opt[TBX_OPT_RENDER_SPLIT];
         // two waves per RGB frame (eight 8-row units each): 0.73-0.76 ms against 0.78-0.79 ms for one at 65 536 envs, four and
-        // eight are slower (scripts/render_probe.py with TBX_RENDER_SPLIT, same box); gray and RGBA stay at one
+        // eight are slower (scripts/render_probe.py over TBX_OPT_RENDER_SPLIT, same box); gray and RGBA stay at one
         const int split = split_env > 0 ? split_env : channels == 3 ? 2 : 1;
         switch (channels) {
         case 1: if (pick_alt) hipLaunchKernelGGL((gw_render_kernel<1, true>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((gw_render_kernel<1, false>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;

@@ -1495,10 +1495,14 @@ struct SiOps : GameOps {
     int render_impl(tbx_engine* e, const SiDev& src, const SiDev& alt, const uint8_t* pick_alt, uint8_t* out_dev, int channels, int first_env,
                     int n_envs, hipStream_t s)
     {
-        // diagnostic switches (scripts/render_probe.py): bit 0 skip blank units; TBX_SI_DIAG bit 0 = no painting (stores
-        // only), bit 1 = no stores (painting only)
+#ifdef TBX_DIAG
+        // measurement builds only (make DIAG=1; scripts/render_probe.py): bit 0 skip blank units; TBX_SI_DIAG bit 0 = no
+        // painting (stores only), bit 1 = no stores (painting only) -- frames are WRONG with either set
         static const int skip_blank = (getenv("TBX_SI_NO_SKIP") ? 0 : 1) | (getenv("TBX_SI_DIAG") ? atoi(getenv("TBX_SI_DIAG")) << 1 : 0);
-        static const int split_env = getenv("TBX_RENDER_SPLIT") ? atoi(getenv("TBX_RENDER_SPLIT")) : 0;
+#else
+        constexpr int skip_blank = 1;
+#endif
+        const int split_env = e->opt[TBX_OPT_RENDER_SPLIT];
         // the painter set-up (~1 500 instructions behind a state load) is too heavy to repeat many times per frame: five waves
         // per RGB frame (A/B on two boxes at 65 536 envs, scripts/ab_render.py: 2.41-2.43 ms in every round against 2.41-2.56
         // for one wave per frame, which drops into the GPU's slower rate state more often; whole step 25.0 -> 25.8 M

@@ -269,26 +269,50 @@ __device__ __forceinline__ void tbx_serve_loop(TbxServeCtl* ctl, int lane, StepF
 
 struct GameOps;
 
+// the outputs of a batch step (TBX_BUF_REWARD / DONE / LIVES / SCORE / PACKED); two sets exist once the pipelined mode is on
+struct TbxStepOut {
+    int32_t* reward = nullptr;
+    uint8_t* done = nullptr;
+    int32_t* lives = nullptr;
+    int32_t* score = nullptr;
+    uint64_t* packed = nullptr;
+};
+
+// Pipelined mode (TBX_OPT_PIPELINE, engine.hip): random-rollout steps and batch renders of engines whose rasteriser reads
+// step-written records run on internal streams, over double-buffered records, step outputs and frames.
+struct TbxPipe {
+    hipStream_t step_stream = nullptr, render_stream[2] = {nullptr, nullptr};
+    hipEvent_t step_ev = nullptr;                    // behind the last pipelined step
+    hipEvent_t render_ev[2] = {nullptr, nullptr};    // behind the last render that READ records buffer p
+    bool render_pending[2] = {false, false};
+    // reader fences on the caller's stream: everything the caller queued there before the step (render) call that made
+    // buffer p the current one was superseded -- the next writer of buffer p waits for it
+    hipEvent_t user_step_ev[2] = {nullptr, nullptr}, user_frame_ev[2] = {nullptr, nullptr};
+    bool user_step_rec[2] = {false, false}, user_frame_rec[2] = {false, false};
+    bool active = false;          // the last call through the handle was a pipelined step or render
+    bool step_outstanding = false;
+    int frame_par = 0;            // frame buffer the last overlapped render wrote
+    uint8_t* frame[2] = {nullptr, nullptr};
+    size_t frame_bytes[2] = {0, 0};
+};
+
 struct tbx_engine {
     int game = -1, n = 0, device = 0;
     mutable std::string err;
     hipStream_t stream = nullptr;   // engine-owned stream used by the host-pointer entry points
-    // cross-stream ordering of everything queued through this handle (tbx_use_stream)
+    // cross-stream ordering of everything queued through this handle (tbx_use_stream): the stream the last call used.  It may
+    // be the caller's; tbx_wait_tail copes with a handle that has been destroyed since.
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     hipEvent_t order_ev = nullptr;
-    // step-ahead (engine.hip, tbx_step_synthetic on games whose rasteriser reads double-buffered records -- GameOps::
-    // step_ahead_ok): the step kernel runs on an internal stream BESIDE the previous frame's rasteriser instead of behind it.
-    hipStream_t step_stream = nullptr;
-    hipEvent_t step_ev = nullptr;
-    hipEvent_t render_ev[2] = {nullptr, nullptr};   // behind the last tbx_render_device that read records buffer 0 / 1
-    bool render_pending[2] = {false, false};
-    bool last_op_readonly = false;                   // the last call through tbx_use_stream only read (a batch render)
-    bool step_needs_join = true;                     // something other than steps and batch renders came since the last step
+    int opt[TBX_OPT_COUNT] = {0, 0, 0, 0, 1};
+    TbxPipe pipe;
     // common device buffers (SoA over envs)
     uint64_t* sim_rng = nullptr;    // [2][N] simulator RNG
     int32_t* prev_score = nullptr;  // [N]
-    int32_t* reward = nullptr;      // [N]
+    TbxStepOut outs[2];             // [1] is allocated when the pipelined mode is switched on
+    int out_par = 0;
+    int32_t* reward = nullptr;      // [N]   == outs[out_par].* : the outputs of the most recently issued step
     uint8_t* done = nullptr;        // [N]
     int32_t* lives_out = nullptr;   // [N]
     int32_t* score_out = nullptr;   // [N]
@@ -303,7 +327,9 @@ struct tbx_engine {
     // into pinned host memory (five pageable copies cost ~100 us per call); actions go up through the pinned block too
     int32_t* io_dev = nullptr;      // 3N + 1 dwords + N bytes
     int32_t* io_host = nullptr;     // pinned mirror (+ N action dwords in front)
-    uint8_t* frame = nullptr;       // engine-owned frame buffer (lazy)
+    uint8_t* frame_own = nullptr;   // engine-owned frame buffer (lazy)
+    size_t frame_own_bytes = 0;
+    uint8_t* frame = nullptr;       // what TBX_BUF_FRAME reports: frame_own, or in pipelined mode the buffer the last render wrote
     size_t frame_bytes = 0;
     void* staging = nullptr;        // device POD staging for get/set state
     size_t staging_bytes = 0;
@@ -324,42 +350,44 @@ struct tbx_engine {
     }
 };
 
+hipError_t tbx_serve_stop(tbx_engine* e);   // engine.hip
+
+// Stream `s` waits for everything queued so far on the stream the previous call used.  That stream may have been the
+// caller's and may be gone by now (created for one call, synchronised, destroyed): the runtime refuses the stale handle,
+// and since nothing can be recorded behind work on a stream that no longer exists, the device is synchronised instead.
+inline hipError_t tbx_wait_tail(tbx_engine* e, hipStream_t s)
+{
+    if (!e->has_last || e->last_stream == s) return hipSuccess;
+    if (!e->order_ev) {
+        hipError_t r = hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming);
+        if (r != hipSuccess) return r;
+    }
+    hipError_t r = hipEventRecord(e->order_ev, e->last_stream);
+    if (r == hipErrorContextIsDestroyed || r == hipErrorInvalidHandle || r == hipErrorInvalidResourceHandle || r == hipErrorInvalidValue) {
+        (void)hipGetLastError();
+        e->has_last = false;
+        return hipDeviceSynchronize();
+    }
+    if (r != hipSuccess) return r;
+    return hipStreamWaitEvent(s, e->order_ev, 0);
+}
+
 // Every entry point that queues work names the stream it is about to use.  When that differs from the stream the previous
 // entry point used (the "_device" forms run on the caller's stream -- including the NULL stream, which does not order itself
 // against the engine's non-blocking stream -- the host-pointer forms on the engine's own), the new stream first waits for an
-// event recorded on the old one, so calls on one handle take effect in program order whatever streams they name.
-hipError_t tbx_serve_stop(tbx_engine* e);   // engine.hip
-
-// Every entry point declares the stream it is about to use: the call is ordered behind whatever came last through this
-// handle, on whatever stream.  readonly: a batch render (it changes nothing a step reads or writes except through the
-// records buffer it was launched on -- what lets the next tbx_step_synthetic run beside it, see tbx_step_ahead in engine.hip).
-inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s, bool readonly = false)
+// event recorded on the old one, so calls on one handle take effect in program order whatever streams they name.  (Pipelined
+// calls make the caller's stream wait for their internal work and leave it as `last_stream`, so this also joins the pipeline.)
+inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s)
 {
     if (e->serve_running) {                    // nothing else runs beside the resident step kernel
         hipError_t r = tbx_serve_stop(e);
         if (r != hipSuccess) return r;
     }
-    if (e->has_last && e->last_stream != s) {
-        if (!e->order_ev) {
-            hipError_t r = hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming);
-            if (r != hipSuccess) return r;
-        }
-        hipError_t r = hipEventRecord(e->order_ev, e->last_stream);
-        if (r != hipSuccess) return r;
-        r = hipStreamWaitEvent(s, e->order_ev, 0);
-        if (r != hipSuccess) return r;
-    }
-    // a step that ran ahead is `last`; the render it ran beside may still be going on another stream
-    for (int p = 0; p < 2; p++)
-        if (e->render_pending[p]) {
-            hipError_t r = hipStreamWaitEvent(s, e->render_ev[p], 0);
-            if (r != hipSuccess) return r;
-            if (!readonly) e->render_pending[p] = false;
-        }
+    hipError_t r = tbx_wait_tail(e, s);
+    if (r != hipSuccess) return r;
+    e->pipe.active = false;
     e->last_stream = s;
     e->has_last = true;
-    e->last_op_readonly = readonly;
-    if (!readonly) e->step_needs_join = true;
     return hipSuccess;
 }
 
@@ -391,12 +419,17 @@ struct GameOps {
     // fused observation kernels (no full-resolution frame leaves the chip)
     virtual bool agent_fused() const { return false; }
     virtual int agent_warp(tbx_engine*, const struct AgentWarpArgs&, hipStream_t) { return TBX_E_UNSUPPORTED; }
-    // step-ahead: the rasteriser reads records the step kernel writes, and there are two buffers of them -- a batch step may
-    // then run while the previous frame is still being rasterised.  records_parity(): the buffer a render launched now reads;
-    // step_ahead(): one frame of every env on stream s, records into the OTHER buffer, which becomes the current one.
-    virtual bool step_ahead_ok() const { return false; }
+    // pipelined mode: the rasteriser reads records the step kernel writes, and there are two buffers of them -- a batch step
+    // may then run while the previous frame is still being rasterised.  pipeline_ok(): this engine can (canonical state
+    // layout, thread-per-env step); records_parity(): the buffer a render launched now reads; step_ahead(): one frame of
+    // every env on stream s, records into the OTHER buffer, which becomes the current one.  The step outputs go wherever
+    // tbx_engine::reward / done / ... point at the time of the launch (rebind_outputs() after the engine moved them).
+    virtual bool pipeline_ok() const { return false; }
     virtual int records_parity() const { return 0; }
     virtual int step_ahead(tbx_engine*, const ActionSource&, uint32_t, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    virtual void rebind_outputs(tbx_engine*) {}
+    // an engine option changed (tbx_set_option): pick it up
+    virtual void options_changed(tbx_engine*) {}
     // generic path: full-resolution gray frames of slot A (source 1), slot B (2) or the live state (0); envs whose
     // pick_live byte is non-zero are painted from the live state instead
     virtual int render_from(tbx_engine*, int /*source*/, const uint8_t* /*pick_live*/, uint8_t* /*out_dev*/, int /*channels*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
@@ -408,6 +441,7 @@ struct GameOps {
 void tbx_agent_free(tbx_engine* e);
 void tbx_gather_free(tbx_engine* e);
 hipError_t tbx_gather_before_step(tbx_engine* e, hipStream_t s);   // a step must not overwrite records a queued gather still reads
+void tbx_set_out_parity(tbx_engine* e, int p);                    // engine.hip: which TbxStepOut set the next step writes
 void tbx_set_create_error(const std::string& msg);                 // text behind tbx_last_error(NULL)
 int tbx_gather_buffer(tbx_engine* e, void** out_ptr, size_t* out_bytes);
 GameOps* tbx_make_breakout_ops();

@@ -68,6 +68,16 @@ class Engine:
     def __exit__(self, *a):
         self.close()
 
+    # ------------------------------------------------------------------ launch-time options (tbx_set_option)
+    def set_option(self, option, value):
+        self._check(self._lib.tbx_set_option(self._h, int(option), int(value)))
+        return self
+
+    def get_option(self, option):
+        v = C.c_int()
+        self._check(self._lib.tbx_get_option(self._h, int(option), C.byref(v)))
+        return v.value
+
     # ------------------------------------------------------------------ seeding / RNG
     def seed(self, seed, env=-1):
         self._check(self._lib.tbx_seed(self._h, int(env), int(seed) & 0xFFFFFFFF))
@@ -286,6 +296,16 @@ class Engine:
         out = np.empty(self._gather_shape, np.uint64)
         self._check(self._lib.tbx_gather_host(self._h, _ptr(out)))
         return out
+
+    def gather_nranks(self):
+        """ranks the communicator spans, as the collective library itself reports it"""
+        n = self._lib.tbx_gather_nranks(self._h)
+        if n < 0:
+            self._check(n)
+        return n
+
+    def gather_library(self):
+        return (self._lib.tbx_gather_library(self._h) or b"").decode()
 
     def gather_reduce_max(self, value):
         v = C.c_double(float(value))
