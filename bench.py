@@ -17,12 +17,24 @@ pre-roll of step-only frames so that the timed region sees mid-game states with 
 W warm-up steps, then R regions of exactly K steps, each bracketed by device-sync + rank barrier on both sides; a region's
 time is the MAX over ranks; the reported value is the MEDIAN region (min / max alongside).
 
+The loop is the north star's random-action rollout: actions come from the device, so step N+1 does not need frame N.  The
+engine's pipelined mode (TBX_OPT_PIPELINE = 1: the step runs beside the previous frame's rasteriser; below 16 384 envs
+consecutive rasteriser launches also overlap) is what `value` is measured with; the same loop with the option off -- what a
+policy-driven loop, whose actions need the frame, gets -- is measured on the same engine and reported beside it as
+`serialised`.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the dominant kernel (the rasteriser) priced against HBM bandwidth with HIP events recorded on the launch
-                  stream around every render launch of the timed regions,
-  step_only    -- the same loop without the rasteriser (not bandwidth-bound: no roofline),
-  cpu_baseline -- the CPU oracle (oracle/, a port: ctoybox itself cannot be built offline) on this box's host cores, a
-                  bounded sample of the same 65 536-env workload, plus BASELINE config 1 (one env, one thread) -- N=1 only.
+  roofline       -- the dominant kernel (the rasteriser) priced against HBM bandwidth with HIP events recorded on the caller's
+                    stream around every render launch of the timed regions,
+  serialised     -- the same loop with TBX_OPT_PIPELINE = 0 (value, ms_per_step, rasteriser fraction),
+  step_only      -- the same loop without the rasteriser (not bandwidth-bound: no roofline),
+  scaling_strong -- the other reading of the metric: the 65 536-env batch in total, i.e. what ONE GPU does with 1/8 of it
+                    plus the per-step gather, and 8 x that over `value` (N=1 only; with --gpus 8 --scaling strong it is measured),
+  rccl           -- for N > 1 (or --with-gather): ranks the communicator spans as RCCL reports it, bytes gathered per step,
+                    the library loaded.  A communicator that cannot be made is a FAILED run (rc 4) unless --allow-no-gather,
+  cpu_baseline   -- the CPU oracle (oracle/, a port: ctoybox itself cannot be built offline) on this box's host cores, a
+                    bounded sample of the same 65 536-env workload, plus BASELINE config 1 (one env, one thread) -- N=1 only.
+--dry-run walks the N-process launch, id exchange, barriers and teardown without touching a GPU (CPU test of the launcher).
 """
 import argparse
 import ctypes
@@ -64,6 +76,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step-only arm and the strong-scaling share probe")
     ap.add_argument("--with-gather", action="store_true", help="run the RCCL record gather even at one rank (1-rank communicator)")
+    ap.add_argument("--allow-no-gather", action="store_true",
+                    help="N > 1 only: if no RCCL communicator can be made, run without the per-step gather (file barrier) instead of failing")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1, 2, 3], help="TBX_OPT_PIPELINE of the main arm (1 = engine's choice)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / barrier walk-through without any GPU call")
+    ap.add_argument("--gym", action="store_true", help="reference protocol: also the env.step() arm (test/benchmark.py:83-97)")
+    ap.add_argument("--reps", type=int, default=30, help="reference protocol: repetitions (mean and s.e.m. reported)")
     ap.add_argument("--protocol", default="batch", choices=["batch", "reference", "agent"],
                     help="'reference' = the raw single-env loop of the reference's harness (test/benchmark.py:44-58)")
     ap.add_argument("--deepmind", action="store_true",
@@ -97,44 +115,47 @@ def _oracle_lib():
     return lib
 
 
-def cpu_baseline(game, channels, n_total, target_seconds):
-    """The CPU oracle on all usable host cores at the headline batch size: n_total envs held as chunks of 4 096 (one frame
-    buffer of a chunk is reused, so host memory stays ~1.5 GB instead of n_total full frames), step + render with auto-reset
-    and the same action rule, for about `target_seconds` of wall time (step count calibrated from a short probe)."""
+def cpu_baseline(segments, channels, target_seconds):
+    """The CPU oracle on all usable host cores at the headline batch size.  segments = [(game, n_envs, global offset)]; every
+    segment is held as chunks of 4 096 envs (one frame buffer per game is reused, so host memory stays ~1.5 GB instead of full
+    frames for every env), step + render with auto-reset and the same action rule, for about `target_seconds` of wall time
+    (step count calibrated from a short probe)."""
     from toybox_amd import Engine
     lib = _oracle_lib()
     if lib is None:
         return None
     cores = usable_cores()
     os.environ["TBX_ORACLE_THREADS"] = str(cores)
-    chunk = min(4096, n_total)
-    n_chunks = max(1, n_total // chunk)
-    engines = []
-    for c in range(n_chunks):
-        e = Engine(game, chunk, lib=lib)
-        e.seed(SEED_BASE + c * chunk)
-        e.new_game()
-        engines.append(e)
-    frame = np.empty((chunk, engines[0].height, engines[0].width, channels), np.uint8)
+    engines, frames, total = [], {}, 0
+    for game, n_seg, off in segments:
+        chunk = min(4096, n_seg)
+        for c in range(max(1, n_seg // chunk)):
+            e = Engine(game, chunk, lib=lib)
+            e.seed(SEED_BASE + off + c * chunk)
+            e.new_game()
+            engines.append((e, off + c * chunk))
+            total += chunk
+            if game not in frames:
+                frames[game] = np.empty((chunk, e.height, e.width, channels), np.uint8)
 
     def run(t_from, count):
         t0 = time.perf_counter()
         for t in range(t_from, t_from + count):
-            for c, e in enumerate(engines):
-                e.step_synthetic(ACTION_SEED, t, env_offset=c * chunk)
-                e.render_device(frame.ctypes.data, channels)
+            for e, off in engines:
+                e.step_synthetic(ACTION_SEED, t, env_offset=off)
+                e.render_device(frames[e.game].ctypes.data, channels)
         return time.perf_counter() - t0
 
     run(0, 1)                                           # warm-up (thread pool, page faults)
     probe = run(1, 2) / 2 + 1e-9                        # calibration
     steps = int(max(3, min(20000, target_seconds / probe)))
     dt = run(3, steps)
-    for e in engines:
+    for e, _ in engines:
         e.close()
-    n = chunk * n_chunks
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%s step+render(%dch), %d envs (as %d x %d) x %d steps, OpenMP static partition over envs, %.1f s" %
-                      (game, channels, n, n_chunks, chunk, steps, dt)}
+    what = " + ".join("%s %d" % (g, n) for g, n, _ in segments)
+    return {"value": total * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%s envs (%d in chunks of <= 4096) step+render(%dch) x %d steps, OpenMP static partition over envs, %.1f s" %
+                      (what, total, channels, steps, dt)}
 
 
 def cpu_config1(game, channels):
@@ -260,20 +281,43 @@ def bench_mixed(args, world, rank, local_rank):
                           "envs_per_gpu": mb.n_envs, "envs_total": total},
                "roofline": ({"bound": "hbm", "kernel": "the three rasterisers together (whole-step time, not per kernel)",
                              "achieved": fb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None} if render else None)}
+                             "frac": fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "algorithmic_bytes_per_step": fb,
+                             "per_kernel": "profiles/ (rocprofv3 kernel trace of this command: the three rasterisers' own durations and "
+                                           "whether they overlap)"} if render else None),
+               "rccl": ({"nranks": lead.gather_nranks(), "gather_bytes_per_step": 8 * per * 3 * world, "lib": lead.gather_library(),
+                         "communicators": len(games)} if gather else None)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline([(g, per, i * per) for i, g in enumerate(games)], C, args.cpu_seconds)
+            except Exception as ex:
+                out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)
     mb.close()
     return 0
 
 
+def _mean_sem(xs):
+    xs = np.asarray(xs, dtype=np.float64)
+    sem = float(xs.std(ddof=1) / np.sqrt(len(xs))) if len(xs) > 1 else 0.0
+    return float(xs.mean()), sem
+
+
 def bench_reference_protocol(args):
-    """Protocol A: test/benchmark.py:44-58 verbatim -- one env, action = legal[i % len(legal)],
-    new_game() when game_over() else apply_ale_action(move), no rendering, FPS = steps / elapsed.  One FFI round trip
-    per step, so on the GPU this measures launch + sync latency, not throughput; the CPU oracle runs the same loop."""
+    """The reference's own harness, test/benchmark.py: the RAW arm (:44-58: one env, action = legal[i % len(legal)],
+    new_game() when game_over() else apply_ale_action(move), no rendering) and with --gym the ENV arm (:83-97: gym-style env,
+    random agent, obs, reward, done, _ = env.step(action), reset when done -- the observation is rendered and copied to the host
+    every step); FPS = steps / elapsed per repetition, --reps repetitions, mean and s.e.m. as :119-148 print them, and the
+    harness's "slowdown" of the env arm against the raw arm.  One FFI round trip per frame: on a GPU this measures latency,
+    not throughput; the CPU oracle runs the same loops beside it."""
     from toybox_amd import Engine
     from toybox_amd import toybox as tbmod
+    from toybox_amd.envs import ENV_IDS
     from toybox_amd.toybox import Toybox
-    nsteps = max(args.steps, 1000)
+    nsteps = args.steps if args.steps != 200 else 10000      # (200 is this script's batch-protocol default; the harness uses 10 000)
+    reps = max(1, args.reps)
+    env_id = {"breakout": "BreakoutToyboxNoFrameskip-v4", "amidar": "AmidarToyboxNoFrameskip-v4",
+              "space_invaders": "SpaceInvadersToyboxNoFrameskip-v4"}.get(args.game)
 
     def raw_loop(tb):
         actions = tb.get_legal_action_set()
@@ -286,20 +330,51 @@ def bench_reference_protocol(args):
                 tb.apply_ale_action(move)
         return nsteps / (time.perf_counter() - t0)
 
+    def env_loop(env, rng):
+        n_act = env.action_space.n
+        env.reset()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            obs, reward, done, _ = env.step(int(rng.integers(n_act)))
+            if done:
+                env.reset()
+        return nsteps / (time.perf_counter() - t0)
+
+    def arms(label):
+        res = {}
+        with Toybox(args.game) as tb:
+            raw_loop(tb)                                        # warm-up (first launch, resident kernel start)
+            res["raw"] = [raw_loop(tb) for _ in range(reps)]
+        if args.gym and env_id:
+            env = ENV_IDS[env_id]()
+            rng = np.random.default_rng(0)
+            env_loop(env, rng)
+            res["gym"] = [env_loop(env, rng) for _ in range(reps)]
+            env.close()
+        return res
+
+    gpu = arms("gpu")
+    mean, sem = _mean_sem(gpu["raw"])
     out = {"metric": "raw single-env steps/sec, reference harness protocol (test/benchmark.py:44-58)", "unit": "env-steps/s",
-           "n_gpus": 1, "steps": nsteps, "warmup": 0, "higher_is_better": True, "vs_baseline": None, "data": "synthetic",
-           "scaling": "weak", "config": {"workload": "%s single env, cycling legal actions, new_game on game over, no render" % args.game}}
-    with Toybox(args.game) as tb:
-        raw_loop(tb)
-        out["value"] = raw_loop(tb)
-    out["ms_per_step"] = 1000.0 / out["value"]
+           "value": mean, "sem": sem, "reps": reps, "n_gpus": 1, "steps": nsteps, "warmup": 1, "ms_per_step": 1000.0 / mean,
+           "higher_is_better": True, "vs_baseline": None, "data": "synthetic", "scaling": "weak", "dtype": "f64" if args.game == "breakout" else "int32",
+           "config": {"workload": "%s single env, cycling legal actions, new_game on game over, no render; %d reps x %d steps"
+                                  % (args.game, reps, nsteps)}}
+    if "gym" in gpu:
+        gm, gs = _mean_sem(gpu["gym"])
+        out["gym"] = {"value": gm, "sem": gs, "unit": "env-steps/s", "slowdown_vs_raw": (mean - gm) / mean,
+                      "workload": "%s, random agent, env.step() returns the (H, W, 1) gray observation on the host every step" % env_id}
     lib = _oracle_lib()
     if lib is not None and not args.no_cpu_baseline:
         tbmod.set_engine_factory(lambda game, n: Engine(game, n, lib=lib))
-        with Toybox(args.game) as tb:
-            out["cpu_baseline"] = {"value": raw_loop(tb), "unit": "env-steps/s", "cores": 1, "kind": "port",
-                                   "sample": "same loop over the CPU oracle, %d steps" % nsteps}
+        cpu = arms("cpu")
         tbmod.set_engine_factory(None)
+        cm, cs = _mean_sem(cpu["raw"])
+        out["cpu_baseline"] = {"value": cm, "sem": cs, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                               "sample": "same raw loop over the CPU oracle, %d reps x %d steps" % (reps, nsteps)}
+        if "gym" in cpu:
+            gm, gs = _mean_sem(cpu["gym"])
+            out["cpu_baseline"]["gym"] = {"value": gm, "sem": gs, "slowdown_vs_raw": (cm - gm) / cm}
     print(json.dumps(out), flush=True)
     return 0
 
@@ -339,7 +414,8 @@ def bench_agent_protocol(args):
 
 def spawn_ranks(args):
     """No RANK in the environment and --gpus N > 1: start the N ranks ourselves (before anything touches a GPU), pass rank
-    0's line through, exit with the worst return code."""
+    0's line through, exit with the worst return code.  A rank that dies takes the others with it (they would wait for it in
+    the communicator set-up or at the next barrier for ever)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -350,11 +426,123 @@ def spawn_ranks(args):
                    MASTER_PORT=str(port), TBX_RDZV_KEY=key)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = max([p.wait() for p in procs])
-    sys.stdout.write(out.decode())
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    return rc
+    return max(abs(c) for c in codes)
+
+
+def dry_run(args, rank, world):
+    """The N-process part of a run without a GPU: every rank finds its place (RANK / WORLD_SIZE), receives the 128-byte
+    communicator id from rank 0 through the rendezvous file, checks that all ranks hold the SAME id, walks R regions of K
+    barrier-bracketed "steps" with a max-over-ranks reduction, and rank 0 prints the JSON line.  What it cannot cover is RCCL
+    itself."""
+    import hashlib
+    from toybox_amd.parallel import FileWorld, exchange_unique_id, forget_unique_id, shard_range
+    from toybox_amd._abi import GATHER_ID_BYTES
+    uid = exchange_unique_id(rank, world, lambda: os.urandom(GATHER_ID_BYTES))
+    fw = FileWorld(rank, world)
+    h = int.from_bytes(hashlib.sha256(uid).digest()[:6], "little")
+    same = fw.allreduce_max(float(h)) == float(h) and fw.allreduce_max(-float(h)) == -float(h)
+    forget_unique_id(rank)
+    if not same:
+        print("bench.py --dry-run: rank %d holds another communicator id than its peers" % rank, file=sys.stderr)
+        return 5
+    if args.scaling == "strong":
+        start, end = shard_range(args.envs, world, rank)
+        n_total = args.envs
+    else:
+        start, end = rank * args.envs, (rank + 1) * args.envs
+        n_total = world * args.envs
+    covered = fw.allreduce_max(float(end))                    # the last rank's end is the whole batch
+    reg = Region(lambda: None, fw.barrier, fw.allreduce_max)
+    times, _ = reg.run(lambda t: time.sleep(0.0002 * (1 + rank)), 0, args.steps, max(1, args.repeats))
+    rep = summarize(times, args.steps)
+    if rank == 0:
+        ms = rep["ms_per_step_median"]
+        print(json.dumps({"metric": "dry run (no GPU work)", "dry_run": True, "value": n_total / (ms * 1e-3), "unit": "env-steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": 0, "ms_per_step": ms, "repeats": rep,
+                          "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "data": "none",
+                          "config": {"workload": "launcher walk-through", "envs_total": n_total, "envs_covered": int(covered),
+                                     "envs_per_gpu": end - start},
+                          "rccl": None, "id_exchange": "ok: %d ranks hold the same %d-byte id" % (world, GATHER_ID_BYTES)}), flush=True)
+    return 0 if int(covered) == n_total else 6
+
+
+class Loop:
+    """The timed loop over one engine: step (+ gather) (+ render with HIP events around the launch)."""
+
+    def __init__(self, eng, hip, stream, start, channels, gather, render, n_events):
+        self.eng, self.sp, self.start, self.C, self.gather, self.render = eng, stream.ptr, start, channels, gather, render
+        self.pool = [(hip.Event(), hip.Event()) for _ in range(n_events)] if render else []
+        self.used = len(self.pool)              # nothing is timed until arm() is called
+
+    def arm(self):
+        self.used = 0
+
+    def full_step(self, t):
+        e, sp = self.eng, self.sp
+        e.step_synthetic(ACTION_SEED, t, env_offset=self.start, auto_reset=True, stream=sp)
+        if self.gather:
+            e.gather(stream=sp)                # on the engine's communication stream: overlaps with the rasteriser below
+        if self.render:
+            i = self.used
+            if i < len(self.pool):
+                self.pool[i][0].record(sp)
+            e.render_device(0, self.C, stream=sp)
+            if i < len(self.pool):
+                self.pool[i][1].record(sp)
+                self.used = i + 1
+
+    def step_only(self, t):
+        self.eng.step_synthetic(ACTION_SEED, t, env_offset=self.start, auto_reset=True, stream=self.sp)
+        if self.gather:
+            self.eng.gather(stream=self.sp)
+
+    def render_ms(self):
+        return float(np.mean([a.elapsed_ms(b) for a, b in self.pool[:self.used]])) if self.render and self.used else None
+
+    def close(self):
+        for a, b in self.pool:
+            a.close(); b.close()
+        self.pool = []
+
+
+def timed_arm(eng, hip, reg, stream, start, C, gather, render, pipeline, t, K, Wm, R):
+    """Warm-up + R regions of K steps with TBX_OPT_PIPELINE = pipeline.  Returns (summary, avg render launch ms, resolved
+    pipeline mode, next t)."""
+    from toybox_amd import _abi
+    eng.set_option(_abi.OPT_PIPELINE, pipeline)
+    mode = eng.get_option(_abi.OPT_PIPELINE_ACTIVE)
+    loop = Loop(eng, hip, stream, start, C, gather, render, K * R)
+    for _ in range(Wm):
+        loop.full_step(t)
+        t += 1
+    hip.synchronize()
+    loop.arm()
+    times, t = reg.run(loop.full_step, t, K, R)
+    rms = loop.render_ms()
+    loop.close()
+    return summarize(times, K), rms, mode, t
+
+
+PIPELINE_NOTE = {0: "off: every call in stream order", 2: "the step runs beside the previous frame's rasteriser (internal step stream, "
+                 "two sets of render records and step outputs)", 3: "the step runs beside the previous frame's rasteriser and consecutive "
+                 "rasteriser launches alternate between two internal streams and two frame buffers"}
 
 
 def main():
@@ -366,12 +554,15 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         return spawn_ranks(args)
 
-    from toybox_amd import Engine, hip
     from toybox_amd.parallel import exchange_unique_id, forget_unique_id, shard_range, world_from_env
     rank, world, local_rank = world_from_env()
     if args.gpus > 1 and world != args.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         return 2
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    from toybox_amd import Engine, _abi, hip
     if os.environ.get("TBX_BENCH_ONE_DEVICE"):     # diagnostic: every rank on device 0 (exercises the N > 1 flow on a 1-GPU box)
         local_rank = 0
     hip.set_device(local_rank)
@@ -394,7 +585,7 @@ def main():
     H, W, C = eng.height, eng.width, args.channels
     render = not args.no_render
     gather = world > 1 or args.with_gather
-    gather_note = None
+    gather_note, rccl = None, None
     fw = None
     if gather:
         try:
@@ -404,14 +595,23 @@ def main():
                 uid = exchange_unique_id(rank, world, eng.gather_unique_id)
                 eng.gather_init(world, rank, uid, records_per_rank=width)   # collective (ncclCommInitRank)
             forget_unique_id(rank)
-        except Exception as ex:    # no usable RCCL: the shards still run; ranks start and stop together through files
+            rccl = {"nranks": eng.gather_nranks(), "records_per_rank": width, "gather_bytes_per_step": 8 * width * world,
+                    "lib": eng.gather_library()}
+            if rccl["nranks"] != world:
+                raise RuntimeError("the communicator spans %d ranks, not %d" % (rccl["nranks"], world))
+        except Exception as ex:
+            msg = str(ex).splitlines()[0][:200] if str(ex) else repr(ex)
+            if world > 1 and not args.allow_no_gather:
+                # the north star's 8-GPU number INCLUDES the collective: a run that cannot make it is a failed run
+                print("bench.py: rank %d: no RCCL communicator over %d ranks (%s); pass --allow-no-gather to measure the shards "
+                      "without the per-step gather" % (rank, world, msg), file=sys.stderr)
+                return 4
             from toybox_amd.parallel import FileWorld
-            gather_note = "RCCL communicator unavailable (%s): no per-step gather, file barrier between ranks" % (str(ex).splitlines()[0][:160],)
+            gather_note = "RCCL communicator unavailable (%s): no per-step gather, file barrier between ranks" % msg
             print("bench.py: " + gather_note, file=sys.stderr)
-            gather = False
-            fw = FileWorld(rank, world)
+            gather, rccl = False, None
+            fw = FileWorld(rank, world) if world > 1 else None
     stream = hip.Stream()
-    sp = stream.ptr
     K, Wm, R = args.steps, args.warmup, max(1, args.repeats)
     if gather:
         reg = Region(hip.synchronize, lambda: eng.gather_reduce_max(0.0), lambda v: eng.gather_reduce_max(v))
@@ -420,47 +620,25 @@ def main():
     else:
         reg = Region(hip.synchronize, lambda: None, lambda v: v)
 
-    # HIP events around every render launch of the timed regions, created up front (nothing is allocated inside a region)
-    pool = [(hip.Event(), hip.Event()) for _ in range(K * R)] if render else []
-    used = [0]
-
-    def full_step(t):
-        eng.step_synthetic(ACTION_SEED, t, env_offset=start, auto_reset=True, stream=sp)
-        if gather:
-            eng.gather(stream=sp)          # on the engine's communication stream: overlaps with the rasteriser below
-        if render:
-            i = used[0]
-            if i < len(pool):
-                pool[i][0].record(sp)
-            eng.render_device(0, C, stream=sp)
-            if i < len(pool):
-                pool[i][1].record(sp)
-                used[0] = i + 1
-
-    def step_only(t):
-        eng.step_synthetic(ACTION_SEED, t, env_offset=start, auto_reset=True, stream=sp)
-        if gather:
-            eng.gather(stream=sp)
-
     t = 0
     for _ in range(args.preroll):          # untimed: bring the batch to mid-game states (episodes end, auto-resets fire)
-        eng.step_synthetic(ACTION_SEED, t, env_offset=start, auto_reset=True, stream=sp)
+        eng.step_synthetic(ACTION_SEED, t, env_offset=start, auto_reset=True, stream=stream.ptr)
         t += 1
-    used[0] = len(pool)                    # warm-up launches are not timed
-    for _ in range(Wm):
-        full_step(t)
-        t += 1
-    hip.synchronize()
-    used[0] = 0
-    times, t = reg.run(full_step, t, K, R)
-    render_ms = float(np.mean([a.elapsed_ms(b) for a, b in pool[:used[0]]])) if render else None
-    for a, b in pool:
-        a.close(); b.close()
-    rep = summarize(times, K)
+    rep, render_ms, mode, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, args.pipeline, t, K, Wm, R)
 
     extras = {}
+    frame_bytes = H * W * C if render else 0
+    if not args.no_extras and mode != 0:
+        # the same engine, the same loop, nothing overlapped: what a policy-driven loop (actions computed from the frame) gets
+        srep, s_ms, _, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, 0, t, K, Wm, R)
+        sms = srep["ms_per_step_median"]
+        extras["serialised"] = {"value": n_total / (sms * 1e-3), "unit": "env-steps/s", "ms_per_step": sms, "repeats": srep,
+                                "avg_launch_ms": s_ms, "roofline_frac": (n * frame_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s_ms else None,
+                                "note": "TBX_OPT_PIPELINE = 0: step and render in stream order"}
+        eng.set_option(_abi.OPT_PIPELINE, args.pipeline)
     if render and not args.no_extras:
-        so_times, t = reg.run(step_only, t, K, R)
+        loop = Loop(eng, hip, stream, start, C, gather, False, 0)
+        so_times, t = reg.run(loop.step_only, t, K, R)
         so = summarize(so_times, K)
         extras["step_only"] = {"value": n_total / (so["ms_per_step_median"] * 1e-3), "unit": "env-steps/s",
                                "ms_per_step": so["ms_per_step_median"], "repeats": so,
@@ -474,7 +652,6 @@ def main():
     if t >= 300 and not (check["mean_score"] > 0):
         print("bench.py: the rollout did not play (mean score %.3f after %d frames)" % (check["mean_score"], t), file=sys.stderr)
         return 3
-    frame_bytes = H * W * C if render else 0
     bytes_per_step = 2 * S_GAME[game] + A_BYTES + O_BYTES + frame_bytes
     eng.close()
 
@@ -506,6 +683,9 @@ def main():
                                ("env-sharded x%d, no collective (%s)" % (world, gather_note)) if gather_note else "single GPU",
                 "algorithmic_bytes_per_env_step": bytes_per_step,
             },
+            "pipeline": {"option": args.pipeline, "resolved": mode, "what": PIPELINE_NOTE.get(mode),
+                         "applies_to": "loops whose actions do not depend on the frame (tbx_step_synthetic); see `serialised`"},
+            "rccl": rccl,
         }
         if render:
             achieved = n * frame_bytes / (render_ms * 1e-3) / 1e9    # GB/s, algorithmic frame bytes of one launch
@@ -524,6 +704,9 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": source,
                 "algorithmic_bytes_per_launch": n * frame_bytes, "avg_launch_ms": render_ms, "launches_timed": K * R,
+                "timing": "HIP events on the caller's stream around every render launch" +
+                          ("" if mode != 3 else "; launches overlap in this mode, so this is the time from one launch's end to the "
+                                               "next one's end (what a launch costs in steady state), not a kernel's own duration"),
             }
         else:
             out["roofline"] = None
@@ -531,12 +714,12 @@ def main():
         out["check"] = check
         if world == 1 and not args.no_extras and args.scaling == "weak" and n >= 16384:
             try:
-                out["strong_scaling_share"] = strong_share_probe(args, game, C, n)
+                out["scaling_strong"] = strong_share_probe(args, game, C, n, out["value"])
             except Exception as ex:
-                out["strong_scaling_share"] = {"error": repr(ex)}
+                out["scaling_strong"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(game, C, n_total, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline([(game, n_total, 0)], C, args.cpu_seconds)
                 out["cpu_config1"] = cpu_config1(game, C)
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(ex)}
@@ -544,11 +727,12 @@ def main():
     return 0
 
 
-def strong_share_probe(args, game, C, n_single):
-    """What ONE GPU of an 8-GPU strong-scaling run of the same batch would do: n/8 envs with the per-step gather on
-    (1-rank communicator: launch + stream-hop cost of the collective, no wire time).  8 x this value over the single-GPU value
-    is the scaling efficiency the per-step fixed costs allow at that shard size."""
-    from toybox_amd import Engine, hip
+def strong_share_probe(args, game, C, n_single, single_value):
+    """The other reading of the headline ("the 64k-env batch on 1/2/4/8 GPUs" = 65 536 envs IN TOTAL): what ONE GPU of an 8-GPU
+    strong-scaling run would do -- n/8 envs with the per-step gather on (1-rank communicator: launch + stream-hop cost of
+    the collective, no wire time) -- pipelined and serialised.  8 x this value over the single-GPU value is the scaling
+    efficiency the per-step fixed costs allow at that shard size."""
+    from toybox_amd import Engine, _abi, hip
     n = n_single // 8
     eng = Engine(game, n, device=0)
     eng.seed(SEED_BASE)
@@ -556,24 +740,22 @@ def strong_share_probe(args, game, C, n_single):
     with quiet_stdout():
         eng.gather_init(1, 0, eng.gather_unique_id())
     st = hip.Stream()
-
-    def one(t):
-        eng.step_synthetic(ACTION_SEED, t, auto_reset=True, stream=st.ptr)
-        eng.gather(stream=st.ptr)
-        eng.render_device(0, C, stream=st.ptr)
-
     for t in range(args.preroll):
         eng.step_synthetic(ACTION_SEED, t, auto_reset=True, stream=st.ptr)
-    for t in range(20):
-        one(args.preroll + t)
     reg = Region(hip.synchronize, lambda: eng.gather_reduce_max(0.0), lambda v: eng.gather_reduce_max(v))
     K = max(args.steps, 200)
-    times, _ = reg.run(one, args.preroll + 20, K, 5)
-    rep = summarize(times, K)
+    t = args.preroll
+    res = {"envs_per_gpu": n, "gpus": 8, "unit": "env-steps/s per GPU",
+           "note": "1/8 of the batch on one GPU with the per-step record gather queued (1-rank RCCL communicator)"}
+    for key, pl in (("pipelined", args.pipeline), ("serialised", 0)):
+        rep, rms, mode, t = timed_arm(eng, hip, reg, st, 0, C, True, True, pl, t, K, 20, 5)
+        v = n / (rep["ms_per_step_median"] * 1e-3)
+        res[key] = {"value": v, "ms_per_step": rep["ms_per_step_median"], "repeats": rep, "pipeline_resolved": mode,
+                    "avg_launch_ms": rms, "share_of_linear": 8 * v / single_value}
+    res["value"] = res["pipelined"]["value"]
+    res["share_of_linear"] = res["pipelined"]["share_of_linear"]
     eng.close()
-    return {"envs": n, "value": n / (rep["ms_per_step_median"] * 1e-3), "unit": "env-steps/s per GPU",
-            "ms_per_step": rep["ms_per_step_median"], "repeats": rep,
-            "note": "1/8 of the batch on one GPU with the per-step record gather queued (1-rank RCCL communicator)"}
+    return res
 
 
 if __name__ == "__main__":

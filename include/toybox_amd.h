@@ -561,6 +561,8 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
 /* 1 (default): tbx_step1 on a one-env engine talks to the resident step kernel; 0: single-env launch + read-back */
 #define TBX_OPT_RESIDENT_STEP 4
 #define TBX_OPT_COUNT         5
+/* read-only (tbx_get_option): what TBX_OPT_PIPELINE resolves to on this engine right now -- 0, 2 or 3 */
+#define TBX_OPT_PIPELINE_ACTIVE 100
 int tbx_set_option(tbx_engine* engine, int option, int value);
 int tbx_get_option(tbx_engine* engine, int option, int* value_out);
 /* Block until all work queued by this engine has finished; reports a pending TBX_E_ACTION. */

@@ -220,3 +220,38 @@ def test_file_world_barrier_and_max(tmp_path, monkeypatch):
         p.join(timeout=30)
     assert all(out == [10 * (world - 1) + i for i in range(40)] for _, out in res)
     assert len(list(tmp_path.iterdir())) <= world          # only the last round's files are left
+
+
+def test_bench_launcher_dry_run_walks_the_n_process_path():
+    """bench.py --gpus N starts its own ranks when no launcher did (subproc_vec_env.py:49-74 is the reference's N-worker
+    launch): --dry-run takes that path end to end without a GPU -- N processes, the communicator id from rank 0 to every rank
+    through the rendezvous file, max-over-ranks barriers around every region, teardown, ONE JSON line from rank 0 -- under both
+    readings of the metric (weak: per-GPU batch; strong: the batch cut into contiguous shards that cover it exactly)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    for scaling, envs, world in (("strong", 65536, 8), ("weak", 1000, 3)):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-run", "--steps", "4",
+                            "--repeats", "2", "--scaling", scaling, "--envs", str(envs)], capture_output=True, text=True, timeout=300,
+                           cwd="/tmp", env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, p.stdout
+        out = json.loads(lines[0])
+        assert out["dry_run"] and out["n_gpus"] == world and out["scaling"] == scaling
+        total = envs if scaling == "strong" else envs * world
+        assert out["config"]["envs_total"] == total == out["config"]["envs_covered"]
+        assert out["id_exchange"].startswith("ok: %d ranks" % world)
+        # the slowest rank sleeps 0.2 ms x world per step: the max over ranks is what is reported
+        assert out["ms_per_step"] >= 0.2 * world
+
+
+def test_bench_launcher_world_size_mismatch_is_an_error():
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, cwd="/tmp", env=env)
+    assert p.returncode == 2 and "WORLD_SIZE" in p.stderr

@@ -62,15 +62,30 @@ def rendezvous_key(env=None):
                             env.get("TORCHELASTIC_RUN_ID", "none").replace("/", "_"), os.getppid())
 
 
+_exchange_count = {}
+
+
 def exchange_unique_id(rank, world, make_id, tag="", key=None, timeout=180.0, directory=None):
     """Rank 0 calls make_id() (tbx_gather_unique_id) and publishes the bytes atomically as a file; the other ranks poll for
-    it.  One node, so the temp directory is shared.  Returns the id bytes on every rank.  The file is left for the
-    launcher's temp cleaning (rank 0 cannot know when the last rank has read it before the collective init returns);
-    `forget_unique_id` removes it afterwards."""
+    it.  One node, so the temp directory is shared.  Returns the id bytes on every rank.
+
+    The file name carries the rendezvous key, the tag and the NUMBER of this exchange among the exchanges this process has
+    made under that (key, tag) -- every rank makes the same exchanges in the same order, so the k-th id of a launch never
+    shares a name with its (k-1)-th (a second ShardedBatch, bench.py's second communicator).  Rank 0 removes whatever a
+    crashed earlier launch may have left under the name before it publishes; an explicit TBX_RDZV_KEY must still be unique
+    per launch (a rank that starts before rank 0 has cleaned up could read a stale id of the same name).
+    `forget_unique_id` removes the file of the last exchange once the collective init has returned."""
     if world == 1:
         return make_id()
-    path = _id_path(tag, key, directory)
+    slot = (key or rendezvous_key(), tag)
+    seq = _exchange_count.get(slot, 0)
+    _exchange_count[slot] = seq + 1
+    path = _id_path(tag, key, directory, seq)
     if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
         data = make_id()
         tmp = "%s.%d.tmp" % (path, os.getpid())
         with open(tmp, "wb") as f:
@@ -91,15 +106,17 @@ def exchange_unique_id(rank, world, make_id, tag="", key=None, timeout=180.0, di
         time.sleep(0.01)
 
 
-def _id_path(tag, key, directory):
+def _id_path(tag, key, directory, seq=0):
     d = directory or os.environ.get("TBX_RDZV_DIR") or tempfile.gettempdir()
-    return os.path.join(d, "tbx_rccl_id_%s%s" % (key or rendezvous_key(), ("_" + tag) if tag else ""))
+    return os.path.join(d, "tbx_rccl_id_%s%s_%d" % (key or rendezvous_key(), ("_" + tag) if tag else "", seq))
 
 
 def forget_unique_id(rank, tag="", key=None, directory=None):
+    """rank 0: remove the file of the most recent exchange under (key, tag)"""
     if rank == 0:
+        seq = _exchange_count.get((key or rendezvous_key(), tag), 1) - 1
         try:
-            os.unlink(_id_path(tag, key, directory))
+            os.unlink(_id_path(tag, key, directory, seq))
         except OSError:
             pass
 
@@ -171,7 +188,8 @@ class ShardedBatch:
 
     engine_factory(n_local) -> Engine.  rank / world come from the launcher (world_from_env()).  The records travel through
     the engine's own tbx_gather (RCCL on the GPU) unless `host_dist` names a torch.distributed module whose CPU process
-    group should carry them instead.
+    group should carry them instead.  A single process (world == 1) needs neither: its own records ARE the gathered
+    records, and no communicator is made unless the device-resident form asks for the gathered buffer.
     """
 
     def __init__(self, engine_factory, n_global, rank=0, world=1, seed_base=1234, host_dist=None, rdzv_tag="", rdzv_key=None):
@@ -185,10 +203,17 @@ class ShardedBatch:
         self.engine.seed(seed_base + self.start)      # env i gets seed_base + global index
         self.engine.new_game()
         self.host = HostGather(host_dist, self.counts) if (host_dist is not None and self.world > 1) else None
-        if self.host is None:
-            uid = exchange_unique_id(self.rank, self.world, self.engine.gather_unique_id, tag=rdzv_tag, key=rdzv_key)
-            self.engine.gather_init(self.world, self.rank, uid, records_per_rank=self.width)   # collective
-            forget_unique_id(self.rank, tag=rdzv_tag, key=rdzv_key)
+        self._rdzv = (rdzv_tag, rdzv_key)
+        self.communicator = False
+        if self.host is None and self.world > 1:
+            self._make_communicator()
+
+    def _make_communicator(self):
+        tag, key = self._rdzv
+        uid = exchange_unique_id(self.rank, self.world, self.engine.gather_unique_id, tag=tag, key=key)
+        self.engine.gather_init(self.world, self.rank, uid, records_per_rank=self.width)   # collective
+        forget_unique_id(self.rank, tag=tag, key=key)
+        self.communicator = True
 
     def _global_order(self, gathered):
         """[world][width] -> records in global env order (drops the padding of short shards)."""
@@ -201,12 +226,16 @@ class ShardedBatch:
         reward, done, lives, _ = self.engine.step(a, auto_reset=auto_reset)
         if self.host is not None:
             return unpack_records(self._global_order(self.host.all_gather(pack_records(reward, done, lives))))
+        if not self.communicator:                      # one process: nothing to exchange
+            return unpack_records(pack_records(reward, done, lives))
         self.engine.gather()
         return unpack_records(self._global_order(self.engine.gather_host()))
 
     def step_synthetic(self, action_seed, t, auto_reset=True, stream=0):
         """Device-resident form: in-kernel actions by global env index, then the asynchronous gather (results in
         TBX_BUF_GATHERED; `gathered()` fetches them)."""
+        if not self.communicator and self.host is None:
+            self._make_communicator()                  # world == 1 and the caller wants the gathered buffer on the device
         self.engine.step_synthetic(action_seed, t, env_offset=self.start, auto_reset=auto_reset, stream=stream)
         self.engine.gather(stream=stream)
 
@@ -214,7 +243,7 @@ class ShardedBatch:
         return unpack_records(self._global_order(self.engine.gather_host()))
 
     def max_over_ranks(self, value):
-        return self.engine.gather_reduce_max(value) if self.host is None else value
+        return self.engine.gather_reduce_max(value) if self.communicator else value
 
     def close(self):
         self.engine.close()
