@@ -16,10 +16,10 @@
  *     device (HBM) pointers (call is asynchronous on the given hipStream_t, passed as void*);
  *   - calls on one handle take effect in program order whatever streams they name: when an entry point uses another stream
  *     than the previous one did (the host-pointer forms run on an engine-owned non-blocking stream), the new stream first
- *     waits for an event recorded on the old one -- no tbx_sync is needed between the two API families.  The library keeps
- *     the handle of the stream the LAST call named until the next call (or tbx_sync) so that it can record that event; a
- *     caller that destroys such a stream in between loses nothing: the stale handle is detected and the next call falls back
- *     to a device-wide synchronisation.  The engine-owned output buffers (TBX_BUF_*) keep their addresses and a result in
+ *     waits for an event recorded on the old one -- no tbx_sync is needed between the two API families.  STREAM LIFETIME: to
+ *     record that event the library keeps the handle of the stream the LAST call named until the next call on the handle;
+ *     a stream passed to a call must therefore stay alive until the next call on the handle has returned, or until
+ *     tbx_sync(), which forgets it (so: tbx_sync, then hipStreamDestroy).  The engine-owned output buffers (TBX_BUF_*) keep their addresses and a result in
  *     them stays valid for whatever the caller queues on the stream of the call that produced it before its next call on the
  *     handle -- unless the pipelined mode is switched on (TBX_OPT_PIPELINE below), which double-buffers them;
  *   - a handle is not thread-safe; different handles may be used concurrently;
@@ -516,7 +516,8 @@ int tbx_gather_nranks(tbx_engine* engine);
 const char* tbx_gather_library(tbx_engine* engine);
 /* Queue the all-gather of the last step's records into out_dev (NULL: the engine-owned TBX_BUF_GATHERED).  Asynchronous: it
  * is ordered after everything queued through this handle so far, runs on an engine-owned communication stream, and the next
- * step on this handle is ordered after it -- what the caller queues in between (the rasteriser) overlaps with it. */
+ * step that rewrites those records is ordered after it -- what the caller queues in between (the rasteriser) overlaps with it.  `stream` is not used to run it; make a
+ * stream wait for the result with tbx_gather_wait. */
 int tbx_gather(tbx_engine* engine, uint64_t* out_dev, void* stream);
 /* Make `stream` wait for the last queued gather (device-side consumers of the gathered records). */
 int tbx_gather_wait(tbx_engine* engine, void* stream);
@@ -543,7 +544,10 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  *     value 3: additionally consecutive rasteriser launches alternate between two internal streams and the two frame
  *              buffers, so that launch N+1 fills the ramp-down of launch N (small batches: BASELINE configs 2-4, the
  *              per-GPU share of a strong-scaled batch);
- *     value 1: the engine picks 0, 2 or 3 from game and batch size (what bench.py measured to pay).
+ *     value 1: the engine's choice: 2 from 16 384 envs up, else 0.  (Measured, scripts/pipeline_sweep.py: value 2 makes the
+ *              large-batch loop 1-15 % faster depending on the box and never slower; value 3 gains 4-10 % at 4 096-8 192 envs
+ *              WITHOUT a per-step gather and loses with one, and its gain depends on which hardware queues the runtime
+ *              hands the internal streams -- it stays an explicit choice.)
  *   Contract in this mode: the stream a call names still waits for the call's work, so anything queued on it afterwards sees
  *   the result; the result of step N (render N) stays valid for readers queued on that stream BEFORE step N+1 (render N+1)
  *   is issued -- the same rule as without the option -- but it lives at the address tbx_device_buffer reports after the

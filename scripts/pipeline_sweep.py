@@ -15,10 +15,14 @@ game = sys.argv[1] if len(sys.argv) > 1 else "breakout"
 sizes = [int(v) for v in sys.argv[2:]] or [4096, 8192, 16384, 65536]
 rounds, gather = int(os.environ.get("PS_ROUNDS", "4")), bool(os.environ.get("PS_GATHER"))
 modes = [int(v) for v in os.environ.get("PS_MODES", "0,2,3").split(",")]
+lib = None
+if os.environ.get("PS_LIB"):                       # another build of the library (A/B in one call)
+    import ctypes
+    lib = _abi.bind(ctypes.CDLL(os.path.abspath(os.environ["PS_LIB"])))
 res = {}
 for n in sizes:
     K = int(os.environ.get("PS_STEPS", "0")) or max(200, min(2000, 200 * 65536 // n // 4))
-    e = Engine(game, n)
+    e = Engine(game, n, lib=lib)
     e.seed(1234); e.new_game()
     if gather:
         e.gather_init(1, 0, e.gather_unique_id())
@@ -46,7 +50,7 @@ for n in sizes:
             hip.synchronize()
             out[m].append(1000.0 * (time.perf_counter() - w0) / K)
     e.sync()
-    line = {"game": game, "envs": n, "steps": K, "gather": gather}
+    line = {"game": game, "envs": n, "steps": K, "gather": gather, "lib": os.environ.get("PS_LIB", "default")}
     for m in modes:
         best, med = min(out[m]), sorted(out[m])[len(out[m]) // 2]
         line["mode%d" % m] = {"ms_per_step": [round(v, 4) for v in out[m]], "median_ms": round(med, 4),

@@ -167,7 +167,7 @@ def test_amidar_step_kernel_forms_parity(form, oracle_lib):
 n, steps = 1100, 700      # not a multiple of 64: the thread form's last wave is ragged
 g, o = Engine("amidar", n, lib=hip), Engine("amidar", n, lib=orc)
 for e in (g, o):
-    e.set_option(_abi.OPT_STEP_FORM, FORM)
+    e.set_option(_abi.OPT_STEP_FORM, @FORM@)
     e.seed(77); e.new_game()
 for t in range(steps):
     a = synthetic_actions("amidar", n, t)
@@ -195,7 +195,7 @@ for t in range(150):
 for i in range(0, n, 3):
     assert bytes(g.get_state(i)) == bytes(o.get_state(i)), i
 """
-    _run_sub(body.replace("FORM", str(form)), {})
+    _run_sub(body.replace("@FORM@", str(form)), {})
 
 
 @pytest.mark.gpu
@@ -208,7 +208,7 @@ for game in ("breakout", "space_invaders", "amidar", "gridworld"):
     for n in (3, 130):
         g, o = Engine(game, n, lib=hip), Engine(game, n, lib=orc)
         for e in (g, o):
-            e.set_option(_abi.OPT_RENDER_SPLIT, SPLIT)
+            e.set_option(_abi.OPT_RENDER_SPLIT, @SPLIT@)
             e.seed(9); e.new_game()
         for t in range(260):
             a = synthetic_actions(game, n, t)
@@ -218,7 +218,7 @@ for game in ("breakout", "space_invaders", "amidar", "gridworld"):
                     assert np.array_equal(g.render(c), o.render(c)), (game, n, t, c)
         assert np.array_equal(g.render_env(n - 1, 3), o.render_env(n - 1, 3))
 """
-    _run_sub(body.replace("SPLIT", str(split)), {})
+    _run_sub(body.replace("@SPLIT@", str(split)), {})
 
 
 @pytest.mark.gpu
@@ -628,10 +628,11 @@ def test_results_stay_valid_for_readers_queued_before_the_next_call(mode, hip_li
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [0, 3])
-def test_a_caller_stream_destroyed_between_calls_is_tolerated(mode, hip_lib, oracle_lib):
-    """The library remembers the stream of the last call to order the next one behind it.  A caller may create a stream for one
-    pair of calls, synchronise and destroy it: the next call on the handle (on another stream, or a host-pointer call) must
-    neither fail nor lose its place in program order."""
+def test_a_caller_stream_may_be_destroyed_after_tbx_sync(mode, hip_lib, oracle_lib):
+    """The library remembers the stream of the last call to order the next one behind it, so that stream has to live until
+    the next call on the handle -- or until tbx_sync, which forgets it (include/toybox_amd.h, STREAM LIFETIME).  A caller that
+    creates a stream for one pair of calls, calls tbx_sync and destroys the stream: the next call on the handle (another
+    stream, or a host-pointer call) must neither fail nor lose its place in program order."""
     from toybox_amd import hip
     game, n = "breakout", 2048
     g, o = _pair(game, n, hip_lib, oracle_lib, seed=3)
@@ -640,8 +641,7 @@ def test_a_caller_stream_destroyed_between_calls_is_tolerated(mode, hip_lib, ora
         s = hip.Stream()
         g.step_synthetic(1337, t, auto_reset=True, stream=s.ptr)
         g.render_device(0, 3, stream=s.ptr)
-        if t % 3:
-            s.synchronize()
+        g.sync()
         s.close()
         o.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
         if t % 2:

@@ -288,9 +288,8 @@ int tbx_destroy(tbx_engine* e)
     if (e->serve_ctl) hipHostFree(e->serve_ctl);
     if (e->stream) hipStreamSynchronize(e->stream);
     TbxPipe& pp = e->pipe;
-    if (pp.step_stream) hipStreamSynchronize(pp.step_stream);
     for (int k = 0; k < 2; k++)
-        if (pp.render_stream[k]) hipStreamSynchronize(pp.render_stream[k]);
+        if (pp.lane[k] && pp.lane[k] != e->stream) hipStreamSynchronize(pp.lane[k]);
     tbx_gather_free(e);
     tbx_agent_free(e);
     if (e->ops) { e->ops->destroy(e); delete e->ops; }
@@ -301,7 +300,7 @@ int tbx_destroy(tbx_engine* e)
         if (pp.render_ev[k]) hipEventDestroy(pp.render_ev[k]);
         if (pp.user_step_ev[k]) hipEventDestroy(pp.user_step_ev[k]);
         if (pp.user_frame_ev[k]) hipEventDestroy(pp.user_frame_ev[k]);
-        if (pp.render_stream[k]) hipStreamDestroy(pp.render_stream[k]);
+        if (pp.lane[k] && pp.lane[k] != e->stream) hipStreamDestroy(pp.lane[k]);
     }
     hipFree(e->actions);
     hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame_own); hipFree(e->staging); hipFree(e->scal); hipFree(e->one_frame); hipFree(e->io_dev);
@@ -309,7 +308,6 @@ int tbx_destroy(tbx_engine* e)
     if (e->scal_host) hipHostFree(e->scal_host);
     if (e->order_ev) hipEventDestroy(e->order_ev);
     if (pp.step_ev) hipEventDestroy(pp.step_ev);
-    if (pp.step_stream) hipStreamDestroy(pp.step_stream);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return TBX_OK;
@@ -505,27 +503,32 @@ int tbx_step_device(tbx_engine* e, const int32_t* actions_dev, uint32_t flags, v
 // engine-owned frame buffer alternate between two internal streams and two buffers as well, so that launch N+1 ramps up in
 // the ramp-down of launch N.
 //
-// Who waits for whom (p = buffer parity; the stream the caller names is U):
-//   step N+1 (step stream, writes records / outputs p')   <- step N (same stream), the render that read records p',
-//                                                             U's readers of outputs p' (fence recorded on U at step N's
-//                                                             call), the gather that read outputs p'
-//   render N (U, or render stream f for frame buffer f)   <- step N (U waits for every step; step_ev on a render stream),
-//                                                             render N-2 (same stream), U's readers of frame buffer f
-//                                                             (fence recorded on U at render N-1's call)
-//   U                                                      <- every step and every overlapped render (so whatever the caller
-//                                                             queues next sees them, and U is the tail other calls join)
+// Streams.  Value 2: one internal step stream; renders stay on the caller's stream U.  Value 3: two internal streams S[0],
+// S[1]; step N and the overlapped render N both go to S[p], p = the parity of the buffers step N writes -- so render N is
+// behind its step, behind render N-2 (same frame buffer) and behind step N-2 / render N-2's reads of records p by stream order
+// alone, and runs beside render N-1 on the other stream.  (Few streams on purpose: the runtime multiplexes streams onto a
+// handful of hardware queues -- GPU_MAX_HW_QUEUES, 4 by default -- and two streams that share one queue do not overlap.)
+//
+// Who waits for whom beyond stream order (U = the stream the caller names):
+//   step N   (writes records / outputs p)   <- step N-1 (the state; other stream in value 3), a render of records p that ran
+//                                              elsewhere, U's readers of outputs p (fence recorded on U at step N-1's call),
+//                                              the gather that read outputs p
+//   render N on U (value 2, or out_dev given) <- nothing: U waits for every step
+//   render N on S[p] (value 3)              <- U's readers of frame buffer p (fence recorded on U at render N-1's call)
+//   U                                        <- every step and every overlapped render (so whatever the caller queues next
+//                                              sees them, and U is the tail that calls of any other kind join)
 static int pipe_mode(const tbx_engine* e)
 {
     const int v = e->opt[TBX_OPT_PIPELINE];
     if (v == 0 || !e->ops->pipeline_ok()) return 0;
-    if (v == 1) return e->n >= 16384 ? 2 : 3;
+    if (v == 1) return e->n >= 16384 ? 2 : 0;
     return v;
 }
 
 static int pipe_prepare(tbx_engine* e)
 {
     TbxPipe& p = e->pipe;
-    if (p.step_stream) return TBX_OK;
+    if (p.lane[0]) return TBX_OK;
     const size_t N = (size_t)e->n;
     EHIP(hipMalloc((void**)&e->outs[1].reward, N * sizeof(int32_t)));
     EHIP(hipMalloc((void**)&e->outs[1].done, N));
@@ -539,12 +542,19 @@ static int pipe_prepare(tbx_engine* e)
     EHIP(hipMemset(e->outs[1].packed, 0, N * sizeof(uint64_t)));
     EHIP(hipEventCreateWithFlags(&p.step_ev, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) {
-        EHIP(hipStreamCreateWithFlags(&p.render_stream[k], hipStreamNonBlocking));
         EHIP(hipEventCreateWithFlags(&p.render_ev[k], hipEventDisableTiming));
         EHIP(hipEventCreateWithFlags(&p.user_step_ev[k], hipEventDisableTiming));
         EHIP(hipEventCreateWithFlags(&p.user_frame_ev[k], hipEventDisableTiming));
     }
-    EHIP(hipStreamCreateWithFlags(&p.step_stream, hipStreamNonBlocking));
+    // The two internal streams are created with the highest priority.  Not for the priority's sake: the runtime multiplexes the
+    // streams of a process onto a few hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES, 4 by default), two streams that
+    // land on one queue do not overlap, and which streams share depends on the creation history of the whole process.  The
+    // high-priority pool is the lanes' own (measured: with ordinary streams the overlapped modes were faster or slower than
+    // the serial loop from one process to the next; scripts/pipeline_sweep.py).
+    int lo = 0, hi = 0;
+    EHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));     // numerically hi <= lo
+    EHIP(hipStreamCreateWithPriority(&p.lane[0], hipStreamNonBlocking, hi));
+    EHIP(hipStreamCreateWithPriority(&p.lane[1], hipStreamNonBlocking, hi));
     return TBX_OK;
 }
 
@@ -556,24 +566,29 @@ static int pipe_enter(tbx_engine* e)
     if (e->serve_running) EHIP(tbx_serve_stop(e));
     int rc = pipe_prepare(e);
     if (rc) return rc;
-    EHIP(tbx_wait_tail(e, p.step_stream));
-    EHIP(tbx_wait_tail(e, p.render_stream[0]));
-    EHIP(tbx_wait_tail(e, p.render_stream[1]));
-    for (int k = 0; k < 2; k++) p.render_pending[k] = p.user_step_rec[k] = p.user_frame_rec[k] = false;
+    EHIP(tbx_wait_tail(e, p.lane[0]));
+    EHIP(tbx_wait_tail(e, p.lane[1]));
+    for (int k = 0; k < 2; k++) { p.render_pending[k] = p.user_step_rec[k] = p.user_frame_rec[k] = false; p.render_on[k] = nullptr; }
     p.step_outstanding = false;
+    p.step_on = nullptr;
+    p.frame_par = -1;
     p.active = true;
     return TBX_OK;
 }
 
-static int pipe_step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t user)
+static int pipe_step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t user, int mode)
 {
     int rc = pipe_enter(e);
     if (rc) return rc;
     TbxPipe& p = e->pipe;
-    hipStream_t ss = p.step_stream;
     const int cur = e->out_par, wp = cur ^ 1;                  // this step writes output set wp ...
     const int rw = e->ops->records_parity() ^ 1;               // ... and records buffer rw
-    if (p.render_pending[rw]) { EHIP(hipStreamWaitEvent(ss, p.render_ev[rw], 0)); p.render_pending[rw] = false; }
+    hipStream_t ss = mode == 3 ? p.lane[wp] : p.lane[0];
+    if (p.step_outstanding && p.step_on != ss) EHIP(hipStreamWaitEvent(ss, p.step_ev, 0));          // the state step N-1 left
+    if (p.render_pending[rw]) {                                                                      // the reader of records rw
+        if (p.render_on[rw] != ss) EHIP(hipStreamWaitEvent(ss, p.render_ev[rw], 0));
+        p.render_pending[rw] = false;
+    }
     if (p.user_step_rec[wp]) { EHIP(hipStreamWaitEvent(ss, p.user_step_ev[wp], 0)); p.user_step_rec[wp] = false; }
     // whatever the caller has queued so far may read the current outputs: the step after this one waits for it
     EHIP(hipEventRecord(p.user_step_ev[cur], user));
@@ -585,6 +600,7 @@ static int pipe_step(tbx_engine* e, const ActionSource& src, uint32_t flags, hip
     EHIP(hipEventRecord(p.step_ev, ss));
     EHIP(hipStreamWaitEvent(user, p.step_ev, 0));
     p.step_outstanding = true;
+    p.step_on = ss;
     e->last_stream = user;
     e->has_last = true;
     return TBX_OK;
@@ -599,10 +615,9 @@ static int pipe_render(tbx_engine* e, uint8_t* out_dev, int channels, hipStream_
     const bool overlap = mode == 3 && out_dev == nullptr;
     const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
     hipStream_t rs = user;                                     // (U already waits for the step: pipe_step made it)
-    int fp = p.frame_par;
     if (overlap) {
-        fp ^= 1;
-        rs = p.render_stream[fp];
+        const int fp = rp;                                     // frame buffer and stream follow the records' parity
+        rs = p.lane[fp];
         if (p.frame_bytes[fp] < bytes) {
             EHIP(hipStreamSynchronize(rs));
             if (p.frame[fp]) hipFree(p.frame[fp]);
@@ -611,28 +626,35 @@ static int pipe_render(tbx_engine* e, uint8_t* out_dev, int channels, hipStream_
             EHIP(hipMalloc((void**)&p.frame[fp], bytes));
             p.frame_bytes[fp] = bytes;
         }
-        if (p.step_outstanding) EHIP(hipStreamWaitEvent(rs, p.step_ev, 0));
+        if (p.step_outstanding && p.step_on != rs) EHIP(hipStreamWaitEvent(rs, p.step_ev, 0));
+        // Readers of a frame are queued on U before the next render call.  Fence what is there now; the render into the OTHER
+        // buffer waits for the fence of the call before (readers of what that buffer held), a second render into the SAME
+        // buffer for the one just recorded.
+        const int prev = p.frame_par < 0 ? fp ^ 1 : p.frame_par;
+        EHIP(hipEventRecord(p.user_frame_ev[prev], user));
+        p.user_frame_rec[prev] = true;
         if (p.user_frame_rec[fp]) { EHIP(hipStreamWaitEvent(rs, p.user_frame_ev[fp], 0)); p.user_frame_rec[fp] = false; }
-        // readers of the frame the previous render wrote, queued so far: the render after this one waits for them
-        EHIP(hipEventRecord(p.user_frame_ev[p.frame_par], user));
-        p.user_frame_rec[p.frame_par] = true;
         out_dev = p.frame[fp];
     } else if (!out_dev) {
         rc = ensure_frame(e, bytes);
         if (rc) return rc;
-        out_dev = e->frame;
+        out_dev = e->frame_own;
     }
     if (((uintptr_t)out_dev & 15u) != 0) return e->fail(TBX_E_INVALID, "frame buffer must be 16-byte aligned");
-    if (p.render_pending[rp]) EHIP(hipStreamWaitEvent(rs, p.render_ev[rp], 0));    // (another render of the same records)
+    if (p.render_pending[rp] && p.render_on[rp] != rs) EHIP(hipStreamWaitEvent(rs, p.render_ev[rp], 0));   // (another render of these records)
     rc = e->ops->render(e, out_dev, channels, 0, e->n, rs);
     if (rc) return rc;
     EHIP(hipEventRecord(p.render_ev[rp], rs));
     p.render_pending[rp] = true;
+    p.render_on[rp] = rs;
     if (overlap) {
         EHIP(hipStreamWaitEvent(user, p.render_ev[rp], 0));
-        p.frame_par = fp;
-        e->frame = p.frame[fp];
-        e->frame_bytes = p.frame_bytes[fp];
+        p.frame_par = rp;
+        e->frame = p.frame[rp];
+        e->frame_bytes = p.frame_bytes[rp];
+    } else if (out_dev == e->frame_own) {
+        e->frame = e->frame_own;
+        e->frame_bytes = e->frame_own_bytes;
     }
     e->last_stream = user;
     e->has_last = true;
@@ -649,7 +671,7 @@ int tbx_step_synthetic(tbx_engine* e, uint64_t action_seed, uint64_t t, uint64_t
     src.t = t;
     src.env_offset = env_offset;
     src.single_env = -1;
-    if (pipe_mode(e)) return pipe_step(e, src, flags, (hipStream_t)stream);
+    if (const int mode = pipe_mode(e)) return pipe_step(e, src, flags, (hipStream_t)stream, mode);
     EHIP(tbx_use_stream(e, (hipStream_t)stream));
     EHIP(tbx_gather_before_step(e, (hipStream_t)stream));
     return e->ops->step(e, src, flags, (hipStream_t)stream);

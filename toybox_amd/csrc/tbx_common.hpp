@@ -281,17 +281,19 @@ struct TbxStepOut {
 // Pipelined mode (TBX_OPT_PIPELINE, engine.hip): random-rollout steps and batch renders of engines whose rasteriser reads
 // step-written records run on internal streams, over double-buffered records, step outputs and frames.
 struct TbxPipe {
-    hipStream_t step_stream = nullptr, render_stream[2] = {nullptr, nullptr};
-    hipEvent_t step_ev = nullptr;                    // behind the last pipelined step
-    hipEvent_t render_ev[2] = {nullptr, nullptr};    // behind the last render that READ records buffer p
+    hipStream_t lane[2] = {nullptr, nullptr};        // value 2: lane[0] is the step stream; value 3: step N and render N on lane[parity]
+    hipEvent_t step_ev = nullptr;                    // behind the last pipelined step ...
+    hipStream_t step_on = nullptr;                   // ... which ran on this stream
+    hipEvent_t render_ev[2] = {nullptr, nullptr};    // behind the last render that READ records buffer p ...
+    hipStream_t render_on[2] = {nullptr, nullptr};   // ... which ran on this stream
     bool render_pending[2] = {false, false};
-    // reader fences on the caller's stream: everything the caller queued there before the step (render) call that made
-    // buffer p the current one was superseded -- the next writer of buffer p waits for it
+    // reader fences on the caller's stream: everything the caller had queued there when the step (render) call that
+    // superseded buffer p's content was made -- the next writer of buffer p waits for it
     hipEvent_t user_step_ev[2] = {nullptr, nullptr}, user_frame_ev[2] = {nullptr, nullptr};
     bool user_step_rec[2] = {false, false}, user_frame_rec[2] = {false, false};
     bool active = false;          // the last call through the handle was a pipelined step or render
     bool step_outstanding = false;
-    int frame_par = 0;            // frame buffer the last overlapped render wrote
+    int frame_par = -1;           // frame buffer the last overlapped render wrote (-1: none since the pipeline was entered)
     uint8_t* frame[2] = {nullptr, nullptr};
     size_t frame_bytes[2] = {0, 0};
 };
@@ -301,7 +303,7 @@ struct tbx_engine {
     mutable std::string err;
     hipStream_t stream = nullptr;   // engine-owned stream used by the host-pointer entry points
     // cross-stream ordering of everything queued through this handle (tbx_use_stream): the stream the last call used.  It may
-    // be the caller's; tbx_wait_tail copes with a handle that has been destroyed since.
+    // be the caller's, which therefore has to outlive the next call on the handle (tbx_sync forgets it).
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     hipEvent_t order_ev = nullptr;
@@ -352,9 +354,9 @@ struct tbx_engine {
 
 hipError_t tbx_serve_stop(tbx_engine* e);   // engine.hip
 
-// Stream `s` waits for everything queued so far on the stream the previous call used.  That stream may have been the
-// caller's and may be gone by now (created for one call, synchronised, destroyed): the runtime refuses the stale handle,
-// and since nothing can be recorded behind work on a stream that no longer exists, the device is synchronised instead.
+// Stream `s` waits for everything queued so far on the stream the previous call used.  That stream may be the caller's: the
+// handle is kept until the next call or tbx_sync (toybox_amd.h: a stream named in a call must stay alive that long -- the
+// runtime does not survive an event record on a destroyed stream, so a stale handle cannot be detected here).
 inline hipError_t tbx_wait_tail(tbx_engine* e, hipStream_t s)
 {
     if (!e->has_last || e->last_stream == s) return hipSuccess;
@@ -363,11 +365,6 @@ inline hipError_t tbx_wait_tail(tbx_engine* e, hipStream_t s)
         if (r != hipSuccess) return r;
     }
     hipError_t r = hipEventRecord(e->order_ev, e->last_stream);
-    if (r == hipErrorContextIsDestroyed || r == hipErrorInvalidHandle || r == hipErrorInvalidResourceHandle || r == hipErrorInvalidValue) {
-        (void)hipGetLastError();
-        e->has_last = false;
-        return hipDeviceSynchronize();
-    }
     if (r != hipSuccess) return r;
     return hipStreamWaitEvent(s, e->order_ev, 0);
 }
