@@ -537,7 +537,7 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  *
  * TBX_OPT_PIPELINE -- random-rollout loops (tbx_step_synthetic + tbx_render_device) only; 0 = off (default).
  *   A step whose actions are generated on the device depends on nothing the previous frame's rasteriser produces, and a
- *   rasteriser that reads step-written render records (Breakout) disturbs nothing the next step touches.  With the option
+ *   rasteriser that reads step-written render records (Breakout, SpaceInvaders) disturbs nothing the next step touches.  With the option
  *   on, such engines keep TWO sets of render records, of step outputs (TBX_BUF_REWARD / DONE / LIVES / SCORE / PACKED) and
  *   -- for tbx_render_device(out_dev = NULL) -- of TBX_BUF_FRAME, and run the calls on internal streams:
  *     value 2: tbx_step_synthetic N+1 runs beside the rasteriser of frame N;
@@ -552,7 +552,8 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  *   the result; the result of step N (render N) stays valid for readers queued on that stream BEFORE step N+1 (render N+1)
  *   is issued -- the same rule as without the option -- but it lives at the address tbx_device_buffer reports after the
  *   call, which alternates.  Every other call on the handle first joins the pipeline.  Engines whose rasteriser reads live
- *   state (SpaceInvaders, Amidar, GridWorld, Breakout with intervention-written bricks) ignore the option. */
+ *   state (Amidar, GridWorld, Breakout with intervention-written bricks, SpaceInvaders with intervention-written enemy
+ *   positions) ignore the option. */
 #define TBX_OPT_PIPELINE      0
 /* batch step kernel form of Breakout and Amidar: 0 = the engine's choice (by batch size), 1 = one thread per env, 2 = one
  * wavefront per env */
@@ -567,6 +568,10 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
 #define TBX_OPT_COUNT         5
 /* read-only (tbx_get_option): what TBX_OPT_PIPELINE resolves to on this engine right now -- 0, 2 or 3 */
 #define TBX_OPT_PIPELINE_ACTIVE 100
+/* read-only: 1 while the rasteriser reads step-written render records (Breakout with the canonical wall, SpaceInvaders with
+ * the canonical formation), 0 once an intervention has switched the engine to the state-reading rasteriser, or for games
+ * without records */
+#define TBX_OPT_RECORDS_ACTIVE  101
 int tbx_set_option(tbx_engine* engine, int option, int value);
 int tbx_get_option(tbx_engine* engine, int option, int* value_out);
 /* Block until all work queued by this engine has finished; reports a pending TBX_E_ACTION. */

@@ -554,3 +554,99 @@ def test_fuzzed_states_parity(game, fuzz, fuzz_seed, hip_lib, oracle_lib):
         a = synthetic_actions(game, n, t, seed=3)
         for p, q in zip(g.agent_step(a), o.agent_step(a)):
             assert np.array_equal(p, q), t
+
+
+def _fuzz_si_on_the_grid(st, rng, extreme):
+    """everything the record rasteriser digests, with the formation left on its grid (moved as a whole): sprites half off every
+    edge, rectangles far outside the frame, coordinates at the ends of int32"""
+    _fuzz_si(st, rng)
+    x0 = int(rng.integers(-130, 330)); y0 = int(rng.integers(-120, 215))
+    for j in range(st.n_enemies):
+        st.enemies[j].x, st.enemies[j].y = x0 + 32 * (j % 6), y0 + 18 * (j // 6)
+    big = 2 ** 30 - 1
+    if extreme == 1:
+        st.ship_x, st.ufo_x = -big, big
+        for k in range(st.n_enemy_lasers):
+            st.enemy_lasers[k].x, st.enemy_lasers[k].w = -big + k, big       # far left, reaching back onto the screen
+        for k in range(st.n_shields):
+            st.shield_x[k] = int(rng.choice([-big, big, -17, 318]))
+    elif extreme == 2:
+        for j in range(st.n_enemies):
+            st.enemies[j].x, st.enemies[j].y = big - 200 + 32 * (j % 6), -big + 18 * (j // 6)
+        st.ship_y, st.ufo_y = int(rng.integers(-30, 230)), int(rng.integers(-30, 230))
+        for k in range(st.n_enemy_lasers):
+            st.enemy_lasers[k].y, st.enemy_lasers[k].h = -5, big
+        for k in range(st.n_shields):
+            st.shield_y[k] = int(rng.choice([-9, 200, big]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows", [6, 10])
+def test_space_invaders_record_rasteriser_fuzz(n_rows, hip_lib, oracle_lib):
+    """SpaceInvaders' rasteriser paints from records the step kernel leaves behind (formation origin + alive / exploding masks,
+    clipped laser rectangles, clamped sprite positions) as long as the enemies sit on the formation grid.  Fuzzed states ON the
+    grid, frames in every format: straight after the write (records rebuilt from state), after steps (records written by the step
+    kernel), with the steps running beside the rasteriser (pipelined mode), and back to the state-reading rasteriser when one
+    env leaves the grid."""
+    from toybox_amd import hip
+    n = 120
+    with Engine("space_invaders", 1, lib=oracle_lib) as e0:
+        cfg = e0.get_config()
+    cfg.n_rows = n_rows
+    for i in range(n_rows):
+        cfg.row_scores[i] = 5 * (n_rows - i)
+    g, o = Engine("space_invaders", n, lib=hip_lib, config=cfg), Engine("space_invaders", n, lib=oracle_lib, config=cfg)
+    for e in (g, o):
+        e.seed(4); e.new_game()
+    assert g.get_option(_abi.OPT_RECORDS_ACTIVE) == 1
+    assert np.array_equal(g.render(3), o.render(3))                      # straight after a new game
+    for t in range(150):
+        a = synthetic_actions("space_invaders", n, t, seed=2)
+        g.step(a); o.step(a)
+    rng = np.random.default_rng(77 + n_rows)
+    recs = o.get_states(0, n)
+    for i in range(n):
+        _fuzz_si_on_the_grid(recs[i], rng, i % 4 if i % 4 < 3 else 0)
+    for e in (g, o):
+        e.set_states(0, recs)
+    assert g.get_option(_abi.OPT_RECORDS_ACTIVE) == 1                    # still on the grid
+    _assert_states_equal(g, o, range(n))
+    for ch in (1, 3, 4):
+        assert np.array_equal(g.render(ch), o.render(ch)), ch
+    for i in (0, 1, 2, n - 1):
+        assert np.array_equal(g.render_env(i, 3), o.render_env(i, 3)), i
+    for t in range(120):                                                # records now come from the step kernel
+        a = synthetic_actions("space_invaders", n, t, seed=9)
+        rg, ro = g.step(a, auto_reset=True), o.step(a, auto_reset=True)
+        for x, y in zip(rg, ro):
+            assert np.array_equal(x, y), t
+        if t % 17 == 0:
+            assert np.array_equal(g.render(3), o.render(3)), t
+    g.set_option(_abi.OPT_PIPELINE, 2)                                  # steps beside the previous frame's rasteriser
+    assert g.get_option(_abi.OPT_PIPELINE_ACTIVE) == 2
+    st = hip.Stream()
+    H, W = g.height, g.width
+    one = np.empty((H, W, 3), np.uint8)
+    for t in range(120, 200):
+        g.step_synthetic(1337, t, auto_reset=True, stream=st.ptr)
+        g.render_device(0, 3, stream=st.ptr)
+        o.step(synthetic_actions("space_invaders", n, t, seed=1337), auto_reset=True)
+        if t % 13 == 0:
+            st.synchronize()
+            p, _ = g.device_buffer(_abi.BUF_FRAME)
+            for i in (0, 7, n - 1):
+                hip.memcpy_dtoh(one, p + i * H * W * 3, H * W * 3)
+                assert np.array_equal(one, o.render_env(i, 3)), (t, i)
+    g.sync()
+    _assert_states_equal(g, o, range(n))
+    s5 = o.get_state(5)
+    s5.enemies[3].x += 1                                                 # one enemy off the grid: records can no longer describe it
+    for e in (g, o):
+        e.set_state(5, s5)
+    assert g.get_option(_abi.OPT_RECORDS_ACTIVE) == 0 and g.get_option(_abi.OPT_PIPELINE_ACTIVE) == 0
+    for t in range(200, 230):
+        g.step_synthetic(1337, t, auto_reset=True, stream=st.ptr)
+        o.step(synthetic_actions("space_invaders", n, t, seed=1337), auto_reset=True)
+    g.sync()
+    for ch in (1, 3, 4):
+        assert np.array_equal(g.render(ch), o.render(ch)), ch

@@ -497,7 +497,7 @@ def test_step1_on_a_batch_engine(lib, oracle_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("game,n,mode", [("breakout", 40000, 2), ("breakout", 40000, 3), ("breakout", 3000, 3), ("breakout", 3000, 1),
-                                         ("amidar", 20000, 3)])
+                                         ("space_invaders", 20000, 2), ("space_invaders", 3000, 3), ("amidar", 20000, 3)])
 @pytest.mark.parametrize("same_stream", [True, False])
 def test_pipelined_mode_keeps_program_order(same_stream, game, n, mode, hip_lib, oracle_lib):
     """TBX_OPT_PIPELINE: tbx_step_synthetic on Breakout runs on the engine's step stream BESIDE the rasteriser launch queued

@@ -26,6 +26,7 @@ GATHER_ID_BYTES = 128
 # engine options (tbx_set_option)
 OPT_PIPELINE, OPT_STEP_FORM, OPT_RENDER_SPLIT, OPT_AGENT_GENERIC, OPT_RESIDENT_STEP = 0, 1, 2, 3, 4
 OPT_PIPELINE_ACTIVE = 100          # read-only: what OPT_PIPELINE resolves to on the engine
+OPT_RECORDS_ACTIVE = 101           # read-only: the rasteriser reads step-written render records
 PIPELINE_OFF, PIPELINE_AUTO, PIPELINE_STEP_BESIDE_RENDER, PIPELINE_OVERLAP_RENDERS = 0, 1, 2, 3
 STEP_FORM_AUTO, STEP_FORM_THREAD_PER_ENV, STEP_FORM_WAVE_PER_ENV = 0, 1, 2
 

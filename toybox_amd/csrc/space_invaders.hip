@@ -570,6 +570,104 @@ __device__ __forceinline__ void si_step(const SiCfg& c, int lane, uint32_t butto
     }
 }
 
+// ------------------------------------------------------------------ rasteriser input record
+//
+// What the rasteriser needs of one env, digested by whoever holds the env's state in registers -- the batch step kernel, or
+// si_rec_prep_kernel after anything else touched the state.  The painter's set-up becomes a few scalar loads and ~300
+// instructions instead of a 2.2 KB gather of state rows followed by ~1 500 dependent instructions (five times per RGB
+// frame), and -- as for Breakout -- a step may run while the previous frame is still being painted, because the painter no
+// longer reads live state (there are two buffers of records: GameOps::step_ahead).
+//
+// CANONICAL formation only: enemy i sits at (fx + 32 (i % 6), fy + 18 (i / 6)) with row = i / 6, col = i % 6.  Every game the
+// engine starts is like that and stays like that (the whole formation marches in lockstep, dead enemies included); an
+// intervention that writes other enemy coordinates switches the engine to the state-reading rasteriser (SiOps::custom).
+// Coordinates are clamped to +-1000 (far off screen either way), rectangles are clipped to the screen.
+struct alignas(128) SiRenderRec {
+    int32_t fx, fy;                    // formation origin
+    uint32_t vis_lo, vis_hi;           // bit i: enemy i is drawn (alive or exploding)
+    uint32_t alive_lo, alive_hi;       // bit i: ... with its marching sprite (else the explosion)
+    uint32_t flags;                    // REC_* below
+    uint32_t hud;                      // 4-bit digits: score 10^4..10^0 (bits 0..19), lives (20..23), level (24..27)
+    int32_t ship_x, ship_y;
+    uint32_t ship_color;
+    int32_t ufo_x, ufo_y;
+    uint32_t shield_xy[TBX_SI_MAX_SHIELDS];      // (uint16)x | (uint16)y << 16, two's complement
+    uint32_t shield_color[TBX_SI_MAX_SHIELDS];
+    uint32_t _pad0;
+    uint32_t laser_x[12], laser_y[12];           // slot 0..7 enemy lasers, 8 the ship's: x0 | x1 << 16, y0 | y1 << 16 (clipped; 0 = none)
+    uint32_t laser_color[12];
+    uint16_t shield_rows[64];                    // lane = shield * 18 + row
+    uint32_t _pad1[8];
+};
+static_assert(sizeof(SiRenderRec) == 384, "render record layout");
+constexpr int REC_HDR_DWORDS = 20;
+enum { REC_ORIENT = 1u << 7, REC_UFO = 1u << 8, REC_SHIP_SHIFT = 9, REC_SHIELDS_SHIFT = 11 };   // bits 0..6: n_enemies
+
+__device__ __forceinline__ int32_t clamp_coord(int32_t v) { return v < -1000 ? -1000 : v > 1000 ? 1000 : v; }
+
+__device__ __forceinline__ uint32_t si_hud_word(int sc, int lv, int le)
+{
+    if (sc < 0) sc = 0;
+    sc %= 100000;
+    lv = lv < 0 ? 0 : lv > 9 ? 9 : lv;
+    if (le < 0) le = 0;
+    le %= 10;
+    uint32_t hud = 0;
+    int div = 10000;
+#pragma unroll
+    for (int g = 0; g < 5; g++) { hud |= (uint32_t)((sc / div) % 10) << (4 * g); div /= 10; }
+    return hud | ((uint32_t)lv << 20) | ((uint32_t)le << 24);
+}
+
+// every lane of the env's wave calls this with the env's state in `s`
+__device__ __forceinline__ void si_write_rec(SiRenderRec* __restrict__ rec, int lane, const SiRegs& s)
+{
+    const int32_t* f = s.f;
+    const int ne = f[F_N_ENEMIES];
+    const uint64_t alive = __ballot(lane < ne && e_alive(s));
+    const uint64_t vis = __ballot(lane < ne && (e_alive(s) || e_dc(s) >= 0));
+    const int pose = (f[F_SHIP_FLAGS] & 1) ? 1 : f[F_SHIP_DC] >= 0 ? ((f[F_SHIP_FLAGS] & 2) ? 2 : 3) : 0;
+    const bool ufo_on = f[F_UFO_APP] == 0 || f[F_UFO_DC] >= 0;
+    uint32_t h[REC_HDR_DWORDS];
+    h[0] = (uint32_t)clamp_coord(ne > 0 ? __builtin_amdgcn_readlane(s.ex, 0) : 0);
+    h[1] = (uint32_t)clamp_coord(ne > 0 ? __builtin_amdgcn_readlane(s.ey, 0) : 0);
+    h[2] = (uint32_t)vis; h[3] = (uint32_t)(vis >> 32);
+    h[4] = (uint32_t)alive; h[5] = (uint32_t)(alive >> 32);
+    h[6] = (uint32_t)(ne & 127) | (f[F_ORIENT] ? REC_ORIENT : 0u) | (ufo_on ? REC_UFO : 0u) | ((uint32_t)pose << REC_SHIP_SHIFT) |
+           ((uint32_t)(f[F_N_SHIELDS] & 3) << REC_SHIELDS_SHIFT);
+    h[7] = si_hud_word(f[F_SCORE], f[F_LIVES], f[F_LEVEL]);
+    h[8] = (uint32_t)clamp_coord(f[F_SHIP_X]); h[9] = (uint32_t)clamp_coord(f[F_SHIP_Y]);
+    h[10] = (uint32_t)f[F_SHIP_COLOR];
+    h[11] = (uint32_t)clamp_coord(f[F_UFO_X]); h[12] = (uint32_t)clamp_coord(f[F_UFO_Y]);
+#pragma unroll
+    for (int k = 0; k < TBX_SI_MAX_SHIELDS; k++) {
+        h[13 + k] = ((uint32_t)clamp_coord(f[F_SHIELD_X0 + k]) & 0xFFFFu) | ((uint32_t)clamp_coord(f[F_SHIELD_Y0 + k]) << 16);
+        h[16 + k] = (uint32_t)f[F_SHIELD_C0 + k];
+    }
+    h[19] = 0u;
+    uint32_t hv = 0u;                              // lane i holds header dword i: one 80-byte store
+#pragma unroll
+    for (int i = 0; i < REC_HDR_DWORDS; i++) asm("v_writelane_b32 %0, %1, %2" : "+v"(hv) : "s"(wave_uniform((int)h[i])), "n"(i));
+    uint32_t* out = reinterpret_cast<uint32_t*>(rec);
+    if (lane < REC_HDR_DWORDS) out[lane] = hv;
+    if (lane < 12) {
+        const bool on = lane == SHIP_SLOT ? f[F_HAS_SHIP_LASER] != 0 : lane < f[F_N_LASERS];
+        const long lx = s.lf[LF_X], ly = s.lf[LF_Y];
+        long x0 = lx, x1 = lx + s.lf[LF_W], y0 = ly, y1 = ly + s.lf[LF_H];
+        x0 = x0 < 0 ? 0 : x0 > TBX_SI_W ? TBX_SI_W : x0; x1 = x1 < x0 ? x0 : x1 > TBX_SI_W ? TBX_SI_W : x1;
+        y0 = y0 < 0 ? 0 : y0 > TBX_SI_H ? TBX_SI_H : y0; y1 = y1 < y0 ? y0 : y1 > TBX_SI_H ? TBX_SI_H : y1;
+        const bool show = on && x0 < x1 && y0 < y1;
+        rec->laser_x[lane] = show ? (uint32_t)x0 | ((uint32_t)x1 << 16) : 0u;
+        rec->laser_y[lane] = show ? (uint32_t)y0 | ((uint32_t)y1 << 16) : 0u;
+        rec->laser_color[lane] = show ? (uint32_t)s.lf[LF_COLOR] : 0u;
+    }
+    {
+        const int k = lane / TBX_SI_SHIELD_H;
+        const bool valid = lane < TBX_SI_MAX_SHIELDS * TBX_SI_SHIELD_H && k < f[F_N_SHIELDS];
+        rec->shield_rows[lane] = valid ? (uint16_t)s.srow : (uint16_t)0;
+    }
+}
+
 // ------------------------------------------------------------------ kernels
 
 __global__ __launch_bounds__(TBX_BLOCK) void si_new_game_kernel(SiDev d, SiCfg c, const uint8_t* mask)
@@ -596,7 +694,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_new_game_kernel(SiDev d, SiCfg c
 // instantiations because the kernel is bound by latency x occupancy: the batch protocol's form carries neither the slot
 // structs nor the frame loop and needs fewer registers
 template <bool AGENT>
-__device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a, const SiDev& slot_b, const SiCfg& c, const ActionSource& src, uint32_t flags, int env, int lane)
+__device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a, const SiDev& slot_b, const SiCfg& c, const ActionSource& src, uint32_t flags, int env, int lane,
+                                             SiRenderRec* __restrict__ recs = nullptr)
 {
     const size_t N = (size_t)d.n;
     if (AGENT) {
@@ -656,6 +755,7 @@ __device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a
     }
     if (AGENT) si_store(d, env, lane, s);                 // (the agent form keeps its registers for the frame loop)
     else si_store_changed(d, env, lane, s, loaded);
+    if (!AGENT && recs) si_write_rec(recs + env, lane, s);  // the rasteriser's input, while the state is in registers
     if (lane == 0) {
         d.prev_score[env] = prev;
         d.reward[env] = rew;
@@ -667,12 +767,24 @@ __device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a
     }
 }
 
-__global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
+__global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count,
+                                                            SiRenderRec* __restrict__ recs)
 {
     const int lane = threadIdx.x & 63;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     if (rel >= count) return;
-    si_step_body<false>(d, d, d, c, src, flags, first_env + rel, lane);
+    si_step_body<false>(d, d, d, c, src, flags, first_env + rel, lane, recs);
+}
+
+// records of envs [first_env, first_env + count) from their state (after a new game, a state write, an agent step ...)
+__global__ __launch_bounds__(TBX_BLOCK) void si_rec_prep_kernel(SiDev d, SiRenderRec* __restrict__ recs, int first_env, int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (rel >= count) return;
+    SiRegs s;
+    si_load(d, first_env + rel, lane, s);
+    si_write_rec(recs + first_env + rel, lane, s);
 }
 
 __global__ __launch_bounds__(TBX_BLOCK) void si_agent_step_kernel(SiDev d, SiDev slot_a, SiDev slot_b, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count)
@@ -1216,6 +1328,241 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
     }
 }
 
+// ------------------------------------------------------------------ the rasteriser over render records
+//
+// Same scanline composition and paint order as SiPainter (shields, enemies, ufo, ship, lasers, HUD), from a SiRenderRec.  The
+// header arrives by scalar loads; the enemy under a pixel group follows from the formation origin by arithmetic (no candidate
+// masks, no lane shuffles); lane = shield row and lane = laser slot keep their roles.  Which scanlines show anything but
+// background is worked out lane-parallel (lane l judges scanlines l, l + 64, l + 128, l + 192; four ballots).
+template <int C>
+struct SiRecPainter {
+    static constexpr int NG = SI_NG;
+    int lane;
+    int gx[SI_NG];
+    bool gact[SI_NG];
+    uint32_t hud[SI_NG][4];
+    uint32_t c_enemy, c_ufo, c_ground, c_hud, c_black, c_ship;
+    // wave-uniform
+    int fx, fy, ship_x, ship_y, ufo_x, ufo_y, n_enemies, n_rows, n_shields, pose;
+    uint64_t vis, alive;
+    bool orient, ufo_on;
+    int sh_x[TBX_SI_MAX_SHIELDS], sh_y[TBX_SI_MAX_SHIELDS];
+    uint32_t sh_c[TBX_SI_MAX_SHIELDS];
+    int e_y0, e_y1, l_lo, l_hi;
+    uint64_t busy[4];
+    // per lane
+    uint32_t srow;                         // lane = shield * 18 + row
+    uint32_t lz_x, lz_y, lz_c;             // lane = laser slot (clipped spans, finished colour)
+    int ecol[SI_NG], eshift[SI_NG];        // formation column whose sprites reach this pixel group (-1: none), sprite-row shift
+    const uint32_t* spr_lds;
+
+    __device__ __forceinline__ void setup(const SiRenderRec* __restrict__ recs, int env, int lane_)
+    {
+        lane = lane_;
+        const SiRenderRec* rec = recs + env;
+        const uint32_t* h = reinterpret_cast<const uint32_t*>(rec);     // wave-uniform address: scalar loads
+        fx = (int)h[0]; fy = (int)h[1];
+        vis = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
+        alive = (uint64_t)h[4] | ((uint64_t)h[5] << 32);
+        const uint32_t flags = h[6];
+        const uint32_t hudw = h[7];
+        ship_x = (int)h[8]; ship_y = (int)h[9];
+        c_ship = pix_of<C>(h[10]);
+        ufo_x = (int)h[11]; ufo_y = (int)h[12];
+        n_enemies = (int)(flags & 127u); orient = (flags & REC_ORIENT) != 0; ufo_on = (flags & REC_UFO) != 0;
+        pose = (int)((flags >> REC_SHIP_SHIFT) & 3u); n_shields = (int)((flags >> REC_SHIELDS_SHIFT) & 3u);
+        n_rows = (n_enemies + TBX_SI_COLS - 1) / TBX_SI_COLS;
+#pragma unroll
+        for (int k = 0; k < TBX_SI_MAX_SHIELDS; k++) {
+            sh_x[k] = (int)(int16_t)(h[13 + k] & 0xFFFFu); sh_y[k] = (int)(int16_t)(h[13 + k] >> 16);
+            sh_c[k] = pix_of<C>(h[16 + k]);
+        }
+        srow = rec->shield_rows[lane];
+        lz_x = lane < 12 ? rec->laser_x[lane] : 0u;
+        lz_y = lane < 12 ? rec->laser_y[lane] : 0u;
+        lz_c = pix_of<C>(lane < 12 ? rec->laser_color[lane] : 0u);
+
+        gx[0] = lane * 4; gx[1] = (lane + 64) * 4;
+        gact[0] = true; gact[1] = lane + 64 < TBX_SI_W / 4;
+        {
+            const int hud_x0[7] = {36, 44, 52, 60, 68, 148, 196};
+#pragma unroll
+            for (int g = 0; g < SI_NG; g++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) hud[g][i] = 0;
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+                const uint32_t glyph = SI_DIGITS[(hudw >> (4 * q)) & 15u];
+#pragma unroll
+                for (int g = 0; g < SI_NG; g++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int dx = gx[g] + i - hud_x0[q];
+                        if (dx >= 0 && dx < 6) hud[g][i] = (glyph >> (dx >> 1)) & 0x1249u;
+                    }
+            }
+        }
+        c_enemy = pix_of<C>(rgb_u32(TBX_SI_COL_ENEMY)); c_ufo = pix_of<C>(rgb_u32(TBX_SI_COL_UFO));
+        c_ground = pix_of<C>(rgb_u32(TBX_SI_COL_GROUND)); c_hud = pix_of<C>(rgb_u32(TBX_SI_COL_HUD));
+        c_black = pix_of<C>(0xFF000000u);
+        // the one formation column whose 16-pixel sprites can reach this lane's 4-pixel group (columns are 32 apart)
+#pragma unroll
+        for (int g = 0; g < SI_NG; g++) {
+            const int t = gx[g] + 3 - fx;
+            const int c = t >> 5, m = t & 31;
+            ecol[g] = (c >= 0 && c < TBX_SI_COLS && m < TBX_SI_ENEMY_W + 3) ? c : -1;
+            eshift[g] = m + 1;                                   // gx - (fx + 32 c) + 4, in [1, 19]
+        }
+        // scanline ranges that can hold enemies / lasers at all
+        e_y0 = INT32_MAX; e_y1 = INT32_MIN;
+        for (int r = 0; r < n_rows; r++)
+            if ((vis >> (TBX_SI_COLS * r)) & 63ull) { e_y0 = min(e_y0, fy + TBX_SI_ENEMY_DY * r); e_y1 = max(e_y1, fy + TBX_SI_ENEMY_DY * r + TBX_SI_ENEMY_H); }
+        l_lo = INT32_MAX; l_hi = INT32_MIN;
+#pragma unroll
+        for (int i = 0; i <= SHIP_SLOT; i++) {
+            const uint32_t ly = (uint32_t)__builtin_amdgcn_readlane((int)lz_y, i);
+            if (ly) { l_lo = min(l_lo, (int)(ly & 0xFFFFu)); l_hi = max(l_hi, (int)(ly >> 16)); }
+        }
+        // busy scanlines: lane l judges l, l + 64, l + 128, l + 192
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = lane + 64 * k;
+            bool on = (y >= 2 && y < 12) || y == TBX_SI_GROUND_Y;
+            on |= ufo_on && y >= ufo_y && y < ufo_y + TBX_SI_UFO_H;
+            on |= pose != 0 && y >= ship_y && y < ship_y + TBX_SI_SHIP_H;
+            if (y >= e_y0 && y < e_y1) {
+                const int dy = y - fy, r = dy / TBX_SI_ENEMY_DY;             // dy >= 0 here
+                on |= dy - r * TBX_SI_ENEMY_DY < TBX_SI_ENEMY_H && r < n_rows && ((vis >> (TBX_SI_COLS * r)) & 63ull) != 0;
+            }
+#pragma unroll
+            for (int q = 0; q < TBX_SI_MAX_SHIELDS; q++) on |= q < n_shields && y >= sh_y[q] && y < sh_y[q] + TBX_SI_SHIELD_H;
+            if (y >= l_lo && y < l_hi) {
+#pragma unroll
+                for (int i = 0; i <= SHIP_SLOT; i++) {
+                    const uint32_t ly = (uint32_t)__builtin_amdgcn_readlane((int)lz_y, i);
+                    on |= y >= (int)(ly & 0xFFFFu) && y < (int)(ly >> 16);
+                }
+            }
+            busy[k] = __ballot(on && y < TBX_SI_H);
+        }
+    }
+
+    __device__ __forceinline__ void paint_row(int y, uint32_t (&px)[SI_NG][4]) const
+    {
+        constexpr int NG = SI_NG;
+        const uint32_t base = y == TBX_SI_GROUND_Y ? c_ground : c_black;
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) px[g][i] = base;
+        // shields, ascending index
+#pragma unroll
+        for (int k = 0; k < TBX_SI_MAX_SHIELDS; k++) {
+            const int r = y - sh_y[k];
+            if (k < n_shields && r >= 0 && r < TBX_SI_SHIELD_H) {
+                const uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)srow, wave_uniform(k * TBX_SI_SHIELD_H + r));
+                if (bits) paint_bits<NG>(px, gx, sh_x[k], bits, TBX_SI_SHIELD_W, sh_c[k]);
+            }
+        }
+        // enemies of the formation row that crosses this scanline
+        if (y >= e_y0 && y < e_y1) {
+            const int dy = y - fy, r = dy / TBX_SI_ENEMY_DY, ry = dy - r * TBX_SI_ENEMY_DY;
+            if (ry < TBX_SI_ENEMY_H && r < n_rows) {
+                const uint32_t v6 = (uint32_t)(vis >> (TBX_SI_COLS * r)) & 63u, a6 = (uint32_t)(alive >> (TBX_SI_COLS * r)) & 63u;
+                if (v6) {
+                    const uint32_t march = spr_lds[(orient ? 0 : TBX_SI_ENEMY_H) + ry] & ((1u << TBX_SI_ENEMY_W) - 1u);
+                    const uint32_t boom = spr_lds[2 * TBX_SI_ENEMY_H + ry] & ((1u << TBX_SI_ENEMY_W) - 1u);
+#pragma unroll
+                    for (int g = 0; g < NG; g++) {
+                        const int c = ecol[g];
+                        if (c >= 0 && ((v6 >> c) & 1u)) {
+                            const uint32_t bits = ((a6 >> c) & 1u) ? march : boom;
+                            const uint32_t four = ((bits << 4) >> eshift[g]) & 15u;
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                if ((four >> i) & 1u) px[g][i] = c_enemy;
+                        }
+                    }
+                }
+            }
+        }
+        if (ufo_on && y >= ufo_y && y < ufo_y + TBX_SI_UFO_H) paint_bits<NG>(px, gx, ufo_x, spr_lds[SPR_UFO + (y - ufo_y)], TBX_SI_UFO_W, c_ufo);
+        if (pose != 0 && y >= ship_y && y < ship_y + TBX_SI_SHIP_H)
+            paint_bits<NG>(px, gx, ship_x, spr_lds[(pose == 1 ? SPR_SHIP : pose == 2 ? SPR_D1 : SPR_D2) + (y - ship_y)], 16, c_ship);
+        // lasers: the ship's first, then the enemies' in slot order
+        if (y >= l_lo && y < l_hi) {
+            uint64_t m = __ballot(lane <= SHIP_SLOT && y >= (int)(lz_y & 0xFFFFu) && y < (int)(lz_y >> 16));
+            if ((m >> SHIP_SLOT) & 1) {
+                const uint32_t lx = bcast(lz_x, SHIP_SLOT);
+                paint_span<NG>(px, gx, (long)(lx & 0xFFFFu), (long)(lx >> 16), bcast(lz_c, SHIP_SLOT));
+            }
+            m &= (1ull << SHIP_SLOT) - 1;
+            while (m) {
+                const int src = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t lx = bcast(lz_x, src);
+                paint_span<NG>(px, gx, (long)(lx & 0xFFFFu), (long)(lx >> 16), bcast(lz_c, src));
+            }
+        }
+        if (y >= 2 && y < 12) {
+            const int gr = ((y - 2) >> 1) * 3;
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if ((hud[g][i] >> gr) & 1u) px[g][i] = c_hud;
+        }
+    }
+};
+
+template <int C>
+__global__ __launch_bounds__(TBX_BLOCK) void si_rec_render_kernel(const SiRenderRec* __restrict__ recs, uint8_t* __restrict__ out, int first_env, int count, int split)
+{
+    constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
+    using Stager = RowStager<C, W, SI_UNIT_ROWS>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
+    __shared__ uint32_t spr_lds[SPR_WORDS];
+    si_fill_sprites(spr_lds);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    const int rel = wid / split, part = wid - rel * split;
+    if (rel >= count) return;
+    const int env = first_env + rel;
+    Stager st{lds_all + wave * Stager::UNIT_BYTES};
+    SiRecPainter<C> p;
+    p.spr_lds = spr_lds;
+    p.setup(recs, env, lane);
+    uint8_t* frame = out + (size_t)rel * H * W * C;
+    constexpr int NUNITS = H / SI_UNIT_ROWS;
+    const int u0 = split > 1 ? 0 : (int)(((uint32_t)env * 11u) % (uint32_t)NUNITS);
+    for (int k = part; k < NUNITS; k += split) {
+        int u = u0 + k;
+        if (u >= NUNITS) u -= NUNITS;
+        const uint32_t rows_busy = row_mask_chunk<SI_UNIT_ROWS>(p.busy, u * SI_UNIT_ROWS);
+        if (rows_busy == 0 && C != 4) {
+            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_black);
+            continue;
+        }
+#pragma unroll 1
+        for (int r = 0; r < SI_UNIT_ROWS; r++) {
+            const int y = u * SI_UNIT_ROWS + r;
+            uint32_t px[NG][4];
+            if ((rows_busy >> r) & 1u) p.paint_row(y, px);
+            else {
+#pragma unroll
+                for (int g = 0; g < NG; g++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) px[g][i] = p.c_black;
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+                if (p.gact[g]) st.put4p(r, lane + 64 * g, px[g][0], px[g][1], px[g][2], px[g][3]);
+        }
+        st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
+    }
+}
+
 // ------------------------------------------------------------------ fused agent observation
 //
 // max(frame A, frame B) -> gray -> area warp -> frame stack without the two full-resolution gray frames ever reaching
@@ -1352,6 +1699,14 @@ struct SiOps : GameOps {
     SiDev d{};
     SiCfg c{};
     tbx_si_config_t cfg{};
+    // rasteriser input records (SiRenderRec): two buffers, `recs` the current one.  Written by the batch step kernel; anything
+    // else that touches state clears recs_valid and the next render rebuilds them (si_rec_prep_kernel).  custom: an
+    // intervention wrote enemies off the formation grid -- records cannot describe that, the state-reading rasteriser paints.
+    SiRenderRec* recs = nullptr;
+    SiRenderRec* recs_other = nullptr;
+    int recs_par = 0;
+    bool recs_valid = false;
+    bool custom = false;
 
     int height() const override { return TBX_SI_H; }
     int width() const override { return TBX_SI_W; }
@@ -1386,11 +1741,14 @@ struct SiOps : GameOps {
         TBX_HIP(hipMalloc((void**)&d.enemies, N * NEF * 64 * sizeof(int32_t)));
         TBX_HIP(hipMalloc((void**)&d.shields, N * 64 * sizeof(uint32_t)));
         TBX_HIP(hipMalloc((void**)&d.lasers, N * NLF * 16 * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&recs, N * sizeof(SiRenderRec)));
+        TBX_HIP(hipMalloc((void**)&recs_other, N * sizeof(SiRenderRec)));
         return TBX_OK;
     }
 
     void destroy(tbx_engine*) override
     {
+        hipFree(recs); hipFree(recs_other);
         hipFree(d.rng); hipFree(d.sc); hipFree(d.enemies); hipFree(d.shields); hipFree(d.lasers);
         hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.enemies); hipFree(dA.shields); hipFree(dA.lasers);
         hipFree(dB.rng); hipFree(dB.sc); hipFree(dB.enemies); hipFree(dB.shields); hipFree(dB.lasers);
@@ -1410,6 +1768,7 @@ struct SiOps : GameOps {
     {
         hipLaunchKernelGGL(si_new_game_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, c, mask_dev);
         TBX_HIP(hipGetLastError());
+        recs_valid = false;
         return TBX_OK;
     }
 
@@ -1420,9 +1779,32 @@ struct SiOps : GameOps {
         if (src.acc_reward || src.buf_valid || src.exec_flag || src.frames > 1) {    // an agent step's frames (never auto-reset)
             if (flags & TBX_STEP_AUTO_RESET) return e->fail(TBX_E_INVALID, "an agent step cannot auto-reset");
             hipLaunchKernelGGL(si_agent_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, c, src, flags, first, count);
-        } else
-            hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count);
+            recs_valid = false;
+        } else {
+            // a whole-batch step leaves the rasteriser's records behind (canonical formations only)
+            const bool whole = src.single_env < 0 && !custom;
+            hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count, whole ? recs : nullptr);
+            recs_valid = whole;
+        }
         TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    // the rasteriser reads nothing but the records, and there are two buffers of them: a batch step can run while the previous
+    // frame is still being painted (engine.hip, pipelined mode)
+    bool pipeline_ok() const override { return !custom && recs_other != nullptr; }
+    int records_parity() const override { return recs_par; }
+    void rebind_outputs(tbx_engine* e) override
+    {
+        d.reward = e->reward; d.done = e->done; d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed;
+    }
+    int step_ahead(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(si_step_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, c, src, flags, 0, e->n, recs_other);
+        TBX_HIP(hipGetLastError());
+        std::swap(recs, recs_other);
+        recs_par ^= 1;
+        recs_valid = true;
         return TBX_OK;
     }
 
@@ -1430,6 +1812,7 @@ struct SiOps : GameOps {
     {
         hipLaunchKernelGGL(si_serve_kernel, dim3(1), dim3(64), 0, s, d, c, ctl_dev);
         TBX_HIP(hipGetLastError());
+        recs_valid = false;
         return TBX_OK;
     }
 
@@ -1478,6 +1861,7 @@ struct SiOps : GameOps {
         const dim3 grid = r.list ? dim3(std::min<unsigned>(grid_for(e->n).x, 512u)) : grid_for(e->n);
         hipLaunchKernelGGL(si_agent_reset_kernel, grid, dim3(TBX_BLOCK), 0, s, d, dA, dB, c, r);
         TBX_HIP(hipGetLastError());
+        recs_valid = false;
         return TBX_OK;
     }
 
@@ -1489,7 +1873,24 @@ struct SiOps : GameOps {
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
     {
-        return render_impl(e, d, d, nullptr, out_dev, channels, first_env, n_envs, s);
+        if (custom) return render_impl(e, d, d, nullptr, out_dev, channels, first_env, n_envs, s);
+        if (!recs_valid) {
+            hipLaunchKernelGGL(si_rec_prep_kernel, grid_for(n_envs), dim3(TBX_BLOCK), 0, s, d, recs, first_env, n_envs);
+            TBX_HIP(hipGetLastError());
+            if (first_env == 0 && n_envs == e->n) recs_valid = true;
+        }
+        // waves per frame: the set-up is light (a record, ~300 instructions), so RGB frames are cut finer than the
+        // state-reading rasteriser could afford: 35 six-row units over seven waves
+        const int split_opt = e->opt[TBX_OPT_RENDER_SPLIT];
+        const int split = split_opt > 0 ? split_opt : channels == 3 ? 7 : (channels == 4 && n_envs <= 32768) ? 5 : 1;
+        switch (channels) {
+        case 1: hipLaunchKernelGGL(si_rec_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, out_dev, first_env, n_envs, split); break;
+        case 3: hipLaunchKernelGGL(si_rec_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, out_dev, first_env, n_envs, split); break;
+        case 4: hipLaunchKernelGGL(si_rec_render_kernel<4>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, out_dev, first_env, n_envs, split); break;
+        default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+        }
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
     }
 
     int render_impl(tbx_engine* e, const SiDev& src, const SiDev& alt, const uint8_t* pick_alt, uint8_t* out_dev, int channels, int first_env,
@@ -1520,6 +1921,18 @@ struct SiOps : GameOps {
         return TBX_OK;
     }
 
+    // the formation grid the render records assume: enemy i at (x0 + 32 (i % 6), y0 + 18 (i / 6)), row i / 6, col i % 6
+    static bool is_canonical(const tbx_si_state_t& st)
+    {
+        for (int i = 0; i < st.n_enemies; i++) {
+            const tbx_si_enemy_t& en = st.enemies[i];
+            const int row = i / TBX_SI_COLS, col = i % TBX_SI_COLS;
+            if (en.row != row || en.col != col) return false;
+            if ((long)en.x != (long)st.enemies[0].x + TBX_SI_ENEMY_DX * col || (long)en.y != (long)st.enemies[0].y + TBX_SI_ENEMY_DY * row) return false;
+        }
+        return true;
+    }
+
     int pack_state(tbx_engine* e, int env, int count, hipStream_t s) override
     {
         hipLaunchKernelGGL(si_pack_kernel, dim3(count), dim3(64), 0, s, d, env, (tbx_si_state_t*)e->staging);
@@ -1541,9 +1954,13 @@ struct SiOps : GameOps {
                     return e->fail(TBX_E_UNSUPPORTED, "space_invaders: the device engine keeps an enemy's row, col (0..255) and id (0..65535) in one word");
             }
         }
+        if (!custom)
+            for (int i = 0; i < count && !custom; i++)
+                if (!is_canonical(sts[i])) custom = true;        // from now on the state-reading rasteriser paints, steps stay in stream order
         TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof(tbx_si_state_t) * (size_t)count, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(si_unpack_kernel, dim3(count), dim3(64), 0, s, d, env, (const tbx_si_state_t*)e->staging);
         TBX_HIP(hipGetLastError());
+        recs_valid = false;
         return TBX_OK;
     }
 
