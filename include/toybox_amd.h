@@ -389,6 +389,14 @@ int tbx_step_synthetic(tbx_engine* engine, uint64_t action_seed, uint64_t t, uin
  * first, so the two never run side by side.  On batch engines it is tbx_apply_input plus a read-back of the outputs
  * (TBX_OPT_RESIDENT_STEP = 0 forces that second form everywhere). */
 int tbx_step1(tbx_engine* engine, int env, int32_t ale_action, uint32_t flags, int32_t out[4]);
+/* The same step plus the env's picture, i.e. the whole of ToyboxBaseEnv.step (apply_ale_action, then get_state / get_rgb_frame:
+ * envs/atari/base.py:126,109,131-145; the env.step() arm of test/benchmark.py:83-97).  *frame_host receives the address of an
+ * engine-owned buffer of H * W * channels bytes (channels 1, 3 or 4) that holds the frame of the state AFTER the step and stays
+ * valid until the next call on the handle.  On a one-env engine the resident kernel rasterises straight into that buffer
+ * (pinned host memory mapped into the device): still no launch, no copy, no synchronisation.  Elsewhere it is tbx_step1
+ * followed by tbx_render_env into the same buffer. */
+int tbx_step1_frame(tbx_engine* engine, int env, int32_t ale_action, uint32_t flags, int channels, int32_t out[4],
+                    const uint8_t** frame_host);
 /* One frame for one env with a raw button mask.
  * replaces Toybox.apply_action(Input) (scripts/utils/test_games.py:13). */
 int tbx_apply_input(tbx_engine* engine, int env, uint32_t buttons);

@@ -49,6 +49,7 @@ struct tbx_engine {
     int32_t* noop_override;
     int pending_needs_reset;
     int opt[TBX_OPT_COUNT];
+    uint8_t* one_frame;     /* tbx_step1_frame's buffer */
 };
 
 static char g_err[256];
@@ -93,7 +94,7 @@ int tbx_destroy(tbx_engine* e)
 {
     if (!e) return TBX_OK;
     free(e->cfg); free(e->states); free(e->sim); free(e->prev); free(e->reward); free(e->lives);
-    free(e->score); free(e->done); free(e->packed); free(e->frame);
+    free(e->score); free(e->done); free(e->packed); free(e->frame); free(e->one_frame);
     gather_close(e);
     agent_free(e);
     free(e);
@@ -287,6 +288,23 @@ int tbx_step1(tbx_engine* e, int env, int32_t ale_action, uint32_t flags, int32_
         free(mask);
     }
     return bad ? fail(e, TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)") : TBX_OK;
+}
+
+/* the step of tbx_step1 followed by the picture of the state it left, in a buffer the engine owns (ToyboxBaseEnv.step) */
+int tbx_step1_frame(tbx_engine* e, int env, int32_t ale_action, uint32_t flags, int channels, int32_t out[4], const uint8_t** frame_host)
+{
+    if (!e) return TBX_E_INVALID;
+    if (frame_host) *frame_host = NULL;
+    if (channels != 1 && channels != 3 && channels != 4) return fail(e, TBX_E_INVALID, "channels must be 1, 3 or 4");
+    int rc = tbx_step1(e, env, ale_action, flags, out);
+    if (rc != TBX_OK && rc != TBX_E_ACTION) return rc;
+    int h = 0, w = 0;
+    orc_frame_dims(e->game, &h, &w);
+    if (!e->one_frame) e->one_frame = (uint8_t*)malloc((size_t)h * w * 4);
+    int rc2 = tbx_render_env(e, env, e->one_frame, channels);
+    if (rc2) return rc2;
+    if (frame_host) *frame_host = e->one_frame;
+    return rc;
 }
 
 int tbx_get_scalars(tbx_engine* e, int32_t* score, int32_t* lives, int32_t* level, uint8_t* over)

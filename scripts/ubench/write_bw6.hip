@@ -5,18 +5,32 @@
 #include <cstdio>
 #include <cstdint>
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("%s: %s\n",#x,hipGetErrorString(e)); return 1;}}while(0)
-__global__ __launch_bounds__(256) void units(uint4* out, int nframes, int frame16, int unit16, int nunits, int split, int rot)
+// occupancy is throttled from the host with dynamic LDS (bytes per block); nap: s_sleep units between two store instructions
+__global__ __launch_bounds__(256) void units(uint4* out, int nframes, int frame16, int unit16, int nunits, int split, int rot, int nap)
 {
+    extern __shared__ uint8_t lds_dyn[];
+    if (nframes < 0) lds_dyn[threadIdx.x] = 1;          // keep the allocation alive
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rel = wid / split, part = wid - rel * split;
     if (rel >= nframes) return;
     uint4* fr = out + (size_t)rel * frame16;
     const uint4 v = make_uint4(rel, part, 2, 3);
+    if (nap >= 1000) {                                   // stagger: waves start their store phase at different times
+        const int k = (int)(((unsigned)wid * 2654435761u) >> 29);          // 0..7
+        for (int j = 0; j < k * (nap - 1000); j++) __builtin_amdgcn_s_sleep(32);     // 32 * 64 clocks ~ 0.85 us per round
+        nap = 0;
+    }
     for (int q = part; q < nunits; q += split) {
         const int u = rot ? (int)(((unsigned)rel * 7u + (unsigned)q) % (unsigned)nunits) : q;
         uint4* dst = fr + (size_t)u * unit16;
-        for (int i = lane; i < unit16; i += 64) dst[i] = v;
+        for (int i = lane; i < unit16; i += 64) {
+            dst[i] = v;
+            if (nap == 1) __builtin_amdgcn_s_sleep(1);
+            else if (nap == 4) __builtin_amdgcn_s_sleep(4);
+            else if (nap == 16) __builtin_amdgcn_s_sleep(16);
+            else if (nap == 64) __builtin_amdgcn_s_sleep(64);
+        }
     }
 }
 template <typename F> float timeit(F f, int reps) {
@@ -29,26 +43,23 @@ int main() {
     const int nf = 65536;
     const size_t cap = (size_t)nf * 201600;
     uint4* p; CK(hipMalloc((void**)&p, cap));
-    struct Cfg { const char* name; int frame, unit, split, rot; };
+    struct Cfg { const char* name; int frame, unit, split, rot, lds, nap; };
     const Cfg cfgs[] = {
-        {"breakout 115200/5760 split10 rot", 115200, 5760, 10, 1}, {"breakout 115200/5760 split10", 115200, 5760, 10, 0},
-        {"breakout 115200/5760 split5", 115200, 5760, 5, 0},
-        {"si 201600/5760 split5", 201600, 5760, 5, 0}, {"si 201600/5760 split7", 201600, 5760, 7, 0}, {"si 201600/5760 split7 rot", 201600, 5760, 7, 1},
-        {"si 201600/5760 split12", 201600, 5760, 12, 0}, {"si 201600/5760 split18 rot", 201600, 5760, 18, 1},
-        {"si 201600/6720 split6", 201600, 6720, 6, 0}, {"si 201600/6720 split10", 201600, 6720, 10, 0}, {"si 201600/6720 split15", 201600, 6720, 15, 0},
-        {"si 201600/9600 split7", 201600, 9600, 7, 0}, {"si 201600/9600 split11", 201600, 9600, 11, 0},
-        {"si 201600/4800 split14", 201600, 4800, 14, 0}, {"si 201600/4800 split21", 201600, 4800, 21, 0},
-        {"si 201600/2880 split14", 201600, 2880, 14, 0}, {"si 201600/2880 split35", 201600, 2880, 35, 0},
-        {"si 201600/14400 split7", 201600, 14400, 7, 0}, {"si 201600/20160 split5", 201600, 20160, 5, 0}, {"si 201600/20160 split10", 201600, 20160, 10, 0},
-        {"amidar 120000/4800 split9", 120000, 4800, 9, 0}, {"amidar 120000/4800 split13", 120000, 4800, 13, 0}, {"amidar 120000/6000 split10", 120000, 6000, 10, 0},
-        {"amidar 120000/2400 split25", 120000, 2400, 25, 0},
+        {"breakout 5760 split10", 115200, 5760, 10, 0, 0, 0},
+        {"breakout 5760 split10 stagger1", 115200, 5760, 10, 0, 0, 1001}, {"breakout 5760 split10 stagger2", 115200, 5760, 10, 0, 0, 1002},
+        {"breakout 5760 split10 stagger4", 115200, 5760, 10, 0, 0, 1004}, {"breakout 5760 split10 stagger8", 115200, 5760, 10, 0, 0, 1008},
+        {"si 5760 split7", 201600, 5760, 7, 0, 0, 0},
+        {"si 5760 split7 stagger1", 201600, 5760, 7, 0, 0, 1001}, {"si 5760 split7 stagger2", 201600, 5760, 7, 0, 0, 1002},
+        {"si 5760 split7 stagger4", 201600, 5760, 7, 0, 0, 1004}, {"si 5760 split7 stagger8", 201600, 5760, 7, 0, 0, 1008},
+        {"si 5760 split5 stagger4", 201600, 5760, 5, 0, 0, 1004},
+        {"amidar 4800 split9", 120000, 4800, 9, 0, 0, 0}, {"amidar 4800 split9 stagger2", 120000, 4800, 9, 0, 0, 1002}, {"amidar 4800 split9 stagger4", 120000, 4800, 9, 0, 0, 1004},
     };
     for (int round = 0; round < 2; round++) {
         { const size_t b = (size_t)nf * 201600; float ms = timeit([&] { hipMemsetAsync(p, 1, b, 0); }, 5); printf("%-40s %8.3f ms %7.1f GB/s\n", "memset 13.2 GB", ms, b / ms / 1e6); }
         for (const Cfg& c : cfgs) {
             const int nun = c.frame / c.unit;
             const int grid = (nf * c.split + 3) / 4;
-            float ms = timeit([&] { units<<<grid, 256>>>(p, nf, c.frame / 16, c.unit / 16, nun, c.split, c.rot); }, 5);
+            float ms = timeit([&] { units<<<grid, 256, c.lds>>>(p, nf, c.frame / 16, c.unit / 16, nun, c.split, c.rot, c.nap); }, 5);
             printf("%-40s %8.3f ms %7.1f GB/s\n", c.name, ms, (double)nf * c.frame / ms / 1e6);
         }
     }

@@ -663,3 +663,56 @@ def test_options_are_validated_and_reported(hip_lib, oracle_lib):
             with pytest.raises(ToyboxAmdError):
                 e.set_option(opt, val)
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", GAMES)
+def test_step1_frame_resident_kernel_paints(game, hip_lib, oracle_lib):
+    """tbx_step1_frame = ToyboxBaseEnv.step in one call (envs/atari/base.py:126,109): on a one-env engine the resident kernel
+    steps AND rasterises into pinned host memory.  Outputs and frames in all three formats against the oracle through game
+    overs (auto-reset), interleaved with calls that stop the resident kernel (state reads, a batch render, a new game); then
+    the same entry point on a batch engine (launch + copy path)."""
+    g, o = Engine(game, 1, lib=hip_lib), Engine(game, 1, lib=oracle_lib)
+    for e in (g, o):
+        e.seed(21); e.new_game()
+    legal = LEGAL[game]
+    rng = np.random.default_rng(4)
+    dones = 0
+    for t in range(1500):
+        a = int(legal[int(rng.integers(len(legal)))]) if game != "breakout" or t % 9 else 1
+        ch = (1, 3, 4)[t % 3]
+        x, y = g.step1_frame(0, a, ch, auto_reset=True), o.step1_frame(0, a, ch, auto_reset=True)
+        assert x[:4] == y[:4], (t, x[:4], y[:4])
+        assert x[4].shape == (g.height, g.width, ch) and np.array_equal(x[4], y[4]), (t, ch)
+        dones += int(x[1])
+        if t % 211 == 210:
+            assert bytes(g.get_state(0)) == bytes(o.get_state(0)), t            # stops the resident kernel; it restarts on demand
+            assert np.array_equal(g.render(3), o.render(3))
+        if t == 700:
+            g.new_game(); o.new_game()
+    if game == "breakout":
+        assert dones > 0
+    with pytest.raises(ToyboxAmdError):
+        g.step1_frame(0, 0, 2)
+    # a custom-bricks / off-grid state keeps working (Breakout: wave-per-env step + record built on the spot; SpaceInvaders:
+    # state-reading painter)
+    if game in ("breakout", "space_invaders"):
+        st = o.get_state(0)
+        if game == "breakout":
+            st.bricks[3].w += 2.0
+        else:
+            st.enemies[2].x += 3
+        for e in (g, o):
+            e.set_state(0, st)
+        for t in range(60):
+            a = int(legal[t % len(legal)])
+            x, y = g.step1_frame(0, a, 3), o.step1_frame(0, a, 3)
+            assert x[:4] == y[:4] and np.array_equal(x[4], y[4]), t
+    # batch engine: the same call is tbx_apply_input + tbx_render_env
+    gb, ob = Engine(game, 5, lib=hip_lib), Engine(game, 5, lib=oracle_lib)
+    for e in (gb, ob):
+        e.seed(2); e.new_game()
+    for t in range(40):
+        env, a = t % 5, int(legal[t % len(legal)])
+        x, y = gb.step1_frame(env, a, 3), ob.step1_frame(env, a, 3)
+        assert x[:4] == y[:4] and np.array_equal(x[4], y[4]), t

@@ -256,6 +256,7 @@ PROTOTYPES = {
     "tbx_step_device": (_i, [_vp, _vp, _u32, _vp]),
     "tbx_step_synthetic": (_i, [_vp, _u64, _u64, _u64, _u32, _vp]),
     "tbx_step1": (_i, [_vp, _i, C.c_int32, _u32, _p(C.c_int32)]),
+    "tbx_step1_frame": (_i, [_vp, _i, C.c_int32, _u32, _i, _p(C.c_int32), _p(_vp)]),
     "tbx_apply_input": (_i, [_vp, _i, _u32]),
     "tbx_get_scalars": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "tbx_render": (_i, [_vp, _vp, _i]),

@@ -1257,14 +1257,6 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_agent_step_kernel(AmiDev d, Ami
     ami_step_body<true>(d, slot_a, slot_b, src, flags, first_env + rel, lane);
 }
 
-// resident single-env form (tbx_serve_loop, tbx_common.hpp): one wave, env 0
-__global__ __launch_bounds__(64) void ami_serve_kernel(AmiDev d, TbxServeCtl* ctl)
-{
-    const int lane = threadIdx.x & 63;
-    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { ami_step_body<false>(d, d, d, src, flags, 0, lane); },
-                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
-}
-
 // reset-time wrappers of the agent layer for the envs flagged in r.kind (agent_device.hpp, AgentResetProc)
 struct AmiAgentEnv {
     const AmiTables& c;
@@ -1517,6 +1509,36 @@ struct AmiGrayPainter : AmiPainter<1> {
     }
 };
 
+// units part, part + split, ... of one env's frame from a painter that has been set up, on one wave: the body of
+// ami_render_kernel and of the resident single-env kernel's paint request.  Background-only units are stored directly.
+template <int C>
+__device__ __forceinline__ void ami_paint_units(const AmiPainter<C>& p, uint8_t* __restrict__ frame, int env, int lane,
+                                                const RowStager<C, TBX_AMI_W, AMI_UNIT_ROWS>& st, int part, int split)
+{
+    constexpr int H = TBX_AMI_H;
+    using Stager = RowStager<C, TBX_AMI_W, AMI_UNIT_ROWS>;
+    constexpr int NUNITS = H / AMI_UNIT_ROWS;
+    const int u0 = split > 1 ? 0 : (int)(((uint32_t)env * 7u) % (uint32_t)NUNITS);
+    for (int k = part; k < NUNITS; k += split) {
+        int u = u0 + k;
+        if (u >= NUNITS) u -= NUNITS;
+        const int y_first = u * AMI_UNIT_ROWS;
+        const uint32_t mv_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.mv_rows, y_first);
+        const uint32_t busy_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.busy, y_first);
+        if (busy_chunk == 0 && C != 4) {                     // background only: no staging (RGBA: staged is faster)
+            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_bg);
+            continue;
+        }
+#pragma unroll 1
+        for (int r = 0; r < AMI_UNIT_ROWS; r++) {
+            uint32_t px[4];
+            p.paint_row(y_first + r, (mv_chunk >> r) & 1u, px);
+            if (p.active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
+        }
+        st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
+    }
+}
+
 // One wave rasterises one env; AMI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte stores, background-only
 // units are stored directly.
 template <int C, bool ALT>
@@ -1540,27 +1562,37 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
     if (ALT && pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;   // (ALT: the agent layer's generic path only)
     p.setup(src, env, lane, lds_mask[wave]);
 
-    uint8_t* frame = out + (size_t)rel * H * W * C;
-    constexpr int NUNITS = H / AMI_UNIT_ROWS;
-    const int u0 = split > 1 ? 0 : (int)(((uint32_t)env * 7u) % (uint32_t)NUNITS);
-    for (int k = part; k < NUNITS; k += split) {
-        int u = u0 + k;
-        if (u >= NUNITS) u -= NUNITS;
-        const int y_first = u * AMI_UNIT_ROWS;
-        const uint32_t mv_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.mv_rows, y_first);
-        const uint32_t busy_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.busy, y_first);
-        if (busy_chunk == 0 && C != 4) {                     // background only: no staging (RGBA: staged is faster)
-            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_bg);
-            continue;
-        }
-#pragma unroll 1
-        for (int r = 0; r < AMI_UNIT_ROWS; r++) {
-            uint32_t px[4];
-            p.paint_row(y_first + r, (mv_chunk >> r) & 1u, px);
-            if (p.active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
-        }
-        st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
-    }
+    ami_paint_units<C>(p, out + (size_t)rel * H * W * C, env, lane, st, part, split);
+}
+
+// ------------------------------------------------------------------ resident single-env form (tbx_serve_loop, tbx_common.hpp)
+//
+// One wave, env 0: steps on request and, when the request asks for it, rasterises the env straight into the engine's mapped
+// pinned frame buffer (ToyboxBaseEnv.step = apply_ale_action + get_state without a launch, a copy or a synchronisation).
+template <int C>
+__device__ __forceinline__ void ami_serve_paint(const AmiDev& d, uint8_t* frame, int lane, uint8_t* lds, uint32_t* cls, int part, int split)
+{
+    const RowStager<C, TBX_AMI_W, AMI_UNIT_ROWS> st{lds};
+    AmiPainter<C> p;
+    p.setup(d, 0, lane, cls);
+    ami_paint_units<C>(p, frame, 0, lane, st, part, split);
+}
+
+__global__ __launch_bounds__(64 * TBX_SERVE_WAVES) void ami_serve_kernel(AmiDev d, TbxServeCtl* ctl)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[TBX_SERVE_WAVES][RowStager<4, TBX_AMI_W, AMI_UNIT_ROWS>::UNIT_BYTES];
+    __shared__ uint32_t cls[TBX_SERVE_WAVES][AmiPainter<1>::NLDS * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { ami_step_body<false>(d, d, d, src, flags, 0, lane); },
+                   [&](int channels, uint8_t* frame, int part, int split) {
+                       switch (channels) {
+                       case 1: ami_serve_paint<1>(d, frame, lane, lds[wave], cls[wave], part, split); break;
+                       case 3: ami_serve_paint<3>(d, frame, lane, lds[wave], cls[wave], part, split); break;
+                       default: ami_serve_paint<4>(d, frame, lane, lds[wave], cls[wave], part, split); break;
+                       }
+                       return true;
+                   },
+                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
 // ------------------------------------------------------------------ fused agent observation
@@ -1812,9 +1844,10 @@ struct AmiOps : GameOps {
         return TBX_OK;
     }
 
+    bool serve_paints() const override { return true; }
     int serve(tbx_engine* e, TbxServeCtl* ctl_dev, hipStream_t s) override
     {
-        hipLaunchKernelGGL(ami_serve_kernel, dim3(1), dim3(64), 0, s, d, ctl_dev);
+        hipLaunchKernelGGL(ami_serve_kernel, dim3(1), dim3(64 * TBX_SERVE_WAVES), 0, s, d, ctl_dev);   // (paints on request: serve_paints)
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

@@ -507,15 +507,6 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_step_kernel(BrkDev d, BrkCfg c,
     brk_step_body<CUSTOM>(d, c, src, flags, first_env + rel, lane);
 }
 
-// resident single-env form (tbx_serve_loop, tbx_common.hpp): one wave, env 0
-template <bool CUSTOM>
-__global__ __launch_bounds__(64) void brk_serve_kernel(BrkDev d, BrkCfg c, TbxServeCtl* ctl)
-{
-    const int lane = threadIdx.x & 63;
-    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { brk_step_body<CUSTOM>(d, c, src, flags, 0, lane); },
-                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
-}
-
 // ------------------------------------------------------------------ step, thread per env (canonical wall)
 //
 // With the canonical brick wall the transition needs no lane-parallel scan: the bricks a ball can
@@ -844,14 +835,6 @@ __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCf
     brk_step_tpe_body<AGENT>(d, *cp, src, flags, recs, recs_a, recs_b, env);   // tables are indexed per thread: read from memory, not from kernel arguments
 }
 
-// resident single-env form (tbx_serve_loop, tbx_common.hpp): lane 0 of one wave, env 0
-__global__ __launch_bounds__(64) void brk_serve_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, BrkRenderRec* recs, TbxServeCtl* ctl)
-{
-    const int lane = threadIdx.x & 63;
-    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { if (lane == 0) brk_step_tpe_body<false>(d, *cp, src, flags, recs, nullptr, nullptr, 0); },
-                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
-}
-
 // reset-time wrappers of the agent layer for the envs flagged in r.kind (agent_device.hpp, AgentResetProc)
 struct BrkTEnv {
     const BrkCfg& c;
@@ -898,17 +881,9 @@ __constant__ uint16_t BRK_DIGITS[10] = {0x7B6F, 0x749A, 0x73E7, 0x79E7, 0x49ED, 
 // slower, 16 rows no better
 constexpr int BRK_UNIT_ROWS = 8;    // scanlines per work item, staged in LDS (160 = 20 units)
 
-// exec_flag (agent layer, single-frame launches): only the envs that ran the frame write their record, and set `bit` of buf_valid
-__global__ __launch_bounds__(256) void brk_render_prep_kernel(BrkDev d, BrkRenderRec* recs, int first_env, int count,
-                                                              const uint8_t* exec_flag = nullptr, uint8_t* buf_valid = nullptr, int bit = 0)
+// the rasteriser's record of one env from the SoA state
+__device__ __forceinline__ BrkRenderRec brk_record_of(const BrkDev& d, int env)
 {
-    const int rel = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rel >= count) return;
-    const int env = first_env + rel;
-    if (exec_flag) {
-        if (!exec_flag[env]) return;
-        buf_valid[env] |= (uint8_t)bit;
-    }
     const size_t N = (size_t)d.n;
     BrkRenderRec r;
 #pragma unroll
@@ -925,10 +900,23 @@ __global__ __launch_bounds__(256) void brk_render_prep_kernel(BrkDev d, BrkRende
         r.ball[b] = b < n_balls ? pack_rect(bx, by, ball_s, ball_s) : 0u;
     }
     r.n_bricks = d.n_bricks[env];
-    const uint32_t hud = brk_hud_word(d.score[env], d.lives[env], d.level[env]);
-    r.hud = hud;
+    r.hud = brk_hud_word(d.score[env], d.lives[env], d.level[env]);
     r._pad = 0;
-    recs[env] = r;
+    return r;
+}
+
+// exec_flag (agent layer, single-frame launches): only the envs that ran the frame write their record, and set `bit` of buf_valid
+__global__ __launch_bounds__(256) void brk_render_prep_kernel(BrkDev d, BrkRenderRec* recs, int first_env, int count,
+                                                              const uint8_t* exec_flag = nullptr, uint8_t* buf_valid = nullptr, int bit = 0)
+{
+    const int rel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rel >= count) return;
+    const int env = first_env + rel;
+    if (exec_flag) {
+        if (!exec_flag[env]) return;
+        buf_valid[env] |= (uint8_t)bit;
+    }
+    recs[env] = brk_record_of(d, env);
 }
 
 // paints the clipped rect `rc` (pack_rect) into this lane's 4 pixels of scanline y
@@ -990,56 +978,59 @@ struct BrkPalette {
 // (scripts/ubench/): a persistent grid over address-ordered units reaches 6.1 TB/s as bare stores but 4.7-4.9 TB/s with
 // record loads and LDS staging; one-shot address-ordered waves of 1, 2, 4 or 10 CONSECUTIVE units 5.3-5.5 TB/s
 // (hipMemset on the same boxes: 6.3-6.5 TB/s).
-template <int C, bool CUSTOM, bool ALT>
-__global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
-                                                               BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split,
-                                                               const BrkRenderRec* __restrict__ recs_alt = nullptr, const uint8_t* __restrict__ pick_alt = nullptr)
+// what a lane needs for every scanline whatever the env: finished palette values, its side-wall pattern, its HUD glyph slots.
+// Built by the kernel BEFORE it looks at its work item (so the record's scalar loads overlap with it).
+template <int C>
+struct BrkLaneTables {
+    int x0;
+    bool active;
+    uint32_t c_bg, c_frame, c_paddle, c_ball;
+    uint32_t side[4];
+    uint32_t hud_sel[4];
+    __device__ __forceinline__ BrkLaneTables(const BrkPalette& pal, int lane)
+    {
+        constexpr int W = TBX_BRK_W;
+        x0 = lane * 4;
+        active = x0 < W;
+        // palette through pix_of<C>() once; the scanline loop only moves finished pixel values
+        c_bg = pix_of<C>(pal.bg); c_frame = pix_of<C>(pal.frame); c_paddle = pix_of<C>(pal.paddle); c_ball = pix_of<C>(pal.ball);
+        // per-lane base pattern of a side-wall row
+#pragma unroll
+        for (int i = 0; i < 4; i++) side[i] = (x0 + i < 12 || x0 + i >= 228) ? c_frame : c_bg;
+        // per-lane HUD slots: which glyph (0..6, 7 = none) and which glyph column covers pixel x0+i
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int hud_x0[7] = {36, 44, 52, 60, 68, 148, 196};
+            uint32_t sel = 7u << 2;
+#pragma unroll
+            for (int g = 0; g < 7; g++) {
+                const int dx = x0 + i - hud_x0[g];
+                if (dx >= 0 && dx < 6) sel = ((uint32_t)g << 2) | (uint32_t)(dx >> 1);
+            }
+            hud_sel[i] = sel;
+        }
+    }
+};
+
+// One frame's units part, part + split, ... of one env from its record, on one wave (st: the wave's LDS slice): the body of
+// brk_render_kernel, also what the resident single-env kernel calls after a step (tbx_serve_loop).  frame_out: the env's frame.
+template <int C, bool CUSTOM>
+__device__ __forceinline__ void brk_paint_units(const BrkRenderRec& rec, const BrkCustom* __restrict__ custom, const BrkPalette& pal, const BrkLaneTables<C>& t,
+                                                uint8_t* __restrict__ frame_out, int env, int lane, const RowStager<C, TBX_BRK_W, BRK_UNIT_ROWS>& st,
+                                                int part, int split)
 {
     constexpr int W = TBX_BRK_W, H = TBX_BRK_H;
-    using Stager = RowStager<C, W, BRK_UNIT_ROWS>;
     constexpr int NUNITS = H / BRK_UNIT_ROWS;
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    Stager st{lds_all + wave * Stager::UNIT_BYTES};
-    const int x0 = lane * 4;
-    const bool active = x0 < W;
+    const int x0 = t.x0;
+    const bool active = t.active;
     const int rows = pal.rows;
-    // palette through pix_of<C>() once; the scanline loop only moves finished pixel values
-    const uint32_t c_bg = pix_of<C>(pal.bg), c_frame = pix_of<C>(pal.frame), c_paddle = pix_of<C>(pal.paddle), c_ball = pix_of<C>(pal.ball);
+    const uint32_t c_bg = t.c_bg, c_frame = t.c_frame, c_paddle = t.c_paddle, c_ball = t.c_ball;
+    const uint32_t (&side)[4] = t.side;
+    const uint32_t (&hud_sel)[4] = t.hud_sel;
 
-    // per-lane base pattern of a side-wall row
-    uint32_t side[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) side[i] = (x0 + i < 12 || x0 + i >= 228) ? c_frame : c_bg;
-    // per-lane HUD slots: which glyph (0..6, 7 = none) and which glyph column covers pixel x0+i
-    uint32_t hud_sel[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int hud_x0[7] = {36, 44, 52, 60, 68, 148, 196};
-        uint32_t sel = 7u << 2;
-#pragma unroll
-        for (int g = 0; g < 7; g++) {
-            const int dx = x0 + i - hud_x0[g];
-            if (dx >= 0 && dx < 6) sel = ((uint32_t)g << 2) | (uint32_t)(dx >> 1);
-        }
-        hud_sel[i] = sel;
-    }
-
-    // `split` waves share a frame, wave `part` taking units part, part + split, ...
-    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
-    const int rel = wid / split, part = wid - rel * split;
-    if (rel >= count) return;
-    // the env's record by value, ONCE, before the unit loop: scalar loads up front, none between the frame stores.  (agent
-    // layer, generic path: flagged envs paint recs_alt -- the ARRAY is selected; a select between two loaded records turns
-    // the scalar loads into vector loads, and a load left inside the loop is repeated per unit behind the stores)
-    const BrkRenderRec* __restrict__ rsrc = (ALT && pick_alt && wave_uniform((int)pick_alt[first_env + rel])) ? recs_alt : recs;
-    const BrkRenderRec rec = rsrc[first_env + rel];
     for (int q = part; q < NUNITS; q += split) {
-        const int u = (int)(((uint32_t)(first_env + rel) * 7u + (uint32_t)q) % (uint32_t)NUNITS);
-        const int env = first_env + rel;
-        uint8_t* dst = out + ((size_t)rel * H + (size_t)u * BRK_UNIT_ROWS) * W * C;
+        const int u = (int)(((uint32_t)env * 7u + (uint32_t)q) % (uint32_t)NUNITS);
+        uint8_t* dst = frame_out + (size_t)u * BRK_UNIT_ROWS * W * C;
         const int y_first = u * BRK_UNIT_ROWS;
 
         // HUD column bits of this lane's pixels (only the first units of a frame show the HUD)
@@ -1135,6 +1126,75 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
         }
         st.flush(dst, lane);
     }
+}
+
+template <int C, bool CUSTOM, bool ALT>
+__global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
+                                                               BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split,
+                                                               const BrkRenderRec* __restrict__ recs_alt = nullptr, const uint8_t* __restrict__ pick_alt = nullptr)
+{
+    constexpr int W = TBX_BRK_W, H = TBX_BRK_H;
+    using Stager = RowStager<C, W, BRK_UNIT_ROWS>;
+    constexpr int NUNITS = H / BRK_UNIT_ROWS;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    Stager st{lds_all + wave * Stager::UNIT_BYTES};
+    const BrkLaneTables<C> tables(pal, lane);
+    // `split` waves share a frame, wave `part` taking units part, part + split, ...
+    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    const int rel = wid / split, part = wid - rel * split;
+    if (rel >= count) return;
+    // the env's record by value, ONCE, before the unit loop: scalar loads up front, none between the frame stores.  (agent
+    // layer, generic path: flagged envs paint recs_alt -- the ARRAY is selected; a select between two loaded records turns
+    // the scalar loads into vector loads, and a load left inside the loop is repeated per unit behind the stores)
+    const BrkRenderRec* __restrict__ rsrc = (ALT && pick_alt && wave_uniform((int)pick_alt[first_env + rel])) ? recs_alt : recs;
+    const BrkRenderRec rec = rsrc[first_env + rel];
+    brk_paint_units<C, CUSTOM>(rec, custom, pal, tables, out + (size_t)rel * H * W * C, first_env + rel, lane, st, part, split);
+}
+
+// ------------------------------------------------------------------ resident single-env form (tbx_serve_loop, tbx_common.hpp)
+//
+// One wave, env 0: steps on request and, when the request asks for it, rasterises the env straight into the engine's mapped
+// pinned frame buffer -- the whole of ToyboxBaseEnv.step (apply_ale_action + get_state, envs/atari/base.py:126,109) without a
+// launch, a copy or a synchronisation.
+template <bool CUSTOM>
+__device__ __forceinline__ bool brk_serve_paint(const BrkDev& d, const BrkRenderRec* recs, const BrkPalette& pal, int channels, uint8_t* frame, int lane, uint8_t* lds,
+                                                int part, int split)
+{
+    const BrkRenderRec rec = recs[0];
+    switch (channels) {
+    case 1: brk_paint_units<1, CUSTOM>(rec, d.custom, pal, BrkLaneTables<1>(pal, lane), frame, 0, lane, RowStager<1, TBX_BRK_W, BRK_UNIT_ROWS>{lds}, part, split); break;
+    case 3: brk_paint_units<3, CUSTOM>(rec, d.custom, pal, BrkLaneTables<3>(pal, lane), frame, 0, lane, RowStager<3, TBX_BRK_W, BRK_UNIT_ROWS>{lds}, part, split); break;
+    default: brk_paint_units<4, CUSTOM>(rec, d.custom, pal, BrkLaneTables<4>(pal, lane), frame, 0, lane, RowStager<4, TBX_BRK_W, BRK_UNIT_ROWS>{lds}, part, split); break;
+    }
+    return true;
+}
+
+template <bool CUSTOM>
+__global__ __launch_bounds__(64 * TBX_SERVE_WAVES) void brk_serve_kernel(BrkDev d, BrkCfg c, BrkRenderRec* recs, BrkPalette pal, TbxServeCtl* ctl)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[TBX_SERVE_WAVES][RowStager<4, TBX_BRK_W, BRK_UNIT_ROWS>::UNIT_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    tbx_serve_loop(ctl, lane,
+                   [&](const ActionSource& src, uint32_t flags) {
+                       brk_step_body<CUSTOM>(d, c, src, flags, 0, lane);
+                       __threadfence();
+                       if (lane == 0) recs[0] = brk_record_of(d, 0);        // the wave-per-env step leaves no record
+                   },
+                   [&](int channels, uint8_t* frame, int part, int split) { return brk_serve_paint<CUSTOM>(d, recs, pal, channels, frame, lane, lds[wave], part, split); },
+                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
+}
+
+// thread-per-env step on lane 0 of wave 0 (canonical wall): it writes env 0's record itself
+__global__ __launch_bounds__(64 * TBX_SERVE_WAVES) void brk_serve_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, BrkRenderRec* recs, BrkPalette pal, TbxServeCtl* ctl)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[TBX_SERVE_WAVES][RowStager<4, TBX_BRK_W, BRK_UNIT_ROWS>::UNIT_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { if (lane == 0) brk_step_tpe_body<false>(d, *cp, src, flags, recs, nullptr, nullptr, 0); },
+                   [&](int channels, uint8_t* frame, int part, int split) { return brk_serve_paint<false>(d, recs, pal, channels, frame, lane, lds[wave], part, split); },
+                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
 // ------------------------------------------------------------------ fused agent observation
@@ -1603,11 +1663,21 @@ struct BreakoutOps : GameOps {
         return TBX_OK;
     }
 
+    BrkPalette palette() const
+    {
+        BrkPalette pal;
+        pal.bg = c.bg; pal.frame = c.frame; pal.paddle = c.paddle; pal.ball = c.ball; pal.rows = c.n_rows;
+        for (int i = 0; i < TBX_BRK_MAX_ROWS; i++) pal.row_colors[i] = c.row_colors[i];
+        return pal;
+    }
+
+    bool serve_paints() const override { return true; }
     int serve(tbx_engine* e, TbxServeCtl* ctl_dev, hipStream_t s) override
     {
-        if (custom) hipLaunchKernelGGL(brk_serve_kernel<true>, dim3(1), dim3(64), 0, s, d, c, ctl_dev);
-        else if (use_tpe) hipLaunchKernelGGL(brk_serve_tpe_kernel, dim3(1), dim3(64), 0, s, d, cfg_dev, recs, ctl_dev);
-        else hipLaunchKernelGGL(brk_serve_kernel<false>, dim3(1), dim3(64), 0, s, d, c, ctl_dev);
+        const BrkPalette pal = palette();
+        if (custom) hipLaunchKernelGGL(brk_serve_kernel<true>, dim3(1), dim3(64 * TBX_SERVE_WAVES), 0, s, d, c, recs, pal, ctl_dev);
+        else if (use_tpe) hipLaunchKernelGGL(brk_serve_tpe_kernel, dim3(1), dim3(64 * TBX_SERVE_WAVES), 0, s, d, cfg_dev, recs, pal, ctl_dev);
+        else hipLaunchKernelGGL(brk_serve_kernel<false>, dim3(1), dim3(64 * TBX_SERVE_WAVES), 0, s, d, c, recs, pal, ctl_dev);
         TBX_HIP(hipGetLastError());
         recs_valid = false;         // (the thread-per-env form keeps env 0's record current, but nothing here relies on it)
         return TBX_OK;
@@ -1620,9 +1690,7 @@ struct BreakoutOps : GameOps {
     void launch_render(uint8_t* out, int first, int count, hipStream_t s, const BrkRenderRec* src_recs = nullptr,
                        const BrkRenderRec* alt = nullptr, const uint8_t* pick_alt = nullptr)
     {
-        BrkPalette pal;
-        pal.bg = c.bg; pal.frame = c.frame; pal.paddle = c.paddle; pal.ball = c.ball; pal.rows = c.n_rows;
-        for (int i = 0; i < TBX_BRK_MAX_ROWS; i++) pal.row_colors[i] = c.row_colors[i];
+        const BrkPalette pal = palette();
         if (!recs_valid && (!src_recs || alt)) {           // the live records are read
             hipLaunchKernelGGL(brk_render_prep_kernel, dim3((count + 255) / 256), dim3(256), 0, s, d, recs, first, count);
             if (first == 0 && count == d.n) recs_valid = true;

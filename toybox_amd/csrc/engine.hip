@@ -286,6 +286,7 @@ int tbx_destroy(tbx_engine* e)
     tbx_serve_stop(e);
     if (e->serve_stream) hipStreamDestroy(e->serve_stream);
     if (e->serve_ctl) hipHostFree(e->serve_ctl);
+    if (e->serve_frame) hipHostFree(e->serve_frame);
     if (e->stream) hipStreamSynchronize(e->stream);
     TbxPipe& pp = e->pipe;
     for (int k = 0; k < 2; k++)
@@ -716,6 +717,17 @@ int tbx_step(tbx_engine* e, const int32_t* actions_host, uint32_t flags, int32_t
 
 // ---- resident single-env step (TbxServeCtl, tbx_common.hpp)
 
+// the pinned, device-mapped frame buffer of the single-env path (tbx_step1_frame): the resident kernel rasterises into it
+static int ensure_serve_frame(tbx_engine* e)
+{
+    if (e->serve_frame) return TBX_OK;
+    const size_t bytes = (size_t)e->ops->height() * e->ops->width() * 4;
+    EHIP(hipHostMalloc((void**)&e->serve_frame, bytes, hipHostMallocMapped));
+    memset(e->serve_frame, 0, bytes);
+    EHIP(hipHostGetDevicePointer((void**)&e->serve_frame_dev, e->serve_frame, 0));
+    return TBX_OK;
+}
+
 static int serve_start(tbx_engine* e)
 {
     if (!e->serve_ctl) {
@@ -724,8 +736,13 @@ static int serve_start(tbx_engine* e)
         EHIP(hipHostGetDevicePointer((void**)&e->serve_ctl_dev, e->serve_ctl, 0));
         EHIP(hipStreamCreateWithFlags(&e->serve_stream, hipStreamNonBlocking));
     }
+    if (!e->serve_frame) {
+        int rc = ensure_serve_frame(e);
+        if (rc) return rc;
+    }
     TbxServeCtl* c = e->serve_ctl;
     c->exited = 0;
+    c->frame_dev = (uint64_t)(uintptr_t)e->serve_frame_dev;
     c->ack_seq = e->serve_seq;
     c->req = (uint64_t)e->serve_seq;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -750,11 +767,14 @@ hipError_t tbx_serve_stop(tbx_engine* e)
 
 extern "C" {
 
-int tbx_step1(tbx_engine* e, int env, int32_t ale_action, uint32_t flags, int32_t out[4])
+// one frame of one env, optionally with its picture (channels 0 / 1 / 3 / 4) in e->serve_frame
+static int step1_impl(tbx_engine* e, int env, int32_t ale_action, uint32_t flags, int channels, int32_t out[4])
 {
     CHECK_ENGINE(e);
     if (env < 0 || env >= e->n) return e->fail(TBX_E_INVALID, "env index out of range");
+    if (channels != 0 && channels != 1 && channels != 3 && channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
     EHIP(hipSetDevice(e->device));
+    bool painted = false;
     if (e->n == 1 && e->opt[TBX_OPT_RESIDENT_STEP] && !e->gather) {
         // the resident kernel: post the request, spin on the acknowledgement (no launch, no copy, no synchronisation)
         TbxServeCtl* c = e->serve_ctl;
@@ -766,8 +786,9 @@ int tbx_step1(tbx_engine* e, int env, int32_t ale_action, uint32_t flags, int32_
             c = e->serve_ctl;
         }
         {
+            const uint32_t want = (channels && e->ops->serve_paints()) ? (channels == 1 ? 1u : channels == 3 ? 2u : 3u) : 0u;
             const uint32_t seq = ++e->serve_seq;
-            const uint64_t word = tbx_serve_word(seq, ale_action, flags);
+            const uint64_t word = tbx_serve_word(seq, ale_action, (flags & 0x0Fu) | (want << TBX_SERVE_FRAME_SHIFT));
             __atomic_store_n(&c->req, word, __ATOMIC_RELEASE);
             unsigned long spins = 0;
             while (__atomic_load_n(&c->ack_seq, __ATOMIC_ACQUIRE) != seq) {
@@ -788,6 +809,13 @@ int tbx_step1(tbx_engine* e, int env, int32_t ale_action, uint32_t flags, int32_
             }
             const uint32_t de = c->done_err;
             if (out) { out[0] = c->reward; out[1] = (int32_t)(de & 1u); out[2] = c->lives; out[3] = c->score; }
+            painted = want != 0 && !(de & 4u);
+            if (channels && !painted) {                      // this game's resident kernel does not paint: the launched rasteriser
+                int rc = ensure_serve_frame(e);
+                if (rc) return rc;
+                rc = tbx_render_env(e, env, e->serve_frame, channels);
+                if (rc) return rc;
+            }
             if (de & 2u) return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
             return TBX_OK;
         }
@@ -796,34 +824,49 @@ slow:
     {
         // any env of a batch engine: the single-env launch of tbx_apply_input, then its outputs
         const uint32_t b = tbx_ale_buttons(ale_action);
+        const int action_rc = b == 0xFFu ? TBX_E_ACTION : TBX_OK;
         int rc = tbx_apply_input(e, env, b == 0xFFu ? 0u : b);
         if (rc) return rc;
-        if (flags & TBX_STEP_AUTO_RESET) {
+        bool reset = false;
+        int32_t o[4] = {0, 0, 0, 0};
+        uint8_t dn = 0;
+        EHIP(hipMemcpy(&o[0], e->reward + env, 4, hipMemcpyDeviceToHost));
+        EHIP(hipMemcpy(&dn, e->done + env, 1, hipMemcpyDeviceToHost));
+        EHIP(hipMemcpy(&o[2], e->lives_out + env, 4, hipMemcpyDeviceToHost));
+        EHIP(hipMemcpy(&o[3], e->score_out + env, 4, hipMemcpyDeviceToHost));
+        o[1] = dn;
+        if ((flags & TBX_STEP_AUTO_RESET) && o[2] <= 0) {
             // (rare on this path) a finished game starts over, as in tbx_step
-            int32_t lv = 0;
-            EHIP(hipMemcpy(&lv, e->lives_out + env, 4, hipMemcpyDeviceToHost));
-            if (lv <= 0) {
-                std::vector<uint8_t> mask((size_t)e->n, 0);
-                mask[(size_t)env] = 1;
-                int32_t o[4];
-                EHIP(hipMemcpy(&o[0], e->reward + env, 4, hipMemcpyDeviceToHost));
-                EHIP(hipMemcpy(&o[3], e->score_out + env, 4, hipMemcpyDeviceToHost));
-                rc = tbx_new_game(e, mask.data());
-                if (rc) return rc;
-                if (out) { out[0] = o[0]; out[1] = 1; out[2] = lv; out[3] = o[3]; }
-                return b == 0xFFu ? e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)") : TBX_OK;
-            }
+            std::vector<uint8_t> mask((size_t)e->n, 0);
+            mask[(size_t)env] = 1;
+            rc = tbx_new_game(e, mask.data());
+            if (rc) return rc;
+            o[1] = 1;
+            reset = true;
         }
-        if (out) {
-            uint8_t dn = 0;
-            EHIP(hipMemcpy(&out[0], e->reward + env, 4, hipMemcpyDeviceToHost));
-            EHIP(hipMemcpy(&dn, e->done + env, 1, hipMemcpyDeviceToHost));
-            EHIP(hipMemcpy(&out[2], e->lives_out + env, 4, hipMemcpyDeviceToHost));
-            EHIP(hipMemcpy(&out[3], e->score_out + env, 4, hipMemcpyDeviceToHost));
-            out[1] = dn;
+        (void)reset;
+        if (out) memcpy(out, o, sizeof o);
+        if (channels) {
+            rc = ensure_serve_frame(e);
+            if (rc) return rc;
+            rc = tbx_render_env(e, env, e->serve_frame, channels);
+            if (rc) return rc;
         }
-        return b == 0xFFu ? e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)") : TBX_OK;
+        return action_rc ? e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)") : TBX_OK;
     }
+}
+
+int tbx_step1(tbx_engine* e, int env, int32_t ale_action, uint32_t flags, int32_t out[4])
+{
+    return step1_impl(e, env, ale_action, flags, 0, out);
+}
+
+int tbx_step1_frame(tbx_engine* e, int env, int32_t ale_action, uint32_t flags, int channels, int32_t out[4], const uint8_t** frame_host)
+{
+    if (e && channels == 0) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+    int rc = step1_impl(e, env, ale_action, flags, channels, out);
+    if (frame_host && e) *frame_host = (rc == TBX_OK || rc == TBX_E_ACTION) ? e->serve_frame : nullptr;
+    return rc;
 }
 
 int tbx_apply_input(tbx_engine* e, int env, uint32_t buttons)

@@ -176,14 +176,6 @@ __global__ __launch_bounds__(128) void gw_step_kernel(GwDev d, ActionSource src,
     gw_step_body(d, src, flags, first_env + rel);
 }
 
-// resident single-env form (tbx_serve_loop, tbx_common.hpp): lane 0 of one wave, env 0
-__global__ __launch_bounds__(64) void gw_serve_kernel(GwDev d, TbxServeCtl* ctl)
-{
-    const int lane = threadIdx.x & 63;
-    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { if (lane == 0) gw_step_body(d, src, flags, 0); },
-                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
-}
-
 // reset-time wrappers of the agent layer (agent_device.hpp, AgentResetProc), thread per flagged env
 // the dynamic state of one env (scalars, tile table, board) copied live -> slot by `lanes` cooperating lanes
 __device__ __forceinline__ void gw_copy_env(const GwDev& dst, const GwDev& src, int env, int lane, int lanes)
@@ -379,6 +371,24 @@ struct GwGrayPainter : GwPainter<1> {
     }
 };
 
+// units part, part + split, ... of one env's frame from a painter that has been set up, on one wave
+template <int C>
+__device__ __forceinline__ void gw_paint_units(const GwPainter<C>& p, uint8_t* __restrict__ dst, int env, int lane,
+                                               const RowStager<C, TBX_GW_W, GW_UNIT_ROWS>& st, int part, int split)
+{
+    constexpr int UNITS = TBX_GW_H / GW_UNIT_ROWS;
+    using Stager = RowStager<C, TBX_GW_W, GW_UNIT_ROWS>;
+    for (int u = part; u < UNITS; u += split) {
+        const int unit = split > 1 ? u : (u + env) % UNITS;  // one wave per frame: rotate the start so waves do not march in lockstep
+        for (int r = 0; r < GW_UNIT_ROWS; r++) {
+            uint32_t px[4];
+            p.paint_row(unit * GW_UNIT_ROWS + r, px);
+            if (p.active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
+        }
+        st.flush(dst + (size_t)unit * Stager::UNIT_BYTES, lane);
+    }
+}
+
 template <int C, bool ALT>
 __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* out, int first_env, int count, int split, GwDev d_alt,
                                                               const uint8_t* __restrict__ pick_alt)
@@ -399,16 +409,35 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* 
     GwDev src = d;                                             // by VALUE: a select between references to kernel arguments puts both into scratch
     if (ALT && pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;   // (ALT: the agent layer's generic path only)
     p.setup(src, env, lane, lds_mask[wave]);
-    uint8_t* dst = out + (size_t)rel * H * W * C;
-    for (int u = part; u < UNITS; u += split) {
-        const int unit = split > 1 ? u : (u + env) % UNITS;  // one wave per frame: rotate the start so waves do not march in lockstep
-        for (int r = 0; r < GW_UNIT_ROWS; r++) {
-            uint32_t px[4];
-            p.paint_row(unit * GW_UNIT_ROWS + r, px);
-            if (p.active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
-        }
-        st.flush(dst + (size_t)unit * Stager::UNIT_BYTES, lane);
-    }
+    gw_paint_units<C>(p, out + (size_t)rel * H * W * C, env, lane, st, part, split);
+}
+
+// resident single-env form (tbx_serve_loop, tbx_common.hpp): one wave, env 0; steps on request and, when the request asks for
+// it, rasterises the env straight into the engine's mapped pinned frame buffer
+template <int C>
+__device__ __forceinline__ void gw_serve_paint(const GwDev& d, uint8_t* frame, int lane, uint8_t* lds, uint32_t* cls, int part, int split)
+{
+    const RowStager<C, TBX_GW_W, GW_UNIT_ROWS> st{lds};
+    GwPainter<C> p;
+    p.setup(d, 0, lane, cls);
+    gw_paint_units<C>(p, frame, 0, lane, st, part, split);
+}
+
+__global__ __launch_bounds__(64 * TBX_SERVE_WAVES) void gw_serve_kernel(GwDev d, TbxServeCtl* ctl)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[TBX_SERVE_WAVES][RowStager<4, TBX_GW_W, GW_UNIT_ROWS>::UNIT_BYTES];
+    __shared__ uint32_t cls[TBX_SERVE_WAVES][GwPainter<1>::NCLS * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { if (lane == 0) gw_step_body(d, src, flags, 0); },
+                   [&](int channels, uint8_t* frame, int part, int split) {
+                       switch (channels) {
+                       case 1: gw_serve_paint<1>(d, frame, lane, lds[wave], cls[wave], part, split); break;
+                       case 3: gw_serve_paint<3>(d, frame, lane, lds[wave], cls[wave], part, split); break;
+                       default: gw_serve_paint<4>(d, frame, lane, lds[wave], cls[wave], part, split); break;
+                       }
+                       return true;
+                   },
+                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
 // fused agent observation: agent_fused_wave (agent_device.hpp) with two GwGrayPainters per wave
@@ -561,9 +590,10 @@ struct GridWorldOps : GameOps {
         return TBX_OK;
     }
 
+    bool serve_paints() const override { return true; }
     int serve(tbx_engine* e, TbxServeCtl* ctl_dev, hipStream_t s) override
     {
-        hipLaunchKernelGGL(gw_serve_kernel, dim3(1), dim3(64), 0, s, d, ctl_dev);
+        hipLaunchKernelGGL(gw_serve_kernel, dim3(1), dim3(64 * TBX_SERVE_WAVES), 0, s, d, ctl_dev);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

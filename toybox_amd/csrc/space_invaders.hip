@@ -795,14 +795,6 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_agent_step_kernel(SiDev d, SiDev
     si_step_body<true>(d, slot_a, slot_b, c, src, flags, first_env + rel, lane);
 }
 
-// resident single-env form (tbx_serve_loop, tbx_common.hpp): one wave, env 0
-__global__ __launch_bounds__(64) void si_serve_kernel(SiDev d, SiCfg c, TbxServeCtl* ctl)
-{
-    const int lane = threadIdx.x & 63;
-    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { si_step_body<false>(d, d, d, c, src, flags, 0, lane); },
-                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
-}
-
 // reset-time wrappers of the agent layer for the envs flagged in r.kind (agent_device.hpp, AgentResetProc)
 struct SiAgentEnv {
     const SiCfg& c;
@@ -1272,34 +1264,15 @@ __device__ __forceinline__ void si_fill_sprites(uint32_t* spr_lds)
     __syncthreads();
 }
 
-// One wave rasterises one env, scanline by scanline; SI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte
-// stores, blank units are stored directly.  `split` > 1: that many waves share a frame.
-// (agent layer, generic path: envs flagged in pick_alt are painted from d_alt)
-template <int C, bool ALT>
-__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank, int split, SiDev d_alt,
-                                                              const uint8_t* __restrict__ pick_alt)
+// units part, part + split, ... of one env's frame from a painter that has been set up (SiPainter or SiRecPainter), on one
+// wave: the body of the render kernels and of the resident single-env kernel's paint request.  Blank units are stored directly.
+template <int C, class Painter>
+__device__ __forceinline__ void si_paint_units(const Painter& p, uint8_t* __restrict__ frame, int env, int lane, const RowStager<C, TBX_SI_W, SI_UNIT_ROWS>& st,
+                                               int part, int split, int skip_blank = 1)
 {
-    constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
-    using Stager = RowStager<C, W, SI_UNIT_ROWS>;
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
-    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][SiPainter<C>::NCLS * 8];
-    __shared__ uint32_t spr_lds[SPR_WORDS];
-    si_fill_sprites(spr_lds);
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);   // `split` waves share a frame (see breakout.hip)
-    const int rel = wid / split, part = wid - rel * split;
-    if (rel >= count) return;
-    const int env = first_env + rel;
-    Stager st{lds_all + wave * Stager::UNIT_BYTES};
-    SiPainter<C> p;
-    p.spr_lds = spr_lds;
-    SiDev src = d;                                            // by VALUE: a select between references to kernel arguments puts both into scratch
-    if (ALT && pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;   // (ALT: the agent layer's generic path only)
-    p.setup(src, env, lane, lds_mask[wave]);
-
-    uint8_t* frame = out + (size_t)rel * H * W * C;
-    constexpr int NUNITS = H / SI_UNIT_ROWS;
+    constexpr int NG = SI_NG;
+    using Stager = RowStager<C, TBX_SI_W, SI_UNIT_ROWS>;
+    constexpr int NUNITS = TBX_SI_H / SI_UNIT_ROWS;
     const int u0 = split > 1 ? 0 : (int)(((uint32_t)env * 11u) % (uint32_t)NUNITS);
     for (int k = part; k < NUNITS; k += split) {
         int u = u0 + k;
@@ -1326,6 +1299,35 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
         }
         if (!(skip_blank & 4)) st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
     }
+}
+
+// One wave rasterises one env, scanline by scanline; SI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte
+// stores, blank units are stored directly.  `split` > 1: that many waves share a frame.
+// (agent layer, generic path: envs flagged in pick_alt are painted from d_alt)
+template <int C, bool ALT>
+__global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank, int split, SiDev d_alt,
+                                                              const uint8_t* __restrict__ pick_alt)
+{
+    constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
+    using Stager = RowStager<C, W, SI_UNIT_ROWS>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
+    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][SiPainter<C>::NCLS * 8];
+    __shared__ uint32_t spr_lds[SPR_WORDS];
+    si_fill_sprites(spr_lds);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);   // `split` waves share a frame (see breakout.hip)
+    const int rel = wid / split, part = wid - rel * split;
+    if (rel >= count) return;
+    const int env = first_env + rel;
+    Stager st{lds_all + wave * Stager::UNIT_BYTES};
+    SiPainter<C> p;
+    p.spr_lds = spr_lds;
+    SiDev src = d;                                            // by VALUE: a select between references to kernel arguments puts both into scratch
+    if (ALT && pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;   // (ALT: the agent layer's generic path only)
+    p.setup(src, env, lane, lds_mask[wave]);
+
+    si_paint_units<C>(p, out + (size_t)rel * H * W * C, env, lane, st, part, split, skip_blank);
 }
 
 // ------------------------------------------------------------------ the rasteriser over render records
@@ -1533,34 +1535,51 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_rec_render_kernel(const SiRender
     SiRecPainter<C> p;
     p.spr_lds = spr_lds;
     p.setup(recs, env, lane);
-    uint8_t* frame = out + (size_t)rel * H * W * C;
-    constexpr int NUNITS = H / SI_UNIT_ROWS;
-    const int u0 = split > 1 ? 0 : (int)(((uint32_t)env * 11u) % (uint32_t)NUNITS);
-    for (int k = part; k < NUNITS; k += split) {
-        int u = u0 + k;
-        if (u >= NUNITS) u -= NUNITS;
-        const uint32_t rows_busy = row_mask_chunk<SI_UNIT_ROWS>(p.busy, u * SI_UNIT_ROWS);
-        if (rows_busy == 0 && C != 4) {
-            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_black);
-            continue;
-        }
-#pragma unroll 1
-        for (int r = 0; r < SI_UNIT_ROWS; r++) {
-            const int y = u * SI_UNIT_ROWS + r;
-            uint32_t px[NG][4];
-            if ((rows_busy >> r) & 1u) p.paint_row(y, px);
-            else {
-#pragma unroll
-                for (int g = 0; g < NG; g++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) px[g][i] = p.c_black;
-            }
-#pragma unroll
-            for (int g = 0; g < NG; g++)
-                if (p.gact[g]) st.put4p(r, lane + 64 * g, px[g][0], px[g][1], px[g][2], px[g][3]);
-        }
-        st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
+    si_paint_units<C>(p, out + (size_t)rel * H * W * C, env, lane, st, part, split);
+}
+
+// ------------------------------------------------------------------ resident single-env form (tbx_serve_loop, tbx_common.hpp)
+//
+// One wave, env 0: steps on request and, when the request asks for it, rasterises the env straight into the engine's mapped
+// pinned frame buffer (ToyboxBaseEnv.step = apply_ale_action + get_state without a launch, a copy or a synchronisation).
+// recs != nullptr: the formation is canonical, the step leaves env 0's record and the record painter paints it; else the
+// state-reading painter does.
+template <int C>
+__device__ __forceinline__ void si_serve_paint(const SiDev& d, const SiRenderRec* recs, uint8_t* frame, int lane, uint8_t* lds, uint32_t* cls, const uint32_t* spr_lds,
+                                               int part, int split)
+{
+    const RowStager<C, TBX_SI_W, SI_UNIT_ROWS> st{lds};
+    if (recs) {
+        SiRecPainter<C> p;
+        p.spr_lds = spr_lds;
+        p.setup(recs, 0, lane);
+        si_paint_units<C>(p, frame, 0, lane, st, part, split);
+    } else {
+        SiPainter<C> p;
+        p.spr_lds = spr_lds;
+        p.setup(d, 0, lane, cls);
+        si_paint_units<C>(p, frame, 0, lane, st, part, split);
     }
+}
+
+__global__ __launch_bounds__(64 * TBX_SERVE_WAVES) void si_serve_kernel(SiDev d, SiCfg c, SiRenderRec* recs, TbxServeCtl* ctl)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[TBX_SERVE_WAVES][RowStager<4, TBX_SI_W, SI_UNIT_ROWS>::UNIT_BYTES];
+    __shared__ uint32_t cls[TBX_SERVE_WAVES][SiPainter<1>::NCLS * 8];
+    __shared__ uint32_t spr_lds[SPR_WORDS];
+    si_fill_sprites(spr_lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    tbx_serve_loop(ctl, lane, [&](const ActionSource& src, uint32_t flags) { si_step_body<false>(d, d, d, c, src, flags, 0, lane, recs); },
+                   [&](int channels, uint8_t* frame, int part, int split) {
+                       // (with split > 1 every wave starts at unit `part`: 35 units over the block's waves)
+                       switch (channels) {
+                       case 1: si_serve_paint<1>(d, recs, frame, lane, lds[wave], cls[wave], spr_lds, part, split); break;
+                       case 3: si_serve_paint<3>(d, recs, frame, lane, lds[wave], cls[wave], spr_lds, part, split); break;
+                       default: si_serve_paint<4>(d, recs, frame, lane, lds[wave], cls[wave], spr_lds, part, split); break;
+                       }
+                       return true;
+                   },
+                   d.reward, d.done, d.lives_out, d.score_out, d.err_flag);
 }
 
 // ------------------------------------------------------------------ fused agent observation
@@ -1808,9 +1827,10 @@ struct SiOps : GameOps {
         return TBX_OK;
     }
 
+    bool serve_paints() const override { return true; }
     int serve(tbx_engine* e, TbxServeCtl* ctl_dev, hipStream_t s) override
     {
-        hipLaunchKernelGGL(si_serve_kernel, dim3(1), dim3(64), 0, s, d, c, ctl_dev);
+        hipLaunchKernelGGL(si_serve_kernel, dim3(1), dim3(64 * TBX_SERVE_WAVES), 0, s, d, c, custom ? nullptr : recs, ctl_dev);
         TBX_HIP(hipGetLastError());
         recs_valid = false;
         return TBX_OK;
@@ -1880,9 +1900,10 @@ struct SiOps : GameOps {
             if (first_env == 0 && n_envs == e->n) recs_valid = true;
         }
         // waves per frame: the set-up is light (a record, ~300 instructions), so RGB frames are cut finer than the
-        // state-reading rasteriser could afford: 35 six-row units over seven waves
+        // state-reading rasteriser could afford: 35 six-row units over twelve waves (measured 3 / 5 / 7 / 9 / 12 / 18 / 35 waves per frame:
+        // 2.45 / 2.50 / 2.49 / 2.49 / 2.43 / 2.49 / 3.67 ms at 65 536 envs, 0.174 / 0.171 / 0.166 / 0.164 / 0.151 / 0.167 / 0.238 ms at 4 096)
         const int split_opt = e->opt[TBX_OPT_RENDER_SPLIT];
-        const int split = split_opt > 0 ? split_opt : channels == 3 ? 7 : (channels == 4 && n_envs <= 32768) ? 5 : 1;
+        const int split = split_opt > 0 ? split_opt : channels == 3 ? 12 : (channels == 4 && n_envs <= 32768) ? 5 : 1;
         switch (channels) {
         case 1: hipLaunchKernelGGL(si_rec_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, out_dev, first_env, n_envs, split); break;
         case 3: hipLaunchKernelGGL(si_rec_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, out_dev, first_env, n_envs, split); break;

@@ -197,16 +197,19 @@ __device__ __forceinline__ int f2i(double v)
 // it first, so nothing else ever runs beside it on the env's state.
 struct TbxServeCtl {
     // host -> device: ONE 64-bit word, so that a single PCIe read per poll brings the whole request:
-    //   bits 0..31 request number, 32..47 ALE action id (int16), 48..55 TBX_STEP_* flags, 63 "leave now"
+    //   bits 0..31 request number, 32..47 ALE action id (int16), 48..51 TBX_STEP_* flags, 52..53 frame wanted (0 none, 1 gray,
+    //   2 RGB, 3 RGBA: the wave rasterises the env into `frame_dev` after the step), 63 "leave now"
     uint64_t req;
-    uint64_t _pad0[7];
+    uint64_t frame_dev;      // device address of the engine's mapped pinned frame buffer (written once before the launch)
+    uint64_t _pad0[6];
     // device -> host (its own cache line): outputs, then the request number they belong to (written last)
     int32_t reward, lives, score;
-    uint32_t done_err;       // bit 0 done, bit 1 illegal action id
+    uint32_t done_err;       // bit 0 done, bit 1 illegal action id, bit 2 the frame was asked for but this kernel cannot paint it
     uint32_t ack_seq;
     uint32_t exited;
     uint32_t _pad1[10];
 };
+constexpr uint32_t TBX_SERVE_FRAME_SHIFT = 4;   // within the 8 flag bits of the request word
 constexpr unsigned long long TBX_SERVE_IDLE_TICKS = 5000000ull;   // 50 ms of the 100 MHz s_memrealtime clock
 constexpr uint64_t TBX_SERVE_STOP = 1ull << 63;
 
@@ -217,51 +220,82 @@ __host__ __device__ __forceinline__ uint64_t tbx_serve_word(uint32_t seq, int ac
     return (uint64_t)seq | ((uint64_t)(uint16_t)(int16_t)a << 32) | ((uint64_t)(flags & 0xFFu) << 48);
 }
 
-// step(src, flags) runs one frame of env 0 on the calling wave (every lane calls it; outputs land in out_* [0])
-template <class StepFn>
-__device__ __forceinline__ void tbx_serve_loop(TbxServeCtl* ctl, int lane, StepFn step, const int32_t* out_reward, const uint8_t* out_done,
+// The resident kernel is ONE block of TBX_SERVE_WAVES waves.  Wave 0 waits for requests and steps: step(src, flags) runs one
+// frame of env 0 on it (every lane of wave 0 calls it; outputs land in out_* [0]).  When the request wants the picture, ALL
+// waves paint: render(channels, frame, part, split) rasterises units part, part + split, ... of env 0 into `frame` (host
+// memory, mapped) and returns false if this game's kernel cannot -- a lone wave needs ~45 us for a frame (one dependent
+// instruction stream), eight need ~8.  The other waves sleep at the block barrier in between and take no issue slots.
+constexpr int TBX_SERVE_WAVES = 8;
+
+template <class StepFn, class RenderFn>
+__device__ __forceinline__ void tbx_serve_loop(TbxServeCtl* ctl, int lane, StepFn step, RenderFn render, const int32_t* out_reward, const uint8_t* out_done,
                                                const int32_t* out_lives, const int32_t* out_score, uint32_t* err_flag)
 {
+    __shared__ uint32_t cmd[2];              // [0]: 0 = nothing to paint, 1 / 3 / 4 = paint that many channels, ~0u = leave; [1]: "cannot paint"
+    const int wave = wave_uniform((int)(threadIdx.x >> 6));
     uint32_t last = __hip_atomic_load(&ctl->ack_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint8_t* const frame = reinterpret_cast<uint8_t*>(__hip_atomic_load(&ctl->frame_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
     for (;;) {
-        uint64_t w = last;
-        bool idle_out = false;
-        if (lane == 0) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            unsigned polls = 0;
+        uint32_t seq = last, err = 0;
+        if (wave == 0) {
+            bool leave = false;
+            uint32_t hi = 0;
             for (;;) {
-                w = __hip_atomic_load(&ctl->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((uint32_t)w != last || (w & TBX_SERVE_STOP)) break;
-                if ((++polls & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > TBX_SERVE_IDLE_TICKS) { idle_out = true; break; }
+                uint64_t w = last;
+                bool idle_out = false;
+                if (lane == 0) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    unsigned polls = 0;
+                    for (;;) {
+                        w = __hip_atomic_load(&ctl->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if ((uint32_t)w != last || (w & TBX_SERVE_STOP)) break;
+                        if ((++polls & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > TBX_SERVE_IDLE_TICKS) { idle_out = true; break; }
+                    }
+                }
+                seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+                hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32));
+                idle_out = __builtin_amdgcn_readfirstlane((int)idle_out) != 0;
+                if (seq != last) break;                          // a request (one that raced with the stop bit is served first)
+                if ((hi >> 31) || idle_out) { leave = true; break; }   // told to leave, or idle for too long
+            }
+            if (leave) {
+                if (lane == 0) cmd[0] = ~0u;
+            } else {
+                const int action = (int)(int16_t)(hi & 0xFFFFu);
+                const uint32_t flags = (hi >> 16) & 0xFFu;
+                ActionSource src{};
+                uint32_t buttons = tbx_ale_buttons(action);
+                if (buttons == 0xFFu) { buttons = 0; err = 2; }  // illegal id: NOOP + TBX_E_ACTION, as in the batch kernels
+                src.single_env = 0;
+                src.single_buttons = buttons;
+                step(src, flags & 0x0Fu);
+                const uint32_t want = (flags >> TBX_SERVE_FRAME_SHIFT) & 3u;
+                if (want) __threadfence();                       // what the step stored, for the waves that paint
+                if (lane == 0) { cmd[0] = want == 0 ? 0u : want == 1 ? 1u : want == 2 ? 3u : 4u; cmd[1] = 0u; }
             }
         }
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32));
-        idle_out = __builtin_amdgcn_readfirstlane((int)idle_out) != 0;
-        const uint32_t seq = lo;
-        if (seq == last) {                                   // nothing to serve: told to leave, or idle for too long
-            if ((hi >> 31) || idle_out) {                    // (a request that raced with the stop bit is served first)
-                if (lane == 0) __hip_atomic_store(&ctl->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                return;
+        __syncthreads();
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmd[0]);
+        if (c == ~0u) {
+            if (wave == 0 && lane == 0) __hip_atomic_store(&ctl->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        if (c) {
+            if (!render((int)c, frame, wave, TBX_SERVE_WAVES) && lane == 0) cmd[1] = 1u;
+            __threadfence_system();                              // this wave's part of the frame is in host memory ...
+        }
+        __syncthreads();                                         // ... and so is everybody's, before the acknowledgement
+        if (wave == 0) {
+            if (c && __builtin_amdgcn_readfirstlane((int)cmd[1])) err |= 4u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (lane == 0) {
+                ctl->reward = out_reward[0]; ctl->lives = out_lives[0]; ctl->score = out_score[0];
+                ctl->done_err = (out_done[0] ? 1u : 0u) | err;
+                __hip_atomic_store(&ctl->ack_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            continue;
+            last = seq;
         }
-        const int action = (int)(int16_t)(hi & 0xFFFFu);
-        const uint32_t flags = (hi >> 16) & 0xFFu;
-        ActionSource src{};
-        uint32_t buttons = tbx_ale_buttons(action);
-        uint32_t err = 0;
-        if (buttons == 0xFFu) { buttons = 0; err = 2; }      // illegal id: NOOP + TBX_E_ACTION, as in the batch kernels
-        src.single_env = 0;
-        src.single_buttons = buttons;
-        step(src, flags);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (lane == 0) {
-            ctl->reward = out_reward[0]; ctl->lives = out_lives[0]; ctl->score = out_score[0];
-            ctl->done_err = (out_done[0] ? 1u : 0u) | err;
-            __hip_atomic_store(&ctl->ack_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        last = seq;
+        __syncthreads();                                         // cmd[] may be rewritten
     }
 }
 
@@ -341,6 +375,8 @@ struct tbx_engine {
     // resident single-env step kernel (tbx_step1 on one-env engines)
     TbxServeCtl* serve_ctl = nullptr;     // host-coherent pinned mailbox (host address)
     TbxServeCtl* serve_ctl_dev = nullptr; // its device address
+    uint8_t* serve_frame = nullptr;       // mapped pinned frame buffer the resident kernel rasterises into (H * W * 4 bytes, host address)
+    uint8_t* serve_frame_dev = nullptr;   // its device address
     hipStream_t serve_stream = nullptr;
     bool serve_running = false;           // a server kernel has been launched and not yet been seen to exit
     uint32_t serve_seq = 0;
@@ -408,6 +444,7 @@ struct GameOps {
     virtual int scalars(tbx_engine* e, int32_t* score_dev, int32_t* lives_dev, int32_t* level_dev, hipStream_t s) = 0;
     // launch the resident single-env step kernel for env 0 on `s` (tbx_serve_loop); optional
     virtual int serve(tbx_engine*, TbxServeCtl* /*ctl_dev*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    virtual bool serve_paints() const { return false; }        // the resident kernel can rasterise env 0 on request
     // ---- agent layer (agent.hip).  The two-frame buffer of MaxAndSkipEnv lives with the game as two snapshot slots.
     virtual int agent_prepare(tbx_engine*) { return TBX_OK; }  // allocate the slots
     virtual bool multi_frame_step() const { return false; }   // step() honours ActionSource::frames and writes the slots itself

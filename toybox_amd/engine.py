@@ -127,6 +127,20 @@ class Engine:
             self._check(rc)
         return out[0], out[1] != 0, out[2], out[3]
 
+    def step1_frame(self, env, ale_action, channels=1, auto_reset=False):
+        """tbx_step1_frame: one frame of one env and the picture of the state it leaves -- (reward, done, lives, score, frame)
+        with frame a fresh uint8 (H, W, channels) array.  On a one-env engine the resident kernel paints into pinned host memory
+        (no launch, no copy on the device side); the array returned here is a host copy of that buffer, because the buffer is
+        reused by the next call and gym code keeps observations."""
+        out = self._out4
+        fp = C.c_void_p()
+        rc = self._lib.tbx_step1_frame(self._h, env, ale_action, _abi.STEP_AUTO_RESET if auto_reset else 0, int(channels), out, C.byref(fp))
+        if rc != _abi.OK:
+            self._check(rc)
+        n = self.height * self.width * int(channels)
+        frame = np.frombuffer((C.c_uint8 * n).from_address(fp.value), np.uint8).reshape(self.height, self.width, int(channels)).copy()
+        return out[0], out[1] != 0, out[2], out[3], frame
+
     def apply_input(self, env, buttons):
         self._check(self._lib.tbx_apply_input(self._h, int(env), int(buttons)))
 

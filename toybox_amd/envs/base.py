@@ -109,14 +109,16 @@ class ToyboxBaseEnv(_EnvBase):
         if not 0 <= action_index < len(self._action_set):
             raise AssertionError("action index %r outside the %d legal actions" % (action_index, len(self._action_set)))
         tb = self.toybox
-        tb.apply_ale_action(self._action_set[int(action_index)])
+        # the frame's step and its picture in one round trip to the engine (a one-env engine answers both from its resident
+        # kernel: no launch, no copy, no synchronisation)
+        frame = tb.step_frame(self._action_set[int(action_index)], self.channels)
         score, lives = tb.get_score(), tb.get_lives()
         done = lives <= 0
         info = {"lives": lives, "score": 0 if done else score}
         if done:
             info["cached_state"] = tb.to_state_json()
         reward, self.score = max(score - self.score, 0), score
-        return self._frame(), reward, done, info
+        return frame, reward, done, info
 
     def reset(self):
         tb = self.toybox

@@ -188,6 +188,18 @@ class Toybox(object):
         for _ in range(self.frames_per_action):
             self._engine.apply_input(self._env, buttons)
 
+    def step_frame(self, action_int, channels):
+        """apply_ale_action(action) followed by the frame of the new state -- what ToyboxBaseEnv.step needs -- in ONE round trip
+        to the engine (tbx_step1_frame).  Returns the (H, W, channels) uint8 frame; score and lives are cached for the
+        get_score / get_lives / game_over calls that follow."""
+        if int(action_int) not in self._engine.legal_actions:
+            raise ValueError("Expected to apply action, but failed: {0}".format(action_int))
+        frame = None
+        for _ in range(self.frames_per_action):
+            _, _, lives, score, frame = self._engine.step1_frame(self._env, action_int, channels)
+        self._scal = (score, lives)
+        return frame
+
     def apply_action(self, action_input_obj):
         if not isinstance(action_input_obj, Input):
             raise TypeError("apply_action takes an Input")
