@@ -251,6 +251,10 @@ def bench_mixed(args, world, rank, local_rank):
             mb.gather_init(rank, world)
     C, K, Wm, R = args.channels, args.steps, args.warmup, args.repeats
     render = not args.no_render
+    # three engines on three streams already keep two or three rasterisers in flight; the pipelined mode on top of that was
+    # measured slower (0.93-1.01 ms per step against 0.83-0.91: its internal streams, the three callers' streams and three
+    # communication streams then share the runtime's few hardware queues): off unless asked for with --pipeline 2 / 3
+    pipe = mb.set_pipeline(0 if args.pipeline == 1 else args.pipeline)
     lead = mb.engines[0]
     reg = Region(hip.synchronize, (lambda: lead.gather_reduce_max(0.0)) if gather else (lambda: None),
                  (lambda v: lead.gather_reduce_max(v)) if gather else (lambda v: v))
@@ -275,6 +279,7 @@ def bench_mixed(args, world, rank, local_rank):
         out = {"metric": "env steps/sec (whole node), mixed Breakout+Amidar+SpaceInvaders batch", "value": total / (ms * 1e-3),
                "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": ms, "repeats": rep,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+int32", "data": "synthetic",
+               "pipeline": {"option": args.pipeline, "resolved_per_game": dict(zip(games, pipe))},
                "config": {"workload": "mixed batch, %d envs/GPU = 3 x %d (breakout, amidar, space_invaders), %s, three streams%s"
                                       % (mb.n_envs, per, "step + RGB render" if render else "step-only",
                                          ", per-step RCCL gather of 8 B/env records" if gather else ""),

@@ -268,6 +268,14 @@ class MixedBatch:
         self.streams = None
         self.gathering = False
 
+    def set_pipeline(self, value):
+        """TBX_OPT_PIPELINE on every engine (those whose rasteriser reads live state ignore it): with three engines sharing one
+        GPU, a step that runs beside its own previous render keeps two or three rasterisers in flight at all times."""
+        from . import _abi
+        for e in self.engines:
+            e.set_option(_abi.OPT_PIPELINE, int(value))
+        return [e.get_option(_abi.OPT_PIPELINE_ACTIVE) for e in self.engines]
+
     def attach_streams(self, streams):
         """One stream handle (int) per game; without it everything runs on the null stream."""
         self.streams = list(streams)
