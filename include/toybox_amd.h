@@ -552,16 +552,17 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  *     value 3: additionally consecutive rasteriser launches alternate between two internal streams and the two frame
  *              buffers, so that launch N+1 fills the ramp-down of launch N (small batches: BASELINE configs 2-4, the
  *              per-GPU share of a strong-scaled batch);
- *     value 1: the engine's choice: 2 from 16 384 envs up, else 0.  (Measured, scripts/pipeline_sweep.py: value 2 makes the
+ *     value 1: the engine's choice: 2 for Breakout and SpaceInvaders from 16 384 envs up, else 0.  (Measured, scripts/pipeline_sweep.py: value 2 makes the
  *              large-batch loop 1-15 % faster depending on the box and never slower; value 3 gains 4-10 % at 4 096-8 192 envs
  *              WITHOUT a per-step gather and loses with one, and its gain depends on which hardware queues the runtime
  *              hands the internal streams -- it stays an explicit choice.)
  *   Contract in this mode: the stream a call names still waits for the call's work, so anything queued on it afterwards sees
  *   the result; the result of step N (render N) stays valid for readers queued on that stream BEFORE step N+1 (render N+1)
  *   is issued -- the same rule as without the option -- but it lives at the address tbx_device_buffer reports after the
- *   call, which alternates.  Every other call on the handle first joins the pipeline.  Engines whose rasteriser reads live
- *   state (Amidar, GridWorld, Breakout with intervention-written bricks, SpaceInvaders with intervention-written enemy
- *   positions) ignore the option. */
+ *   call, which alternates.  Every other call on the handle first joins the pipeline.  Amidar takes part through a record
+ *   kernel that follows its step on the internal stream (values 2 and 3 only: measured slower than stream order, its step is
+ *   long enough to disturb the rasteriser it runs beside).  Engines whose rasteriser can only read live state (GridWorld,
+ *   Breakout with intervention-written bricks, SpaceInvaders with intervention-written enemy positions) ignore the option. */
 #define TBX_OPT_PIPELINE      0
 /* batch step kernel form of Breakout and Amidar: 0 = the engine's choice (by batch size), 1 = one thread per env, 2 = one
  * wavefront per env */

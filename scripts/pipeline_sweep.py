@@ -24,6 +24,8 @@ for n in sizes:
     K = int(os.environ.get("PS_STEPS", "0")) or max(200, min(2000, 200 * 65536 // n // 4))
     e = Engine(game, n, lib=lib)
     e.seed(1234); e.new_game()
+    if os.environ.get("PS_STEP_FORM"):
+        e.set_option(_abi.OPT_STEP_FORM, int(os.environ["PS_STEP_FORM"]))
     if gather:
         e.gather_init(1, 0, e.gather_unique_id())
     st = hip.Stream()
@@ -50,7 +52,7 @@ for n in sizes:
             hip.synchronize()
             out[m].append(1000.0 * (time.perf_counter() - w0) / K)
     e.sync()
-    line = {"game": game, "envs": n, "steps": K, "gather": gather, "lib": os.environ.get("PS_LIB", "default")}
+    line = {"game": game, "envs": n, "steps": K, "gather": gather, "lib": os.environ.get("PS_LIB", "default"), "step_form": os.environ.get("PS_STEP_FORM", "auto")}
     for m in modes:
         best, med = min(out[m]), sorted(out[m])[len(out[m]) // 2]
         line["mode%d" % m] = {"ms_per_step": [round(v, 4) for v in out[m]], "median_ms": round(med, 4),

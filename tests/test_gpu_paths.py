@@ -497,12 +497,14 @@ def test_step1_on_a_batch_engine(lib, oracle_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("game,n,mode", [("breakout", 40000, 2), ("breakout", 40000, 3), ("breakout", 3000, 3), ("breakout", 3000, 1),
-                                         ("space_invaders", 20000, 2), ("space_invaders", 3000, 3), ("amidar", 20000, 3)])
+                                         ("space_invaders", 20000, 2), ("space_invaders", 3000, 3), ("amidar", 20000, 3), ("amidar", 3000, 2),
+                                         ("gridworld", 5000, 3)])
 @pytest.mark.parametrize("same_stream", [True, False])
 def test_pipelined_mode_keeps_program_order(same_stream, game, n, mode, hip_lib, oracle_lib):
     """TBX_OPT_PIPELINE: tbx_step_synthetic on Breakout runs on the engine's step stream BESIDE the rasteriser launch queued
     before it (two buffers of records and of step outputs); with value 3 consecutive rasteriser launches alternate between two
-    internal streams and two frame buffers (Amidar, which ignores the option, walks the same call pattern as the control).
+    internal streams and two frame buffers; SpaceInvaders likewise (records), Amidar through the record-prep kernel that follows
+    its step on the step's stream (GridWorld, which ignores the option, walks the same call pattern as the control).
     What the caller sees must stay program order: every frame is the frame of the step before it, device buffers read behind
     the caller's stream are the step's, and calls of every other kind in between (state reads and writes, new games,
     host-pointer steps and renders, a device-action step, a second render of one frame, two steps in a row) join the

@@ -522,7 +522,7 @@ static int pipe_mode(const tbx_engine* e)
 {
     const int v = e->opt[TBX_OPT_PIPELINE];
     if (v == 0 || !e->ops->pipeline_ok()) return 0;
-    if (v == 1) return e->n >= 16384 ? 2 : 0;
+    if (v == 1) return (e->n >= 16384 && e->ops->pipeline_pays()) ? 2 : 0;
     return v;
 }
 
@@ -572,6 +572,7 @@ static int pipe_enter(tbx_engine* e)
     for (int k = 0; k < 2; k++) { p.render_pending[k] = p.user_step_rec[k] = p.user_frame_rec[k] = false; p.render_on[k] = nullptr; }
     p.step_outstanding = false;
     p.step_on = nullptr;
+    p.step_user = nullptr;
     p.frame_par = -1;
     p.active = true;
     return TBX_OK;
@@ -602,6 +603,7 @@ static int pipe_step(tbx_engine* e, const ActionSource& src, uint32_t flags, hip
     EHIP(hipStreamWaitEvent(user, p.step_ev, 0));
     p.step_outstanding = true;
     p.step_on = ss;
+    p.step_user = user;
     e->last_stream = user;
     e->has_last = true;
     return TBX_OK;
@@ -615,7 +617,7 @@ static int pipe_render(tbx_engine* e, uint8_t* out_dev, int channels, hipStream_
     const int rp = e->ops->records_parity();
     const bool overlap = mode == 3 && out_dev == nullptr;
     const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
-    hipStream_t rs = user;                                     // (U already waits for the step: pipe_step made it)
+    hipStream_t rs = user;
     if (overlap) {
         const int fp = rp;                                     // frame buffer and stream follow the records' parity
         rs = p.lane[fp];
@@ -636,10 +638,14 @@ static int pipe_render(tbx_engine* e, uint8_t* out_dev, int channels, hipStream_
         p.user_frame_rec[prev] = true;
         if (p.user_frame_rec[fp]) { EHIP(hipStreamWaitEvent(rs, p.user_frame_ev[fp], 0)); p.user_frame_rec[fp] = false; }
         out_dev = p.frame[fp];
-    } else if (!out_dev) {
-        rc = ensure_frame(e, bytes);
-        if (rc) return rc;
-        out_dev = e->frame_own;
+    } else {
+        // on the caller's stream: it waits for the step unless it is the stream the step call named (pipe_step made that one wait)
+        if (p.step_outstanding && p.step_user != user) EHIP(hipStreamWaitEvent(rs, p.step_ev, 0));
+        if (!out_dev) {
+            rc = ensure_frame(e, bytes);
+            if (rc) return rc;
+            out_dev = e->frame_own;
+        }
     }
     if (((uintptr_t)out_dev & 15u) != 0) return e->fail(TBX_E_INVALID, "frame buffer must be 16-byte aligned");
     if (p.render_pending[rp] && p.render_on[rp] != rs) EHIP(hipStreamWaitEvent(rs, p.render_ev[rp], 0));   // (another render of these records)

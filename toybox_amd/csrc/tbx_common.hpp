@@ -317,7 +317,8 @@ struct TbxStepOut {
 struct TbxPipe {
     hipStream_t lane[2] = {nullptr, nullptr};        // value 2: lane[0] is the step stream; value 3: step N and render N on lane[parity]
     hipEvent_t step_ev = nullptr;                    // behind the last pipelined step ...
-    hipStream_t step_on = nullptr;                   // ... which ran on this stream
+    hipStream_t step_on = nullptr;                   // ... which ran on this stream ...
+    hipStream_t step_user = nullptr;                 // ... and which this caller's stream has been made to wait for (compared, never used)
     hipEvent_t render_ev[2] = {nullptr, nullptr};    // behind the last render that READ records buffer p ...
     hipStream_t render_on[2] = {nullptr, nullptr};   // ... which ran on this stream
     bool render_pending[2] = {false, false};
@@ -459,6 +460,7 @@ struct GameOps {
     // every env on stream s, records into the OTHER buffer, which becomes the current one.  The step outputs go wherever
     // tbx_engine::reward / done / ... point at the time of the launch (rebind_outputs() after the engine moved them).
     virtual bool pipeline_ok() const { return false; }
+    virtual bool pipeline_pays() const { return pipeline_ok(); }     // TBX_OPT_PIPELINE = 1 (the engine's choice) may pick it
     virtual int records_parity() const { return 0; }
     virtual int step_ahead(tbx_engine*, const ActionSource&, uint32_t, hipStream_t) { return TBX_E_UNSUPPORTED; }
     virtual void rebind_outputs(tbx_engine*) {}
