@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """What a short kernel serialised between two rasteriser launches costs: one engine, 2-second blocks of render only /
-step + render (the library runs Breakout's step beside the render: tbx_step_ahead; TBX_NO_STEP_AHEAD=1 serialises it).
+step + render in stream order / step + render with TBX_OPT_PIPELINE = 2 (the step beside the previous render).
 usage: interleave_probe.py [game]"""
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from toybox_amd import Engine, hip  # noqa: E402
+from toybox_amd import Engine, _abi, hip  # noqa: E402
 
 n = 65536
 e = Engine(sys.argv[1] if len(sys.argv) > 1 else "breakout", n)
@@ -39,9 +39,13 @@ def block(name, fn, seconds=2.0):
             k += 1
         hip.synchronize()
     dt = time.perf_counter() - t0
-    print("%-14s %.4f ms per pass   %s" % (name, dt / k * 1e3, "TBX_NO_STEP_AHEAD" if os.environ.get("TBX_NO_STEP_AHEAD") else ""), flush=True)
+    print("%-28s %.4f ms per pass" % (name, dt / k * 1e3), flush=True)
 
 
 for rnd in range(3):
     block("render only", render_only)
-    block("step + render", step_render)
+    e.set_option(_abi.OPT_PIPELINE, 0)
+    block("step + render, stream order", step_render)
+    e.set_option(_abi.OPT_PIPELINE, 2)
+    block("step + render, pipelined", step_render)
+    e.set_option(_abi.OPT_PIPELINE, 0)
