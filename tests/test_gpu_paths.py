@@ -160,7 +160,7 @@ for t in range(120):
 @pytest.mark.gpu
 @pytest.mark.parametrize("form", [1, 2])
 def test_amidar_step_kernel_forms_parity(form, oracle_lib):
-    """Amidar's batch step has two forms, chosen by batch size (thread per env from 16 384 envs up, wavefront per env
+    """Amidar's batch step has two forms, chosen by batch size (thread per env from 32 768 envs up, wavefront per env
     below): TBX_OPT_STEP_FORM forces either one at a batch size the oracle finishes, through the batch protocol, device
     actions and the agent pipeline with every reset-time wrapper on."""
     body = r"""

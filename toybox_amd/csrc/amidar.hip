@@ -1955,10 +1955,12 @@ struct AmiOps : GameOps {
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         dA.tab = dB.tab = d.tab;
         // TBX_OPT_STEP_FORM: 2 = never, 1 = always, 0 = by batch size.  The thread form is one wave per 64 envs with a long
-        // serial path per thread (~40 us whatever the batch), the wave form scales with the batch (~28 us at 12 288 envs, ~14 us
-        // at 4 096): below ~16 k envs the wave form is the faster one (measured)
+        // serial path per thread (~45 us whatever the batch), the wave form scales with the batch.  Measured in the step + render
+        // loop (scripts/pipeline_sweep.py amidar, PS_STEP_FORM=1|2, one box): ms per step thread / wave form 0.246 / 0.215 at
+        // 8 192 envs, 0.419 / 0.394 at 16 384, 0.601 / 0.591 at 24 576, 0.778 / 0.779 at 32 768, 1.130 / 1.168 at 49 152,
+        // 1.483 / 1.546 at 65 536 (round 2 had put the switch at 16 384 from step-only timings)
         const int form = e->opt[TBX_OPT_STEP_FORM];
-        const bool use_tpe = form == 2 ? false : form == 1 ? true : e->n >= 16384;
+        const bool use_tpe = form == 2 ? false : form == 1 ? true : e->n >= 32768;
         if (use_tpe && src.single_env < 0) {
             // large batches: one THREAD per env (the wave-per-env form stays for small batches, single-env calls and the
             // in-kernel reset procedure)
