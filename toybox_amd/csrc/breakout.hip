@@ -978,6 +978,27 @@ struct BrkPalette {
 // (scripts/ubench/): a persistent grid over address-ordered units reaches 6.1 TB/s as bare stores but 4.7-4.9 TB/s with
 // record loads and LDS staging; one-shot address-ordered waves of 1, 2, 4 or 10 CONSECUTIVE units 5.3-5.5 TB/s
 // (hipMemset on the same boxes: 6.3-6.5 TB/s).
+// a render record travels through the rasteriser as ONE VGPR (lane i < 16 holds dword i: a single 64-byte request)
+__device__ __forceinline__ uint32_t brk_rec_load_lanes(const BrkRenderRec* __restrict__ r, int lane)
+{
+    return lane < 16 ? reinterpret_cast<const uint32_t*>(r)[lane] : 0u;
+}
+__device__ __forceinline__ BrkRenderRec brk_rec_from_lanes(uint32_t rv)
+{
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)rv, i);
+    BrkRenderRec rec;
+#pragma unroll
+    for (int i = 0; i < MAXK; i++) rec.alive[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    rec.paddle = w[8];
+#pragma unroll
+    for (int i = 0; i < MAXB; i++) rec.ball[i] = w[9 + i];
+    rec.hud = w[13]; rec.n_bricks = (int32_t)w[14]; rec._pad = w[15];
+    return rec;
+}
+static_assert(MAXK == 4 && MAXB == 4, "record layout: alive[4] u64, paddle, ball[4], hud, n_bricks, pad");
+
 // what a lane needs for every scanline whatever the env: finished palette values, its side-wall pattern, its HUD glyph slots.
 // Built by the kernel BEFORE it looks at its work item (so the record's scalar loads overlap with it).
 template <int C>
@@ -1014,8 +1035,13 @@ struct BrkLaneTables {
 
 // One frame's units part, part + split, ... of one env from its record, on one wave (st: the wave's LDS slice): the body of
 // brk_render_kernel, also what the resident single-env kernel calls after a step (tbx_serve_loop).  frame_out: the env's frame.
-template <int C, bool CUSTOM>
-__device__ __forceinline__ void brk_paint_units(const BrkRenderRec& rec, const BrkCustom* __restrict__ custom, const BrkPalette& pal, const BrkLaneTables<C>& t,
+// how brk_paint_units gets at the record: carried as one VGPR and turned into SGPRs per unit (RGB / RGBA launches), or held in
+// SGPRs for the whole frame (gray launches, where the former form measured 25 % slower: 0.83 against 0.66 ms at 65 536 envs)
+struct BrkRecLanes { uint32_t rv; __device__ __forceinline__ BrkRenderRec get() const { return brk_rec_from_lanes(rv); } };
+struct BrkRecHeld { const BrkRenderRec& r; __device__ __forceinline__ const BrkRenderRec& get() const { return r; } };
+
+template <int C, bool CUSTOM, class RecSrc>
+__device__ __forceinline__ void brk_paint_units(const RecSrc src, const BrkCustom* __restrict__ custom, const BrkPalette& pal, const BrkLaneTables<C>& t,
                                                 uint8_t* __restrict__ frame_out, int env, int lane, const RowStager<C, TBX_BRK_W, BRK_UNIT_ROWS>& st,
                                                 int part, int split)
 {
@@ -1029,6 +1055,9 @@ __device__ __forceinline__ void brk_paint_units(const BrkRenderRec& rec, const B
     const uint32_t (&hud_sel)[4] = t.hud_sel;
 
     for (int q = part; q < NUNITS; q += split) {
+        // the record, wave-uniform, for the length of one unit: sixteen v_readlane out of the VGPR that carries it (rv: lane i =
+        // dword i) -- sixteen SGPRs that are not held across the frame loop of the kernel
+        const BrkRenderRec rec = src.get();
         const int u = (int)(((uint32_t)env * 7u + (uint32_t)q) % (uint32_t)NUNITS);
         uint8_t* dst = frame_out + (size_t)u * BRK_UNIT_ROWS * W * C;
         const int y_first = u * BRK_UNIT_ROWS;
@@ -1129,9 +1158,9 @@ __device__ __forceinline__ void brk_paint_units(const BrkRenderRec& rec, const B
 }
 
 template <int C, bool CUSTOM, bool ALT>
-__global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
+__device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
                                                                BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split,
-                                                               const BrkRenderRec* __restrict__ recs_alt = nullptr, const uint8_t* __restrict__ pick_alt = nullptr)
+                                                               const BrkRenderRec* __restrict__ recs_alt, const uint8_t* __restrict__ pick_alt)
 {
     constexpr int W = TBX_BRK_W, H = TBX_BRK_H;
     using Stager = RowStager<C, W, BRK_UNIT_ROWS>;
@@ -1146,12 +1175,45 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
     const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
     const int rel = wid / split, part = wid - rel * split;
     if (rel >= count) return;
-    // the env's record by value, ONCE, before the unit loop: scalar loads up front, none between the frame stores.  (agent
-    // layer, generic path: flagged envs paint recs_alt -- the ARRAY is selected; a select between two loaded records turns
-    // the scalar loads into vector loads, and a load left inside the loop is repeated per unit behind the stores)
+    // (agent layer, generic path: flagged envs paint recs_alt -- the ARRAY is selected; a select between two loaded records turns
+    // scalar loads into vector loads)
     const BrkRenderRec* __restrict__ rsrc = (ALT && pick_alt && wave_uniform((int)pick_alt[first_env + rel])) ? recs_alt : recs;
-    const BrkRenderRec rec = rsrc[first_env + rel];
-    brk_paint_units<C, CUSTOM>(rec, custom, pal, tables, out + (size_t)rel * H * W * C, first_env + rel, lane, st, part, split);
+    uint8_t* frame = out + (size_t)rel * H * W * C;
+    if (C == 1) {          // gray: the record by scalar loads, held in SGPRs for the frame
+        const BrkRenderRec rec = rsrc[first_env + rel];
+        brk_paint_units<C, CUSTOM>(BrkRecHeld{rec}, custom, pal, tables, frame, first_env + rel, lane, st, part, split);
+        return;
+    }
+    // RGB / RGBA: the record arrives as ONE 64-byte vector load (lane i < 16 = dword i) and is turned into SGPRs unit by unit,
+    // sixteen v_readlane each time.  Two things came out of that, both measured (scripts/ubench/rate_state.hip, one box, processes
+    // of both builds interleaved): 67 VGPRs instead of 87 and 29 spilled SGPRs instead of 64 -- and a launch that follows a step
+    // costs 1.23-1.25 ms instead of 1.29-1.34 (back to back: 1.19 against 1.18).  What the experiments there showed about the two
+    // rates of round 2: it is the step kernel's RECORD STORE, nothing else it does, that slows the following rasteriser launch (a
+    // step without it: 1.19 ms; with only it: 1.41; empty kernels, a 13 MB read-modify-write, event records, binary64 chains
+    // between two launches: 1.18): a record that has just been rewritten is in nobody's cache, its read goes to HBM and queues
+    // there behind this kernel's own 6 TB/s of writes, at the start of every wave.  Fetching the next frame's record a frame ahead
+    // (two or four frames per wave) hides the latency but costs more than it saves: 1.32-1.37 ms.
+    brk_paint_units<C, CUSTOM>(BrkRecLanes{brk_rec_load_lanes(&rsrc[first_env + rel], lane)}, custom, pal, tables, frame, first_env + rel, lane, st, part, split);
+}
+
+// Two launch forms of the same body.  RGB and RGBA frames stream fastest with exactly FIVE waves per SIMD (measured at 65 536 envs,
+// builds with amdgpu_waves_per_eu 3 / 4 / 5 / 6: 1.75 / 1.40 / 1.22 / 1.37 ms -- the record carried as one VGPR leaves room for
+// seven, and the launch is slower with more writers in flight, not faster); gray frames, a third of the bytes, take what the
+// registers allow (0.66 against 0.85 ms when held to five).
+template <int C, bool CUSTOM, bool ALT>
+__global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void brk_render_kernel_w5(
+    const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom, BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split,
+    const BrkRenderRec* __restrict__ recs_alt = nullptr, const uint8_t* __restrict__ pick_alt = nullptr)
+{
+    brk_render_body<C, CUSTOM, ALT>(recs, custom, pal, out, first_env, count, split, recs_alt, pick_alt);
+}
+
+template <int C, bool CUSTOM, bool ALT>
+__global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom, BrkPalette pal,
+                                                               uint8_t* __restrict__ out, int first_env, int count, int split,
+                                                               const BrkRenderRec* __restrict__ recs_alt = nullptr, const uint8_t* __restrict__ pick_alt = nullptr)
+{
+    brk_render_body<C, CUSTOM, ALT>(recs, custom, pal, out, first_env, count, split, recs_alt, pick_alt);
 }
 
 // ------------------------------------------------------------------ resident single-env form (tbx_serve_loop, tbx_common.hpp)
@@ -1163,7 +1225,7 @@ template <bool CUSTOM>
 __device__ __forceinline__ bool brk_serve_paint(const BrkDev& d, const BrkRenderRec* recs, const BrkPalette& pal, int channels, uint8_t* frame, int lane, uint8_t* lds,
                                                 int part, int split)
 {
-    const BrkRenderRec rec = recs[0];
+    const BrkRecLanes rec{brk_rec_load_lanes(&recs[0], lane)};
     switch (channels) {
     case 1: brk_paint_units<1, CUSTOM>(rec, d.custom, pal, BrkLaneTables<1>(pal, lane), frame, 0, lane, RowStager<1, TBX_BRK_W, BRK_UNIT_ROWS>{lds}, part, split); break;
     case 3: brk_paint_units<3, CUSTOM>(rec, d.custom, pal, BrkLaneTables<3>(pal, lane), frame, 0, lane, RowStager<3, TBX_BRK_W, BRK_UNIT_ROWS>{lds}, part, split); break;
@@ -1700,13 +1762,16 @@ struct BreakoutOps : GameOps {
         // lower): measured 6.05-6.25 TB/s against 5.4-5.7 for one wave per frame and for every other split from 1 to 20
         // except 9..12 (scripts/ab_render.py over TBX_OPT_RENDER_SPLIT); also what keeps small batches from under-filling the chip
         const int split = split_opt > 0 ? split_opt : C == 3 ? 10 : count <= 8192 ? 4 : count <= 32768 ? 2 : 1;   // gray / RGBA: no such effect
-        if (pick_alt) {        // the agent layer's generic path: per-env choice between two record arrays
-            if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true, true>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
-            else hipLaunchKernelGGL((brk_render_kernel<C, false, true>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
+        const dim3 grid = grid_for(count * split), block(TBX_BLOCK);
+#define BRK_LAUNCH(KERNEL, CUSTOM_, ALT_) hipLaunchKernelGGL((KERNEL<C, CUSTOM_, ALT_>), grid, block, 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt)
+        if (C >= 3) {          // (pick_alt: the agent layer's generic path, per-env choice between two record arrays)
+            if (pick_alt) { if (custom) BRK_LAUNCH(brk_render_kernel_w5, true, true); else BRK_LAUNCH(brk_render_kernel_w5, false, true); }
+            else { if (custom) BRK_LAUNCH(brk_render_kernel_w5, true, false); else BRK_LAUNCH(brk_render_kernel_w5, false, false); }
         } else {
-            if (custom) hipLaunchKernelGGL((brk_render_kernel<C, true, false>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
-            else hipLaunchKernelGGL((brk_render_kernel<C, false, false>), grid_for(count * split), dim3(TBX_BLOCK), 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt);
+            if (pick_alt) { if (custom) BRK_LAUNCH(brk_render_kernel, true, true); else BRK_LAUNCH(brk_render_kernel, false, true); }
+            else { if (custom) BRK_LAUNCH(brk_render_kernel, true, false); else BRK_LAUNCH(brk_render_kernel, false, false); }
         }
+#undef BRK_LAUNCH
     }
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override

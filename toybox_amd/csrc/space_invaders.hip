@@ -1362,7 +1362,13 @@ struct SiRecPainter {
     {
         lane = lane_;
         const SiRenderRec* rec = recs + env;
-        const uint32_t* h = reinterpret_cast<const uint32_t*>(rec);     // wave-uniform address: scalar loads
+        // the header by ONE vector load (lane i = dword i) and a v_readlane per dword, not by scalar loads: a record the step kernel
+        // has just rewritten is in nobody's cache, and cold reads through the scalar cache at the start of every wave are what made
+        // Breakout's rasteriser 10-15 % slower behind a step than back to back (breakout.hip, brk_render_body)
+        const uint32_t hv = lane < REC_HDR_DWORDS ? reinterpret_cast<const uint32_t*>(rec)[lane] : 0u;
+        uint32_t h[REC_HDR_DWORDS];
+#pragma unroll
+        for (int i = 0; i < REC_HDR_DWORDS; i++) h[i] = (uint32_t)__builtin_amdgcn_readlane((int)hv, i);
         fx = (int)h[0]; fy = (int)h[1];
         vis = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
         alive = (uint64_t)h[4] | ((uint64_t)h[5] << 32);
