@@ -875,7 +875,18 @@ __global__ __launch_bounds__(128) void brk_agent_reset_kernel(BrkDev d, const Br
 
 // ------------------------------------------------------------------ render
 
-__constant__ uint16_t BRK_DIGITS[10] = {0x7B6F, 0x749A, 0x73E7, 0x79E7, 0x49ED, 0x79CF, 0x7BCF, 0x4927, 0x7BEF, 0x79EF};
+// 3x5 digit glyphs, bit 3*row + column.  Looked up out of four immediates, not out of memory: a load inside the rasteriser's
+// unit loop brings an `s_waitcnt vmcnt(0)` with it, and on gfx9 that waits for every STORE the wave has in flight as well
+__device__ __forceinline__ uint32_t brk_digit_glyph(uint32_t digit)
+{
+    constexpr uint16_t G[16] = {0x7B6F, 0x749A, 0x73E7, 0x79E7, 0x49ED, 0x79CF, 0x7BCF, 0x4927, 0x7BEF, 0x79EF, 0, 0, 0, 0, 0, 0};
+    constexpr uint64_t K0 = G[0] | ((uint64_t)G[1] << 16) | ((uint64_t)G[2] << 32) | ((uint64_t)G[3] << 48);
+    constexpr uint64_t K1 = G[4] | ((uint64_t)G[5] << 16) | ((uint64_t)G[6] << 32) | ((uint64_t)G[7] << 48);
+    constexpr uint64_t K2 = G[8] | ((uint64_t)G[9] << 16);
+    const uint32_t k = digit >> 2;
+    const uint64_t w = k == 0 ? K0 : k == 1 ? K1 : k == 2 ? K2 : 0ull;
+    return (uint32_t)(w >> (16u * (digit & 3u))) & 0xFFFFu;
+}
 
 // 8 scanlines = 5 760 B (RGB) = 45 x 128 B: units whose size is not a multiple of 128 B (5, 10, 20 rows) measured 15-40 %
 // slower, 16 rows no better
@@ -1037,8 +1048,15 @@ struct BrkLaneTables {
 // brk_render_kernel, also what the resident single-env kernel calls after a step (tbx_serve_loop).  frame_out: the env's frame.
 // how brk_paint_units gets at the record: carried as one VGPR and turned into SGPRs per unit (RGB / RGBA launches), or held in
 // SGPRs for the whole frame (gray launches, where the former form measured 25 % slower: 0.83 against 0.66 ms at 65 536 envs)
-struct BrkRecLanes { uint32_t rv; __device__ __forceinline__ BrkRenderRec get() const { return brk_rec_from_lanes(rv); } };
-struct BrkRecHeld { const BrkRenderRec& r; __device__ __forceinline__ const BrkRenderRec& get() const { return r; } };
+struct BrkRecLanes {
+    uint32_t rv;
+    __device__ __forceinline__ BrkRenderRec get() const { return brk_rec_from_lanes(rv); }
+    // called once before the unit loop: one lane of the record is read there, so the wait for the record's load stands in front
+    // of the loop.  Left to the first use inside the loop, the compiler's wait sits at the loop header as `s_waitcnt vmcnt(0)`,
+    // and every later unit of the wave then starts by waiting for the previous unit's stores
+    __device__ __forceinline__ void arrive() const { const int x = __builtin_amdgcn_readlane((int)rv, 15); asm volatile("" :: "s"(x)); }
+};
+struct BrkRecHeld { const BrkRenderRec& r; __device__ __forceinline__ const BrkRenderRec& get() const { return r; } __device__ __forceinline__ void arrive() const {} };
 
 template <int C, bool CUSTOM, class RecSrc>
 __device__ __forceinline__ void brk_paint_units(const RecSrc src, const BrkCustom* __restrict__ custom, const BrkPalette& pal, const BrkLaneTables<C>& t,
@@ -1054,6 +1072,7 @@ __device__ __forceinline__ void brk_paint_units(const RecSrc src, const BrkCusto
     const uint32_t (&side)[4] = t.side;
     const uint32_t (&hud_sel)[4] = t.hud_sel;
 
+    src.arrive();
     for (int q = part; q < NUNITS; q += split) {
         // the record, wave-uniform, for the length of one unit: sixteen v_readlane out of the VGPR that carries it (rv: lane i =
         // dword i) -- sixteen SGPRs that are not held across the frame loop of the kernel
@@ -1069,7 +1088,7 @@ __device__ __forceinline__ void brk_paint_units(const RecSrc src, const BrkCusto
             for (int i = 0; i < 4; i++) {
                 const uint32_t g = hud_sel[i] >> 2;
                 const uint32_t digit = (rec.hud >> (4 * g)) & 15u;    // g == 7 reads the unused top nibble
-                const uint32_t glyph = g < 7 ? (uint32_t)BRK_DIGITS[digit] : 0u;
+                const uint32_t glyph = g < 7 ? brk_digit_glyph(digit) : 0u;
                 hud[i] = (glyph >> (hud_sel[i] & 3u)) & 0x1249u;      // bit 3*r = lit in glyph row r
             }
         }
@@ -1384,8 +1403,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
                 if (dx >= 0 && dx < 6) sel = ((uint32_t)g << 2) | (uint32_t)(dx >> 1);
             }
             const uint32_t g = sel >> 2;
-            const uint32_t ga = g < 7 ? (uint32_t)BRK_DIGITS[(recA.hud >> (4 * g)) & 15u] : 0u;
-            const uint32_t gb = g < 7 ? (uint32_t)BRK_DIGITS[(recB.hud >> (4 * g)) & 15u] : 0u;
+            const uint32_t ga = g < 7 ? brk_digit_glyph((recA.hud >> (4 * g)) & 15u) : 0u;
+            const uint32_t gb = g < 7 ? brk_digit_glyph((recB.hud >> (4 * g)) & 15u) : 0u;
             hudA[i] = (ga >> (sel & 3u)) & 0x1249u;
             hudB[i] = (gb >> (sel & 3u)) & 0x1249u;
         }
