@@ -552,10 +552,12 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  *     value 3: additionally consecutive rasteriser launches alternate between two internal streams and the two frame
  *              buffers, so that launch N+1 fills the ramp-down of launch N (small batches: BASELINE configs 2-4, the
  *              per-GPU share of a strong-scaled batch);
- *     value 1: the engine's choice: 2 for Breakout and SpaceInvaders from 16 384 envs up, else 0.  (Measured, scripts/pipeline_sweep.py: value 2 makes the
- *              large-batch loop 1-15 % faster depending on the box and never slower; value 3 gains 4-10 % at 4 096-8 192 envs
- *              WITHOUT a per-step gather and loses with one, and its gain depends on which hardware queues the runtime
- *              hands the internal streams -- it stays an explicit choice.)
+ *     value 1: the engine's choice, which is 0 for every game today.  (Rounds 2-3 chose 2 for Breakout and SpaceInvaders from
+ *              16 384 envs up, 1-15 % faster "depending on the box": what it bought was a rasteriser launch that does not start
+ *              against an idle memory system, and the rasterisers now see to that themselves -- csrc/raster.hpp,
+ *              tbx_stagger_first_waves.  scripts/pipeline_sweep.py, 8 192 .. 65 536 envs: stream order 0.5-3 % ahead of value 2.
+ *              Value 3 gains 4-10 % at 4 096-8 192 envs WITHOUT a per-step gather and loses with one, and its gain depends on
+ *              which hardware queues the runtime hands the internal streams.  Both stay explicit choices.)
  *   Contract in this mode: the stream a call names still waits for the call's work, so anything queued on it afterwards sees
  *   the result; the result of step N (render N) stays valid for readers queued on that stream BEFORE step N+1 (render N+1)
  *   is issued -- the same rule as without the option -- but it lives at the address tbx_device_buffer reports after the

@@ -19,6 +19,7 @@ for p in sys.argv[3:]:
     libs.append((p, lib))
 n = int(__import__("os").environ.get("AB_ENVS", "65536"))
 pre = int(__import__("os").environ.get("AB_PREROLL", "30"))     # frames played before timing (mid-game states paint more)
+with_step = __import__("os").environ.get("AB_STEP", "0") == "1"   # time [step ; render] instead of [render]
 for rnd in range(3):
     for p, lib in libs:
         e = Engine(game, n, lib=lib)
@@ -28,7 +29,9 @@ for rnd in range(3):
         e.render_device(channels=ch)
         hip.synchronize()
         t0 = time.perf_counter()
-        for _ in range(40):
+        for k in range(40):
+            if with_step:
+                e.step_synthetic(1337, pre + k)
             e.render_device(channels=ch)
         hip.synchronize()
         dt = (time.perf_counter() - t0) / 40

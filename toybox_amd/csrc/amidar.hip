@@ -1303,7 +1303,6 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_agent_reset_kernel(AmiDev d, Am
 
 // ------------------------------------------------------------------ render
 
-__constant__ uint16_t AMI_DIGITS[10] = TBX_DIGIT_FONT;
 constexpr int AMI_UNIT_ROWS = 10;   // 250 = 25 units; 10 x 480 B (RGB) of LDS per wave
 
 __device__ __forceinline__ int world_to_px(int v)
@@ -1460,7 +1459,7 @@ struct AmiPainter {
             const int hud_x0[8] = {20, 28, 36, 44, 52, 84, 108, 132};
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                const uint32_t glyph = AMI_DIGITS[(hudw >> (4 * q)) & 15u];
+                const uint32_t glyph = tbx_digit_glyph((hudw >> (4 * q)) & 15u);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int dx = x0 + i - hud_x0[q];

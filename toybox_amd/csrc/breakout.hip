@@ -875,19 +875,6 @@ __global__ __launch_bounds__(128) void brk_agent_reset_kernel(BrkDev d, const Br
 
 // ------------------------------------------------------------------ render
 
-// 3x5 digit glyphs, bit 3*row + column.  Looked up out of four immediates, not out of memory: a load inside the rasteriser's
-// unit loop brings an `s_waitcnt vmcnt(0)` with it, and on gfx9 that waits for every STORE the wave has in flight as well
-__device__ __forceinline__ uint32_t brk_digit_glyph(uint32_t digit)
-{
-    constexpr uint16_t G[16] = {0x7B6F, 0x749A, 0x73E7, 0x79E7, 0x49ED, 0x79CF, 0x7BCF, 0x4927, 0x7BEF, 0x79EF, 0, 0, 0, 0, 0, 0};
-    constexpr uint64_t K0 = G[0] | ((uint64_t)G[1] << 16) | ((uint64_t)G[2] << 32) | ((uint64_t)G[3] << 48);
-    constexpr uint64_t K1 = G[4] | ((uint64_t)G[5] << 16) | ((uint64_t)G[6] << 32) | ((uint64_t)G[7] << 48);
-    constexpr uint64_t K2 = G[8] | ((uint64_t)G[9] << 16);
-    const uint32_t k = digit >> 2;
-    const uint64_t w = k == 0 ? K0 : k == 1 ? K1 : k == 2 ? K2 : 0ull;
-    return (uint32_t)(w >> (16u * (digit & 3u))) & 0xFFFFu;
-}
-
 // 8 scanlines = 5 760 B (RGB) = 45 x 128 B: units whose size is not a multiple of 128 B (5, 10, 20 rows) measured 15-40 %
 // slower, 16 rows no better
 constexpr int BRK_UNIT_ROWS = 8;    // scanlines per work item, staged in LDS (160 = 20 units)
@@ -1088,7 +1075,7 @@ __device__ __forceinline__ void brk_paint_units(const RecSrc src, const BrkCusto
             for (int i = 0; i < 4; i++) {
                 const uint32_t g = hud_sel[i] >> 2;
                 const uint32_t digit = (rec.hud >> (4 * g)) & 15u;    // g == 7 reads the unused top nibble
-                const uint32_t glyph = g < 7 ? brk_digit_glyph(digit) : 0u;
+                const uint32_t glyph = g < 7 ? tbx_digit_glyph(digit) : 0u;
                 hud[i] = (glyph >> (hud_sel[i] & 3u)) & 0x1249u;      // bit 3*r = lit in glyph row r
             }
         }
@@ -1200,19 +1187,19 @@ __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__
     uint8_t* frame = out + (size_t)rel * H * W * C;
     if (C == 1) {          // gray: the record by scalar loads, held in SGPRs for the frame
         const BrkRenderRec rec = rsrc[first_env + rel];
+        tbx_stagger_first_waves(wid);
         brk_paint_units<C, CUSTOM>(BrkRecHeld{rec}, custom, pal, tables, frame, first_env + rel, lane, st, part, split);
         return;
     }
     // RGB / RGBA: the record arrives as ONE 64-byte vector load (lane i < 16 = dword i) and is turned into SGPRs unit by unit,
-    // sixteen v_readlane each time.  Two things came out of that, both measured (scripts/ubench/rate_state.hip, one box, processes
-    // of both builds interleaved): 67 VGPRs instead of 87 and 29 spilled SGPRs instead of 64 -- and a launch that follows a step
-    // costs 1.23-1.25 ms instead of 1.29-1.34 (back to back: 1.19 against 1.18).  What the experiments there showed about the two
-    // rates of round 2: it is the step kernel's RECORD STORE, nothing else it does, that slows the following rasteriser launch (a
-    // step without it: 1.19 ms; with only it: 1.41; empty kernels, a 13 MB read-modify-write, event records, binary64 chains
-    // between two launches: 1.18): a record that has just been rewritten is in nobody's cache, its read goes to HBM and queues
-    // there behind this kernel's own 6 TB/s of writes, at the start of every wave.  Fetching the next frame's record a frame ahead
-    // (two or four frames per wave) hides the latency but costs more than it saves: 1.32-1.37 ms.
-    brk_paint_units<C, CUSTOM>(BrkRecLanes{brk_rec_load_lanes(&rsrc[first_env + rel], lane)}, custom, pal, tables, frame, first_env + rel, lane, st, part, split);
+    // sixteen v_readlane each time: 53 VGPRs instead of 87 and 19 spilled SGPRs instead of 64 (same-box A/B of the two forms,
+    // render-only loops: 1.214-1.222 ms against 1.236-1.244).  The "two rates" of round 2 -- the same loop of [step ; render]
+    // at 1.20 ms on one box and 1.35 on the next -- were NOT about this load (a kernel that re-reads every record between the
+    // step and the rasteriser changes nothing; writing the records to a buffer the rasteriser does not read removes the slow
+    // rate, and so does a rasteriser launch that follows another one): see tbx_stagger_first_waves in raster.hpp.
+    const BrkRecLanes rl{brk_rec_load_lanes(&rsrc[first_env + rel], lane)};
+    tbx_stagger_first_waves(wid);          // (raster.hpp; the record's load is in flight meanwhile)
+    brk_paint_units<C, CUSTOM>(rl, custom, pal, tables, frame, first_env + rel, lane, st, part, split);
 }
 
 // Two launch forms of the same body.  RGB and RGBA frames stream fastest with exactly FIVE waves per SIMD (measured at 65 536 envs,
@@ -1403,8 +1390,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
                 if (dx >= 0 && dx < 6) sel = ((uint32_t)g << 2) | (uint32_t)(dx >> 1);
             }
             const uint32_t g = sel >> 2;
-            const uint32_t ga = g < 7 ? brk_digit_glyph((recA.hud >> (4 * g)) & 15u) : 0u;
-            const uint32_t gb = g < 7 ? brk_digit_glyph((recB.hud >> (4 * g)) & 15u) : 0u;
+            const uint32_t ga = g < 7 ? tbx_digit_glyph((recA.hud >> (4 * g)) & 15u) : 0u;
+            const uint32_t gb = g < 7 ? tbx_digit_glyph((recB.hud >> (4 * g)) & 15u) : 0u;
             hudA[i] = (ga >> (sel & 3u)) & 0x1249u;
             hudB[i] = (gb >> (sel & 3u)) & 0x1249u;
         }

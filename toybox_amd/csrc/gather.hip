@@ -187,8 +187,8 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
     g.nranks = nranks; g.rank = rank; g.width = records_per_rank;
     GHIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     GHIP(hipEventCreateWithFlags(&g.ready, hipEventDisableTiming));
-    GHIP(hipEventCreateWithFlags(&g.done[0], hipEventDisableTiming));
-    GHIP(hipEventCreateWithFlags(&g.done[1], hipEventDisableTiming));
+    GHIP(hipEventCreateWithFlags(&g.done[0], hipEventDisableTiming | hipEventReleaseToDevice));
+    GHIP(hipEventCreateWithFlags(&g.done[1], hipEventDisableTiming | hipEventReleaseToDevice));
     GHIP(hipMalloc((void**)&g.out, sizeof(uint64_t) * (size_t)nranks * (size_t)g.width));
     GHIP(hipMemset(g.out, 0, sizeof(uint64_t) * (size_t)nranks * (size_t)g.width));
     GHIP(hipMalloc((void**)&g.scalar, sizeof(double)));

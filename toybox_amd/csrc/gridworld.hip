@@ -347,10 +347,22 @@ struct GwPainter {
         const int cy = y / th;
         if (cy != last_cy) {
             last_cy = cy;
+            // the cell row's sixteen board bytes out of lane cy's registers (setup loaded them): a load here would sit inside
+            // the unit loop, and its `s_waitcnt vmcnt(0)` waits for the wave's frame stores as well
+            static_assert(GD == 32, "a grid row is 32 bytes: lanes 2 cy and 2 cy + 1 of `cells`");
+            const int rl = wave_uniform(2 * (cy < GD ? cy : GD - 1));
+            uint32_t row[8];
+            row[0] = (uint32_t)__builtin_amdgcn_readlane((int)cells.x, rl); row[1] = (uint32_t)__builtin_amdgcn_readlane((int)cells.y, rl);
+            row[2] = (uint32_t)__builtin_amdgcn_readlane((int)cells.z, rl); row[3] = (uint32_t)__builtin_amdgcn_readlane((int)cells.w, rl);
+            row[4] = (uint32_t)__builtin_amdgcn_readlane((int)cells.x, rl + 1); row[5] = (uint32_t)__builtin_amdgcn_readlane((int)cells.y, rl + 1);
+            row[6] = (uint32_t)__builtin_amdgcn_readlane((int)cells.z, rl + 1); row[7] = (uint32_t)__builtin_amdgcn_readlane((int)cells.w, rl + 1);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const bool inside = active && cx[k] < gw && cy < gh;
-                const int id = inside ? g[cy * GD + cx[k]] : 255;
+                uint32_t word = row[0];
+#pragma unroll
+                for (int q = 1; q < 8; q++) word = (cx[k] >> 2) == q ? row[q] : word;
+                const int id = inside ? (int)((word >> (8 * (cx[k] & 3))) & 255u) : 255;
                 const uint32_t tc = __shfl(tcol, id & 15);
                 c[k] = !inside ? black : (cx[k] == px && cy == py) ? pcol : id < GT ? tc : black;
             }

@@ -9,10 +9,46 @@
 #pragma once
 
 #include "tbx_common.hpp"
+#include "../../include/toybox_amd_spec.h"
 
 // the frame stores are plain 16-byte stores: non-temporal (`nt`) stores measured within run-to-run noise of them (A/B on one
 // box, scripts/ab_render.py)
 __device__ __forceinline__ void tbx_store16(uint4* p, const uint4& v) { *p = v; }
+
+// The 3x5 HUD digit font (bit 3*row + column), looked up out of immediates.  Not a table in memory: inside a rasteriser every
+// vector load queues behind the compute unit's own stores (measured on the Breakout kernel: 2 700 cycles for a 64-byte record
+// whatever cache holds it), and the `s_waitcnt vmcnt(0)` the compiler puts in front of the first use also waits, on gfx9, for
+// every store the wave still has in flight.
+__device__ __forceinline__ uint32_t tbx_digit_glyph(uint32_t digit)
+{
+    constexpr uint16_t G[16] = TBX_DIGIT_FONT;      // ten glyphs, the rest zero
+    constexpr uint64_t K0 = G[0] | ((uint64_t)G[1] << 16) | ((uint64_t)G[2] << 32) | ((uint64_t)G[3] << 48);
+    constexpr uint64_t K1 = G[4] | ((uint64_t)G[5] << 16) | ((uint64_t)G[6] << 32) | ((uint64_t)G[7] << 48);
+    constexpr uint64_t K2 = G[8] | ((uint64_t)G[9] << 16);
+    const uint32_t k = digit >> 2;
+    const uint64_t w = k == 0 ? K0 : k == 1 ? K1 : k == 2 ? K2 : 0ull;
+    return (uint32_t)(w >> (16u * (digit & 3u))) & 0xFFFFu;
+}
+
+// The waves a rasteriser launch STARTS with (one per wave slot of the chip) sleep for a pseudo-random 0 .. 20 us before they paint.
+//
+// Why: a launch whose first waves all start together keeps them in lockstep -- every wave composes its unit and flushes it at the
+// same moments -- and the frame stores then reach HBM in bursts whose cost depends on where the frames lie: the same
+// Breakout loop of [step ; render] ran at 1.20 ms per step into some hipMalloc'ed buffers and at 1.34-1.38 ms into others (a
+// process-to-process and box-to-box lottery: the "two rate states" of round 2; scripts/ubench/rate_addr.hip shows it buffer by
+// buffer).  Back-to-back render launches do not show it -- their first waves start against the tail of the previous launch and
+// are spread by that -- and neither does the pipelined mode, for the same reason.  With the stagger the loop runs at
+// 1.21 ms into every buffer (at 8 192 envs 0.165-0.169 instead of 0.162-0.182, at 16 384 0.314-0.318 instead of 0.311-0.349);
+// back to back it costs about half the longest sleep once per launch (1.194 against 1.184 ms).  Launches of fewer than 16 384
+// blocks (a dozen generations of waves) gain nothing and are left alone.
+constexpr unsigned TBX_STAGGER_BLOCKS = 1280;      // 256 CUs x 4 SIMDs x 5 wave slots / 4 waves per block
+__device__ __forceinline__ void tbx_stagger_first_waves(int wid)
+{
+    if (blockIdx.x >= TBX_STAGGER_BLOCKS || gridDim.x < 16384u) return;
+    const unsigned units = min(12u, gridDim.x / 5120u);
+    const int k = (int)((((uint32_t)wid * 2654435761u) >> 26) * units);       // 0 .. 63 * units sleeps of 64 cycles
+    for (int i = 0; i < k; i++) __builtin_amdgcn_s_sleep(1);
+}
 
 template <int C>
 struct PixBytes;   // bytes of a 4-pixel group

@@ -398,7 +398,7 @@ inline hipError_t tbx_wait_tail(tbx_engine* e, hipStream_t s)
 {
     if (!e->has_last || e->last_stream == s) return hipSuccess;
     if (!e->order_ev) {
-        hipError_t r = hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming);
+        hipError_t r = hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming | hipEventReleaseToDevice);
         if (r != hipSuccess) return r;
     }
     hipError_t r = hipEventRecord(e->order_ev, e->last_stream);
@@ -460,7 +460,11 @@ struct GameOps {
     // every env on stream s, records into the OTHER buffer, which becomes the current one.  The step outputs go wherever
     // tbx_engine::reward / done / ... point at the time of the launch (rebind_outputs() after the engine moved them).
     virtual bool pipeline_ok() const { return false; }
-    virtual bool pipeline_pays() const { return pipeline_ok(); }     // TBX_OPT_PIPELINE = 1 (the engine's choice) may pick it
+    // TBX_OPT_PIPELINE = 1 (the engine's choice) picks the pipelined mode only for engines that say it pays.  None does since
+    // the rasterisers stagger their first waves (raster.hpp, tbx_stagger_first_waves): what the mode bought Breakout and
+    // SpaceInvaders was a rasteriser launch that did not start against an idle memory system, and stream order now has that too
+    // (scripts/pipeline_sweep.py, 8 192 .. 65 536 envs: stream order 0.5-3 % ahead); Amidar's painter never gained from it
+    virtual bool pipeline_pays() const { return false; }
     virtual int records_parity() const { return 0; }
     virtual int step_ahead(tbx_engine*, const ActionSource&, uint32_t, hipStream_t) { return TBX_E_UNSUPPORTED; }
     virtual void rebind_outputs(tbx_engine*) {}
