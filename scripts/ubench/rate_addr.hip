@@ -18,7 +18,9 @@ int main(int argc, char** argv) {
     const size_t frame_bytes = (size_t)n * w * h * 3;
     hipStream_t s; CK(hipStreamCreate(&s));
     uint64_t t = 0;
-    for (int i = 0; i < 600; i++) tbx_step_synthetic(e, 1337, t++, 0, TBX_STEP_AUTO_RESET, s);
+    const int preroll = argc > 5 ? atoi(argv[5]) : 600;
+    if (argc > 6) tbx_set_option(e, TBX_OPT_PIPELINE, atoi(argv[6]));
+    for (int i = 0; i < preroll; i++) tbx_step_synthetic(e, 1337, t++, 0, TBX_STEP_AUTO_RESET, s);
     struct Target { const char* name; uint8_t* p; };
     std::vector<Target> targets;
     targets.push_back({"engine-owned buffer", nullptr});
