@@ -1316,9 +1316,13 @@ __device__ __forceinline__ int world_to_px(int v)
 __device__ __forceinline__ uint32_t ami_inner_of(const AmiRegs& s, int lane)
 {
     uint32_t inner = 0;
-    for (int b = 0; b < s.f[A_N_BOXES]; b++) {
-        const uint32_t g = bcast(s.bgeom, b), fl = bcast(s.bflags, b);
-        if (!(fl & 1u)) continue;
+    // only the PAINTED boxes (lane b holds box b): a ballot and a loop over its set bits, ascending like the loop over all boxes
+    // it replaces -- a random agent's game has none or a few of the board's boxes painted, and nine waves per frame run this
+    uint64_t painted = __ballot(lane < s.f[A_N_BOXES] && (s.bflags & 1u));
+    while (painted) {
+        const int b = (int)__builtin_ctzll(painted);
+        painted &= painted - 1;
+        const uint32_t g = bcast(s.bgeom, b);
         const int tl_tx = g & 255, tl_ty = (g >> 8) & 255, br_tx = (g >> 16) & 255, br_ty = (g >> 24) & 255;
         if (lane > tl_ty && lane < br_ty && br_tx - tl_tx >= 2) {
             const int lo = tl_tx + 1, hi = br_tx - 1;   // inclusive
@@ -1616,9 +1620,15 @@ __device__ __forceinline__ void ami_paint_units(const AmiPainter<C>& p, uint8_t*
 
 // One wave rasterises one env; AMI_UNIT_ROWS scanlines are staged in LDS and flushed as 16-byte stores, background-only
 // units are stored directly.
+// RGB launches run fastest with SIX waves per SIMD (the kernel's registers and LDS allow eight): builds held to 4 / 5 / 6 / 7 / 8
+// measured 1.68 / 1.47 / 1.33 / 1.52-1.62 / 1.53-1.59 ms per launch at 65 536 envs (scripts/ubench/rate_addr).  How many waves
+// the frame stores want in flight depends on how much of its life a wave spends storing: with the painter's set-up as it was
+// before ami_inner_of looped over the painted boxes only, eight was best (1.37 ms), and every cut in set-up work made the
+// eight-wave launch SLOWER -- more of the waves in flight are then storing at any time, and the frames' write locality in HBM
+// goes (the same effect that puts Breakout's RGB launches at five, breakout.hip).  Gray and RGBA launches: as the registers allow.
 template <int C, bool ALT>
-__global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t* out, int first_env, int count, int split, AmiDev d_alt,
-                                                               const uint8_t* __restrict__ pick_alt)
+__device__ __forceinline__ void ami_render_body(const AmiDev& d, uint8_t* out, int first_env, int count, int split, const AmiDev& d_alt,
+                                                const uint8_t* __restrict__ pick_alt)
 {
     constexpr int W = TBX_AMI_W, H = TBX_AMI_H;
     using Stager = RowStager<C, W, AMI_UNIT_ROWS>;
@@ -1639,8 +1649,19 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
 
     ami_paint_units<C>(p, out + (size_t)rel * H * W * C, env, lane, st, part, split);
 }
+template <int C, bool ALT>
+__global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void ami_render_kernel_w6(AmiDev d, uint8_t* out, int first_env, int count,
+                                                                                                         int split, AmiDev d_alt, const uint8_t* __restrict__ pick_alt)
+{
+    ami_render_body<C, ALT>(d, out, first_env, count, split, d_alt, pick_alt);
+}
+template <int C, bool ALT>
+__global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t* out, int first_env, int count, int split, AmiDev d_alt,
+                                                               const uint8_t* __restrict__ pick_alt)
+{
+    ami_render_body<C, ALT>(d, out, first_env, count, split, d_alt, pick_alt);
+}
 
-// the same launch geometry over render records (pipelined mode)
 template <int C>
 __global__ __launch_bounds__(TBX_BLOCK) void ami_rec_render_kernel(const AmiRenderRec* __restrict__ recs, const AmiTables* __restrict__ tab, uint8_t* out,
                                                                    int first_env, int count, int split)
@@ -2074,7 +2095,7 @@ struct AmiOps : GameOps {
         const int split = split_env > 0 ? split_env : channels == 3 ? 9 : 1;
         switch (channels) {
         case 1: if (pick_alt) hipLaunchKernelGGL((ami_render_kernel<1, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((ami_render_kernel<1, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
-        case 3: if (pick_alt) hipLaunchKernelGGL((ami_render_kernel<3, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((ami_render_kernel<3, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
+        case 3: if (pick_alt) hipLaunchKernelGGL((ami_render_kernel_w6<3, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((ami_render_kernel_w6<3, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
         case 4: if (pick_alt) hipLaunchKernelGGL((ami_render_kernel<4, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((ami_render_kernel<4, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
         default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
         }
