@@ -2073,7 +2073,7 @@ struct AmiOps : GameOps {
     {
         if (e->pipe.active && recs_valid) {       // pipelined loop: from the records the last step left (a step may be writing state now)
             const int split_opt = e->opt[TBX_OPT_RENDER_SPLIT];
-            const int split = split_opt > 0 ? split_opt : channels == 3 ? 9 : 1;
+            const int split = split_opt > 0 ? split_opt : channels == 3 ? 9 : (channels == 1 && n_envs <= 4096) ? 4 : 1;
             switch (channels) {
             case 1: hipLaunchKernelGGL(ami_rec_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, tab_dev, out_dev, first_env, n_envs, split); break;
             case 3: hipLaunchKernelGGL(ami_rec_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, tab_dev, out_dev, first_env, n_envs, split); break;
@@ -2092,7 +2092,9 @@ struct AmiOps : GameOps {
         const int split_env = e->opt[TBX_OPT_RENDER_SPLIT];
         // RGB: nine waves per frame (2-3 of the 25 units each) measured 5.45-5.55 TB/s against 4.9 for one wave per frame;
         // gray and RGBA show no such effect (scripts/ab_render.py over TBX_OPT_RENDER_SPLIT)
-        const int split = split_env > 0 ? split_env : channels == 3 ? 9 : 1;
+        // (gray: one wave per frame under-fills the chip at small batches -- four per frame up to 4 096 envs: 0.026 against 0.047 ms
+        // at 1 024, 0.064 against 0.066 at 4 096; at 16 384 it is the slower form, 0.196 against 0.187, and so it is for RGBA at 4 096)
+        const int split = split_env > 0 ? split_env : channels == 3 ? 9 : (channels == 1 && n_envs <= 4096) ? 4 : 1;
         switch (channels) {
         case 1: if (pick_alt) hipLaunchKernelGGL((ami_render_kernel<1, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((ami_render_kernel<1, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
         case 3: if (pick_alt) hipLaunchKernelGGL((ami_render_kernel_w6<3, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((ami_render_kernel_w6<3, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
