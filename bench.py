@@ -17,16 +17,15 @@ pre-roll of step-only frames so that the timed region sees mid-game states with 
 W warm-up steps, then R regions of exactly K steps, each bracketed by device-sync + rank barrier on both sides; a region's
 time is the MAX over ranks; the reported value is the MEDIAN region (min / max alongside).
 
-The loop is the north star's random-action rollout: actions come from the device, so step N+1 does not need frame N.  The
-engine's pipelined mode (TBX_OPT_PIPELINE = 1: the step runs beside the previous frame's rasteriser; below 16 384 envs
-consecutive rasteriser launches also overlap) is what `value` is measured with; the same loop with the option off -- what a
-policy-driven loop, whose actions need the frame, gets -- is measured on the same engine and reported beside it as
-`serialised`.
+The loop is the north star's random-action rollout: actions come from the device, so step N+1 does not need frame N.
+`value` is measured with TBX_OPT_PIPELINE = 1, the engine's choice -- which is stream order (0) for every game since the
+rasterisers stagger their first waves (csrc/raster.hpp); `--pipeline 2 / 3` selects the pipelined modes explicitly, and then
+the same loop with the option off is measured on the same engine and reported beside it as `serialised`.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline       -- the dominant kernel (the rasteriser) priced against HBM bandwidth with HIP events recorded on the caller's
-                    stream around every render launch of the timed regions,
-  serialised     -- the same loop with TBX_OPT_PIPELINE = 0 (value, ms_per_step, rasteriser fraction),
+                    stream around every 8th render launch of the timed regions,
+  serialised     -- (only when a pipelined mode is in force) the same loop with TBX_OPT_PIPELINE = 0,
   step_only      -- the same loop without the rasteriser (not bandwidth-bound: no roofline),
   scaling_strong -- the other reading of the metric: the 65 536-env batch in total, i.e. what ONE GPU does with 1/8 of it
                     plus the per-step gather, and 8 x that over `value` (N=1 only; with --gpus 8 --scaling strong it is measured),

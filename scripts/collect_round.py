@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", name)
+    m = re.search(r"(\w+_kernel(?:_w\d)?(?:<[^>]*>)?)", name)
     return m.group(1) if m else name.split("(")[0]
 
 

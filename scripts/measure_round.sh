@@ -33,6 +33,21 @@ python scripts/render_probe.py space_invaders 3 4096 400 3 5 7 9 12 18 >> "$OUT/
 # the rasterisers against the previous round's build, interleaved
 for g in breakout space_invaders amidar; do AB_PREROLL=400 timeout 300 python scripts/ab_render.py $g 3 scripts/ab/lib_prev.so toybox_amd/csrc/libtoybox_amd.so > "$OUT/ab_render_$g.txt" 2>&1; done
 AB_ENVS=4096 AB_PREROLL=400 timeout 300 python scripts/ab_render.py space_invaders 3 scripts/ab/lib_prev.so toybox_amd/csrc/libtoybox_amd.so > "$OUT/ab_render_space_invaders_4096.txt" 2>&1
+# the rasteriser's rate by output buffer, [step ; render] and render only, this build and the build before the first-wave stagger
+# (scripts/ab/r03b/libtoybox_amd.so, commit 4c779ae), and the step;render / render-only / what-sits-between-two-launches table
+make -C scripts/ubench rate_addr rate_state > /dev/null 2>&1
+( cd scripts/ubench
+  for g in 0 2 1 3; do for st in 1 0; do
+    echo -n "game $g step=$st this build:      "; timeout 200 ./rate_addr 65536 $g $st 0 | grep -E "round 1" | awk '{printf "%s ", $(NF-3)}'; echo
+    echo -n "game $g step=$st before stagger:  "; LD_LIBRARY_PATH=$PWD/../ab/r03b timeout 200 ./rate_addr 65536 $g $st 0 | grep -E "round 1" | awk '{printf "%s ", $(NF-3)}'; echo
+  done; done
+  for n in 8192 16384; do for st in 1 0; do
+    echo -n "breakout $n step=$st this build:      "; timeout 200 ./rate_addr $n 0 $st 0 | grep -E "round 1" | awk '{printf "%s ", $(NF-3)}'; echo
+    echo -n "breakout $n step=$st before stagger:  "; LD_LIBRARY_PATH=$PWD/../ab/r03b timeout 200 ./rate_addr $n 0 $st 0 | grep -E "round 1" | awk '{printf "%s ", $(NF-3)}'; echo
+  done; done ) > "$OUT/rate_addr.txt" 2>&1
+( cd scripts/ubench; timeout 200 ./rate_state 65536 | grep "round 2"; echo "-- before stagger"; LD_LIBRARY_PATH=$PWD/../ab/r03b timeout 200 ./rate_state 65536 | grep "round 2" ) > "$OUT/rate_state.txt" 2>&1
+BENCH_ARGS="--game amidar --no-extras --repeats 1" bash scripts/pmc_gpu.sh ${TAG}_ami_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" > "$OUT/pmc_ami_sq.txt" 2>&1
+BENCH_ARGS="--no-extras --repeats 1" bash scripts/pmc_gpu.sh ${TAG}_brk_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" > "$OUT/pmc_brk_sq.txt" 2>&1
 # profiles: kernel trace + PMC (separate passes)
 bash scripts/profile_gpu.sh ${TAG} --no-extras > /dev/null 2>&1
 bash scripts/profile_gpu.sh ${TAG}_space_invaders --game space_invaders --no-extras > /dev/null 2>&1

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", name)
+    m = re.search(r"(\w+_kernel(?:_w\d)?(?:<[^>]*>)?)", name)
     return m.group(1) if m else name.split("(")[0]
 
 
@@ -68,7 +68,7 @@ def main():
             lines.append("| `%s` | %s | %s | %s | %s | %s | %s | %s | %.1f |" % (
                 k, g, w, v, s, "%.0f" % fs if fs is not None else "-", "%.0f" % ws if ws is not None else "-",
                 "%.4g" % hbm if hbm else "-", mean("_dur_us")))
-            if kernel_sub in k and hbm:
+            if kernel_sub in re.sub(r"_w\d<", "<", k) and hbm:       # (brk_render_kernel_w5<3,..> is a render_kernel<3)
                 traffic = {"hbm_bytes_per_launch": hbm, "fetch_kib_raw": fs, "write_kib_raw": ws,
                            "correction": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE exact",
                            "source": "profiles/%s_summary.md" % tag}

@@ -30,17 +30,19 @@ __device__ __forceinline__ uint32_t tbx_digit_glyph(uint32_t digit)
     return (uint32_t)(w >> (16u * (digit & 3u))) & 0xFFFFu;
 }
 
-// The waves a rasteriser launch STARTS with (one per wave slot of the chip) sleep for a pseudo-random 0 .. 20 us before they paint.
+// The waves a rasteriser launch STARTS with (one per wave slot at five waves per SIMD) sleep for a pseudo-random 0 .. 20 us before
+// they paint.
 //
-// Why: a launch whose first waves all start together keeps them in lockstep -- every wave composes its unit and flushes it at the
-// same moments -- and the frame stores then reach HBM in bursts whose cost depends on where the frames lie: the same
-// Breakout loop of [step ; render] ran at 1.20 ms per step into some hipMalloc'ed buffers and at 1.34-1.38 ms into others (a
-// process-to-process and box-to-box lottery: the "two rate states" of round 2; scripts/ubench/rate_addr.hip shows it buffer by
-// buffer).  Back-to-back render launches do not show it -- their first waves start against the tail of the previous launch and
-// are spread by that -- and neither does the pipelined mode, for the same reason.  With the stagger the loop runs at
-// 1.21 ms into every buffer (at 8 192 envs 0.165-0.169 instead of 0.162-0.182, at 16 384 0.314-0.318 instead of 0.311-0.349);
-// back to back it costs about half the longest sleep once per launch (1.194 against 1.184 ms).  Launches of fewer than 16 384
-// blocks (a dozen generations of waves) gain nothing and are left alone.
+// Why: a launch whose first waves all start together into an idle memory system keeps them in lockstep -- every wave composes
+// its unit and flushes it at the same moments -- and the frame stores then reach HBM in bursts whose cost depends on where the
+// frames lie: the same Breakout loop of [step ; render] ran at 1.20 ms per step into some hipMalloc'ed buffers and at
+// 1.34-1.38 ms into others (a process-to-process and box-to-box lottery: the "two rate states" of rounds 2-3;
+// scripts/ubench/rate_addr.hip shows it buffer by buffer, profiles/r03_rate_addr.txt).  Back-to-back render launches do not show
+// it -- their first waves start against the tail of the previous launch and are spread by that -- and neither did the
+// pipelined mode, for the same reason.  With the stagger the loop runs at 1.22 ms into every buffer (at 8 192 envs 0.165-0.168
+// instead of 0.176-0.187, at 16 384 0.318-0.322 instead of 0.325-0.357); back to back it costs about half the longest sleep
+// once per launch (1.20 against 1.18 ms).  Launches of fewer than 16 384 blocks (a dozen generations of waves) gain nothing and
+// are left alone.  Breakout's and SpaceInvaders' rasterisers call it; Amidar's shows no such lottery and loses 6 % with it.
 constexpr unsigned TBX_STAGGER_BLOCKS = 1280;      // 256 CUs x 4 SIMDs x 5 wave slots / 4 waves per block
 __device__ __forceinline__ void tbx_stagger_first_waves(int wid)
 {
