@@ -461,7 +461,8 @@ int tbx_query(tbx_engine* engine, int env, int query_id, const int32_t* args, in
  *   ClipRewardEnv          atari_wrappers.py:221-227  sign(reward)
  *   DummyVecEnv            vec_env/dummy_vec_env.py:45-60  an env that reports done is reset and its observation is reset()'s
  *   VecFrameStack(stack)   vec_env/vec_frame_stack.py:17-30  roll the channel axis, zero the stack of envs that are done,
- *                          write the new frame last
+ *                          write the new frame last -- or, with stack_fill = 1, FrameStack(k) inside every env
+ *                          (atari_wrappers.py:246-275): the same roll, but a reset fills the whole stack with its observation
  * obs = uint8[N][out_h][out_w][stack], reward float32[N], done uint8[N].
  * Not the Python's: NoopResetEnv draws its count from numpy's RandomState; here it is counter-based (below) unless counts
  * are injected with tbx_agent_set_noops.  bench.Monitor raises when an env is stepped after its game ended inside
@@ -476,6 +477,10 @@ typedef struct tbx_agent_config {
     int32_t noop_max;      /* NoopResetEnv: 1..noop_max no-op frames after a real reset; 0 = off */
     uint64_t noop_seed;    /* count = 1 + splitmix64(noop_seed ^ (global env << 32) ^ episode index) % noop_max */
     uint64_t env_offset;   /* global index of env 0 of this engine (sharded batches) */
+    int32_t stack_fill;    /* what a reset leaves in the OLDER stack slots: 0 = zeros (VecFrameStack, vec_frame_stack.py:22-33),
+                            * 1 = the reset observation itself (the per-env FrameStack of wrap_deepmind(frame_stack=True),
+                            * atari_wrappers.py:246-275: reset() appends the observation k times) */
+    int32_t _reserved;
 } tbx_agent_config_t;
 
 int tbx_agent_init(tbx_engine* engine, const tbx_agent_config_t* cfg);

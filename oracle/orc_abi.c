@@ -751,8 +751,8 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     orc_frame_dims(e->game, &H, &W);
     if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
         cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > 84 * 84 || cfg->noop_max < 0 ||
-        cfg->noop_max > 1000)
-        return fail(e, TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000)");
+        cfg->noop_max > 1000 || cfg->stack_fill < 0 || cfg->stack_fill > 1)
+        return fail(e, TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000, stack_fill 0..1)");
     if ((H + cfg->out_h - 1) / cfg->out_h + 1 > 8 || (W + cfg->out_w - 1) / cfg->out_w + 1 > 8)
         return fail(e, TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
     agent_free(e);
@@ -962,7 +962,7 @@ static void commit_obs(wrap_t* w, int zero_stack)
     const int oh = e->acfg.out_h, ow = e->acfg.out_w, st = e->acfg.stack;
     uint8_t* small = (uint8_t*)malloc((size_t)oh * ow);
     orc_warp_area(w->obs, w->H, w->W, small, oh, ow);
-    orc_stack_push(e->aobs + (size_t)w->i * oh * ow * st, small, oh, ow, st, zero_stack);
+    orc_stack_push(e->aobs + (size_t)w->i * oh * ow * st, small, oh, ow, st, zero_stack ? (e->acfg.stack_fill ? 2 : 1) : 0);
     free(small);
 }
 

@@ -31,12 +31,13 @@ void orc_warp_area(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int o
         }
 }
 
-/* roll the stack of one env and write the new frame last; fresh: zero the older slots first */
+/* roll the stack of one env and write the new frame last; fresh = 1: zero the older slots first (VecFrameStack,
+ * vec_frame_stack.py:22-33), fresh = 2: the older slots get the new frame too (FrameStack.reset, atari_wrappers.py:257-261) */
 void orc_stack_push(uint8_t* obs, const uint8_t* frame, int oh, int ow, int stack, int fresh)
 {
     for (int p = 0; p < oh * ow; p++) {
         uint8_t* px = obs + (size_t)p * stack;
-        for (int c = 0; c + 1 < stack; c++) px[c] = fresh ? 0 : px[c + 1];
+        for (int c = 0; c + 1 < stack; c++) px[c] = fresh == 2 ? frame[p] : fresh ? 0 : px[c + 1];
         px[stack - 1] = frame[p];
     }
 }

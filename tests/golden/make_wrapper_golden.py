@@ -76,10 +76,11 @@ class CounterNoops:
 
 
 def build_stack(R, game, n, seed, skip=4, oh=84, ow=84, stack=4, clip=True, episodic=False, fire=False, noop_max=0, noop_seed=0,
-                env_offset=0, monitor=True, factory=False):
+                env_offset=0, monitor=True, factory=False, per_env_stack=False, scale=False):
     """make_atari + Monitor + wrap_deepmind + DummyVecEnv + VecFrameStack out of the reference's classes.  factory=True goes
     through the reference's own make_atari / wrap_deepmind functions (their fixed options), else the same classes in the same
-    order with this case's options."""
+    order with this case's options.  per_env_stack / scale: wrap_deepmind's frame_stack=True / scale=True -- a FrameStack(stack)
+    (and a ScaledFloatFrame) inside every env, and no VecFrameStack over the vector env."""
     tops, parts = [], []
     for i in range(n):
         if factory:
@@ -100,8 +101,8 @@ def build_stack(R, game, n, seed, skip=4, oh=84, ow=84, stack=4, clip=True, epis
         if monitor:
             env = mon = R.Monitor(env, None, allow_early_resets=True)
         if factory:
-            env = R.aw.wrap_deepmind(env, episode_life=episodic, clip_rewards=clip)
-            assert fire
+            env = R.aw.wrap_deepmind(env, episode_life=episodic, clip_rewards=clip, frame_stack=per_env_stack, scale=scale)
+            assert fire and (stack == 4 or not per_env_stack)
         else:
             if episodic:
                 env = R.aw.EpisodicLifeEnv(env)
@@ -111,11 +112,17 @@ def build_stack(R, game, n, seed, skip=4, oh=84, ow=84, stack=4, clip=True, epis
             if (oh, ow) != (84, 84):
                 warp.height, warp.width = oh, ow
                 warp.observation_space = R.gym.spaces.Box(low=0, high=255, shape=(oh, ow, 1), dtype=np.uint8)
+            if scale:
+                env = R.aw.ScaledFloatFrame(env)
             if clip:
                 env = R.aw.ClipRewardEnv(env)
+            if per_env_stack:
+                env = R.aw.FrameStack(env, stack)
         tops.append(env)
         parts.append(types.SimpleNamespace(raw=raw, noop=noop, monitor=mon))
-    venv = R.VecFrameStack(R.DummyVecEnv([(lambda e=e: e) for e in tops]), stack)
+    venv = R.DummyVecEnv([(lambda e=e: e) for e in tops])
+    if not per_env_stack:
+        venv = R.VecFrameStack(venv, stack)
     return venv, parts
 
 
@@ -158,7 +165,8 @@ class Recorder:
         def st(x, dt, shape):
             return np.stack(x) if x else np.zeros((0,) + shape, dt)
         n = self.n
-        d = {"action_idx": st(self.idx, np.int32, (n,)), "obs": st(self.obs, np.uint8, self.venv.stackedobs.shape),
+        shape = self.venv.stackedobs.shape if hasattr(self.venv, "stackedobs") else (n,) + tuple(self.venv.observation_space.shape)
+        d = {"action_idx": st(self.idx, np.int32, (n,)), "obs": st(self.obs, self.venv.observation_space.dtype, shape),
              "rew": st(self.rew, np.float32, (n,)), "done": st(self.done, bool, (n,)), "ep_flag": st(self.ep_flag, bool, (n,)),
              "ep_r": st(self.ep_r, np.float32, (n,)), "ep_l": st(self.ep_l, np.int32, (n,))}
         d.update(self.finals())
@@ -308,6 +316,14 @@ def all_cases(R):
     for game in ("breakout", "space_invaders", "amidar"):
         cases.append(rollout_case(R, "default_path_%s" % game, game, 2, 120, 1234, 1337, skip=4, oh=84, ow=84, stack=4, clip=True,
                                   episodic=True, fire=True, noop_max=30, noop_seed=7, env_offset=64, factory=True))
+    # wrap_deepmind(frame_stack=True[, scale=True]): FrameStack (and ScaledFloatFrame) inside every env, no VecFrameStack
+    cases.append(rollout_case(R, "env_stack_breakout", "breakout", 3, 200, 77, 21, skip=4, oh=42, ow=42, stack=4, clip=True, episodic=True,
+                              fire=True, noop_max=5, noop_seed=99, env_offset=10, per_env_stack=True))
+    cases.append(rollout_case(R, "env_stack_space_invaders", "space_invaders", 2, 160, 78, 22, skip=4, oh=42, ow=64, stack=3, clip=True,
+                              episodic=True, fire=True, per_env_stack=True))
+    cases.append(rollout_case(R, "default_path_frame_stack_scale_breakout", "breakout", 2, 60, 1234, 1337, skip=4, oh=84, ow=84, stack=4,
+                              clip=True, episodic=True, fire=True, noop_max=30, noop_seed=7, env_offset=64, factory=True,
+                              per_env_stack=True, scale=True))
     cases.append(second_reset_case(R, True))
     cases.append(second_reset_case(R, False))
     cases.append(injected_noops_case(R))

@@ -105,8 +105,13 @@ class Case:
         e.seed(m["seed"])
         e.agent_init(skip=m["skip"], out_h=m["oh"], out_w=m["ow"], stack=m["stack"], clip_reward=m["clip"],
                      episodic_life=m.get("episodic", False), fire_reset=m.get("fire", False), noop_max=m.get("noop_max", 0),
-                     noop_seed=m.get("noop_seed", 0), env_offset=m.get("env_offset", 0))
+                     noop_seed=m.get("noop_seed", 0), env_offset=m.get("env_offset", 0),
+                     stack_fill=1 if m.get("per_env_stack") else 0)
         return e
+
+    def seen(self, obs):
+        """what the fixture's learner saw of a uint8 observation: ScaledFloatFrame's float32 / 255 where the case has it"""
+        return obs.astype(np.float32) / 255.0 if self.meta.get("scale") else obs
 
     def ale(self, idx):
         """the fixtures hold action INDICES (what a learner emits, envs/atari/base.py:123-126); the engine takes ALE ids"""
@@ -120,7 +125,7 @@ class Case:
         for t in range(first, last):
             obs, rew, done = e.agent_step(self.ale(idx[t]), tolerate_needs_reset=bool(prefix))
             assert np.array_equal(rew, self.a[prefix + "rew"][t]) and np.array_equal(done, self.a[prefix + "done"][t]), (self.name, t)
-            assert np.array_equal(obs, self.a[prefix + "obs"][t]), (self.name, t)
+            assert np.array_equal(self.seen(obs), self.a[prefix + "obs"][t]), (self.name, t)
             if episodes and not prefix:
                 ended, ret, length = e.agent_episodes()
                 assert np.array_equal(ended, self.a["ep_flag"][t]), (self.name, t)       # info["episode"] of bench.Monitor
@@ -192,6 +197,49 @@ def test_fused_equals_reference_factory_functions(game, lib):
     eps = c.replay(e)
     c.check_states(e)
     c.check_monitor(eps)
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("name", ["env_stack_breakout", "env_stack_space_invaders", "default_path_frame_stack_scale_breakout"])
+def test_fused_equals_frame_stack_inside_every_env(name, generic, lib):
+    """wrap_deepmind(frame_stack=True[, scale=True]) (atari_wrappers.py:346-360): a FrameStack(k) -- and a ScaledFloatFrame --
+    inside every env and no VecFrameStack over the vector env.  A reset fills the whole stack with its observation
+    (FrameStack.reset, :257-261) where VecFrameStack leaves zeros; the third case goes through the reference's own
+    make_atari / wrap_deepmind functions and holds float32 observations."""
+    c = Case(name)
+    assert c.meta["per_env_stack"]
+    e = c.engine(lib)
+    if generic:                                              # two gray renders + the generic warp kernel (HIP library)
+        e.set_option(_abi.OPT_AGENT_GENERIC, 1)
+    first = e.agent_reset()
+    assert np.array_equal(c.seen(first), c["reset_obs"])
+    k = c.meta["stack"]
+    assert all(np.array_equal(first[..., j], first[..., k - 1]) for j in range(k)) and first.max() > 0
+    eps = c.replay(e)
+    c.check_states(e)
+    c.check_monitor(eps)
+    assert c["done"].sum() > 0                               # resets happened inside the run as well
+
+
+def test_preproc_vec_env_frame_stack_and_scale_options(oracle_lib):
+    """the adapter's frame_stack="env" / scale=True against the same fixture, through ToyboxPreprocVecEnv itself"""
+    from toybox_amd.envs import ToyboxPreprocVecEnv
+    c = Case("default_path_frame_stack_scale_breakout")
+    m = c.meta
+    eng = Engine("breakout", c.n, lib=oracle_lib)
+    eng.seed(m["seed"])
+    env = ToyboxPreprocVecEnv("breakout", c.n, skip=m["skip"], size=m["oh"], stack=m["stack"], clip_rewards=m["clip"], engine=eng,
+                              episode_life=m["episodic"], fire_reset=m["fire"], noop_max=m["noop_max"], noop_seed=m["noop_seed"],
+                              env_offset=m["env_offset"], frame_stack="env", scale=True)
+    assert env.observation_space.dtype == np.float32
+    obs = env.reset()
+    assert obs.dtype == np.float32 and np.array_equal(obs, c["reset_obs"])
+    for t in range(len(c["action_idx"])):
+        obs, rew, done, _ = env.step(c["action_idx"][t])
+        assert np.array_equal(obs, c["obs"][t]) and np.array_equal(rew, c["rew"][t]) and np.array_equal(done, c["done"][t]), t
+    with pytest.raises(ValueError):
+        ToyboxPreprocVecEnv("breakout", 1, engine=eng, frame_stack="lazy")
+    env.close()
 
 
 @pytest.mark.gpu

@@ -228,7 +228,7 @@ CONFIG_TYPES = {GAME_BREAKOUT: BreakoutConfig, GAME_SPACE_INVADERS: SIConfig, GA
 class AgentConfig(C.Structure):
     _fields_ = [("skip", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32), ("stack", C.c_int32), ("clip_reward", C.c_int32),
                 ("episodic_life", C.c_int32), ("fire_reset", C.c_int32), ("noop_max", C.c_int32),
-                ("noop_seed", C.c_uint64), ("env_offset", C.c_uint64)]
+                ("noop_seed", C.c_uint64), ("env_offset", C.c_uint64), ("stack_fill", C.c_int32), ("_reserved", C.c_int32)]
 
 
 _p = C.POINTER

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
     // B holds slot B, or the live frame where the env's observation is a raw frame; A holds slot A
     const ObsSel sel = agent_obs_sel(wa, env);
     const bool use_a = !sel.none && (sel.two || sel.single == 1), use_b = !sel.none && (sel.two || sel.single != 1);
-    const bool fresh = sel.zero;                        // VecFrameStack: older slots become zero
+    const int fresh = sel.zero;                         // VecFrameStack: older slots become zero (FrameStack: the new frame)
     const uint8_t* fa = A + (size_t)env * H * W;
     const uint8_t* fb = B + (size_t)env * H * W;
     uint8_t* o = obs + (size_t)env * oh * ow * S;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
                         // (sum + area/2) / area by multiply-shift
                         const uint32_t val = (uint32_t)(((uint64_t)(acc0[q] + half) * magic) >> 42);
                         uint8_t* px = o + ((size_t)oy * ow + ox) * S;
-                        if (S == 4) *reinterpret_cast<uint32_t*>(px) = ((fresh ? 0u : old[q]) >> 8) | (val << 24);
+                        if (S == 4) *reinterpret_cast<uint32_t*>(px) = (stack_old_word(fresh ? 0u : old[q], val, fresh) >> 8) | (val << 24);
                         else stack_push<S>(px, val, fresh);
                     }
                     acc0[q] = acc1[q];
@@ -223,6 +223,7 @@ AgentWarpArgs warp_args(tbx_engine* e, int reset_mode)
     w.zero = a.done_out; w.mode = a.mode; w.valid = a.buf_valid; w.tx = a.tx; w.obs = a.obs;
     w.H = a.H; w.W = a.W; w.oh = a.cfg.out_h; w.ow = a.cfg.out_w; w.stack = a.cfg.stack;
     w.reset_mode = reset_mode;
+    w.fill_repeat = a.cfg.stack_fill != 0;
     w.magic = (1ull << 42) / (uint64_t)(a.H * a.W) + 1ull;   // exact for numerators < 2^42 / area >= 2^25
     return w;
 }
@@ -384,8 +385,8 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     const int H = e->ops->height(), W = e->ops->width();
     if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
         cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > AGENT_MAX_OUT_PX || cfg->noop_max < 0 ||
-        cfg->noop_max > 1000)
-        return e->fail(TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000)");
+        cfg->noop_max > 1000 || cfg->stack_fill < 0 || cfg->stack_fill > 1)
+        return e->fail(TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000, stack_fill 0..1)");
     if ((H + cfg->out_h - 1) / cfg->out_h + 1 > MAX_TAPS || (W + cfg->out_w - 1) / cfg->out_w + 1 > MAX_TAPS)
         return e->fail(TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
     AHIP(hipSetDevice(e->device));

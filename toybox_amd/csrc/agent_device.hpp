@@ -20,12 +20,13 @@ struct AgentWarpArgs {
     uint8_t* obs;              // [N][out_h][out_w][stack]
     int H, W, oh, ow, stack;
     int reset_mode;            // venv.reset(): every stack starts from zeros
+    int fill_repeat;           // tbx_agent_config_t::stack_fill: a fresh stack holds the new frame in every slot, not zeros
     uint64_t magic;            // floor(2^42 / (H*W)) + 1
 };
 
 // which frames make up this env's observation (wave-uniform)
 struct ObsSel {
-    bool zero;    // zero the older stack slots
+    int zero;     // 0: roll the stack; 1: zero the older slots (VecFrameStack); 2: fill them with the new frame (FrameStack.reset)
     bool none;    // both buffer slots still hold np.zeros: the observation is black
     bool two;     // max(slot A, slot B)
     int single;   // !two: the one source -- 0 live state, 1 slot A, 2 slot B
@@ -36,7 +37,7 @@ __device__ __forceinline__ ObsSel agent_obs_sel(const AgentWarpArgs& a, int env)
     ObsSel s;
     const uint32_t mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.mode[env]);
     const uint32_t valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.valid[env]);
-    s.zero = a.reset_mode || __builtin_amdgcn_readfirstlane((int)a.zero[env]) != 0;
+    s.zero = (a.reset_mode || __builtin_amdgcn_readfirstlane((int)a.zero[env]) != 0) ? (a.fill_repeat ? 2 : 1) : 0;
     const bool raw = (mode & 1u) != 0;
     s.none = !raw && (valid & 3u) == 0u;
     s.two = !raw && (valid & 3u) == 3u;
@@ -79,16 +80,21 @@ __device__ __forceinline__ uint32_t hsum(const uint8_t* row, const ColTaps& c)
 }
 
 
-// rolls `val` into the frame stack at px (S bytes per pixel, newest last); fresh: older slots become 0
+// what the stack word of a pixel is taken to have held before the new value is rolled in (S == 4); fresh as ObsSel::zero
+__device__ __forceinline__ uint32_t stack_old_word(uint32_t stored, uint32_t val, int fresh)
+{
+    return fresh == 0 ? stored : fresh == 2 ? val * 0x01010101u : 0u;
+}
+// rolls `val` into the frame stack at px (S bytes per pixel, newest last); fresh: 1 = older slots become 0, 2 = become val
 template <int S>
-__device__ __forceinline__ void stack_push(uint8_t* px, uint32_t val, bool fresh)
+__device__ __forceinline__ void stack_push(uint8_t* px, uint32_t val, int fresh)
 {
     if (S == 4) {
-        const uint32_t old = fresh ? 0u : *reinterpret_cast<uint32_t*>(px);
+        const uint32_t old = stack_old_word(fresh ? 0u : *reinterpret_cast<uint32_t*>(px), val, fresh);
         *reinterpret_cast<uint32_t*>(px) = (old >> 8) | (val << 24);
     } else {
 #pragma unroll
-        for (int c = 0; c + 1 < S; c++) px[c] = fresh ? (uint8_t)0 : px[c + 1];
+        for (int c = 0; c + 1 < S; c++) px[c] = fresh == 2 ? (uint8_t)val : fresh ? (uint8_t)0 : px[c + 1];
         px[S - 1] = (uint8_t)val;
     }
 }
@@ -99,23 +105,25 @@ __device__ __forceinline__ void stack_push(uint8_t* px, uint32_t val, bool fresh
 constexpr int AGENT_MAX_OUT_PX = 84 * 84;
 
 template <int S>
-__device__ __forceinline__ void stack_commit(const uint8_t* vals, uint8_t* o, int n_px, int lane, bool fresh)
+__device__ __forceinline__ void stack_commit(const uint8_t* vals, uint8_t* o, int n_px, int lane, int fresh)
 {
     __builtin_amdgcn_wave_barrier();
     if (S == 4) {
         uint32_t* o4 = reinterpret_cast<uint32_t*>(o);
+        if (fresh) {                                   // (wave-uniform) nothing of the old stack survives: stores only
+            const uint32_t spread = fresh == 2 ? 0x01010101u : 0x01000000u;      // FrameStack.reset: every slot / VecFrameStack: the last
+            for (int i = lane; i < n_px; i += 64) o4[i] = (uint32_t)vals[i] * spread;
+            return;
+        }
         int i = lane;
         for (; i + 7 * 64 < n_px; i += 8 * 64) {
             uint32_t old[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) old[k] = fresh ? 0u : o4[i + 64 * k];
+            for (int k = 0; k < 8; k++) old[k] = o4[i + 64 * k];
 #pragma unroll
             for (int k = 0; k < 8; k++) o4[i + 64 * k] = (old[k] >> 8) | ((uint32_t)vals[i + 64 * k] << 24);
         }
-        for (; i < n_px; i += 64) {
-            const uint32_t old = fresh ? 0u : o4[i];
-            o4[i] = (old >> 8) | ((uint32_t)vals[i] << 24);
-        }
+        for (; i < n_px; i += 64) o4[i] = (o4[i] >> 8) | ((uint32_t)vals[i] << 24);
     } else {
         for (int i = lane; i < n_px; i += 64) stack_push<S>(o + (size_t)i * S, vals[i], fresh);
     }

@@ -1592,8 +1592,10 @@ __global__ __launch_bounds__(64 * TBX_SERVE_WAVES) void si_serve_kernel(SiDev d,
 //
 // max(frame A, frame B) -> gray -> area warp -> frame stack without the two full-resolution gray frames ever reaching
 // HBM: agent_fused_wave (agent_device.hpp) with two SiGrayPainters in one wave per env.
+// (three waves per SIMD: the two painters sit at 168-170 VGPRs, one register either side of the step from three waves to two,
+// and the kernel is issue-bound -- 2.98 ms per agent step with three, 4.07 with two)
 template <int S>
-__global__ __launch_bounds__(TBX_BLOCK) void si_agent_warp_kernel(SiDev dLive, SiDev dA, SiDev dB, AgentWarpArgs a, int n)
+__global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(3))) void si_agent_warp_kernel(SiDev dLive, SiDev dA, SiDev dB, AgentWarpArgs a, int n)
 {
     __shared__ AgentFusedLds<SiGrayPainter> lds[TBX_WAVES_PER_BLOCK];
     __shared__ uint32_t spr_lds[SPR_WORDS];

@@ -215,9 +215,11 @@ class Engine:
 
     # ------------------------------------------------------------------ agent-side preprocessing (fused wrapper stack)
     def agent_init(self, skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=False, fire_reset=False,
-                   noop_max=0, noop_seed=0, env_offset=0):
+                   noop_max=0, noop_seed=0, env_offset=0, stack_fill=0):
+        """stack_fill: what a reset leaves in the older stack slots -- 0 zeros (VecFrameStack), 1 the reset observation (the
+        per-env FrameStack of wrap_deepmind(frame_stack=True))."""
         cfg = _abi.AgentConfig(int(skip), int(out_h), int(out_w), int(stack), int(bool(clip_reward)), int(bool(episodic_life)),
-                               int(bool(fire_reset)), int(noop_max), int(noop_seed), int(env_offset))
+                               int(bool(fire_reset)), int(noop_max), int(noop_seed), int(env_offset), int(stack_fill), 0)
         self._check(self._lib.tbx_agent_init(self._h, C.byref(cfg)))
         self._agent_shape = (self.n_envs, int(out_h), int(out_w), int(stack))
 

@@ -139,27 +139,40 @@ class ToyboxPreprocVecEnv:
     episode_life / fire_reset / noop_max switch on the reset-time wrappers of wrap_deepmind / make_atari
     (EpisodicLifeEnv :58-96, FireResetEnv :38-56, NoopResetEnv :12-36), run inside the reset kernel; the Monitor
     record of a finished game arrives as info["episode"] = {"r", "l"} like bench/monitor.py:68-76.  env_offset is the
-    global index of env 0 (multi-GPU sharding) so no-op counts do not depend on the shard layout."""
+    global index of env 0 (multi-GPU sharding) so no-op counts do not depend on the shard layout.
+
+    frame_stack="vec" (default) stacks like VecFrameStack over the vector env: a reset leaves zeros in the older slots.
+    frame_stack="env" stacks like wrap_deepmind(frame_stack=True), a FrameStack(k) inside every env
+    (atari_wrappers.py:246-275): a reset fills the whole stack with its observation.  scale=True is ScaledFloatFrame
+    (atari_wrappers.py:277-286): observations come back as float32 in [0, 1] (uint8 / 255, converted on the host; the device
+    buffer TBX_BUF_AGENT_OBS stays uint8)."""
 
     def __init__(self, game, num_envs, skip=4, size=84, stack=4, clip_rewards=True, seed=None, engine=None,
-                 episode_life=False, fire_reset=False, noop_max=0, noop_seed=0, env_offset=0):
+                 episode_life=False, fire_reset=False, noop_max=0, noop_seed=0, env_offset=0, frame_stack="vec", scale=False):
         self.game = {"spaceinvaders": "space_invaders"}.get(game, game)
         self.num_envs = int(num_envs)
         self.engine = engine if engine is not None else _make_engine(self.game, self.num_envs)
         self._action_set = sorted(self.engine.legal_actions)
         self._lut = np.asarray(self._action_set, dtype=np.int32)
         self.action_space = Discrete(len(self._action_set))
-        self.observation_space = Box(0, 255, (size, size, stack), "uint8")
+        if frame_stack not in ("vec", "env"):
+            raise ValueError("frame_stack must be 'vec' (VecFrameStack) or 'env' (FrameStack inside every env)")
+        self.scale = bool(scale)
+        self.observation_space = Box(0, 1.0, (size, size, stack), "float32") if self.scale else Box(0, 255, (size, size, stack), "uint8")
         if seed is not None:
             self.engine.seed_array([hash_seed(int(seed) + i + 1) % 2 ** 31 for i in range(self.num_envs)])
         self.engine.agent_init(skip=skip, out_h=size, out_w=size, stack=stack, clip_reward=clip_rewards,
                                episodic_life=episode_life, fire_reset=fire_reset, noop_max=noop_max, noop_seed=noop_seed,
-                               env_offset=env_offset)
+                               env_offset=env_offset, stack_fill=1 if frame_stack == "env" else 0)
         self._pending = None
         self.closed = False
 
+    def _obs(self, obs):
+        # ScaledFloatFrame.observation: np.array(observation).astype(np.float32) / 255.0
+        return obs.astype(np.float32) / 255.0 if self.scale else obs
+
     def reset(self):
-        return self.engine.agent_reset()
+        return self._obs(self.engine.agent_reset())
 
     def step_async(self, actions):
         a = np.asarray(actions)
@@ -175,7 +188,7 @@ class ToyboxPreprocVecEnv:
         obs, reward, done = self.engine.agent_step(actions)
         ended, ret, length = self.engine.agent_episodes()
         extras = {int(i): {"episode": {"r": float(ret[i]), "l": int(length[i])}} for i in np.flatnonzero(ended)}
-        return obs, reward, done, LazyInfos(self.num_envs, None, extras)
+        return self._obs(obs), reward, done, LazyInfos(self.num_envs, None, extras)
 
     def step(self, actions):
         self.step_async(actions)
