@@ -1187,7 +1187,7 @@ __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__
     uint8_t* frame = out + (size_t)rel * H * W * C;
     if (C == 1) {          // gray: the record by scalar loads, held in SGPRs for the frame
         const BrkRenderRec rec = rsrc[first_env + rel];
-        tbx_stagger_first_waves(wid);
+        if (C == 3) tbx_stagger_first_waves(wid);
         brk_paint_units<C, CUSTOM>(BrkRecHeld{rec}, custom, pal, tables, frame, first_env + rel, lane, st, part, split);
         return;
     }
@@ -1198,7 +1198,7 @@ __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__
     // step and the rasteriser changes nothing; writing the records to a buffer the rasteriser does not read removes the slow
     // rate, and so does a rasteriser launch that follows another one): see tbx_stagger_first_waves in raster.hpp.
     const BrkRecLanes rl{brk_rec_load_lanes(&rsrc[first_env + rel], lane)};
-    tbx_stagger_first_waves(wid);          // (raster.hpp; the record's load is in flight meanwhile)
+    if (C == 3) tbx_stagger_first_waves(wid);          // (raster.hpp; the record's load is in flight meanwhile)
     brk_paint_units<C, CUSTOM>(rl, custom, pal, tables, frame, first_env + rel, lane, st, part, split);
 }
 

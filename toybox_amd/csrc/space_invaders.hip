@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* 
     p.spr_lds = spr_lds;
     SiDev src = d;                                            // by VALUE: a select between references to kernel arguments puts both into scratch
     if (ALT && pick_alt && wave_uniform((int)pick_alt[env])) src = d_alt;   // (ALT: the agent layer's generic path only)
-    tbx_stagger_first_waves(wid);
+    if (C == 3) tbx_stagger_first_waves(wid);
     p.setup(src, env, lane, lds_mask[wave]);
 
     si_paint_units<C>(p, out + (size_t)rel * H * W * C, env, lane, st, part, split, skip_blank);
@@ -1539,7 +1539,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_rec_render_kernel(const SiRender
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
     SiRecPainter<C> p;
     p.spr_lds = spr_lds;
-    tbx_stagger_first_waves(wid);
+    if (C == 3) tbx_stagger_first_waves(wid);
     p.setup(recs, env, lane);
     si_paint_units<C>(p, out + (size_t)rel * H * W * C, env, lane, st, part, split);
 }
