@@ -1,5 +1,6 @@
 // Does the rasteriser's rate depend on WHERE the frames go?  One engine (Breakout, 65 536 envs, fixed records), several output
 // buffers and offsets, render-only loops interleaved over them.  (diagnostic; uses the product library through its C-ABI)
+// usage: rate_addr [envs] [game id] [0 render only | 1 step;render] [offset scan KiB | 0] [pre-roll steps] [TBX_OPT_PIPELINE] [TBX_OPT_RENDER_SPLIT]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -20,6 +21,7 @@ int main(int argc, char** argv) {
     uint64_t t = 0;
     const int preroll = argc > 5 ? atoi(argv[5]) : 600;
     if (argc > 6) tbx_set_option(e, TBX_OPT_PIPELINE, atoi(argv[6]));
+    if (argc > 7) tbx_set_option(e, TBX_OPT_RENDER_SPLIT, atoi(argv[7]));       // waves per frame
     for (int i = 0; i < preroll; i++) tbx_step_synthetic(e, 1337, t++, 0, TBX_STEP_AUTO_RESET, s);
     struct Target { const char* name; uint8_t* p; };
     std::vector<Target> targets;

@@ -681,9 +681,11 @@ struct GridWorldOps : GameOps {
                     int n_envs, hipStream_t s)
     {
         const int split_env = e->opt[TBX_OPT_RENDER_SPLIT];
-        // two waves per RGB frame (eight 8-row units each): 0.73-0.76 ms against 0.78-0.79 ms for one at 65 536 envs, four and
-        // eight are slower (scripts/render_probe.py over TBX_OPT_RENDER_SPLIT, same box); gray and RGBA stay at one
-        const int split = split_env > 0 ? split_env : channels == 3 ? 2 : 1;
+        // waves per RGB frame (sixteen 8-row units), measured per output buffer with scripts/ubench/rate_addr (eight buffers, one
+        // box, [step ; render] at 65 536 envs): 2 / 3 / 4 / 5 / 6 / 7 -> 0.76-0.80 / 0.74-0.81 / 0.72-0.78 / 0.695-0.716 / 0.76-0.775 /
+        // 0.845-0.86 ms -- five is 8 % faster than two and its rate no longer depends on the buffer; 16 384 envs 0.189-0.201
+        // against 0.195-0.208, 32 768 equal, 4 096 envs 0.047 against 0.0456: five from 16 384 envs, two below; gray and RGBA one
+        const int split = split_env > 0 ? split_env : channels == 3 ? (n_envs >= 16384 ? 5 : 2) : 1;
         switch (channels) {
         case 1: if (pick_alt) hipLaunchKernelGGL((gw_render_kernel<1, true>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((gw_render_kernel<1, false>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
         case 3: if (pick_alt) hipLaunchKernelGGL((gw_render_kernel<3, true>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); else hipLaunchKernelGGL((gw_render_kernel<3, false>), wave_grid(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, split, alt, pick_alt); break;
