@@ -22,15 +22,16 @@ int main(int argc, char** argv) {
     uint64_t t = 0;
     for (int i = 0; i < 600; i++) tbx_step_synthetic(e, 1337, t++, 0, TBX_STEP_AUTO_RESET, s);
     uint32_t* scratch; const size_t words = 13u << 18;     // 13 MB, about what the step kernel touches
-    CK(hipMalloc((void**)&scratch, words * 4));
+    CK(hipMalloc((void**)&scratch, words * 16));
     hipEvent_t ev, a, b; CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     const char* names[] = {"render only", "step ; render", "empty<<<1,64>>> ; render", "empty<<<512,128>>> ; render", "memset 4 B ; render",
                            "event record ; render", "touch 13 MB ; render", "step ; empty<<<1,64>>> ; render", "render ; render ; step (2 frames per step)",
                            "64-B record per thread (4 MB) ; render", "f64 chain 2000 x 65536 threads ; render", "i32 chain 2000 x 65536 threads ; render",
-                           "f64 chain 200 ; render", "step with wave-per-env kernel (+ record prep) ; render"};
+                           "f64 chain 200 ; render", "step with wave-per-env kernel (+ record prep) ; render",
+                           "step ; touch 13 MB ; render", "step ; 64-B record per thread (4 MB, elsewhere) ; render", "step ; touch 52 MB ; render"};
     for (int round = 0; round < 3; round++)
-        for (int p = 0; p < 14; p++) {
-            if (p == 13) tbx_set_option(e, TBX_OPT_STEP_FORM, 2); else if (p == 0) tbx_set_option(e, TBX_OPT_STEP_FORM, 0);
+        for (int p = 0; p < 17; p++) {
+            if (p == 13) tbx_set_option(e, TBX_OPT_STEP_FORM, 2); else if (p == 0 || p == 14) tbx_set_option(e, TBX_OPT_STEP_FORM, 0);
             const int K = 100;
             for (int w = 0; w < 2; w++) {
                 if (w == 1) CK(hipEventRecord(a, s));
@@ -49,6 +50,9 @@ int main(int argc, char** argv) {
                     case 11: i32_kernel<<<(n + 127) / 128, 128, 0, s>>>(scratch, n, 2000); break;
                     case 12: f64_kernel<<<(n + 127) / 128, 128, 0, s>>>((double*)scratch, n, 200); break;
                     case 13: tbx_step_synthetic(e, 1337, t++, 0, TBX_STEP_AUTO_RESET, s); break;
+                    case 14: tbx_step_synthetic(e, 1337, t++, 0, TBX_STEP_AUTO_RESET, s); touch_kernel<<<(unsigned)((words + 255) / 256), 256, 0, s>>>(scratch, words); break;
+                    case 15: tbx_step_synthetic(e, 1337, t++, 0, TBX_STEP_AUTO_RESET, s); recwrite_kernel<<<(n + 127) / 128, 128, 0, s>>>((uint4*)scratch, n, (uint32_t)i); break;
+                    case 16: tbx_step_synthetic(e, 1337, t++, 0, TBX_STEP_AUTO_RESET, s); touch_kernel<<<(unsigned)((4 * words + 255) / 256), 256, 0, s>>>(scratch, 4 * words); break;
                     default: break;
                     }
                     tbx_render_device(e, nullptr, 3, s);
