@@ -18,9 +18,10 @@ W warm-up steps, then R regions of exactly K steps, each bracketed by device-syn
 time is the MAX over ranks; the reported value is the MEDIAN region (min / max alongside).
 
 The loop is the north star's random-action rollout: actions come from the device, so step N+1 does not need frame N.
-`value` is measured with TBX_OPT_PIPELINE = 1, the engine's choice -- which is stream order (0) for every game since the
-rasterisers stagger their first waves (csrc/raster.hpp); `--pipeline 2 / 3` selects the pipelined modes explicitly, and then
-the same loop with the option off is measured on the same engine and reported beside it as `serialised`.
+`value` is measured with TBX_OPT_PIPELINE = 1, the engine's choice -- stream order (0) for large batches since the
+rasterisers stagger their first waves (csrc/raster.hpp), overlapped launches (3) for small Breakout / SpaceInvaders batches
+without a gather; `--pipeline 0 / 2 / 3` selects a mode explicitly.  Whenever a pipelined mode is in force the same loop with
+the option off is measured on the same engine and reported beside it as `serialised`.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline       -- the dominant kernel (the rasteriser) priced against HBM bandwidth with HIP events recorded on the caller's

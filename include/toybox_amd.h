@@ -557,12 +557,12 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  *     value 3: additionally consecutive rasteriser launches alternate between two internal streams and the two frame
  *              buffers, so that launch N+1 fills the ramp-down of launch N (small batches: BASELINE configs 2-4, the
  *              per-GPU share of a strong-scaled batch);
- *     value 1: the engine's choice, which is 0 for every game today.  (Rounds 2-3 chose 2 for Breakout and SpaceInvaders from
- *              16 384 envs up, 1-15 % faster "depending on the box": what it bought was a rasteriser launch that does not start
- *              against an idle memory system, and the rasterisers now see to that themselves -- csrc/raster.hpp,
- *              tbx_stagger_first_waves.  scripts/pipeline_sweep.py, 8 192 .. 65 536 envs: stream order 0.5-3 % ahead of value 2.
- *              Value 3 gains 4-10 % at 4 096-8 192 envs WITHOUT a per-step gather and loses with one, and its gain depends on
- *              which hardware queues the runtime hands the internal streams.  Both stay explicit choices.)
+ *     value 1: the engine's choice: value 3 for Breakout from 4 096 to 16 383 envs and for SpaceInvaders below 16 384 envs while
+ *              no per-step gather is initialised (BASELINE configs 2-4: 0.0985 -> 0.0868 ms and 0.162 -> 0.150 ms per step at
+ *              4 096 envs), 0 otherwise.  (Rounds 2-3 chose 2 for large batches, 1-15 % faster "depending on the box": what it
+ *              bought was a rasteriser launch that does not start against an idle memory system, and the rasterisers now see to
+ *              that themselves -- csrc/raster.hpp, tbx_stagger_first_waves; scripts/pipeline_sweep.py, 16 384 .. 65 536 envs:
+ *              stream order 0.5-3 % ahead of value 2.  Value 3 loses with a gather: 0.230 against 0.175 ms at 8 192 envs.)
  *   Contract in this mode: the stream a call names still waits for the call's work, so anything queued on it afterwards sees
  *   the result; the result of step N (render N) stays valid for readers queued on that stream BEFORE step N+1 (render N+1)
  *   is issued -- the same rule as without the option -- but it lives at the address tbx_device_buffer reports after the

@@ -1946,7 +1946,7 @@ struct AmiOps : GameOps {
     // amidar --pipeline 2, profiles/r03_amidar_pipeline2_*): the step starts with the render it runs beside, as intended, but takes
     // 420-520 us there instead of 45 (thread form; its blocks hold 17 KB of LDS each for that long) and the rasteriser beside it
     // 1.69-1.72 ms instead of 1.37: 1.73 ms per step against 1.49 in stream order (wave-per-env step: 1.83 against 1.54).
-    bool pipeline_pays() const override { return false; }
+    // (pipeline_auto stays 0: never the engine's choice)
     int records_parity() const override { return recs_par; }
     void rebind_outputs(tbx_engine* e) override
     {

@@ -522,7 +522,7 @@ static int pipe_mode(const tbx_engine* e)
 {
     const int v = e->opt[TBX_OPT_PIPELINE];
     if (v == 0 || !e->ops->pipeline_ok()) return 0;
-    if (v == 1) return (e->n >= 16384 && e->ops->pipeline_pays()) ? 2 : 0;
+    if (v == 1) return e->ops->pipeline_auto(e->n, e->gather != nullptr);
     return v;
 }
 

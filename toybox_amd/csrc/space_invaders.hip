@@ -1822,6 +1822,9 @@ struct SiOps : GameOps {
     // the rasteriser reads nothing but the records, and there are two buffers of them: a batch step can run while the previous
     // frame is still being painted (engine.hip, pipelined mode)
     bool pipeline_ok() const override { return !custom && recs_other != nullptr; }
+    // scripts/pipeline_sweep.py, stream order against value 3, ms per step without a gather: 1 024 envs 0.0546 / 0.0514, 2 048
+    // 0.0926 / 0.0799, 4 096 0.162 / 0.150, 8 192 0.306 / 0.296, 12 288 0.452 / 0.447
+    int pipeline_auto(int n, bool gather) const override { return (!gather && n < 16384) ? 3 : 0; }
     int records_parity() const override { return recs_par; }
     void rebind_outputs(tbx_engine* e) override
     {

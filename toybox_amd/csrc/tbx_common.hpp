@@ -460,11 +460,12 @@ struct GameOps {
     // every env on stream s, records into the OTHER buffer, which becomes the current one.  The step outputs go wherever
     // tbx_engine::reward / done / ... point at the time of the launch (rebind_outputs() after the engine moved them).
     virtual bool pipeline_ok() const { return false; }
-    // TBX_OPT_PIPELINE = 1 (the engine's choice) picks the pipelined mode only for engines that say it pays.  None does since
-    // the rasterisers stagger their first waves (raster.hpp, tbx_stagger_first_waves): what the mode bought Breakout and
-    // SpaceInvaders was a rasteriser launch that did not start against an idle memory system, and stream order now has that too
-    // (scripts/pipeline_sweep.py, 8 192 .. 65 536 envs: stream order 0.5-3 % ahead); Amidar's painter never gained from it
-    virtual bool pipeline_pays() const { return false; }
+    // TBX_OPT_PIPELINE = 1, the engine's choice: the mode (0, 2 or 3) for a batch of n envs, with or without a per-step gather.
+    // Large batches: stream order for every game since the rasterisers stagger their first waves (raster.hpp) -- what values 2
+    // and 3 bought Breakout and SpaceInvaders there was a rasteriser launch that did not start against an idle memory system.
+    // Small batches without a gather: overlapped launches (value 3) where they measure faster (BrkOps, SiOps); a gather adds
+    // cross-queue dependencies that cost more than the overlap gains.
+    virtual int pipeline_auto(int /*n*/, bool /*gather*/) const { return 0; }
     virtual int records_parity() const { return 0; }
     virtual int step_ahead(tbx_engine*, const ActionSource&, uint32_t, hipStream_t) { return TBX_E_UNSUPPORTED; }
     virtual void rebind_outputs(tbx_engine*) {}
