@@ -668,6 +668,27 @@ def test_options_are_validated_and_reported(hip_lib, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_engines_choice_of_pipelined_mode(hip_lib):
+    """TBX_OPT_PIPELINE = 1: overlapped launches (3) for small Breakout / SpaceInvaders batches while no per-step gather is
+    initialised, stream order (0) otherwise -- what include/toybox_amd.h says, read back through TBX_OPT_PIPELINE_ACTIVE."""
+    want = {("breakout", 1024): 0, ("breakout", 4096): 3, ("breakout", 16384): 0, ("space_invaders", 1024): 3,
+            ("space_invaders", 16384): 0, ("amidar", 4096): 0, ("gridworld", 4096): 0}
+    for (game, n), mode in want.items():
+        e = Engine(game, n, lib=hip_lib)
+        assert e.get_option(_abi.OPT_PIPELINE_ACTIVE) == 0                     # the option is off by default
+        e.set_option(_abi.OPT_PIPELINE, 1)
+        assert e.get_option(_abi.OPT_PIPELINE_ACTIVE) == mode, (game, n)
+        if mode:
+            try:
+                e.gather_init(1, 0, e.gather_unique_id())
+            except ToyboxAmdError:
+                e.close()
+                continue                                                         # no librccl on this box
+            assert e.get_option(_abi.OPT_PIPELINE_ACTIVE) == 0, (game, n)       # a gather: stream order
+        e.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("game", GAMES)
 def test_step1_frame_resident_kernel_paints(game, hip_lib, oracle_lib):
     """tbx_step1_frame = ToyboxBaseEnv.step in one call (envs/atari/base.py:126,109): on a one-env engine the resident kernel
