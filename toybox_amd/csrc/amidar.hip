@@ -1988,7 +1988,7 @@ struct AmiOps : GameOps {
                 if (flags & TBX_STEP_AUTO_RESET) return e->fail(TBX_E_INVALID, "an agent step cannot auto-reset");
                 hipLaunchKernelGGL(ami_step_tpe_kernel<true>, dim3((e->n + 63) / 64), dim3(64), 0, s, d, dA, dB, src, flags);
             } else
-                hipLaunchKernelGGL(ami_step_tpe_kernel<false>, dim3((e->n + 63) / 64), dim3(64), 0, s, d, d, d, src, flags);
+                TBX_LAUNCH_STEP(e, s, (ami_step_tpe_kernel<false>), dim3((e->n + 63) / 64), dim3(64), d, d, d, src, flags);
             TBX_HIP(hipGetLastError());
             return TBX_OK;
         }
@@ -1996,7 +1996,8 @@ struct AmiOps : GameOps {
             if (flags & TBX_STEP_AUTO_RESET) return e->fail(TBX_E_INVALID, "an agent step cannot auto-reset");
             hipLaunchKernelGGL(ami_agent_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, dA, dB, src, flags, first, count);
         } else
-            hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, src, flags, first, count);
+            if (src.single_env < 0) TBX_LAUNCH_STEP(e, s, ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), d, src, flags, first, count);
+            else hipLaunchKernelGGL(ami_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, src, flags, first, count);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }

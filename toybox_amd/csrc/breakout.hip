@@ -1694,7 +1694,7 @@ struct BreakoutOps : GameOps {
                 if (flags & TBX_STEP_AUTO_RESET) return e->fail(TBX_E_INVALID, "an agent step cannot auto-reset");
                 hipLaunchKernelGGL(brk_step_tpe_kernel<true>, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs, recsA, recsB);
             } else
-                hipLaunchKernelGGL(brk_step_tpe_kernel<false>, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs, recsA, recsB);
+                TBX_LAUNCH_STEP(e, s, (brk_step_tpe_kernel<false>), dim3((e->n + 127) / 128), dim3(128), d, cfg_dev, src, flags, recs, recsA, recsB);
             TBX_HIP(hipGetLastError());
             recs_valid = true;
             return TBX_OK;

@@ -187,8 +187,8 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
     g.nranks = nranks; g.rank = rank; g.width = records_per_rank;
     GHIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     GHIP(hipEventCreateWithFlags(&g.ready, hipEventDisableTiming));
-    GHIP(hipEventCreateWithFlags(&g.done[0], hipEventDisableTiming | hipEventReleaseToDevice));
-    GHIP(hipEventCreateWithFlags(&g.done[1], hipEventDisableTiming | hipEventReleaseToDevice));
+    GHIP(hipEventCreateWithFlags(&g.done[0], hipEventDisableTiming));
+    GHIP(hipEventCreateWithFlags(&g.done[1], hipEventDisableTiming));
     GHIP(hipMalloc((void**)&g.out, sizeof(uint64_t) * (size_t)nranks * (size_t)g.width));
     GHIP(hipMemset(g.out, 0, sizeof(uint64_t) * (size_t)nranks * (size_t)g.width));
     GHIP(hipMalloc((void**)&g.scalar, sizeof(double)));
@@ -215,7 +215,7 @@ int tbx_gather(tbx_engine* e, uint64_t* out_dev, void* stream)
     (void)stream;
     hipStream_t gs = g.stream;
     if (e->pipe.active && e->pipe.step_outstanding) GHIP(hipStreamWaitEvent(gs, e->pipe.step_ev, 0));
-    else GHIP(tbx_wait_tail(e, gs));
+    else GHIP(tbx_wait_tail(e, gs, true));
     if (g.any && g.done_on[g.last_par] != gs) GHIP(hipStreamWaitEvent(gs, g.done[g.last_par], 0));
     const uint64_t* send = e->packed;
     if (g.send) {

@@ -1812,7 +1812,8 @@ struct SiOps : GameOps {
         } else {
             // a whole-batch step leaves the rasteriser's records behind (canonical formations only)
             const bool whole = src.single_env < 0 && !custom && want_recs;
-            hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count, whole ? recs : nullptr);
+            if (src.single_env < 0) TBX_LAUNCH_STEP(e, s, si_step_kernel, grid_for(count), dim3(TBX_BLOCK), d, c, src, flags, first, count, whole ? recs : nullptr);
+            else hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count, whole ? recs : nullptr);
             recs_valid = whole;
         }
         TBX_HIP(hipGetLastError());

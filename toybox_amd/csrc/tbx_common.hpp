@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 
@@ -342,6 +343,7 @@ struct tbx_engine {
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     hipEvent_t order_ev = nullptr;
+    bool step_carries_order_ev = false;        // order_ev is the completion event of the last launch on last_stream (a batch step)
     int opt[TBX_OPT_COUNT] = {0, 0, 0, 0, 1};
     TbxPipe pipe;
     // common device buffers (SoA over envs)
@@ -394,17 +396,41 @@ hipError_t tbx_serve_stop(tbx_engine* e);   // engine.hip
 // Stream `s` waits for everything queued so far on the stream the previous call used.  That stream may be the caller's: the
 // handle is kept until the next call or tbx_sync (toybox_amd.h: a stream named in a call must stay alive that long -- the
 // runtime does not survive an event record on a destroyed stream, so a stale handle cannot be detected here).
-inline hipError_t tbx_wait_tail(tbx_engine* e, hipStream_t s)
+// after_step_only: the caller (the gather) needs nothing but the last batch step; when that step's launch carried the ordering
+// event as its completion event (TBX_LAUNCH_STEP below) no event has to be recorded behind it.
+inline hipError_t tbx_wait_tail(tbx_engine* e, hipStream_t s, bool after_step_only = false)
 {
     if (!e->has_last || e->last_stream == s) return hipSuccess;
     if (!e->order_ev) {
-        hipError_t r = hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming | hipEventReleaseToDevice);
+        hipError_t r = hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming);
         if (r != hipSuccess) return r;
     }
-    hipError_t r = hipEventRecord(e->order_ev, e->last_stream);
-    if (r != hipSuccess) return r;
+    if (!(after_step_only && e->step_carries_order_ev)) {
+        hipError_t r = hipEventRecord(e->order_ev, e->last_stream);
+        if (r != hipSuccess) return r;
+    }
     return hipStreamWaitEvent(s, e->order_ev, 0);
 }
+
+// The launch of a whole-batch step kernel.  With a per-step gather initialised the ordering event rides on the launch as its
+// completion event (hipExtLaunchKernelGGL's stopEvent) instead of being recorded behind it: measured on this runtime
+// (scripts/ubench/evgap.hip), an event record between two kernels of a stream that another stream waits for delays the second
+// kernel by 5.7 us, the completion-event form by 2.4 (two kernels with nothing between them: 1.0).
+inline hipEvent_t tbx_step_order_event(tbx_engine* e)
+{
+    if (!e->gather) return nullptr;
+    if (!e->order_ev && hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e->order_ev;
+}
+#define TBX_LAUNCH_STEP(e, s, KERNEL, GRID, BLOCK, ...)                                                             \
+    do {                                                                                                            \
+        hipEvent_t tail_ev_ = tbx_step_order_event(e);                                                              \
+        if (tail_ev_) {                                                                                             \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, s, nullptr, tail_ev_, 0, __VA_ARGS__);                    \
+            (e)->step_carries_order_ev = true;                                                                      \
+        } else                                                                                                      \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, s, __VA_ARGS__);                                             \
+    } while (0)
 
 // Every entry point that queues work names the stream it is about to use.  When that differs from the stream the previous
 // entry point used (the "_device" forms run on the caller's stream -- including the NULL stream, which does not order itself
@@ -419,6 +445,7 @@ inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s)
     }
     hipError_t r = tbx_wait_tail(e, s);
     if (r != hipSuccess) return r;
+    e->step_carries_order_ev = false;          // whatever this call queues moves the tail
     e->pipe.active = false;
     e->last_stream = s;
     e->has_last = true;
