@@ -43,11 +43,35 @@ def main():
             lines.append("| `%s` | %s | %.1f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                                                              float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
         lines.append("")
+    # a big Breakout RGB render goes out as TWO launches of the same kernel (1 024 envs, then the rest): the table above
+    # averages over both, so the rasteriser launches are listed once more by grid size, with the sum of a render's parts
+    traces = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+    if traces:
+        by = collections.defaultdict(list)
+        for r in csv.DictReader(open(traces[0])):
+            k = short(r["Kernel_Name"])
+            if "render_kernel" in k:
+                by[(k, int(r["Grid_Size"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        names = collections.defaultdict(list)
+        for (k, g), v in by.items():
+            names[k].append((g, v))
+        multi = {k: parts for k, parts in names.items() if len(parts) > 1}
+        if multi:
+            lines += ["## rasteriser launches by grid size (kernel trace)", "", "| kernel | grid (threads) | calls | avg us |", "|---|---|---|---|"]
+            for k, parts in sorted(multi.items()):
+                total = 0.0
+                for g, v in sorted(parts):
+                    lines.append("| `%s` | %d | %d | %.1f |" % (k, g, len(v), sum(v) / len(v)))
+                    total += sum(v) / len(v)
+                lines.append("| `%s` | one render = the sum of its parts | | **%.1f** |" % (k, total))
+            lines.append("")
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
     for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
+            if "render_kernel" in k:
+                k = "%s @ grid %s" % (k, r["Grid_Size"])       # (the parts of a two-part launch are different rows)
             per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             per[k]["_dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
             meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Grid_Size"], r["Workgroup_Size"])
@@ -69,8 +93,10 @@ def main():
                 k, g, w, v, s, "%.0f" % fs if fs is not None else "-", "%.0f" % ws if ws is not None else "-",
                 "%.4g" % hbm if hbm else "-", mean("_dur_us")))
             if kernel_sub in re.sub(r"_w\d<", "<", k) and hbm:       # (brk_render_kernel_w5<3,..> is a render_kernel<3)
-                traffic = {"hbm_bytes_per_launch": hbm, "fetch_kib_raw": fs, "write_kib_raw": ws,
-                           "correction": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE exact",
+                # a render = all the launches of the rasteriser it takes (two for big Breakout RGB batches): bytes add up
+                traffic = {"hbm_bytes_per_launch": hbm + traffic.get("hbm_bytes_per_launch", 0.0),
+                           "fetch_kib_raw": fs + traffic.get("fetch_kib_raw", 0.0), "write_kib_raw": ws + traffic.get("write_kib_raw", 0.0),
+                           "correction": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE exact; summed over the launches of one render",
                            "source": "profiles/%s_summary.md" % tag}
             extra = {n: mean(n) for n in c if n not in ("FETCH_SIZE", "WRITE_SIZE", "_dur_us")}
             if extra:

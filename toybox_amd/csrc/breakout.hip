@@ -1178,6 +1178,8 @@ __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
     const BrkLaneTables<C> tables(pal, lane);
     // `split` waves share a frame, wave `part` taking units part, part + split, ...
+    const bool stagger = C == 3 && !(split >> 16);        // (bit 16 of the argument: one of the two parts of a big launch)
+    split &= 0xFFFF;
     const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
     const int rel = wid / split, part = wid - rel * split;
     if (rel >= count) return;
@@ -1187,7 +1189,6 @@ __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__
     uint8_t* frame = out + (size_t)rel * H * W * C;
     if (C == 1) {          // gray: the record by scalar loads, held in SGPRs for the frame
         const BrkRenderRec rec = rsrc[first_env + rel];
-        if (C == 3) tbx_stagger_first_waves(wid);
         brk_paint_units<C, CUSTOM>(BrkRecHeld{rec}, custom, pal, tables, frame, first_env + rel, lane, st, part, split);
         return;
     }
@@ -1196,9 +1197,9 @@ __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__
     // render-only loops: 1.214-1.222 ms against 1.236-1.244).  The "two rates" of round 2 -- the same loop of [step ; render]
     // at 1.20 ms on one box and 1.35 on the next -- were NOT about this load (a kernel that re-reads every record between the
     // step and the rasteriser changes nothing; writing the records to a buffer the rasteriser does not read removes the slow
-    // rate, and so does a rasteriser launch that follows another one): see tbx_stagger_first_waves in raster.hpp.
+    // rate, and so does a rasteriser launch that follows another one): see launch_render (the two-part launch) and raster.hpp.
     const BrkRecLanes rl{brk_rec_load_lanes(&rsrc[first_env + rel], lane)};
-    if (C == 3) tbx_stagger_first_waves(wid);          // (raster.hpp; the record's load is in flight meanwhile)
+    if (stagger) tbx_stagger_first_waves(wid);          // (raster.hpp: mid-size launches; the record's load is in flight meanwhile)
     brk_paint_units<C, CUSTOM>(rl, custom, pal, tables, frame, first_env + rel, lane, st, part, split);
 }
 
@@ -1771,16 +1772,37 @@ struct BreakoutOps : GameOps {
         // lower): measured 6.05-6.25 TB/s against 5.4-5.7 for one wave per frame and for every other split from 1 to 20
         // except 9..12 (scripts/ab_render.py over TBX_OPT_RENDER_SPLIT); also what keeps small batches from under-filling the chip
         const int split = split_opt > 0 ? split_opt : C == 3 ? 10 : count <= 8192 ? 4 : count <= 32768 ? 2 : 1;   // gray / RGBA: no such effect
-        const dim3 grid = grid_for(count * split), block(TBX_BLOCK);
-#define BRK_LAUNCH(KERNEL, CUSTOM_, ALT_) hipLaunchKernelGGL((KERNEL<C, CUSTOM_, ALT_>), grid, block, 0, s, rr, d.custom, pal, out, first, count, split, alt, pick_alt)
-        if (C >= 3) {          // (pick_alt: the agent layer's generic path, per-env choice between two record arrays)
-            if (pick_alt) { if (custom) BRK_LAUNCH(brk_render_kernel_w5, true, true); else BRK_LAUNCH(brk_render_kernel_w5, false, true); }
-            else { if (custom) BRK_LAUNCH(brk_render_kernel_w5, true, false); else BRK_LAUNCH(brk_render_kernel_w5, false, false); }
-        } else {
-            if (pick_alt) { if (custom) BRK_LAUNCH(brk_render_kernel, true, true); else BRK_LAUNCH(brk_render_kernel, false, true); }
-            else { if (custom) BRK_LAUNCH(brk_render_kernel, true, false); else BRK_LAUNCH(brk_render_kernel, false, false); }
-        }
+        // A big RGB launch goes out in TWO parts, the first 1 024 envs (two generations of waves) and then the rest.  A launch
+        // whose first waves all start together into an idle memory system -- behind a step kernel -- keeps them in lockstep,
+        // and the frame stores then cost 0-15 % more depending on where the frame buffer lies (the "two rate states" of rounds
+        // 2-3; DESIGN.md section 6, raster.hpp).  The second part starts against the draining stores of the first and its waves
+        // are spread by that, like those of a launch that follows another rasteriser launch.  Measured per output buffer
+        // (scripts/ubench/rate_addr, [step ; render], three processes x eight buffers each, ms per step): 65 536 envs
+        // 1.208-1.214 in all 24 against 1.211-1.236 with the staggered first waves of raster.hpp and 1.19-1.38 with neither;
+        // 32 768: 0.615-0.621 / 0.618-0.692; 16 384: 0.319-0.320 / 0.317-0.345; 8 192: 0.171-0.173 / 0.165-0.181.  First
+        // parts of 256 or 512 envs leave some buffers slow, 2 048 costs 3 us more.  Render-only loops pay 8 us per launch for
+        // it (1.195 against 1.187 ms).
+        // Launches of 16 384 .. 32 767 blocks (6 554 .. 13 107 envs) keep the staggered first waves instead: there the second
+        // kernel boundary costs as much as it saves (scripts/pipeline_sweep.py, 8 192 envs: 0.172 / 0.169-0.173 ms per step two
+        // parts / stagger, with a per-step gather 0.179 / 0.175).
+        const bool two_parts = C == 3 && grid_for(count * split).x >= 32768u;
+        const int head = two_parts ? 1024 : count;
+        const int split_arg = split | (two_parts ? 1 << 16 : 0);          // bit 16: no stagger (this is one of two parts)
+        for (int f0 = 0; f0 < count; f0 += head) {
+            const int n = f0 == 0 ? head : count - head;
+            uint8_t* o = out + (size_t)f0 * TBX_BRK_H * TBX_BRK_W * C;
+            const dim3 grid = grid_for(n * split), block(TBX_BLOCK);
+#define BRK_LAUNCH(KERNEL, CUSTOM_, ALT_) hipLaunchKernelGGL((KERNEL<C, CUSTOM_, ALT_>), grid, block, 0, s, rr, d.custom, pal, o, first + f0, n, split_arg, alt, pick_alt)
+            if (C >= 3) {          // (pick_alt: the agent layer's generic path, per-env choice between two record arrays)
+                if (pick_alt) { if (custom) BRK_LAUNCH(brk_render_kernel_w5, true, true); else BRK_LAUNCH(brk_render_kernel_w5, false, true); }
+                else { if (custom) BRK_LAUNCH(brk_render_kernel_w5, true, false); else BRK_LAUNCH(brk_render_kernel_w5, false, false); }
+            } else {
+                if (pick_alt) { if (custom) BRK_LAUNCH(brk_render_kernel, true, true); else BRK_LAUNCH(brk_render_kernel, false, true); }
+                else { if (custom) BRK_LAUNCH(brk_render_kernel, true, false); else BRK_LAUNCH(brk_render_kernel, false, false); }
+            }
 #undef BRK_LAUNCH
+            if (f0) break;
+        }
     }
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override

@@ -42,8 +42,10 @@ __device__ __forceinline__ uint32_t tbx_digit_glyph(uint32_t digit)
 // pipelined mode, for the same reason.  With the stagger the loop runs at 1.22 ms into every buffer (at 8 192 envs 0.165-0.168
 // instead of 0.176-0.187, at 16 384 0.318-0.322 instead of 0.325-0.357); back to back it costs about half the longest sleep
 // once per launch (1.20 against 1.18 ms).  Launches of fewer than 16 384 blocks (a dozen generations of waves) gain nothing and
-// are left alone.  Breakout's and SpaceInvaders' RGB launches call it; their gray and RGBA launches show no such lottery and
-// only pay for it (1-3 %, same-box A/B), Amidar's rasteriser shows none either and loses 6 % with it.
+// are left alone.  SpaceInvaders' RGB launches and Breakout's mid-size ones (up to 65 535 blocks) call it; Breakout's big RGB
+// launches reach the same end by going out in two parts (BrkOps::launch_render: 54.0 against 53.5 M env-steps/s at 65 536 envs
+// and no slow buffer in 24).  Gray and RGBA launches show no such lottery and only pay for it (1-3 %, same-box A/B), Amidar's
+// rasteriser shows none either and loses 6 % with it.
 constexpr unsigned TBX_STAGGER_BLOCKS = 1280;      // 256 CUs x 4 SIMDs x 5 wave slots / 4 waves per block
 __device__ __forceinline__ void tbx_stagger_first_waves(int wid)
 {
