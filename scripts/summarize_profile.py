@@ -51,7 +51,7 @@ def main():
         for r in csv.DictReader(open(traces[0])):
             k = short(r["Kernel_Name"])
             if "render_kernel" in k:
-                by[(k, int(r["Grid_Size"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                by[(k, int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         names = collections.defaultdict(list)
         for (k, g), v in by.items():
             names[k].append((g, v))
