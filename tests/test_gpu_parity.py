@@ -279,6 +279,34 @@ def test_full_size_batch_parity(game, hip_lib, oracle_lib, monkeypatch):
     assert acc.sum() > 0 and (game != "breakout" or dones > 0)      # rewards flowed; Breakout games ended and restarted
 
 
+@pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar", "gridworld"])
+def test_big_batch_launch_frames_parity(game, hip_lib, oracle_lib, monkeypatch):
+    """The batched RGB launch at a size where the big-launch forms are in force -- Breakout's render in two parts (1 024 envs,
+    then the rest), SpaceInvaders' staggered first waves, GridWorld's five waves per frame, Amidar's six waves per SIMD --
+    against the oracle's frames: the envs on both sides of the part boundary, the ends of the batch and a random sample, after
+    a mid-game pre-roll, and again after more steps."""
+    from toybox_amd import hip
+    monkeypatch.setenv("TBX_ORACLE_THREADS", str(min(16, len(__import__("os").sched_getaffinity(0)))))
+    n = 16384
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=77)
+    H, W = g.height, g.width
+    one = np.empty((H, W, 3), np.uint8)
+    picks = [0, 1, 1022, 1023, 1024, 1025, 2047, 2048, n - 2, n - 1] + [int(i) for i in np.random.default_rng(3).choice(n, 30, replace=False)]
+    t = 0
+    for rounds in (120, 40):
+        for _ in range(rounds):
+            a = synthetic_actions(game, n, t, seed=5)
+            g.step(a, auto_reset=True), o.step(a, auto_reset=True)
+            t += 1
+        g.render_device(0, 3)
+        g.sync()
+        p, nbytes = g.device_buffer(_abi.BUF_FRAME)
+        assert nbytes >= n * H * W * 3
+        for i in picks:
+            hip.memcpy_dtoh(one, p + i * H * W * 3, H * W * 3)
+            assert np.array_equal(one, o.render_env(i, 3)), (game, t, i)
+
+
 def test_space_invaders_interventions_parity(hip_lib, oracle_lib):
     """Hand-written SpaceInvaders states: enemies stacked on top of each other (paint order, the multi-candidate path of the
     rasteriser), eight enemy lasers over shields and ship, a chewed shield, a visible ufo, an exploding ship, out-of-frame
