@@ -1786,10 +1786,8 @@ struct BreakoutOps : GameOps {
         // kernel boundary costs as much as it saves (scripts/pipeline_sweep.py, 8 192 envs: 0.172 / 0.169-0.173 ms per step two
         // parts / stagger, with a per-step gather 0.179 / 0.175).
         const bool two_parts = C == 3 && grid_for(count * split).x >= 32768u;
-        const int head = two_parts ? 1024 : count;
         const int split_arg = split | (two_parts ? 1 << 16 : 0);          // bit 16: no stagger (this is one of two parts)
-        for (int f0 = 0; f0 < count; f0 += head) {
-            const int n = f0 == 0 ? head : count - head;
+        auto launch_part = [&](int f0, int n) {                           // envs first + f0 .. first + f0 + n - 1 into their frames
             uint8_t* o = out + (size_t)f0 * TBX_BRK_H * TBX_BRK_W * C;
             const dim3 grid = grid_for(n * split), block(TBX_BLOCK);
 #define BRK_LAUNCH(KERNEL, CUSTOM_, ALT_) hipLaunchKernelGGL((KERNEL<C, CUSTOM_, ALT_>), grid, block, 0, s, rr, d.custom, pal, o, first + f0, n, split_arg, alt, pick_alt)
@@ -1801,8 +1799,10 @@ struct BreakoutOps : GameOps {
                 else { if (custom) BRK_LAUNCH(brk_render_kernel, true, false); else BRK_LAUNCH(brk_render_kernel, false, false); }
             }
 #undef BRK_LAUNCH
-            if (f0) break;
-        }
+        };
+        constexpr int HEAD_ENVS = 1024;
+        if (two_parts) { launch_part(0, HEAD_ENVS); launch_part(HEAD_ENVS, count - HEAD_ENVS); }
+        else launch_part(0, count);
     }
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
