@@ -16,7 +16,8 @@ __global__ void i32_kernel(uint32_t* p, int n, int iters) { int i = blockIdx.x *
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 65536;
     tbx_engine* e = nullptr;
-    if (tbx_create(TBX_GAME_BREAKOUT, n, 0, nullptr, 0, &e)) { printf("create failed: %s\n", tbx_last_error(nullptr)); return 1; }
+    const int game = argc > 2 ? atoi(argv[2]) : TBX_GAME_BREAKOUT;
+    if (tbx_create(game, n, 0, nullptr, 0, &e)) { printf("create failed: %s\n", tbx_last_error(nullptr)); return 1; }
     tbx_seed(e, -1, 1234); tbx_new_game(e, nullptr);
     hipStream_t s; CK(hipStreamCreate(&s));
     uint64_t t = 0;
