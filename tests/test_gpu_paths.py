@@ -629,6 +629,60 @@ def test_results_stay_valid_for_readers_queued_before_the_next_call(mode, hip_li
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("game,n", [("breakout", 40000), ("space_invaders", 24000), ("amidar", 30000)])
+@pytest.mark.parametrize("mode", [2, 3])
+def test_pipelined_render_of_a_rewritten_state_is_not_overtaken_by_the_next_step(mode, game, n, hip_lib, oracle_lib):
+    """ADVICE r03 (engine.hip, pipe_step): after new_game / set_state the render records are stale, so the first render of the
+    pipelined loop starts from LIVE state (the record-prep kernel, or Amidar's state-reading rasteriser) on the render stream;
+    the tbx_step_synthetic that follows runs on an internal stream and rewrites that state -- it has to wait for that reader.
+    [new_game | set_state -> render_device -> step_synthetic x 3] with device-side copies of sampled frames queued straight
+    behind the render and nothing synchronised in between: every copy must show the state BEFORE the steps."""
+    from toybox_amd import hip
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=77)
+    g.set_option(_abi.OPT_PIPELINE, mode)
+    H, W = g.height, g.width
+    fb = H * W * 3
+    sample = [0, 1, n // 3, n // 2, n - 2, n - 1]
+    s = hip.Stream()
+    rounds = 10
+    hold = hip.malloc(fb * len(sample) * rounds)
+    want = []
+    t = 0
+    for rnd in range(rounds):
+        for k in range(3 + rnd % 3):                         # the loop proper, so that records exist and the lanes are busy
+            g.step_synthetic(1337, t, auto_reset=True, stream=s.ptr)
+            g.render_device(0, 3, stream=s.ptr)
+            o.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
+            t += 1
+        if rnd % 2 == 0:                                     # every env starts over ...
+            m = np.ones(n, np.uint8)
+            m[1] = 0
+            g.new_game(m); o.new_game(m)
+        else:                                                # ... or sampled envs take another env's state
+            for i in sample:
+                st = o.get_state((i * 7 + 3) % n)
+                g.set_state(i, st); o.set_state(i, st)
+        g.render_device(0, 3, stream=s.ptr)                  # records are stale: this launch reads live state
+        f, _ = g.device_buffer(_abi.BUF_FRAME)
+        for k, i in enumerate(sample):
+            hip.memcpy_dtod_async(hold + fb * (len(sample) * rnd + k), f + fb * i, fb, s)
+        want.append([o.render_env(i, 3) for i in sample])
+        for _ in range(3):                                   # steps right behind it; they must not reach into that frame
+            g.step_synthetic(1337, t, auto_reset=True, stream=s.ptr)
+            o.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
+            t += 1
+    s.synchronize()
+    one = np.empty((H, W, 3), np.uint8)
+    for rnd in range(rounds):
+        for k, i in enumerate(sample):
+            hip.memcpy_dtoh(one, hold + fb * (len(sample) * rnd + k), fb)
+            assert np.array_equal(one, want[rnd][k]), (game, mode, rnd, i)
+    hip.free(hold)
+    g.sync()
+    _same_states(g, o, sample, "end")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", [0, 3])
 def test_a_caller_stream_may_be_destroyed_after_tbx_sync(mode, hip_lib, oracle_lib):
     """The library remembers the stream of the last call to order the next one behind it, so that stream has to live until

@@ -1948,6 +1948,7 @@ struct AmiOps : GameOps {
     // 1.69-1.72 ms instead of 1.37: 1.73 ms per step against 1.49 in stream order (wave-per-env step: 1.83 against 1.54).
     // (pipeline_auto stays 0: never the engine's choice)
     int records_parity() const override { return recs_par; }
+    bool records_valid() const override { return recs_valid; }
     void rebind_outputs(tbx_engine* e) override
     {
         d.reward = e->reward; d.done = e->done; d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed;

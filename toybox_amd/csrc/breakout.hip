@@ -1725,6 +1725,7 @@ struct BreakoutOps : GameOps {
         split_opt = e->opt[TBX_OPT_RENDER_SPLIT];
     }
     int records_parity() const override { return recs_par; }
+    bool records_valid() const override { return recs_valid; }
     int step_ahead(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
     {
         hipLaunchKernelGGL(brk_step_tpe_kernel<false>, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, recs_other, recsA, recsB);

@@ -529,23 +529,21 @@ static int pipe_mode(const tbx_engine* e)
 static int pipe_prepare(tbx_engine* e)
 {
     TbxPipe& p = e->pipe;
-    if (p.lane[0]) return TBX_OK;
+    if (p.prepared) return TBX_OK;
+    // every resource is made only while it is still missing, so that a call that failed half way can be repeated without
+    // leaking what the first attempt got; `prepared` is set last
     const size_t N = (size_t)e->n;
-    EHIP(hipMalloc((void**)&e->outs[1].reward, N * sizeof(int32_t)));
-    EHIP(hipMalloc((void**)&e->outs[1].done, N));
-    EHIP(hipMalloc((void**)&e->outs[1].lives, N * sizeof(int32_t)));
-    EHIP(hipMalloc((void**)&e->outs[1].score, N * sizeof(int32_t)));
-    EHIP(hipMalloc((void**)&e->outs[1].packed, N * sizeof(uint64_t)));
-    EHIP(hipMemset(e->outs[1].reward, 0, N * sizeof(int32_t)));
-    EHIP(hipMemset(e->outs[1].done, 0, N));
-    EHIP(hipMemset(e->outs[1].lives, 0, N * sizeof(int32_t)));
-    EHIP(hipMemset(e->outs[1].score, 0, N * sizeof(int32_t)));
-    EHIP(hipMemset(e->outs[1].packed, 0, N * sizeof(uint64_t)));
-    EHIP(hipEventCreateWithFlags(&p.step_ev, hipEventDisableTiming));
+    TbxStepOut& o = e->outs[1];
+    if (!o.reward) { EHIP(hipMalloc((void**)&o.reward, N * sizeof(int32_t))); EHIP(hipMemset(o.reward, 0, N * sizeof(int32_t))); }
+    if (!o.done) { EHIP(hipMalloc((void**)&o.done, N)); EHIP(hipMemset(o.done, 0, N)); }
+    if (!o.lives) { EHIP(hipMalloc((void**)&o.lives, N * sizeof(int32_t))); EHIP(hipMemset(o.lives, 0, N * sizeof(int32_t))); }
+    if (!o.score) { EHIP(hipMalloc((void**)&o.score, N * sizeof(int32_t))); EHIP(hipMemset(o.score, 0, N * sizeof(int32_t))); }
+    if (!o.packed) { EHIP(hipMalloc((void**)&o.packed, N * sizeof(uint64_t))); EHIP(hipMemset(o.packed, 0, N * sizeof(uint64_t))); }
+    if (!p.step_ev) EHIP(hipEventCreateWithFlags(&p.step_ev, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) {
-        EHIP(hipEventCreateWithFlags(&p.render_ev[k], hipEventDisableTiming));
-        EHIP(hipEventCreateWithFlags(&p.user_step_ev[k], hipEventDisableTiming));
-        EHIP(hipEventCreateWithFlags(&p.user_frame_ev[k], hipEventDisableTiming));
+        if (!p.render_ev[k]) EHIP(hipEventCreateWithFlags(&p.render_ev[k], hipEventDisableTiming));
+        if (!p.user_step_ev[k]) EHIP(hipEventCreateWithFlags(&p.user_step_ev[k], hipEventDisableTiming));
+        if (!p.user_frame_ev[k]) EHIP(hipEventCreateWithFlags(&p.user_frame_ev[k], hipEventDisableTiming));
     }
     // The two internal streams are created with the highest priority.  Not for the priority's sake: the runtime multiplexes the
     // streams of a process onto a few hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES, 4 by default), two streams that
@@ -554,8 +552,9 @@ static int pipe_prepare(tbx_engine* e)
     // the serial loop from one process to the next; scripts/pipeline_sweep.py).
     int lo = 0, hi = 0;
     EHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));     // numerically hi <= lo
-    EHIP(hipStreamCreateWithPriority(&p.lane[0], hipStreamNonBlocking, hi));
-    EHIP(hipStreamCreateWithPriority(&p.lane[1], hipStreamNonBlocking, hi));
+    for (int k = 0; k < 2; k++)
+        if (!p.lane[k]) EHIP(hipStreamCreateWithPriority(&p.lane[k], hipStreamNonBlocking, hi));
+    p.prepared = true;
     return TBX_OK;
 }
 
@@ -574,6 +573,7 @@ static int pipe_enter(tbx_engine* e)
     p.step_on = nullptr;
     p.step_user = nullptr;
     p.frame_par = -1;
+    p.live_reader = -1;
     p.active = true;
     return TBX_OK;
 }
@@ -592,13 +592,23 @@ static int pipe_step(tbx_engine* e, const ActionSource& src, uint32_t flags, hip
         p.render_pending[rw] = false;
     }
     if (p.user_step_rec[wp]) { EHIP(hipStreamWaitEvent(ss, p.user_step_ev[wp], 0)); p.user_step_rec[wp] = false; }
+    // A render issued while the records did not reflect the state (after new_game / set_state / a single-env step) read LIVE
+    // state -- the prep kernel that rebuilds the records, or a state-reading rasteriser -- on its own stream: this step, which
+    // rewrites that state, goes behind it (it only waited for the reader of the OTHER records buffer).
+    if (p.live_reader >= 0) {
+        if (p.render_on[p.live_reader] != ss) EHIP(hipStreamWaitEvent(ss, p.render_ev[p.live_reader], 0));
+        p.live_reader = -1;
+    }
     // whatever the caller has queued so far may read the current outputs: the step after this one waits for it
     EHIP(hipEventRecord(p.user_step_ev[cur], user));
     p.user_step_rec[cur] = true;
     tbx_set_out_parity(e, wp);
-    EHIP(tbx_gather_before_step(e, ss));
-    rc = e->ops->step_ahead(e, src, flags, ss);
-    if (rc) return rc;
+    hipError_t ge = tbx_gather_before_step(e, ss);
+    rc = ge == hipSuccess ? e->ops->step_ahead(e, src, flags, ss) : hip_fail(e, "tbx_gather_before_step", ge);
+    if (rc) {                                                  // nothing was launched: TBX_BUF_* keep naming the set that holds results
+        tbx_set_out_parity(e, cur);
+        return rc;
+    }
     EHIP(hipEventRecord(p.step_ev, ss));
     EHIP(hipStreamWaitEvent(user, p.step_ev, 0));
     p.step_outstanding = true;
@@ -649,11 +659,13 @@ static int pipe_render(tbx_engine* e, uint8_t* out_dev, int channels, hipStream_
     }
     if (((uintptr_t)out_dev & 15u) != 0) return e->fail(TBX_E_INVALID, "frame buffer must be 16-byte aligned");
     if (p.render_pending[rp] && p.render_on[rp] != rs) EHIP(hipStreamWaitEvent(rs, p.render_ev[rp], 0));   // (another render of these records)
+    const bool reads_live = !e->ops->records_valid();          // the launch below starts from live state (pipe_step waits for it)
     rc = e->ops->render(e, out_dev, channels, 0, e->n, rs);
     if (rc) return rc;
     EHIP(hipEventRecord(p.render_ev[rp], rs));
     p.render_pending[rp] = true;
     p.render_on[rp] = rs;
+    if (reads_live) p.live_reader = rp;
     if (overlap) {
         EHIP(hipStreamWaitEvent(user, p.render_ev[rp], 0));
         p.frame_par = rp;

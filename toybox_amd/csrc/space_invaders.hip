@@ -1827,6 +1827,7 @@ struct SiOps : GameOps {
     // 0.0926 / 0.0799, 4 096 0.162 / 0.150, 8 192 0.306 / 0.296, 12 288 0.452 / 0.447
     int pipeline_auto(int n, bool gather) const override { return (!gather && n < 16384) ? 3 : 0; }
     int records_parity() const override { return recs_par; }
+    bool records_valid() const override { return recs_valid; }
     void rebind_outputs(tbx_engine* e) override
     {
         d.reward = e->reward; d.done = e->done; d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed;

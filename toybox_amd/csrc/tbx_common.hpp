@@ -328,7 +328,9 @@ struct TbxPipe {
     hipEvent_t user_step_ev[2] = {nullptr, nullptr}, user_frame_ev[2] = {nullptr, nullptr};
     bool user_step_rec[2] = {false, false}, user_frame_rec[2] = {false, false};
     bool active = false;          // the last call through the handle was a pipelined step or render
+    bool prepared = false;        // every resource above exists (set last by pipe_prepare)
     bool step_outstanding = false;
+    int live_reader = -1;         // >= 0: the render behind render_ev[live_reader] read LIVE state (records were not valid): the next step waits for it
     int frame_par = -1;           // frame buffer the last overlapped render wrote (-1: none since the pipeline was entered)
     uint8_t* frame[2] = {nullptr, nullptr};
     size_t frame_bytes[2] = {0, 0};
@@ -445,6 +447,16 @@ inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s)
     }
     hipError_t r = tbx_wait_tail(e, s);
     if (r != hipSuccess) return r;
+    if (e->pipe.active) {
+        // leaving the pipelined mode: a render that ran on another caller stream than the one the last pipelined call named
+        // (mode 2, or out_dev given: render on U1, then a step naming U2) is not behind last_stream -- join it here
+        TbxPipe& p = e->pipe;
+        for (int k = 0; k < 2; k++)
+            if (p.render_pending[k] && p.render_on[k] && p.render_on[k] != s) {
+                r = hipStreamWaitEvent(s, p.render_ev[k], 0);
+                if (r != hipSuccess) return r;
+            }
+    }
     e->step_carries_order_ev = false;          // whatever this call queues moves the tail
     e->pipe.active = false;
     e->last_stream = s;
@@ -494,6 +506,7 @@ struct GameOps {
     // cross-queue dependencies that cost more than the overlap gains.
     virtual int pipeline_auto(int /*n*/, bool /*gather*/) const { return 0; }
     virtual int records_parity() const { return 0; }
+    virtual bool records_valid() const { return true; }        // false: the next render starts from live state (prep kernel / state-reading rasteriser)
     virtual int step_ahead(tbx_engine*, const ActionSource&, uint32_t, hipStream_t) { return TBX_E_UNSUPPORTED; }
     virtual void rebind_outputs(tbx_engine*) {}
     // an engine option changed (tbx_set_option): pick it up

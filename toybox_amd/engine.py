@@ -137,6 +137,8 @@ class Engine:
         rc = self._lib.tbx_step1_frame(self._h, env, ale_action, _abi.STEP_AUTO_RESET if auto_reset else 0, int(channels), out, C.byref(fp))
         if rc != _abi.OK:
             self._check(rc)
+        if not fp.value:
+            raise ToyboxAmdError(rc, "tbx_step1_frame returned no frame buffer")
         n = self.height * self.width * int(channels)
         frame = np.frombuffer((C.c_uint8 * n).from_address(fp.value), np.uint8).reshape(self.height, self.width, int(channels)).copy()
         return out[0], out[1] != 0, out[2], out[3], frame

@@ -78,6 +78,12 @@ class ToyboxBaseEnv(_EnvBase):
         self.score = tb.get_score()                     # the score one step ago: rewards are its increases
         self.cached_state = None
         self._np_random = None
+        self.viewer = None                              # (headless: never created; the attribute is part of the reference's surface)
+        # the private names the reference's class carries (envs/atari/base.py:60-66), for code that peeks at them
+        self._rgba = self.channels
+        self._height, self._width = tb.get_height(), tb.get_width()
+        self._dim = (self._height, self._width, self._rgba)
+        self._obs_type, self._pixel_high = "image", 255
 
     # ------------------------------------------------------------------ gym.Env
     @property
@@ -92,9 +98,16 @@ class ToyboxBaseEnv(_EnvBase):
         return self._np_random
 
     def seed(self, seed=None):
+        # gym.utils.seeding.np_random of the gym era the reference targets (envs/atari/base.py:84-98): the RandomState is seeded
+        # with the two 32-bit halves of hash_seed(seed), not with the seed itself -- NoopResetEnv's draws depend on it
         first = int.from_bytes(os.urandom(4), "little") % 2 ** 31 if seed is None else int(seed)
+        if _gym is not None and hasattr(_gym, "utils") and hasattr(_gym.utils, "seeding"):
+            self._np_random, first = _gym.utils.seeding.np_random(first)
+        else:
+            h = hash_seed(first)
+            self._np_random = np.random.RandomState()
+            self._np_random.seed([(h >> (32 * i)) & 0xFFFFFFFF for i in range(2)])
         second = hash_seed(first + 1) % 2 ** 31
-        self._np_random = np.random.RandomState(first % 2 ** 32)
         self.toybox.set_seed(second)
         self.toybox.new_game()                          # the simulator's seed only acts through a new game
         return [first, second]
@@ -104,6 +117,10 @@ class ToyboxBaseEnv(_EnvBase):
 
     def _frame(self):
         return self.toybox._engine.render_env(self.toybox._env, self.channels)
+
+    def _get_obs(self):
+        """the reference's name for it (envs/atari/base.py:106-113): the current frame, gray (H, W, 1) or colour without / with alpha"""
+        return self._frame()
 
     def step(self, action_index):
         if not 0 <= action_index < len(self._action_set):

@@ -194,9 +194,10 @@ class Toybox(object):
         get_score / get_lives / game_over calls that follow."""
         if int(action_int) not in self._engine.legal_actions:
             raise ValueError("Expected to apply action, but failed: {0}".format(action_int))
-        frame = None
-        for _ in range(self.frames_per_action):
-            _, _, lives, score, frame = self._engine.step1_frame(self._env, action_int, channels)
+        # only the last sub-frame is rasterised (a frame per sub-frame is a render launch, a copy and a sync each on batch engines)
+        for _ in range(self.frames_per_action - 1):
+            self._engine.step1(self._env, action_int)
+        _, _, lives, score, frame = self._engine.step1_frame(self._env, action_int, channels)
         self._scal = (score, lives)
         return frame
 
