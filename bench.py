@@ -1,37 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the batched game-step hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+  python bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--loop auto|pair] [--gather-every K]
 
-One "step" = one pass of the hot path over one batch: the step kernel (transition + auto-reset, actions generated on the
-device by the counter-based rule of SURVEY 8d) followed by the frame rasteriser writing uint8[N,H,W,3] into HBM.
-Workload: Breakout, 65 536 envs per GPU (weak scaling, the default: the batch shards embarrassingly, envs never interact)
-or 65 536 envs in total (--scaling strong: SURVEY 8d's headline batch cut into N contiguous shards), env seeds 1234 + global
-env index.  For N > 1 there is one process per GPU: started by any launcher that exports RANK / LOCAL_RANK / WORLD_SIZE
-(torch.distributed.run does), or by this script itself when it finds no RANK in its environment.  The only exchange is the
-per-step all-gather of the packed 8-byte {reward, done, lives} records -- tbx_gather, RCCL behind the C-ABI, no PyTorch --
-queued between the step and the rasteriser so that it overlaps with the latter.
+One "step" = one pass of the hot path over one batch: every env is stepped one frame (transition + auto-reset, actions
+generated on the device by the counter-based rule of SURVEY 8d) and one uint8[N,H,W,3] frame batch is rasterised into HBM.
+Workload: Breakout, 65 536 envs IN TOTAL (the metric names one 64k-env batch on 1/2/4/8 MI355X: `--scaling strong`, the
+default -- rank r owns the contiguous shard r of N), env seeds 1234 + global env index.  For N > 1 there is one
+process per GPU: started by any launcher that exports RANK / LOCAL_RANK / WORLD_SIZE (torch.distributed.run does), or by this
+script itself when it finds no RANK in its environment; the other reading (65 536 envs PER GPU, `weak`) is measured in the
+same invocation with a communicator of its own and printed beside `value`, and `share_of_linear` = strong total / weak total.
+The only exchange is the all-gather of the packed 8-byte {reward, done, lives} records -- tbx_gather, RCCL behind the C-ABI,
+no PyTorch -- through a K-step record ring (--gather-every, default 4: one collective per 4 steps carrying all 4 steps'
+records; 1 = one per step); before anything is timed one exchange is verified (own slice == TBX_BUF_PACKED, every other rank's
+slice arrived) and the line says so (`rccl.verified`).  A communicator that cannot be made is a FAILED run (rc 4).
+
+Loop forms.  The north star's loop is a random-action rollout: actions come from the device, step t+1 does not need frame t.
+`fused` (default where the engine fuses: Breakout RGB / RGBA) is one tbx_render_step_synthetic per iteration -- the rasteriser
+of frame t and the step to frame t+1 as ONE launch; `pair` is tbx_step_synthetic ; tbx_render_device, two launches in stream
+order, the rate a policy-driven loop gets.  Whenever `value` is not the pair form in stream order, that is measured on the
+same engine and reported beside it as `serialised`.
 
 Protocol (mirroring the repeat-and-summarise shape of the reference's test/benchmark.py:119-148): an untimed
 pre-roll of step-only frames so that the timed region sees mid-game states with episodes ending and auto-resets firing,
 W warm-up steps, then R regions of exactly K steps, each bracketed by device-sync + rank barrier on both sides; a region's
 time is the MAX over ranks; the reported value is the MEDIAN region (min / max alongside).
 
-The loop is the north star's random-action rollout: actions come from the device, so step N+1 does not need frame N.
-`value` is measured with TBX_OPT_PIPELINE = 1, the engine's choice -- stream order (0) for large batches since the
-rasterisers stagger their first waves (csrc/raster.hpp), overlapped launches (3) for small Breakout / SpaceInvaders batches
-without a gather; `--pipeline 0 / 2 / 3` selects a mode explicitly.  Whenever a pipelined mode is in force the same loop with
-the option off is measured on the same engine and reported beside it as `serialised`.
-
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline       -- the dominant kernel (the rasteriser) priced against HBM bandwidth with HIP events recorded on the caller's
-                    stream around every 8th render launch of the timed regions,
-  serialised     -- (only when a pipelined mode is in force) the same loop with TBX_OPT_PIPELINE = 0,
+  roofline       -- the dominant kernel (the rasteriser; fused: rasteriser + step launch) priced against HBM bandwidth with HIP
+                    events recorded on the caller's stream around every 8th such launch of the timed regions,
+  loop           -- which loop form `value` was measured with,
+  serialised     -- the two-launch loop in stream order on the same engine (when `value` is anything else),
   step_only      -- the same loop without the rasteriser (not bandwidth-bound: no roofline),
-  scaling_strong -- the other reading of the metric: the 65 536-env batch in total, i.e. what ONE GPU does with 1/8 of it
-                    plus the per-step gather, and 8 x that over `value` (N=1 only; with --gpus 8 --scaling strong it is measured),
-  rccl           -- for N > 1 (or --with-gather): ranks the communicator spans as RCCL reports it, bytes gathered per step,
-                    the library loaded.  A communicator that cannot be made is a FAILED run (rc 4) unless --allow-no-gather,
+  weak / strong  -- (N > 1) the other reading, and share_of_linear,
+  scaling_strong -- (N = 1) what ONE GPU does with 1/8 of the batch plus the record gather, as a share of linear (a fraction),
+  rccl           -- ranks the communicator spans as RCCL reports it, ring depth, bytes per collective, library, verified,
   cpu_baseline   -- the CPU oracle (oracle/, a port: ctoybox itself cannot be built offline) on this box's host cores, a
                     bounded sample of the same 65 536-env workload, plus BASELINE config 1 (one env, one thread) -- N=1 only.
 --dry-run walks the N-process launch, id exchange, barriers and teardown without touching a GPU (CPU test of the launcher).
@@ -67,8 +70,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--preroll", type=int, default=1000, help="untimed step-only frames before the warm-up (mid-game states)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: --envs per GPU; strong: --envs in total, sharded contiguously over the GPUs")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="which reading is `value`.  strong (default): --envs IN TOTAL, sharded contiguously over the GPUs -- the metric "
+                         "names one 64k-env batch on 1/2/4/8 GPUs; weak: --envs per GPU.  With N > 1 the other one is measured too")
+    ap.add_argument("--loop", default="auto", choices=["auto", "fused", "pair"],
+                    help="auto / fused: tbx_render_step_synthetic where the engine fuses (Breakout RGB / RGBA); pair: step ; render")
+    ap.add_argument("--gather-every", type=int, default=4,
+                    help="K of the record ring (TBX_OPT_GATHER_EVERY): one RCCL all-gather per K steps (1 = every step)")
     ap.add_argument("--game", default="breakout")
     ap.add_argument("--envs", type=int, default=65536)
     ap.add_argument("--channels", type=int, default=3)
@@ -489,13 +497,19 @@ def dry_run(args, rank, world):
 
 
 class Loop:
-    """The timed loop over one engine: step (+ gather) (+ render with HIP events around the launch)."""
+    """The timed loop over one engine.  Two forms of one iteration ("step" of the bench contract = one frame stepped AND one
+    frame rasterised for every env):
+      pair   tbx_step_synthetic ; [tbx_gather] ; tbx_render_device   -- two launches in stream order (what a policy loop does)
+      fused  tbx_render_step_synthetic ; [tbx_gather]                -- the frame of the current state and the step to the
+             next one in ONE launch where the rasteriser reads step-written records (Breakout RGB); random rollouts only
+    HIP events bracket every EVERY-th rasteriser (fused: rasteriser + step) launch."""
 
-    EVERY = 8       # one render launch in EVERY carries the two HIP events (a pair costs the stream 5-10 us: around every launch
+    EVERY = 8       # one launch in EVERY carries the two HIP events (a pair costs the stream 5-10 us: around every launch
                     # that was 1 % of the 65 536-env step and 5 % of the 8 192-env one)
 
-    def __init__(self, eng, hip, stream, start, channels, gather, render, n_steps):
+    def __init__(self, eng, hip, stream, start, channels, gather, render, n_steps, fused=False):
         self.eng, self.sp, self.start, self.C, self.gather, self.render = eng, stream.ptr, start, channels, gather, render
+        self.fused = bool(fused and render)
         self.pool = [(hip.Event(), hip.Event()) for _ in range((n_steps + self.EVERY - 1) // self.EVERY)] if render else []
         self.used = len(self.pool)              # nothing is timed until arm() is called
         self.calls = 0
@@ -506,19 +520,25 @@ class Loop:
 
     def full_step(self, t):
         e, sp = self.eng, self.sp
-        e.step_synthetic(ACTION_SEED, t, env_offset=self.start, auto_reset=True, stream=sp)
-        if self.gather:
-            e.gather(stream=sp)                # on the engine's communication stream: overlaps with the rasteriser below
+        if not self.fused:
+            e.step_synthetic(ACTION_SEED, t, env_offset=self.start, auto_reset=True, stream=sp)
+            if self.gather:
+                e.gather(stream=sp)            # on the engine's communication stream: overlaps with the rasteriser below
         if self.render:
             i = self.used
             timed = i < len(self.pool) and self.calls % self.EVERY == 0
             self.calls += 1
             if timed:
                 self.pool[i][0].record(sp)
-            e.render_device(0, self.C, stream=sp)
+            if self.fused:
+                e.render_step_synthetic(ACTION_SEED, t, channels=self.C, env_offset=self.start, auto_reset=True, stream=sp)
+            else:
+                e.render_device(0, self.C, stream=sp)
             if timed:
                 self.pool[i][1].record(sp)
                 self.used = i + 1
+        if self.fused and self.gather:
+            e.gather(stream=sp)                # the records of the step that rode in the launch above
 
     def step_only(self, t):
         self.eng.step_synthetic(ACTION_SEED, t, env_offset=self.start, auto_reset=True, stream=self.sp)
@@ -534,13 +554,13 @@ class Loop:
         self.pool = []
 
 
-def timed_arm(eng, hip, reg, stream, start, C, gather, render, pipeline, t, K, Wm, R):
-    """Warm-up + R regions of K steps with TBX_OPT_PIPELINE = pipeline.  Returns (summary, avg render launch ms, resolved
-    pipeline mode, next t)."""
+def timed_arm(eng, hip, reg, stream, start, C, gather, render, pipeline, t, K, Wm, R, fused=False):
+    """Warm-up + R regions of K steps with TBX_OPT_PIPELINE = pipeline (pair form) or the fused call.  Returns (summary, avg
+    rasteriser launch ms, resolved pipeline mode, next t)."""
     from toybox_amd import _abi
-    eng.set_option(_abi.OPT_PIPELINE, pipeline)
+    eng.set_option(_abi.OPT_PIPELINE, 0 if fused else pipeline)
     mode = eng.get_option(_abi.OPT_PIPELINE_ACTIVE)
-    loop = Loop(eng, hip, stream, start, C, gather, render, K * R)
+    loop = Loop(eng, hip, stream, start, C, gather, render, K * R, fused=fused)
     for _ in range(Wm):
         loop.full_step(t)
         t += 1
@@ -556,41 +576,68 @@ def timed_arm(eng, hip, reg, stream, start, C, gather, render, pipeline, t, K, W
 PIPELINE_NOTE = {0: "off: every call in stream order", 2: "the step runs beside the previous frame's rasteriser (internal step stream, "
                  "two sets of render records and step outputs)", 3: "the step runs beside the previous frame's rasteriser and consecutive "
                  "rasteriser launches alternate between two internal streams and two frame buffers"}
+FUSED_NOTE = ("tbx_render_step_synthetic: the rasteriser of frame t and the batch step to frame t+1 are ONE launch (the step's blocks "
+              "in front of the rasteriser's, other records buffer); random-action rollouts only -- `serialised` is the two-launch loop")
 
 
-def main():
-    args = parse()
-    if args.protocol == "reference":
-        return bench_reference_protocol(args)
-    if args.protocol == "agent":
-        return bench_agent_protocol(args)
-    if args.gpus > 1 and "RANK" not in os.environ:
-        return spawn_ranks(args)
+def make_communicator(eng, rank, world, width, gather_every, tag):
+    """tbx_gather_init over `world` ranks (id from rank 0 through the rendezvous file), K-step record ring if asked.  Returns the
+    `rccl` object of the JSON line; raises when no communicator over `world` ranks comes out of it."""
+    from toybox_amd import _abi
+    from toybox_amd.parallel import exchange_unique_id, forget_unique_id
+    if os.environ.get("TBX_BENCH_NO_RCCL"):
+        raise RuntimeError("disabled by TBX_BENCH_NO_RCCL")
+    eng.set_option(_abi.OPT_GATHER_EVERY, max(1, gather_every))
+    with quiet_stdout():
+        uid = exchange_unique_id(rank, world, eng.gather_unique_id, tag=tag)
+        eng.gather_init(world, rank, uid, records_per_rank=width)   # collective (ncclCommInitRank)
+    forget_unique_id(rank, tag=tag)
+    K = eng.gather_every()
+    rccl = {"nranks": eng.gather_nranks(), "records_per_rank": width, "gather_every": K,
+            "gather_bytes_per_collective": 8 * width * world * K, "gather_bytes_per_step": 8 * width * world, "lib": eng.gather_library()}
+    if rccl["nranks"] != world:
+        raise RuntimeError("the communicator spans %d ranks, not %d" % (rccl["nranks"], world))
+    return rccl
 
-    from toybox_amd.parallel import exchange_unique_id, forget_unique_id, shard_range, world_from_env
-    rank, world, local_rank = world_from_env()
-    if args.gpus > 1 and world != args.gpus:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-        return 2
-    if args.dry_run:
-        return dry_run(args, rank, world)
 
-    from toybox_amd import Engine, _abi, hip
-    if os.environ.get("TBX_BENCH_ONE_DEVICE"):     # diagnostic: every rank on device 0 (exercises the N > 1 flow on a 1-GPU box)
-        local_rank = 0
-    hip.set_device(local_rank)
+def verify_gather(eng, hip, rank, world, n_local, shard_sizes, start):
+    """One real exchange before anything is timed: K steps (K = ring depth) with the gather queued, then the gathered block is
+    read back -- this rank's slice must equal its own TBX_BUF_PACKED records, and in every OTHER rank's slice every env's
+    `lives` byte must be non-zero (fresh games: a slice that never arrived reads zero).  Returns True or raises."""
+    from toybox_amd import _abi
+    K = eng.gather_every()
+    for j in range(K):
+        eng.step_synthetic(ACTION_SEED, j, env_offset=start, auto_reset=True)
+        eng.gather()
+    got = eng.gather_host().reshape(world, K, -1)
+    mine = np.empty(n_local, np.uint64)
+    p, _ = eng.device_buffer(_abi.BUF_PACKED)
+    hip.synchronize()
+    hip.memcpy_dtoh(mine, p, 8 * n_local)
+    if not np.array_equal(got[rank, K - 1, :n_local], mine):
+        raise RuntimeError("rank %d: its own slice of the gathered records differs from TBX_BUF_PACKED" % rank)
+    for r in range(world):
+        lives = (got[r, :, :shard_sizes[r]] >> np.uint64(40)) & np.uint64(0xFF)
+        if not lives.all():
+            raise RuntimeError("rank %d: the slice of rank %d did not arrive (zero lives fields)" % (rank, r))
+    return True
 
-    game = args.game
-    if game == "mixed":
-        return bench_mixed(args, world, rank, local_rank)
-    if args.scaling == "strong":
-        start, end = shard_range(args.envs, world, rank)
+
+def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_extras):
+    """One reading of the metric on this rank: engine for its shard, communicator (N > 1 or --with-gather) with one verified
+    exchange, pre-roll, the timed arm (fused where the engine fuses, unless --loop pair), and with_extras the serialised
+    two-launch loop and the step-only loop beside it.  Returns a dict (rank 0 assembles the line) or an int return code."""
+    from toybox_amd import Engine, _abi
+    from toybox_amd.parallel import FileWorld, shard_range
+    if scaling == "strong":
+        spans = [shard_range(args.envs, world, r) for r in range(world)]
         n_total = args.envs
-        width = max(e - s for s, e in (shard_range(args.envs, world, r) for r in range(world)))
     else:
-        start, end = rank * args.envs, (rank + 1) * args.envs
+        spans = [(r * args.envs, (r + 1) * args.envs) for r in range(world)]
         n_total = world * args.envs
-        width = args.envs
+    start, end = spans[rank]
+    sizes = [e - s for s, e in spans]
+    width = max(sizes)
     n = end - start
     eng = Engine(game, n, device=local_rank)
     eng.seed(SEED_BASE + start)            # env i of this rank: seed 1234 + global index
@@ -598,28 +645,19 @@ def main():
     H, W, C = eng.height, eng.width, args.channels
     render = not args.no_render
     gather = world > 1 or args.with_gather
-    gather_note, rccl = None, None
-    fw = None
+    gather_note, rccl, fw = None, None, None
     if gather:
         try:
-            if os.environ.get("TBX_BENCH_NO_RCCL"):
-                raise RuntimeError("disabled by TBX_BENCH_NO_RCCL")
-            with quiet_stdout():
-                uid = exchange_unique_id(rank, world, eng.gather_unique_id)
-                eng.gather_init(world, rank, uid, records_per_rank=width)   # collective (ncclCommInitRank)
-            forget_unique_id(rank)
-            rccl = {"nranks": eng.gather_nranks(), "records_per_rank": width, "gather_bytes_per_step": 8 * width * world,
-                    "lib": eng.gather_library()}
-            if rccl["nranks"] != world:
-                raise RuntimeError("the communicator spans %d ranks, not %d" % (rccl["nranks"], world))
+            rccl = make_communicator(eng, rank, world, width, args.gather_every, tag)
+            rccl["verified"] = verify_gather(eng, hip, rank, world, n, sizes, start)
+            eng.new_game()                 # (the verification stepped K frames)
         except Exception as ex:
             msg = str(ex).splitlines()[0][:200] if str(ex) else repr(ex)
             if world > 1 and not args.allow_no_gather:
                 # the north star's 8-GPU number INCLUDES the collective: a run that cannot make it is a failed run
-                print("bench.py: rank %d: no RCCL communicator over %d ranks (%s); pass --allow-no-gather to measure the shards "
+                print("bench.py: rank %d: no verified RCCL gather over %d ranks (%s); pass --allow-no-gather to measure the shards "
                       "without the per-step gather" % (rank, world, msg), file=sys.stderr)
                 return 4
-            from toybox_amd.parallel import FileWorld
             gather_note = "RCCL communicator unavailable (%s): no per-step gather, file barrier between ranks" % msg
             print("bench.py: " + gather_note, file=sys.stderr)
             gather, rccl = False, None
@@ -637,47 +675,94 @@ def main():
     for _ in range(args.preroll):          # untimed: bring the batch to mid-game states (episodes end, auto-resets fire)
         eng.step_synthetic(ACTION_SEED, t, env_offset=start, auto_reset=True, stream=stream.ptr)
         t += 1
-    rep, render_ms, mode, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, args.pipeline, t, K, Wm, R)
-    launches_timed = timed_arm.launches_timed
-
-    extras = {}
+    fused = render and args.loop != "pair" and game == "breakout" and C >= 3 and eng.get_option(_abi.OPT_RECORDS_ACTIVE) == 1
+    rep, render_ms, mode, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, args.pipeline, t, K, Wm, R, fused=fused)
+    res = {"n": n, "n_total": n_total, "start": start, "H": H, "W": W, "C": C, "render": render, "gather": gather, "rccl": rccl,
+           "gather_note": gather_note, "rep": rep, "render_ms": render_ms, "mode": mode, "fused": fused,
+           "launches_timed": timed_arm.launches_timed, "extras": {}}
     frame_bytes = H * W * C if render else 0
-    if not args.no_extras and mode != 0:
-        # the same engine, the same loop, nothing overlapped: what a policy-driven loop (actions computed from the frame) gets
-        srep, s_ms, _, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, 0, t, K, Wm, R)
+    if with_extras and (fused or mode != 0):
+        # the same engine, two launches per frame in stream order: what a policy-driven loop (actions computed from the frame) gets
+        srep, s_ms, _, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, 0, t, K, Wm, R, fused=False)
         sms = srep["ms_per_step_median"]
-        extras["serialised"] = {"value": n_total / (sms * 1e-3), "unit": "env-steps/s", "ms_per_step": sms, "repeats": srep,
-                                "avg_launch_ms": s_ms, "roofline_frac": (n * frame_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s_ms else None,
-                                "note": "TBX_OPT_PIPELINE = 0: step and render in stream order"}
+        res["extras"]["serialised"] = {"value": n_total / (sms * 1e-3), "unit": "env-steps/s", "ms_per_step": sms, "repeats": srep,
+                                       "avg_launch_ms": s_ms,
+                                       "roofline_frac": (n * frame_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s_ms else None,
+                                       "note": "tbx_step_synthetic ; tbx_render_device in stream order (TBX_OPT_PIPELINE = 0): the rate of a loop whose "
+                                               "actions depend on the frame"}
         eng.set_option(_abi.OPT_PIPELINE, args.pipeline)
-    if render and not args.no_extras:
+    if render and with_extras:
         loop = Loop(eng, hip, stream, start, C, gather, False, 0)
         so_times, t = reg.run(loop.step_only, t, K, R)
         so = summarize(so_times, K)
-        extras["step_only"] = {"value": n_total / (so["ms_per_step_median"] * 1e-3), "unit": "env-steps/s",
-                               "ms_per_step": so["ms_per_step_median"], "repeats": so,
-                               "note": "same loop without the rasteriser; latency / issue bound, no roofline"}
-
+        res["extras"]["step_only"] = {"value": n_total / (so["ms_per_step_median"] * 1e-3), "unit": "env-steps/s",
+                                      "ms_per_step": so["ms_per_step_median"], "repeats": so,
+                                      "note": "same loop without the rasteriser; latency / issue bound, no roofline"}
     # sanity: the rollout really played (scores move, lives are lost, episodes end)
     eng.sync()
     score, lives, level, over = eng.scalars()
-    check = {"mean_score": float(score.mean()), "mean_lives": float(lives.mean()), "max_level": int(level.max()),
-             "frames_played": t}
-    if t >= 300 and not (check["mean_score"] > 0):
-        print("bench.py: the rollout did not play (mean score %.3f after %d frames)" % (check["mean_score"], t), file=sys.stderr)
-        return 3
-    bytes_per_step = 2 * S_GAME[game] + A_BYTES + O_BYTES + frame_bytes
+    res["check"] = {"mean_score": float(score.mean()), "mean_lives": float(lives.mean()), "max_level": int(level.max()), "frames_played": t}
     eng.close()
+    if t >= 300 and not (res["check"]["mean_score"] > 0):
+        print("bench.py: the rollout did not play (mean score %.3f after %d frames)" % (res["check"]["mean_score"], t), file=sys.stderr)
+        return 3
+    return res
+
+
+def main():
+    args = parse()
+    if args.protocol == "reference":
+        return bench_reference_protocol(args)
+    if args.protocol == "agent":
+        return bench_agent_protocol(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args)
+
+    from toybox_amd.parallel import world_from_env
+    rank, world, local_rank = world_from_env()
+    if args.gpus > 1 and world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        return 2
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    from toybox_amd import hip
+    if os.environ.get("TBX_BENCH_ONE_DEVICE"):     # diagnostic: every rank on device 0 (exercises the N > 1 flow on a 1-GPU box)
+        local_rank = 0
+    hip.set_device(local_rank)
+
+    game = args.game
+    if game == "mixed":
+        return bench_mixed(args, world, rank, local_rank)
+
+    # The metric names ONE batch -- "Breakout 64k-env batch, 1/2/4/8 MI355X" -- so `value` is the reading with --envs IN TOTAL,
+    # sharded contiguously over the ranks (env i -> GPU i / (N / G)); with N > 1 the other reading (--envs per GPU,
+    # `weak`) is measured in the same invocation and printed beside it, each with its own verified communicator.
+    main_res = run_reading(args, hip, game, rank, world, local_rank, args.scaling, "main", not args.no_extras)
+    if isinstance(main_res, int):
+        return main_res
+    other = None
+    if world > 1 and not args.no_extras:
+        other_scaling = "weak" if args.scaling == "strong" else "strong"
+        other = run_reading(args, hip, game, rank, world, local_rank, other_scaling, "other", False)
+        if isinstance(other, int):
+            return other
 
     if rank == 0:
+        r = main_res
+        n, n_total, H, W, C, render, gather = r["n"], r["n_total"], r["H"], r["W"], r["C"], r["render"], r["gather"]
+        rep, mode, fused = r["rep"], r["mode"], r["fused"]
+        frame_bytes = H * W * C if render else 0
+        bytes_per_step = 2 * S_GAME[game] + A_BYTES + O_BYTES + frame_bytes
         ms = rep["ms_per_step_median"]
+        K_ring = r["rccl"]["gather_every"] if r["rccl"] else 1
         out = {
             "metric": "env steps/sec (whole node), Breakout 64k-env batch" if game == "breakout" else "env steps/sec (whole node), %s" % game,
             "value": n_total / (ms * 1e-3),
             "unit": "env-steps/s",
             "n_gpus": world,
-            "steps": K,
-            "warmup": Wm,
+            "steps": args.steps,
+            "warmup": args.warmup,
             "ms_per_step": ms,
             "repeats": rep,
             "higher_is_better": True,
@@ -692,41 +777,53 @@ def main():
                             % (game, "step + %dx%dx%d uint8 frame render" % (H, W, C) if render else "step-only",
                                args.envs, "per GPU" if args.scaling == "weak" else "in total", args.preroll),
                 "envs_per_gpu": n, "envs_total": n_total, "frame_hwc": [H, W, C] if render else None,
-                "parallelism": ("env-sharded x%d, per-step RCCL all-gather of 8 B/env records behind the C-ABI (tbx_gather), "
-                                "overlapped with the rasteriser" % world) if gather else
-                               ("env-sharded x%d, no collective (%s)" % (world, gather_note)) if gather_note else "single GPU",
+                "parallelism": ("env-sharded x%d, RCCL all-gather of 8 B/env records behind the C-ABI (tbx_gather), %s, overlapped with the "
+                                "rasteriser" % (world, "one collective per step" if K_ring == 1 else "K-step record ring: one collective per %d steps" % K_ring))
+                               if gather else ("env-sharded x%d, no collective (%s)" % (world, r["gather_note"])) if r["gather_note"] else "single GPU",
                 "algorithmic_bytes_per_env_step": bytes_per_step,
             },
+            "loop": {"form": "fused" if fused else "pair", "what": FUSED_NOTE if fused else "tbx_step_synthetic ; tbx_render_device, two launches per frame"},
             "pipeline": {"option": args.pipeline, "resolved": mode, "what": PIPELINE_NOTE.get(mode),
-                         "applies_to": "loops whose actions do not depend on the frame (tbx_step_synthetic); see `serialised`"},
-            "rccl": rccl,
+                         "applies_to": "the two-launch loop form only; see `serialised`"},
+            "rccl": r["rccl"],
         }
         if render:
+            render_ms = r["render_ms"]
             achieved = n * frame_bytes / (render_ms * 1e-3) / 1e9    # GB/s, algorithmic frame bytes of one launch
             traffic, source = None, None
             tp = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tp):
                 try:
-                    rec = json.load(open(tp)).get("%s_render_%dch_%d" % (game, C, n))
+                    rec = json.load(open(tp)).get("%s_render_%dch_%d%s" % (game, C, n, "_fused" if fused else ""))
                     if rec:
                         traffic = rec["hbm_bytes_per_launch"]
                         source = "profiles/traffic.json (static: rocprofv3 PMC pass %s, not measured in this run)" % rec.get("source", "")
                 except Exception:
                     traffic = None
             out["roofline"] = {
-                "bound": "hbm", "kernel": "%s render (%d ch)" % (game, C),
+                "bound": "hbm", "kernel": "%s render (%d ch)%s" % (game, C, " + step, one launch" if fused else ""),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": source,
-                "algorithmic_bytes_per_launch": n * frame_bytes, "avg_launch_ms": render_ms, "launches_timed": launches_timed,
-                "timing": "HIP events on the caller's stream around every %dth render launch of the timed regions" % Loop.EVERY +
+                "algorithmic_bytes_per_launch": n * frame_bytes, "avg_launch_ms": render_ms, "launches_timed": r["launches_timed"],
+                "timing": "HIP events on the caller's stream around every %dth rasteriser launch of the timed regions" % Loop.EVERY +
                           ("" if mode != 3 else "; launches overlap in this mode, so this is the time from one launch's end to the "
                                                "next one's end (what a launch costs in steady state), not a kernel's own duration"),
             }
         else:
             out["roofline"] = None
-        out.update(extras)
-        out["check"] = check
-        if world == 1 and not args.no_extras and args.scaling == "weak" and n >= 16384:
+        out.update(r["extras"])
+        out["check"] = r["check"]
+        if other is not None:
+            oms = other["rep"]["ms_per_step_median"]
+            key = "weak" if args.scaling == "strong" else "strong"
+            out[key] = {"value": other["n_total"] / (oms * 1e-3), "unit": "env-steps/s", "ms_per_step": oms, "repeats": other["rep"],
+                        "envs_per_gpu": other["n"], "envs_total": other["n_total"], "rccl": other["rccl"],
+                        "loop": "fused" if other["fused"] else "pair",
+                        "note": "the other reading of the metric, measured in the same invocation with its own communicator"}
+            s_, w_ = (out, out[key]) if args.scaling == "strong" else (out[key], out)
+            # strong total over weak total = what N GPUs make of ONE batch against N x a full batch each: the share of linear scaling
+            out["share_of_linear"] = s_["value"] / w_["value"]
+        if world == 1 and not args.no_extras and n >= 16384:
             try:
                 out["scaling_strong"] = strong_share_probe(args, game, C, n, out["value"])
             except Exception as ex:
@@ -742,33 +839,35 @@ def main():
 
 
 def strong_share_probe(args, game, C, n_single, single_value):
-    """The other reading of the headline ("the 64k-env batch on 1/2/4/8 GPUs" = 65 536 envs IN TOTAL): what ONE GPU of an 8-GPU
-    strong-scaling run would do -- n/8 envs with the per-step gather on (1-rank communicator: launch + stream-hop cost of
-    the collective, no wire time) -- pipelined and serialised.  8 x this value over the single-GPU value is the scaling
-    efficiency the per-step fixed costs allow at that shard size."""
+    """What ONE GPU of an 8-GPU run of the SAME batch would do: n/8 envs with the record gather on (1-rank communicator: launch
+    and stream-hop cost of the collective, no wire time).  share_of_linear = that rate over the single-GPU rate of the whole
+    batch (a fraction: 1.0 = eight GPUs are eight times one).  Measured for the loop form and ring depth of the main arm and,
+    beside it, for the two-launch loop with a collective every step."""
     from toybox_amd import Engine, _abi, hip
     n = n_single // 8
-    eng = Engine(game, n, device=0)
-    eng.seed(SEED_BASE)
-    eng.new_game()
-    with quiet_stdout():
-        eng.gather_init(1, 0, eng.gather_unique_id())
-    st = hip.Stream()
-    for t in range(args.preroll):
-        eng.step_synthetic(ACTION_SEED, t, auto_reset=True, stream=st.ptr)
-    reg = Region(hip.synchronize, lambda: eng.gather_reduce_max(0.0), lambda v: eng.gather_reduce_max(v))
-    K = max(args.steps, 200)
-    t = args.preroll
     res = {"envs_per_gpu": n, "gpus": 8, "unit": "env-steps/s per GPU",
-           "note": "1/8 of the batch on one GPU with the per-step record gather queued (1-rank RCCL communicator)"}
-    for key, pl in (("pipelined", args.pipeline), ("serialised", 0)):
-        rep, rms, mode, t = timed_arm(eng, hip, reg, st, 0, C, True, True, pl, t, K, 20, 5)
+           "note": "1/8 of the batch on one GPU with the record gather queued (1-rank RCCL communicator)"}
+    K = max(args.steps, 200)
+    arms = (("main", args.gather_every, args.loop != "pair"), ("pair_gather_every_step", 1, False))
+    for key, every, want_fused in arms:
+        eng = Engine(game, n, device=0)
+        eng.seed(SEED_BASE)
+        eng.new_game()
+        eng.set_option(_abi.OPT_GATHER_EVERY, max(1, every))
+        with quiet_stdout():
+            eng.gather_init(1, 0, eng.gather_unique_id())
+        st = hip.Stream()
+        for t in range(args.preroll):
+            eng.step_synthetic(ACTION_SEED, t, auto_reset=True, stream=st.ptr)
+        reg = Region(hip.synchronize, lambda: eng.gather_reduce_max(0.0), lambda v: eng.gather_reduce_max(v))
+        fused = want_fused and game == "breakout" and C >= 3 and eng.get_option(_abi.OPT_RECORDS_ACTIVE) == 1
+        rep, rms, mode, _ = timed_arm(eng, hip, reg, st, 0, C, True, True, args.pipeline, args.preroll, K, 20, 5, fused=fused)
         v = n / (rep["ms_per_step_median"] * 1e-3)
-        res[key] = {"value": v, "ms_per_step": rep["ms_per_step_median"], "repeats": rep, "pipeline_resolved": mode,
-                    "avg_launch_ms": rms, "share_of_linear": 8 * v / single_value}
-    res["value"] = res["pipelined"]["value"]
-    res["share_of_linear"] = res["pipelined"]["share_of_linear"]
-    eng.close()
+        res[key] = {"value": v, "ms_per_step": rep["ms_per_step_median"], "repeats": rep, "loop": "fused" if fused else "pair",
+                    "gather_every": eng.gather_every(), "pipeline_resolved": mode, "avg_launch_ms": rms, "share_of_linear": v / single_value}
+        eng.close()
+    res["value"] = res["main"]["value"]
+    res["share_of_linear"] = res["main"]["share_of_linear"]
     return res
 
 

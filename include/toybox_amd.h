@@ -411,6 +411,18 @@ int tbx_get_scalars(tbx_engine* engine, int32_t* score_host, int32_t* lives_host
 int tbx_render(tbx_engine* engine, uint8_t* out_host, int channels);
 /* out_dev == NULL renders into the engine-owned TBX_BUF_FRAME buffer. */
 int tbx_render_device(tbx_engine* engine, uint8_t* out_dev, int channels, void* stream);
+/* The random-rollout loop body as ONE call: rasterise every env's CURRENT state into out_dev (NULL: TBX_BUF_FRAME) and step
+ * every env one frame with device-generated actions (the rule of tbx_step_synthetic) -- i.e. tbx_render_device followed by
+ * tbx_step_synthetic, asynchronous on `stream`, same results bit for bit: the frame shows the state BEFORE the step, the
+ * TBX_BUF_* outputs and the state are the step's.  Where the rasteriser reads step-written render records (Breakout with the
+ * canonical wall, RGB / RGBA) both halves are ONE launch: the step's few blocks ride in front of the rasteriser's, write the
+ * other records buffer and hide in the launch's ramp-up, so a loop of these calls runs like a render-only loop -- no kernel
+ * boundary per frame, no rasteriser that starts in lockstep behind a short kernel (8 192 envs + gather, the per-GPU share of
+ * the strong-scaled headline batch: see DESIGN.md section 6).  Only a loop whose actions do not depend on the frame can use
+ * it (the north star's random-action rollouts; replaces the loop body of test/benchmark.py:50-56 plus the frame);
+ * a policy-driven loop calls tbx_step_device and tbx_render_device.  Everywhere else it is the two launches in stream order. */
+int tbx_render_step_synthetic(tbx_engine* engine, uint8_t* out_dev, int channels, uint64_t action_seed, uint64_t t,
+                              uint64_t env_offset, uint32_t flags, void* stream);
 /* Rasterise one env (host pointer, synchronous). */
 int tbx_render_env(tbx_engine* engine, int env, uint8_t* out_host, int channels);
 
@@ -527,18 +539,24 @@ int tbx_gather_init(tbx_engine* engine, int nranks, int rank, int records_per_ra
  * librccl that was loaded -- so that a benchmark line can say which collective really ran over how many ranks. */
 int tbx_gather_nranks(tbx_engine* engine);
 const char* tbx_gather_library(tbx_engine* engine);
-/* Queue the all-gather of the last step's records into out_dev (NULL: the engine-owned TBX_BUF_GATHERED).  Asynchronous: it
+/* K of the record ring this communicator was initialised with (TBX_OPT_GATHER_EVERY at tbx_gather_init; 1 = a collective per
+ * step), and how many steps' records sit in the ring waiting for the next collective (0 right after one went out). */
+int tbx_gather_every(tbx_engine* engine);
+int tbx_gather_fill(tbx_engine* engine);
+/* Queue the all-gather of the last step's records into out_dev (NULL: the engine-owned TBX_BUF_GATHERED) -- with a K-step ring
+ * (TBX_OPT_GATHER_EVERY) only every K-th call queues anything, then for the last K steps at once.  Asynchronous: it
  * is ordered after everything queued through this handle so far, runs on an engine-owned communication stream, and the next
  * step that rewrites those records is ordered after it -- what the caller queues in between (the rasteriser) overlaps with it.  `stream` is not used to run it; make a
  * stream wait for the result with tbx_gather_wait. */
 int tbx_gather(tbx_engine* engine, uint64_t* out_dev, void* stream);
 /* Make `stream` wait for the last queued gather (device-side consumers of the gathered records). */
 int tbx_gather_wait(tbx_engine* engine, void* stream);
-/* Block until the last queued gather has finished and copy TBX_BUF_GATHERED to the host: uint64[nranks * records_per_rank]. */
+/* Block until the last queued gather has finished and copy TBX_BUF_GATHERED to the host: uint64[nranks * K * records_per_rank]
+ * (K = tbx_gather_every, 1 by default). */
 int tbx_gather_host(tbx_engine* engine, uint64_t* out_host);
 /* Blocking max-reduction of one double over all ranks (barrier + "slowest rank" timing of bench.py). */
 int tbx_gather_reduce_max(tbx_engine* engine, double* inout_host);
-#define TBX_BUF_GATHERED 12   /* uint64[nranks][records_per_rank] result of tbx_gather(out_dev = NULL) */
+#define TBX_BUF_GATHERED 12   /* uint64[nranks][K][records_per_rank] result of tbx_gather(out_dev = NULL) */
 
 /* Address of an engine-owned device buffer (TBX_BUF_*).  In pipelined mode (TBX_OPT_PIPELINE) the step outputs and the
  * engine-owned frame buffer each alternate between two addresses: ask again after every step / render. */
@@ -581,7 +599,17 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
 #define TBX_OPT_AGENT_GENERIC 3
 /* 1 (default): tbx_step1 on a one-env engine talks to the resident step kernel; 0: single-env launch + read-back */
 #define TBX_OPT_RESIDENT_STEP 4
-#define TBX_OPT_COUNT         5
+/* K-step record ring of the multi-GPU gather, 1..64 (default 1 = one collective per step).  Read by tbx_gather_init (like
+ * TBX_OPT_AGENT_GENERIC by tbx_agent_init; a later change takes effect at the next tbx_gather_init).  SURVEY.md 8e: "one
+ * ncclAllGather per step (or per K steps)" -- and what the reference's learners consume is a K-step rollout anyway: the A2C
+ * runner collects nsteps = 5 steps of (obs, rewards, dones) per update, PPO2 128 (baselines/baselines/a2c/runner.py:16,
+ * a2c/a2c.py:87, ppo2/ppo2.py:103).  With K > 1 the step kernels write their 8-byte records straight into slot j of a ring
+ * [K][records_per_rank] (j = steps since the last collective; TBX_BUF_PACKED names the slot of the most recent step), tbx_gather
+ * only counts -- no stream operation at all -- and every K-th call sends the whole ring with ONE ncclAllGather of
+ * K * records_per_rank records; the following K steps fill a second ring meanwhile.  Gathered layout
+ * [nranks][K][records_per_rank] (TBX_BUF_GATHERED, tbx_gather_host).  The pipelined mode is off while a ring is in force. */
+#define TBX_OPT_GATHER_EVERY  5
+#define TBX_OPT_COUNT         6
 /* read-only (tbx_get_option): what TBX_OPT_PIPELINE resolves to on this engine right now -- 0, 2 or 3 */
 #define TBX_OPT_PIPELINE_ACTIVE 100
 /* read-only: 1 while the rasteriser reads step-written render records (Breakout with the canonical wall, SpaceInvaders with

@@ -41,6 +41,11 @@ struct tbx_engine {
     size_t gshm_len;
     char gshm_name[TBX_GATHER_ID_BYTES];
     uint64_t gather_calls[2];
+    /* TBX_OPT_GATHER_EVERY = K > 1: batch steps write their records into slot `gather_fill` of ring[ring_par] ([K][width]),
+     * tbx_gather only counts and the K-th call exchanges the whole ring */
+    int gather_every, gather_fill, ring_par, gather_advance;
+    uint64_t* ring[2];
+    uint64_t* packed_own;
     /* Monitor / EpisodicLifeEnv state and this step's episode records */
     int32_t *ep_ret, *ep_len, *ep_index, *prev_lives, *ep_len_out;
     uint8_t* ep_done;
@@ -94,8 +99,8 @@ int tbx_destroy(tbx_engine* e)
 {
     if (!e) return TBX_OK;
     free(e->cfg); free(e->states); free(e->sim); free(e->prev); free(e->reward); free(e->lives);
+    gather_close(e);                       /* (puts e->packed back onto the engine's own array) */
     free(e->score); free(e->done); free(e->packed); free(e->frame); free(e->one_frame);
-    gather_close(e);
     agent_free(e);
     free(e);
     return TBX_OK;
@@ -124,6 +129,8 @@ int tbx_create(int game, int n, int device, const void* cfg, size_t cfg_size, tb
     const char* th = getenv("TBX_ORACLE_THREADS");
     e->threads = th ? atoi(th) : 1;
     e->opt[TBX_OPT_RESIDENT_STEP] = 1;
+    e->opt[TBX_OPT_GATHER_EVERY] = 1;
+    e->gather_every = 1;
     if (cfg) memcpy(e->cfg, cfg, csz);
     else switch (game) {
         case TBX_GAME_BREAKOUT: orc_breakout_default_config((tbx_breakout_config_t*)e->cfg); break;
@@ -187,6 +194,10 @@ int tbx_new_game(tbx_engine* e, const uint8_t* mask)
 
 static void pack_outputs(tbx_engine* e)
 {
+    if (e->gather_advance) {               /* ring mode: the first step after a tbx_gather opens the next slot */
+        e->gather_advance = 0;
+        e->packed = e->ring[e->ring_par] + (size_t)e->gather_fill * (size_t)e->gather_width;
+    }
     for (int i = 0; i < e->n; i++) {
         int32_t lv = e->lives[i];
         uint32_t l8 = lv < 0 ? 0u : lv > 255 ? 255u : (uint32_t)lv;
@@ -334,6 +345,14 @@ int tbx_render_device(tbx_engine* e, uint8_t* out, int channels, void* stream)
     }
     orc_render_batch(e->game, e->cfg, e->states, e->n, out, channels, e->threads);
     return TBX_OK;
+}
+
+/* the random-rollout loop body as one call: the picture of the current state, then one frame with device-rule actions */
+int tbx_render_step_synthetic(tbx_engine* e, uint8_t* out, int channels, uint64_t seed, uint64_t t, uint64_t env_offset, uint32_t flags, void* stream)
+{
+    int rc = tbx_render_device(e, out, channels, stream);
+    if (rc) return rc;
+    return tbx_step_synthetic(e, seed, t, env_offset, flags, stream);
 }
 
 int tbx_render(tbx_engine* e, uint8_t* out, int channels)
@@ -562,7 +581,7 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
         break;
     case TBX_BUF_GATHERED:
         if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
-        p = e->gathered; b = (size_t)e->gather_ranks * e->gather_width * 8;
+        p = e->gathered; b = (size_t)e->gather_ranks * e->gather_every * e->gather_width * 8;
         break;
     default: return fail(e, TBX_E_INVALID, "unknown buffer id");
     }
@@ -599,6 +618,12 @@ static void gather_close(tbx_engine* e)
     if (e->gshm) munmap(e->gshm, e->gshm_len);
     if (e->gather_on && e->gather_rank == 0 && e->gshm_name[0]) shm_unlink(e->gshm_name);
     free(e->gathered);
+    if (e->ring[0]) {
+        e->packed = e->packed_own;
+        free(e->ring[0]); free(e->ring[1]);
+        e->ring[0] = e->ring[1] = NULL;
+    }
+    e->gather_every = 1; e->gather_fill = 0; e->ring_par = 0; e->gather_advance = 0;
     e->gshm = NULL; e->gathered = NULL; e->gather_on = 0;
 }
 
@@ -612,9 +637,17 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
     gather_close(e);
     e->gather_ranks = nranks; e->gather_rank = rank; e->gather_width = records_per_rank;
     e->gather_calls[0] = e->gather_calls[1] = 0;
-    e->gathered = (uint64_t*)calloc((size_t)nranks * records_per_rank, 8);
+    const int K = e->opt[TBX_OPT_GATHER_EVERY] > 1 ? e->opt[TBX_OPT_GATHER_EVERY] : 1;
+    e->gather_every = K;
+    e->gathered = (uint64_t*)calloc((size_t)nranks * K * records_per_rank, 8);
+    if (K > 1) {
+        for (int k = 0; k < 2; k++) e->ring[k] = (uint64_t*)calloc((size_t)K * records_per_rank, 8);
+        memcpy(e->ring[0], e->packed, (size_t)e->n * 8);   /* TBX_BUF_PACKED keeps reading what it read */
+        e->packed_own = e->packed;
+        e->packed = e->ring[0];
+    }
     snprintf(e->gshm_name, sizeof e->gshm_name, "%s", (const char*)id);
-    e->gshm_len = gshm_bytes(nranks, records_per_rank);
+    e->gshm_len = gshm_bytes(nranks, K * records_per_rank);
     if (nranks > 1) {
         if (e->gshm_name[0] != '/') return fail(e, TBX_E_INVALID, "gather: not an id made by tbx_gather_unique_id");
         int fd = shm_open(e->gshm_name, O_CREAT | O_RDWR, 0600);
@@ -654,8 +687,20 @@ int tbx_gather(tbx_engine* e, uint64_t* out, void* stream)
     (void)stream;
     if (!e) return TBX_E_INVALID;
     if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
-    const size_t slot = (size_t)e->gather_width * 8;
     uint64_t* dst = out ? out : e->gathered;
+    if (e->gather_every > 1) {
+        /* ring mode: K - 1 of K calls only count; the K-th exchanges the ring [K][width] as one slot */
+        e->gather_advance = 1;
+        if (++e->gather_fill < e->gather_every) return TBX_OK;
+        const size_t ring_bytes = (size_t)e->gather_every * e->gather_width * 8;
+        const uint64_t* ring = e->ring[e->ring_par];
+        if (e->gather_ranks == 1) memcpy(dst, ring, ring_bytes);
+        else gshm_exchange(e, 0, (char*)e->gshm + sizeof(gshm_head_t), ring_bytes, ring, dst);
+        e->gather_fill = 0;
+        e->ring_par ^= 1;
+        return TBX_OK;
+    }
+    const size_t slot = (size_t)e->gather_width * 8;
     uint64_t* mine = (uint64_t*)calloc(1, slot);
     memcpy(mine, e->packed, (size_t)e->n * 8);
     if (e->gather_ranks == 1) memcpy(dst, mine, slot);
@@ -677,7 +722,7 @@ int tbx_gather_host(tbx_engine* e, uint64_t* out)
     if (!e) return TBX_E_INVALID;
     if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
     if (!out) return fail(e, TBX_E_INVALID, "output pointer is NULL");
-    memcpy(out, e->gathered, (size_t)e->gather_ranks * e->gather_width * 8);
+    memcpy(out, e->gathered, (size_t)e->gather_ranks * e->gather_every * e->gather_width * 8);
     return TBX_OK;
 }
 
@@ -688,7 +733,7 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout)
     if (!inout) return fail(e, TBX_E_INVALID, "value pointer is NULL");
     if (e->gather_ranks > 1) {
         double all[64];
-        char* base = (char*)e->gshm + sizeof(gshm_head_t) + 2 * (size_t)e->gather_ranks * e->gather_width * 8;
+        char* base = (char*)e->gshm + sizeof(gshm_head_t) + 2 * (size_t)e->gather_ranks * e->gather_every * e->gather_width * 8;
         gshm_exchange(e, 1, base, sizeof(double), inout, all);
         for (int r = 0; r < e->gather_ranks; r++) if (all[r] > *inout) *inout = all[r];
     }
@@ -698,10 +743,10 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout)
 /* launch-time choices of the device engine: stored and reported, without effect on a scalar CPU restatement */
 int tbx_set_option(tbx_engine* e, int option, int value)
 {
-    static const int hi[TBX_OPT_COUNT] = {3, 2, 64, 1, 1};
+    static const int hi[TBX_OPT_COUNT] = {3, 2, 64, 1, 1, 64};
     if (!e) return TBX_E_INVALID;
     if (option < 0 || option >= TBX_OPT_COUNT) return fail(e, TBX_E_INVALID, "unknown option");
-    if (value < 0 || value > hi[option]) return fail(e, TBX_E_INVALID, "option value out of range");
+    if (value < (option == TBX_OPT_GATHER_EVERY ? 1 : 0) || value > hi[option]) return fail(e, TBX_E_INVALID, "option value out of range");
     e->opt[option] = value;
     return TBX_OK;
 }
@@ -723,6 +768,20 @@ int tbx_gather_nranks(tbx_engine* e)
 }
 
 const char* tbx_gather_library(tbx_engine* e) { (void)e; return "oracle: POSIX shared memory"; }
+
+int tbx_gather_every(tbx_engine* e)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
+    return e->gather_every;
+}
+
+int tbx_gather_fill(tbx_engine* e)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->gather_on) return fail(e, TBX_E_INVALID, "tbx_gather_init has not been called");
+    return e->gather_fill;
+}
 
 int tbx_sync(tbx_engine* e)
 {

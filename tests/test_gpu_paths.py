@@ -412,26 +412,90 @@ def test_gather_one_rank_equals_local_records(lib):
     e.close()
 
 
+@pytest.mark.parametrize("game,K", [("breakout", 4), ("space_invaders", 3), ("amidar", 5), ("gridworld", 2)])
+def test_gather_ring_sends_k_steps_with_one_collective(game, K, lib, oracle_lib):
+    """TBX_OPT_GATHER_EVERY = K ("per step or per K steps"): the step kernels write their records into slot j of a
+    ring [K][width], tbx_gather only counts, the K-th call sends the ring with ONE collective; gathered layout [1][K][width],
+    slot j = the records of the j-th step since the last collective.  TBX_BUF_PACKED names the slot of the most recent step;
+    steps queued behind a collective (the other ring fills meanwhile) do not change what it sends; a step without a tbx_gather
+    rewrites its slot; leaving ring mode (a new tbx_gather_init with K = 1) hands the records back to the engine's own array."""
+    from toybox_amd.parallel import pack_records
+    n, width = 333, 340
+    e, ref = Engine(game, n, lib=lib), Engine(game, n, lib=oracle_lib)
+    for x in (e, ref):
+        x.seed(21)
+        x.new_game()
+    e.set_option(_abi.OPT_GATHER_EVERY, K)
+    with pytest.raises(ToyboxAmdError):
+        e.set_option(_abi.OPT_GATHER_EVERY, 0)
+    e.gather_init(1, 0, e.gather_unique_id(), records_per_rank=width)
+    assert e.gather_every() == K and e.gather_fill() == 0
+    assert e.device_buffer(_abi.BUF_GATHERED)[1] == 8 * K * width
+    assert e.get_option(_abi.OPT_PIPELINE_ACTIVE) == 0
+    window, slots, t = [], set(), 0
+    for rnd in range(7):
+        for j in range(K):
+            if rnd == 3 and j == 1:                         # a step nobody gathers: the next one takes its slot
+                e.step_synthetic(1337, t, auto_reset=True)
+                ref.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
+                t += 1
+            e.step_synthetic(1337, t, auto_reset=True)
+            r, d, l, _ = ref.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
+            t += 1
+            window.append(pack_records(r, d, l))
+            slots.add(e.device_buffer(_abi.BUF_PACKED)[0])
+            e.gather()
+            assert e.gather_fill() == (j + 1) % K
+        if rnd % 2:                                         # two steps of the NEXT ring queued before the result is read
+            for _ in range(2):
+                e.step_synthetic(1337, t, auto_reset=True)
+                ref.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
+                t += 1
+        got = e.gather_host()
+        assert got.shape == (1, K, width)
+        for j in range(K):
+            assert np.array_equal(got[0, j, :n], window[j]), (rnd, j)
+            assert not got[0, j, n:].any()
+        window = []
+    assert len(slots) == 2 * K                              # two rings of K slots
+    e.sync()
+    for i in range(0, n, 37):
+        assert bytes(e.get_state(i)) == bytes(ref.get_state(i))
+    e.set_option(_abi.OPT_GATHER_EVERY, 1)
+    e.gather_init(1, 0, e.gather_unique_id(), records_per_rank=width)
+    assert e.gather_every() == 1 and e.device_buffer(_abi.BUF_PACKED)[0] not in slots
+    r, d, l, _ = e.step(synthetic_actions(game, n, t), auto_reset=True)
+    e.gather()
+    got = e.gather_host()
+    assert got.shape == (1, width) and np.array_equal(got[0, :n], pack_records(r, d, l))
+    e.close()
+
+
 @pytest.mark.gpu
-def test_gather_overlaps_with_render_and_keeps_parity(hip_lib, oracle_lib):
+@pytest.mark.parametrize("K", [1, 4])
+def test_gather_overlaps_with_render_and_keeps_parity(K, hip_lib, oracle_lib):
     """The bench loop shape: step -> gather -> render on the caller's stream, 8 192 envs (the 8-GPU strong-scaling share):
     gathered records and final states equal the oracle's."""
     from toybox_amd import hip
     from toybox_amd.parallel import unpack_records
     n = 8192
     g, o = _pair("breakout", n, hip_lib, oracle_lib)
+    g.set_option(_abi.OPT_GATHER_EVERY, K)
     g.gather_init(1, 0, g.gather_unique_id())
     st = hip.Stream()
-    tot = np.zeros(n, np.int64)
-    want = np.zeros(n, np.int64)
+    last = []
     for t in range(300):
         g.step_synthetic(1337, t, auto_reset=True, stream=st.ptr)
         g.gather(stream=st.ptr)
         g.render_device(0, 3, stream=st.ptr)
         r, d, l, _ = o.step(synthetic_actions("breakout", n, t), auto_reset=True)
-        if t % 7 == 0 or t > 290:
-            rr, dd, ll = unpack_records(g.gather_host()[0])
-            assert np.array_equal(rr, r) and np.array_equal(dd, d) and np.array_equal(ll, np.clip(l, 0, 255)), t
+        last = (last + [(r, d, l)])[-K:]
+        if (t + 1) % K == 0 and (t % 7 < K or t > 290):     # (K > 1: a collective has just gone out, with the last K steps)
+            got = g.gather_host()[0].reshape(K, n)
+            for j in range(K):
+                rr, dd, ll = unpack_records(got[j])
+                r, d, l = last[j]
+                assert np.array_equal(rr, r) and np.array_equal(dd, d) and np.array_equal(ll, np.clip(l, 0, 255)), (t, j)
     st.synchronize()
     _same_states(g, o, range(0, n, 211), "end")
     st.close()
@@ -680,6 +744,91 @@ def test_pipelined_render_of_a_rewritten_state_is_not_overtaken_by_the_next_step
     hip.free(hold)
     g.sync()
     _same_states(g, o, sample, "end")
+
+
+@pytest.mark.parametrize("game", GAMES)
+def test_render_step_synthetic_call_contract(game, lib):
+    """one call == tbx_render_device + tbx_step_synthetic on either library (host-visible results only: small batch)"""
+    n = 9
+    a, b = Engine(game, n, lib=lib), Engine(game, n, lib=lib)
+    for e in (a, b):
+        e.seed(4)
+        e.new_game()
+    for t in range(40):
+        a.render_step_synthetic(1337, t, channels=3, auto_reset=True)
+        fa = a.device_buffer(_abi.BUF_FRAME)
+        b.render_device(0, 3)
+        b.step_synthetic(1337, t, auto_reset=True)
+        assert fa[1] == b.device_buffer(_abi.BUF_FRAME)[1]
+    a.sync(); b.sync()
+    for i in range(n):
+        assert bytes(a.get_state(i)) == bytes(b.get_state(i))
+    with pytest.raises(ToyboxAmdError):
+        a.render_step_synthetic(1337, 0, channels=2)
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game,n,channels", [("breakout", 20000, 3), ("breakout", 8192, 4), ("breakout", 300, 3), ("breakout", 5000, 1),
+                                             ("space_invaders", 3000, 3), ("amidar", 2000, 3), ("gridworld", 1000, 3)])
+def test_render_step_synthetic_equals_render_then_step(game, n, channels, hip_lib, oracle_lib):
+    """tbx_render_step_synthetic = tbx_render_device followed by tbx_step_synthetic, bit for bit: the frame shows the state
+    before the step, outputs and state are the step's.  For Breakout RGB / RGBA that is ONE launch (brk_render_step_kernel_w5:
+    step blocks in front of the rasteriser's, the other records buffer); everywhere else two launches.  Calls of other kinds
+    in between (state writes that invalidate the records, new games, host steps, a K-step gather ring, plain step / render
+    pairs, the pipelined mode switched on) must not disturb it.  Frames are copied device-side right behind each call."""
+    from toybox_amd import hip
+    from toybox_amd.parallel import pack_records
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=5)
+    H, W = g.height, g.width
+    fb = H * W * channels
+    sample = sorted({0, 1, 255, 256, n // 2, n - 1} & set(range(n)))
+    s = hip.Stream()
+    T = 90
+    hold = hip.malloc(fb * len(sample) * T)
+    want, packed = [], np.empty(n, np.uint64)
+    g.set_option(_abi.OPT_GATHER_EVERY, 3)
+    g.gather_init(1, 0, g.gather_unique_id())
+    for t in range(T):
+        if t == 20:
+            st = o.get_state(3)
+            g.set_state(0, st); o.set_state(0, st)           # records stale: the fused launch rebuilds them first
+        if t == 35:
+            m = (np.arange(n) % 3 == 0).astype(np.uint8)
+            g.new_game(m); o.new_game(m)
+        if t == 50:
+            a = synthetic_actions(game, n, t, seed=9)
+            for x, y in zip(g.step(a, auto_reset=True), o.step(a, auto_reset=True)):
+                assert np.array_equal(x, y)
+        if t == 60:
+            g.set_option(_abi.OPT_PIPELINE, 3)               # (no effect while a record ring is in force, and none on this call)
+        if t in (65, 66):                                    # the unfused pair in between
+            g.step_synthetic(77, t, auto_reset=True, stream=s.ptr)
+            g.render_device(0, channels, stream=s.ptr)
+            o.step(synthetic_actions(game, n, t, seed=77), auto_reset=True)
+        g.render_step_synthetic(1337, t, channels=channels, auto_reset=True, stream=s.ptr)
+        g.gather(stream=s.ptr)
+        f, _ = g.device_buffer(_abi.BUF_FRAME)
+        for k, i in enumerate(sample):
+            hip.memcpy_dtod_async(hold + fb * (len(sample) * t + k), f + fb * i, fb, s)
+        want.append([o.render_env(i, channels) for i in sample])
+        ro = o.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
+        if t % 11 == 0:
+            s.synchronize()
+            p, _ = g.device_buffer(_abi.BUF_PACKED)
+            hip.memcpy_dtoh(packed, p, 8 * n)
+            assert np.array_equal(packed, pack_records(ro[0], ro[1], ro[2])), t
+    s.synchronize()
+    one = np.empty((H, W, channels), np.uint8)
+    for t in range(T):
+        for k, i in enumerate(sample):
+            hip.memcpy_dtoh(one, hold + fb * (len(sample) * t + k), fb)
+            assert np.array_equal(one, want[t][k]), (game, t, i)
+    hip.free(hold)
+    g.sync()
+    _same_states(g, o, sample + list(range(0, n, max(1, n // 50))), "end")
+    for x, y in zip(g.scalars(), o.scalars()):
+        assert np.array_equal(x, y)
 
 
 @pytest.mark.gpu

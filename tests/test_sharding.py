@@ -132,6 +132,58 @@ def test_multi_rank_gather_through_the_abi_equals_single_process(game, world, or
     assert not os.listdir(str(tmp_path)) or all(not f.startswith("tbx_rccl_id_") for f in os.listdir(str(tmp_path))), "id file left behind"
 
 
+RING_WORKER = r"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from toybox_amd import Engine, _abi
+from toybox_amd.parallel import ShardedBatch, world_from_env
+lib = ctypes.CDLL(os.path.join({root!r}, "oracle", "liboracle.so")); _abi.bind(lib)
+rank, world, _ = world_from_env()
+sb = ShardedBatch(lambda n: Engine({game!r}, n, lib=lib), {n}, rank=rank, world=world, gather_every={K})
+assert sb.engine.gather_every() == {K}
+tot = np.zeros({n}, np.int64); dn = np.zeros({n}, np.int64); calls = 0
+for t in range({steps}):
+    sb.step_synthetic(1337, t)
+    if (t + 1) % {K} == 0:                  # the collective went out with this step: K steps' records, oldest first
+        for r, d, l in sb.gathered():
+            tot += r; dn += d
+        calls += 1
+assert calls == {steps} // {K}
+if rank == 0:
+    np.save({out!r}, np.stack([tot, dn, l.astype(np.int64)]))
+sb.close()
+"""
+
+
+@pytest.mark.parametrize("game,world,K", [("breakout", 2, 4), ("space_invaders", 3, 5)])
+def test_multi_rank_ring_gather_equals_single_process(game, world, K, oracle_lib, tmp_path):
+    """The K-step record ring (TBX_OPT_GATHER_EVERY) over world > 1: every rank's K x width ring travels with ONE collective
+    per K steps; summed over the run the records equal a single-process run over the whole batch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from support import synthetic_actions
+    from toybox_amd import Engine
+    from toybox_amd.parallel import ShardedBatch
+    n, steps = 37, 40 * K
+    out = str(tmp_path / "r0.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(RING_WORKER.format(root=ROOT, n=n, steps=steps, out=out, game=game, K=K))
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="2", TBX_RDZV_DIR=str(tmp_path))
+    env.pop("TBX_RDZV_KEY", None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = np.load(out)
+    sb = ShardedBatch(lambda k: Engine(game, k, lib=oracle_lib), n)
+    tot = np.zeros(n, np.int64)
+    dn = np.zeros(n, np.int64)
+    for t in range(steps):
+        r, d, l = sb.step_host(synthetic_actions(game, n, t, seed=1337))
+        tot += r
+        dn += d
+    assert np.array_equal(got[0], tot) and np.array_equal(got[1], dn) and np.array_equal(got[2], l.astype(np.int64))
+
+
 def test_exchange_unique_id_times_out(tmp_path):
     from toybox_amd.parallel import exchange_unique_id
     with pytest.raises(TimeoutError):

@@ -24,7 +24,7 @@ BUF_AGENT_EP_DONE, BUF_AGENT_EP_RETURN, BUF_AGENT_EP_LENGTH = 9, 10, 11
 BUF_GATHERED = 12
 GATHER_ID_BYTES = 128
 # engine options (tbx_set_option)
-OPT_PIPELINE, OPT_STEP_FORM, OPT_RENDER_SPLIT, OPT_AGENT_GENERIC, OPT_RESIDENT_STEP = 0, 1, 2, 3, 4
+OPT_PIPELINE, OPT_STEP_FORM, OPT_RENDER_SPLIT, OPT_AGENT_GENERIC, OPT_RESIDENT_STEP, OPT_GATHER_EVERY = 0, 1, 2, 3, 4, 5
 OPT_PIPELINE_ACTIVE = 100          # read-only: what OPT_PIPELINE resolves to on the engine
 OPT_RECORDS_ACTIVE = 101           # read-only: the rasteriser reads step-written render records
 PIPELINE_OFF, PIPELINE_AUTO, PIPELINE_STEP_BESIDE_RENDER, PIPELINE_OVERLAP_RENDERS = 0, 1, 2, 3
@@ -261,6 +261,7 @@ PROTOTYPES = {
     "tbx_get_scalars": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "tbx_render": (_i, [_vp, _vp, _i]),
     "tbx_render_device": (_i, [_vp, _vp, _i, _vp]),
+    "tbx_render_step_synthetic": (_i, [_vp, _vp, _i, _u64, _u64, _u64, _u32, _vp]),
     "tbx_render_env": (_i, [_vp, _i, _vp, _i]),
     "tbx_get_state": (_i, [_vp, _i, _vp, _sz]),
     "tbx_set_state": (_i, [_vp, _i, _vp, _sz]),
@@ -284,6 +285,8 @@ PROTOTYPES = {
     "tbx_gather_reduce_max": (_i, [_vp, _p(C.c_double)]),
     "tbx_gather_nranks": (_i, [_vp]),
     "tbx_gather_library": (C.c_char_p, [_vp]),
+    "tbx_gather_every": (_i, [_vp]),
+    "tbx_gather_fill": (_i, [_vp]),
     "tbx_device_buffer": (_i, [_vp, _i, _p(_vp), _p(_sz)]),
     "tbx_set_option": (_i, [_vp, _i, _i]),
     "tbx_get_option": (_i, [_vp, _i, _p(_i)]),

@@ -1166,7 +1166,8 @@ __device__ __forceinline__ void brk_paint_units(const RecSrc src, const BrkCusto
 template <int C, bool CUSTOM, bool ALT>
 __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
                                                                BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split,
-                                                               const BrkRenderRec* __restrict__ recs_alt, const uint8_t* __restrict__ pick_alt)
+                                                               const BrkRenderRec* __restrict__ recs_alt, const uint8_t* __restrict__ pick_alt,
+                                                               const int block)
 {
     constexpr int W = TBX_BRK_W, H = TBX_BRK_H;
     using Stager = RowStager<C, W, BRK_UNIT_ROWS>;
@@ -1180,7 +1181,7 @@ __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__
     // `split` waves share a frame, wave `part` taking units part, part + split, ...
     const bool stagger = C == 3 && !(split >> 16);        // (bit 16 of the argument: one of the two parts of a big launch)
     split &= 0xFFFF;
-    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    const int wid = wave_uniform(block * TBX_WAVES_PER_BLOCK + wave);
     const int rel = wid / split, part = wid - rel * split;
     if (rel >= count) return;
     // (agent layer, generic path: flagged envs paint recs_alt -- the ARRAY is selected; a select between two loaded records turns
@@ -1212,7 +1213,30 @@ __global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5)
     const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom, BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split,
     const BrkRenderRec* __restrict__ recs_alt = nullptr, const uint8_t* __restrict__ pick_alt = nullptr)
 {
-    brk_render_body<C, CUSTOM, ALT>(recs, custom, pal, out, first_env, count, split, recs_alt, pick_alt);
+    brk_render_body<C, CUSTOM, ALT>(recs, custom, pal, out, first_env, count, split, recs_alt, pick_alt, (int)blockIdx.x);
+}
+
+// The fused rollout launch (tbx_render_step_synthetic): the rasteriser of frame t and, in the SAME launch, the batch step that
+// produces frame t + 1.  The first `step_blocks` blocks step 256 envs each (one thread per env, brk_step_tpe_body) into the OTHER
+// records buffer and the step outputs; every later block is a rasteriser block of the launch above, reading the records the
+// previous launch's step left.  Nothing the two halves touch overlaps: the painter reads `recs` only, the step reads and writes
+// state, outputs and `recs_next`.  Why one launch: at the per-GPU share of a strong-scaled batch (8 192 envs) the step kernel
+// is 8 us of pure latency on 128 waves plus a kernel boundary in front of a 150 us rasteriser, and a rasteriser that starts
+// behind a short kernel starts in lockstep (raster.hpp) -- here the step's waves hide in the launch's ramp-up, consecutive
+// launches follow each other like render-only loops, and neither the staggered first waves nor the two-part launch is needed.
+// The kernel is held to five waves per SIMD like the rasteriser it contains, so the step half (190 VGPRs on its own) is
+// compiled to the rasteriser's register budget and spills; it runs on 0.6 % of the launch's waves beside the ramp-up.
+template <int C>
+__global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void brk_render_step_kernel_w5(
+    const BrkRenderRec* __restrict__ recs, BrkPalette pal, uint8_t* __restrict__ out, int count, int split, BrkDev d, const BrkCfg* __restrict__ cp,
+    ActionSource src, uint32_t flags, BrkRenderRec* __restrict__ recs_next, int step_blocks)
+{
+    if ((int)blockIdx.x < step_blocks) {
+        const int env = (int)blockIdx.x * TBX_BLOCK + (int)threadIdx.x;
+        if (env < d.n) brk_step_tpe_body<false>(d, *cp, src, flags, recs_next, nullptr, nullptr, env);
+        return;
+    }
+    brk_render_body<C, false, false>(recs, nullptr, pal, out, 0, count, split | (1 << 16), nullptr, nullptr, (int)blockIdx.x - step_blocks);
 }
 
 template <int C, bool CUSTOM, bool ALT>
@@ -1220,7 +1244,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_render_kernel(const BrkRenderRe
                                                                uint8_t* __restrict__ out, int first_env, int count, int split,
                                                                const BrkRenderRec* __restrict__ recs_alt = nullptr, const uint8_t* __restrict__ pick_alt = nullptr)
 {
-    brk_render_body<C, CUSTOM, ALT>(recs, custom, pal, out, first_env, count, split, recs_alt, pick_alt);
+    brk_render_body<C, CUSTOM, ALT>(recs, custom, pal, out, first_env, count, split, recs_alt, pick_alt, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------ resident single-env form (tbx_serve_loop, tbx_common.hpp)
@@ -1733,6 +1757,30 @@ struct BreakoutOps : GameOps {
         std::swap(recs, recs_other);
         recs_par ^= 1;
         recs_valid = true;
+        return TBX_OK;
+    }
+
+    // tbx_render_step_synthetic: frame t and the step to frame t + 1 in one launch (brk_render_step_kernel_w5)
+    bool render_step_fused(int channels) const override { return pipeline_ok() && channels >= 3; }   // (gray frames stream fastest at more than five waves per SIMD)
+    int render_step(tbx_engine* e, uint8_t* out_dev, int channels, const ActionSource& src, uint32_t flags, hipStream_t s) override
+    {
+        if (!recs_valid) {                                     // the painter reads records: bring them up to the state first
+            hipLaunchKernelGGL(brk_render_prep_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, recs, 0, e->n);
+            TBX_HIP(hipGetLastError());
+            recs_valid = true;
+        }
+        const BrkPalette pal = palette();
+        const int split = split_opt > 0 ? split_opt : channels == 3 ? 10 : e->n <= 8192 ? 4 : e->n <= 32768 ? 2 : 1;
+        const int step_blocks = (e->n + TBX_BLOCK - 1) / TBX_BLOCK;
+        const dim3 grid(grid_for(e->n * split).x + (unsigned)step_blocks), block(TBX_BLOCK);
+        switch (channels) {
+        case 3: TBX_LAUNCH_STEP(e, s, brk_render_step_kernel_w5<3>, grid, block, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks); break;
+        case 4: TBX_LAUNCH_STEP(e, s, brk_render_step_kernel_w5<4>, grid, block, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks); break;
+        default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+        }
+        TBX_HIP(hipGetLastError());
+        std::swap(recs, recs_other);
+        recs_par ^= 1;
         return TBX_OK;
     }
 

@@ -521,7 +521,7 @@ int tbx_step_device(tbx_engine* e, const int32_t* actions_dev, uint32_t flags, v
 static int pipe_mode(const tbx_engine* e)
 {
     const int v = e->opt[TBX_OPT_PIPELINE];
-    if (v == 0 || !e->ops->pipeline_ok()) return 0;
+    if (v == 0 || e->gather_ring || !e->ops->pipeline_ok()) return 0;      // (the K-step record ring moves the one record pointer)
     if (v == 1) return e->ops->pipeline_auto(e->n, e->gather != nullptr);
     return v;
 }
@@ -942,6 +942,38 @@ int tbx_render_device(tbx_engine* e, uint8_t* out_dev, int channels, void* strea
     return e->ops->render(e, out_dev, channels, 0, e->n, (hipStream_t)stream);
 }
 
+int tbx_render_step_synthetic(tbx_engine* e, uint8_t* out_dev, int channels, uint64_t action_seed, uint64_t t, uint64_t env_offset,
+                              uint32_t flags, void* stream)
+{
+    CHECK_ENGINE(e);
+    if (channels != 1 && channels != 3 && channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+    EHIP(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    EHIP(tbx_use_stream(e, s));                                 // (everything on the caller's stream: leaves a pipelined mode first)
+    if (!out_dev) {
+        const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
+        int rc = ensure_frame(e, bytes);
+        if (rc) return rc;
+        out_dev = e->frame;
+    }
+    if (((uintptr_t)out_dev & 15u) != 0) return e->fail(TBX_E_INVALID, "frame buffer must be 16-byte aligned");
+    ActionSource src{};
+    src.actions = nullptr;
+    src.seed = action_seed;
+    src.t = t;
+    src.env_offset = env_offset;
+    src.single_env = -1;
+    if (e->ops->render_step_fused(channels)) {
+        EHIP(tbx_gather_before_step(e, s));
+        return e->ops->render_step(e, out_dev, channels, src, flags, s);
+    }
+    // engines whose rasteriser reads live state (or gray frames): the same two things as two launches in stream order
+    int rc = e->ops->render(e, out_dev, channels, 0, e->n, s);
+    if (rc) return rc;
+    EHIP(tbx_gather_before_step(e, s));
+    return e->ops->step(e, src, flags, s);
+}
+
 int tbx_render(tbx_engine* e, uint8_t* out_host, int channels)
 {
     CHECK_ENGINE(e);
@@ -1109,6 +1141,7 @@ int tbx_set_option(tbx_engine* e, int option, int value)
     case TBX_OPT_STEP_FORM: ok = value >= 0 && value <= 2; break;
     case TBX_OPT_RENDER_SPLIT: ok = value >= 0 && value <= 64; break;
     case TBX_OPT_AGENT_GENERIC: case TBX_OPT_RESIDENT_STEP: ok = value == 0 || value == 1; break;
+    case TBX_OPT_GATHER_EVERY: ok = value >= 1 && value <= 64; break;
     default: return e->fail(TBX_E_INVALID, "unknown option");
     }
     if (!ok) return e->fail(TBX_E_INVALID, "option value out of range");

@@ -49,6 +49,14 @@ struct GatherState {
     int last_par = 0;
     bool any = false;                         // a gather has been queued at all
     uint64_t* send = nullptr;                 // [width] padded copy of the local records when width != N
+    // TBX_OPT_GATHER_EVERY = K > 1: the step kernels write their records straight into slot `fill` of ring[ring_par]
+    // ([K][width], zero beyond the engine's envs), tbx_gather only counts, and the K-th call sends the whole ring with ONE
+    // collective; the next K steps fill the other ring meanwhile
+    int every = 1;
+    int fill = 0;                             // steps whose records sit in the current ring and have not been sent
+    int ring_par = 0;
+    bool advance = false;                     // the next step has to move to the next slot first (tbx_gather_before_step)
+    uint64_t* ring[2] = {nullptr, nullptr};
     uint64_t* out = nullptr;                  // [nranks][width] engine-owned result (TBX_BUF_GATHERED)
     double* scalar = nullptr;                 // device scalar for the max-reduction
     tbx_nccl_get_unique_id_fn get_unique_id = nullptr;
@@ -127,18 +135,39 @@ void tbx_gather_free(tbx_engine* e)
         if (g->done[k]) hipEventDestroy(g->done[k]);
     if (g->stream) hipStreamDestroy(g->stream);
     hipFree(g->send); hipFree(g->out); hipFree(g->scalar);
+    if (g->ring[0]) {                         // the step kernels go back to the engine's own record array
+        hipFree(g->ring[0]); hipFree(g->ring[1]);
+        e->packed = e->outs[e->out_par].packed;
+        if (e->ops) e->ops->rebind_outputs(e);
+    }
+    e->gather_ring = false;
+    e->gather_wants_step_event = false;
     if (g->dl) dlclose(g->dl);
     delete g;
     e->gather = nullptr;
 }
 
 // a step overwrites the records of the output set it writes (tbx_engine::out_par at the time of this call): a queued gather
-// that still has to read that set goes first
+// that still has to read that set goes first.  Ring mode: the step moves on to the next slot of the ring (the address only --
+// no stream operation), and only when it opens a ring that was sent 2 K steps ago does it wait for that collective.
 hipError_t tbx_gather_before_step(tbx_engine* e, hipStream_t s)
 {
     GatherState* g = e->gather;
+    if (!g) return hipSuccess;
+    if (g->every > 1) {
+        if (!g->advance) return hipSuccess;                 // a step without a tbx_gather since the last one rewrites its slot
+        g->advance = false;
+        e->packed = g->ring[g->ring_par] + (size_t)g->fill * (size_t)g->width;
+        e->ops->rebind_outputs(e);
+        e->gather_wants_step_event = g->fill == g->every - 1;   // the step that completes the ring is the one the collective waits for
+        const int p = g->ring_par;
+        if (g->fill != 0 || !g->pending[p]) return hipSuccess;
+        g->pending[p] = false;
+        if (g->done_on[p] == s) return hipSuccess;
+        return hipStreamWaitEvent(s, g->done[p], 0);
+    }
     const int p = e->out_par;
-    if (!g || !g->pending[p]) return hipSuccess;
+    if (!g->pending[p]) return hipSuccess;
     g->pending[p] = false;
     if (g->done_on[p] == s) return hipSuccess;          // the same stream: already in order
     return hipStreamWaitEvent(s, g->done[p], 0);
@@ -148,7 +177,7 @@ int tbx_gather_buffer(tbx_engine* e, void** out_ptr, size_t* out_bytes)
 {
     if (!e->gather) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called");
     *out_ptr = e->gather->out;
-    if (out_bytes) *out_bytes = sizeof(uint64_t) * (size_t)e->gather->nranks * (size_t)e->gather->width;
+    if (out_bytes) *out_bytes = sizeof(uint64_t) * (size_t)e->gather->nranks * (size_t)e->gather->every * (size_t)e->gather->width;
     return TBX_OK;
 }
 
@@ -185,14 +214,35 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
     g.dl = open_rccl(err, &g.lib_path);
     if (!g.dl || !load_symbols(g, err)) { tbx_gather_free(e); return e->fail(TBX_E_UNSUPPORTED, err); }
     g.nranks = nranks; g.rank = rank; g.width = records_per_rank;
+    g.every = e->opt[TBX_OPT_GATHER_EVERY] > 1 ? e->opt[TBX_OPT_GATHER_EVERY] : 1;
     GHIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     GHIP(hipEventCreateWithFlags(&g.ready, hipEventDisableTiming));
     GHIP(hipEventCreateWithFlags(&g.done[0], hipEventDisableTiming));
     GHIP(hipEventCreateWithFlags(&g.done[1], hipEventDisableTiming));
-    GHIP(hipMalloc((void**)&g.out, sizeof(uint64_t) * (size_t)nranks * (size_t)g.width));
-    GHIP(hipMemset(g.out, 0, sizeof(uint64_t) * (size_t)nranks * (size_t)g.width));
+    const size_t out_records = (size_t)nranks * (size_t)g.every * (size_t)g.width;
+    GHIP(hipMalloc((void**)&g.out, sizeof(uint64_t) * out_records));
+    GHIP(hipMemset(g.out, 0, sizeof(uint64_t) * out_records));
     GHIP(hipMalloc((void**)&g.scalar, sizeof(double)));
-    if (g.width != e->n) GHIP(hipMalloc((void**)&g.send, sizeof(uint64_t) * (size_t)g.width));
+    if (g.every > 1) {
+        // the engine must be idle while the step kernels' record pointer moves into the ring
+        GHIP(hipDeviceSynchronize());
+        e->has_last = false;
+        e->pipe.active = false;
+        const size_t ring_bytes = sizeof(uint64_t) * (size_t)g.every * (size_t)g.width;
+        for (int k = 0; k < 2; k++) {
+            GHIP(hipMalloc((void**)&g.ring[k], ring_bytes));
+            GHIP(hipMemset(g.ring[k], 0, ring_bytes));      // slots are `width` wide: what lies beyond the engine's envs stays 0
+        }
+        // slot 0 starts as a copy of the records of the step before (TBX_BUF_PACKED keeps reading what it read)
+        GHIP(hipMemcpy(g.ring[0], e->packed, sizeof(uint64_t) * (size_t)e->n, hipMemcpyDeviceToDevice));
+        e->packed = g.ring[0];
+        e->ops->rebind_outputs(e);
+        e->gather_ring = true;
+        e->gather_wants_step_event = g.every == 1;
+    } else {
+        e->gather_wants_step_event = true;
+        if (g.width != e->n) GHIP(hipMalloc((void**)&g.send, sizeof(uint64_t) * (size_t)g.width));
+    }
     tbx_nccl_id_t uid;
     memcpy(&uid, id, sizeof uid);
     GNCCL(g.comm_init_rank(&g.comm, nranks, uid, rank));
@@ -214,6 +264,23 @@ int tbx_gather(tbx_engine* e, uint64_t* out_dev, void* stream)
     // against 0.10 -- the lanes then wait for each other's collectives.
     (void)stream;
     hipStream_t gs = g.stream;
+    if (g.every > 1) {
+        // ring mode: the records of the last step already sit in slot `fill` of the current ring
+        g.advance = true;
+        if (++g.fill < g.every) return TBX_OK;              // nothing is queued: K - 1 of K calls cost no stream operation at all
+        const int p = g.ring_par;
+        GHIP(tbx_wait_tail(e, gs, true));
+        if (g.any && g.done_on[g.last_par] != gs) GHIP(hipStreamWaitEvent(gs, g.done[g.last_par], 0));
+        GNCCL(g.all_gather(g.ring[p], out_dev ? out_dev : g.out, (size_t)g.every * (size_t)g.width, TBX_NCCL_UINT64, g.comm, gs));
+        g.last_par = p;
+        GHIP(hipEventRecord(g.done[p], gs));
+        g.done_on[p] = gs;
+        g.pending[p] = true;                                // the step that re-opens this ring, 2 K steps from now, waits for it
+        g.any = true;
+        g.fill = 0;
+        g.ring_par = p ^ 1;
+        return TBX_OK;
+    }
     if (e->pipe.active && e->pipe.step_outstanding) GHIP(hipStreamWaitEvent(gs, e->pipe.step_ev, 0));
     else GHIP(tbx_wait_tail(e, gs, true));
     if (g.any && g.done_on[g.last_par] != gs) GHIP(hipStreamWaitEvent(gs, g.done[g.last_par], 0));
@@ -251,7 +318,7 @@ int tbx_gather_host(tbx_engine* e, uint64_t* out_host)
     GatherState& g = *e->gather;
     GHIP(hipSetDevice(e->device));
     if (g.any) GHIP(hipStreamWaitEvent(g.stream, g.done[g.last_par], 0));
-    GHIP(hipMemcpyAsync(out_host, g.out, sizeof(uint64_t) * (size_t)g.nranks * (size_t)g.width, hipMemcpyDeviceToHost, g.stream));
+    GHIP(hipMemcpyAsync(out_host, g.out, sizeof(uint64_t) * (size_t)g.nranks * (size_t)g.every * (size_t)g.width, hipMemcpyDeviceToHost, g.stream));
     GHIP(hipStreamSynchronize(g.stream));
     return TBX_OK;
 }
@@ -283,6 +350,20 @@ const char* tbx_gather_library(tbx_engine* e)
 {
     if (!e || !e->gather) return "";
     return e->gather->lib_path.c_str();
+}
+
+int tbx_gather_every(tbx_engine* e)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->gather) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called");
+    return e->gather->every;
+}
+
+int tbx_gather_fill(tbx_engine* e)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->gather) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called");
+    return e->gather->fill;
 }
 
 }  // extern "C"

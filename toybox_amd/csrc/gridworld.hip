@@ -568,6 +568,11 @@ struct GridWorldOps : GameOps {
         return TBX_OK;
     }
 
+    void rebind_outputs(tbx_engine* e) override
+    {
+        d.reward = e->reward; d.done = e->done; d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed;
+    }
+
     void destroy(tbx_engine*) override
     {
         hipFree(d.sc); hipFree(d.tiles); hipFree(d.grid); hipFree(cfg_dev);

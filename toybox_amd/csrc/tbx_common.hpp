@@ -346,7 +346,9 @@ struct tbx_engine {
     bool has_last = false;
     hipEvent_t order_ev = nullptr;
     bool step_carries_order_ev = false;        // order_ev is the completion event of the last launch on last_stream (a batch step)
-    int opt[TBX_OPT_COUNT] = {0, 0, 0, 0, 1};
+    int opt[TBX_OPT_COUNT] = {0, 0, 0, 0, 1, 1};
+    bool gather_ring = false;                  // a K-step record ring is in force (TBX_OPT_GATHER_EVERY > 1 at tbx_gather_init): no pipelined mode
+    bool gather_wants_step_event = false;      // the next batch step is one a collective will wait for: its launch carries the ordering event
     TbxPipe pipe;
     // common device buffers (SoA over envs)
     uint64_t* sim_rng = nullptr;    // [2][N] simulator RNG
@@ -420,7 +422,7 @@ inline hipError_t tbx_wait_tail(tbx_engine* e, hipStream_t s, bool after_step_on
 // kernel by 5.7 us, the completion-event form by 2.4 (two kernels with nothing between them: 1.0).
 inline hipEvent_t tbx_step_order_event(tbx_engine* e)
 {
-    if (!e->gather) return nullptr;
+    if (!e->gather || !e->gather_wants_step_event) return nullptr;    // (ring mode: only the step that completes the ring)
     if (!e->order_ev && hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
     return e->order_ev;
 }
@@ -509,6 +511,10 @@ struct GameOps {
     virtual bool records_valid() const { return true; }        // false: the next render starts from live state (prep kernel / state-reading rasteriser)
     virtual int step_ahead(tbx_engine*, const ActionSource&, uint32_t, hipStream_t) { return TBX_E_UNSUPPORTED; }
     virtual void rebind_outputs(tbx_engine*) {}
+    // tbx_render_step_synthetic: the rasteriser of the current frame and the batch step to the next one as ONE launch on s
+    // (engines whose rasteriser reads step-written records); render_step_fused() false: the engine runs render(), then step()
+    virtual bool render_step_fused(int /*channels*/) const { return false; }
+    virtual int render_step(tbx_engine*, uint8_t* /*out_dev*/, int /*channels*/, const ActionSource&, uint32_t /*flags*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
     // an engine option changed (tbx_set_option): pick it up
     virtual void options_changed(tbx_engine*) {}
     // generic path: full-resolution gray frames of slot A (source 1), slot B (2) or the live state (0); envs whose

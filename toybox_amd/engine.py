@@ -282,6 +282,13 @@ class Engine:
         self._check(self._lib.tbx_render_device(self._h, C.c_void_p(int(out_ptr)) if out_ptr else None,
                                                 int(channels), C.c_void_p(int(stream))))
 
+    def render_step_synthetic(self, action_seed, t, out_ptr=0, channels=3, env_offset=0, auto_reset=True, stream=0):
+        """tbx_render_step_synthetic: the frame of the current state into out_ptr (0: TBX_BUF_FRAME) and one step with
+        device-generated actions, one launch where the rasteriser reads step-written records (random-rollout loops only)."""
+        flags = _abi.STEP_AUTO_RESET if auto_reset else 0
+        self._check(self._lib.tbx_render_step_synthetic(self._h, C.c_void_p(int(out_ptr)) if out_ptr else None, int(channels),
+                                                        int(action_seed), int(t), int(env_offset), flags, C.c_void_p(int(stream))))
+
     def device_buffer(self, which):
         p, b = C.c_void_p(), C.c_size_t()
         self._check(self._lib.tbx_device_buffer(self._h, int(which), C.byref(p), C.byref(b)))
@@ -301,7 +308,8 @@ class Engine:
         width = self.n_envs if records_per_rank is None else int(records_per_rank)
         buf = (C.c_uint8 * _abi.GATHER_ID_BYTES).from_buffer_copy(bytes(unique_id))
         self._check(self._lib.tbx_gather_init(self._h, int(nranks), int(rank), width, buf, _abi.GATHER_ID_BYTES))
-        self._gather_shape = (int(nranks), width)
+        k = self._lib.tbx_gather_every(self._h)
+        self._gather_shape = (int(nranks), width) if k <= 1 else (int(nranks), k, width)
 
     def gather(self, out_ptr=0, stream=0):
         self._check(self._lib.tbx_gather(self._h, C.c_void_p(int(out_ptr)) if out_ptr else None, C.c_void_p(int(stream))))
@@ -309,8 +317,17 @@ class Engine:
     def gather_wait(self, stream=0):
         self._check(self._lib.tbx_gather_wait(self._h, C.c_void_p(int(stream))))
 
+    def gather_every(self):
+        """K of the record ring the communicator was initialised with (OPT_GATHER_EVERY at gather_init)"""
+        return self._lib.tbx_gather_every(self._h)
+
+    def gather_fill(self):
+        """steps whose records wait in the ring for the next collective"""
+        return self._lib.tbx_gather_fill(self._h)
+
     def gather_host(self):
-        """uint64[nranks, records_per_rank] of the last queued gather (blocks until it has finished)."""
+        """uint64[nranks, records_per_rank] -- [nranks, K, records_per_rank] with a K-step ring -- of the last queued gather
+        (blocks until it has finished)."""
         out = np.empty(self._gather_shape, np.uint64)
         self._check(self._lib.tbx_gather_host(self._h, _ptr(out)))
         return out

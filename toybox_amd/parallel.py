@@ -192,8 +192,10 @@ class ShardedBatch:
     records, and no communicator is made unless the device-resident form asks for the gathered buffer.
     """
 
-    def __init__(self, engine_factory, n_global, rank=0, world=1, seed_base=1234, host_dist=None, rdzv_tag="", rdzv_key=None):
+    def __init__(self, engine_factory, n_global, rank=0, world=1, seed_base=1234, host_dist=None, rdzv_tag="", rdzv_key=None,
+                 gather_every=1):
         self.rank, self.world = int(rank), int(world)
+        self.gather_every = max(1, int(gather_every))   # K-step record ring (TBX_OPT_GATHER_EVERY): one collective per K steps
         self.n_global = int(n_global)
         self.start, self.end = shard_range(n_global, self.world, self.rank)
         self.n_local = self.end - self.start
@@ -211,6 +213,9 @@ class ShardedBatch:
     def _make_communicator(self):
         tag, key = self._rdzv
         uid = exchange_unique_id(self.rank, self.world, self.engine.gather_unique_id, tag=tag, key=key)
+        if self.gather_every > 1:
+            from . import _abi
+            self.engine.set_option(_abi.OPT_GATHER_EVERY, self.gather_every)   # read by gather_init
         self.engine.gather_init(self.world, self.rank, uid, records_per_rank=self.width)   # collective
         forget_unique_id(self.rank, tag=tag, key=key)
         self.communicator = True
@@ -228,6 +233,8 @@ class ShardedBatch:
             return unpack_records(self._global_order(self.host.all_gather(pack_records(reward, done, lives))))
         if not self.communicator:                      # one process: nothing to exchange
             return unpack_records(pack_records(reward, done, lives))
+        if self.gather_every > 1:
+            raise ValueError("step_host returns every step's records: use step_synthetic / gathered() with a K-step ring")
         self.engine.gather()
         return unpack_records(self._global_order(self.engine.gather_host()))
 
@@ -240,7 +247,12 @@ class ShardedBatch:
         self.engine.gather(stream=stream)
 
     def gathered(self):
-        return unpack_records(self._global_order(self.engine.gather_host()))
+        """(reward, done, lives) in global env order of the last collective -- with a K-step ring a list of K such triples,
+        oldest step first (the collective goes out with every K-th step_synthetic)"""
+        g = self.engine.gather_host()
+        if g.ndim == 3:
+            return [unpack_records(self._global_order(g[:, j, :])) for j in range(g.shape[1])]
+        return unpack_records(self._global_order(g))
 
     def max_over_ranks(self, value):
         return self.engine.gather_reduce_max(value) if self.communicator else value
