@@ -453,6 +453,69 @@ int tbx_set_config(tbx_engine* engine, const void* pod, size_t size);
 #define TBX_QUERY_WORLD_TO_TILE 2
 int tbx_query(tbx_engine* engine, int env, int query_id, const int32_t* args, int n_args, int32_t* out, int n_out);
 
+/* ------------------------------------------------------------------ batched interventions on the device
+ * The reference's per-game intervention classes are helper methods over ONE env's decoded JSON state
+ * (toybox/interventions/breakout.py:303-429, amidar.py:360-615, space_invaders.py:165-176).  Their batched forms here act on
+ * the struct-of-arrays state in HBM directly -- one kernel over every selected env, no state record leaves the device:
+ *   tbx_edit    a field write ("add_channel", "set_mode", "set_tile_tag", "set_enemy_protocol", ...) in the envs whose mask
+ *               byte is non-zero (mask NULL: every env);
+ *   tbx_reduce  a per-env feature ("num_bricks_remaining", "channel_count", "player_enemy_distances", ...) as
+ *               out[N][tbx_reduce_width(game, query)] doubles (integers are exact in binary64; Breakout's positions are
+ *               binary64 anyway); entries that do not exist (a fifth enemy of four, a tile outside the board) read -1.
+ * args: up to TBX_EDIT_MAX_ARGS doubles, the same for every env (per_env = 0) or one row per env, args[N][n_args]
+ * (per_env = 1: a sweep in which env i gets its own column, tile, timer ...).  The "_device" forms take device pointers for
+ * mask / per-env args / out and are asynchronous on `stream`; args with per_env = 0 are always a host pointer.
+ * Helpers of the reference that only sample (get_random_tile, get_random_track_position, set_player_random_start's draw,
+ * get_random_dir_for_tile) or take a Python predicate (find_brick, filter_tiles) have no device form: the deterministic
+ * half of each is here (TBX_EDIT_AMI_PLAYER_TILE, TBX_QUERY_AMI_COUNT_TILES, TBX_QUERY_BRK_COLUMN ...).  Config-level
+ * helpers (set_jitter, add_row) go through tbx_set_config like the reference's dirty_config path. */
+#define TBX_EDIT_MAX_ARGS 16
+/* every game -- `intervention.game.lives = v` (interventions/space_invaders.py:199, test_breakout_interventions.py) */
+#define TBX_EDIT_SET_LIVES          1   /* {lives} */
+#define TBX_EDIT_SET_SCORE          2   /* {score} */
+#define TBX_EDIT_SET_LEVEL          3   /* {level} */
+/* Breakout (interventions/breakout.py) */
+#define TBX_EDIT_BRK_COLUMN_ALIVE  10   /* {col, alive}: add_channel :392-396 (alive 0), fill_column :398-402 (alive 1) */
+#define TBX_EDIT_BRK_ROW_ALIVE     11   /* {row, alive} */
+#define TBX_EDIT_BRK_ALL_ALIVE     12   /* {alive}: clear_board :412-415 (alive 0) */
+#define TBX_EDIT_BRK_BRICK_ALIVE   13   /* {brick index, alive} (test_breakout_interventions.py:48) */
+#define TBX_EDIT_BRK_PADDLE        14   /* {x[, y]} paddle.position (get_paddle_position :379; test :111-118) */
+#define TBX_EDIT_BRK_BALL          15   /* {ball, x, y, vx, vy} balls[ball] position and velocity (:365-377) */
+/* Amidar (interventions/amidar.py) */
+#define TBX_EDIT_AMI_TIMERS        20   /* {jump_timer, chase_timer}, -1 = leave: set_mode :402-416 */
+#define TBX_EDIT_AMI_JUMPS         21   /* {jumps} (test_amidar_interventions.py:174) */
+#define TBX_EDIT_AMI_TILE          22   /* {tx, ty, tag}: set_tile_tag :476-478 */
+#define TBX_EDIT_AMI_ENEMY_AI      23   /* {enemy, the 14 fields of tbx_amidar_ai_t}: set_enemy_protocol :418-471 */
+#define TBX_EDIT_AMI_PLAYER_TILE   24   /* {tx, ty}: player.position = tile_to_world(tile), the write of set_player_random_start :531-538 */
+/* SpaceInvaders (interventions/space_invaders.py) */
+#define TBX_EDIT_SI_UFO_APPEARANCE 30   /* {appearance_counter}: remove_mothership :172-173 (-1) */
+
+#define TBX_QUERY_BRK_BRICKS_REMAINING 110  /* -> 1  num_bricks_remaining :309-310 */
+#define TBX_QUERY_BRK_NUM_BRICKS       111  /* -> 1  num_bricks :312-313 */
+#define TBX_QUERY_BRK_COLUMN           112  /* {col} -> 32  alive flag of each brick with that col, in brick order (get_column :349-355) */
+#define TBX_QUERY_BRK_ROW              113  /* {row} -> 32  the same by row (get_row :357-359, read as documented: the ith row) */
+#define TBX_QUERY_BRK_IS_CHANNEL       114  /* {col} -> 1  the column has bricks and none is alive (is_channel :340-347) */
+#define TBX_QUERY_BRK_CHANNEL_COUNT    115  /* {n_columns} -> 1  channel_count :361-366 */
+#define TBX_QUERY_BRK_FIND_CHANNEL     116  /* {n_columns} -> 1  first channel column or -1 (find_channel :404-410) */
+#define TBX_QUERY_BRK_PADDLE           117  /* -> 4  position x, y, velocity x, y (:379-383) */
+#define TBX_QUERY_BRK_BALLS            118  /* -> 17 n_balls, x[4], y[4], vx[4], vy[4] (:365-377) */
+#define TBX_QUERY_AMI_MODE             120  /* -> 2  jump_timer, chase_timer (get_regular / jump / chase_mode :385-395) */
+#define TBX_QUERY_AMI_ANY_CAUGHT       121  /* -> 1  any_enemy_caught :397-399 */
+#define TBX_QUERY_AMI_TILE             122  /* {tx, ty} -> 1  tag (get_tile_by_pos :480-481, is_tile_walkable :472-474) */
+#define TBX_QUERY_AMI_COUNT_TILES      123  /* {tag} -> 1  len(filter_tiles(tag == ...)) :483-488 */
+#define TBX_QUERY_AMI_ADJACENT         124  /* {tx, ty} -> 4  tags of the up, left, right, down neighbours -- the order filter_tiles finds them (get_adjacent_tiles :512-524) */
+#define TBX_QUERY_AMI_ENEMY_DISTANCES  125  /* {tx, ty} -> 8  manhattan tile distance of every enemy (enemy_distances_from_tile :526-530) */
+#define TBX_QUERY_AMI_PLAYER_TILE      126  /* -> 3  tx, ty, tag (player_tile :573-576) */
+#define TBX_QUERY_AMI_PLAYER_ENEMY_DISTANCES 127  /* -> 8  player_enemy_distances :579-583 */
+#define TBX_QUERY_AMI_PLAYER_ON_PAINTED 128 /* -> 1  player_on_painted :586-589 */
+#define TBX_QUERY_AMI_PLAYER_NEAR_UNPAINTED 129 /* {radius} -> 1  player_near_unpainted :592-603 */
+#define TBX_QUERY_SI_SHIP              130  /* -> 8  x, y, w, h, speed, alive, death_counter, death_hit_1 (get_player :175-176) */
+int tbx_reduce_width(int game, int query);   /* doubles per env, or TBX_E_INVALID */
+int tbx_edit(tbx_engine* engine, int op, const double* args_host, int n_args, int per_env, const uint8_t* mask_host);
+int tbx_edit_device(tbx_engine* engine, int op, const double* args, int n_args, int per_env, const uint8_t* mask_dev, void* stream);
+int tbx_reduce(tbx_engine* engine, int query, const double* args_host, int n_args, int per_env, double* out_host);
+int tbx_reduce_device(tbx_engine* engine, int query, const double* args, int n_args, int per_env, double* out_dev, void* stream);
+
 /* ------------------------------------------------------------------ agent-side preprocessing (SURVEY.md 8f rank 1 + 2)
  * The per-env wrapper stack that the reference's vendored baselines put between the env and the learner, fused on the
  * device so that only the small stacked observation ever leaves the chip.  The composition is the reference's, class by

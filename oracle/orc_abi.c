@@ -590,6 +590,259 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     return TBX_OK;
 }
 
+/* ---------------------------------------------------------------- batched interventions (tbx_edit / tbx_reduce)
+ * The reference's helper methods (toybox/interventions/breakout.py:303-429, amidar.py:360-615, space_invaders.py:165-176),
+ * restated env by env over the POD state records -- plain loops over `bricks`, `tiles`, `enemies`, the way the Python walks
+ * the decoded JSON. */
+
+int tbx_reduce_width(int game, int query)
+{
+    switch (query) {
+    case TBX_QUERY_BRK_BRICKS_REMAINING: case TBX_QUERY_BRK_NUM_BRICKS: case TBX_QUERY_BRK_IS_CHANNEL: case TBX_QUERY_BRK_CHANNEL_COUNT:
+    case TBX_QUERY_BRK_FIND_CHANNEL: return game == TBX_GAME_BREAKOUT ? 1 : TBX_E_INVALID;
+    case TBX_QUERY_BRK_COLUMN: case TBX_QUERY_BRK_ROW: return game == TBX_GAME_BREAKOUT ? 32 : TBX_E_INVALID;
+    case TBX_QUERY_BRK_PADDLE: return game == TBX_GAME_BREAKOUT ? 4 : TBX_E_INVALID;
+    case TBX_QUERY_BRK_BALLS: return game == TBX_GAME_BREAKOUT ? 1 + 4 * TBX_BRK_MAX_BALLS : TBX_E_INVALID;
+    case TBX_QUERY_AMI_MODE: return game == TBX_GAME_AMIDAR ? 2 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_ANY_CAUGHT: case TBX_QUERY_AMI_TILE: case TBX_QUERY_AMI_COUNT_TILES: case TBX_QUERY_AMI_PLAYER_ON_PAINTED:
+    case TBX_QUERY_AMI_PLAYER_NEAR_UNPAINTED: return game == TBX_GAME_AMIDAR ? 1 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_ADJACENT: return game == TBX_GAME_AMIDAR ? 4 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_ENEMY_DISTANCES: case TBX_QUERY_AMI_PLAYER_ENEMY_DISTANCES: return game == TBX_GAME_AMIDAR ? TBX_AMI_MAX_ENEMIES : TBX_E_INVALID;
+    case TBX_QUERY_AMI_PLAYER_TILE: return game == TBX_GAME_AMIDAR ? 3 : TBX_E_INVALID;
+    case TBX_QUERY_SI_SHIP: return game == TBX_GAME_SPACE_INVADERS ? 8 : TBX_E_INVALID;
+    default: return TBX_E_INVALID;
+    }
+}
+
+static int arg_i(const double* a, int n, int i)
+{
+    double x = i < n ? a[i] : 0.0;
+    if (!(x > -2.0e9)) x = -2.0e9;
+    if (x > 2.0e9) x = 2.0e9;
+    return (int)x;
+}
+static double arg_d(const double* a, int n, int i) { return i < n ? a[i] : 0.0; }
+
+static int brk_edit_one(const tbx_breakout_config_t* cfg, tbx_breakout_state_t* st, int op, const double* a, int n)
+{
+    (void)cfg;
+    switch (op) {
+    case TBX_EDIT_SET_LIVES: st->lives = arg_i(a, n, 0); return 0;
+    case TBX_EDIT_SET_SCORE: st->score = arg_i(a, n, 0); return 0;
+    case TBX_EDIT_SET_LEVEL: st->level = arg_i(a, n, 0); return 0;
+    case TBX_EDIT_BRK_COLUMN_ALIVE:
+        for (int j = 0; j < st->n_bricks; j++) if (st->bricks[j].col == arg_i(a, n, 0)) st->bricks[j].alive = arg_i(a, n, 1) != 0;
+        return 0;
+    case TBX_EDIT_BRK_ROW_ALIVE:
+        for (int j = 0; j < st->n_bricks; j++) if (st->bricks[j].row == arg_i(a, n, 0)) st->bricks[j].alive = arg_i(a, n, 1) != 0;
+        return 0;
+    case TBX_EDIT_BRK_ALL_ALIVE:
+        for (int j = 0; j < st->n_bricks; j++) st->bricks[j].alive = arg_i(a, n, 0) != 0;
+        return 0;
+    case TBX_EDIT_BRK_BRICK_ALIVE: {
+        const int j = arg_i(a, n, 0);
+        if (j >= 0 && j < st->n_bricks) st->bricks[j].alive = arg_i(a, n, 1) != 0;
+        return 0;
+    }
+    case TBX_EDIT_BRK_PADDLE:
+        st->paddle_x = arg_d(a, n, 0);
+        if (n >= 2) st->paddle_y = arg_d(a, n, 1);
+        return 0;
+    case TBX_EDIT_BRK_BALL: {
+        const int b = arg_i(a, n, 0);
+        if (b >= 0 && b < TBX_BRK_MAX_BALLS && b < st->n_balls) {
+            st->ball_x[b] = arg_d(a, n, 1); st->ball_y[b] = arg_d(a, n, 2); st->ball_vx[b] = arg_d(a, n, 3); st->ball_vy[b] = arg_d(a, n, 4);
+        }
+        return 0;
+    }
+    default: return -1;
+    }
+}
+
+static int brk_is_channel(const tbx_breakout_state_t* st, int col)
+{
+    int bricks = 0, live = 0;
+    for (int j = 0; j < st->n_bricks; j++) if (st->bricks[j].col == col) { bricks++; live += st->bricks[j].alive != 0; }
+    return bricks > 0 && live == 0;
+}
+
+static int brk_reduce_one(const tbx_breakout_config_t* cfg, const tbx_breakout_state_t* st, int q, const double* a, int n, double* o, int width)
+{
+    switch (q) {
+    case TBX_QUERY_BRK_BRICKS_REMAINING: { int c = 0; for (int j = 0; j < st->n_bricks; j++) c += st->bricks[j].alive != 0; o[0] = c; return 0; }
+    case TBX_QUERY_BRK_NUM_BRICKS: o[0] = st->n_bricks; return 0;
+    case TBX_QUERY_BRK_COLUMN: case TBX_QUERY_BRK_ROW: {
+        int m = 0;
+        for (int j = 0; j < st->n_bricks && m < width; j++)
+            if ((q == TBX_QUERY_BRK_COLUMN ? st->bricks[j].col : st->bricks[j].row) == arg_i(a, n, 0)) o[m++] = st->bricks[j].alive != 0;
+        for (; m < width; m++) o[m] = -1.0;
+        return 0;
+    }
+    case TBX_QUERY_BRK_IS_CHANNEL: o[0] = brk_is_channel(st, arg_i(a, n, 0)); return 0;
+    case TBX_QUERY_BRK_CHANNEL_COUNT: case TBX_QUERY_BRK_FIND_CHANNEL: {
+        const int ncols = cfg->n_rows > 0 ? st->n_bricks / cfg->n_rows : 0;       /* num_columns: bricks // rows */
+        int count = 0, first = -1;
+        for (int c = 0; c < ncols; c++) if (brk_is_channel(st, c)) { count++; if (first < 0) first = c; }
+        o[0] = q == TBX_QUERY_BRK_CHANNEL_COUNT ? count : first;
+        return 0;
+    }
+    case TBX_QUERY_BRK_PADDLE: o[0] = st->paddle_x; o[1] = st->paddle_y; o[2] = st->paddle_vx; o[3] = st->paddle_vy; return 0;
+    case TBX_QUERY_BRK_BALLS:
+        o[0] = st->n_balls;
+        for (int b = 0; b < TBX_BRK_MAX_BALLS; b++) {
+            const int on = b < st->n_balls;
+            o[1 + b] = on ? st->ball_x[b] : -1.0; o[1 + TBX_BRK_MAX_BALLS + b] = on ? st->ball_y[b] : -1.0;
+            o[1 + 2 * TBX_BRK_MAX_BALLS + b] = on ? st->ball_vx[b] : -1.0; o[1 + 3 * TBX_BRK_MAX_BALLS + b] = on ? st->ball_vy[b] : -1.0;
+        }
+        return 0;
+    default: return -1;
+    }
+}
+
+static int ami_edit_one(tbx_amidar_state_t* st, int op, const double* a, int n)
+{
+    switch (op) {
+    case TBX_EDIT_SET_LIVES: st->lives = arg_i(a, n, 0); return 0;
+    case TBX_EDIT_SET_SCORE: st->score = arg_i(a, n, 0); return 0;
+    case TBX_EDIT_SET_LEVEL: st->level = arg_i(a, n, 0); return 0;
+    case TBX_EDIT_AMI_JUMPS: st->jumps = arg_i(a, n, 0); return 0;
+    case TBX_EDIT_AMI_TIMERS:
+        if (arg_i(a, n, 0) >= 0) st->jump_timer = arg_i(a, n, 0);
+        if (arg_i(a, n, 1) >= 0) st->chase_timer = arg_i(a, n, 1);
+        return 0;
+    case TBX_EDIT_AMI_TILE: {
+        const int tx = arg_i(a, n, 0), ty = arg_i(a, n, 1);
+        if (tx >= 0 && ty >= 0 && tx < TBX_AMI_BOARD_W && ty < TBX_AMI_BOARD_H) st->tiles[ty][tx] = (uint8_t)(arg_i(a, n, 2) & 3);
+        return 0;
+    }
+    case TBX_EDIT_AMI_ENEMY_AI: {
+        const int e = arg_i(a, n, 0);
+        if (e >= 0 && e < st->n_enemies) {
+            int32_t* ai = &st->enemies[e].ai.kind;
+            for (int k = 0; k < 14; k++) ai[k] = arg_i(a, n, 1 + k);
+        }
+        return 0;
+    }
+    case TBX_EDIT_AMI_PLAYER_TILE:
+        st->player.x = arg_i(a, n, 0) * TBX_AMI_TILE_WX; st->player.y = arg_i(a, n, 1) * TBX_AMI_TILE_WY;
+        return 0;
+    default: return -1;
+    }
+}
+
+static int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+static int ami_tag(const tbx_amidar_state_t* st, int tx, int ty)
+{
+    return (tx < 0 || ty < 0 || tx >= TBX_AMI_BOARD_W || ty >= TBX_AMI_BOARD_H) ? -1 : st->tiles[ty][tx];
+}
+static void ami_distances(const tbx_amidar_state_t* st, int tx, int ty, double* o)
+{
+    for (int i = 0; i < TBX_AMI_MAX_ENEMIES; i++) {
+        if (i >= st->n_enemies) { o[i] = -1.0; continue; }
+        const int ex = floor_div(st->enemies[i].x, TBX_AMI_TILE_WX), ey = floor_div(st->enemies[i].y, TBX_AMI_TILE_WY);
+        o[i] = abs(ex - tx) + abs(ey - ty);
+    }
+}
+
+static int ami_reduce_one(const tbx_amidar_state_t* st, int q, const double* a, int n, double* o)
+{
+    const int ptx = floor_div(st->player.x, TBX_AMI_TILE_WX), pty = floor_div(st->player.y, TBX_AMI_TILE_WY);
+    switch (q) {
+    case TBX_QUERY_AMI_MODE: o[0] = st->jump_timer; o[1] = st->chase_timer; return 0;
+    case TBX_QUERY_AMI_ANY_CAUGHT: { int any = 0; for (int i = 0; i < st->n_enemies; i++) any |= st->enemies[i].caught != 0; o[0] = any; return 0; }
+    case TBX_QUERY_AMI_TILE: o[0] = ami_tag(st, arg_i(a, n, 0), arg_i(a, n, 1)); return 0;
+    case TBX_QUERY_AMI_COUNT_TILES: {
+        int c = 0;
+        for (int ty = 0; ty < TBX_AMI_BOARD_H; ty++) for (int tx = 0; tx < TBX_AMI_BOARD_W; tx++) c += st->tiles[ty][tx] == arg_i(a, n, 0);
+        o[0] = c;
+        return 0;
+    }
+    case TBX_QUERY_AMI_ADJACENT: {
+        const int tx = arg_i(a, n, 0), ty = arg_i(a, n, 1);
+        o[0] = ami_tag(st, tx, ty - 1); o[1] = ami_tag(st, tx - 1, ty); o[2] = ami_tag(st, tx + 1, ty); o[3] = ami_tag(st, tx, ty + 1);
+        return 0;
+    }
+    case TBX_QUERY_AMI_ENEMY_DISTANCES: ami_distances(st, arg_i(a, n, 0), arg_i(a, n, 1), o); return 0;
+    case TBX_QUERY_AMI_PLAYER_TILE: o[0] = ptx; o[1] = pty; o[2] = ami_tag(st, ptx, pty); return 0;
+    case TBX_QUERY_AMI_PLAYER_ENEMY_DISTANCES: ami_distances(st, ptx, pty, o); return 0;
+    case TBX_QUERY_AMI_PLAYER_ON_PAINTED: o[0] = ami_tag(st, ptx, pty) == TBX_TILE_PAINTED; return 0;
+    case TBX_QUERY_AMI_PLAYER_NEAR_UNPAINTED: {
+        int near = 0, painted = 0;
+        for (int ty = 0; ty < TBX_AMI_BOARD_H; ty++)
+            for (int tx = 0; tx < TBX_AMI_BOARD_W; tx++)
+                if (abs(tx - ptx) + abs(ty - pty) < arg_i(a, n, 0) && st->tiles[ty][tx] != TBX_TILE_EMPTY) { near++; painted += st->tiles[ty][tx] == TBX_TILE_PAINTED; }
+        o[0] = painted != near;
+        return 0;
+    }
+    default: return -1;
+    }
+}
+
+static int si_edit_one(tbx_si_state_t* st, int op, const double* a, int n)
+{
+    switch (op) {
+    case TBX_EDIT_SET_LIVES: st->lives = arg_i(a, n, 0); return 0;
+    case TBX_EDIT_SET_SCORE: st->score = arg_i(a, n, 0); return 0;
+    case TBX_EDIT_SET_LEVEL: st->level = arg_i(a, n, 0); return 0;
+    case TBX_EDIT_SI_UFO_APPEARANCE: st->ufo_appearance_counter = arg_i(a, n, 0); return 0;
+    default: return -1;
+    }
+}
+
+int tbx_edit_device(tbx_engine* e, int op, const double* args, int n_args, int per_env, const uint8_t* mask, void* stream)
+{
+    (void)stream;
+    if (!e) return TBX_E_INVALID;
+    if (n_args < 0 || n_args > TBX_EDIT_MAX_ARGS || (n_args > 0 && !args)) return fail(e, TBX_E_INVALID, "bad intervention arguments");
+    for (int i = 0; i < e->n; i++) {
+        if (mask && !mask[i]) continue;
+        const double* a = per_env ? args + (size_t)i * n_args : args;
+        void* st = e->states + e->ssz * (size_t)i;
+        int rc = -1;
+        if (e->game == TBX_GAME_BREAKOUT) rc = brk_edit_one((const tbx_breakout_config_t*)e->cfg, (tbx_breakout_state_t*)st, op, a, n_args);
+        else if (e->game == TBX_GAME_AMIDAR) rc = ami_edit_one((tbx_amidar_state_t*)st, op, a, n_args);
+        else if (e->game == TBX_GAME_SPACE_INVADERS) rc = si_edit_one((tbx_si_state_t*)st, op, a, n_args);
+        if (rc) return fail(e, TBX_E_INVALID, "unknown edit for this game");
+    }
+    return TBX_OK;
+}
+
+int tbx_edit(tbx_engine* e, int op, const double* args, int n_args, int per_env, const uint8_t* mask)
+{
+    return tbx_edit_device(e, op, args, n_args, per_env, mask, NULL);
+}
+
+int tbx_reduce_device(tbx_engine* e, int query, const double* args, int n_args, int per_env, double* out, void* stream)
+{
+    (void)stream;
+    if (!e) return TBX_E_INVALID;
+    const int width = tbx_reduce_width(e->game, query);
+    if (width < 0) return fail(e, TBX_E_INVALID, "unknown query for this game");
+    if (!out) return fail(e, TBX_E_INVALID, "output pointer is NULL");
+    if (n_args < 0 || n_args > TBX_EDIT_MAX_ARGS || (n_args > 0 && !args)) return fail(e, TBX_E_INVALID, "bad intervention arguments");
+    for (int i = 0; i < e->n; i++) {
+        const double* a = per_env ? args + (size_t)i * n_args : args;
+        const void* st = e->states + e->ssz * (size_t)i;
+        double* o = out + (size_t)i * width;
+        int rc = -1;
+        if (e->game == TBX_GAME_BREAKOUT) rc = brk_reduce_one((const tbx_breakout_config_t*)e->cfg, (const tbx_breakout_state_t*)st, query, a, n_args, o, width);
+        else if (e->game == TBX_GAME_AMIDAR) rc = ami_reduce_one((const tbx_amidar_state_t*)st, query, a, n_args, o);
+        else if (e->game == TBX_GAME_SPACE_INVADERS && query == TBX_QUERY_SI_SHIP) {
+            const tbx_si_state_t* s = (const tbx_si_state_t*)st;
+            o[0] = s->ship_x; o[1] = s->ship_y; o[2] = s->ship_w; o[3] = s->ship_h; o[4] = s->ship_speed;
+            o[5] = s->ship_alive != 0; o[6] = s->ship_death_counter; o[7] = s->ship_death_hit_1 != 0;
+            rc = 0;
+        }
+        if (rc) return fail(e, TBX_E_INVALID, "unknown query for this game");
+    }
+    return TBX_OK;
+}
+
+int tbx_reduce(tbx_engine* e, int query, const double* args, int n_args, int per_env, double* out)
+{
+    return tbx_reduce_device(e, query, args, n_args, per_env, out, NULL);
+}
+
 /* ---------------------------------------------------------------- record gather
  * The product does this with RCCL over xGMI (toybox_amd/csrc/gather.hip).  The checker restates the same calls over a POSIX
  * shared-memory segment named by the "unique id", so that the multi-process CPU tests (world size 2) drive the real control

@@ -147,3 +147,240 @@ def test_seed_array_equals_per_env_seed(lib):
         assert a.get_sim_rng(i) == b.get_sim_rng(i) and bytes(a.get_state(i)) == bytes(b.get_state(i))
     with pytest.raises(ValueError):
         a.seed_array(seeds[:-1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The reference's helper methods (interventions/breakout.py:303-429, amidar.py:360-615, space_invaders.py:165-176) as
+# device-side kernels (tbx_edit / tbx_reduce).  Three checks: (1) every query against a second formulation -- numpy over the
+# POD records -- on whichever library runs; (2) HIP against the oracle after a sequence of edits, states and rollout;
+# (3) (build container only) the oracle's batched forms against the reference's OWN single-env classes driven through the
+# ctoybox shim, tests/interventions_reference_worker.py.
+
+def _played(game, n, lib, frames=260, seed=17):
+    e = Engine(game, n, lib=lib)
+    e.seed(seed)
+    e.new_game()
+    for t in range(frames):
+        e.step(synthetic_actions(game, n, t, seed=3), auto_reset=True)
+    return e
+
+
+def test_breakout_helpers_against_numpy(lib):
+    n = 41
+    e = _played("breakout", n, lib)
+    rng = np.random.default_rng(5)
+    with BatchIntervention(e) as bi:
+        st = e.get_states_np()
+        live = (np.arange(256)[None, :] < st["n_bricks"][:, None]) & (st["bricks"]["alive"] != 0)
+        assert np.array_equal(bi.num_bricks_remaining(), live.sum(axis=1))
+        assert np.array_equal(bi.num_bricks(), st["n_bricks"]) and bi.num_rows() == 6 and (bi.num_columns() == 18).all()
+        cols = rng.integers(0, 18, n)
+        bi.add_channel(cols)                                      # a different column in every env
+        bi.add_channel(3, envs=np.arange(n) % 2 == 0)             # and column 3 in the even ones
+        st = e.get_states_np()
+        for i in range(n):
+            b = st["bricks"][i][:st["n_bricks"][i]]
+            assert not b["alive"][b["col"] == cols[i]].any()
+            assert (not b["alive"][b["col"] == 3].any()) if i % 2 == 0 or cols[i] == 3 else True
+        chan = np.array([[not st["bricks"][i]["alive"][:108][st["bricks"][i]["col"][:108] == c].any() for c in range(18)] for i in range(n)])
+        assert np.array_equal(bi.channel_count(), chan.sum(axis=1))
+        assert np.array_equal(bi.find_channel(), np.where(chan.any(axis=1), chan.argmax(axis=1), -1))
+        assert np.array_equal(bi.is_channel(3), chan[:, 3]) and np.array_equal(bi.is_channel(cols), chan[np.arange(n), cols])
+        col7 = bi.get_column(7)
+        assert col7.shape == (n, 6)
+        for i in range(n):
+            assert np.array_equal(col7[i], st["bricks"][i]["alive"][42:48])
+        row2 = bi.get_row(2)
+        assert row2.shape == (n, 18) and np.array_equal(row2, st["bricks"]["alive"][:, 2:108:6])
+        bi.fill_column(cols)
+        assert not bi.is_channel(cols).any()
+        bi.clear_board(envs=[1, 5])
+        rem = bi.num_bricks_remaining()
+        assert rem[1] == 0 and rem[5] == 0 and (rem[[0, 2, 3]] > 0).all()
+        bi.set_row_alive(0, 1)
+        bi.set_brick_alive(107, 0)
+        assert (bi.get_row(0) == 1).all() and (bi.get_column(17)[:, 5] == 0).all()
+        pp = bi.get_paddle_position()
+        assert np.array_equal(pp[:, 0], st["paddle_x"]) and np.array_equal(pp[:, 1], st["paddle_y"])
+        assert np.array_equal(bi.get_paddle_velocity()[:, 0], st["paddle_vx"])
+        nb, pos = bi.get_ball_position()
+        assert np.array_equal(nb, st["n_balls"]) and np.array_equal(pos[:, 0, 0], np.where(nb > 0, st["ball_x"][:, 0], -1.0))
+        bi.set_paddle_position(100.5 + np.arange(n) * 0.25)
+        bi.set_ball(0, 60.0, 90.0, 1.0, -1.5, envs=nb > 0)
+        bi.set_lives(np.arange(n) % 4 + 1)
+        st2 = e.get_states_np()
+        assert np.array_equal(st2["paddle_x"], 100.5 + np.arange(n) * 0.25) and np.array_equal(st2["lives"], np.arange(n) % 4 + 1)
+        assert (st2["ball_vy"][nb > 0, 0] == -1.5).all() and np.array_equal(st2["ball_x"][nb == 0], st["ball_x"][nb == 0])
+        assert not bi.dirty_state and not bi.dirty_config      # device-side edits need no write-back
+    e.close()
+
+
+def test_amidar_helpers_against_numpy(lib):
+    n = 23
+    e = _played("amidar", n, lib, frames=400)
+    with BatchIntervention(e, 2, n - 4) as bi:                    # a sub-range of the batch
+        m = n - 4
+        st = e.get_states_np()[2:n - 2]
+        assert np.array_equal(bi.get_jump_mode(), st["jump_timer"] > 0) and np.array_equal(bi.get_chase_mode(), st["chase_timer"] > 0)
+        assert np.array_equal(bi.get_regular_mode(), (st["jump_timer"] == 0) & (st["chase_timer"] == 0))
+        ne = st["n_enemies"]
+        caught = np.array([st["enemies"][i]["caught"][:ne[i]].any() for i in range(m)])
+        assert np.array_equal(bi.any_enemy_caught(), caught)
+        tiles = st["tiles"]
+        for tx, ty in ((0, 0), (31, 30), (5, 6), (1, 1)):
+            assert list(bi.get_tile_by_pos(tx, ty)) == [["Empty", "Unpainted", "Painted", "ChaseMarker"][v] for v in tiles[:, ty, tx]]
+            assert np.array_equal(bi.is_tile_walkable(tx, ty), tiles[:, ty, tx] != 0)
+        for k, tag in enumerate(["Empty", "Unpainted", "Painted", "ChaseMarker"]):
+            assert np.array_equal(bi.count_tiles(tag), (tiles == k).reshape(m, -1).sum(axis=1))
+        adj = bi.get_adjacent_tiles(6, 6)
+        assert np.array_equal(adj, np.stack([tiles[:, 5, 6], tiles[:, 6, 5], tiles[:, 6, 7], tiles[:, 7, 6]], axis=1))
+        assert (bi.get_adjacent_tiles(0, 0)[:, :2] == -1).all()
+        ptx, pty = st["player"]["x"] // 64, st["player"]["y"] // 80
+        gx, gy, gtag = bi.player_tile()
+        assert np.array_equal(gx, ptx) and np.array_equal(gy, pty)
+        etx, ety = st["enemies"]["x"] // 64, st["enemies"]["y"] // 80
+        want = np.abs(etx - ptx[:, None]) + np.abs(ety - pty[:, None])
+        want[np.arange(8)[None, :] >= ne[:, None]] = -1
+        assert np.array_equal(bi.player_enemy_distances(), want)
+        want9 = np.abs(etx - 9) + np.abs(ety - 12)
+        want9[np.arange(8)[None, :] >= ne[:, None]] = -1
+        assert np.array_equal(bi.enemy_distances_from_tile(9, 12), want9)
+        on = tiles[np.arange(m), pty, ptx] == 2
+        assert np.array_equal(bi.player_on_painted(), on)
+        yy, xx = np.mgrid[0:31, 0:32]
+        for radius in (1, 3, 5):
+            near = (np.abs(xx[None] - ptx[:, None, None]) + np.abs(yy[None] - pty[:, None, None]) < radius) & (tiles != 0)
+            assert np.array_equal(bi.player_near_unpainted(radius), (near & (tiles == 2)).reshape(m, -1).sum(1) != near.reshape(m, -1).sum(1))
+        # edits
+        bi.set_mode("jump", envs=np.arange(m) < 5)
+        bi.set_mode("chase", set_time=np.arange(m) + 7)
+        bi.set_tile_tag(5, 6, "Painted")
+        bi.set_tile_tag(np.arange(m) % 32, 0, "ChaseMarker", envs=np.arange(m) % 3 == 0)
+        bi.set_jumps(5)
+        bi.set_player_tile(31, 15, envs=[0])
+        bi.set_enemy_protocol(1, "EnemyTargetPlayer", start={"tx": 0, "ty": 30}, start_dir="Right", vision_distance=9, dir="Up")
+        bi.set_enemy_protocol(0, "EnemyPerimeterAI", start={"tx": 0, "ty": 0}, envs=[2, 3])
+        all_st = e.get_states_np()
+        s2 = all_st[2:n - 2]
+        assert np.array_equal(s2["jump_timer"][:5], [75] * 5) and np.array_equal(s2["chase_timer"], np.arange(m) + 7)
+        assert (s2["tiles"][:, 6, 5] == 2).all() and (s2["jumps"] == 5).all()
+        for i in range(m):
+            assert s2["tiles"][i, 0, i % 32] == (3 if i % 3 == 0 else tiles[i, 0, i % 32])
+        assert s2["player"]["x"][0] == 31 * 64 and s2["player"]["y"][0] == 15 * 80
+        ai = s2["enemies"]["ai"][:, 1]
+        assert (ai["kind"] == 4).all() and (ai["vision_distance"] == 9).all() and (ai["dir"] == 0).all() and (ai["start_ty"] == 30).all()
+        assert (s2["enemies"]["ai"]["kind"][[2, 3], 0] == 2).all()
+        # the two envs on either side of the range were left alone
+        for k in (0, 1, n - 2, n - 1):
+            assert all_st["jumps"][k] != 5 or all_st["chase_timer"][k] == 0
+    for t in range(120):                                          # and the game goes on from there
+        e.step(synthetic_actions("amidar", n, t, seed=8), auto_reset=True)
+    e.close()
+
+
+def test_space_invaders_helpers(lib):
+    n = 12
+    e = _played("space_invaders", n, lib, frames=200)
+    with BatchIntervention(e) as bi:
+        st = e.get_states_np()
+        ship = bi.get_player()
+        assert np.array_equal(ship["x"], st["ship_x"]) and np.array_equal(ship["alive"], st["ship_alive"] != 0)
+        assert np.array_equal(ship["death_counter"], st["ship_death_counter"]) and np.array_equal(ship["speed"], st["ship_speed"])
+        bi.remove_mothership(envs=np.arange(n) < 6)
+        bi.set_lives(1, envs=[n - 1])
+        assert bi.get_jitter() == 0.5
+    s2 = e.get_states_np()
+    assert (s2["ufo_appearance_counter"][:6] == -1).all() and (s2["ufo_appearance_counter"][6:] >= 0).all() and s2["lives"][n - 1] == 1
+    with BatchIntervention(e) as bi:
+        bi.set_jitter(0.25)                                       # config intervention: new game on exit
+    assert e.get_config().jitter == 0.25 and (e.scalars()[0] == 0).all()
+    with pytest.raises(TypeError):
+        with BatchIntervention(e) as bi:
+            bi.channel_count()
+    with pytest.raises(Exception):
+        e.reduce(_abi_mod().QUERY_BRK_BALLS)
+    e.close()
+
+
+def _abi_mod():
+    from toybox_amd import _abi
+    return _abi
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", ["breakout", "amidar", "space_invaders"])
+def test_device_side_interventions_hip_equals_oracle(game, oracle_lib):
+    """The same sequence of batched helper calls on the HIP library and on the oracle (4 096 envs, per-env arguments and
+    masks): every query answer, every state record of a sample and the rollout from there are identical.  Breakout also with
+    intervention-written (non-canonical) bricks, where column / row come from the per-env tables."""
+    from toybox_amd import _lib
+    n = 4096
+    hip_lib = _lib.load()
+    g, o = _played(game, n, hip_lib, frames=300), _played(game, n, oracle_lib, frames=300)
+    rng = np.random.default_rng(11)
+    cols, mask = rng.integers(0, 18, n), rng.random(n) < 0.4
+    tx, ty = rng.integers(0, 32, n), rng.integers(0, 31, n)
+    answers = []
+    for e in (g, o):
+        out = []
+        with BatchIntervention(e) as bi:
+            if game == "breakout":
+                for rnd in range(2):
+                    bi.add_channel(cols, envs=mask)
+                    bi.fill_column((cols + 5) % 18)
+                    bi.set_row_alive(3, 0, envs=~mask)
+                    bi.set_paddle_position(40.0 + (np.arange(n) % 150))
+                    bi.set_ball(0, 100.0, 100.0, 1.25, -1.75, envs=mask)
+                    out += [bi.num_bricks_remaining(), bi.num_bricks(), bi.channel_count(), bi.find_channel(), bi.is_channel(cols),
+                            bi.get_column(4), bi.get_row(1), bi.get_paddle_position(), bi.get_ball_position()[1], bi.get_ball_velocity()[0]]
+                    if rnd == 0:                                   # now the same on per-env brick tables
+                        js = bi.json(7)
+                        js["bricks"][5]["col"] = 17
+                        js["bricks"][20]["position"]["x"] += 1.0
+                        bi.write_json(7, js)
+            elif game == "amidar":
+                bi.set_mode("jump", set_time=1 + (np.arange(n) % 50), envs=mask)
+                bi.set_mode("chase", envs=~mask)
+                bi.set_tile_tag(tx, ty, "Painted", envs=mask)
+                bi.set_player_tile(tx, ty, envs=np.arange(n) % 97 == 0)
+                bi.set_enemy_protocol(2, "EnemyRandomMvmt", start={"tx": 12, "ty": 12}, start_dir="Left", dir="Left", envs=mask)
+                bi.set_enemy_protocol(0, "EnemyAmidarMvmt", vert="Down", horiz="Right", start_vert="Down", start_horiz="Right", start={"tx": 6, "ty": 0})
+                bi.set_jumps(np.arange(n) % 6)
+                out += [bi.get_jump_mode(), bi.get_chase_mode(), bi.any_enemy_caught(), bi.count_tiles("Painted"), bi.count_tiles("Empty"),
+                        bi.get_adjacent_tiles(tx, ty), bi.enemy_distances_from_tile(tx, ty), np.stack(bi.player_tile()[:2]),
+                        bi.player_enemy_distances(), bi.player_on_painted(), bi.player_near_unpainted(4), bi.is_tile_walkable(tx, ty)]
+            else:
+                bi.remove_mothership(envs=mask)
+                bi.set_lives(1 + np.arange(n) % 3)
+                out += list(bi.get_player().values())
+        answers.append(out)
+    for k, (x, y) in enumerate(zip(*answers)):
+        assert np.array_equal(np.asarray(x), np.asarray(y)), (game, k)
+    sample = list(range(0, n, 61)) + [7]
+    for i in sample:
+        assert bytes(g.get_state(i)) == bytes(o.get_state(i)), (game, i)
+    for t in range(300):
+        a = synthetic_actions(game, n, t, seed=21)
+        for x, y in zip(g.step(a, auto_reset=True), o.step(a, auto_reset=True)):
+            assert np.array_equal(x, y), (game, t)
+    assert np.array_equal(g.render(3)[::97], o.render(3)[::97])
+    for i in sample:
+        assert bytes(g.get_state(i)) == bytes(o.get_state(i)), (game, i)
+
+
+def test_batched_helpers_equal_the_references_own_classes(oracle_lib):
+    """Build container only: tests/interventions_reference_worker.py imports the reference's UNMODIFIED
+    toybox.interventions.{breakout,amidar,space_invaders} (over the ctoybox shim, one-env oracle engines), replays each env's
+    state into it, calls the reference's helper and compares with what the batched form answered for that env."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    ref = os.environ.get("TOYBOX_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "toybox", "interventions")):
+        pytest.skip("the reference tree is only present in the build container")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests", "shim"), ROOT, os.path.join(ROOT, "tests"), ref]),
+               PYTHONDONTWRITEBYTECODE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "interventions_reference_worker.py")], cwd="/tmp", env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "WORKER_OK" in p.stdout, (p.stdout + p.stderr)[-4000:]

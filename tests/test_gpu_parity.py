@@ -171,24 +171,26 @@ def test_breakout_config_change_parity(hip_lib, oracle_lib):
     assert np.array_equal(g.render(3), o.render(3))
 
 
-def test_full_size_properties(hip_lib):
-    """BASELINE size (65536 envs): properties that need no oracle -- determinism of two identically seeded
-    engines' frames and outputs, reward == max(delta score, 0), done == (lives <= 0)."""
+@pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar"])
+def test_full_size_properties(game, hip_lib):
+    """BASELINE size (65536 envs), every game: properties that need no oracle -- determinism of two identically seeded
+    engines' frames and outputs (host actions on one, device-generated ones on the other), reward == max(delta score, 0),
+    done == (lives <= 0)."""
     n = 65536
-    a_eng = Engine("breakout", n, lib=hip_lib)
+    a_eng = Engine(game, n, lib=hip_lib)
     a_eng.seed(1234)
     a_eng.new_game()
     prev = np.zeros(n, np.int64)
     total = np.zeros(n, np.int64)
     for t in range(300):
-        r, d, l, s = a_eng.step(synthetic_actions("breakout", n, t), auto_reset=False)
+        r, d, l, s = a_eng.step(synthetic_actions(game, n, t), auto_reset=False)
         assert np.array_equal(r, np.maximum(s - prev, 0))
         assert np.array_equal(d, l <= 0)
         prev = s.astype(np.int64)
         total += r
     assert total.sum() > 0
     # a second engine, same seeds/actions, rendered in chunks: checksums must agree
-    b_eng = Engine("breakout", n, lib=hip_lib)
+    b_eng = Engine(game, n, lib=hip_lib)
     b_eng.seed(1234)
     b_eng.new_game()
     for t in range(300):
@@ -277,6 +279,27 @@ def test_full_size_batch_parity(game, hip_lib, oracle_lib, monkeypatch):
     for i in sample[:24]:
         assert np.array_equal(g.render_env(int(i), 3), o.render_env(int(i), 3)), i
     assert acc.sum() > 0 and (game != "breakout" or dones > 0)      # rewards flowed; Breakout games ended and restarted
+    # the bench's own launches at the bench's size: the batched RGB render of all 65 536 envs (Breakout: two parts), then the
+    # fused rollout call (Breakout: rasteriser + step in one launch), frames read back through device-side sampling
+    from toybox_amd import hip
+    H, W = g.height, g.width
+    fb = H * W * 3
+    picks = [0, 1, 1023, 1024, 1025, n - 1] + [int(i) for i in sample[:34]]
+    one = np.empty((H, W, 3), np.uint8)
+    for fused in (False, True):
+        want = [o.render_env(i, 3) for i in picks]
+        if fused:
+            g.render_step_synthetic(1337, steps, channels=3, auto_reset=True)
+            o.step(synthetic_actions(game, n, steps, seed=1337), auto_reset=True)
+        else:
+            g.render_device(0, 3)
+        g.sync()
+        p, nbytes = g.device_buffer(_abi.BUF_FRAME)
+        assert nbytes >= n * fb
+        for i, w in zip(picks, want):
+            hip.memcpy_dtoh(one, p + i * fb, fb)
+            assert np.array_equal(one, w), (game, fused, i)
+    _assert_states_equal(g, o, sample[:32])
 
 
 @pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar", "gridworld"])

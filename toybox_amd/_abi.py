@@ -30,6 +30,46 @@ OPT_RECORDS_ACTIVE = 101           # read-only: the rasteriser reads step-writte
 PIPELINE_OFF, PIPELINE_AUTO, PIPELINE_STEP_BESIDE_RENDER, PIPELINE_OVERLAP_RENDERS = 0, 1, 2, 3
 STEP_FORM_AUTO, STEP_FORM_THREAD_PER_ENV, STEP_FORM_WAVE_PER_ENV = 0, 1, 2
 
+# batched interventions (tbx_edit / tbx_reduce): ids as include/toybox_amd.h declares them
+QUERY_TILE_TO_WORLD = 1
+QUERY_WORLD_TO_TILE = 2
+EDIT_MAX_ARGS = 16
+EDIT_SET_LIVES = 1
+EDIT_SET_SCORE = 2
+EDIT_SET_LEVEL = 3
+EDIT_BRK_COLUMN_ALIVE = 10
+EDIT_BRK_ROW_ALIVE = 11
+EDIT_BRK_ALL_ALIVE = 12
+EDIT_BRK_BRICK_ALIVE = 13
+EDIT_BRK_PADDLE = 14
+EDIT_BRK_BALL = 15
+EDIT_AMI_TIMERS = 20
+EDIT_AMI_JUMPS = 21
+EDIT_AMI_TILE = 22
+EDIT_AMI_ENEMY_AI = 23
+EDIT_AMI_PLAYER_TILE = 24
+EDIT_SI_UFO_APPEARANCE = 30
+QUERY_BRK_BRICKS_REMAINING = 110
+QUERY_BRK_NUM_BRICKS = 111
+QUERY_BRK_COLUMN = 112
+QUERY_BRK_ROW = 113
+QUERY_BRK_IS_CHANNEL = 114
+QUERY_BRK_CHANNEL_COUNT = 115
+QUERY_BRK_FIND_CHANNEL = 116
+QUERY_BRK_PADDLE = 117
+QUERY_BRK_BALLS = 118
+QUERY_AMI_MODE = 120
+QUERY_AMI_ANY_CAUGHT = 121
+QUERY_AMI_TILE = 122
+QUERY_AMI_COUNT_TILES = 123
+QUERY_AMI_ADJACENT = 124
+QUERY_AMI_ENEMY_DISTANCES = 125
+QUERY_AMI_PLAYER_TILE = 126
+QUERY_AMI_PLAYER_ENEMY_DISTANCES = 127
+QUERY_AMI_PLAYER_ON_PAINTED = 128
+QUERY_AMI_PLAYER_NEAR_UNPAINTED = 129
+QUERY_SI_SHIP = 130
+
 BRK_MAX_BALLS, BRK_COLS, BRK_MAX_ROWS, BRK_MAX_BRICKS, BRK_MAX_STARTS, BRK_MAX_SEGMENTS = 4, 18, 14, 256, 8, 16
 
 
@@ -270,6 +310,11 @@ PROTOTYPES = {
     "tbx_get_config": (_i, [_vp, _vp, _sz]),
     "tbx_set_config": (_i, [_vp, _vp, _sz]),
     "tbx_query": (_i, [_vp, _i, _i, _p(C.c_int32), _i, _p(C.c_int32), _i]),
+    "tbx_reduce_width": (_i, [_i, _i]),
+    "tbx_edit": (_i, [_vp, _i, _vp, _i, _i, _vp]),
+    "tbx_edit_device": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    "tbx_reduce": (_i, [_vp, _i, _vp, _i, _i, _vp]),
+    "tbx_reduce_device": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "tbx_agent_init": (_i, [_vp, _p(AgentConfig)]),
     "tbx_agent_set_noops": (_i, [_vp, _vp]),
     "tbx_agent_reset": (_i, [_vp, _vp]),

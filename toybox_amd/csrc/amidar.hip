@@ -1811,6 +1811,121 @@ __global__ void ami_unpack_kernel(AmiDev d, int env, const tbx_amidar_state_t* i
     ami_store(d, env, lane, s);
 }
 
+// ------------------------------------------------------------------ batched interventions (tbx_edit / tbx_reduce)
+//
+// AmidarIntervention's helper methods (toybox/interventions/amidar.py:360-615) over the batch: one thread per env.  Mover fields
+// are written to the env-major table AND to the struct-of-arrays mirror of the per-frame fields (AmiDev::mh), like every writer.
+
+__device__ __forceinline__ int ami_floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+__device__ __forceinline__ void ami_mover_write(const AmiDev& d, int env, int field, int slot, int v)
+{
+    d.movers[((size_t)env * NMF + field) * 16 + slot] = v;
+    const int h = ami_hot_row(field);
+    if (h >= 0) d.mh[((size_t)h * MSLOTS + slot) * (size_t)d.n + env] = v;
+}
+__device__ __forceinline__ int ami_mover_read(const AmiDev& d, int env, int field, int slot) { return d.movers[((size_t)env * NMF + field) * 16 + slot]; }
+
+__device__ __forceinline__ int ami_tile_tag(const AmiDev& d, int env, int tx, int ty)
+{
+    if (tx < 0 || ty < 0 || tx >= BW || ty >= BH) return -1;
+    return (int)((d.tiles[(size_t)env * 32 + ty] >> (2 * tx)) & 3ull);
+}
+
+__global__ __launch_bounds__(256) void ami_edit_kernel(AmiDev d, int op, TbxEditArgs a, const uint8_t* __restrict__ mask)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n || (mask && !mask[env])) return;
+    const size_t N = (size_t)d.n;
+    switch (op) {
+    case TBX_EDIT_SET_LIVES: d.sc[(size_t)A_LIVES * N + env] = a.geti(env, 0); break;
+    case TBX_EDIT_SET_SCORE: d.sc[(size_t)A_SCORE * N + env] = a.geti(env, 0); break;
+    case TBX_EDIT_SET_LEVEL: d.sc[(size_t)A_LEVEL * N + env] = a.geti(env, 0); break;
+    case TBX_EDIT_AMI_JUMPS: d.sc[(size_t)A_JUMPS * N + env] = a.geti(env, 0); break;
+    case TBX_EDIT_AMI_TIMERS:
+        if (a.geti(env, 0) >= 0) d.sc[(size_t)A_JUMP_TIMER * N + env] = a.geti(env, 0);
+        if (a.geti(env, 1) >= 0) d.sc[(size_t)A_CHASE_TIMER * N + env] = a.geti(env, 1);
+        break;
+    case TBX_EDIT_AMI_TILE: {
+        const int tx = a.geti(env, 0), ty = a.geti(env, 1), tag = a.geti(env, 2) & 3;
+        if (tx >= 0 && ty >= 0 && tx < BW && ty < BH) {
+            uint64_t& w = d.tiles[(size_t)env * 32 + ty];
+            w = (w & ~(3ull << (2 * tx))) | ((uint64_t)tag << (2 * tx));
+        }
+        break;
+    }
+    case TBX_EDIT_AMI_ENEMY_AI: {
+        const int slot = a.geti(env, 0);
+        if (slot >= 0 && slot < d.sc[(size_t)A_N_ENEMIES * N + env])
+            for (int k = 0; k < 14; k++) ami_mover_write(d, env, M_KIND + k, slot, a.geti(env, 1 + k));
+        break;
+    }
+    case TBX_EDIT_AMI_PLAYER_TILE:
+        ami_mover_write(d, env, M_X, PLAYER_SLOT, a.geti(env, 0) * TBX_AMI_TILE_WX);
+        ami_mover_write(d, env, M_Y, PLAYER_SLOT, a.geti(env, 1) * TBX_AMI_TILE_WY);
+        break;
+    default: break;
+    }
+}
+
+__global__ __launch_bounds__(256) void ami_reduce_kernel(AmiDev d, int query, TbxEditArgs a, double* __restrict__ out, int width)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n) return;
+    const size_t N = (size_t)d.n;
+    double* o = out + (size_t)env * width;
+    const int ne = d.sc[(size_t)A_N_ENEMIES * N + env];
+    const int ptx = ami_floor_div(ami_mover_read(d, env, M_X, PLAYER_SLOT), TBX_AMI_TILE_WX);
+    const int pty = ami_floor_div(ami_mover_read(d, env, M_Y, PLAYER_SLOT), TBX_AMI_TILE_WY);
+    auto distances = [&](int tx, int ty) {
+        for (int i = 0; i < TBX_AMI_MAX_ENEMIES; i++) {
+            if (i >= ne) { o[i] = -1.0; continue; }
+            const int ex = ami_floor_div(ami_mover_read(d, env, M_X, i), TBX_AMI_TILE_WX), ey = ami_floor_div(ami_mover_read(d, env, M_Y, i), TBX_AMI_TILE_WY);
+            o[i] = abs(ex - tx) + abs(ey - ty);
+        }
+    };
+    switch (query) {
+    case TBX_QUERY_AMI_MODE: o[0] = d.sc[(size_t)A_JUMP_TIMER * N + env]; o[1] = d.sc[(size_t)A_CHASE_TIMER * N + env]; break;
+    case TBX_QUERY_AMI_ANY_CAUGHT: {
+        int any = 0;
+        for (int i = 0; i < ne; i++) any |= ami_mover_read(d, env, M_CAUGHT, i) != 0;
+        o[0] = any;
+        break;
+    }
+    case TBX_QUERY_AMI_TILE: o[0] = ami_tile_tag(d, env, a.geti(env, 0), a.geti(env, 1)); break;
+    case TBX_QUERY_AMI_COUNT_TILES: {
+        const int tag = a.geti(env, 0);
+        int c = 0;
+        for (int ty = 0; ty < BH; ty++)
+            for (int tx = 0; tx < BW; tx++) c += ami_tile_tag(d, env, tx, ty) == tag;
+        o[0] = c;
+        break;
+    }
+    case TBX_QUERY_AMI_ADJACENT: {
+        const int tx = a.geti(env, 0), ty = a.geti(env, 1);
+        o[0] = ami_tile_tag(d, env, tx, ty - 1); o[1] = ami_tile_tag(d, env, tx - 1, ty);
+        o[2] = ami_tile_tag(d, env, tx + 1, ty); o[3] = ami_tile_tag(d, env, tx, ty + 1);
+        break;
+    }
+    case TBX_QUERY_AMI_ENEMY_DISTANCES: distances(a.geti(env, 0), a.geti(env, 1)); break;
+    case TBX_QUERY_AMI_PLAYER_TILE: o[0] = ptx; o[1] = pty; o[2] = ami_tile_tag(d, env, ptx, pty); break;
+    case TBX_QUERY_AMI_PLAYER_ENEMY_DISTANCES: distances(ptx, pty); break;
+    case TBX_QUERY_AMI_PLAYER_ON_PAINTED: o[0] = ami_tile_tag(d, env, ptx, pty) == TBX_TILE_PAINTED; break;
+    case TBX_QUERY_AMI_PLAYER_NEAR_UNPAINTED: {
+        const int radius = a.geti(env, 0);
+        int near = 0, painted = 0;
+        for (int ty = 0; ty < BH; ty++)
+            for (int tx = 0; tx < BW; tx++) {
+                const int tag = ami_tile_tag(d, env, tx, ty);
+                if (abs(tx - ptx) + abs(ty - pty) < radius && tag != TBX_TILE_EMPTY) { near++; painted += tag == TBX_TILE_PAINTED; }
+            }
+        o[0] = painted != near;
+        break;
+    }
+    default: break;
+    }
+}
+
 __global__ void ami_scalars_kernel(AmiDev d, int32_t* score, int32_t* lives, int32_t* level)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2126,6 +2241,26 @@ struct AmiOps : GameOps {
         hipLaunchKernelGGL(ami_unpack_kernel, dim3(count), dim3(64), 0, s, d, env, (const tbx_amidar_state_t*)e->staging);
         TBX_HIP(hipGetLastError());
         recs_valid = false;
+        return TBX_OK;
+    }
+
+    int edit(tbx_engine* e, int op, const TbxEditArgs& a, const uint8_t* mask_dev, hipStream_t s) override
+    {
+        switch (op) {
+        case TBX_EDIT_SET_LIVES: case TBX_EDIT_SET_SCORE: case TBX_EDIT_SET_LEVEL: case TBX_EDIT_AMI_TIMERS: case TBX_EDIT_AMI_JUMPS:
+        case TBX_EDIT_AMI_TILE: case TBX_EDIT_AMI_ENEMY_AI: case TBX_EDIT_AMI_PLAYER_TILE: break;
+        default: return e->fail(TBX_E_INVALID, "amidar: unknown edit");
+        }
+        hipLaunchKernelGGL(ami_edit_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, op, a, mask_dev);
+        TBX_HIP(hipGetLastError());
+        recs_valid = false;
+        return TBX_OK;
+    }
+
+    int reduce(tbx_engine* e, int query, const TbxEditArgs& a, double* out_dev, int width, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(ami_reduce_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, query, a, out_dev, width);
+        TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 

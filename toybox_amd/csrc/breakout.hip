@@ -1594,6 +1594,128 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_fill_custom_kernel(BrkDev d, Br
     }
 }
 
+// ------------------------------------------------------------------ batched interventions (tbx_edit / tbx_reduce)
+//
+// The helper methods of the reference's BreakoutIntervention (toybox/interventions/breakout.py:303-429) over the whole batch:
+// one thread per env on the struct-of-arrays state.  Brick j's column / row are the canonical col = j / rows, row = j % rows,
+// or the per-env table's once an intervention has written non-canonical bricks.
+
+template <bool CUSTOM>
+__device__ __forceinline__ void brk_brick_rc(const BrkDev& d, int env, int j, int rows, int& row, int& col)
+{
+    if (CUSTOM) { row = d.custom[env].row[j]; col = d.custom[env].col[j]; }
+    else { col = j / rows; row = j - col * rows; }
+}
+
+template <bool CUSTOM>
+__global__ __launch_bounds__(256) void brk_edit_kernel(BrkDev d, int rows, int op, TbxEditArgs a, const uint8_t* __restrict__ mask)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n || (mask && !mask[env])) return;
+    const size_t N = (size_t)d.n;
+    switch (op) {
+    case TBX_EDIT_SET_LIVES: d.lives[env] = a.geti(env, 0); break;
+    case TBX_EDIT_SET_SCORE: d.score[env] = a.geti(env, 0); break;      // (like tbx_set_state: the next step's reward sees the jump)
+    case TBX_EDIT_SET_LEVEL: d.level[env] = a.geti(env, 0); break;
+    case TBX_EDIT_BRK_COLUMN_ALIVE: case TBX_EDIT_BRK_ROW_ALIVE: case TBX_EDIT_BRK_ALL_ALIVE: case TBX_EDIT_BRK_BRICK_ALIVE: {
+        const int nb = d.n_bricks[env];
+        const int key = a.geti(env, 0);
+        const bool on = a.geti(env, op == TBX_EDIT_BRK_ALL_ALIVE ? 0 : 1) != 0;
+        for (int k = 0; k < MAXK; k++) {
+            uint64_t w = d.alive[(size_t)k * N + env], sel = 0;
+            for (int b = 0; b < 64; b++) {
+                const int j = 64 * k + b;
+                if (j >= nb) break;
+                int row, col;
+                brk_brick_rc<CUSTOM>(d, env, j, rows, row, col);
+                const bool hit = op == TBX_EDIT_BRK_ALL_ALIVE || (op == TBX_EDIT_BRK_COLUMN_ALIVE && col == key) ||
+                                 (op == TBX_EDIT_BRK_ROW_ALIVE && row == key) || (op == TBX_EDIT_BRK_BRICK_ALIVE && j == key);
+                if (hit) sel |= 1ull << b;
+            }
+            w = on ? (w | sel) : (w & ~sel);
+            d.alive[(size_t)k * N + env] = w;
+        }
+        break;
+    }
+    case TBX_EDIT_BRK_PADDLE:
+        d.paddle[0 * N + env] = a.get(env, 0);
+        if (a.n >= 2) d.paddle[1 * N + env] = a.get(env, 1);
+        break;
+    case TBX_EDIT_BRK_BALL: {
+        const int b = a.geti(env, 0);
+        if (b >= 0 && b < MAXB && b < d.n_balls[env]) {
+            d.balls[(size_t)(0 * MAXB + b) * N + env] = a.get(env, 1); d.balls[(size_t)(1 * MAXB + b) * N + env] = a.get(env, 2);
+            d.balls[(size_t)(2 * MAXB + b) * N + env] = a.get(env, 3); d.balls[(size_t)(3 * MAXB + b) * N + env] = a.get(env, 4);
+        }
+        break;
+    }
+    default: break;
+    }
+}
+
+template <bool CUSTOM>
+__global__ __launch_bounds__(256) void brk_reduce_kernel(BrkDev d, int rows, int query, TbxEditArgs a, double* __restrict__ out, int width)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n) return;
+    const size_t N = (size_t)d.n;
+    double* o = out + (size_t)env * width;
+    const int nb = d.n_bricks[env];
+    uint64_t al[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) al[k] = d.alive[(size_t)k * N + env];
+    auto alive = [&](int j) { return (int)((sel4(j >> 6, al[0], al[1], al[2], al[3]) >> (j & 63)) & 1ull); };
+    switch (query) {
+    case TBX_QUERY_BRK_BRICKS_REMAINING: {
+        int c = 0;
+        for (int j = 0; j < nb; j++) c += alive(j);
+        o[0] = c;
+        break;
+    }
+    case TBX_QUERY_BRK_NUM_BRICKS: o[0] = nb; break;
+    case TBX_QUERY_BRK_COLUMN: case TBX_QUERY_BRK_ROW: {
+        const int key = a.geti(env, 0);
+        int m = 0;
+        for (int j = 0; j < nb && m < width; j++) {
+            int row, col;
+            brk_brick_rc<CUSTOM>(d, env, j, rows, row, col);
+            if ((query == TBX_QUERY_BRK_COLUMN ? col : row) == key) o[m++] = alive(j);
+        }
+        for (; m < width; m++) o[m] = -1.0;
+        break;
+    }
+    case TBX_QUERY_BRK_IS_CHANNEL: case TBX_QUERY_BRK_CHANNEL_COUNT: case TBX_QUERY_BRK_FIND_CHANNEL: {
+        // per column: bricks, alive bricks
+        const int ncols = query == TBX_QUERY_BRK_IS_CHANNEL ? 0 : (rows > 0 ? nb / rows : 0);
+        const int want = a.geti(env, 0);
+        int count = 0, first = -1, is = 0;
+        const int c0 = query == TBX_QUERY_BRK_IS_CHANNEL ? want : 0, c1 = query == TBX_QUERY_BRK_IS_CHANNEL ? want + 1 : ncols;
+        for (int cc = c0; cc < c1; cc++) {
+            int bricks = 0, live = 0;
+            for (int j = 0; j < nb; j++) {
+                int row, col;
+                brk_brick_rc<CUSTOM>(d, env, j, rows, row, col);
+                if (col == cc) { bricks++; live += alive(j); }
+            }
+            if (bricks > 0 && live == 0) { count++; if (first < 0) first = cc; is = 1; }
+        }
+        o[0] = query == TBX_QUERY_BRK_IS_CHANNEL ? is : query == TBX_QUERY_BRK_CHANNEL_COUNT ? count : first;
+        break;
+    }
+    case TBX_QUERY_BRK_PADDLE:
+        for (int i = 0; i < 4; i++) o[i] = d.paddle[(size_t)i * N + env];
+        break;
+    case TBX_QUERY_BRK_BALLS: {
+        const int n = d.n_balls[env];
+        o[0] = n;
+        for (int f = 0; f < 4; f++)
+            for (int b = 0; b < MAXB; b++) o[1 + f * MAXB + b] = b < n ? d.balls[(size_t)(f * MAXB + b) * N + env] : -1.0;
+        break;
+    }
+    default: break;
+    }
+}
+
 __global__ void brk_scalars_kernel(BrkDev d, int32_t* score, int32_t* lives, int32_t* level)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2004,6 +2126,30 @@ struct BreakoutOps : GameOps {
         else hipLaunchKernelGGL(brk_unpack_kernel<false>, dim3(count), dim3(64), 0, s, d, env, in);
         TBX_HIP(hipGetLastError());
         recs_valid = false;
+        return TBX_OK;
+    }
+
+    int edit(tbx_engine* e, int op, const TbxEditArgs& a, const uint8_t* mask_dev, hipStream_t s) override
+    {
+        switch (op) {
+        case TBX_EDIT_SET_LIVES: case TBX_EDIT_SET_SCORE: case TBX_EDIT_SET_LEVEL: case TBX_EDIT_BRK_COLUMN_ALIVE: case TBX_EDIT_BRK_ROW_ALIVE:
+        case TBX_EDIT_BRK_ALL_ALIVE: case TBX_EDIT_BRK_BRICK_ALIVE: case TBX_EDIT_BRK_PADDLE: case TBX_EDIT_BRK_BALL: break;
+        default: return e->fail(TBX_E_INVALID, "breakout: unknown edit");
+        }
+        const dim3 grid((e->n + 255) / 256), block(256);
+        if (custom) hipLaunchKernelGGL(brk_edit_kernel<true>, grid, block, 0, s, d, c.n_rows, op, a, mask_dev);
+        else hipLaunchKernelGGL(brk_edit_kernel<false>, grid, block, 0, s, d, c.n_rows, op, a, mask_dev);
+        TBX_HIP(hipGetLastError());
+        recs_valid = false;
+        return TBX_OK;
+    }
+
+    int reduce(tbx_engine* e, int query, const TbxEditArgs& a, double* out_dev, int width, hipStream_t s) override
+    {
+        const dim3 grid((e->n + 255) / 256), block(256);
+        if (custom) hipLaunchKernelGGL(brk_reduce_kernel<true>, grid, block, 0, s, d, c.n_rows, query, a, out_dev, width);
+        else hipLaunchKernelGGL(brk_reduce_kernel<false>, grid, block, 0, s, d, c.n_rows, query, a, out_dev, width);
+        TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 

@@ -304,6 +304,7 @@ int tbx_destroy(tbx_engine* e)
         if (pp.lane[k] && pp.lane[k] != e->stream) hipStreamDestroy(pp.lane[k]);
     }
     hipFree(e->actions);
+    hipFree(e->edit_args); hipFree(e->reduce_out);
     hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame_own); hipFree(e->staging); hipFree(e->scal); hipFree(e->one_frame); hipFree(e->io_dev);
     if (e->io_host) hipHostFree(e->io_host);
     if (e->scal_host) hipHostFree(e->scal_host);
@@ -1089,6 +1090,121 @@ int tbx_set_config(tbx_engine* e, const void* pod, size_t size)
     if (rc) return rc;
     if (r[0] == cur[0] && r[1] == cur[1]) return TBX_OK;
     return tbx_set_sim_rng(e, -1, r);
+}
+
+// ---- batched interventions (include/toybox_amd.h): field writes and per-env features over the state in HBM
+
+int tbx_reduce_width(int game, int query)
+{
+    switch (query) {
+    case TBX_QUERY_BRK_BRICKS_REMAINING: case TBX_QUERY_BRK_NUM_BRICKS: case TBX_QUERY_BRK_IS_CHANNEL: case TBX_QUERY_BRK_CHANNEL_COUNT:
+    case TBX_QUERY_BRK_FIND_CHANNEL: return game == TBX_GAME_BREAKOUT ? 1 : TBX_E_INVALID;
+    case TBX_QUERY_BRK_COLUMN: case TBX_QUERY_BRK_ROW: return game == TBX_GAME_BREAKOUT ? 32 : TBX_E_INVALID;
+    case TBX_QUERY_BRK_PADDLE: return game == TBX_GAME_BREAKOUT ? 4 : TBX_E_INVALID;
+    case TBX_QUERY_BRK_BALLS: return game == TBX_GAME_BREAKOUT ? 1 + 4 * TBX_BRK_MAX_BALLS : TBX_E_INVALID;
+    case TBX_QUERY_AMI_MODE: return game == TBX_GAME_AMIDAR ? 2 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_ANY_CAUGHT: case TBX_QUERY_AMI_TILE: case TBX_QUERY_AMI_COUNT_TILES: case TBX_QUERY_AMI_PLAYER_ON_PAINTED:
+    case TBX_QUERY_AMI_PLAYER_NEAR_UNPAINTED: return game == TBX_GAME_AMIDAR ? 1 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_ADJACENT: return game == TBX_GAME_AMIDAR ? 4 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_ENEMY_DISTANCES: case TBX_QUERY_AMI_PLAYER_ENEMY_DISTANCES: return game == TBX_GAME_AMIDAR ? TBX_AMI_MAX_ENEMIES : TBX_E_INVALID;
+    case TBX_QUERY_AMI_PLAYER_TILE: return game == TBX_GAME_AMIDAR ? 3 : TBX_E_INVALID;
+    case TBX_QUERY_SI_SHIP: return game == TBX_GAME_SPACE_INVADERS ? 8 : TBX_E_INVALID;
+    default: return TBX_E_INVALID;
+    }
+}
+
+static int edit_args(tbx_engine* e, const double* args, int n_args, int per_env, bool args_on_host, hipStream_t s, TbxEditArgs& a)
+{
+    if (n_args < 0 || n_args > TBX_EDIT_MAX_ARGS || (n_args > 0 && !args)) return e->fail(TBX_E_INVALID, "bad intervention arguments");
+    memset(&a, 0, sizeof a);
+    a.n = n_args;
+    a.per_env = nullptr;
+    if (!per_env || n_args == 0) {
+        for (int i = 0; i < n_args; i++) a.v[i] = args[i];                  // (a host pointer in every form)
+        return TBX_OK;
+    }
+    if (!args_on_host) { a.per_env = args; return TBX_OK; }
+    const size_t bytes = sizeof(double) * (size_t)e->n * (size_t)n_args;
+    if (e->edit_args_bytes < bytes) {
+        EHIP(hipStreamSynchronize(e->stream));
+        hipFree(e->edit_args);
+        e->edit_args = nullptr; e->edit_args_bytes = 0;
+        EHIP(hipMalloc((void**)&e->edit_args, bytes));
+        e->edit_args_bytes = bytes;
+    }
+    EHIP(hipMemcpyAsync(e->edit_args, args, bytes, hipMemcpyHostToDevice, s));
+    a.per_env = e->edit_args;
+    return TBX_OK;
+}
+
+int tbx_edit_device(tbx_engine* e, int op, const double* args, int n_args, int per_env, const uint8_t* mask_dev, void* stream)
+{
+    CHECK_ENGINE(e);
+    EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, (hipStream_t)stream));
+    TbxEditArgs a;
+    int rc = edit_args(e, args, n_args, per_env, false, (hipStream_t)stream, a);
+    if (rc) return rc;
+    return e->ops->edit(e, op, a, mask_dev, (hipStream_t)stream);
+}
+
+int tbx_edit(tbx_engine* e, int op, const double* args, int n_args, int per_env, const uint8_t* mask_host)
+{
+    CHECK_ENGINE(e);
+    EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
+    TbxEditArgs a;
+    int rc = edit_args(e, args, n_args, per_env, true, e->stream, a);
+    if (rc) return rc;
+    const uint8_t* m = nullptr;
+    if (mask_host) {
+        EHIP(hipMemcpyAsync(e->mask, mask_host, (size_t)e->n, hipMemcpyHostToDevice, e->stream));
+        m = e->mask;
+    }
+    rc = e->ops->edit(e, op, a, m, e->stream);
+    if (rc) return rc;
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_reduce_device(tbx_engine* e, int query, const double* args, int n_args, int per_env, double* out_dev, void* stream)
+{
+    CHECK_ENGINE(e);
+    const int width = tbx_reduce_width(e->game, query);
+    if (width < 0) return e->fail(TBX_E_INVALID, "unknown query for this game");
+    if (!out_dev) return e->fail(TBX_E_INVALID, "output pointer is NULL");
+    EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, (hipStream_t)stream));
+    TbxEditArgs a;
+    int rc = edit_args(e, args, n_args, per_env, false, (hipStream_t)stream, a);
+    if (rc) return rc;
+    return e->ops->reduce(e, query, a, out_dev, width, (hipStream_t)stream);
+}
+
+int tbx_reduce(tbx_engine* e, int query, const double* args, int n_args, int per_env, double* out_host)
+{
+    CHECK_ENGINE(e);
+    const int width = tbx_reduce_width(e->game, query);
+    if (width < 0) return e->fail(TBX_E_INVALID, "unknown query for this game");
+    if (!out_host) return e->fail(TBX_E_INVALID, "output pointer is NULL");
+    EHIP(hipSetDevice(e->device));
+    EHIP(tbx_use_stream(e, e->stream));
+    TbxEditArgs a;
+    int rc = edit_args(e, args, n_args, per_env, true, e->stream, a);
+    if (rc) return rc;
+    const size_t bytes = sizeof(double) * (size_t)e->n * (size_t)width;
+    if (e->reduce_out_bytes < bytes) {
+        EHIP(hipStreamSynchronize(e->stream));
+        hipFree(e->reduce_out);
+        e->reduce_out = nullptr; e->reduce_out_bytes = 0;
+        EHIP(hipMalloc((void**)&e->reduce_out, bytes));
+        e->reduce_out_bytes = bytes;
+    }
+    rc = e->ops->reduce(e, query, a, e->reduce_out, width, e->stream);
+    if (rc) return rc;
+    EHIP(hipMemcpyAsync(out_host, e->reduce_out, bytes, hipMemcpyDeviceToHost, e->stream));
+    EHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
 }
 
 int tbx_query(tbx_engine* e, int env, int query_id, const int32_t* args, int n_args, int32_t* out, int n_out)

@@ -1710,6 +1710,30 @@ __global__ void si_unpack_kernel(SiDev d, int env, const tbx_si_state_t* in)
     si_store(d, env, lane, s);
 }
 
+// ------------------------------------------------------------------ batched interventions (tbx_edit / tbx_reduce)
+// SpaceInvadersIntervention (toybox/interventions/space_invaders.py:159-176) over the batch, one thread per env on the [field][N] scalars
+__global__ __launch_bounds__(256) void si_edit_kernel(SiDev d, int op, TbxEditArgs a, const uint8_t* __restrict__ mask)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n || (mask && !mask[env])) return;
+    const size_t N = (size_t)d.n;
+    const int f = op == TBX_EDIT_SET_LIVES ? F_LIVES : op == TBX_EDIT_SET_SCORE ? F_SCORE : op == TBX_EDIT_SET_LEVEL ? F_LEVEL : F_UFO_APP;
+    d.sc[(size_t)f * N + env] = a.geti(env, 0);
+}
+
+__global__ __launch_bounds__(256) void si_reduce_kernel(SiDev d, int query, TbxEditArgs a, double* __restrict__ out, int width)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n) return;
+    const size_t N = (size_t)d.n;
+    double* o = out + (size_t)env * width;
+    auto F = [&](int f) { return d.sc[(size_t)f * N + env]; };
+    if (query == TBX_QUERY_SI_SHIP) {
+        o[0] = F(F_SHIP_X); o[1] = F(F_SHIP_Y); o[2] = F(F_SHIP_W); o[3] = F(F_SHIP_H); o[4] = F(F_SHIP_SPEED);
+        o[5] = F(F_SHIP_FLAGS) & 1; o[6] = F(F_SHIP_DC); o[7] = (F(F_SHIP_FLAGS) >> 1) & 1;
+    }
+}
+
 __global__ void si_scalars_kernel(SiDev d, int32_t* score, int32_t* lives, int32_t* level)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1998,6 +2022,23 @@ struct SiOps : GameOps {
         hipLaunchKernelGGL(si_unpack_kernel, dim3(count), dim3(64), 0, s, d, env, (const tbx_si_state_t*)e->staging);
         TBX_HIP(hipGetLastError());
         recs_valid = false;
+        return TBX_OK;
+    }
+
+    int edit(tbx_engine* e, int op, const TbxEditArgs& a, const uint8_t* mask_dev, hipStream_t s) override
+    {
+        if (op != TBX_EDIT_SET_LIVES && op != TBX_EDIT_SET_SCORE && op != TBX_EDIT_SET_LEVEL && op != TBX_EDIT_SI_UFO_APPEARANCE)
+            return e->fail(TBX_E_INVALID, "space_invaders: unknown edit");
+        hipLaunchKernelGGL(si_edit_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, op, a, mask_dev);
+        TBX_HIP(hipGetLastError());
+        recs_valid = false;
+        return TBX_OK;
+    }
+
+    int reduce(tbx_engine* e, int query, const TbxEditArgs& a, double* out_dev, int width, hipStream_t s) override
+    {
+        hipLaunchKernelGGL(si_reduce_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, query, a, out_dev, width);
+        TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 

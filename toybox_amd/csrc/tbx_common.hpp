@@ -374,6 +374,10 @@ struct tbx_engine {
     size_t frame_own_bytes = 0;
     uint8_t* frame = nullptr;       // what TBX_BUF_FRAME reports: frame_own, or in pipelined mode the buffer the last render wrote
     size_t frame_bytes = 0;
+    double* edit_args = nullptr;    // [N][n_args] per-env arguments of tbx_edit / tbx_reduce (host-pointer forms)
+    size_t edit_args_bytes = 0;
+    double* reduce_out = nullptr;   // [N][width] result staging of tbx_reduce
+    size_t reduce_out_bytes = 0;
     void* staging = nullptr;        // device POD staging for get/set state
     size_t staging_bytes = 0;
     GameOps* ops = nullptr;
@@ -466,6 +470,21 @@ inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s)
     return hipSuccess;
 }
 
+// arguments of a batched intervention (tbx_edit / tbx_reduce): the same row for every env, or one row per env in HBM
+struct TbxEditArgs {
+    double v[TBX_EDIT_MAX_ARGS];
+    int n;
+    const double* per_env;        // device [N][n] or nullptr
+    __device__ __forceinline__ double get(int env, int i) const { return i >= n ? 0.0 : per_env ? per_env[(size_t)env * n + i] : v[i]; }
+    __device__ __forceinline__ int geti(int env, int i) const
+    {
+        double x = get(env, i);
+        if (!(x > -2.0e9)) x = -2.0e9;
+        if (x > 2.0e9) x = 2.0e9;
+        return (int)x;
+    }
+};
+
 // per-game operations; all launches are asynchronous on `s`
 struct GameOps {
     virtual ~GameOps() {}
@@ -515,6 +534,9 @@ struct GameOps {
     // (engines whose rasteriser reads step-written records); render_step_fused() false: the engine runs render(), then step()
     virtual bool render_step_fused(int /*channels*/) const { return false; }
     virtual int render_step(tbx_engine*, uint8_t* /*out_dev*/, int /*channels*/, const ActionSource&, uint32_t /*flags*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    // batched interventions (include/toybox_amd.h, tbx_edit / tbx_reduce): one kernel over the selected envs
+    virtual int edit(tbx_engine* e, int /*op*/, const TbxEditArgs&, const uint8_t* /*mask_dev*/, hipStream_t) { return e->fail(TBX_E_INVALID, "this game has no such edit"); }
+    virtual int reduce(tbx_engine* e, int /*query*/, const TbxEditArgs&, double* /*out_dev*/, int /*width*/, hipStream_t) { return e->fail(TBX_E_INVALID, "this game has no such query"); }
     // an engine option changed (tbx_set_option): pick it up
     virtual void options_changed(tbx_engine*) {}
     // generic path: full-resolution gray frames of slot A (source 1), slot B (2) or the live state (0); envs whose

@@ -209,6 +209,48 @@ class Engine:
             raise TypeError("config must be a %s" % self.config_type.__name__)
         self._check(self._lib.tbx_set_config(self._h, C.byref(cfg), C.sizeof(cfg)))
 
+    # ------------------------------------------------------------------ batched interventions on the device
+    def _edit_args(self, args):
+        """args: a sequence of scalars (the same for every env) or an array [N, n_args] (one row per env)"""
+        a = np.ascontiguousarray(args, dtype=np.float64)
+        if a.ndim == 2:
+            if a.shape[0] != self.n_envs:
+                raise ValueError("per-env arguments need one row per env (%d), got %d" % (self.n_envs, a.shape[0]))
+            return a, a.shape[1], 1
+        a = a.reshape(-1)
+        return a, a.shape[0], 0
+
+    def edit(self, op, args=(), mask=None):
+        """tbx_edit: one field write in every env whose mask entry is true (mask None: all) -- a kernel over the state in HBM,
+        no state record crosses PCIe.  args as in _edit_args."""
+        a, n, per_env = self._edit_args(args)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(np.asarray(mask).astype(bool), dtype=np.uint8)
+            if m.shape != (self.n_envs,):
+                raise ValueError("mask must have one entry per env")
+        self._check(self._lib.tbx_edit(self._h, int(op), _ptr(a) if n else None, n, per_env, _ptr(m) if m is not None else None))
+
+    def reduce(self, query, args=()):
+        """tbx_reduce: a per-env feature as float64 [N, width] (integers are exact; missing entries read -1)"""
+        width = self._lib.tbx_reduce_width(_abi.GAME_IDS[self.game], int(query))
+        if width < 0:
+            raise ToyboxAmdError(width, "unknown query %d for %s" % (query, self.game))
+        a, n, per_env = self._edit_args(args)
+        out = np.empty((self.n_envs, width), np.float64)
+        self._check(self._lib.tbx_reduce(self._h, int(query), _ptr(a) if n else None, n, per_env, _ptr(out)))
+        return out
+
+    def edit_device(self, op, args=(), mask_ptr=0, stream=0):
+        """asynchronous form: mask (and per-env args, given as an int address with n_args) already in HBM"""
+        a, n, per_env = self._edit_args(args)
+        self._check(self._lib.tbx_edit_device(self._h, int(op), _ptr(a) if n else None, n, 0, C.c_void_p(int(mask_ptr)) if mask_ptr else None,
+                                              C.c_void_p(int(stream))))
+
+    def reduce_device(self, query, out_ptr, args=(), stream=0):
+        a, n, per_env = self._edit_args(args)
+        self._check(self._lib.tbx_reduce_device(self._h, int(query), _ptr(a) if n else None, n, 0, C.c_void_p(int(out_ptr)), C.c_void_p(int(stream))))
+
     def query(self, env, query_id, args, n_out=2):
         a = (C.c_int32 * len(args))(*[int(v) for v in args])
         out = (C.c_int32 * n_out)()
