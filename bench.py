@@ -675,7 +675,7 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
     for _ in range(args.preroll):          # untimed: bring the batch to mid-game states (episodes end, auto-resets fire)
         eng.step_synthetic(ACTION_SEED, t, env_offset=start, auto_reset=True, stream=stream.ptr)
         t += 1
-    fused = render and args.loop != "pair" and game == "breakout" and C >= 3 and eng.get_option(_abi.OPT_RECORDS_ACTIVE) == 1
+    fused = render and args.loop != "pair" and C >= 3 and eng.get_option(_abi.OPT_RENDER_STEP_FUSED) == 1
     rep, render_ms, mode, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, args.pipeline, t, K, Wm, R, fused=fused)
     res = {"n": n, "n_total": n_total, "start": start, "H": H, "W": W, "C": C, "render": render, "gather": gather, "rccl": rccl,
            "gather_note": gather_note, "rep": rep, "render_ms": render_ms, "mode": mode, "fused": fused,
@@ -860,7 +860,7 @@ def strong_share_probe(args, game, C, n_single, single_value):
         for t in range(args.preroll):
             eng.step_synthetic(ACTION_SEED, t, auto_reset=True, stream=st.ptr)
         reg = Region(hip.synchronize, lambda: eng.gather_reduce_max(0.0), lambda v: eng.gather_reduce_max(v))
-        fused = want_fused and game == "breakout" and C >= 3 and eng.get_option(_abi.OPT_RECORDS_ACTIVE) == 1
+        fused = want_fused and C >= 3 and eng.get_option(_abi.OPT_RENDER_STEP_FUSED) == 1
         rep, rms, mode, _ = timed_arm(eng, hip, reg, st, 0, C, True, True, args.pipeline, args.preroll, K, 20, 5, fused=fused)
         v = n / (rep["ms_per_step_median"] * 1e-3)
         res[key] = {"value": v, "ms_per_step": rep["ms_per_step_median"], "repeats": rep, "loop": "fused" if fused else "pair",

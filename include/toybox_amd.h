@@ -415,7 +415,7 @@ int tbx_render_device(tbx_engine* engine, uint8_t* out_dev, int channels, void* 
  * every env one frame with device-generated actions (the rule of tbx_step_synthetic) -- i.e. tbx_render_device followed by
  * tbx_step_synthetic, asynchronous on `stream`, same results bit for bit: the frame shows the state BEFORE the step, the
  * TBX_BUF_* outputs and the state are the step's.  Where the rasteriser reads step-written render records (Breakout with the
- * canonical wall, RGB / RGBA) both halves are ONE launch: the step's few blocks ride in front of the rasteriser's, write the
+ * canonical wall, SpaceInvaders with the canonical formation; RGB / RGBA) both halves are ONE launch: the step's blocks ride with the rasteriser's, write the
  * other records buffer and hide in the launch's ramp-up, so a loop of these calls runs like a render-only loop -- no kernel
  * boundary per frame, no rasteriser that starts in lockstep behind a short kernel (8 192 envs + gather, the per-GPU share of
  * the strong-scaled headline batch: see DESIGN.md section 6).  Only a loop whose actions do not depend on the frame can use
@@ -679,6 +679,9 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  * the canonical formation), 0 once an intervention has switched the engine to the state-reading rasteriser, or for games
  * without records */
 #define TBX_OPT_RECORDS_ACTIVE  101
+/* read-only: 1 if tbx_render_step_synthetic(channels = 3) is ONE launch on this engine right now (the rasteriser reads
+ * step-written records and the game has a fused kernel), 0 if it is the two launches in stream order */
+#define TBX_OPT_RENDER_STEP_FUSED 102
 int tbx_set_option(tbx_engine* engine, int option, int value);
 int tbx_get_option(tbx_engine* engine, int option, int* value_out);
 /* Block until all work queued by this engine has finished; reports a pending TBX_E_ACTION. */

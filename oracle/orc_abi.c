@@ -1007,7 +1007,7 @@ int tbx_set_option(tbx_engine* e, int option, int value)
 int tbx_get_option(tbx_engine* e, int option, int* value_out)
 {
     if (!e) return TBX_E_INVALID;
-    if (value_out && (option == TBX_OPT_PIPELINE_ACTIVE || option == TBX_OPT_RECORDS_ACTIVE)) { *value_out = 0; return TBX_OK; }   /* nothing to overlap on one CPU thread */
+    if (value_out && (option == TBX_OPT_PIPELINE_ACTIVE || option == TBX_OPT_RECORDS_ACTIVE || option == TBX_OPT_RENDER_STEP_FUSED)) { *value_out = 0; return TBX_OK; }   /* nothing to overlap on one CPU thread */
     if (option < 0 || option >= TBX_OPT_COUNT || !value_out) return fail(e, TBX_E_INVALID, "unknown option");
     *value_out = e->opt[option];
     return TBX_OK;

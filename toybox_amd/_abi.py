@@ -27,6 +27,7 @@ GATHER_ID_BYTES = 128
 OPT_PIPELINE, OPT_STEP_FORM, OPT_RENDER_SPLIT, OPT_AGENT_GENERIC, OPT_RESIDENT_STEP, OPT_GATHER_EVERY = 0, 1, 2, 3, 4, 5
 OPT_PIPELINE_ACTIVE = 100          # read-only: what OPT_PIPELINE resolves to on the engine
 OPT_RECORDS_ACTIVE = 101           # read-only: the rasteriser reads step-written render records
+OPT_RENDER_STEP_FUSED = 102        # read-only: tbx_render_step_synthetic is one launch on this engine
 PIPELINE_OFF, PIPELINE_AUTO, PIPELINE_STEP_BESIDE_RENDER, PIPELINE_OVERLAP_RENDERS = 0, 1, 2, 3
 STEP_FORM_AUTO, STEP_FORM_THREAD_PER_ENV, STEP_FORM_WAVE_PER_ENV = 0, 1, 2
 

@@ -1359,45 +1359,6 @@ __device__ __forceinline__ uint32_t ami_hud_word(const int32_t* f)
     return hud | ((uint32_t)lv << 20) | ((uint32_t)jp << 24) | ((uint32_t)le << 28);
 }
 
-// ------------------------------------------------------------------ rasteriser input record (pipelined mode)
-//
-// Amidar's painter reads the whole state (board rows, boxes, movers: ~3 KB per env).  For a step to run beside the previous
-// frame's rasteriser the painter has to read something the step does not write: in pipelined mode the step is followed, ON THE
-// STEP'S STREAM (i.e. beside the previous rasteriser), by ami_rec_prep_kernel, which digests the state into one of two buffers
-// of 512-byte records -- board rows, painted-box interiors, mover screen positions (clamped to +-1000, far off screen either
-// way), HUD digits -- and the rasteriser of the frame paints from that.  Outside the pipelined mode nothing changes: a prep
-// launch in stream order would only add its own time.
-struct alignas(64) AmiRenderRec {
-    uint64_t tiles[32];          // lane = board row
-    uint32_t inner[32];          // lane = board row: tiles strictly inside a painted box
-    uint32_t mover_xy[16];       // lane = mover slot: (uint16)screen x | (uint16)screen y << 16
-    uint32_t shown;              // bit = mover slot drawn
-    uint32_t hud;
-    uint32_t _pad[14];
-};
-static_assert(sizeof(AmiRenderRec) == 512, "render record layout");
-
-__device__ __forceinline__ int ami_clamp_px(int v) { return v < -1000 ? -1000 : v > 1000 ? 1000 : v; }
-
-__global__ __launch_bounds__(TBX_BLOCK) void ami_rec_prep_kernel(AmiDev d, AmiRenderRec* __restrict__ recs, int first_env, int count)
-{
-    const int lane = threadIdx.x & 63;
-    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-    if (rel >= count) return;
-    const int env = first_env + rel;
-    AmiRegs s;
-    ami_load(d, env, lane, s);
-    AmiRenderRec& r = recs[env];
-    const uint32_t inner = ami_inner_of(s, lane);
-    if (lane < 32) { r.tiles[lane] = s.trow; r.inner[lane] = inner; }
-    const bool shown = lane < MSLOTS && ami_mover_shown(s, lane);
-    if (lane < 16)
-        r.mover_xy[lane] = ((uint32_t)ami_clamp_px(ami_mover_px(s.mv[M_X], TBX_AMI_BOARD_OX)) & 0xFFFFu) |
-                           ((uint32_t)ami_clamp_px(ami_mover_px(s.mv[M_Y], TBX_AMI_BOARD_OY)) << 16);
-    const uint64_t shown_mask = __ballot(shown);
-    if (lane == 0) { r.shown = (uint32_t)shown_mask; r.hud = ami_hud_word(s.f); }
-}
-
 // Everything one wave needs to paint scanlines of one env; lane l makes pixels 4l..4l+3 of each scanline (160 px = 40
 // lanes).  In the board band a lane's 4 pixels are exactly one tile (tile = 4x5 px, board origin x = 16).  Built once
 // per frame by setup(); paint_row() then composes one scanline (board, movers in index order then the player, HUD).
@@ -1435,19 +1396,6 @@ struct AmiPainter {
         m_on = ami_mover_shown(s, lane);
         m_x0 = ami_mover_px(s.mv[M_X], TBX_AMI_BOARD_OX); m_y0 = ami_mover_px(s.mv[M_Y], TBX_AMI_BOARD_OY);
         finish_setup(t, ami_hud_word(s.f), cls);
-    }
-
-    // the same from a render record (pipelined mode: AmiOps::step_ahead leaves one behind every step)
-    __device__ __forceinline__ void setup(const AmiRenderRec* __restrict__ recs, const AmiTables& t, int env, int lane_, uint32_t* cls)
-    {
-        lane = lane_;
-        const AmiRenderRec& r = recs[env];
-        s.trow = r.tiles[lane & 31];
-        inner = r.inner[lane & 31];
-        const uint32_t mxy = r.mover_xy[lane & 15];
-        m_on = lane < MSLOTS && ((r.shown >> lane) & 1u);
-        m_x0 = (int)(int16_t)(mxy & 0xFFFFu); m_y0 = (int)(int16_t)(mxy >> 16);
-        finish_setup(t, r.hud, cls);
     }
 
     // hudw: 4-bit digits, score 10^4..10^0 (bits 0..19), lives, jumps, level
@@ -1660,26 +1608,6 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_render_kernel(AmiDev d, uint8_t
                                                                const uint8_t* __restrict__ pick_alt)
 {
     ami_render_body<C, ALT>(d, out, first_env, count, split, d_alt, pick_alt);
-}
-
-template <int C>
-__global__ __launch_bounds__(TBX_BLOCK) void ami_rec_render_kernel(const AmiRenderRec* __restrict__ recs, const AmiTables* __restrict__ tab, uint8_t* out,
-                                                                   int first_env, int count, int split)
-{
-    constexpr int W = TBX_AMI_W, H = TBX_AMI_H;
-    using Stager = RowStager<C, W, AMI_UNIT_ROWS>;
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
-    __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][AmiPainter<C>::NLDS * 8];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
-    const int rel = wid / split, part = wid - rel * split;
-    if (rel >= count) return;
-    const int env = first_env + rel;
-    Stager st{lds_all + wave * Stager::UNIT_BYTES};
-    AmiPainter<C> p;
-    p.setup(recs, *tab, env, lane, lds_mask[wave]);
-    ami_paint_units<C>(p, out + (size_t)rel * H * W * C, env, lane, st, part, split);
 }
 
 // ------------------------------------------------------------------ resident single-env form (tbx_serve_loop, tbx_common.hpp)
@@ -1943,14 +1871,6 @@ struct AmiOps : GameOps {
     tbx_amidar_config_t cfg{};
     AmiTables tab{};
     AmiTables* tab_dev = nullptr;
-    // pipelined mode: two buffers of rasteriser input records, `recs` the current one (ami_rec_prep_kernel fills the other one
-    // right behind a step that runs ahead).  Allocated when the mode is first used; records are only current straight after such
-    // a step -- anything else that touches state clears recs_valid and the state-reading rasteriser paints.
-    AmiRenderRec* recs = nullptr;
-    AmiRenderRec* recs_other = nullptr;
-    int recs_par = 0;
-    bool recs_valid = false;
-
     int height() const override { return TBX_AMI_H; }
     int width() const override { return TBX_AMI_W; }
     size_t state_size() const override { return sizeof(tbx_amidar_state_t); }
@@ -2029,7 +1949,6 @@ struct AmiOps : GameOps {
 
     void destroy(tbx_engine*) override
     {
-        hipFree(recs); hipFree(recs_other);
         hipFree(d.rng); hipFree(d.sc); hipFree(d.tiles); hipFree(d.boxes); hipFree(d.movers); hipFree(d.mh); hipFree(tab_dev);
         hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.tiles); hipFree(dA.boxes); hipFree(dA.movers); hipFree(dA.mh);
         hipFree(dB.rng); hipFree(dB.sc); hipFree(dB.tiles); hipFree(dB.boxes); hipFree(dB.movers); hipFree(dB.mh);
@@ -2051,42 +1970,23 @@ struct AmiOps : GameOps {
     {
         hipLaunchKernelGGL(ami_new_game_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, mask_dev);
         TBX_HIP(hipGetLastError());
-        recs_valid = false;
         return TBX_OK;
     }
 
-    // pipelined mode (engine.hip): the step, then the rasteriser's records into the buffer that is not being painted from
-    bool pipeline_ok() const override { return true; }
-    // ... but it does not pay, so the engine never picks it by itself.  Measured at 65 536 envs (rocprofv3 trace of bench.py --game
-    // amidar --pipeline 2, profiles/r03_amidar_pipeline2_*): the step starts with the render it runs beside, as intended, but takes
-    // 420-520 us there instead of 45 (thread form; its blocks hold 17 KB of LDS each for that long) and the rasteriser beside it
-    // 1.69-1.72 ms instead of 1.37: 1.73 ms per step against 1.49 in stream order (wave-per-env step: 1.83 against 1.54).
-    // (pipeline_auto stays 0: never the engine's choice)
-    int records_parity() const override { return recs_par; }
-    bool records_valid() const override { return recs_valid; }
+    // The rasteriser reads live state, so a step never runs beside or inside a rasteriser launch (GameOps::pipeline_ok and
+    // render_step_fused stay false; tbx_render_step_synthetic is the two launches in stream order).  Both were built and measured
+    // slower than stream order at every batch size: records behind the step on a second stream (round 3: the step took
+    // 420-520 us beside a rasteriser instead of 45, the rasteriser 1.69-1.72 ms instead of 1.37) and the step's thread-per-env
+    // form riding in the rasteriser's launch with the records written by the step itself (round 4, 80-VGPR budget of the
+    // six-waves-per-SIMD launch: 1.61 against 1.47 ms per step at 65 536 envs, 0.160 against 0.106 at 4 096) -- the step is a chain
+    // of dependent loads, and beside a kernel that saturates the memory system with stores every one of them queues.
     void rebind_outputs(tbx_engine* e) override
     {
         d.reward = e->reward; d.done = e->done; d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed;
     }
-    int step_ahead(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
-    {
-        if (!recs) {
-            TBX_HIP(hipMalloc((void**)&recs, sizeof(AmiRenderRec) * (size_t)e->n));
-            TBX_HIP(hipMalloc((void**)&recs_other, sizeof(AmiRenderRec) * (size_t)e->n));
-        }
-        int rc = step(e, src, flags, s);
-        if (rc) return rc;
-        hipLaunchKernelGGL(ami_rec_prep_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, recs_other, 0, e->n);
-        TBX_HIP(hipGetLastError());
-        std::swap(recs, recs_other);
-        recs_par ^= 1;
-        recs_valid = true;
-        return TBX_OK;
-    }
 
     int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
     {
-        recs_valid = false;
         int first = 0, count = e->n;
         if (src.single_env >= 0) { first = src.single_env; count = 1; }
         dA.tab = dB.tab = d.tab;
@@ -2123,7 +2023,6 @@ struct AmiOps : GameOps {
     {
         hipLaunchKernelGGL(ami_serve_kernel, dim3(1), dim3(64 * TBX_SERVE_WAVES), 0, s, d, ctl_dev);   // (paints on request: serve_paints)
         TBX_HIP(hipGetLastError());
-        recs_valid = false;
         return TBX_OK;
     }
 
@@ -2175,7 +2074,6 @@ struct AmiOps : GameOps {
         const dim3 grid = r.list ? dim3(std::min<unsigned>(grid_for(e->n).x, 512u)) : grid_for(e->n);
         hipLaunchKernelGGL(ami_agent_reset_kernel, grid, dim3(TBX_BLOCK), 0, s, d, dA, dB, r);
         TBX_HIP(hipGetLastError());
-        recs_valid = false;
         return TBX_OK;
     }
 
@@ -2188,18 +2086,6 @@ struct AmiOps : GameOps {
 
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
     {
-        if (e->pipe.active && recs_valid) {       // pipelined loop: from the records the last step left (a step may be writing state now)
-            const int split_opt = e->opt[TBX_OPT_RENDER_SPLIT];
-            const int split = split_opt > 0 ? split_opt : channels == 3 ? 9 : (channels == 1 && n_envs <= 4096) ? 4 : 1;
-            switch (channels) {
-            case 1: hipLaunchKernelGGL(ami_rec_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, tab_dev, out_dev, first_env, n_envs, split); break;
-            case 3: hipLaunchKernelGGL(ami_rec_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, tab_dev, out_dev, first_env, n_envs, split); break;
-            case 4: hipLaunchKernelGGL(ami_rec_render_kernel<4>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, tab_dev, out_dev, first_env, n_envs, split); break;
-            default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
-            }
-            TBX_HIP(hipGetLastError());
-            return TBX_OK;
-        }
         return render_impl(e, d, d, nullptr, out_dev, channels, first_env, n_envs, s);
     }
 
@@ -2240,7 +2126,6 @@ struct AmiOps : GameOps {
         TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof(tbx_amidar_state_t) * (size_t)count, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(ami_unpack_kernel, dim3(count), dim3(64), 0, s, d, env, (const tbx_amidar_state_t*)e->staging);
         TBX_HIP(hipGetLastError());
-        recs_valid = false;
         return TBX_OK;
     }
 
@@ -2253,7 +2138,6 @@ struct AmiOps : GameOps {
         }
         hipLaunchKernelGGL(ami_edit_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, op, a, mask_dev);
         TBX_HIP(hipGetLastError());
-        recs_valid = false;
         return TBX_OK;
     }
 

@@ -1276,6 +1276,7 @@ int tbx_get_option(tbx_engine* e, int option, int* value_out)
     CHECK_ENGINE(e);
     if (value_out && option == TBX_OPT_PIPELINE_ACTIVE) { *value_out = pipe_mode(e); return TBX_OK; }
     if (value_out && option == TBX_OPT_RECORDS_ACTIVE) { *value_out = e->ops->pipeline_ok() ? 1 : 0; return TBX_OK; }
+    if (value_out && option == TBX_OPT_RENDER_STEP_FUSED) { *value_out = e->ops->render_step_fused(3) ? 1 : 0; return TBX_OK; }
     if (option < 0 || option >= TBX_OPT_COUNT || !value_out) return e->fail(TBX_E_INVALID, "unknown option");
     *value_out = e->opt[option];
     return TBX_OK;
