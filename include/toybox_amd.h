@@ -647,10 +647,10 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  *   Contract in this mode: the stream a call names still waits for the call's work, so anything queued on it afterwards sees
  *   the result; the result of step N (render N) stays valid for readers queued on that stream BEFORE step N+1 (render N+1)
  *   is issued -- the same rule as without the option -- but it lives at the address tbx_device_buffer reports after the
- *   call, which alternates.  Every other call on the handle first joins the pipeline.  Amidar takes part through a record
- *   kernel that follows its step on the internal stream (values 2 and 3 only: measured slower than stream order, its step is
- *   long enough to disturb the rasteriser it runs beside).  Engines whose rasteriser can only read live state (GridWorld,
- *   Breakout with intervention-written bricks, SpaceInvaders with intervention-written enemy positions) ignore the option. */
+ *   call, which alternates.  Every other call on the handle first joins the pipeline.  Engines whose rasteriser reads live
+ *   state (Amidar, GridWorld, Breakout with intervention-written bricks, SpaceInvaders with intervention-written enemy
+ *   positions) ignore the option.  (Round 3 let Amidar take part through a record kernel behind its step: slower than stream
+ *   order at every size -- its step, a chain of dependent loads, runs ten times longer beside a rasteriser -- and removed.) */
 #define TBX_OPT_PIPELINE      0
 /* batch step kernel form of Breakout and Amidar: 0 = the engine's choice (by batch size), 1 = one thread per env, 2 = one
  * wavefront per env */

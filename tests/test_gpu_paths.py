@@ -770,7 +770,7 @@ def test_render_step_synthetic_call_contract(game, lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("game,n,channels", [("breakout", 20000, 3), ("breakout", 8192, 4), ("breakout", 300, 3), ("breakout", 5000, 1),
-                                             ("space_invaders", 3000, 3), ("space_invaders", 1500, 4), ("space_invaders", 9000, 3), ("amidar", 2000, 3), ("amidar", 4100, 3), ("amidar", 33000, 3),
+                                             ("space_invaders", 3000, 3), ("space_invaders", 1500, 4), ("space_invaders", 9000, 3), ("space_invaders", 17000, 3), ("amidar", 2000, 3),
                                              ("gridworld", 1000, 3)])
 def test_render_step_synthetic_equals_render_then_step(game, n, channels, hip_lib, oracle_lib):
     """tbx_render_step_synthetic = tbx_render_device followed by tbx_step_synthetic, bit for bit: the frame shows the state
