@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""One engine, one loop form, N iterations -- the thing to put under rocprofv3 --kernel-trace when the question is what happens
+BETWEEN the kernels of the loop.   python scripts/loop_once.py game envs pair|fused|render|step iterations"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from toybox_amd import Engine, hip  # noqa: E402
+
+game, n, form, iters = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+e = Engine(game, n)
+e.seed(1234); e.new_game()
+st = hip.Stream()
+for t in range(300):
+    e.step_synthetic(1337, t, auto_reset=True, stream=st.ptr)
+hip.synchronize()
+for t in range(300, 300 + iters):
+    if form == "pair":
+        e.step_synthetic(1337, t, auto_reset=True, stream=st.ptr)
+        e.render_device(0, 3, stream=st.ptr)
+    elif form == "fused":
+        e.render_step_synthetic(1337, t, channels=3, auto_reset=True, stream=st.ptr)
+    elif form == "render":
+        e.render_device(0, 3, stream=st.ptr)
+    else:
+        e.step_synthetic(1337, t, auto_reset=True, stream=st.ptr)
+hip.synchronize()
+e.close()

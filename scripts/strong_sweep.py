@@ -14,11 +14,15 @@ from toybox_amd import Engine, _abi, hip  # noqa: E402
 game = sys.argv[1] if len(sys.argv) > 1 else "breakout"
 sizes = [int(v) for v in sys.argv[2:]] or [8192, 65536]
 rounds, ring = int(os.environ.get("SS_ROUNDS", "4")), int(os.environ.get("SS_RING", "4"))
+LIB = None
+if os.environ.get("SS_LIB"):                       # another build of the library (A/B in one call: run the script twice on one box)
+    import ctypes
+    LIB = _abi.bind(ctypes.CDLL(os.path.abspath(os.environ["SS_LIB"])))
 for n in sizes:
     K = int(os.environ.get("SS_STEPS", "0")) or max(200, min(2000, 200 * 65536 // n // 4))
     engines = {}
     for name, every in (("none", 0), ("k1", 1), ("k%d" % ring, ring)):
-        e = Engine(game, n)
+        e = Engine(game, n, lib=LIB)
         e.seed(1234); e.new_game()
         if every:
             e.set_option(_abi.OPT_GATHER_EVERY, every)

@@ -11,8 +11,11 @@
 #include "tbx_common.hpp"
 #include "../../include/toybox_amd_spec.h"
 
-// the frame stores are plain 16-byte stores: non-temporal (`nt`) stores measured within run-to-run noise of them (A/B on one
-// box, scripts/ab_render.py)
+// the frame stores are plain 16-byte stores.  Non-temporal (`global_store_dwordx4 ... nt`) stores were measured twice: in
+// render-only loops within noise of plain ones (round 2), and in the [step ; render] loops of round 4 -- where a step kernel finds
+// its state evicted by the 7.5 GB the rasteriser has just written (profiles/r04_kernel_gaps.txt) and a store that does not
+// allocate might have spared it -- SLOWER for large batches: Breakout 1.44 against 1.21 ms per step at 65 536 envs, Amidar 1.58
+// against 1.47, SpaceInvaders 2.45 against 2.33; faster only for SpaceInvaders at 4 096 envs (0.152 against 0.161).  Plain stores stay.
 __device__ __forceinline__ void tbx_store16(uint4* p, const uint4& v) { *p = v; }
 
 // The 3x5 HUD digit font (bit 3*row + column), looked up out of immediates.  Not a table in memory: inside a rasteriser every

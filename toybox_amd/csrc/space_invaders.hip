@@ -116,6 +116,48 @@ __device__ __forceinline__ void si_load(const SiDev& d, int env, int lane, SiReg
     si_load(d, env, lane, s, o);
 }
 
+// The same for an engine whose states are CANONICAL (SiOps::custom == false: every env's enemy i sits at formation origin +
+// (32 (i % 6), 18 (i / 6)) with row i / 6, col i % 6, id i and the config's points of its row, and every laser in flight has
+// the size, speed, direction and colour of its kind): what never changes is derived instead of loaded.  Of the five 256-byte
+// enemy rows only the status row is read -- plus the first word of the x and y rows, the formation origin -- and of the eight
+// laser rows only x, y and t: ~1.0 KB instead of ~2.2 KB per env-frame.  `o` receives exactly what a full load would have
+// found, so si_store_changed() keeps writing back the rows a frame changed (x / y when the formation marches, the constant
+// laser rows when a laser spawns or dies) and every other kernel keeps reading the full table.
+__device__ __forceinline__ void si_load_canonical(const SiDev& d, const SiCfg& c, int env, int lane, SiRegs& s, SiLoaded& o)
+{
+    const size_t N = (size_t)d.n;
+    s.rng.s0 = d.rng[env];
+    s.rng.s1 = d.rng[N + env];
+    o.fv = lane < NF ? d.sc[(size_t)lane * N + env] : 0;
+#pragma unroll
+    for (int i = 0; i < NF; i++) s.f[i] = __builtin_amdgcn_readlane(o.fv, i);
+    const int32_t* e = d.enemies + (size_t)env * NEF * 64;
+    o.estatus = e[EF_STATUS * 64 + lane];
+    const int32_t fx = wave_uniform(e[EF_X * 64]), fy = wave_uniform(e[EF_Y * 64]);      // enemy 0 = the formation origin
+    const bool on = lane < s.f[F_N_ENEMIES];
+    const int row = lane / TBX_SI_COLS, col = lane - row * TBX_SI_COLS;
+    int32_t pts = 0;
+#pragma unroll
+    for (int r = 0; r < TBX_SI_MAX_ROWS; r++) pts = row == r ? c.row_scores[r] : pts;
+    o.ex = on ? fx + TBX_SI_ENEMY_DX * col : 0; o.ey = on ? fy + TBX_SI_ENEMY_DY * row : 0;
+    o.rci = on ? (int32_t)((uint32_t)row | ((uint32_t)col << 8) | ((uint32_t)lane << 16)) : 0;
+    o.epoints = on ? pts : 0;
+    s.ex = o.ex; s.ey = o.ey; s.epoints = o.epoints; s.estatus = o.estatus;
+    s.erow = on ? row : 0; s.ecol = on ? col : 0; s.eid = on ? lane : 0;
+    s.srow = o.srow = d.shields[(size_t)env * 64 + lane];
+    const int32_t* l = d.lasers + (size_t)env * NLF * 16;
+    const int slot = lane & 15;
+    const bool enemy_laser = slot < s.f[F_N_LASERS] && slot < TBX_SI_MAX_LASERS, ship_laser = slot == SHIP_SLOT && s.f[F_HAS_SHIP_LASER] != 0;
+    const bool lz = enemy_laser || ship_laser;
+    o.lf[LF_X] = l[LF_X * 16 + slot]; o.lf[LF_Y] = l[LF_Y * 16 + slot]; o.lf[LF_T] = l[LF_T * 16 + slot];
+    o.lf[LF_W] = lz ? TBX_SI_LASER_W : 0; o.lf[LF_H] = lz ? TBX_SI_LASER_H : 0;
+    o.lf[LF_MOV] = ship_laser ? TBX_DIR_UP : enemy_laser ? TBX_DIR_DOWN : 0;
+    o.lf[LF_SPEED] = ship_laser ? TBX_SI_SHIP_LASER_V : enemy_laser ? TBX_SI_ENEMY_LASER_V : 0;
+    o.lf[LF_COLOR] = ship_laser ? (int32_t)rgb_u32(TBX_SI_COL_SHIP_LASER) : enemy_laser ? (int32_t)rgb_u32(TBX_SI_COL_ENEMY_LASER) : 0;
+#pragma unroll
+    for (int i = 0; i < NLF; i++) s.lf[i] = o.lf[i];
+}
+
 __device__ __forceinline__ int32_t si_scalar_row(int lane, const SiRegs& s)
 {
     int32_t fv = 0;                               // v_writelane: one instruction per field (a select chain is two)
@@ -693,7 +735,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_new_game_kernel(SiDev d, SiCfg c
 // one frame (AGENT: the agent layer's whole action repeat, with MaxAndSkipEnv's bookkeeping) of one env on one wave.  Two
 // instantiations because the kernel is bound by latency x occupancy: the batch protocol's form carries neither the slot
 // structs nor the frame loop and needs fewer registers
-template <bool AGENT>
+// CANON: the engine's states are canonical (si_load_canonical) -- the batch protocol of an engine no intervention has taken off the grid
+template <bool AGENT, bool CANON = false>
 __device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a, const SiDev& slot_b, const SiCfg& c, const ActionSource& src, uint32_t flags, int env, int lane,
                                              SiRenderRec* __restrict__ recs = nullptr)
 {
@@ -722,7 +765,8 @@ __device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a
 
     SiRegs s;
     SiLoaded loaded;
-    si_load(d, env, lane, s, loaded);
+    if (CANON) si_load_canonical(d, c, env, lane, s, loaded);
+    else si_load(d, env, lane, s, loaded);
     int32_t prev = d.prev_score[env];
     const int frames = AGENT && src.frames > 1 ? src.frames : 1;
     int32_t rew = 0, out_lives = 0, out_score = 0;
@@ -767,13 +811,14 @@ __device__ __forceinline__ void si_step_body(const SiDev& d, const SiDev& slot_a
     }
 }
 
+template <bool CANON>
 __global__ __launch_bounds__(TBX_BLOCK) void si_step_kernel(SiDev d, SiCfg c, ActionSource src, uint32_t flags, int first_env, int count,
                                                             SiRenderRec* __restrict__ recs)
 {
     const int lane = threadIdx.x & 63;
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     if (rel >= count) return;
-    si_step_body<false>(d, d, d, c, src, flags, first_env + rel, lane, recs);
+    si_step_body<false, CANON>(d, d, d, c, src, flags, first_env + rel, lane, recs);
 }
 
 // records of envs [first_env, first_env + count) from their state (after a new game, a state write, an agent step ...)
@@ -1566,7 +1611,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void si_render_step_kernel(const SiRende
     const int group = (int)blockIdx.x / per, r = (int)blockIdx.x - group * per;
     if (r == 0) {
         const int env = wave_uniform(group * TBX_WAVES_PER_BLOCK + (int)(threadIdx.x >> 6));
-        if (env < count) si_step_body<false>(d, d, d, c, src, flags, env, (int)(threadIdx.x & 63), recs_next);
+        if (env < count) si_step_body<false, true>(d, d, d, c, src, flags, env, (int)(threadIdx.x & 63), recs_next);   // (fused only while canonical)
         return;
     }
     si_rec_render_body<C>(recs, out, 0, count, split, group * split + r - 1, false);
@@ -1786,6 +1831,7 @@ struct SiOps : GameOps {
     int recs_par = 0;
     bool recs_valid = false;
     bool custom = false;
+    bool plain = true;          // every state's ids, points and laser constants are what si_load_canonical derives (is_plain)
     bool want_recs = false;     // a batch render has been asked for since creation: steps leave records from now on (a loop that
                                 // never renders keeps the 12 us the record costs the step kernel: 61 against 50 us at 65 536 envs)
 
@@ -1840,6 +1886,9 @@ struct SiOps : GameOps {
     {
         tbx_si_config_t k;
         memcpy(&k, pod, sizeof k);
+        // enemies keep the points they were made with until their next game: a config with other row scores (or rows) means the
+        // running games no longer carry "the config's points of their row" -- the step kernel loads every row from here on
+        if (k.n_rows != cfg.n_rows || memcmp(k.row_scores, cfg.row_scores, sizeof k.row_scores) != 0) plain = false;
         return load_cfg(e, k);
     }
 
@@ -1864,8 +1913,13 @@ struct SiOps : GameOps {
         } else {
             // a whole-batch step leaves the rasteriser's records behind (canonical formations only)
             const bool whole = src.single_env < 0 && !custom && want_recs;
-            if (src.single_env < 0) TBX_LAUNCH_STEP(e, s, si_step_kernel, grid_for(count), dim3(TBX_BLOCK), d, c, src, flags, first, count, whole ? recs : nullptr);
-            else hipLaunchKernelGGL(si_step_kernel, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count, whole ? recs : nullptr);
+            const bool canon = !custom && plain;               // the short load (si_load_canonical)
+            SiRenderRec* const wr = whole ? recs : nullptr;
+            if (src.single_env < 0) {
+                if (canon) TBX_LAUNCH_STEP(e, s, si_step_kernel<true>, grid_for(count), dim3(TBX_BLOCK), d, c, src, flags, first, count, wr);
+                else TBX_LAUNCH_STEP(e, s, si_step_kernel<false>, grid_for(count), dim3(TBX_BLOCK), d, c, src, flags, first, count, wr);
+            } else if (canon) hipLaunchKernelGGL(si_step_kernel<true>, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count, wr);
+            else hipLaunchKernelGGL(si_step_kernel<false>, grid_for(count), dim3(TBX_BLOCK), 0, s, d, c, src, flags, first, count, wr);
             recs_valid = whole;
         }
         TBX_HIP(hipGetLastError());
@@ -1886,7 +1940,8 @@ struct SiOps : GameOps {
     }
     int step_ahead(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
     {
-        hipLaunchKernelGGL(si_step_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, c, src, flags, 0, e->n, recs_other);
+        if (plain) hipLaunchKernelGGL(si_step_kernel<true>, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, c, src, flags, 0, e->n, recs_other);
+        else hipLaunchKernelGGL(si_step_kernel<false>, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, c, src, flags, 0, e->n, recs_other);
         TBX_HIP(hipGetLastError());
         std::swap(recs, recs_other);
         recs_par ^= 1;
@@ -2042,6 +2097,22 @@ struct SiOps : GameOps {
         }
         return true;
     }
+    // ... and what the step kernel's short load (si_load_canonical) derives on top of that: ids, the config's points, and lasers
+    // that have the size, speed, direction and colour of their kind
+    bool is_plain(const tbx_si_state_t& st) const
+    {
+        for (int i = 0; i < st.n_enemies; i++) {
+            const int row = i / TBX_SI_COLS;
+            if (st.enemies[i].id != i || row >= TBX_SI_MAX_ROWS || st.enemies[i].points != cfg.row_scores[row]) return false;
+        }
+        auto laser_ok = [](const tbx_si_laser_t& l, int mov, int speed, uint32_t color) {
+            return l.w == TBX_SI_LASER_W && l.h == TBX_SI_LASER_H && (l.movement & 3) == mov && l.speed == speed && pack_color(l.color) == color;
+        };
+        for (int i = 0; i < st.n_enemy_lasers; i++)
+            if (!laser_ok(st.enemy_lasers[i], TBX_DIR_DOWN, TBX_SI_ENEMY_LASER_V, rgb_u32(TBX_SI_COL_ENEMY_LASER))) return false;
+        if (st.has_ship_laser && !laser_ok(st.ship_laser, TBX_DIR_UP, TBX_SI_SHIP_LASER_V, rgb_u32(TBX_SI_COL_SHIP_LASER))) return false;
+        return true;
+    }
 
     int pack_state(tbx_engine* e, int env, int count, hipStream_t s) override
     {
@@ -2067,6 +2138,9 @@ struct SiOps : GameOps {
         if (!custom)
             for (int i = 0; i < count && !custom; i++)
                 if (!is_canonical(sts[i])) custom = true;        // from now on the state-reading rasteriser paints, steps stay in stream order
+        if (plain)
+            for (int i = 0; i < count && plain; i++)
+                if (!is_plain(sts[i])) plain = false;            // from now on the step kernel loads every row
         TBX_HIP(hipMemcpyAsync(e->staging, pod_host, sizeof(tbx_si_state_t) * (size_t)count, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(si_unpack_kernel, dim3(count), dim3(64), 0, s, d, env, (const tbx_si_state_t*)e->staging);
         TBX_HIP(hipGetLastError());
