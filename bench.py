@@ -256,9 +256,10 @@ def bench_mixed(args, world, rank, local_rank):
     gather = world > 1 or args.with_gather
     if gather:
         with quiet_stdout():
-            mb.gather_init(rank, world)
+            mb.gather_init(rank, world, gather_every=args.gather_every)
     C, K, Wm, R = args.channels, args.steps, args.warmup, args.repeats
     render = not args.no_render
+    fused = render and args.loop != "pair" and C >= 3
     # three engines on three streams already keep two or three rasterisers in flight; the pipelined mode on top of that was
     # measured slower (0.93-1.01 ms per step against 0.83-0.91: its internal streams, the three callers' streams and three
     # communication streams then share the runtime's few hardware queues): off unless asked for with --pipeline 2 / 3
@@ -268,6 +269,9 @@ def bench_mixed(args, world, rank, local_rank):
                  (lambda v: lead.gather_reduce_max(v)) if gather else (lambda v: v))
 
     def one(t):
+        if fused:
+            mb.render_step_synthetic(ACTION_SEED, t, C)       # per segment: one launch where the game fuses, else render ; step
+            return
         mb.step_synthetic(ACTION_SEED, t)
         if render:
             mb.render_device(C)
@@ -288,9 +292,10 @@ def bench_mixed(args, world, rank, local_rank):
                "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": ms, "repeats": rep,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+int32", "data": "synthetic",
                "pipeline": {"option": args.pipeline, "resolved_per_game": dict(zip(games, pipe))},
+               "loop": {"form": "fused" if fused else "pair", "fused_per_game": dict(zip(games, [e.get_option(_abi_mod().OPT_RENDER_STEP_FUSED) for e in mb.engines]))},
                "config": {"workload": "mixed batch, %d envs/GPU = 3 x %d (breakout, amidar, space_invaders), %s, three streams%s"
                                       % (mb.n_envs, per, "step + RGB render" if render else "step-only",
-                                         ", per-step RCCL gather of 8 B/env records" if gather else ""),
+                                         (", RCCL gather of 8 B/env records, one collective per %d steps" % max(1, args.gather_every)) if gather else ""),
                           "envs_per_gpu": mb.n_envs, "envs_total": total},
                "roofline": ({"bound": "hbm", "kernel": "the three rasterisers together (whole-step time, not per kernel)",
                              "achieved": fb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -308,6 +313,11 @@ def bench_mixed(args, world, rank, local_rank):
         print(json.dumps(out), flush=True)
     mb.close()
     return 0
+
+
+def _abi_mod():
+    from toybox_amd import _abi
+    return _abi
 
 
 def _mean_sem(xs):

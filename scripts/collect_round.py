@@ -2,8 +2,13 @@
 """Condense what scripts/measure_round.sh <tag> left under gpurun_out/ into profiles/:
   profiles/<tag>_agent_summary.md     kernel-trace --stats of the agent protocol, per game
   profiles/<tag>_pmc_sq_counters.txt  SQ instruction / wave counters of the step + render kernels (pmc_*_sq*.txt)
-  profiles/<tag>_bench_lines.md       one table row per bench.py line of the call (all from the same box)
-usage: collect_round.py r02"""
+  profiles/<tag>_bench_lines.md       one table row per bench.py line of the call (all from the same box), with the loop form
+                                      `value` was measured with and the two-launch (`serialised`) rate beside it
+  profiles/<tag>_loop_sweeps.txt      scripts/strong_sweep.py: loop forms x record-ring depths, interleaved per process
+  profiles/<tag>_kernel_gaps.txt      kernel durations inside the loops and the gaps between them
+  profiles/<tag>_ab_prev_round.txt    rasterisers and [step ; render] against the previous round's build
+  profiles/<tag>*_summary.md, *_kernel_stats.csv, traffic.json   through scripts/summarize_profile.py, one per profile
+usage: collect_round.py r04"""
 import csv
 import glob
 import json
@@ -43,7 +48,11 @@ def sq_counters(tag):
 
 def bench_lines(tag):
     rows = ["# bench.py lines of `scripts/measure_round.sh %s` (one gpurun call, one box)" % tag, "",
-            "| file | metric | value | ms/step (median) | min–max | roofline GB/s | frac | config |", "|---|---|---|---|---|---|---|---|"]
+            "`loop`: the form `value` was measured with (fused = tbx_render_step_synthetic, one launch per frame where the engine fuses; "
+            "pair = tbx_step_synthetic ; tbx_render_device).  `serialised`: the pair form in stream order on the same engine -- what a "
+            "loop whose actions depend on the frame gets.  `whole-step frac` = frame bytes of the batch / ms per step / 8 TB/s.", "",
+            "| file | metric | value | ms/step (median) | min–max | loop | serialised value (ms/step) | rasteriser GB/s | kernel frac | whole-step frac | strong share | config |",
+            "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, "*.json"))):
         line = None
         for ln in open(f):
@@ -59,17 +68,66 @@ def bench_lines(tag):
         rl = j.get("roofline") or {}
         rep = j.get("repeats") or {}
         ms = rep.get("ms_per_step_in_run_order") or []
-        rows.append("| %s | %s | %.4g %s | %.4f | %s | %s | %s | %s |" % (
+        ser = j.get("serialised") or {}
+        whole = None
+        if rl.get("algorithmic_bytes_per_launch") and j.get("ms_per_step"):
+            whole = rl["algorithmic_bytes_per_launch"] * (j.get("n_gpus", 1) if (j.get("config", {}).get("envs_per_gpu") == j.get("config", {}).get("envs_total")) else 1) / (j["ms_per_step"] * 1e-3) / 8e12
+        elif rl.get("algorithmic_bytes_per_step") and j.get("ms_per_step"):
+            whole = rl["algorithmic_bytes_per_step"] / (j["ms_per_step"] * 1e-3) / 8e12
+        ss = (j.get("scaling_strong") or {}).get("share_of_linear")
+        rows.append("| %s | %s | %.4g %s | %.4f | %s | %s | %s | %s | %s | %s | %s | %s |" % (
             os.path.basename(f), j.get("metric"), j.get("value", 0), j.get("unit", ""), j.get("ms_per_step", 0),
-            ("%.4f–%.4f" % (min(ms), max(ms))) if ms else "", ("%.0f" % rl["achieved"]) if rl.get("achieved") else "",
-            ("%.3f" % rl["frac"]) if rl.get("frac") else "", json.dumps(j.get("config", {}))))
+            ("%.4f–%.4f" % (min(ms), max(ms))) if ms else "", (j.get("loop") or {}).get("form", ""),
+            ("%.4g (%.4f)" % (ser["value"], ser["ms_per_step"])) if ser.get("value") else "",
+            ("%.0f" % rl["achieved"]) if rl.get("achieved") else "", ("%.3f" % rl["frac"]) if rl.get("frac") else "",
+            ("%.3f" % whole) if whole else "", ("%.3f" % ss) if ss else "", json.dumps(j.get("config", {}))))
     return "\n".join(rows) + "\n"
+
+
+def cat_files(tag, pattern, header):
+    out = [header, ""]
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, pattern))):
+        out += ["## " + os.path.basename(f), open(f).read().rstrip(), ""]
+    return "\n".join(out)
+
+
+def loop_sweeps(tag):
+    out = ["# scripts/strong_sweep.py (one process per game and call, rounds of [pair, fused] x [no gather, a collective per step, a K-step ring]): "
+           "median ms per step and M env-steps/s", ""]
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, "sweep_*.txt"))):
+        out.append("## " + os.path.basename(f))
+        for ln in open(f):
+            try:
+                d = json.loads(ln)
+            except ValueError:
+                continue
+            cells = ", ".join("%s %.4f (%.1f M)" % (k, v["median"], v["M_per_s"]) for k, v in d.items() if isinstance(v, dict))
+            out.append("%s %d envs, %d steps: %s" % (d["game"], d["envs"], d["steps"], cells))
+        out.append("")
+    return "\n".join(out)
+
+
+PROFILES = [  # (profile tag suffix, traffic key, kernel substring)
+    ("", "breakout_render_3ch_65536_fused", "render_step_kernel<3"), ("_pair", "breakout_render_3ch_65536", "render_kernel<3"),
+    ("_space_invaders", "space_invaders_render_3ch_65536", "render_kernel<3"), ("_amidar", "amidar_render_3ch_65536", "render_kernel<3"),
+    ("_breakout_4096", "breakout_render_3ch_4096_fused", "render_step_kernel<3"), ("_breakout_4096_pair", "breakout_render_3ch_4096", "render_kernel<3"),
+    ("_space_invaders_4096_pair", "space_invaders_render_3ch_4096", "render_kernel<3"), ("_amidar_4096_pair", "amidar_render_3ch_4096", "render_kernel<3"),
+    ("_breakout_8192_gather", "breakout_render_3ch_8192_fused", "render_step_kernel<3"), ("_mixed", None, "render"),
+]
 
 
 def main():
     tag = sys.argv[1]
     dst = os.path.join(ROOT, "profiles")
+    import subprocess
+    for suffix, key, sub in PROFILES:
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out", "prof_%s%s" % (tag, suffix))):
+            cmd = [sys.executable, os.path.join(ROOT, "scripts", "summarize_profile.py"), tag + suffix] + ([key, sub] if key else [])
+            subprocess.run(cmd, stdout=subprocess.DEVNULL)
     for name, text in (("agent_summary.md", agent_summary(tag)), ("pmc_sq_counters.txt", sq_counters(tag)),
+                       ("loop_sweeps.txt", loop_sweeps(tag)),
+                       ("ab_prev_round.txt", cat_files(tag, "ab_*.txt", "# scripts/ab_render.py: lib_prev.so = the previous round's final build, interleaved with this build on one box")),
+                       ("kernel_gaps.txt", cat_files(tag, "kernel_gaps.txt", "# scripts/gpu_gaps.sh + scripts/trace_gaps.py: kernel durations inside the loops and the idle gaps in front of them")),
                        ("bench_lines.md", bench_lines(tag))):
         with open(os.path.join(dst, "%s_%s" % (tag, name)), "w") as fh:
             fh.write(text + ("\n" if not text.endswith("\n") else ""))

@@ -244,8 +244,11 @@ def test_mixed_batch_config5_share_on_three_streams(hip_lib, oracle_lib):
     rec = np.empty(per, np.uint64)
     n_done = 0
     for t in range(steps):
-        mb.step_synthetic(1337, t)
-        mb.render_device(3)
+        if t < steps // 2:
+            mb.step_synthetic(1337, t)
+            mb.render_device(3)
+        else:                                   # the fused rollout call per segment (one launch for Breakout and SpaceInvaders)
+            mb.render_step_synthetic(1337, t, 3)
         ref.step_synthetic(1337, t)
         if t % 10 == 9 or t == steps - 1:
             for s in streams:
@@ -258,6 +261,7 @@ def test_mixed_batch_config5_share_on_three_streams(hip_lib, oracle_lib):
                 want = np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_uint64)), (per,))
                 assert np.array_equal(rec, want), (ge.game, t)
                 n_done += int(unpack_records(rec)[1].sum())
+    mb.render_device(3)                          # (a fused call's frame shows the state before its step)
     for s in streams:
         s.synchronize()
     sample = list(range(0, per, 97)) + [per - 1]

@@ -295,10 +295,13 @@ class MixedBatch:
     def _stream(self, i):
         return self.streams[i] if self.streams else 0
 
-    def gather_init(self, rank, world, rdzv_key=None):
-        """One communicator per game segment (every rank holds the same three segments)."""
+    def gather_init(self, rank, world, rdzv_key=None, gather_every=1):
+        """One communicator per game segment (every rank holds the same three segments); gather_every = K: a K-step record
+        ring per segment (TBX_OPT_GATHER_EVERY)."""
+        from . import _abi
         for g, e in zip(self.games, self.engines):
             uid = exchange_unique_id(rank, world, e.gather_unique_id, tag=g, key=rdzv_key)
+            e.set_option(_abi.OPT_GATHER_EVERY, max(1, int(gather_every)))
             e.gather_init(world, rank, uid)
             forget_unique_id(rank, tag=g, key=rdzv_key)
         self.gathering = True
@@ -312,6 +315,13 @@ class MixedBatch:
     def render_device(self, channels=3):
         for i, e in enumerate(self.engines):
             e.render_device(0, channels, stream=self._stream(i))
+
+    def render_step_synthetic(self, action_seed, t, channels=3, auto_reset=True):
+        """the random-rollout loop body per segment (tbx_render_step_synthetic: one launch where the game fuses, else render then step)"""
+        for i, (e, off) in enumerate(zip(self.engines, self.offsets)):
+            e.render_step_synthetic(action_seed, t, channels=channels, env_offset=off, auto_reset=auto_reset, stream=self._stream(i))
+            if self.gathering:
+                e.gather(stream=self._stream(i))
 
     def step_host(self, actions_by_game, auto_reset=True):
         """actions_by_game: list of int arrays (ALE ids), one per game.  Returns per-game (reward, done, lives, score)."""
