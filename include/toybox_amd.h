@@ -415,7 +415,7 @@ int tbx_render_device(tbx_engine* engine, uint8_t* out_dev, int channels, void* 
  * every env one frame with device-generated actions (the rule of tbx_step_synthetic) -- i.e. tbx_render_device followed by
  * tbx_step_synthetic, asynchronous on `stream`, same results bit for bit: the frame shows the state BEFORE the step, the
  * TBX_BUF_* outputs and the state are the step's.  Where the rasteriser reads step-written render records (Breakout with the
- * canonical wall, SpaceInvaders with the canonical formation; RGB / RGBA) both halves are ONE launch: the step's blocks ride with the rasteriser's, write the
+ * canonical wall; RGB / RGBA) both halves are ONE launch: the step's few blocks ride in front of the rasteriser's, write the
  * other records buffer and hide in the launch's ramp-up, so a loop of these calls runs like a render-only loop -- no kernel
  * boundary per frame, no rasteriser that starts in lockstep behind a short kernel (8 192 envs + gather, the per-GPU share of
  * the strong-scaled headline batch: see DESIGN.md section 6).  Only a loop whose actions do not depend on the frame can use

@@ -247,7 +247,7 @@ def test_mixed_batch_config5_share_on_three_streams(hip_lib, oracle_lib):
         if t < steps // 2:
             mb.step_synthetic(1337, t)
             mb.render_device(3)
-        else:                                   # the fused rollout call per segment (one launch for Breakout and SpaceInvaders)
+        else:                                   # the fused rollout call per segment (one launch for Breakout)
             mb.render_step_synthetic(1337, t, 3)
         ref.step_synthetic(1337, t)
         if t % 10 == 9 or t == steps - 1:
@@ -834,6 +834,43 @@ def test_render_step_synthetic_equals_render_then_step(game, n, channels, hip_li
     _same_states(g, o, sample + list(range(0, n, max(1, n // 50))), "end")
     for x, y in zip(g.scalars(), o.scalars()):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_space_invaders_short_load_only_while_states_are_plain(hip_lib, oracle_lib):
+    """The canonical step kernel (si_load_canonical) derives enemy ids, the config's points and the lasers' constants instead of
+    loading them; a state that carries other values -- on the grid, so the record rasteriser stays -- must take the engine back
+    to the full load, in the batch step and the pipelined step alike."""
+    game, n = "space_invaders", 600
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=12)
+    for t in range(120):
+        a = synthetic_actions(game, n, t)
+        g.step(a, auto_reset=True); o.step(a, auto_reset=True)
+    st = o.get_state(5)
+    for k in range(st.n_enemies):
+        st.enemies[k].points = 1000 + k                     # not the config's row scores
+        st.enemies[k].id = 200 - k
+    if st.n_enemy_lasers:
+        st.enemy_lasers[0].speed = 1
+    st.has_ship_laser = 1
+    st.ship_laser.x, st.ship_laser.y, st.ship_laser.w, st.ship_laser.h = 100, 150, 3, 5
+    st.ship_laser.t, st.ship_laser.movement, st.ship_laser.speed = 0, 0, 2
+    for e in (g, o):
+        e.set_state(5, st)
+    assert g.get_option(_abi.OPT_RECORDS_ACTIVE) == 1
+    g.set_option(_abi.OPT_PIPELINE, 3)                      # step_ahead picks its kernel by the same flag
+    for t in range(120, 400):
+        if t % 3 == 0:
+            g.render_step_synthetic(1337, t, channels=3, auto_reset=False)
+            o.render_step_synthetic(1337, t, channels=3, auto_reset=False)
+        else:
+            a = synthetic_actions(game, n, t)
+            for x, y in zip(g.step(a), o.step(a)):
+                assert np.array_equal(x, y), t
+    g.sync()
+    _same_states(g, o, range(0, n, 7), "end")
+    assert bytes(g.get_state(5)) == bytes(o.get_state(5))
+    assert np.array_equal(g.render_env(5, 3), o.render_env(5, 3))
 
 
 @pytest.mark.gpu

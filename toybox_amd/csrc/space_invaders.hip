@@ -1568,8 +1568,7 @@ struct SiRecPainter {
 };
 
 template <int C>
-__device__ __forceinline__ void si_rec_render_body(const SiRenderRec* __restrict__ recs, uint8_t* __restrict__ out, int first_env, int count, int split,
-                                                   const int block, const bool stagger)
+__global__ __launch_bounds__(TBX_BLOCK) void si_rec_render_kernel(const SiRenderRec* __restrict__ recs, uint8_t* __restrict__ out, int first_env, int count, int split)
 {
     constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
     using Stager = RowStager<C, W, SI_UNIT_ROWS>;
@@ -1578,43 +1577,16 @@ __device__ __forceinline__ void si_rec_render_body(const SiRenderRec* __restrict
     si_fill_sprites(spr_lds);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wid = wave_uniform(block * TBX_WAVES_PER_BLOCK + wave);
+    const int wid = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
     const int rel = wid / split, part = wid - rel * split;
     if (rel >= count) return;
     const int env = first_env + rel;
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
     SiRecPainter<C> p;
     p.spr_lds = spr_lds;
-    if (C == 3 && stagger) tbx_stagger_first_waves(wid);
+    if (C == 3) tbx_stagger_first_waves(wid);
     p.setup(recs, env, lane);
     si_paint_units<C>(p, out + (size_t)rel * H * W * C, env, lane, st, part, split);
-}
-
-template <int C>
-__global__ __launch_bounds__(TBX_BLOCK) void si_rec_render_kernel(const SiRenderRec* __restrict__ recs, uint8_t* __restrict__ out, int first_env, int count, int split)
-{
-    si_rec_render_body<C>(recs, out, first_env, count, split, (int)blockIdx.x, true);
-}
-
-// The fused rollout launch (tbx_render_step_synthetic): the record rasteriser of frame t and the batch step to frame t + 1 in ONE
-// launch.  Blocks come in groups of 1 + split: the first block of a group steps four envs (one wave each, si_step_body) into
-// the OTHER records buffer and the step outputs, the other `split` blocks are the rasteriser blocks of those same four envs,
-// reading the records the previous launch's step left -- the two halves touch nothing in common.  Interleaved like this the
-// step's waves (latency-bound, 2 % of the launch's bytes and instructions) run beside painting waves for the whole launch
-// instead of in front of it; a loop of these launches has no kernel boundary per frame and no rasteriser that starts in
-// lockstep behind a short kernel, so the staggered first waves of raster.hpp are not needed either.
-template <int C>
-__global__ __launch_bounds__(TBX_BLOCK) void si_render_step_kernel(const SiRenderRec* __restrict__ recs, uint8_t* __restrict__ out, int count, int split,
-                                                                   SiDev d, SiCfg c, ActionSource src, uint32_t flags, SiRenderRec* __restrict__ recs_next)
-{
-    const int per = split + 1;
-    const int group = (int)blockIdx.x / per, r = (int)blockIdx.x - group * per;
-    if (r == 0) {
-        const int env = wave_uniform(group * TBX_WAVES_PER_BLOCK + (int)(threadIdx.x >> 6));
-        if (env < count) si_step_body<false, true>(d, d, d, c, src, flags, env, (int)(threadIdx.x & 63), recs_next);   // (fused only while canonical)
-        return;
-    }
-    si_rec_render_body<C>(recs, out, 0, count, split, group * split + r - 1, false);
 }
 
 // ------------------------------------------------------------------ resident single-env form (tbx_serve_loop, tbx_common.hpp)
@@ -1949,27 +1921,11 @@ struct SiOps : GameOps {
         return TBX_OK;
     }
 
-    // tbx_render_step_synthetic: frame t and the step to frame t + 1 in one launch (si_render_step_kernel)
-    bool render_step_fused(int channels) const override { return pipeline_ok() && channels >= 3; }
-    int render_step(tbx_engine* e, uint8_t* out_dev, int channels, const ActionSource& src, uint32_t flags, hipStream_t s) override
-    {
-        want_recs = true;
-        if (!recs_valid) {
-            hipLaunchKernelGGL(si_rec_prep_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, recs, 0, e->n);
-            TBX_HIP(hipGetLastError());
-            recs_valid = true;
-        }
-        const int split_opt = e->opt[TBX_OPT_RENDER_SPLIT];
-        const int split = split_opt > 0 ? split_opt : channels == 3 ? 12 : e->n <= 32768 ? 5 : 1;
-        const dim3 grid(grid_for(e->n).x * (unsigned)(split + 1)), block(TBX_BLOCK);
-        if (channels == 3) TBX_LAUNCH_STEP(e, s, si_render_step_kernel<3>, grid, block, recs, out_dev, e->n, split, d, c, src, flags, recs_other);
-        else TBX_LAUNCH_STEP(e, s, si_render_step_kernel<4>, grid, block, recs, out_dev, e->n, split, d, c, src, flags, recs_other);
-        TBX_HIP(hipGetLastError());
-        std::swap(recs, recs_other);
-        recs_par ^= 1;
-        return TBX_OK;
-    }
-
+    // tbx_render_step_synthetic stays the two launches in stream order (GameOps::render_step_fused false).  A fused launch -- one step
+    // block (four envs, a wave each) in front of the twelve rasteriser blocks of the same four envs, other records buffer -- was built
+    // and measured in round 4 (scripts/strong_sweep.py, ms per step two launches / fused on one box): 4 096 envs 0.1625 / 0.1645,
+    // 8 192 envs 0.3103 / 0.3147, 65 536 envs 2.299 / 2.421.  The rasteriser is not waiting for anything the step's waves could hide
+    // in: inside the launch they cost what they cost in front of it, plus the block slots (23 KB of LDS each) they hold.  Removed.
     bool serve_paints() const override { return true; }
     int serve(tbx_engine* e, TbxServeCtl* ctl_dev, hipStream_t s) override
     {
