@@ -56,6 +56,19 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
+# Test seams (tests/test_sharding.py walks the WHOLE N-process flow of main() -- both readings, communicators, the verified
+# exchange, the JSON line -- without a GPU by putting the CPU checker and a stand-in for toybox_amd.hip here).  Never set by this
+# script: without them every engine is the HIP library's and a missing GPU is an error.
+ENGINE_FACTORY = None     # callable(game, n_envs, device) -> Engine
+HIP_MODULE = None         # object with Stream / Event / synchronize / set_device / memcpy_dtoh
+
+
+def _engine(game, n, device):
+    if ENGINE_FACTORY is not None:
+        return ENGINE_FACTORY(game, n, device)
+    from toybox_amd import Engine
+    return Engine(game, n, device=device)
+
 # algorithmic bytes per env-step: 2*S_game + A + O + F
 S_GAME = {"breakout": 72, "space_invaders": 248, "amidar": 420, "gridworld": 17}   # gridworld: player 8 + score 4 + over 4 + one cell
 A_BYTES, O_BYTES = 1, 5
@@ -649,7 +662,7 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
     sizes = [e - s for s, e in spans]
     width = max(sizes)
     n = end - start
-    eng = Engine(game, n, device=local_rank)
+    eng = _engine(game, n, local_rank)
     eng.seed(SEED_BASE + start)            # env i of this rank: seed 1234 + global index
     eng.new_game()
     H, W, C = eng.height, eng.width, args.channels
@@ -736,7 +749,10 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world)
 
-    from toybox_amd import hip
+    if HIP_MODULE is not None:
+        hip = HIP_MODULE
+    else:
+        from toybox_amd import hip
     if os.environ.get("TBX_BENCH_ONE_DEVICE"):     # diagnostic: every rank on device 0 (exercises the N > 1 flow on a 1-GPU box)
         local_rank = 0
     hip.set_device(local_rank)
@@ -833,12 +849,12 @@ def main():
             s_, w_ = (out, out[key]) if args.scaling == "strong" else (out[key], out)
             # strong total over weak total = what N GPUs make of ONE batch against N x a full batch each: the share of linear scaling
             out["share_of_linear"] = s_["value"] / w_["value"]
-        if world == 1 and not args.no_extras and n >= 16384:
+        if world == 1 and not args.no_extras and n >= 16384 and ENGINE_FACTORY is None:
             try:
                 out["scaling_strong"] = strong_share_probe(args, game, C, n, out["value"])
             except Exception as ex:
                 out["scaling_strong"] = {"error": repr(ex)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and ENGINE_FACTORY is None:
             try:
                 out["cpu_baseline"] = cpu_baseline([(game, n_total, 0)], C, args.cpu_seconds)
                 out["cpu_config1"] = cpu_config1(game, C)

@@ -307,3 +307,69 @@ def test_bench_launcher_world_size_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
                        timeout=120, cwd="/tmp", env=env)
     assert p.returncode == 2 and "WORLD_SIZE" in p.stderr
+
+
+BENCH_FLOW_WORKER = r"""
+# One rank of `bench.py --gpus N` with the CPU checker behind bench.ENGINE_FACTORY and a stand-in for toybox_amd.hip behind
+# bench.HIP_MODULE: everything main() does for N > 1 -- both readings, a communicator each, the verified exchange, max-over-ranks
+# regions, rank 0's JSON line -- runs for real; only the kernels are the oracle's.
+import ctypes, os, sys, time
+import numpy as np
+sys.path.insert(0, {root!r})
+import bench
+from toybox_amd import Engine, _abi
+lib = ctypes.CDLL(os.path.join({root!r}, "oracle", "liboracle.so")); _abi.bind(lib)
+
+class Ev:
+    def __init__(self): self.t = 0.0
+    def record(self, stream): self.t = time.perf_counter()
+    def elapsed_ms(self, other): return max(1e-3, 1000.0 * (other.t - self.t))
+    def close(self): pass
+class St:
+    ptr = 0
+    def synchronize(self): pass
+    def close(self): pass
+class FakeHip:
+    Event, Stream = Ev, St
+    @staticmethod
+    def synchronize(): pass
+    @staticmethod
+    def set_device(i): pass
+    @staticmethod
+    def memcpy_dtoh(dst, src, nbytes): ctypes.memmove(dst.ctypes.data, src, nbytes)
+bench.ENGINE_FACTORY = lambda game, n, device: Engine(game, n, lib=lib)
+bench.HIP_MODULE = FakeHip
+sys.argv = ["bench.py"] + {argv!r}
+sys.exit(bench.main())
+"""
+
+
+@pytest.mark.parametrize("world,extra", [(2, []), (3, ["--scaling", "weak", "--gather-every", "1", "--loop", "pair"])])
+def test_bench_n_process_flow_end_to_end_on_the_checker(world, extra, oracle_lib, tmp_path):
+    """The first hardware run of `bench.py --gpus N > 1` is the driver's: everything in it that is not a kernel is walked here --
+    value = the strong reading (envs in total) with the weak one beside it, a K-step ring communicator per reading, the verified
+    exchange, share_of_linear as a fraction -- over the oracle's shared-memory gather."""
+    import json
+    argv = ["--gpus", str(world), "--envs", "96", "--steps", "6", "--warmup", "2", "--repeats", "2", "--preroll", "300", "--no-cpu-baseline"] + extra
+    script = tmp_path / "worker.py"
+    script.write_text(BENCH_FLOW_WORKER.format(root=ROOT, argv=argv))
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="3", TBX_RDZV_DIR=str(tmp_path))
+    env.pop("TBX_RDZV_KEY", None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True) for r in range(world)]
+    out0 = procs[0].communicate(timeout=600)[0]
+    for p in procs:
+        assert p.wait(timeout=600) == 0, out0[-2000:]
+    line = json.loads([ln for ln in out0.splitlines() if ln.startswith("{")][-1])
+    strong_is_value = "--scaling" not in extra
+    assert line["n_gpus"] == world and line["scaling"] == ("strong" if strong_is_value else "weak")
+    assert line["rccl"]["nranks"] == world and line["rccl"]["verified"] is True
+    assert line["rccl"]["gather_every"] == (4 if strong_is_value else 1)
+    other = line["weak" if strong_is_value else "strong"]
+    assert other["rccl"]["verified"] is True and other["rccl"]["nranks"] == world
+    s_, w_ = (line, other) if strong_is_value else (other, line)
+    assert s_["config"]["envs_total"] == 96 if strong_is_value else s_["envs_total"] == 96
+    assert (w_["envs_total"] if strong_is_value else w_["config"]["envs_total"]) == 96 * world
+    assert abs(line["share_of_linear"] - s_["value"] / w_["value"]) < 1e-9 and 0 < line["share_of_linear"]
+    assert line["loop"]["form"] == "pair"                      # (the checker reports no fused launch)
+    assert line["check"]["frames_played"] > 300
