@@ -287,7 +287,7 @@ typedef struct tbx_amidar_state {
 
 /* The reference only ships this game's two golden dumps (toybox/interventions/defaults/gridworld_{config,state}_default.json)
  * and the env class envs/atari/gridworld.py:8-13; the records below hold exactly the fields of those dumps.  The rules
- * and the picture are this repo's own ("GridWorld"): a fixed 160x128 frame divided into
+ * and the picture are this repo's own (SPEC.md, "GridWorld"): a fixed 160x128 frame divided into
  * game_size cells of floor(160/w) x floor(128/h) pixels. */
 #define TBX_GW_W          160
 #define TBX_GW_H          128

@@ -1,6 +1,6 @@
 /*
  * toybox_amd_spec.h -- numeric constants and sprite bitmaps of this repo's game specifications
- * (DESIGN.md "Game specifications").  Data only: the HIP kernels and the CPU checker each state
+ * (SPEC.md).  Data only: the HIP kernels and the CPU checker each state
  * the rules themselves and share just these tables.  Values anchored on the reference's golden
  * dumps are marked [golden]; the rest is this repo's own choice (the reference's Rust core,
  * ctoybox==0.5.0, is not in the reference tree).

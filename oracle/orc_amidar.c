@@ -8,7 +8,7 @@
  * Pinned by the reference's tests: one FIRE leaves jumps == 3
  * (test/interventions/test_amidar_interventions.py:170-173); tile<->world queries scale by (64,80).
  * Everything else (movement, painting, enemy protocols, default routes, pixels) is PARITY
- * UNPINNED and follows DESIGN.md "Amidar".  Integer arithmetic only. */
+ * UNPINNED and follows SPEC.md "Amidar".  Integer arithmetic only. */
 #include "oracle.h"
 #include "../include/toybox_amd_spec.h"
 #include <string.h>

@@ -8,7 +8,7 @@
  * Pinned by the reference's tests: FIRE leaves the paddle at (120,143)
  * (test/interventions/test_breakout_interventions.py:137-145) and keeps >=1 ball (:94-95).
  * Everything else in orc_breakout_step/_render is PARITY UNPINNED: it follows this repo's
- * specification (DESIGN.md "Breakout"), modelled on toybox-rs' published behaviour.
+ * specification (SPEC.md "Breakout"), modelled on toybox-rs' published behaviour.
  *
  * Arithmetic: IEEE-754 binary64, only + - * / sqrt ceil fabs compare; built with
  * -ffp-contract=off so no FMA is formed (the device build does the same). */

@@ -5,7 +5,7 @@
  * (toybox/envs/atari/gridworld.py:8-13); the rules live in the absent ctoybox 0.5.0 core.  What the dumps pin:
  * the field set, the default board, tile attributes (color / goal / reward / walkable), player start and colour,
  * and that a state carries its own tile table with the grid as indices into it.  The movement rule, the reward
- * bookkeeping and the picture below are this repo's own specification ("GridWorld"). */
+ * bookkeeping and the picture below are this repo's own specification (SPEC.md, "GridWorld"). */
 #include "oracle.h"
 #include <string.h>
 

@@ -5,7 +5,7 @@
  * (44+32c, 31+18r) with points by row, three 16x18 shields with the golden pixel mask and colour,
  * ship (68,185) 16x10 speed 3 not yet alive, life_display_timer 128, ufo (-2,12) appearance 500,
  * enemy_shot_delay 50, lives 3, RNG bookkeeping (KAT-C).
- * The per-frame rules and the pixels are PARITY UNPINNED: they follow DESIGN.md "SpaceInvaders".
+ * The per-frame rules and the pixels are PARITY UNPINNED: they follow SPEC.md "SpaceInvaders".
  * All arithmetic is int32 except the jitter test, a binary64 compare of (draw >> 11) * 2^-53. */
 #include "oracle.h"
 #include "../include/toybox_amd_spec.h"

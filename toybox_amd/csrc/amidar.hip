@@ -2,7 +2,7 @@
 //
 // Replaces the per-env Rust transition + rasteriser behind ctoybox.Toybox.apply_ale_action /
 // get_state (call sites: /root/reference/toybox/envs/atari/base.py:126,109) for the game the
-// reference registers as AmidarToyboxNoFrameskip-v4 (toybox/__init__.py:14-18).  Rules: DESIGN.md
+// reference registers as AmidarToyboxNoFrameskip-v4 (toybox/__init__.py:14-18).  Rules: SPEC.md
 // "Amidar"; independently restated in scalar C by the CPU checker under oracle/ and compared bit
 // for bit by tests/test_gpu_parity.py.  Integer arithmetic only.
 //

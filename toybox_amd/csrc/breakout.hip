@@ -2,7 +2,7 @@
 //
 // Replaces the per-env Rust transition + rasteriser behind ctoybox.Toybox.apply_ale_action /
 // get_state (call sites: /root/reference/toybox/envs/atari/base.py:126,109).  Semantics are the
-// ones stated in DESIGN.md "Breakout" and restated independently (scalar C) by the CPU checker under oracle/;
+// ones stated in SPEC.md "Breakout" and restated independently (scalar C) by the CPU checker under oracle/;
 // the two are compared bit for bit by tests/test_gpu_parity.py.
 //
 // Layout in HBM: struct-of-arrays over the env batch for every scalar field (field f of env e at
@@ -628,7 +628,7 @@ __device__ __forceinline__ BrkRenderRec t_record(const BrkT& s)
     return rec;
 }
 
-// one frame of one env (the transition of DESIGN.md "Breakout" for the canonical wall)
+// one frame of one env (the transition of SPEC.md "Breakout" for the canonical wall)
 __device__ __forceinline__ void brk_t_step(const BrkCfg& c, BrkT& s, uint32_t buttons)
 {
     const int rows = c.n_rows;
@@ -1946,7 +1946,7 @@ struct BreakoutOps : GameOps {
         // A big RGB launch goes out in TWO parts, the first 1 024 envs (two generations of waves) and then the rest.  A launch
         // whose first waves all start together into an idle memory system -- behind a step kernel -- keeps them in lockstep,
         // and the frame stores then cost 0-15 % more depending on where the frame buffer lies (the "two rate states" of rounds
-        // 2-3; DESIGN.md section 6, raster.hpp).  The second part starts against the draining stores of the first and its waves
+        // 2-3; profiles/HISTORY.md, raster.hpp).  The second part starts against the draining stores of the first and its waves
         // are spread by that, like those of a launch that follows another rasteriser launch.  Measured per output buffer
         // (scripts/ubench/rate_addr, [step ; render], three processes x eight buffers each, ms per step): 65 536 envs
         // 1.208-1.214 in all 24 against 1.211-1.236 with the staggered first waves of raster.hpp and 1.19-1.38 with neither;

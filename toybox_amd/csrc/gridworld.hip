@@ -2,8 +2,8 @@
 //
 // The reference holds this game's env class (toybox/envs/atari/gridworld.py:8-13) and two golden dumps
 // (toybox/interventions/defaults/gridworld_config_default.json, gridworld_state_default.json); the rules are in the
-// absent ctoybox core, so movement, reward bookkeeping and the picture are this repo's specification (DESIGN.md
-// section 3, "GridWorld"), restated independently in the CPU checker.
+// absent ctoybox core, so movement, reward bookkeeping and the picture are this repo's specification (SPEC.md
+// "GridWorld"), restated independently in the CPU checker.
 //
 // HBM layout: nine int32 scalars as SoA [field][N]; the tile table env-major [N][16][3 words]; the board env-major
 // [N][32*32] bytes.  A step touches the scalars (coalesced), one board byte and one tile record, so it is one thread

@@ -3,7 +3,7 @@
 // Replaces the per-env Rust transition + rasteriser behind ctoybox.Toybox.apply_ale_action /
 // get_state (call sites: /root/reference/toybox/envs/atari/base.py:126,109) for the game the
 // reference registers as SpaceInvadersToyboxNoFrameskip-v4 (toybox/__init__.py:20-24).  Rules:
-// DESIGN.md "SpaceInvaders"; independently restated in scalar C by the CPU checker under oracle/
+// SPEC.md "SpaceInvaders"; independently restated in scalar C by the CPU checker under oracle/
 // and compared bit for bit by tests/test_gpu_parity.py.  All arithmetic is int32 except the
 // jitter test (one binary64 compare).
 //
@@ -2030,7 +2030,7 @@ struct SiOps : GameOps {
         // for one wave per frame, which drops into the GPU's slower rate state more often; whole step 25.0 -> 25.8 M
         // env-steps/s), five per RGBA frame only for batches that would leave the chip under-filled, one per gray frame.  A
         // two-stage form (set-up once per env into a 3.5 KB record, 9-18 light waves per frame) and a set-up shared by a
-        // block's waves through LDS were built and measured this round: both slower.
+        // block's waves through LDS were built and measured this round: both slower (profiles/HISTORY.md).
         const int split = split_env > 0 ? split_env : channels == 3 ? 5 : (channels == 4 && n_envs <= 32768) ? 5 : 1;
         switch (channels) {
         case 1: if (pick_alt) hipLaunchKernelGGL((si_render_kernel<1, true>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); else hipLaunchKernelGGL((si_render_kernel<1, false>), grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, src, out_dev, first_env, n_envs, skip_blank, split, alt, pick_alt); break;
