@@ -368,6 +368,45 @@ def test_device_side_interventions_hip_equals_oracle(game, oracle_lib):
         assert bytes(g.get_state(i)) == bytes(o.get_state(i)), (game, i)
 
 
+@pytest.mark.gpu
+def test_device_pointer_forms_of_edit_and_reduce(oracle_lib):
+    """tbx_edit_device / tbx_reduce_device: mask, per-env arguments and results all in HBM, queued on a caller's stream between
+    rollout steps without a synchronisation -- same answers as the host-pointer forms, and the edits land in program order."""
+    from toybox_amd import _abi, _lib, hip
+    n = 5000
+    g, o = _played("breakout", n, _lib.load(), frames=100), _played("breakout", n, oracle_lib, frames=100)
+    rng = np.random.default_rng(4)
+    mask = (rng.random(n) < 0.5).astype(np.uint8)
+    cols = np.stack([rng.integers(0, 18, n).astype(np.float64), np.zeros(n)], axis=1)          # {col, alive = 0} per env
+    s = hip.Stream()
+    d_mask, d_args, d_out = hip.malloc(n), hip.malloc(8 * 2 * n), hip.malloc(8 * n)
+    hip.memcpy_htod(d_mask, mask, n)
+    hip.memcpy_htod(d_args, cols, cols.nbytes)
+    for t in range(100, 110):
+        g.step_synthetic(1337, t, auto_reset=True, stream=s.ptr)
+    g.edit_device(_abi.EDIT_BRK_COLUMN_ALIVE, mask_ptr=d_mask, stream=s.ptr, per_env_ptr=d_args, n_args=2)
+    g.edit_device(_abi.EDIT_SET_LIVES, [2], mask_ptr=d_mask, stream=s.ptr)
+    g.reduce_device(_abi.QUERY_BRK_CHANNEL_COUNT, d_out, stream=s.ptr)
+    for t in range(110, 120):
+        g.step_synthetic(1337, t, auto_reset=True, stream=s.ptr)
+    s.synchronize()
+    got = np.empty(n, np.float64)
+    hip.memcpy_dtoh(got, d_out, 8 * n)
+    for t in range(100, 110):
+        o.step(synthetic_actions("breakout", n, t, seed=1337), auto_reset=True)
+    o.edit(_abi.EDIT_BRK_COLUMN_ALIVE, cols, mask)
+    o.edit(_abi.EDIT_SET_LIVES, [2], mask)
+    want = o.reduce(_abi.QUERY_BRK_CHANNEL_COUNT)[:, 0]
+    for t in range(110, 120):
+        o.step(synthetic_actions("breakout", n, t, seed=1337), auto_reset=True)
+    assert np.array_equal(got, want) and want[mask != 0].min() >= 1
+    assert g.reduce_width(_abi.QUERY_BRK_BALLS) == 17 and g.reduce_width(_abi.QUERY_AMI_MODE) < 0
+    for i in range(0, n, 53):
+        assert bytes(g.get_state(i)) == bytes(o.get_state(i)), i
+    for p in (d_mask, d_args, d_out):
+        hip.free(p)
+
+
 def test_batched_helpers_equal_the_references_own_classes(oracle_lib):
     """Build container only: tests/interventions_reference_worker.py imports the reference's UNMODIFIED
     toybox.interventions.{breakout,amidar,space_invaders} (over the ctoybox shim, one-env oracle engines), replays each env's

@@ -759,6 +759,13 @@ def test_render_step_synthetic_call_contract(game, lib):
         e.seed(4)
         e.new_game()
     for t in range(40):
+        if t == 20 and game == "breakout":                  # intervention-written bricks: the call is two launches from here on
+            for e in (a, b):
+                st = e.get_state(2)
+                st.bricks[7].col = 3
+                st.bricks[30].x += 2.0
+                e.set_state(2, st)
+            assert a.get_option(_abi.OPT_RENDER_STEP_FUSED) == 0
         a.render_step_synthetic(1337, t, channels=3, auto_reset=True)
         fa = a.device_buffer(_abi.BUF_FRAME)
         b.render_device(0, 3)
@@ -767,6 +774,7 @@ def test_render_step_synthetic_call_contract(game, lib):
     a.sync(); b.sync()
     for i in range(n):
         assert bytes(a.get_state(i)) == bytes(b.get_state(i))
+        assert np.array_equal(a.render_env(i, 3), b.render_env(i, 3))
     with pytest.raises(ToyboxAmdError):
         a.render_step_synthetic(1337, 0, channels=2)
     a.close(); b.close()

@@ -241,15 +241,28 @@ class Engine:
         self._check(self._lib.tbx_reduce(self._h, int(query), _ptr(a) if n else None, n, per_env, _ptr(out)))
         return out
 
-    def edit_device(self, op, args=(), mask_ptr=0, stream=0):
-        """asynchronous form: mask (and per-env args, given as an int address with n_args) already in HBM"""
-        a, n, per_env = self._edit_args(args)
+    def edit_device(self, op, args=(), mask_ptr=0, stream=0, per_env_ptr=0, n_args=0):
+        """tbx_edit_device, asynchronous on `stream`: mask_ptr = device address of uint8[N] (0: every env); arguments either
+        `args` (scalars, the same for every env) or per_env_ptr = device address of float64[N][n_args]"""
+        if per_env_ptr:
+            self._check(self._lib.tbx_edit_device(self._h, int(op), C.c_void_p(int(per_env_ptr)), int(n_args), 1,
+                                                  C.c_void_p(int(mask_ptr)) if mask_ptr else None, C.c_void_p(int(stream))))
+            return
+        a, n, _ = self._edit_args(args)
         self._check(self._lib.tbx_edit_device(self._h, int(op), _ptr(a) if n else None, n, 0, C.c_void_p(int(mask_ptr)) if mask_ptr else None,
                                               C.c_void_p(int(stream))))
 
-    def reduce_device(self, query, out_ptr, args=(), stream=0):
-        a, n, per_env = self._edit_args(args)
+    def reduce_device(self, query, out_ptr, args=(), stream=0, per_env_ptr=0, n_args=0):
+        """tbx_reduce_device: float64[N][width] into the device buffer at out_ptr, asynchronous on `stream`"""
+        if per_env_ptr:
+            self._check(self._lib.tbx_reduce_device(self._h, int(query), C.c_void_p(int(per_env_ptr)), int(n_args), 1, C.c_void_p(int(out_ptr)),
+                                                    C.c_void_p(int(stream))))
+            return
+        a, n, _ = self._edit_args(args)
         self._check(self._lib.tbx_reduce_device(self._h, int(query), _ptr(a) if n else None, n, 0, C.c_void_p(int(out_ptr)), C.c_void_p(int(stream))))
+
+    def reduce_width(self, query):
+        return self._lib.tbx_reduce_width(_abi.GAME_IDS[self.game], int(query))
 
     def query(self, env, query_id, args, n_out=2):
         a = (C.c_int32 * len(args))(*[int(v) for v in args])
