@@ -7,8 +7,12 @@
 // and compared bit for bit by tests/test_gpu_parity.py.  All arithmetic is int32 except the
 // jitter test (one binary64 compare).
 //
-// Layout in HBM: scalar fields struct-of-arrays over envs ([field][N] int32); the per-entity
-// tables are env-major so that the 64 lanes of an env's wave read them coalesced:
+// Layout in HBM: everything of an env is env-major, so that the 64 lanes of its wave read it coalesced:
+//   head     [N][64]    int32   lane i < NF = scalar field i; words 60..63 = the env's RNG (s0 lo, s0 hi, s1 lo, s1 hi);
+//                               words 33, 34 = a MIRROR of enemy 0's x, y (the formation origin), written with every head
+//                               row and read only by the step of an engine whose states are plain (si_load_canonical).
+//                               (A [field][N] table costs a wave-per-env kernel 8x its bytes: the 32 envs of a 128-byte
+//                               line sit in 8 consecutive blocks, which run on the 8 XCDs, and every L2 fetches the line.)
 //   enemies  [N][5][64] int32   lane = enemy index (x, y, row | col << 8 | id << 16, points, status)
 //   shields  [N][64]    uint32  lane = shield*18 + row (16-bit pixel mask)
 //   lasers   [N][8][16] int32   lane (0..8) = laser slot (8 = the ship's laser), field-major
@@ -41,13 +45,15 @@ enum SiField {
 enum { EF_X, EF_Y, EF_RCI, EF_POINTS, EF_STATUS, NEF };
 enum { LF_X, LF_Y, LF_W, LF_H, LF_T, LF_MOV, LF_SPEED, LF_COLOR, NLF };
 constexpr int SHIP_SLOT = TBX_SI_MAX_LASERS;   // lane 8 carries the ship's laser
+constexpr int HEAD_WORDS = 64, HEAD_RNG = 60;  // the head row: one 256-byte load per env
+constexpr int HEAD_ORIGIN = 33;                // enemy 0's x, y
+static_assert(NF <= HEAD_ORIGIN && HEAD_ORIGIN + 2 <= HEAD_RNG, "the head row's sections");
 
 struct SiDev {
     int n;
     uint64_t* sim_rng; int32_t* prev_score; int32_t* reward; uint8_t* done; int32_t* lives_out; int32_t* score_out;
     uint64_t* packed; uint32_t* err_flag;
-    uint64_t* rng;        // [2][N]
-    int32_t* sc;          // [NF][N]
+    int32_t* sc;          // [N][HEAD_WORDS]: the head row (scalars + RNG)
     int32_t* enemies;     // [N][NEF][64]
     uint32_t* shields;    // [N][64]
     int32_t* lasers;      // [N][NLF][16]
@@ -88,17 +94,20 @@ struct SiLoaded {
 
 __device__ __forceinline__ int32_t si_rci(const SiRegs& s) { return (int32_t)((uint32_t)(s.erow & 0xFF) | ((uint32_t)(s.ecol & 0xFF) << 8) | ((uint32_t)s.eid << 16)); }
 
-__device__ __forceinline__ void si_load(const SiDev& d, int env, int lane, SiRegs& s, SiLoaded& o)
+__device__ __forceinline__ void si_load_head(const SiDev& d, int env, int lane, SiRegs& s, SiLoaded& o)
 {
-    const size_t N = (size_t)d.n;
-    s.rng.s0 = d.rng[env];
-    s.rng.s1 = d.rng[N + env];
-    // the env's NF scalars with ONE load instruction (lane i fetches field i) and a v_readlane per field actually used:
-    // they land in SGPRs instead of occupying NF VGPRs, and NF - 1 single-dword VMEM instructions disappear
-    static_assert(NF <= 64, "one lane per scalar field");
-    o.fv = lane < NF ? d.sc[(size_t)lane * N + env] : 0;
+    o.fv = d.sc[(size_t)env * HEAD_WORDS + lane];
 #pragma unroll
     for (int i = 0; i < NF; i++) s.f[i] = __builtin_amdgcn_readlane(o.fv, i);
+    s.rng.s0 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(o.fv, HEAD_RNG) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(o.fv, HEAD_RNG + 1) << 32);
+    s.rng.s1 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(o.fv, HEAD_RNG + 2) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(o.fv, HEAD_RNG + 3) << 32);
+}
+
+__device__ __forceinline__ void si_load(const SiDev& d, int env, int lane, SiRegs& s, SiLoaded& o)
+{
+    // the env's NF scalars and its RNG with ONE coalesced load (lane i fetches word i of the head row) and a v_readlane per
+    // field actually used: they land in SGPRs instead of occupying NF VGPRs
+    si_load_head(d, env, lane, s, o);
     const int32_t* e = d.enemies + (size_t)env * NEF * 64;
     o.ex = e[EF_X * 64 + lane]; o.ey = e[EF_Y * 64 + lane]; o.rci = e[EF_RCI * 64 + lane];
     o.epoints = e[EF_POINTS * 64 + lane]; o.estatus = e[EF_STATUS * 64 + lane];
@@ -119,22 +128,20 @@ __device__ __forceinline__ void si_load(const SiDev& d, int env, int lane, SiReg
 // The same for an engine whose states are CANONICAL (SiOps::custom == false: every env's enemy i sits at formation origin +
 // (32 (i % 6), 18 (i / 6)) with row i / 6, col i % 6, id i and the config's points of its row, and every laser in flight has
 // the size, speed, direction and colour of its kind): what never changes is derived instead of loaded.  Of the five 256-byte
-// enemy rows only the status row is read -- plus the first word of the x and y rows, the formation origin -- and of the eight
-// laser rows only x, y and t: ~1.0 KB instead of ~2.2 KB per env-frame.  `o` receives exactly what a full load would have
-// found, so si_store_changed() keeps writing back the rows a frame changed (x / y when the formation marches, the constant
-// laser rows when a laser spawns or dies) and every other kernel keeps reading the full table.
+// enemy rows only the status row is read -- the formation origin comes out of the head row's mirror -- and of the eight laser
+// rows only x, y and t: ~1.3 KB instead of ~2.2 KB per env-frame.  `o` receives exactly what a full load would have found, so
+// si_store_changed() keeps writing back the rows a frame changed (x / y when the formation marches, the constant laser rows
+// when a laser spawns or dies) and every other kernel keeps reading the full table.
+// (Measured and not kept: the status as bytes and the lasers' (x, y, t) as packed words in the head row as well -- two loads per
+// env-frame, 844 B = 1.7x the algorithmic bytes -- is 3 % SLOWER (51.1 against 49.6 us): the kernel is bound by its instruction
+// stream and exposed latency, not by bytes, and the packing costs more issue slots than the six loads it removes.)
 __device__ __forceinline__ void si_load_canonical(const SiDev& d, const SiCfg& c, int env, int lane, SiRegs& s, SiLoaded& o)
 {
-    const size_t N = (size_t)d.n;
-    s.rng.s0 = d.rng[env];
-    s.rng.s1 = d.rng[N + env];
-    o.fv = lane < NF ? d.sc[(size_t)lane * N + env] : 0;
-#pragma unroll
-    for (int i = 0; i < NF; i++) s.f[i] = __builtin_amdgcn_readlane(o.fv, i);
+    si_load_head(d, env, lane, s, o);
+    const int32_t fx = __builtin_amdgcn_readlane(o.fv, HEAD_ORIGIN), fy = __builtin_amdgcn_readlane(o.fv, HEAD_ORIGIN + 1);   // enemy 0 = the formation origin
+    const bool on = lane < s.f[F_N_ENEMIES];
     const int32_t* e = d.enemies + (size_t)env * NEF * 64;
     o.estatus = e[EF_STATUS * 64 + lane];
-    const int32_t fx = wave_uniform(e[EF_X * 64]), fy = wave_uniform(e[EF_Y * 64]);      // enemy 0 = the formation origin
-    const bool on = lane < s.f[F_N_ENEMIES];
     const int row = lane / TBX_SI_COLS, col = lane - row * TBX_SI_COLS;
     int32_t pts = 0;
 #pragma unroll
@@ -145,10 +152,10 @@ __device__ __forceinline__ void si_load_canonical(const SiDev& d, const SiCfg& c
     s.ex = o.ex; s.ey = o.ey; s.epoints = o.epoints; s.estatus = o.estatus;
     s.erow = on ? row : 0; s.ecol = on ? col : 0; s.eid = on ? lane : 0;
     s.srow = o.srow = d.shields[(size_t)env * 64 + lane];
-    const int32_t* l = d.lasers + (size_t)env * NLF * 16;
     const int slot = lane & 15;
     const bool enemy_laser = slot < s.f[F_N_LASERS] && slot < TBX_SI_MAX_LASERS, ship_laser = slot == SHIP_SLOT && s.f[F_HAS_SHIP_LASER] != 0;
     const bool lz = enemy_laser || ship_laser;
+    const int32_t* l = d.lasers + (size_t)env * NLF * 16;
     o.lf[LF_X] = l[LF_X * 16 + slot]; o.lf[LF_Y] = l[LF_Y * 16 + slot]; o.lf[LF_T] = l[LF_T * 16 + slot];
     o.lf[LF_W] = lz ? TBX_SI_LASER_W : 0; o.lf[LF_H] = lz ? TBX_SI_LASER_H : 0;
     o.lf[LF_MOV] = ship_laser ? TBX_DIR_UP : enemy_laser ? TBX_DIR_DOWN : 0;
@@ -163,18 +170,19 @@ __device__ __forceinline__ int32_t si_scalar_row(int lane, const SiRegs& s)
     int32_t fv = 0;                               // v_writelane: one instruction per field (a select chain is two)
 #pragma unroll
     for (int i = 0; i < NF; i++) asm("v_writelane_b32 %0, %1, %2" : "+v"(fv) : "s"(wave_uniform(s.f[i])), "n"(i));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(fv) : "s"(__builtin_amdgcn_readlane(s.ex, 0)), "n"(HEAD_ORIGIN));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(fv) : "s"(__builtin_amdgcn_readlane(s.ey, 0)), "n"(HEAD_ORIGIN + 1));
+    const uint64_t r0 = wave_uniform64(s.rng.s0), r1 = wave_uniform64(s.rng.s1);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(fv) : "s"((int32_t)(uint32_t)r0), "n"(HEAD_RNG));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(fv) : "s"((int32_t)(uint32_t)(r0 >> 32)), "n"(HEAD_RNG + 1));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(fv) : "s"((int32_t)(uint32_t)r1), "n"(HEAD_RNG + 2));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(fv) : "s"((int32_t)(uint32_t)(r1 >> 32)), "n"(HEAD_RNG + 3));
     return fv;
 }
 
 __device__ __forceinline__ void si_store(const SiDev& d, int env, int lane, const SiRegs& s)
 {
-    const size_t N = (size_t)d.n;
-    if (lane == 0) {
-        d.rng[env] = s.rng.s0;
-        d.rng[N + env] = s.rng.s1;
-    }
-    // lane i stores field i: one store instruction for the NF scalars
-    if (lane < NF) d.sc[(size_t)lane * N + env] = si_scalar_row(lane, s);
+    d.sc[(size_t)env * HEAD_WORDS + lane] = si_scalar_row(lane, s);      // the head row: scalars, zeros, RNG
     int32_t* e = d.enemies + (size_t)env * NEF * 64;
     e[EF_X * 64 + lane] = s.ex; e[EF_Y * 64 + lane] = s.ey; e[EF_RCI * 64 + lane] = si_rci(s);
     e[EF_POINTS * 64 + lane] = s.epoints; e[EF_STATUS * 64 + lane] = s.estatus;
@@ -191,13 +199,8 @@ __device__ __forceinline__ void si_store(const SiDev& d, int env, int lane, cons
 // hits -- the step kernel is bound by its HBM bytes, and most of them were rows written back unchanged
 __device__ __forceinline__ void si_store_changed(const SiDev& d, int env, int lane, const SiRegs& s, const SiLoaded& o)
 {
-    const size_t N = (size_t)d.n;
-    if (lane == 0) {
-        d.rng[env] = s.rng.s0;
-        d.rng[N + env] = s.rng.s1;
-    }
     const int32_t fv = si_scalar_row(lane, s);
-    if (lane < NF && fv != o.fv) d.sc[(size_t)lane * N + env] = fv;
+    if (fv != o.fv) d.sc[(size_t)env * HEAD_WORDS + lane] = fv;
     int32_t* e = d.enemies + (size_t)env * NEF * 64;
     const int32_t rci = si_rci(s);
     if (__ballot(s.ex != o.ex)) e[EF_X * 64 + lane] = s.ex;
@@ -1761,18 +1764,16 @@ __global__ __launch_bounds__(256) void si_edit_kernel(SiDev d, int op, TbxEditAr
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= d.n || (mask && !mask[env])) return;
-    const size_t N = (size_t)d.n;
     const int f = op == TBX_EDIT_SET_LIVES ? F_LIVES : op == TBX_EDIT_SET_SCORE ? F_SCORE : op == TBX_EDIT_SET_LEVEL ? F_LEVEL : F_UFO_APP;
-    d.sc[(size_t)f * N + env] = a.geti(env, 0);
+    d.sc[(size_t)env * HEAD_WORDS + f] = a.geti(env, 0);
 }
 
 __global__ __launch_bounds__(256) void si_reduce_kernel(SiDev d, int query, TbxEditArgs a, double* __restrict__ out, int width)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= d.n) return;
-    const size_t N = (size_t)d.n;
     double* o = out + (size_t)env * width;
-    auto F = [&](int f) { return d.sc[(size_t)f * N + env]; };
+    auto F = [&](int f) { return d.sc[(size_t)env * HEAD_WORDS + f]; };
     if (query == TBX_QUERY_SI_SHIP) {
         o[0] = F(F_SHIP_X); o[1] = F(F_SHIP_Y); o[2] = F(F_SHIP_W); o[3] = F(F_SHIP_H); o[4] = F(F_SHIP_SPEED);
         o[5] = F(F_SHIP_FLAGS) & 1; o[6] = F(F_SHIP_DC); o[7] = (F(F_SHIP_FLAGS) >> 1) & 1;
@@ -1783,10 +1784,9 @@ __global__ void si_scalars_kernel(SiDev d, int32_t* score, int32_t* lives, int32
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.n) return;
-    const size_t N = (size_t)d.n;
-    if (score) score[i] = d.sc[(size_t)F_SCORE * N + i];
-    if (lives) lives[i] = d.sc[(size_t)F_LIVES * N + i];
-    if (level) level[i] = d.sc[(size_t)F_LEVEL * N + i];
+    if (score) score[i] = d.sc[(size_t)i * HEAD_WORDS + F_SCORE];
+    if (lives) lives[i] = d.sc[(size_t)i * HEAD_WORDS + F_LIVES];
+    if (level) level[i] = d.sc[(size_t)i * HEAD_WORDS + F_LEVEL];
 }
 
 // ------------------------------------------------------------------ host ops
@@ -1835,8 +1835,7 @@ struct SiOps : GameOps {
         d.n = e->n;
         d.sim_rng = e->sim_rng; d.prev_score = e->prev_score; d.reward = e->reward; d.done = e->done;
         d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed; d.err_flag = e->err_flag;
-        TBX_HIP(hipMalloc((void**)&d.rng, 2 * N * sizeof(uint64_t)));
-        TBX_HIP(hipMalloc((void**)&d.sc, (size_t)NF * N * sizeof(int32_t)));
+        TBX_HIP(hipMalloc((void**)&d.sc, N * HEAD_WORDS * sizeof(int32_t)));
         TBX_HIP(hipMalloc((void**)&d.enemies, N * NEF * 64 * sizeof(int32_t)));
         TBX_HIP(hipMalloc((void**)&d.shields, N * 64 * sizeof(uint32_t)));
         TBX_HIP(hipMalloc((void**)&d.lasers, N * NLF * 16 * sizeof(int32_t)));
@@ -1848,9 +1847,9 @@ struct SiOps : GameOps {
     void destroy(tbx_engine*) override
     {
         hipFree(recs); hipFree(recs_other);
-        hipFree(d.rng); hipFree(d.sc); hipFree(d.enemies); hipFree(d.shields); hipFree(d.lasers);
-        hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.enemies); hipFree(dA.shields); hipFree(dA.lasers);
-        hipFree(dB.rng); hipFree(dB.sc); hipFree(dB.enemies); hipFree(dB.shields); hipFree(dB.lasers);
+        hipFree(d.sc); hipFree(d.enemies); hipFree(d.shields); hipFree(d.lasers);
+        hipFree(dA.sc); hipFree(dA.enemies); hipFree(dA.shields); hipFree(dA.lasers);
+        hipFree(dB.sc); hipFree(dB.enemies); hipFree(dB.shields); hipFree(dB.lasers);
     }
 
     int get_config(tbx_engine*, void* pod) override { memcpy(pod, &cfg, sizeof cfg); return TBX_OK; }
@@ -1946,9 +1945,8 @@ struct SiOps : GameOps {
         if (x.sc) return TBX_OK;
         const size_t N = (size_t)e->n;
         x = d;
-        x.sc = nullptr; x.enemies = nullptr; x.shields = nullptr; x.lasers = nullptr; x.rng = nullptr;
-        TBX_HIP(hipMalloc((void**)&x.rng, 2 * N * sizeof(uint64_t)));
-        TBX_HIP(hipMalloc((void**)&x.sc, (size_t)NF * N * sizeof(int32_t)));
+        x.sc = nullptr; x.enemies = nullptr; x.shields = nullptr; x.lasers = nullptr;
+        TBX_HIP(hipMalloc((void**)&x.sc, N * HEAD_WORDS * sizeof(int32_t)));
         TBX_HIP(hipMalloc((void**)&x.enemies, N * NEF * 64 * sizeof(int32_t)));
         TBX_HIP(hipMalloc((void**)&x.shields, N * 64 * sizeof(uint32_t)));
         TBX_HIP(hipMalloc((void**)&x.lasers, N * NLF * 16 * sizeof(int32_t)));
@@ -2061,6 +2059,7 @@ struct SiOps : GameOps {
             const int row = i / TBX_SI_COLS;
             if (st.enemies[i].id != i || row >= TBX_SI_MAX_ROWS || st.enemies[i].points != cfg.row_scores[row]) return false;
         }
+
         auto laser_ok = [](const tbx_si_laser_t& l, int mov, int speed, uint32_t color) {
             return l.w == TBX_SI_LASER_W && l.h == TBX_SI_LASER_H && (l.movement & 3) == mov && l.speed == speed && pack_color(l.color) == color;
         };

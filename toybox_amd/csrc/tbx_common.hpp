@@ -157,6 +157,10 @@ __device__ __forceinline__ uint32_t tbx_snap_slots(const ActionSource& src, int 
 }
 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t wave_uniform64(uint64_t v)
+{
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
 
 // value of lane `src` for a WAVE-UNIFORM src: v_readlane_b32 (a few cycles, result in an SGPR) instead of ds_bpermute_b32
 __device__ __forceinline__ int bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
