@@ -127,6 +127,7 @@ def main():
     for name, text in (("agent_summary.md", agent_summary(tag)), ("pmc_sq_counters.txt", sq_counters(tag)),
                        ("loop_sweeps.txt", loop_sweeps(tag)),
                        ("ab_prev_round.txt", cat_files(tag, "ab_*.txt", "# scripts/ab_render.py: lib_prev.so = the previous round's final build, interleaved with this build on one box")),
+                       ("issue_rate.txt", cat_files(tag, "issue_rate.txt", "# scripts/ubench/issue_rate.hip: scalar-ALU and vector-ALU instructions a compute unit issues per nanosecond, alone and side by side")),
                        ("kernel_gaps.txt", cat_files(tag, "kernel_gaps.txt", "# scripts/gpu_gaps.sh + scripts/trace_gaps.py: kernel durations inside the loops and the idle gaps in front of them")),
                        ("bench_lines.md", bench_lines(tag))):
         with open(os.path.join(dst, "%s_%s" % (tag, name)), "w") as fh:

@@ -35,6 +35,8 @@ for g in breakout space_invaders amidar; do
   AB_PREROLL=400 timeout 300 python scripts/ab_render.py $g 3 scripts/ab/lib_prev.so toybox_amd/csrc/libtoybox_amd.so > "$OUT/ab_render_$g.txt" 2>&1
   AB_STEP=1 AB_PREROLL=400 timeout 300 python scripts/ab_render.py $g 3 scripts/ab/lib_prev.so toybox_amd/csrc/libtoybox_amd.so > "$OUT/ab_step_render_$g.txt" 2>&1
 done
+# ---- instruction issue rates of a compute unit (SALU / VALU alone and side by side), for the issue-time prices of DESIGN section 6
+make -C scripts/ubench issue_rate > /dev/null 2>&1; timeout 120 scripts/ubench/issue_rate 2>&1 | grep -v "waves/SIMD 8" > "$OUT/issue_rate.txt"
 # ---- what the loops' time is made of (kernel trace: durations in the loop, gaps)
 bash scripts/gpu_gaps.sh > /dev/null 2>&1
 cp "$REPO/gpurun_out/gaps/summary.txt" "$OUT/kernel_gaps.txt" 2>/dev/null
