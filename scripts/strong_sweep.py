@@ -2,7 +2,7 @@
 """Loop forms and record-ring depths against each other in ONE process on ONE box: for every batch size, engines with no
 gather / a collective per step / a K-step ring, each pre-rolled, then rounds of [pair, fused] x [no gather, K=1, K=ring] of
 STEPS steps each -- ms per step of the bench loop (one frame stepped + one RGB frame rasterised per env).
-  python scripts/strong_sweep.py [game] [sizes ...]    (env SS_ROUNDS, SS_STEPS, SS_RING)"""
+  python scripts/strong_sweep.py [game] [sizes ...]    (env SS_ROUNDS, SS_STEPS, SS_RING, SS_LIB, SS_STEP_FORM)"""
 import json
 import os
 import sys
@@ -24,6 +24,8 @@ for n in sizes:
     for name, every in (("none", 0), ("k1", 1), ("k%d" % ring, ring)):
         e = Engine(game, n, lib=LIB)
         e.seed(1234); e.new_game()
+        if os.environ.get("SS_STEP_FORM"):             # Amidar: 2 = the wave-per-env step (and with it the fused launch) at every size
+            e.set_option(_abi.OPT_STEP_FORM, int(os.environ["SS_STEP_FORM"]))
         if every:
             e.set_option(_abi.OPT_GATHER_EVERY, every)
             e.gather_init(1, 0, e.gather_unique_id())

@@ -1979,7 +1979,12 @@ struct AmiOps : GameOps {
     // 420-520 us beside a rasteriser instead of 45, the rasteriser 1.69-1.72 ms instead of 1.37) and the step's thread-per-env
     // form riding in the rasteriser's launch with the records written by the step itself (round 4, 80-VGPR budget of the
     // six-waves-per-SIMD launch: 1.61 against 1.47 ms per step at 65 536 envs, 0.160 against 0.106 at 4 096) -- the step is a chain
-    // of dependent loads, and beside a kernel that saturates the memory system with stores every one of them queues.
+    // of dependent loads, and beside a kernel that saturates the memory system with stores every one of them queues.  A third
+    // form needs no records at all: the WAVE-per-env step (one round of loads, then registers) as the first blocks of the
+    // rasteriser's launch, writing the whole next state into a second state buffer that becomes the current one after the
+    // launch.  Built, bit-identical, and no faster either: ms per step fused / two launches 0.1072 / 0.1085 at 4 096 envs,
+    // 0.214 / 0.204 at 8 192, 0.421 / 0.391 at 16 384, 1.68 / 1.53 at 65 536 (five waves per SIMD, no spills; six: 0.209 at
+    // 8 192, 1.62 at 65 536) -- a step wave holds a rasteriser wave's slot for its whole latency-bound life.  Removed.
     void rebind_outputs(tbx_engine* e) override
     {
         d.reward = e->reward; d.done = e->done; d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed;
