@@ -103,7 +103,7 @@ def parse():
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / barrier walk-through without any GPU call")
     ap.add_argument("--gym", action="store_true", help="reference protocol: also the env.step() arm (test/benchmark.py:83-97)")
     ap.add_argument("--reps", type=int, default=30, help="reference protocol: repetitions (mean and s.e.m. reported)")
-    ap.add_argument("--protocol", default="batch", choices=["batch", "reference", "agent"],
+    ap.add_argument("--protocol", default="batch", choices=["batch", "reference", "agent", "host"],
                     help="'reference' = the raw single-env loop of the reference's harness (test/benchmark.py:44-58)")
     ap.add_argument("--deepmind", action="store_true",
                     help="agent protocol: also EpisodicLife + FireReset + NoopReset(30) + episode monitor (wrap_deepmind)")
@@ -446,6 +446,55 @@ def bench_agent_protocol(args):
     return 0
 
 
+def bench_host_protocol(args):
+    """The PCIe-inclusive rate: what a caller on the HOST side of the boundary gets, the way the reference's consumers sit
+    (ToyboxBaseEnv / VecEnv hand every frame to numpy: envs/atari/base.py:109, vec_env/__init__.py:63-74).  One step = actions
+    from a host array, the batch step, every env's frame copied to host memory -- through ToyboxVecEnv.step().  Two arms: a
+    fresh pageable array per step (the VecEnv contract as the reference's learners use it) and one reused page-locked array
+    (reuse_obs_buffer=True); and the agent pipeline, whose observation is 7 KB per env instead of 100-200 KB.  Never `value`
+    of the headline: that one is measured with everything resident in HBM."""
+    import numpy as np
+    from toybox_amd.envs import ToyboxPreprocVecEnv, ToyboxVecEnv
+    n, K, Wm = args.envs, args.steps, args.warmup
+    rng = np.random.default_rng(ACTION_SEED)
+    arms = {}
+    for name, reuse in (("pageable_fresh_array", False), ("pinned_reused_array", True)):
+        env = ToyboxVecEnv(args.game, n, grayscale=False, seed=SEED_BASE, reuse_obs_buffer=reuse)
+        na = env.action_space.n
+        obs = env.reset()
+        acts = [rng.integers(0, na, n) for _ in range(8)]
+        for t in range(Wm):
+            obs, _, _, _ = env.step(acts[t % 8])
+        t0 = time.perf_counter()
+        for t in range(K):
+            obs, _, _, _ = env.step(acts[t % 8])
+        dt = time.perf_counter() - t0
+        arms[name] = {"value": n * K / dt, "unit": "env-steps/s", "ms_per_step": 1000 * dt / K, "host_GB_per_s": obs.nbytes * K / dt / 1e9}
+        frame_bytes = obs.nbytes // n
+        env.close()
+    for name, reuse in (("agent_obs_84x84x4_pageable", False), ("agent_obs_84x84x4_pinned", True)):
+        env = ToyboxPreprocVecEnv(args.game, n, seed=SEED_BASE, reuse_obs_buffer=reuse)
+        na = env.action_space.n
+        obs = env.reset()
+        acts = [rng.integers(0, na, n) for _ in range(8)]
+        for t in range(Wm):
+            obs, _, _, _ = env.step(acts[t % 8])
+        t0 = time.perf_counter()
+        for t in range(K):
+            obs, _, _, _ = env.step(acts[t % 8])
+        dt = time.perf_counter() - t0
+        arms[name] = {"value": n * K / dt, "unit": "agent-steps/s", "ms_per_step": 1000 * dt / K, "host_GB_per_s": obs.nbytes * K / dt / 1e9}
+        env.close()
+    best = arms["pinned_reused_array"]
+    out = {"metric": "env steps/sec INCLUDING the PCIe transfer of every frame to the host, %s" % args.game, "value": best["value"],
+           "unit": "env-steps/s", "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": best["ms_per_step"], "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic", "arms": arms,
+           "config": {"workload": "%s ToyboxVecEnv.step(host actions) -> RGB frames in host memory, %d envs, %d B per frame"
+                                  % (args.game, n, frame_bytes)}}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 # ---------------------------------------------------------------------------------------------- launcher
 
 def spawn_ranks(args):
@@ -738,6 +787,8 @@ def main():
         return bench_reference_protocol(args)
     if args.protocol == "agent":
         return bench_agent_protocol(args)
+    if args.protocol == "host":
+        return bench_host_protocol(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         return spawn_ranks(args)
 

@@ -127,6 +127,48 @@ def test_vec_env_contract(game, factory):
         e.close()
 
 
+def test_render_into_a_given_array(factory):
+    """Engine.render(out=...) writes every env's frame into the caller's array (shape and dtype checked)"""
+    n = 5
+    e = factory("amidar", n)
+    e.seed(3); e.new_game()
+    want = e.render(3)
+    buf = np.zeros((n, e.height, e.width, 3), np.uint8)
+    assert e.render(3, out=buf) is buf and np.array_equal(buf, want)
+    for bad in (np.zeros((n, e.height, e.width, 4), np.uint8), np.zeros((n, e.height, e.width, 3), np.int32), buf[:, :, ::2]):
+        with pytest.raises(ValueError):
+            e.render(3, out=bad)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_vec_env_with_a_reused_page_locked_observation_buffer(hip_lib, oracle_lib):
+    """reuse_obs_buffer=True: the same page-locked array comes back from every reset() / step(), holding what the default
+    (a fresh array per call) holds -- checked against a second env over the CPU restatement"""
+    n, game = 40, "space_invaders"
+    a = ToyboxVecEnv(game, n, grayscale=False, engine=Engine(game, n, lib=hip_lib), seed=7, reuse_obs_buffer=True)
+    b = ToyboxVecEnv(game, n, grayscale=False, engine=Engine(game, n, lib=oracle_lib), seed=7)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob)
+    rng = np.random.default_rng(1)
+    for t in range(60):
+        act = rng.integers(0, a.action_space.n, n)
+        ra, rb = a.step(act), b.step(act)
+        assert ra[0] is oa                                   # the one buffer
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2]), t
+    a.close(); b.close()
+    # ... and the agent pipeline's observations
+    a = ToyboxPreprocVecEnv(game, n, engine=Engine(game, n, lib=hip_lib), seed=7, reuse_obs_buffer=True)
+    b = ToyboxPreprocVecEnv(game, n, engine=Engine(game, n, lib=oracle_lib), seed=7)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob)
+    for t in range(30):
+        act = rng.integers(0, a.action_space.n, n)
+        ra, rb = a.step(act), b.step(act)
+        assert ra[0] is oa and np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2]), t
+    a.close(); b.close()
+
+
 def test_vec_env_cached_terminal_state(factory):
     eng = factory("breakout", 4)
     env = ToyboxVecEnv("breakout", 4, cache_terminal_state=True, engine=eng)

@@ -154,8 +154,14 @@ class Engine:
         return score, lives, level, over.astype(bool)
 
     # ------------------------------------------------------------------ frames
-    def render(self, channels=3):
-        out = np.empty((self.n_envs, self.height, self.width, channels), np.uint8)
+    def render(self, channels=3, out=None):
+        """Every env's frame as uint8 [N, H, W, channels] on the host.  `out`: write into this array instead of a fresh one
+        (a reused, page-locked one -- toybox_amd.hip.PinnedArray -- receives the frames at the PCIe link's rate)."""
+        shape = (self.n_envs, self.height, self.width, channels)
+        if out is None:
+            out = np.empty(shape, np.uint8)
+        elif out.shape != shape or out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous uint8 array of shape %r" % (shape,))
         self._check(self._lib.tbx_render(self._h, _ptr(out), int(channels)))
         return out
 
@@ -290,19 +296,27 @@ class Engine:
             raise ValueError("counts must have shape (%d,)" % self.n_envs)
         self._check(self._lib.tbx_agent_set_noops(self._h, _ptr(a)))
 
-    def agent_reset(self):
-        obs = np.empty(self._agent_shape, np.uint8)
+    def _agent_obs_array(self, out):
+        if out is None:
+            return np.empty(self._agent_shape, np.uint8)
+        if out.shape != tuple(self._agent_shape) or out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous uint8 array of shape %r" % (tuple(self._agent_shape),))
+        return out
+
+    def agent_reset(self, out=None):
+        obs = self._agent_obs_array(out)
         self._check(self._lib.tbx_agent_reset(self._h, _ptr(obs)))
         return obs
 
-    def agent_step(self, actions, tolerate_needs_reset=False):
-        """actions: ALE ids.  Returns (obs uint8[N,oh,ow,stack], reward float32[N], done bool[N]).
+    def agent_step(self, actions, tolerate_needs_reset=False, out=None):
+        """actions: ALE ids.  Returns (obs uint8[N,oh,ow,stack], reward float32[N], done bool[N]); `out`: the array the
+        observations go into (a reused page-locked one takes them at the PCIe link's rate).
         TBX_E_NEEDS_RESET (where bench.Monitor raises) is raised like every other error unless tolerate_needs_reset: the step
         has been carried out either way and the outputs are valid."""
         a = np.ascontiguousarray(actions, dtype=np.int32)
         if a.shape != (self.n_envs,):
             raise ValueError("actions must have shape (%d,)" % self.n_envs)
-        obs = np.empty(self._agent_shape, np.uint8)
+        obs = self._agent_obs_array(out)
         reward = np.empty(self.n_envs, np.float32)
         done = np.empty(self.n_envs, np.uint8)
         rc = self._lib.tbx_agent_step(self._h, _ptr(a), _ptr(reward), _ptr(done), _ptr(obs))

@@ -49,11 +49,19 @@ class LazyInfos:
 
 
 class ToyboxVecEnv:
-    def __init__(self, game, num_envs, grayscale=True, alpha=False, seed=None, cache_terminal_state=False, engine=None):
+    def __init__(self, game, num_envs, grayscale=True, alpha=False, seed=None, cache_terminal_state=False, engine=None,
+                 reuse_obs_buffer=False):
+        """reuse_obs_buffer: observations are written into ONE page-locked host array that every reset() / step() returns
+        again (the copy then runs at the PCIe link's rate; a fresh pageable array per call, the default and what the
+        reference's VecEnvs hand out, costs a staged copy and page faults -- bench.py --protocol host times both)."""
         self.game = {"spaceinvaders": "space_invaders"}.get(game, game)
         self.num_envs = int(num_envs)
         self.engine = engine if engine is not None else _make_engine(self.game, self.num_envs)
         self._channels = 1 if grayscale else 4 if alpha else 3
+        self._obs_buf = None
+        if reuse_obs_buffer:
+            from ..hip import PinnedArray
+            self._obs_buf = PinnedArray((self.num_envs, self.engine.height, self.engine.width, self._channels))
         self._action_set = sorted(self.engine.legal_actions)
         self._lut = np.asarray(self._action_set, dtype=np.int32)
         self.action_space = Discrete(len(self._action_set))
@@ -75,9 +83,12 @@ class ToyboxVecEnv:
         return out
 
     # ------------------------------------------------------------------ VecEnv
+    def _frames(self):
+        return self.engine.render(self._channels, out=self._obs_buf.array if self._obs_buf is not None else None)
+
     def reset(self):
         self.engine.new_game()
-        return self.engine.render(self._channels)
+        return self._frames()
 
     def step_async(self, actions):
         a = np.asarray(actions)
@@ -100,7 +111,7 @@ class ToyboxVecEnv:
                 self.engine.new_game(done.astype(np.uint8))
         else:
             reward, done, lives, score = self.engine.step(actions, auto_reset=True)
-        obs = self.engine.render(self._channels)
+        obs = self._frames()
         infos = LazyInfos(self.num_envs, {"lives": lives, "score": np.where(done, 0, score)}, extras)
         return obs, reward.astype(np.float32), done, infos
 
@@ -120,6 +131,8 @@ class ToyboxVecEnv:
     def close(self):
         if not self.closed:
             self.engine.close()
+            if self._obs_buf is not None:
+                self._obs_buf.close()
             self.closed = True
 
     @property
@@ -148,7 +161,8 @@ class ToyboxPreprocVecEnv:
     buffer TBX_BUF_AGENT_OBS stays uint8)."""
 
     def __init__(self, game, num_envs, skip=4, size=84, stack=4, clip_rewards=True, seed=None, engine=None,
-                 episode_life=False, fire_reset=False, noop_max=0, noop_seed=0, env_offset=0, frame_stack="vec", scale=False):
+                 episode_life=False, fire_reset=False, noop_max=0, noop_seed=0, env_offset=0, frame_stack="vec", scale=False,
+                 reuse_obs_buffer=False):
         self.game = {"spaceinvaders": "space_invaders"}.get(game, game)
         self.num_envs = int(num_envs)
         self.engine = engine if engine is not None else _make_engine(self.game, self.num_envs)
@@ -166,13 +180,20 @@ class ToyboxPreprocVecEnv:
                                env_offset=env_offset, stack_fill=1 if frame_stack == "env" else 0)
         self._pending = None
         self.closed = False
+        self._obs_buf = None                                 # reuse_obs_buffer: as in ToyboxVecEnv (the uint8 observations)
+        if reuse_obs_buffer:
+            from ..hip import PinnedArray
+            self._obs_buf = PinnedArray((self.num_envs, size, size, stack))
+
+    def _out(self):
+        return self._obs_buf.array if self._obs_buf is not None else None
 
     def _obs(self, obs):
         # ScaledFloatFrame.observation: np.array(observation).astype(np.float32) / 255.0
         return obs.astype(np.float32) / 255.0 if self.scale else obs
 
     def reset(self):
-        return self._obs(self.engine.agent_reset())
+        return self._obs(self.engine.agent_reset(out=self._out()))
 
     def step_async(self, actions):
         a = np.asarray(actions)
@@ -185,7 +206,7 @@ class ToyboxPreprocVecEnv:
     def step_wait(self):
         assert self._pending is not None, "step_wait without step_async"
         actions, self._pending = self._pending, None
-        obs, reward, done = self.engine.agent_step(actions)
+        obs, reward, done = self.engine.agent_step(actions, out=self._out())
         ended, ret, length = self.engine.agent_episodes()
         extras = {int(i): {"episode": {"r": float(ret[i]), "l": int(length[i])}} for i in np.flatnonzero(ended)}
         return self._obs(obs), reward, done, LazyInfos(self.num_envs, None, extras)
@@ -197,4 +218,6 @@ class ToyboxPreprocVecEnv:
     def close(self):
         if not self.closed:
             self.engine.close()
+            if self._obs_buf is not None:
+                self._obs_buf.close()
             self.closed = True

@@ -109,6 +109,31 @@ def memcpy_htod(dst_ptr, src_array, nbytes):
           "hipMemcpy H2D")
 
 
+class PinnedArray:
+    """A numpy array over page-locked host memory (hipHostMalloc): the destination of frame copies that are to run at the PCIe
+    link's rate (a copy into pageable memory is staged through a bounce buffer and faults fresh pages in)."""
+
+    def __init__(self, shape, dtype="uint8"):
+        import numpy as np
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._ptr = C.c_void_p()
+        check(runtime().hipHostMalloc(C.byref(self._ptr), C.c_size_t(max(self.nbytes, 1)), C.c_uint(0)), "hipHostMalloc")
+        buf = (C.c_uint8 * max(self.nbytes, 1)).from_address(self._ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self._ptr:
+            self.array = None
+            runtime().hipHostFree(self._ptr)
+            self._ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def mem_info():
     free_b, total_b = C.c_size_t(), C.c_size_t()
     check(runtime().hipMemGetInfo(C.byref(free_b), C.byref(total_b)), "hipMemGetInfo")
