@@ -1171,7 +1171,6 @@ __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__
 {
     constexpr int W = TBX_BRK_W, H = TBX_BRK_H;
     using Stager = RowStager<C, W, BRK_UNIT_ROWS>;
-    constexpr int NUNITS = H / BRK_UNIT_ROWS;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
 
     const int lane = threadIdx.x & 63;

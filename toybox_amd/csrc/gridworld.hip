@@ -405,7 +405,7 @@ template <int C, bool ALT>
 __global__ __launch_bounds__(TBX_BLOCK) void gw_render_kernel(GwDev d, uint8_t* out, int first_env, int count, int split, GwDev d_alt,
                                                               const uint8_t* __restrict__ pick_alt)
 {
-    constexpr int W = TBX_GW_W, H = TBX_GW_H, UNITS = H / GW_UNIT_ROWS;
+    constexpr int W = TBX_GW_W, H = TBX_GW_H;
     using Stager = RowStager<C, W, GW_UNIT_ROWS>;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
     __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][GwPainter<C>::NCLS * 8];

@@ -1355,7 +1355,7 @@ template <int C, bool ALT>
 __global__ __launch_bounds__(TBX_BLOCK) void si_render_kernel(SiDev d, uint8_t* out, int first_env, int count, int skip_blank, int split, SiDev d_alt,
                                                               const uint8_t* __restrict__ pick_alt)
 {
-    constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
+    constexpr int W = TBX_SI_W, H = TBX_SI_H;
     using Stager = RowStager<C, W, SI_UNIT_ROWS>;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
     __shared__ uint32_t lds_mask[TBX_WAVES_PER_BLOCK][SiPainter<C>::NCLS * 8];
@@ -1573,7 +1573,7 @@ struct SiRecPainter {
 template <int C>
 __global__ __launch_bounds__(TBX_BLOCK) void si_rec_render_kernel(const SiRenderRec* __restrict__ recs, uint8_t* __restrict__ out, int first_env, int count, int split)
 {
-    constexpr int W = TBX_SI_W, H = TBX_SI_H, NG = SI_NG;
+    constexpr int W = TBX_SI_W, H = TBX_SI_H;
     using Stager = RowStager<C, W, SI_UNIT_ROWS>;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK * Stager::UNIT_BYTES];
     __shared__ uint32_t spr_lds[SPR_WORDS];
