@@ -25,6 +25,9 @@ done
 for g in breakout space_invaders amidar; do
   python bench.py --protocol reference --gym --game $g --reps 10 > "$OUT/reference_${g}.json" 2>/dev/null        # 10 reps x 10 000 steps, both arms, CPU beside
 done
+for g in breakout space_invaders amidar; do
+  python bench.py --protocol host --game $g --envs 8192 --steps 20 --warmup 3 > "$OUT/host_${g}.json" 2>/dev/null        # PCIe-inclusive: frames / observations to host memory
+done
 # ---- loop forms and ring depths against each other, interleaved in one process per game
 timeout 400 python scripts/strong_sweep.py breakout 4096 8192 16384 65536 2>&1 | grep '^{' > "$OUT/sweep_breakout.txt"
 SS_RING=8 timeout 200 python scripts/strong_sweep.py breakout 8192 2>&1 | grep '^{' > "$OUT/sweep_breakout_ring8.txt"
