@@ -1925,6 +1925,9 @@ struct SiOps : GameOps {
     // and measured in round 4 (scripts/strong_sweep.py, ms per step two launches / fused on one box): 4 096 envs 0.1625 / 0.1645,
     // 8 192 envs 0.3103 / 0.3147, 65 536 envs 2.299 / 2.421.  The rasteriser is not waiting for anything the step's waves could hide
     // in: inside the launch they cost what they cost in front of it, plus the block slots (23 KB of LDS each) they hold.  Removed.
+    // Breakout's form -- ALL the step blocks first, then the rasteriser's -- was built too (bit-identical): 0.1561 / 0.1610 at 4 096
+    // envs (the overlapped launches of pipeline_auto get 0.150), 0.2999 / 0.3070 at 8 192, 2.311 / 2.309 at 65 536 (fused / two
+    // launches; staggered first waves inside it: no better).  Nothing at the size that matters, less than mode 3 below it: removed.
     bool serve_paints() const override { return true; }
     int serve(tbx_engine* e, TbxServeCtl* ctl_dev, hipStream_t s) override
     {
