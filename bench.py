@@ -28,15 +28,21 @@ time is the MAX over ranks; the reported value is the MEDIAN region (min / max a
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline       -- the dominant kernel (the rasteriser; fused: rasteriser + step launch) priced against HBM bandwidth with HIP
-                    events recorded on the caller's stream around every 8th such launch of the timed regions,
+                    events on the caller's stream: fused, around runs of 8 back-to-back launches (time / 8); two-launch form,
+                    around every 8th rasteriser launch; never next to a synchronisation,
   loop           -- which loop form `value` was measured with,
   serialised     -- the two-launch loop in stream order on the same engine (when `value` is anything else),
   step_only      -- the same loop without the rasteriser (not bandwidth-bound: no roofline),
   weak / strong  -- (N > 1) the other reading, and share_of_linear,
-  scaling_strong -- (N = 1) what ONE GPU does with 1/8 of the batch plus the record gather, as a share of linear (a fraction),
+  scaling_strong -- (N = 1) what ONE GPU does with 1/8 of the batch plus the record gather, as a share of linear (a fraction): `main`
+                    (the loop form of `value`), `policy_loop` (two launches + the same ring, over `serialised`), and two launches
+                    with a collective every step,
+  configs        -- (N = 1, Breakout) BASELINE.json configs 2-4 (4 096 envs per game) and config 5's per-GPU share (mixed
+                    32 768 envs + 1-rank gather) measured in the same invocation: value, serialised, whole-step fraction of 8 TB/s,
+  metric_version -- what `value` means (it changed between rounds 3 and 4) and which arms carry the older reading,
   rccl           -- ranks the communicator spans as RCCL reports it, ring depth, bytes per collective, library, verified,
   cpu_baseline   -- the CPU oracle (oracle/, a port: ctoybox itself cannot be built offline) on this box's host cores, a
-                    bounded sample of the same 65 536-env workload, plus BASELINE config 1 (one env, one thread) -- N=1 only.
+                    bounded sample of the same 65 536-env workload, plus BASELINE config 1 (one env, one thread); rank 0, every N.
 --dry-run walks the N-process launch, id exchange, barriers and teardown without touching a GPU (CPU test of the launcher).
 """
 import argparse
@@ -83,6 +89,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--preroll", type=int, default=1000, help="untimed step-only frames before the warm-up (mid-game states)")
+    ap.add_argument("--settle", type=int, default=40,
+                    help="untimed FULL steps (step + render, the loop form about to be timed) at the end of the pre-roll, in front of the "
+                         "--warmup steps: the chip comes out of the step-only pre-roll nearly idle")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="which reading is `value`.  strong (default): --envs IN TOTAL, sharded contiguously over the GPUs -- the metric "
                          "names one 64k-env batch on 1/2/4/8 GPUs; weak: --envs per GPU.  With N > 1 the other one is measured too")
@@ -96,6 +105,7 @@ def parse():
     ap.add_argument("--no-render", action="store_true", help="step-only mode as the main arm (no roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step-only arm and the strong-scaling share probe")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2-5 beside the headline line (N = 1, Breakout)")
     ap.add_argument("--with-gather", action="store_true", help="run the RCCL record gather even at one rank (1-rank communicator)")
     ap.add_argument("--allow-no-gather", action="store_true",
                     help="N > 1 only: if no RCCL communicator can be made, run without the per-step gather (file barrier) instead of failing")
@@ -149,15 +159,15 @@ def cpu_baseline(segments, channels, target_seconds):
     os.environ["TBX_ORACLE_THREADS"] = str(cores)
     engines, frames, total = [], {}, 0
     for game, n_seg, off in segments:
-        chunk = min(4096, n_seg)
-        for c in range(max(1, n_seg // chunk)):
+        for c0 in range(0, n_seg, 4096):                # (the last chunk of a ragged segment is shorter)
+            chunk = min(4096, n_seg - c0)
             e = Engine(game, chunk, lib=lib)
-            e.seed(SEED_BASE + off + c * chunk)
+            e.seed(SEED_BASE + off + c0)
             e.new_game()
-            engines.append((e, off + c * chunk))
+            engines.append((e, off + c0))
             total += chunk
             if game not in frames:
-                frames[game] = np.empty((chunk, e.height, e.width, channels), np.uint8)
+                frames[game] = np.empty((min(4096, n_seg), e.height, e.width, channels), np.uint8)
 
     def run(t_from, count):
         t0 = time.perf_counter()
@@ -233,11 +243,13 @@ class Region:
     def __init__(self, sync, rank_barrier, rank_max):
         self.sync, self.rank_barrier, self.rank_max = sync, rank_barrier, rank_max
 
-    def run(self, one_step, t0_index, K, R):
+    def run(self, one_step, t0_index, K, R, on_region=None):
         times = []
         t = t0_index
         for _ in range(R):
             self.sync(); self.rank_barrier()
+            if on_region is not None:
+                on_region()
             w0 = time.perf_counter()
             for i in range(K):
                 one_step(t + i)
@@ -256,21 +268,21 @@ def summarize(times, K):
 
 # ---------------------------------------------------------------------------------------------- other protocols
 
-def bench_mixed(args, world, rank, local_rank):
-    """BASELINE config 5: Breakout + Amidar + SpaceInvaders, args.envs envs per GPU split in three contiguous segments,
-    three homogeneous launches per phase on three streams, one record gather per segment."""
+def mixed_reading(args, world, rank, local_rank, envs, K, Wm, R, gather, cpu_seconds=None):
+    """BASELINE config 5: Breakout + Amidar + SpaceInvaders, `envs` envs per GPU in three contiguous segments whose sizes
+    differ by at most one (32 768 = 10 923 + 10 923 + 10 922), three homogeneous launches per phase on three streams, one
+    record gather per segment.  Returns the JSON object on rank 0 (None elsewhere)."""
     from toybox_amd import hip
     from toybox_amd.parallel import MixedBatch
     games = ["breakout", "amidar", "space_invaders"]
-    per = args.envs // 3
-    mb = MixedBatch(games, per, device=local_rank, global_offset=rank * per * 3)
+    sizes = MixedBatch.split_sizes(envs, len(games))
+    mb = MixedBatch(games, sizes, device=local_rank, global_offset=rank * envs)
     streams = [hip.Stream() for _ in games]
     mb.attach_streams([s.ptr for s in streams])
-    gather = world > 1 or args.with_gather
     if gather:
         with quiet_stdout():
             mb.gather_init(rank, world, gather_every=args.gather_every)
-    C, K, Wm, R = args.channels, args.steps, args.warmup, args.repeats
+    C = args.channels
     render = not args.no_render
     fused = render and args.loop != "pair" and C >= 3
     # three engines on three streams already keep two or three rasterisers in flight; the pipelined mode on top of that was
@@ -292,10 +304,11 @@ def bench_mixed(args, world, rank, local_rank):
     for e, off in zip(mb.engines, mb.offsets):
         for t in range(args.preroll):
             e.step_synthetic(ACTION_SEED, t, env_offset=off, auto_reset=True)
-    for t in range(Wm):
+    for t in range(SETTLE + Wm):
         one(args.preroll + t)
-    times, _ = reg.run(one, args.preroll + Wm, K, R)
+    times, _ = reg.run(one, args.preroll + SETTLE + Wm, K, R)
     mb.sync()
+    out = None
     if rank == 0:
         total = world * mb.n_envs
         fb = mb.frame_bytes(C) if render else 0
@@ -306,25 +319,34 @@ def bench_mixed(args, world, rank, local_rank):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+int32", "data": "synthetic",
                "pipeline": {"option": args.pipeline, "resolved_per_game": dict(zip(games, pipe))},
                "loop": {"form": "fused" if fused else "pair", "fused_per_game": dict(zip(games, [e.get_option(_abi_mod().OPT_RENDER_STEP_FUSED) for e in mb.engines]))},
-               "config": {"workload": "mixed batch, %d envs/GPU = 3 x %d (breakout, amidar, space_invaders), %s, three streams%s"
-                                      % (mb.n_envs, per, "step + RGB render" if render else "step-only",
+               "config": {"workload": "mixed batch, %d envs/GPU = %s (breakout, amidar, space_invaders), %s, three streams%s"
+                                      % (mb.n_envs, " + ".join(str(v) for v in sizes), "step + RGB render" if render else "step-only",
                                          (", RCCL gather of 8 B/env records, one collective per %d steps" % max(1, args.gather_every)) if gather else ""),
-                          "envs_per_gpu": mb.n_envs, "envs_total": total},
+                          "envs_per_gpu": mb.n_envs, "envs_total": total, "segment_sizes": sizes},
                "roofline": ({"bound": "hbm", "kernel": "the three rasterisers together (whole-step time, not per kernel)",
                              "achieved": fb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                              "algorithmic_bytes_per_step": fb,
                              "per_kernel": "profiles/ (rocprofv3 kernel trace of this command: the three rasterisers' own durations and "
                                            "whether they overlap)"} if render else None),
-               "rccl": ({"nranks": lead.gather_nranks(), "gather_bytes_per_step": 8 * per * 3 * world, "lib": lead.gather_library(),
-                         "communicators": len(games)} if gather else None)}
-        if world == 1 and not args.no_cpu_baseline:
+               "rccl": ({"nranks": lead.gather_nranks(), "gather_bytes_per_step": 8 * mb.n_envs * world, "lib": lead.gather_library(),
+                         "gather_every": lead.gather_every(), "communicators": len(games)} if gather else None)}
+        if cpu_seconds:
             try:
-                out["cpu_baseline"] = cpu_baseline([(g, per, i * per) for i, g in enumerate(games)], C, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline([(g, n, off) for g, n, off in zip(games, sizes, mb.offsets)], C, cpu_seconds)
             except Exception as ex:
                 out["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(out), flush=True)
     mb.close()
+    for st in streams:
+        st.close()
+    return out
+
+
+def bench_mixed(args, world, rank, local_rank):
+    out = mixed_reading(args, world, rank, local_rank, args.envs, args.steps, args.warmup, args.repeats, world > 1 or args.with_gather,
+                        cpu_seconds=None if args.no_cpu_baseline else args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     return 0
 
 
@@ -449,48 +471,50 @@ def bench_agent_protocol(args):
 def bench_host_protocol(args):
     """The PCIe-inclusive rate: what a caller on the HOST side of the boundary gets, the way the reference's consumers sit
     (ToyboxBaseEnv / VecEnv hand every frame to numpy: envs/atari/base.py:109, vec_env/__init__.py:63-74).  One step = actions
-    from a host array, the batch step, every env's frame copied to host memory -- through ToyboxVecEnv.step().  Two arms: a
-    fresh pageable array per step (the VecEnv contract as the reference's learners use it) and one reused page-locked array
-    (reuse_obs_buffer=True); and the agent pipeline, whose observation is 7 KB per env instead of 100-200 KB.  Never `value`
-    of the headline: that one is measured with everything resident in HBM."""
+    from a host array, the batch step, the observation of every env in host memory -- through the VecEnv classes' step().
+    Arms: the RGB frames through ToyboxVecEnv (rotating page-locked pool, the default; a fresh pageable array per step, the
+    contract as the reference spells it) and the agent pipeline through ToyboxPreprocVecEnv in its three layouts: whole
+    uint8[N,84,84,4] stacks from the device (default pool / fresh pageable arrays), ONE new plane per env and step with the stack
+    kept on the host as planes (the reference's data flow: subproc_vec_env.py:63-74 + vec_frame_stack.py:17-30), and the same
+    transfer rolled into a real array by numpy.  Never `value` of the headline: that one is measured with everything resident
+    in HBM."""
     import numpy as np
     from toybox_amd.envs import ToyboxPreprocVecEnv, ToyboxVecEnv
     n, K, Wm = args.envs, args.steps, args.warmup
     rng = np.random.default_rng(ACTION_SEED)
     arms = {}
-    for name, reuse in (("pageable_fresh_array", False), ("pinned_reused_array", True)):
-        env = ToyboxVecEnv(args.game, n, grayscale=False, seed=SEED_BASE, reuse_obs_buffer=reuse)
+
+    def run(env, unit, bytes_per_step, steps):
         na = env.action_space.n
-        obs = env.reset()
+        env.reset()
         acts = [rng.integers(0, na, n) for _ in range(8)]
         for t in range(Wm):
-            obs, _, _, _ = env.step(acts[t % 8])
+            env.step(acts[t % 8])
         t0 = time.perf_counter()
-        for t in range(K):
-            obs, _, _, _ = env.step(acts[t % 8])
+        for t in range(steps):
+            env.step(acts[t % 8])
         dt = time.perf_counter() - t0
-        arms[name] = {"value": n * K / dt, "unit": "env-steps/s", "ms_per_step": 1000 * dt / K, "host_GB_per_s": obs.nbytes * K / dt / 1e9}
-        frame_bytes = obs.nbytes // n
         env.close()
-    for name, reuse in (("agent_obs_84x84x4_pageable", False), ("agent_obs_84x84x4_pinned", True)):
-        env = ToyboxPreprocVecEnv(args.game, n, seed=SEED_BASE, reuse_obs_buffer=reuse)
-        na = env.action_space.n
-        obs = env.reset()
-        acts = [rng.integers(0, na, n) for _ in range(8)]
-        for t in range(Wm):
-            obs, _, _, _ = env.step(acts[t % 8])
-        t0 = time.perf_counter()
-        for t in range(K):
-            obs, _, _, _ = env.step(acts[t % 8])
-        dt = time.perf_counter() - t0
-        arms[name] = {"value": n * K / dt, "unit": "agent-steps/s", "ms_per_step": 1000 * dt / K, "host_GB_per_s": obs.nbytes * K / dt / 1e9}
-        env.close()
-    best = arms["pinned_reused_array"]
+        return {"value": n * steps / dt, "unit": unit, "ms_per_step": 1000 * dt / steps, "pcie_GB_per_s": bytes_per_step * steps / dt / 1e9}
+
+    frame_bytes = None
+    for name, pool in (("frames_pinned_pool", 2), ("frames_pageable_fresh_array", 0)):
+        env = ToyboxVecEnv(args.game, n, grayscale=False, seed=SEED_BASE, obs_pool=pool)
+        frame_bytes = int(np.prod(env.observation_space.shape))
+        arms[name] = run(env, "env-steps/s", n * frame_bytes, K if pool else max(3, K // 4))
+    px = 84 * 84
+    for name, layout, pool, per_env, steps in (("agent_planes_pinned_ring", "planes", 2, px, 4 * K),
+                                               ("agent_device_stack_pinned_pool", "device_stack", 2, 4 * px, 2 * K),
+                                               ("agent_device_stack_pageable_fresh_array", "device_stack", 0, 4 * px, K),
+                                               ("agent_host_stack_numpy_roll", "host_stack", 2, px, max(3, K // 4))):
+        env = ToyboxPreprocVecEnv(args.game, n, seed=SEED_BASE, obs_layout=layout, obs_pool=pool)
+        arms[name] = run(env, "agent-steps/s", n * per_env, steps)
+    best = arms["frames_pinned_pool"]
     out = {"metric": "env steps/sec INCLUDING the PCIe transfer of every frame to the host, %s" % args.game, "value": best["value"],
            "unit": "env-steps/s", "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": best["ms_per_step"], "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic", "arms": arms,
-           "config": {"workload": "%s ToyboxVecEnv.step(host actions) -> RGB frames in host memory, %d envs, %d B per frame"
-                                  % (args.game, n, frame_bytes)}}
+           "config": {"workload": "%s ToyboxVecEnv.step(host actions) -> RGB frames in host memory, %d envs, %d B per frame; "
+                                  "ToyboxPreprocVecEnv.step -> 84x84x4 observations" % (args.game, n, frame_bytes)}}
     print(json.dumps(out), flush=True)
     return 0
 
@@ -574,75 +598,131 @@ class Loop:
       pair   tbx_step_synthetic ; [tbx_gather] ; tbx_render_device   -- two launches in stream order (what a policy loop does)
       fused  tbx_render_step_synthetic ; [tbx_gather]                -- the frame of the current state and the step to the
              next one in ONE launch where the rasteriser reads step-written records (Breakout RGB); random rollouts only
-    HIP events bracket every EVERY-th rasteriser (fused: rasteriser + step) launch."""
+    Timing of the dominant kernel (roofline.avg_launch_ms) with HIP events on the caller's stream, never next to a device
+    synchronisation (the first SKIP launches of a region run against an idle memory system and are left out):
+      fused  RUNS of RUN back-to-back launches between two events -- the events of a region form a chain, each one the end of a
+             run and the start of the next -- divided by RUN: what one launch costs in the steady state of the loop;
+      pair   the rasteriser launches are separated by step kernels, so every RUN-th rasteriser launch is bracketed on its own."""
 
-    EVERY = 8       # one launch in EVERY carries the two HIP events (a pair costs the stream 5-10 us: around every launch
-                    # that was 1 % of the 65 536-env step and 5 % of the 8 192-env one)
+    RUN = 8         # launches per event pair (an event costs the stream a few microseconds: around every launch that was 1 % of
+                    # the 65 536-env step and 5 % of the 8 192-env one)
+    SKIP = 2        # launches after a region's opening synchronisation that no event pair covers
 
-    def __init__(self, eng, hip, stream, start, channels, gather, render, n_steps, fused=False):
+    def __init__(self, eng, hip, stream, start, channels, gather, render, K, R, fused=False):
         self.eng, self.sp, self.start, self.C, self.gather, self.render = eng, stream.ptr, start, channels, gather, render
         self.fused = bool(fused and render)
-        self.pool = [(hip.Event(), hip.Event()) for _ in range((n_steps + self.EVERY - 1) // self.EVERY)] if render else []
-        self.used = len(self.pool)              # nothing is timed until arm() is called
-        self.calls = 0
+        self.K = int(K)
+        self.run = max(1, min(self.RUN, self.K - self.SKIP)) if self.K > 1 else 1
+        self.skip = max(0, min(self.SKIP, self.K - self.run))
+        per_region = 0
+        if render and K > 0:
+            per_region = ((self.K - self.skip) // self.run + 1) if self.fused else 2 * ((self.K - self.skip + self.run - 1) // self.run)
+        self.pool = [hip.Event() for _ in range(per_region * max(0, R))]
+        self.next_ev = 0
+        self.armed = False          # nothing is timed until arm() is called
+        self.spans = []             # (start event, end event, launches covered)
+        self.chain = None
+        self.c = 0
 
     def arm(self):
-        self.used = 0
-        self.calls = 0
+        self.armed = True
+        self.next_ev = 0
+        self.spans = []
+
+    def begin_region(self):
+        self.c = 0
+        self.chain = None
+
+    def _mark(self):
+        if self.next_ev >= len(self.pool):
+            return None
+        ev = self.pool[self.next_ev]
+        self.next_ev += 1
+        ev.record(self.sp)
+        return ev
 
     def full_step(self, t):
         e, sp = self.eng, self.sp
+        c = self.c
+        self.c += 1
+        timing = self.armed and self.render and c >= self.skip
         if not self.fused:
             e.step_synthetic(ACTION_SEED, t, env_offset=self.start, auto_reset=True, stream=sp)
             if self.gather:
                 e.gather(stream=sp)            # on the engine's communication stream: overlaps with the rasteriser below
-        if self.render:
-            i = self.used
-            timed = i < len(self.pool) and self.calls % self.EVERY == 0
-            self.calls += 1
-            if timed:
-                self.pool[i][0].record(sp)
-            if self.fused:
-                e.render_step_synthetic(ACTION_SEED, t, channels=self.C, env_offset=self.start, auto_reset=True, stream=sp)
-            else:
+            if self.render:
+                a = self._mark() if timing and (c - self.skip) % self.run == 0 else None
                 e.render_device(0, self.C, stream=sp)
-            if timed:
-                self.pool[i][1].record(sp)
-                self.used = i + 1
-        if self.fused and self.gather:
+                if a is not None:
+                    b = self._mark()
+                    if b is not None:
+                        self.spans.append((a, b, 1))
+            return
+        if timing and c == self.skip:
+            self.chain = self._mark()
+        e.render_step_synthetic(ACTION_SEED, t, channels=self.C, env_offset=self.start, auto_reset=True, stream=sp)
+        if self.gather:
             e.gather(stream=sp)                # the records of the step that rode in the launch above
+        if timing and self.chain is not None and (c + 1 - self.skip) % self.run == 0:
+            b = self._mark()
+            if b is not None:
+                self.spans.append((self.chain, b, self.run))
+            self.chain = b
 
     def step_only(self, t):
         self.eng.step_synthetic(ACTION_SEED, t, env_offset=self.start, auto_reset=True, stream=self.sp)
         if self.gather:
             self.eng.gather(stream=self.sp)
 
-    def render_ms(self):
-        return float(np.mean([a.elapsed_ms(b) for a, b in self.pool[:self.used]])) if self.render and self.used else None
+    def launch_ms(self):
+        """per-launch times of the timed spans (call after a device synchronisation): list of ms, launches covered"""
+        per = [a.elapsed_ms(b) / k for a, b, k in self.spans]
+        return per, sum(k for _, _, k in self.spans)
 
     def close(self):
-        for a, b in self.pool:
-            a.close(); b.close()
+        for ev in self.pool:
+            ev.close()
         self.pool = []
 
 
+SETTLE = 40     # untimed full steps of the loop form about to be timed, in front of its W warm-up steps (--settle)
+
+
 def timed_arm(eng, hip, reg, stream, start, C, gather, render, pipeline, t, K, Wm, R, fused=False):
-    """Warm-up + R regions of K steps with TBX_OPT_PIPELINE = pipeline (pair form) or the fused call.  Returns (summary, avg
-    rasteriser launch ms, resolved pipeline mode, next t)."""
+    """SETTLE untimed steps + W warm-up steps + R regions of K steps with TBX_OPT_PIPELINE = pipeline (pair form) or the fused
+    call.  Returns (summary, launch timing dict or None, resolved pipeline mode, next t).
+    Why the settle steps: the pre-roll is 1 000 ten-microsecond step kernels, and the first dozen rasteriser launches behind it
+    run 2-19 % long (kernel trace of `--steps 20 --warmup 5`: 1 224, 1 296, 1 425, 1 430, 1 411, 1 348 ... 1 204 us, clocks and
+    memory system coming up from a nearly idle chip); with a 5-step warm-up they landed in the first timed region.  They belong
+    to the untimed pre-roll, like the 1 000 frames before them; the W warm-up steps and the K timed steps are the caller's."""
     from toybox_amd import _abi
     eng.set_option(_abi.OPT_PIPELINE, 0 if fused else pipeline)
     mode = eng.get_option(_abi.OPT_PIPELINE_ACTIVE)
-    loop = Loop(eng, hip, stream, start, C, gather, render, K * R, fused=fused)
-    for _ in range(Wm):
+    loop = Loop(eng, hip, stream, start, C, gather, render, K, R, fused=fused)
+    for _ in range(SETTLE + Wm):
         loop.full_step(t)
         t += 1
     hip.synchronize()
     loop.arm()
-    times, t = reg.run(loop.full_step, t, K, R)
-    rms = loop.render_ms()
-    timed_arm.launches_timed = loop.used
+    times, t = reg.run(loop.full_step, t, K, R, on_region=loop.begin_region)
+    per, covered = loop.launch_ms()
+    launch = None
+    if per:
+        launch = {"avg_ms": float(np.mean(per)), "median_ms": float(np.median(per)), "min_ms": float(min(per)), "max_ms": float(max(per)),
+                  "spans": len(per), "launches": covered, "launches_per_span": loop.run if loop.fused else 1,
+                  "skipped_after_sync": loop.skip}
     loop.close()
-    return summarize(times, K), rms, mode, t
+    return summarize(times, K), launch, mode, t
+
+
+def launch_timing_note(fused, mode):
+    if fused:
+        return ("HIP events on the caller's stream around RUNS of %d back-to-back launches (chained: one event ends a run and starts the "
+                "next), time / %d; the first %d launches after a region's opening synchronisation are not covered" % (Loop.RUN, Loop.RUN, Loop.SKIP))
+    return ("HIP events on the caller's stream around every %dth rasteriser launch of the timed regions (step kernels sit between "
+            "rasteriser launches in this loop form), never one of the first %d after a synchronisation" % (Loop.RUN, Loop.SKIP) +
+            ("" if mode != 3 else "; launches overlap in this mode, so this is the time from one launch's end to the next one's end "
+                                  "(what a launch costs in steady state), not a kernel's own duration"))
 
 
 PIPELINE_NOTE = {0: "off: every call in stream order", 2: "the step runs beside the previous frame's rasteriser (internal step stream, "
@@ -695,10 +775,11 @@ def verify_gather(eng, hip, rank, world, n_local, shard_sizes, start):
     return True
 
 
-def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_extras):
+def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_extras, extras=("serialised", "step_only")):
     """One reading of the metric on this rank: engine for its shard, communicator (N > 1 or --with-gather) with one verified
     exchange, pre-roll, the timed arm (fused where the engine fuses, unless --loop pair), and with_extras the serialised
-    two-launch loop and the step-only loop beside it.  Returns a dict (rank 0 assembles the line) or an int return code."""
+    two-launch loop and the step-only loop beside it (`extras` names which).  Returns a dict (rank 0 assembles the line) or an
+    int return code."""
     from toybox_amd import Engine, _abi
     from toybox_amd.parallel import FileWorld, shard_range
     if scaling == "strong":
@@ -748,23 +829,24 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
         eng.step_synthetic(ACTION_SEED, t, env_offset=start, auto_reset=True, stream=stream.ptr)
         t += 1
     fused = render and args.loop != "pair" and C >= 3 and eng.get_option(_abi.OPT_RENDER_STEP_FUSED) == 1
-    rep, render_ms, mode, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, args.pipeline, t, K, Wm, R, fused=fused)
+    rep, launch, mode, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, args.pipeline, t, K, Wm, R, fused=fused)
     res = {"n": n, "n_total": n_total, "start": start, "H": H, "W": W, "C": C, "render": render, "gather": gather, "rccl": rccl,
-           "gather_note": gather_note, "rep": rep, "render_ms": render_ms, "mode": mode, "fused": fused,
-           "launches_timed": timed_arm.launches_timed, "extras": {}}
+           "gather_note": gather_note, "rep": rep, "launch": launch, "mode": mode, "fused": fused, "steps": K, "extras": {}}
     frame_bytes = H * W * C if render else 0
-    if with_extras and (fused or mode != 0):
+    if with_extras and "serialised" in extras and (fused or mode != 0):
         # the same engine, two launches per frame in stream order: what a policy-driven loop (actions computed from the frame) gets
-        srep, s_ms, _, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, 0, t, K, Wm, R, fused=False)
+        srep, sl, _, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, 0, t, K, Wm, R, fused=False)
         sms = srep["ms_per_step_median"]
+        s_ms = sl["avg_ms"] if sl else None
         res["extras"]["serialised"] = {"value": n_total / (sms * 1e-3), "unit": "env-steps/s", "ms_per_step": sms, "repeats": srep,
                                        "avg_launch_ms": s_ms,
                                        "roofline_frac": (n * frame_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s_ms else None,
+                                       "whole_step_frac": n * frame_bytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "note": "tbx_step_synthetic ; tbx_render_device in stream order (TBX_OPT_PIPELINE = 0): the rate of a loop whose "
                                                "actions depend on the frame"}
         eng.set_option(_abi.OPT_PIPELINE, args.pipeline)
-    if render and with_extras:
-        loop = Loop(eng, hip, stream, start, C, gather, False, 0)
+    if render and with_extras and "step_only" in extras:
+        loop = Loop(eng, hip, stream, start, C, gather, False, 0, 0)
         so_times, t = reg.run(loop.step_only, t, K, R)
         so = summarize(so_times, K)
         res["extras"]["step_only"] = {"value": n_total / (so["ms_per_step_median"] * 1e-3), "unit": "env-steps/s",
@@ -782,7 +864,9 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
 
 
 def main():
+    global SETTLE
     args = parse()
+    SETTLE = max(0, args.settle)
     if args.protocol == "reference":
         return bench_reference_protocol(args)
     if args.protocol == "agent":
@@ -850,12 +934,12 @@ def main():
             "config": {
                 "workload": "%s %s, %d envs %s, uniform random legal actions generated on device "
                             "(splitmix64 counter rule, seed 1337), env seeds 1234+global index, auto-reset on done, "
-                            "%d-frame step-only pre-roll before the warm-up"
+                            "untimed pre-roll of %d step-only frames + %d full steps before the warm-up"
                             % (game, "step + %dx%dx%d uint8 frame render" % (H, W, C) if render else "step-only",
-                               args.envs, "per GPU" if args.scaling == "weak" else "in total", args.preroll),
+                               args.envs, "per GPU" if args.scaling == "weak" else "in total", args.preroll, SETTLE),
                 "envs_per_gpu": n, "envs_total": n_total, "frame_hwc": [H, W, C] if render else None,
-                "parallelism": ("env-sharded x%d, RCCL all-gather of 8 B/env records behind the C-ABI (tbx_gather), %s, overlapped with the "
-                                "rasteriser" % (world, "one collective per step" if K_ring == 1 else "K-step record ring: one collective per %d steps" % K_ring))
+                "parallelism": ("env-sharded x%d, RCCL all-gather of 8 B/env records behind the C-ABI (tbx_gather), %s"
+                                % (world, gather_overlap_note(K_ring, fused)))
                                if gather else ("env-sharded x%d, no collective (%s)" % (world, r["gather_note"])) if r["gather_note"] else "single GPU",
                 "algorithmic_bytes_per_env_step": bytes_per_step,
             },
@@ -865,29 +949,10 @@ def main():
             "rccl": r["rccl"],
         }
         if render:
-            render_ms = r["render_ms"]
-            achieved = n * frame_bytes / (render_ms * 1e-3) / 1e9    # GB/s, algorithmic frame bytes of one launch
-            traffic, source = None, None
-            tp = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tp):
-                try:
-                    rec = json.load(open(tp)).get("%s_render_%dch_%d%s" % (game, C, n, "_fused" if fused else ""))
-                    if rec:
-                        traffic = rec["hbm_bytes_per_launch"]
-                        source = "profiles/traffic.json (static: rocprofv3 PMC pass %s, not measured in this run)" % rec.get("source", "")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {
-                "bound": "hbm", "kernel": "%s render (%d ch)%s" % (game, C, " + step, one launch" if fused else ""),
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": source,
-                "algorithmic_bytes_per_launch": n * frame_bytes, "avg_launch_ms": render_ms, "launches_timed": r["launches_timed"],
-                "timing": "HIP events on the caller's stream around every %dth rasteriser launch of the timed regions" % Loop.EVERY +
-                          ("" if mode != 3 else "; launches overlap in this mode, so this is the time from one launch's end to the "
-                                               "next one's end (what a launch costs in steady state), not a kernel's own duration"),
-            }
+            out["roofline"] = roofline_object(game, n, frame_bytes, C, fused, mode, r["launch"])
         else:
             out["roofline"] = None
+        out["metric_version"] = METRIC_VERSION
         out.update(r["extras"])
         out["check"] = r["check"]
         if other is not None:
@@ -900,22 +965,117 @@ def main():
             s_, w_ = (out, out[key]) if args.scaling == "strong" else (out[key], out)
             # strong total over weak total = what N GPUs make of ONE batch against N x a full batch each: the share of linear scaling
             out["share_of_linear"] = s_["value"] / w_["value"]
-        if world == 1 and not args.no_extras and n >= 16384 and ENGINE_FACTORY is None:
-            try:
-                out["scaling_strong"] = strong_share_probe(args, game, C, n, out["value"])
-            except Exception as ex:
-                out["scaling_strong"] = {"error": repr(ex)}
-        if world == 1 and not args.no_cpu_baseline and ENGINE_FACTORY is None:
-            try:
-                out["cpu_baseline"] = cpu_baseline([(game, n_total, 0)], C, args.cpu_seconds)
-                out["cpu_config1"] = cpu_config1(game, C)
-            except Exception as ex:  # the baseline must never take the GPU number down with it
-                out["cpu_baseline"] = {"error": repr(ex)}
+    # ---- the arms that only one GPU's worth of a run carries (every rank walks the same code; ranks > 0 have nothing to do)
+    single = world == 1 and ENGINE_FACTORY is None
+    if rank == 0 and single and not args.no_extras and main_res["n"] >= 16384:
+        try:
+            out["scaling_strong"] = strong_share_probe(args, game, main_res["C"], main_res["n"], out["value"],
+                                                       (out.get("serialised") or {}).get("value") or out["value"])
+        except Exception as ex:
+            out["scaling_strong"] = {"error": repr(ex)}
+    if rank == 0 and single and not args.no_extras and not args.no_configs and game == "breakout" and main_res["render"]:
+        # BASELINE.json configs 2-5 beside the headline (config 1 is cpu_config1 below): every arm from one invocation, as the
+        # reference's harness prints all of its arms from one run (test/benchmark.py:119-166)
+        try:
+            out["configs"] = baseline_configs(args, hip)
+        except Exception as ex:
+            out["configs"] = {"error": repr(ex)}
+    if rank == 0 and not args.no_cpu_baseline:
+        # the CPU path "in the same run" (north star), also for N > 1: rank 0's host cores, a bounded sample of the same batch,
+        # after every GPU region (the other ranks have nothing left to do and leave)
+        try:
+            out["cpu_baseline"] = cpu_baseline([(game, main_res["n_total"], 0)], main_res["C"], args.cpu_seconds)
+            out["cpu_config1"] = cpu_config1(game, main_res["C"])
+        except Exception as ex:  # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"error": repr(ex)}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     return 0
 
 
-def strong_share_probe(args, game, C, n_single, single_value):
+# `value` changed meaning between rounds 3 and 4: the same `bench.py --gpus N` line is comparable across rounds only
+# under the same version.  1 = rounds 1-3: --envs PER GPU (weak), two launches per step, one collective per step.
+# 2 = round 4 on: --envs IN TOTAL (strong; identical at N = 1), the fused launch where the engine fuses, K = 4 record ring.
+# The version-1 reading of the same engine is still in every line: `serialised` (two launches) and, for N > 1, `weak`.
+METRIC_VERSION = {"version": 2, "value_is": "strong reading (envs in total), loop form the engine offers a random rollout, one collective per "
+                                            "--gather-every steps",
+                  "version_1_arms_in_this_line": {"two launches per step": "serialised", "envs per GPU (N > 1)": "weak",
+                                                  "a collective every step (N = 1 probe)": "scaling_strong.pair_gather_every_step"}}
+
+
+def gather_overlap_note(K_ring, fused):
+    if K_ring > 1:
+        return ("K-step record ring: one collective per %d steps on the engine's communication stream, overlapping the launches of "
+                "the following steps (the step that re-opens a ring, 2 K steps later, waits for it)" % K_ring)
+    if fused:
+        return ("one collective per step, queued behind each fused launch and waited for by the next one: NOT overlapped in this loop "
+                "form (the ring, --gather-every > 1, or --loop pair overlaps it)")
+    return "one collective per step on the engine's communication stream, overlapped with the rasteriser launch that follows the step"
+
+
+def roofline_object(game, n, frame_bytes, C, fused, mode, launch):
+    """The dominant kernel (rasteriser; fused: rasteriser + step launch) against HBM bandwidth: algorithmic frame bytes of one
+    launch over the event-timed launch time of the loop's steady state."""
+    if not launch:
+        return None
+    ms = launch["avg_ms"]
+    achieved = n * frame_bytes / (ms * 1e-3) / 1e9            # GB/s
+    traffic, source = None, None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        try:
+            rec = json.load(open(tp)).get("%s_render_%dch_%d%s" % (game, C, n, "_fused" if fused else ""))
+            if rec:
+                traffic = rec["hbm_bytes_per_launch"]
+                source = "profiles/traffic.json (static: rocprofv3 PMC pass %s, not measured in this run)" % rec.get("source", "")
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": "%s render (%d ch)%s" % (game, C, " + step, one launch" if fused else ""),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": source,
+            "algorithmic_bytes_per_launch": n * frame_bytes, "avg_launch_ms": ms, "median_launch_ms": launch["median_ms"],
+            "min_launch_ms": launch["min_ms"], "max_launch_ms": launch["max_ms"], "launches_timed": launch["launches"],
+            "event_spans": launch["spans"], "timing": launch_timing_note(fused, mode)}
+
+
+def baseline_configs(args, hip):
+    """BASELINE.json configs 2, 3, 4 (4 096 envs of Breakout / SpaceInvaders / Amidar on one GPU) and the per-GPU share of
+    config 5 (mixed 32 768 envs = 10 923 + 10 923 + 10 922 with the 1-rank record gather), each with the protocol of the
+    headline (pre-roll, warm-up, 5 regions, median) but regions of >= 200 (mixed: >= 50) steps: a 20-step region of a 0.1 ms step
+    is mostly its two synchronisations.  `whole_step_frac` = frame bytes of the batch / ms_per_step / 8 TB/s."""
+    cfgs = {}
+    for key, g in (("2_breakout_4096", "breakout"), ("3_space_invaders_4096", "space_invaders"), ("4_amidar_4096", "amidar")):
+        a = argparse.Namespace(**vars(args))
+        a.envs, a.steps, a.warmup, a.repeats, a.with_gather, a.no_render, a.scaling = 4096, max(args.steps, 200), 20, 5, False, False, "strong"
+        r = run_reading(a, hip, g, 0, 1, 0, "strong", "cfg_" + g, True, extras=("serialised",))
+        if isinstance(r, int):
+            cfgs[key] = {"error": "rc %d" % r}
+            continue
+        ms = r["rep"]["ms_per_step_median"]
+        fb = r["H"] * r["W"] * r["C"]
+        e = {"value": r["n"] / (ms * 1e-3), "unit": "env-steps/s", "ms_per_step": ms, "steps": a.steps, "repeats": r["rep"]["n"],
+             "ms_per_step_min_max": [r["rep"]["ms_per_step_min"], r["rep"]["ms_per_step_max"]],
+             "loop": "fused" if r["fused"] else "pair", "pipeline_resolved": r["mode"],
+             "whole_step_frac": r["n"] * fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "kernel_frac": (r["n"] * fb / (r["launch"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if r["launch"] else None,
+             "avg_launch_ms": r["launch"]["avg_ms"] if r["launch"] else None, "frame_hwc": [r["H"], r["W"], r["C"]]}
+        sr = r["extras"].get("serialised")
+        e["serialised"] = ({"value": sr["value"], "ms_per_step": sr["ms_per_step"], "whole_step_frac": sr["whole_step_frac"],
+                            "kernel_frac": sr["roofline_frac"]} if sr else "= value (the main arm is the two-launch loop in stream order)")
+        cfgs[key] = e
+    a = argparse.Namespace(**vars(args))
+    a.no_render = False
+    m = mixed_reading(a, 1, 0, 0, 32768, max(args.steps, 50), 10, 5, True)
+    cfgs["5_mixed_32768_per_gpu"] = {"value": m["value"], "unit": "env-steps/s per GPU", "ms_per_step": m["ms_per_step"], "steps": m["steps"],
+                                     "ms_per_step_min_max": [m["repeats"]["ms_per_step_min"], m["repeats"]["ms_per_step_max"]],
+                                     "segment_sizes": m["config"]["segment_sizes"], "loop": m["loop"], "rccl": m["rccl"],
+                                     "whole_step_frac": m["roofline"]["frac"],
+                                     "note": "the per-GPU share of BASELINE config 5 (262 144 envs over 8 GPUs) on ONE GPU with the record gather "
+                                             "queued over a 1-rank communicator: launch cost of the collective, no wire time"}
+    return cfgs
+
+
+def strong_share_probe(args, game, C, n_single, single_value, single_pair_value):
     """What ONE GPU of an 8-GPU run of the SAME batch would do: n/8 envs with the record gather on (1-rank communicator: launch
     and stream-hop cost of the collective, no wire time).  share_of_linear = that rate over the single-GPU rate of the whole
     batch (a fraction: 1.0 = eight GPUs are eight times one).  Measured for the loop form and ring depth of the main arm and,
@@ -925,7 +1085,7 @@ def strong_share_probe(args, game, C, n_single, single_value):
     res = {"envs_per_gpu": n, "gpus": 8, "unit": "env-steps/s per GPU",
            "note": "1/8 of the batch on one GPU with the record gather queued (1-rank RCCL communicator)"}
     K = max(args.steps, 200)
-    arms = (("main", args.gather_every, args.loop != "pair"), ("pair_gather_every_step", 1, False))
+    arms = (("main", args.gather_every, args.loop != "pair"), ("policy_loop", args.gather_every, False), ("pair_gather_every_step", 1, False))
     for key, every, want_fused in arms:
         eng = Engine(game, n, device=0)
         eng.seed(SEED_BASE)
@@ -938,13 +1098,17 @@ def strong_share_probe(args, game, C, n_single, single_value):
             eng.step_synthetic(ACTION_SEED, t, auto_reset=True, stream=st.ptr)
         reg = Region(hip.synchronize, lambda: eng.gather_reduce_max(0.0), lambda v: eng.gather_reduce_max(v))
         fused = want_fused and C >= 3 and eng.get_option(_abi.OPT_RENDER_STEP_FUSED) == 1
-        rep, rms, mode, _ = timed_arm(eng, hip, reg, st, 0, C, True, True, args.pipeline, args.preroll, K, 20, 5, fused=fused)
+        rep, launch, mode, _ = timed_arm(eng, hip, reg, st, 0, C, True, True, args.pipeline, args.preroll, K, 20, 5, fused=fused)
         v = n / (rep["ms_per_step_median"] * 1e-3)
         res[key] = {"value": v, "ms_per_step": rep["ms_per_step_median"], "repeats": rep, "loop": "fused" if fused else "pair",
-                    "gather_every": eng.gather_every(), "pipeline_resolved": mode, "avg_launch_ms": rms, "share_of_linear": v / single_value}
+                    "gather_every": eng.gather_every(), "pipeline_resolved": mode, "avg_launch_ms": launch["avg_ms"] if launch else None,
+                    "share_of_linear": v / (single_value if key == "main" else single_pair_value),
+                    "share_of": "value" if key == "main" else "serialised (the two-launch loop on the whole batch)"}
         eng.close()
+        st.close()
     res["value"] = res["main"]["value"]
     res["share_of_linear"] = res["main"]["share_of_linear"]
+    res["share_of_linear_policy_loop"] = res["policy_loop"]["share_of_linear"]
     return res
 
 

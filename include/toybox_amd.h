@@ -555,7 +555,9 @@ typedef struct tbx_agent_config {
     int32_t stack_fill;    /* what a reset leaves in the OLDER stack slots: 0 = zeros (VecFrameStack, vec_frame_stack.py:22-33),
                             * 1 = the reset observation itself (the per-env FrameStack of wrap_deepmind(frame_stack=True),
                             * atari_wrappers.py:246-275: reset() appends the observation k times) */
-    int32_t _reserved;
+    int32_t new_plane;     /* 1: the observation kernels also write the NEWEST plane alone, dense, into TBX_BUF_AGENT_PLANE
+                            * (uint8[N][out_h][out_w]) -- what a host-side VecFrameStack receives per step (one new frame per
+                            * env, vec_frame_stack.py:19-27), a quarter of the bytes of the whole stacks */
 } tbx_agent_config_t;
 
 int tbx_agent_init(tbx_engine* engine, const tbx_agent_config_t* cfg);
@@ -583,6 +585,49 @@ int tbx_agent_step_synthetic(tbx_engine* engine, uint64_t action_seed, uint64_t 
 #define TBX_BUF_AGENT_EP_LENGTH 11   /* int32[N]   its length 'l' in agent steps (valid where EP_DONE) */
 /* host copy of the three episode-monitor arrays of the last agent step (any pointer may be NULL) */
 int tbx_agent_episodes(tbx_engine* engine, uint8_t* ep_done_host, float* ep_return_host, int32_t* ep_length_host);
+#define TBX_BUF_AGENT_PLANE    13   /* uint8[N][out_h][out_w] the newest plane of every stack (tbx_agent_config_t::new_plane) */
+
+/* ------------------------------------------------------------------ host delivery: step_async / step_wait
+ * The reference's consumers sit on the HOST side of the boundary: VecEnv.step_async(actions) sends the actions to the workers,
+ * step_wait() receives (obs, rews, dones, infos) (baselines/baselines/common/vec_env/__init__.py:26-131,
+ * subproc_vec_env.py:63-74), and what a worker sends per step is ONE new frame per env -- VecFrameStack rolls its stack on the
+ * receiving side (vec_frame_stack.py:17-30).  The "_begin" calls queue the whole step on the engine's stream -- actions host ->
+ * device, the step (the agent step with all its wrappers), and the copies of every requested output into the caller's host
+ * buffers -- and return at once; the "_end" call blocks until they have arrived and reports what the synchronous form reports
+ * (TBX_E_ACTION, TBX_E_NEEDS_RESET).  Between the two the caller's thread is free (the learner's update of the previous
+ * rollout step overlaps with the device step and the PCIe copy).  Every pointer of the out-struct may be NULL; the buffers must stay valid
+ * until the "_end" call returns and should be page-locked (tbx_host_alloc): a copy into pageable memory is staged by the runtime and blocks the
+ * "_begin" call.  The actions are copied out of the caller's array before "_begin" returns.  Any other call on the handle
+ * between "_begin" and "_end" ends the step first (program order holds as everywhere). */
+int tbx_host_alloc(void** out_ptr, size_t bytes);   /* page-locked host memory (hipHostMalloc), any device */
+int tbx_host_free(void* ptr);
+typedef struct tbx_agent_host_out {
+    float*   reward;      /* float32[N] */
+    uint8_t* done;        /* uint8[N] */
+    uint8_t* obs;         /* uint8[N][out_h][out_w][stack]: the whole stacks (TBX_BUF_AGENT_OBS) */
+    uint8_t* plane;       /* uint8[N][out_h][out_w]: the newest plane only (TBX_BUF_AGENT_PLANE; needs new_plane = 1) */
+    uint8_t* ep_done;     /* uint8[N], float32[N], int32[N]: the episode monitor (tbx_agent_episodes) */
+    float*   ep_return;
+    int32_t* ep_length;
+} tbx_agent_host_out_t;
+int tbx_agent_step_begin(tbx_engine* engine, const int32_t* ale_actions_host, const tbx_agent_host_out_t* out);
+int tbx_agent_step_end(tbx_engine* engine);
+/* the current contents of the same buffers (after tbx_agent_reset or a step), synchronous: what venv.reset() hands out when
+ * the host keeps the stacks (tbx_agent_reset(NULL), then the plane) */
+int tbx_agent_fetch(tbx_engine* engine, const tbx_agent_host_out_t* out);
+/* The plain env step in the same shape: ToyboxBaseEnv.step for every env (envs/atari/base.py:115-149 under
+ * dummy_vec_env.py:45-54) = tbx_step + the frames of the states it leaves (channels 1, 3 or 4; frame may be NULL). */
+typedef struct tbx_step_host_out {
+    int32_t* reward;      /* int32[N] */
+    uint8_t* done;        /* uint8[N] */
+    int32_t* lives;       /* int32[N] */
+    int32_t* score;       /* int32[N] */
+    uint8_t* frame;       /* uint8[N][H][W][channels] */
+    int32_t  channels;
+    int32_t  _pad;
+} tbx_step_host_out_t;
+int tbx_step_begin(tbx_engine* engine, const int32_t* ale_actions_host, uint32_t flags, const tbx_step_host_out_t* out);
+int tbx_step_end(tbx_engine* engine);
 
 /* ------------------------------------------------------------------ multi-GPU record gather
  * One process per GPU, one engine per process = one contiguous shard of the env batch; envs never interact, so the only

@@ -33,7 +33,10 @@ struct tbx_engine {
     int agent_on;
     tbx_agent_config_t acfg;
     uint8_t *gray_a, *gray_b, *aobs, *afin, *adone;
+    uint8_t* aplane;      /* [n][out_h][out_w] the newest plane of every stack (acfg.new_plane), else NULL */
     float* areward;
+    /* host delivery: the oracle's "_begin" calls do everything at once; "_end" hands out the error the step left */
+    int host_pending, agent_host_pending, host_rc;
     /* record gather: the oracle restates the one-rank case only (there is no second process to talk to) */
     int gather_on, gather_width, gather_ranks, gather_rank;
     uint64_t* gathered;
@@ -570,9 +573,13 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     case TBX_BUF_FRAME: p = e->frame; b = e->frame_bytes; break;
     case TBX_BUF_PACKED: p = e->packed; b = n * 8; break;
     case TBX_BUF_AGENT_OBS: case TBX_BUF_AGENT_REWARD: case TBX_BUF_AGENT_DONE:
-    case TBX_BUF_AGENT_EP_DONE: case TBX_BUF_AGENT_EP_RETURN: case TBX_BUF_AGENT_EP_LENGTH:
+    case TBX_BUF_AGENT_EP_DONE: case TBX_BUF_AGENT_EP_RETURN: case TBX_BUF_AGENT_EP_LENGTH: case TBX_BUF_AGENT_PLANE:
         if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
-        if (which == TBX_BUF_AGENT_OBS) { p = e->aobs; b = n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack; }
+        if (which == TBX_BUF_AGENT_PLANE) {
+            if (!e->aplane) return fail(e, TBX_E_INVALID, "TBX_BUF_AGENT_PLANE needs tbx_agent_config_t::new_plane = 1");
+            p = e->aplane; b = n * e->acfg.out_h * e->acfg.out_w;
+        }
+        else if (which == TBX_BUF_AGENT_OBS) { p = e->aobs; b = n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack; }
         else if (which == TBX_BUF_AGENT_REWARD) { p = e->areward; b = n * 4; }
         else if (which == TBX_BUF_AGENT_DONE) { p = e->adone; b = n; }
         else if (which == TBX_BUF_AGENT_EP_DONE) { p = e->ep_done; b = n; }
@@ -1046,7 +1053,8 @@ int tbx_sync(tbx_engine* e)
 
 static void agent_free(tbx_engine* e)
 {
-    free(e->gray_a); free(e->gray_b); free(e->aobs); free(e->afin); free(e->adone); free(e->areward);
+    free(e->gray_a); free(e->gray_b); free(e->aobs); free(e->afin); free(e->adone); free(e->areward); free(e->aplane);
+    e->aplane = NULL;
     free(e->ep_ret); free(e->ep_len); free(e->ep_index); free(e->prev_lives); free(e->ep_len_out); free(e->ep_done);
     free(e->ep_ret_out); free(e->was_real_done); free(e->needs_reset); free(e->noop_override);
     e->was_real_done = e->needs_reset = NULL; e->noop_override = NULL;
@@ -1063,8 +1071,8 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     orc_frame_dims(e->game, &H, &W);
     if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
         cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > 84 * 84 || cfg->noop_max < 0 ||
-        cfg->noop_max > 1000 || cfg->stack_fill < 0 || cfg->stack_fill > 1)
-        return fail(e, TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000, stack_fill 0..1)");
+        cfg->noop_max > 1000 || cfg->stack_fill < 0 || cfg->stack_fill > 1 || cfg->new_plane < 0 || cfg->new_plane > 1)
+        return fail(e, TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000, stack_fill 0..1, new_plane 0..1)");
     if ((H + cfg->out_h - 1) / cfg->out_h + 1 > 8 || (W + cfg->out_w - 1) / cfg->out_w + 1 > 8)
         return fail(e, TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
     agent_free(e);
@@ -1073,6 +1081,7 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     e->gray_a = (uint8_t*)calloc(n, (size_t)H * W);
     e->gray_b = (uint8_t*)calloc(n, (size_t)H * W);
     e->aobs = (uint8_t*)calloc(n, (size_t)cfg->out_h * cfg->out_w * cfg->stack);
+    e->aplane = cfg->new_plane ? (uint8_t*)calloc(n, (size_t)cfg->out_h * cfg->out_w) : NULL;
     e->afin = (uint8_t*)calloc(n, 1);
     e->adone = (uint8_t*)calloc(n, 1);
     e->areward = (float*)calloc(n, sizeof(float));
@@ -1275,6 +1284,7 @@ static void commit_obs(wrap_t* w, int zero_stack)
     uint8_t* small = (uint8_t*)malloc((size_t)oh * ow);
     orc_warp_area(w->obs, w->H, w->W, small, oh, ow);
     orc_stack_push(e->aobs + (size_t)w->i * oh * ow * st, small, oh, ow, st, zero_stack ? (e->acfg.stack_fill ? 2 : 1) : 0);
+    if (e->aplane) memcpy(e->aplane + (size_t)w->i * oh * ow, small, (size_t)oh * ow);   /* what the worker sends: the new frame alone */
     free(small);
 }
 
@@ -1380,5 +1390,94 @@ int tbx_agent_step(tbx_engine* e, const int32_t* actions, float* reward, uint8_t
     if (reward) memcpy(reward, e->areward, n * 4);
     if (done) memcpy(done, e->adone, n);
     if (obs) memcpy(obs, e->aobs, n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack);
+    return take_action_error(e);
+}
+
+/* ---------------------------------------------------------------- host delivery (toybox_amd.h: step_async / step_wait)
+ * The oracle has no device and no stream: "_begin" carries the whole step out and fills the caller's buffers, "_end" returns
+ * what the synchronous form returns.  Same calls, same order, same results as the HIP library's asynchronous forms. */
+
+int tbx_host_alloc(void** out_ptr, size_t bytes)
+{
+    if (!out_ptr) return TBX_E_INVALID;
+    void* p = NULL;
+    if (posix_memalign(&p, 4096, bytes ? bytes : 1)) { *out_ptr = NULL; return TBX_E_NOMEM; }
+    *out_ptr = p;
+    return TBX_OK;
+}
+
+int tbx_host_free(void* ptr) { free(ptr); return TBX_OK; }
+
+static int agent_copy_out(tbx_engine* e, const tbx_agent_host_out_t* o)
+{
+    const size_t n = (size_t)e->n, px = (size_t)e->acfg.out_h * e->acfg.out_w;
+    if (o->plane && !e->aplane) return fail(e, TBX_E_INVALID, "the newest plane needs tbx_agent_config_t::new_plane = 1");
+    if (o->reward) memcpy(o->reward, e->areward, n * 4);
+    if (o->done) memcpy(o->done, e->adone, n);
+    if (o->ep_done) memcpy(o->ep_done, e->ep_done, n);
+    if (o->ep_return) memcpy(o->ep_return, e->ep_ret_out, n * 4);
+    if (o->ep_length) memcpy(o->ep_length, e->ep_len_out, n * 4);
+    if (o->plane) memcpy(o->plane, e->aplane, n * px);
+    if (o->obs) memcpy(o->obs, e->aobs, n * px * e->acfg.stack);
+    return TBX_OK;
+}
+
+int tbx_agent_step_begin(tbx_engine* e, const int32_t* actions, const tbx_agent_host_out_t* out)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (!actions || !out) return fail(e, TBX_E_INVALID, "actions / output descriptor is NULL");
+    if (e->agent_host_pending) return fail(e, TBX_E_INVALID, "tbx_agent_step_begin: the previous step has not been ended (tbx_agent_step_end)");
+    int rc = tbx_agent_step_device(e, actions, NULL);
+    if (rc) return rc;
+    rc = agent_copy_out(e, out);
+    if (rc) return rc;
+    e->agent_host_pending = 1;
+    return TBX_OK;
+}
+
+int tbx_agent_step_end(tbx_engine* e)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (!e->agent_host_pending) return fail(e, TBX_E_INVALID, "tbx_agent_step_end without tbx_agent_step_begin");
+    e->agent_host_pending = 0;
+    return take_action_error(e);
+}
+
+int tbx_agent_fetch(tbx_engine* e, const tbx_agent_host_out_t* out)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (!out) return fail(e, TBX_E_INVALID, "output descriptor is NULL");
+    return agent_copy_out(e, out);
+}
+
+int tbx_step_begin(tbx_engine* e, const int32_t* actions, uint32_t flags, const tbx_step_host_out_t* out)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!actions || !out) return fail(e, TBX_E_INVALID, "actions / output descriptor is NULL");
+    if (e->host_pending) return fail(e, TBX_E_INVALID, "tbx_step_begin: the previous step has not been ended (tbx_step_end)");
+    if (out->frame && out->channels != 1 && out->channels != 3 && out->channels != 4) return fail(e, TBX_E_INVALID, "channels must be 1, 3 or 4");
+    int rc = tbx_step_device(e, actions, flags, NULL);
+    if (rc) return rc;
+    const size_t n = (size_t)e->n;
+    if (out->reward) memcpy(out->reward, e->reward, n * 4);
+    if (out->done) memcpy(out->done, e->done, n);
+    if (out->lives) memcpy(out->lives, e->lives, n * 4);
+    if (out->score) memcpy(out->score, e->score, n * 4);
+    if (out->frame) {
+        rc = tbx_render_device(e, out->frame, out->channels, NULL);
+        if (rc) return rc;
+    }
+    e->host_pending = 1;
+    return TBX_OK;
+}
+
+int tbx_step_end(tbx_engine* e)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->host_pending) return fail(e, TBX_E_INVALID, "tbx_step_end without tbx_step_begin");
+    e->host_pending = 0;
     return take_action_error(e);
 }

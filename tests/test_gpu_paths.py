@@ -286,7 +286,7 @@ def test_mixed_batch_config5_share_on_three_streams(hip_lib, oracle_lib):
 
 
 ALL_BUFS = ["BUF_REWARD", "BUF_DONE", "BUF_LIVES", "BUF_SCORE", "BUF_FRAME", "BUF_PACKED", "BUF_AGENT_OBS", "BUF_AGENT_REWARD",
-            "BUF_AGENT_DONE", "BUF_AGENT_EP_DONE", "BUF_AGENT_EP_RETURN", "BUF_AGENT_EP_LENGTH", "BUF_GATHERED"]
+            "BUF_AGENT_DONE", "BUF_AGENT_EP_DONE", "BUF_AGENT_EP_RETURN", "BUF_AGENT_EP_LENGTH", "BUF_GATHERED", "BUF_AGENT_PLANE"]
 
 
 @pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
@@ -313,7 +313,7 @@ def test_every_device_buffer_id(lib):
             with pytest.raises(ToyboxAmdError) as ei:
                 e.device_buffer(declared[name])
             assert ei.value.code == _abi.E_INVALID, name
-    for bad in (-1, 13, 99):
+    for bad in (-1, 14, 99):
         with pytest.raises(ToyboxAmdError) as ei:
             e.device_buffer(bad)
         assert ei.value.code == _abi.E_INVALID
@@ -321,12 +321,16 @@ def test_every_device_buffer_id(lib):
     e.render_device(0, 3)
     e.sync()
     e.agent_init(skip=2, out_h=42, out_w=60, stack=3)
+    with pytest.raises(ToyboxAmdError) as ei:                # the newest plane alone exists only when asked for
+        e.device_buffer(_abi.BUF_AGENT_PLANE)
+    assert ei.value.code == _abi.E_INVALID
+    e.agent_init(skip=2, out_h=42, out_w=60, stack=3, new_plane=True)
     e.agent_reset()
     e.agent_step([1] * n)
     e.gather_init(1, 0, e.gather_unique_id(), records_per_rank=n + 3)
     want = {"BUF_GATHERED": 8 * (n + 3),"BUF_REWARD": 4 * n, "BUF_DONE": n, "BUF_LIVES": 4 * n, "BUF_SCORE": 4 * n, "BUF_FRAME": n * 160 * 240 * 3,
             "BUF_PACKED": 8 * n, "BUF_AGENT_OBS": n * 42 * 60 * 3, "BUF_AGENT_REWARD": 4 * n, "BUF_AGENT_DONE": n,
-            "BUF_AGENT_EP_DONE": n, "BUF_AGENT_EP_RETURN": 4 * n, "BUF_AGENT_EP_LENGTH": 4 * n}
+            "BUF_AGENT_EP_DONE": n, "BUF_AGENT_EP_RETURN": 4 * n, "BUF_AGENT_EP_LENGTH": 4 * n, "BUF_AGENT_PLANE": n * 42 * 60}
     seen = set()
     for name in ALL_BUFS:
         p, b = e.device_buffer(declared[name])

@@ -242,6 +242,59 @@ def test_preproc_vec_env_frame_stack_and_scale_options(oracle_lib):
     env.close()
 
 
+ADAPTER_CASES = ["composition_breakout", "composition_space_invaders", "composition_amidar", "default_path_breakout",
+                 "default_path_space_invaders", "default_path_amidar", "env_stack_breakout", "env_stack_space_invaders",
+                 "default_path_frame_stack_scale_breakout", "wrappers_breakout_e1_f1_n30", "wrappers_space_invaders_e1_f1_n7",
+                 "wrappers_amidar_e0_f1_n30"]
+
+
+@pytest.mark.parametrize("layout", ["device_stack", "planes", "host_stack"])
+@pytest.mark.parametrize("name", ADAPTER_CASES)
+def test_preproc_vec_env_host_delivery_layouts(name, layout, lib):
+    """What the reference's VecFrameStack / FrameStack hand a learner, through ToyboxPreprocVecEnv's three ways of getting the
+    observation to the host: the whole stacks from the device; ONE new plane per env and step with the stack
+    kept on the host as a ring of planes (PlaneStack) or rolled into a real array -- step_async() queues, step_wait() collects.
+    Every reset() / step() output of the fixture (recorded from the reference's own classes) must come back, rotating pool,
+    done-aware fill (zeros for VecFrameStack, the reset observation for FrameStack) and episode infos included."""
+    from toybox_amd.envs import ToyboxPreprocVecEnv
+    from toybox_amd.envs.vec_env import PlaneStack
+    c = Case(name)
+    m = c.meta
+    if m["ow"] != m["oh"]:
+        pytest.skip("the adapter takes one `size`")
+    eng = Engine(c.game, c.n, lib=lib)
+    eng.seed(m["seed"])
+    env = ToyboxPreprocVecEnv(c.game, c.n, skip=m["skip"], size=m["oh"], stack=m["stack"], clip_rewards=m["clip"], engine=eng,
+                              episode_life=m.get("episodic", False), fire_reset=m.get("fire", False), noop_max=m.get("noop_max", 0),
+                              noop_seed=m.get("noop_seed", 0), env_offset=m.get("env_offset", 0),
+                              frame_stack="env" if m.get("per_env_stack") else "vec", scale=bool(m.get("scale")),
+                              obs_layout=layout, obs_pool=2)
+    obs = env.reset()
+    assert np.array_equal(np.asarray(obs), c["reset_obs"])
+    kept = None
+    for t in range(len(c["action_idx"])):
+        env.step_async(c["action_idx"][t])
+        if kept is not None and layout != "planes":          # the previous observation stays intact while the next step is in flight
+            assert np.array_equal(kept[0], kept[1])
+        obs, rew, done, infos = env.step_wait()
+        if layout == "planes" and not m.get("scale"):
+            assert isinstance(obs, PlaneStack) and obs.shape == c["obs"][t].shape
+            assert np.array_equal(obs[c.n - 1], c["obs"][t][c.n - 1])
+        assert np.array_equal(np.asarray(obs), c["obs"][t]), (name, layout, t)
+        assert np.array_equal(rew, c["rew"][t]) and np.array_equal(done, c["done"][t]), (name, layout, t)
+        ended = np.flatnonzero(c["ep_flag"][t])
+        got = infos.with_key("episode")
+        assert sorted(got) == [int(i) for i in ended]
+        for i in ended:
+            assert got[int(i)] == {"r": float(c["ep_r"][t][i]), "l": int(c["ep_l"][t][i])}
+        kept = (obs, np.asarray(obs).copy()) if not m.get("scale") else None
+    c.check_states(eng)
+    env.close()
+    # an observation a caller kept outlives the env (page-locked memory is owned by the arrays, ADVICE r04)
+    if kept is not None:
+        assert np.array_equal(np.asarray(kept[0]), kept[1])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("game", GAMES)
 def test_gpu_fused_preprocessing_parity(game, hip_lib, oracle_lib):
@@ -280,6 +333,94 @@ def test_gpu_fused_preprocessing_parity(game, hip_lib, oracle_lib):
     x, y = g2.agent_step(a), o2.agent_step(a)
     for p, q in zip(x, y):
         assert np.array_equal(p, q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("game,oh,ow,stack", [("breakout", 84, 84, 4), ("space_invaders", 84, 84, 4), ("amidar", 84, 84, 4),
+                                              ("gridworld", 84, 84, 4), ("breakout", 45, 71, 3), ("amidar", 50, 41, 2)])
+def test_gpu_newest_plane_and_async_host_delivery(game, oh, ow, stack, generic, hip_lib, oracle_lib):
+    """tbx_agent_config_t::new_plane on the HIP library: TBX_BUF_AGENT_PLANE (what tbx_agent_step_begin delivers as `plane`) is
+    the newest slot of every stack, from the fused observation kernels and from the generic warp kernel, for plane sizes that
+    are and are not a multiple of four bytes; every output of the begin / end form equals the oracle's synchronous step, with
+    the wrappers on, through episode ends; a second _begin without _end, an _end without _begin and a plane request without
+    new_plane are TBX_E_INVALID."""
+    from toybox_amd._lib import ToyboxAmdError
+    n = 300
+    wrappers = game != "gridworld"
+    g, o = Engine(game, n, lib=hip_lib), Engine(game, n, lib=oracle_lib)
+    if generic:
+        g.set_option(_abi.OPT_AGENT_GENERIC, 1)
+    for e in (g, o):
+        e.seed(77)
+        e.agent_init(skip=3, out_h=oh, out_w=ow, stack=stack, clip_reward=True, episodic_life=wrappers, fire_reset=wrappers,
+                     noop_max=9 if wrappers else 0, noop_seed=5, new_plane=True)
+    og, oo = g.agent_reset(), o.agent_reset()
+    assert np.array_equal(og, oo)
+    plane = g.host_array((n, oh, ow))
+    g.agent_fetch(plane=plane)
+    assert np.array_equal(plane, oo[..., -1])
+    bufs = {"reward": g.host_array((n,), np.float32), "done": g.host_array((n,), np.uint8), "obs": g.host_array((n, oh, ow, stack)),
+            "ep_done": g.host_array((n,), np.uint8), "ep_return": g.host_array((n,), np.float32), "ep_length": g.host_array((n,), np.int32)}
+    ends = 0
+    for t in range(150):
+        a = synthetic_actions(game, n, t, seed=3)
+        g.agent_step_begin(a, plane=plane, **bufs)
+        if t == 0:
+            with pytest.raises(ToyboxAmdError) as ei:
+                g.agent_step_begin(a, plane=plane)
+            assert ei.value.code == _abi.E_INVALID
+        oo, ro, do = o.agent_step(a, tolerate_needs_reset=True)   # (the CPU step runs while the device step is in flight)
+        g.agent_step_end(tolerate_needs_reset=True)
+        assert np.array_equal(bufs["obs"], oo) and np.array_equal(plane, oo[..., -1]), t
+        assert np.array_equal(bufs["reward"], ro) and np.array_equal(bufs["done"].astype(bool), do), t
+        eo = o.agent_episodes()
+        assert np.array_equal(bufs["ep_done"].astype(bool), eo[0])
+        assert np.array_equal(bufs["ep_return"][eo[0]], eo[1][eo[0]]) and np.array_equal(bufs["ep_length"][eo[0]], eo[2][eo[0]])
+        ends += int(do.sum())
+    assert ends > 0 or game in ("gridworld",)
+    with pytest.raises(ToyboxAmdError) as ei:
+        g.agent_step_end()
+    assert ei.value.code == _abi.E_INVALID
+    g.agent_init(skip=3, out_h=oh, out_w=ow, stack=stack)
+    g.agent_reset()
+    with pytest.raises(ToyboxAmdError) as ei:
+        g.agent_fetch(plane=plane)
+    assert ei.value.code == _abi.E_INVALID
+    g.close(); o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", GAMES)
+def test_gpu_step_begin_end_with_frames(game, hip_lib, oracle_lib):
+    """tbx_step_begin / tbx_step_end (ToyboxVecEnv.step_async / step_wait): outputs and RGB frames of every step == the oracle's
+    tbx_step + tbx_render, auto-reset on; an illegal action id is reported by the _end call like tbx_step reports it."""
+    from toybox_amd._lib import ToyboxAmdError
+    n = 200
+    g, o = Engine(game, n, lib=hip_lib), Engine(game, n, lib=oracle_lib)
+    for e in (g, o):
+        e.seed(5)
+        e.new_game()
+    out = {"reward": g.host_array((n,), np.int32), "done": g.host_array((n,), np.uint8), "lives": g.host_array((n,), np.int32),
+           "score": g.host_array((n,), np.int32)}
+    frames = [g.host_array((n, g.height, g.width, 3)) for _ in range(2)]
+    for t in range(120):
+        a = synthetic_actions(game, n, t, seed=11)
+        g.step_begin(a, auto_reset=True, frame=frames[t % 2], channels=3, **out)
+        r, d, l, sc = o.step(a, auto_reset=True)
+        fo = o.render(3) if t % 10 == 0 else None
+        g.step_end()
+        assert np.array_equal(out["reward"], r) and np.array_equal(out["done"].astype(bool), d), t
+        assert np.array_equal(out["lives"], l) and np.array_equal(out["score"], sc), t
+        if fo is not None:
+            assert np.array_equal(frames[t % 2], fo), t
+    bad = synthetic_actions(game, n, 0)
+    bad[3] = 99
+    g.step_begin(bad, auto_reset=True, **out)
+    with pytest.raises(ToyboxAmdError) as ei:
+        g.step_end()
+    assert ei.value.code == _abi.E_ACTION
+    g.close(); o.close()
 
 
 @pytest.mark.gpu

@@ -350,7 +350,9 @@ def test_bench_n_process_flow_end_to_end_on_the_checker(world, extra, oracle_lib
     value = the strong reading (envs in total) with the weak one beside it, a K-step ring communicator per reading, the verified
     exchange, share_of_linear as a fraction -- over the oracle's shared-memory gather."""
     import json
-    argv = ["--gpus", str(world), "--envs", "96", "--steps", "6", "--warmup", "2", "--repeats", "2", "--preroll", "300", "--no-cpu-baseline"] + extra
+    # world 2 also carries the CPU arm: the north star wants it "in the same run" at every GPU count (rank 0, bounded sample)
+    argv = ["--gpus", str(world), "--envs", "96", "--steps", "6", "--warmup", "2", "--repeats", "2", "--preroll", "300"] + \
+           (["--cpu-seconds", "0.3"] if world == 2 else ["--no-cpu-baseline"]) + extra
     script = tmp_path / "worker.py"
     script.write_text(BENCH_FLOW_WORKER.format(root=ROOT, argv=argv))
     env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="3", TBX_RDZV_DIR=str(tmp_path))
@@ -373,3 +375,89 @@ def test_bench_n_process_flow_end_to_end_on_the_checker(world, extra, oracle_lib
     assert abs(line["share_of_linear"] - s_["value"] / w_["value"]) < 1e-9 and 0 < line["share_of_linear"]
     assert line["loop"]["form"] == "pair"                      # (the checker reports no fused launch)
     assert line["check"]["frames_played"] > 300
+    assert line["metric_version"]["version"] == 2
+    if world == 2:
+        cb = line["cpu_baseline"]
+        assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and "96" in cb["sample"]
+        assert line["cpu_config1"]["step_only"] > 0
+    else:
+        assert "cpu_baseline" not in line
+    rf = line["roofline"]
+    assert rf["avg_launch_ms"] > 0 and rf["launches_timed"] >= 1 and "never" in rf["timing"]
+
+
+class _FakeEvent:
+    log = []
+
+    def __init__(self):
+        self.at = None
+
+    def record(self, stream):
+        self.at = len(_FakeEvent.log)
+        _FakeEvent.log.append(("event", id(self)))
+
+    def elapsed_ms(self, other):
+        # "time" = launches between the two events
+        return float(sum(1 for x in _FakeEvent.log[self.at:other.at] if x[0] == "launch"))
+
+    def close(self):
+        pass
+
+
+class _FakeEngine:
+    def step_synthetic(self, *a, **k):
+        _FakeEvent.log.append(("step",))
+
+    def render_device(self, *a, **k):
+        _FakeEvent.log.append(("launch",))
+
+    def render_step_synthetic(self, *a, **k):
+        _FakeEvent.log.append(("launch",))
+
+    def gather(self, **k):
+        pass
+
+
+@pytest.mark.parametrize("fused,K", [(True, 20), (True, 5), (True, 1), (False, 20), (False, 3)])
+def test_bench_launch_timing_brackets_runs_never_next_to_a_sync(fused, K):
+    """roofline.avg_launch_ms of bench.py (bracketing single launches incl. the first one after a
+    synchronisation made a kernel 'longer' than the step that contains it).  Fused loop: chained events around runs of up to 8
+    back-to-back launches, none of the first two launches of a region; pair loop: single rasteriser launches, the same rule;
+    the counters start again with every region."""
+    import bench
+
+    class Hip:
+        Event = _FakeEvent
+
+    class St:
+        ptr = 0
+
+    _FakeEvent.log = []
+    R = 3
+    loop = bench.Loop(_FakeEngine(), Hip, St(), 0, 3, False, True, K, R, fused=fused)
+    for t in range(4):
+        loop.full_step(t)                                   # warm-up: nothing is timed before arm()
+    assert not any(x[0] == "event" for x in _FakeEvent.log)
+    loop.arm()
+    region_starts = []
+    for r in range(R):
+        region_starts.append(len(_FakeEvent.log))
+        loop.begin_region()
+        for i in range(K):
+            loop.full_step(100 * r + i)
+    per, covered = loop.launch_ms()
+    run, skip = loop.run, loop.skip
+    assert run == max(1, min(8, K - 2)) and skip == max(0, min(2, K - run))
+    if fused:
+        assert covered == R * ((K - skip) // run) * run and all(v == 1.0 for v in per)     # run launches between the events / run
+    else:
+        assert covered == R * ((K - skip + run - 1) // run) and all(v == 1.0 for v in per)
+    # no event before the `skip`-th launch of a region
+    for start in region_starts:
+        seen = 0
+        for x in _FakeEvent.log[start:]:
+            if x[0] == "launch":
+                seen += 1
+            if x[0] == "event":
+                assert seen >= skip
+                break

@@ -22,6 +22,7 @@ BUF_REWARD, BUF_DONE, BUF_LIVES, BUF_SCORE, BUF_FRAME, BUF_PACKED = 0, 1, 2, 3, 
 BUF_AGENT_OBS, BUF_AGENT_REWARD, BUF_AGENT_DONE = 6, 7, 8
 BUF_AGENT_EP_DONE, BUF_AGENT_EP_RETURN, BUF_AGENT_EP_LENGTH = 9, 10, 11
 BUF_GATHERED = 12
+BUF_AGENT_PLANE = 13
 GATHER_ID_BYTES = 128
 # engine options (tbx_set_option)
 OPT_PIPELINE, OPT_STEP_FORM, OPT_RENDER_SPLIT, OPT_AGENT_GENERIC, OPT_RESIDENT_STEP, OPT_GATHER_EVERY = 0, 1, 2, 3, 4, 5
@@ -269,7 +270,19 @@ CONFIG_TYPES = {GAME_BREAKOUT: BreakoutConfig, GAME_SPACE_INVADERS: SIConfig, GA
 class AgentConfig(C.Structure):
     _fields_ = [("skip", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32), ("stack", C.c_int32), ("clip_reward", C.c_int32),
                 ("episodic_life", C.c_int32), ("fire_reset", C.c_int32), ("noop_max", C.c_int32),
-                ("noop_seed", C.c_uint64), ("env_offset", C.c_uint64), ("stack_fill", C.c_int32), ("_reserved", C.c_int32)]
+                ("noop_seed", C.c_uint64), ("env_offset", C.c_uint64), ("stack_fill", C.c_int32), ("new_plane", C.c_int32)]
+
+
+class AgentHostOut(C.Structure):
+    """tbx_agent_host_out_t: host destinations of an agent step's outputs (addresses; 0 = not wanted)"""
+    _fields_ = [("reward", C.c_void_p), ("done", C.c_void_p), ("obs", C.c_void_p), ("plane", C.c_void_p),
+                ("ep_done", C.c_void_p), ("ep_return", C.c_void_p), ("ep_length", C.c_void_p)]
+
+
+class StepHostOut(C.Structure):
+    """tbx_step_host_out_t"""
+    _fields_ = [("reward", C.c_void_p), ("done", C.c_void_p), ("lives", C.c_void_p), ("score", C.c_void_p), ("frame", C.c_void_p),
+                ("channels", C.c_int32), ("_pad", C.c_int32)]
 
 
 _p = C.POINTER
@@ -323,6 +336,13 @@ PROTOTYPES = {
     "tbx_agent_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "tbx_agent_step_device": (_i, [_vp, _vp, _vp]),
     "tbx_agent_step_synthetic": (_i, [_vp, _u64, _u64, _u64, _vp]),
+    "tbx_host_alloc": (_i, [_p(_vp), _sz]),
+    "tbx_host_free": (_i, [_vp]),
+    "tbx_agent_step_begin": (_i, [_vp, _vp, _p(AgentHostOut)]),
+    "tbx_agent_step_end": (_i, [_vp]),
+    "tbx_agent_fetch": (_i, [_vp, _p(AgentHostOut)]),
+    "tbx_step_begin": (_i, [_vp, _vp, _u32, _p(StepHostOut)]),
+    "tbx_step_end": (_i, [_vp]),
     "tbx_gather_unique_id": (_i, [_vp, _sz]),
     "tbx_gather_init": (_i, [_vp, _i, _i, _i, _vp, _sz]),
     "tbx_gather": (_i, [_vp, _vp, _vp]),

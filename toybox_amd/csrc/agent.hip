@@ -17,6 +17,11 @@ struct AgentState {
     int H = 0, W = 0;
     uint8_t *gray_a = nullptr, *gray_b = nullptr;   // generic path only: full-resolution gray frames of the two buffer slots
     uint8_t *obs = nullptr, *fin = nullptr, *done_out = nullptr;
+    uint8_t* plane = nullptr;                       // [N][out_h][out_w] newest plane alone (cfg.new_plane), else nullptr
+    // host delivery (tbx_agent_step_begin / _end): an agent step whose outputs are on their way to the caller's host buffers
+    bool host_pending = false;
+    int32_t* host_actions = nullptr;                // pinned [N]: the caller's actions, copied before _begin returns
+    uint32_t* host_flags = nullptr;                 // pinned: the device's error word as the step left it
     int32_t* racc = nullptr;
     float* reward_out = nullptr;
     AgentTaps *ty = nullptr, *tx = nullptr;
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
                         uint8_t* px = o + ((size_t)oy * ow + ox) * S;
                         if (S == 4) *reinterpret_cast<uint32_t*>(px) = (stack_old_word(fresh ? 0u : old[q], val, fresh) >> 8) | (val << 24);
                         else stack_push<S>(px, val, fresh);
+                        if (wa.plane) wa.plane[((size_t)env * oh + oy) * ow + ox] = (uint8_t)val;
                     }
                     acc0[q] = acc1[q];
                     acc1[q] = 0;
@@ -220,7 +226,7 @@ AgentWarpArgs warp_args(tbx_engine* e, int reset_mode)
 {
     AgentState& a = *e->agent;
     AgentWarpArgs w;
-    w.zero = a.done_out; w.mode = a.mode; w.valid = a.buf_valid; w.tx = a.tx; w.obs = a.obs;
+    w.zero = a.done_out; w.mode = a.mode; w.valid = a.buf_valid; w.tx = a.tx; w.obs = a.obs; w.plane = a.plane;
     w.H = a.H; w.W = a.W; w.oh = a.cfg.out_h; w.ow = a.cfg.out_w; w.stack = a.cfg.stack;
     w.reset_mode = reset_mode;
     w.fill_repeat = a.cfg.stack_fill != 0;
@@ -345,6 +351,8 @@ void tbx_agent_free(tbx_engine* e)
 {
     if (!e->agent) return;
     AgentState* a = e->agent;
+    if (a->host_pending) hipStreamSynchronize(e->stream);      // copies into the caller's buffers are still in flight
+    hipFree(a->plane); hipHostFree(a->host_actions); hipHostFree(a->host_flags);
     hipFree(a->gray_a); hipFree(a->gray_b); hipFree(a->obs); hipFree(a->fin); hipFree(a->done_out);
     hipFree(a->racc); hipFree(a->reward_out); hipFree(a->ty); hipFree(a->tx);
     hipFree(a->was_real_done); hipFree(a->needs_reset); hipFree(a->mode); hipFree(a->buf_valid); hipFree(a->exec_flag);
@@ -364,6 +372,9 @@ int tbx_agent_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_bytes
     size_t b = 0;
     switch (which) {
     case TBX_BUF_AGENT_OBS: p = a.obs; b = N * a.cfg.out_h * a.cfg.out_w * a.cfg.stack; break;
+    case TBX_BUF_AGENT_PLANE:
+        if (!a.plane) return e->fail(TBX_E_INVALID, "TBX_BUF_AGENT_PLANE needs tbx_agent_config_t::new_plane = 1");
+        p = a.plane; b = N * a.cfg.out_h * a.cfg.out_w; break;
     case TBX_BUF_AGENT_REWARD: p = a.reward_out; b = N * sizeof(float); break;
     case TBX_BUF_AGENT_DONE: p = a.done_out; b = N; break;
     case TBX_BUF_AGENT_EP_DONE: p = a.ep_done; b = N; break;
@@ -385,8 +396,8 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     const int H = e->ops->height(), W = e->ops->width();
     if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
         cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > AGENT_MAX_OUT_PX || cfg->noop_max < 0 ||
-        cfg->noop_max > 1000 || cfg->stack_fill < 0 || cfg->stack_fill > 1)
-        return e->fail(TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000, stack_fill 0..1)");
+        cfg->noop_max > 1000 || cfg->stack_fill < 0 || cfg->stack_fill > 1 || cfg->new_plane < 0 || cfg->new_plane > 1)
+        return e->fail(TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000, stack_fill 0..1, new_plane 0..1)");
     if ((H + cfg->out_h - 1) / cfg->out_h + 1 > MAX_TAPS || (W + cfg->out_w - 1) / cfg->out_w + 1 > MAX_TAPS)
         return e->fail(TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
     AHIP(hipSetDevice(e->device));
@@ -420,6 +431,10 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
         if (rc) return rc;
     }
     AHIP(hipMalloc((void**)&a->obs, N * cfg->out_h * cfg->out_w * cfg->stack));
+    if (cfg->new_plane) {
+        AHIP(hipMalloc((void**)&a->plane, N * cfg->out_h * cfg->out_w));
+        AHIP(hipMemset(a->plane, 0, N * cfg->out_h * cfg->out_w));
+    }
     AHIP(hipMalloc((void**)&a->fin, N));
     AHIP(hipMalloc((void**)&a->done_out, N));
     AHIP(hipMalloc((void**)&a->racc, N * sizeof(int32_t)));
@@ -551,6 +566,83 @@ int tbx_agent_step_synthetic(tbx_engine* e, uint64_t action_seed, uint64_t t, ui
     src.seed = action_seed; src.t = t; src.env_offset = env_offset;
     src.single_env = -1;
     return agent_step_async(e, src, (hipStream_t)stream);
+}
+
+// the copies of an agent step's outputs into the caller's host buffers, queued on `s`
+static int agent_queue_outputs(tbx_engine* e, const tbx_agent_host_out_t& out, hipStream_t s)
+{
+    AgentState& a = *e->agent;
+    const size_t N = (size_t)e->n, px = (size_t)a.cfg.out_h * a.cfg.out_w;
+    if (out.plane && !a.plane) return e->fail(TBX_E_INVALID, "the newest plane needs tbx_agent_config_t::new_plane = 1");
+    if (out.reward) AHIP(hipMemcpyAsync(out.reward, a.reward_out, N * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (out.done) AHIP(hipMemcpyAsync(out.done, a.done_out, N, hipMemcpyDeviceToHost, s));
+    if (out.ep_done) AHIP(hipMemcpyAsync(out.ep_done, a.ep_done, N, hipMemcpyDeviceToHost, s));
+    if (out.ep_return) AHIP(hipMemcpyAsync(out.ep_return, a.ep_ret_out, N * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (out.ep_length) AHIP(hipMemcpyAsync(out.ep_length, a.ep_len_out, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (out.plane) AHIP(hipMemcpyAsync(out.plane, a.plane, N * px, hipMemcpyDeviceToHost, s));
+    if (out.obs) AHIP(hipMemcpyAsync(out.obs, a.obs, N * px * a.cfg.stack, hipMemcpyDeviceToHost, s));
+    return TBX_OK;
+}
+
+int tbx_agent_step_begin(tbx_engine* e, const int32_t* actions_host, const tbx_agent_host_out_t* out)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (!actions_host || !out) return e->fail(TBX_E_INVALID, "actions / output descriptor is NULL");
+    AgentState& a = *e->agent;
+    if (a.host_pending) return e->fail(TBX_E_INVALID, "tbx_agent_step_begin: the previous step has not been ended (tbx_agent_step_end)");
+    AHIP(hipSetDevice(e->device));
+    AHIP(tbx_use_stream(e, e->stream));
+    AHIP(tbx_gather_before_step(e, e->stream));
+    const size_t N = (size_t)e->n;
+    if (!a.host_actions) {
+        AHIP(hipHostMalloc((void**)&a.host_actions, N * sizeof(int32_t), hipHostMallocDefault));
+        AHIP(hipHostMalloc((void**)&a.host_flags, sizeof(uint32_t), hipHostMallocDefault));
+    }
+    memcpy(a.host_actions, actions_host, N * sizeof(int32_t));
+    AHIP(hipMemcpyAsync(e->actions, a.host_actions, N * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    ActionSource src{};
+    src.actions = e->actions;
+    src.single_env = -1;
+    int rc = agent_step_async(e, src, e->stream);
+    if (rc) return rc;
+    rc = agent_queue_outputs(e, *out, e->stream);
+    if (rc) return rc;
+    AHIP(hipMemcpyAsync(a.host_flags, e->err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    a.host_pending = true;
+    return TBX_OK;
+}
+
+int tbx_agent_step_end(tbx_engine* e)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    AgentState& a = *e->agent;
+    if (!a.host_pending) return e->fail(TBX_E_INVALID, "tbx_agent_step_end without tbx_agent_step_begin");
+    AHIP(hipSetDevice(e->device));
+    AHIP(hipStreamSynchronize(e->stream));
+    a.host_pending = false;
+    const uint32_t f = *a.host_flags;
+    if (f) {
+        AHIP(hipMemsetAsync(e->err_flag, 0, sizeof f, e->stream));
+        if (f & 2u)
+            return e->fail(TBX_E_NEEDS_RESET, "an env was stepped after its game ended inside EpisodicLifeEnv's no-op step (bench.Monitor raises here)");
+        return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
+    }
+    return TBX_OK;
+}
+
+int tbx_agent_fetch(tbx_engine* e, const tbx_agent_host_out_t* out)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (!out) return e->fail(TBX_E_INVALID, "output descriptor is NULL");
+    AHIP(hipSetDevice(e->device));
+    AHIP(tbx_use_stream(e, e->stream));
+    int rc = agent_queue_outputs(e, *out, e->stream);
+    if (rc) return rc;
+    AHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
 }
 
 int tbx_agent_step(tbx_engine* e, const int32_t* actions_host, float* reward_host, uint8_t* done_host, uint8_t* obs_host)

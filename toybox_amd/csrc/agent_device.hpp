@@ -18,6 +18,7 @@ struct AgentWarpArgs {
     const uint8_t* valid;      // [N] bit 0 / 1: buffer slot A / B has been written since construction (else a zero frame)
     const AgentTaps* tx;       // [out_w] column taps
     uint8_t* obs;              // [N][out_h][out_w][stack]
+    uint8_t* plane;            // [N][out_h][out_w] the newest plane alone (tbx_agent_config_t::new_plane), or nullptr
     int H, W, oh, ow, stack;
     int reset_mode;            // venv.reset(): every stack starts from zeros
     int fill_repeat;           // tbx_agent_config_t::stack_fill: a fresh stack holds the new frame in every slot, not zeros
@@ -104,10 +105,20 @@ __device__ __forceinline__ void stack_push(uint8_t* px, uint32_t val, int fresh)
 // load -> store per output row.  out_h * out_w <= AGENT_MAX_OUT_PX.
 constexpr int AGENT_MAX_OUT_PX = 84 * 84;
 
+// plane_env: where the env's newest plane goes as well (dense, the host-delivery form), or nullptr.
 template <int S>
-__device__ __forceinline__ void stack_commit(const uint8_t* vals, uint8_t* o, int n_px, int lane, int fresh)
+__device__ __forceinline__ void stack_commit(const uint8_t* vals, uint8_t* o, int n_px, int lane, int fresh, uint8_t* plane_env)
 {
     __builtin_amdgcn_wave_barrier();
+    if (plane_env) {                                   // (wave-uniform) vals is 16-byte aligned LDS; the plane 4-byte aligned when n_px % 4 == 0
+        if ((n_px & 3) == 0) {
+            const uint32_t* v4 = reinterpret_cast<const uint32_t*>(vals);
+            uint32_t* p4 = reinterpret_cast<uint32_t*>(plane_env);
+            for (int i = lane; i < (n_px >> 2); i += 64) p4[i] = v4[i];
+        } else {
+            for (int i = lane; i < n_px; i += 64) plane_env[i] = vals[i];
+        }
+    }
     if (S == 4) {
         uint32_t* o4 = reinterpret_cast<uint32_t*>(o);
         if (fresh) {                                   // (wave-uniform) nothing of the old stack survives: stores only
@@ -317,9 +328,10 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
     static_assert(W % 4 == 0 && W / 4 <= 64 * NG && H <= 256, "painter geometry");
     const ObsSel sel = agent_obs_sel(a, env);
     uint8_t* o = a.obs + (size_t)env * a.oh * a.ow * S;
+    uint8_t* plane_env = a.plane ? a.plane + (size_t)env * a.oh * a.ow : nullptr;
     if (sel.none) {                                                    // max over two zero frames
         for (int i = lane; i < a.oh * a.ow; i += 64) L.vals[i] = 0;
-        stack_commit<S>(L.vals, o, a.oh * a.ow, lane, sel.zero);
+        stack_commit<S>(L.vals, o, a.oh * a.ow, lane, sel.zero, plane_env);
         return;
     }
     const bool two = sel.two;
@@ -445,5 +457,5 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
     }
     // the read-modify-write of the frame stack in one sweep with many loads in flight (a dependent load -> store per
     // output row, even fetched a row ahead, left this kernel waiting on HBM latency 84 times per env)
-    stack_commit<S>(L.vals, o, a.oh * a.ow, lane, sel.zero);
+    stack_commit<S>(L.vals, o, a.oh * a.ow, lane, sel.zero, plane_env);
 }

@@ -1553,7 +1553,7 @@ __device__ __forceinline__ void ami_paint_units(const AmiPainter<C>& p, uint8_t*
         const uint32_t mv_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.mv_rows, y_first);
         const uint32_t busy_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.busy, y_first);
         if (busy_chunk == 0 && C != 4) {                     // background only: no staging (RGBA: staged is faster)
-            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_bg);
+            Stager::fill_unit_aligned(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_bg);
             continue;
         }
 #pragma unroll 1
@@ -1562,7 +1562,7 @@ __device__ __forceinline__ void ami_paint_units(const AmiPainter<C>& p, uint8_t*
             p.paint_row(y_first + r, (mv_chunk >> r) & 1u, px);
             if (p.active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
         }
-        st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
+        st.flush_aligned(frame + (size_t)u * Stager::UNIT_BYTES, lane);   // 4 800-byte units: see RowStager::flush_aligned
     }
 }
 

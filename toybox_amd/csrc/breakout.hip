@@ -1378,9 +1378,10 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
     uint8_t* vals = vals_all[wave];
     const ObsSel sel = agent_obs_sel(a, env);
     uint8_t* o = a.obs + (size_t)env * a.oh * a.ow * S;
+    uint8_t* plane_env = a.plane ? a.plane + (size_t)env * a.oh * a.ow : nullptr;
     if (sel.none) {                                        // max over two zero frames
         for (int i = lane; i < a.oh * a.ow; i += 64) vals[i] = 0;
-        stack_commit<S>(vals, o, a.oh * a.ow, lane, sel.zero);
+        stack_commit<S>(vals, o, a.oh * a.ow, lane, sel.zero, plane_env);
         return;
     }
     const bool fresh = !sel.two;                           // one frame alone: record B is its source, record A is not composed
@@ -1487,7 +1488,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
             }
         }
     }
-    stack_commit<S>(vals, o, a.oh * a.ow, lane, sel.zero);
+    stack_commit<S>(vals, o, a.oh * a.ow, lane, sel.zero, plane_env);
 }
 
 // ------------------------------------------------------------------ state pack / unpack, scalars

@@ -697,11 +697,31 @@ int tbx_step_synthetic(tbx_engine* e, uint64_t action_seed, uint64_t t, uint64_t
     return e->ops->step(e, src, flags, (hipStream_t)stream);
 }
 
-int tbx_step(tbx_engine* e, const int32_t* actions_host, uint32_t flags, int32_t* reward, uint8_t* done,
-             int32_t* lives, int32_t* score)
+// ---- host delivery (toybox_amd.h: step_async / step_wait).  tbx_step is begin + end without a frame.
+
+int tbx_host_alloc(void** out_ptr, size_t bytes)
+{
+    if (!out_ptr) { tbx_set_create_error("tbx_host_alloc: out_ptr is NULL"); return TBX_E_INVALID; }
+    *out_ptr = nullptr;
+    hipError_t r = hipHostMalloc(out_ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (r != hipSuccess) { tbx_set_create_error(std::string("hipHostMalloc: ") + hipGetErrorString(r)); return r == hipErrorOutOfMemory ? TBX_E_NOMEM : TBX_E_NO_DEVICE; }
+    return TBX_OK;
+}
+
+int tbx_host_free(void* ptr)
+{
+    if (!ptr) return TBX_OK;
+    hipError_t r = hipHostFree(ptr);
+    if (r != hipSuccess) { tbx_set_create_error(std::string("hipHostFree: ") + hipGetErrorString(r)); return TBX_E_INVALID; }
+    return TBX_OK;
+}
+
+int tbx_step_begin(tbx_engine* e, const int32_t* actions_host, uint32_t flags, const tbx_step_host_out_t* out)
 {
     CHECK_ENGINE(e);
-    if (!actions_host) return e->fail(TBX_E_INVALID, "actions pointer is NULL");
+    if (!actions_host || !out) return e->fail(TBX_E_INVALID, "actions / output descriptor is NULL");
+    if (e->host_pending) return e->fail(TBX_E_INVALID, "tbx_step_begin: the previous step has not been ended (tbx_step_end)");
+    if (out->frame && out->channels != 1 && out->channels != 3 && out->channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
     EHIP(hipSetDevice(e->device));
     EHIP(tbx_use_stream(e, e->stream));
     EHIP(tbx_gather_before_step(e, e->stream));
@@ -724,14 +744,50 @@ int tbx_step(tbx_engine* e, const int32_t* actions_host, uint32_t flags, int32_t
                        e->done, e->err_flag, e->io_dev, e->n);
     EHIP(hipGetLastError());
     EHIP(hipMemcpyAsync(host_out, e->io_dev, out_bytes, hipMemcpyDeviceToHost, e->stream));
+    if (out->frame) {
+        const size_t bytes = N * e->ops->height() * e->ops->width() * out->channels;
+        rc = ensure_frame(e, bytes);
+        if (rc) return rc;
+        rc = e->ops->render(e, e->frame_own, out->channels, 0, e->n, e->stream);
+        if (rc) return rc;
+        e->frame = e->frame_own;
+        e->frame_bytes = e->frame_own_bytes;
+        EHIP(hipMemcpyAsync(out->frame, e->frame_own, bytes, hipMemcpyDeviceToHost, e->stream));
+    }
+    e->host_out = *out;
+    e->host_pending = true;
+    return TBX_OK;
+}
+
+int tbx_step_end(tbx_engine* e)
+{
+    CHECK_ENGINE(e);
+    if (!e->host_pending) return e->fail(TBX_E_INVALID, "tbx_step_end without tbx_step_begin");
+    EHIP(hipSetDevice(e->device));
     EHIP(hipStreamSynchronize(e->stream));
-    if (reward) memcpy(reward, host_out, N * sizeof(int32_t));
-    if (lives) memcpy(lives, host_out + N, N * sizeof(int32_t));
-    if (score) memcpy(score, host_out + 2 * N, N * sizeof(int32_t));
-    if (done) memcpy(done, host_out + 3 * N + 1, N);
+    e->host_pending = false;
+    const size_t N = (size_t)e->n;
+    const int32_t* host_out = e->io_host + N;
+    const tbx_step_host_out_t& o = e->host_out;
+    if (o.reward) memcpy(o.reward, host_out, N * sizeof(int32_t));
+    if (o.lives) memcpy(o.lives, host_out + N, N * sizeof(int32_t));
+    if (o.score) memcpy(o.score, host_out + 2 * N, N * sizeof(int32_t));
+    if (o.done) memcpy(o.done, host_out + 3 * N + 1, N);
     if (host_out[3 * N] & 2) return e->fail(TBX_E_NEEDS_RESET, "an env was stepped after its game ended inside EpisodicLifeEnv's no-op step (bench.Monitor raises here)");
     if (host_out[3 * N]) return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
     return TBX_OK;
+}
+
+int tbx_step(tbx_engine* e, const int32_t* actions_host, uint32_t flags, int32_t* reward, uint8_t* done,
+             int32_t* lives, int32_t* score)
+{
+    CHECK_ENGINE(e);
+    if (e->host_pending) return e->fail(TBX_E_INVALID, "tbx_step: a tbx_step_begin has not been ended (tbx_step_end)");
+    tbx_step_host_out_t out{};
+    out.reward = reward; out.done = done; out.lives = lives; out.score = score;
+    int rc = tbx_step_begin(e, actions_host, flags, &out);
+    if (rc) return rc;
+    return tbx_step_end(e);
 }
 
 // ---- resident single-env step (TbxServeCtl, tbx_common.hpp)
@@ -1238,7 +1294,7 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     case TBX_BUF_FRAME: p = e->frame; b = e->frame_bytes; break;
     case TBX_BUF_PACKED: p = e->packed; b = N * 8; break;
     case TBX_BUF_AGENT_OBS: case TBX_BUF_AGENT_REWARD: case TBX_BUF_AGENT_DONE:
-    case TBX_BUF_AGENT_EP_DONE: case TBX_BUF_AGENT_EP_RETURN: case TBX_BUF_AGENT_EP_LENGTH:
+    case TBX_BUF_AGENT_EP_DONE: case TBX_BUF_AGENT_EP_RETURN: case TBX_BUF_AGENT_EP_LENGTH: case TBX_BUF_AGENT_PLANE:
         return tbx_agent_buffer(e, which, out_ptr, out_bytes);
     case TBX_BUF_GATHERED: return tbx_gather_buffer(e, out_ptr, out_bytes);
     default: return e->fail(TBX_E_INVALID, "unknown buffer id");

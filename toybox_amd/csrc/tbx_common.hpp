@@ -374,6 +374,8 @@ struct tbx_engine {
     // into pinned host memory (five pageable copies cost ~100 us per call); actions go up through the pinned block too
     int32_t* io_dev = nullptr;      // 3N + 1 dwords + N bytes
     int32_t* io_host = nullptr;     // pinned mirror (+ N action dwords in front)
+    bool host_pending = false;      // a tbx_step_begin whose outputs are on their way (tbx_step_end takes them)
+    tbx_step_host_out_t host_out{}; // where they go
     uint8_t* frame_own = nullptr;   // engine-owned frame buffer (lazy)
     size_t frame_own_bytes = 0;
     uint8_t* frame = nullptr;       // what TBX_BUF_FRAME reports: frame_own, or in pipelined mode the buffer the last render wrote

@@ -17,6 +17,48 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def _addr(a):
+    """address of a C-contiguous numpy array for a descriptor struct (None -> 0)"""
+    if a is None:
+        return None
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("host output arrays must be C-contiguous")
+    return a.ctypes.data
+
+
+class HostArray:
+    """Owner of one block of page-locked host memory from the engine library's tbx_host_alloc.  The numpy arrays made over it
+    keep the owner alive through their `base` chain, so the memory is released only when the last view is gone (an observation
+    a caller kept past env.close() stays valid: ADVICE r04 on the earlier PinnedArray.close())."""
+
+    def __init__(self, lib, nbytes):
+        self._lib = lib
+        p = C.c_void_p()
+        rc = lib.tbx_host_alloc(C.byref(p), int(max(1, nbytes)))
+        if rc != _abi.OK or not p.value:
+            msg = lib.tbx_last_error(None)
+            raise ToyboxAmdError(rc, msg.decode() if msg else "tbx_host_alloc failed")
+        self._ptr = p
+        self.nbytes = int(nbytes)
+        self._buf = (C.c_uint8 * max(1, self.nbytes)).from_address(p.value)
+        self._buf._owner = self              # ctypes array -> owner: the array is the base of every numpy view
+
+    @staticmethod
+    def make(lib, shape, dtype=np.uint8):
+        dt = np.dtype(dtype)
+        count = int(np.prod(shape))
+        h = HostArray(lib, count * dt.itemsize)
+        return np.frombuffer(h._buf, dtype=dt, count=count).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                self._lib.tbx_host_free(self._ptr)
+                self._ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
 class Engine:
     def __init__(self, game, n_envs=1, device=0, config=None, lib=None):
         self._lib = lib if lib is not None else load()
@@ -278,11 +320,12 @@ class Engine:
 
     # ------------------------------------------------------------------ agent-side preprocessing (fused wrapper stack)
     def agent_init(self, skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=False, fire_reset=False,
-                   noop_max=0, noop_seed=0, env_offset=0, stack_fill=0):
+                   noop_max=0, noop_seed=0, env_offset=0, stack_fill=0, new_plane=False):
         """stack_fill: what a reset leaves in the older stack slots -- 0 zeros (VecFrameStack), 1 the reset observation (the
-        per-env FrameStack of wrap_deepmind(frame_stack=True))."""
+        per-env FrameStack of wrap_deepmind(frame_stack=True)).  new_plane: the device also keeps every stack's newest plane
+        alone (TBX_BUF_AGENT_PLANE) -- what a host-side frame stack receives per step."""
         cfg = _abi.AgentConfig(int(skip), int(out_h), int(out_w), int(stack), int(bool(clip_reward)), int(bool(episodic_life)),
-                               int(bool(fire_reset)), int(noop_max), int(noop_seed), int(env_offset), int(stack_fill), 0)
+                               int(bool(fire_reset)), int(noop_max), int(noop_seed), int(env_offset), int(stack_fill), int(bool(new_plane)))
         self._check(self._lib.tbx_agent_init(self._h, C.byref(cfg)))
         self._agent_shape = (self.n_envs, int(out_h), int(out_w), int(stack))
 
@@ -330,6 +373,49 @@ class Engine:
         ended, ret, length = np.empty(n, np.uint8), np.empty(n, np.float32), np.empty(n, np.int32)
         self._check(self._lib.tbx_agent_episodes(self._h, _ptr(ended), _ptr(ret), _ptr(length)))
         return ended.astype(bool), ret, length
+
+    # ------------------------------------------------------------------ host delivery: step_async / step_wait
+    def host_array(self, shape, dtype=np.uint8):
+        """A numpy array over page-locked host memory of the engine's library (tbx_host_alloc): the destination of the
+        asynchronous copies of step_begin / agent_step_begin.  The memory lives as long as the array or any view of it."""
+        return HostArray.make(self._lib, shape, dtype)
+
+    def agent_step_begin(self, actions, reward=None, done=None, obs=None, plane=None, ep_done=None, ep_return=None, ep_length=None):
+        """tbx_agent_step_begin: queues actions -> device, the agent step and the copies of the requested outputs into the given
+        host arrays (C-contiguous, of the documented dtypes; page-locked ones from host_array() keep the call asynchronous);
+        returns at once.  agent_step_end() waits."""
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        if a.shape != (self.n_envs,):
+            raise ValueError("actions must have shape (%d,)" % self.n_envs)
+        out = _abi.AgentHostOut(*[_addr(x) for x in (reward, done, obs, plane, ep_done, ep_return, ep_length)])
+        self._host_keep = (a, reward, done, obs, plane, ep_done, ep_return, ep_length)     # alive until the step has ended
+        self._check(self._lib.tbx_agent_step_begin(self._h, _ptr(a), C.byref(out)))
+
+    def agent_step_end(self, tolerate_needs_reset=False):
+        rc = self._lib.tbx_agent_step_end(self._h)
+        self._host_keep = None
+        if not (tolerate_needs_reset and rc == _abi.E_NEEDS_RESET):
+            self._check(rc)
+
+    def agent_fetch(self, reward=None, done=None, obs=None, plane=None, ep_done=None, ep_return=None, ep_length=None):
+        """the current contents of the agent layer's output buffers (after agent_reset or a step), synchronous"""
+        out = _abi.AgentHostOut(*[_addr(x) for x in (reward, done, obs, plane, ep_done, ep_return, ep_length)])
+        self._check(self._lib.tbx_agent_fetch(self._h, C.byref(out)))
+
+    def step_begin(self, actions, auto_reset=False, reward=None, done=None, lives=None, score=None, frame=None, channels=3):
+        """tbx_step_begin: one frame for every env plus (frame given) the picture of the state it leaves, queued; step_end() waits.
+        reward / lives / score int32[N], done uint8[N], frame uint8[N, H, W, channels]."""
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        if a.shape != (self.n_envs,):
+            raise ValueError("actions must have shape (%d,)" % self.n_envs)
+        out = _abi.StepHostOut(_addr(reward), _addr(done), _addr(lives), _addr(score), _addr(frame), int(channels), 0)
+        self._host_keep = (a, reward, done, lives, score, frame)
+        self._check(self._lib.tbx_step_begin(self._h, _ptr(a), _abi.STEP_AUTO_RESET if auto_reset else 0, C.byref(out)))
+
+    def step_end(self):
+        rc = self._lib.tbx_step_end(self._h)
+        self._host_keep = None
+        self._check(rc)
 
     def agent_step_synthetic(self, action_seed, t, env_offset=0, stream=0):
         self._check(self._lib.tbx_agent_step_synthetic(self._h, int(action_seed), int(t), int(env_offset), C.c_void_p(int(stream))))

@@ -267,18 +267,30 @@ class MixedBatch:
     launches of a batch step overlap on the device.  Global env order: games in the order given, contiguous per game."""
 
     def __init__(self, games, n_per_game, device=0, seed_base=1234, engine_factory=None, global_offset=0):
+        """n_per_game: one size for every segment, or one size per game (BASELINE config 5's 32 768 envs per GPU are
+        10 923 + 10 923 + 10 922: `split_sizes(32768, 3)`)."""
         from .engine import Engine
         self.games = list(games)
-        self.n_per_game = int(n_per_game)
+        sizes = [int(n_per_game)] * len(self.games) if np.isscalar(n_per_game) else [int(v) for v in n_per_game]
+        if len(sizes) != len(self.games) or min(sizes) < 1:
+            raise ValueError("one positive segment size per game is needed")
+        self.sizes = sizes
+        self.n_per_game = sizes[0] if len(set(sizes)) == 1 else None
         make = engine_factory or (lambda game, n: Engine(game, n, device=device))
-        self.engines = [make(g, self.n_per_game) for g in self.games]
-        self.offsets = [global_offset + i * self.n_per_game for i in range(len(self.games))]
+        self.engines = [make(g, n) for g, n in zip(self.games, sizes)]
+        self.offsets = [global_offset + sum(sizes[:i]) for i in range(len(self.games))]
         for e, off in zip(self.engines, self.offsets):
             e.seed(seed_base + off)
             e.new_game()
-        self.n_envs = self.n_per_game * len(self.games)
+        self.n_envs = sum(sizes)
         self.streams = None
         self.gathering = False
+
+    @staticmethod
+    def split_sizes(n_envs, n_games):
+        """n_envs cut into n_games contiguous segments whose sizes differ by at most one (the first n_envs % n_games hold the
+        extra env) -- the same rule as shard_range"""
+        return [shard_range(n_envs, n_games, i)[1] - shard_range(n_envs, n_games, i)[0] for i in range(n_games)]
 
     def set_pipeline(self, value):
         """TBX_OPT_PIPELINE on every engine (those whose rasteriser reads live state ignore it): with three engines sharing one
