@@ -107,6 +107,13 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the step-only arm and the strong-scaling share probe")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2-5 beside the headline line (N = 1, Breakout)")
     ap.add_argument("--with-gather", action="store_true", help="run the RCCL record gather even at one rank (1-rank communicator)")
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "host"],
+                    help="transport of the record gather (TBX_OPT_GATHER_TRANSPORT): rccl = ncclAllGather over xGMI; host = staged through "
+                         "page-locked buffers and a POSIX shared-memory segment, one node, no librccl (SURVEY 8e's fallback) -- the line then "
+                         "says `rccl: null, gather: {transport: host}`")
+    ap.add_argument("--one-device", action="store_true",
+                    help="every rank uses device 0 (with --gather host: the whole N-process flow on a one-GPU box; RCCL refuses two ranks "
+                         "of one communicator on one device)")
     ap.add_argument("--allow-no-gather", action="store_true",
                     help="N > 1 only: if no RCCL communicator can be made, run without the per-step gather (file barrier) instead of failing")
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1, 2, 3], help="TBX_OPT_PIPELINE of the main arm (1 = engine's choice)")
@@ -281,7 +288,7 @@ def mixed_reading(args, world, rank, local_rank, envs, K, Wm, R, gather, cpu_sec
     mb.attach_streams([s.ptr for s in streams])
     if gather:
         with quiet_stdout():
-            mb.gather_init(rank, world, gather_every=args.gather_every)
+            mb.gather_init(rank, world, gather_every=args.gather_every, transport=GATHER_TRANSPORT)
     C = args.channels
     render = not args.no_render
     fused = render and args.loop != "pair" and C >= 3
@@ -329,7 +336,7 @@ def mixed_reading(args, world, rank, local_rank, envs, K, Wm, R, gather, cpu_sec
                              "algorithmic_bytes_per_step": fb,
                              "per_kernel": "profiles/ (rocprofv3 kernel trace of this command: the three rasterisers' own durations and "
                                            "whether they overlap)"} if render else None),
-               "rccl": ({"nranks": lead.gather_nranks(), "gather_bytes_per_step": 8 * mb.n_envs * world, "lib": lead.gather_library(),
+               "rccl": ({"transport": GATHER_TRANSPORT, "nranks": lead.gather_nranks(), "gather_bytes_per_step": 8 * mb.n_envs * world, "lib": lead.gather_library(),
                          "gather_every": lead.gather_every(), "communicators": len(games)} if gather else None)}
         if cpu_seconds:
             try:
@@ -732,20 +739,24 @@ FUSED_NOTE = ("tbx_render_step_synthetic: the rasteriser of frame t and the batc
               "in front of the rasteriser's, other records buffer); random-action rollouts only -- `serialised` is the two-launch loop")
 
 
+GATHER_TRANSPORT = "rccl"      # --gather
+
+
 def make_communicator(eng, rank, world, width, gather_every, tag):
     """tbx_gather_init over `world` ranks (id from rank 0 through the rendezvous file), K-step record ring if asked.  Returns the
     `rccl` object of the JSON line; raises when no communicator over `world` ranks comes out of it."""
     from toybox_amd import _abi
     from toybox_amd.parallel import exchange_unique_id, forget_unique_id
-    if os.environ.get("TBX_BENCH_NO_RCCL"):
+    if os.environ.get("TBX_BENCH_NO_RCCL") and GATHER_TRANSPORT == "rccl":
         raise RuntimeError("disabled by TBX_BENCH_NO_RCCL")
+    eng.set_option(_abi.OPT_GATHER_TRANSPORT, _abi.GATHER_HOST if GATHER_TRANSPORT == "host" else _abi.GATHER_RCCL)
     eng.set_option(_abi.OPT_GATHER_EVERY, max(1, gather_every))
     with quiet_stdout():
         uid = exchange_unique_id(rank, world, eng.gather_unique_id, tag=tag)
         eng.gather_init(world, rank, uid, records_per_rank=width)   # collective (ncclCommInitRank)
     forget_unique_id(rank, tag=tag)
     K = eng.gather_every()
-    rccl = {"nranks": eng.gather_nranks(), "records_per_rank": width, "gather_every": K,
+    rccl = {"transport": GATHER_TRANSPORT, "nranks": eng.gather_nranks(), "records_per_rank": width, "gather_every": K,
             "gather_bytes_per_collective": 8 * width * world * K, "gather_bytes_per_step": 8 * width * world, "lib": eng.gather_library()}
     if rccl["nranks"] != world:
         raise RuntimeError("the communicator spans %d ranks, not %d" % (rccl["nranks"], world))
@@ -864,9 +875,10 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
 
 
 def main():
-    global SETTLE
+    global SETTLE, GATHER_TRANSPORT
     args = parse()
     SETTLE = max(0, args.settle)
+    GATHER_TRANSPORT = args.gather
     if args.protocol == "reference":
         return bench_reference_protocol(args)
     if args.protocol == "agent":
@@ -888,7 +900,7 @@ def main():
         hip = HIP_MODULE
     else:
         from toybox_amd import hip
-    if os.environ.get("TBX_BENCH_ONE_DEVICE"):     # diagnostic: every rank on device 0 (exercises the N > 1 flow on a 1-GPU box)
+    if args.one_device or os.environ.get("TBX_BENCH_ONE_DEVICE"):     # every rank on device 0 (the N > 1 flow on a 1-GPU box)
         local_rank = 0
     hip.set_device(local_rank)
 
@@ -917,6 +929,7 @@ def main():
         bytes_per_step = 2 * S_GAME[game] + A_BYTES + O_BYTES + frame_bytes
         ms = rep["ms_per_step_median"]
         K_ring = r["rccl"]["gather_every"] if r["rccl"] else 1
+        host_gather = (r["rccl"] or {}).get("transport") == "host"
         out = {
             "metric": "env steps/sec (whole node), Breakout 64k-env batch" if game == "breakout" else "env steps/sec (whole node), %s" % game,
             "value": n_total / (ms * 1e-3),
@@ -938,15 +951,19 @@ def main():
                             % (game, "step + %dx%dx%d uint8 frame render" % (H, W, C) if render else "step-only",
                                args.envs, "per GPU" if args.scaling == "weak" else "in total", args.preroll, SETTLE),
                 "envs_per_gpu": n, "envs_total": n_total, "frame_hwc": [H, W, C] if render else None,
-                "parallelism": ("env-sharded x%d, RCCL all-gather of 8 B/env records behind the C-ABI (tbx_gather), %s"
-                                % (world, gather_overlap_note(K_ring, fused)))
+                "parallelism": (("env-sharded x%d, HOST-STAGED all-gather of 8 B/env records behind the C-ABI (tbx_gather over a POSIX "
+                                 "shared-memory segment, no RCCL: every collective blocks the calling thread until the step has finished "
+                                 "and all ranks have exchanged), one per %d step(s)" % (world, K_ring)) if host_gather else
+                                ("env-sharded x%d, RCCL all-gather of 8 B/env records behind the C-ABI (tbx_gather), %s"
+                                 % (world, gather_overlap_note(K_ring, fused))))
                                if gather else ("env-sharded x%d, no collective (%s)" % (world, r["gather_note"])) if r["gather_note"] else "single GPU",
                 "algorithmic_bytes_per_env_step": bytes_per_step,
             },
             "loop": {"form": "fused" if fused else "pair", "what": FUSED_NOTE if fused else "tbx_step_synthetic ; tbx_render_device, two launches per frame"},
             "pipeline": {"option": args.pipeline, "resolved": mode, "what": PIPELINE_NOTE.get(mode),
                          "applies_to": "the two-launch loop form only; see `serialised`"},
-            "rccl": r["rccl"],
+            "rccl": r["rccl"] if (r["rccl"] or {}).get("transport") == "rccl" else None,
+            "gather": r["rccl"],
         }
         if render:
             out["roofline"] = roofline_object(game, n, frame_bytes, C, fused, mode, r["launch"])
@@ -959,7 +976,8 @@ def main():
             oms = other["rep"]["ms_per_step_median"]
             key = "weak" if args.scaling == "strong" else "strong"
             out[key] = {"value": other["n_total"] / (oms * 1e-3), "unit": "env-steps/s", "ms_per_step": oms, "repeats": other["rep"],
-                        "envs_per_gpu": other["n"], "envs_total": other["n_total"], "rccl": other["rccl"],
+                        "envs_per_gpu": other["n"], "envs_total": other["n_total"],
+                        "rccl": other["rccl"] if (other["rccl"] or {}).get("transport") == "rccl" else None, "gather": other["rccl"],
                         "loop": "fused" if other["fused"] else "pair",
                         "note": "the other reading of the metric, measured in the same invocation with its own communicator"}
             s_, w_ = (out, out[key]) if args.scaling == "strong" else (out[key], out)
@@ -1091,6 +1109,7 @@ def strong_share_probe(args, game, C, n_single, single_value, single_pair_value)
         eng.seed(SEED_BASE)
         eng.new_game()
         eng.set_option(_abi.OPT_GATHER_EVERY, max(1, every))
+        eng.set_option(_abi.OPT_GATHER_TRANSPORT, _abi.GATHER_HOST if GATHER_TRANSPORT == "host" else _abi.GATHER_RCCL)
         with quiet_stdout():
             eng.gather_init(1, 0, eng.gather_unique_id())
         st = hip.Stream()

@@ -465,10 +465,16 @@ int tbx_query(tbx_engine* engine, int env, int query_id, const int32_t* args, in
  * args: up to TBX_EDIT_MAX_ARGS doubles, the same for every env (per_env = 0) or one row per env, args[N][n_args]
  * (per_env = 1: a sweep in which env i gets its own column, tile, timer ...).  The "_device" forms take device pointers for
  * mask / per-env args / out and are asynchronous on `stream`; args with per_env = 0 are always a host pointer.
- * Helpers of the reference that only sample (get_random_tile, get_random_track_position, set_player_random_start's draw,
- * get_random_dir_for_tile) or take a Python predicate (find_brick, filter_tiles) have no device form: the deterministic
- * half of each is here (TBX_EDIT_AMI_PLAYER_TILE, TBX_QUERY_AMI_COUNT_TILES, TBX_QUERY_BRK_COLUMN ...).  Config-level
- * helpers (set_jitter, add_row) go through tbx_set_config like the reference's dirty_config path. */
+ * Helpers that take a Python predicate have a MASK form here: find_brick(pred) -> TBX_QUERY_BRK_FIND_BRICK over a bit mask of
+ * brick indices (the host evaluates the predicate once over the brick table, whose attributes other than `alive` are the same
+ * in every env) plus the wanted `alive`; filter_tiles(pred) for predicates on the tag -> TBX_QUERY_AMI_TILES_MASK over a mask
+ * of tags.  Helpers that sample with Python's `random` (get_random_tile, get_random_track_position, set_player_random_start,
+ * get_random_dir_for_tile: amidar.py:360-399,541-583) have COUNTER-RNG forms: draw number k of env e is
+ * splitmix64(seed ^ (e_global << 32) ^ k) -- the rule of tbx_step_synthetic -- taken modulo the number of candidates, and
+ * the candidates are exactly the elements the reference's predicate accepts, in the order its loops visit them (tiles row by
+ * row, directions Up, Down, Left, Right).  Not `random`-compatible (the reference's draws depend on Python's global
+ * Mersenne Twister and on rejection sampling); uniform over the same candidate set, reproducible, and independent of the batch
+ * layout.  Config-level helpers (set_jitter, add_row) go through tbx_set_config like the reference's dirty_config path. */
 #define TBX_EDIT_MAX_ARGS 16
 /* every game -- `intervention.game.lives = v` (interventions/space_invaders.py:199, test_breakout_interventions.py) */
 #define TBX_EDIT_SET_LIVES          1   /* {lives} */
@@ -487,6 +493,9 @@ int tbx_query(tbx_engine* engine, int env, int query_id, const int32_t* args, in
 #define TBX_EDIT_AMI_TILE          22   /* {tx, ty, tag}: set_tile_tag :476-478 */
 #define TBX_EDIT_AMI_ENEMY_AI      23   /* {enemy, the 14 fields of tbx_amidar_ai_t}: set_enemy_protocol :418-471 */
 #define TBX_EDIT_AMI_PLAYER_TILE   24   /* {tx, ty}: player.position = tile_to_world(tile), the write of set_player_random_start :531-538 */
+#define TBX_EDIT_AMI_PLAYER_RANDOM_START 25  /* {seed, draw, env_offset, min_enemy_distance}: set_player_random_start :541-548 -- the player goes
+                                              * to the tile TBX_QUERY_AMI_RANDOM_TILE {seed, draw, env_offset, 15, min_enemy_distance} names
+                                              * (ANY tag, as the reference draws it; no candidate: the env is left alone) */
 /* SpaceInvaders (interventions/space_invaders.py) */
 #define TBX_EDIT_SI_UFO_APPEARANCE 30   /* {appearance_counter}: remove_mothership :172-173 (-1) */
 
@@ -499,6 +508,9 @@ int tbx_query(tbx_engine* engine, int env, int query_id, const int32_t* args, in
 #define TBX_QUERY_BRK_FIND_CHANNEL     116  /* {n_columns} -> 1  first channel column or -1 (find_channel :404-410) */
 #define TBX_QUERY_BRK_PADDLE           117  /* -> 4  position x, y, velocity x, y (:379-383) */
 #define TBX_QUERY_BRK_BALLS            118  /* -> 17 n_balls, x[4], y[4], vx[4], vy[4] (:365-377) */
+#define TBX_QUERY_BRK_FIND_BRICK       119  /* {alive (-1: either), m0 .. m7} -> 1  index of the first brick, in brick order, whose bit is set in the
+                                             * mask (brick i = bit i % 32 of m[i / 32], each m an integer < 2^32) and whose alive flag is the one
+                                             * asked for, else -1 (find_brick :400-404 for predicates the host has turned into a mask) */
 #define TBX_QUERY_AMI_MODE             120  /* -> 2  jump_timer, chase_timer (get_regular / jump / chase_mode :385-395) */
 #define TBX_QUERY_AMI_ANY_CAUGHT       121  /* -> 1  any_enemy_caught :397-399 */
 #define TBX_QUERY_AMI_TILE             122  /* {tx, ty} -> 1  tag (get_tile_by_pos :480-481, is_tile_walkable :472-474) */
@@ -510,6 +522,14 @@ int tbx_query(tbx_engine* engine, int env, int query_id, const int32_t* args, in
 #define TBX_QUERY_AMI_PLAYER_ON_PAINTED 128 /* -> 1  player_on_painted :586-589 */
 #define TBX_QUERY_AMI_PLAYER_NEAR_UNPAINTED 129 /* {radius} -> 1  player_near_unpainted :592-603 */
 #define TBX_QUERY_SI_SHIP              130  /* -> 8  x, y, w, h, speed, alive, death_counter, death_hit_1 (get_player :175-176) */
+#define TBX_QUERY_AMI_TILES_MASK       131  /* {tag_mask} -> 32  filter_tiles(pred on the tag) :494-499: [ty] = bit tx set where tile (tx, ty)'s tag is in
+                                             * tag_mask (bit t = tag t), ty = 0 .. 30; [31] = their number */
+#define TBX_QUERY_AMI_RANDOM_TILE      133  /* {seed, draw, env_offset, tag_mask, min_enemy_distance} -> 4  tx, ty, tag, number of candidates: the
+                                             * (r mod count)-th, row by row, of the tiles whose tag is in tag_mask and -- min_enemy_distance > 0 --
+                                             * for which NOT every enemy is nearer than that (the predicate of set_player_random_start :543-546
+                                             * as written); get_random_tile :360-378, get_random_track_position :380-386 (tag_mask 14); -1 x 3, 0 without a candidate */
+#define TBX_QUERY_AMI_RANDOM_DIR       134  /* {seed, draw, env_offset, tx, ty} -> 2  direction (TBX_DIR_*) drawn among those of Up, Down, Left, Right whose
+                                             * neighbour tile is walkable, and their number (get_random_dir_for_tile :550-583); -1, 0 if none */
 int tbx_reduce_width(int game, int query);   /* doubles per env, or TBX_E_INVALID */
 int tbx_edit(tbx_engine* engine, int op, const double* args_host, int n_args, int per_env, const uint8_t* mask_host);
 int tbx_edit_device(tbx_engine* engine, int op, const double* args, int n_args, int per_env, const uint8_t* mask_dev, void* stream);
@@ -628,6 +648,14 @@ typedef struct tbx_step_host_out {
 } tbx_step_host_out_t;
 int tbx_step_begin(tbx_engine* engine, const int32_t* ale_actions_host, uint32_t flags, const tbx_step_host_out_t* out);
 int tbx_step_end(tbx_engine* engine);
+/* The receiving side's frame stack as host code: VecFrameStack.step_wait (vec_frame_stack.py:17-27) over channel-last stacks
+ * uint8[n][px][stack] -- dst = src with every pixel's channels rolled by one and `plane` (uint8[n][px], what tbx_agent_host_out_t::
+ * plane received) as the newest channel; the stack of an env whose `done` byte is set starts anew: zeros in the older channels
+ * (fill = 0, VecFrameStack :21-23) or the new plane in every channel (fill = 1, FrameStack.reset inside the env,
+ * atari_wrappers.py:257-261).  done == NULL: no env is done; reset != 0: every env is (VecFrameStack.reset :29-33).  dst may
+ * be src.  Plain host loops on `threads` threads (<= 0: the usable cores, at most 16); no engine, no device. */
+int tbx_host_stack_push(uint8_t* dst, const uint8_t* src, const uint8_t* plane, const uint8_t* done, int reset,
+                        int n, int px, int stack, int fill, int threads);
 
 /* ------------------------------------------------------------------ multi-GPU record gather
  * One process per GPU, one engine per process = one contiguous shard of the env batch; envs never interact, so the only
@@ -717,7 +745,14 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  * K * records_per_rank records; the following K steps fill a second ring meanwhile.  Gathered layout
  * [nranks][K][records_per_rank] (TBX_BUF_GATHERED, tbx_gather_host).  The pipelined mode is off while a ring is in force. */
 #define TBX_OPT_GATHER_EVERY  5
-#define TBX_OPT_COUNT         6
+/* how the record gather travels, read by tbx_gather_init: 0 (default) = RCCL (ncclAllGather over xGMI); 1 = host-staged over a
+ * POSIX shared-memory segment named after the id -- the ranks of ONE node, no librccl needed ("a host-staged
+ * gather is the fallback if RCCL is missing").  Same calls, same gathered layout, same ordering rules; but every collective
+ * blocks the calling thread until the step that wrote the records has finished and all ranks have exchanged them.  It also lets
+ * several ranks share ONE device (RCCL refuses two ranks of a communicator on one GPU): `bench.py --gather host --one-device`
+ * walks the whole N-process flow on a one-GPU box.  tbx_gather_library() names the transport in use. */
+#define TBX_OPT_GATHER_TRANSPORT 6
+#define TBX_OPT_COUNT         7
 /* read-only (tbx_get_option): what TBX_OPT_PIPELINE resolves to on this engine right now -- 0, 2 or 3 */
 #define TBX_OPT_PIPELINE_ACTIVE 100
 /* read-only: 1 while the rasteriser reads step-written render records (Breakout with the canonical wall, SpaceInvaders with

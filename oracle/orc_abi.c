@@ -617,8 +617,18 @@ int tbx_reduce_width(int game, int query)
     case TBX_QUERY_AMI_ENEMY_DISTANCES: case TBX_QUERY_AMI_PLAYER_ENEMY_DISTANCES: return game == TBX_GAME_AMIDAR ? TBX_AMI_MAX_ENEMIES : TBX_E_INVALID;
     case TBX_QUERY_AMI_PLAYER_TILE: return game == TBX_GAME_AMIDAR ? 3 : TBX_E_INVALID;
     case TBX_QUERY_SI_SHIP: return game == TBX_GAME_SPACE_INVADERS ? 8 : TBX_E_INVALID;
+    case TBX_QUERY_BRK_FIND_BRICK: return game == TBX_GAME_BREAKOUT ? 1 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_TILES_MASK: return game == TBX_GAME_AMIDAR ? 32 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_RANDOM_TILE: return game == TBX_GAME_AMIDAR ? 4 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_RANDOM_DIR: return game == TBX_GAME_AMIDAR ? 2 : TBX_E_INVALID;
     default: return TBX_E_INVALID;
     }
+}
+
+static uint32_t arg_u(const double* a, int n, int i)
+{
+    const double x = i < n ? a[i] : 0.0;
+    return x >= 4294967295.0 ? 0xFFFFFFFFu : x > 0.0 ? (uint32_t)x : 0u;
 }
 
 static int arg_i(const double* a, int n, int i)
@@ -678,6 +688,15 @@ static int brk_reduce_one(const tbx_breakout_config_t* cfg, const tbx_breakout_s
     switch (q) {
     case TBX_QUERY_BRK_BRICKS_REMAINING: { int c = 0; for (int j = 0; j < st->n_bricks; j++) c += st->bricks[j].alive != 0; o[0] = c; return 0; }
     case TBX_QUERY_BRK_NUM_BRICKS: o[0] = st->n_bricks; return 0;
+    case TBX_QUERY_BRK_FIND_BRICK: {                          /* find_brick :400-404: `for i, b in enumerate(bricks): if pred(b): return i` */
+        const int want = arg_i(a, n, 0);
+        o[0] = -1;
+        for (int j = 0; j < st->n_bricks; j++) {
+            const int in_mask = (arg_u(a, n, 1 + j / 32) >> (j % 32)) & 1u;
+            if (in_mask && (want < 0 || (st->bricks[j].alive != 0) == (want != 0))) { o[0] = j; break; }
+        }
+        return 0;
+    }
     case TBX_QUERY_BRK_COLUMN: case TBX_QUERY_BRK_ROW: {
         int m = 0;
         for (int j = 0; j < st->n_bricks && m < width; j++)
@@ -706,9 +725,49 @@ static int brk_reduce_one(const tbx_breakout_config_t* cfg, const tbx_breakout_s
     }
 }
 
-static int ami_edit_one(tbx_amidar_state_t* st, int op, const double* a, int n)
+static int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+/* get_random_tile(pred) (interventions/amidar.py:360-378) with the draw replaced by the counter rule of toybox_amd.h: the list
+ * filter_tiles(pred) would return -- `for row in tiles: for tile in row: if pred(tile)` -- and element (r mod len) of it.
+ * pred: tag in tag_mask, and (min_dist > 0) set_player_random_start's within_min_manhattan :543-546 as written:
+ * `not all(d < min_enemy_distance for d in enemy distances)`.  Returns the number of candidates. */
+static int ami_pick_tile(const tbx_amidar_state_t* st, int env_global, uint32_t seed, uint32_t draw, uint32_t tag_mask, int min_dist,
+                         int* tx_out, int* ty_out)
+{
+    static __thread int cand[TBX_AMI_BOARD_H * TBX_AMI_BOARD_W];
+    int count = 0;
+    for (int ty = 0; ty < TBX_AMI_BOARD_H; ty++)
+        for (int tx = 0; tx < TBX_AMI_BOARD_W; tx++) {
+            if (!((tag_mask >> st->tiles[ty][tx]) & 1u)) continue;
+            if (min_dist > 0) {
+                int all_near = 1;
+                for (int i = 0; i < st->n_enemies; i++) {
+                    const int ex = floor_div(st->enemies[i].x, TBX_AMI_TILE_WX), ey = floor_div(st->enemies[i].y, TBX_AMI_TILE_WY);
+                    if (!(abs(ex - tx) + abs(ey - ty) < min_dist)) all_near = 0;
+                }
+                if (all_near) continue;
+            }
+            cand[count++] = ty * TBX_AMI_BOARD_W + tx;
+        }
+    *tx_out = *ty_out = -1;
+    if (count) {
+        const uint64_t r = orc_splitmix64((uint64_t)seed ^ ((uint64_t)(uint32_t)env_global << 32) ^ (uint64_t)draw);
+        const int c = cand[r % (uint64_t)count];
+        *tx_out = c % TBX_AMI_BOARD_W; *ty_out = c / TBX_AMI_BOARD_W;
+    }
+    return count;
+}
+
+static int ami_edit_one(tbx_amidar_state_t* st, int op, const double* a, int n, int env)
 {
     switch (op) {
+    case TBX_EDIT_AMI_PLAYER_RANDOM_START: {
+        int tx, ty;
+        if (ami_pick_tile(st, (int)(arg_u(a, n, 2) + (uint32_t)env), arg_u(a, n, 0), arg_u(a, n, 1), 0xFu, arg_i(a, n, 3), &tx, &ty)) {
+            st->player.x = tx * TBX_AMI_TILE_WX; st->player.y = ty * TBX_AMI_TILE_WY;     /* tile_to_worldpoint(pos) */
+        }
+        return 0;
+    }
     case TBX_EDIT_SET_LIVES: st->lives = arg_i(a, n, 0); return 0;
     case TBX_EDIT_SET_SCORE: st->score = arg_i(a, n, 0); return 0;
     case TBX_EDIT_SET_LEVEL: st->level = arg_i(a, n, 0); return 0;
@@ -737,7 +796,6 @@ static int ami_edit_one(tbx_amidar_state_t* st, int op, const double* a, int n)
     }
 }
 
-static int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 static int ami_tag(const tbx_amidar_state_t* st, int tx, int ty)
 {
     return (tx < 0 || ty < 0 || tx >= TBX_AMI_BOARD_W || ty >= TBX_AMI_BOARD_H) ? -1 : st->tiles[ty][tx];
@@ -751,10 +809,41 @@ static void ami_distances(const tbx_amidar_state_t* st, int tx, int ty, double* 
     }
 }
 
-static int ami_reduce_one(const tbx_amidar_state_t* st, int q, const double* a, int n, double* o)
+static int ami_reduce_one(const tbx_amidar_state_t* st, int q, const double* a, int n, double* o, int env)
 {
     const int ptx = floor_div(st->player.x, TBX_AMI_TILE_WX), pty = floor_div(st->player.y, TBX_AMI_TILE_WY);
     switch (q) {
+    case TBX_QUERY_AMI_TILES_MASK: {                         /* filter_tiles(lambda t: t.tag in ...) as one bitmap row per board row */
+        const uint32_t tm = arg_u(a, n, 0);
+        int c = 0;
+        for (int ty = 0; ty < TBX_AMI_BOARD_H; ty++) {
+            uint32_t bits = 0;
+            for (int tx = 0; tx < TBX_AMI_BOARD_W; tx++)
+                if ((tm >> st->tiles[ty][tx]) & 1u) { bits |= 1u << tx; c++; }
+            o[ty] = bits;
+        }
+        o[31] = c;
+        return 0;
+    }
+    case TBX_QUERY_AMI_RANDOM_TILE: {
+        int tx, ty;
+        const int c = ami_pick_tile(st, (int)(arg_u(a, n, 2) + (uint32_t)env), arg_u(a, n, 0), arg_u(a, n, 1), arg_u(a, n, 3), arg_i(a, n, 4), &tx, &ty);
+        o[0] = tx; o[1] = ty; o[2] = c ? st->tiles[ty][tx] : -1; o[3] = c;
+        return 0;
+    }
+    case TBX_QUERY_AMI_RANDOM_DIR: {                         /* get_random_dir_for_tile :550-583: a direction whose neighbour is walkable */
+        const int tx = arg_i(a, n, 3), ty = arg_i(a, n, 4);
+        const int dx[4] = {0, 0, -1, 1}, dy[4] = {-1, 1, 0, 0};           /* Up, Down, Left, Right */
+        int dirs[4], nd = 0;
+        for (int k = 0; k < 4; k++)
+            if (ami_tag(st, tx + dx[k], ty + dy[k]) > TBX_TILE_EMPTY) dirs[nd++] = k;
+        o[0] = -1; o[1] = nd;
+        if (nd) {
+            const uint64_t r = orc_splitmix64((uint64_t)arg_u(a, n, 0) ^ ((uint64_t)(arg_u(a, n, 2) + (uint32_t)env) << 32) ^ (uint64_t)arg_u(a, n, 1));
+            o[0] = dirs[r % (uint64_t)nd];
+        }
+        return 0;
+    }
     case TBX_QUERY_AMI_MODE: o[0] = st->jump_timer; o[1] = st->chase_timer; return 0;
     case TBX_QUERY_AMI_ANY_CAUGHT: { int any = 0; for (int i = 0; i < st->n_enemies; i++) any |= st->enemies[i].caught != 0; o[0] = any; return 0; }
     case TBX_QUERY_AMI_TILE: o[0] = ami_tag(st, arg_i(a, n, 0), arg_i(a, n, 1)); return 0;
@@ -807,7 +896,7 @@ int tbx_edit_device(tbx_engine* e, int op, const double* args, int n_args, int p
         void* st = e->states + e->ssz * (size_t)i;
         int rc = -1;
         if (e->game == TBX_GAME_BREAKOUT) rc = brk_edit_one((const tbx_breakout_config_t*)e->cfg, (tbx_breakout_state_t*)st, op, a, n_args);
-        else if (e->game == TBX_GAME_AMIDAR) rc = ami_edit_one((tbx_amidar_state_t*)st, op, a, n_args);
+        else if (e->game == TBX_GAME_AMIDAR) rc = ami_edit_one((tbx_amidar_state_t*)st, op, a, n_args, i);
         else if (e->game == TBX_GAME_SPACE_INVADERS) rc = si_edit_one((tbx_si_state_t*)st, op, a, n_args);
         if (rc) return fail(e, TBX_E_INVALID, "unknown edit for this game");
     }
@@ -833,7 +922,7 @@ int tbx_reduce_device(tbx_engine* e, int query, const double* args, int n_args, 
         double* o = out + (size_t)i * width;
         int rc = -1;
         if (e->game == TBX_GAME_BREAKOUT) rc = brk_reduce_one((const tbx_breakout_config_t*)e->cfg, (const tbx_breakout_state_t*)st, query, a, n_args, o, width);
-        else if (e->game == TBX_GAME_AMIDAR) rc = ami_reduce_one((const tbx_amidar_state_t*)st, query, a, n_args, o);
+        else if (e->game == TBX_GAME_AMIDAR) rc = ami_reduce_one((const tbx_amidar_state_t*)st, query, a, n_args, o, i);
         else if (e->game == TBX_GAME_SPACE_INVADERS && query == TBX_QUERY_SI_SHIP) {
             const tbx_si_state_t* s = (const tbx_si_state_t*)st;
             o[0] = s->ship_x; o[1] = s->ship_y; o[2] = s->ship_w; o[3] = s->ship_h; o[4] = s->ship_speed;
@@ -1003,7 +1092,7 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout)
 /* launch-time choices of the device engine: stored and reported, without effect on a scalar CPU restatement */
 int tbx_set_option(tbx_engine* e, int option, int value)
 {
-    static const int hi[TBX_OPT_COUNT] = {3, 2, 64, 1, 1, 64};
+    static const int hi[TBX_OPT_COUNT] = {3, 2, 64, 1, 1, 64, 1};
     if (!e) return TBX_E_INVALID;
     if (option < 0 || option >= TBX_OPT_COUNT) return fail(e, TBX_E_INVALID, "unknown option");
     if (value < (option == TBX_OPT_GATHER_EVERY ? 1 : 0) || value > hi[option]) return fail(e, TBX_E_INVALID, "option value out of range");
@@ -1480,4 +1569,24 @@ int tbx_step_end(tbx_engine* e)
     if (!e->host_pending) return fail(e, TBX_E_INVALID, "tbx_step_end without tbx_step_begin");
     e->host_pending = 0;
     return take_action_error(e);
+}
+
+/* VecFrameStack.step_wait / .reset on the host (vec_frame_stack.py:17-33), pixel by pixel as the Python's np.roll + slice writes
+ * spell it; `threads` is ignored */
+int tbx_host_stack_push(uint8_t* dst, const uint8_t* src, const uint8_t* plane, const uint8_t* done, int reset, int n, int px, int stack,
+                        int fill, int threads)
+{
+    (void)threads;
+    if (!dst || !src || !plane || n < 0 || px < 1 || stack < 1 || stack > 16 || fill < 0 || fill > 1) return TBX_E_INVALID;
+    for (int i = 0; i < n; i++) {
+        const int fresh = reset || (done && done[i]);
+        for (int k = 0; k < px; k++) {
+            uint8_t* d = dst + ((size_t)i * px + k) * stack;
+            const uint8_t* s = src + ((size_t)i * px + k) * stack;
+            const uint8_t v = plane[(size_t)i * px + k];
+            for (int c = 0; c + 1 < stack; c++) d[c] = fresh ? (fill ? v : (uint8_t)0) : s[c + 1];   /* (dst may be src: ascending c) */
+            d[stack - 1] = v;
+        }
+    }
+    return TBX_OK;
 }

@@ -10,7 +10,7 @@ import numpy as np
 
 import ctoybox
 from ctoybox import Toybox
-from support import synthetic_actions
+from support import splitmix64, synthetic_actions
 from toybox.interventions import amidar as ref_ami
 from toybox.interventions.amidar import AmidarIntervention
 from toybox.interventions.breakout import BreakoutIntervention
@@ -53,13 +53,32 @@ def breakout():
         q = dict(remaining=bi.num_bricks_remaining(), bricks=bi.num_bricks(), rows=bi.num_rows(), columns=bi.num_columns(),
                  count=bi.channel_count(), find=bi.find_channel(), col=bi.get_column(cols), is_chan=bi.is_channel(cols),
                  ppos=bi.get_paddle_position(), pvel=bi.get_paddle_velocity(), bpos=bi.get_ball_position(), bvel=bi.get_ball_velocity())
+        # find_brick (:400-404): predicates over the static attributes, evaluated once on the host, + the per-env alive flag
+        preds = {"row2_right": lambda b: b.row == 2 and b.col >= 5, "cheap": lambda b: b.points == 1, "red": lambda b: b.color.r > 150,
+                 "none": lambda b: b.row > 99}
+        q["find_alive"] = {k: bi.find_brick(p, alive=True) for k, p in preds.items()}
+        q["find_dead"] = {k: bi.find_brick(p, alive=False) for k, p in preds.items()}
+        q["find_any"] = {k: bi.find_brick(p) for k, p in preds.items()}
+        q["find_mask"] = bi.find_brick(np.arange(108) % 7 == 3, alive=True)
         bi.add_channel(cols)
         bi.fill_column((cols + 1) % 18)
         bi.clear_board(envs=np.arange(n) == 4)
+
+    def ref_find(iv, pred):
+        try:
+            return iv.find_brick(pred)[0]
+        except ValueError:
+            return -1
     for i in range(n):
         tb = Toybox("breakout")
         tb.write_state_json(before[i])
         with BreakoutIntervention(tb) as iv:
+            for k, p in preds.items():
+                assert ref_find(iv, lambda b, p=p: p(b) and b.alive) == q["find_alive"][k][i], (i, k)
+                assert ref_find(iv, lambda b, p=p: p(b) and not b.alive) == q["find_dead"][k][i], (i, k)
+                assert ref_find(iv, p) == q["find_any"][k][i], (i, k)
+            idx = {id(b): j for j, b in enumerate(iv.game.bricks)}
+            assert ref_find(iv, lambda b: idx[id(b)] % 7 == 3 and b.alive) == q["find_mask"][i]
             assert iv.num_bricks_remaining() == q["remaining"][i] and iv.num_bricks() == q["bricks"][i]
             assert iv.num_rows() == q["rows"] and iv.num_columns() == q["columns"][i]
             assert iv.channel_count() == q["count"][i], (i, iv.channel_count(), q["count"][i])
@@ -97,6 +116,14 @@ def amidar():
                  count={t: bi.count_tiles(t) for t in tags}, dist={p: bi.enemy_distances_from_tile(*p) for p in probe},
                  ptile=bi.player_tile(), pdist=bi.player_enemy_distances(), painted=bi.player_on_painted(),
                  near={r: bi.player_near_unpainted(r) for r in (2, 5)})
+        # the mask / counter-RNG forms of the predicate- and `random`-driven helpers
+        walk_pred = lambda tag: tag != "Empty"
+        q["filter"] = {"walk": bi.filter_tiles(walk_pred), "painted": bi.filter_tiles("Painted"), "all": bi.filter_tiles()}
+        q["fcount"] = bi.count_filtered_tiles(["Painted", "ChaseMarker"])
+        q["rtile"] = {k: bi.get_random_tile(walk_pred, seed=77, draw=k, env_offset=1000) for k in range(3)}
+        q["rtile_far"] = bi.get_random_tile(seed=5, draw=1, min_enemy_distance=9)
+        q["rtrack"] = bi.get_random_track_position(seed=77, draw=0, env_offset=1000)
+        q["rdir"] = {p: bi.get_random_dir_for_tile(*p, seed=3, draw=2) for p in probe}
         bi.set_mode("regular", envs=[1])
         bi.set_mode("jump", set_time=33, envs=[0, 5])
         bi.set_mode("chase", envs=[6])
@@ -125,6 +152,43 @@ def amidar():
             assert iv.player_on_painted() == bool(q["painted"][i])
             for r in (2, 5):
                 assert iv.player_near_unpainted(r) == bool(q["near"][r][i]), (i, r)
+            # filter_tiles(pred) in the reference's order; the drawn tile is element (r mod len) of that list
+            def where(tiles):
+                return [(iv.tile_to_tilepoint(t).tx, iv.tile_to_tilepoint(t).ty) for t in tiles]
+            walk = where(iv.filter_tiles(lambda t: t.tag != "Empty"))
+            assert walk == [(int(x), int(y)) for y, x in np.argwhere(q["filter"]["walk"][i])]
+            assert len(iv.filter_tiles(lambda t: t.tag == "Painted")) == int(q["filter"]["painted"][i].sum())
+            assert q["filter"]["all"][i].all() and len(iv.filter_tiles()) == q["filter"]["all"][i].size
+            assert len(iv.filter_tiles(lambda t: t.tag in ("Painted", "ChaseMarker"))) == q["fcount"][i]
+            for k in range(3):
+                tx, ty, tag, cnt = (v[i] for v in q["rtile"][k])
+                r = int(splitmix64(77 ^ ((1000 + i) << 32) ^ k))
+                assert cnt == len(walk) and (tx, ty) == walk[r % len(walk)] and tag == iv.get_tile_by_pos(tx, ty).tag
+                # the reference's own get_random_tile, its two randint draws scripted to land on that tile: accepted at once
+                draws = iter([int(ty), int(tx)])
+                ref_ami.random.randint = lambda a, b: next(draws)
+                got = iv.get_random_tile(lambda t: t.tag != "Empty")
+                assert got is iv.get_tile_by_pos(tx, ty)
+            draws = iter([int(q["rtile"][0][1][i]), int(q["rtile"][0][0][i])])
+            ref_ami.random.randint = lambda a, b: next(draws)
+            wp = iv.get_random_track_position()
+            assert (wp.x, wp.y) == (q["rtrack"][0][i], q["rtrack"][1][i])
+            # set_player_random_start's predicate, as written: not all enemies nearer than the minimum
+            def within(t, m=9):
+                return not all(d < m for d in iv.enemy_distances_from_tile(t))
+            far = where(iv.filter_tiles(within))
+            tx, ty, _, cnt = (v[i] for v in q["rtile_far"])
+            assert cnt == len(far) and (tx, ty) == far[int(splitmix64(5 ^ (i << 32) ^ 1)) % len(far)]
+            # get_random_dir_for_tile cannot be called (it reads tile.tx, which the reference's Tile does not have): its rule --
+            # a direction whose neighbour is walkable -- against is_tile_walkable of the reference
+            for p in probe:
+                ok = []
+                for name, (dx, dy) in (("Up", (0, -1)), ("Down", (0, 1)), ("Left", (-1, 0)), ("Right", (1, 0))):
+                    x, y = p[0] + dx, p[1] + dy
+                    if 0 <= x < 32 and 0 <= y < 31 and iv.is_tile_walkable(iv.get_tile_by_pos(x, y)):
+                        ok.append(name)
+                want = ok[int(splitmix64(3 ^ (i << 32) ^ 2)) % len(ok)] if ok else None
+                assert q["rdir"][p][i] == want, (i, p, ok)
             # the same edits through the reference's own methods
             if i == 1:
                 iv.set_mode("regular")
@@ -150,6 +214,23 @@ def amidar():
         got, want = tb.to_state_json(), env_json(e, i)
         got["board"]["junctions"], want["board"]["junctions"] = sorted(got["board"]["junctions"]), sorted(want["board"]["junctions"])
         same_json(got, want, "amidar env %d after the edits" % i)
+    # set_player_random_start (:541-548): the batched edit, then the reference's method with its draws scripted to the tile the
+    # counter rule chose for that env -- the reference must accept it at once and leave the same state
+    before = [env_json(e, i) for i in range(n)]
+    with BatchIntervention(e) as bi:
+        chosen = bi.get_random_tile(seed=11, draw=4, env_offset=50, min_enemy_distance=5)
+        bi.set_player_random_start(5, seed=11, draw=4, env_offset=50, envs=np.arange(n) != 2)
+    for i in range(n):
+        tb = Toybox("amidar")
+        tb.write_state_json(before[i])
+        if i != 2:
+            with AmidarIntervention(tb) as iv:
+                draws = iter([int(chosen[1][i]), int(chosen[0][i])])
+                ref_ami.random.randint = lambda a, b: next(draws)
+                iv.set_player_random_start(5)
+        got, want = tb.to_state_json(), env_json(e, i)
+        got["board"]["junctions"], want["board"]["junctions"] = sorted(got["board"]["junctions"]), sorted(want["board"]["junctions"])
+        same_json(got, want, "amidar env %d after set_player_random_start" % i)
     print("amidar ok")
 
 

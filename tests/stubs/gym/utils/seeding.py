@@ -12,11 +12,20 @@ def hash_seed(seed=None, max_bytes=8):
     return int.from_bytes(digest[:max_bytes], "little")
 
 
+def _int_list_from_bigint(bigint):
+    if bigint == 0:
+        return [0]
+    ints = []
+    while bigint > 0:
+        bigint, mod = divmod(bigint, 2 ** 32)
+        ints.append(mod)
+    return ints
+
+
 def np_random(seed=None):
     if seed is None:
-        seed = int.from_bytes(os.urandom(4), "little")
-    seed = int(seed)
-    h = hash_seed(seed)
+        seed = int.from_bytes(os.urandom(8), "big")
+    seed = int(seed) % 2 ** 64
     rng = np.random.RandomState()
-    rng.seed([(h >> (32 * i)) & 0xFFFFFFFF for i in range(2)])
+    rng.seed(_int_list_from_bigint(hash_seed(seed)))
     return rng, seed

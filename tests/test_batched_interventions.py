@@ -67,6 +67,22 @@ def test_mode_sweeps(lib):
         bi.amidar_set_mode("jump")
     jt = a.get_states_np()["jump_timer"]
     assert (jt[2:7] == 75).all() and (jt[:2] == 0).all() and (jt[7:] == 0).all()
+    # per-env times: a zero means the config's default for THAT env, like the reference's `set_time or config[...]`
+    with BatchIntervention(a, 2, 5) as bi:
+        bi.set_mode("chase", set_time=np.array([0, 11, 0, 12, 13]))
+        bi.set_mode("jump", set_time=np.zeros(5, int), envs=[0, 1])
+    st = a.get_states_np()
+    assert list(st["chase_timer"][2:7]) == [300, 11, 300, 12, 13] and list(st["jump_timer"][2:4]) == [75, 75]
+    # a `.states` array taken before a device-side helper is stale after it: writing through it raises instead of being lost
+    with BatchIntervention(a) as bi:
+        old = bi.states
+        old["lives"][0] = 2
+        bi.set_jumps(1)                                      # flushes the edit above, drops the host copy
+        with pytest.raises(ValueError):
+            old["lives"][1] = 1
+        assert bi.states["lives"][0] == 2 and (bi.states["jumps"] == 1).all()
+        bi.states["lives"][1] = 1                            # the fresh array takes edits
+    assert list(a.get_states_np()["lives"][:2]) == [2, 1]
     s = Engine("space_invaders", 4, lib=lib)
     with BatchIntervention(s) as bi:
         bi.space_invaders_remove_mothership()
@@ -192,6 +208,16 @@ def test_breakout_helpers_against_numpy(lib):
             assert np.array_equal(col7[i], st["bricks"][i]["alive"][42:48])
         row2 = bi.get_row(2)
         assert row2.shape == (n, 18) and np.array_equal(row2, st["bricks"]["alive"][:, 2:108:6])
+        # find_brick (:400-404): a host-evaluated predicate over the static attributes (or a mask) + the per-env alive flag
+        bk = st["bricks"][:, :108]
+        def first(sel):                                              # first True per env, -1 without one
+            return np.where(sel.any(axis=1), sel.argmax(axis=1), -1)
+        static = (bk["row"][0] >= 1) & (bk["col"][0] % 4 == 3)
+        assert np.array_equal(bi.find_brick(lambda b: b.row >= 1 and b.col % 4 == 3, alive=True), first(static[None, :] & (bk["alive"] != 0)))
+        assert np.array_equal(bi.find_brick(lambda b: b.row >= 1 and b.col % 4 == 3, alive=False), first(static[None, :] & (bk["alive"] == 0)))
+        assert np.array_equal(bi.find_brick(static), np.full(n, int(static.argmax())))
+        assert (bi.find_brick(lambda b: b.color.r == 1 and b.color.g == 2) == -1).all() and (bi.find_brick(np.zeros(108, bool)) == -1).all()
+        assert bi.brick_table()[7].points == int(bk["points"][0][7]) and bi.brick_table()[7].position.x == float(bk["x"][0][7])
         bi.fill_column(cols)
         assert not bi.is_channel(cols).any()
         bi.clear_board(envs=[1, 5])
@@ -251,6 +277,33 @@ def test_amidar_helpers_against_numpy(lib):
         for radius in (1, 3, 5):
             near = (np.abs(xx[None] - ptx[:, None, None]) + np.abs(yy[None] - pty[:, None, None]) < radius) & (tiles != 0)
             assert np.array_equal(bi.player_near_unpainted(radius), (near & (tiles == 2)).reshape(m, -1).sum(1) != near.reshape(m, -1).sum(1))
+        # mask / counter-RNG forms against numpy over the state records
+        from support import splitmix64
+        walk = tiles != 0
+        assert np.array_equal(bi.filter_tiles(lambda tag: tag != "Empty"), walk) and np.array_equal(bi.filter_tiles("ChaseMarker"), tiles == 3)
+        assert np.array_equal(bi.count_filtered_tiles(["Painted", "Unpainted"]), ((tiles == 1) | (tiles == 2)).reshape(m, -1).sum(1))
+        rtx, rty, rtag, rcnt = bi.get_random_tile(lambda tag: tag != "Empty", seed=21, draw=5, env_offset=40)
+        dirs = bi.get_random_dir_for_tile(rtx, rty, seed=21, draw=6, env_offset=40)
+        far = bi.get_random_tile(seed=3, draw=0, min_enemy_distance=12)
+        for i in range(m):
+            cand = np.argwhere(walk[i])                            # row by row: (ty, tx)
+            r = int(splitmix64(21 ^ ((40 + 2 + i) << 32) ^ 5))    # env index within the ENGINE (the range starts at env 2)
+            assert rcnt[i] == len(cand) and (rty[i], rtx[i]) == tuple(cand[r % len(cand)]) and rtag[i] == TILE_NAMES[tiles[i, rty[i], rtx[i]]]
+            ok = [name for name, (dx, dy) in (("Up", (0, -1)), ("Down", (0, 1)), ("Left", (-1, 0)), ("Right", (1, 0)))
+                  if 0 <= rtx[i] + dx < 32 and 0 <= rty[i] + dy < 31 and tiles[i, rty[i] + dy, rtx[i] + dx] != 0]
+            assert dirs[i] == ok[int(splitmix64(21 ^ ((40 + 2 + i) << 32) ^ 6)) % len(ok)]
+            d = np.abs(etx[i, :ne[i], None, None] - xx[None]) + np.abs(ety[i, :ne[i], None, None] - yy[None])
+            cand = np.argwhere(~(d < 12).all(axis=0))
+            assert far[3][i] == len(cand) and (far[1][i], far[0][i]) == tuple(cand[int(splitmix64(3 ^ ((2 + i) << 32) ^ 0)) % len(cand)])
+        none = bi.get_random_tile("Painted", seed=1, min_enemy_distance=200)       # nobody is 200 tiles away: no candidate anywhere
+        assert (none[0] == -1).all() and (none[3] == 0).all() and all(t is None for t in none[2])
+        before_pos = (st["player"]["x"].copy(), st["player"]["y"].copy())
+        bi.set_player_random_start(12, seed=3, draw=0, envs=np.arange(m) % 2 == 0)
+        after = e.get_states_np()[2:n - 2]["player"]
+        for i in range(m):
+            want_xy = (far[0][i] * 64, far[1][i] * 80) if i % 2 == 0 else (before_pos[0][i], before_pos[1][i])
+            assert (after["x"][i], after["y"][i]) == want_xy
+        bi.set_player_tile(ptx, pty)                                  # back, for the checks below
         # edits
         bi.set_mode("jump", envs=np.arange(m) < 5)
         bi.set_mode("chase", set_time=np.arange(m) + 7)
@@ -307,6 +360,9 @@ def _abi_mod():
     return _abi
 
 
+TILE_NAMES = ["Empty", "Unpainted", "Painted", "ChaseMarker"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("game", ["breakout", "amidar", "space_invaders"])
 def test_device_side_interventions_hip_equals_oracle(game, oracle_lib):
@@ -332,7 +388,9 @@ def test_device_side_interventions_hip_equals_oracle(game, oracle_lib):
                     bi.set_paddle_position(40.0 + (np.arange(n) % 150))
                     bi.set_ball(0, 100.0, 100.0, 1.25, -1.75, envs=mask)
                     out += [bi.num_bricks_remaining(), bi.num_bricks(), bi.channel_count(), bi.find_channel(), bi.is_channel(cols),
-                            bi.get_column(4), bi.get_row(1), bi.get_paddle_position(), bi.get_ball_position()[1], bi.get_ball_velocity()[0]]
+                            bi.get_column(4), bi.get_row(1), bi.get_paddle_position(), bi.get_ball_position()[1], bi.get_ball_velocity()[0],
+                            bi.find_brick(lambda b: b.row >= 2 and b.col % 3 == 1, alive=True), bi.find_brick(np.arange(108) > 50, alive=False),
+                            bi.find_brick(lambda b: b.points == 7)]
                     if rnd == 0:                                   # now the same on per-env brick tables
                         js = bi.json(7)
                         js["bricks"][5]["col"] = 17
@@ -346,6 +404,11 @@ def test_device_side_interventions_hip_equals_oracle(game, oracle_lib):
                 bi.set_enemy_protocol(2, "EnemyRandomMvmt", start={"tx": 12, "ty": 12}, start_dir="Left", dir="Left", envs=mask)
                 bi.set_enemy_protocol(0, "EnemyAmidarMvmt", vert="Down", horiz="Right", start_vert="Down", start_horiz="Right", start={"tx": 6, "ty": 0})
                 bi.set_jumps(np.arange(n) % 6)
+                bi.set_player_random_start(6, seed=9, draw=3, env_offset=123456, envs=np.arange(n) % 5 == 1)
+                rt = bi.get_random_tile(lambda tag: tag != "Empty", seed=4, draw=np.arange(n) % 7, env_offset=99)
+                out += [bi.filter_tiles("Unpainted"), bi.count_filtered_tiles(lambda tag: tag in ("Painted", "ChaseMarker")), rt[0], rt[1], rt[3],
+                        np.stack(bi.get_random_tile(seed=1, min_enemy_distance=20)[:2]), np.stack(bi.get_random_track_position(seed=8, draw=2)),
+                        bi.get_random_dir_for_tile(tx, ty, seed=2, draw=1) == "Up", bi.get_random_dir_for_tile(tx, ty, seed=2, draw=1) == None]  # noqa: E711
                 out += [bi.get_jump_mode(), bi.get_chase_mode(), bi.any_enemy_caught(), bi.count_tiles("Painted"), bi.count_tiles("Empty"),
                         bi.get_adjacent_tiles(tx, ty), bi.enemy_distances_from_tile(tx, ty), np.stack(bi.player_tile()[:2]),
                         bi.player_enemy_distances(), bi.player_on_painted(), bi.player_near_unpainted(4), bi.is_tile_walkable(tx, ty)]

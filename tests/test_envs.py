@@ -29,6 +29,28 @@ def test_hash_seed_is_gyms():
         assert hash_seed(s) == int.from_bytes(hashlib.sha512(str(s).encode()).digest()[:8], "little")
 
 
+def test_seed_builds_the_random_state_gym_built(factory):
+    """ToyboxBaseEnv.seed (envs/atari/base.py:84-98) over gym.utils.seeding.np_random of the gym the reference targets: a
+    RandomState (NoopResetEnv calls .randint on it) seeded with the 32-bit words of hash_seed(seed), zero high words left out;
+    no seed = 8 bytes of entropy; the second value, < 2**31, seeds the simulator (never gym >= 0.26's Generator)."""
+    from toybox_amd.envs.base import _int_list_from_bigint
+    assert _int_list_from_bigint(0) == [0] and _int_list_from_bigint(5) == [5] and _int_list_from_bigint(2 ** 32) == [0, 1]
+    assert _int_list_from_bigint(2 ** 64 - 1) == [2 ** 32 - 1] * 2
+    env = BreakoutEnv()
+    for s in (0, 5, 2 ** 40 + 3):
+        first, second = env.seed(s)
+        assert first == s and second == hash_seed(s + 1) % 2 ** 31
+        assert isinstance(env.np_random, np.random.RandomState)
+        want = np.random.RandomState()
+        want.seed(_int_list_from_bigint(hash_seed(s)))
+        assert [env.np_random.randint(1, 31) for _ in range(5)] == [want.randint(1, 31) for _ in range(5)]
+    first, second = env.seed()
+    assert 0 <= first < 2 ** 64 and 0 <= second < 2 ** 31
+    with pytest.raises(ValueError):
+        env.seed(-1)
+    env.close()
+
+
 @pytest.mark.parametrize("cls,game,dims,n_act", [(BreakoutEnv, "breakout", (160, 240), 4), (AmidarEnv, "amidar", (250, 160), 6),
                                                  (SpaceInvadersEnv, "space_invaders", (210, 320), 6)])
 def test_base_env_semantics(cls, game, dims, n_act, factory):

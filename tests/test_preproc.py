@@ -754,3 +754,38 @@ def test_gpu_space_invaders_observation_of_handwritten_formations(oh, ow, hip_li
         x, y = g.agent_step(a), o.agent_step(a)
         for p, q in zip(x, y):
             assert np.array_equal(p, q), t
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
+def test_host_stack_push_is_vec_frame_stack(which, oracle_lib):
+    """tbx_host_stack_push (host code of both libraries; the product's is threaded and loads without a GPU) == the lines of
+    VecFrameStack.step_wait / .reset (vec_frame_stack.py:17-33) spelled with numpy, and FrameStack.reset's fill
+    (atari_wrappers.py:257-261): depths 4 (dword path) and 3, in place and into a second array, one thread and several."""
+    if which == "product":
+        from toybox_amd import _lib
+        lib = _lib.load()
+    else:
+        lib = oracle_lib
+    rng = np.random.default_rng(5)
+    for n, h, w, k, threads in ((70, 84, 84, 4, 0), (70, 84, 84, 4, 1), (9, 20, 31, 3, 3), (1, 5, 7, 4, 2), (40, 84, 84, 2, 4)):
+        for fill in (0, 1):
+            stacked = rng.integers(0, 256, (n, h, w, k), dtype=np.uint8)
+            want = stacked.copy()
+            cur = stacked.copy()
+            other = np.empty_like(cur)
+            for step in range(4):
+                plane = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+                done = rng.random(n) < 0.3
+                reset = step == 2
+                # the Python: roll, clear / refill finished envs, newest frame last
+                want = np.roll(want, shift=-1, axis=-1)
+                fresh = np.ones(n, bool) if reset else done
+                want[fresh] = plane[fresh][..., None] if fill else 0
+                want[..., -1] = plane
+                dst = cur if step % 2 == 0 else other           # in place, then into the second array
+                rc = lib.tbx_host_stack_push(dst.ctypes.data, cur.ctypes.data, plane.ctypes.data, done.astype(np.uint8).ctypes.data,
+                                             int(reset), n, h * w, k, fill, threads)
+                assert rc == 0
+                cur = dst
+                assert np.array_equal(cur, want), (which, n, k, fill, step)
+    assert lib.tbx_host_stack_push(None, None, None, None, 0, 1, 1, 1, 0, 0) == _abi.E_INVALID

@@ -461,3 +461,103 @@ def test_bench_launch_timing_brackets_runs_never_next_to_a_sync(fused, K):
             if x[0] == "event":
                 assert seen >= skip
                 break
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("every", [1, 3])
+def test_gpu_host_transport_gather_between_two_engines_on_one_device(every, hip_lib):
+    """TBX_OPT_GATHER_TRANSPORT = 1 (SURVEY 8e's fallback, and the way two ranks can share ONE GPU): two engines = two ranks, one
+    thread each (a host-transport collective blocks its caller until every rank has arrived), the same id, shards of unequal
+    size; the gathered block of every collective must hold both ranks' records in rank order -- checked against one engine that
+    owns the whole batch -- with one collective per step and with a 3-step ring; the max-reduction and what the engine reports
+    about the transport."""
+    import threading
+    from toybox_amd import Engine, _abi
+    from toybox_amd.parallel import shard_range, unpack_records
+    game, n_total, world, steps = "breakout", 1000, 2, 12
+    spans = [shard_range(n_total, world, r) for r in range(world)]
+    width = max(e - s for s, e in spans)
+    ref = Engine(game, n_total, lib=hip_lib)
+    ref.seed(1234); ref.new_game()
+    want = []
+    for t in range(steps):
+        ref.step_synthetic(1337, t, env_offset=0, auto_reset=True)
+        ref.sync()
+        p, _ = ref.device_buffer(_abi.BUF_PACKED)
+        rec = np.empty(n_total, np.uint64)
+        from toybox_amd import hip
+        hip.memcpy_dtoh(rec, p, 8 * n_total)
+        want.append(rec)
+    ref.close()
+    engines = []
+    for r, (s, e_) in enumerate(spans):
+        e = Engine(game, e_ - s, lib=hip_lib)
+        e.seed(1234 + s); e.new_game()
+        e.set_option(_abi.OPT_GATHER_TRANSPORT, _abi.GATHER_HOST)
+        e.set_option(_abi.OPT_GATHER_EVERY, every)
+        engines.append(e)
+    uid = engines[0].gather_unique_id()
+    got, errors, maxima = [[] for _ in spans], [], [None] * world
+
+    def rank_main(r):
+        try:
+            e = engines[r]
+            e.gather_init(world, r, uid, records_per_rank=width)
+            assert e.gather_nranks() == world and e.gather_library().startswith("host:")
+            for t in range(steps):
+                e.step_synthetic(1337, t, env_offset=spans[r][0], auto_reset=True)
+                e.gather()
+                if (t + 1) % every == 0:
+                    got[r].append(e.gather_host().copy())
+            maxima[r] = e.gather_reduce_max(10.0 + r)
+        except Exception as ex:                                # noqa: BLE001
+            errors.append((r, repr(ex)))
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert maxima == [10.0 + world - 1] * world
+    for r in range(world):
+        assert len(got[r]) == steps // every
+        for c, block in enumerate(got[r]):
+            block = block.reshape(world, every, width)
+            for j in range(every):
+                t = c * every + j
+                for q, (s, e_) in enumerate(spans):
+                    assert np.array_equal(block[q, j, :e_ - s], want[t][s:e_]), (r, t, q)
+                    assert not block[q, j, e_ - s:].any()
+    lives = unpack_records(got[0][-1].reshape(world, every, width)[1, -1, :spans[1][1] - spans[1][0]])[2]
+    assert lives.min() >= 1
+    for e in engines:
+        e.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bench_n_process_flow_on_one_device_with_the_host_transport(tmp_path):
+    """The dress rehearsal of `bench.py --gpus N` that needs no second GPU: bench.py's own spawner starts two
+    fresh rank processes (before anything touches the GPU), both on device 0, and the whole N > 1 flow runs on real HIP --
+    engines for contiguous shards, both readings of the metric with a communicator each, the verified exchange, ring
+    bookkeeping, max-over-ranks regions, rank 0's JSON line with the CPU arm -- everything except RCCL's wire, which is
+    replaced by the host transport and labelled as such."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TBX_RDZV_KEY")}
+    env["TBX_RDZV_DIR"] = str(tmp_path)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gather", "host", "--one-device", "--envs", "4096",
+                        "--steps", "6", "--warmup", "2", "--repeats", "2", "--preroll", "300", "--settle", "4", "--cpu-seconds", "0.5"],
+                       capture_output=True, text=True, timeout=900, cwd="/tmp", env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["envs_total"] == 4096 and line["config"]["envs_per_gpu"] == 2048
+    assert line["rccl"] is None
+    g = line["gather"]
+    assert g["transport"] == "host" and g["nranks"] == 2 and g["verified"] is True and g["gather_every"] == 4 and g["lib"].startswith("host:")
+    assert line["weak"]["gather"]["transport"] == "host" and line["weak"]["envs_total"] == 8192 and line["weak"]["rccl"] is None
+    assert 0 < line["share_of_linear"] < 1.5
+    assert "HOST-STAGED" in line["config"]["parallelism"]
+    assert line["loop"]["form"] == "fused" and line["roofline"]["avg_launch_ms"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["check"]["mean_score"] > 0

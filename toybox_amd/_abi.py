@@ -26,6 +26,8 @@ BUF_AGENT_PLANE = 13
 GATHER_ID_BYTES = 128
 # engine options (tbx_set_option)
 OPT_PIPELINE, OPT_STEP_FORM, OPT_RENDER_SPLIT, OPT_AGENT_GENERIC, OPT_RESIDENT_STEP, OPT_GATHER_EVERY = 0, 1, 2, 3, 4, 5
+OPT_GATHER_TRANSPORT = 6           # 0 RCCL, 1 host-staged over POSIX shared memory (one node)
+GATHER_RCCL, GATHER_HOST = 0, 1
 OPT_PIPELINE_ACTIVE = 100          # read-only: what OPT_PIPELINE resolves to on the engine
 OPT_RECORDS_ACTIVE = 101           # read-only: the rasteriser reads step-written render records
 OPT_RENDER_STEP_FUSED = 102        # read-only: tbx_render_step_synthetic is one launch on this engine
@@ -50,6 +52,7 @@ EDIT_AMI_JUMPS = 21
 EDIT_AMI_TILE = 22
 EDIT_AMI_ENEMY_AI = 23
 EDIT_AMI_PLAYER_TILE = 24
+EDIT_AMI_PLAYER_RANDOM_START = 25
 EDIT_SI_UFO_APPEARANCE = 30
 QUERY_BRK_BRICKS_REMAINING = 110
 QUERY_BRK_NUM_BRICKS = 111
@@ -60,6 +63,7 @@ QUERY_BRK_CHANNEL_COUNT = 115
 QUERY_BRK_FIND_CHANNEL = 116
 QUERY_BRK_PADDLE = 117
 QUERY_BRK_BALLS = 118
+QUERY_BRK_FIND_BRICK = 119
 QUERY_AMI_MODE = 120
 QUERY_AMI_ANY_CAUGHT = 121
 QUERY_AMI_TILE = 122
@@ -71,6 +75,9 @@ QUERY_AMI_PLAYER_ENEMY_DISTANCES = 127
 QUERY_AMI_PLAYER_ON_PAINTED = 128
 QUERY_AMI_PLAYER_NEAR_UNPAINTED = 129
 QUERY_SI_SHIP = 130
+QUERY_AMI_TILES_MASK = 131
+QUERY_AMI_RANDOM_TILE = 133
+QUERY_AMI_RANDOM_DIR = 134
 
 BRK_MAX_BALLS, BRK_COLS, BRK_MAX_ROWS, BRK_MAX_BRICKS, BRK_MAX_STARTS, BRK_MAX_SEGMENTS = 4, 18, 14, 256, 8, 16
 
@@ -343,6 +350,7 @@ PROTOTYPES = {
     "tbx_agent_fetch": (_i, [_vp, _p(AgentHostOut)]),
     "tbx_step_begin": (_i, [_vp, _vp, _u32, _p(StepHostOut)]),
     "tbx_step_end": (_i, [_vp]),
+    "tbx_host_stack_push": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "tbx_gather_unique_id": (_i, [_vp, _sz]),
     "tbx_gather_init": (_i, [_vp, _i, _i, _i, _vp, _sz]),
     "tbx_gather": (_i, [_vp, _vp, _vp]),

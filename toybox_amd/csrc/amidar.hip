@@ -1553,7 +1553,7 @@ __device__ __forceinline__ void ami_paint_units(const AmiPainter<C>& p, uint8_t*
         const uint32_t mv_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.mv_rows, y_first);
         const uint32_t busy_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.busy, y_first);
         if (busy_chunk == 0 && C != 4) {                     // background only: no staging (RGBA: staged is faster)
-            Stager::fill_unit_aligned(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_bg);
+            Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_bg);
             continue;
         }
 #pragma unroll 1
@@ -1562,7 +1562,7 @@ __device__ __forceinline__ void ami_paint_units(const AmiPainter<C>& p, uint8_t*
             p.paint_row(y_first + r, (mv_chunk >> r) & 1u, px);
             if (p.active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
         }
-        st.flush_aligned(frame + (size_t)u * Stager::UNIT_BYTES, lane);   // 4 800-byte units: see RowStager::flush_aligned
+        st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
     }
 }
 
@@ -1760,6 +1760,37 @@ __device__ __forceinline__ int ami_tile_tag(const AmiDev& d, int env, int tx, in
     return (int)((d.tiles[(size_t)env * 32 + ty] >> (2 * tx)) & 3ull);
 }
 
+// The counter-RNG forms of the reference's `random`-driven helpers (toybox_amd.h).  Candidates of a tile draw: tiles row by row
+// whose tag is in tag_mask and, with min_dist > 0, for which not every enemy is nearer than min_dist (manhattan, in tiles).
+struct AmiTilePick { int tx, ty, tag, count; };
+__device__ AmiTilePick ami_random_tile(const AmiDev& d, int env, uint32_t seed, uint32_t draw, uint32_t env_offset, uint32_t tag_mask, int min_dist)
+{
+    const size_t N = (size_t)d.n;
+    const int ne = d.sc[(size_t)A_N_ENEMIES * N + env];
+    int ex[TBX_AMI_MAX_ENEMIES], ey[TBX_AMI_MAX_ENEMIES];
+    for (int i = 0; i < TBX_AMI_MAX_ENEMIES; i++) {
+        ex[i] = i < ne ? ami_floor_div(ami_mover_read(d, env, M_X, i), TBX_AMI_TILE_WX) : 0;
+        ey[i] = i < ne ? ami_floor_div(ami_mover_read(d, env, M_Y, i), TBX_AMI_TILE_WY) : 0;
+    }
+    auto accepted = [&](int tx, int ty) {
+        if (!((tag_mask >> ami_tile_tag(d, env, tx, ty)) & 1u)) return false;
+        if (min_dist <= 0) return true;
+        bool all_near = true;                                 // `not all(d < min for every enemy)`; no enemies: all([]) is True
+        for (int i = 0; i < ne; i++) all_near = all_near && (abs(ex[i] - tx) + abs(ey[i] - ty) < min_dist);
+        return !all_near;
+    };
+    AmiTilePick p{-1, -1, -1, 0};
+    for (int ty = 0; ty < BH; ty++)
+        for (int tx = 0; tx < BW; tx++) p.count += accepted(tx, ty) ? 1 : 0;
+    if (p.count == 0) return p;
+    const uint64_t r = tbx_splitmix64((uint64_t)seed ^ ((uint64_t)(env_offset + (uint32_t)env) << 32) ^ (uint64_t)draw);
+    int k = (int)(r % (uint64_t)p.count);
+    for (int ty = 0; ty < BH && p.tx < 0; ty++)
+        for (int tx = 0; tx < BW; tx++)
+            if (accepted(tx, ty) && k-- == 0) { p.tx = tx; p.ty = ty; p.tag = ami_tile_tag(d, env, tx, ty); break; }
+    return p;
+}
+
 __global__ __launch_bounds__(256) void ami_edit_kernel(AmiDev d, int op, TbxEditArgs a, const uint8_t* __restrict__ mask)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1792,6 +1823,14 @@ __global__ __launch_bounds__(256) void ami_edit_kernel(AmiDev d, int op, TbxEdit
         ami_mover_write(d, env, M_X, PLAYER_SLOT, a.geti(env, 0) * TBX_AMI_TILE_WX);
         ami_mover_write(d, env, M_Y, PLAYER_SLOT, a.geti(env, 1) * TBX_AMI_TILE_WY);
         break;
+    case TBX_EDIT_AMI_PLAYER_RANDOM_START: {
+        const AmiTilePick p = ami_random_tile(d, env, a.getu(env, 0), a.getu(env, 1), a.getu(env, 2), 0xFu, a.geti(env, 3));
+        if (p.count > 0) {
+            ami_mover_write(d, env, M_X, PLAYER_SLOT, p.tx * TBX_AMI_TILE_WX);
+            ami_mover_write(d, env, M_Y, PLAYER_SLOT, p.ty * TBX_AMI_TILE_WY);
+        }
+        break;
+    }
     default: break;
     }
 }
@@ -1827,6 +1866,38 @@ __global__ __launch_bounds__(256) void ami_reduce_kernel(AmiDev d, int query, Tb
         for (int ty = 0; ty < BH; ty++)
             for (int tx = 0; tx < BW; tx++) c += ami_tile_tag(d, env, tx, ty) == tag;
         o[0] = c;
+        break;
+    }
+    case TBX_QUERY_AMI_TILES_MASK: {
+        const uint32_t tm = a.getu(env, 0);
+        int c = 0;
+        for (int ty = 0; ty < BH; ty++) {
+            uint32_t bits = 0;
+            for (int tx = 0; tx < BW; tx++)
+                if ((tm >> ami_tile_tag(d, env, tx, ty)) & 1u) { bits |= 1u << tx; c++; }
+            o[ty] = bits;
+        }
+        o[31] = c;
+        break;
+    }
+    case TBX_QUERY_AMI_RANDOM_TILE: {
+        const AmiTilePick p = ami_random_tile(d, env, a.getu(env, 0), a.getu(env, 1), a.getu(env, 2), a.getu(env, 3), a.geti(env, 4));
+        o[0] = p.tx; o[1] = p.ty; o[2] = p.tag; o[3] = p.count;
+        break;
+    }
+    case TBX_QUERY_AMI_RANDOM_DIR: {
+        const int tx = a.geti(env, 3), ty = a.geti(env, 4);
+        const int nx[4] = {tx, tx, tx - 1, tx + 1}, ny[4] = {ty - 1, ty + 1, ty, ty};     // TBX_DIR_UP, DOWN, LEFT, RIGHT
+        int valid = 0;
+        for (int k = 0; k < 4; k++) valid += ami_tile_tag(d, env, nx[k], ny[k]) > TBX_TILE_EMPTY;
+        int dir = -1;
+        if (valid) {
+            const uint64_t r = tbx_splitmix64((uint64_t)a.getu(env, 0) ^ ((uint64_t)(a.getu(env, 2) + (uint32_t)env) << 32) ^ (uint64_t)a.getu(env, 1));
+            int pick = (int)(r % (uint64_t)valid);
+            for (int k = 0; k < 4 && dir < 0; k++)
+                if (ami_tile_tag(d, env, nx[k], ny[k]) > TBX_TILE_EMPTY && pick-- == 0) dir = k;
+        }
+        o[0] = dir; o[1] = valid;
         break;
     }
     case TBX_QUERY_AMI_ADJACENT: {
@@ -2138,7 +2209,7 @@ struct AmiOps : GameOps {
     {
         switch (op) {
         case TBX_EDIT_SET_LIVES: case TBX_EDIT_SET_SCORE: case TBX_EDIT_SET_LEVEL: case TBX_EDIT_AMI_TIMERS: case TBX_EDIT_AMI_JUMPS:
-        case TBX_EDIT_AMI_TILE: case TBX_EDIT_AMI_ENEMY_AI: case TBX_EDIT_AMI_PLAYER_TILE: break;
+        case TBX_EDIT_AMI_TILE: case TBX_EDIT_AMI_ENEMY_AI: case TBX_EDIT_AMI_PLAYER_TILE: case TBX_EDIT_AMI_PLAYER_RANDOM_START: break;
         default: return e->fail(TBX_E_INVALID, "amidar: unknown edit");
         }
         hipLaunchKernelGGL(ami_edit_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, op, a, mask_dev);

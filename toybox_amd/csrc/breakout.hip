@@ -1702,6 +1702,14 @@ __global__ __launch_bounds__(256) void brk_reduce_kernel(BrkDev d, int rows, int
         o[0] = query == TBX_QUERY_BRK_IS_CHANNEL ? is : query == TBX_QUERY_BRK_CHANNEL_COUNT ? count : first;
         break;
     }
+    case TBX_QUERY_BRK_FIND_BRICK: {
+        const int want = a.geti(env, 0);
+        int first = -1;
+        for (int j = 0; j < nb && first < 0; j++)
+            if (((a.getu(env, 1 + (j >> 5)) >> (j & 31)) & 1u) && (want < 0 || alive(j) == (want != 0))) first = j;
+        o[0] = first;
+        break;
+    }
     case TBX_QUERY_BRK_PADDLE:
         for (int i = 0; i < 4; i++) o[i] = d.paddle[(size_t)i * N + env];
         break;

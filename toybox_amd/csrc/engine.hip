@@ -3,6 +3,10 @@
 
 #include "tbx_common.hpp"
 
+#include <sched.h>
+#include <thread>
+#include <vector>
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -716,6 +720,60 @@ int tbx_host_free(void* ptr)
     return TBX_OK;
 }
 
+// rows [first, last) of the host-side frame stack (see toybox_amd.h)
+static void host_stack_rows(uint8_t* dst, const uint8_t* src, const uint8_t* plane, const uint8_t* done, int reset, int first, int last,
+                            int px, int stack, int fill)
+{
+    for (int i = first; i < last; i++) {
+        uint8_t* d = dst + (size_t)i * px * stack;
+        const uint8_t* s = src + (size_t)i * px * stack;
+        const uint8_t* p = plane + (size_t)i * px;
+        const bool fresh = reset || (done && done[i]);
+        if (stack == 4) {                                    // one dword per pixel: shift the older three down, the new byte on top
+            uint32_t* d4 = reinterpret_cast<uint32_t*>(d);
+            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
+            if (!fresh) for (int k = 0; k < px; k++) d4[k] = (s4[k] >> 8) | ((uint32_t)p[k] << 24);
+            else if (fill) for (int k = 0; k < px; k++) d4[k] = (uint32_t)p[k] * 0x01010101u;
+            else for (int k = 0; k < px; k++) d4[k] = (uint32_t)p[k] << 24;
+            continue;
+        }
+        for (int k = 0; k < px; k++) {
+            uint8_t* dk = d + (size_t)k * stack;
+            const uint8_t* sk = s + (size_t)k * stack;
+            for (int c = 0; c + 1 < stack; c++) dk[c] = fresh ? (fill ? p[k] : (uint8_t)0) : sk[c + 1];
+            dk[stack - 1] = p[k];
+        }
+    }
+}
+
+int tbx_host_stack_push(uint8_t* dst, const uint8_t* src, const uint8_t* plane, const uint8_t* done, int reset, int n, int px, int stack,
+                        int fill, int threads)
+{
+    if (!dst || !src || !plane || n < 0 || px < 1 || stack < 1 || stack > 16 || fill < 0 || fill > 1) {
+        tbx_set_create_error("tbx_host_stack_push: bad argument");
+        return TBX_E_INVALID;
+    }
+    if (stack == 4 && ((((uintptr_t)dst | (uintptr_t)src) & 3u) != 0)) { tbx_set_create_error("tbx_host_stack_push: stacks of depth 4 must be 4-byte aligned"); return TBX_E_INVALID; }
+    int T = threads;
+    if (T <= 0) {
+        cpu_set_t set;
+        T = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 1;
+        if (T > 16) T = 16;
+    }
+    const long work = (long)n * px;
+    if (T > 1 && work < (1L << 18)) T = 1;                   // a few dozen envs: thread start-up costs more than the loop
+    if (T > n) T = n > 0 ? n : 1;
+    if (T <= 1) { host_stack_rows(dst, src, plane, done, reset, 0, n, px, stack, fill); return TBX_OK; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)T);
+    for (int t = 0; t < T; t++) {
+        const int first = (int)((long)n * t / T), last = (int)((long)n * (t + 1) / T);
+        pool.emplace_back(host_stack_rows, dst, src, plane, done, reset, first, last, px, stack, fill);
+    }
+    for (auto& th : pool) th.join();
+    return TBX_OK;
+}
+
 int tbx_step_begin(tbx_engine* e, const int32_t* actions_host, uint32_t flags, const tbx_step_host_out_t* out)
 {
     CHECK_ENGINE(e);
@@ -1165,6 +1223,10 @@ int tbx_reduce_width(int game, int query)
     case TBX_QUERY_AMI_ENEMY_DISTANCES: case TBX_QUERY_AMI_PLAYER_ENEMY_DISTANCES: return game == TBX_GAME_AMIDAR ? TBX_AMI_MAX_ENEMIES : TBX_E_INVALID;
     case TBX_QUERY_AMI_PLAYER_TILE: return game == TBX_GAME_AMIDAR ? 3 : TBX_E_INVALID;
     case TBX_QUERY_SI_SHIP: return game == TBX_GAME_SPACE_INVADERS ? 8 : TBX_E_INVALID;
+    case TBX_QUERY_BRK_FIND_BRICK: return game == TBX_GAME_BREAKOUT ? 1 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_TILES_MASK: return game == TBX_GAME_AMIDAR ? 32 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_RANDOM_TILE: return game == TBX_GAME_AMIDAR ? 4 : TBX_E_INVALID;
+    case TBX_QUERY_AMI_RANDOM_DIR: return game == TBX_GAME_AMIDAR ? 2 : TBX_E_INVALID;
     default: return TBX_E_INVALID;
     }
 }
@@ -1312,7 +1374,7 @@ int tbx_set_option(tbx_engine* e, int option, int value)
     case TBX_OPT_PIPELINE: ok = value >= 0 && value <= 3; break;
     case TBX_OPT_STEP_FORM: ok = value >= 0 && value <= 2; break;
     case TBX_OPT_RENDER_SPLIT: ok = value >= 0 && value <= 64; break;
-    case TBX_OPT_AGENT_GENERIC: case TBX_OPT_RESIDENT_STEP: ok = value == 0 || value == 1; break;
+    case TBX_OPT_AGENT_GENERIC: case TBX_OPT_RESIDENT_STEP: case TBX_OPT_GATHER_TRANSPORT: ok = value == 0 || value == 1; break;
     case TBX_OPT_GATHER_EVERY: ok = value >= 1 && value <= 64; break;
     default: return e->fail(TBX_E_INVALID, "unknown option");
     }

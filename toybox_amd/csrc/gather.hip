@@ -12,7 +12,12 @@
 #include "tbx_common.hpp"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
+#include <chrono>
 #include <cstring>
 
 // The handful of RCCL declarations this file needs, stated locally: the library is found with dlopen at run time and its
@@ -34,6 +39,60 @@ static_assert(TBX_GATHER_ID_BYTES == NCCL_UNIQUE_ID_BYTES && sizeof(tbx_nccl_id_
 static_assert((int)ncclSuccess == TBX_NCCL_SUCCESS && (int)ncclUint64 == TBX_NCCL_UINT64 && (int)ncclFloat64 == TBX_NCCL_FLOAT64 &&
               (int)ncclMax == TBX_NCCL_MAX, "RCCL enum values");
 #endif
+
+// ---- host transport.  Segment layout: seq[3][64] call counters (records / scalar / attach), two parity buffers of
+// nranks * slot bytes for the records, two parity buffers of nranks doubles.  A collective: write the own slot of parity
+// (call & 1), publish the call number, wait until every rank has published it, read all slots.  Two parities are enough: a rank
+// can be at most one call ahead of the slowest one (it waits for everybody before it returns).
+struct HostWorld {
+    struct Head { volatile uint64_t seq[3][64]; };
+    void* map = nullptr;
+    size_t len = 0, slot = 0;
+    int nranks = 1, rank = 0;
+    uint64_t calls[2] = {0, 0};
+    char name[64] = {0};
+    uint64_t* stage_out = nullptr;    // pinned: this rank's records on their way out
+    uint64_t* gathered = nullptr;     // pinned: [nranks][slot / 8] result of the last collective
+
+    Head* head() const { return reinterpret_cast<Head*>(map); }
+    char* records(int parity) const { return reinterpret_cast<char*>(map) + sizeof(Head) + (size_t)parity * nranks * slot; }
+    double* scalars(int parity) const { return reinterpret_cast<double*>(reinterpret_cast<char*>(map) + sizeof(Head) + 2 * (size_t)nranks * slot) + (size_t)parity * nranks; }
+
+    // false: a rank did not arrive within `seconds`
+    bool wait_all(int which, uint64_t call, double seconds = 120.0) const
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < nranks; r++) {
+            unsigned spins = 0;
+            while (__atomic_load_n(&head()->seq[which][r], __ATOMIC_ACQUIRE) < call) {
+                sched_yield();
+                if ((++spins & 0xFFFu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+            }
+        }
+        return true;
+    }
+    bool exchange_records(const void* mine, void* all)
+    {
+        const uint64_t call = ++calls[0];
+        char* buf = records((int)(call & 1u));
+        memcpy(buf + (size_t)rank * slot, mine, slot);
+        __atomic_store_n(&head()->seq[0][rank], call, __ATOMIC_RELEASE);
+        if (!wait_all(0, call)) return false;
+        memcpy(all, buf, (size_t)nranks * slot);
+        return true;
+    }
+    bool max_scalar(double* v)
+    {
+        const uint64_t call = ++calls[1];
+        double* buf = scalars((int)(call & 1u));
+        buf[rank] = *v;
+        __atomic_store_n(&head()->seq[1][rank], call, __ATOMIC_RELEASE);
+        if (!wait_all(1, call)) return false;
+        for (int r = 0; r < nranks; r++)
+            if (buf[r] > *v) *v = buf[r];
+        return true;
+    }
+};
 
 struct GatherState {
     void* dl = nullptr;
@@ -59,6 +118,9 @@ struct GatherState {
     uint64_t* ring[2] = {nullptr, nullptr};
     uint64_t* out = nullptr;                  // [nranks][width] engine-owned result (TBX_BUF_GATHERED)
     double* scalar = nullptr;                 // device scalar for the max-reduction
+    // TBX_OPT_GATHER_TRANSPORT = 1: no RCCL -- the ranks of ONE node exchange the records through a POSIX shared-memory segment
+    // named after the id ("a host-staged gather is the fallback if RCCL is missing"); see HostWorld below
+    HostWorld* host = nullptr;
     tbx_nccl_get_unique_id_fn get_unique_id = nullptr;
     tbx_nccl_comm_init_rank_fn comm_init_rank = nullptr;
     tbx_nccl_comm_destroy_fn comm_destroy = nullptr;
@@ -129,6 +191,13 @@ void tbx_gather_free(tbx_engine* e)
     GatherState* g = e->gather;
     if (!g) return;
     if (g->stream) hipStreamSynchronize(g->stream);
+    if (g->host) {
+        if (g->host->map) munmap(g->host->map, g->host->len);
+        if (g->host->rank == 0 && g->host->name[0]) shm_unlink(g->host->name);
+        if (g->host->stage_out) hipHostFree(g->host->stage_out);
+        if (g->host->gathered) hipHostFree(g->host->gathered);
+        delete g->host;
+    }
     if (g->comm && g->comm_destroy) g->comm_destroy(g->comm);
     if (g->ready) hipEventDestroy(g->ready);
     for (int k = 0; k < 2; k++)
@@ -189,7 +258,14 @@ int tbx_gather_unique_id(void* id_out, size_t id_bytes)
     if (!id_out || id_bytes != TBX_GATHER_ID_BYTES) { tbx_set_create_error("id buffer must be TBX_GATHER_ID_BYTES long"); return TBX_E_INVALID; }
     GatherState g;
     g.dl = open_rccl(err);
-    if (!g.dl) { tbx_set_create_error(err); return TBX_E_UNSUPPORTED; }
+    if (!g.dl) {
+        // no librccl on this machine: an id that names a host-transport world (TBX_OPT_GATHER_TRANSPORT = 1) and nothing else
+        int fd = open("/dev/urandom", O_RDONLY);
+        const bool ok = fd >= 0 && read(fd, id_out, TBX_GATHER_ID_BYTES) == (ssize_t)TBX_GATHER_ID_BYTES;
+        if (fd >= 0) close(fd);
+        if (!ok) { tbx_set_create_error(err + "; and /dev/urandom is not readable"); return TBX_E_UNSUPPORTED; }
+        return TBX_OK;
+    }
     if (!load_symbols(g, err)) { dlclose(g.dl); tbx_set_create_error(err); return TBX_E_UNSUPPORTED; }
     tbx_nccl_id_t id;
     const int r = g.get_unique_id(&id);
@@ -211,8 +287,14 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
     e->gather = new GatherState();
     GatherState& g = *e->gather;
     std::string err;
-    g.dl = open_rccl(err, &g.lib_path);
-    if (!g.dl || !load_symbols(g, err)) { tbx_gather_free(e); return e->fail(TBX_E_UNSUPPORTED, err); }
+    const bool host_transport = e->opt[TBX_OPT_GATHER_TRANSPORT] == 1;
+    if (host_transport) {
+        if (nranks > 64) { tbx_gather_free(e); return e->fail(TBX_E_UNSUPPORTED, "gather: the host transport handles at most 64 ranks"); }
+        g.lib_path = "host: POSIX shared memory, staged through page-locked buffers (no RCCL)";
+    } else {
+        g.dl = open_rccl(err, &g.lib_path);
+        if (!g.dl || !load_symbols(g, err)) { tbx_gather_free(e); return e->fail(TBX_E_UNSUPPORTED, err); }
+    }
     g.nranks = nranks; g.rank = rank; g.width = records_per_rank;
     g.every = e->opt[TBX_OPT_GATHER_EVERY] > 1 ? e->opt[TBX_OPT_GATHER_EVERY] : 1;
     GHIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
@@ -243,11 +325,49 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
         e->gather_wants_step_event = true;
         if (g.width != e->n) GHIP(hipMalloc((void**)&g.send, sizeof(uint64_t) * (size_t)g.width));
     }
+    if (host_transport) {
+        HostWorld* h = g.host = new HostWorld();
+        h->nranks = nranks; h->rank = rank;
+        h->slot = sizeof(uint64_t) * (size_t)g.every * (size_t)g.width;
+        h->len = sizeof(HostWorld::Head) + 2 * (size_t)nranks * h->slot + 2 * (size_t)nranks * sizeof(double);
+        uint64_t fnv = 1469598103934665603ull;                              // the segment's name: a hash of the 128 id bytes
+        for (size_t i = 0; i < TBX_GATHER_ID_BYTES; i++) fnv = (fnv ^ ((const uint8_t*)id)[i]) * 1099511628211ull;
+        snprintf(h->name, sizeof h->name, "/tbx_hg_%016llx", (unsigned long long)fnv);
+        GHIP(hipHostMalloc((void**)&h->stage_out, h->slot, hipHostMallocDefault));
+        GHIP(hipHostMalloc((void**)&h->gathered, (size_t)nranks * h->slot, hipHostMallocDefault));
+        memset(h->stage_out, 0, h->slot);
+        memset(h->gathered, 0, (size_t)nranks * h->slot);
+        const int fd = shm_open(h->name, O_CREAT | O_RDWR, 0600);
+        if (fd < 0) return e->fail(TBX_E_NO_DEVICE, "gather: shm_open failed for the host transport");
+        if (ftruncate(fd, (off_t)h->len) != 0) { close(fd); return e->fail(TBX_E_NO_DEVICE, "gather: ftruncate failed"); }
+        void* m = mmap(nullptr, h->len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);     // a fresh segment reads as zeros
+        close(fd);
+        if (m == MAP_FAILED) return e->fail(TBX_E_NO_DEVICE, "gather: mmap failed");
+        h->map = m;
+        // collective like ncclCommInitRank: returns once every rank has attached
+        __atomic_store_n(&h->head()->seq[2][rank], (uint64_t)1, __ATOMIC_RELEASE);
+        if (!h->wait_all(2, 1)) return e->fail(TBX_E_NO_DEVICE, "gather: not every rank attached to the host transport's segment");
+        g.comm_count = nranks;
+        return TBX_OK;
+    }
     tbx_nccl_id_t uid;
     memcpy(&uid, id, sizeof uid);
     GNCCL(g.comm_init_rank(&g.comm, nranks, uid, rank));
     GNCCL(g.comm_count_fn(g.comm, &g.comm_count));
     if (g.comm_count != nranks) return e->fail(TBX_E_NO_DEVICE, "gather: the communicator does not span the ranks asked for");
+    return TBX_OK;
+}
+
+// the host transport's collective: records device -> page-locked memory on the communication stream, the host WAITS for them
+// (so the step that wrote them has finished), exchange through the segment, gathered block -> device.  The caller's thread is
+// blocked for the length of the step + the exchange: a fallback and a dress rehearsal, not the product's data path.
+static int host_collective(tbx_engine* e, GatherState& g, const uint64_t* send_dev, uint64_t* out_dev, hipStream_t gs)
+{
+    HostWorld& h = *g.host;
+    GHIP(hipMemcpyAsync(h.stage_out, send_dev, h.slot, hipMemcpyDeviceToHost, gs));
+    GHIP(hipStreamSynchronize(gs));
+    if (!h.exchange_records(h.stage_out, h.gathered)) return e->fail(TBX_E_NO_DEVICE, "gather: a rank did not reach the collective (host transport)");
+    GHIP(hipMemcpyAsync(out_dev, h.gathered, (size_t)h.nranks * h.slot, hipMemcpyHostToDevice, gs));
     return TBX_OK;
 }
 
@@ -271,7 +391,11 @@ int tbx_gather(tbx_engine* e, uint64_t* out_dev, void* stream)
         const int p = g.ring_par;
         GHIP(tbx_wait_tail(e, gs, true));
         if (g.any && g.done_on[g.last_par] != gs) GHIP(hipStreamWaitEvent(gs, g.done[g.last_par], 0));
-        GNCCL(g.all_gather(g.ring[p], out_dev ? out_dev : g.out, (size_t)g.every * (size_t)g.width, TBX_NCCL_UINT64, g.comm, gs));
+        if (g.host) {
+            int rc = host_collective(e, g, g.ring[p], out_dev ? out_dev : g.out, gs);
+            if (rc) return rc;
+        } else
+            GNCCL(g.all_gather(g.ring[p], out_dev ? out_dev : g.out, (size_t)g.every * (size_t)g.width, TBX_NCCL_UINT64, g.comm, gs));
         g.last_par = p;
         GHIP(hipEventRecord(g.done[p], gs));
         g.done_on[p] = gs;
@@ -290,7 +414,11 @@ int tbx_gather(tbx_engine* e, uint64_t* out_dev, void* stream)
         GHIP(hipGetLastError());
         send = g.send;
     }
-    GNCCL(g.all_gather(send, out_dev ? out_dev : g.out, (size_t)g.width, TBX_NCCL_UINT64, g.comm, gs));
+    if (g.host) {
+        int rc = host_collective(e, g, send, out_dev ? out_dev : g.out, gs);
+        if (rc) return rc;
+    } else
+        GNCCL(g.all_gather(send, out_dev ? out_dev : g.out, (size_t)g.width, TBX_NCCL_UINT64, g.comm, gs));
     // ... and before the next step that rewrites these records (tbx_gather_before_step)
     g.last_par = e->out_par;
     GHIP(hipEventRecord(g.done[g.last_par], gs));
@@ -330,6 +458,10 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout_host)
     if (!inout_host) return e->fail(TBX_E_INVALID, "value pointer is NULL");
     GatherState& g = *e->gather;
     GHIP(hipSetDevice(e->device));
+    if (g.host) {
+        if (!g.host->max_scalar(inout_host)) return e->fail(TBX_E_NO_DEVICE, "gather: a rank did not reach the reduction (host transport)");
+        return TBX_OK;
+    }
     if (g.any) GHIP(hipStreamWaitEvent(g.stream, g.done[g.last_par], 0));     // one collective of a communicator at a time
     GHIP(hipMemcpyAsync(g.scalar, inout_host, sizeof(double), hipMemcpyHostToDevice, g.stream));
     GNCCL(g.all_reduce(g.scalar, g.scalar, 1, TBX_NCCL_FLOAT64, TBX_NCCL_MAX, g.comm, g.stream));
@@ -342,7 +474,7 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout_host)
 int tbx_gather_nranks(tbx_engine* e)
 {
     if (!e) return TBX_E_INVALID;
-    if (!e->gather || !e->gather->comm) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called");
+    if (!e->gather || (!e->gather->comm && !e->gather->host)) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called");
     return e->gather->comm_count;
 }
 

@@ -169,57 +169,16 @@ struct RowStager {
         }
     }
 
-    // Units whose size is no multiple of 128 bytes (Amidar: 10 scanlines x 480 B = 4 800 B = 64 x 75) start, every other one,
-    // 64 bytes into a 128-byte line, and a 1-KiB store instruction that starts there touches nine lines instead of eight:
-    // scripts/ubench/write_align.hip (profiles/r05_write_align.txt) -- the same store stream runs 8-11 % slower with every
-    // unit moved by 64 bytes, 15 % by 16 bytes, and Amidar's geometry gains 9 % with 128-byte aligned unit starts, while the
-    // alignment of the FRAMES (128 B .. 4 KiB strides) changes nothing.  The "_aligned" forms below keep the dense layout and
-    // shift the lane -> chunk mapping instead: lane l of store instruction i writes chunk 64 i + l COUNTED FROM THE 128-BYTE
-    // LINE dst LIES IN, so every instruction covers whole lines; the `head` chunks in front of dst are masked off in the
-    // first instruction and the unit's last instruction takes what is left (same instruction count: 300 + 4 chunks are still 5).
-    static constexpr bool UNIT_STARTS_ALIGNED = UNIT_BYTES % 128 == 0;
-
-    static __device__ __forceinline__ void fill_unit_aligned(uint8_t* dst, int lane, uint32_t p)
-    {
-        if (UNIT_STARTS_ALIGNED) { fill_unit(dst, lane, p); return; }
-        const int head = __builtin_amdgcn_readfirstlane((int)(((uintptr_t)dst >> 4) & 7u));
-        uint4* out = reinterpret_cast<uint4*>(dst) - head;
-        constexpr int chunks = UNIT_BYTES / 16;
-        if (C == 3) {
-            const uint32_t q = p & 0xFFFFFFu;
-            const uint32_t d0 = q | (q << 24), d1 = (q >> 8) | (q << 16), d2 = (q >> 16) | (q << 8);
-            const int ph0 = (lane + 9 - head) % 3;          // phase of chunk (lane - head) of the unit
-#pragma unroll
-            for (int i = 0; i < (chunks + 7 + 63) / 64; i++) {
-                const int c = lane + 64 * i;
-                const int ph = (ph0 + i) % 3;
-                const uint4 v = ph == 0 ? make_uint4(d0, d1, d2, d0) : ph == 1 ? make_uint4(d1, d2, d0, d1) : make_uint4(d2, d0, d1, d2);
-                if (c >= head && c < chunks + head) tbx_store16(out + c, v);
-            }
-        } else {
-            const uint32_t q = C == 1 ? p * 0x01010101u : (p | 0xFF000000u);
-            const uint4 v = make_uint4(q, q, q, q);
-#pragma unroll
-            for (int i = 0; i < (chunks + 7 + 63) / 64; i++) {
-                const int c = lane + 64 * i;
-                if (c >= head && c < chunks + head) tbx_store16(out + c, v);
-            }
-        }
-    }
-
-    __device__ __forceinline__ void flush_aligned(uint8_t* dst, int lane, int rows = R) const
-    {
-        if (UNIT_STARTS_ALIGNED) { flush(dst, lane, rows); return; }
-        const int chunks = rows * (ROW_BYTES / 16);
-        const int head = __builtin_amdgcn_readfirstlane((int)(((uintptr_t)dst >> 4) & 7u));
-        const uint4* src = reinterpret_cast<const uint4*>(lds);
-        uint4* out = reinterpret_cast<uint4*>(dst);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-        for (int i = lane - head; i < chunks; i += 64)
-            if (i >= 0) tbx_store16(out + i, src[i]);
-        __builtin_amdgcn_wave_barrier();
-    }
+    // Store ADDRESSES (round 5).  Units whose size is no multiple of 128 bytes (Amidar: 10 scanlines x 480 B
+    // = 4 800 B = 64 x 75) start, every other one, 64 bytes into a 128-byte line, and a 1-KiB store instruction that starts
+    // there touches nine lines instead of eight.  As a PURE store stream that costs 8-11 % (scripts/ubench/write_align.hip,
+    // profiles/r05_write_align.txt: every unit moved by 64 bytes; 15 % for 16 bytes; Amidar's geometry +9 % with 128-byte
+    // aligned unit starts), while the alignment of the FRAMES -- dense, or strides rounded up to 128 B .. 4 KiB -- changes
+    // nothing (+-1 %).  Inside the rasteriser it does not carry over: a flush whose lane -> chunk mapping is counted from the
+    // 128-byte line dst lies in (every instruction covers whole lines, the chunks in front of dst masked off, 38 instead of 42
+    // line requests per misaligned unit, same instruction count) was parity-green and 2.7 % SLOWER for Amidar RGB (1.412
+    // against 1.371 ms at 65 536 envs) and gray (0.685 / 0.667), within noise at 4 096 (profiles/r05_experiments.txt) --
+    // removed.  The rasterisers' store rate is address-independent; what bounds it is in DESIGN.md section 6.
 
     // write `rows` staged scanlines to dst (16-byte aligned, contiguous)
     __device__ __forceinline__ void flush(uint8_t* dst, int lane, int rows = R) const

@@ -350,7 +350,7 @@ struct tbx_engine {
     bool has_last = false;
     hipEvent_t order_ev = nullptr;
     bool step_carries_order_ev = false;        // order_ev is the completion event of the last launch on last_stream (a batch step)
-    int opt[TBX_OPT_COUNT] = {0, 0, 0, 0, 1, 1};
+    int opt[TBX_OPT_COUNT] = {0, 0, 0, 0, 1, 1, 0};
     bool gather_ring = false;                  // a K-step record ring is in force (TBX_OPT_GATHER_EVERY > 1 at tbx_gather_init): no pipelined mode
     bool gather_wants_step_event = false;      // the next batch step is one a collective will wait for: its launch carries the ordering event
     TbxPipe pipe;
@@ -482,6 +482,12 @@ struct TbxEditArgs {
     int n;
     const double* per_env;        // device [N][n] or nullptr
     __device__ __forceinline__ double get(int env, int i) const { return i >= n ? 0.0 : per_env ? per_env[(size_t)env * n + i] : v[i]; }
+    // an unsigned 32-bit argument (masks, seeds, counters: integers below 2^32 are exact in binary64)
+    __device__ __forceinline__ uint32_t getu(int env, int i) const
+    {
+        const double x = get(env, i);
+        return x >= 4294967295.0 ? 0xFFFFFFFFu : x > 0.0 ? (uint32_t)x : 0u;
+    }
     __device__ __forceinline__ int geti(int env, int i) const
     {
         double x = get(env, i);

@@ -380,6 +380,24 @@ class Engine:
         asynchronous copies of step_begin / agent_step_begin.  The memory lives as long as the array or any view of it."""
         return HostArray.make(self._lib, shape, dtype)
 
+    def host_stack_push(self, dst, src, plane, done=None, reset=False, fill_repeat=False, threads=0):
+        """tbx_host_stack_push: dst = VecFrameStack's next stackedobs (uint8[N, h, w, stack]) from src (may be dst itself), the
+        newly received plane uint8[N, h, w] and the done flags -- the roll of vec_frame_stack.py:17-27 as threaded host code"""
+        n, h, w, k = dst.shape
+        if src.shape != dst.shape or plane.shape != (n, h, w) or dst.dtype != np.uint8 or src.dtype != np.uint8 or plane.dtype != np.uint8:
+            raise ValueError("host_stack_push: uint8 stacks [N, h, w, stack] and a uint8 plane [N, h, w] are needed")
+        d = None
+        if done is not None:
+            d = np.ascontiguousarray(done, dtype=np.uint8)
+            if d.shape != (n,):
+                raise ValueError("done must have one entry per env")
+        rc = self._lib.tbx_host_stack_push(_addr(dst), _addr(src), _addr(plane), _ptr(d), int(bool(reset)), n, h * w, k,
+                                           int(bool(fill_repeat)), int(threads))
+        if rc != _abi.OK:
+            msg = self._lib.tbx_last_error(None)
+            raise ToyboxAmdError(rc, msg.decode() if msg else "tbx_host_stack_push failed")
+        return dst
+
     def agent_step_begin(self, actions, reward=None, done=None, obs=None, plane=None, ep_done=None, ep_return=None, ep_length=None):
         """tbx_agent_step_begin: queues actions -> device, the agent step and the copies of the requested outputs into the given
         host arrays (C-contiguous, of the documented dtypes; page-locked ones from host_array() keep the call asynchronous);

@@ -37,6 +37,17 @@ def hash_seed(seed, max_bytes=8):
     return int.from_bytes(digest[:max_bytes], "little")
 
 
+def _int_list_from_bigint(bigint):
+    """gym.utils.seeding._int_list_from_bigint: little-endian 32-bit words, none for the zero high part ([0] for 0)"""
+    if bigint == 0:
+        return [0]
+    ints = []
+    while bigint > 0:
+        bigint, mod = divmod(bigint, 2 ** 32)
+        ints.append(mod)
+    return ints
+
+
 class MockALE:
     """What baselines' wrappers read from `env.unwrapped.ale` (EpisodicLifeEnv: lives(); envs/atari/base.py:15-35)."""
 
@@ -98,15 +109,16 @@ class ToyboxBaseEnv(_EnvBase):
         return self._np_random
 
     def seed(self, seed=None):
-        # gym.utils.seeding.np_random of the gym era the reference targets (envs/atari/base.py:84-98): the RandomState is seeded
-        # with the two 32-bit halves of hash_seed(seed), not with the seed itself -- NoopResetEnv's draws depend on it
-        first = int.from_bytes(os.urandom(4), "little") % 2 ** 31 if seed is None else int(seed)
-        if _gym is not None and hasattr(_gym, "utils") and hasattr(_gym.utils, "seeding"):
-            self._np_random, first = _gym.utils.seeding.np_random(first)
-        else:
-            h = hash_seed(first)
-            self._np_random = np.random.RandomState()
-            self._np_random.seed([(h >> (32 * i)) & 0xFFFFFFFF for i in range(2)])
+        # gym.utils.seeding.np_random of the gym era the reference targets (envs/atari/base.py:84-98), restated rather than
+        # called: from gym 0.26 on that function returns a numpy Generator, which has no .randint (NoopResetEnv calls
+        # unwrapped.np_random.randint, atari_wrappers.py:124) and draws another stream.  create_seed: an int is taken modulo
+        # 2**64, None becomes 8 bytes of OS entropy; the RandomState is seeded with the little-endian 32-bit words of
+        # hash_seed(seed) -- zero high words dropped, as _int_list_from_bigint leaves them out -- not with the seed itself.
+        if seed is not None and not (isinstance(seed, (int, np.integer)) and seed >= 0):
+            raise ValueError("Seed must be a non-negative integer or omitted, not %r" % (seed,))
+        first = int.from_bytes(os.urandom(8), "big") if seed is None else int(seed) % 2 ** 64
+        self._np_random = np.random.RandomState()
+        self._np_random.seed(_int_list_from_bigint(hash_seed(first)))
         second = hash_seed(first + 1) % 2 ** 31
         self.toybox.set_seed(second)
         self.toybox.new_game()                          # the simulator's seed only acts through a new game

@@ -242,9 +242,10 @@ class ToyboxPreprocVecEnv:
                                 PlaneStack over the newest `stack` of them -- a quarter of the bytes, no roll at all; a
                                 finished env's older planes are zeroed (frame_stack="env": overwritten with the reset
                                 observation) in place, exactly the values VecFrameStack / FrameStack produce;
-      "host_stack"              the same one-plane transfer, then the stack is rolled on the host into a real
-                                uint8[N, size, size, stack] array of the rotating pool (np.roll's data movement, done by
-                                numpy: meant for the few dozen envs the reference's learners run, not for 10^4).
+      "host_stack"              the same one-plane transfer, then VecFrameStack's roll on the host into a real
+                                uint8[N, size, size, stack] array of the rotating pool (tbx_host_stack_push: np.roll's data
+                                movement as threaded host code; 9 bytes of host memory traffic per pixel, so at 10^4 envs it is
+                                the host's memory system that sets the rate, not the link).
     step_async() queues the device work and the copies; step_wait() waits for them (vec_env/__init__.py:67-87)."""
 
     def __init__(self, game, num_envs, skip=4, size=84, stack=4, clip_rewards=True, seed=None, engine=None,
@@ -287,7 +288,7 @@ class ToyboxPreprocVecEnv:
             self._head = 0                       # ring slot of the newest plane
             if obs_layout == "host_stack":
                 self._ring = self._ring[:1]      # one landing plane is enough: the stack itself lives in the pool arrays
-                self._stacked = np.zeros((n, size, size, stack), np.uint8)
+                self._stacked = None             # the array the last observation went out in (the roll's source)
         self._st = {"reward": self.engine.host_array((n,), np.float32), "done": self.engine.host_array((n,), np.uint8),
                     "ep_done": self.engine.host_array((n,), np.uint8), "ep_return": self.engine.host_array((n,), np.float32),
                     "ep_length": self.engine.host_array((n,), np.int32)}
@@ -323,17 +324,10 @@ class ToyboxPreprocVecEnv:
                 for p in older:                  # stackedobs[i] = 0  (FrameStack.reset: the observation k times)
                     p[idx] = landed[idx] if self._fill_repeat else 0
             return PlaneStack(older[::-1] + [landed])
-        st = self._stacked
-        if reset:
-            st[...] = landed[..., None] if self._fill_repeat else 0
-        else:
-            st[...] = np.roll(st, shift=-1, axis=-1)
-            idx = np.flatnonzero(done)
-            if len(idx):
-                st[idx] = landed[idx][..., None] if self._fill_repeat else 0
-        st[..., -1] = landed
-        out = self._next_obs_array()
-        out[...] = st
+        out = self._next_obs_array()                 # (one pool array: rolled in place)
+        src = self._stacked if self._stacked is not None else out
+        self.engine.host_stack_push(out, src, landed, done=None if reset else done, reset=reset, fill_repeat=self._fill_repeat)
+        self._stacked = out
         return out
 
     def _obs(self, obs):

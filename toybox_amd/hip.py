@@ -109,29 +109,38 @@ def memcpy_htod(dst_ptr, src_array, nbytes):
           "hipMemcpy H2D")
 
 
+class _PinnedBlock:
+    """owner of one hipHostMalloc block; freed when the last numpy view of it is gone"""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        check(runtime().hipHostMalloc(C.byref(self.ptr), C.c_size_t(max(nbytes, 1)), C.c_uint(0)), "hipHostMalloc")
+        self.buf = (C.c_uint8 * max(nbytes, 1)).from_address(self.ptr.value)
+        self.buf._owner = self                          # the ctypes array is the base of every view: views keep the block
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                runtime().hipHostFree(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
 class PinnedArray:
     """A numpy array over page-locked host memory (hipHostMalloc): the destination of frame copies that are to run at the PCIe
-    link's rate (a copy into pageable memory is staged through a bounce buffer and faults fresh pages in)."""
+    link's rate (a copy into pageable memory is staged through a bounce buffer and faults fresh pages in).  The memory belongs to
+    the array and its views: close() only drops this object's reference, and the block is released when the last view has gone
+    (an observation kept past close() used to point at freed memory: ADVICE r04)."""
 
     def __init__(self, shape, dtype="uint8"):
         import numpy as np
         self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        self._ptr = C.c_void_p()
-        check(runtime().hipHostMalloc(C.byref(self._ptr), C.c_size_t(max(self.nbytes, 1)), C.c_uint(0)), "hipHostMalloc")
-        buf = (C.c_uint8 * max(self.nbytes, 1)).from_address(self._ptr.value)
-        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        block = _PinnedBlock(self.nbytes)
+        self.array = np.frombuffer(block.buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def close(self):
-        if self._ptr:
-            self.array = None
-            runtime().hipHostFree(self._ptr)
-            self._ptr = C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        self.array = None
 
 
 def mem_info():

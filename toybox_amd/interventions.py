@@ -27,6 +27,8 @@ from .games import codec
 
 TILE_TAGS = ["Empty", "Unpainted", "Painted", "ChaseMarker"]       # interventions/amidar.py:55-59; index == TBX_TILE_*
 TILE_WX, TILE_WY = 64, 80                                         # world units per tile (TBX_AMI_TILE_WX / WY)
+BOARD_W, BOARD_H = 32, 31                                         # TBX_AMI_BOARD_W / H
+DIRECTIONS = ["Up", "Down", "Left", "Right"]                      # interventions/core.py:125-135; index == TBX_DIR_*
 
 
 def diff_states(a, b, rel_tol=1e-9, prefix=""):
@@ -96,9 +98,13 @@ class BatchIntervention:
         return self._states
 
     def _flush(self):
-        """a device-side helper is about to run: records edited on the host go down first, and the host copy is dropped"""
+        """a device-side helper is about to run: records edited on the host go down first, and the host copy is dropped.
+        An array a caller took from `.states` before this point is STALE afterwards (the device state has moved on): it is made
+        read-only, so that a later write through it raises instead of being lost -- read `.states` again."""
         if self.dirty_state:
             self.engine.set_states_np(self.first, self._states)
+        if self._states is not None:
+            self._states.flags.writeable = False
         self._states = None
         self._before = None
 
@@ -240,6 +246,38 @@ class BatchIntervention:
         self._need("breakout")
         return self._reduce(_abi.QUERY_BRK_FIND_CHANNEL)[:, 0].astype(np.int64)
 
+    def brick_table(self, env=0):
+        """the attributes of the bricks that a predicate may look at, as the reference's Brick objects carry them (:196-222), from
+        env `env` of the range: everything but `alive` is the same in every env of a batch that shares its config"""
+        from types import SimpleNamespace
+        js = self.json(env)
+        out = []
+        for b in js["bricks"]:
+            ns = SimpleNamespace(**{k: v for k, v in b.items() if k not in ("position", "size", "color")})
+            ns.position = SimpleNamespace(**b["position"]); ns.size = SimpleNamespace(**b["size"]); ns.color = SimpleNamespace(**b["color"])
+            out.append(ns)
+        return out
+
+    def find_brick(self, pred, alive=None):
+        """:400-404 over the batch -> int[N]: the index of the first brick that satisfies the predicate, -1 where none does (the
+        reference raises ValueError for its one env).  `pred` is either a boolean mask over brick indices or a Python predicate
+        over a brick's STATIC attributes (row, col, points, depth, color, position, size, destructible): it is evaluated ONCE over
+        the brick table -- those attributes are the same in every env -- and turned into the mask of TBX_QUERY_BRK_FIND_BRICK.
+        The one per-env attribute, `alive`, is given beside it: alive=True / False restricts the search, None takes either.
+        (A predicate that reads b.alive sees env 0's flags: pass alive= instead.)"""
+        self._need("breakout")
+        if callable(pred):
+            mask = np.array([bool(pred(b)) for b in self.brick_table()], bool)
+        else:
+            mask = np.asarray(pred, bool)
+        if mask.ndim != 1 or len(mask) > _abi.BRK_MAX_BRICKS:
+            raise ValueError("the brick mask must be one-dimensional with at most %d entries" % _abi.BRK_MAX_BRICKS)
+        bits = np.zeros(8 * 32, np.uint64)
+        bits[:len(mask)] = mask
+        words = [int((bits[32 * k:32 * k + 32] << np.arange(32, dtype=np.uint64)).sum()) for k in range(8)]
+        want = -1 if alive is None else int(bool(alive))
+        return self._reduce(_abi.QUERY_BRK_FIND_BRICK, want, *words)[:, 0].astype(np.int64)
+
     def add_channel(self, i, envs=None):
         """:392-396: turns column i into a channel (i may be an array: env k gets column i[k])"""
         self._need("breakout")
@@ -342,11 +380,18 @@ class BatchIntervention:
     def set_mode(self, mode, set_time=None, envs=None):
         """:402-416"""
         self._need("amidar")
-        given = set_time is not None and (np.ndim(set_time) > 0 or bool(set_time))      # (the reference: `set_time or config[...]`)
+        def timer(default):
+            # the reference: `set_time or config[...]` -- a zero (or missing) time means the config's; per env for an array
+            if set_time is None:
+                return default
+            if np.ndim(set_time) > 0:
+                t = np.asarray(set_time)
+                return np.where(t == 0, default, t)
+            return set_time if set_time else default
         if mode == "jump":
-            self._edit(_abi.EDIT_AMI_TIMERS, set_time if given else self.config["jump_time"], -1, envs=envs)
+            self._edit(_abi.EDIT_AMI_TIMERS, timer(self.config["jump_time"]), -1, envs=envs)
         elif mode == "chase":
-            self._edit(_abi.EDIT_AMI_TIMERS, -1, set_time if given else self.config["chase_time"], envs=envs)
+            self._edit(_abi.EDIT_AMI_TIMERS, -1, timer(self.config["chase_time"]), envs=envs)
         elif mode == "regular":
             self._edit(_abi.EDIT_AMI_TIMERS, 0, 0, envs=envs)
         else:
@@ -388,6 +433,68 @@ class BatchIntervention:
         """len(filter_tiles(lambda t: t.tag == tag)) :483-488 -> int[N]"""
         self._need("amidar")
         return self._reduce(_abi.QUERY_AMI_COUNT_TILES, TILE_TAGS.index(tag))[:, 0].astype(np.int64)
+
+    @staticmethod
+    def _tag_mask(tags):
+        """tag names (or a predicate over a tag name) -> bit mask over TILE_TAGS"""
+        if callable(tags):
+            return sum(1 << i for i, t in enumerate(TILE_TAGS) if tags(t))
+        if isinstance(tags, str):
+            tags = [tags]
+        return sum(1 << TILE_TAGS.index(t) for t in tags)
+
+    def filter_tiles(self, tags=lambda tag: True):
+        """:494-499 for predicates on the tile's tag -> bool[N, 31, 32]: [env, ty, tx] is set where the reference's list would
+        hold tile (tx, ty).  `tags`: a tag name, a collection of them, or a predicate over the tag name (evaluated once for
+        each of the four tags).  np.argwhere(result[env]) lists the tiles in the reference's row-by-row order."""
+        self._need("amidar")
+        rows = self._reduce(_abi.QUERY_AMI_TILES_MASK, self._tag_mask(tags))[:, :BOARD_H].astype(np.uint64)
+        return ((rows[:, :, None] >> np.arange(BOARD_W, dtype=np.uint64)[None, None, :]) & np.uint64(1)).astype(bool)
+
+    def count_filtered_tiles(self, tags):
+        """len(filter_tiles(pred on the tag)) -> int[N]"""
+        self._need("amidar")
+        return self._reduce(_abi.QUERY_AMI_TILES_MASK, self._tag_mask(tags))[:, 31].astype(np.int64)
+
+    @staticmethod
+    def tile_to_tilepoint(tx, ty):
+        """:501-506: in the reference a Tile object is looked up by identity to find its (tx, ty); a batched tile IS its (tx, ty)"""
+        return np.asarray(tx), np.asarray(ty)
+
+    @classmethod
+    def tile_to_worldpoint(cls, tx, ty):
+        """:512-514"""
+        return cls.tilepoint_to_worldpoint(tx, ty)
+
+    def get_random_tile(self, tags=lambda tag: True, seed=0, draw=0, env_offset=0, min_enemy_distance=0):
+        """:360-378 with the counter rule instead of `random` (include/toybox_amd.h): draw number `draw` of env e picks element
+        splitmix64(seed ^ (env_offset + e) << 32 ^ draw) mod len of the list filter_tiles(pred) would return for that env --
+        uniform over exactly the tiles the reference's rejection loop can return, reproducible, not `random`-compatible.
+        pred: the tag is in `tags` and (min_enemy_distance > 0) set_player_random_start's within_min_manhattan.
+        -> (tx int[N], ty int[N], tag object[N], candidates int[N]); -1 / None where an env has no candidate (the reference raises)."""
+        self._need("amidar")
+        r = self._reduce(_abi.QUERY_AMI_RANDOM_TILE, seed, draw, env_offset, self._tag_mask(tags), min_enemy_distance).astype(np.int64)
+        return r[:, 0], r[:, 1], np.array([TILE_TAGS[v] if v >= 0 else None for v in r[:, 2]], dtype=object), r[:, 3]
+
+    def get_random_track_position(self, seed=0, draw=0, env_offset=0):
+        """:380-386 -> world (x int[N], y int[N]) of a random tile whose tag is not Empty"""
+        tx, ty, _, _ = self.get_random_tile(lambda tag: tag != "Empty", seed, draw, env_offset)
+        x, y = self.tilepoint_to_worldpoint(tx, ty)
+        return np.where(tx >= 0, x, -1), np.where(ty >= 0, y, -1)
+
+    def set_player_random_start(self, min_enemy_distance=5, seed=0, draw=0, env_offset=0, envs=None):
+        """:541-548 on the device: the player of every selected env goes to get_random_tile(within_min_manhattan) -- ANY tile, as
+        the reference draws it (its predicate does not ask for a walkable one), for which not every enemy is nearer than
+        min_enemy_distance"""
+        self._need("amidar")
+        self._edit(_abi.EDIT_AMI_PLAYER_RANDOM_START, seed, draw, env_offset, min_enemy_distance, envs=envs)
+
+    def get_random_dir_for_tile(self, tx, ty, seed=0, draw=0, env_offset=0):
+        """:550-583 -> direction names, object array [N]: drawn (counter rule) among those of Up, Down, Left, Right whose neighbour
+        tile is walkable; None where there is none (the reference raises)"""
+        self._need("amidar")
+        r = self._reduce(_abi.QUERY_AMI_RANDOM_DIR, seed, draw, env_offset, tx, ty).astype(np.int64)
+        return np.array([DIRECTIONS[v] if v >= 0 else None for v in r[:, 0]], dtype=object)
 
     @staticmethod
     def tilepoint_to_worldpoint(tx, ty):

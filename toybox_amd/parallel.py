@@ -193,9 +193,10 @@ class ShardedBatch:
     """
 
     def __init__(self, engine_factory, n_global, rank=0, world=1, seed_base=1234, host_dist=None, rdzv_tag="", rdzv_key=None,
-                 gather_every=1):
+                 gather_every=1, transport="rccl"):
         self.rank, self.world = int(rank), int(world)
         self.gather_every = max(1, int(gather_every))   # K-step record ring (TBX_OPT_GATHER_EVERY): one collective per K steps
+        self.transport = transport                      # "rccl", or "host": tbx_gather over shared memory (TBX_OPT_GATHER_TRANSPORT)
         self.n_global = int(n_global)
         self.start, self.end = shard_range(n_global, self.world, self.rank)
         self.n_local = self.end - self.start
@@ -212,9 +213,11 @@ class ShardedBatch:
 
     def _make_communicator(self):
         tag, key = self._rdzv
+        from . import _abi
         uid = exchange_unique_id(self.rank, self.world, self.engine.gather_unique_id, tag=tag, key=key)
+        if self.transport == "host":
+            self.engine.set_option(_abi.OPT_GATHER_TRANSPORT, _abi.GATHER_HOST)
         if self.gather_every > 1:
-            from . import _abi
             self.engine.set_option(_abi.OPT_GATHER_EVERY, self.gather_every)   # read by gather_init
         self.engine.gather_init(self.world, self.rank, uid, records_per_rank=self.width)   # collective
         forget_unique_id(self.rank, tag=tag, key=key)
@@ -307,12 +310,13 @@ class MixedBatch:
     def _stream(self, i):
         return self.streams[i] if self.streams else 0
 
-    def gather_init(self, rank, world, rdzv_key=None, gather_every=1):
+    def gather_init(self, rank, world, rdzv_key=None, gather_every=1, transport="rccl"):
         """One communicator per game segment (every rank holds the same three segments); gather_every = K: a K-step record
-        ring per segment (TBX_OPT_GATHER_EVERY)."""
+        ring per segment (TBX_OPT_GATHER_EVERY); transport "rccl" or "host" (TBX_OPT_GATHER_TRANSPORT)."""
         from . import _abi
         for g, e in zip(self.games, self.engines):
             uid = exchange_unique_id(rank, world, e.gather_unique_id, tag=g, key=rdzv_key)
+            e.set_option(_abi.OPT_GATHER_TRANSPORT, _abi.GATHER_HOST if transport == "host" else _abi.GATHER_RCCL)
             e.set_option(_abi.OPT_GATHER_EVERY, max(1, int(gather_every)))
             e.gather_init(world, rank, uid)
             forget_unique_id(rank, tag=g, key=rdzv_key)
