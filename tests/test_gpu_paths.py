@@ -570,7 +570,7 @@ def test_step1_on_a_batch_engine(lib, oracle_lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("game,n,mode", [("breakout", 40000, 2), ("breakout", 40000, 3), ("breakout", 3000, 3), ("breakout", 3000, 1),
                                          ("space_invaders", 20000, 2), ("space_invaders", 3000, 3), ("amidar", 20000, 3), ("amidar", 3000, 2),
-                                         ("gridworld", 5000, 3)])
+                                         ("amidar", 3000, 3), ("amidar", 12000, 2), ("gridworld", 5000, 3)])
 @pytest.mark.parametrize("same_stream", [True, False])
 def test_pipelined_mode_keeps_program_order(same_stream, game, n, mode, hip_lib, oracle_lib):
     """TBX_OPT_PIPELINE: tbx_step_synthetic on Breakout runs on the engine's step stream BESIDE the rasteriser launch queued
@@ -701,7 +701,7 @@ def test_results_stay_valid_for_readers_queued_before_the_next_call(mode, hip_li
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("game,n", [("breakout", 40000), ("space_invaders", 24000), ("amidar", 30000)])
+@pytest.mark.parametrize("game,n", [("breakout", 40000), ("space_invaders", 24000), ("amidar", 30000), ("amidar", 9000)])
 @pytest.mark.parametrize("mode", [2, 3])
 def test_pipelined_render_of_a_rewritten_state_is_not_overtaken_by_the_next_step(mode, game, n, hip_lib, oracle_lib):
     """ADVICE r03 (engine.hip, pipe_step): after new_game / set_state the render records are stale, so the first render of the

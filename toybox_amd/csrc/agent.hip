@@ -250,6 +250,9 @@ AgentWarpArgs warp_args(tbx_engine* e, int reset_mode)
     w.reset_mode = reset_mode;
     w.fill_repeat = a.cfg.stack_fill != 0;
     w.magic = (1ull << 42) / (uint64_t)(a.H * a.W) + 1ull;   // exact for numerators < 2^42 / area >= 2^25
+#ifdef TBX_DIAG
+    w.diag = getenv("TBX_AGENT_DIAG") ? atoi(getenv("TBX_AGENT_DIAG")) : 0;
+#endif
     return w;
 }
 

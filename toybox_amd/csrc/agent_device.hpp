@@ -23,7 +23,16 @@ struct AgentWarpArgs {
     int reset_mode;            // venv.reset(): every stack starts from zeros
     int fill_repeat;           // tbx_agent_config_t::stack_fill: a fresh stack holds the new frame in every slot, not zeros
     uint64_t magic;            // floor(2^42 / (H*W)) + 1
+#ifdef TBX_DIAG
+    int diag;                  // measurement builds only (make DIAG=1, scripts/agent_diag.sh; observations are WRONG with any bit set):
+                               // 1 no stack commit, 2 no scanline loop, 4 every scanline skipped, 8 never a second painter, 16 no fast rows
+#endif
 };
+#ifdef TBX_DIAG
+#define AGENT_DIAG(a, bit) (((a).diag & (bit)) != 0)
+#else
+#define AGENT_DIAG(a, bit) false
+#endif
 
 // which frames make up this env's observation (wave-uniform)
 struct ObsSel {
@@ -106,11 +115,53 @@ __device__ __forceinline__ void stack_push(uint8_t* px, uint32_t val, int fresh)
 constexpr int AGENT_MAX_OUT_PX = 84 * 84;
 
 // plane_env: where the env's newest plane goes as well (dense, the host-delivery form), or nullptr.
+//
+// Depth 4 and a whole number of pixel quads (84 x 84 is one): a lane takes FOUR consecutive pixels per turn -- one 32-bit LDS
+// read of the new bytes, one 16-byte load and one 16-byte store of their four stack words (1 KiB per instruction, like the
+// frame stores), and the roll of a word, (old >> 8) | (new << 24), is ONE v_perm_b32 that picks bytes 1, 2, 3 of the old
+// word and byte k of the LDS dword.  Round 5: the byte-at-a-time form before it cost 1 021 VALU and 418 memory instructions
+// per wave of si_agent_warp_kernel<4> (scripts/asm_attrib.py: 9 % of the kernel's VALU, a third of its memory instructions).
 template <int S>
 __device__ __forceinline__ void stack_commit(const uint8_t* vals, uint8_t* o, int n_px, int lane, int fresh, uint8_t* plane_env)
 {
     __builtin_amdgcn_wave_barrier();
-    if (plane_env) {                                   // (wave-uniform) vals is 16-byte aligned LDS; the plane 4-byte aligned when n_px % 4 == 0
+    if (S == 4 && (n_px & 3) == 0) {
+        const int nq = n_px >> 2;
+        const uint32_t* v4 = reinterpret_cast<const uint32_t*>(vals);
+        uint4* oq = reinterpret_cast<uint4*>(o);                         // n_px * 4 bytes per env: 16-byte aligned
+        uint32_t* p4 = reinterpret_cast<uint32_t*>(plane_env);
+        // byte selectors of v_perm_b32 over {new dword (bytes 4-7), old word (bytes 0-3)}; 0x0C selects a zero byte
+        const uint32_t keep = fresh == 0 ? 0x00030201u : fresh == 2 ? 0u : 0x000C0C0Cu;
+        const uint32_t rep = fresh == 2 ? 0x01010101u : 0x01000000u;    // where the new byte's selector goes
+        const uint32_t s0 = keep + 4u * rep, s1 = keep + 5u * rep, s2 = keep + 6u * rep, s3 = keep + 7u * rep;
+        constexpr int B = 4;                                             // quads in flight per lane
+        int i = lane;
+        for (; i + (B - 1) * 64 < nq; i += B * 64) {
+            uint4 old[B];
+            uint32_t w[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                w[k] = v4[i + 64 * k];
+                if (!fresh) old[k] = oq[i + 64 * k];
+                else old[k] = make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                oq[i + 64 * k] = make_uint4(__builtin_amdgcn_perm(w[k], old[k].x, s0), __builtin_amdgcn_perm(w[k], old[k].y, s1),
+                                            __builtin_amdgcn_perm(w[k], old[k].z, s2), __builtin_amdgcn_perm(w[k], old[k].w, s3));
+                if (plane_env) p4[i + 64 * k] = w[k];
+            }
+        }
+        for (; i < nq; i += 64) {
+            const uint32_t w = v4[i];
+            const uint4 old = fresh ? make_uint4(0u, 0u, 0u, 0u) : oq[i];
+            oq[i] = make_uint4(__builtin_amdgcn_perm(w, old.x, s0), __builtin_amdgcn_perm(w, old.y, s1), __builtin_amdgcn_perm(w, old.z, s2),
+                               __builtin_amdgcn_perm(w, old.w, s3));
+            if (plane_env) p4[i] = w;
+        }
+        return;
+    }
+    if (plane_env) {                                   // (wave-uniform)
         if ((n_px & 3) == 0) {
             const uint32_t* v4 = reinterpret_cast<const uint32_t*>(vals);
             uint32_t* p4 = reinterpret_cast<uint32_t*>(plane_env);
@@ -126,15 +177,7 @@ __device__ __forceinline__ void stack_commit(const uint8_t* vals, uint8_t* o, in
             for (int i = lane; i < n_px; i += 64) o4[i] = (uint32_t)vals[i] * spread;
             return;
         }
-        int i = lane;
-        for (; i + 7 * 64 < n_px; i += 8 * 64) {
-            uint32_t old[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) old[k] = o4[i + 64 * k];
-#pragma unroll
-            for (int k = 0; k < 8; k++) o4[i + 64 * k] = (old[k] >> 8) | ((uint32_t)vals[i + 64 * k] << 24);
-        }
-        for (; i < n_px; i += 64) o4[i] = (o4[i] >> 8) | ((uint32_t)vals[i] << 24);
+        for (int i = lane; i < n_px; i += 64) o4[i] = (o4[i] >> 8) | ((uint32_t)vals[i] << 24);
     } else {
         for (int i = lane; i < n_px; i += 64) stack_push<S>(o + (size_t)i * S, vals[i], fresh);
     }
@@ -334,7 +377,7 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
         stack_commit<S>(L.vals, o, a.oh * a.ow, lane, sel.zero, plane_env);
         return;
     }
-    const bool two = sel.two;
+    const bool two = sel.two && !AGENT_DIAG(a, 8);
     uint8_t* row = L.row;
     // painter B is the one that is always set up: slot B, or the single source of a one-frame observation
     pb.setup(sel.single == 0 ? dLive : sel.single == 1 ? dA : dB, env, lane, &L.cls[1][0][0]);
@@ -366,7 +409,7 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
     // scanlines whose horizontal sums the painter can give without painting (P::FAST_ROWS; SpaceInvaders: scanlines that hold
     // nothing but enemies): those of B's that frame A cannot change
     uint64_t fast[4] = {0ull, 0ull, 0ull, 0ull};
-    if (P::FAST_ROWS) {
+    if (P::FAST_ROWS && !AGENT_DIAG(a, 16)) {
         if (lane < 8) L.masks[0][lane] = P::fast_row_word(&L.cls[1][0][0], lane) & ~(two ? L.masks[1][lane] : 0u);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -393,12 +436,12 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
     int prev_kind = 0;                                                 // 0: the scanline above was skipped; else 1 + B painted + 2 * A painted
     uint32_t hl0 = 0u, hl1 = 0u;                                        // sums of the last composed scanline
 #pragma unroll 1
-    for (int wi = 0; wi < (H + 63) / 64; wi++) {
-        uint64_t nw = sel4(wi, need[0], need[1], need[2], need[3]);
+    for (int wi = 0; wi < (AGENT_DIAG(a, 2) ? 0 : (H + 63) / 64); wi++) {
+        uint64_t nw = AGENT_DIAG(a, 4) ? 0ull : sel4(wi, need[0], need[1], need[2], need[3]);
         uint64_t bw = sel4(wi, pb.busy[0], pb.busy[1], pb.busy[2], pb.busy[3]);
         uint64_t aw = sel4(wi, need_a[0], need_a[1], need_a[2], need_a[3]);
         uint64_t rb = sel4(wi, pb.rep[0], pb.rep[1], pb.rep[2], pb.rep[3]), ra = two ? sel4(wi, pa.rep[0], pa.rep[1], pa.rep[2], pa.rep[3]) : 0ull;
-        uint64_t fw = P::FAST_ROWS ? sel4(wi, fast[0], fast[1], fast[2], fast[3]) : 0ull;
+        uint64_t fw = P::FAST_ROWS && !AGENT_DIAG(a, 4) ? sel4(wi, fast[0], fast[1], fast[2], fast[3]) : 0ull;
         const int sy_end = min(H, 64 * wi + 64);
 #pragma unroll 1
         for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, bw >>= 1, aw >>= 1, rb >>= 1, ra >>= 1, fw >>= 1) {
@@ -457,5 +500,5 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
     }
     // the read-modify-write of the frame stack in one sweep with many loads in flight (a dependent load -> store per
     // output row, even fetched a row ahead, left this kernel waiting on HBM latency 84 times per env)
-    stack_commit<S>(L.vals, o, a.oh * a.ow, lane, sel.zero, plane_env);
+    if (!AGENT_DIAG(a, 1)) stack_commit<S>(L.vals, o, a.oh * a.ow, lane, sel.zero, plane_env);
 }

@@ -1228,7 +1228,9 @@ __device__ __forceinline__ void ami_step_body(const AmiDev& d, const AmiDev& slo
             }
         }
     }
-    ami_store(d, env, lane, s);
+    // (batch protocol: slot_a is the state buffer the frame's result goes to -- the one it came from, or, for a step that runs
+    // ahead of the previous frame's rasteriser, the other one: AmiOps::step_ahead)
+    ami_store(AGENT ? d : slot_a, env, lane, s);
     if (lane == 0) {
         d.prev_score[env] = prev;
         d.reward[env] = rew;
@@ -1247,6 +1249,16 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, ActionSou
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     if (rel >= count) return;
     ami_step_body<false>(d, d, d, src, flags, first_env + rel, lane);
+}
+
+// the same frame read from state buffer d and written to state buffer `next` (pipelined mode: the rasteriser of the previous
+// frame is still reading d)
+__global__ __launch_bounds__(TBX_BLOCK) void ami_step_ahead_kernel(AmiDev d, AmiDev next, ActionSource src, uint32_t flags, int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (rel >= count) return;
+    ami_step_body<false>(d, next, next, src, flags, rel, lane);
 }
 
 __global__ __launch_bounds__(TBX_BLOCK) void ami_agent_step_kernel(AmiDev d, AmiDev slot_a, AmiDev slot_b, ActionSource src, uint32_t flags, int first_env, int count)
@@ -2021,6 +2033,7 @@ struct AmiOps : GameOps {
     void destroy(tbx_engine*) override
     {
         hipFree(d.rng); hipFree(d.sc); hipFree(d.tiles); hipFree(d.boxes); hipFree(d.movers); hipFree(d.mh); hipFree(tab_dev);
+        hipFree(d2.rng); hipFree(d2.sc); hipFree(d2.tiles); hipFree(d2.boxes); hipFree(d2.movers); hipFree(d2.mh);
         hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.tiles); hipFree(dA.boxes); hipFree(dA.movers); hipFree(dA.mh);
         hipFree(dB.rng); hipFree(dB.sc); hipFree(dB.tiles); hipFree(dB.boxes); hipFree(dB.movers); hipFree(dB.mh);
     }
@@ -2059,6 +2072,32 @@ struct AmiOps : GameOps {
     void rebind_outputs(tbx_engine* e) override
     {
         d.reward = e->reward; d.done = e->done; d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed;
+    }
+
+    // ---- round 5, the one form not tried: the wave-per-env step of frame t + 1 on the engine's STEP STREAM beside the rasteriser
+    // of frame t (TBX_OPT_PIPELINE = 2 / 3, explicit values only, up to 16 384 envs), over TWO state buffers: it reads the
+    // buffer the rasteriser reads and writes the other one, which becomes the current one (GameOps::records_parity = the
+    // buffer a render launched now reads; the engine's fences keep step t + 2 behind the rasteriser of frame t).
+    AmiDev d2{};
+    int state_par = 0;
+    bool ahead_ok = false;
+    void options_changed(tbx_engine* e) override
+    {
+        ahead_ok = false;
+        if (e->opt[TBX_OPT_PIPELINE] >= 2 && e->n <= 16384 && alloc_slot(e, d2) == TBX_OK) ahead_ok = true;
+    }
+    bool pipeline_ok() const override { return ahead_ok; }
+    int records_parity() const override { return state_par; }
+    int step_ahead(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
+    {
+        AmiDev next = d;                                   // everything that is not per-frame state is shared
+        next.rng = d2.rng; next.sc = d2.sc; next.tiles = d2.tiles; next.boxes = d2.boxes; next.movers = d2.movers; next.mh = d2.mh;
+        TBX_LAUNCH_STEP(e, s, ami_step_ahead_kernel, grid_for(e->n), dim3(TBX_BLOCK), d, next, src, flags, e->n);
+        TBX_HIP(hipGetLastError());
+        d2.rng = d.rng; d2.sc = d.sc; d2.tiles = d.tiles; d2.boxes = d.boxes; d2.movers = d.movers; d2.mh = d.mh;
+        d = next;
+        state_par ^= 1;
+        return TBX_OK;
     }
 
     int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override

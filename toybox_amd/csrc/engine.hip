@@ -761,7 +761,8 @@ int tbx_host_stack_push(uint8_t* dst, const uint8_t* src, const uint8_t* plane, 
         if (T > 16) T = 16;
     }
     const long work = (long)n * px;
-    if (T > 1 && work < (1L << 18)) T = 1;                   // a few dozen envs: thread start-up costs more than the loop
+    if ((long)T > work >> 19) T = (int)(work >> 19);         // half a million pixels per thread at least: starting a thread costs ~20 us
+                                                             // (64 envs: 0.54 ms with sixteen threads, 0.07 with one)
     if (T > n) T = n > 0 ? n : 1;
     if (T <= 1) { host_stack_rows(dst, src, plane, done, reset, 0, n, px, stack, fill); return TBX_OK; }
     std::vector<std::thread> pool;
