@@ -483,7 +483,7 @@ def bench_host_protocol(args):
     contract as the reference spells it) and the agent pipeline through ToyboxPreprocVecEnv in its three layouts: whole
     uint8[N,84,84,4] stacks from the device (default pool / fresh pageable arrays), ONE new plane per env and step with the stack
     kept on the host as planes (the reference's data flow: subproc_vec_env.py:63-74 + vec_frame_stack.py:17-30), and the same
-    transfer rolled into a real array by numpy.  Never `value` of the headline: that one is measured with everything resident
+    transfer rolled into a real array on the host (tbx_host_stack_push, threaded).  Never `value` of the headline: that one is measured with everything resident
     in HBM."""
     import numpy as np
     from toybox_amd.envs import ToyboxPreprocVecEnv, ToyboxVecEnv
@@ -513,7 +513,7 @@ def bench_host_protocol(args):
     for name, layout, pool, per_env, steps in (("agent_planes_pinned_ring", "planes", 2, px, 4 * K),
                                                ("agent_device_stack_pinned_pool", "device_stack", 2, 4 * px, 2 * K),
                                                ("agent_device_stack_pageable_fresh_array", "device_stack", 0, 4 * px, K),
-                                               ("agent_host_stack_numpy_roll", "host_stack", 2, px, max(3, K // 4))):
+                                               ("agent_host_stack_native_roll", "host_stack", 2, px, max(3, K // 4))):
         env = ToyboxPreprocVecEnv(args.game, n, seed=SEED_BASE, obs_layout=layout, obs_pool=pool)
         arms[name] = run(env, "agent-steps/s", n * per_env, steps)
     best = arms["frames_pinned_pool"]
