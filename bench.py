@@ -114,6 +114,8 @@ def parse():
     ap.add_argument("--one-device", action="store_true",
                     help="every rank uses device 0 (with --gather host: the whole N-process flow on a one-GPU box; RCCL refuses two ranks "
                          "of one communicator on one device)")
+    ap.add_argument("--strict-rccl", action="store_true",
+                    help="N > 1: a run whose RCCL communicator cannot be made or verified FAILS (rc 4) instead of falling back to --gather host")
     ap.add_argument("--allow-no-gather", action="store_true",
                     help="N > 1 only: if no RCCL communicator can be made, run without the per-step gather (file barrier) instead of failing")
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1, 2, 3], help="TBX_OPT_PIPELINE of the main arm (1 = engine's choice)")
@@ -742,21 +744,22 @@ FUSED_NOTE = ("tbx_render_step_synthetic: the rasteriser of frame t and the batc
 GATHER_TRANSPORT = "rccl"      # --gather
 
 
-def make_communicator(eng, rank, world, width, gather_every, tag):
+def make_communicator(eng, rank, world, width, gather_every, tag, transport=None):
     """tbx_gather_init over `world` ranks (id from rank 0 through the rendezvous file), K-step record ring if asked.  Returns the
     `rccl` object of the JSON line; raises when no communicator over `world` ranks comes out of it."""
     from toybox_amd import _abi
     from toybox_amd.parallel import exchange_unique_id, forget_unique_id
-    if os.environ.get("TBX_BENCH_NO_RCCL") and GATHER_TRANSPORT == "rccl":
+    transport = transport or GATHER_TRANSPORT
+    if os.environ.get("TBX_BENCH_NO_RCCL") and transport == "rccl":
         raise RuntimeError("disabled by TBX_BENCH_NO_RCCL")
-    eng.set_option(_abi.OPT_GATHER_TRANSPORT, _abi.GATHER_HOST if GATHER_TRANSPORT == "host" else _abi.GATHER_RCCL)
+    eng.set_option(_abi.OPT_GATHER_TRANSPORT, _abi.GATHER_HOST if transport == "host" else _abi.GATHER_RCCL)
     eng.set_option(_abi.OPT_GATHER_EVERY, max(1, gather_every))
     with quiet_stdout():
         uid = exchange_unique_id(rank, world, eng.gather_unique_id, tag=tag)
         eng.gather_init(world, rank, uid, records_per_rank=width)   # collective (ncclCommInitRank)
     forget_unique_id(rank, tag=tag)
     K = eng.gather_every()
-    rccl = {"transport": GATHER_TRANSPORT, "nranks": eng.gather_nranks(), "records_per_rank": width, "gather_every": K,
+    rccl = {"transport": transport, "nranks": eng.gather_nranks(), "records_per_rank": width, "gather_every": K,
             "gather_bytes_per_collective": 8 * width * world * K, "gather_bytes_per_step": 8 * width * world, "lib": eng.gather_library()}
     if rccl["nranks"] != world:
         raise RuntimeError("the communicator spans %d ranks, not %d" % (rccl["nranks"], world))
@@ -811,18 +814,40 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
     gather = world > 1 or args.with_gather
     gather_note, rccl, fw = None, None, None
     if gather:
-        try:
-            rccl = make_communicator(eng, rank, world, width, args.gather_every, tag)
-            rccl["verified"] = verify_gather(eng, hip, rank, world, n, sizes, start)
-            eng.new_game()                 # (the verification stepped K frames)
-        except Exception as ex:
-            msg = str(ex).splitlines()[0][:200] if str(ex) else repr(ex)
+        def attempt(transport, tag_):
+            try:
+                c = make_communicator(eng, rank, world, width, args.gather_every, tag_, transport=transport)
+                c["verified"] = verify_gather(eng, hip, rank, world, n, sizes, start)
+                eng.new_game()             # (the verification stepped K frames)
+                return c, None
+            except Exception as ex:
+                return None, (str(ex).splitlines()[0][:200] if str(ex) else repr(ex))
+        rccl, msg = attempt(GATHER_TRANSPORT, tag)
+        # the ranks agree on the outcome through the rendezvous directory (a communicator that came up on some ranks only is no
+        # communicator): if RCCL failed anywhere, EVERY rank falls back to the host transport ("a host-staged gather
+        # is the fallback if RCCL is missing") and the line says so -- `rccl: null`, `gather.fallback_from_rccl` -- instead of
+        # there being no line at all; --strict-rccl keeps the failed run
+        failed_somewhere = bool(msg)
+        if world > 1:
+            from toybox_amd.parallel import rendezvous_key
+            agree = FileWorld(rank, world, key=rendezvous_key() + "_agree_" + tag)
+            failed_somewhere = agree.allreduce_max(1.0 if msg else 0.0) > 0.0
+        if failed_somewhere and GATHER_TRANSPORT == "rccl" and world > 1 and not args.strict_rccl:
+            first_msg = msg or "another rank could not make or verify its RCCL communicator"
+            print("bench.py: rank %d: no verified RCCL gather over %d ranks (%s): falling back to the host transport"
+                  % (rank, world, first_msg), file=sys.stderr)
+            rccl, msg = attempt("host", tag + "_host")
+            if rccl is not None:
+                rccl["fallback_from_rccl"] = first_msg
+            failed_somewhere = agree.allreduce_max(1.0 if msg else 0.0) > 0.0
+        if failed_somewhere:
+            msg = msg or "another rank could not make or verify its communicator"
             if world > 1 and not args.allow_no_gather:
                 # the north star's 8-GPU number INCLUDES the collective: a run that cannot make it is a failed run
-                print("bench.py: rank %d: no verified RCCL gather over %d ranks (%s); pass --allow-no-gather to measure the shards "
+                print("bench.py: rank %d: no verified record gather over %d ranks (%s); pass --allow-no-gather to measure the shards "
                       "without the per-step gather" % (rank, world, msg), file=sys.stderr)
                 return 4
-            gather_note = "RCCL communicator unavailable (%s): no per-step gather, file barrier between ranks" % msg
+            gather_note = "communicator unavailable (%s): no per-step gather, file barrier between ranks" % msg
             print("bench.py: " + gather_note, file=sys.stderr)
             gather, rccl = False, None
             fw = FileWorld(rank, world) if world > 1 else None

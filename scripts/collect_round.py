@@ -107,6 +107,37 @@ def loop_sweeps(tag):
     return "\n".join(out)
 
 
+def host_rates(tag):
+    out = ["# bench.py --protocol host (the PCIe link in the loop; never `value`): what VecEnv.step() hands a caller on the host, per arm", ""]
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, "host_*.json"))):
+        try:
+            j = json.loads([ln for ln in open(f) if ln.startswith("{")][-1])
+        except (IndexError, ValueError):
+            continue
+        out.append("## %s -- %s" % (os.path.basename(f), j.get("config", {}).get("workload", "")))
+        for k, v in j.get("arms", {}).items():
+            out.append("  %-44s %8.3f M %-14s %8.3f ms per step  %5.1f GB/s over the link" % (k, v["value"] / 1e6, v["unit"], v["ms_per_step"], v.get("pcie_GB_per_s", 0.0)))
+        out.append("")
+    return "\n".join(out)
+
+
+def rehearsal(tag):
+    out = ["# bench.py --gpus N --gather host --one-device: the whole N-process flow on ONE GPU (every rank on device 0, the record gather over the",
+           "# host transport): what it exercises is the flow, not a scaling figure -- N ranks share one GPU", ""]
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, "rehearsal_*.json"))):
+        try:
+            j = json.loads([ln for ln in open(f) if ln.startswith("{")][-1])
+        except (IndexError, ValueError):
+            out.append("## %s: no line" % os.path.basename(f))
+            continue
+        keep = {k: j.get(k) for k in ("n_gpus", "value", "ms_per_step", "scaling", "rccl", "gather", "share_of_linear", "loop")}
+        keep["weak"] = {k: (j.get("weak") or {}).get(k) for k in ("value", "ms_per_step", "envs_total", "gather")}
+        keep["config"] = {k: j["config"].get(k) for k in ("envs_per_gpu", "envs_total", "parallelism")}
+        keep["cpu_baseline"] = (j.get("cpu_baseline") or {}).get("value")
+        out += ["## " + os.path.basename(f), json.dumps(keep, indent=1), ""]
+    return "\n".join(out)
+
+
 PROFILES = [  # (profile tag suffix, traffic key, kernel substring)
     ("", "breakout_render_3ch_65536_fused", "render_step_kernel<3"), ("_pair", "breakout_render_3ch_65536", "render_kernel<3"),
     ("_space_invaders", "space_invaders_render_3ch_65536", "render_kernel<3"), ("_amidar", "amidar_render_3ch_65536", "render_kernel<3"),
@@ -129,6 +160,9 @@ def main():
                        ("ab_prev_round.txt", cat_files(tag, "ab_*.txt", "# scripts/ab_render.py: lib_prev.so = the previous round's final build, interleaved with this build on one box")),
                        ("issue_rate.txt", cat_files(tag, "issue_rate.txt", "# scripts/ubench/issue_rate.hip: scalar-ALU and vector-ALU instructions a compute unit issues per nanosecond, alone and side by side")),
                        ("kernel_gaps.txt", cat_files(tag, "kernel_gaps.txt", "# scripts/gpu_gaps.sh + scripts/trace_gaps.py: kernel durations inside the loops and the idle gaps in front of them")),
+                       ("host_rates.txt", host_rates(tag)), ("rehearsal.txt", rehearsal(tag)),
+                       ("agent_diag.txt", cat_files(tag, "agent_diag_*.txt", "# scripts/agent_diag.sh: the fused agent observation kernel of SpaceInvaders with parts switched off (DIAG build), time per agent step and SQ counters per launch")),
+                       ("write_align.txt", cat_files(tag, "write_align.txt", "# scripts/ubench/write_align.hip")),
                        ("bench_lines.md", bench_lines(tag))):
         with open(os.path.join(dst, "%s_%s" % (tag, name)), "w") as fh:
             fh.write(text + ("\n" if not text.endswith("\n") else ""))

@@ -9,7 +9,10 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 echo "== host: $(nproc) nproc, affinity $(python3 -c 'import os;print(len(os.sched_getaffinity(0)))'), cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)" | tee "$OUT/host.txt"
 BENCH="python3 $REPO/bench.py --no-cpu-baseline $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps 100 --warmup 10 > "$OUT/trace.log" 2>&1
+# PROFILE_STEPS / PROFILE_WARMUP: the step counts of the traced run (default 100 / 10; "20 5" = the driver's own command)
+TS=${PROFILE_STEPS:-100}; TW=${PROFILE_WARMUP:-10}
+echo "bench.py --no-cpu-baseline $* --steps $TS --warmup $TW" > "$OUT/cmd.txt"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps $TS --warmup $TW > "$OUT/trace.log" 2>&1
 tail -2 "$OUT/trace.log"
 for CTR in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$OUT/pmc_$CTR" -- $BENCH --steps 10 --warmup 2 > "$OUT/pmc_$CTR.log" 2>&1

@@ -37,7 +37,7 @@ def main():
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
-        lines += ["## kernel-trace --stats (bench.py --steps 100 --warmup 10)", "",
+        lines += ["## kernel-trace --stats (%s)" % (open(os.path.join(src, "cmd.txt")).read().strip() if os.path.exists(os.path.join(src, "cmd.txt")) else "bench.py --steps 100 --warmup 10"), "",
                   "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
         for r in csv.DictReader(open(stats[0])):
             lines.append("| `%s` | %s | %.1f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
@@ -65,6 +65,40 @@ def main():
                     total += sum(v) / len(v)
                 lines.append("| `%s` | one render = the sum of its parts | | **%.1f** |" % (k, total))
             lines.append("")
+    # the dominant kernel inside the TIMED regions against what bench.py's own line of the same run says (roofline.avg_launch_ms):
+    # --stats above averages over every launch of the process, the settle and warm-up launches included
+    log = os.path.join(src, "trace.log")
+    line = None
+    if os.path.exists(log):
+        for ln in open(log, errors="replace"):
+            ln = ln.strip()
+            if ln.startswith("{") and '"metric"' in ln:
+                try:
+                    line = json.loads(ln)
+                except ValueError:
+                    pass
+    if traces and line and line.get("roofline"):
+        rl = line["roofline"]
+        K, R = int(line.get("steps", 0)), int((line.get("repeats") or {}).get("n", 0))
+        fused = (line.get("loop") or {}).get("form") == "fused"
+        want = "render_step_kernel" if fused else "render_kernel"
+        rows = [r for r in csv.DictReader(open(traces[0])) if want in short(r["Kernel_Name"]) and ("render_step" in short(r["Kernel_Name"])) == fused]
+        # one render = all launches of the rasteriser between two step kernels (big Breakout renders go out in two parts): group by
+        # launch order into renders of `parts` launches each
+        grids = sorted({int(r["Grid_Size_X"]) for r in rows})
+        parts = len(grids) if not fused else 1
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+        renders = [sum(durs[i:i + parts]) for i in range(0, len(durs) - parts + 1, parts)]
+        timed = renders[-K * R:] if K * R and len(renders) >= K * R else renders
+        if timed:
+            avg_t, avg_all = sum(timed) / len(timed), sum(renders) / len(renders)
+            bytes_l = rl.get("algorithmic_bytes_per_launch", 0)
+            lines += ["## the dominant kernel in the timed regions vs bench.py's own line of this run", "",
+                      "| | launches | avg us | achieved GB/s | frac of 8 TB/s |", "|---|---|---|---|---|",
+                      "| kernel trace, the %d timed launches (%d regions x %d steps) | %d | %.1f | %.0f | **%.4f** |" % (len(timed), R, K, len(timed), avg_t, bytes_l / avg_t / 1e3, bytes_l / avg_t / 1e3 / 8000.0),
+                      "| kernel trace, every launch of the process (settle + warm-up included) | %d | %.1f | %.0f | %.4f |" % (len(renders), avg_all, bytes_l / avg_all / 1e3, bytes_l / avg_all / 1e3 / 8000.0),
+                      "| bench.py `roofline` (HIP events, %s launches in %s spans) | %s | %.1f | %.0f | **%.4f** |" % (rl.get("launches_timed"), rl.get("event_spans"), rl.get("launches_timed"), 1e3 * rl["avg_launch_ms"], rl["achieved"], rl["frac"]),
+                      "| bench.py `ms_per_step` (median region, host clock) | | %.1f | | |" % (1e3 * line["ms_per_step"]), ""]
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
     for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):

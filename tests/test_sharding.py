@@ -386,6 +386,33 @@ def test_bench_n_process_flow_end_to_end_on_the_checker(world, extra, oracle_lib
     assert rf["avg_launch_ms"] > 0 and rf["launches_timed"] >= 1 and "never" in rf["timing"]
 
 
+@pytest.mark.parametrize("strict", [False, True])
+def test_bench_falls_back_to_the_host_transport_when_rccl_fails(strict, oracle_lib, tmp_path):
+    """N > 1 and the RCCL communicator cannot be made (forced here with TBX_BENCH_NO_RCCL): the ranks agree on that through the
+    rendezvous directory and ALL fall back to the host transport -- the line says `rccl: null` and names the error -- so that
+    the first hardware run yields a labelled line instead of none; --strict-rccl keeps the failed run (rc 4, no line)."""
+    import json
+    world = 2
+    argv = ["--gpus", str(world), "--envs", "64", "--steps", "4", "--warmup", "1", "--repeats", "2", "--preroll", "300", "--settle", "2",
+            "--no-cpu-baseline", "--no-extras"] + (["--strict-rccl"] if strict else [])
+    script = tmp_path / "worker.py"
+    script.write_text(BENCH_FLOW_WORKER.format(root=ROOT, argv=argv))
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="5", TBX_RDZV_DIR=str(tmp_path), TBX_BENCH_NO_RCCL="1")
+    env.pop("TBX_RDZV_KEY", None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    out0, err0 = procs[0].communicate(timeout=600)
+    codes = [p.wait(timeout=600) for p in procs]
+    if strict:
+        assert codes == [4] * world and not [ln for ln in out0.splitlines() if ln.startswith("{")]
+        return
+    assert codes == [0] * world, err0[-2000:]
+    line = json.loads([ln for ln in out0.splitlines() if ln.startswith("{")][-1])
+    assert line["rccl"] is None and line["gather"]["transport"] == "host" and line["gather"]["verified"] is True
+    assert "TBX_BENCH_NO_RCCL" in line["gather"]["fallback_from_rccl"] and line["gather"]["nranks"] == world
+    assert "falling back to the host transport" in err0
+
+
 class _FakeEvent:
     log = []
 

@@ -184,8 +184,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
             const int top = (oy + 1) * H;
             const int w_cur = min((sy + 1) * oh, top) - sy * oh, w_next = oh - w_cur;
             const uint32_t h0 = on0 ? hsum(row, c0) : 0u, h1 = on1 ? hsum(row, c1) : 0u;
-            acc0[0] += (uint32_t)w_cur * h0; acc0[1] += (uint32_t)w_cur * h1;
-            acc1[0] += (uint32_t)w_next * h0; acc1[1] += (uint32_t)w_next * h1;
+            acc0[0] += __umul24((uint32_t)w_cur, h0); acc0[1] += __umul24((uint32_t)w_cur, h1);     // 24-bit operands (weights <= out_h, sums <= 255 W): full-rate v_mad_u32_u24, not v_mad_u64_u32
+            acc1[0] += __umul24((uint32_t)w_next, h0); acc1[1] += __umul24((uint32_t)w_next, h1);
             __builtin_amdgcn_wave_barrier();
             if ((sy + 1) * oh >= top) {                  // output row oy is complete
 #pragma unroll

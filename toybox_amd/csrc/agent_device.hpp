@@ -482,8 +482,8 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
             }
             const int pos_next = pos + a.oh;
             const int w_cur = min(pos_next, top) - pos, w_next = a.oh - w_cur;
-            acc0[0] += (uint32_t)w_cur * h0; acc0[1] += (uint32_t)w_cur * h1;
-            acc1[0] += (uint32_t)w_next * h0; acc1[1] += (uint32_t)w_next * h1;
+            acc0[0] += __umul24((uint32_t)w_cur, h0); acc0[1] += __umul24((uint32_t)w_cur, h1);     // 24-bit operands (weights <= out_h, sums <= 255 W): full-rate v_mad_u32_u24, not v_mad_u64_u32
+            acc1[0] += __umul24((uint32_t)w_next, h0); acc1[1] += __umul24((uint32_t)w_next, h1);
             pos = pos_next;
             if (pos_next >= top) {                                     // output row oy is complete
 #pragma unroll

@@ -1228,9 +1228,7 @@ __device__ __forceinline__ void ami_step_body(const AmiDev& d, const AmiDev& slo
             }
         }
     }
-    // (batch protocol: slot_a is the state buffer the frame's result goes to -- the one it came from, or, for a step that runs
-    // ahead of the previous frame's rasteriser, the other one: AmiOps::step_ahead)
-    ami_store(AGENT ? d : slot_a, env, lane, s);
+    ami_store(d, env, lane, s);
     if (lane == 0) {
         d.prev_score[env] = prev;
         d.reward[env] = rew;
@@ -1249,16 +1247,6 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_step_kernel(AmiDev d, ActionSou
     const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     if (rel >= count) return;
     ami_step_body<false>(d, d, d, src, flags, first_env + rel, lane);
-}
-
-// the same frame read from state buffer d and written to state buffer `next` (pipelined mode: the rasteriser of the previous
-// frame is still reading d)
-__global__ __launch_bounds__(TBX_BLOCK) void ami_step_ahead_kernel(AmiDev d, AmiDev next, ActionSource src, uint32_t flags, int count)
-{
-    const int lane = threadIdx.x & 63;
-    const int rel = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-    if (rel >= count) return;
-    ami_step_body<false>(d, next, next, src, flags, rel, lane);
 }
 
 __global__ __launch_bounds__(TBX_BLOCK) void ami_agent_step_kernel(AmiDev d, AmiDev slot_a, AmiDev slot_b, ActionSource src, uint32_t flags, int first_env, int count)
@@ -2033,7 +2021,6 @@ struct AmiOps : GameOps {
     void destroy(tbx_engine*) override
     {
         hipFree(d.rng); hipFree(d.sc); hipFree(d.tiles); hipFree(d.boxes); hipFree(d.movers); hipFree(d.mh); hipFree(tab_dev);
-        hipFree(d2.rng); hipFree(d2.sc); hipFree(d2.tiles); hipFree(d2.boxes); hipFree(d2.movers); hipFree(d2.mh);
         hipFree(dA.rng); hipFree(dA.sc); hipFree(dA.tiles); hipFree(dA.boxes); hipFree(dA.movers); hipFree(dA.mh);
         hipFree(dB.rng); hipFree(dB.sc); hipFree(dB.tiles); hipFree(dB.boxes); hipFree(dB.movers); hipFree(dB.mh);
     }
@@ -2069,35 +2056,16 @@ struct AmiOps : GameOps {
     // launch.  Built, bit-identical, and no faster either: ms per step fused / two launches 0.1072 / 0.1085 at 4 096 envs,
     // 0.214 / 0.204 at 8 192, 0.421 / 0.391 at 16 384, 1.68 / 1.53 at 65 536 (five waves per SIMD, no spills; six: 0.209 at
     // 8 192, 1.62 at 65 536) -- a step wave holds a rasteriser wave's slot for its whole latency-bound life.  Removed.
+    // Round 5, the one form left: the same wave-per-env step over two state buffers, but on the engine's STEP
+    // STREAM beside the rasteriser of the previous frame (TBX_OPT_PIPELINE = 2 / 3, the fences of the pipelined mode; parity-green
+    // in tests/test_gpu_paths.py's pipelined-mode tests).  scripts/pipeline_sweep.py amidar, one box, ms per step
+    // stream order / value 2 / value 3: 0.0605 / 0.0695 / 0.0622 at 2 048 envs, 0.1085 / 0.1181 / 0.1130 at 4 096,
+    // 0.200 / 0.212 / 0.2085 at 8 192, 0.3886 / 0.4324 / 0.4055 at 16 384 -- slower everywhere (the kill criterion was a gain of
+    // 3 % at 4 096): beside a kernel that saturates the memory system with stores the step's loads and its full-state write-back
+    // queue, and the rasteriser loses the slots the step's waves hold.  Removed; Amidar's step stays in stream order.
     void rebind_outputs(tbx_engine* e) override
     {
         d.reward = e->reward; d.done = e->done; d.lives_out = e->lives_out; d.score_out = e->score_out; d.packed = e->packed;
-    }
-
-    // ---- round 5, the one form not tried: the wave-per-env step of frame t + 1 on the engine's STEP STREAM beside the rasteriser
-    // of frame t (TBX_OPT_PIPELINE = 2 / 3, explicit values only, up to 16 384 envs), over TWO state buffers: it reads the
-    // buffer the rasteriser reads and writes the other one, which becomes the current one (GameOps::records_parity = the
-    // buffer a render launched now reads; the engine's fences keep step t + 2 behind the rasteriser of frame t).
-    AmiDev d2{};
-    int state_par = 0;
-    bool ahead_ok = false;
-    void options_changed(tbx_engine* e) override
-    {
-        ahead_ok = false;
-        if (e->opt[TBX_OPT_PIPELINE] >= 2 && e->n <= 16384 && alloc_slot(e, d2) == TBX_OK) ahead_ok = true;
-    }
-    bool pipeline_ok() const override { return ahead_ok; }
-    int records_parity() const override { return state_par; }
-    int step_ahead(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
-    {
-        AmiDev next = d;                                   // everything that is not per-frame state is shared
-        next.rng = d2.rng; next.sc = d2.sc; next.tiles = d2.tiles; next.boxes = d2.boxes; next.movers = d2.movers; next.mh = d2.mh;
-        TBX_LAUNCH_STEP(e, s, ami_step_ahead_kernel, grid_for(e->n), dim3(TBX_BLOCK), d, next, src, flags, e->n);
-        TBX_HIP(hipGetLastError());
-        d2.rng = d.rng; d2.sc = d.sc; d2.tiles = d.tiles; d2.boxes = d.boxes; d2.movers = d.movers; d2.mh = d.mh;
-        d = next;
-        state_par ^= 1;
-        return TBX_OK;
     }
 
     int step(tbx_engine* e, const ActionSource& src, uint32_t flags, hipStream_t s) override
