@@ -683,7 +683,10 @@ int tbx_gather_fill(tbx_engine* engine);
  * (TBX_OPT_GATHER_EVERY) only every K-th call queues anything, then for the last K steps at once.  Asynchronous: it
  * is ordered after everything queued through this handle so far, runs on an engine-owned communication stream, and the next
  * step that rewrites those records is ordered after it -- what the caller queues in between (the rasteriser) overlaps with it.  `stream` is not used to run it; make a
- * stream wait for the result with tbx_gather_wait. */
+ * stream wait for the result with tbx_gather_wait.
+ * With the fused call (tbx_render_step_synthetic) and one collective PER STEP there is nothing in between: the collective waits
+ * for the whole launch (the step rides in it) and the next launch rewrites the same records, so it waits for the collective --
+ * no overlap in that combination; the K-step ring (TBX_OPT_GATHER_EVERY > 1) or the two-launch loop overlaps it. */
 int tbx_gather(tbx_engine* engine, uint64_t* out_dev, void* stream);
 /* Make `stream` wait for the last queued gather (device-side consumers of the gathered records). */
 int tbx_gather_wait(tbx_engine* engine, void* stream);

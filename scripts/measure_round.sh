@@ -41,6 +41,9 @@ timeout 400 python scripts/strong_sweep.py breakout 4096 8192 65536 2>&1 | grep 
 for g in breakout space_invaders amidar; do
   AB_PREROLL=400 timeout 300 python scripts/ab_render.py $g 3 scripts/ab/lib_prev.so toybox_amd/csrc/libtoybox_amd.so > "$OUT/ab_render_$g.txt" 2>&1
 done
+for g in breakout space_invaders amidar gridworld; do
+  AB_PREROLL=60 timeout 300 python scripts/ab_agent.py $g scripts/ab/lib_prev.so toybox_amd/csrc/libtoybox_amd.so > "$OUT/ab_agent_$g.txt" 2>&1
+done
 # ---- the agent observation kernel of SpaceInvaders taken apart (DIAG build) and the store-alignment microbenchmark
 bash scripts/agent_diag.sh space_invaders 65536 > /dev/null 2>&1
 cp "$REPO/gpurun_out/agent_diag/times_space_invaders.txt" "$OUT/agent_diag_times.txt" 2>/dev/null

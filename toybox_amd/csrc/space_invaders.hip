@@ -963,6 +963,7 @@ struct SiPainter {
     // fused agent observation, scanlines that hold nothing but enemies (fast_*): per output column of this lane the visible
     // enemies whose columns reach its 8-pixel tap window, and the lookups of the current formation row
     static constexpr bool FAST_ROWS = true;
+    static constexpr bool SPARSE_ROWS = true;    // (agent_fused_wave: walk the active scanlines only -- about half of the 210 scanlines hold nothing)
     int f_start[2];                         // first source pixel of this lane's two output columns (-1: column not in use)
     mutable uint64_t fym_cached;
     mutable uint32_t f_hit[2];              // (enemy x + 64) << 16 | (sprite-table row of scanline 0 + 1024); ~0u: no enemy under the window
