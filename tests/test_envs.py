@@ -280,3 +280,68 @@ print("ok")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests", "stubs"), os.path.join(ROOT, "tests", "shim"), ROOT]))
     p = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.stdout + p.stderr)[-3000:]
+
+
+@pytest.mark.parametrize("stack,size", [(1, 40), (3, 42), (4, 45)])
+@pytest.mark.parametrize("frame_stack", ["vec", "env"])
+def test_preproc_vec_env_layouts_agree_for_every_stack_depth(stack, size, frame_stack, factory):
+    """The three ways ToyboxPreprocVecEnv gets observations to the host hold the same values for stack depths other than 4
+    (byte-wise stack paths), plane sizes that are not a multiple of four bytes, one env, and every pool size -- step by step
+    through episode ends, with the reset-time wrappers on."""
+    from toybox_amd.envs.vec_env import PlaneStack
+    game, n = "breakout", 5
+    envs = {}
+    for layout, pool in (("device_stack", 0), ("device_stack", 1), ("planes", 2), ("planes", 1), ("host_stack", 2), ("host_stack", 0)):
+        envs[(layout, pool)] = ToyboxPreprocVecEnv(game, n, skip=3, size=size, stack=stack, seed=11, engine=factory(game, n), frame_stack=frame_stack,
+                                                   episode_life=True, fire_reset=True, noop_max=5, noop_seed=2, obs_layout=layout, obs_pool=pool)
+    first = {k: np.asarray(e.reset()).copy() for k, e in envs.items()}
+    ref = first[("device_stack", 0)]
+    assert ref.shape == (n, size, size, stack) and all(np.array_equal(v, ref) for v in first.values())
+    rng = np.random.default_rng(3)
+    dones = 0
+    for t in range(120):
+        a = rng.integers(0, 4, n)
+        outs = {k: e.step(a) for k, e in envs.items()}
+        o0, r0, d0, i0 = outs[("device_stack", 0)]
+        for k, (o, r, d, info) in outs.items():
+            assert np.array_equal(np.asarray(o), o0) and np.array_equal(r, r0) and np.array_equal(d, d0), (k, t)
+            assert info.with_key("episode") == i0.with_key("episode")
+            assert isinstance(o, PlaneStack) == (k[0] == "planes")
+        dones += int(d0.sum())
+    assert dones > 0
+    one = ToyboxPreprocVecEnv(game, 1, size=size, stack=stack, seed=1, engine=factory(game, 1), obs_layout="planes")
+    assert np.asarray(one.reset()).shape == (1, size, size, stack) and np.asarray(one.step([1])[0]).shape == (1, size, size, stack)
+    for e in list(envs.values()) + [one]:
+        e.close()
+    with pytest.raises(ValueError):
+        ToyboxPreprocVecEnv(game, 1, engine=factory(game, 1), obs_layout="rows")
+
+
+def test_vec_env_step_async_then_wait_and_pool_rotation(factory):
+    """ToyboxVecEnv: step_async() queues, step_wait() collects (vec_env/__init__.py:67-87); observations rotate through the pool, so
+    the one returned by the previous step is intact after the next; rewards and dones come back as fresh arrays every step (rollout
+    buffers keep references: ppo2.py:113); obs_pool = 0 hands out a new array per call."""
+    game, n = "amidar", 6
+    a = ToyboxVecEnv(game, n, grayscale=False, engine=factory(game, n), seed=4, obs_pool=2)
+    b = ToyboxVecEnv(game, n, grayscale=False, engine=factory(game, n), seed=4, obs_pool=0)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob)
+    rng = np.random.default_rng(9)
+    kept, rewards = None, []
+    for t in range(40):
+        act = rng.integers(0, a.action_space.n, n)
+        a.step_async(act)
+        with pytest.raises(Exception):
+            a.engine.step_begin(np.zeros(n, np.int32))               # one step in flight at a time
+        ra, rb = a.step_wait(), b.step(act)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+        assert ra[3][2] == rb[3][2]
+        if kept is not None:
+            assert np.array_equal(kept[0], kept[1]) and kept[0] is not ra[0]      # the previous observation is intact
+        kept = (ra[0], ra[0].copy())
+        rewards.append(ra[1])
+        assert rb[0] is not ob
+        ob = rb[0]
+    assert len({id(r) for r in rewards}) == len(rewards)
+    a.close(); b.close()
+    assert np.array_equal(kept[0], kept[1])                           # ... and outlives the env
