@@ -26,6 +26,12 @@ struct AgentState {
     uint32_t* io_dev = nullptr;
     uint32_t* io_host = nullptr;                    // pinned mirror; tbx_agent_step_end hands its parts to the caller's arrays
     tbx_agent_host_out_t host_out{};
+    // the observation of a big batch goes out in CHUNKS of envs: chunk c's planes (stacks) travel on the copy stream while the
+    // observation kernel of chunk c + 1 runs (the link carries 7 KB per env and step: at 8 192 envs the copy takes 1.05 ms, the
+    // SpaceInvaders observation kernel 0.26 ms -- all of it would otherwise sit in front of the copy)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t chunk_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t copies_done = nullptr;
     int32_t* racc = nullptr;
     float* reward_out = nullptr;
     AgentTaps *ty = nullptr, *tx = nullptr;
@@ -122,8 +128,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[TBX_WAVES_PER_BLOCK][352];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
-    if (env >= n) return;
+    const int env = wave_uniform(wa.first + blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (env >= wa.end) return;
     uint8_t* row = lds_all[wave];
     // B holds slot B, or the live frame where the env's observation is a raw frame; A holds slot A
     const ObsSel sel = agent_obs_sel(wa, env);
@@ -247,6 +253,7 @@ AgentWarpArgs warp_args(tbx_engine* e, int reset_mode)
     AgentWarpArgs w;
     w.zero = a.done_out; w.mode = a.mode; w.valid = a.buf_valid; w.tx = a.tx; w.obs = a.obs; w.plane = a.plane;
     w.H = a.H; w.W = a.W; w.oh = a.cfg.out_h; w.ow = a.cfg.out_w; w.stack = a.cfg.stack;
+    w.first = 0; w.end = e->n;
     w.reset_mode = reset_mode;
     w.fill_repeat = a.cfg.stack_fill != 0;
     w.magic = (1ull << 42) / (uint64_t)(a.H * a.W) + 1ull;   // exact for numerators < 2^42 / area >= 2^25
@@ -294,6 +301,16 @@ AgentResetArgs reset_args(tbx_engine* e)
     return r;
 }
 
+// the fused observation kernels can be launched for a range of envs (observe_chunk); the generic path cannot
+bool observe_in_chunks(tbx_engine* e) { return e->ops->agent_fused() && !e->agent->force_generic; }
+
+int observe_chunk(tbx_engine* e, int first, int end, hipStream_t s)
+{
+    AgentWarpArgs w = warp_args(e, 0);
+    w.first = first; w.end = end;
+    return e->ops->agent_warp(e, w, s);
+}
+
 // the observation, once the frames and the resets of the agent step are done
 int observe(tbx_engine* e, int reset_mode, hipStream_t s)
 {
@@ -307,8 +324,9 @@ int observe(tbx_engine* e, int reset_mode, hipStream_t s)
     return launch_warp(e, reset_mode, s);
 }
 
-// the whole agent step, asynchronous on `s`
-int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s)
+// the whole agent step, asynchronous on `s` (with_observation = false: everything but the observation kernel, which the caller
+// launches itself -- tbx_agent_step_begin does, chunk by chunk)
+int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s, bool with_observation = true)
 {
     AgentState& a = *e->agent;
     const int n = e->n, tb = 256, gb = (n + tb - 1) / tb;
@@ -350,7 +368,7 @@ int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s)
     a.parity ^= 1;
     int rc = in_kernel_reset ? e->ops->agent_reset_envs(e, ra, s) : e->ops->new_game(e, a.fin, s);
     if (rc) return rc;
-    return observe(e, 0, s);
+    return with_observation ? observe(e, 0, s) : TBX_OK;
 }
 
 // the error word of the device: bit 0 illegal action id, bit 1 a step on an env whose Monitor needed a reset
@@ -375,6 +393,9 @@ void tbx_agent_free(tbx_engine* e)
     AgentState* a = e->agent;
     if (a->host_pending) hipStreamSynchronize(e->stream);      // copies into the caller's buffers are still in flight
     hipFree(a->plane); hipHostFree(a->host_actions); hipFree(a->io_dev); hipHostFree(a->io_host);
+    if (a->copy_stream) { hipStreamSynchronize(a->copy_stream); hipStreamDestroy(a->copy_stream); }
+    for (hipEvent_t ev : a->chunk_ev) if (ev) hipEventDestroy(ev);
+    if (a->copies_done) hipEventDestroy(a->copies_done);
     hipFree(a->gray_a); hipFree(a->gray_b); hipFree(a->obs); hipFree(a->fin); hipFree(a->done_out);
     hipFree(a->racc); hipFree(a->reward_out); hipFree(a->ty); hipFree(a->tx);
     hipFree(a->was_real_done); hipFree(a->needs_reset); hipFree(a->mode); hipFree(a->buf_valid); hipFree(a->exec_flag);
@@ -629,11 +650,33 @@ int tbx_agent_step_begin(tbx_engine* e, const int32_t* actions_host, const tbx_a
     ActionSource src{};
     src.actions = e->actions;
     src.single_env = -1;
-    int rc = agent_step_async(e, src, e->stream);
+    // Batches of 2 048 envs and more (fused observation kernels): four chunks, the copy of chunk c beside the kernel of chunk c + 1.
+    const int chunks = (observe_in_chunks(e) && e->n >= 2048 && (out->plane || out->obs)) ? 4 : 1;
+    int rc = agent_step_async(e, src, e->stream, chunks == 1);
     if (rc) return rc;
-    // the observation first (the long copy starts as soon as the observation kernel has finished), the small block behind it
-    if (out->plane) AHIP(hipMemcpyAsync(out->plane, a.plane, N * px, hipMemcpyDeviceToHost, e->stream));
-    if (out->obs) AHIP(hipMemcpyAsync(out->obs, a.obs, N * px * a.cfg.stack, hipMemcpyDeviceToHost, e->stream));
+    if (chunks == 1) {
+        // the observation first (the long copy starts as soon as the observation kernel has finished), the small block behind it
+        if (out->plane) AHIP(hipMemcpyAsync(out->plane, a.plane, N * px, hipMemcpyDeviceToHost, e->stream));
+        if (out->obs) AHIP(hipMemcpyAsync(out->obs, a.obs, N * px * a.cfg.stack, hipMemcpyDeviceToHost, e->stream));
+    } else {
+        if (!a.copy_stream) {
+            AHIP(hipStreamCreateWithFlags(&a.copy_stream, hipStreamNonBlocking));
+            for (int c = 0; c < 8; c++) AHIP(hipEventCreateWithFlags(&a.chunk_ev[c], hipEventDisableTiming));
+            AHIP(hipEventCreateWithFlags(&a.copies_done, hipEventDisableTiming));
+        }
+        for (int c = 0; c < chunks; c++) {
+            const int first = (int)((long)e->n * c / chunks), end = (int)((long)e->n * (c + 1) / chunks);
+            rc = observe_chunk(e, first, end, e->stream);
+            if (rc) return rc;
+            AHIP(hipEventRecord(a.chunk_ev[c], e->stream));
+            AHIP(hipStreamWaitEvent(a.copy_stream, a.chunk_ev[c], 0));
+            const size_t off = (size_t)first * px, cnt = (size_t)(end - first) * px;
+            if (out->plane) AHIP(hipMemcpyAsync(out->plane + off, a.plane + off, cnt, hipMemcpyDeviceToHost, a.copy_stream));
+            if (out->obs) AHIP(hipMemcpyAsync(out->obs + off * a.cfg.stack, a.obs + off * a.cfg.stack, cnt * a.cfg.stack, hipMemcpyDeviceToHost, a.copy_stream));
+        }
+        AHIP(hipEventRecord(a.copies_done, a.copy_stream));
+        AHIP(hipStreamWaitEvent(e->stream, a.copies_done, 0));     // the engine's stream is the tail everything else orders itself behind
+    }
     hipLaunchKernelGGL(agent_pack_outputs_kernel, dim3((e->n + 255) / 256), dim3(256), 0, e->stream, a.reward_out, a.ep_ret_out, a.ep_len_out,
                        a.done_out, a.ep_done, e->err_flag, a.io_dev, e->n);
     AHIP(hipGetLastError());

@@ -20,6 +20,8 @@ struct AgentWarpArgs {
     uint8_t* obs;              // [N][out_h][out_w][stack]
     uint8_t* plane;            // [N][out_h][out_w] the newest plane alone (tbx_agent_config_t::new_plane), or nullptr
     int H, W, oh, ow, stack;
+    int first, end;            // the envs this launch makes observations for: [first, end) (the whole batch, or one chunk of it when the
+                               // host-delivery path overlaps the copy of a chunk's planes with the next chunk's kernel)
     int reset_mode;            // venv.reset(): every stack starts from zeros
     int fill_repeat;           // tbx_agent_config_t::stack_fill: a fresh stack holds the new frame in every slot, not zeros
     uint64_t magic;            // floor(2^42 / (H*W)) + 1

@@ -1651,8 +1651,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_agent_warp_kernel(AmiDev dLive,
     __shared__ AgentFusedLds<AmiGrayPainter> lds[TBX_WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
-    if (env >= n) return;
+    const int env = wave_uniform(a.first + blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (env >= a.end) return;
     AmiGrayPainter pa, pb;
     agent_fused_wave<S, AmiGrayPainter>(pa, pb, dLive, dA, dB, a, env, lane, lds[wave]);
 }
@@ -2141,7 +2141,7 @@ struct AmiOps : GameOps {
     int agent_warp(tbx_engine* e, const AgentWarpArgs& a, hipStream_t s) override
     {
         dA.tab = dB.tab = d.tab;
-        const dim3 grid = grid_for(e->n), block(TBX_BLOCK);
+        const dim3 grid = grid_for(a.end - a.first), block(TBX_BLOCK);
         switch (a.stack) {
         case 1: hipLaunchKernelGGL(ami_agent_warp_kernel<1>, grid, block, 0, s, d, dA, dB, a, e->n); break;
         case 2: hipLaunchKernelGGL(ami_agent_warp_kernel<2>, grid, block, 0, s, d, dA, dB, a, e->n); break;

@@ -1372,8 +1372,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
     __shared__ __attribute__((aligned(16))) uint8_t vals_all[TBX_WAVES_PER_BLOCK][AGENT_MAX_OUT_PX];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
-    if (env >= n) return;
+    const int env = wave_uniform(a.first + blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (env >= a.end) return;
     uint8_t* row = lds_all[wave];
     uint8_t* vals = vals_all[wave];
     const ObsSel sel = agent_obs_sel(a, env);
@@ -2067,7 +2067,7 @@ struct BreakoutOps : GameOps {
             TBX_HIP(hipGetLastError());
             recs_valid = true;
         }
-        const dim3 grid = grid_for(e->n), block(TBX_BLOCK);
+        const dim3 grid = grid_for(a.end - a.first), block(TBX_BLOCK);
         switch (a.stack) {
         case 1: hipLaunchKernelGGL(brk_agent_warp_kernel<1>, grid, block, 0, s, recs, recsA, recsB, pal, a, e->n); break;
         case 2: hipLaunchKernelGGL(brk_agent_warp_kernel<2>, grid, block, 0, s, recs, recsA, recsB, pal, a, e->n); break;

@@ -460,8 +460,8 @@ __global__ __launch_bounds__(TBX_BLOCK) void gw_agent_warp_kernel(GwDev dLive, G
     __shared__ AgentFusedLds<GwGrayPainter> lds[TBX_WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
-    if (env >= n) return;
+    const int env = wave_uniform(a.first + blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (env >= a.end) return;
     GwGrayPainter pa, pb;
     agent_fused_wave<S, GwGrayPainter>(pa, pb, dLive, dA, dB, a, env, lane, lds[wave]);
 }
@@ -651,7 +651,7 @@ struct GridWorldOps : GameOps {
     int agent_warp(tbx_engine* e, const AgentWarpArgs& a, hipStream_t s) override
     {
         dA.cfg = dB.cfg = d.cfg;
-        const dim3 grid = wave_grid(e->n), block(TBX_BLOCK);
+        const dim3 grid = wave_grid(a.end - a.first), block(TBX_BLOCK);
         switch (a.stack) {
         case 1: hipLaunchKernelGGL(gw_agent_warp_kernel<1>, grid, block, 0, s, d, dA, dB, a, e->n); break;
         case 2: hipLaunchKernelGGL(gw_agent_warp_kernel<2>, grid, block, 0, s, d, dA, dB, a, e->n); break;

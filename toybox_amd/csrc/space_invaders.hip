@@ -1651,8 +1651,8 @@ __global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(3))) 
     si_fill_sprites(spr_lds);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int env = wave_uniform(blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
-    if (env >= n) return;
+    const int env = wave_uniform(a.first + blockIdx.x * TBX_WAVES_PER_BLOCK + wave);
+    if (env >= a.end) return;
     SiGrayPainter pa, pb;
     pa.spr_lds = spr_lds; pb.spr_lds = spr_lds;
     agent_fused_wave<S, SiGrayPainter>(pa, pb, dLive, dA, dB, a, env, lane, lds[wave]);
@@ -1966,7 +1966,7 @@ struct SiOps : GameOps {
 
     int agent_warp(tbx_engine* e, const AgentWarpArgs& a, hipStream_t s) override
     {
-        const dim3 grid = grid_for(e->n), block(TBX_BLOCK);
+        const dim3 grid = grid_for(a.end - a.first), block(TBX_BLOCK);
         switch (a.stack) {
         case 1: hipLaunchKernelGGL(si_agent_warp_kernel<1>, grid, block, 0, s, d, dA, dB, a, e->n); break;
         case 2: hipLaunchKernelGGL(si_agent_warp_kernel<2>, grid, block, 0, s, d, dA, dB, a, e->n); break;
