@@ -1646,7 +1646,7 @@ __global__ __launch_bounds__(64 * TBX_SERVE_WAVES) void ami_serve_kernel(AmiDev 
 // max(frame A, frame B) -> gray -> area warp -> frame stack without the two full-resolution gray frames ever reaching
 // HBM: agent_fused_wave (agent_device.hpp) with two AmiGrayPainters in one wave per env.
 template <int S>
-__global__ __launch_bounds__(TBX_BLOCK) void ami_agent_warp_kernel(AmiDev dLive, AmiDev dA, AmiDev dB, AgentWarpArgs a, int n)
+__global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void ami_agent_warp_kernel(AmiDev dLive, AmiDev dA, AmiDev dB, AgentWarpArgs a, int n)
 {
     __shared__ AgentFusedLds<AmiGrayPainter> lds[TBX_WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;

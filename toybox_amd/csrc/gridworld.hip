@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64 * TBX_SERVE_WAVES) void gw_serve_kernel(GwDev d,
 
 // fused agent observation: agent_fused_wave (agent_device.hpp) with two GwGrayPainters per wave
 template <int S>
-__global__ __launch_bounds__(TBX_BLOCK) void gw_agent_warp_kernel(GwDev dLive, GwDev dA, GwDev dB, AgentWarpArgs a, int n)
+__global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void gw_agent_warp_kernel(GwDev dLive, GwDev dA, GwDev dB, AgentWarpArgs a, int n)
 {
     __shared__ AgentFusedLds<GwGrayPainter> lds[TBX_WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
