@@ -1100,8 +1100,9 @@ def baseline_configs(args, hip):
              "ms_per_step_min_max": [r["rep"]["ms_per_step_min"], r["rep"]["ms_per_step_max"]],
              "loop": "fused" if r["fused"] else "pair", "pipeline_resolved": r["mode"],
              "whole_step_frac": r["n"] * fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-             "kernel_frac": (r["n"] * fb / (r["launch"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if r["launch"] else None,
-             "avg_launch_ms": r["launch"]["avg_ms"] if r["launch"] else None, "frame_hwc": [r["H"], r["W"], r["C"]]}
+             # (overlapped launches, TBX_OPT_PIPELINE 3: an event pair on the caller's stream does not bracket a kernel)
+             "kernel_frac": (r["n"] * fb / (r["launch"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if r["launch"] and r["mode"] == 0 else None,
+             "avg_launch_ms": r["launch"]["avg_ms"] if r["launch"] and r["mode"] == 0 else None, "frame_hwc": [r["H"], r["W"], r["C"]]}
         sr = r["extras"].get("serialised")
         e["serialised"] = ({"value": sr["value"], "ms_per_step": sr["ms_per_step"], "whole_step_frac": sr["whole_step_frac"],
                             "kernel_frac": sr["roofline_frac"]} if sr else "= value (the main arm is the two-launch loop in stream order)")

@@ -455,6 +455,10 @@ __global__ __launch_bounds__(64 * TBX_SERVE_WAVES) void gw_serve_kernel(GwDev d,
 
 // fused agent observation: agent_fused_wave (agent_device.hpp) with two GwGrayPainters per wave
 template <int S>
+// Held to FIVE waves per SIMD (the LDS of a block allows five): with the newest-plane output and the 16-byte stack commit of round 5
+// the depth-4 instantiation asked for 99-101 VGPRs -- four waves -- and the agent step at 65 536 envs lost 3-7 % against round 4;
+// at 96 VGPRs it spills 16-52 bytes per lane and runs 3.5 % AHEAD of round 4 (same box: Amidar 1.848 / 1.987 / 1.911 ms pinned /
+// unpinned / round 4, GridWorld 1.053 / 1.156 / 1.091).
 __global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void gw_agent_warp_kernel(GwDev dLive, GwDev dA, GwDev dB, AgentWarpArgs a, int n)
 {
     __shared__ AgentFusedLds<GwGrayPainter> lds[TBX_WAVES_PER_BLOCK];
