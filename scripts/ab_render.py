@@ -23,6 +23,9 @@ with_step = __import__("os").environ.get("AB_STEP", "0") == "1"   # time [step ;
 for rnd in range(3):
     for p, lib in libs:
         e = Engine(game, n, lib=lib)
+        if __import__("os").environ.get("AB_SPLIT"):              # waves per frame (TBX_OPT_RENDER_SPLIT); "a,b": one value per library
+            sp = __import__("os").environ["AB_SPLIT"].split(",")
+            e.set_option(_abi.OPT_RENDER_SPLIT, int(sp[min(len(sp) - 1, [q for q, _ in libs].index(p))]))
         e.seed(1234)
         for t in range(pre):
             e.step_synthetic(1337, t)

@@ -1303,7 +1303,15 @@ __global__ __launch_bounds__(TBX_BLOCK) void ami_agent_reset_kernel(AmiDev d, Am
 
 // ------------------------------------------------------------------ render
 
-constexpr int AMI_UNIT_ROWS = 10;   // 250 = 25 units; 10 x 480 B (RGB) of LDS per wave
+#ifndef AMI_UNIT_ROWS_V
+#define AMI_UNIT_ROWS_V 10
+#endif
+constexpr int AMI_UNIT_ROWS = AMI_UNIT_ROWS_V;   // 250 = 25 units; 10 x 480 B (RGB) of LDS per wave (other values: the last unit is shorter)
+// Round 5 measured the unit SIZE as part of the store-address question (4 800-byte units start 64 bytes off a 128-byte line every
+// other time; as a pure store stream 128-byte aligned units gain 9-11 %): builds with 12 rows (5 760 B, Breakout's unit) and 8 rows
+// (3 840 B), parity-green for every split factor, RGB launch at 65 536 envs on one box, best split of each: 1.365 ms (10 rows, nine
+// waves per frame) / 1.510 (12 rows, eleven) / 1.444 (8 rows, ten) -- ten rows are two tile rows of the board, and that outweighs the
+// addresses.  scripts/ami_units_probe.sh, profiles/r05_experiments.txt.
 
 __device__ __forceinline__ int world_to_px(int v)
 {
@@ -1545,7 +1553,7 @@ __device__ __forceinline__ void ami_paint_units(const AmiPainter<C>& p, uint8_t*
 {
     constexpr int H = TBX_AMI_H;
     using Stager = RowStager<C, TBX_AMI_W, AMI_UNIT_ROWS>;
-    constexpr int NUNITS = H / AMI_UNIT_ROWS;
+    constexpr int NUNITS = (H + AMI_UNIT_ROWS - 1) / AMI_UNIT_ROWS;
     const int u0 = split > 1 ? 0 : (int)(((uint32_t)env * 7u) % (uint32_t)NUNITS);
     for (int k = part; k < NUNITS; k += split) {
         int u = u0 + k;
@@ -1553,17 +1561,18 @@ __device__ __forceinline__ void ami_paint_units(const AmiPainter<C>& p, uint8_t*
         const int y_first = u * AMI_UNIT_ROWS;
         const uint32_t mv_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.mv_rows, y_first);
         const uint32_t busy_chunk = row_mask_chunk<AMI_UNIT_ROWS>(p.busy, y_first);
-        if (busy_chunk == 0 && C != 4) {                     // background only: no staging (RGBA: staged is faster)
+        const int rows_here = H % AMI_UNIT_ROWS == 0 ? AMI_UNIT_ROWS : min(AMI_UNIT_ROWS, H - y_first);
+        if (busy_chunk == 0 && C != 4 && rows_here == AMI_UNIT_ROWS) {   // background only: no staging (RGBA: staged is faster)
             Stager::fill_unit(frame + (size_t)u * Stager::UNIT_BYTES, lane, p.c_bg);
             continue;
         }
 #pragma unroll 1
-        for (int r = 0; r < AMI_UNIT_ROWS; r++) {
+        for (int r = 0; r < rows_here; r++) {
             uint32_t px[4];
             p.paint_row(y_first + r, (mv_chunk >> r) & 1u, px);
             if (p.active) st.put4p(r, lane, px[0], px[1], px[2], px[3]);
         }
-        st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane);
+        st.flush(frame + (size_t)u * Stager::UNIT_BYTES, lane, rows_here);
     }
 }
 
