@@ -901,6 +901,9 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
 
 def main():
     global SETTLE, GATHER_TRANSPORT
+    # multi-process GPU work on this pool needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails with "invalid argument" under the
+    # legacy mode); the GPU boxes export it already -- set before anything loads the HIP runtime, for launchers that do not
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse()
     SETTLE = max(0, args.settle)
     GATHER_TRANSPORT = args.gather

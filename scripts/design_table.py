@@ -26,25 +26,25 @@ h = L("bench_breakout_65536.json")
 whole = lambda j: (j["roofline"].get("algorithmic_bytes_per_launch") or j["roofline"].get("algorithmic_bytes_per_step")) / (j["ms_per_step"] * 1e-3) / 8e12
 if h:
     s = h["serialised"]
-    rows.append("| **Breakout 65 536** (headline, the driver's command; fused) | **%s** | %.4f | **%.3f** / %.3f | %s (%.4f; kernel %.3f) |" % (
+    rows.append("| **Breakout 65 536** (headline line, fused; it also carries the config rows) | **%s** | %.4f | **%.3f** / %.3f | %s (%.4f; kernel %.3f) |" % (
         M(h["value"]), h["ms_per_step"], h["roofline"]["frac"], whole(h), M(s["value"]), s["ms_per_step"], s["roofline_frac"]))
 for name, label in (("bench_space_invaders_65536.json", "SpaceInvaders 65 536"), ("bench_amidar_65536.json", "Amidar 65 536"), ("bench_gridworld_65536.json", "GridWorld 65 536")):
     j = L(name)
     if j:
         rows.append("| %s | %s | %.4f | %.3f / %.3f | = value |" % (label, M(j["value"]), j["ms_per_step"], j["roofline"]["frac"], whole(j)))
 if h and "configs" in h:
-    for key, label in (("2_breakout_4096", "Breakout 4 096 (config 2, fused)"), ("3_space_invaders_4096", "SpaceInvaders 4 096 (config 3, overlapped launches)"),
-                       ("4_amidar_4096", "Amidar 4 096 (config 4)"), ("5_mixed_32768_per_gpu", "mixed 10 923 + 10 923 + 10 922 + gather (config 5's per-GPU share, K = 4)")):
+    for key, label in (("2_breakout_4096", "Breakout 4 096 (config 2)"), ("3_space_invaders_4096", "SpaceInvaders 4 096 (config 3)"),
+                       ("4_amidar_4096", "Amidar 4 096 (config 4)"), ("5_mixed_32768_per_gpu", "mixed 32 768 + gather (config 5 per GPU, K = 4)")):
         c = h["configs"].get(key)
         if not c or "error" in c:
             continue
         ser = c.get("serialised")
-        rows.append("| %s — in the headline line | %s | %.4f | %s / %.3f | %s |" % (
+        rows.append("| %s | %s | %.4f | %s / %.3f | %s |" % (
             label, M(c["value"]), c["ms_per_step"], ("%.3f" % c["kernel_frac"]) if c.get("kernel_frac") else "—", c["whole_step_frac"],
             ("%s (%.4f)" % (M(ser["value"]), ser["ms_per_step"])) if isinstance(ser, dict) else "= value"))
 g = L("bench_breakout_8192_gather.json")
 if g:
-    rows.append("| Breakout 8 192 + gather (1/8 of the headline batch; fused, K = 4) | %s per GPU | %.4f | %.3f / %.3f | pair K = 4: %.4f; pair, a collective per step: %.4f |" % (
+    rows.append("| Breakout 8 192 + gather (1/8 batch; fused, K = 4) | %s per GPU | %.4f | %.3f / %.3f | pair K = 4: %.4f; pair, a collective per step: %.4f |" % (
         M(g["value"]), g["ms_per_step"], g["roofline"]["frac"], whole(g), (L("bench_breakout_8192_gather_pair_k4.json") or {}).get("ms_per_step", 0),
         (L("bench_breakout_8192_gather_pair_k1.json") or {}).get("ms_per_step", 0)))
 print("\n".join(rows))

@@ -347,7 +347,7 @@ def test_gpu_newest_plane_and_async_host_delivery(game, oh, ow, stack, generic, 
     new_plane are TBX_E_INVALID."""
     from toybox_amd._lib import ToyboxAmdError
     # 2 048 envs and more: the fused observation kernels go out in four chunks of envs, each chunk's copy beside the next chunk's kernel
-    n = 2501 if (oh == 84 and game in ("breakout", "space_invaders", "amidar")) else 300
+    n = 2501 if (oh == 84 and not generic and game in ("breakout", "space_invaders", "amidar")) else 300
     wrappers = game != "gridworld"
     g, o = Engine(game, n, lib=hip_lib), Engine(game, n, lib=oracle_lib)
     if generic:
@@ -364,7 +364,7 @@ def test_gpu_newest_plane_and_async_host_delivery(game, oh, ow, stack, generic, 
     bufs = {"reward": g.host_array((n,), np.float32), "done": g.host_array((n,), np.uint8), "obs": g.host_array((n, oh, ow, stack)),
             "ep_done": g.host_array((n,), np.uint8), "ep_return": g.host_array((n,), np.float32), "ep_length": g.host_array((n,), np.int32)}
     ends = 0
-    for t in range(150 if n == 300 else 60):
+    for t in range(150 if n == 300 else 40):
         a = synthetic_actions(game, n, t, seed=3)
         g.agent_step_begin(a, plane=plane, **bufs)
         if t == 0:
