@@ -951,8 +951,8 @@ struct SiPainter {
     uint32_t c_enemy, c_ufo, c_ground, c_hud, c_black, c_ship, l_col, s_c;
     bool ufo_on, s_valid, e_vis, l_on;
     int s_x, s_y;
-    int e_y0, e_y1, s_y0, s_y1;             // scanline ranges that can hold enemies / shield rows at all (wave-uniform)
-    long l_lo, l_hi;                        // ... lasers
+    int e_y0, e_y1, s_y0, s_y1;             // scanline ranges that can hold enemies / shield rows at all (wave-uniform; clipped to the
+    int l_lo, l_hi;                         // ... lasers                                           256 rows of the class masks)
     uint64_t cand[SI_NG];                   // per pixel group: visible enemies whose columns overlap it (bit e)
     int e_tab;                              // lane = enemy: its sprite table base in spr_lds
     uint64_t busy[4];                       // scanlines that show anything but black (wave-uniform, 256 bits)
@@ -1021,27 +1021,19 @@ struct SiPainter {
         s_y = sel3(sk, f[F_SHIELD_Y0], f[F_SHIELD_Y1], f[F_SHIELD_Y2]) + sr;
         s_c = pix_of<C>((uint32_t)sel3(sk, f[F_SHIELD_C0], f[F_SHIELD_C1], f[F_SHIELD_C2]));
         e_vis = lane < ne && (e_alive(s) || e_dc(s) >= 0);
-        e_y0 = e_vis ? s.ey : INT32_MAX; e_y1 = e_vis ? s.ey + TBX_SI_ENEMY_H : INT32_MIN;
         l_on = lane == SHIP_SLOT ? f[F_HAS_SHIP_LASER] != 0 : lane < f[F_N_LASERS];
-        l_lo = l_on ? (long)s.lf[LF_Y] : LONG_MAX; l_hi = l_on ? (long)s.lf[LF_Y] + s.lf[LF_H] : LONG_MIN;
-        s_y0 = s_valid && s.srow ? s_y : INT32_MAX; s_y1 = s_valid && s.srow ? s_y + 1 : INT32_MIN;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            e_y0 = min(e_y0, __shfl_xor(e_y0, o)); e_y1 = max(e_y1, __shfl_xor(e_y1, o));
-            s_y0 = min(s_y0, __shfl_xor(s_y0, o)); s_y1 = max(s_y1, __shfl_xor(s_y1, o));
-            const long a = ((long)__shfl_xor((int)(l_lo >> 32), o) << 32) | (uint32_t)__shfl_xor((int)l_lo, o);
-            const long b = ((long)__shfl_xor((int)(l_hi >> 32), o) << 32) | (uint32_t)__shfl_xor((int)l_hi, o);
-            l_lo = a < l_lo ? a : l_lo; l_hi = b > l_hi ? b : l_hi;
-        }
-        e_y0 = wave_uniform(e_y0); e_y1 = wave_uniform(e_y1); s_y0 = wave_uniform(s_y0); s_y1 = wave_uniform(s_y1);
+        // (the scanline ranges e_y0 .. l_hi come out of the class masks below: first and last set bit, scalar -- round 5; until then
+        // they were six 6-step wave reductions, 36 ds_bpermute per set-up, and the set-ups are 29 % of the agent observation kernel)
 
         cand[0] = cand[1] = 0ull;
-        for (uint64_t m = __ballot(e_vis); m; m &= m - 1) {
+        for (uint64_t m = __ballot(e_vis); m;) {                // one turn per distinct x (six for a formation), not per enemy
             const int e = (int)__builtin_ctzll(m);
             const int ex = __builtin_amdgcn_readlane(s.ex, e);
+            const uint64_t same = __ballot(e_vis && s.ex == ex);
+            m &= ~same;
 #pragma unroll
             for (int g = 0; g < SI_NG; g++)
-                if (gx[g] + 3 >= ex && gx[g] < ex + TBX_SI_ENEMY_W) cand[g] |= 1ull << e;
+                if (gx[g] + 3 >= ex && gx[g] < ex + TBX_SI_ENEMY_W) cand[g] |= same;
         }
         e_tab = (s.estatus & 1) ? (f[F_ORIENT] ? 0 : TBX_SI_ENEMY_H) : 2 * TBX_SI_ENEMY_H;
         ym_cached = 0ull; ec_multi = false;
@@ -1075,13 +1067,25 @@ struct SiPainter {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        int y0[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, y1[3] = {INT32_MIN, INT32_MIN, INT32_MIN};   // CLS_ENEMY, CLS_SHIELD, CLS_LASER
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             uint32_t lo = 0u, hi = 0u;
 #pragma unroll
-            for (int c = 0; c < NCLS; c++) { lo |= cls[c * 8 + 2 * k]; hi |= cls[c * 8 + 2 * k + 1]; }
-            busy[k] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(lo) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(hi) << 32);
+            for (int c = 0; c < NCLS; c++) {
+                const uint32_t cl = (uint32_t)__builtin_amdgcn_readfirstlane(cls[c * 8 + 2 * k]), ch = (uint32_t)__builtin_amdgcn_readfirstlane(cls[c * 8 + 2 * k + 1]);
+                lo |= cl; hi |= ch;
+                if (c <= CLS_LASER) {
+                    const uint64_t m = (uint64_t)cl | ((uint64_t)ch << 32);
+                    if (m) {
+                        if (y0[c] == INT32_MAX) y0[c] = 64 * k + (int)__builtin_ctzll(m);
+                        y1[c] = 64 * k + 64 - (int)__builtin_clzll(m);
+                    }
+                }
+            }
+            busy[k] = (uint64_t)lo | ((uint64_t)hi << 32);
         }
+        e_y0 = y0[CLS_ENEMY]; e_y1 = y1[CLS_ENEMY]; s_y0 = y0[CLS_SHIELD]; s_y1 = y1[CLS_SHIELD]; l_lo = y0[CLS_LASER]; l_hi = y1[CLS_LASER];
         __builtin_amdgcn_wave_barrier();
     }
 
