@@ -45,9 +45,11 @@ for g in breakout space_invaders amidar gridworld; do
   AB_PREROLL=60 timeout 300 python scripts/ab_agent.py $g scripts/ab/lib_prev.so toybox_amd/csrc/libtoybox_amd.so > "$OUT/ab_agent_$g.txt" 2>&1
 done
 # ---- the agent observation kernel of SpaceInvaders taken apart (DIAG build) and the store-alignment microbenchmark
-bash scripts/agent_diag.sh space_invaders 65536 > /dev/null 2>&1
-cp "$REPO/gpurun_out/agent_diag/times_space_invaders.txt" "$OUT/agent_diag_times.txt" 2>/dev/null
-cp "$REPO/gpurun_out/agent_diag/counters_space_invaders.txt" "$OUT/agent_diag_counters.txt" 2>/dev/null
+for g in space_invaders amidar; do
+  bash scripts/agent_diag.sh $g 65536 > /dev/null 2>&1
+  cp "$REPO/gpurun_out/agent_diag/times_$g.txt" "$OUT/agent_diag_times_$g.txt" 2>/dev/null
+  cp "$REPO/gpurun_out/agent_diag/counters_$g.txt" "$OUT/agent_diag_counters_$g.txt" 2>/dev/null
+done
 make -C scripts/ubench write_align > /dev/null 2>&1; timeout 200 scripts/ubench/write_align > "$OUT/write_align.txt" 2>&1
 # ---- profiles: kernel trace + PMC (separate passes).  The first one is the driver's own command (--steps 20 --warmup 5).
 PROFILE_STEPS=20 PROFILE_WARMUP=5 bash scripts/profile_gpu.sh ${TAG} --no-extras > /dev/null 2>&1
