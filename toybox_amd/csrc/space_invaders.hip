@@ -965,6 +965,7 @@ struct SiPainter {
     static constexpr bool FAST_ROWS = true;
     static constexpr bool SPARSE_ROWS = true;    // (agent_fused_wave: walk the active scanlines only -- about half of the 210 scanlines hold nothing)
     int f_start[2];                         // first source pixel of this lane's two output columns (-1: column not in use)
+    uint64_t fcand[2];                      // per window: visible enemies whose columns reach it (bit e)
     mutable uint64_t fym_cached;
     mutable uint32_t f_hit[2];              // (enemy x + 64) << 16 | (sprite-table row of scanline 0 + 1024); ~0u: no enemy under the window
     mutable bool f_multi;
@@ -1107,28 +1108,36 @@ struct SiPainter {
         f_start[0] = on0 ? c0.start : -1; f_start[1] = on1 ? c1.start : -1;
         fym_cached = 0ull; f_multi = false;
         f_hit[0] = f_hit[1] = ~0u;
+        // per window: the visible enemies whose columns reach it -- one loop turn per distinct enemy x, like `cand` in setup()
+        fcand[0] = fcand[1] = 0ull;
+        for (uint64_t m = __ballot(e_vis); m;) {
+            const int e = (int)__builtin_ctzll(m);
+            const int ex = __builtin_amdgcn_readlane(s.ex, e);
+            const uint64_t same = __ballot(e_vis && s.ex == ex);
+            m &= ~same;
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                if (f_start[q] >= 0 && f_start[q] + 8 > ex && f_start[q] < ex + TBX_SI_ENEMY_W) fcand[q] |= same;
+        }
     }
 
     // looks up the enemies crossing scanline y under this lane's two windows (once per formation row: the set is the same
     // for its ten scanlines); false if some window holds two of them (states written by hand): the scanline then takes the
-    // painted path
+    // painted path.  Round 5: the one enemy of a window comes out of fcand & ym with three cross-lane reads, where a serial loop
+    // over the row's enemies (find-first-set -> readlane -> compare, six dependent turns per formation row) used to look for it.
     __device__ __forceinline__ bool fast_ready(int y) const
     {
         const uint64_t ym = __ballot(e_vis && y >= s.ey && y < s.ey + TBX_SI_ENEMY_H);
         if (ym != fym_cached) {
             fym_cached = ym;
-            f_hit[0] = f_hit[1] = ~0u;
             bool multi = false;
-            for (uint64_t m = ym; m; m &= m - 1) {
-                const int e = (int)__builtin_ctzll(m);
-                const int ex = __builtin_amdgcn_readlane(s.ex, e);
-                const uint32_t hit = ((uint32_t)(ex + 64) << 16) | (uint32_t)(__builtin_amdgcn_readlane(e_tab, e) - __builtin_amdgcn_readlane(s.ey, e) + 1024);
 #pragma unroll
-                for (int q = 0; q < 2; q++)
-                    if (f_start[q] >= 0 && f_start[q] + 8 > ex && f_start[q] < ex + TBX_SI_ENEMY_W) {
-                        multi |= f_hit[q] != ~0u;
-                        f_hit[q] = hit;
-                    }
+            for (int q = 0; q < 2; q++) {
+                const uint64_t c = fcand[q] & ym;
+                const int e = c ? (int)__builtin_ctzll(c) : 0;
+                const int ex = __shfl(s.ex, e), ey = __shfl(s.ey, e), tab = __shfl(e_tab, e);
+                f_hit[q] = c ? ((uint32_t)(ex + 64) << 16) | (uint32_t)(tab - ey + 1024) : ~0u;
+                multi |= (c & (c - 1)) != 0;
             }
             f_multi = __ballot(multi) != 0;
         }
