@@ -588,3 +588,35 @@ def test_gpu_bench_n_process_flow_on_one_device_with_the_host_transport(tmp_path
     assert "HOST-STAGED" in line["config"]["parallelism"]
     assert line["loop"]["form"] == "fused" and line["roofline"]["avg_launch_ms"] > 0
     assert line["cpu_baseline"]["value"] > 0 and line["check"]["mean_score"] > 0
+
+
+def test_mixed_batch_segment_sizes(oracle_lib):
+    """BASELINE config 5's per-GPU share is 32 768 envs in three contiguous segments whose sizes differ by at most one
+    (10 923 + 10 923 + 10 922; VERDICT r04 weak #10: 3 x 10 922 is not 32 768): MixedBatch takes one size per game, offsets and
+    seeds follow the global env index, and a MixedBatch cut that way equals three engines seeded at those offsets."""
+    from toybox_amd import Engine
+    from toybox_amd.parallel import MixedBatch
+    assert MixedBatch.split_sizes(32768, 3) == [10923, 10923, 10922] and sum(MixedBatch.split_sizes(262144 // 8, 3)) == 32768
+    assert MixedBatch.split_sizes(7, 3) == [3, 2, 2] and MixedBatch.split_sizes(9, 3) == [3, 3, 3]
+    games = ["breakout", "amidar", "space_invaders"]
+    sizes = MixedBatch.split_sizes(20, 3)
+    mb = MixedBatch(games, sizes, engine_factory=lambda g, n: Engine(g, n, lib=oracle_lib), global_offset=100)
+    assert mb.n_envs == 20 and mb.sizes == [7, 7, 6] and mb.offsets == [100, 107, 114] and mb.n_per_game is None
+    refs = []
+    for g, n, off in zip(games, sizes, mb.offsets):
+        e = Engine(g, n, lib=oracle_lib)
+        e.seed(1234 + off); e.new_game()
+        refs.append(e)
+    for t in range(60):
+        mb.step_synthetic(1337, t)
+        for e, off in zip(refs, mb.offsets):
+            e.step_synthetic(1337, t, env_offset=off)
+    for a, b in zip(mb.engines, refs):
+        for i in range(a.n_envs):
+            assert bytes(a.get_state(i)) == bytes(b.get_state(i))
+    assert MixedBatch(games, 4, engine_factory=lambda g, n: Engine(g, n, lib=oracle_lib)).n_per_game == 4
+    with pytest.raises(ValueError):
+        MixedBatch(games, [4, 4], engine_factory=lambda g, n: Engine(g, n, lib=oracle_lib))
+    mb.close()
+    for e in refs:
+        e.close()
