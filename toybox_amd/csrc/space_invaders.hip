@@ -951,7 +951,6 @@ struct SiPainter {
     uint32_t c_enemy, c_ufo, c_ground, c_hud, c_black, c_ship, l_col, s_c;
     bool ufo_on, s_valid, e_vis, l_on;
     int s_x, s_y;
-    bool sh_multi;                          // some pixel group lies under two shields (states written by hand): paint_row walks them (wave-uniform)
     int e_y0, e_y1, s_y0, s_y1;             // scanline ranges that can hold enemies / shield rows at all (wave-uniform; clipped to the
     int l_lo, l_hi;                         // ... lasers                                           256 rows of the class masks)
     uint64_t cand[SI_NG];                   // per pixel group: visible enemies whose columns overlap it (bit e)
@@ -1022,17 +1021,6 @@ struct SiPainter {
         s_x = sel3(sk, f[F_SHIELD_X0], f[F_SHIELD_X1], f[F_SHIELD_X2]);
         s_y = sel3(sk, f[F_SHIELD_Y0], f[F_SHIELD_Y1], f[F_SHIELD_Y2]) + sr;
         s_c = pix_of<C>((uint32_t)sel3(sk, f[F_SHIELD_C0], f[F_SHIELD_C1], f[F_SHIELD_C2]));
-        {
-            bool multi = false;
-#pragma unroll
-            for (int g = 0; g < SI_NG; g++) {
-                int under = 0;
-#pragma unroll
-                for (int k = 0; k < TBX_SI_MAX_SHIELDS; k++) under += shield_over(f, k, gx[g]) ? 1 : 0;
-                multi |= under > 1;
-            }
-            sh_multi = __ballot(multi) != 0;
-        }
         e_vis = lane < ne && (e_alive(s) || e_dc(s) >= 0);
         l_on = lane == SHIP_SLOT ? f[F_HAS_SHIP_LASER] != 0 : lane < f[F_N_LASERS];
         // (the scanline ranges e_y0 .. l_hi come out of the class masks below: first and last set bit, scalar -- round 5; until then
@@ -1198,13 +1186,6 @@ struct SiPainter {
         return wave_uniform((int)m);
     }
 
-    // shield k exists and its 16 columns reach the 4-pixel group that starts at x
-    static __device__ __forceinline__ bool shield_over(const int32_t* f, int k, int x)
-    {
-        const int sx = f[F_SHIELD_X0 + k];
-        return k < f[F_N_SHIELDS] && x + 3 >= sx && x < sx + TBX_SI_SHIELD_W;
-    }
-
     // one busy scanline as finished pixel values
     __device__ __forceinline__ void paint_row(int y, uint32_t (&px)[SI_NG][4]) const
     {
@@ -1215,37 +1196,13 @@ struct SiPainter {
         for (int g = 0; g < NG; g++)
 #pragma unroll
             for (int i = 0; i < 4; i++) px[g][i] = base;
-        // shields (ascending shield index, then row: one row per shield can match y).  A pixel group lies under at most one shield
-        // unless a state written by hand stacks them (sh_multi): its row of that shield comes with one cross-lane read (round 5:
-        // the walk over the scanline's shield rows below -- find-first-set, three readlanes, paint, up to three dependent turns on
-        // each of 18 scanlines -- is a serial chain, and those are what the set-ups and painted rows of this kernel pay for)
+        // shields (ascending shield index, then row: one row per shield can match y)
         if (y >= s_y0 && y < s_y1) {
-            if (!sh_multi) {
-#pragma unroll
-                for (int g = 0; g < NG; g++) {
-                    int kk = -1;                                     // the shield over this group: three compares, nothing kept between scanlines
-#pragma unroll
-                    for (int q = 0; q < TBX_SI_MAX_SHIELDS; q++) kk = shield_over(f, q, gx[g]) ? q : kk;
-                    const int k = kk < 0 ? 0 : kk;
-                    const int r = y - sel3(k, f[F_SHIELD_Y0], f[F_SHIELD_Y1], f[F_SHIELD_Y2]);
-                    const bool in = kk >= 0 && r >= 0 && r < TBX_SI_SHIELD_H;
-                    const uint32_t bits = (uint32_t)__shfl((int)s.srow, in ? k * TBX_SI_SHIELD_H + r : 0);
-                    if (in && bits) {
-                        const int sx = sel3(k, f[F_SHIELD_X0], f[F_SHIELD_X1], f[F_SHIELD_X2]);
-                        const uint32_t col = pix_of<C>((uint32_t)sel3(k, f[F_SHIELD_C0], f[F_SHIELD_C1], f[F_SHIELD_C2]));
-                        const uint32_t four = (uint32_t)(((uint64_t)(bits & ((1u << TBX_SI_SHIELD_W) - 1u)) << 4) >> (gx[g] - sx + 4)) & 15u;   // shift in [1, 19]
-#pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            if ((four >> i) & 1u) px[g][i] = col;
-                    }
-                }
-            } else {
-                uint64_t m = __ballot(s_valid && s_y == y && s.srow != 0);
-                while (m) {
-                    const int src = (int)__builtin_ctzll(m);
-                    m &= m - 1;
-                    paint_bits<NG>(px, gx, bcast(s_x, src), bcast(s.srow, src), TBX_SI_SHIELD_W, bcast(s_c, src));
-                }
+            uint64_t m = __ballot(s_valid && s_y == y && s.srow != 0);
+            while (m) {
+                const int src = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                paint_bits<NG>(px, gx, bcast(s_x, src), bcast(s.srow, src), TBX_SI_SHIELD_W, bcast(s_c, src));
             }
         }
         // enemies in index order.  The set of enemies crossing a scanline (ym) is the same for the ten scanlines of a
