@@ -126,6 +126,9 @@ def parse():
                     help="'reference' = the raw single-env loop of the reference's harness (test/benchmark.py:44-58)")
     ap.add_argument("--deepmind", action="store_true",
                     help="agent protocol: also EpisodicLife + FireReset + NoopReset(30) + episode monitor (wrap_deepmind)")
+    ap.add_argument("--obs", default="stack", choices=["stack", "ring"],
+                    help="agent protocol: 'stack' = the rolled uint8[N,84,84,4] on the device (VecFrameStack's array); 'ring' = one new "
+                         "plane per step into a ring of the last 4 (tbx_agent_config_t::new_plane = 2: the reference's data flow)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU arm at the headline batch")
     return ap.parse_args()
 
@@ -455,7 +458,7 @@ def bench_agent_protocol(args):
     eng.seed(SEED_BASE)
     dm = bool(args.deepmind)
     eng.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=dm, fire_reset=dm,
-                   noop_max=30 if dm else 0, noop_seed=2024)
+                   noop_max=30 if dm else 0, noop_seed=2024, new_plane=2 if args.obs == "ring" else 0)
     eng.agent_reset()
     stream = hip.Stream()
     for t in range(Wm):
@@ -470,8 +473,10 @@ def bench_agent_protocol(args):
     out = {"metric": "agent steps/sec (skip-4, 84x84x4 obs), %s" % args.game, "value": n * K / dt, "unit": "agent-steps/s",
            "env_frames_per_s": 4 * n * K / dt, "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": 1000 * dt / K,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": "%s fused %sMaxAndSkip(4)+WarpFrame(84)+ClipReward+FrameStack(4), %d envs, device actions"
-                                  % (args.game, "NoopReset(30)+EpisodicLife+FireReset+Monitor+" if dm else "", n)}}
+           "config": {"workload": "%s fused %sMaxAndSkip(4)+WarpFrame(84)+ClipReward+%s, %d envs, device actions"
+                                  % (args.game, "NoopReset(30)+EpisodicLife+FireReset+Monitor+" if dm else "",
+                                     "ring of the last 4 planes (the stack as LazyFrames)" if args.obs == "ring" else "FrameStack(4)", n),
+                      "obs": args.obs}}
     print(json.dumps(out), flush=True)
     eng.close()
     return 0

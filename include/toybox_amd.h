@@ -577,7 +577,17 @@ typedef struct tbx_agent_config {
                             * atari_wrappers.py:246-275: reset() appends the observation k times) */
     int32_t new_plane;     /* 1: the observation kernels also write the NEWEST plane alone, dense, into TBX_BUF_AGENT_PLANE
                             * (uint8[N][out_h][out_w]) -- what a host-side VecFrameStack receives per step (one new frame per
-                            * env, vec_frame_stack.py:19-27), a quarter of the bytes of the whole stacks */
+                            * env, vec_frame_stack.py:19-27), a quarter of the bytes of the whole stacks.
+                            * 2: the plane INSTEAD of the stack -- the reference's own data flow, where a worker produces one
+                            * frame per step and the stack exists only at the receiver (vec_frame_stack.py:17-30; LazyFrames
+                            * shares the frames between observations, atari_wrappers.py:288-317).  The device keeps a ring of
+                            * the last `stack` planes, TBX_BUF_AGENT_RING = uint8[stack][N][out_h][out_w]; every reset / agent
+                            * step writes slot head = (head + 1) % stack (tbx_agent_ring_head; TBX_BUF_AGENT_PLANE is that slot's
+                            * address and moves with it), so the stack of env i, oldest first, is ring[(head + 1 + c) % stack][i],
+                            * c = 0 .. stack - 1 -- the same bytes as TBX_BUF_AGENT_OBS[i][y][x][c] of the other modes.  An env
+                            * whose stack starts afresh (reset; done under VecFrameStack) gets its other slots rewritten (zeros,
+                            * or the observation with stack_fill = 1).  7 KB written per env and step instead of the roll's 21 KB
+                            * read + 28 KB written.  There is no TBX_BUF_AGENT_OBS and no obs output in this mode (TBX_E_INVALID). */
 } tbx_agent_config_t;
 
 int tbx_agent_init(tbx_engine* engine, const tbx_agent_config_t* cfg);
@@ -606,6 +616,9 @@ int tbx_agent_step_synthetic(tbx_engine* engine, uint64_t action_seed, uint64_t 
 /* host copy of the three episode-monitor arrays of the last agent step (any pointer may be NULL) */
 int tbx_agent_episodes(tbx_engine* engine, uint8_t* ep_done_host, float* ep_return_host, int32_t* ep_length_host);
 #define TBX_BUF_AGENT_PLANE    13   /* uint8[N][out_h][out_w] the newest plane of every stack (tbx_agent_config_t::new_plane) */
+#define TBX_BUF_AGENT_RING     14   /* uint8[stack][N][out_h][out_w] the last `stack` planes (new_plane = 2), newest in slot head */
+/* the ring slot that holds the newest plane (new_plane = 2; 0 .. stack - 1, advanced by every tbx_agent_reset / agent step) */
+int tbx_agent_ring_head(tbx_engine* engine, int32_t* out_head);
 
 /* ------------------------------------------------------------------ host delivery: step_async / step_wait
  * The reference's consumers sit on the HOST side of the boundary: VecEnv.step_async(actions) sends the actions to the workers,
@@ -624,8 +637,8 @@ int tbx_host_free(void* ptr);
 typedef struct tbx_agent_host_out {
     float*   reward;      /* float32[N] */
     uint8_t* done;        /* uint8[N] */
-    uint8_t* obs;         /* uint8[N][out_h][out_w][stack]: the whole stacks (TBX_BUF_AGENT_OBS) */
-    uint8_t* plane;       /* uint8[N][out_h][out_w]: the newest plane only (TBX_BUF_AGENT_PLANE; needs new_plane = 1) */
+    uint8_t* obs;         /* uint8[N][out_h][out_w][stack]: the whole stacks (TBX_BUF_AGENT_OBS; not with new_plane = 2) */
+    uint8_t* plane;       /* uint8[N][out_h][out_w]: the newest plane only (TBX_BUF_AGENT_PLANE; needs new_plane = 1 or 2) */
     uint8_t* ep_done;     /* uint8[N], float32[N], int32[N]: the episode monitor (tbx_agent_episodes) */
     float*   ep_return;
     int32_t* ep_length;

@@ -33,7 +33,9 @@ struct tbx_engine {
     int agent_on;
     tbx_agent_config_t acfg;
     uint8_t *gray_a, *gray_b, *aobs, *afin, *adone;
-    uint8_t* aplane;      /* [n][out_h][out_w] the newest plane of every stack (acfg.new_plane), else NULL */
+    uint8_t* aplane;      /* [n][out_h][out_w] the newest plane of every stack (acfg.new_plane = 1), else NULL */
+    uint8_t* aring;       /* [stack][n][out_h][out_w] the last `stack` planes INSTEAD of the stack (acfg.new_plane = 2: aobs == NULL) */
+    int ahead;            /* the ring slot that holds the newest plane */
     float* areward;
     /* host delivery: the oracle's "_begin" calls do everything at once; "_end" hands out the error the step left */
     int host_pending, agent_host_pending, host_rc;
@@ -559,6 +561,9 @@ int tbx_query(tbx_engine* e, int env, int query_id, const int32_t* args, int n_a
     return fail(e, TBX_E_INVALID, "unknown query for this game");
 }
 
+static uint8_t* agent_newest_plane(tbx_engine* e);
+static int agent_no_stack(tbx_engine* e);
+
 int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_bytes)
 {
     if (!e) return TBX_E_INVALID;
@@ -574,12 +579,20 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     case TBX_BUF_PACKED: p = e->packed; b = n * 8; break;
     case TBX_BUF_AGENT_OBS: case TBX_BUF_AGENT_REWARD: case TBX_BUF_AGENT_DONE:
     case TBX_BUF_AGENT_EP_DONE: case TBX_BUF_AGENT_EP_RETURN: case TBX_BUF_AGENT_EP_LENGTH: case TBX_BUF_AGENT_PLANE:
+    case TBX_BUF_AGENT_RING:
         if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
         if (which == TBX_BUF_AGENT_PLANE) {
-            if (!e->aplane) return fail(e, TBX_E_INVALID, "TBX_BUF_AGENT_PLANE needs tbx_agent_config_t::new_plane = 1");
-            p = e->aplane; b = n * e->acfg.out_h * e->acfg.out_w;
+            if (!agent_newest_plane(e)) return fail(e, TBX_E_INVALID, "TBX_BUF_AGENT_PLANE needs tbx_agent_config_t::new_plane = 1 or 2");
+            p = agent_newest_plane(e); b = n * e->acfg.out_h * e->acfg.out_w;
         }
-        else if (which == TBX_BUF_AGENT_OBS) { p = e->aobs; b = n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack; }
+        else if (which == TBX_BUF_AGENT_RING) {
+            if (!e->aring) return fail(e, TBX_E_INVALID, "TBX_BUF_AGENT_RING needs tbx_agent_config_t::new_plane = 2");
+            p = e->aring; b = n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack;
+        }
+        else if (which == TBX_BUF_AGENT_OBS) {
+            if (!e->aobs) return agent_no_stack(e);
+            p = e->aobs; b = n * e->acfg.out_h * e->acfg.out_w * e->acfg.stack;
+        }
         else if (which == TBX_BUF_AGENT_REWARD) { p = e->areward; b = n * 4; }
         else if (which == TBX_BUF_AGENT_DONE) { p = e->adone; b = n; }
         else if (which == TBX_BUF_AGENT_EP_DONE) { p = e->ep_done; b = n; }
@@ -1140,10 +1153,22 @@ int tbx_sync(tbx_engine* e)
 
 /* ---------------------------------------------------------------- agent-side preprocessing */
 
+static uint8_t* agent_newest_plane(tbx_engine* e)
+{
+    if (e->aring) return e->aring + (size_t)e->ahead * e->n * e->acfg.out_h * e->acfg.out_w;
+    return e->aplane;
+}
+
+static int agent_no_stack(tbx_engine* e)
+{
+    return fail(e, TBX_E_INVALID, "no rolled stack on the device with tbx_agent_config_t::new_plane = 2: the planes are in TBX_BUF_AGENT_RING (newest: TBX_BUF_AGENT_PLANE)");
+}
+
 static void agent_free(tbx_engine* e)
 {
-    free(e->gray_a); free(e->gray_b); free(e->aobs); free(e->afin); free(e->adone); free(e->areward); free(e->aplane);
-    e->aplane = NULL;
+    free(e->gray_a); free(e->gray_b); free(e->aobs); free(e->afin); free(e->adone); free(e->areward); free(e->aplane); free(e->aring);
+    e->aplane = e->aring = NULL;
+    e->ahead = 0;
     free(e->ep_ret); free(e->ep_len); free(e->ep_index); free(e->prev_lives); free(e->ep_len_out); free(e->ep_done);
     free(e->ep_ret_out); free(e->was_real_done); free(e->needs_reset); free(e->noop_override);
     e->was_real_done = e->needs_reset = NULL; e->noop_override = NULL;
@@ -1160,8 +1185,8 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     orc_frame_dims(e->game, &H, &W);
     if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
         cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > 84 * 84 || cfg->noop_max < 0 ||
-        cfg->noop_max > 1000 || cfg->stack_fill < 0 || cfg->stack_fill > 1 || cfg->new_plane < 0 || cfg->new_plane > 1)
-        return fail(e, TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000, stack_fill 0..1, new_plane 0..1)");
+        cfg->noop_max > 1000 || cfg->stack_fill < 0 || cfg->stack_fill > 1 || cfg->new_plane < 0 || cfg->new_plane > 2)
+        return fail(e, TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000, stack_fill 0..1, new_plane 0..2)");
     if ((H + cfg->out_h - 1) / cfg->out_h + 1 > 8 || (W + cfg->out_w - 1) / cfg->out_w + 1 > 8)
         return fail(e, TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
     agent_free(e);
@@ -1169,8 +1194,9 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     e->acfg = *cfg;
     e->gray_a = (uint8_t*)calloc(n, (size_t)H * W);
     e->gray_b = (uint8_t*)calloc(n, (size_t)H * W);
-    e->aobs = (uint8_t*)calloc(n, (size_t)cfg->out_h * cfg->out_w * cfg->stack);
-    e->aplane = cfg->new_plane ? (uint8_t*)calloc(n, (size_t)cfg->out_h * cfg->out_w) : NULL;
+    if (cfg->new_plane == 2) e->aring = (uint8_t*)calloc(n, (size_t)cfg->out_h * cfg->out_w * cfg->stack);
+    else e->aobs = (uint8_t*)calloc(n, (size_t)cfg->out_h * cfg->out_w * cfg->stack);
+    e->aplane = cfg->new_plane == 1 ? (uint8_t*)calloc(n, (size_t)cfg->out_h * cfg->out_w) : NULL;
     e->afin = (uint8_t*)calloc(n, 1);
     e->adone = (uint8_t*)calloc(n, 1);
     e->areward = (float*)calloc(n, sizeof(float));
@@ -1372,7 +1398,18 @@ static void commit_obs(wrap_t* w, int zero_stack)
     const int oh = e->acfg.out_h, ow = e->acfg.out_w, st = e->acfg.stack;
     uint8_t* small = (uint8_t*)malloc((size_t)oh * ow);
     orc_warp_area(w->obs, w->H, w->W, small, oh, ow);
-    orc_stack_push(e->aobs + (size_t)w->i * oh * ow * st, small, oh, ow, st, zero_stack ? (e->acfg.stack_fill ? 2 : 1) : 0);
+    if (e->aring) {
+        /* toybox_amd.h, new_plane = 2: the new frame into the head slot; a stack that starts afresh (reset / done) gets its other
+         * slots rewritten -- zeros (VecFrameStack) or the observation (FrameStack.reset) */
+        const size_t px = (size_t)oh * ow, slot = (size_t)e->n * px;
+        for (int k = 0; k < st; k++) {
+            uint8_t* dst = e->aring + (size_t)((e->ahead + k) % st) * slot + (size_t)w->i * px;
+            if (k == 0 || (zero_stack && e->acfg.stack_fill)) memcpy(dst, small, px);
+            else if (zero_stack) memset(dst, 0, px);
+        }
+    } else {
+        orc_stack_push(e->aobs + (size_t)w->i * oh * ow * st, small, oh, ow, st, zero_stack ? (e->acfg.stack_fill ? 2 : 1) : 0);
+    }
     if (e->aplane) memcpy(e->aplane + (size_t)w->i * oh * ow, small, (size_t)oh * ow);   /* what the worker sends: the new frame alone */
     free(small);
 }
@@ -1406,8 +1443,10 @@ int tbx_agent_reset(tbx_engine* e, uint8_t* obs)
 {
     if (!e) return TBX_E_INVALID;
     if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (obs && !e->aobs) return agent_no_stack(e);
     const int n = e->n;
     memset(e->ep_done, 0, (size_t)n);
+    if (e->aring) e->ahead = (e->ahead + 1) % e->acfg.stack;
 #pragma omp parallel for schedule(static) num_threads(e->threads > 1 ? e->threads : 1)
     for (int i = 0; i < n; i++) {
         wrap_t w;
@@ -1441,6 +1480,7 @@ int tbx_agent_step_device(tbx_engine* e, const int32_t* actions, void* stream)
     if (!actions) return fail(e, TBX_E_INVALID, "actions pointer is NULL");
     const int n = e->n;
     int bad = 0;
+    if (e->aring) e->ahead = (e->ahead + 1) % e->acfg.stack;
 #pragma omp parallel for schedule(static) num_threads(e->threads > 1 ? e->threads : 1) reduction(| : bad)
     for (int i = 0; i < n; i++) {
         wrap_t w;
@@ -1471,8 +1511,19 @@ int tbx_agent_step_synthetic(tbx_engine* e, uint64_t seed, uint64_t t, uint64_t 
     return rc;
 }
 
+int tbx_agent_ring_head(tbx_engine* e, int32_t* out_head)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (!e->aring) return fail(e, TBX_E_INVALID, "tbx_agent_ring_head needs tbx_agent_config_t::new_plane = 2");
+    if (!out_head) return fail(e, TBX_E_INVALID, "output pointer is NULL");
+    *out_head = e->ahead;
+    return TBX_OK;
+}
+
 int tbx_agent_step(tbx_engine* e, const int32_t* actions, float* reward, uint8_t* done, uint8_t* obs)
 {
+    if (e && e->agent_on && obs && !e->aobs) return agent_no_stack(e);
     int rc = tbx_agent_step_device(e, actions, NULL);
     if (rc) return rc;
     size_t n = (size_t)e->n;
@@ -1500,13 +1551,14 @@ int tbx_host_free(void* ptr) { free(ptr); return TBX_OK; }
 static int agent_copy_out(tbx_engine* e, const tbx_agent_host_out_t* o)
 {
     const size_t n = (size_t)e->n, px = (size_t)e->acfg.out_h * e->acfg.out_w;
-    if (o->plane && !e->aplane) return fail(e, TBX_E_INVALID, "the newest plane needs tbx_agent_config_t::new_plane = 1");
+    if (o->plane && !agent_newest_plane(e)) return fail(e, TBX_E_INVALID, "the newest plane needs tbx_agent_config_t::new_plane = 1 or 2");
+    if (o->obs && !e->aobs) return agent_no_stack(e);
     if (o->reward) memcpy(o->reward, e->areward, n * 4);
     if (o->done) memcpy(o->done, e->adone, n);
     if (o->ep_done) memcpy(o->ep_done, e->ep_done, n);
     if (o->ep_return) memcpy(o->ep_return, e->ep_ret_out, n * 4);
     if (o->ep_length) memcpy(o->ep_length, e->ep_len_out, n * 4);
-    if (o->plane) memcpy(o->plane, e->aplane, n * px);
+    if (o->plane) memcpy(o->plane, agent_newest_plane(e), n * px);
     if (o->obs) memcpy(o->obs, e->aobs, n * px * e->acfg.stack);
     return TBX_OK;
 }
@@ -1517,6 +1569,8 @@ int tbx_agent_step_begin(tbx_engine* e, const int32_t* actions, const tbx_agent_
     if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
     if (!actions || !out) return fail(e, TBX_E_INVALID, "actions / output descriptor is NULL");
     if (e->agent_host_pending) return fail(e, TBX_E_INVALID, "tbx_agent_step_begin: the previous step has not been ended (tbx_agent_step_end)");
+    if (out->plane && !agent_newest_plane(e)) return fail(e, TBX_E_INVALID, "the newest plane needs tbx_agent_config_t::new_plane = 1 or 2");
+    if (out->obs && !e->aobs) return agent_no_stack(e);
     int rc = tbx_agent_step_device(e, actions, NULL);
     if (rc) return rc;
     rc = agent_copy_out(e, out);

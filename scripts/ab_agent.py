@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B timing of the agent step of several library builds on ONE box, interleaved.  usage: ab_agent.py game lib1.so lib2.so ..."""
+"""A/B timing of the agent step of several library builds on ONE box, interleaved.  usage: ab_agent.py game lib1.so lib2.so[:ring] ...
+(":ring" behind a path: that arm runs with tbx_agent_config_t::new_plane = 2, the ring of planes instead of the rolled stack)"""
 import ctypes as C
 import os
 import sys
@@ -10,20 +11,22 @@ from toybox_amd import Engine, _abi, hip  # noqa: E402
 
 game = sys.argv[1]
 libs = []
-for p in sys.argv[2:]:
+for spec in sys.argv[2:]:
+    p = spec[:-5] if spec.endswith(":ring") else spec
     lib = C.CDLL(p)
     for name, (res, args) in _abi.PROTOTYPES.items():     # older builds lack the newest entry points: bind what is there
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-    libs.append((p, lib))
+    libs.append((spec, lib))
 n = 65536
 for rnd in range(3):
     for p, lib in libs:
         e = Engine(game, n, lib=lib)
         e.seed(1234)
         dm = bool(int(os.environ.get("AB_DEEPMIND", "0")))
-        e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=dm, fire_reset=dm, noop_max=30 if dm else 0)
+        e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=dm, fire_reset=dm, noop_max=30 if dm else 0,
+                     new_plane=2 if p.endswith(":ring") else 0)
         e.agent_reset()
         for t in range(int(os.environ.get("AB_PREROLL", "10"))):
             e.agent_step_synthetic(1337, t)

@@ -62,6 +62,13 @@ for g_ in ("breakout", "space_invaders", "amidar", "gridworld"):
     if a and d:
         ag.append("%s %.1f / %.1f M" % (g_, a["value"] / 1e6, d["value"] / 1e6))
 print("**Agent path** (65 536 envs, skip 4, 84×84×4; plain / every wrapper, agent-steps/s): " + ", ".join(ag) + ".")
+rg = []
+for g_ in ("breakout", "space_invaders", "amidar", "gridworld"):
+    a, d = L("agent_%s_ring.json" % g_), L("agent_%s_ring_deepmind.json" % g_)
+    if a and d:
+        rg.append("%s %.1f / %.1f M" % (g_, a["value"] / 1e6, d["value"] / 1e6))
+if rg:
+    print("**Agent path, ring of planes instead of the rolled stack** (`--obs ring`, `new_plane = 2`): " + ", ".join(rg) + ".")
 ref = []
 for g_ in ("breakout", "space_invaders", "amidar"):
     r = L("reference_%s.json" % g_)

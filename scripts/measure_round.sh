@@ -27,6 +27,8 @@ python bench.py --gpus 8 --gather host --one-device --cpu-seconds 4 --steps 50 >
 for g in breakout space_invaders amidar gridworld; do
   python bench.py --protocol agent --game $g --steps 100 --warmup 10 > "$OUT/agent_${g}.json" 2>/dev/null
   python bench.py --protocol agent --deepmind --game $g --steps 100 --warmup 10 > "$OUT/agent_${g}_deepmind.json" 2>/dev/null
+  python bench.py --protocol agent --obs ring --game $g --steps 100 --warmup 10 > "$OUT/agent_${g}_ring.json" 2>/dev/null
+  python bench.py --protocol agent --obs ring --deepmind --game $g --steps 100 --warmup 10 > "$OUT/agent_${g}_ring_deepmind.json" 2>/dev/null
 done
 for g in breakout space_invaders amidar; do
   python bench.py --protocol reference --gym --game $g --reps 10 > "$OUT/reference_${g}.json" 2>/dev/null        # 10 reps x 10 000 steps, both arms, CPU beside

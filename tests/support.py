@@ -47,3 +47,24 @@ def amidar_edit_last_lives(js, lives, jump_timer, perimeter_from_start):
         if perimeter_from_start:
             en["ai"] = {"EnemyPerimeterAI": {"start": {"tx": 31, "ty": 15}}}
     return js
+
+
+def read_buffer(engine, which, shape, dtype=np.uint8):
+    """host copy of an engine-owned buffer (TBX_BUF_*): device memory of the HIP library, plain memory of the CPU checker"""
+    import ctypes as C
+    ptr, nbytes = engine.device_buffer(which)
+    out = np.empty(shape, dtype)
+    assert out.nbytes == nbytes, (out.nbytes, nbytes)
+    if hasattr(engine._lib, "orc_splitmix64"):
+        C.memmove(out.ctypes.data, ptr, nbytes)
+    else:
+        from toybox_amd import hip
+        engine.sync()
+        hip.memcpy_dtoh(out, ptr, nbytes)
+    return out
+
+
+def stack_from_ring(ring, head):
+    """uint8[stack][N][h][w] + the newest slot -> uint8[N][h][w][stack], oldest first (include/toybox_amd.h, new_plane = 2)"""
+    k = ring.shape[0]
+    return np.stack([ring[(head + 1 + c) % k] for c in range(k)], axis=-1)

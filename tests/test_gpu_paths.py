@@ -286,7 +286,7 @@ def test_mixed_batch_config5_share_on_three_streams(hip_lib, oracle_lib):
 
 
 ALL_BUFS = ["BUF_REWARD", "BUF_DONE", "BUF_LIVES", "BUF_SCORE", "BUF_FRAME", "BUF_PACKED", "BUF_AGENT_OBS", "BUF_AGENT_REWARD",
-            "BUF_AGENT_DONE", "BUF_AGENT_EP_DONE", "BUF_AGENT_EP_RETURN", "BUF_AGENT_EP_LENGTH", "BUF_GATHERED", "BUF_AGENT_PLANE"]
+            "BUF_AGENT_DONE", "BUF_AGENT_EP_DONE", "BUF_AGENT_EP_RETURN", "BUF_AGENT_EP_LENGTH", "BUF_GATHERED", "BUF_AGENT_PLANE", "BUF_AGENT_RING"]
 
 
 @pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
@@ -313,7 +313,7 @@ def test_every_device_buffer_id(lib):
             with pytest.raises(ToyboxAmdError) as ei:
                 e.device_buffer(declared[name])
             assert ei.value.code == _abi.E_INVALID, name
-    for bad in (-1, 14, 99):
+    for bad in (-1, 15, 99):
         with pytest.raises(ToyboxAmdError) as ei:
             e.device_buffer(bad)
         assert ei.value.code == _abi.E_INVALID
@@ -333,10 +333,24 @@ def test_every_device_buffer_id(lib):
             "BUF_AGENT_EP_DONE": n, "BUF_AGENT_EP_RETURN": 4 * n, "BUF_AGENT_EP_LENGTH": 4 * n, "BUF_AGENT_PLANE": n * 42 * 60}
     seen = set()
     for name in ALL_BUFS:
+        if name == "BUF_AGENT_RING":                         # the ring of planes exists INSTEAD of the stack (new_plane = 2)
+            with pytest.raises(ToyboxAmdError) as ei:
+                e.device_buffer(declared[name])
+            assert ei.value.code == _abi.E_INVALID
+            continue
         p, b = e.device_buffer(declared[name])
         assert p and b == want[name], (name, p, b)
         seen.add(p)
-    assert len(seen) == len(ALL_BUFS), "two buffer ids share an address"
+    assert len(seen) == len(ALL_BUFS) - 1, "two buffer ids share an address"
+    e.agent_init(skip=2, out_h=42, out_w=60, stack=3, new_plane=2)
+    e.agent_reset()
+    p, b = e.device_buffer(_abi.BUF_AGENT_RING)
+    assert p and b == n * 42 * 60 * 3
+    q, b = e.device_buffer(_abi.BUF_AGENT_PLANE)             # the ring's newest slot
+    assert b == n * 42 * 60 and q == p + e.agent_ring_head() * b
+    with pytest.raises(ToyboxAmdError) as ei:
+        e.device_buffer(_abi.BUF_AGENT_OBS)
+    assert ei.value.code == _abi.E_INVALID
     e.close()
 
 

@@ -391,6 +391,92 @@ def test_gpu_newest_plane_and_async_host_delivery(game, oh, ow, stack, generic, 
     g.close(); o.close()
 
 
+RING_CASES = [("breakout", 84, 84, 4, 0), ("space_invaders", 84, 84, 4, 0), ("amidar", 84, 84, 4, 1), ("gridworld", 84, 84, 4, 0),
+              ("breakout", 45, 71, 3, 1), ("amidar", 50, 41, 2, 0), ("space_invaders", 64, 64, 1, 0)]
+
+
+def _ring_against_stack(ring_engine, stack_engine, game, n, oh, ow, stack, steps, wrappers):
+    """every reset / agent step: the ring (TBX_BUF_AGENT_RING + tbx_agent_ring_head) read as a stack == the rolled stack of the
+    other engine; TBX_BUF_AGENT_PLANE is the head slot; rewards, dones and episode records agree"""
+    from support import read_buffer, stack_from_ring
+    from toybox_amd._lib import ToyboxAmdError
+    r, s = ring_engine, stack_engine
+    assert r.agent_reset() is None
+    want = s.agent_reset()
+    heads = []
+    ends = 0
+    for t in range(-1, steps):
+        if t >= 0:
+            a = synthetic_actions(game, n, t, seed=9)
+            o1, rew1, done1 = r.agent_step(a, tolerate_needs_reset=True)
+            want, rew2, done2 = s.agent_step(a, tolerate_needs_reset=True)
+            assert o1 is None and np.array_equal(rew1, rew2) and np.array_equal(done1, done2), t
+            e1, e2 = r.agent_episodes(), s.agent_episodes()
+            assert np.array_equal(e1[0], e2[0]) and np.array_equal(e1[1][e1[0]], e2[1][e2[0]]) and np.array_equal(e1[2][e1[0]], e2[2][e2[0]])
+            ends += int(done1.sum())
+        head = r.agent_ring_head()
+        heads.append(head)
+        ring = read_buffer(r, _abi.BUF_AGENT_RING, (stack, n, oh, ow))
+        assert np.array_equal(stack_from_ring(ring, head), want), t
+        assert np.array_equal(read_buffer(r, _abi.BUF_AGENT_PLANE, (n, oh, ow)), ring[head]), t
+        assert r.device_buffer(_abi.BUF_AGENT_PLANE)[0] == r.device_buffer(_abi.BUF_AGENT_RING)[0] + head * n * oh * ow
+    assert heads == [(heads[0] + i) % stack for i in range(len(heads))]
+    assert ends > 0 or game not in ("breakout", "amidar")     # (SpaceInvaders' first life lasts longer than these rollouts)
+    # there is no rolled stack in this mode: every way of asking for one is TBX_E_INVALID
+    plane, obs = r.host_array((n, oh, ow)), r.host_array((n, oh, ow, stack))
+    for call in (lambda: r.device_buffer(_abi.BUF_AGENT_OBS), lambda: r.agent_fetch(obs=obs),
+                 lambda: r.agent_step_begin(synthetic_actions(game, n, 0), obs=obs),
+                 lambda: r._check(r._lib.tbx_agent_reset(r._h, obs.ctypes.data_as(C.c_void_p))),
+                 lambda: r._check(r._lib.tbx_agent_step(r._h, synthetic_actions(game, n, 0).ctypes.data_as(C.c_void_p), None, None,
+                                                        obs.ctypes.data_as(C.c_void_p)))):
+        with pytest.raises(ToyboxAmdError) as ei:
+            call()
+        assert ei.value.code == _abi.E_INVALID
+    r.agent_fetch(plane=plane)
+    assert np.array_equal(plane, want[..., -1])
+    with pytest.raises(ToyboxAmdError) as ei:                       # ... and no ring in the other modes
+        s.agent_ring_head()
+    assert ei.value.code == _abi.E_INVALID
+    with pytest.raises(ToyboxAmdError) as ei:
+        s.device_buffer(_abi.BUF_AGENT_RING)
+    assert ei.value.code == _abi.E_INVALID
+
+
+@pytest.mark.parametrize("game,oh,ow,stack,fill", RING_CASES)
+def test_plane_ring_is_the_rolled_stack_on_the_checker(game, oh, ow, stack, fill, oracle_lib):
+    """tbx_agent_config_t::new_plane = 2 as the header states it, on the CPU restatement: its ring, read through the head index,
+    holds the bytes of the rolled stack (the mode the wrapper fixtures pin: test_fixture_*), with VecFrameStack's zeroing and
+    FrameStack's refill of a finished env's older frames."""
+    n = 24
+    wrappers = game != "gridworld"
+    r, s = Engine(game, n, lib=oracle_lib), Engine(game, n, lib=oracle_lib)
+    for e, mode in ((r, 2), (s, 0)):
+        e.seed(31)
+        e.agent_init(skip=4, out_h=oh, out_w=ow, stack=stack, clip_reward=False, episodic_life=wrappers, fire_reset=wrappers,
+                     noop_max=6 if wrappers else 0, noop_seed=2, stack_fill=fill, new_plane=mode)
+    _ring_against_stack(r, s, game, n, oh, ow, stack, 220, wrappers)
+    r.close(); s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generic", [False, True], ids=["fused", "generic"])
+@pytest.mark.parametrize("game,oh,ow,stack,fill", RING_CASES)
+def test_gpu_plane_ring_is_the_oracles_rolled_stack(game, oh, ow, stack, fill, generic, hip_lib, oracle_lib):
+    """new_plane = 2 on the HIP library (fused observation kernels and the generic warp kernel; plane sizes that are and are not
+    whole 16-byte groups) against the ORACLE's rolled stack, bit for bit, through episode ends with every wrapper on."""
+    n = 700
+    wrappers = game != "gridworld"
+    r, s = Engine(game, n, lib=hip_lib), Engine(game, n, lib=oracle_lib)
+    if generic:
+        r.set_option(_abi.OPT_AGENT_GENERIC, 1)
+    for e, mode in ((r, 2), (s, 0)):
+        e.seed(31)
+        e.agent_init(skip=4, out_h=oh, out_w=ow, stack=stack, clip_reward=False, episodic_life=wrappers, fire_reset=wrappers,
+                     noop_max=6 if wrappers else 0, noop_seed=2, stack_fill=fill, new_plane=mode)
+    _ring_against_stack(r, s, game, n, oh, ow, stack, 220, wrappers)
+    r.close(); s.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("game", GAMES)
 def test_gpu_step_begin_end_with_frames(game, hip_lib, oracle_lib):

@@ -23,6 +23,7 @@ BUF_AGENT_OBS, BUF_AGENT_REWARD, BUF_AGENT_DONE = 6, 7, 8
 BUF_AGENT_EP_DONE, BUF_AGENT_EP_RETURN, BUF_AGENT_EP_LENGTH = 9, 10, 11
 BUF_GATHERED = 12
 BUF_AGENT_PLANE = 13
+BUF_AGENT_RING = 14
 GATHER_ID_BYTES = 128
 # engine options (tbx_set_option)
 OPT_PIPELINE, OPT_STEP_FORM, OPT_RENDER_SPLIT, OPT_AGENT_GENERIC, OPT_RESIDENT_STEP, OPT_GATHER_EVERY = 0, 1, 2, 3, 4, 5
@@ -348,6 +349,7 @@ PROTOTYPES = {
     "tbx_agent_step_begin": (_i, [_vp, _vp, _p(AgentHostOut)]),
     "tbx_agent_step_end": (_i, [_vp]),
     "tbx_agent_fetch": (_i, [_vp, _p(AgentHostOut)]),
+    "tbx_agent_ring_head": (_i, [_vp, _p(C.c_int32)]),
     "tbx_step_begin": (_i, [_vp, _vp, _u32, _p(StepHostOut)]),
     "tbx_step_end": (_i, [_vp]),
     "tbx_host_stack_push": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),

@@ -17,7 +17,10 @@ struct AgentState {
     int H = 0, W = 0;
     uint8_t *gray_a = nullptr, *gray_b = nullptr;   // generic path only: full-resolution gray frames of the two buffer slots
     uint8_t *obs = nullptr, *fin = nullptr, *done_out = nullptr;
-    uint8_t* plane = nullptr;                       // [N][out_h][out_w] newest plane alone (cfg.new_plane), else nullptr
+    uint8_t* plane = nullptr;                       // [N][out_h][out_w] newest plane alone (cfg.new_plane = 1), else nullptr
+    // cfg.new_plane = 2: no rolled stack (obs == nullptr) but a ring of planes [stack][N][out_h][out_w]; slot `head` holds the newest
+    uint8_t* ring = nullptr;
+    int head = 0;
     // host delivery (tbx_agent_step_begin / _end): an agent step whose outputs are on their way to the caller's host buffers
     bool host_pending = false;
     int32_t* host_actions = nullptr;                // pinned [N]: the caller's actions, copied before _begin returns
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
     const int fresh = sel.zero;                         // VecFrameStack: older slots become zero (FrameStack: the new frame)
     const uint8_t* fa = A + (size_t)env * H * W;
     const uint8_t* fb = B + (size_t)env * H * W;
-    uint8_t* o = obs + (size_t)env * oh * ow * S;
+    uint8_t* o = S != 0 ? obs + (size_t)env * oh * ow * S : nullptr;
     const int words = W >> 2;
     const uint32_t half = (uint32_t)(H * W) / 2u;
     const ColTaps c0 = load_col(tx, lane, ow), c1 = load_col(tx, lane + 64, ow);
@@ -200,10 +203,15 @@ __global__ __launch_bounds__(TBX_BLOCK) void agent_warp_kernel(const uint8_t* __
                     if (q == 0 ? on0 : on1) {
                         // (sum + area/2) / area by multiply-shift
                         const uint32_t val = (uint32_t)(((uint64_t)(acc0[q] + half) * magic) >> 42);
-                        uint8_t* px = o + ((size_t)oy * ow + ox) * S;
-                        if (S == 4) *reinterpret_cast<uint32_t*>(px) = (stack_old_word(fresh ? 0u : old[q], val, fresh) >> 8) | (val << 24);
-                        else stack_push<S>(px, val, fresh);
-                        if (wa.plane) wa.plane[((size_t)env * oh + oy) * ow + ox] = (uint8_t)val;
+                        const size_t at = ((size_t)env * oh + oy) * ow + ox;
+                        if constexpr (S != 0) {
+                            uint8_t* px = o + ((size_t)oy * ow + ox) * S;
+                            if (S == 4) *reinterpret_cast<uint32_t*>(px) = (stack_old_word(fresh ? 0u : old[q], val, fresh) >> 8) | (val << 24);
+                            else stack_push<S>(px, val, fresh);
+                        } else if (fresh) {                  // the plane ring (S == 0): a stack that starts afresh rewrites the other slots too
+                            for (int k = 0; k + 1 < wa.stack; k++) ring_older(wa, k)[at] = fresh == 2 ? (uint8_t)val : (uint8_t)0;
+                        }
+                        if (wa.plane) wa.plane[at] = (uint8_t)val;
                     }
                     acc0[q] = acc1[q];
                     acc1[q] = 0;
@@ -247,11 +255,25 @@ std::vector<AgentTaps> make_taps(int src, int out)
     return t;
 }
 
+size_t ring_stride(const AgentState& a, int n) { return (size_t)n * a.cfg.out_h * a.cfg.out_w; }
+
+// where the observation kernels put the newest plane alone: the plane buffer, the ring's head slot, or nowhere
+uint8_t* newest_plane(const AgentState& a, int n) { return a.ring ? a.ring + (size_t)a.head * ring_stride(a, n) : a.plane; }
+
+int no_stack(tbx_engine* e)
+{
+    return e->fail(TBX_E_INVALID, "no rolled stack on the device with tbx_agent_config_t::new_plane = 2: the planes are in TBX_BUF_AGENT_RING (newest: TBX_BUF_AGENT_PLANE)");
+}
+
 AgentWarpArgs warp_args(tbx_engine* e, int reset_mode)
 {
     AgentState& a = *e->agent;
     AgentWarpArgs w;
-    w.zero = a.done_out; w.mode = a.mode; w.valid = a.buf_valid; w.tx = a.tx; w.obs = a.obs; w.plane = a.plane;
+    w.zero = a.done_out; w.mode = a.mode; w.valid = a.buf_valid; w.tx = a.tx; w.obs = a.obs; w.plane = newest_plane(a, e->n);
+    uint8_t* older[3];
+    for (int k = 0; k < 3; k++)
+        older[k] = (a.ring && k + 1 < a.cfg.stack) ? a.ring + (size_t)((a.head + 1 + k) % a.cfg.stack) * ring_stride(a, e->n) : nullptr;
+    w.older0 = older[0]; w.older1 = older[1]; w.older2 = older[2];
     w.H = a.H; w.W = a.W; w.oh = a.cfg.out_h; w.ow = a.cfg.out_w; w.stack = a.cfg.stack;
     w.first = 0; w.end = e->n;
     w.reset_mode = reset_mode;
@@ -269,7 +291,8 @@ int launch_warp(tbx_engine* e, int reset_mode, hipStream_t s)
     const dim3 grid((e->n + TBX_WAVES_PER_BLOCK - 1) / TBX_WAVES_PER_BLOCK), block(TBX_BLOCK);
     const AgentWarpArgs w = warp_args(e, reset_mode);
 #define WARP(S) hipLaunchKernelGGL(agent_warp_kernel<S>, grid, block, 0, s, a.gray_a, a.gray_b, w, e->n)
-    switch (a.cfg.stack) {
+    switch (a.obs ? a.cfg.stack : 0) {
+    case 0: WARP(0); break;                              // the plane ring (new_plane = 2), any depth
     case 1: WARP(1); break;
     case 2: WARP(2); break;
     case 3: WARP(3); break;
@@ -368,6 +391,7 @@ int agent_step_async(tbx_engine* e, ActionSource src, hipStream_t s, bool with_o
     a.parity ^= 1;
     int rc = in_kernel_reset ? e->ops->agent_reset_envs(e, ra, s) : e->ops->new_game(e, a.fin, s);
     if (rc) return rc;
+    if (a.ring) a.head = (a.head + 1) % a.cfg.stack;     // the slot of the oldest plane takes the new one
     return with_observation ? observe(e, 0, s) : TBX_OK;
 }
 
@@ -392,7 +416,7 @@ void tbx_agent_free(tbx_engine* e)
     if (!e->agent) return;
     AgentState* a = e->agent;
     if (a->host_pending) hipStreamSynchronize(e->stream);      // copies into the caller's buffers are still in flight
-    hipFree(a->plane); hipHostFree(a->host_actions); hipFree(a->io_dev); hipHostFree(a->io_host);
+    hipFree(a->plane); hipFree(a->ring); hipHostFree(a->host_actions); hipFree(a->io_dev); hipHostFree(a->io_host);
     if (a->copy_stream) { hipStreamSynchronize(a->copy_stream); hipStreamDestroy(a->copy_stream); }
     for (hipEvent_t ev : a->chunk_ev) if (ev) hipEventDestroy(ev);
     if (a->copies_done) hipEventDestroy(a->copies_done);
@@ -414,10 +438,15 @@ int tbx_agent_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_bytes
     void* p = nullptr;
     size_t b = 0;
     switch (which) {
-    case TBX_BUF_AGENT_OBS: p = a.obs; b = N * a.cfg.out_h * a.cfg.out_w * a.cfg.stack; break;
+    case TBX_BUF_AGENT_OBS:
+        if (!a.obs) return no_stack(e);
+        p = a.obs; b = N * a.cfg.out_h * a.cfg.out_w * a.cfg.stack; break;
     case TBX_BUF_AGENT_PLANE:
-        if (!a.plane) return e->fail(TBX_E_INVALID, "TBX_BUF_AGENT_PLANE needs tbx_agent_config_t::new_plane = 1");
-        p = a.plane; b = N * a.cfg.out_h * a.cfg.out_w; break;
+        if (!newest_plane(a, e->n)) return e->fail(TBX_E_INVALID, "TBX_BUF_AGENT_PLANE needs tbx_agent_config_t::new_plane = 1 or 2");
+        p = newest_plane(a, e->n); b = N * a.cfg.out_h * a.cfg.out_w; break;
+    case TBX_BUF_AGENT_RING:
+        if (!a.ring) return e->fail(TBX_E_INVALID, "TBX_BUF_AGENT_RING needs tbx_agent_config_t::new_plane = 2");
+        p = a.ring; b = N * a.cfg.out_h * a.cfg.out_w * a.cfg.stack; break;
     case TBX_BUF_AGENT_REWARD: p = a.reward_out; b = N * sizeof(float); break;
     case TBX_BUF_AGENT_DONE: p = a.done_out; b = N; break;
     case TBX_BUF_AGENT_EP_DONE: p = a.ep_done; b = N; break;
@@ -439,8 +468,8 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     const int H = e->ops->height(), W = e->ops->width();
     if (cfg->skip < 1 || cfg->skip > 64 || cfg->stack < 1 || cfg->stack > 4 || cfg->out_h < 1 || cfg->out_w < 1 ||
         cfg->out_h > H || cfg->out_w > W || cfg->out_w > 128 || cfg->out_h * cfg->out_w > AGENT_MAX_OUT_PX || cfg->noop_max < 0 ||
-        cfg->noop_max > 1000 || cfg->stack_fill < 0 || cfg->stack_fill > 1 || cfg->new_plane < 0 || cfg->new_plane > 1)
-        return e->fail(TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000, stack_fill 0..1, new_plane 0..1)");
+        cfg->noop_max > 1000 || cfg->stack_fill < 0 || cfg->stack_fill > 1 || cfg->new_plane < 0 || cfg->new_plane > 2)
+        return e->fail(TBX_E_INVALID, "agent config out of range (skip 1..64, stack 1..4, 1 <= out <= frame, out_w <= 128, out_h*out_w <= 7056, noop_max 0..1000, stack_fill 0..1, new_plane 0..2)");
     if ((H + cfg->out_h - 1) / cfg->out_h + 1 > MAX_TAPS || (W + cfg->out_w - 1) / cfg->out_w + 1 > MAX_TAPS)
         return e->fail(TBX_E_UNSUPPORTED, "agent: the resize ratio needs more than 8 taps per axis");
     AHIP(hipSetDevice(e->device));
@@ -473,8 +502,14 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
         int rc = e->ops->agent_prepare(e);
         if (rc) return rc;
     }
-    AHIP(hipMalloc((void**)&a->obs, N * cfg->out_h * cfg->out_w * cfg->stack));
-    if (cfg->new_plane) {
+    if (cfg->new_plane == 2) {
+        AHIP(hipMalloc((void**)&a->ring, N * cfg->out_h * cfg->out_w * cfg->stack));
+        AHIP(hipMemset(a->ring, 0, N * cfg->out_h * cfg->out_w * cfg->stack));
+    } else {
+        AHIP(hipMalloc((void**)&a->obs, N * cfg->out_h * cfg->out_w * cfg->stack));
+        AHIP(hipMemset(a->obs, 0, N * cfg->out_h * cfg->out_w * cfg->stack));
+    }
+    if (cfg->new_plane == 1) {
         AHIP(hipMalloc((void**)&a->plane, N * cfg->out_h * cfg->out_w));
         AHIP(hipMemset(a->plane, 0, N * cfg->out_h * cfg->out_w));
     }
@@ -498,7 +533,6 @@ int tbx_agent_init(tbx_engine* e, const tbx_agent_config_t* cfg)
     AHIP(hipMalloc((void**)&a->tx, tx.size() * sizeof(AgentTaps)));
     AHIP(hipMemcpy(a->ty, ty.data(), ty.size() * sizeof(AgentTaps), hipMemcpyHostToDevice));
     AHIP(hipMemcpy(a->tx, tx.data(), tx.size() * sizeof(AgentTaps), hipMemcpyHostToDevice));
-    AHIP(hipMemset(a->obs, 0, N * cfg->out_h * cfg->out_w * cfg->stack));
     AHIP(hipMemset(a->fin, 0, N));
     AHIP(hipMemset(a->done_out, 0, N));
     AHIP(hipMemset(a->racc, 0, N * sizeof(int32_t)));
@@ -539,6 +573,7 @@ int tbx_agent_reset(tbx_engine* e, uint8_t* obs_host)
     if (!e) return TBX_E_INVALID;
     if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
     AgentState& a = *e->agent;
+    if (obs_host && !a.obs) return no_stack(e);
     AHIP(hipSetDevice(e->device));
     AHIP(tbx_use_stream(e, e->stream));
     const int n = e->n, tb = 256, gb = (n + tb - 1) / tb;
@@ -561,11 +596,22 @@ int tbx_agent_reset(tbx_engine* e, uint8_t* obs_host)
         if (rc) return rc;
     }
     AHIP(hipMemsetAsync(a.ep_done, 0, N, e->stream));   // records of games that ended inside the reset procedure are not reported here
+    if (a.ring) a.head = (a.head + 1) % a.cfg.stack;
     rc = observe(e, 1, e->stream);
     if (rc) return rc;
     if (obs_host)
         AHIP(hipMemcpyAsync(obs_host, a.obs, N * a.cfg.out_h * a.cfg.out_w * a.cfg.stack, hipMemcpyDeviceToHost, e->stream));
     AHIP(hipStreamSynchronize(e->stream));
+    return TBX_OK;
+}
+
+int tbx_agent_ring_head(tbx_engine* e, int32_t* out_head)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (!e->agent->ring) return e->fail(TBX_E_INVALID, "tbx_agent_ring_head needs tbx_agent_config_t::new_plane = 2");
+    if (!out_head) return e->fail(TBX_E_INVALID, "output pointer is NULL");
+    *out_head = e->agent->head;
     return TBX_OK;
 }
 
@@ -616,13 +662,14 @@ static int agent_queue_outputs(tbx_engine* e, const tbx_agent_host_out_t& out, h
 {
     AgentState& a = *e->agent;
     const size_t N = (size_t)e->n, px = (size_t)a.cfg.out_h * a.cfg.out_w;
-    if (out.plane && !a.plane) return e->fail(TBX_E_INVALID, "the newest plane needs tbx_agent_config_t::new_plane = 1");
+    if (out.plane && !newest_plane(a, e->n)) return e->fail(TBX_E_INVALID, "the newest plane needs tbx_agent_config_t::new_plane = 1 or 2");
+    if (out.obs && !a.obs) return no_stack(e);
     if (out.reward) AHIP(hipMemcpyAsync(out.reward, a.reward_out, N * sizeof(float), hipMemcpyDeviceToHost, s));
     if (out.done) AHIP(hipMemcpyAsync(out.done, a.done_out, N, hipMemcpyDeviceToHost, s));
     if (out.ep_done) AHIP(hipMemcpyAsync(out.ep_done, a.ep_done, N, hipMemcpyDeviceToHost, s));
     if (out.ep_return) AHIP(hipMemcpyAsync(out.ep_return, a.ep_ret_out, N * sizeof(float), hipMemcpyDeviceToHost, s));
     if (out.ep_length) AHIP(hipMemcpyAsync(out.ep_length, a.ep_len_out, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (out.plane) AHIP(hipMemcpyAsync(out.plane, a.plane, N * px, hipMemcpyDeviceToHost, s));
+    if (out.plane) AHIP(hipMemcpyAsync(out.plane, newest_plane(a, e->n), N * px, hipMemcpyDeviceToHost, s));
     if (out.obs) AHIP(hipMemcpyAsync(out.obs, a.obs, N * px * a.cfg.stack, hipMemcpyDeviceToHost, s));
     return TBX_OK;
 }
@@ -634,7 +681,8 @@ int tbx_agent_step_begin(tbx_engine* e, const int32_t* actions_host, const tbx_a
     if (!actions_host || !out) return e->fail(TBX_E_INVALID, "actions / output descriptor is NULL");
     AgentState& a = *e->agent;
     if (a.host_pending) return e->fail(TBX_E_INVALID, "tbx_agent_step_begin: the previous step has not been ended (tbx_agent_step_end)");
-    if (out->plane && !a.plane) return e->fail(TBX_E_INVALID, "the newest plane needs tbx_agent_config_t::new_plane = 1");
+    if (out->plane && !newest_plane(a, e->n)) return e->fail(TBX_E_INVALID, "the newest plane needs tbx_agent_config_t::new_plane = 1 or 2");
+    if (out->obs && !a.obs) return no_stack(e);
     AHIP(hipSetDevice(e->device));
     AHIP(tbx_use_stream(e, e->stream));
     AHIP(tbx_gather_before_step(e, e->stream));
@@ -656,7 +704,7 @@ int tbx_agent_step_begin(tbx_engine* e, const int32_t* actions_host, const tbx_a
     if (rc) return rc;
     if (chunks == 1) {
         // the observation first (the long copy starts as soon as the observation kernel has finished), the small block behind it
-        if (out->plane) AHIP(hipMemcpyAsync(out->plane, a.plane, N * px, hipMemcpyDeviceToHost, e->stream));
+        if (out->plane) AHIP(hipMemcpyAsync(out->plane, newest_plane(a, e->n), N * px, hipMemcpyDeviceToHost, e->stream));
         if (out->obs) AHIP(hipMemcpyAsync(out->obs, a.obs, N * px * a.cfg.stack, hipMemcpyDeviceToHost, e->stream));
     } else {
         if (!a.copy_stream) {
@@ -671,7 +719,7 @@ int tbx_agent_step_begin(tbx_engine* e, const int32_t* actions_host, const tbx_a
             AHIP(hipEventRecord(a.chunk_ev[c], e->stream));
             AHIP(hipStreamWaitEvent(a.copy_stream, a.chunk_ev[c], 0));
             const size_t off = (size_t)first * px, cnt = (size_t)(end - first) * px;
-            if (out->plane) AHIP(hipMemcpyAsync(out->plane + off, a.plane + off, cnt, hipMemcpyDeviceToHost, a.copy_stream));
+            if (out->plane) AHIP(hipMemcpyAsync(out->plane + off, newest_plane(a, e->n) + off, cnt, hipMemcpyDeviceToHost, a.copy_stream));
             if (out->obs) AHIP(hipMemcpyAsync(out->obs + off * a.cfg.stack, a.obs + off * a.cfg.stack, cnt * a.cfg.stack, hipMemcpyDeviceToHost, a.copy_stream));
         }
         AHIP(hipEventRecord(a.copies_done, a.copy_stream));
@@ -733,6 +781,7 @@ int tbx_agent_step(tbx_engine* e, const int32_t* actions_host, float* reward_hos
     if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
     if (!actions_host) return e->fail(TBX_E_INVALID, "actions pointer is NULL");
     AgentState& a = *e->agent;
+    if (obs_host && !a.obs) return no_stack(e);
     AHIP(hipSetDevice(e->device));
     AHIP(tbx_use_stream(e, e->stream));
     AHIP(tbx_gather_before_step(e, e->stream));

@@ -19,6 +19,8 @@ struct AgentWarpArgs {
     const AgentTaps* tx;       // [out_w] column taps
     uint8_t* obs;              // [N][out_h][out_w][stack]
     uint8_t* plane;            // [N][out_h][out_w] the newest plane alone (tbx_agent_config_t::new_plane), or nullptr
+    uint8_t *older0, *older1, *older2;   // ring mode (new_plane = 2; obs == nullptr, plane = the ring slot that takes the newest plane): the ring's
+                               // stack - 1 other slots, [N][out_h][out_w] each -- written only for an env whose stack starts afresh
     int H, W, oh, ow, stack;
     int first, end;            // the envs this launch makes observations for: [first, end) (the whole batch, or one chunk of it when the
                                // host-delivery path overlaps the copy of a chunk's planes with the next chunk's kernel)
@@ -183,6 +185,52 @@ __device__ __forceinline__ void stack_commit(const uint8_t* vals, uint8_t* o, in
     } else {
         for (int i = lane; i < n_px; i += 64) stack_push<S>(o + (size_t)i * S, vals[i], fresh);
     }
+}
+
+// Ring mode (tbx_agent_config_t::new_plane = 2): no rolled stack on the device.  The newest plane goes into the ring slot a.plane
+// points at -- 7 KB per env and agent step instead of the roll's 21 KB read + 28 KB written -- and only an env whose stack starts
+// afresh (VecFrameStack zeroes a finished env's older frames, FrameStack.reset repeats the observation) touches the other slots.
+// (named fields, not an array: an array in the by-value kernel argument is copied to scratch when it is indexed)
+__device__ __forceinline__ uint8_t* ring_older(const AgentWarpArgs& a, int k) { return k == 0 ? a.older0 : k == 1 ? a.older1 : a.older2; }
+
+__device__ __forceinline__ void ring_commit(const uint8_t* vals, const AgentWarpArgs& a, int env, int n_px, int lane, int fresh)
+{
+    __builtin_amdgcn_wave_barrier();
+    const size_t off = (size_t)env * n_px;
+    const int others = a.stack - 1;                        // (wave-uniform)
+    if ((n_px & 15) == 0) {                                // 84 x 84 = 441 x 16: 1 KiB per store instruction
+        const uint4* v = reinterpret_cast<const uint4*>(vals);
+        uint4* p = reinterpret_cast<uint4*>(a.plane + off);
+        const int nq = n_px >> 4;
+        for (int i = lane; i < nq; i += 64) p[i] = v[i];
+        if (fresh) {                                       // (wave-uniform)
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            for (int k = 0; k < others; k++) {
+                uint4* q = reinterpret_cast<uint4*>(ring_older(a, k) + off);
+                if (fresh == 2) for (int i = lane; i < nq; i += 64) q[i] = v[i];
+                else for (int i = lane; i < nq; i += 64) q[i] = z;
+            }
+        }
+        return;
+    }
+    for (int i = lane; i < n_px; i += 64) a.plane[off + i] = vals[i];
+    if (fresh) {
+        for (int k = 0; k < others; k++) {
+            uint8_t* q = ring_older(a, k) + off;
+            for (int i = lane; i < n_px; i += 64) q[i] = fresh == 2 ? vals[i] : (uint8_t)0;
+        }
+    }
+}
+
+// the finished observation plane of one env (LDS) -> the device's frame stack of depth S (and the plane alone), or -- the S == 0
+// instantiation of the observation kernels, one per game whatever the depth -- the plane ring.  (A run-time choice between the
+// two inside one kernel cost the depth-4 stack kernels of GridWorld and Amidar 2.8 % and 1.2 %: register allocation.)
+template <int S>
+__device__ __forceinline__ void observation_commit(const uint8_t* vals, const AgentWarpArgs& a, int env, int lane, int fresh)
+{
+    const int n_px = a.oh * a.ow;
+    if constexpr (S == 0) ring_commit(vals, a, env, n_px, lane, fresh);
+    else stack_commit<S>(vals, a.obs + (size_t)env * n_px * S, n_px, lane, fresh, a.plane ? a.plane + (size_t)env * n_px : nullptr);
 }
 
 // ------------------------------------------------------------------ reset-time wrappers + episode monitor (8f rank 2)
@@ -372,11 +420,9 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
     constexpr int W = P::W, H = P::H, NG = P::NG, NCLS = P::NCLS;
     static_assert(W % 4 == 0 && W / 4 <= 64 * NG && H <= 256, "painter geometry");
     const ObsSel sel = agent_obs_sel(a, env);
-    uint8_t* o = a.obs + (size_t)env * a.oh * a.ow * S;
-    uint8_t* plane_env = a.plane ? a.plane + (size_t)env * a.oh * a.ow : nullptr;
     if (sel.none) {                                                    // max over two zero frames
         for (int i = lane; i < a.oh * a.ow; i += 64) L.vals[i] = 0;
-        stack_commit<S>(L.vals, o, a.oh * a.ow, lane, sel.zero, plane_env);
+        observation_commit<S>(L.vals, a, env, lane, sel.zero);
         return;
     }
     const bool two = sel.two && !AGENT_DIAG(a, 8);
@@ -606,5 +652,5 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
     }
     // the read-modify-write of the frame stack in one sweep with many loads in flight (a dependent load -> store per
     // output row, even fetched a row ahead, left this kernel waiting on HBM latency 84 times per env)
-    if (!AGENT_DIAG(a, 1)) stack_commit<S>(L.vals, o, a.oh * a.ow, lane, sel.zero, plane_env);
+    if (!AGENT_DIAG(a, 1)) observation_commit<S>(L.vals, a, env, lane, sel.zero);
 }

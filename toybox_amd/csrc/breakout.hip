@@ -1377,11 +1377,9 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
     uint8_t* row = lds_all[wave];
     uint8_t* vals = vals_all[wave];
     const ObsSel sel = agent_obs_sel(a, env);
-    uint8_t* o = a.obs + (size_t)env * a.oh * a.ow * S;
-    uint8_t* plane_env = a.plane ? a.plane + (size_t)env * a.oh * a.ow : nullptr;
     if (sel.none) {                                        // max over two zero frames
         for (int i = lane; i < a.oh * a.ow; i += 64) vals[i] = 0;
-        stack_commit<S>(vals, o, a.oh * a.ow, lane, sel.zero, plane_env);
+        observation_commit<S>(vals, a, env, lane, sel.zero);
         return;
     }
     const bool fresh = !sel.two;                           // one frame alone: record B is its source, record A is not composed
@@ -1488,7 +1486,7 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
             }
         }
     }
-    stack_commit<S>(vals, o, a.oh * a.ow, lane, sel.zero, plane_env);
+    observation_commit<S>(vals, a, env, lane, sel.zero);
 }
 
 // ------------------------------------------------------------------ state pack / unpack, scalars
@@ -2068,7 +2066,8 @@ struct BreakoutOps : GameOps {
             recs_valid = true;
         }
         const dim3 grid = grid_for(a.end - a.first), block(TBX_BLOCK);
-        switch (a.stack) {
+        switch (a.obs ? a.stack : 0) {
+        case 0: hipLaunchKernelGGL(brk_agent_warp_kernel<0>, grid, block, 0, s, recs, recsA, recsB, pal, a, e->n); break;      // the plane ring (new_plane = 2), any depth
         case 1: hipLaunchKernelGGL(brk_agent_warp_kernel<1>, grid, block, 0, s, recs, recsA, recsB, pal, a, e->n); break;
         case 2: hipLaunchKernelGGL(brk_agent_warp_kernel<2>, grid, block, 0, s, recs, recsA, recsB, pal, a, e->n); break;
         case 3: hipLaunchKernelGGL(brk_agent_warp_kernel<3>, grid, block, 0, s, recs, recsA, recsB, pal, a, e->n); break;

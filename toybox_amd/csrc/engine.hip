@@ -1357,7 +1357,7 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     case TBX_BUF_FRAME: p = e->frame; b = e->frame_bytes; break;
     case TBX_BUF_PACKED: p = e->packed; b = N * 8; break;
     case TBX_BUF_AGENT_OBS: case TBX_BUF_AGENT_REWARD: case TBX_BUF_AGENT_DONE:
-    case TBX_BUF_AGENT_EP_DONE: case TBX_BUF_AGENT_EP_RETURN: case TBX_BUF_AGENT_EP_LENGTH: case TBX_BUF_AGENT_PLANE:
+    case TBX_BUF_AGENT_EP_DONE: case TBX_BUF_AGENT_EP_RETURN: case TBX_BUF_AGENT_EP_LENGTH: case TBX_BUF_AGENT_PLANE: case TBX_BUF_AGENT_RING:
         return tbx_agent_buffer(e, which, out_ptr, out_bytes);
     case TBX_BUF_GATHERED: return tbx_gather_buffer(e, out_ptr, out_bytes);
     default: return e->fail(TBX_E_INVALID, "unknown buffer id");

@@ -656,7 +656,8 @@ struct GridWorldOps : GameOps {
     {
         dA.cfg = dB.cfg = d.cfg;
         const dim3 grid = wave_grid(a.end - a.first), block(TBX_BLOCK);
-        switch (a.stack) {
+        switch (a.obs ? a.stack : 0) {
+        case 0: hipLaunchKernelGGL(gw_agent_warp_kernel<0>, grid, block, 0, s, d, dA, dB, a, e->n); break;      // the plane ring (new_plane = 2), any depth
         case 1: hipLaunchKernelGGL(gw_agent_warp_kernel<1>, grid, block, 0, s, d, dA, dB, a, e->n); break;
         case 2: hipLaunchKernelGGL(gw_agent_warp_kernel<2>, grid, block, 0, s, d, dA, dB, a, e->n); break;
         case 3: hipLaunchKernelGGL(gw_agent_warp_kernel<3>, grid, block, 0, s, d, dA, dB, a, e->n); break;

@@ -1980,7 +1980,8 @@ struct SiOps : GameOps {
     int agent_warp(tbx_engine* e, const AgentWarpArgs& a, hipStream_t s) override
     {
         const dim3 grid = grid_for(a.end - a.first), block(TBX_BLOCK);
-        switch (a.stack) {
+        switch (a.obs ? a.stack : 0) {
+        case 0: hipLaunchKernelGGL(si_agent_warp_kernel<0>, grid, block, 0, s, d, dA, dB, a, e->n); break;      // the plane ring (new_plane = 2), any depth
         case 1: hipLaunchKernelGGL(si_agent_warp_kernel<1>, grid, block, 0, s, d, dA, dB, a, e->n); break;
         case 2: hipLaunchKernelGGL(si_agent_warp_kernel<2>, grid, block, 0, s, d, dA, dB, a, e->n); break;
         case 3: hipLaunchKernelGGL(si_agent_warp_kernel<3>, grid, block, 0, s, d, dA, dB, a, e->n); break;

@@ -322,12 +322,22 @@ class Engine:
     def agent_init(self, skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=False, fire_reset=False,
                    noop_max=0, noop_seed=0, env_offset=0, stack_fill=0, new_plane=False):
         """stack_fill: what a reset leaves in the older stack slots -- 0 zeros (VecFrameStack), 1 the reset observation (the
-        per-env FrameStack of wrap_deepmind(frame_stack=True)).  new_plane: the device also keeps every stack's newest plane
-        alone (TBX_BUF_AGENT_PLANE) -- what a host-side frame stack receives per step."""
+        per-env FrameStack of wrap_deepmind(frame_stack=True)).  new_plane = 1 / True: the device also keeps every stack's newest
+        plane alone (TBX_BUF_AGENT_PLANE) -- what a host-side frame stack receives per step.  new_plane = 2: the plane INSTEAD
+        of the stack -- a ring of the last `stack` planes (TBX_BUF_AGENT_RING, agent_ring_head()); agent_reset / agent_step
+        return None for the observation, agent_fetch / agent_step_begin deliver plane= only."""
         cfg = _abi.AgentConfig(int(skip), int(out_h), int(out_w), int(stack), int(bool(clip_reward)), int(bool(episodic_life)),
-                               int(bool(fire_reset)), int(noop_max), int(noop_seed), int(env_offset), int(stack_fill), int(bool(new_plane)))
+                               int(bool(fire_reset)), int(noop_max), int(noop_seed), int(env_offset), int(stack_fill), int(new_plane))
         self._check(self._lib.tbx_agent_init(self._h, C.byref(cfg)))
         self._agent_shape = (self.n_envs, int(out_h), int(out_w), int(stack))
+        self._agent_ring = int(new_plane) == 2
+
+    def agent_ring_head(self):
+        """new_plane = 2: the slot of TBX_BUF_AGENT_RING (uint8[stack][N][h][w]) that holds the newest plane; env i's stack, oldest
+        first, is ring[(head + 1 + c) % stack][i], c = 0 .. stack - 1"""
+        h = C.c_int32()
+        self._check(self._lib.tbx_agent_ring_head(self._h, C.byref(h)))
+        return int(h.value)
 
     def agent_set_noops(self, counts):
         """NoopResetEnv.override_num_noops per env (counts[i] > 0 overrides, 0 keeps the default rule); None removes it."""
@@ -347,7 +357,7 @@ class Engine:
         return out
 
     def agent_reset(self, out=None):
-        obs = self._agent_obs_array(out)
+        obs = None if self._agent_ring else self._agent_obs_array(out)
         self._check(self._lib.tbx_agent_reset(self._h, _ptr(obs)))
         return obs
 
@@ -359,7 +369,7 @@ class Engine:
         a = np.ascontiguousarray(actions, dtype=np.int32)
         if a.shape != (self.n_envs,):
             raise ValueError("actions must have shape (%d,)" % self.n_envs)
-        obs = self._agent_obs_array(out)
+        obs = None if self._agent_ring else self._agent_obs_array(out)
         reward = np.empty(self.n_envs, np.float32)
         done = np.empty(self.n_envs, np.uint8)
         rc = self._lib.tbx_agent_step(self._h, _ptr(a), _ptr(reward), _ptr(done), _ptr(obs))

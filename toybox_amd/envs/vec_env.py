@@ -239,7 +239,8 @@ class ToyboxPreprocVecEnv:
       "planes"                  the reference's data flow: ONE new size x size plane per env and step crosses PCIe
                                 (subproc_vec_env.py:63-74 sends one frame per env; VecFrameStack stacks on the receiving side,
                                 vec_frame_stack.py:17-30) into a ring of page-locked planes, and the observation is a
-                                PlaneStack over the newest `stack` of them -- a quarter of the bytes, no roll at all; a
+                                PlaneStack over the newest `stack` of them -- a quarter of the bytes, no roll at all (nor on
+                                the device: tbx_agent_config_t::new_plane = 2, the observation kernels write the plane alone); a
                                 finished env's older planes are zeroed (frame_stack="env": overwritten with the reset
                                 observation) in place, exactly the values VecFrameStack / FrameStack produce;
       "host_stack"              the same one-plane transfer, then VecFrameStack's roll on the host into a real
@@ -271,7 +272,7 @@ class ToyboxPreprocVecEnv:
         self.engine.agent_init(skip=skip, out_h=size, out_w=size, stack=stack, clip_reward=clip_rewards,
                                episodic_life=episode_life, fire_reset=fire_reset, noop_max=noop_max, noop_seed=noop_seed,
                                env_offset=env_offset, stack_fill=1 if frame_stack == "env" else 0,
-                               new_plane=obs_layout != "device_stack")
+                               new_plane=0 if obs_layout == "device_stack" else 2)     # host layouts: no stack on the device at all
         self._pending = None
         self._in_flight = None
         self.closed = False
