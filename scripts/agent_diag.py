@@ -3,7 +3,8 @@
 scripts/ab/lib_diag.so) runs the agent step with parts of agent_fused_wave switched off by TBX_AGENT_DIAG (observations are
 WRONG with any bit set: a measurement build).  One process per variant (the knob is read once per launch from the environment);
 rounds interleaved.  usage: agent_diag.py [game] [envs]          -> ms per agent step per variant
-With AGENT_DIAG_ONE=<bits> it runs that one variant for rocprofv3 --pmc (scripts/agent_diag.sh)."""
+With AGENT_DIAG_ONE=<bits> it runs that one variant for rocprofv3 --pmc (scripts/agent_diag.sh); AGENT_DIAG_OBS=ring: the plane
+ring (new_plane = 2) instead of the rolled stack."""
 import ctypes
 import json
 import os
@@ -24,7 +25,7 @@ def one(bits, steps=40):
     lib = _abi.bind(ctypes.CDLL(os.path.join(ROOT, "scripts", "ab", "lib_diag.so")))
     e = Engine(game, n, lib=lib)
     e.seed(1234)
-    e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True)
+    e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, new_plane=2 if os.environ.get("AGENT_DIAG_OBS") == "ring" else 0)
     e.agent_reset()
     st = hip.Stream()
     for t in range(60):                                   # mid-game states (observations do not feed back into the games)
@@ -53,6 +54,6 @@ for rnd in range(3):
             res[b].append(json.loads(p.stdout.strip().splitlines()[-1])["ms"])
         except Exception:
             print("variant %d failed: %s" % (b, (p.stdout + p.stderr)[-500:]), file=sys.stderr)
-print("%s, %d envs: ms per agent step (4 frames + observation), three rounds" % (game, n))
+print("%s, %d envs%s: ms per agent step (4 frames + observation), three rounds" % (game, n, ", plane ring" if os.environ.get("AGENT_DIAG_OBS") == "ring" else ""))
 for b, name in VARIANTS:
     print("  diag %2d  %-46s %s" % (b, name, "  ".join("%.3f" % v for v in res[b])))

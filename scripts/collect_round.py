@@ -26,11 +26,12 @@ def short(name):
 
 def agent_summary(tag):
     out = ["# rocprofv3 kernel-trace --stats, agent protocol (`bench.py --protocol agent --deepmind --steps 60 --warmup 5`, 65 536 envs)", ""]
-    for game in ("breakout", "space_invaders", "amidar", "gridworld"):
-        stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s_agent_%s" % (tag, game), "*", "*_kernel_stats.csv"))
+    for game, mode in [(g, m) for g in ("breakout", "space_invaders", "amidar", "gridworld") for m in ("", "ring_")]:
+        stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s_agent_%s%s" % (tag, mode, game), "*", "*_kernel_stats.csv"))
         if not stats:
             continue
-        out += ["## " + game, "", "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
+        out += ["## " + game + (", the plane ring instead of the rolled stack (`--obs ring`; `*_agent_warp_kernel<0>`)" if mode else ""), "",
+                "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
         for r in csv.DictReader(open(stats[0])):
             out.append("| `%s` | %s | %.1f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                                                           float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))

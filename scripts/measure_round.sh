@@ -51,6 +51,7 @@ for g in space_invaders amidar; do
   bash scripts/agent_diag.sh $g 65536 > /dev/null 2>&1
   cp "$REPO/gpurun_out/agent_diag/times_$g.txt" "$OUT/agent_diag_times_$g.txt" 2>/dev/null
   cp "$REPO/gpurun_out/agent_diag/counters_$g.txt" "$OUT/agent_diag_counters_$g.txt" 2>/dev/null
+  AGENT_DIAG_OBS=ring timeout 400 python scripts/agent_diag.py $g 65536 > "$OUT/agent_diag_times_${g}_ring.txt" 2>&1
 done
 make -C scripts/ubench write_align > /dev/null 2>&1; timeout 200 scripts/ubench/write_align > "$OUT/write_align.txt" 2>&1
 # ---- profiles: kernel trace + PMC (separate passes).  The first one is the driver's own command (--steps 20 --warmup 5).
@@ -64,6 +65,7 @@ bash scripts/profile_gpu.sh ${TAG}_breakout_8192_gather --envs 8192 --with-gathe
 cd /tmp && export TMPDIR=/tmp
 for g in breakout space_invaders amidar gridworld; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_agent_$g" -- python3 $REPO/bench.py --protocol agent --deepmind --game $g --steps 60 --warmup 5 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_agent_ring_$g" -- python3 $REPO/bench.py --protocol agent --deepmind --obs ring --game $g --steps 60 --warmup 5 > /dev/null 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_mixed/trace" -- python3 $REPO/bench.py --game mixed --envs 32768 --with-gather --no-cpu-baseline --steps 50 --warmup 5 --repeats 2 > /dev/null 2>&1
 cd "$REPO"

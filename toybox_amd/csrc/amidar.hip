@@ -1107,19 +1107,22 @@ __global__ __launch_bounds__(64) void ami_step_tpe_kernel(AmiDev d, AmiDev slot_
                     const int g = it * 64 + lane, r = g >> 5;
                     if ((want >> r) & 1ull) dst.tiles[(size_t)env0 * 32 + g] = lds_rows[r * tpe::ROW_STRIDE + (g & 31)];
                 }
-#pragma unroll 4
-                for (int it = 0; it < 128; it++) {                     // boxes: 64 envs x 128 dwords
-                    const int g = it * 64 + lane, r = g >> 7;
-                    if ((want >> r) & 1ull) dst.boxes[(size_t)env0 * 128 + g] = d.boxes[(size_t)env0 * 128 + g];
+                // (16 bytes per lane and eight loads in flight: at one wave per SIMD every dependent round trip is paid in full)
+                const uint4* bsrc = reinterpret_cast<const uint4*>(d.boxes + (size_t)env0 * 128);
+                uint4* bdst = reinterpret_cast<uint4*>(dst.boxes + (size_t)env0 * 128);
+#pragma unroll 8
+                for (int it = 0; it < 32; it++) {                      // boxes: 64 envs x 128 dwords = 64 x 32 quads
+                    const int g = it * 64 + lane, r = g >> 5;
+                    if ((want >> r) & 1ull) bdst[g] = bsrc[g];
                 }
                 // the movers' positions and caught flags: the three table rows the painter reads (the table is current: the
                 // thread form writes it along with its struct-of-arrays mirror)
 #pragma unroll 4
-                for (int it = 0; it < 48; it++) {                      // 64 envs x 3 rows x 16 slots
-                    const int g = it * 64 + lane, r = g / 48, w = g - r * 48;
-                    const int fld = w < 16 ? M_X : w < 32 ? M_Y : M_CAUGHT;
-                    const size_t at = (size_t)(env0 + r) * NMF * 16 + (size_t)fld * 16 + (w & 15);
-                    if ((want >> r) & 1ull) dst.movers[at] = d.movers[at];
+                for (int it = 0; it < 12; it++) {                      // 64 envs x 3 rows x 4 quads of slots
+                    const int g = it * 64 + lane, r = g / 12, w = g - r * 12;
+                    const int fld = w < 4 ? M_X : w < 8 ? M_Y : M_CAUGHT;
+                    const size_t at = (size_t)(env0 + r) * NMF * 16 + (size_t)fld * 16 + (size_t)(w & 3) * 4;
+                    if ((want >> r) & 1ull) *reinterpret_cast<uint4*>(dst.movers + at) = *reinterpret_cast<const uint4*>(d.movers + at);
                 }
             }
         }

@@ -181,13 +181,26 @@ __global__ __launch_bounds__(128) void gw_step_kernel(GwDev d, ActionSource src,
 __device__ __forceinline__ void gw_copy_env(const GwDev& dst, const GwDev& src, int env, int lane, int lanes)
 {
     const size_t N = (size_t)src.n;
+    static_assert(CELLS % 16 == 0 && (GT * 3 * 4) % 16 == 0, "16-byte copies");
+    // 16 bytes per lane: the 1 KB board is ONE load and one store per wave, the tile table a second pair (all loads first)
+    const uint4* gs = reinterpret_cast<const uint4*>(src.grid + (size_t)env * CELLS);
+    uint4* gd = reinterpret_cast<uint4*>(dst.grid + (size_t)env * CELLS);
+    const uint4* ts = reinterpret_cast<const uint4*>(src.tiles + (size_t)env * GT * 3);
+    uint4* td = reinterpret_cast<uint4*>(dst.tiles + (size_t)env * GT * 3);
+    if (lanes == 64 && CELLS / 16 == 64) {
+        const uint4 g = gs[lane];
+        uint4 t = make_uint4(0u, 0u, 0u, 0u);
+        int32_t sc = 0;
+        if (lane < GT * 3 / 4) t = ts[lane];
+        if (lane < GF) sc = src.sc[(size_t)lane * N + env];
+        gd[lane] = g;
+        if (lane < GT * 3 / 4) td[lane] = t;
+        if (lane < GF) dst.sc[(size_t)lane * N + env] = sc;
+        return;
+    }
     for (int f = lane; f < GF; f += lanes) dst.sc[(size_t)f * N + env] = src.sc[(size_t)f * N + env];
-    const uint32_t* ts = src.tiles + (size_t)env * GT * 3;
-    uint32_t* td = dst.tiles + (size_t)env * GT * 3;
-    for (int i = lane; i < GT * 3; i += lanes) td[i] = ts[i];
-    const uint32_t* gs = reinterpret_cast<const uint32_t*>(src.grid + (size_t)env * CELLS);
-    uint32_t* gd = reinterpret_cast<uint32_t*>(dst.grid + (size_t)env * CELLS);
-    for (int i = lane; i < CELLS / 4; i += lanes) gd[i] = gs[i];
+    for (int i = lane; i < GT * 3 / 4; i += lanes) td[i] = ts[i];
+    for (int i = lane; i < CELLS / 16; i += lanes) gd[i] = gs[i];
 }
 
 // agent layer, single-frame launches: the envs that ran the frame copy their state into a buffer slot
