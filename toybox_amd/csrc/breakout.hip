@@ -1363,8 +1363,10 @@ __device__ __forceinline__ uint32_t brk_gray_line(const BrkRenderRec& rec, const
     return d;
 }
 
+// (five waves per SIMD is what the 29 KB of LDS per block allow; the depth-4 instantiation came out at 97 VGPRs -- four waves -- and ran
+// 10 % slower than before the run-based walk; held to five it stays under 96)
 template <int S>
-__global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRenderRec* __restrict__ recsLive, const BrkRenderRec* __restrict__ recsA,
+__global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void brk_agent_warp_kernel(const BrkRenderRec* __restrict__ recsLive, const BrkRenderRec* __restrict__ recsA,
                                                                    const BrkRenderRec* __restrict__ recsB, BrkGrayPal pal, AgentWarpArgs a, int n)
 {
     constexpr int W = TBX_BRK_W, H = TBX_BRK_H;
@@ -1443,49 +1445,47 @@ __global__ __launch_bounds__(TBX_BLOCK) void brk_agent_warp_kernel(const BrkRend
         need[0] |= (ov[0] << 1) | 1ull;
     }
     uint32_t h0 = 0, h1 = 0;
-    uint32_t acc0[2] = {0, 0}, acc1[2] = {0, 0};
-    // source row sy covers [sy*oh, (sy+1)*oh), output row oy covers [oy*H, (oy+1)*H) in refined units: both walk
-    // incrementally (no division per scanline) and the need mask is consumed one bit per scanline -- this kernel was
-    // SALU-bound (86 % of issue slots) on exactly that bookkeeping
+    uint32_t acc[2] = {0, 0};
+    // source row sy covers [sy*oh, (sy+1)*oh), output row oy covers [oy*H, (oy+1)*H) in refined units.  Only the COMPOSED
+    // scanlines are visited (find-first-set over the need mask; scanline 0 always is one): the run of lines since the previous
+    // composed one shares its horizontal sums h, so it adds h x (its overlap with each output row) -- one turn per composed line
+    // plus one per finished output row instead of one per source scanline (round 5; the walk over all 160 lines was ~130 turns of
+    // bookkeeping and four multiply-adds for lines that change nothing)
     int oy = 0, top = H, pos = 0;
+    auto run_to = [&](int end) {                           // the refined interval [pos, end) has the sums h0 / h1   (wave-uniform)
+        while (top <= end) {
+            const uint32_t w = (uint32_t)(top - pos);      // <= H: 24-bit operands (sums <= 255 W): full-rate v_mad_u32_u24
+            const uint32_t s0 = acc[0] + __umul24(w, h0), s1 = acc[1] + __umul24(w, h1);
+            if (on0) vals[oy * a.ow + lane] = (uint8_t)(((uint64_t)(s0 + half) * a.magic) >> 42);
+            if (on1) vals[oy * a.ow + lane + 64] = (uint8_t)(((uint64_t)(s1 + half) * a.magic) >> 42);
+            acc[0] = 0; acc[1] = 0;
+            pos = top; top += H; oy += 1;
+        }
+        const uint32_t w = (uint32_t)(end - pos);
+        acc[0] += __umul24(w, h0); acc[1] += __umul24(w, h1);
+        pos = end;
+    };
 #pragma unroll 1
     for (int wi = 0; wi < 3; wi++) {
         uint64_t nw = sel4(wi, need[0], need[1], need[2], 0ull);
-        uint64_t oa = sel4(wi, ovA[0], ovA[1], ovA[2], 0ull), ob = sel4(wi, ovB[0], ovB[1], ovB[2], 0ull);
-        uint64_t da = sel4(wi, diff_a[0], diff_a[1], diff_a[2], 0ull);
-        const int sy_end = min(H, 64 * wi + 64);
+        const uint64_t oa = sel4(wi, ovA[0], ovA[1], ovA[2], 0ull), ob = sel4(wi, ovB[0], ovB[1], ovB[2], 0ull);
+        const uint64_t da = sel4(wi, diff_a[0], diff_a[1], diff_a[2], 0ull);
+        if (wi == 2) nw &= (1ull << (H - 128)) - 1ull;      // (bits past the last scanline: the shifted overlay mask may set one)
 #pragma unroll 1
-        for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, oa >>= 1, ob >>= 1, da >>= 1) {
-            if (nw & 1ull) {
-                const uint32_t dB = brk_gray_line(recB, pal, sy, x0, side_dw, hudB, bcB, ob & 1ull);
-                uint32_t v = dB;
-                if (da & 1ull) v = bytemax4(brk_gray_line(recA, pal, sy, x0, side_dw, hudA, bcA, oa & 1ull), dB);   // diff_a is 0 when fresh
-                if (active) reinterpret_cast<uint32_t*>(row)[lane] = v;
-                __builtin_amdgcn_wave_barrier();
-                h0 = on0 ? hsum(row, c0) : 0u;
-                h1 = on1 ? hsum(row, c1) : 0u;
-                __builtin_amdgcn_wave_barrier();
-            }
-            const int pos_next = pos + a.oh;
-            const int w_cur = min(pos_next, top) - pos, w_next = a.oh - w_cur;
-            acc0[0] += __umul24((uint32_t)w_cur, h0); acc0[1] += __umul24((uint32_t)w_cur, h1);     // 24-bit operands (weights <= out_h, sums <= 255 W): full-rate v_mad_u32_u24, not v_mad_u64_u32
-            acc1[0] += __umul24((uint32_t)w_next, h0); acc1[1] += __umul24((uint32_t)w_next, h1);
-            pos = pos_next;
-            if (pos_next >= top) {
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int ox = lane + 64 * q;
-                    if (q == 0 ? on0 : on1) {
-                        vals[oy * a.ow + ox] = (uint8_t)(((uint64_t)(acc0[q] + half) * a.magic) >> 42);
-                    }
-                    acc0[q] = acc1[q];
-                    acc1[q] = 0;
-                }
-                oy += 1;
-                top += H;
-            }
+        for (; nw; nw &= nw - 1ull) {
+            const int b = (int)__builtin_ctzll(nw), sy = 64 * wi + b;
+            run_to(sy * a.oh);
+            const uint32_t dB = brk_gray_line(recB, pal, sy, x0, side_dw, hudB, bcB, (ob >> b) & 1ull);
+            uint32_t v = dB;
+            if ((da >> b) & 1ull) v = bytemax4(brk_gray_line(recA, pal, sy, x0, side_dw, hudA, bcA, (oa >> b) & 1ull), dB);   // diff_a is 0 when fresh
+            if (active) reinterpret_cast<uint32_t*>(row)[lane] = v;
+            __builtin_amdgcn_wave_barrier();
+            h0 = on0 ? hsum(row, c0) : 0u;
+            h1 = on1 ? hsum(row, c1) : 0u;
+            __builtin_amdgcn_wave_barrier();
         }
     }
+    run_to(H * a.oh);
     observation_commit<S>(vals, a, env, lane, sel.zero);
 }
 
