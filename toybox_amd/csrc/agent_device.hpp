@@ -577,78 +577,75 @@ __device__ __forceinline__ void agent_fused_wave(P& pa, P& pb, const typename P:
         if (dirty1 && oy + 1 < a.oh) flush(oy + 1, dev1);
         __builtin_amdgcn_wave_barrier();
     } else {
-    // every scanline in turn (Amidar, GridWorld: the board fills the frame, nearly every scanline is busy, and the bit-by-bit
-    // mask stream below is cheaper per visited scanline than the sparse walk's find-first-set -- same box, agent step at 65 536
-    // envs with the sparse walk: Amidar 2.04 against 1.92 ms, GridWorld 1.56 against 1.09)
-        uint32_t acc0[2] = {0, 0}, acc1[2] = {0, 0};                       // [column slot]: current / next output row
-        // source row sy covers [sy*oh, (sy+1)*oh) and output row oy covers [oy*H, (oy+1)*H) in refined units; both walk
-        // incrementally (no division), and the three row masks are consumed one bit per scanline, 64 scanlines per word
-        int oy = 0, top = H, pos = 0;
-        int prev_kind = 0;                                                 // 0: the scanline above was skipped; else 1 + B painted + 2 * A painted
-        uint32_t hl0 = 0u, hl1 = 0u;                                        // sums of the last composed scanline
+    // The scanlines where the horizontal sums CHANGE, and only those (Amidar, GridWorld: the board fills the frame, but a tile /
+    // cell row paints the same scanline several times over).  A scanline keeps the sums of the one above it when it paints
+    // exactly like it -- same painters on, and each painter says so (rep masks) -- or when both are blank; the rest are found
+    // with mask arithmetic per 64-scanline word (the previous word's last bit carried in), and the run since the previous such
+    // scanline adds h x (its overlap with each output row): one turn per change plus one per finished output row instead of
+    // one per source scanline.  Same integers as summing every scanline.  (Round 5; the form before it walked all H scanlines
+    // bit by bit, and the sparse walk above it visits every ACTIVE scanline, which for these two games is nearly all of them.)
+        static_assert(!P::FAST_ROWS, "fast rows belong to the sparse form");
+        uint32_t acc[2] = {0, 0};                                          // [column slot]: the output row being filled
+        int oy = 0, top = H, pos = 0;                                      // source row sy covers [sy*oh, (sy+1)*oh), output row oy [oy*H, (oy+1)*H)
+        uint32_t h0 = hb0, h1 = hb1;                                       // sums of the current run
+        auto run_to = [&](int end) {                                       // [pos, end) in refined units has the sums h0 / h1   (wave-uniform)
+            while (top <= end) {
+                const uint32_t w = (uint32_t)(top - pos);                  // <= H < 2^8, sums <= 255 W: 24-bit operands, full-rate v_mad_u32_u24
+                const uint32_t s0 = acc[0] + __umul24(w, h0), s1 = acc[1] + __umul24(w, h1);
+                if (on0) L.vals[oy * a.ow + lane] = (uint8_t)(((uint64_t)(s0 + half) * a.magic) >> 42);
+                if (on1) L.vals[oy * a.ow + lane + 64] = (uint8_t)(((uint64_t)(s1 + half) * a.magic) >> 42);
+                acc[0] = 0; acc[1] = 0;
+                pos = top; top += H; oy += 1;
+            }
+            const uint32_t w = (uint32_t)(end - pos);
+            acc[0] += __umul24(w, h0); acc[1] += __umul24(w, h1);
+            pos = end;
+        };
+        uint64_t cn = 0ull, cb = 0ull, ca = 0ull;                          // the previous word's last scanline: composed / B on / A on
     #pragma unroll 1
         for (int wi = 0; wi < (AGENT_DIAG(a, 2) ? 0 : (H + 63) / 64); wi++) {
-            uint64_t nw = AGENT_DIAG(a, 4) ? 0ull : sel4(wi, need[0], need[1], need[2], need[3]);
-            uint64_t bw = sel4(wi, pb.busy[0], pb.busy[1], pb.busy[2], pb.busy[3]);
-            uint64_t aw = sel4(wi, need_a[0], need_a[1], need_a[2], need_a[3]);
-            uint64_t rb = sel4(wi, pb.rep[0], pb.rep[1], pb.rep[2], pb.rep[3]), ra = two ? sel4(wi, pa.rep[0], pa.rep[1], pa.rep[2], pa.rep[3]) : 0ull;
-            uint64_t fw = P::FAST_ROWS && !AGENT_DIAG(a, 4) ? sel4(wi, fast[0], fast[1], fast[2], fast[3]) : 0ull;
-            const int sy_end = min(H, 64 * wi + 64);
+            const uint64_t nw = AGENT_DIAG(a, 4) ? 0ull : sel4(wi, need[0], need[1], need[2], need[3]);
+            const uint64_t bw = nw & sel4(wi, pb.busy[0], pb.busy[1], pb.busy[2], pb.busy[3]);
+            const uint64_t aw = nw & sel4(wi, need_a[0], need_a[1], need_a[2], need_a[3]);
+            const uint64_t rb = sel4(wi, pb.rep[0], pb.rep[1], pb.rep[2], pb.rep[3]), ra = two ? sel4(wi, pa.rep[0], pa.rep[1], pa.rep[2], pa.rep[3]) : 0ull;
+            const uint64_t pn = (nw << 1) | cn, pbw = (bw << 1) | cb, paw = (aw << 1) | ca;     // the same three of the scanline above
+            cn = nw >> 63; cb = bw >> 63; ca = aw >> 63;
+            // paints exactly like the scanline above: both composed, the same painters on, each of them repeating
+            const uint64_t reuse = nw & pn & ~(bw ^ pbw) & ~(aw ^ paw) & (~bw | rb) & (~aw | ra);
+            const uint64_t compose = nw & ~reuse;
+            uint64_t ev = compose | (~nw & pn);                            // ... or the first blank scanline after a composed one
+            if (64 * wi + 64 > H) ev &= (1ull << (H - 64 * wi)) - 1ull;     // (H is not a multiple of 64 anywhere: no shift by 64)
     #pragma unroll 1
-            for (int sy = 64 * wi; sy < sy_end; sy++, nw >>= 1, bw >>= 1, aw >>= 1, rb >>= 1, ra >>= 1, fw >>= 1) {
-                uint32_t h0 = hb0, h1 = hb1;
-                if (P::FAST_ROWS && (fw & 1ull) && pb.fast_ready(sy)) {
-                    pb.fast_sums(sy, c0, c1, on0, on1, h0, h1);
-                    prev_kind = 0;
-                } else if (nw & 1ull) {
-                    const bool b_on = bw & 1ull, a_on = aw & 1ull;
-                    // a scanline that paints exactly like the one above it (same tile / cell / glyph row, same objects) has
-                    // the same horizontal sums: neither painted nor reduced again
-                    const bool reuse = prev_kind == (1 + (b_on ? 1 : 0) + (a_on ? 2 : 0)) && (!b_on || (rb & 1ull)) && (!a_on || (ra & 1ull));
-                    if (!reuse) {
-                        uint32_t v[NG];
-                        if (b_on) pb.row_dwords(sy, v);
-                        else {
+            for (; ev; ev &= ev - 1ull) {
+                const int bit = (int)__builtin_ctzll(ev), sy = 64 * wi + bit;
+                run_to(sy * a.oh);
+                if ((compose >> bit) & 1ull) {
+                    const bool b_on = (bw >> bit) & 1ull, a_on = (aw >> bit) & 1ull;
+                    uint32_t v[NG];
+                    if (b_on) pb.row_dwords(sy, v);
+                    else {
     #pragma unroll
-                            for (int g = 0; g < NG; g++) v[g] = blank;
-                        }
-                        if (a_on) {                                        // only then can frame A show different pixels
-                            uint32_t va[NG];
-                            pa.row_dwords(sy, va);
-    #pragma unroll
-                            for (int g = 0; g < NG; g++) v[g] = bytemax4(v[g], va[g]);
-                        }
-    #pragma unroll
-                        for (int g = 0; g < NG; g++)
-                            if (lane + 64 * g < W / 4) reinterpret_cast<uint32_t*>(row)[lane + 64 * g] = v[g];
-                        __builtin_amdgcn_wave_barrier();
-                        hl0 = on0 ? hsum(row, c0) : 0u;
-                        hl1 = on1 ? hsum(row, c1) : 0u;
-                        __builtin_amdgcn_wave_barrier();
+                        for (int g = 0; g < NG; g++) v[g] = blank;
                     }
-                    h0 = hl0; h1 = hl1;
-                    prev_kind = 1 + (b_on ? 1 : 0) + (a_on ? 2 : 0);
+                    if (a_on) {                                            // only then can frame A show different pixels
+                        uint32_t va[NG];
+                        pa.row_dwords(sy, va);
+    #pragma unroll
+                        for (int g = 0; g < NG; g++) v[g] = bytemax4(v[g], va[g]);
+                    }
+    #pragma unroll
+                    for (int g = 0; g < NG; g++)
+                        if (lane + 64 * g < W / 4) reinterpret_cast<uint32_t*>(row)[lane + 64 * g] = v[g];
+                    __builtin_amdgcn_wave_barrier();
+                    h0 = on0 ? hsum(row, c0) : 0u;
+                    h1 = on1 ? hsum(row, c1) : 0u;
+                    __builtin_amdgcn_wave_barrier();
                 } else {
-                    prev_kind = 0;
-                }
-                const int pos_next = pos + a.oh;
-                const int w_cur = min(pos_next, top) - pos, w_next = a.oh - w_cur;
-                acc0[0] += __umul24((uint32_t)w_cur, h0); acc0[1] += __umul24((uint32_t)w_cur, h1);     // 24-bit operands (weights <= out_h, sums <= 255 W): full-rate v_mad_u32_u24, not v_mad_u64_u32
-                acc1[0] += __umul24((uint32_t)w_next, h0); acc1[1] += __umul24((uint32_t)w_next, h1);
-                pos = pos_next;
-                if (pos_next >= top) {                                     // output row oy is complete
-    #pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int ox = lane + 64 * q;
-                        if (q == 0 ? on0 : on1) L.vals[oy * a.ow + ox] = (uint8_t)(((uint64_t)(acc0[q] + half) * a.magic) >> 42);
-                        acc0[q] = acc1[q];
-                        acc1[q] = 0;
-                    }
-                    oy += 1;
-                    top += H;
+                    h0 = hb0; h1 = hb1;
                 }
             }
         }
+        run_to(H * a.oh);
     }
     // the read-modify-write of the frame stack in one sweep with many loads in flight (a dependent load -> store per
     // output row, even fetched a row ahead, left this kernel waiting on HBM latency 84 times per env)
