@@ -12,7 +12,7 @@ from toybox_amd import Engine, _abi, hip  # noqa: E402
 game = sys.argv[1]
 libs = []
 for spec in sys.argv[2:]:
-    p = spec[:-5] if spec.endswith(":ring") else spec
+    p = spec.split(":")[0]                                  # "lib.so[:ring][:formK]" (formK = TBX_OPT_STEP_FORM K for that arm)
     lib = C.CDLL(p)
     for name, (res, args) in _abi.PROTOTYPES.items():     # older builds lack the newest entry points: bind what is there
         if hasattr(lib, name):
@@ -23,10 +23,12 @@ n = 65536
 for rnd in range(3):
     for p, lib in libs:
         e = Engine(game, n, lib=lib)
+        if ":form" in p:
+            e.set_option(_abi.OPT_STEP_FORM, int(p.split(":form")[1].split(":")[0]))
         e.seed(1234)
         dm = bool(int(os.environ.get("AB_DEEPMIND", "0")))
         e.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=dm, fire_reset=dm, noop_max=30 if dm else 0,
-                     new_plane=2 if p.endswith(":ring") else 0)
+                     new_plane=2 if ":ring" in p else 0)
         e.agent_reset()
         for t in range(int(os.environ.get("AB_PREROLL", "10"))):
             e.agent_step_synthetic(1337, t)

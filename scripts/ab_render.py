@@ -10,13 +10,14 @@ from toybox_amd import Engine, _abi, hip  # noqa: E402
 
 game, ch = sys.argv[1], int(sys.argv[2])
 libs = []
-for p in sys.argv[3:]:
+for spec in sys.argv[3:]:                                  # "lib.so:formK" = TBX_OPT_STEP_FORM K for that arm
+    p = spec.split(":form")[0]
     lib = C.CDLL(p)
     for name, (res, args) in _abi.PROTOTYPES.items():     # older builds lack the newest entry points: bind what is there
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-    libs.append((p, lib))
+    libs.append((spec, lib))
 n = int(__import__("os").environ.get("AB_ENVS", "65536"))
 pre = int(__import__("os").environ.get("AB_PREROLL", "30"))     # frames played before timing (mid-game states paint more)
 with_step = __import__("os").environ.get("AB_STEP", "0") == "1"   # time [step ; render] instead of [render]
@@ -26,6 +27,8 @@ for rnd in range(3):
         if __import__("os").environ.get("AB_SPLIT"):              # waves per frame (TBX_OPT_RENDER_SPLIT); "a,b": one value per library
             sp = __import__("os").environ["AB_SPLIT"].split(",")
             e.set_option(_abi.OPT_RENDER_SPLIT, int(sp[min(len(sp) - 1, [q for q, _ in libs].index(p))]))
+        if ":form" in p:
+            e.set_option(_abi.OPT_STEP_FORM, int(p.split(":form")[1]))
         e.seed(1234)
         for t in range(pre):
             e.step_synthetic(1337, t)

@@ -11,18 +11,21 @@ from toybox_amd import Engine, _abi, hip  # noqa: E402
 
 game = sys.argv[1]
 libs = []
-for p in sys.argv[2:]:
+for spec in sys.argv[2:]:                                  # "lib.so:formK" = TBX_OPT_STEP_FORM K for that arm
+    p = spec.split(":form")[0]
     lib = C.CDLL(p)
     for name, (res, args) in _abi.PROTOTYPES.items():     # older builds lack the newest entry points: bind what is there
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-    libs.append((p, lib))
+    libs.append((spec, lib))
 n = int(os.environ.get("AB_ENVS", "65536"))
 steps = int(os.environ.get("AB_STEPS", "400"))
 for rnd in range(3):
     for p, lib in libs:
         e = Engine(game, n, lib=lib)
+        if ":form" in p:
+            e.set_option(_abi.OPT_STEP_FORM, int(p.split(":form")[1]))
         e.seed(1234)
         e.new_game()
         for t in range(int(os.environ.get("AB_PREROLL", "300"))):

@@ -1,5 +1,9 @@
-O=gpurun_out/r05q; mkdir -p $O
-AB_PREROLL=60 timeout 300 python scripts/ab_agent.py amidar scripts/ab/lib_before_dense_runs.so toybox_amd/csrc/libtoybox_amd.so scripts/ab/lib_before_dense_runs.so:ring toybox_amd/csrc/libtoybox_amd.so:ring > $O/ab_agent_amidar.txt 2>&1
-AB_PREROLL=60 timeout 400 python scripts/ab_agent.py gridworld scripts/ab/lib_before_dense_runs.so toybox_amd/csrc/libtoybox_amd.so scripts/ab/lib_gw4.so scripts/ab/lib_before_dense_runs.so:ring toybox_amd/csrc/libtoybox_amd.so:ring scripts/ab/lib_gw4.so:ring > $O/ab_agent_gridworld.txt 2>&1
-timeout 1500 python -m pytest tests/test_preproc.py tests/test_gridworld.py tests/test_gpu_parity.py -x -q -m gpu -k "amidar or gridworld" > $O/tests.txt 2>&1
-tail -3 $O/tests.txt
+O=gpurun_out/r05t; mkdir -p $O
+L=toybox_amd/csrc/libtoybox_amd.so
+timeout 300 python scripts/epw_check.py > $O/parity.txt 2>&1
+AB_PREROLL=300 timeout 300 python scripts/ab_step.py amidar $L $L:form3 > $O/ab_step.txt 2>&1
+AB_STEP=1 AB_PREROLL=300 timeout 300 python scripts/ab_render.py amidar 3 $L $L:form3 > $O/ab_pair.txt 2>&1
+AB_PREROLL=60 timeout 300 python scripts/ab_agent.py amidar $L $L:form3 $L:ring $L:ring:form3 > $O/ab_agent.txt 2>&1
+AB_ENVS=16384 AB_PREROLL=300 timeout 300 python scripts/ab_step.py amidar $L:form2 $L:form1 $L:form3 > $O/ab_step_16384.txt 2>&1
+AB_ENVS=32768 AB_PREROLL=300 timeout 300 python scripts/ab_step.py amidar $L:form2 $L:form1 $L:form3 > $O/ab_step_32768.txt 2>&1
+tail -2 $O/parity.txt; tail -2 $O/ab_step.txt; tail -2 $O/ab_pair.txt; tail -4 $O/ab_agent.txt; tail -3 $O/ab_step_16384.txt; tail -3 $O/ab_step_32768.txt
