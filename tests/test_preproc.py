@@ -480,6 +480,35 @@ def test_gpu_plane_ring_is_the_oracles_rolled_stack(game, oh, ow, stack, fill, g
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar"])
+def test_gpu_plane_ring_host_delivery_in_chunks(game, hip_lib, oracle_lib):
+    """new_plane = 2 with the asynchronous host delivery of a batch big enough for the chunked form (four launches of the
+    observation kernel over env ranges, each range's planes copied beside the next range's kernel): the delivered plane is the
+    newest channel of the oracle's rolled stack, the device ring its whole stack, rewards / dones / episode records agree."""
+    from support import read_buffer, stack_from_ring
+    n = 2301
+    g, o = Engine(game, n, lib=hip_lib), Engine(game, n, lib=oracle_lib)
+    for e, mode in ((g, 2), (o, 0)):
+        e.seed(12)
+        e.agent_init(skip=4, clip_reward=True, episodic_life=True, fire_reset=True, noop_max=7, noop_seed=1, new_plane=mode)
+    g.agent_reset()
+    want = o.agent_reset()
+    plane = [g.host_array((n, 84, 84)) for _ in range(2)]
+    bufs = {"reward": g.host_array((n,), np.float32), "done": g.host_array((n,), np.uint8), "ep_done": g.host_array((n,), np.uint8)}
+    for t in range(30):
+        a = synthetic_actions(game, n, t, seed=8)
+        g.agent_step_begin(a, plane=plane[t % 2], **bufs)
+        want, ro, do = o.agent_step(a, tolerate_needs_reset=True)
+        g.agent_step_end(tolerate_needs_reset=True)
+        assert np.array_equal(plane[t % 2], want[..., -1]), t
+        assert np.array_equal(bufs["reward"], ro) and np.array_equal(bufs["done"].astype(bool), do), t
+        assert np.array_equal(bufs["ep_done"].astype(bool), o.agent_episodes()[0]), t
+        if t % 7 == 0:
+            assert np.array_equal(stack_from_ring(read_buffer(g, _abi.BUF_AGENT_RING, (4, n, 84, 84)), g.agent_ring_head()), want), t
+    g.close(); o.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("game", GAMES)
 def test_gpu_step_begin_end_with_frames(game, hip_lib, oracle_lib):
     """tbx_step_begin / tbx_step_end (ToyboxVecEnv.step_async / step_wait): outputs and RGB frames of every step == the oracle's
