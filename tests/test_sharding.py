@@ -386,6 +386,37 @@ def test_bench_n_process_flow_end_to_end_on_the_checker(world, extra, oracle_lib
     assert rf["avg_launch_ms"] > 0 and rf["launches_timed"] >= 1 and "never" in rf["timing"]
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_n_process_flow_under_torch_distributed_run(oracle_lib, tmp_path):
+    """The driver's own launch line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- with the checker behind the engine: the ranks take RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from the launcher (which also sets OMP_NUM_THREADS = 1: the CPU arm names its own thread count), the
+    rendezvous key is derived from MASTER_ADDR:MASTER_PORT, rank 0 prints the one line."""
+    import json
+    pytest.importorskip("torch")
+    world = 2
+    argv = ["--gpus", str(world), "--envs", "96", "--steps", "6", "--warmup", "2", "--repeats", "2", "--preroll", "300", "--cpu-seconds", "0.3"]
+    script = tmp_path / "worker.py"
+    script.write_text(BENCH_FLOW_WORKER.format(root=ROOT, argv=argv))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TBX_RDZV_KEY", "MASTER_ADDR", "MASTER_PORT")}
+    env["TBX_RDZV_DIR"] = str(tmp_path)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["rccl"]["nranks"] == world and line["rccl"]["verified"] is True
+    assert line["weak"]["rccl"]["verified"] is True and 0 < line["share_of_linear"]
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+
+
 @pytest.mark.parametrize("strict", [False, True])
 def test_bench_falls_back_to_the_host_transport_when_rccl_fails(strict, oracle_lib, tmp_path):
     """N > 1 and the RCCL communicator cannot be made (forced here with TBX_BENCH_NO_RCCL): the ranks agree on that through the
@@ -563,7 +594,8 @@ def test_gpu_host_transport_gather_between_two_engines_on_one_device(every, hip_
 
 
 @pytest.mark.gpu
-def test_gpu_bench_n_process_flow_on_one_device_with_the_host_transport(tmp_path):
+@pytest.mark.parametrize("launcher", ["own", "torch.distributed.run"])
+def test_gpu_bench_n_process_flow_on_one_device_with_the_host_transport(launcher, tmp_path):
     """The dress rehearsal of `bench.py --gpus N` that needs no second GPU: bench.py's own spawner starts two
     fresh rank processes (before anything touches the GPU), both on device 0, and the whole N > 1 flow runs on real HIP --
     engines for contiguous shards, both readings of the metric with a communicator each, the verified exchange, ring
@@ -572,8 +604,14 @@ def test_gpu_bench_n_process_flow_on_one_device_with_the_host_transport(tmp_path
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TBX_RDZV_KEY")}
     env["TBX_RDZV_DIR"] = str(tmp_path)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gather", "host", "--one-device", "--envs", "4096",
-                        "--steps", "6", "--warmup", "2", "--repeats", "2", "--preroll", "300", "--settle", "4", "--cpu-seconds", "0.5"],
+    # "torch.distributed.run": the driver's own launch line for N > 1 (the launcher exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)
+    if launcher != "own":
+        pytest.importorskip("torch")
+        env.pop("MASTER_ADDR", None); env.pop("MASTER_PORT", None)
+    head = [sys.executable] if launcher == "own" else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
+    p = subprocess.run(head + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gather", "host", "--one-device", "--envs", "4096",
+                               "--steps", "6", "--warmup", "2", "--repeats", "2", "--preroll", "300", "--settle", "4", "--cpu-seconds", "0.5"],
                        capture_output=True, text=True, timeout=900, cwd="/tmp", env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
