@@ -280,7 +280,7 @@ struct GwPainter {
     typedef GwDev Dev;
     static constexpr int W = TBX_GW_W, H = TBX_GW_H, NG = 1;
     static constexpr bool FAST_ROWS = false;      // (agent_fused_wave: no scanline class with sums known without painting)
-    static constexpr bool SPARSE_ROWS = false;    // (agent_fused_wave: walk the active scanlines only -- every scanline belongs to a cell)
+    static constexpr bool SPARSE_ROWS = false;    // (agent_fused_wave: nearly every scanline is busy but most repeat the one above -- the walk over the CHANGES)
     static __device__ __forceinline__ uint32_t fast_row_word(const uint32_t*, int) { return 0u; }
     __device__ __forceinline__ void fast_init(const ColTaps&, const ColTaps&, bool, bool) {}
     __device__ __forceinline__ bool fast_ready(int) const { return false; }
