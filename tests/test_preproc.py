@@ -480,6 +480,30 @@ def test_gpu_plane_ring_is_the_oracles_rolled_stack(game, oh, ow, stack, fill, g
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("game", ["breakout", "amidar"])
+def test_gpu_plane_ring_equals_rolled_stack_at_16384_envs(game, hip_lib):
+    """The two observation forms of the HIP library against each other on a batch of the size the fused kernels are tuned for
+    (16 384 envs: 4 096 blocks per observation launch): after 24 agent steps with every wrapper on, the ring read through its head
+    is the rolled stack, byte for byte, and the per-env outputs agree at every step."""
+    from support import read_buffer, stack_from_ring
+    n = 16384
+    r, s = Engine(game, n, lib=hip_lib), Engine(game, n, lib=hip_lib)
+    for e, mode in ((r, 2), (s, 0)):
+        e.seed(2)
+        e.agent_init(skip=4, clip_reward=True, episodic_life=True, fire_reset=True, noop_max=30, noop_seed=11, new_plane=mode)
+    r.agent_reset()
+    want = s.agent_reset()
+    for t in range(24):
+        a = synthetic_actions(game, n, t, seed=6)
+        _, r1, d1 = r.agent_step(a, tolerate_needs_reset=True)
+        want, r2, d2 = s.agent_step(a, tolerate_needs_reset=True)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2), t
+        if t in (0, 11, 23):
+            assert np.array_equal(stack_from_ring(read_buffer(r, _abi.BUF_AGENT_RING, (4, n, 84, 84)), r.agent_ring_head()), want), t
+    r.close(); s.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("game", ["breakout", "space_invaders", "amidar"])
 def test_gpu_plane_ring_host_delivery_in_chunks(game, hip_lib, oracle_lib):
     """new_plane = 2 with the asynchronous host delivery of a batch big enough for the chunked form (four launches of the
