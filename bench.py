@@ -39,6 +39,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                     with a collective every step,
   configs        -- (N = 1, Breakout) BASELINE.json configs 2-4 (4 096 envs per game) and config 5's per-GPU share (mixed
                     32 768 envs + 1-rank gather) measured in the same invocation: value, serialised, whole-step fraction of 8 TB/s,
+  agent_path     -- (N = 1, Breakout) agent steps/s of the fused baselines wrapper stack at the headline batch size, every game,
+                    rolled stack and plane ring (`--protocol agent --deepmind [--obs ring]` in short form),
   metric_version -- what `value` means (it changed between rounds 3 and 4) and which arms carry the older reading,
   rccl           -- ranks the communicator spans as RCCL reports it, ring depth, bytes per collective, library, verified,
   cpu_baseline   -- the CPU oracle (oracle/, a port: ctoybox itself cannot be built offline) on this box's host cores, a
@@ -1031,6 +1033,11 @@ def main():
             out["configs"] = baseline_configs(args, hip)
         except Exception as ex:
             out["configs"] = {"error": repr(ex)}
+        # ... and the learner-side pipeline of every game, so that its rates are driver-timed too
+        try:
+            out["agent_path"] = agent_path_rates(hip, main_res["n"])
+        except Exception as ex:
+            out["agent_path"] = {"error": repr(ex)}
     if rank == 0 and not args.no_cpu_baseline:
         # the CPU path "in the same run" (north star), also for N > 1: rank 0's host cores, a bounded sample of the same batch,
         # after every GPU region (the other ranks have nothing left to do and leave)
@@ -1087,6 +1094,36 @@ def roofline_object(game, n, frame_bytes, C, fused, mode, launch):
             "algorithmic_bytes_per_launch": n * frame_bytes, "avg_launch_ms": ms, "median_launch_ms": launch["median_ms"],
             "min_launch_ms": launch["min_ms"], "max_launch_ms": launch["max_ms"], "launches_timed": launch["launches"],
             "event_spans": launch["spans"], "timing": launch_timing_note(fused, mode)}
+
+
+def agent_path_rates(hip, n, steps=40, warmup=12):
+    """agent steps/s of the fused wrapper stack (NoopReset(30) + MaxAndSkip(4) + Monitor + EpisodicLife + FireReset + WarpFrame(84) +
+    ClipReward + FrameStack(4); device-generated actions) at the headline batch size, per game, with the rolled uint8[N,84,84,4] stack
+    on the device and with the ring of the last 4 planes instead (tbx_agent_config_t::new_plane = 2): `bench.py --protocol agent
+    --deepmind [--obs ring]` in short form (one region of `steps` agent steps after `warmup`)."""
+    from toybox_amd import Engine
+    rates = {"unit": "agent-steps/s", "envs": n, "steps": steps, "agent_step": "4 game frames + observation, every baselines wrapper"}
+    stream = hip.Stream()
+    for game in ("breakout", "space_invaders", "amidar", "gridworld"):
+        rates[game] = {}
+        for obs, mode in (("rolled_stack", 0), ("plane_ring", 2)):
+            eng = Engine(game, n, device=0)
+            eng.seed(SEED_BASE)
+            eng.agent_init(skip=4, out_h=84, out_w=84, stack=4, clip_reward=True, episodic_life=True, fire_reset=True, noop_max=30,
+                           noop_seed=2024, new_plane=mode)
+            eng.agent_reset()
+            for t in range(warmup):
+                eng.agent_step_synthetic(ACTION_SEED, t, stream=stream.ptr)
+            hip.synchronize()
+            t0 = time.perf_counter()
+            for t in range(warmup, warmup + steps):
+                eng.agent_step_synthetic(ACTION_SEED, t, stream=stream.ptr)
+            hip.synchronize()
+            dt = time.perf_counter() - t0
+            eng.close()
+            rates[game][obs] = {"value": n * steps / dt, "ms_per_step": 1000 * dt / steps}
+    stream.close()
+    return rates
 
 
 def baseline_configs(args, hip):

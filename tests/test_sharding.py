@@ -628,6 +628,35 @@ def test_gpu_bench_n_process_flow_on_one_device_with_the_host_transport(launcher
     assert line["cpu_baseline"]["value"] > 0 and line["check"]["mean_score"] > 0
 
 
+@pytest.mark.gpu
+def test_gpu_bench_default_line_carries_every_arm():
+    """The driver's own N = 1 command (`bench.py --gpus 1 --steps 20 --warmup 5`; the CPU arm cut to a second here): ONE JSON line
+    whose roofline timing is consistent with the step it sits in, with BASELINE configs 2-5, the strong-scaling probe incl. the
+    policy loop, the agent path of every game in both observation forms, and the CPU oracle beside it."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TBX_RDZV_KEY")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=900, cwd="/tmp", env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 20 and j["warmup"] == 5 and j["unit"] == "env-steps/s" and j["value"] > 1e7
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and 0.5 < rf["frac"] < 1.0 and rf["launches_timed"] >= 40
+    assert rf["avg_launch_ms"] <= 1.01 * j["ms_per_step"]            # a kernel cannot take longer than the step that contains it
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert j["serialised"]["value"] > 0 and j["scaling_strong"]["policy_loop"]["share_of_linear"] > 0.5
+    cfg = j["configs"]
+    assert sorted(cfg) == ["2_breakout_4096", "3_space_invaders_4096", "4_amidar_4096", "5_mixed_32768_per_gpu"]
+    assert all(c["value"] > 1e6 for c in cfg.values()) and cfg["5_mixed_32768_per_gpu"]["segment_sizes"] == [10923, 10923, 10922]
+    ap = j["agent_path"]
+    for game in ("breakout", "space_invaders", "amidar", "gridworld"):
+        assert ap[game]["rolled_stack"]["value"] > 1e6 and ap[game]["plane_ring"]["value"] > 0.9 * ap[game]["rolled_stack"]["value"]
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["kind"] == "port" and j["cpu_config1"]["step_only"] > 0
+    assert j["check"]["mean_score"] > 0
+
+
 def test_mixed_batch_segment_sizes(oracle_lib):
     """BASELINE config 5's per-GPU share is 32 768 envs in three contiguous segments whose sizes differ by at most one
     (10 923 + 10 923 + 10 922; VERDICT r04 weak #10: 3 x 10 922 is not 32 768): MixedBatch takes one size per game, offsets and
