@@ -697,9 +697,10 @@ int tbx_gather_fill(tbx_engine* engine);
  * is ordered after everything queued through this handle so far, runs on an engine-owned communication stream, and the next
  * step that rewrites those records is ordered after it -- what the caller queues in between (the rasteriser) overlaps with it.  `stream` is not used to run it; make a
  * stream wait for the result with tbx_gather_wait.
- * With the fused call (tbx_render_step_synthetic) and one collective PER STEP there is nothing in between: the collective waits
- * for the whole launch (the step rides in it) and the next launch rewrites the same records, so it waits for the collective --
- * no overlap in that combination; the K-step ring (TBX_OPT_GATHER_EVERY > 1) or the two-launch loop overlaps it. */
+ * With the fused call (tbx_render_step_synthetic) in stream order and one collective PER STEP there is nothing in between: the
+ * collective waits for the whole launch (the step rides in it) and the next launch rewrites the same records, so it waits for
+ * the collective -- no overlap in that combination; the K-step ring (TBX_OPT_GATHER_EVERY > 1), the two-launch loop or
+ * overlapped fused launches (TBX_OPT_FUSED_OVERLAP: two output sets) overlap it. */
 int tbx_gather(tbx_engine* engine, uint64_t* out_dev, void* stream);
 /* Make `stream` wait for the last queued gather (device-side consumers of the gathered records). */
 int tbx_gather_wait(tbx_engine* engine, void* stream);
@@ -768,7 +769,28 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  * several ranks share ONE device (RCCL refuses two ranks of a communicator on one GPU): `bench.py --gather host --one-device`
  * walks the whole N-process flow on a one-GPU box.  tbx_gather_library() names the transport in use. */
 #define TBX_OPT_GATHER_TRANSPORT 6
-#define TBX_OPT_COUNT         7
+/* Consecutive tbx_render_step_synthetic(out_dev = NULL) calls of an engine whose call is ONE launch (TBX_OPT_RENDER_STEP_FUSED):
+ * 0 (default) = the engine's choice by batch size, 1 = overlap them, 2 = stream order.
+ *   Launch N+1 needs only what the STEP BLOCKS of launch N write (state, render records, outputs) -- the first few blocks of a
+ *   launch that otherwise paints for 70 .. 1 200 us.  Overlapped, consecutive launches alternate between two internal streams,
+ *   the two sets of step outputs and two engine-owned frame buffers (as in the pipelined mode), over THREE buffers of render
+ *   records, and launch N+1 is ordered behind a device counter that the step blocks of launch N bump once their stores are
+ *   visible device-wide: a one-wave kernel in front of launch N+1 waits for it (bounded; a time-out is reported by tbx_sync as
+ *   TBX_E_NO_DEVICE), the launch itself never spins.  So launch N+1 ramps up in the ramp-down of launch N -- what N worker
+ *   processes stepping independently of each other give the reference (baselines/baselines/common/vec_env/subproc_vec_env.py:49-74),
+ *   and what the per-GPU share of a strong-scaled batch (8 192 envs) loses between launches in stream order.  It works with the
+ *   record gather in both forms (one collective per step: the collective of step N then runs beside launch N+1; K-step ring).
+ *   Contract as in the pipelined mode: the stream the call names waits for the call's work; results of call N stay valid for
+ *   readers queued on that stream before call N+1; TBX_BUF_FRAME / TBX_BUF_REWARD ... alternate between two addresses -- ask
+ *   tbx_device_buffer after every call.  A call with out_dev != NULL, or any other call on the handle, first joins. */
+#define TBX_OPT_FUSED_OVERLAP 7
+/* How early an overlapped launch is released, in blocks of the launch before it: launch N+1 starts once the step blocks of
+ * launch N are through AND the block `lead` blocks before the end of launch N's grid has STARTED (blocks start in index order:
+ * from there on launch N only drains).  0 = the engine's choice; 1 .. 2^20 blocks; a value beyond the grid releases launch N+1
+ * as soon as the step blocks are through (both launches then run side by side for most of their length -- measured slower,
+ * profiles/r06_experiments.txt). */
+#define TBX_OPT_FUSED_OVERLAP_LEAD 8
+#define TBX_OPT_COUNT         9
 /* read-only (tbx_get_option): what TBX_OPT_PIPELINE resolves to on this engine right now -- 0, 2 or 3 */
 #define TBX_OPT_PIPELINE_ACTIVE 100
 /* read-only: 1 while the rasteriser reads step-written render records (Breakout with the canonical wall, SpaceInvaders with
@@ -778,6 +800,9 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
 /* read-only: 1 if tbx_render_step_synthetic(channels = 3) is ONE launch on this engine right now (the rasteriser reads
  * step-written records and the game has a fused kernel), 0 if it is the two launches in stream order */
 #define TBX_OPT_RENDER_STEP_FUSED 102
+/* read-only: 1 if tbx_render_step_synthetic(out_dev = NULL, channels = 3) would be an overlapped launch right now
+ * (TBX_OPT_FUSED_OVERLAP resolved), 0 if it runs in stream order */
+#define TBX_OPT_FUSED_OVERLAP_ACTIVE 103
 int tbx_set_option(tbx_engine* engine, int option, int value);
 int tbx_get_option(tbx_engine* engine, int option, int* value_out);
 /* Block until all work queued by this engine has finished; reports a pending TBX_E_ACTION. */

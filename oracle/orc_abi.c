@@ -1105,7 +1105,7 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout)
 /* launch-time choices of the device engine: stored and reported, without effect on a scalar CPU restatement */
 int tbx_set_option(tbx_engine* e, int option, int value)
 {
-    static const int hi[TBX_OPT_COUNT] = {3, 2, 64, 1, 1, 64, 1};
+    static const int hi[TBX_OPT_COUNT] = {3, 2, 64, 1, 1, 64, 1, 2, 1 << 20};
     if (!e) return TBX_E_INVALID;
     if (option < 0 || option >= TBX_OPT_COUNT) return fail(e, TBX_E_INVALID, "unknown option");
     if (value < (option == TBX_OPT_GATHER_EVERY ? 1 : 0) || value > hi[option]) return fail(e, TBX_E_INVALID, "option value out of range");
@@ -1116,7 +1116,7 @@ int tbx_set_option(tbx_engine* e, int option, int value)
 int tbx_get_option(tbx_engine* e, int option, int* value_out)
 {
     if (!e) return TBX_E_INVALID;
-    if (value_out && (option == TBX_OPT_PIPELINE_ACTIVE || option == TBX_OPT_RECORDS_ACTIVE || option == TBX_OPT_RENDER_STEP_FUSED)) { *value_out = 0; return TBX_OK; }   /* nothing to overlap on one CPU thread */
+    if (value_out && (option == TBX_OPT_PIPELINE_ACTIVE || option == TBX_OPT_RECORDS_ACTIVE || option == TBX_OPT_RENDER_STEP_FUSED || option == TBX_OPT_FUSED_OVERLAP_ACTIVE)) { *value_out = 0; return TBX_OK; }   /* nothing to overlap on one CPU thread */
     if (option < 0 || option >= TBX_OPT_COUNT || !value_out) return fail(e, TBX_E_INVALID, "unknown option");
     *value_out = e->opt[option];
     return TBX_OK;
@@ -1568,7 +1568,7 @@ int tbx_agent_step_begin(tbx_engine* e, const int32_t* actions, const tbx_agent_
     if (!e) return TBX_E_INVALID;
     if (!e->agent_on) return fail(e, TBX_E_INVALID, "tbx_agent_init has not been called");
     if (!actions || !out) return fail(e, TBX_E_INVALID, "actions / output descriptor is NULL");
-    if (e->agent_host_pending) return fail(e, TBX_E_INVALID, "tbx_agent_step_begin: the previous step has not been ended (tbx_agent_step_end)");
+    if (e->agent_host_pending || e->host_pending) return fail(e, TBX_E_INVALID, "tbx_agent_step_begin: the previous step has not been ended (tbx_agent_step_end / tbx_step_end)");
     if (out->plane && !agent_newest_plane(e)) return fail(e, TBX_E_INVALID, "the newest plane needs tbx_agent_config_t::new_plane = 1 or 2");
     if (out->obs && !e->aobs) return agent_no_stack(e);
     int rc = tbx_agent_step_device(e, actions, NULL);
@@ -1600,7 +1600,7 @@ int tbx_step_begin(tbx_engine* e, const int32_t* actions, uint32_t flags, const 
 {
     if (!e) return TBX_E_INVALID;
     if (!actions || !out) return fail(e, TBX_E_INVALID, "actions / output descriptor is NULL");
-    if (e->host_pending) return fail(e, TBX_E_INVALID, "tbx_step_begin: the previous step has not been ended (tbx_step_end)");
+    if (e->host_pending || e->agent_host_pending) return fail(e, TBX_E_INVALID, "tbx_step_begin: the previous step has not been ended (tbx_step_end / tbx_agent_step_end)");
     if (out->frame && out->channels != 1 && out->channels != 3 && out->channels != 4) return fail(e, TBX_E_INVALID, "channels must be 1, 3 or 4");
     int rc = tbx_step_device(e, actions, flags, NULL);
     if (rc) return rc;

@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """One engine, one loop form, N iterations -- the thing to put under rocprofv3 --kernel-trace when the question is what happens
-BETWEEN the kernels of the loop.   python scripts/loop_once.py game envs pair|fused|render|step iterations"""
+BETWEEN the kernels of the loop.   python scripts/loop_once.py game envs pair|fused|render|step iterations
+env LO_OVERLAP = TBX_OPT_FUSED_OVERLAP (0 engine's choice, 1 overlapped, 2 stream order), LO_GATHER = K of a 1-rank record gather (0: none)"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from toybox_amd import Engine, hip  # noqa: E402
+from toybox_amd import Engine, _abi, hip  # noqa: E402
 
 game, n, form, iters = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
 e = Engine(game, n)
 e.seed(1234); e.new_game()
+e.set_option(_abi.OPT_FUSED_OVERLAP, int(os.environ.get("LO_OVERLAP", "0")))
+G = int(os.environ.get("LO_GATHER", "0"))
+if G:
+    e.set_option(_abi.OPT_GATHER_EVERY, G)
+    e.gather_init(1, 0, e.gather_unique_id())
 st = hip.Stream()
 for t in range(300):
     e.step_synthetic(1337, t, auto_reset=True, stream=st.ptr)
@@ -20,6 +26,8 @@ for t in range(300, 300 + iters):
         e.render_device(0, 3, stream=st.ptr)
     elif form == "fused":
         e.render_step_synthetic(1337, t, channels=3, auto_reset=True, stream=st.ptr)
+        if G:
+            e.gather(stream=st.ptr)
     elif form == "render":
         e.render_device(0, 3, stream=st.ptr)
     else:

@@ -486,3 +486,24 @@ def test_batched_helpers_equal_the_references_own_classes(oracle_lib):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "interventions_reference_worker.py")], cwd="/tmp", env=env,
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "WORKER_OK" in p.stdout, (p.stdout + p.stderr)[-4000:]
+
+
+def test_counter_rule_arguments_are_folded_or_refused(lib):
+    """ADVICE r05: seeds above 32 bits used to saturate onto ONE stream on the device (TbxEditArgs::getu).  The Python layer folds a
+    seed of any size to 32 bits (so two different 64-bit seeds name different streams) and refuses draws / offsets that do not fit."""
+    from toybox_amd.interventions import BatchIntervention
+    n = 12
+    e = Engine("amidar", n, lib=lib)
+    e.seed(5); e.new_game()
+    big_a, big_b = 0xDEADBEEF12345678, 0xDEADBEEF12345679
+    with BatchIntervention(e) as bi:
+        a = np.stack(bi.get_random_tile(seed=big_a, draw=1)[:2])
+        b = np.stack(bi.get_random_tile(seed=big_b, draw=1)[:2])
+        a32 = np.stack(bi.get_random_tile(seed=(big_a & 0xFFFFFFFF) ^ (big_a >> 32), draw=1)[:2])
+        assert np.array_equal(a, a32) and not np.array_equal(a, b)
+        for bad in ({"draw": 1 << 32}, {"env_offset": -1}, {"seed": -3}, {"draw": np.array([0] * (n - 1) + [1 << 40])}):
+            with pytest.raises(ValueError):
+                bi.get_random_tile(**bad)
+        with pytest.raises(ValueError):
+            bi.set_player_random_start(seed=1, draw=1 << 33)
+    e.close()

@@ -107,7 +107,10 @@ def test_seed_reproduces_rollout(factory):
 @pytest.mark.parametrize("game", ["breakout", "amidar", "space_invaders"])
 def test_vec_env_contract(game, factory):
     n = 6
-    env = ToyboxVecEnv(game, n, grayscale=False, engine=factory(game, n))
+    # (Breakout: the default for small batches, info["cached_state"] on the game-over step through the synchronous path; the
+    # other two: the asynchronous step_begin / step_end path)
+    env = ToyboxVecEnv(game, n, grayscale=False, engine=factory(game, n), cache_terminal_state=None if game == "breakout" else False)
+    assert env.cache_terminal_state == (game == "breakout")
     seeds = env.seed(100)
     assert [s[0] for s in seeds] == list(range(100, 100 + n)) and seeds[2][1] == hash_seed(103) % 2 ** 31   # cmd_util.py:31
     obs = env.reset()
@@ -136,6 +139,10 @@ def test_vec_env_contract(game, factory):
                 ends += 1
             assert rew[i] == r and done[i] == d, (t, i)
             assert infos[i]["lives"] == info["lives"] and infos[i]["score"] == info["score"], (t, i)
+            if game == "breakout":                                       # envs/atari/base.py:128-130: always on the game-over step
+                assert ("cached_state" in infos[i]) == d == ("cached_state" in info), (t, i)
+                if d:
+                    assert infos[i]["cached_state"] == info["cached_state"], (t, i)
             assert np.array_equal(obs[i], o), (t, i)
     if game == "breakout":
         assert ends > 0
@@ -322,8 +329,8 @@ def test_vec_env_step_async_then_wait_and_pool_rotation(factory):
     the one returned by the previous step is intact after the next; rewards and dones come back as fresh arrays every step (rollout
     buffers keep references: ppo2.py:113); obs_pool = 0 hands out a new array per call."""
     game, n = "amidar", 6
-    a = ToyboxVecEnv(game, n, grayscale=False, engine=factory(game, n), seed=4, obs_pool=2)
-    b = ToyboxVecEnv(game, n, grayscale=False, engine=factory(game, n), seed=4, obs_pool=0)
+    a = ToyboxVecEnv(game, n, grayscale=False, engine=factory(game, n), seed=4, obs_pool=2, cache_terminal_state=False)
+    b = ToyboxVecEnv(game, n, grayscale=False, engine=factory(game, n), seed=4, obs_pool=0, cache_terminal_state=False)
     oa, ob = a.reset(), b.reset()
     assert np.array_equal(oa, ob)
     rng = np.random.default_rng(9)
@@ -345,3 +352,120 @@ def test_vec_env_step_async_then_wait_and_pool_rotation(factory):
     assert len({id(r) for r in rewards}) == len(rewards)
     a.close(); b.close()
     assert np.array_equal(kept[0], kept[1])                           # ... and outlives the env
+
+
+def test_cached_state_default_follows_the_batch_size(factory):
+    """ToyboxBaseEnv.step attaches info["cached_state"] on every game-over step (envs/atari/base.py:128-130); the batched env does
+    so by default up to ToyboxVecEnv.CACHE_TERMINAL_STATE_UP_TO envs and leaves the asynchronous path alone above."""
+    small = ToyboxVecEnv("amidar", 3, engine=factory("amidar", 3))
+    big = ToyboxVecEnv("amidar", ToyboxVecEnv.CACHE_TERMINAL_STATE_UP_TO + 1, engine=factory("amidar", ToyboxVecEnv.CACHE_TERMINAL_STATE_UP_TO + 1))
+    forced = ToyboxVecEnv("amidar", 3, engine=factory("amidar", 3), cache_terminal_state=False)
+    assert small.cache_terminal_state and not big.cache_terminal_state and not forced.cache_terminal_state
+    for e in (small, big, forced):
+        e.close()
+
+
+def test_reset_between_step_async_and_step_wait(factory):
+    """A step between step_async and step_wait is ended by whatever is called next (reset() queued more work, the next
+    step_async failed with 'previous step has not been ended' and step_wait handed out the stale observation)."""
+    game, n = "space_invaders", 5
+    a = ToyboxVecEnv(game, n, engine=factory(game, n), seed=2, cache_terminal_state=False)
+    b = ToyboxVecEnv(game, n, engine=factory(game, n), seed=2, cache_terminal_state=False)
+    a.reset(); b.reset()
+    act = np.array([1, 2, 3, 0, 1])
+    a.step_async(act)
+    oa = a.reset()                                  # ends the step in flight, then resets
+    b.step(act)
+    ob = b.reset()
+    assert np.array_equal(oa, ob)
+    for t in range(5):
+        a.step_async(act)
+        ra, rb = a.step_wait(), b.step(act)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+    with pytest.raises(AssertionError):
+        a.step_wait()                               # nothing in flight
+    # the preprocessing adapter already waited in reset(); the same sequence holds there
+    pa = ToyboxPreprocVecEnv(game, n, engine=factory(game, n), seed=2)
+    pb = ToyboxPreprocVecEnv(game, n, engine=factory(game, n), seed=2)
+    pa.reset(); pb.reset()
+    pa.step_async(act)
+    pb.step(act)
+    assert np.array_equal(pa.reset(), pb.reset())
+    for e in (a, b, pa, pb):
+        e.close()
+
+
+@pytest.mark.parametrize("kind", ["step", "agent"])
+def test_another_call_between_begin_and_end_ends_the_step_first(kind, factory):
+    """include/toybox_amd.h, host delivery: "Any other call on the handle between _begin and _end ends the step first".  The
+    outputs of the begun step arrive in the caller's buffers, the call in between acts on the state the step left, and the late
+    "_end" reports the step's own result instead of delivering anything again."""
+    game, n = "breakout", 7
+    g, h = factory(game, n), factory(game, n)
+    for e in (g, h):
+        e.seed(8); e.new_game()
+    acts = np.array([1, 3, 4, 0, 1, 3, 4], np.int32)
+    if kind == "step":
+        rew, lives, score = (g.host_array((n,), np.int32) for _ in range(3))
+        done = g.host_array((n,), np.uint8)
+        for t in range(3):
+            g.step_begin(acts, reward=rew, done=done, lives=lives, score=score)
+            if t == 1:
+                g.new_game((np.arange(n) % 2).astype(np.uint8))        # another call: the step ends first, then half the envs restart
+            elif t == 2:
+                _ = g.scalars()
+            want = h.step(acts)
+            if t == 1:
+                h.new_game((np.arange(n) % 2).astype(np.uint8))
+            g.step_end()
+            assert np.array_equal(rew, want[0]) and np.array_equal(done.astype(bool), want[1]) and np.array_equal(lives, want[2])
+        with pytest.raises(Exception):
+            g.step_end()                                                 # ... once
+    else:
+        for e in (g, h):
+            e.agent_init(skip=4, out_h=84, out_w=84, stack=4)
+            e.agent_reset()
+        rew = g.host_array((n,), np.float32)
+        done = g.host_array((n,), np.uint8)
+        obs = g.host_array((n, 84, 84, 4), np.uint8)
+        for t in range(3):
+            g.agent_step_begin(acts, reward=rew, done=done, obs=obs)
+            if t == 1:
+                got = g.render(1)                                        # another call in between
+            want = h.agent_step(acts)
+            if t == 1:
+                assert np.array_equal(got, h.render(1))
+            g.agent_step_end()
+            assert np.array_equal(obs, want[0]) and np.array_equal(rew, want[1]) and np.array_equal(done.astype(bool), np.asarray(want[2]).astype(bool))
+        with pytest.raises(Exception):
+            g.agent_step_end()
+    for i in range(n):
+        assert bytes(g.get_state(i)) == bytes(h.get_state(i))
+    g.close(); h.close()
+
+
+def test_episode_info_carries_r_l_and_t(factory):
+    """bench.Monitor / VecMonitor hand out info["episode"] = {"r", "l", "t"} with t = seconds since the monitor was constructed,
+    rounded to 6 places (bench/monitor.py:64, vec_monitor.py:31)."""
+    import time
+    game, n = "breakout", 4
+    eng = factory(game, n)
+    t0 = time.time()
+    env = ToyboxPreprocVecEnv(game, n, engine=eng, seed=3)
+    env.reset()
+    for i in range(n):                                   # one life left and a ball about to leave: episodes end soon
+        st = eng.get_state(i)
+        st.lives = 1
+        eng.set_state(i, st)
+    seen = []
+    for t in range(3000):
+        _, _, done, infos = env.step(np.zeros(n, np.int64) + (1 if t % 7 == 0 else 0))
+        seen += [infos[int(i)]["episode"] for i in np.flatnonzero(done) if "episode" in infos[int(i)]]
+        if len(seen) >= 2:
+            break
+    assert len(seen) >= 2
+    for ep in seen:
+        assert set(ep) == {"r", "l", "t"} and ep["l"] >= 1
+        assert 0.0 <= ep["t"] <= time.time() - t0 + 1e-3 and round(ep["t"], 6) == ep["t"]
+    assert seen[-1]["t"] >= seen[0]["t"]
+    env.close()

@@ -799,18 +799,25 @@ def test_render_step_synthetic_call_contract(game, lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("game,n,channels", [("breakout", 20000, 3), ("breakout", 8192, 4), ("breakout", 300, 3), ("breakout", 5000, 1),
-                                             ("space_invaders", 3000, 3), ("space_invaders", 1500, 4), ("space_invaders", 9000, 3), ("space_invaders", 17000, 3), ("amidar", 2000, 3),
-                                             ("gridworld", 1000, 3)])
-def test_render_step_synthetic_equals_render_then_step(game, n, channels, hip_lib, oracle_lib):
+@pytest.mark.parametrize("game,n,channels,overlap", [("breakout", 20000, 3, 2), ("breakout", 20000, 3, 1), ("breakout", 8192, 4, 0), ("breakout", 8192, 4, 2),
+                                                     ("breakout", 300, 3, 1), ("breakout", 300, 3, 2), ("breakout", 5000, 1, 1),
+                                                     ("space_invaders", 3000, 3, 0), ("space_invaders", 1500, 4, 1), ("space_invaders", 9000, 3, 0),
+                                                     ("space_invaders", 17000, 3, 0), ("amidar", 2000, 3, 1), ("gridworld", 1000, 3, 0)])
+def test_render_step_synthetic_equals_render_then_step(game, n, channels, overlap, hip_lib, oracle_lib):
     """tbx_render_step_synthetic = tbx_render_device followed by tbx_step_synthetic, bit for bit: the frame shows the state
     before the step, outputs and state are the step's.  For Breakout RGB / RGBA that is ONE launch (brk_render_step_kernel_w5:
     step blocks in front of the rasteriser's, the other records buffer); everywhere else two launches.  Calls of other kinds
     in between (state writes that invalidate the records, new games, host steps, a K-step gather ring, plain step / render
-    pairs, the pipelined mode switched on) must not disturb it.  Frames are copied device-side right behind each call."""
+    pairs, the pipelined mode switched on) must not disturb it.  Frames are copied device-side right behind each call.
+    overlap = TBX_OPT_FUSED_OVERLAP: 1 = consecutive fused launches on two lanes behind the device-side ticket (round 6), 2 =
+    stream order, 0 = the engine's choice; engines without a fused launch ignore it."""
     from toybox_amd import hip
     from toybox_amd.parallel import pack_records
     g, o = _pair(game, n, hip_lib, oracle_lib, seed=5)
+    g.set_option(_abi.OPT_FUSED_OVERLAP, overlap)
+    fused = game == "breakout" and channels >= 3
+    if channels >= 3:                                       # (the read-only option answers for RGB / RGBA frames)
+        assert g.get_option(_abi.OPT_FUSED_OVERLAP_ACTIVE) == (1 if fused and (overlap == 1 or (overlap == 0 and n <= 16384)) else 0)
     H, W = g.height, g.width
     fb = H * W * channels
     sample = sorted({0, 1, 255, 256, n // 2, n - 1} & set(range(n)))
@@ -860,6 +867,97 @@ def test_render_step_synthetic_equals_render_then_step(game, n, channels, hip_li
     _same_states(g, o, sample + list(range(0, n, max(1, n // 50))), "end")
     for x, y in zip(g.scalars(), o.scalars()):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,channels,K", [(8192, 3, 0), (8192, 3, 1), (8192, 3, 4), (4096, 4, 1), (700, 3, 2), (20000, 3, 4)])
+def test_fused_overlap_outputs_frames_and_gather(n, channels, K, hip_lib, oracle_lib):
+    """Overlapped fused launches (TBX_OPT_FUSED_OVERLAP = 1) under the contract the header states: EVERY call's outputs (reward,
+    done, lives, score, packed) and sampled frames are read by copies queued on the caller's stream right behind the call --
+    i.e. before the next call, which may start while this call's rasteriser blocks still run -- and must equal the oracle's;
+    TBX_BUF_FRAME / TBX_BUF_REWARD alternate between two addresses; with a gather (K = 1: a collective per step, now beside
+    the next launch; K > 1: the record ring) the gathered block equals the oracle's records of the last K steps; a call with
+    out_dev given, a stream-order call (option 2) and a host step in between join and re-enter.  8 192 envs + K = 4 is the
+    per-GPU share of the strong-scaled headline batch."""
+    from toybox_amd import hip
+    from toybox_amd.parallel import pack_records
+    game = "breakout"
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=21)
+    H, W = g.height, g.width
+    fb = H * W * channels
+    g.set_option(_abi.OPT_FUSED_OVERLAP, _abi.FUSED_OVERLAP_ON)
+    if K:
+        g.set_option(_abi.OPT_GATHER_EVERY, K)
+        g.gather_init(1, 0, g.gather_unique_id())
+    assert g.get_option(_abi.OPT_FUSED_OVERLAP_ACTIVE) == 1
+    sample = sorted({0, 1, 255, 256, n // 2, n - 1})
+    s = hip.Stream()
+    T = 64
+    per = 4 * n * 3 + n + 8 * n                       # reward, lives, score (i32), done (u8), packed (u64)
+    hold_o = hip.malloc(per * T)
+    hold_f = hip.malloc(fb * len(sample) * T)
+    side = hip.malloc(fb * n)                         # a caller-owned frame buffer for the out_dev call
+    want_f, want_o, frame_addr, reward_addr = [], [], [], []
+    gathered_checked = 0
+    for t in range(T):
+        if t == 23:
+            a = synthetic_actions(game, n, t, seed=3)
+            for x, y in zip(g.step(a, auto_reset=True), o.step(a, auto_reset=True)):
+                assert np.array_equal(x, y)
+        if t == 40:
+            g.set_option(_abi.OPT_FUSED_OVERLAP, _abi.FUSED_OVERLAP_OFF)
+        if t == 44:
+            g.set_option(_abi.OPT_FUSED_OVERLAP, _abi.FUSED_OVERLAP_ON)
+        if t == 31:                                   # the caller's own buffer: stream order for this call
+            g.render_step_synthetic(1337, t, out_ptr=side, channels=channels, auto_reset=True, stream=s.ptr)
+            f = side
+        else:
+            g.render_step_synthetic(1337, t, channels=channels, auto_reset=True, stream=s.ptr)
+            f, _ = g.device_buffer(_abi.BUF_FRAME)
+        if K:
+            g.gather(stream=s.ptr)
+        frame_addr.append(f)
+        off = per * t
+        for which, nb in ((_abi.BUF_REWARD, 4 * n), (_abi.BUF_LIVES, 4 * n), (_abi.BUF_SCORE, 4 * n), (_abi.BUF_DONE, n), (_abi.BUF_PACKED, 8 * n)):
+            p, _ = g.device_buffer(which)
+            if which == _abi.BUF_REWARD:
+                reward_addr.append(p)
+            hip.memcpy_dtod_async(hold_o + off, p, nb, s)
+            off += nb
+        for k, i in enumerate(sample):
+            hip.memcpy_dtod_async(hold_f + fb * (len(sample) * t + k), f + fb * i, fb, s)
+        want_f.append([o.render_env(i, channels) for i in sample])
+        ro = o.step(synthetic_actions(game, n, t, seed=1337), auto_reset=True)
+        want_o.append((ro[0], ro[2], ro[3], ro[1], pack_records(ro[0], ro[1], ro[2])))
+        if K and (t + 1) % K == 0 and g.gather_fill() == 0:
+            got = g.gather_host().reshape(K, -1)[:, :n]
+            for j in range(K):
+                assert np.array_equal(got[j], want_o[t - K + 1 + j][4]), (t, j)
+            gathered_checked += 1
+    s.synchronize()
+    g.sync()                                          # (reports a ticket time-out of the wait kernel, if any)
+    # the overlapped calls alternate between two frame buffers and two output sets
+    run = list(range(2, 22))
+    assert all(frame_addr[t] == frame_addr[t - 2] and frame_addr[t] != frame_addr[t - 1] for t in run[2:])
+    assert all(reward_addr[t] == reward_addr[t - 2] and reward_addr[t] != reward_addr[t - 1] for t in run[2:])
+    assert not K or gathered_checked >= T // K - 3
+    buf = np.empty(per, np.uint8)
+    one = np.empty((H, W, channels), np.uint8)
+    for t in range(T):
+        hip.memcpy_dtoh(buf, hold_o + per * t, per)
+        rew, liv, sco = (buf[4 * n * k:4 * n * (k + 1)].view(np.int32) for k in range(3))
+        don = buf[12 * n:13 * n]
+        pk = buf[13 * n:].view(np.uint64)
+        w = want_o[t]
+        assert np.array_equal(rew, w[0]) and np.array_equal(liv, w[1]) and np.array_equal(sco, w[2]), t
+        assert np.array_equal(don, w[3].astype(np.uint8)) and np.array_equal(pk, w[4]), t
+        for k, i in enumerate(sample):
+            hip.memcpy_dtoh(one, hold_f + fb * (len(sample) * t + k), fb)
+            assert np.array_equal(one, want_f[t][k]), (t, i)
+    for p in (hold_o, hold_f, side):
+        hip.free(p)
+    _same_states(g, o, sample + list(range(0, n, max(1, n // 40))), "end")
+    g.close(); o.close()
 
 
 @pytest.mark.gpu

@@ -29,9 +29,13 @@ GATHER_ID_BYTES = 128
 OPT_PIPELINE, OPT_STEP_FORM, OPT_RENDER_SPLIT, OPT_AGENT_GENERIC, OPT_RESIDENT_STEP, OPT_GATHER_EVERY = 0, 1, 2, 3, 4, 5
 OPT_GATHER_TRANSPORT = 6           # 0 RCCL, 1 host-staged over POSIX shared memory (one node)
 GATHER_RCCL, GATHER_HOST = 0, 1
+OPT_FUSED_OVERLAP = 7              # consecutive fused render+step launches: 0 the engine's choice, 1 overlapped on two lanes, 2 stream order
+FUSED_OVERLAP_AUTO, FUSED_OVERLAP_ON, FUSED_OVERLAP_OFF = 0, 1, 2
+OPT_FUSED_OVERLAP_LEAD = 8         # blocks before the end of launch N at which launch N+1 is released (0: the engine's choice)
 OPT_PIPELINE_ACTIVE = 100          # read-only: what OPT_PIPELINE resolves to on the engine
 OPT_RECORDS_ACTIVE = 101           # read-only: the rasteriser reads step-written render records
 OPT_RENDER_STEP_FUSED = 102        # read-only: tbx_render_step_synthetic is one launch on this engine
+OPT_FUSED_OVERLAP_ACTIVE = 103     # read-only: such launches would be overlapped right now
 PIPELINE_OFF, PIPELINE_AUTO, PIPELINE_STEP_BESIDE_RENDER, PIPELINE_OVERLAP_RENDERS = 0, 1, 2, 3
 STEP_FORM_AUTO, STEP_FORM_THREAD_PER_ENV, STEP_FORM_WAVE_PER_ENV = 0, 1, 2
 

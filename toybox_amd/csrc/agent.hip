@@ -415,7 +415,10 @@ void tbx_agent_free(tbx_engine* e)
 {
     if (!e->agent) return;
     AgentState* a = e->agent;
-    if (a->host_pending) hipStreamSynchronize(e->stream);      // copies into the caller's buffers are still in flight
+    if (a->host_pending) {                                     // copies into the caller's buffers are still in flight
+        hipStreamSynchronize(e->stream);
+        if (e->pending_kind == 2) e->pending_kind = 0;
+    }
     hipFree(a->plane); hipFree(a->ring); hipHostFree(a->host_actions); hipFree(a->io_dev); hipHostFree(a->io_host);
     if (a->copy_stream) { hipStreamSynchronize(a->copy_stream); hipStreamDestroy(a->copy_stream); }
     for (hipEvent_t ev : a->chunk_ev) if (ev) hipEventDestroy(ev);
@@ -680,7 +683,8 @@ int tbx_agent_step_begin(tbx_engine* e, const int32_t* actions_host, const tbx_a
     if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
     if (!actions_host || !out) return e->fail(TBX_E_INVALID, "actions / output descriptor is NULL");
     AgentState& a = *e->agent;
-    if (a.host_pending) return e->fail(TBX_E_INVALID, "tbx_agent_step_begin: the previous step has not been ended (tbx_agent_step_end)");
+    if (e->pending_kind) return e->fail(TBX_E_INVALID, "tbx_agent_step_begin: the previous step has not been ended (tbx_agent_step_end / tbx_step_end)");
+    e->ended_early_kind = 0;
     if (out->plane && !newest_plane(a, e->n)) return e->fail(TBX_E_INVALID, "the newest plane needs tbx_agent_config_t::new_plane = 1 or 2");
     if (out->obs && !a.obs) return no_stack(e);
     AHIP(hipSetDevice(e->device));
@@ -731,6 +735,7 @@ int tbx_agent_step_begin(tbx_engine* e, const int32_t* actions_host, const tbx_a
     AHIP(hipMemcpyAsync(a.io_host, a.io_dev, io_bytes, hipMemcpyDeviceToHost, e->stream));
     a.host_out = *out;
     a.host_pending = true;
+    e->pending_kind = 2;
     return TBX_OK;
 }
 
@@ -738,11 +743,26 @@ int tbx_agent_step_end(tbx_engine* e)
 {
     if (!e) return TBX_E_INVALID;
     if (!e->agent) return e->fail(TBX_E_INVALID, "tbx_agent_init has not been called");
+    if (!e->agent->host_pending) {
+        if (e->ended_early_kind == 2) {        // another call on the handle ended the step (tbx_finish_pending): outputs delivered
+            e->ended_early_kind = 0;
+            return e->ended_early_rc ? e->fail(e->ended_early_rc, e->ended_early_msg) : TBX_OK;
+        }
+        return e->fail(TBX_E_INVALID, "tbx_agent_step_end without tbx_agent_step_begin");
+    }
+    return tbx_agent_deliver(e);
+}
+
+}  // extern "C"
+
+// the waiting half of tbx_agent_step_end (also reached through tbx_finish_pending when another call ends the step)
+int tbx_agent_deliver(tbx_engine* e)
+{
     AgentState& a = *e->agent;
-    if (!a.host_pending) return e->fail(TBX_E_INVALID, "tbx_agent_step_end without tbx_agent_step_begin");
     AHIP(hipSetDevice(e->device));
     AHIP(hipStreamSynchronize(e->stream));
     a.host_pending = false;
+    e->pending_kind = 0;
     const size_t N = (size_t)e->n;
     const tbx_agent_host_out_t& o = a.host_out;
     const uint32_t* io = a.io_host;
@@ -761,6 +781,8 @@ int tbx_agent_step_end(tbx_engine* e)
     }
     return TBX_OK;
 }
+
+extern "C" {
 
 int tbx_agent_fetch(tbx_engine* e, const tbx_agent_host_out_t* out)
 {

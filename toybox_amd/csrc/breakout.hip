@@ -577,38 +577,63 @@ __device__ __forceinline__ void t_new_game(const BrkCfg& c, Rng& sim, BrkT& s)
     t_start_ball(c, s);
 }
 
+// COH = the step half of an OVERLAPPED fused launch (engine.hip, fused_overlapped): the launch before it may still be running on
+// the other stream, on other XCDs with L2s of their own, and the launch after it starts before this one ends.  Every load of
+// step-written memory and every store then carries agent scope (global_load / global_store ... sc1: past the XCD's L2 to the
+// memory side), so that publishing a block's results needs no L2 write-back and reading the previous step's needs no L2
+// invalidate -- one `buffer_wbl2` per step wave cost the 8 192-env launch 7 % and the 65 536-env one 7 % (profiles/r06_experiments.txt).
+template <bool COH, class T>
+__device__ __forceinline__ T t_ld(const T* p)
+{
+    if (!COH) return *p;
+    if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const uint8_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <bool COH, class T, class V>
+__device__ __forceinline__ void t_st(T* p, V value)
+{
+    const T v = (T)value;
+    if (!COH) { *p = v; return; }
+    if constexpr (sizeof(T) == 8) __hip_atomic_store(reinterpret_cast<uint64_t*>(p), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if constexpr (sizeof(T) == 4) __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(reinterpret_cast<uint8_t*>(p), __builtin_bit_cast(uint8_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool COH = false>
 __device__ __forceinline__ void t_load(const BrkDev& d, int env, BrkT& s)
 {
     const size_t N = (size_t)d.n;
-    s.rng.s0 = d.rng[env]; s.rng.s1 = d.rng[N + env];
-    s.score = d.score[env]; s.lives = d.lives[env]; s.level = d.level[env]; s.flags = d.flags[env];
-    s.px = d.paddle[0 * N + env]; s.py = d.paddle[1 * N + env]; s.pvx = d.paddle[2 * N + env]; s.pvy = d.paddle[3 * N + env];
-    s.pw = d.paddle[4 * N + env]; s.pspeed = d.paddle[5 * N + env]; s.radius = d.paddle[6 * N + env];
-    s.n_balls = d.n_balls[env]; s.n_bricks = d.n_bricks[env];
+    s.rng.s0 = t_ld<COH>(&d.rng[env]); s.rng.s1 = t_ld<COH>(&d.rng[N + env]);
+    s.score = t_ld<COH>(&d.score[env]); s.lives = t_ld<COH>(&d.lives[env]); s.level = t_ld<COH>(&d.level[env]); s.flags = t_ld<COH>(&d.flags[env]);
+    s.px = t_ld<COH>(&d.paddle[0 * N + env]); s.py = t_ld<COH>(&d.paddle[1 * N + env]); s.pvx = t_ld<COH>(&d.paddle[2 * N + env]); s.pvy = t_ld<COH>(&d.paddle[3 * N + env]);
+    s.pw = t_ld<COH>(&d.paddle[4 * N + env]); s.pspeed = t_ld<COH>(&d.paddle[5 * N + env]); s.radius = t_ld<COH>(&d.paddle[6 * N + env]);
+    s.n_balls = t_ld<COH>(&d.n_balls[env]); s.n_bricks = t_ld<COH>(&d.n_bricks[env]);
 #pragma unroll
     for (int b = 0; b < MAXB; b++) {
-        s.bx[b] = d.balls[(size_t)(0 * MAXB + b) * N + env]; s.by[b] = d.balls[(size_t)(1 * MAXB + b) * N + env];
-        s.bvx[b] = d.balls[(size_t)(2 * MAXB + b) * N + env]; s.bvy[b] = d.balls[(size_t)(3 * MAXB + b) * N + env];
+        s.bx[b] = t_ld<COH>(&d.balls[(size_t)(0 * MAXB + b) * N + env]); s.by[b] = t_ld<COH>(&d.balls[(size_t)(1 * MAXB + b) * N + env]);
+        s.bvx[b] = t_ld<COH>(&d.balls[(size_t)(2 * MAXB + b) * N + env]); s.bvy[b] = t_ld<COH>(&d.balls[(size_t)(3 * MAXB + b) * N + env]);
     }
 #pragma unroll
-    for (int k = 0; k < MAXK; k++) s.alive[k] = d.alive[(size_t)k * N + env];
+    for (int k = 0; k < MAXK; k++) s.alive[k] = t_ld<COH>(&d.alive[(size_t)k * N + env]);
 }
 
+template <bool COH = false>
 __device__ __forceinline__ void t_store(const BrkDev& d, int env, const BrkT& s)
 {
     const size_t N = (size_t)d.n;
-    d.rng[env] = s.rng.s0; d.rng[N + env] = s.rng.s1;
-    d.score[env] = s.score; d.lives[env] = s.lives; d.level[env] = s.level; d.flags[env] = s.flags;
-    d.paddle[0 * N + env] = s.px; d.paddle[1 * N + env] = s.py; d.paddle[2 * N + env] = s.pvx; d.paddle[3 * N + env] = s.pvy;
-    d.paddle[4 * N + env] = s.pw; d.paddle[5 * N + env] = s.pspeed; d.paddle[6 * N + env] = s.radius;
-    d.n_balls[env] = s.n_balls; d.n_bricks[env] = s.n_bricks;
+    t_st<COH>(&d.rng[env], s.rng.s0); t_st<COH>(&d.rng[N + env], s.rng.s1);
+    t_st<COH>(&d.score[env], s.score); t_st<COH>(&d.lives[env], s.lives); t_st<COH>(&d.level[env], s.level); t_st<COH>(&d.flags[env], s.flags);
+    t_st<COH>(&d.paddle[0 * N + env], s.px); t_st<COH>(&d.paddle[1 * N + env], s.py); t_st<COH>(&d.paddle[2 * N + env], s.pvx); t_st<COH>(&d.paddle[3 * N + env], s.pvy);
+    t_st<COH>(&d.paddle[4 * N + env], s.pw); t_st<COH>(&d.paddle[5 * N + env], s.pspeed); t_st<COH>(&d.paddle[6 * N + env], s.radius);
+    t_st<COH>(&d.n_balls[env], s.n_balls); t_st<COH>(&d.n_bricks[env], s.n_bricks);
 #pragma unroll
     for (int b = 0; b < MAXB; b++) {
-        d.balls[(size_t)(0 * MAXB + b) * N + env] = s.bx[b]; d.balls[(size_t)(1 * MAXB + b) * N + env] = s.by[b];
-        d.balls[(size_t)(2 * MAXB + b) * N + env] = s.bvx[b]; d.balls[(size_t)(3 * MAXB + b) * N + env] = s.bvy[b];
+        t_st<COH>(&d.balls[(size_t)(0 * MAXB + b) * N + env], s.bx[b]); t_st<COH>(&d.balls[(size_t)(1 * MAXB + b) * N + env], s.by[b]);
+        t_st<COH>(&d.balls[(size_t)(2 * MAXB + b) * N + env], s.bvx[b]); t_st<COH>(&d.balls[(size_t)(3 * MAXB + b) * N + env], s.bvy[b]);
     }
 #pragma unroll
-    for (int k = 0; k < MAXK; k++) d.alive[(size_t)k * N + env] = s.alive[k];
+    for (int k = 0; k < MAXK; k++) t_st<COH>(&d.alive[(size_t)k * N + env], s.alive[k]);
 }
 
 // the rasteriser's record of one env
@@ -757,10 +782,11 @@ __device__ __forceinline__ void brk_t_step(const BrkCfg& c, BrkT& s, uint32_t bu
 // one frame (or the agent layer's whole action repeat) of one env on one THREAD
 // AGENT: the agent layer's action repeat with MaxAndSkipEnv's bookkeeping and frame-buffer records; the batch protocol's
 // instantiation carries neither (fewer registers, less spill code)
-template <bool AGENT>
+template <bool AGENT, bool COH = false>
 __device__ __forceinline__ void brk_step_tpe_body(const BrkDev& d, const BrkCfg& c, const ActionSource& src, uint32_t flags, BrkRenderRec* recs,
                                                   BrkRenderRec* recs_a, BrkRenderRec* recs_b, int env)
 {
+    static_assert(!(AGENT && COH), "the agent layer's action repeat is never an overlapped launch");
     const size_t N = (size_t)d.n;
     if (AGENT) {
         if (src.exec_flag) src.exec_flag[env] = tbx_agent_env_finished(src, env) ? 0 : 1;
@@ -781,8 +807,8 @@ __device__ __forceinline__ void brk_step_tpe_body(const BrkDev& d, const BrkCfg&
     }
 
     BrkT s;
-    t_load(d, env, s);
-    int32_t prev = d.prev_score[env];
+    t_load<COH>(d, env, s);
+    int32_t prev = t_ld<COH>(&d.prev_score[env]);
     const int frames = AGENT && src.frames > 1 ? src.frames : 1;
     int32_t rew = 0, out_lives = 0, out_score = 0;
     bool is_done = false;
@@ -795,9 +821,9 @@ __device__ __forceinline__ void brk_step_tpe_body(const BrkDev& d, const BrkCfg&
         prev = s.score;
         if (!AGENT && is_done && (flags & TBX_STEP_AUTO_RESET)) {   // (the agent layer resets through its own procedure)
             Rng sim;
-            sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
+            sim.s0 = t_ld<COH>(&d.sim_rng[env]); sim.s1 = t_ld<COH>(&d.sim_rng[N + env]);
             t_new_game(c, sim, s);
-            d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
+            t_st<COH>(&d.sim_rng[env], sim.s0); t_st<COH>(&d.sim_rng[N + env], sim.s1);
             prev = s.score;
         }
         if (AGENT) {
@@ -814,15 +840,23 @@ __device__ __forceinline__ void brk_step_tpe_body(const BrkDev& d, const BrkCfg&
             }
         }
     }
-    t_store(d, env, s);
-    d.prev_score[env] = prev;
-    d.reward[env] = rew;
-    d.done[env] = is_done ? 1 : 0;
-    d.lives_out[env] = out_lives;
-    d.score_out[env] = out_score;
+    t_store<COH>(d, env, s);
+    t_st<COH>(&d.prev_score[env], prev);
+    t_st<COH>(&d.reward[env], rew);
+    t_st<COH>(&d.done[env], is_done ? 1 : 0);
+    t_st<COH>(&d.lives_out[env], out_lives);
+    t_st<COH>(&d.score_out[env], out_score);
     const uint32_t lv8 = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
-    d.packed[env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv8 << 40);
-    recs[env] = t_record(s);
+    t_st<COH>(&d.packed[env], (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv8 << 40));
+    if (COH) {                                               // the 64-byte record as eight agent-scope stores
+        const BrkRenderRec rec = t_record(s);
+        static_assert(sizeof(BrkRenderRec) == 64, "render record size");
+        uint64_t w[8];
+        __builtin_memcpy(w, &rec, sizeof rec);
+#pragma unroll
+        for (int i = 0; i < 8; i++) t_st<true>(reinterpret_cast<uint64_t*>(&recs[env]) + i, w[i]);
+    } else
+        recs[env] = t_record(s);
 }
 
 
@@ -977,8 +1011,11 @@ struct BrkPalette {
 // record loads and LDS staging; one-shot address-ordered waves of 1, 2, 4 or 10 CONSECUTIVE units 5.3-5.5 TB/s
 // (hipMemset on the same boxes: 6.3-6.5 TB/s).
 // a render record travels through the rasteriser as ONE VGPR (lane i < 16 holds dword i: a single 64-byte request)
-__device__ __forceinline__ uint32_t brk_rec_load_lanes(const BrkRenderRec* __restrict__ r, int lane)
+// coherent: the record may have been written by a launch that is still running on another stream (overlapped fused launches) --
+// its step blocks fenced it out to memory, and this load goes past whatever older copy an L2 of this XCD still holds
+__device__ __forceinline__ uint32_t brk_rec_load_lanes(const BrkRenderRec* __restrict__ r, int lane, bool coherent = false)
 {
+    if (coherent) return lane < 16 ? __hip_atomic_load(reinterpret_cast<const uint32_t*>(r) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     return lane < 16 ? reinterpret_cast<const uint32_t*>(r)[lane] : 0u;
 }
 __device__ __forceinline__ BrkRenderRec brk_rec_from_lanes(uint32_t rv)
@@ -1178,7 +1215,8 @@ __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__
     Stager st{lds_all + wave * Stager::UNIT_BYTES};
     const BrkLaneTables<C> tables(pal, lane);
     // `split` waves share a frame, wave `part` taking units part, part + split, ...
-    const bool stagger = C == 3 && !(split >> 16);        // (bit 16 of the argument: one of the two parts of a big launch)
+    const bool stagger = C == 3 && !((split >> 16) & 1);  // (bit 16 of the argument: one of the two parts of a big launch)
+    const bool coherent = (split >> 17) & 1;              // (bit 17: an overlapped fused launch -- brk_rec_load_lanes)
     split &= 0xFFFF;
     const int wid = wave_uniform(block * TBX_WAVES_PER_BLOCK + wave);
     const int rel = wid / split, part = wid - rel * split;
@@ -1198,7 +1236,7 @@ __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__
     // at 1.20 ms on one box and 1.35 on the next -- were NOT about this load (a kernel that re-reads every record between the
     // step and the rasteriser changes nothing; writing the records to a buffer the rasteriser does not read removes the slow
     // rate, and so does a rasteriser launch that follows another one): see launch_render (the two-part launch) and raster.hpp.
-    const BrkRecLanes rl{brk_rec_load_lanes(&rsrc[first_env + rel], lane)};
+    const BrkRecLanes rl{brk_rec_load_lanes(&rsrc[first_env + rel], lane, coherent)};
     if (stagger) tbx_stagger_first_waves(wid);          // (raster.hpp: mid-size launches; the record's load is in flight meanwhile)
     brk_paint_units<C, CUSTOM>(rl, custom, pal, tables, frame, first_env + rel, lane, st, part, split);
 }
@@ -1228,14 +1266,35 @@ __global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5)
 template <int C>
 __global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void brk_render_step_kernel_w5(
     const BrkRenderRec* __restrict__ recs, BrkPalette pal, uint8_t* __restrict__ out, int count, int split, BrkDev d, const BrkCfg* __restrict__ cp,
-    ActionSource src, uint32_t flags, BrkRenderRec* __restrict__ recs_next, int step_blocks)
+    ActionSource src, uint32_t flags, BrkRenderRec* __restrict__ recs_next, int step_blocks, unsigned long long* arrive, int release_block, int diag)
 {
+    // arrive != nullptr: an overlapped launch (engine.hip, fused_overlapped).  The launch before this one may still be painting on
+    // the other lane; what it STEPPED (state, the records read below) was fenced out before its step blocks bumped the counter
+    // the engine's wait kernel saw.  The step blocks' waves start by dropping what their caches hold from before that (one
+    // invalidate per wave of a few hundred waves; as the first instruction of EVERY wave of the launch it made the launch four times
+    // slower, profiles/r06_experiments.txt); the rasteriser blocks read one record each, with a load that bypasses those caches.
     if ((int)blockIdx.x < step_blocks) {
         const int env = (int)blockIdx.x * TBX_BLOCK + (int)threadIdx.x;
-        if (env < d.n) brk_step_tpe_body<false>(d, *cp, src, flags, recs_next, nullptr, nullptr, env);
+        if (!arrive) {
+            if (env < d.n) brk_step_tpe_body<false, false>(d, *cp, src, flags, recs_next, nullptr, nullptr, env);
+            return;
+        }
+        if (OVL_DIAG(diag, 1)) {                                // (DIAG: plain loads and stores behind a per-wave invalidate / write-back)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (env < d.n) brk_step_tpe_body<false, false>(d, *cp, src, flags, recs_next, nullptr, nullptr, env);
+            if (!OVL_DIAG(diag, 2)) __threadfence();
+        } else {
+            if (env < d.n) brk_step_tpe_body<false, true>(d, *cp, src, flags, recs_next, nullptr, nullptr, env);
+            // every store above went past the L2 (sc1); once this wave's have been acknowledged they are visible device-wide
+            __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0), nothing else (gfx9 encoding)
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    brk_render_body<C, false, false>(recs, nullptr, pal, out, 0, count, split | (1 << 16), nullptr, nullptr, (int)blockIdx.x - step_blocks);
+    // blocks start in index order: once this one runs, the launch has only `lead` blocks left to hand out -- the next launch may come
+    if (arrive && (int)blockIdx.x == release_block && threadIdx.x == 0) __hip_atomic_fetch_add(arrive + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    brk_render_body<C, false, false>(recs, nullptr, pal, out, 0, count, split | (1 << 16) | (arrive && !OVL_DIAG(diag, 4) ? 1 << 17 : 0), nullptr, nullptr, (int)blockIdx.x - step_blocks);
 }
 
 template <int C, bool CUSTOM, bool ALT>
@@ -1741,6 +1800,8 @@ struct BreakoutOps : GameOps {
     BrkRenderRec* recs = nullptr;   // [N] rasteriser input records (the CURRENT of two buffers)
     BrkRenderRec* recs_other = nullptr;   // the other one: a step that runs ahead of the previous frame's rasteriser writes
     int recs_par = 0;               // here and the two swap (GameOps::step_ahead)
+    BrkRenderRec* recs_third = nullptr;   // fused launches rotate through three (render_step): a launch overlapped on the other lane must not
+                                          // rewrite what this launch's rasteriser blocks still read
     bool recs_valid = false;        // records reflect the current state of every env
     BrkCfg* cfg_dev = nullptr;      // device copy of `c` for kernels that index the tables per thread
 
@@ -1805,6 +1866,7 @@ struct BreakoutOps : GameOps {
         TBX_HIP(dalloc(&d.alive, 4 * N));
         TBX_HIP(dalloc(&recs, N));
         TBX_HIP(dalloc(&recs_other, N));
+        TBX_HIP(dalloc(&recs_third, N));
         d.custom = nullptr;
         return TBX_OK;
     }
@@ -1816,6 +1878,7 @@ struct BreakoutOps : GameOps {
         if (d.custom) hipFree(d.custom);
         hipFree(recs);
         hipFree(recs_other);
+        hipFree(recs_third);
         hipFree(recsA);
         hipFree(recsB);
         hipFree(cfg_dev);
@@ -1890,7 +1953,10 @@ struct BreakoutOps : GameOps {
 
     // tbx_render_step_synthetic: frame t and the step to frame t + 1 in one launch (brk_render_step_kernel_w5)
     bool render_step_fused(int channels) const override { return pipeline_ok() && channels >= 3; }   // (gray frames stream fastest at more than five waves per SIMD)
-    int render_step(tbx_engine* e, uint8_t* out_dev, int channels, const ActionSource& src, uint32_t flags, hipStream_t s) override
+    // scripts/strong_sweep.py / bench.py (round 6, same-box A/B of TBX_OPT_FUSED_OVERLAP 2 / 1): see profiles/r06_experiments.txt
+    bool fused_overlap_auto(int n) const override { return n <= 16384; }
+    static constexpr int FUSED_LEAD_BLOCKS = 1024;
+    int render_step(tbx_engine* e, uint8_t* out_dev, int channels, const ActionSource& src, uint32_t flags, hipStream_t s, TbxOverlapLaunch* ov) override
     {
         if (!recs_valid) {                                     // the painter reads records: bring them up to the state first
             hipLaunchKernelGGL(brk_render_prep_kernel, dim3((e->n + 255) / 256), dim3(256), 0, s, d, recs, 0, e->n);
@@ -1901,13 +1967,32 @@ struct BreakoutOps : GameOps {
         const int split = split_opt > 0 ? split_opt : channels == 3 ? 10 : e->n <= 8192 ? 4 : e->n <= 32768 ? 2 : 1;
         const int step_blocks = (e->n + TBX_BLOCK - 1) / TBX_BLOCK;
         const dim3 grid(grid_for(e->n * split).x + (unsigned)step_blocks), block(TBX_BLOCK);
-        switch (channels) {
-        case 3: TBX_LAUNCH_STEP(e, s, brk_render_step_kernel_w5<3>, grid, block, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks); break;
-        case 4: TBX_LAUNCH_STEP(e, s, brk_render_step_kernel_w5<4>, grid, block, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks); break;
-        default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
-        }
+        unsigned long long* const no_counter = nullptr;
+        if (ov) {                                              // overlapped: the lane's completion event rides on the launch
+            ov->step_blocks = step_blocks;
+            // the next launch is released when the block `lead` blocks before the end of this grid starts (never a step block).
+            // The engine's choice: see fused_overlap_auto
+            const int lead = ov->lead > 0 ? ov->lead : FUSED_LEAD_BLOCKS;
+            const int release_block = std::max(step_blocks, (int)grid.x - lead);
+            hipEvent_t done = OVL_DIAG(ov->diag, 128) ? nullptr : ov->done;
+            switch (channels) {
+            case 3: hipExtLaunchKernelGGL(brk_render_step_kernel_w5<3>, grid, block, 0, s, nullptr, done, 0, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, ov->arrive, release_block, ov->diag); break;
+            case 4: hipExtLaunchKernelGGL(brk_render_step_kernel_w5<4>, grid, block, 0, s, nullptr, done, 0, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, ov->arrive, release_block, ov->diag); break;
+            default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+            }
+        } else
+            switch (channels) {
+            case 3: TBX_LAUNCH_STEP(e, s, brk_render_step_kernel_w5<3>, grid, block, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, no_counter, 0, 0); break;
+            case 4: TBX_LAUNCH_STEP(e, s, brk_render_step_kernel_w5<4>, grid, block, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, no_counter, 0, 0); break;
+            default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+            }
         TBX_HIP(hipGetLastError());
-        std::swap(recs, recs_other);
+        // THREE buffers in rotation: the launch after this one reads what this one's step wrote and writes the third, so that a
+        // launch on the other lane never rewrites records this launch's rasteriser blocks may still be reading
+        BrkRenderRec* const was_read = recs;
+        recs = recs_other;
+        recs_other = recs_third;
+        recs_third = was_read;
         recs_par ^= 1;
         return TBX_OK;
     }

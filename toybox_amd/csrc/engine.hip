@@ -221,6 +221,8 @@ int check_err_flag(tbx_engine* e)
     EHIP(hipStreamSynchronize(e->stream));
     if (f) {
         EHIP(hipMemsetAsync(e->err_flag, 0, sizeof f, e->stream));
+        if (f & 4u)
+            return e->fail(TBX_E_NO_DEVICE, "an overlapped fused launch waited 3 s for the step blocks of the launch before it (TBX_OPT_FUSED_OVERLAP): results are not valid");
         if (f & 2u)
             return e->fail(TBX_E_NEEDS_RESET, "an env was stepped after its game ended inside EpisodicLifeEnv's no-op step (bench.Monitor raises here)");
         return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
@@ -306,8 +308,10 @@ int tbx_destroy(tbx_engine* e)
         if (pp.render_ev[k]) hipEventDestroy(pp.render_ev[k]);
         if (pp.user_step_ev[k]) hipEventDestroy(pp.user_step_ev[k]);
         if (pp.user_frame_ev[k]) hipEventDestroy(pp.user_frame_ev[k]);
+        if (pp.launch_ev[k]) hipEventDestroy(pp.launch_ev[k]);
         if (pp.lane[k] && pp.lane[k] != e->stream) hipStreamDestroy(pp.lane[k]);
     }
+    hipFree(pp.arrive);
     hipFree(e->actions);
     hipFree(e->edit_args); hipFree(e->reduce_out);
     hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame_own); hipFree(e->staging); hipFree(e->scal); hipFree(e->one_frame); hipFree(e->io_dev);
@@ -550,6 +554,12 @@ static int pipe_prepare(tbx_engine* e)
         if (!p.render_ev[k]) EHIP(hipEventCreateWithFlags(&p.render_ev[k], hipEventDisableTiming));
         if (!p.user_step_ev[k]) EHIP(hipEventCreateWithFlags(&p.user_step_ev[k], hipEventDisableTiming));
         if (!p.user_frame_ev[k]) EHIP(hipEventCreateWithFlags(&p.user_frame_ev[k], hipEventDisableTiming));
+        if (!p.launch_ev[k]) EHIP(hipEventCreateWithFlags(&p.launch_ev[k], hipEventDisableTiming));
+    }
+    if (!p.arrive) {
+        EHIP(hipMalloc((void**)&p.arrive, 2 * sizeof(unsigned long long)));
+        EHIP(hipMemset(p.arrive, 0, 2 * sizeof(unsigned long long)));
+        p.arrive_want = p.release_want = 0;
     }
     // The two internal streams are created with the highest priority.  Not for the priority's sake: the runtime multiplexes the
     // streams of a process onto a few hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES, 4 by default), two streams that
@@ -558,6 +568,9 @@ static int pipe_prepare(tbx_engine* e)
     // the serial loop from one process to the next; scripts/pipeline_sweep.py).
     int lo = 0, hi = 0;
     EHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));     // numerically hi <= lo
+#ifdef TBX_DIAG
+    if (getenv("TBX_LANE_PRIORITY")) hi = atoi(getenv("TBX_LANE_PRIORITY")) ? lo : hi;      // measurement builds: ordinary streams
+#endif
     for (int k = 0; k < 2; k++)
         if (!p.lane[k]) EHIP(hipStreamCreateWithPriority(&p.lane[k], hipStreamNonBlocking, hi));
     p.prepared = true;
@@ -565,9 +578,13 @@ static int pipe_prepare(tbx_engine* e)
 }
 
 // the first pipelined call after a call of any other kind: every internal stream behind all that came before
-static int pipe_enter(tbx_engine* e)
+static int pipe_enter(tbx_engine* e, bool fused = false)
 {
     TbxPipe& p = e->pipe;
+    if (e->pending_kind) EHIP(tbx_finish_pending(e));           // (a host-delivery step between its begin and end calls)
+    // pipelined steps / renders and overlapped fused launches keep different books on the same lanes: a change of kind joins
+    // first (the caller's stream has been made to wait for every internal launch, so the lanes re-enter behind it)
+    if (p.active && p.fused != fused) EHIP(tbx_use_stream(e, e->last_stream));
     if (p.active) return TBX_OK;
     if (e->serve_running) EHIP(tbx_serve_stop(e));
     int rc = pipe_prepare(e);
@@ -580,6 +597,9 @@ static int pipe_enter(tbx_engine* e)
     p.step_user = nullptr;
     p.frame_par = -1;
     p.live_reader = -1;
+    p.fused = fused;
+    p.prev_overlapped = false;
+    p.launch_rec[0] = p.launch_rec[1] = false;
     p.active = true;
     return TBX_OK;
 }
@@ -681,6 +701,101 @@ static int pipe_render(tbx_engine* e, uint8_t* out_dev, int channels, hipStream_
         e->frame = e->frame_own;
         e->frame_bytes = e->frame_own_bytes;
     }
+    e->last_stream = user;
+    e->has_last = true;
+    return TBX_OK;
+}
+
+// ---- overlapped fused launches (TBX_OPT_FUSED_OVERLAP; contract in include/toybox_amd.h)
+//
+// Launch N of a loop of tbx_render_step_synthetic calls = [step blocks: state t -> t+1, records R[b], outputs O[wp]] +
+// [rasteriser blocks: R[a] -> frame F[wp]].  Launch N+1 needs the step blocks of launch N and nothing else of it, so it goes to
+// the OTHER lane (a stream per parity, like value 3 of the pipelined mode) behind a one-wave kernel that waits until the device
+// counter `arrive` says those blocks are through (they fence and bump it last).  The launch itself never waits: a grid that
+// spins could fill the chip before the launch it waits for has been dispatched.  Hazards and who orders them:
+//   state, O[wp] written by step N, read / rewritten by step N+1     the counter (+ an acquire fence at the head of every wave)
+//   R[b] written by step N, read by rasteriser N+1                   the counter
+//   R[a] read by rasteriser N, rewritten by step N+2 (three buffers) stream order: N and N+2 share a lane
+//   F[wp], O[wp] written by N, rewritten by N+2                       stream order; their READERS on the caller's stream U by the
+//                                                                    fence recorded on U at call N+1 (user_step_ev), awaited by N+2
+//   the collective that reads O[wp] / a ring                          tbx_gather waits for both lanes' completion events;
+//                                                                    tbx_gather_before_step makes the rewriting launch wait for it
+//   U                                                                 waits for every launch's completion event (what the caller
+//                                                                    queues next sees the results; calls of other kinds join through U)
+// Measured (scripts/ubench/overlap_ticket.hip, a stand-in launch, ms per launch serial / completion-event dependency / this /
+// hipStreamWaitValue64 on the counter): 4 096 envs 0.0920 / 0.0982 / 0.0887 / 0.0886, 8 192: 0.1854 / 0.1917 / 0.1794 / 0.1791,
+// 65 536: 1.555 / 1.560 / 1.477 / 1.483 -- the wait kernel costs nothing against the command processor's own (beta) wait.
+__global__ void tbx_ticket_wait_kernel(const unsigned long long* arrive, unsigned long long want_steps, unsigned long long want_releases, uint32_t* err_flag)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    // (relaxed: what has to be seen behind the counter is read with agent-scope loads by the launch that follows)
+    while (__hip_atomic_load(arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want_releases ||
+           __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want_steps) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > 300000000ull) { atomicOr(err_flag, 4u); return; }   // 3 s of the 100 MHz clock: report, never hang
+    }
+}
+
+static bool fused_overlap_on(const tbx_engine* e, const uint8_t* out_dev, int channels)
+{
+    const int v = e->opt[TBX_OPT_FUSED_OVERLAP];
+    if (v == 2 || out_dev != nullptr || !e->ops->render_step_fused(channels)) return false;
+    return v == 1 || e->ops->fused_overlap_auto(e->n);
+}
+
+static int fused_overlapped(tbx_engine* e, int channels, const ActionSource& src, uint32_t flags, hipStream_t user)
+{
+    int rc = pipe_enter(e, true);
+    if (rc) return rc;
+    TbxPipe& p = e->pipe;
+    const int cur = e->out_par, wp = cur ^ 1;                  // this launch writes output set wp and frame buffer wp, on lane wp
+#ifdef TBX_DIAG
+    const int diag = getenv("TBX_OVERLAP_DIAG") ? atoi(getenv("TBX_OVERLAP_DIAG")) : 0;
+#else
+    const int diag = 0;
+#endif
+    hipStream_t ls = p.lane[OVL_DIAG(diag, 8) ? 0 : wp];
+    const int fb = OVL_DIAG(diag, 32) ? 0 : wp;
+    const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
+    if (p.frame_bytes[fb] < bytes) {
+        EHIP(hipStreamSynchronize(ls));
+        if (p.frame[fb]) hipFree(p.frame[fb]);
+        p.frame[fb] = nullptr;
+        p.frame_bytes[fb] = 0;
+        EHIP(hipMalloc((void**)&p.frame[fb], bytes));
+        p.frame_bytes[fb] = bytes;
+    }
+    // readers of what call N-2 left in set / frame wp were queued on U before call N-1, which fenced them; this call fences the
+    // readers of call N-1's results for call N+1
+    if (!OVL_DIAG(diag, 16)) {
+        if (p.user_step_rec[wp]) { EHIP(hipStreamWaitEvent(ls, p.user_step_ev[wp], 0)); p.user_step_rec[wp] = false; }
+        EHIP(hipEventRecord(p.user_step_ev[cur], user));
+        p.user_step_rec[cur] = true;
+    }
+    uint64_t* const ring_slot = e->gather_ring ? e->packed : nullptr;      // (a K-step ring owns the record pointer)
+    tbx_set_out_parity(e, wp);
+    if (ring_slot) { e->packed = ring_slot; e->ops->rebind_outputs(e); }
+    auto undo = [&]() { tbx_set_out_parity(e, cur); if (ring_slot) { e->packed = ring_slot; e->ops->rebind_outputs(e); } };
+    hipError_t ge = tbx_gather_before_step(e, ls);
+    if (ge != hipSuccess) { undo(); return hip_fail(e, "tbx_gather_before_step", ge); }
+    if (p.prev_overlapped && !OVL_DIAG(diag, 64)) {
+        hipLaunchKernelGGL(tbx_ticket_wait_kernel, dim3(1), dim3(64), 0, ls, p.arrive, p.arrive_want, p.release_want, e->err_flag);
+        ge = hipGetLastError();
+        if (ge != hipSuccess) { undo(); return hip_fail(e, "tbx_ticket_wait_kernel", ge); }
+    }
+    TbxOverlapLaunch ov{p.arrive, p.launch_ev[wp], e->opt[TBX_OPT_FUSED_OVERLAP_LEAD], 0, diag};
+    rc = e->ops->render_step(e, p.frame[fb], channels, src, flags, ls, &ov);
+    if (rc) { undo(); return rc; }                             // nothing was launched: TBX_BUF_* keep naming the set that holds results
+    p.arrive_want += (unsigned long long)ov.step_blocks;
+    p.release_want += 1;
+    p.prev_overlapped = true;
+    p.launch_rec[wp] = true;
+    if (OVL_DIAG(diag, 128)) EHIP(hipEventRecord(p.launch_ev[wp], ls));
+    if (!OVL_DIAG(diag, 16)) EHIP(hipStreamWaitEvent(user, p.launch_ev[wp], 0));
+    e->frame = p.frame[fb];
+    e->frame_bytes = p.frame_bytes[fb];
+    e->step_carries_order_ev = false;
     e->last_stream = user;
     e->has_last = true;
     return TBX_OK;
@@ -796,11 +911,50 @@ int tbx_host_stack_push(uint8_t* dst, const uint8_t* src, const uint8_t* plane, 
     return TBX_OK;
 }
 
+// the waiting half of tbx_step_end: the queued step has finished, its outputs are in the caller's buffers
+static int step_deliver(tbx_engine* e)
+{
+    EHIP(hipSetDevice(e->device));
+    EHIP(hipStreamSynchronize(e->stream));
+    e->host_pending = false;
+    e->pending_kind = 0;
+    const size_t N = (size_t)e->n;
+    const int32_t* host_out = e->io_host + N;
+    const tbx_step_host_out_t& o = e->host_out;
+    if (o.reward) memcpy(o.reward, host_out, N * sizeof(int32_t));
+    if (o.lives) memcpy(o.lives, host_out + N, N * sizeof(int32_t));
+    if (o.score) memcpy(o.score, host_out + 2 * N, N * sizeof(int32_t));
+    if (o.done) memcpy(o.done, host_out + 3 * N + 1, N);
+    if (host_out[3 * N] & 2) return e->fail(TBX_E_NEEDS_RESET, "an env was stepped after its game ended inside EpisodicLifeEnv's no-op step (bench.Monitor raises here)");
+    if (host_out[3 * N]) return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
+    return TBX_OK;
+}
+
+// Another entry point was called between "_begin" and "_end" (every one that queues work comes through tbx_use_stream or
+// pipe_enter): the step is ended here -- the stream drained, the outputs delivered to the caller's buffers -- and what its "_end"
+// call would have returned is kept for that call (the header promised this, and a later "_end" delivered stale data).
+}  // extern "C"
+
+hipError_t tbx_finish_pending(tbx_engine* e)
+{
+    const int kind = e->pending_kind;
+    if (!kind) return hipSuccess;
+    const int rc = kind == 1 ? step_deliver(e) : tbx_agent_deliver(e);
+    e->pending_kind = 0;
+    e->ended_early_kind = kind;
+    e->ended_early_rc = rc;
+    e->ended_early_msg = rc ? e->err : std::string();
+    return rc == TBX_E_NO_DEVICE ? hipErrorUnknown : hipSuccess;
+}
+
+extern "C" {
+
 int tbx_step_begin(tbx_engine* e, const int32_t* actions_host, uint32_t flags, const tbx_step_host_out_t* out)
 {
     CHECK_ENGINE(e);
     if (!actions_host || !out) return e->fail(TBX_E_INVALID, "actions / output descriptor is NULL");
-    if (e->host_pending) return e->fail(TBX_E_INVALID, "tbx_step_begin: the previous step has not been ended (tbx_step_end)");
+    if (e->pending_kind) return e->fail(TBX_E_INVALID, "tbx_step_begin: the previous step has not been ended (tbx_step_end / tbx_agent_step_end)");
+    e->ended_early_kind = 0;                   // (an "_end" that was never called for a step another call ended)
     if (out->frame && out->channels != 1 && out->channels != 3 && out->channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
     EHIP(hipSetDevice(e->device));
     EHIP(tbx_use_stream(e, e->stream));
@@ -836,33 +990,28 @@ int tbx_step_begin(tbx_engine* e, const int32_t* actions_host, uint32_t flags, c
     }
     e->host_out = *out;
     e->host_pending = true;
+    e->pending_kind = 1;
     return TBX_OK;
 }
 
 int tbx_step_end(tbx_engine* e)
 {
     CHECK_ENGINE(e);
-    if (!e->host_pending) return e->fail(TBX_E_INVALID, "tbx_step_end without tbx_step_begin");
-    EHIP(hipSetDevice(e->device));
-    EHIP(hipStreamSynchronize(e->stream));
-    e->host_pending = false;
-    const size_t N = (size_t)e->n;
-    const int32_t* host_out = e->io_host + N;
-    const tbx_step_host_out_t& o = e->host_out;
-    if (o.reward) memcpy(o.reward, host_out, N * sizeof(int32_t));
-    if (o.lives) memcpy(o.lives, host_out + N, N * sizeof(int32_t));
-    if (o.score) memcpy(o.score, host_out + 2 * N, N * sizeof(int32_t));
-    if (o.done) memcpy(o.done, host_out + 3 * N + 1, N);
-    if (host_out[3 * N] & 2) return e->fail(TBX_E_NEEDS_RESET, "an env was stepped after its game ended inside EpisodicLifeEnv's no-op step (bench.Monitor raises here)");
-    if (host_out[3 * N]) return e->fail(TBX_E_ACTION, "an illegal ALE action id was passed (treated as NOOP)");
-    return TBX_OK;
+    if (!e->host_pending) {
+        if (e->ended_early_kind == 1) {        // another call on the handle ended the step: its outputs have been delivered
+            e->ended_early_kind = 0;
+            return e->ended_early_rc ? e->fail(e->ended_early_rc, e->ended_early_msg) : TBX_OK;
+        }
+        return e->fail(TBX_E_INVALID, "tbx_step_end without tbx_step_begin");
+    }
+    return step_deliver(e);
 }
 
 int tbx_step(tbx_engine* e, const int32_t* actions_host, uint32_t flags, int32_t* reward, uint8_t* done,
              int32_t* lives, int32_t* score)
 {
     CHECK_ENGINE(e);
-    if (e->host_pending) return e->fail(TBX_E_INVALID, "tbx_step: a tbx_step_begin has not been ended (tbx_step_end)");
+    if (e->pending_kind) return e->fail(TBX_E_INVALID, "tbx_step: a step is between its begin and end calls (tbx_step_end / tbx_agent_step_end)");
     tbx_step_host_out_t out{};
     out.reward = reward; out.done = done; out.lives = lives; out.score = score;
     int rc = tbx_step_begin(e, actions_host, flags, &out);
@@ -1086,20 +1235,21 @@ int tbx_render_step_synthetic(tbx_engine* e, uint8_t* out_dev, int channels, uin
     if (channels != 1 && channels != 3 && channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
     EHIP(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
-    EHIP(tbx_use_stream(e, s));                                 // (everything on the caller's stream: leaves a pipelined mode first)
-    if (!out_dev) {
-        const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
-        int rc = ensure_frame(e, bytes);
-        if (rc) return rc;
-        out_dev = e->frame;
-    }
-    if (((uintptr_t)out_dev & 15u) != 0) return e->fail(TBX_E_INVALID, "frame buffer must be 16-byte aligned");
     ActionSource src{};
     src.actions = nullptr;
     src.seed = action_seed;
     src.t = t;
     src.env_offset = env_offset;
     src.single_env = -1;
+    if (fused_overlap_on(e, out_dev, channels)) return fused_overlapped(e, channels, src, flags, s);
+    EHIP(tbx_use_stream(e, s));                                 // (everything on the caller's stream: leaves a pipelined mode first)
+    if (!out_dev) {
+        const size_t bytes = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
+        int rc = ensure_frame(e, bytes);
+        if (rc) return rc;
+        out_dev = e->frame;                                     // (ensure_frame: TBX_BUF_FRAME is the engine's own buffer again)
+    }
+    if (((uintptr_t)out_dev & 15u) != 0) return e->fail(TBX_E_INVALID, "frame buffer must be 16-byte aligned");
     if (e->ops->render_step_fused(channels)) {
         EHIP(tbx_gather_before_step(e, s));
         return e->ops->render_step(e, out_dev, channels, src, flags, s);
@@ -1398,6 +1548,8 @@ int tbx_set_option(tbx_engine* e, int option, int value)
     case TBX_OPT_RENDER_SPLIT: ok = value >= 0 && value <= 64; break;
     case TBX_OPT_AGENT_GENERIC: case TBX_OPT_RESIDENT_STEP: case TBX_OPT_GATHER_TRANSPORT: ok = value == 0 || value == 1; break;
     case TBX_OPT_GATHER_EVERY: ok = value >= 1 && value <= 64; break;
+    case TBX_OPT_FUSED_OVERLAP: ok = value >= 0 && value <= 2; break;
+    case TBX_OPT_FUSED_OVERLAP_LEAD: ok = value >= 0 && value <= (1 << 20); break;
     default: return e->fail(TBX_E_INVALID, "unknown option");
     }
     if (!ok) return e->fail(TBX_E_INVALID, "option value out of range");
@@ -1417,6 +1569,7 @@ int tbx_get_option(tbx_engine* e, int option, int* value_out)
     if (value_out && option == TBX_OPT_PIPELINE_ACTIVE) { *value_out = pipe_mode(e); return TBX_OK; }
     if (value_out && option == TBX_OPT_RECORDS_ACTIVE) { *value_out = e->ops->pipeline_ok() ? 1 : 0; return TBX_OK; }
     if (value_out && option == TBX_OPT_RENDER_STEP_FUSED) { *value_out = e->ops->render_step_fused(3) ? 1 : 0; return TBX_OK; }
+    if (value_out && option == TBX_OPT_FUSED_OVERLAP_ACTIVE) { *value_out = fused_overlap_on(e, nullptr, 3) ? 1 : 0; return TBX_OK; }
     if (option < 0 || option >= TBX_OPT_COUNT || !value_out) return e->fail(TBX_E_INVALID, "unknown option");
     *value_out = e->opt[option];
     return TBX_OK;
@@ -1427,6 +1580,7 @@ int tbx_sync(tbx_engine* e)
     CHECK_ENGINE(e);
     EHIP(hipSetDevice(e->device));
     EHIP(tbx_serve_stop(e));
+    EHIP(tbx_finish_pending(e));
     EHIP(hipDeviceSynchronize());
     e->has_last = false;              // nothing is pending any more: the stream of the last call is no longer needed
     e->pipe.active = false;

@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 // The handful of RCCL declarations this file needs, stated locally: the library is found with dlopen at run time and its
@@ -297,6 +298,13 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
     }
     g.nranks = nranks; g.rank = rank; g.width = records_per_rank;
     g.every = e->opt[TBX_OPT_GATHER_EVERY] > 1 ? e->opt[TBX_OPT_GATHER_EVERY] : 1;
+#ifdef TBX_DIAG
+    if (getenv("TBX_GATHER_PRIORITY") && atoi(getenv("TBX_GATHER_PRIORITY"))) {      // measurement builds: the communication stream in the high-priority pool
+        int lo = 0, hi = 0;
+        GHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        GHIP(hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, hi));
+    } else
+#endif
     GHIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     GHIP(hipEventCreateWithFlags(&g.ready, hipEventDisableTiming));
     GHIP(hipEventCreateWithFlags(&g.done[0], hipEventDisableTiming));
@@ -333,28 +341,40 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
         uint64_t fnv = 1469598103934665603ull;                              // the segment's name: a hash of the 128 id bytes
         for (size_t i = 0; i < TBX_GATHER_ID_BYTES; i++) fnv = (fnv ^ ((const uint8_t*)id)[i]) * 1099511628211ull;
         snprintf(h->name, sizeof h->name, "/tbx_hg_%016llx", (unsigned long long)fnv);
-        GHIP(hipHostMalloc((void**)&h->stage_out, h->slot, hipHostMallocDefault));
-        GHIP(hipHostMalloc((void**)&h->gathered, (size_t)nranks * h->slot, hipHostMallocDefault));
+        if (hipHostMalloc((void**)&h->stage_out, h->slot, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&h->gathered, (size_t)nranks * h->slot, hipHostMallocDefault) != hipSuccess) {
+            h->name[0] = 0;                                     // (no segment has been made under this name yet)
+            tbx_gather_free(e);
+            return e->fail(TBX_E_NOMEM, "gather: page-locked staging buffers of the host transport");
+        }
         memset(h->stage_out, 0, h->slot);
         memset(h->gathered, 0, (size_t)nranks * h->slot);
+        // every failure from here on takes the half-made world down with it (tbx_gather_free: staging buffers, the mapping, the
+        // segment's name), so that a later tbx_gather finds no communicator instead of a HostWorld without a map
+        auto bail = [&](const char* msg) { tbx_gather_free(e); return e->fail(TBX_E_NO_DEVICE, msg); };
         const int fd = shm_open(h->name, O_CREAT | O_RDWR, 0600);
-        if (fd < 0) return e->fail(TBX_E_NO_DEVICE, "gather: shm_open failed for the host transport");
-        if (ftruncate(fd, (off_t)h->len) != 0) { close(fd); return e->fail(TBX_E_NO_DEVICE, "gather: ftruncate failed"); }
+        if (fd < 0) { h->name[0] = 0; return bail("gather: shm_open failed for the host transport"); }
+        if (ftruncate(fd, (off_t)h->len) != 0) { close(fd); return bail("gather: ftruncate failed"); }
         void* m = mmap(nullptr, h->len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);     // a fresh segment reads as zeros
         close(fd);
-        if (m == MAP_FAILED) return e->fail(TBX_E_NO_DEVICE, "gather: mmap failed");
+        if (m == MAP_FAILED) return bail("gather: mmap failed");
         h->map = m;
         // collective like ncclCommInitRank: returns once every rank has attached
         __atomic_store_n(&h->head()->seq[2][rank], (uint64_t)1, __ATOMIC_RELEASE);
-        if (!h->wait_all(2, 1)) return e->fail(TBX_E_NO_DEVICE, "gather: not every rank attached to the host transport's segment");
+        if (!h->wait_all(2, 1)) return bail("gather: not every rank attached to the host transport's segment");
         g.comm_count = nranks;
         return TBX_OK;
     }
     tbx_nccl_id_t uid;
     memcpy(&uid, id, sizeof uid);
-    GNCCL(g.comm_init_rank(&g.comm, nranks, uid, rank));
-    GNCCL(g.comm_count_fn(g.comm, &g.comm_count));
-    if (g.comm_count != nranks) return e->fail(TBX_E_NO_DEVICE, "gather: the communicator does not span the ranks asked for");
+    int nr = g.comm_init_rank(&g.comm, nranks, uid, rank);
+    if (nr == TBX_NCCL_SUCCESS) nr = g.comm_count_fn(g.comm, &g.comm_count);
+    if (nr != TBX_NCCL_SUCCESS) {
+        const std::string msg = std::string("ncclCommInitRank / ncclCommCount: ") + g.error_string(nr);
+        tbx_gather_free(e);
+        return e->fail(TBX_E_NO_DEVICE, msg);
+    }
+    if (g.comm_count != nranks) { tbx_gather_free(e); return e->fail(TBX_E_NO_DEVICE, "gather: the communicator does not span the ranks asked for"); }
     return TBX_OK;
 }
 
@@ -371,10 +391,28 @@ static int host_collective(tbx_engine* e, GatherState& g, const uint64_t* send_d
     return TBX_OK;
 }
 
+// the communication stream behind the step(s) whose records the collective reads.  Overlapped fused launches (TbxPipe::fused): the
+// completion events of both lanes -- the last launch and the one before it, which may still be painting but whose step blocks
+// the last launch waited for; pipelined mode: the step stream's event; otherwise the tail of the handle.
+static hipError_t wait_for_steps(tbx_engine* e, hipStream_t gs)
+{
+    const TbxPipe& p = e->pipe;
+    if (p.active && p.fused) {
+        for (int k = 0; k < 2; k++)
+            if (p.launch_rec[k]) {
+                hipError_t r = hipStreamWaitEvent(gs, p.launch_ev[k], 0);
+                if (r != hipSuccess) return r;
+            }
+        return hipSuccess;
+    }
+    if (p.active && p.step_outstanding) return hipStreamWaitEvent(gs, p.step_ev, 0);
+    return tbx_wait_tail(e, gs, true);
+}
+
 int tbx_gather(tbx_engine* e, uint64_t* out_dev, void* stream)
 {
     if (!e) return TBX_E_INVALID;
-    if (!e->gather) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called");
+    if (!e->gather || (!e->gather->comm && !(e->gather->host && e->gather->host->map))) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called (or failed)");
     GatherState& g = *e->gather;
     GHIP(hipSetDevice(e->device));
     // After the step that wrote the records, on the communication stream, so that the rasteriser the caller queues next overlaps
@@ -389,7 +427,7 @@ int tbx_gather(tbx_engine* e, uint64_t* out_dev, void* stream)
         g.advance = true;
         if (++g.fill < g.every) return TBX_OK;              // nothing is queued: K - 1 of K calls cost no stream operation at all
         const int p = g.ring_par;
-        GHIP(tbx_wait_tail(e, gs, true));
+        GHIP(wait_for_steps(e, gs));
         if (g.any && g.done_on[g.last_par] != gs) GHIP(hipStreamWaitEvent(gs, g.done[g.last_par], 0));
         if (g.host) {
             int rc = host_collective(e, g, g.ring[p], out_dev ? out_dev : g.out, gs);
@@ -405,8 +443,7 @@ int tbx_gather(tbx_engine* e, uint64_t* out_dev, void* stream)
         g.ring_par = p ^ 1;
         return TBX_OK;
     }
-    if (e->pipe.active && e->pipe.step_outstanding) GHIP(hipStreamWaitEvent(gs, e->pipe.step_ev, 0));
-    else GHIP(tbx_wait_tail(e, gs, true));
+    GHIP(wait_for_steps(e, gs));
     if (g.any && g.done_on[g.last_par] != gs) GHIP(hipStreamWaitEvent(gs, g.done[g.last_par], 0));
     const uint64_t* send = e->packed;
     if (g.send) {
@@ -457,6 +494,7 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout_host)
     if (!e->gather) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called");
     if (!inout_host) return e->fail(TBX_E_INVALID, "value pointer is NULL");
     GatherState& g = *e->gather;
+    if (!g.comm && !(g.host && g.host->map)) return e->fail(TBX_E_INVALID, "tbx_gather_init has not been called (or failed)");
     GHIP(hipSetDevice(e->device));
     if (g.host) {
         if (!g.host->max_scalar(inout_host)) return e->fail(TBX_E_NO_DEVICE, "gather: a rank did not reach the reduction (host transport)");

@@ -338,6 +338,38 @@ struct TbxPipe {
     int frame_par = -1;           // frame buffer the last overlapped render wrote (-1: none since the pipeline was entered)
     uint8_t* frame[2] = {nullptr, nullptr};
     size_t frame_bytes[2] = {0, 0};
+    // Overlapped fused launches (TBX_OPT_FUSED_OVERLAP; engine.hip, fused_overlapped): consecutive tbx_render_step_synthetic
+    // launches alternate between the two lanes, the two output sets and the two frame buffers, and launch N+1 is ordered behind
+    // the STEP BLOCKS of launch N only -- a device counter they bump when their state, records and outputs are written, waited
+    // for by a one-wave kernel in front of launch N+1 (tbx_ticket_wait_kernel) -- not behind its rasteriser blocks.
+    bool fused = false;                              // the calls since the pipeline was entered are such launches (pipe_enter joins before the kind of call changes)
+    hipEvent_t launch_ev[2] = {nullptr, nullptr};    // completion event of the last fused launch on lane k (it rides on the launch)
+    bool launch_rec[2] = {false, false};
+    unsigned long long* arrive = nullptr;            // device [2]: step blocks of overlapped launches that have finished, ever; launches
+                                                     // whose RELEASE block has started (the block `lead` blocks before the end of the grid)
+    unsigned long long arrive_want = 0;              // host: what the launches issued so far add up to
+    unsigned long long release_want = 0;
+    bool prev_overlapped = false;                    // the call before this one was an overlapped launch (else stream order holds)
+};
+
+// what an overlapped fused launch gets from the engine: the counter its step blocks bump, the event that rides on the launch as
+// its completion event; step_blocks comes back (how many arrivals the launch adds)
+// measurement builds only (make DIAG=1; env TBX_OVERLAP_DIAG read in engine.hip; results are WRONG or racy with any bit set): parts of
+// the overlapped launch switched off one at a time -- 1 the first build's step half: plain loads and stores behind a per-wave L2
+// invalidate and write-back (+ 2: no write-back) instead of agent-scope loads and stores, 4 plain record load, 8 both launches on ONE lane (the machinery without any overlap), 16 no fence / wait on the caller's
+// stream, 32 one frame buffer, 64 no wait kernel, 128 no completion event on the launch
+#ifdef TBX_DIAG
+#define OVL_DIAG(mask, bit) (((mask) & (bit)) != 0)
+#else
+#define OVL_DIAG(mask, bit) false
+#endif
+
+struct TbxOverlapLaunch {
+    unsigned long long* arrive;     // [0] bumped by every step block when its stores are out, [1] by the release block when it starts
+    hipEvent_t done;
+    int lead;                       // TBX_OPT_FUSED_OVERLAP_LEAD (0: the engine's choice)
+    int step_blocks;
+    int diag;                       // OVL_DIAG mask (0 in product builds)
 };
 
 struct tbx_engine {
@@ -350,7 +382,7 @@ struct tbx_engine {
     bool has_last = false;
     hipEvent_t order_ev = nullptr;
     bool step_carries_order_ev = false;        // order_ev is the completion event of the last launch on last_stream (a batch step)
-    int opt[TBX_OPT_COUNT] = {0, 0, 0, 0, 1, 1, 0};
+    int opt[TBX_OPT_COUNT] = {0, 0, 0, 0, 1, 1, 0, 0, 0};
     bool gather_ring = false;                  // a K-step record ring is in force (TBX_OPT_GATHER_EVERY > 1 at tbx_gather_init): no pipelined mode
     bool gather_wants_step_event = false;      // the next batch step is one a collective will wait for: its launch carries the ordering event
     TbxPipe pipe;
@@ -375,6 +407,13 @@ struct tbx_engine {
     int32_t* io_dev = nullptr;      // 3N + 1 dwords + N bytes
     int32_t* io_host = nullptr;     // pinned mirror (+ N action dwords in front)
     bool host_pending = false;      // a tbx_step_begin whose outputs are on their way (tbx_step_end takes them)
+    // "Any other call on the handle between _begin and _end ends the step first" (toybox_amd.h): which kind of step is pending
+    // (0 none, 1 tbx_step_begin, 2 tbx_agent_step_begin), and -- once another entry point has ended it through
+    // tbx_finish_pending -- the result its own "_end" call still has to report
+    int pending_kind = 0;
+    int ended_early_kind = 0;
+    int ended_early_rc = 0;
+    std::string ended_early_msg;
     tbx_step_host_out_t host_out{}; // where they go
     uint8_t* frame_own = nullptr;   // engine-owned frame buffer (lazy)
     size_t frame_own_bytes = 0;
@@ -406,6 +445,8 @@ struct tbx_engine {
 };
 
 hipError_t tbx_serve_stop(tbx_engine* e);   // engine.hip
+hipError_t tbx_finish_pending(tbx_engine* e);   // engine.hip: ends a step that is between "_begin" and "_end" (outputs delivered, result kept)
+int tbx_agent_deliver(tbx_engine* e);       // agent.hip: the waiting half of tbx_agent_step_end
 
 // Stream `s` waits for everything queued so far on the stream the previous call used.  That stream may be the caller's: the
 // handle is kept until the next call or tbx_sync (toybox_amd.h: a stream named in a call must stay alive that long -- the
@@ -453,6 +494,10 @@ inline hipEvent_t tbx_step_order_event(tbx_engine* e)
 // calls make the caller's stream wait for their internal work and leave it as `last_stream`, so this also joins the pipeline.)
 inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s)
 {
+    if (e->pending_kind) {                     // a step between "_begin" and "_end": this call ends it first
+        hipError_t r = tbx_finish_pending(e);
+        if (r != hipSuccess) return r;
+    }
     if (e->serve_running) {                    // nothing else runs beside the resident step kernel
         hipError_t r = tbx_serve_stop(e);
         if (r != hipSuccess) return r;
@@ -545,7 +590,12 @@ struct GameOps {
     // tbx_render_step_synthetic: the rasteriser of the current frame and the batch step to the next one as ONE launch on s
     // (engines whose rasteriser reads step-written records); render_step_fused() false: the engine runs render(), then step()
     virtual bool render_step_fused(int /*channels*/) const { return false; }
-    virtual int render_step(tbx_engine*, uint8_t* /*out_dev*/, int /*channels*/, const ActionSource&, uint32_t /*flags*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    // ov != nullptr: an overlapped launch (TbxPipe::fused) -- its step blocks bump ov->arrive when their stores are visible
+    // device-wide, ov->done rides on the launch as its completion event, ov->step_blocks is filled in
+    virtual int render_step(tbx_engine*, uint8_t* /*out_dev*/, int /*channels*/, const ActionSource&, uint32_t /*flags*/, hipStream_t,
+                            TbxOverlapLaunch* /*ov*/ = nullptr) { return TBX_E_UNSUPPORTED; }
+    // TBX_OPT_FUSED_OVERLAP = 0, the engine's choice: overlap consecutive fused launches for a batch of n envs?
+    virtual bool fused_overlap_auto(int /*n*/) const { return false; }
     // batched interventions (include/toybox_amd.h, tbx_edit / tbx_reduce): one kernel over the selected envs
     virtual int edit(tbx_engine* e, int /*op*/, const TbxEditArgs&, const uint8_t* /*mask_dev*/, hipStream_t) { return e->fail(TBX_E_INVALID, "this game has no such edit"); }
     virtual int reduce(tbx_engine* e, int /*query*/, const TbxEditArgs&, double* /*out_dev*/, int /*width*/, hipStream_t) { return e->fail(TBX_E_INVALID, "this game has no such query"); }

@@ -7,6 +7,8 @@ test-suite uses it to drive this host code over its CPU checker).
 """
 import ctypes as C
 
+import weakref
+
 import numpy as np
 
 from . import _abi
@@ -27,36 +29,32 @@ def _addr(a):
 
 
 class HostArray:
-    """Owner of one block of page-locked host memory from the engine library's tbx_host_alloc.  The numpy arrays made over it
-    keep the owner alive through their `base` chain, so the memory is released only when the last view is gone (an observation
-    a caller kept past env.close() stays valid: ADVICE r04 on the earlier PinnedArray.close())."""
+    """One block of page-locked host memory from the engine library's tbx_host_alloc, handed out as a numpy array.  The block
+    belongs to the ctypes array that is the `base` of every numpy view of it: a finaliser on that array calls tbx_host_free when
+    the last view is gone -- by reference counting alone, no garbage-collector pass needed (the earlier owner
+    object <-> buffer cycle kept blocks of several hundred MB alive until a full collection).  An observation a caller kept past
+    env.close() stays valid."""
 
-    def __init__(self, lib, nbytes):
-        self._lib = lib
-        p = C.c_void_p()
-        rc = lib.tbx_host_alloc(C.byref(p), int(max(1, nbytes)))
-        if rc != _abi.OK or not p.value:
-            msg = lib.tbx_last_error(None)
-            raise ToyboxAmdError(rc, msg.decode() if msg else "tbx_host_alloc failed")
-        self._ptr = p
-        self.nbytes = int(nbytes)
-        self._buf = (C.c_uint8 * max(1, self.nbytes)).from_address(p.value)
-        self._buf._owner = self              # ctypes array -> owner: the array is the base of every numpy view
+    @staticmethod
+    def _release(lib, address):
+        try:
+            lib.tbx_host_free(C.c_void_p(address))
+        except Exception:
+            pass
 
     @staticmethod
     def make(lib, shape, dtype=np.uint8):
         dt = np.dtype(dtype)
         count = int(np.prod(shape))
-        h = HostArray(lib, count * dt.itemsize)
-        return np.frombuffer(h._buf, dtype=dt, count=count).reshape(shape)
-
-    def __del__(self):
-        try:
-            if self._ptr:
-                self._lib.tbx_host_free(self._ptr)
-                self._ptr = C.c_void_p()
-        except Exception:
-            pass
+        nbytes = max(1, count * dt.itemsize)
+        p = C.c_void_p()
+        rc = lib.tbx_host_alloc(C.byref(p), nbytes)
+        if rc != _abi.OK or not p.value:
+            msg = lib.tbx_last_error(None)
+            raise ToyboxAmdError(rc, msg.decode() if msg else "tbx_host_alloc failed")
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        weakref.finalize(buf, HostArray._release, lib, p.value)      # (holds the library and the address, not the buffer)
+        return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
 
 
 class Engine:

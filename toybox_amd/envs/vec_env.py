@@ -3,6 +3,8 @@
 step_async(actions[N]); step_wait() -> (obs, rews float32, dones bool, infos); a done env is reset and
 the returned obs is the reset obs (dummy_vec_env.py:51-54, subproc_vec_env.py:11-15).  The N worker
 processes + pipes of SubprocVecEnv collapse into one device batch: one step kernel + one render kernel."""
+import time
+
 import numpy as np
 
 from .. import _abi
@@ -59,9 +61,17 @@ def _pool_size(obs_pool, reuse_obs_buffer):
 
 
 class ToyboxVecEnv:
-    def __init__(self, game, num_envs, grayscale=True, alpha=False, seed=None, cache_terminal_state=False, engine=None,
+    CACHE_TERMINAL_STATE_UP_TO = 64      # cache_terminal_state=None: on up to this many envs
+
+    def __init__(self, game, num_envs, grayscale=True, alpha=False, seed=None, cache_terminal_state=None, engine=None,
                  obs_pool=2, reuse_obs_buffer=None):
-        """obs_pool: the observations that reset() / step() return are page-locked host arrays handed out in rotation, so an
+        """cache_terminal_state: ToyboxBaseEnv.step always attaches info["cached_state"] = the state JSON on the step that ends
+        a game (envs/atari/base.py:128-130).  Here that needs the finished envs' state records on the host BEFORE they are reset,
+        which takes the step out of the asynchronous path (step, read-back, new_game, render as four synchronous calls).  None
+        (default): on for batches of up to CACHE_TERMINAL_STATE_UP_TO envs -- the sizes the reference's own vector envs run
+        (run.py: nenv = the CPU count) -- and off above, where the batch step with in-kernel auto-reset is the point; True /
+        False force it.  INTEGRATION.md section 3, row V.
+        obs_pool: the observations that reset() / step() return are page-locked host arrays handed out in rotation, so an
         observation stays valid until obs_pool - 1 further steps have been taken (default 2: the reference's learners copy on
         receipt -- `self.obs[:] = self.env.step(...)`, baselines/ppo2/ppo2.py:110 -- and the copy from the device runs at the PCIe
         link's rate, asynchronously between step_async and step_wait).  obs_pool = 0 is the contract as the reference's VecEnvs
@@ -84,7 +94,7 @@ class ToyboxVecEnv:
         self._lut = np.asarray(self._action_set, dtype=np.int32)
         self.action_space = Discrete(len(self._action_set))
         self.observation_space = Box(0, 255, (self.engine.height, self.engine.width, self._channels), "uint8")
-        self.cache_terminal_state = bool(cache_terminal_state)
+        self.cache_terminal_state = self.num_envs <= self.CACHE_TERMINAL_STATE_UP_TO if cache_terminal_state is None else bool(cache_terminal_state)
         self._codec = codec(self.game)
         self._pending = None
         self._in_flight = None
@@ -113,6 +123,9 @@ class ToyboxVecEnv:
         return self.engine.render(self._channels, out=self._next_obs_array())
 
     def reset(self):
+        if self._in_flight is not None:          # a step between step_async and step_wait: it ends first (its results are dropped)
+            self.step_wait()
+        self._pending = None
         self.engine.new_game()
         return self._frames()
 
@@ -224,7 +237,8 @@ class ToyboxPreprocVecEnv:
 
     episode_life / fire_reset / noop_max switch on the reset-time wrappers of wrap_deepmind / make_atari
     (EpisodicLifeEnv :58-96, FireResetEnv :38-56, NoopResetEnv :12-36), run inside the reset kernel; the Monitor
-    record of a finished game arrives as info["episode"] = {"r", "l"} like bench/monitor.py:68-76.  env_offset is the
+    record of a finished game arrives as info["episode"] = {"r", "l", "t"} like bench/monitor.py:64-76 (t = seconds since this
+    adapter was constructed, where Monitor / VecMonitor count from their own construction; 6 decimals).  env_offset is the
     global index of env 0 (multi-GPU sharding) so no-op counts do not depend on the shard layout.
 
     frame_stack="vec" (default) stacks like VecFrameStack over the vector env: a reset leaves zeros in the older slots.
@@ -276,6 +290,7 @@ class ToyboxPreprocVecEnv:
         self._pending = None
         self._in_flight = None
         self.closed = False
+        self.tstart = time.time()                # Monitor.tstart (bench/monitor.py:19), VecMonitor.tstart (vec_monitor.py:12)
         n = self.num_envs
         pool = _pool_size(obs_pool, reuse_obs_buffer)
         self._pool, self._turn = [], 0
@@ -363,7 +378,8 @@ class ToyboxPreprocVecEnv:
         reward, done = st["reward"].copy(), st["done"].astype(bool)
         ended = np.flatnonzero(st["ep_done"])
         ret, length = st["ep_return"], st["ep_length"]
-        extras = {int(i): {"episode": {"r": float(ret[i]), "l": int(length[i])}} for i in ended}
+        t = round(time.time() - self.tstart, 6) if len(ended) else 0.0
+        extras = {int(i): {"episode": {"r": float(ret[i]), "l": int(length[i]), "t": t}} for i in ended}
         return self._obs(self._stacked_obs(landed, done, False)), reward, done, LazyInfos(self.num_envs, None, extras)
 
     def step(self, actions):

@@ -109,35 +109,30 @@ def memcpy_htod(dst_ptr, src_array, nbytes):
           "hipMemcpy H2D")
 
 
-class _PinnedBlock:
-    """owner of one hipHostMalloc block; freed when the last numpy view of it is gone"""
-
-    def __init__(self, nbytes):
-        self.ptr = C.c_void_p()
-        check(runtime().hipHostMalloc(C.byref(self.ptr), C.c_size_t(max(nbytes, 1)), C.c_uint(0)), "hipHostMalloc")
-        self.buf = (C.c_uint8 * max(nbytes, 1)).from_address(self.ptr.value)
-        self.buf._owner = self                          # the ctypes array is the base of every view: views keep the block
-
-    def __del__(self):
-        try:
-            if self.ptr:
-                runtime().hipHostFree(self.ptr)
-                self.ptr = C.c_void_p()
-        except Exception:
-            pass
+def _free_pinned(address):
+    try:
+        runtime().hipHostFree(C.c_void_p(address))
+    except Exception:
+        pass
 
 
 class PinnedArray:
     """A numpy array over page-locked host memory (hipHostMalloc): the destination of frame copies that are to run at the PCIe
     link's rate (a copy into pageable memory is staged through a bounce buffer and faults fresh pages in).  The memory belongs to
-    the array and its views: close() only drops this object's reference, and the block is released when the last view has gone
-    (an observation kept past close() used to point at freed memory: ADVICE r04)."""
+    the array and its views -- a finaliser on the ctypes buffer under them frees it when the last one has gone, by reference
+    counting alone (no owner <-> buffer cycle); close() only drops this object's reference (an observation kept past
+    close() used to point at freed memory: ADVICE r04)."""
 
     def __init__(self, shape, dtype="uint8"):
+        import weakref
         import numpy as np
-        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        block = _PinnedBlock(self.nbytes)
-        self.array = np.frombuffer(block.buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        count = int(np.prod(shape))
+        self.nbytes = count * np.dtype(dtype).itemsize
+        ptr = C.c_void_p()
+        check(runtime().hipHostMalloc(C.byref(ptr), C.c_size_t(max(self.nbytes, 1)), C.c_uint(0)), "hipHostMalloc")
+        buf = (C.c_uint8 * max(self.nbytes, 1)).from_address(ptr.value)
+        weakref.finalize(buf, _free_pinned, ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
     def close(self):
         self.array = None

@@ -466,6 +466,28 @@ class BatchIntervention:
         """:512-514"""
         return cls.tilepoint_to_worldpoint(tx, ty)
 
+    @staticmethod
+    def _counter_args(seed, draw, env_offset):
+        """The counter rule's three arguments travel as binary64 and are read as unsigned 32-bit integers on the device
+        (TbxEditArgs::getu saturates above that: every larger seed would name ONE stream, ADVICE r05).  A seed of any size -- the
+        64-bit hash_seed() of the gym layer, say -- is folded to 32 bits the way gym folds its own (sha-free: xor of the halves);
+        draw and env_offset are counters and must fit as they are."""
+        def fold(v):
+            v = int(v)
+            if v < 0:
+                raise ValueError("seed must be >= 0")
+            while v >> 32:
+                v = (v & 0xFFFFFFFF) ^ (v >> 32)
+            return v
+        seed = fold(seed) if np.ndim(seed) == 0 else np.asarray([fold(v) for v in np.asarray(seed).ravel()], np.float64)
+        out = [seed]
+        for name, v in (("draw", draw), ("env_offset", env_offset)):       # (one value for the batch, or one per env)
+            a = np.asarray(v)
+            if a.size and (a.min() < 0 or a.max() >= 1 << 32):
+                raise ValueError("%s must be in [0, 2**32)" % name)
+            out.append(int(v) if a.ndim == 0 else a)
+        return tuple(out)
+
     def get_random_tile(self, tags=lambda tag: True, seed=0, draw=0, env_offset=0, min_enemy_distance=0):
         """:360-378 with the counter rule instead of `random` (include/toybox_amd.h): draw number `draw` of env e picks element
         splitmix64(seed ^ (env_offset + e) << 32 ^ draw) mod len of the list filter_tiles(pred) would return for that env --
@@ -473,6 +495,7 @@ class BatchIntervention:
         pred: the tag is in `tags` and (min_enemy_distance > 0) set_player_random_start's within_min_manhattan.
         -> (tx int[N], ty int[N], tag object[N], candidates int[N]); -1 / None where an env has no candidate (the reference raises)."""
         self._need("amidar")
+        seed, draw, env_offset = self._counter_args(seed, draw, env_offset)
         r = self._reduce(_abi.QUERY_AMI_RANDOM_TILE, seed, draw, env_offset, self._tag_mask(tags), min_enemy_distance).astype(np.int64)
         return r[:, 0], r[:, 1], np.array([TILE_TAGS[v] if v >= 0 else None for v in r[:, 2]], dtype=object), r[:, 3]
 
@@ -487,12 +510,14 @@ class BatchIntervention:
         the reference draws it (its predicate does not ask for a walkable one), for which not every enemy is nearer than
         min_enemy_distance"""
         self._need("amidar")
+        seed, draw, env_offset = self._counter_args(seed, draw, env_offset)
         self._edit(_abi.EDIT_AMI_PLAYER_RANDOM_START, seed, draw, env_offset, min_enemy_distance, envs=envs)
 
     def get_random_dir_for_tile(self, tx, ty, seed=0, draw=0, env_offset=0):
         """:550-583 -> direction names, object array [N]: drawn (counter rule) among those of Up, Down, Left, Right whose neighbour
         tile is walkable; None where there is none (the reference raises)"""
         self._need("amidar")
+        seed, draw, env_offset = self._counter_args(seed, draw, env_offset)
         r = self._reduce(_abi.QUERY_AMI_RANDOM_DIR, seed, draw, env_offset, tx, ty).astype(np.int64)
         return np.array([DIRECTIONS[v] if v >= 0 else None for v in r[:, 0]], dtype=object)
 
