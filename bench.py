@@ -99,6 +99,12 @@ def parse():
                          "names one 64k-env batch on 1/2/4/8 GPUs; weak: --envs per GPU.  With N > 1 the other one is measured too")
     ap.add_argument("--loop", default="auto", choices=["auto", "fused", "pair"],
                     help="auto / fused: tbx_render_step_synthetic where the engine fuses (Breakout RGB / RGBA); pair: step ; render")
+    ap.add_argument("--fused-overlap", default="auto", choices=["auto", "on", "off"],
+                    help="TBX_OPT_FUSED_OVERLAP: consecutive fused launches on two lanes behind the device-side step ticket "
+                         "(auto = the engine's choice: up to 4 096 envs)")
+    ap.add_argument("--rollout-chunks", default="auto", choices=["auto", "on", "off"],
+                    help="TBX_OPT_ROLLOUT_CHUNKS: the fused loop as tbx_rollout_synthetic chunks of --gather-every steps (one step launch + "
+                         "k overlapped rasteriser launches); auto = the engine's choice: up to 4 096 envs")
     ap.add_argument("--gather-every", type=int, default=4,
                     help="K of the record ring (TBX_OPT_GATHER_EVERY): one RCCL all-gather per K steps (1 = every step)")
     ap.add_argument("--game", default="breakout")
@@ -257,7 +263,8 @@ class Region:
     def __init__(self, sync, rank_barrier, rank_max):
         self.sync, self.rank_barrier, self.rank_max = sync, rank_barrier, rank_max
 
-    def run(self, one_step, t0_index, K, R, on_region=None):
+    def run(self, one_step, t0_index, K, R, on_region=None, many=None):
+        """many(t, K): the K steps of a region as one call of the loop object (rollout chunks) instead of K calls of one_step"""
         times = []
         t = t0_index
         for _ in range(R):
@@ -265,8 +272,11 @@ class Region:
             if on_region is not None:
                 on_region()
             w0 = time.perf_counter()
-            for i in range(K):
-                one_step(t + i)
+            if many is not None:
+                many(t, K)
+            else:
+                for i in range(K):
+                    one_step(t + i)
             self.sync(); self.rank_barrier()
             times.append(self.rank_max(time.perf_counter() - w0))
             t += K
@@ -625,11 +635,24 @@ class Loop:
     SKIP = 2        # launches after a region's opening synchronisation that no event pair covers
 
     def __init__(self, eng, hip, stream, start, channels, gather, render, K, R, fused=False):
+        from toybox_amd import _abi
         self.eng, self.sp, self.start, self.C, self.gather, self.render = eng, stream.ptr, start, channels, gather, render
         self.fused = bool(fused and render)
+        # overlapped fused launches (TBX_OPT_FUSED_OVERLAP): the caller's stream joins lazily -- when an address is asked for.  A mark
+        # there is a join + a timing event + (next call) a fence for the lane: measured at 8 192 envs, a mark every 8 launches cost the
+        # loop 4-6 % (0.1715 against 0.1576 ms per step with the K = 4 ring) -- so an overlapped region is ONE span, two marks
+        self.overlapped = self.fused and eng.get_option(_abi.OPT_FUSED_OVERLAP_ACTIVE) == 1
+        self._frame_id = _abi.BUF_FRAME
         self.K = int(K)
         self.run = max(1, min(self.RUN, self.K - self.SKIP)) if self.K > 1 else 1
         self.skip = max(0, min(self.SKIP, self.K - self.run))
+        if self.overlapped and self.K > 1:
+            self.run = self.K - self.skip
+        # rollout chunks (tbx_rollout_synthetic / TBX_OPT_ROLLOUT_CHUNKS): the fused loop in chunks of `chunk_k` steps -- one step launch
+        # + chunk_k overlapped rasteriser launches per call, the ring's collective queued by the call itself.  Only when every phase of the
+        # loop is a whole number of chunks (a K-step ring cannot be left partly filled)
+        self.chunk_k = 0
+        self._rollout_ids = (_abi.BUF_ROLLOUT_FRAMES,)
         per_region = 0
         if render and K > 0:
             per_region = ((self.K - self.skip) // self.run + 1) if self.fused else 2 * ((self.K - self.skip + self.run - 1) // self.run)
@@ -654,6 +677,8 @@ class Loop:
             return None
         ev = self.pool[self.next_ev]
         self.next_ev += 1
+        if self.overlapped:
+            self.eng.device_buffer(self._frame_id)     # "where is the last frame": the stream now waits for the launch that wrote it
         ev.record(self.sp)
         return ev
 
@@ -685,6 +710,43 @@ class Loop:
                 self.spans.append((self.chain, b, self.run))
             self.chain = b
 
+    def use_chunks(self, k, phases):
+        """switch to the chunk form if the engine runs it overlapped and every phase length in `phases` is a multiple of k"""
+        from toybox_amd import _abi
+        if not self.fused or k < 2 or any(p % k for p in phases):
+            return False
+        if self.eng.get_option(_abi.OPT_ROLLOUT_CHUNKS_ACTIVE) != 1:
+            return False
+        if self.gather and self.eng.gather_every() != k:
+            return False
+        self.chunk_k = k
+        self.overlapped = True
+        return True
+
+    def many_steps(self, t, count):
+        """`count` steps in the chunk form (count is a multiple of chunk_k); one event span per armed region: behind the first chunk
+        to behind the last one"""
+        e, sp, k = self.eng, self.sp, self.chunk_k
+        first = None
+        for c in range(count // k):
+            e.rollout_synthetic(ACTION_SEED, t + c * k, k, channels=self.C, env_offset=self.start, auto_reset=True, stream=sp)
+            if self.armed and self.render and c == 0 and count > k:
+                e.device_buffer(self._rollout_ids[0])              # (lazy join: the stream now waits for this chunk's launches)
+                first = self._mark_raw()
+        if first is not None:
+            e.device_buffer(self._rollout_ids[0])
+            last = self._mark_raw()
+            if last is not None:
+                self.spans.append((first, last, count - k))
+
+    def _mark_raw(self):
+        if self.next_ev >= len(self.pool):
+            return None
+        ev = self.pool[self.next_ev]
+        self.next_ev += 1
+        ev.record(self.sp)
+        return ev
+
     def step_only(self, t):
         self.eng.step_synthetic(ACTION_SEED, t, env_offset=self.start, auto_reset=True, stream=self.sp)
         if self.gather:
@@ -713,20 +775,29 @@ def timed_arm(eng, hip, reg, stream, start, C, gather, render, pipeline, t, K, W
     to the untimed pre-roll, like the 1 000 frames before them; the W warm-up steps and the K timed steps are the caller's."""
     from toybox_amd import _abi
     eng.set_option(_abi.OPT_PIPELINE, 0 if fused else pipeline)
+    eng.set_option(_abi.OPT_FUSED_OVERLAP, {"auto": _abi.FUSED_OVERLAP_AUTO, "on": _abi.FUSED_OVERLAP_ON, "off": _abi.FUSED_OVERLAP_OFF}[FUSED_OVERLAP])
     mode = eng.get_option(_abi.OPT_PIPELINE_ACTIVE)
+    eng.set_option(_abi.OPT_ROLLOUT_CHUNKS, {"auto": _abi.ROLLOUT_CHUNKS_AUTO, "on": _abi.ROLLOUT_CHUNKS_ON, "off": _abi.ROLLOUT_CHUNKS_OFF}[ROLLOUT_CHUNKS])
     loop = Loop(eng, hip, stream, start, C, gather, render, K, R, fused=fused)
-    for _ in range(SETTLE + Wm):
-        loop.full_step(t)
-        t += 1
+    chunked = loop.use_chunks(CHUNK_K, (SETTLE + Wm, K))
+    if chunked:
+        loop.many_steps(t, SETTLE + Wm)
+        t += SETTLE + Wm
+    else:
+        for _ in range(SETTLE + Wm):
+            loop.full_step(t)
+            t += 1
     hip.synchronize()
     loop.arm()
-    times, t = reg.run(loop.full_step, t, K, R, on_region=loop.begin_region)
+    times, t = reg.run(loop.full_step, t, K, R, on_region=loop.begin_region, many=loop.many_steps if chunked else None)
     per, covered = loop.launch_ms()
     launch = None
     if per:
         launch = {"avg_ms": float(np.mean(per)), "median_ms": float(np.median(per)), "min_ms": float(min(per)), "max_ms": float(max(per)),
                   "spans": len(per), "launches": covered, "launches_per_span": loop.run if loop.fused else 1,
-                  "skipped_after_sync": loop.skip}
+                  "skipped_after_sync": loop.skip, "overlapped": loop.overlapped, "chunk_k": loop.chunk_k}
+    LAST_LOOP_FORM["chunk_k"] = loop.chunk_k
+    LAST_LOOP_FORM["overlapped"] = loop.overlapped
     loop.close()
     return summarize(times, K), launch, mode, t
 
@@ -749,6 +820,21 @@ FUSED_NOTE = ("tbx_render_step_synthetic: the rasteriser of frame t and the batc
 
 
 GATHER_TRANSPORT = "rccl"      # --gather
+FUSED_OVERLAP = "auto"         # --fused-overlap
+ROLLOUT_CHUNKS = "auto"        # --rollout-chunks
+CHUNK_K = 4                    # --gather-every: the ring depth is the chunk length
+LAST_LOOP_FORM = {"chunk_k": 0, "overlapped": False}    # what timed_arm's loop resolved to (read right after the call)
+CHUNK_NOTE = ("tbx_rollout_synthetic: the fused loop in chunks of %d steps -- per chunk ONE step launch on an internal stream (every env %d "
+              "frames with its state in registers: %d render records, the %d step records straight into the record ring, the state once) and "
+              "%d plain rasteriser launches alternating between two more internal streams, dependent on that step launch alone; the next chunk's "
+              "step launch runs beside this chunk's rasterisers and the ring's collective waits for the step launch only (TBX_OPT_ROLLOUT_CHUNKS; "
+              "the engine's choice up to 4 096 envs).  avg_launch_ms: the time from one rasteriser launch's end to the next one's -- what a "
+              "frame costs in steady state -- not a kernel's own duration")
+OVERLAP_NOTE = ("consecutive fused launches alternate between two internal streams, output sets and frame buffers; launch N+1 is ordered "
+                "behind the STEP BLOCKS of launch N only (a device-side counter they bump once their agent-scope stores are out, awaited by "
+                "a one-wave kernel in front of launch N+1), so it ramps up while launch N still paints (TBX_OPT_FUSED_OVERLAP; the engine's "
+                "choice up to 4 096 envs).  avg_launch_ms in this mode is the time from one launch's end to the next one's end -- what a "
+                "launch costs in steady state -- not a kernel's own duration")
 
 
 def make_communicator(eng, rank, world, width, gather_every, tag, transport=None):
@@ -874,7 +960,8 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
     fused = render and args.loop != "pair" and C >= 3 and eng.get_option(_abi.OPT_RENDER_STEP_FUSED) == 1
     rep, launch, mode, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, args.pipeline, t, K, Wm, R, fused=fused)
     res = {"n": n, "n_total": n_total, "start": start, "H": H, "W": W, "C": C, "render": render, "gather": gather, "rccl": rccl,
-           "gather_note": gather_note, "rep": rep, "launch": launch, "mode": mode, "fused": fused, "steps": K, "extras": {}}
+           "gather_note": gather_note, "rep": rep, "launch": launch, "mode": mode, "fused": fused, "steps": K, "extras": {},
+           "overlapped": LAST_LOOP_FORM["overlapped"], "chunk_k": LAST_LOOP_FORM["chunk_k"]}
     frame_bytes = H * W * C if render else 0
     if with_extras and "serialised" in extras and (fused or mode != 0):
         # the same engine, two launches per frame in stream order: what a policy-driven loop (actions computed from the frame) gets
@@ -907,13 +994,16 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
 
 
 def main():
-    global SETTLE, GATHER_TRANSPORT
+    global SETTLE, GATHER_TRANSPORT, FUSED_OVERLAP, ROLLOUT_CHUNKS, CHUNK_K
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails with "invalid argument" under the
     # legacy mode); the GPU boxes export it already -- set before anything loads the HIP runtime, for launchers that do not
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse()
     SETTLE = max(0, args.settle)
     GATHER_TRANSPORT = args.gather
+    FUSED_OVERLAP = args.fused_overlap
+    ROLLOUT_CHUNKS = args.rollout_chunks
+    CHUNK_K = max(1, args.gather_every)
     if args.protocol == "reference":
         return bench_reference_protocol(args)
     if args.protocol == "agent":
@@ -994,7 +1084,10 @@ def main():
                                if gather else ("env-sharded x%d, no collective (%s)" % (world, r["gather_note"])) if r["gather_note"] else "single GPU",
                 "algorithmic_bytes_per_env_step": bytes_per_step,
             },
-            "loop": {"form": "fused" if fused else "pair", "what": FUSED_NOTE if fused else "tbx_step_synthetic ; tbx_render_device, two launches per frame"},
+            "loop": {"form": "fused" if fused else "pair", "what": FUSED_NOTE if fused else "tbx_step_synthetic ; tbx_render_device, two launches per frame",
+                     "overlapped": r["overlapped"], "chunk_k": r["chunk_k"],
+                     "overlap": (CHUNK_NOTE % ((r["chunk_k"],) * 5)) if r["chunk_k"] else OVERLAP_NOTE if r["overlapped"] else
+                     ("stream order (--fused-overlap %s; the engine overlaps consecutive fused launches / runs rollout chunks up to 4 096 envs -- see configs)" % FUSED_OVERLAP if fused else None)},
             "pipeline": {"option": args.pipeline, "resolved": mode, "what": PIPELINE_NOTE.get(mode),
                          "applies_to": "the two-launch loop form only; see `serialised`"},
             "rccl": r["rccl"] if (r["rccl"] or {}).get("transport") == "rccl" else None,
@@ -1143,11 +1236,15 @@ def baseline_configs(args, hip):
         fb = r["H"] * r["W"] * r["C"]
         e = {"value": r["n"] / (ms * 1e-3), "unit": "env-steps/s", "ms_per_step": ms, "steps": a.steps, "repeats": r["rep"]["n"],
              "ms_per_step_min_max": [r["rep"]["ms_per_step_min"], r["rep"]["ms_per_step_max"]],
-             "loop": "fused" if r["fused"] else "pair", "pipeline_resolved": r["mode"],
+             "loop": (("fused, rollout chunks of %d" % r["chunk_k"]) if r["chunk_k"] else "fused, overlapped launches" if r["overlapped"] else "fused") if r["fused"] else "pair",
+             "pipeline_resolved": r["mode"],
              "whole_step_frac": r["n"] * fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-             # (overlapped launches, TBX_OPT_PIPELINE 3: an event pair on the caller's stream does not bracket a kernel)
+             # (overlapped launches -- TBX_OPT_PIPELINE 3, TBX_OPT_FUSED_OVERLAP: an event pair on the caller's stream does not bracket a
+             # kernel; with fused overlap it is the steady-state period of a launch, printed as such)
              "kernel_frac": (r["n"] * fb / (r["launch"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if r["launch"] and r["mode"] == 0 else None,
-             "avg_launch_ms": r["launch"]["avg_ms"] if r["launch"] and r["mode"] == 0 else None, "frame_hwc": [r["H"], r["W"], r["C"]]}
+             "avg_launch_ms": r["launch"]["avg_ms"] if r["launch"] and r["mode"] == 0 else None,
+             "launch_timing": "end-to-end period of overlapped launches" if r["overlapped"] else "events around launches in stream order",
+             "frame_hwc": [r["H"], r["W"], r["C"]]}
         sr = r["extras"].get("serialised")
         e["serialised"] = ({"value": sr["value"], "ms_per_step": sr["ms_per_step"], "whole_step_frac": sr["whole_step_frac"],
                             "kernel_frac": sr["roofline_frac"]} if sr else "= value (the main arm is the two-launch loop in stream order)")
@@ -1190,7 +1287,9 @@ def strong_share_probe(args, game, C, n_single, single_value, single_pair_value)
         fused = want_fused and C >= 3 and eng.get_option(_abi.OPT_RENDER_STEP_FUSED) == 1
         rep, launch, mode, _ = timed_arm(eng, hip, reg, st, 0, C, True, True, args.pipeline, args.preroll, K, 20, 5, fused=fused)
         v = n / (rep["ms_per_step_median"] * 1e-3)
-        res[key] = {"value": v, "ms_per_step": rep["ms_per_step_median"], "repeats": rep, "loop": "fused" if fused else "pair",
+        res[key] = {"value": v, "ms_per_step": rep["ms_per_step_median"], "repeats": rep,
+                    "loop": (("fused, rollout chunks of %d" % LAST_LOOP_FORM["chunk_k"]) if LAST_LOOP_FORM["chunk_k"] else
+                             "fused, overlapped launches" if LAST_LOOP_FORM["overlapped"] else "fused") if fused else "pair",
                     "gather_every": eng.gather_every(), "pipeline_resolved": mode, "avg_launch_ms": launch["avg_ms"] if launch else None,
                     "share_of_linear": v / (single_value if key == "main" else single_pair_value),
                     "share_of": "value" if key == "main" else "serialised (the two-launch loop on the whole batch)"}

@@ -423,6 +423,30 @@ int tbx_render_device(tbx_engine* engine, uint8_t* out_dev, int channels, void* 
  * a policy-driven loop calls tbx_step_device and tbx_render_device.  Everywhere else it is the two launches in stream order. */
 int tbx_render_step_synthetic(tbx_engine* engine, uint8_t* out_dev, int channels, uint64_t action_seed, uint64_t t,
                               uint64_t env_offset, uint32_t flags, void* stream);
+/* A rollout CHUNK: k consecutive tbx_render_step_synthetic calls (t = t0 .. t0 + k - 1; with a K-step record ring each followed by
+ * tbx_gather) as one call -- what the reference's learners consume is a K-step rollout anyway (A2C nsteps = 5, PPO2 128:
+ * baselines/baselines/a2c/runner.py:16, ppo2/ppo2.py:103).  Results bit for bit those of the k single calls:
+ *   TBX_BUF_ROLLOUT_FRAMES  uint8[k][N][H][W][channels]: frame j shows the state BEFORE step t0 + j;
+ *   TBX_BUF_ROLLOUT_PACKED  uint64[k][stride] step records (reward, done, lives) of step j in row j -- with a K-step record ring
+ *                           in force (TBX_OPT_GATHER_EVERY = K; k must equal K and the ring must be empty) the rows ARE the ring
+ *                           (stride = records_per_rank) and the call queues the collective itself: no tbx_gather for these steps;
+ *                           otherwise an engine-owned array with stride = N;
+ *   TBX_BUF_REWARD / DONE / LIVES / SCORE / PACKED and the state: those of the chunk's LAST step; TBX_BUF_FRAME: its last frame.
+ * Where the rasteriser reads step-written records (Breakout, canonical wall, RGB / RGBA; TBX_OPT_ROLLOUT_CHUNKS) a chunk is ONE step
+ * launch on an internal stream -- every env k frames with its state in registers, writing k render records, the k step records and
+ * the state once -- and k plain rasteriser launches that alternate between two more internal streams and depend on that step
+ * launch alone: consecutive rasteriser launches overlap freely, the next chunk's step launch runs beside this chunk's
+ * rasterisers (a whole chunk ahead of its own), and with a ring the collective waits for the step launch only.  That is what N
+ * worker processes stepping independently of each other give the reference (baselines/baselines/common/vec_env/subproc_vec_env.py:49-74),
+ * and what the per-GPU share of a strong-scaled batch (8 192 envs) loses to ramp-up and tail between launches in stream order.
+ * Contract in that form: as for overlapped fused launches (TBX_OPT_FUSED_OVERLAP) -- two chunk buffers alternate; ask
+ * tbx_device_buffer after the call for what is to be read, and it is that call which makes `stream` wait for the chunk (lazy
+ * join); results stay valid for readers queued on `stream` before the next chunk.  Everywhere else (other games, gray frames,
+ * one collective per step, the option off) the call is the k single calls in stream order. */
+int tbx_rollout_synthetic(tbx_engine* engine, int channels, uint64_t action_seed, uint64_t t0, int k, uint64_t env_offset,
+                          uint32_t flags, void* stream);
+#define TBX_BUF_ROLLOUT_FRAMES 15
+#define TBX_BUF_ROLLOUT_PACKED 16
 /* Rasterise one env (host pointer, synchronous). */
 int tbx_render_env(tbx_engine* engine, int env, uint8_t* out_host, int channels);
 
@@ -780,9 +804,12 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  *   processes stepping independently of each other give the reference (baselines/baselines/common/vec_env/subproc_vec_env.py:49-74),
  *   and what the per-GPU share of a strong-scaled batch (8 192 envs) loses between launches in stream order.  It works with the
  *   record gather in both forms (one collective per step: the collective of step N then runs beside launch N+1; K-step ring).
- *   Contract as in the pipelined mode: the stream the call names waits for the call's work; results of call N stay valid for
- *   readers queued on that stream before call N+1; TBX_BUF_FRAME / TBX_BUF_REWARD ... alternate between two addresses -- ask
- *   tbx_device_buffer after every call.  A call with out_dev != NULL, or any other call on the handle, first joins. */
+ *   Contract: TBX_BUF_FRAME / TBX_BUF_REWARD ... alternate between two addresses -- ask tbx_device_buffer after every call whose
+ *   results are to be read -- and it is THAT call which makes the stream the step call named wait for the launch that wrote
+ *   them (the stream joins lazily: a loop that only rolls, or whose only consumer is the record gather, queues nothing on the
+ *   caller's stream -- with a gather on the device a wait and a fence per call there cost more than the overlap gains).  The
+ *   results of call N stay valid for readers queued on that stream after tbx_device_buffer and before call N+1.  A call with
+ *   out_dev != NULL, or any other call on the handle, first joins everything (program order holds as everywhere). */
 #define TBX_OPT_FUSED_OVERLAP 7
 /* How early an overlapped launch is released, in blocks of the launch before it: launch N+1 starts once the step blocks of
  * launch N are through AND the block `lead` blocks before the end of launch N's grid has STARTED (blocks start in index order:
@@ -790,7 +817,10 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  * as soon as the step blocks are through (both launches then run side by side for most of their length -- measured slower,
  * profiles/r06_experiments.txt). */
 #define TBX_OPT_FUSED_OVERLAP_LEAD 8
-#define TBX_OPT_COUNT         9
+/* tbx_rollout_synthetic as ONE step launch + k overlapped rasteriser launches per chunk (see there): 0 (default) = the engine's
+ * choice by batch size, 1 = wherever the engine can, 2 = never (the k single calls in stream order) */
+#define TBX_OPT_ROLLOUT_CHUNKS 9
+#define TBX_OPT_COUNT         10
 /* read-only (tbx_get_option): what TBX_OPT_PIPELINE resolves to on this engine right now -- 0, 2 or 3 */
 #define TBX_OPT_PIPELINE_ACTIVE 100
 /* read-only: 1 while the rasteriser reads step-written render records (Breakout with the canonical wall, SpaceInvaders with
@@ -803,6 +833,8 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
 /* read-only: 1 if tbx_render_step_synthetic(out_dev = NULL, channels = 3) would be an overlapped launch right now
  * (TBX_OPT_FUSED_OVERLAP resolved), 0 if it runs in stream order */
 #define TBX_OPT_FUSED_OVERLAP_ACTIVE 103
+/* read-only: 1 if tbx_rollout_synthetic(channels = 3) would run as overlapped chunks right now, 0 if as single calls */
+#define TBX_OPT_ROLLOUT_CHUNKS_ACTIVE 104
 int tbx_set_option(tbx_engine* engine, int option, int value);
 int tbx_get_option(tbx_engine* engine, int option, int* value_out);
 /* Block until all work queued by this engine has finished; reports a pending TBX_E_ACTION. */

@@ -60,6 +60,12 @@ struct tbx_engine {
     int pending_needs_reset;
     int opt[TBX_OPT_COUNT];
     uint8_t* one_frame;     /* tbx_step1_frame's buffer */
+    /* tbx_rollout_synthetic: the chunk's frames [k][n][H][W][C] and, without a record ring, its step records [k][n] */
+    uint8_t* chunk_frames;
+    size_t chunk_frame_bytes;
+    uint64_t *chunk_packed, *chunk_packed_base;
+    size_t chunk_packed_records, chunk_stride;
+    int chunk_k, chunk_channels;
 };
 
 static char g_err[256];
@@ -105,7 +111,7 @@ int tbx_destroy(tbx_engine* e)
     if (!e) return TBX_OK;
     free(e->cfg); free(e->states); free(e->sim); free(e->prev); free(e->reward); free(e->lives);
     gather_close(e);                       /* (puts e->packed back onto the engine's own array) */
-    free(e->score); free(e->done); free(e->packed); free(e->frame); free(e->one_frame);
+    free(e->score); free(e->done); free(e->packed); free(e->frame); free(e->one_frame); free(e->chunk_frames); free(e->chunk_packed);
     agent_free(e);
     free(e);
     return TBX_OK;
@@ -360,6 +366,54 @@ int tbx_render_step_synthetic(tbx_engine* e, uint8_t* out, int channels, uint64_
     return tbx_step_synthetic(e, seed, t, env_offset, flags, stream);
 }
 
+/* A rollout chunk = the k single calls, one after the other (include/toybox_amd.h): frame j into row j of the chunk buffer; the
+ * step records into the ring (K-step ring: tbx_gather after every step, the k-th one exchanges it) or copied out row by row. */
+int tbx_rollout_synthetic(tbx_engine* e, int channels, uint64_t seed, uint64_t t0, int k, uint64_t env_offset, uint32_t flags, void* stream)
+{
+    if (!e) return TBX_E_INVALID;
+    if (channels != 1 && channels != 3 && channels != 4) return fail(e, TBX_E_INVALID, "channels must be 1, 3 or 4");
+    if (k < 1 || k > 64) return fail(e, TBX_E_INVALID, "tbx_rollout_synthetic: k must be in 1 .. 64");
+    const int ring = e->gather_on && e->gather_every > 1;
+    if (ring && e->gather_every != k)
+        return fail(e, TBX_E_INVALID, "tbx_rollout_synthetic: the chunk must be as long as the gather's record ring (TBX_OPT_GATHER_EVERY)");
+    if (ring && e->gather_fill != 0)
+        return fail(e, TBX_E_INVALID, "tbx_rollout_synthetic: the record ring is partly filled (finish it with single steps + tbx_gather)");
+    int h = 0, w = 0;
+    tbx_frame_dims(e->game, &h, &w);
+    const size_t n = (size_t)e->n, fb = n * (size_t)h * (size_t)w * (size_t)channels;
+    if (e->chunk_frame_bytes < fb * (size_t)k) {
+        free(e->chunk_frames);
+        e->chunk_frames = (uint8_t*)malloc(fb * (size_t)k);
+        e->chunk_frame_bytes = fb * (size_t)k;
+    }
+    if (!ring && e->chunk_packed_records < n * (size_t)k) {
+        free(e->chunk_packed);
+        e->chunk_packed = (uint64_t*)calloc(n * (size_t)k, 8);
+        e->chunk_packed_records = n * (size_t)k;
+    }
+    uint64_t* ring_base = NULL;
+    for (int j = 0; j < k; j++) {
+        int rc = tbx_render_step_synthetic(e, e->chunk_frames + fb * (size_t)j, channels, seed, t0 + (uint64_t)j, env_offset, flags, stream);
+        if (rc) return rc;
+        if (ring && j == 0) ring_base = e->packed;
+        if (!ring) memcpy(e->chunk_packed + n * (size_t)j, e->packed, n * 8);
+        if (e->gather_on) {
+            rc = tbx_gather(e, NULL, stream);
+            if (rc) return rc;
+        }
+    }
+    e->chunk_k = k; e->chunk_channels = channels;
+    e->chunk_packed_base = ring ? ring_base : e->chunk_packed;
+    e->chunk_stride = ring ? (size_t)e->gather_width : n;
+    /* TBX_BUF_FRAME: the chunk's last frame, as after the k-th single call into a caller's buffer it is whatever it was -- the HIP
+     * library names the last frame of the chunk; so does this one */
+    free(e->frame);
+    e->frame = (uint8_t*)malloc(fb);
+    memcpy(e->frame, e->chunk_frames + fb * (size_t)(k - 1), fb);
+    e->frame_bytes = fb;
+    return TBX_OK;
+}
+
 int tbx_render(tbx_engine* e, uint8_t* out, int channels)
 {
     if (!e) return TBX_E_INVALID;
@@ -577,6 +631,14 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     case TBX_BUF_SCORE: p = e->score; b = n * 4; break;
     case TBX_BUF_FRAME: p = e->frame; b = e->frame_bytes; break;
     case TBX_BUF_PACKED: p = e->packed; b = n * 8; break;
+    case TBX_BUF_ROLLOUT_FRAMES:
+        if (!e->chunk_k) return fail(e, TBX_E_INVALID, "tbx_rollout_synthetic has not been called");
+        { int hh = 0, ww = 0; tbx_frame_dims(e->game, &hh, &ww); p = e->chunk_frames; b = (size_t)e->chunk_k * n * hh * ww * e->chunk_channels; }
+        break;
+    case TBX_BUF_ROLLOUT_PACKED:
+        if (!e->chunk_k) return fail(e, TBX_E_INVALID, "tbx_rollout_synthetic has not been called");
+        p = e->chunk_packed_base; b = 8 * (size_t)e->chunk_k * e->chunk_stride;
+        break;
     case TBX_BUF_AGENT_OBS: case TBX_BUF_AGENT_REWARD: case TBX_BUF_AGENT_DONE:
     case TBX_BUF_AGENT_EP_DONE: case TBX_BUF_AGENT_EP_RETURN: case TBX_BUF_AGENT_EP_LENGTH: case TBX_BUF_AGENT_PLANE:
     case TBX_BUF_AGENT_RING:
@@ -1105,7 +1167,7 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout)
 /* launch-time choices of the device engine: stored and reported, without effect on a scalar CPU restatement */
 int tbx_set_option(tbx_engine* e, int option, int value)
 {
-    static const int hi[TBX_OPT_COUNT] = {3, 2, 64, 1, 1, 64, 1, 2, 1 << 20};
+    static const int hi[TBX_OPT_COUNT] = {3, 2, 64, 1, 1, 64, 1, 2, 1 << 20, 2};
     if (!e) return TBX_E_INVALID;
     if (option < 0 || option >= TBX_OPT_COUNT) return fail(e, TBX_E_INVALID, "unknown option");
     if (value < (option == TBX_OPT_GATHER_EVERY ? 1 : 0) || value > hi[option]) return fail(e, TBX_E_INVALID, "option value out of range");
@@ -1116,7 +1178,7 @@ int tbx_set_option(tbx_engine* e, int option, int value)
 int tbx_get_option(tbx_engine* e, int option, int* value_out)
 {
     if (!e) return TBX_E_INVALID;
-    if (value_out && (option == TBX_OPT_PIPELINE_ACTIVE || option == TBX_OPT_RECORDS_ACTIVE || option == TBX_OPT_RENDER_STEP_FUSED || option == TBX_OPT_FUSED_OVERLAP_ACTIVE)) { *value_out = 0; return TBX_OK; }   /* nothing to overlap on one CPU thread */
+    if (value_out && (option == TBX_OPT_PIPELINE_ACTIVE || option == TBX_OPT_RECORDS_ACTIVE || option == TBX_OPT_RENDER_STEP_FUSED || option == TBX_OPT_FUSED_OVERLAP_ACTIVE || option == TBX_OPT_ROLLOUT_CHUNKS_ACTIVE)) { *value_out = 0; return TBX_OK; }   /* nothing to overlap on one CPU thread */
     if (option < 0 || option >= TBX_OPT_COUNT || !value_out) return fail(e, TBX_E_INVALID, "unknown option");
     *value_out = e->opt[option];
     return TBX_OK;

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from toybox_amd import Engine, _abi, hip  # noqa: E402
 
-lib = _abi.bind(ctypes.CDLL(os.path.join(ROOT, "scripts", "ab", "lib_diag.so")))
+lib = None if os.environ.get("OD_LIB") == "product" else _abi.bind(ctypes.CDLL(os.path.join(ROOT, "scripts", "ab", "lib_diag.so")))
 sizes = [int(v) for v in sys.argv[1:]] or [8192, 65536]
 rounds = int(os.environ.get("OD_ROUNDS", "3"))
 masks = [int(v) for v in os.environ.get("OD_MASKS", "0,8,10,9,12,24,40,72,136,255,2,1,16,32,3,19").split(",")]
@@ -44,7 +44,7 @@ for n in sizes:
                 hip.synchronize()
             out.setdefault(label, []).append(1000.0 * (time.perf_counter() - w0) / K)
     base = sorted(out["order"])[len(out["order"]) // 2]
-    print(json.dumps({"envs": n, "steps": K, "gather": G, "lane_priority": os.environ.get("TBX_LANE_PRIORITY", "high"), **{k: [round(sorted(v)[len(v) // 2], 4), round(sorted(v)[len(v) // 2] / base - 1.0, 4)] for k, v in out.items()}}), flush=True)
+    print(json.dumps({"lib": os.environ.get("OD_LIB", "diag"), "envs": n, "steps": K, "gather": G, "lane_priority": os.environ.get("TBX_LANE_PRIORITY", "high"), **{k: [round(sorted(v)[len(v) // 2], 4), round(sorted(v)[len(v) // 2] / base - 1.0, 4)] for k, v in out.items()}}), flush=True)
     try:
         e.sync()
     except Exception as ex:

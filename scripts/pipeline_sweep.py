@@ -18,7 +18,7 @@ modes = [int(v) for v in os.environ.get("PS_MODES", "0,2,3").split(",")]
 lib = None
 if os.environ.get("PS_LIB"):                       # another build of the library (A/B in one call)
     import ctypes
-    lib = _abi.bind(ctypes.CDLL(os.path.abspath(os.environ["PS_LIB"])))
+    lib = _abi.bind(ctypes.CDLL(os.path.abspath(os.environ["PS_LIB"])), older_build=True)
 res = {}
 for n in sizes:
     K = int(os.environ.get("PS_STEPS", "0")) or max(200, min(2000, 200 * 65536 // n // 4))

@@ -17,7 +17,7 @@ rounds, ring = int(os.environ.get("SS_ROUNDS", "4")), int(os.environ.get("SS_RIN
 LIB = None
 if os.environ.get("SS_LIB"):                       # another build of the library (A/B in one call: run the script twice on one box)
     import ctypes
-    LIB = _abi.bind(ctypes.CDLL(os.path.abspath(os.environ["SS_LIB"])))
+    LIB = _abi.bind(ctypes.CDLL(os.path.abspath(os.environ["SS_LIB"])), older_build=True)
 for n in sizes:
     K = int(os.environ.get("SS_STEPS", "0")) or max(200, min(2000, 200 * 65536 // n // 4))
     engines = {}

@@ -286,7 +286,8 @@ def test_mixed_batch_config5_share_on_three_streams(hip_lib, oracle_lib):
 
 
 ALL_BUFS = ["BUF_REWARD", "BUF_DONE", "BUF_LIVES", "BUF_SCORE", "BUF_FRAME", "BUF_PACKED", "BUF_AGENT_OBS", "BUF_AGENT_REWARD",
-            "BUF_AGENT_DONE", "BUF_AGENT_EP_DONE", "BUF_AGENT_EP_RETURN", "BUF_AGENT_EP_LENGTH", "BUF_GATHERED", "BUF_AGENT_PLANE", "BUF_AGENT_RING"]
+            "BUF_AGENT_DONE", "BUF_AGENT_EP_DONE", "BUF_AGENT_EP_RETURN", "BUF_AGENT_EP_LENGTH", "BUF_GATHERED", "BUF_AGENT_PLANE", "BUF_AGENT_RING",
+            "BUF_ROLLOUT_FRAMES", "BUF_ROLLOUT_PACKED"]
 
 
 @pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
@@ -309,11 +310,11 @@ def test_every_device_buffer_id(lib):
     n = 5
     e = Engine("breakout", n, lib=lib)
     for name in ALL_BUFS:
-        if "AGENT" in name or name == "BUF_GATHERED":
+        if "AGENT" in name or "ROLLOUT" in name or name == "BUF_GATHERED":
             with pytest.raises(ToyboxAmdError) as ei:
                 e.device_buffer(declared[name])
             assert ei.value.code == _abi.E_INVALID, name
-    for bad in (-1, 15, 99):
+    for bad in (-1, 17, 99):
         with pytest.raises(ToyboxAmdError) as ei:
             e.device_buffer(bad)
         assert ei.value.code == _abi.E_INVALID
@@ -328,7 +329,9 @@ def test_every_device_buffer_id(lib):
     e.agent_reset()
     e.agent_step([1] * n)
     e.gather_init(1, 0, e.gather_unique_id(), records_per_rank=n + 3)
-    want = {"BUF_GATHERED": 8 * (n + 3),"BUF_REWARD": 4 * n, "BUF_DONE": n, "BUF_LIVES": 4 * n, "BUF_SCORE": 4 * n, "BUF_FRAME": n * 160 * 240 * 3,
+    e.rollout_synthetic(7, 0, 2, channels=3)                 # (a collective per step: the two single calls; rows of N records)
+    e.sync()
+    want = {"BUF_ROLLOUT_FRAMES": 2 * n * 160 * 240 * 3, "BUF_ROLLOUT_PACKED": 2 * 8 * n, "BUF_GATHERED": 8 * (n + 3),"BUF_REWARD": 4 * n, "BUF_DONE": n, "BUF_LIVES": 4 * n, "BUF_SCORE": 4 * n, "BUF_FRAME": n * 160 * 240 * 3,
             "BUF_PACKED": 8 * n, "BUF_AGENT_OBS": n * 42 * 60 * 3, "BUF_AGENT_REWARD": 4 * n, "BUF_AGENT_DONE": n,
             "BUF_AGENT_EP_DONE": n, "BUF_AGENT_EP_RETURN": 4 * n, "BUF_AGENT_EP_LENGTH": 4 * n, "BUF_AGENT_PLANE": n * 42 * 60}
     seen = set()
@@ -340,8 +343,9 @@ def test_every_device_buffer_id(lib):
             continue
         p, b = e.device_buffer(declared[name])
         assert p and b == want[name], (name, p, b)
-        seen.add(p)
-    assert len(seen) == len(ALL_BUFS) - 1, "two buffer ids share an address"
+        if name != "BUF_FRAME":                              # (after a chunk TBX_BUF_FRAME may name the chunk's last frame)
+            seen.add(p)
+    assert len(seen) == len(ALL_BUFS) - 2, "two buffer ids share an address"
     e.agent_init(skip=2, out_h=42, out_w=60, stack=3, new_plane=2)
     e.agent_reset()
     p, b = e.device_buffer(_abi.BUF_AGENT_RING)
@@ -799,7 +803,7 @@ def test_render_step_synthetic_call_contract(game, lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("game,n,channels,overlap", [("breakout", 20000, 3, 2), ("breakout", 20000, 3, 1), ("breakout", 8192, 4, 0), ("breakout", 8192, 4, 2),
+@pytest.mark.parametrize("game,n,channels,overlap", [("breakout", 20000, 3, 2), ("breakout", 20000, 3, 1), ("breakout", 4096, 4, 0), ("breakout", 8192, 4, 2),
                                                      ("breakout", 300, 3, 1), ("breakout", 300, 3, 2), ("breakout", 5000, 1, 1),
                                                      ("space_invaders", 3000, 3, 0), ("space_invaders", 1500, 4, 1), ("space_invaders", 9000, 3, 0),
                                                      ("space_invaders", 17000, 3, 0), ("amidar", 2000, 3, 1), ("gridworld", 1000, 3, 0)])
@@ -817,7 +821,7 @@ def test_render_step_synthetic_equals_render_then_step(game, n, channels, overla
     g.set_option(_abi.OPT_FUSED_OVERLAP, overlap)
     fused = game == "breakout" and channels >= 3
     if channels >= 3:                                       # (the read-only option answers for RGB / RGBA frames)
-        assert g.get_option(_abi.OPT_FUSED_OVERLAP_ACTIVE) == (1 if fused and (overlap == 1 or (overlap == 0 and n <= 16384)) else 0)
+        assert g.get_option(_abi.OPT_FUSED_OVERLAP_ACTIVE) == (1 if fused and (overlap == 1 or (overlap == 0 and n <= 4096)) else 0)
     H, W = g.height, g.width
     fb = H * W * channels
     sample = sorted({0, 1, 255, 256, n // 2, n - 1} & set(range(n)))
@@ -955,6 +959,162 @@ def test_fused_overlap_outputs_frames_and_gather(n, channels, K, hip_lib, oracle
             hip.memcpy_dtoh(one, hold_f + fb * (len(sample) * t + k), fb)
             assert np.array_equal(one, want_f[t][k]), (t, i)
     for p in (hold_o, hold_f, side):
+        hip.free(p)
+    _same_states(g, o, sample + list(range(0, n, max(1, n // 40))), "end")
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("game", GAMES)
+def test_rollout_synthetic_call_contract(game, lib):
+    """tbx_rollout_synthetic(k) == k x (tbx_render_device ; tbx_step_synthetic) on either library: the chunk's frames (frame j = the
+    state BEFORE step t0 + j), its step records, the last step's outputs, TBX_BUF_FRAME = the last frame, the state -- with calls of
+    other kinds between chunks (a host step, a state write, new games, a single fused call, the option switched off and on)."""
+    from support import read_buffer
+    n, k = 9, 3
+    a, b = Engine(game, n, lib=lib), Engine(game, n, lib=lib)
+    for e in (a, b):
+        e.seed(11)
+        e.new_game()
+    a.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_ON)
+    H, W = a.height, a.width
+    t = 0
+    for c in range(9):
+        if c == 3:
+            act = synthetic_actions(game, n, 500, seed=3)
+            for x, y in zip(a.step(act, auto_reset=True), b.step(act, auto_reset=True)):
+                assert np.array_equal(x, y)
+        if c == 4:
+            for e in (a, b):
+                st = e.get_state(2)
+                e.set_state(5, st)
+                e.new_game((np.arange(n) % 4 == 0).astype(np.uint8))
+        if c == 5:
+            a.render_step_synthetic(1337, t, channels=3, auto_reset=True)
+            b.render_device(0, 3); b.step_synthetic(1337, t, auto_reset=True)
+            t += 1
+        if c == 6:
+            a.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_OFF)
+        if c == 7:
+            a.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_AUTO)
+        a.rollout_synthetic(1337, t, k, channels=3, auto_reset=True)
+        frames = read_buffer(a, _abi.BUF_ROLLOUT_FRAMES, (k, n, H, W, 3))
+        packed = read_buffer(a, _abi.BUF_ROLLOUT_PACKED, (k, n), np.uint64)
+        for j in range(k):
+            assert np.array_equal(frames[j], b.render(3)), (game, c, j)
+            b.step_synthetic(1337, t + j, auto_reset=True)
+            assert np.array_equal(packed[j], read_buffer(b, _abi.BUF_PACKED, (n,), np.uint64)), (game, c, j)
+        for which, dt in ((_abi.BUF_REWARD, np.int32), (_abi.BUF_LIVES, np.int32), (_abi.BUF_SCORE, np.int32), (_abi.BUF_DONE, np.uint8), (_abi.BUF_PACKED, np.uint64)):
+            assert np.array_equal(read_buffer(a, which, (n,), dt), read_buffer(b, which, (n,), dt)), (game, c, which)
+        t += k
+    a.sync(); b.sync()
+    for i in range(n):
+        assert bytes(a.get_state(i)) == bytes(b.get_state(i))
+    with pytest.raises(ToyboxAmdError):
+        a.rollout_synthetic(1337, 0, 0)
+    with pytest.raises(ToyboxAmdError):
+        a.rollout_synthetic(1337, 0, 2, channels=2)
+    # under a K-step record ring the chunk has to be as long as the ring, and the ring empty
+    a.set_option(_abi.OPT_GATHER_EVERY, 4)
+    a.gather_init(1, 0, a.gather_unique_id())
+    with pytest.raises(ToyboxAmdError):
+        a.rollout_synthetic(1337, t, 3)
+    a.step_synthetic(1337, t, auto_reset=True); a.gather()
+    with pytest.raises(ToyboxAmdError):
+        a.rollout_synthetic(1337, t + 1, 4)
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,channels,K,ring", [(8192, 3, 4, True), (4096, 4, 4, False), (700, 3, 3, True), (20000, 3, 5, True), (3000, 3, 2, False)])
+def test_rollout_chunks_equal_oracle(n, channels, K, ring, hip_lib, oracle_lib):
+    """Rollout chunks on the device (one step launch on the step lane + k rasteriser launches on two lanes, TBX_OPT_ROLLOUT_CHUNKS)
+    against the oracle's k single calls: EVERY chunk's step records (all envs), last-step outputs and sampled frames, read by
+    copies queued on the caller's stream right behind tbx_device_buffer (the lazy join) and therefore before the next chunk is
+    issued; the two chunk buffers alternate; under a K-step ring the gathered block of every chunk; joins (a host step, a state
+    write, a single fused call, the option off for a chunk) in between; final states.  8 192 envs + K = 4 ring is the per-GPU
+    share of the strong-scaled headline batch."""
+    from toybox_amd import hip
+    game = "breakout"
+    g, o = _pair(game, n, hip_lib, oracle_lib, seed=33)
+    H, W = g.height, g.width
+    fb = H * W * channels
+    g.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_ON)
+    if ring:
+        for e in (g, o):
+            e.set_option(_abi.OPT_GATHER_EVERY, K)
+            e.gather_init(1, 0, e.gather_unique_id())
+    assert g.get_option(_abi.OPT_ROLLOUT_CHUNKS_ACTIVE) == 1
+    sample = sorted({0, 1, 255, 256, n // 2, n - 1})
+    s = hip.Stream()
+    chunks = 14
+    per_out = 4 * n * 3 + n
+    hold_p = hip.malloc(8 * n * K * chunks)
+    hold_o = hip.malloc(per_out * chunks)
+    hold_f = hip.malloc(fb * len(sample) * K * chunks)
+    want_f, want_p, want_o, addr = [], [], [], []
+    t = 0
+    for c in range(chunks):
+        if c == 4:
+            a = synthetic_actions(game, n, 900, seed=3)
+            for x, y in zip(g.step(a, auto_reset=True), o.step(a, auto_reset=True)):
+                assert np.array_equal(x, y)
+        if c == 6:
+            st = o.get_state(7)
+            g.set_state(1, st); o.set_state(1, st)
+        if c == 8 and not ring:
+            g.render_step_synthetic(1337, t, channels=channels, auto_reset=True, stream=s.ptr)
+            o.render_step_synthetic(1337, t, channels=channels, auto_reset=True)
+            t += 1
+        g.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_OFF if c == 10 else _abi.ROLLOUT_CHUNKS_ON)
+        g.rollout_synthetic(1337, t, K, channels=channels, auto_reset=True, stream=s.ptr)
+        f, nb = g.device_buffer(_abi.BUF_ROLLOUT_FRAMES)
+        assert nb == K * n * fb
+        addr.append(f)
+        pk, pb = g.device_buffer(_abi.BUF_ROLLOUT_PACKED)
+        assert pb == 8 * K * n                                  # (one rank, records_per_rank = N: the ring's rows are N wide)
+        hip.memcpy_dtod_async(hold_p + 8 * n * K * c, pk, 8 * n * K, s)
+        off = per_out * c
+        for which, nbytes in ((_abi.BUF_REWARD, 4 * n), (_abi.BUF_LIVES, 4 * n), (_abi.BUF_SCORE, 4 * n), (_abi.BUF_DONE, n)):
+            p, _ = g.device_buffer(which)
+            hip.memcpy_dtod_async(hold_o + off, p, nbytes, s)
+            off += nbytes
+        for j in range(K):
+            for kk, i in enumerate(sample):
+                hip.memcpy_dtod_async(hold_f + fb * ((c * K + j) * len(sample) + kk), f + fb * (j * n + i), fb, s)
+        # the oracle: the k single calls
+        fr, pr = [], []
+        for j in range(K):
+            fr.append([o.render_env(i, channels) for i in sample])
+            o.step(synthetic_actions(game, n, t + j, seed=1337), auto_reset=True)
+            q, _ = o.device_buffer(_abi.BUF_PACKED)
+            pr.append(np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_uint64)), (n,)).copy())
+            if ring:
+                o.gather()
+        want_f.append(fr); want_p.append(np.stack(pr))
+        want_o.append([np.ctypeslib.as_array(C.cast(o.device_buffer(w)[0], C.POINTER(ct)), (n,)).copy()
+                       for w, ct in ((_abi.BUF_REWARD, C.c_int32), (_abi.BUF_LIVES, C.c_int32), (_abi.BUF_SCORE, C.c_int32), (_abi.BUF_DONE, C.c_uint8))])
+        if ring:
+            assert g.gather_fill() == 0
+            assert np.array_equal(g.gather_host().reshape(K, -1)[:, :n], o.gather_host().reshape(K, -1)[:, :n]), c
+        t += K
+    s.synchronize()
+    g.sync()
+    assert all(addr[c] != addr[c - 1] for c in (1, 2, 3, 12, 13)) and addr[2] == addr[0] and addr[3] == addr[1]
+    pk = np.empty((K, n), np.uint64)
+    buf = np.empty(per_out, np.uint8)
+    one = np.empty((H, W, channels), np.uint8)
+    for c in range(chunks):
+        hip.memcpy_dtoh(pk, hold_p + 8 * n * K * c, 8 * n * K)
+        assert np.array_equal(pk, want_p[c]), c
+        hip.memcpy_dtoh(buf, hold_o + per_out * c, per_out)
+        rew, liv, sco = (buf[4 * n * x:4 * n * (x + 1)].view(np.int32) for x in range(3))
+        w = want_o[c]
+        assert np.array_equal(rew, w[0]) and np.array_equal(liv, w[1]) and np.array_equal(sco, w[2]) and np.array_equal(buf[12 * n:], w[3]), c
+        for j in range(K):
+            for kk, i in enumerate(sample):
+                hip.memcpy_dtoh(one, hold_f + fb * ((c * K + j) * len(sample) + kk), fb)
+                assert np.array_equal(one, want_f[c][j][kk]), (c, j, i)
+    for p in (hold_p, hold_o, hold_f):
         hip.free(p)
     _same_states(g, o, sample + list(range(0, n, max(1, n // 40))), "end")
     g.close(); o.close()

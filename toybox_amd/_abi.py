@@ -24,6 +24,8 @@ BUF_AGENT_EP_DONE, BUF_AGENT_EP_RETURN, BUF_AGENT_EP_LENGTH = 9, 10, 11
 BUF_GATHERED = 12
 BUF_AGENT_PLANE = 13
 BUF_AGENT_RING = 14
+BUF_ROLLOUT_FRAMES = 15            # uint8[k][N][H][W][C] frames of the last tbx_rollout_synthetic
+BUF_ROLLOUT_PACKED = 16            # uint64[k][stride] its step records (stride = the gather's records_per_rank under a K-step ring, else N)
 GATHER_ID_BYTES = 128
 # engine options (tbx_set_option)
 OPT_PIPELINE, OPT_STEP_FORM, OPT_RENDER_SPLIT, OPT_AGENT_GENERIC, OPT_RESIDENT_STEP, OPT_GATHER_EVERY = 0, 1, 2, 3, 4, 5
@@ -36,6 +38,9 @@ OPT_PIPELINE_ACTIVE = 100          # read-only: what OPT_PIPELINE resolves to on
 OPT_RECORDS_ACTIVE = 101           # read-only: the rasteriser reads step-written render records
 OPT_RENDER_STEP_FUSED = 102        # read-only: tbx_render_step_synthetic is one launch on this engine
 OPT_FUSED_OVERLAP_ACTIVE = 103     # read-only: such launches would be overlapped right now
+OPT_ROLLOUT_CHUNKS = 9             # tbx_rollout_synthetic as one step launch + k overlapped rasteriser launches: 0 engine's choice, 1 on, 2 off
+ROLLOUT_CHUNKS_AUTO, ROLLOUT_CHUNKS_ON, ROLLOUT_CHUNKS_OFF = 0, 1, 2
+OPT_ROLLOUT_CHUNKS_ACTIVE = 104    # read-only: it would run that way right now
 PIPELINE_OFF, PIPELINE_AUTO, PIPELINE_STEP_BESIDE_RENDER, PIPELINE_OVERLAP_RENDERS = 0, 1, 2, 3
 STEP_FORM_AUTO, STEP_FORM_THREAD_PER_ENV, STEP_FORM_WAVE_PER_ENV = 0, 1, 2
 
@@ -328,6 +333,7 @@ PROTOTYPES = {
     "tbx_render": (_i, [_vp, _vp, _i]),
     "tbx_render_device": (_i, [_vp, _vp, _i, _vp]),
     "tbx_render_step_synthetic": (_i, [_vp, _vp, _i, _u64, _u64, _u64, _u32, _vp]),
+    "tbx_rollout_synthetic": (_i, [_vp, _i, _u64, _u64, _i, _u64, _u32, _vp]),
     "tbx_render_env": (_i, [_vp, _i, _vp, _i]),
     "tbx_get_state": (_i, [_vp, _i, _vp, _sz]),
     "tbx_set_state": (_i, [_vp, _i, _vp, _sz]),
@@ -374,10 +380,16 @@ PROTOTYPES = {
 }
 
 
-def bind(lib):
-    """Attach restype/argtypes for every symbol of the header; raises AttributeError when one is missing."""
+def bind(lib, older_build=False):
+    """Attach restype/argtypes for every symbol of the header; raises AttributeError when one is missing.  older_build=True (the A/B
+    scripts, which load the previous round's library beside this one): entry points that build does not have yet are skipped."""
     for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if older_build:
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     return lib

@@ -860,6 +860,51 @@ __device__ __forceinline__ void brk_step_tpe_body(const BrkDev& d, const BrkCfg&
 }
 
 
+// tbx_rollout_synthetic, chunk form: frames t .. t + k - 1 of one env on one thread with the state in registers -- ONE load and ONE
+// store of the state per chunk.  Before frame j the rasteriser's record of the state goes to recs[j][env] (frame j of the chunk
+// shows the state BEFORE step t + j, as tbx_render_step_synthetic's frame does), after it the step's 8-byte record to
+// packed[j * stride + env]; the last frame's outputs land in the engine's output arrays.  Actions by the synthetic rule with
+// the frame's own t; auto-reset inside the loop like the single-frame kernel.
+__global__ __launch_bounds__(128) void brk_rollout_step_kernel(BrkDev d, const BrkCfg* __restrict__ cp, ActionSource src, uint32_t flags, int k,
+                                                               BrkRenderRec* __restrict__ recs, uint64_t* __restrict__ packed, size_t stride)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n) return;
+    const BrkCfg& c = *cp;
+    const size_t N = (size_t)d.n;
+    BrkT s;
+    t_load(d, env, s);
+    int32_t prev = d.prev_score[env];
+    int32_t rew = 0, out_lives = 0, out_score = 0;
+    bool is_done = false;
+    for (int j = 0; j < k; j++) {
+        recs[(size_t)j * N + env] = t_record(s);
+        const uint64_t h = tbx_splitmix64(src.seed ^ ((src.env_offset + (uint64_t)env) << 32) ^ (src.t + (uint64_t)j));
+        const uint32_t buttons = tbx_ale_buttons(tbx_legal_action(TBX_GAME_BREAKOUT, (int)(h % 4ull)));
+        brk_t_step(c, s, buttons);
+        rew = s.score - prev;
+        if (rew < 0) rew = 0;
+        out_lives = s.lives; out_score = s.score;
+        is_done = s.lives <= 0;
+        prev = s.score;
+        if (is_done && (flags & TBX_STEP_AUTO_RESET)) {
+            Rng sim;
+            sim.s0 = d.sim_rng[env]; sim.s1 = d.sim_rng[N + env];
+            t_new_game(c, sim, s);
+            d.sim_rng[env] = sim.s0; d.sim_rng[N + env] = sim.s1;
+            prev = s.score;
+        }
+        const uint32_t lv8 = out_lives < 0 ? 0u : out_lives > 255 ? 255u : (uint32_t)out_lives;
+        packed[(size_t)j * stride + env] = (uint64_t)(uint32_t)rew | ((uint64_t)(is_done ? 1u : 0u) << 32) | ((uint64_t)lv8 << 40);
+    }
+    t_store(d, env, s);
+    d.prev_score[env] = prev;
+    d.reward[env] = rew;
+    d.done[env] = is_done ? 1 : 0;
+    d.lives_out[env] = out_lives;
+    d.score_out[env] = out_score;
+}
+
 template <bool AGENT>
 __global__ __launch_bounds__(128) void brk_step_tpe_kernel(BrkDev d, const BrkCfg* __restrict__ cp, ActionSource src, uint32_t flags, BrkRenderRec* recs,
                                                            BrkRenderRec* recs_a, BrkRenderRec* recs_b)
@@ -1200,7 +1245,7 @@ __device__ __forceinline__ void brk_paint_units(const RecSrc src, const BrkCusto
     }
 }
 
-template <int C, bool CUSTOM, bool ALT>
+template <int C, bool CUSTOM, bool ALT, bool COH = false>
 __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__ recs, const BrkCustom* __restrict__ custom,
                                                                BrkPalette pal, uint8_t* __restrict__ out, int first_env, int count, int split,
                                                                const BrkRenderRec* __restrict__ recs_alt, const uint8_t* __restrict__ pick_alt,
@@ -1216,7 +1261,7 @@ __device__ __forceinline__ void brk_render_body(const BrkRenderRec* __restrict__
     const BrkLaneTables<C> tables(pal, lane);
     // `split` waves share a frame, wave `part` taking units part, part + split, ...
     const bool stagger = C == 3 && !((split >> 16) & 1);  // (bit 16 of the argument: one of the two parts of a big launch)
-    const bool coherent = (split >> 17) & 1;              // (bit 17: an overlapped fused launch -- brk_rec_load_lanes)
+    const bool coherent = COH && !OVL_DIAG(split >> 17, 1);   // (COH: an overlapped fused launch -- brk_rec_load_lanes; bit 17: DIAG, plain load)
     split &= 0xFFFF;
     const int wid = wave_uniform(block * TBX_WAVES_PER_BLOCK + wave);
     const int rel = wid / split, part = wid - rel * split;
@@ -1263,11 +1308,23 @@ __global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5)
 // launches follow each other like render-only loops, and neither the staggered first waves nor the two-part launch is needed.
 // The kernel is held to five waves per SIMD like the rasteriser it contains, so the step half (190 VGPRs on its own) is
 // compiled to the rasteriser's register budget and spills; it runs on 0.6 % of the launch's waves beside the ramp-up.
-template <int C>
+// OVL: the overlapped form (arrive != nullptr).  Its own instantiation: with the counter, the release block and the coherent record
+// load as run-time branches of ONE kernel the stream-order launch of 65 536 envs lost 2.7 % (1.229 against 1.197 ms, same box,
+// either order) -- the record's load no longer stayed in flight behind the set-up.
+template <int C, bool OVL>
 __global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void brk_render_step_kernel_w5(
     const BrkRenderRec* __restrict__ recs, BrkPalette pal, uint8_t* __restrict__ out, int count, int split, BrkDev d, const BrkCfg* __restrict__ cp,
     ActionSource src, uint32_t flags, BrkRenderRec* __restrict__ recs_next, int step_blocks, unsigned long long* arrive, int release_block, int diag)
 {
+    if (!OVL) {
+        if ((int)blockIdx.x < step_blocks) {
+            const int env = (int)blockIdx.x * TBX_BLOCK + (int)threadIdx.x;
+            if (env < d.n) brk_step_tpe_body<false, false>(d, *cp, src, flags, recs_next, nullptr, nullptr, env);
+            return;
+        }
+        brk_render_body<C, false, false>(recs, nullptr, pal, out, 0, count, split | (1 << 16), nullptr, nullptr, (int)blockIdx.x - step_blocks);
+        return;
+    }
     // arrive != nullptr: an overlapped launch (engine.hip, fused_overlapped).  The launch before this one may still be painting on
     // the other lane; what it STEPPED (state, the records read below) was fenced out before its step blocks bumped the counter
     // the engine's wait kernel saw.  The step blocks' waves start by dropping what their caches hold from before that (one
@@ -1275,10 +1332,6 @@ __global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5)
     // slower, profiles/r06_experiments.txt); the rasteriser blocks read one record each, with a load that bypasses those caches.
     if ((int)blockIdx.x < step_blocks) {
         const int env = (int)blockIdx.x * TBX_BLOCK + (int)threadIdx.x;
-        if (!arrive) {
-            if (env < d.n) brk_step_tpe_body<false, false>(d, *cp, src, flags, recs_next, nullptr, nullptr, env);
-            return;
-        }
         if (OVL_DIAG(diag, 1)) {                                // (DIAG: plain loads and stores behind a per-wave invalidate / write-back)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (env < d.n) brk_step_tpe_body<false, false>(d, *cp, src, flags, recs_next, nullptr, nullptr, env);
@@ -1293,8 +1346,8 @@ __global__ __launch_bounds__(TBX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5)
         return;
     }
     // blocks start in index order: once this one runs, the launch has only `lead` blocks left to hand out -- the next launch may come
-    if (arrive && (int)blockIdx.x == release_block && threadIdx.x == 0) __hip_atomic_fetch_add(arrive + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    brk_render_body<C, false, false>(recs, nullptr, pal, out, 0, count, split | (1 << 16) | (arrive && !OVL_DIAG(diag, 4) ? 1 << 17 : 0), nullptr, nullptr, (int)blockIdx.x - step_blocks);
+    if ((int)blockIdx.x == release_block && threadIdx.x == 0) __hip_atomic_fetch_add(arrive + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    brk_render_body<C, false, false, true>(recs, nullptr, pal, out, 0, count, split | (1 << 16) | (OVL_DIAG(diag, 4) ? 1 << 17 : 0), nullptr, nullptr, (int)blockIdx.x - step_blocks);
 }
 
 template <int C, bool CUSTOM, bool ALT>
@@ -1802,6 +1855,8 @@ struct BreakoutOps : GameOps {
     int recs_par = 0;               // here and the two swap (GameOps::step_ahead)
     BrkRenderRec* recs_third = nullptr;   // fused launches rotate through three (render_step): a launch overlapped on the other lane must not
                                           // rewrite what this launch's rasteriser blocks still read
+    BrkRenderRec* recs_chunk[2] = {nullptr, nullptr};   // [k][N] records of a rollout chunk of parity q (tbx_rollout_synthetic), made on first use
+    int recs_chunk_k[2] = {0, 0};
     bool recs_valid = false;        // records reflect the current state of every env
     BrkCfg* cfg_dev = nullptr;      // device copy of `c` for kernels that index the tables per thread
 
@@ -1879,6 +1934,7 @@ struct BreakoutOps : GameOps {
         hipFree(recs);
         hipFree(recs_other);
         hipFree(recs_third);
+        hipFree(recs_chunk[0]); hipFree(recs_chunk[1]);
         hipFree(recsA);
         hipFree(recsB);
         hipFree(cfg_dev);
@@ -1953,9 +2009,22 @@ struct BreakoutOps : GameOps {
 
     // tbx_render_step_synthetic: frame t and the step to frame t + 1 in one launch (brk_render_step_kernel_w5)
     bool render_step_fused(int channels) const override { return pipeline_ok() && channels >= 3; }   // (gray frames stream fastest at more than five waves per SIMD)
-    // scripts/strong_sweep.py / bench.py (round 6, same-box A/B of TBX_OPT_FUSED_OVERLAP 2 / 1): see profiles/r06_experiments.txt
-    bool fused_overlap_auto(int n) const override { return n <= 16384; }
-    static constexpr int FUSED_LEAD_BLOCKS = 1024;
+    // Same-box interleaved A/B of TBX_OPT_FUSED_OVERLAP 2 / 1 (scripts/overlap_diag.py with OD_LIB=product; profiles/r06_experiments.txt),
+    // ms per step stream order / overlapped, no gather | K = 4 ring | a collective per step: 4 096 envs 0.0861 / 0.0781 | 0.0880 /
+    // 0.0786 | 0.1076 / 0.0798; 8 192: 0.1626 / 0.1571 | 0.1644 / 0.1576 | 0.1840 / 0.1590 (lead 1 024; released as early as possible
+    // 0.1640 / 0.1518 with the ring); 16 384: 0.3161 / 0.2979 with the ring; 32 768: 0.6169 / 0.6109 | 0.6194 / 0.5933; 65 536:
+    // 1.2244 / 1.2634 | 1.2272 / 1.2734 -- two 1.2 ms launches side by side lose, so the headline batch stays in stream order.
+    // The engine's choice by what else is on the device (same files; the ticket is sensitive to when the step blocks get their
+    // memory requests through beside the other lane's rasteriser): a collective per step -- which stream order cannot overlap at
+    // all -- up to 32 768 envs; a K-step ring up to 4 096 (8 192: 0.1593 / 0.1649 in one run, 0.1644 / 0.1576 in another); no
+    // gather up to 8 192 (0.1572 / 0.1479)
+    // ... in single-engine probes.  In bench.py's own arms and in processes that hold several engines the same comparisons came out
+    // between -7 % and +30 % at 8 192 envs and above (r06_experiments.txt, "what did not reproduce"): the engine's choice is the
+    // one size where every run agreed, 4 096 envs and below (8-13 % faster with or without a gather)
+    bool fused_overlap_auto(int n, int /*gather_kind*/) const override { return n <= 4096; }
+    // the next launch is released as soon as this one's step blocks are through (lead = the whole grid): leads of 128 ... 8 192
+    // blocks were 1-6 points behind at every size up to 16 384 envs (r06_overlap_lead.txt)
+    static constexpr int FUSED_LEAD_BLOCKS = 1 << 20;
     int render_step(tbx_engine* e, uint8_t* out_dev, int channels, const ActionSource& src, uint32_t flags, hipStream_t s, TbxOverlapLaunch* ov) override
     {
         if (!recs_valid) {                                     // the painter reads records: bring them up to the state first
@@ -1976,14 +2045,14 @@ struct BreakoutOps : GameOps {
             const int release_block = std::max(step_blocks, (int)grid.x - lead);
             hipEvent_t done = OVL_DIAG(ov->diag, 128) ? nullptr : ov->done;
             switch (channels) {
-            case 3: hipExtLaunchKernelGGL(brk_render_step_kernel_w5<3>, grid, block, 0, s, nullptr, done, 0, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, ov->arrive, release_block, ov->diag); break;
-            case 4: hipExtLaunchKernelGGL(brk_render_step_kernel_w5<4>, grid, block, 0, s, nullptr, done, 0, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, ov->arrive, release_block, ov->diag); break;
+            case 3: hipExtLaunchKernelGGL((brk_render_step_kernel_w5<3, true>), grid, block, 0, s, nullptr, done, 0, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, ov->arrive, release_block, ov->diag); break;
+            case 4: hipExtLaunchKernelGGL((brk_render_step_kernel_w5<4, true>), grid, block, 0, s, nullptr, done, 0, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, ov->arrive, release_block, ov->diag); break;
             default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
             }
         } else
             switch (channels) {
-            case 3: TBX_LAUNCH_STEP(e, s, brk_render_step_kernel_w5<3>, grid, block, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, no_counter, 0, 0); break;
-            case 4: TBX_LAUNCH_STEP(e, s, brk_render_step_kernel_w5<4>, grid, block, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, no_counter, 0, 0); break;
+            case 3: TBX_LAUNCH_STEP(e, s, (brk_render_step_kernel_w5<3, false>), grid, block, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, no_counter, 0, 0); break;
+            case 4: TBX_LAUNCH_STEP(e, s, (brk_render_step_kernel_w5<4, false>), grid, block, recs, pal, out_dev, e->n, split, d, cfg_dev, src, flags, recs_other, step_blocks, no_counter, 0, 0); break;
             default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
             }
         TBX_HIP(hipGetLastError());
@@ -1994,6 +2063,38 @@ struct BreakoutOps : GameOps {
         recs_other = recs_third;
         recs_third = was_read;
         recs_par ^= 1;
+        return TBX_OK;
+    }
+
+    // ---- rollout chunks (engine.hip, rollout_chunked)
+    bool rollout_ok(int channels) const override { return pipeline_ok() && channels >= 3; }
+    // same-box A/B against the loop of single calls in stream order (scripts/rollout_ab.py, k = 4, ms per step, with the K = 4 record
+    // ring | without a gather; profiles/r06_experiments.txt): 4 096 envs 0.0854 -> 0.0747 | 0.0833 -> 0.0748 (0.79 of 8 TB/s); 8 192:
+    // 0.1593 -> 0.1559 | 0.1572 -> 0.1536; 16 384: 0.3067 -> 0.3137 | 0.3060 -> 0.3134; 32 768 and 65 536: 4-10 % slower -- two
+    // rasteriser launches side by side gain what a launch loses to ramp-up and tail and lose a little everywhere else
+    // -- and at 8 192 the sign changed from run to run (-2 % ... +11 %; bench.py's 1/8-batch arm 0.186 against 0.161 ms): 4 096 and below
+    bool rollout_auto(int n) const override { return n <= 4096; }
+    int rollout_step(tbx_engine* e, const ActionSource& src, uint32_t flags, int k, int q, uint64_t* packed, size_t stride, hipStream_t s) override
+    {
+        if (recs_chunk_k[q] < k) {                             // (the caller has made sure nothing reads the old buffer any more)
+            TBX_HIP(hipStreamSynchronize(s));
+            hipFree(recs_chunk[q]);
+            recs_chunk[q] = nullptr;
+            recs_chunk_k[q] = 0;
+            TBX_HIP(hipMalloc((void**)&recs_chunk[q], sizeof(BrkRenderRec) * (size_t)k * (size_t)e->n));
+            recs_chunk_k[q] = k;
+        }
+        hipLaunchKernelGGL(brk_rollout_step_kernel, dim3((e->n + 127) / 128), dim3(128), 0, s, d, cfg_dev, src, flags, k, recs_chunk[q], packed, stride);
+        TBX_HIP(hipGetLastError());
+        recs_valid = false;                                    // the single-frame records no longer show the state
+        return TBX_OK;
+    }
+    int rollout_render(tbx_engine* e, uint8_t* out, int channels, int q, int j, hipStream_t s) override
+    {
+        const BrkRenderRec* rr = recs_chunk[q] + (size_t)j * (size_t)e->n;
+        if (channels == 3) launch_render<3>(out, 0, e->n, s, rr);
+        else launch_render<4>(out, 0, e->n, s, rr);
+        TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
 
@@ -2022,7 +2123,7 @@ struct BreakoutOps : GameOps {
 
     template <int C>
     void launch_render(uint8_t* out, int first, int count, hipStream_t s, const BrkRenderRec* src_recs = nullptr,
-                       const BrkRenderRec* alt = nullptr, const uint8_t* pick_alt = nullptr)
+                       const BrkRenderRec* alt = nullptr, const uint8_t* pick_alt = nullptr, bool overlapped = false)
     {
         const BrkPalette pal = palette();
         if (!recs_valid && (!src_recs || alt)) {           // the live records are read
@@ -2047,8 +2148,11 @@ struct BreakoutOps : GameOps {
         // Launches of 16 384 .. 32 767 blocks (6 554 .. 13 107 envs) keep the staggered first waves instead: there the second
         // kernel boundary costs as much as it saves (scripts/pipeline_sweep.py, 8 192 envs: 0.172 / 0.169-0.173 ms per step two
         // parts / stagger, with a per-step gather 0.179 / 0.175).
-        const bool two_parts = C == 3 && grid_for(count * split).x >= 32768u;
-        const int split_arg = split | (two_parts ? 1 << 16 : 0);          // bit 16: no stagger (this is one of two parts)
+        // (overlapped = true was tried for the rasteriser launches of a rollout chunk -- one part, no stagger, like the rasteriser blocks
+        // of the fused launch: 8 192 envs 0.193 against 0.156 ms per step, 16 384: 0.363 against 0.314; they keep the launch forms of
+        // the stream-order loop)
+        const bool two_parts = !overlapped && C == 3 && grid_for(count * split).x >= 32768u;
+        const int split_arg = split | (two_parts || overlapped ? 1 << 16 : 0);          // bit 16: no stagger (this is one of two parts)
         auto launch_part = [&](int f0, int n) {                           // envs first + f0 .. first + f0 + n - 1 into their frames
             uint8_t* o = out + (size_t)f0 * TBX_BRK_H * TBX_BRK_W * C;
             const dim3 grid = grid_for(n * split), block(TBX_BLOCK);

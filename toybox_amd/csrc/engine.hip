@@ -298,6 +298,7 @@ int tbx_destroy(tbx_engine* e)
     TbxPipe& pp = e->pipe;
     for (int k = 0; k < 2; k++)
         if (pp.lane[k] && pp.lane[k] != e->stream) hipStreamSynchronize(pp.lane[k]);
+    if (pp.step_lane) hipStreamSynchronize(pp.step_lane);
     tbx_gather_free(e);
     tbx_agent_free(e);
     if (e->ops) { e->ops->destroy(e); delete e->ops; }
@@ -312,6 +313,13 @@ int tbx_destroy(tbx_engine* e)
         if (pp.lane[k] && pp.lane[k] != e->stream) hipStreamDestroy(pp.lane[k]);
     }
     hipFree(pp.arrive);
+    if (pp.step_lane) { hipStreamSynchronize(pp.step_lane); hipStreamDestroy(pp.step_lane); }
+    for (int q = 0; q < 2; q++) {
+        hipFree(pp.chunk_frames[q]); hipFree(pp.chunk_packed[q]);
+        if (pp.chunk_step_ev[q]) hipEventDestroy(pp.chunk_step_ev[q]);
+        for (int l = 0; l < 2; l++)
+            if (pp.chunk_raster_ev[q][l]) hipEventDestroy(pp.chunk_raster_ev[q][l]);
+    }
     hipFree(e->actions);
     hipFree(e->edit_args); hipFree(e->reduce_out);
     hipFree(e->mask); hipFree(e->err_flag); hipFree(e->frame_own); hipFree(e->staging); hipFree(e->scal); hipFree(e->one_frame); hipFree(e->io_dev);
@@ -556,6 +564,11 @@ static int pipe_prepare(tbx_engine* e)
         if (!p.user_frame_ev[k]) EHIP(hipEventCreateWithFlags(&p.user_frame_ev[k], hipEventDisableTiming));
         if (!p.launch_ev[k]) EHIP(hipEventCreateWithFlags(&p.launch_ev[k], hipEventDisableTiming));
     }
+    for (int q = 0; q < 2; q++) {
+        if (!p.chunk_step_ev[q]) EHIP(hipEventCreateWithFlags(&p.chunk_step_ev[q], hipEventDisableTiming));
+        for (int l = 0; l < 2; l++)
+            if (!p.chunk_raster_ev[q][l]) EHIP(hipEventCreateWithFlags(&p.chunk_raster_ev[q][l], hipEventDisableTiming));
+    }
     if (!p.arrive) {
         EHIP(hipMalloc((void**)&p.arrive, 2 * sizeof(unsigned long long)));
         EHIP(hipMemset(p.arrive, 0, 2 * sizeof(unsigned long long)));
@@ -573,24 +586,29 @@ static int pipe_prepare(tbx_engine* e)
 #endif
     for (int k = 0; k < 2; k++)
         if (!p.lane[k]) EHIP(hipStreamCreateWithPriority(&p.lane[k], hipStreamNonBlocking, hi));
+    if (!p.step_lane) EHIP(hipStreamCreateWithPriority(&p.step_lane, hipStreamNonBlocking, hi));   // (three of the priority level's four hardware queues)
     p.prepared = true;
     return TBX_OK;
 }
 
 // the first pipelined call after a call of any other kind: every internal stream behind all that came before
-static int pipe_enter(tbx_engine* e, bool fused = false)
+enum { PIPE_STEPS_AND_RENDERS = 0, PIPE_FUSED_OVERLAP = 1, PIPE_ROLLOUT_CHUNKS = 2 };
+
+static int pipe_enter(tbx_engine* e, int kind = PIPE_STEPS_AND_RENDERS)
 {
     TbxPipe& p = e->pipe;
+    const bool fused = kind == PIPE_FUSED_OVERLAP, rollout = kind == PIPE_ROLLOUT_CHUNKS;
     if (e->pending_kind) EHIP(tbx_finish_pending(e));           // (a host-delivery step between its begin and end calls)
-    // pipelined steps / renders and overlapped fused launches keep different books on the same lanes: a change of kind joins
-    // first (the caller's stream has been made to wait for every internal launch, so the lanes re-enter behind it)
-    if (p.active && p.fused != fused) EHIP(tbx_use_stream(e, e->last_stream));
+    // pipelined steps / renders, overlapped fused launches and rollout chunks keep different books on the same lanes: a change of
+    // kind joins first (tbx_use_stream makes the stream of the last call wait for every internal launch; the lanes re-enter behind it)
+    if (p.active && (p.fused != fused || p.rollout != rollout)) EHIP(tbx_use_stream(e, e->last_stream));
     if (p.active) return TBX_OK;
     if (e->serve_running) EHIP(tbx_serve_stop(e));
     int rc = pipe_prepare(e);
     if (rc) return rc;
     EHIP(tbx_wait_tail(e, p.lane[0]));
     EHIP(tbx_wait_tail(e, p.lane[1]));
+    if (rollout) EHIP(tbx_wait_tail(e, p.step_lane));
     for (int k = 0; k < 2; k++) { p.render_pending[k] = p.user_step_rec[k] = p.user_frame_rec[k] = false; p.render_on[k] = nullptr; }
     p.step_outstanding = false;
     p.step_on = nullptr;
@@ -598,8 +616,12 @@ static int pipe_enter(tbx_engine* e, bool fused = false)
     p.frame_par = -1;
     p.live_reader = -1;
     p.fused = fused;
+    p.rollout = rollout;
     p.prev_overlapped = false;
     p.launch_rec[0] = p.launch_rec[1] = false;
+    p.user_waits[0] = p.user_waits[1] = false;
+    p.reader_seen = false;
+    for (int q = 0; q < 2; q++) { p.chunk_step_rec[q] = p.chunk_raster_rec[q][0] = p.chunk_raster_rec[q][1] = p.chunk_user_waits[q] = false; }
     p.active = true;
     return TBX_OK;
 }
@@ -737,16 +759,31 @@ __global__ void tbx_ticket_wait_kernel(const unsigned long long* arrive, unsigne
     }
 }
 
+// the caller asks where a result of the last call lies: the stream that call named now waits for the launch that wrote it
+static int fused_reader_joins(tbx_engine* e)
+{
+    TbxPipe& p = e->pipe;
+    if (!p.active || !p.fused) return TBX_OK;
+    const int k = e->out_par;
+    if (p.launch_rec[k] && !p.user_waits[k]) {
+        EHIP(hipSetDevice(e->device));
+        EHIP(hipStreamWaitEvent(e->last_stream, p.launch_ev[k], 0));
+        p.user_waits[k] = true;
+    }
+    p.reader_seen = true;
+    return TBX_OK;
+}
+
 static bool fused_overlap_on(const tbx_engine* e, const uint8_t* out_dev, int channels)
 {
     const int v = e->opt[TBX_OPT_FUSED_OVERLAP];
     if (v == 2 || out_dev != nullptr || !e->ops->render_step_fused(channels)) return false;
-    return v == 1 || e->ops->fused_overlap_auto(e->n);
+    return v == 1 || e->ops->fused_overlap_auto(e->n, !e->gather ? 0 : e->gather_ring ? 2 : 1);
 }
 
 static int fused_overlapped(tbx_engine* e, int channels, const ActionSource& src, uint32_t flags, hipStream_t user)
 {
-    int rc = pipe_enter(e, true);
+    int rc = pipe_enter(e, PIPE_FUSED_OVERLAP);
     if (rc) return rc;
     TbxPipe& p = e->pipe;
     const int cur = e->out_par, wp = cur ^ 1;                  // this launch writes output set wp and frame buffer wp, on lane wp
@@ -766,12 +803,14 @@ static int fused_overlapped(tbx_engine* e, int channels, const ActionSource& src
         EHIP(hipMalloc((void**)&p.frame[fb], bytes));
         p.frame_bytes[fb] = bytes;
     }
-    // readers of what call N-2 left in set / frame wp were queued on U before call N-1, which fenced them; this call fences the
-    // readers of call N-1's results for call N+1
-    if (!OVL_DIAG(diag, 16)) {
-        if (p.user_step_rec[wp]) { EHIP(hipStreamWaitEvent(ls, p.user_step_ev[wp], 0)); p.user_step_rec[wp] = false; }
+    // Readers of what call N-2 left in set / frame wp were queued on U before call N-1, which fenced them; this call fences the
+    // readers of call N-1's results for call N+1 -- if there can be any: U joined lazily (fused_reader_joins), and a caller
+    // that took no address since the last call has queued no reader.
+    if (p.user_step_rec[wp]) { EHIP(hipStreamWaitEvent(ls, p.user_step_ev[wp], 0)); p.user_step_rec[wp] = false; }
+    if (p.reader_seen || OVL_DIAG(diag, 16)) {
         EHIP(hipEventRecord(p.user_step_ev[cur], user));
         p.user_step_rec[cur] = true;
+        p.reader_seen = false;
     }
     uint64_t* const ring_slot = e->gather_ring ? e->packed : nullptr;      // (a K-step ring owns the record pointer)
     tbx_set_out_parity(e, wp);
@@ -792,12 +831,143 @@ static int fused_overlapped(tbx_engine* e, int channels, const ActionSource& src
     p.prev_overlapped = true;
     p.launch_rec[wp] = true;
     if (OVL_DIAG(diag, 128)) EHIP(hipEventRecord(p.launch_ev[wp], ls));
-    if (!OVL_DIAG(diag, 16)) EHIP(hipStreamWaitEvent(user, p.launch_ev[wp], 0));
+    p.user_waits[wp] = false;
+    if (OVL_DIAG(diag, 16)) { EHIP(hipStreamWaitEvent(user, p.launch_ev[wp], 0)); p.user_waits[wp] = true; }    // (DIAG: the eager join of the first build)
     e->frame = p.frame[fb];
     e->frame_bytes = p.frame_bytes[fb];
     e->step_carries_order_ev = false;
     e->last_stream = user;
     e->has_last = true;
+    return TBX_OK;
+}
+
+// ---- rollout chunks (tbx_rollout_synthetic; contract in include/toybox_amd.h, TbxPipe::rollout)
+//
+// Chunk c (parity q = c & 1) of k frames:
+//   step lane   T_c: ONE launch steps every env k frames with the state in registers; it writes the k render records R[q][0..k-1]
+//               (record j = the state before frame j), the k step records (straight into a ring of the gather, or an engine-owned
+//               [k][N] array) and the state.  It is ordered behind T_{c-1} by the lane, behind the rasterisers of chunk c-2 (they read
+//               R[q]), behind the collective that last read the ring, behind the caller's readers of output set q.
+//   lanes 0, 1  k plain rasteriser launches, launch j on lane j & 1: R[q][j] -> F[q][j].  They wait for T_c and for nothing else --
+//               and T_{c+1} has the whole length of these k launches to finish beside them.  No launch ever waits for a step that is
+//               running beside a rasteriser (a Breakout step kernel that takes 10 us alone takes 100-250 us there -- what made the
+//               device-side ticket of overlapped fused launches wait for most of the launch before it).
+//   collective  (K-step ring, K = k) behind T_c alone: it runs beside the chunk's rasterisers.
+//   caller      joins lazily (tbx_device_buffer), as with overlapped fused launches.
+static bool rollout_chunks_on(const tbx_engine* e, int channels)
+{
+    const int v = e->opt[TBX_OPT_ROLLOUT_CHUNKS];
+    if (v == 2 || !e->ops->rollout_ok(channels)) return false;
+    if (e->gather && !e->gather_ring) return false;              // one collective per step: k collectives cannot ride on one launch
+    return v == 1 || e->ops->rollout_auto(e->n);
+}
+
+static int chunk_buffers(tbx_engine* e, int q, int k, size_t frame_bytes, bool want_packed, hipStream_t sync_a, hipStream_t sync_b)
+{
+    TbxPipe& p = e->pipe;
+    if (p.chunk_frame_bytes[q] < (size_t)k * frame_bytes) {
+        if (sync_a) EHIP(hipStreamSynchronize(sync_a));
+        if (sync_b) EHIP(hipStreamSynchronize(sync_b));
+        if (p.chunk_frames[q]) hipFree(p.chunk_frames[q]);
+        p.chunk_frames[q] = nullptr;
+        p.chunk_frame_bytes[q] = 0;
+        EHIP(hipMalloc((void**)&p.chunk_frames[q], (size_t)k * frame_bytes));
+        p.chunk_frame_bytes[q] = (size_t)k * frame_bytes;
+    }
+    const size_t pb = sizeof(uint64_t) * (size_t)k * (size_t)e->n;
+    if (want_packed && p.chunk_packed_bytes[q] < pb) {
+        if (sync_a) EHIP(hipStreamSynchronize(sync_a));
+        if (sync_b) EHIP(hipStreamSynchronize(sync_b));
+        if (p.chunk_packed[q]) hipFree(p.chunk_packed[q]);
+        p.chunk_packed[q] = nullptr;
+        p.chunk_packed_bytes[q] = 0;
+        EHIP(hipMalloc((void**)&p.chunk_packed[q], pb));
+        p.chunk_packed_bytes[q] = pb;
+    }
+    return TBX_OK;
+}
+
+static int rollout_chunked(tbx_engine* e, int channels, const ActionSource& src, uint32_t flags, int k, hipStream_t user)
+{
+    int rc = pipe_enter(e, PIPE_ROLLOUT_CHUNKS);
+    if (rc) return rc;
+    TbxPipe& p = e->pipe;
+    const int cur = e->out_par, q = cur ^ 1;                   // this chunk: output set q, record buffer q, frame chunk q
+    hipStream_t ss = p.step_lane;
+    const size_t fb = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
+    rc = chunk_buffers(e, q, k, fb, !e->gather_ring, p.lane[0], p.lane[1]);
+    if (rc) return rc;
+    uint64_t* packed = p.chunk_packed[q];
+    size_t stride = (size_t)e->n;
+    if (e->gather_ring) {
+        rc = tbx_gather_ring_open(e, ss, k, &packed, &stride);
+        if (rc) return rc;
+    }
+    // T_c behind the rasterisers of chunk c - 2, which read the record buffer it rewrites
+    for (int l = 0; l < 2; l++)
+        if (p.chunk_raster_rec[q][l]) EHIP(hipStreamWaitEvent(ss, p.chunk_raster_ev[q][l], 0));
+    // ... and behind the caller's readers of what chunk c - 2 left in output set q (fenced by call c - 1); the same fence holds the
+    // rasterisers below back from the frames those readers may still read.  This call fences the readers of chunk c - 1, if the
+    // caller took an address since (lazy join: no address, no reader)
+    const bool fenced = p.user_step_rec[q];
+    if (fenced) { EHIP(hipStreamWaitEvent(ss, p.user_step_ev[q], 0)); p.user_step_rec[q] = false; }
+    if (p.reader_seen) {
+        EHIP(hipEventRecord(p.user_step_ev[cur], user));
+        p.user_step_rec[cur] = true;
+        p.reader_seen = false;
+    }
+    tbx_set_out_parity(e, q);
+    e->packed = packed + (size_t)(k - 1) * stride;              // TBX_BUF_PACKED: the record of the chunk's last step
+    e->ops->rebind_outputs(e);
+    rc = e->ops->rollout_step(e, src, flags, k, q, packed, stride, ss);
+    if (rc) { tbx_set_out_parity(e, cur); return rc; }
+    EHIP(hipEventRecord(p.chunk_step_ev[q], ss));
+    p.chunk_step_rec[q] = true;
+    bool lane_used[2] = {false, false};
+    for (int j = 0; j < k; j++) {
+        const int l = j & 1;
+        hipStream_t ls = p.lane[l];
+        if (!lane_used[l]) {
+            EHIP(hipStreamWaitEvent(ls, p.chunk_step_ev[q], 0));
+            if (fenced) EHIP(hipStreamWaitEvent(ls, p.user_step_ev[q], 0));
+            lane_used[l] = true;
+        }
+        rc = e->ops->rollout_render(e, p.chunk_frames[q] + (size_t)j * fb, channels, q, j, ls);
+        if (rc) return rc;
+    }
+    for (int l = 0; l < 2; l++) {
+        p.chunk_raster_rec[q][l] = lane_used[l];
+        if (lane_used[l]) EHIP(hipEventRecord(p.chunk_raster_ev[q][l], p.lane[l]));
+    }
+    if (e->gather_ring) {
+        rc = tbx_gather_ring_filled(e, p.chunk_step_ev[q]);
+        if (rc) return rc;
+    }
+    p.chunk_user_waits[q] = false;
+    p.chunk_cur = q; p.chunk_k = k; p.chunk_channels = channels;
+    p.chunk_packed_base = packed; p.chunk_packed_stride = stride;
+    e->frame = p.chunk_frames[q] + (size_t)(k - 1) * fb;        // TBX_BUF_FRAME: the chunk's last frame
+    e->frame_bytes = fb;
+    e->step_carries_order_ev = false;
+    e->last_stream = user;
+    e->has_last = true;
+    return TBX_OK;
+}
+
+// the caller asks where a result of the last chunk lies: the stream that call named now waits for the chunk (its step launch and,
+// for the frames, its rasterisers)
+static int rollout_reader_joins(tbx_engine* e, bool frames)
+{
+    TbxPipe& p = e->pipe;
+    if (!p.active || !p.rollout) return TBX_OK;
+    const int q = p.chunk_cur;
+    EHIP(hipSetDevice(e->device));
+    if (p.chunk_step_rec[q] && !p.chunk_user_waits[q]) EHIP(hipStreamWaitEvent(e->last_stream, p.chunk_step_ev[q], 0));
+    if (frames)
+        for (int l = 0; l < 2; l++)
+            if (p.chunk_raster_rec[q][l]) EHIP(hipStreamWaitEvent(e->last_stream, p.chunk_raster_ev[q][l], 0));
+    p.chunk_user_waits[q] = true;
+    p.reader_seen = true;
     return TBX_OK;
 }
 
@@ -1261,6 +1431,52 @@ int tbx_render_step_synthetic(tbx_engine* e, uint8_t* out_dev, int channels, uin
     return e->ops->step(e, src, flags, s);
 }
 
+int tbx_rollout_synthetic(tbx_engine* e, int channels, uint64_t action_seed, uint64_t t0, int k, uint64_t env_offset, uint32_t flags, void* stream)
+{
+    CHECK_ENGINE(e);
+    if (channels != 1 && channels != 3 && channels != 4) return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+    if (k < 1 || k > 64) return e->fail(TBX_E_INVALID, "tbx_rollout_synthetic: k must be in 1 .. 64");
+    EHIP(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (e->gather_ring && e->gather_ring_every != k)
+        return e->fail(TBX_E_INVALID, "tbx_rollout_synthetic: the chunk must be as long as the gather's record ring (TBX_OPT_GATHER_EVERY)");
+    if (e->gather_ring && tbx_gather_fill(e) != 0)
+        return e->fail(TBX_E_INVALID, "tbx_rollout_synthetic: the record ring is partly filled (finish it with single steps + tbx_gather)");
+    ActionSource src{};
+    src.actions = nullptr;
+    src.seed = action_seed;
+    src.t = t0;
+    src.env_offset = env_offset;
+    src.single_env = -1;
+    if (rollout_chunks_on(e, channels)) return rollout_chunked(e, channels, src, flags, k, s);
+    // everywhere else: the k single calls in stream order, frames into chunk buffer 0, the step records into the ring (K-step ring:
+    // tbx_gather after every step, the k-th one sends it) or copied out of TBX_BUF_PACKED after every step
+    EHIP(tbx_use_stream(e, s));
+    TbxPipe& p = e->pipe;
+    const size_t fb = (size_t)e->n * e->ops->height() * e->ops->width() * channels;
+    int rc = chunk_buffers(e, 0, k, fb, !e->gather_ring, s, nullptr);
+    if (rc) return rc;
+    uint64_t* ring_base = nullptr;
+    for (int j = 0; j < k; j++) {
+        rc = tbx_render_step_synthetic(e, p.chunk_frames[0] + (size_t)j * fb, channels, action_seed, t0 + (uint64_t)j, env_offset, flags, s);
+        if (rc) return rc;
+        if (e->gather_ring) {
+            if (j == 0) ring_base = e->packed;                  // slot 0 of the ring this chunk fills
+            rc = tbx_gather(e, nullptr, s);
+            if (rc) return rc;
+        } else if (e->gather) {
+            rc = tbx_gather(e, nullptr, s);                     // one collective per step
+            if (rc) return rc;
+            EHIP(hipMemcpyAsync(p.chunk_packed[0] + (size_t)j * e->n, e->packed, sizeof(uint64_t) * (size_t)e->n, hipMemcpyDeviceToDevice, s));
+        } else
+            EHIP(hipMemcpyAsync(p.chunk_packed[0] + (size_t)j * e->n, e->packed, sizeof(uint64_t) * (size_t)e->n, hipMemcpyDeviceToDevice, s));
+    }
+    p.chunk_cur = 0; p.chunk_k = k; p.chunk_channels = channels;
+    p.chunk_packed_base = e->gather_ring ? ring_base : p.chunk_packed[0];
+    p.chunk_packed_stride = e->gather_ring ? (size_t)e->gather_ring_width : (size_t)e->n;
+    return TBX_OK;
+}
+
 int tbx_render(tbx_engine* e, uint8_t* out_host, int channels)
 {
     CHECK_ENGINE(e);
@@ -1520,7 +1736,22 @@ int tbx_device_buffer(tbx_engine* e, int which, void** out_ptr, size_t* out_byte
     const size_t N = (size_t)e->n;
     void* p = nullptr;
     size_t b = 0;
+    if ((which >= TBX_BUF_REWARD && which <= TBX_BUF_PACKED) || which == TBX_BUF_ROLLOUT_FRAMES || which == TBX_BUF_ROLLOUT_PACKED) {
+        int rc = fused_reader_joins(e);                                // (overlapped fused launches, rollout chunks: the caller's stream joins here)
+        if (!rc) rc = rollout_reader_joins(e, which == TBX_BUF_FRAME || which == TBX_BUF_ROLLOUT_FRAMES);
+        if (rc) return rc;
+    }
     switch (which) {
+    case TBX_BUF_ROLLOUT_FRAMES:
+        if (!e->pipe.chunk_k) return e->fail(TBX_E_INVALID, "tbx_rollout_synthetic has not been called");
+        p = e->pipe.chunk_frames[e->pipe.chunk_cur];
+        b = (size_t)e->pipe.chunk_k * N * e->ops->height() * e->ops->width() * e->pipe.chunk_channels;
+        break;
+    case TBX_BUF_ROLLOUT_PACKED:
+        if (!e->pipe.chunk_k) return e->fail(TBX_E_INVALID, "tbx_rollout_synthetic has not been called");
+        p = e->pipe.chunk_packed_base;
+        b = sizeof(uint64_t) * (size_t)e->pipe.chunk_k * e->pipe.chunk_packed_stride;
+        break;
     case TBX_BUF_REWARD: p = e->reward; b = N * 4; break;
     case TBX_BUF_DONE: p = e->done; b = N; break;
     case TBX_BUF_LIVES: p = e->lives_out; b = N * 4; break;
@@ -1550,6 +1781,7 @@ int tbx_set_option(tbx_engine* e, int option, int value)
     case TBX_OPT_GATHER_EVERY: ok = value >= 1 && value <= 64; break;
     case TBX_OPT_FUSED_OVERLAP: ok = value >= 0 && value <= 2; break;
     case TBX_OPT_FUSED_OVERLAP_LEAD: ok = value >= 0 && value <= (1 << 20); break;
+    case TBX_OPT_ROLLOUT_CHUNKS: ok = value >= 0 && value <= 2; break;
     default: return e->fail(TBX_E_INVALID, "unknown option");
     }
     if (!ok) return e->fail(TBX_E_INVALID, "option value out of range");
@@ -1570,6 +1802,7 @@ int tbx_get_option(tbx_engine* e, int option, int* value_out)
     if (value_out && option == TBX_OPT_RECORDS_ACTIVE) { *value_out = e->ops->pipeline_ok() ? 1 : 0; return TBX_OK; }
     if (value_out && option == TBX_OPT_RENDER_STEP_FUSED) { *value_out = e->ops->render_step_fused(3) ? 1 : 0; return TBX_OK; }
     if (value_out && option == TBX_OPT_FUSED_OVERLAP_ACTIVE) { *value_out = fused_overlap_on(e, nullptr, 3) ? 1 : 0; return TBX_OK; }
+    if (value_out && option == TBX_OPT_ROLLOUT_CHUNKS_ACTIVE) { *value_out = rollout_chunks_on(e, 3) ? 1 : 0; return TBX_OK; }
     if (option < 0 || option >= TBX_OPT_COUNT || !value_out) return e->fail(TBX_E_INVALID, "unknown option");
     *value_out = e->opt[option];
     return TBX_OK;

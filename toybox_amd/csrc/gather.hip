@@ -328,6 +328,8 @@ int tbx_gather_init(tbx_engine* e, int nranks, int rank, int records_per_rank, c
         e->packed = g.ring[0];
         e->ops->rebind_outputs(e);
         e->gather_ring = true;
+        e->gather_ring_every = g.every;
+        e->gather_ring_width = g.width;
         e->gather_wants_step_event = g.every == 1;
     } else {
         e->gather_wants_step_event = true;
@@ -537,3 +539,46 @@ int tbx_gather_fill(tbx_engine* e)
 }
 
 }  // extern "C"
+
+// ---- a whole ring filled by ONE launch (tbx_rollout_synthetic, engine.hip)
+
+int tbx_gather_ring_open(tbx_engine* e, hipStream_t s, int k, uint64_t** base, size_t* stride)
+{
+    GatherState* g = e->gather;
+    if (!g || g->every < 2) return e->fail(TBX_E_INVALID, "no K-step record ring is in force");
+    if (g->every != k) return e->fail(TBX_E_INVALID, "tbx_rollout_synthetic: the chunk must be as long as the gather's record ring (TBX_OPT_GATHER_EVERY)");
+    if (g->fill != 0) return e->fail(TBX_E_INVALID, "tbx_rollout_synthetic: the record ring is partly filled (finish it with single steps + tbx_gather)");
+    const int p = g->ring_par;
+    g->advance = false;
+    *base = g->ring[p];
+    *stride = (size_t)g->width;
+    if (g->pending[p]) {                                    // the collective that read this ring, 2 K steps ago
+        g->pending[p] = false;
+        if (g->done_on[p] != s) GHIP(hipStreamWaitEvent(s, g->done[p], 0));
+    }
+    return TBX_OK;
+}
+
+int tbx_gather_ring_filled(tbx_engine* e, hipEvent_t filled_ev)
+{
+    GatherState& g = *e->gather;
+    hipStream_t gs = g.stream;
+    const int p = g.ring_par;
+    GHIP(hipStreamWaitEvent(gs, filled_ev, 0));             // the step launch alone: the chunk's rasterisers run beside the collective
+    if (g.any && g.done_on[g.last_par] != gs) GHIP(hipStreamWaitEvent(gs, g.done[g.last_par], 0));
+    if (g.host) {
+        int rc = host_collective(e, g, g.ring[p], g.out, gs);
+        if (rc) return rc;
+    } else
+        GNCCL(g.all_gather(g.ring[p], g.out, (size_t)g.every * (size_t)g.width, TBX_NCCL_UINT64, g.comm, gs));
+    g.last_par = p;
+    GHIP(hipEventRecord(g.done[p], gs));
+    g.done_on[p] = gs;
+    g.pending[p] = true;
+    g.any = true;
+    g.fill = 0;
+    g.advance = true;                                       // a single step that follows opens slot 0 of the other ring
+    g.ring_par = p ^ 1;
+    e->gather_wants_step_event = false;
+    return TBX_OK;
+}

@@ -343,6 +343,23 @@ struct TbxPipe {
     // the STEP BLOCKS of launch N only -- a device counter they bump when their state, records and outputs are written, waited
     // for by a one-wave kernel in front of launch N+1 (tbx_ticket_wait_kernel) -- not behind its rasteriser blocks.
     bool fused = false;                              // the calls since the pipeline was entered are such launches (pipe_enter joins before the kind of call changes)
+    // Rollout chunks (tbx_rollout_synthetic; engine.hip, rollout_chunked): k frames per call.  ONE step launch on the step lane
+    // writes the k render records, the k step records and the state; k plain rasteriser launches alternate between the two lanes,
+    // dependent on that step launch alone -- and the step launch of chunk c+1 runs beside them, a whole chunk ahead of its own
+    // rasterisers: no launch waits for a step that runs beside a rasteriser (what kept overlapped fused launches unstable).
+    bool rollout = false;                            // the calls since the pipeline was entered are rollout chunks
+    hipStream_t step_lane = nullptr;
+    hipEvent_t chunk_step_ev[2] = {nullptr, nullptr};        // behind the step launch of the last chunk of parity q
+    hipEvent_t chunk_raster_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [q][lane]: behind that chunk's last rasteriser launch on the lane
+    bool chunk_step_rec[2] = {false, false}, chunk_raster_rec[2][2] = {{false, false}, {false, false}};
+    bool chunk_user_waits[2] = {false, false};       // the caller's stream has been made to wait for chunk q (lazy join)
+    uint8_t* chunk_frames[2] = {nullptr, nullptr};   // [k][N][H][W][C] frames of the last chunk of parity q
+    size_t chunk_frame_bytes[2] = {0, 0};
+    uint64_t* chunk_packed[2] = {nullptr, nullptr};  // [k][N] step records of that chunk when no gather ring takes them
+    size_t chunk_packed_bytes[2] = {0, 0};
+    int chunk_cur = 0, chunk_k = 0, chunk_channels = 0;      // what TBX_BUF_ROLLOUT_* name: parity, frames and channels of the last chunk
+    uint64_t* chunk_packed_base = nullptr;           // ... and where its step records lie (a ring of the gather, or chunk_packed)
+    size_t chunk_packed_stride = 0;
     hipEvent_t launch_ev[2] = {nullptr, nullptr};    // completion event of the last fused launch on lane k (it rides on the launch)
     bool launch_rec[2] = {false, false};
     unsigned long long* arrive = nullptr;            // device [2]: step blocks of overlapped launches that have finished, ever; launches
@@ -350,6 +367,12 @@ struct TbxPipe {
     unsigned long long arrive_want = 0;              // host: what the launches issued so far add up to
     unsigned long long release_want = 0;
     bool prev_overlapped = false;                    // the call before this one was an overlapped launch (else stream order holds)
+    // The caller's stream joins LAZILY in this mode: it is made to wait for the launch that wrote a result when the caller asks
+    // for the result's address (tbx_device_buffer -- required after every call, the addresses alternate) or makes a call of any
+    // other kind.  A loop that only rolls queues nothing on the caller's stream: with a record gather on the device, a wait and
+    // a fence per call on that stream turned a gain of 4-25 % into a loss of 10-100 % (profiles/r06_experiments.txt).
+    bool user_waits[2] = {false, false};             // the caller's stream has been made to wait for launch_ev[k]
+    bool reader_seen = false;                        // an address was handed out since the last call: the next call fences the caller's stream
 };
 
 // what an overlapped fused launch gets from the engine: the counter its step blocks bump, the event that rides on the launch as
@@ -382,8 +405,9 @@ struct tbx_engine {
     bool has_last = false;
     hipEvent_t order_ev = nullptr;
     bool step_carries_order_ev = false;        // order_ev is the completion event of the last launch on last_stream (a batch step)
-    int opt[TBX_OPT_COUNT] = {0, 0, 0, 0, 1, 1, 0, 0, 0};
+    int opt[TBX_OPT_COUNT] = {0, 0, 0, 0, 1, 1, 0, 0, 0, 0};
     bool gather_ring = false;                  // a K-step record ring is in force (TBX_OPT_GATHER_EVERY > 1 at tbx_gather_init): no pipelined mode
+    int gather_ring_every = 0, gather_ring_width = 0;   // ... its K and its row width in records (tbx_rollout_synthetic)
     bool gather_wants_step_event = false;      // the next batch step is one a collective will wait for: its launch carries the ordering event
     TbxPipe pipe;
     // common device buffers (SoA over envs)
@@ -513,6 +537,26 @@ inline hipError_t tbx_use_stream(tbx_engine* e, hipStream_t s)
                 r = hipStreamWaitEvent(s, p.render_ev[k], 0);
                 if (r != hipSuccess) return r;
             }
+        // ... and overlapped fused launches, which the caller's stream joins lazily (TbxPipe::user_waits): both lanes
+        if (p.fused)
+            for (int k = 0; k < 2; k++)
+                if (p.launch_rec[k] && p.lane[k] != s) {
+                    r = hipStreamWaitEvent(s, p.launch_ev[k], 0);
+                    if (r != hipSuccess) return r;
+                }
+        // ... and rollout chunks: the step lane and the rasterisers of both parities
+        if (p.rollout)
+            for (int q = 0; q < 2; q++) {
+                if (p.chunk_step_rec[q]) {
+                    r = hipStreamWaitEvent(s, p.chunk_step_ev[q], 0);
+                    if (r != hipSuccess) return r;
+                }
+                for (int l = 0; l < 2; l++)
+                    if (p.chunk_raster_rec[q][l]) {
+                        r = hipStreamWaitEvent(s, p.chunk_raster_ev[q][l], 0);
+                        if (r != hipSuccess) return r;
+                    }
+            }
     }
     e->step_carries_order_ev = false;          // whatever this call queues moves the tail
     e->pipe.active = false;
@@ -595,7 +639,16 @@ struct GameOps {
     virtual int render_step(tbx_engine*, uint8_t* /*out_dev*/, int /*channels*/, const ActionSource&, uint32_t /*flags*/, hipStream_t,
                             TbxOverlapLaunch* /*ov*/ = nullptr) { return TBX_E_UNSUPPORTED; }
     // TBX_OPT_FUSED_OVERLAP = 0, the engine's choice: overlap consecutive fused launches for a batch of n envs?
-    virtual bool fused_overlap_auto(int /*n*/) const { return false; }
+    // (gather_kind: 0 no record gather, 1 one collective per step, 2 a K-step ring)
+    virtual bool fused_overlap_auto(int /*n*/, int /*gather_kind*/) const { return false; }
+    // tbx_rollout_synthetic as chunks (TbxPipe::rollout).  rollout_ok(): this engine can right now (canonical state layout, RGB /
+    // RGBA); rollout_auto(): the engine's choice for n envs; rollout_step(): frames t .. t + k - 1 of every env in ONE launch on s --
+    // render record j (the state BEFORE frame j) into the chunk's record buffer of parity q, step record j into packed + j * stride,
+    // the last frame's outputs into tbx_engine::reward / ...; rollout_render(): the rasteriser of record j of parity q into out.
+    virtual bool rollout_ok(int /*channels*/) const { return false; }
+    virtual bool rollout_auto(int /*n*/) const { return false; }
+    virtual int rollout_step(tbx_engine*, const ActionSource&, uint32_t /*flags*/, int /*k*/, int /*q*/, uint64_t* /*packed*/, size_t /*stride*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    virtual int rollout_render(tbx_engine*, uint8_t* /*out*/, int /*channels*/, int /*q*/, int /*j*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
     // batched interventions (include/toybox_amd.h, tbx_edit / tbx_reduce): one kernel over the selected envs
     virtual int edit(tbx_engine* e, int /*op*/, const TbxEditArgs&, const uint8_t* /*mask_dev*/, hipStream_t) { return e->fail(TBX_E_INVALID, "this game has no such edit"); }
     virtual int reduce(tbx_engine* e, int /*query*/, const TbxEditArgs&, double* /*out_dev*/, int /*width*/, hipStream_t) { return e->fail(TBX_E_INVALID, "this game has no such query"); }
@@ -615,6 +668,10 @@ hipError_t tbx_gather_before_step(tbx_engine* e, hipStream_t s);   // a step mus
 void tbx_set_out_parity(tbx_engine* e, int p);                    // engine.hip: which TbxStepOut set the next step writes
 void tbx_set_create_error(const std::string& msg);                 // text behind tbx_last_error(NULL)
 int tbx_gather_buffer(tbx_engine* e, void** out_ptr, size_t* out_bytes);
+// gather.hip, for tbx_rollout_synthetic over a K-step ring: the ring the next K steps fill (stream s is made to wait for the collective
+// that last read it) and, once ONE launch has filled it, the collective behind that launch's event
+int tbx_gather_ring_open(tbx_engine* e, hipStream_t s, int k, uint64_t** base, size_t* stride);
+int tbx_gather_ring_filled(tbx_engine* e, hipEvent_t filled_ev);
 GameOps* tbx_make_breakout_ops();
 GameOps* tbx_make_si_ops();
 GameOps* tbx_make_amidar_ops();

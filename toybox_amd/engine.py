@@ -470,6 +470,14 @@ class Engine:
         self._check(self._lib.tbx_render_step_synthetic(self._h, C.c_void_p(int(out_ptr)) if out_ptr else None, int(channels),
                                                         int(action_seed), int(t), int(env_offset), flags, C.c_void_p(int(stream))))
 
+    def rollout_synthetic(self, action_seed, t0, k, channels=3, env_offset=0, auto_reset=True, stream=0):
+        """tbx_rollout_synthetic: k consecutive render_step_synthetic calls (each followed by gather() under a K-step record ring, K = k)
+        as one -- frames in BUF_ROLLOUT_FRAMES [k, N, H, W, C], step records in BUF_ROLLOUT_PACKED [k, stride].  Where the engine can
+        (Breakout RGB / RGBA) one step launch + k rasteriser launches overlapped on internal streams."""
+        flags = _abi.STEP_AUTO_RESET if auto_reset else 0
+        self._check(self._lib.tbx_rollout_synthetic(self._h, int(channels), int(action_seed), int(t0), int(k), int(env_offset), flags,
+                                                    C.c_void_p(int(stream))))
+
     def device_buffer(self, which):
         p, b = C.c_void_p(), C.c_size_t()
         self._check(self._lib.tbx_device_buffer(self._h, int(which), C.byref(p), C.byref(b)))
