@@ -888,7 +888,7 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
     two-launch loop and the step-only loop beside it (`extras` names which).  Returns a dict (rank 0 assembles the line) or an
     int return code."""
     from toybox_amd import Engine, _abi
-    from toybox_amd.parallel import FileWorld, shard_range
+    from toybox_amd.parallel import FileWorld, rendezvous_key, shard_range
     if scaling == "strong":
         spans = [shard_range(args.envs, world, r) for r in range(world)]
         n_total = args.envs
@@ -902,6 +902,11 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
     eng = _engine(game, n, local_rank)
     eng.seed(SEED_BASE + start)            # env i of this rank: seed 1234 + global index
     eng.new_game()
+    # which device every rank drives, as the engine itself reports it (hipGetDeviceProperties behind tbx_device_identity), gathered
+    # through the rendezvous directory: the line shows that N ranks drove N distinct GPUs, and an RCCL run in which two ranks report
+    # the same PCI address is refused below (VERDICT r05 #4b; per-rank placement as baselines/common/cmd_util.py:31 seeds per rank)
+    ident = dict(eng.device_identity(), rank=rank, local_rank=local_rank, envs=[start, end])
+    ranks = FileWorld(rank, world, key=rendezvous_key() + "_ident_" + tag).allgather(ident) if world > 1 else [ident]
     H, W, C = eng.height, eng.width, args.channels
     render = not args.no_render
     gather = world > 1 or args.with_gather
@@ -915,6 +920,11 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
                 return c, None
             except Exception as ex:
                 return None, (str(ex).splitlines()[0][:200] if str(ex) else repr(ex))
+        pcis = [r_["pci"] for r_ in ranks if r_.get("pci")]
+        if GATHER_TRANSPORT == "rccl" and world > 1 and len(set(pcis)) != len(pcis) and not (args.one_device or os.environ.get("TBX_BENCH_ONE_DEVICE")):
+            print("bench.py: rank %d: two ranks of an RCCL run drive the same device (%s) -- one process per GPU is the contract"
+                  % (rank, ", ".join("rank %d: %s" % (r_["rank"], r_["pci"]) for r_ in ranks)), file=sys.stderr)
+            return 7
         rccl, msg = attempt(GATHER_TRANSPORT, tag)
         # the ranks agree on the outcome through the rendezvous directory (a communicator that came up on some ranks only is no
         # communicator): if RCCL failed anywhere, EVERY rank falls back to the host transport ("a host-staged gather
@@ -961,7 +971,7 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
     rep, launch, mode, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, args.pipeline, t, K, Wm, R, fused=fused)
     res = {"n": n, "n_total": n_total, "start": start, "H": H, "W": W, "C": C, "render": render, "gather": gather, "rccl": rccl,
            "gather_note": gather_note, "rep": rep, "launch": launch, "mode": mode, "fused": fused, "steps": K, "extras": {},
-           "overlapped": LAST_LOOP_FORM["overlapped"], "chunk_k": LAST_LOOP_FORM["chunk_k"]}
+           "overlapped": LAST_LOOP_FORM["overlapped"], "chunk_k": LAST_LOOP_FORM["chunk_k"], "ranks": ranks}
     frame_bytes = H * W * C if render else 0
     if with_extras and "serialised" in extras and (fused or mode != 0):
         # the same engine, two launches per frame in stream order: what a policy-driven loop (actions computed from the frame) gets
@@ -1076,12 +1086,7 @@ def main():
                             % (game, "step + %dx%dx%d uint8 frame render" % (H, W, C) if render else "step-only",
                                args.envs, "per GPU" if args.scaling == "weak" else "in total", args.preroll, SETTLE),
                 "envs_per_gpu": n, "envs_total": n_total, "frame_hwc": [H, W, C] if render else None,
-                "parallelism": (("env-sharded x%d, HOST-STAGED all-gather of 8 B/env records behind the C-ABI (tbx_gather over a POSIX "
-                                 "shared-memory segment, no RCCL: every collective blocks the calling thread until the step has finished "
-                                 "and all ranks have exchanged), one per %d step(s)" % (world, K_ring)) if host_gather else
-                                ("env-sharded x%d, RCCL all-gather of 8 B/env records behind the C-ABI (tbx_gather), %s"
-                                 % (world, gather_overlap_note(K_ring, fused))))
-                               if gather else ("env-sharded x%d, no collective (%s)" % (world, r["gather_note"])) if r["gather_note"] else "single GPU",
+                "parallelism": parallelism_note(world, K_ring, fused, gather, host_gather, r),
                 "algorithmic_bytes_per_env_step": bytes_per_step,
             },
             "loop": {"form": "fused" if fused else "pair", "what": FUSED_NOTE if fused else "tbx_step_synthetic ; tbx_render_device, two launches per frame",
@@ -1092,6 +1097,7 @@ def main():
                          "applies_to": "the two-launch loop form only; see `serialised`"},
             "rccl": r["rccl"] if (r["rccl"] or {}).get("transport") == "rccl" else None,
             "gather": r["rccl"],
+            "ranks": r["ranks"],
         }
         if render:
             out["roofline"] = roofline_object(game, n, frame_bytes, C, fused, mode, r["launch"])
@@ -1154,6 +1160,18 @@ METRIC_VERSION = {"version": 2, "value_is": "strong reading (envs in total), loo
                                                   "a collective every step (N = 1 probe)": "scaling_strong.pair_gather_every_step"}}
 
 
+def parallelism_note(world, K_ring, fused, gather, host_gather, r):
+    if not gather:
+        return ("env-sharded x%d, no collective (%s)" % (world, r["gather_note"])) if r["gather_note"] else "single GPU"
+    if host_gather:
+        fb = (r["rccl"] or {}).get("fallback_from_rccl")
+        head = ("HOST-STAGED FALLBACK (RCCL failed: %s) -- this `value` understates the design by the whole overlap of the collective: " % fb) if fb else ""
+        return head + ("env-sharded x%d, HOST-STAGED all-gather of 8 B/env records behind the C-ABI (tbx_gather over a POSIX shared-memory "
+                       "segment, no RCCL: every collective blocks the calling thread until the step has finished and all ranks have "
+                       "exchanged), one per %d step(s)" % (world, K_ring))
+    return "env-sharded x%d, RCCL all-gather of 8 B/env records behind the C-ABI (tbx_gather), %s" % (world, gather_overlap_note(K_ring, fused))
+
+
 def gather_overlap_note(K_ring, fused):
     if K_ring > 1:
         return ("K-step record ring: one collective per %d steps on the engine's communication stream, overlapping the launches of "
@@ -1164,6 +1182,21 @@ def gather_overlap_note(K_ring, fused):
     return "one collective per step on the engine's communication stream, overlapped with the rasteriser launch that follows the step"
 
 
+def csrc_fingerprint():
+    """sha256 (16 hex digits) over the kernel sources and the header as they lie in this tree -- what a static measurement
+    (profiles/traffic.json) is tied to: a figure measured on other sources is reported as stale.  The same rule
+    is in scripts/summarize_profile.py, which writes the figure."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "toybox_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "toybox_amd", "csrc", "*.hpp")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def roofline_object(game, n, frame_bytes, C, fused, mode, launch):
     """The dominant kernel (rasteriser; fused: rasteriser + step launch) against HBM bandwidth: algorithmic frame bytes of one
     launch over the event-timed launch time of the loop's steady state."""
@@ -1171,7 +1204,7 @@ def roofline_object(game, n, frame_bytes, C, fused, mode, launch):
         return None
     ms = launch["avg_ms"]
     achieved = n * frame_bytes / (ms * 1e-3) / 1e9            # GB/s
-    traffic, source = None, None
+    traffic, source, stale, measured_on = None, None, None, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
@@ -1179,11 +1212,14 @@ def roofline_object(game, n, frame_bytes, C, fused, mode, launch):
             if rec:
                 traffic = rec["hbm_bytes_per_launch"]
                 source = "profiles/traffic.json (static: rocprofv3 PMC pass %s, not measured in this run)" % rec.get("source", "")
+                measured_on = rec.get("csrc_sha16")
+                # stale: the kernel sources of this tree are not the ones the counters were read on (unknown for entries of rounds <= 5)
+                stale = (measured_on != csrc_fingerprint()) if measured_on else None
         except Exception:
             traffic = None
     return {"bound": "hbm", "kernel": "%s render (%d ch)%s" % (game, C, " + step, one launch" if fused else ""),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": source,
+            "traffic": traffic, "traffic_source": source, "traffic_stale": stale, "traffic_measured_on_csrc": measured_on,
             "algorithmic_bytes_per_launch": n * frame_bytes, "avg_launch_ms": ms, "median_launch_ms": launch["median_ms"],
             "min_launch_ms": launch["min_ms"], "max_launch_ms": launch["max_ms"], "launches_timed": launch["launches"],
             "event_spans": launch["spans"], "timing": launch_timing_note(fused, mode)}
@@ -1258,6 +1294,21 @@ def baseline_configs(args, hip):
                                      "whole_step_frac": m["roofline"]["frac"],
                                      "note": "the per-GPU share of BASELINE config 5 (262 144 envs over 8 GPUs) on ONE GPU with the record gather "
                                              "queued over a 1-rank communicator: launch cost of the collective, no wire time"}
+    # BASELINE config 5 as written -- the whole mixed batch of 262 144 envs (87 382 + 87 381 + 87 381) -- on ONE MI355X: ~38 GB of
+    # frames; the denominator any later 8-GPU line of this config needs
+    try:
+        a = argparse.Namespace(**vars(args))
+        a.no_render = False
+        m = mixed_reading(a, 1, 0, 0, 262144, min(max(args.steps, 10), 30), 5, 3, True)
+        cfgs["5_mixed_262144_one_gpu"] = {"value": m["value"], "unit": "env-steps/s", "ms_per_step": m["ms_per_step"], "steps": m["steps"],
+                                          "ms_per_step_min_max": [m["repeats"]["ms_per_step_min"], m["repeats"]["ms_per_step_max"]],
+                                          "segment_sizes": m["config"]["segment_sizes"], "loop": m["loop"], "rccl": m["rccl"],
+                                          "whole_step_frac": m["roofline"]["frac"], "frame_bytes_per_step": m["roofline"]["algorithmic_bytes_per_step"],
+                                          "note": "BASELINE config 5 in full on one GPU: three homogeneous segments on three streams, the record gather "
+                                                  "queued over a 1-rank communicator per segment (K = %d ring); 8 GPUs would each take a 32 768-env "
+                                                  "share of it (5_mixed_32768_per_gpu)" % max(1, args.gather_every)}
+    except Exception as ex:
+        cfgs["5_mixed_262144_one_gpu"] = {"error": repr(ex)[:300]}
     return cfgs
 
 

@@ -342,6 +342,20 @@ int tbx_ale_action_to_buttons(int ale_action);
 size_t tbx_state_size(int game);
 size_t tbx_config_size(int game);
 
+/* Which device an engine drives: one process per GPU shards the batch (cmd_util.py:31 gives every worker its own rank and seed),
+ * and a benchmark line has to show that N ranks drove N DISTINCT GPUs -- bench.py gathers one of these per rank and refuses
+ * (rc 7) when two ranks of an RCCL run report the same PCI address. */
+typedef struct tbx_device_identity {
+    int32_t  ordinal;                 /* HIP device ordinal inside this process (HIP_VISIBLE_DEVICES applied) */
+    int32_t  pci_domain, pci_bus, pci_device;
+    uint64_t total_memory;            /* bytes of device memory */
+    int32_t  compute_units;
+    int32_t  _pad;
+    char     arch[64];                /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+    char     name[64];                /* marketing name */
+} tbx_device_identity_t;
+int tbx_device_identity(tbx_engine* engine, tbx_device_identity_t* out);
+
 /* Create an engine of n_envs envs of one game on HIP device `device`.
  * config_pod may be NULL (game defaults == interventions/defaults/<game>_config_default.json).
  * Every env's simulator RNG starts at config.rand; all envs are then given a first game.

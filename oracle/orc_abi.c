@@ -117,6 +117,18 @@ int tbx_destroy(tbx_engine* e)
     return TBX_OK;
 }
 
+/* the checker has no device: ordinal -1 and an arch string that says so */
+int tbx_device_identity(tbx_engine* e, tbx_device_identity_t* out)
+{
+    if (!e) return TBX_E_INVALID;
+    if (!out) return fail(e, TBX_E_INVALID, "out is NULL");
+    memset(out, 0, sizeof *out);
+    out->ordinal = -1; out->pci_domain = out->pci_bus = out->pci_device = -1;
+    snprintf(out->arch, sizeof out->arch, "cpu-oracle");
+    snprintf(out->name, sizeof out->name, "scalar C restatement (test infrastructure)");
+    return TBX_OK;
+}
+
 int tbx_create(int game, int n, int device, const void* cfg, size_t cfg_size, tbx_engine** out)
 {
     (void)device;

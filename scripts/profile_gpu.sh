@@ -12,6 +12,8 @@ BENCH="python3 $REPO/bench.py --no-cpu-baseline $*"
 # PROFILE_STEPS / PROFILE_WARMUP: the step counts of the traced run (default 100 / 10; "20 5" = the driver's own command)
 TS=${PROFILE_STEPS:-100}; TW=${PROFILE_WARMUP:-10}
 echo "bench.py --no-cpu-baseline $* --steps $TS --warmup $TW" > "$OUT/cmd.txt"
+# the sources these counters are read on (bench.py reports a traffic figure measured on other sources as stale)
+python3 -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.csrc_fingerprint())" > "$OUT/csrc_sha16.txt" 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps $TS --warmup $TW > "$OUT/trace.log" 2>&1
 tail -2 "$OUT/trace.log"
 for CTR in FETCH_SIZE WRITE_SIZE; do

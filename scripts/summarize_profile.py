@@ -131,7 +131,10 @@ def main():
                 traffic = {"hbm_bytes_per_launch": hbm + traffic.get("hbm_bytes_per_launch", 0.0),
                            "fetch_kib_raw": fs + traffic.get("fetch_kib_raw", 0.0), "write_kib_raw": ws + traffic.get("write_kib_raw", 0.0),
                            "correction": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE exact; summed over the launches of one render",
-                           "source": "profiles/%s_summary.md" % tag}
+                           "source": "profiles/%s_summary.md" % tag,
+                           # what the figure is tied to: the kernel sources of the profiled tree and the kernel's register counts
+                           "csrc_sha16": (open(os.path.join(src, "csrc_sha16.txt")).read().strip() or None) if os.path.exists(os.path.join(src, "csrc_sha16.txt")) else None,
+                           "kernel": k, "vgpr": v, "sgpr": s}
             extra = {n: mean(n) for n in c if n not in ("FETCH_SIZE", "WRITE_SIZE", "_dur_us")}
             if extra:
                 lines.append("|  | | | | | " + ", ".join("%s=%.4g" % kv for kv in sorted(extra.items())) + " | | | |")

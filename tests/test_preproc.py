@@ -286,7 +286,8 @@ def test_preproc_vec_env_host_delivery_layouts(name, layout, lib):
         got = infos.with_key("episode")
         assert sorted(got) == [int(i) for i in ended]
         for i in ended:
-            assert got[int(i)] == {"r": float(c["ep_r"][t][i]), "l": int(c["ep_l"][t][i])}
+            ep = got[int(i)]                                 # {"r", "l", "t"}: bench/monitor.py:64; t is wall-clock, the fixture holds r and l
+            assert {k: ep[k] for k in ("r", "l")} == {"r": float(c["ep_r"][t][i]), "l": int(c["ep_l"][t][i])} and ep["t"] >= 0.0
         kept = (obs, np.asarray(obs).copy()) if not m.get("scale") else None
     c.check_states(eng)
     env.close()

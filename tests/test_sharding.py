@@ -475,6 +475,9 @@ class _FakeEngine:
     def gather(self, **k):
         pass
 
+    def get_option(self, option):          # (stream order: neither overlapped fused launches nor rollout chunks)
+        return 0
+
 
 @pytest.mark.parametrize("fused,K", [(True, 20), (True, 5), (True, 1), (False, 20), (False, 3)])
 def test_bench_launch_timing_brackets_runs_never_next_to_a_sync(fused, K):
@@ -519,6 +522,60 @@ def test_bench_launch_timing_brackets_runs_never_next_to_a_sync(fused, K):
             if x[0] == "event":
                 assert seen >= skip
                 break
+
+
+def test_bench_chunk_form_runs_whole_chunks_and_times_one_span_per_region():
+    """bench.py's fused loop as rollout chunks (tbx_rollout_synthetic, round 6): only when every phase is a whole number of chunks and
+    the ring (if any) is as deep as the chunk; a region is K / k chunk calls; its launch timing is ONE span from behind the first
+    chunk to behind the last one, each mark preceded by the address request that joins the caller's stream (lazy join)."""
+    import bench
+    from toybox_amd import _abi
+
+    class Eng(_FakeEngine):
+        ring = 4
+
+        def get_option(self, option):
+            return 1 if option == _abi.OPT_ROLLOUT_CHUNKS_ACTIVE else 0
+
+        def gather_every(self):
+            return self.ring
+
+        def rollout_synthetic(self, seed, t0, k, **kw):
+            _FakeEvent.log.append(("chunk", t0, k))
+            for _ in range(k):
+                _FakeEvent.log.append(("launch",))
+
+        def device_buffer(self, which):
+            _FakeEvent.log.append(("join", which))
+            return 1, 1
+
+    class Hip:
+        Event = _FakeEvent
+
+    class St:
+        ptr = 0
+
+    K, R, k = 20, 3, 4
+    _FakeEvent.log = []
+    loop = bench.Loop(Eng(), Hip, St(), 0, 3, True, True, K, R, fused=True)
+    assert not loop.use_chunks(k, (45, K)) and not loop.use_chunks(k, (44, 18)) and not loop.use_chunks(5, (45, K))   # phases / ring do not fit
+    assert not bench.Loop(Eng(), Hip, St(), 0, 3, True, True, K, R, fused=False).use_chunks(k, (44, K))            # the two-launch loop
+    assert loop.use_chunks(k, (44, K)) and loop.chunk_k == k and loop.overlapped
+    loop.many_steps(0, 44)                                  # settle + warm-up: nothing is timed
+    assert [x for x in _FakeEvent.log if x[0] == "chunk"] == [("chunk", 4 * c, 4) for c in range(11)]
+    assert not any(x[0] in ("event", "join") for x in _FakeEvent.log)
+    loop.arm()
+    for r in range(R):
+        loop.begin_region()
+        at = len(_FakeEvent.log)
+        loop.many_steps(100 * r, K)
+        kinds = [x[0] for x in _FakeEvent.log[at:]]
+        assert kinds.count("chunk") == K // k and kinds.count("event") == 2 and kinds.count("join") == 2
+        first_ev, last_ev = [i for i, x in enumerate(kinds) if x == "event"]
+        assert kinds[first_ev - 1] == "join" and kinds[last_ev - 1] == "join" and last_ev == len(kinds) - 1
+        assert kinds[:first_ev].count("launch") == k        # behind the first chunk
+    per, covered = loop.launch_ms()
+    assert covered == R * (K - k) and all(v == 1.0 for v in per)
 
 
 @pytest.mark.gpu
@@ -623,7 +680,8 @@ def test_gpu_bench_n_process_flow_on_one_device_with_the_host_transport(launcher
     assert g["transport"] == "host" and g["nranks"] == 2 and g["verified"] is True and g["gather_every"] == 4 and g["lib"].startswith("host:")
     assert line["weak"]["gather"]["transport"] == "host" and line["weak"]["envs_total"] == 8192 and line["weak"]["rccl"] is None
     assert 0 < line["share_of_linear"] < 1.5
-    assert "HOST-STAGED" in line["config"]["parallelism"]
+    assert "HOST-STAGED" in line["config"]["parallelism"] and not line["config"]["parallelism"].startswith("HOST-STAGED FALLBACK")   # (asked for, not fallen back to)
+    assert [r_["rank"] for r_ in line["ranks"]] == [0, 1] and line["ranks"][0]["pci"] == line["ranks"][1]["pci"]      # --one-device: both ranks on device 0
     assert line["loop"]["form"] == "fused" and line["roofline"]["avg_launch_ms"] > 0
     assert line["cpu_baseline"]["value"] > 0 and line["check"]["mean_score"] > 0
 
@@ -648,8 +706,11 @@ def test_gpu_bench_default_line_carries_every_arm():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert j["serialised"]["value"] > 0 and j["scaling_strong"]["policy_loop"]["share_of_linear"] > 0.5
     cfg = j["configs"]
-    assert sorted(cfg) == ["2_breakout_4096", "3_space_invaders_4096", "4_amidar_4096", "5_mixed_32768_per_gpu"]
+    assert sorted(cfg) == ["2_breakout_4096", "3_space_invaders_4096", "4_amidar_4096", "5_mixed_262144_one_gpu", "5_mixed_32768_per_gpu"]
     assert all(c["value"] > 1e6 for c in cfg.values()) and cfg["5_mixed_32768_per_gpu"]["segment_sizes"] == [10923, 10923, 10922]
+    assert cfg["5_mixed_262144_one_gpu"]["segment_sizes"] == [87382, 87381, 87381] and 0.3 < cfg["5_mixed_262144_one_gpu"]["whole_step_frac"] < 1.0
+    assert cfg["2_breakout_4096"]["loop"].startswith("fused, rollout chunks")       # (the engine's choice at 4 096 envs)
+    assert len(j["ranks"]) == 1 and j["ranks"][0]["arch"].startswith("gfx950") and j["ranks"][0]["pci"] and j["ranks"][0]["rank"] == 0
     ap = j["agent_path"]
     for game in ("breakout", "space_invaders", "amidar", "gridworld"):
         assert ap[game]["rolled_stack"]["value"] > 1e6 and ap[game]["plane_ring"]["value"] > 0.9 * ap[game]["rolled_stack"]["value"]

@@ -302,6 +302,12 @@ class StepHostOut(C.Structure):
                 ("channels", C.c_int32), ("_pad", C.c_int32)]
 
 
+class DeviceIdentity(C.Structure):
+    """tbx_device_identity_t"""
+    _fields_ = [("ordinal", C.c_int32), ("pci_domain", C.c_int32), ("pci_bus", C.c_int32), ("pci_device", C.c_int32),
+                ("total_memory", C.c_uint64), ("compute_units", C.c_int32), ("_pad", C.c_int32), ("arch", C.c_char * 64), ("name", C.c_char * 64)]
+
+
 _p = C.POINTER
 _vp, _i, _u32, _u64, _sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_size_t
 
@@ -332,6 +338,7 @@ PROTOTYPES = {
     "tbx_get_scalars": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "tbx_render": (_i, [_vp, _vp, _i]),
     "tbx_render_device": (_i, [_vp, _vp, _i, _vp]),
+    "tbx_device_identity": (_i, [_vp, _vp]),
     "tbx_render_step_synthetic": (_i, [_vp, _vp, _i, _u64, _u64, _u64, _u32, _vp]),
     "tbx_rollout_synthetic": (_i, [_vp, _i, _u64, _u64, _i, _u64, _u32, _vp]),
     "tbx_render_env": (_i, [_vp, _i, _vp, _i]),

@@ -332,6 +332,22 @@ int tbx_destroy(tbx_engine* e)
     return TBX_OK;
 }
 
+int tbx_device_identity(tbx_engine* e, tbx_device_identity_t* out)
+{
+    CHECK_ENGINE(e);
+    if (!out) return e->fail(TBX_E_INVALID, "out is NULL");
+    hipDeviceProp_t prop;
+    EHIP(hipGetDeviceProperties(&prop, e->device));
+    memset(out, 0, sizeof *out);
+    out->ordinal = e->device;
+    out->pci_domain = prop.pciDomainID; out->pci_bus = prop.pciBusID; out->pci_device = prop.pciDeviceID;
+    out->total_memory = (uint64_t)prop.totalGlobalMem;
+    out->compute_units = prop.multiProcessorCount;
+    snprintf(out->arch, sizeof out->arch, "%s", prop.gcnArchName);
+    snprintf(out->name, sizeof out->name, "%s", prop.name);
+    return TBX_OK;
+}
+
 int tbx_create(int game, int n_envs, int device, const void* config_pod, size_t config_size, tbx_engine** out)
 {
     if (!out) return TBX_E_INVALID;

@@ -470,6 +470,14 @@ class Engine:
         self._check(self._lib.tbx_render_step_synthetic(self._h, C.c_void_p(int(out_ptr)) if out_ptr else None, int(channels),
                                                         int(action_seed), int(t), int(env_offset), flags, C.c_void_p(int(stream))))
 
+    def device_identity(self):
+        """tbx_device_identity: which device this engine drives -- {"ordinal", "pci" ("dddd:bb:dd"), "arch", "name", "total_memory",
+        "compute_units"}; the CPU checker reports ordinal -1 and arch "cpu-oracle"."""
+        d = _abi.DeviceIdentity()
+        self._check(self._lib.tbx_device_identity(self._h, C.byref(d)))
+        return {"ordinal": int(d.ordinal), "pci": "%04x:%02x:%02x" % (d.pci_domain & 0xFFFF, d.pci_bus & 0xFF, d.pci_device & 0xFF) if d.ordinal >= 0 else None,
+                "arch": d.arch.decode(), "name": d.name.decode(), "total_memory": int(d.total_memory), "compute_units": int(d.compute_units)}
+
     def rollout_synthetic(self, action_seed, t0, k, channels=3, env_offset=0, auto_reset=True, stream=0):
         """tbx_rollout_synthetic: k consecutive render_step_synthetic calls (each followed by gather() under a K-step record ring, K = k)
         as one -- frames in BUF_ROLLOUT_FRAMES [k, N, H, W, C], step records in BUF_ROLLOUT_PACKED [k, stride].  Where the engine can

@@ -164,6 +164,37 @@ class FileWorld:
     def barrier(self):
         self.allreduce_max(0.0)
 
+    def allgather(self, obj):
+        """every rank's JSON-serialisable `obj`, in rank order (the same files-in-a-directory exchange as allreduce_max)"""
+        import json
+        if self.world == 1:
+            return [obj]
+        self.seq += 1
+        mine = "%s_%d_%d" % (self.base, self.seq, self.rank)
+        tmp = mine + ".tmp"
+        with open(tmp, "w") as f:
+            f.write(json.dumps(obj))
+        os.replace(tmp, mine)
+        deadline = time.monotonic() + self.timeout
+        vals = []
+        for r in range(self.world):
+            path = "%s_%d_%d" % (self.base, self.seq, r)
+            while True:
+                try:
+                    with open(path) as f:
+                        vals.append(json.loads(f.read()))
+                    break
+                except (FileNotFoundError, ValueError):
+                    if time.monotonic() > deadline:
+                        raise TimeoutError("rank %d: rank %d never reached step %d of the file exchange" % (self.rank, r, self.seq))
+                    time.sleep(0.0005)
+        if self.seq > 1:
+            try:
+                os.unlink("%s_%d_%d" % (self.base, self.seq - 1, self.rank))
+            except OSError:
+                pass
+        return vals
+
 
 class HostGather:
     """Fallback exchange when RCCL is not available: the 8-byte records are gathered on the host through a
