@@ -14,6 +14,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU side of a parity test is what takes the time (GPUTEST_r05: 822 s of the driver's 1 200 s; the SpaceInvaders agent
+    # pipeline of the checker alone 20-30 s per test on ONE thread): the checker's batch loops are OpenMP-parallel over envs when
+    # TBX_ORACLE_THREADS says so at engine creation, and envs never interact -- results do not depend on the thread count
+    # (tests/test_oracle_golden.py::test_checker_results_do_not_depend_on_its_thread_count).  Every test engine gets the usable cores.
+    os.environ.setdefault("TBX_ORACLE_THREADS", str(max(1, min(16, len(os.sched_getaffinity(0))))))
 
 
 def _build(directory, target):
