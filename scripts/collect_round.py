@@ -164,6 +164,8 @@ def main():
                        ("host_rates.txt", host_rates(tag)), ("rehearsal.txt", rehearsal(tag)),
                        ("agent_diag.txt", cat_files(tag, "agent_diag_*.txt", "# scripts/agent_diag.sh: the fused agent observation kernel of SpaceInvaders with parts switched off (DIAG build), time per agent step and SQ counters per launch")),
                        ("write_align.txt", cat_files(tag, "write_align.txt", "# scripts/ubench/write_align.hip")),
+                       ("rollout_forms.txt", cat_files(tag, "rollout_forms.txt", "# scripts/rollout_ab.py: the random-rollout loop of ONE engine in stream order / overlapped behind the device-side ticket / as rollout chunks of 4, interleaved, ms per step (first block: K = 4 record ring, second: no gather)")),
+                       ("fused_lib_ab.txt", cat_files(tag, "fused_lib_ab.txt", "# scripts/fused_lib_ab.py: the fused loop of the previous round's build (A) and of this build (B), interleaved on one box")),
                        ("bench_lines.md", bench_lines(tag))):
         with open(os.path.join(dst, "%s_%s" % (tag, name)), "w") as fh:
             fh.write(text + ("\n" if not text.endswith("\n") else ""))

@@ -2,8 +2,8 @@
 # Everything DESIGN.md section 6 quotes, measured in ONE gpurun call on ONE box (boxes differ by up to ~15 %, so numbers of
 # different calls are not comparable): bench lines per game / batch size / protocol, the N-process dress rehearsal on one GPU,
 # loop-form sweeps, rocprofv3 kernel-trace + PMC passes, rasterisers against the previous round's build.
-# usage (on the GPU box): bash scripts/measure_round.sh r05        then, back home: python scripts/collect_round.py r05
-TAG=${1:-r05}
+# usage (on the GPU box): bash scripts/measure_round.sh r06        then, back home: python scripts/collect_round.py r06
+TAG=${1:-r06}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -41,6 +41,13 @@ done
 python bench.py --protocol host --game breakout --envs 64 --steps 200 --warmup 20 > "$OUT/host_breakout_64envs.json" 2>/dev/null
 # ---- loop forms and ring depths against each other, interleaved in one process
 timeout 400 python scripts/strong_sweep.py breakout 4096 8192 65536 2>&1 | grep '^{' > "$OUT/sweep_breakout.txt"
+# ---- round 6: the random-rollout loop in stream order / overlapped behind the ticket / as rollout chunks, ONE engine per process
+for g in 1 0; do RA_GATHER=$g timeout 300 python scripts/rollout_ab.py 2048 4096 8192 16384 65536 2>&1 | grep '^{' >> "$OUT/rollout_forms.txt"; done
+$B --envs 4096 --steps 400 --rollout-chunks off --fused-overlap off --no-extras > "$OUT/bench_breakout_4096_stream_order.json" 2>/dev/null
+$B --envs 4096 --steps 400 --rollout-chunks off --fused-overlap on --no-extras > "$OUT/bench_breakout_4096_ticket.json" 2>/dev/null
+$B --envs 8192 --with-gather --no-extras --steps 400 --rollout-chunks on > "$OUT/bench_breakout_8192_gather_chunks.json" 2>/dev/null
+# ... and this build against the previous round's on the headline loop (stream order at 65 536 envs)
+timeout 300 python scripts/fused_lib_ab.py scripts/ab/lib_prev.so toybox_amd/csrc/libtoybox_amd.so 65536 4096 2>&1 | grep '^{' > "$OUT/fused_lib_ab.txt"
 # ---- the rasterisers (and [step ; render]) against the previous round's build, interleaved
 for g in breakout space_invaders amidar; do
   AB_PREROLL=400 timeout 300 python scripts/ab_render.py $g 3 scripts/ab/lib_prev.so toybox_amd/csrc/libtoybox_amd.so > "$OUT/ab_render_$g.txt" 2>&1
