@@ -634,10 +634,13 @@ class Loop:
                     # the 65 536-env step and 5 % of the 8 192-env one)
     SKIP = 2        # launches after a region's opening synchronisation that no event pair covers
 
-    def __init__(self, eng, hip, stream, start, channels, gather, render, K, R, fused=False):
+    def __init__(self, eng, hip, stream, start, channels, gather, render, K, R, fused=False, rollout=None):
         from toybox_amd import _abi
         self.eng, self.sp, self.start, self.C, self.gather, self.render = eng, stream.ptr, start, channels, gather, render
         self.fused = bool(fused and render)
+        # a random rollout (actions do not depend on the frame): the arm may run as rollout chunks even where the single call is two
+        # launches (SpaceInvaders); default: wherever the fused call is asked for
+        self.rollout = self.fused if rollout is None else bool(rollout and render)
         # overlapped fused launches (TBX_OPT_FUSED_OVERLAP): the caller's stream joins lazily -- when an address is asked for.  A mark
         # there is a join + a timing event + (next call) a fence for the lane: measured at 8 192 envs, a mark every 8 launches cost the
         # loop 4-6 % (0.1715 against 0.1576 ms per step with the K = 4 ring) -- so an overlapped region is ONE span, two marks
@@ -713,7 +716,7 @@ class Loop:
     def use_chunks(self, k, phases):
         """switch to the chunk form if the engine runs it overlapped and every phase length in `phases` is a multiple of k"""
         from toybox_amd import _abi
-        if not self.fused or k < 2 or any(p % k for p in phases):
+        if not self.rollout or k < 2 or any(p % k for p in phases):
             return False
         if self.eng.get_option(_abi.OPT_ROLLOUT_CHUNKS_ACTIVE) != 1:
             return False
@@ -766,7 +769,7 @@ class Loop:
 SETTLE = 40     # untimed full steps of the loop form about to be timed, in front of its W warm-up steps (--settle)
 
 
-def timed_arm(eng, hip, reg, stream, start, C, gather, render, pipeline, t, K, Wm, R, fused=False):
+def timed_arm(eng, hip, reg, stream, start, C, gather, render, pipeline, t, K, Wm, R, fused=False, rollout=None):
     """SETTLE untimed steps + W warm-up steps + R regions of K steps with TBX_OPT_PIPELINE = pipeline (pair form) or the fused
     call.  Returns (summary, launch timing dict or None, resolved pipeline mode, next t).
     Why the settle steps: the pre-roll is 1 000 ten-microsecond step kernels, and the first dozen rasteriser launches behind it
@@ -778,7 +781,7 @@ def timed_arm(eng, hip, reg, stream, start, C, gather, render, pipeline, t, K, W
     eng.set_option(_abi.OPT_FUSED_OVERLAP, {"auto": _abi.FUSED_OVERLAP_AUTO, "on": _abi.FUSED_OVERLAP_ON, "off": _abi.FUSED_OVERLAP_OFF}[FUSED_OVERLAP])
     mode = eng.get_option(_abi.OPT_PIPELINE_ACTIVE)
     eng.set_option(_abi.OPT_ROLLOUT_CHUNKS, {"auto": _abi.ROLLOUT_CHUNKS_AUTO, "on": _abi.ROLLOUT_CHUNKS_ON, "off": _abi.ROLLOUT_CHUNKS_OFF}[ROLLOUT_CHUNKS])
-    loop = Loop(eng, hip, stream, start, C, gather, render, K, R, fused=fused)
+    loop = Loop(eng, hip, stream, start, C, gather, render, K, R, fused=fused, rollout=rollout)
     chunked = loop.use_chunks(CHUNK_K, (SETTLE + Wm, K))
     if chunked:
         loop.many_steps(t, SETTLE + Wm)
@@ -968,12 +971,13 @@ def run_reading(args, hip, game, rank, world, local_rank, scaling, tag, with_ext
         eng.step_synthetic(ACTION_SEED, t, env_offset=start, auto_reset=True, stream=stream.ptr)
         t += 1
     fused = render and args.loop != "pair" and C >= 3 and eng.get_option(_abi.OPT_RENDER_STEP_FUSED) == 1
-    rep, launch, mode, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, args.pipeline, t, K, Wm, R, fused=fused)
+    rep, launch, mode, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, args.pipeline, t, K, Wm, R, fused=fused,
+                                     rollout=render and args.loop != "pair")
     res = {"n": n, "n_total": n_total, "start": start, "H": H, "W": W, "C": C, "render": render, "gather": gather, "rccl": rccl,
            "gather_note": gather_note, "rep": rep, "launch": launch, "mode": mode, "fused": fused, "steps": K, "extras": {},
            "overlapped": LAST_LOOP_FORM["overlapped"], "chunk_k": LAST_LOOP_FORM["chunk_k"], "ranks": ranks}
     frame_bytes = H * W * C if render else 0
-    if with_extras and "serialised" in extras and (fused or mode != 0):
+    if with_extras and "serialised" in extras and (fused or mode != 0 or LAST_LOOP_FORM["chunk_k"]):
         # the same engine, two launches per frame in stream order: what a policy-driven loop (actions computed from the frame) gets
         srep, sl, _, t = timed_arm(eng, hip, reg, stream, start, C, gather, render, 0, t, K, Wm, R, fused=False)
         sms = srep["ms_per_step_median"]
@@ -1089,7 +1093,8 @@ def main():
                 "parallelism": parallelism_note(world, K_ring, fused, gather, host_gather, r),
                 "algorithmic_bytes_per_env_step": bytes_per_step,
             },
-            "loop": {"form": "fused" if fused else "pair", "what": FUSED_NOTE if fused else "tbx_step_synthetic ; tbx_render_device, two launches per frame",
+            "loop": {"form": "chunks" if r["chunk_k"] else "fused" if fused else "pair",
+                     "what": FUSED_NOTE if fused else "tbx_step_synthetic ; tbx_render_device, two launches per frame",
                      "overlapped": r["overlapped"], "chunk_k": r["chunk_k"],
                      "overlap": (CHUNK_NOTE % ((r["chunk_k"],) * 5)) if r["chunk_k"] else OVERLAP_NOTE if r["overlapped"] else
                      ("stream order (--fused-overlap %s; the engine overlaps consecutive fused launches / runs rollout chunks up to 4 096 envs -- see configs)" % FUSED_OVERLAP if fused else None)},
@@ -1272,7 +1277,7 @@ def baseline_configs(args, hip):
         fb = r["H"] * r["W"] * r["C"]
         e = {"value": r["n"] / (ms * 1e-3), "unit": "env-steps/s", "ms_per_step": ms, "steps": a.steps, "repeats": r["rep"]["n"],
              "ms_per_step_min_max": [r["rep"]["ms_per_step_min"], r["rep"]["ms_per_step_max"]],
-             "loop": (("fused, rollout chunks of %d" % r["chunk_k"]) if r["chunk_k"] else "fused, overlapped launches" if r["overlapped"] else "fused") if r["fused"] else "pair",
+             "loop": ("rollout chunks of %d" % r["chunk_k"]) if r["chunk_k"] else ("fused, overlapped launches" if r["overlapped"] else "fused") if r["fused"] else "pair",
              "pipeline_resolved": r["mode"],
              "whole_step_frac": r["n"] * fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
              # (overlapped launches -- TBX_OPT_PIPELINE 3, TBX_OPT_FUSED_OVERLAP: an event pair on the caller's stream does not bracket a
@@ -1339,8 +1344,8 @@ def strong_share_probe(args, game, C, n_single, single_value, single_pair_value)
         rep, launch, mode, _ = timed_arm(eng, hip, reg, st, 0, C, True, True, args.pipeline, args.preroll, K, 20, 5, fused=fused)
         v = n / (rep["ms_per_step_median"] * 1e-3)
         res[key] = {"value": v, "ms_per_step": rep["ms_per_step_median"], "repeats": rep,
-                    "loop": (("fused, rollout chunks of %d" % LAST_LOOP_FORM["chunk_k"]) if LAST_LOOP_FORM["chunk_k"] else
-                             "fused, overlapped launches" if LAST_LOOP_FORM["overlapped"] else "fused") if fused else "pair",
+                    "loop": ("rollout chunks of %d" % LAST_LOOP_FORM["chunk_k"]) if LAST_LOOP_FORM["chunk_k"] else
+                            ("fused, overlapped launches" if LAST_LOOP_FORM["overlapped"] else "fused") if fused else "pair",
                     "gather_every": eng.gather_every(), "pipeline_resolved": mode, "avg_launch_ms": launch["avg_ms"] if launch else None,
                     "share_of_linear": v / (single_value if key == "main" else single_pair_value),
                     "share_of": "value" if key == "main" else "serialised (the two-launch loop on the whole batch)"}

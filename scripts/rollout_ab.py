@@ -20,9 +20,10 @@ if os.environ.get("RA_LIB"):                       # another build (the DIAG bui
 sizes = [int(v) for v in sys.argv[1:]] or [4096, 8192]
 rounds, k, G = int(os.environ.get("RA_ROUNDS", "5")), int(os.environ.get("RA_K", "4")), int(os.environ.get("RA_GATHER", "1"))
 forms = os.environ.get("RA_FORMS", "order,ticket,chunks").split(",")
+GAME = os.environ.get("RA_GAME", "breakout")
 for n in sizes:
     K = max(40, min(400, 40 * 65536 // n // 4)) * k              # steps per timed region, a multiple of k
-    e = Engine("breakout", n, lib=LIB)
+    e = Engine(GAME, n, lib=LIB)
     e.seed(1234); e.new_game()
     if G:
         e.set_option(_abi.OPT_GATHER_EVERY, k)
@@ -35,7 +36,7 @@ for n in sizes:
 
     def run(form, steps):
         global t
-        if form == "pair":                                       # the policy loop: two launches per step in stream order
+        if form in ("pair", "pipe"):                             # the policy loop: two launches per step (pipe: TBX_OPT_PIPELINE = the engine's choice)
             for _ in range(steps):
                 e.step_synthetic(1337, t, auto_reset=True, stream=st.ptr); t += 1
                 if G:
@@ -54,6 +55,7 @@ for n in sizes:
         for form in forms:
             e.set_option(_abi.OPT_FUSED_OVERLAP, _abi.FUSED_OVERLAP_ON if form == "ticket" else _abi.FUSED_OVERLAP_OFF)
             e.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_ON)
+            e.set_option(_abi.OPT_PIPELINE, 1 if form == "pipe" else 0)
             run(form, 10 * k)
             hip.synchronize()
             w0 = time.perf_counter()
@@ -62,7 +64,7 @@ for n in sizes:
             out.setdefault(form, []).append(1000.0 * (time.perf_counter() - w0) / K)
     H, W = e.height, e.width
     base = sorted(out[forms[0]])[len(out[forms[0]]) // 2]
-    line = {"envs": n, "k": k, "gather_ring": bool(G), "steps": K, "lib": os.environ.get("RA_LIB", "product"), "lane_priority": os.environ.get("TBX_LANE_PRIORITY", "high")}
+    line = {"game": GAME, "envs": n, "k": k, "gather_ring": bool(G), "steps": K, "lib": os.environ.get("RA_LIB", "product"), "lane_priority": os.environ.get("TBX_LANE_PRIORITY", "high")}
     for f, v in out.items():
         med = sorted(v)[len(v) // 2]
         line[f] = {"median": round(med, 4), "min": round(min(v), 4), "max": round(max(v), 4), "vs_first": round(med / base - 1.0, 4),

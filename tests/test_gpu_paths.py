@@ -1025,16 +1025,18 @@ def test_rollout_synthetic_call_contract(game, lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,channels,K,ring", [(8192, 3, 4, True), (4096, 4, 4, False), (700, 3, 3, True), (20000, 3, 5, True), (3000, 3, 2, False)])
-def test_rollout_chunks_equal_oracle(n, channels, K, ring, hip_lib, oracle_lib):
+@pytest.mark.parametrize("game,n,channels,K,ring", [("breakout", 8192, 3, 4, True), ("breakout", 4096, 4, 4, False), ("breakout", 700, 3, 3, True),
+                                                    ("breakout", 20000, 3, 5, True), ("breakout", 3000, 3, 2, False),
+                                                    ("space_invaders", 4096, 3, 4, True), ("space_invaders", 900, 1, 3, False), ("space_invaders", 9000, 4, 2, True)])
+def test_rollout_chunks_equal_oracle(game, n, channels, K, ring, hip_lib, oracle_lib):
     """Rollout chunks on the device (one step launch on the step lane + k rasteriser launches on two lanes, TBX_OPT_ROLLOUT_CHUNKS)
-    against the oracle's k single calls: EVERY chunk's step records (all envs), last-step outputs and sampled frames, read by
+    against the oracle's k single calls (Breakout: one multi-frame step launch per chunk; SpaceInvaders: the record of the current state
+    and the k single-frame step launches back to back on the step lane): EVERY chunk's step records (all envs), last-step outputs and sampled frames, read by
     copies queued on the caller's stream right behind tbx_device_buffer (the lazy join) and therefore before the next chunk is
     issued; the two chunk buffers alternate; under a K-step ring the gathered block of every chunk; joins (a host step, a state
     write, a single fused call, the option off for a chunk) in between; final states.  8 192 envs + K = 4 ring is the per-GPU
     share of the strong-scaled headline batch."""
     from toybox_amd import hip
-    game = "breakout"
     g, o = _pair(game, n, hip_lib, oracle_lib, seed=33)
     H, W = g.height, g.width
     fb = H * W * channels

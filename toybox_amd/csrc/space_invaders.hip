@@ -1820,6 +1820,8 @@ struct SiOps : GameOps {
     bool plain = true;          // every state's ids, points and laser constants are what si_load_canonical derives (is_plain)
     bool want_recs = false;     // a batch render has been asked for since creation: steps leave records from now on (a loop that
                                 // never renders keeps the 12 us the record costs the step kernel: 61 against 50 us at 65 536 envs)
+    SiRenderRec* recs_chunk[2] = {nullptr, nullptr};   // [k][N] records of a rollout chunk of parity q (tbx_rollout_synthetic), made on first use
+    int recs_chunk_k[2] = {0, 0};
 
     int height() const override { return TBX_SI_H; }
     int width() const override { return TBX_SI_W; }
@@ -1860,7 +1862,7 @@ struct SiOps : GameOps {
 
     void destroy(tbx_engine*) override
     {
-        hipFree(recs); hipFree(recs_other);
+        hipFree(recs); hipFree(recs_other); hipFree(recs_chunk[0]); hipFree(recs_chunk[1]);
         hipFree(d.sc); hipFree(d.enemies); hipFree(d.shields); hipFree(d.lasers);
         hipFree(dA.sc); hipFree(dA.enemies); hipFree(dA.shields); hipFree(dA.lasers);
         hipFree(dB.sc); hipFree(dB.enemies); hipFree(dB.shields); hipFree(dB.lasers);
@@ -2006,6 +2008,62 @@ struct SiOps : GameOps {
         return render_impl(e, src, d, source ? pick_live : nullptr, out_dev, channels, 0, e->n, s);
     }
 
+    // ---- rollout chunks (engine.hip, rollout_chunked): the step lane runs the record of the current state and then the k single-frame
+    // step launches of the chunk back to back, step j leaving the record of frame j + 1 in the chunk's buffer; the k rasteriser
+    // launches on the two lanes read them.  (No multi-frame kernel: the wave-per-env step keeps its state in HBM rows anyway.)
+    bool rollout_ok(int) const override { return pipeline_ok(); }
+    // scripts/rollout_ab.py (RA_GAME=space_invaders), k = 4, ms per step, single calls in stream order / the pipelined two-launch loop
+    // (the engine's choice, off under a record ring) / chunks; no gather | K = 4 ring (r06_rollout_ab_si.txt): 2 048 envs 0.0918 / 0.0793 /
+    // 0.0736 | 0.0972 / 0.0972 / 0.0809; 4 096: 0.1614 / 0.1481 / 0.1439 | 0.1658 / 0.1658 / 0.1487; 8 192: 0.3080 / 0.2966 / 0.2950 |
+    // 0.3124 / 0.3119 / 0.2950; 16 384: 0.5943 / 0.5987 / 0.5950 | 0.6010 / 0.6026 / 0.6301
+    bool rollout_auto(int n) const override { return n <= 8192; }
+    int rollout_step(tbx_engine* e, const ActionSource& src, uint32_t flags, int k, int q, uint64_t* packed, size_t stride, hipStream_t s) override
+    {
+        const size_t N = (size_t)e->n;
+        if (recs_chunk_k[q] < k) {                             // (the caller has made sure nothing reads the old buffer any more)
+            TBX_HIP(hipStreamSynchronize(s));
+            hipFree(recs_chunk[q]);
+            recs_chunk[q] = nullptr;
+            recs_chunk_k[q] = 0;
+            TBX_HIP(hipMalloc((void**)&recs_chunk[q], sizeof(SiRenderRec) * (size_t)k * N));
+            recs_chunk_k[q] = k;
+        }
+        hipLaunchKernelGGL(si_rec_prep_kernel, grid_for(e->n), dim3(TBX_BLOCK), 0, s, d, recs_chunk[q], 0, e->n);
+        for (int j = 0; j < k; j++) {
+            SiDev dj = d;
+            dj.packed = packed + (size_t)j * stride;
+            ActionSource sj = src;
+            sj.t = src.t + (uint64_t)j;
+            SiRenderRec* const wr = j + 1 < k ? recs_chunk[q] + (size_t)(j + 1) * N : nullptr;
+            if (plain) hipLaunchKernelGGL(si_step_kernel<true>, grid_for(e->n), dim3(TBX_BLOCK), 0, s, dj, c, sj, flags, 0, e->n, wr);
+            else hipLaunchKernelGGL(si_step_kernel<false>, grid_for(e->n), dim3(TBX_BLOCK), 0, s, dj, c, sj, flags, 0, e->n, wr);
+        }
+        TBX_HIP(hipGetLastError());
+        recs_valid = false;                                    // the single-frame records no longer show the state
+        return TBX_OK;
+    }
+    int rollout_render(tbx_engine* e, uint8_t* out, int channels, int q, int j, hipStream_t s) override
+    {
+        return launch_rec_render(e, recs_chunk[q] + (size_t)j * (size_t)e->n, out, channels, 0, e->n, s);
+    }
+
+    int launch_rec_render(tbx_engine* e, const SiRenderRec* rr, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s)
+    {
+        // waves per frame: the set-up is light (a record, ~300 instructions), so RGB frames are cut finer than the
+        // state-reading rasteriser could afford: 35 six-row units over twelve waves (measured 3 / 5 / 7 / 9 / 12 / 18 / 35 waves per frame:
+        // 2.45 / 2.50 / 2.49 / 2.49 / 2.43 / 2.49 / 3.67 ms at 65 536 envs, 0.174 / 0.171 / 0.166 / 0.164 / 0.151 / 0.167 / 0.238 ms at 4 096)
+        const int split_opt = e->opt[TBX_OPT_RENDER_SPLIT];
+        const int split = split_opt > 0 ? split_opt : channels == 3 ? 12 : (channels == 4 && n_envs <= 32768) ? 5 : (channels == 1 && n_envs <= 4096) ? 4 : 1;   // (gray, small batches: 0.035 against 0.067 ms at 1 024 envs, 0.094 against 0.102 at 4 096)
+        switch (channels) {
+        case 1: hipLaunchKernelGGL(si_rec_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, rr, out_dev, first_env, n_envs, split); break;
+        case 3: hipLaunchKernelGGL(si_rec_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, rr, out_dev, first_env, n_envs, split); break;
+        case 4: hipLaunchKernelGGL(si_rec_render_kernel<4>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, rr, out_dev, first_env, n_envs, split); break;
+        default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
+        }
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
     int render(tbx_engine* e, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s) override
     {
         if (custom) return render_impl(e, d, d, nullptr, out_dev, channels, first_env, n_envs, s);
@@ -2015,19 +2073,7 @@ struct SiOps : GameOps {
             TBX_HIP(hipGetLastError());
             if (first_env == 0 && n_envs == e->n) recs_valid = true;
         }
-        // waves per frame: the set-up is light (a record, ~300 instructions), so RGB frames are cut finer than the
-        // state-reading rasteriser could afford: 35 six-row units over twelve waves (measured 3 / 5 / 7 / 9 / 12 / 18 / 35 waves per frame:
-        // 2.45 / 2.50 / 2.49 / 2.49 / 2.43 / 2.49 / 3.67 ms at 65 536 envs, 0.174 / 0.171 / 0.166 / 0.164 / 0.151 / 0.167 / 0.238 ms at 4 096)
-        const int split_opt = e->opt[TBX_OPT_RENDER_SPLIT];
-        const int split = split_opt > 0 ? split_opt : channels == 3 ? 12 : (channels == 4 && n_envs <= 32768) ? 5 : (channels == 1 && n_envs <= 4096) ? 4 : 1;   // (gray, small batches: 0.035 against 0.067 ms at 1 024 envs, 0.094 against 0.102 at 4 096)
-        switch (channels) {
-        case 1: hipLaunchKernelGGL(si_rec_render_kernel<1>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, out_dev, first_env, n_envs, split); break;
-        case 3: hipLaunchKernelGGL(si_rec_render_kernel<3>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, out_dev, first_env, n_envs, split); break;
-        case 4: hipLaunchKernelGGL(si_rec_render_kernel<4>, grid_for(n_envs * split), dim3(TBX_BLOCK), 0, s, recs, out_dev, first_env, n_envs, split); break;
-        default: return e->fail(TBX_E_INVALID, "channels must be 1, 3 or 4");
-        }
-        TBX_HIP(hipGetLastError());
-        return TBX_OK;
+        return launch_rec_render(e, recs, out_dev, channels, first_env, n_envs, s);
     }
 
     int render_impl(tbx_engine* e, const SiDev& src, const SiDev& alt, const uint8_t* pick_alt, uint8_t* out_dev, int channels, int first_env,
