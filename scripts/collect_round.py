@@ -142,7 +142,7 @@ def rehearsal(tag):
 PROFILES = [  # (profile tag suffix, traffic key, kernel substring)
     ("", "breakout_render_3ch_65536_fused", "render_step_kernel<3"), ("_pair", "breakout_render_3ch_65536", "render_kernel<3"),
     ("_space_invaders", "space_invaders_render_3ch_65536", "render_kernel<3"), ("_amidar", "amidar_render_3ch_65536", "render_kernel<3"),
-    ("_breakout_4096", "breakout_render_3ch_4096_fused", "render_step_kernel<3"), ("_breakout_4096_pair", "breakout_render_3ch_4096", "render_kernel<3"),
+    ("_breakout_4096", "breakout_render_3ch_4096_fused", "render_kernel<3"), ("_breakout_4096_pair", "breakout_render_3ch_4096", "render_kernel<3"),
     ("_space_invaders_4096_pair", "space_invaders_render_3ch_4096", "render_kernel<3"), ("_amidar_4096_pair", "amidar_render_3ch_4096", "render_kernel<3"),
     ("_breakout_8192_gather", "breakout_render_3ch_8192_fused", "render_step_kernel<3"), ("_mixed", None, "render"),
 ]
