@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The random-rollout loop in its three forms on ONE engine, interleaved on one box: single fused calls in stream order
 (`order`), single fused calls overlapped behind the device-side ticket (`ticket`, TBX_OPT_FUSED_OVERLAP), and rollout chunks of
-k steps (`chunks`, tbx_rollout_synthetic / TBX_OPT_ROLLOUT_CHUNKS) -- ms per step, with the K = k record ring (1-rank
+k steps (`chunks`; tbx_rollout_synthetic / TBX_OPT_ROLLOUT_CHUNKS; `pair` / `pipe` = the two-launch
+loop in stream order / with TBX_OPT_PIPELINE = the engine's choice) -- ms per step, with the K = k record ring (1-rank
 communicator) or without a gather.   python scripts/rollout_ab.py [sizes ...]   (env RA_ROUNDS, RA_K, RA_GATHER = 0 / 1, RA_FORMS)"""
 import json
 import os
