@@ -127,6 +127,8 @@ def parse():
     ap.add_argument("--allow-no-gather", action="store_true",
                     help="N > 1 only: if no RCCL communicator can be made, run without the per-step gather (file barrier) instead of failing")
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1, 2, 3], help="TBX_OPT_PIPELINE of the main arm (1 = engine's choice)")
+    ap.add_argument("--in-process-arms", action="store_true",
+                    help="run BASELINE configs 2-5 and the strong-scaling probe in this process instead of one process per arm")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / barrier walk-through without any GPU call")
     ap.add_argument("--gym", action="store_true", help="reference protocol: also the env.step() arm (test/benchmark.py:83-97)")
     ap.add_argument("--reps", type=int, default=30, help="reference protocol: repetitions (mean and s.e.m. reported)")
@@ -1012,6 +1014,8 @@ def main():
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails with "invalid argument" under the
     # legacy mode); the GPU boxes export it already -- set before anything loads the HIP runtime, for launchers that do not
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get(ARM_ENV):                        # the child side of run_arm: one arm of the line in a process of its own
+        return arm_main(json.loads(os.environ.pop(ARM_ENV)))
     args = parse()
     SETTLE = max(0, args.settle)
     GATHER_TRANSPORT = args.gather
@@ -1127,7 +1131,7 @@ def main():
     if rank == 0 and single and not args.no_extras and main_res["n"] >= 16384:
         try:
             out["scaling_strong"] = strong_share_probe(args, game, main_res["C"], main_res["n"], out["value"],
-                                                       (out.get("serialised") or {}).get("value") or out["value"])
+                                                       (out.get("serialised") or {}).get("value") or out["value"], hip)
         except Exception as ex:
             out["scaling_strong"] = {"error": repr(ex)}
     if rank == 0 and single and not args.no_extras and not args.no_configs and game == "breakout" and main_res["render"]:
@@ -1260,101 +1264,161 @@ def agent_path_rates(hip, n, steps=40, warmup=12):
     return rates
 
 
-def baseline_configs(args, hip):
-    """BASELINE.json configs 2, 3, 4 (4 096 envs of Breakout / SpaceInvaders / Amidar on one GPU) and the per-GPU share of
-    config 5 (mixed 32 768 envs = 10 923 + 10 923 + 10 922 with the 1-rank record gather), each with the protocol of the
-    headline (pre-roll, warm-up, 5 regions, median) but regions of >= 200 (mixed: >= 50) steps: a 20-step region of a 0.1 ms step
-    is mostly its two synchronisations.  `whole_step_frac` = frame bytes of the batch / ms_per_step / 8 TB/s."""
-    cfgs = {}
-    for key, g in (("2_breakout_4096", "breakout"), ("3_space_invaders_4096", "space_invaders"), ("4_amidar_4096", "amidar")):
-        a = argparse.Namespace(**vars(args))
-        a.envs, a.steps, a.warmup, a.repeats, a.with_gather, a.no_render, a.scaling = 4096, max(args.steps, 200), 20, 5, False, False, "strong"
-        r = run_reading(a, hip, g, 0, 1, 0, "strong", "cfg_" + g, True, extras=("serialised",))
-        if isinstance(r, int):
-            cfgs[key] = {"error": "rc %d" % r}
-            continue
-        ms = r["rep"]["ms_per_step_median"]
-        fb = r["H"] * r["W"] * r["C"]
-        e = {"value": r["n"] / (ms * 1e-3), "unit": "env-steps/s", "ms_per_step": ms, "steps": a.steps, "repeats": r["rep"]["n"],
-             "ms_per_step_min_max": [r["rep"]["ms_per_step_min"], r["rep"]["ms_per_step_max"]],
-             "loop": ("rollout chunks of %d" % r["chunk_k"]) if r["chunk_k"] else ("fused, overlapped launches" if r["overlapped"] else "fused") if r["fused"] else "pair",
-             "pipeline_resolved": r["mode"],
-             "whole_step_frac": r["n"] * fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-             # (overlapped launches -- TBX_OPT_PIPELINE 3, TBX_OPT_FUSED_OVERLAP: an event pair on the caller's stream does not bracket a
-             # kernel; with fused overlap it is the steady-state period of a launch, printed as such)
-             "kernel_frac": (r["n"] * fb / (r["launch"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if r["launch"] and r["mode"] == 0 else None,
-             "avg_launch_ms": r["launch"]["avg_ms"] if r["launch"] and r["mode"] == 0 else None,
-             "launch_timing": "end-to-end period of overlapped launches" if r["overlapped"] else "events around launches in stream order",
-             "frame_hwc": [r["H"], r["W"], r["C"]]}
-        sr = r["extras"].get("serialised")
-        e["serialised"] = ({"value": sr["value"], "ms_per_step": sr["ms_per_step"], "whole_step_frac": sr["whole_step_frac"],
-                            "kernel_frac": sr["roofline_frac"]} if sr else "= value (the main arm is the two-launch loop in stream order)")
-        cfgs[key] = e
+ARM_ENV = "TBX_BENCH_ARM"
+
+
+def run_arm(kind, key, args, extra, hip, timeout=900):
+    """One arm of the line -- a BASELINE config, an arm of the strong-scaling probe -- in a process of its OWN, as that workload's own
+    run would be (and as a rank of an N-GPU run is: it never hosted a 65 536-env engine first).  Measured: the 8 192-env chunk loop
+    runs 0.154-0.156 ms per step in a fresh process and 0.162-0.165 as the second engine of the process that ran the headline batch
+    (stream order: 0.160 in both); the small-batch rows of the line were 5-20 % behind their own invocations for the same reason
+    (profiles/r06_experiments.txt 4).  --in-process-arms (or a failing child) runs the arm here instead and says so."""
+    if not getattr(args, "in_process_arms", False):
+        import subprocess
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TBX_RDZV_KEY")}
+        env[ARM_ENV] = json.dumps({"kind": kind, "key": key, "args": vars(args), "extra": extra})
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=timeout)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode == 0 and lines:
+                out = json.loads(lines[-1])
+                out["process"] = "own"
+                return out
+            note = "child rc %d: %s" % (p.returncode, (p.stderr or "").strip().splitlines()[-1][:160] if (p.stderr or "").strip() else "no line")
+        except Exception as ex:
+            note = repr(ex)[:160]
+    else:
+        note = "--in-process-arms"
+    out = ARMS[kind](args, key, extra, hip)
+    out["process"] = "shared with the headline arm (%s)" % note
+    return out
+
+
+def arm_main(payload):
+    """the child side of run_arm"""
+    global SETTLE, GATHER_TRANSPORT, FUSED_OVERLAP, ROLLOUT_CHUNKS, CHUNK_K
+    args = argparse.Namespace(**payload["args"])
+    args.in_process_arms = True
+    SETTLE = max(0, args.settle)
+    GATHER_TRANSPORT, FUSED_OVERLAP, ROLLOUT_CHUNKS, CHUNK_K = args.gather, args.fused_overlap, args.rollout_chunks, max(1, args.gather_every)
+    from toybox_amd import hip
+    hip.set_device(0)
+    print(json.dumps(ARMS[payload["kind"]](args, payload["key"], payload["extra"], hip)), flush=True)
+    return 0
+
+
+def config_arm(args, key, extra, hip):
+    """BASELINE config 2, 3 or 4: 4 096 envs of one game, the protocol of the headline but regions of >= 200 steps"""
+    g = extra["game"]
+    a = argparse.Namespace(**vars(args))
+    a.envs, a.steps, a.warmup, a.repeats, a.with_gather, a.no_render, a.scaling = 4096, max(args.steps, 200), 20, 5, False, False, "strong"
+    r = run_reading(a, hip, g, 0, 1, 0, "strong", "cfg_" + g, True, extras=("serialised",))
+    if isinstance(r, int):
+        return {"error": "rc %d" % r}
+    ms = r["rep"]["ms_per_step_median"]
+    fb = r["H"] * r["W"] * r["C"]
+    e = {"value": r["n"] / (ms * 1e-3), "unit": "env-steps/s", "ms_per_step": ms, "steps": a.steps, "repeats": r["rep"]["n"],
+         "ms_per_step_min_max": [r["rep"]["ms_per_step_min"], r["rep"]["ms_per_step_max"]],
+         "loop": ("rollout chunks of %d" % r["chunk_k"]) if r["chunk_k"] else ("fused, overlapped launches" if r["overlapped"] else "fused") if r["fused"] else "pair",
+         "pipeline_resolved": r["mode"],
+         "whole_step_frac": r["n"] * fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+         # (overlapped launches -- TBX_OPT_PIPELINE 3, TBX_OPT_FUSED_OVERLAP, rollout chunks: an event pair on the caller's stream does not
+         # bracket a kernel; it is the steady-state period of a launch, printed as such)
+         "kernel_frac": (r["n"] * fb / (r["launch"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if r["launch"] and r["mode"] == 0 else None,
+         "avg_launch_ms": r["launch"]["avg_ms"] if r["launch"] and r["mode"] == 0 else None,
+         "launch_timing": "end-to-end period of overlapped launches" if r["overlapped"] else "events around launches in stream order",
+         "frame_hwc": [r["H"], r["W"], r["C"]]}
+    sr = r["extras"].get("serialised")
+    e["serialised"] = ({"value": sr["value"], "ms_per_step": sr["ms_per_step"], "whole_step_frac": sr["whole_step_frac"],
+                        "kernel_frac": sr["roofline_frac"]} if sr else "= value (the main arm is the two-launch loop in stream order)")
+    return e
+
+
+def mixed_arm(args, key, extra, hip):
+    """BASELINE config 5: its per-GPU share (32 768 envs) or the whole mixed batch (262 144 envs) on one GPU, 1-rank record gather"""
     a = argparse.Namespace(**vars(args))
     a.no_render = False
-    m = mixed_reading(a, 1, 0, 0, 32768, max(args.steps, 50), 10, 5, True)
-    cfgs["5_mixed_32768_per_gpu"] = {"value": m["value"], "unit": "env-steps/s per GPU", "ms_per_step": m["ms_per_step"], "steps": m["steps"],
-                                     "ms_per_step_min_max": [m["repeats"]["ms_per_step_min"], m["repeats"]["ms_per_step_max"]],
-                                     "segment_sizes": m["config"]["segment_sizes"], "loop": m["loop"], "rccl": m["rccl"],
-                                     "whole_step_frac": m["roofline"]["frac"],
-                                     "note": "the per-GPU share of BASELINE config 5 (262 144 envs over 8 GPUs) on ONE GPU with the record gather "
-                                             "queued over a 1-rank communicator: launch cost of the collective, no wire time"}
-    # BASELINE config 5 as written -- the whole mixed batch of 262 144 envs (87 382 + 87 381 + 87 381) -- on ONE MI355X: ~38 GB of
-    # frames; the denominator any later 8-GPU line of this config needs (VERDICT r05 #3)
-    try:
-        a = argparse.Namespace(**vars(args))
-        a.no_render = False
-        m = mixed_reading(a, 1, 0, 0, 262144, min(max(args.steps, 10), 30), 5, 3, True)
-        cfgs["5_mixed_262144_one_gpu"] = {"value": m["value"], "unit": "env-steps/s", "ms_per_step": m["ms_per_step"], "steps": m["steps"],
-                                          "ms_per_step_min_max": [m["repeats"]["ms_per_step_min"], m["repeats"]["ms_per_step_max"]],
-                                          "segment_sizes": m["config"]["segment_sizes"], "loop": m["loop"], "rccl": m["rccl"],
-                                          "whole_step_frac": m["roofline"]["frac"], "frame_bytes_per_step": m["roofline"]["algorithmic_bytes_per_step"],
-                                          "note": "BASELINE config 5 in full on one GPU: three homogeneous segments on three streams, the record gather "
-                                                  "queued over a 1-rank communicator per segment (K = %d ring); 8 GPUs would each take a 32 768-env "
-                                                  "share of it (5_mixed_32768_per_gpu)" % max(1, args.gather_every)}
-    except Exception as ex:
-        cfgs["5_mixed_262144_one_gpu"] = {"error": repr(ex)[:300]}
+    m = mixed_reading(a, 1, 0, 0, extra["envs"], extra["steps"], extra["warmup"], extra["repeats"], True)
+    return {"value": m["value"], "unit": "env-steps/s" + (" per GPU" if extra["envs"] == 32768 else ""), "ms_per_step": m["ms_per_step"], "steps": m["steps"],
+            "ms_per_step_min_max": [m["repeats"]["ms_per_step_min"], m["repeats"]["ms_per_step_max"]],
+            "segment_sizes": m["config"]["segment_sizes"], "loop": m["loop"], "rccl": m["rccl"],
+            "whole_step_frac": m["roofline"]["frac"], "frame_bytes_per_step": m["roofline"]["algorithmic_bytes_per_step"], "note": extra["note"]}
+
+
+def baseline_configs(args, hip):
+    """BASELINE.json configs 2, 3, 4 (4 096 envs of Breakout / SpaceInvaders / Amidar on one GPU), the per-GPU share of config 5
+    (mixed 32 768 envs = 10 923 + 10 923 + 10 922 with the 1-rank record gather) and config 5 in full on ONE GPU (262 144 envs =
+    87 382 + 87 381 + 87 381, ~38 GB of frames: the denominator any later 8-GPU line of this config needs), each in a
+    process of its own (run_arm).  `whole_step_frac` = frame bytes of the batch / ms_per_step / 8 TB/s."""
+    cfgs = {}
+    for key, g in (("2_breakout_4096", "breakout"), ("3_space_invaders_4096", "space_invaders"), ("4_amidar_4096", "amidar")):
+        try:
+            cfgs[key] = run_arm("config", key, args, {"game": g}, hip)
+        except Exception as ex:
+            cfgs[key] = {"error": repr(ex)[:300]}
+    for key, extra in (("5_mixed_32768_per_gpu", {"envs": 32768, "steps": max(args.steps, 50), "warmup": 10, "repeats": 5,
+                                                  "note": "the per-GPU share of BASELINE config 5 (262 144 envs over 8 GPUs) on ONE GPU with the record gather "
+                                                          "queued over a 1-rank communicator: launch cost of the collective, no wire time"}),
+                       ("5_mixed_262144_one_gpu", {"envs": 262144, "steps": min(max(args.steps, 10), 30), "warmup": 5, "repeats": 3,
+                                                   "note": "BASELINE config 5 in full on one GPU: three homogeneous segments on three streams, the record gather "
+                                                           "queued over a 1-rank communicator per segment (K = %d ring); 8 GPUs would each take a 32 768-env "
+                                                           "share of it (5_mixed_32768_per_gpu)" % max(1, args.gather_every)})):
+        try:
+            cfgs[key] = run_arm("mixed", key, args, extra, hip)
+        except Exception as ex:
+            cfgs[key] = {"error": repr(ex)[:300]}
     return cfgs
 
 
-def strong_share_probe(args, game, C, n_single, single_value, single_pair_value):
+def probe_arm(args, key, extra, hip):
+    """one arm of the strong-scaling probe: n envs (1/8 of the batch) with the record gather on"""
+    from toybox_amd import Engine, _abi
+    game, C, n, every, want_fused = extra["game"], extra["C"], extra["n"], extra["every"], extra["fused"]
+    K = max(args.steps, 200)
+    eng = Engine(game, n, device=0)
+    eng.seed(SEED_BASE)
+    eng.new_game()
+    eng.set_option(_abi.OPT_GATHER_EVERY, max(1, every))
+    eng.set_option(_abi.OPT_GATHER_TRANSPORT, _abi.GATHER_HOST if GATHER_TRANSPORT == "host" else _abi.GATHER_RCCL)
+    with quiet_stdout():
+        eng.gather_init(1, 0, eng.gather_unique_id())
+    st = hip.Stream()
+    for t in range(args.preroll):
+        eng.step_synthetic(ACTION_SEED, t, auto_reset=True, stream=st.ptr)
+    reg = Region(hip.synchronize, lambda: eng.gather_reduce_max(0.0), lambda v: eng.gather_reduce_max(v))
+    fused = want_fused and C >= 3 and eng.get_option(_abi.OPT_RENDER_STEP_FUSED) == 1
+    rep, launch, mode, _ = timed_arm(eng, hip, reg, st, 0, C, True, True, args.pipeline, args.preroll, K, 20, 5, fused=fused)
+    v = n / (rep["ms_per_step_median"] * 1e-3)
+    out = {"value": v, "ms_per_step": rep["ms_per_step_median"], "repeats": rep,
+           "loop": ("rollout chunks of %d" % LAST_LOOP_FORM["chunk_k"]) if LAST_LOOP_FORM["chunk_k"] else
+                   ("fused, overlapped launches" if LAST_LOOP_FORM["overlapped"] else "fused") if fused else "pair",
+           "gather_every": eng.gather_every(), "pipeline_resolved": mode, "avg_launch_ms": launch["avg_ms"] if launch else None}
+    eng.close()
+    st.close()
+    return out
+
+
+def strong_share_probe(args, game, C, n_single, single_value, single_pair_value, hip):
     """What ONE GPU of an 8-GPU run of the SAME batch would do: n/8 envs with the record gather on (1-rank communicator: launch
-    and stream-hop cost of the collective, no wire time).  share_of_linear = that rate over the single-GPU rate of the whole
-    batch (a fraction: 1.0 = eight GPUs are eight times one).  Measured for the loop form and ring depth of the main arm and,
-    beside it, for the two-launch loop with a collective every step."""
-    from toybox_amd import Engine, _abi, hip
+    and stream-hop cost of the collective, no wire time), each arm in a process of its own like the rank it stands for (run_arm).
+    share_of_linear = that rate over the single-GPU rate of the whole batch (a fraction: 1.0 = eight GPUs are eight times one).
+    Measured for the loop form and ring depth of the main arm and, beside it, for the two-launch loop with a collective every step."""
     n = n_single // 8
     res = {"envs_per_gpu": n, "gpus": 8, "unit": "env-steps/s per GPU",
            "note": "1/8 of the batch on one GPU with the record gather queued (1-rank RCCL communicator)"}
-    K = max(args.steps, 200)
     arms = (("main", args.gather_every, args.loop != "pair"), ("policy_loop", args.gather_every, False), ("pair_gather_every_step", 1, False))
     for key, every, want_fused in arms:
-        eng = Engine(game, n, device=0)
-        eng.seed(SEED_BASE)
-        eng.new_game()
-        eng.set_option(_abi.OPT_GATHER_EVERY, max(1, every))
-        eng.set_option(_abi.OPT_GATHER_TRANSPORT, _abi.GATHER_HOST if GATHER_TRANSPORT == "host" else _abi.GATHER_RCCL)
-        with quiet_stdout():
-            eng.gather_init(1, 0, eng.gather_unique_id())
-        st = hip.Stream()
-        for t in range(args.preroll):
-            eng.step_synthetic(ACTION_SEED, t, auto_reset=True, stream=st.ptr)
-        reg = Region(hip.synchronize, lambda: eng.gather_reduce_max(0.0), lambda v: eng.gather_reduce_max(v))
-        fused = want_fused and C >= 3 and eng.get_option(_abi.OPT_RENDER_STEP_FUSED) == 1
-        rep, launch, mode, _ = timed_arm(eng, hip, reg, st, 0, C, True, True, args.pipeline, args.preroll, K, 20, 5, fused=fused)
-        v = n / (rep["ms_per_step_median"] * 1e-3)
-        res[key] = {"value": v, "ms_per_step": rep["ms_per_step_median"], "repeats": rep,
-                    "loop": ("rollout chunks of %d" % LAST_LOOP_FORM["chunk_k"]) if LAST_LOOP_FORM["chunk_k"] else
-                            ("fused, overlapped launches" if LAST_LOOP_FORM["overlapped"] else "fused") if fused else "pair",
-                    "gather_every": eng.gather_every(), "pipeline_resolved": mode, "avg_launch_ms": launch["avg_ms"] if launch else None,
-                    "share_of_linear": v / (single_value if key == "main" else single_pair_value),
-                    "share_of": "value" if key == "main" else "serialised (the two-launch loop on the whole batch)"}
-        eng.close()
-        st.close()
+        r = run_arm("probe", key, args, {"game": game, "C": C, "n": n, "every": every, "fused": want_fused}, hip)
+        r["share_of_linear"] = r["value"] / (single_value if key == "main" else single_pair_value)
+        r["share_of"] = "value" if key == "main" else "serialised (the two-launch loop on the whole batch)"
+        res[key] = r
     res["value"] = res["main"]["value"]
     res["share_of_linear"] = res["main"]["share_of_linear"]
     res["share_of_linear_policy_loop"] = res["policy_loop"]["share_of_linear"]
     return res
+
+
+ARMS = {"config": config_arm, "mixed": mixed_arm, "probe": probe_arm}
 
 
 if __name__ == "__main__":
