@@ -784,10 +784,11 @@ def timed_arm(eng, hip, reg, stream, start, C, gather, render, pipeline, t, K, W
     mode = eng.get_option(_abi.OPT_PIPELINE_ACTIVE)
     eng.set_option(_abi.OPT_ROLLOUT_CHUNKS, {"auto": _abi.ROLLOUT_CHUNKS_AUTO, "on": _abi.ROLLOUT_CHUNKS_ON, "off": _abi.ROLLOUT_CHUNKS_OFF}[ROLLOUT_CHUNKS])
     loop = Loop(eng, hip, stream, start, C, gather, render, K, R, fused=fused, rollout=rollout)
-    chunked = loop.use_chunks(CHUNK_K, (SETTLE + Wm, K))
+    chunked = loop.use_chunks(CHUNK_K, (K,))
     if chunked:
-        loop.many_steps(t, SETTLE + Wm)
-        t += SETTLE + Wm
+        warm = -(-(SETTLE + Wm) // CHUNK_K) * CHUNK_K       # untimed: rounded UP to whole chunks (a record ring cannot be left partly filled)
+        loop.many_steps(t, warm)
+        t += warm
     else:
         for _ in range(SETTLE + Wm):
             loop.full_step(t)

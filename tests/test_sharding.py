@@ -558,7 +558,7 @@ def test_bench_chunk_form_runs_whole_chunks_and_times_one_span_per_region():
     K, R, k = 20, 3, 4
     _FakeEvent.log = []
     loop = bench.Loop(Eng(), Hip, St(), 0, 3, True, True, K, R, fused=True)
-    assert not loop.use_chunks(k, (45, K)) and not loop.use_chunks(k, (44, 18)) and not loop.use_chunks(5, (45, K))   # phases / ring do not fit
+    assert not loop.use_chunks(k, (18,)) and not loop.use_chunks(5, (K,))   # the timed phase / the ring do not fit
     assert not bench.Loop(Eng(), Hip, St(), 0, 3, True, True, K, R, fused=False).use_chunks(k, (44, K))            # the two-launch loop
     assert loop.use_chunks(k, (44, K)) and loop.chunk_k == k and loop.overlapped
     loop.many_steps(0, 44)                                  # settle + warm-up: nothing is timed
