@@ -18,8 +18,11 @@ slice arrived) and the line says so (`rccl.verified`).  A communicator that cann
 Loop forms.  The north star's loop is a random-action rollout: actions come from the device, step t+1 does not need frame t.
 `fused` (default where the engine fuses: Breakout RGB / RGBA) is one tbx_render_step_synthetic per iteration -- the rasteriser
 of frame t and the step to frame t+1 as ONE launch; `pair` is tbx_step_synthetic ; tbx_render_device, two launches in stream
-order, the rate a policy-driven loop gets.  Whenever `value` is not the pair form in stream order, that is measured on the
-same engine and reported beside it as `serialised`.
+order, the rate a policy-driven loop gets.  `chunks` (round 6; where the engine runs them: Breakout and SpaceInvaders up to 8 192
+envs, --rollout-chunks) is one tbx_rollout_synthetic per --gather-every steps -- step launches on a step lane, the chunk's
+rasteriser launches overlapped on two more, the ring's collective queued by the call -- when the timed region is a whole number
+of chunks.  Whenever `value` is not the pair form in stream order, that is measured on the same engine and reported beside it
+as `serialised`.
 
 Protocol (mirroring the repeat-and-summarise shape of the reference's test/benchmark.py:119-148): an untimed
 pre-roll of step-only frames so that the timed region sees mid-game states with episodes ending and auto-resets firing,
@@ -30,15 +33,18 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline       -- the dominant kernel (the rasteriser; fused: rasteriser + step launch) priced against HBM bandwidth with HIP
                     events on the caller's stream: fused, around runs of 8 back-to-back launches (time / 8); two-launch form,
                     around every 8th rasteriser launch; never next to a synchronisation,
-  loop           -- which loop form `value` was measured with,
+  loop           -- which loop form `value` was measured with (form, chunk_k, overlapped),
+  ranks          -- one record per rank: HIP ordinal, PCI address, arch, shard (tbx_device_identity); two ranks of an RCCL run on one
+                    PCI address end the run with rc 7,
   serialised     -- the two-launch loop in stream order on the same engine (when `value` is anything else),
   step_only      -- the same loop without the rasteriser (not bandwidth-bound: no roofline),
   weak / strong  -- (N > 1) the other reading, and share_of_linear,
   scaling_strong -- (N = 1) what ONE GPU does with 1/8 of the batch plus the record gather, as a share of linear (a fraction): `main`
                     (the loop form of `value`), `policy_loop` (two launches + the same ring, over `serialised`), and two launches
-                    with a collective every step,
-  configs        -- (N = 1, Breakout) BASELINE.json configs 2-4 (4 096 envs per game) and config 5's per-GPU share (mixed
-                    32 768 envs + 1-rank gather) measured in the same invocation: value, serialised, whole-step fraction of 8 TB/s,
+                    with a collective every step -- each arm in a process of its own, like the rank it stands for (`process`),
+  configs        -- (N = 1, Breakout) BASELINE.json configs 2-4 (4 096 envs per game), config 5's per-GPU share (mixed 32 768 envs +
+                    1-rank gather) and config 5 in full on one GPU (262 144 envs), each in a process of its own: value, serialised,
+                    whole-step fraction of 8 TB/s,
   agent_path     -- (N = 1, Breakout) agent steps/s of the fused baselines wrapper stack at the headline batch size, every game,
                     rolled stack and plane ring (`--protocol agent --deepmind [--obs ring]` in short form),
   metric_version -- what `value` means (it changed between rounds 3 and 4) and which arms carry the older reading,
@@ -101,10 +107,10 @@ def parse():
                     help="auto / fused: tbx_render_step_synthetic where the engine fuses (Breakout RGB / RGBA); pair: step ; render")
     ap.add_argument("--fused-overlap", default="auto", choices=["auto", "on", "off"],
                     help="TBX_OPT_FUSED_OVERLAP: consecutive fused launches on two lanes behind the device-side step ticket "
-                         "(auto = the engine's choice: up to 4 096 envs)")
+                         "(auto = the engine's choice: up to 4 096 envs; rollout chunks take precedence where both apply)")
     ap.add_argument("--rollout-chunks", default="auto", choices=["auto", "on", "off"],
                     help="TBX_OPT_ROLLOUT_CHUNKS: the fused loop as tbx_rollout_synthetic chunks of --gather-every steps (one step launch + "
-                         "k overlapped rasteriser launches); auto = the engine's choice: up to 4 096 envs")
+                         "k overlapped rasteriser launches); auto = the engine's choice: Breakout and SpaceInvaders up to 8 192 envs")
     ap.add_argument("--gather-every", type=int, default=4,
                     help="K of the record ring (TBX_OPT_GATHER_EVERY): one RCCL all-gather per K steps (1 = every step)")
     ap.add_argument("--game", default="breakout")
@@ -834,7 +840,7 @@ CHUNK_NOTE = ("tbx_rollout_synthetic: the fused loop in chunks of %d steps -- pe
               "frames with its state in registers: %d render records, the %d step records straight into the record ring, the state once) and "
               "%d plain rasteriser launches alternating between two more internal streams, dependent on that step launch alone; the next chunk's "
               "step launch runs beside this chunk's rasterisers and the ring's collective waits for the step launch only (TBX_OPT_ROLLOUT_CHUNKS; "
-              "the engine's choice up to 4 096 envs).  avg_launch_ms: the time from one rasteriser launch's end to the next one's -- what a "
+              "the engines' choice up to 8 192 envs).  avg_launch_ms: the time from one rasteriser launch's end to the next one's -- what a "
               "frame costs in steady state -- not a kernel's own duration")
 OVERLAP_NOTE = ("consecutive fused launches alternate between two internal streams, output sets and frame buffers; launch N+1 is ordered "
                 "behind the STEP BLOCKS of launch N only (a device-side counter they bump once their agent-scope stores are out, awaited by "
@@ -1102,7 +1108,7 @@ def main():
                      "what": FUSED_NOTE if fused else "tbx_step_synthetic ; tbx_render_device, two launches per frame",
                      "overlapped": r["overlapped"], "chunk_k": r["chunk_k"],
                      "overlap": (CHUNK_NOTE % ((r["chunk_k"],) * 5)) if r["chunk_k"] else OVERLAP_NOTE if r["overlapped"] else
-                     ("stream order (--fused-overlap %s; the engine overlaps consecutive fused launches / runs rollout chunks up to 4 096 envs -- see configs)" % FUSED_OVERLAP if fused else None)},
+                     ("stream order (--fused-overlap %s; the engine runs rollout chunks up to 8 192 envs and overlaps single fused launches up to 4 096 -- see configs and scaling_strong)" % FUSED_OVERLAP if fused else None)},
             "pipeline": {"option": args.pipeline, "resolved": mode, "what": PIPELINE_NOTE.get(mode),
                          "applies_to": "the two-launch loop form only; see `serialised`"},
             "rccl": r["rccl"] if (r["rccl"] or {}).get("transport") == "rccl" else None,
