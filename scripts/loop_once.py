@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One engine, one loop form, N iterations -- the thing to put under rocprofv3 --kernel-trace when the question is what happens
-BETWEEN the kernels of the loop.   python scripts/loop_once.py game envs pair|fused|render|step iterations
+BETWEEN the kernels of the loop.   python scripts/loop_once.py game envs pair|fused|chunks|render|step iterations
 env LO_OVERLAP = TBX_OPT_FUSED_OVERLAP (0 engine's choice, 1 overlapped, 2 stream order), LO_GATHER = K of a 1-rank record gather (0: none)"""
 import os
 import sys
@@ -28,6 +28,9 @@ for t in range(300, 300 + iters):
         e.render_step_synthetic(1337, t, channels=3, auto_reset=True, stream=st.ptr)
         if G:
             e.gather(stream=st.ptr)
+    elif form == "chunks":                     # tbx_rollout_synthetic, 4 frames per call (with LO_GATHER: the K = 4 ring)
+        if (t - 300) % 4 == 0:
+            e.rollout_synthetic(1337, t, 4, channels=3, auto_reset=True, stream=st.ptr)
     elif form == "render":
         e.render_device(0, 3, stream=st.ptr)
     else:
