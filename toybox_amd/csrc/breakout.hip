@@ -2072,11 +2072,11 @@ struct BreakoutOps : GameOps {
     // ring | without a gather; profiles/r06_experiments.txt): 4 096 envs 0.0854 -> 0.0747 | 0.0833 -> 0.0748 (0.79 of 8 TB/s); 8 192:
     // 0.1593 -> 0.1559 | 0.1572 -> 0.1536; 16 384: 0.3067 -> 0.3137 | 0.3060 -> 0.3134; 32 768 and 65 536: 4-10 % slower -- two
     // rasteriser launches side by side gain what a launch loses to ramp-up and tail and lose a little everywhere else
-    // -- and at 8 192 the sign changed with what else the PROCESS had done: an engine that runs nothing but chunks in a process of its
-    // own (what a rank of an 8-GPU run is) 0.1540 / 0.1561 / 0.1538 ms against 0.1602 / 0.1609 / 0.1610 in stream order (three boxes);
-    // as the second engine of the process that ran the 65 536-env batch 0.162-0.165 against 0.160, and with other loop forms
-    // interleaved on the same engine up to +11 % (r06_experiments.txt 1g, 4)
-    bool rollout_auto(int n) const override { return n <= 8192; }
+    // -- and at 8 192 the sign changes with the BOX and with what else the process has done: an engine that runs nothing but chunks in
+    // a process of its own 0.152-0.156 ms on five boxes (0.96-0.98 of linear for the 1/8 batch) and 0.170-0.173 on two (all ten runs
+    // of one box), against 0.160-0.161 in stream order everywhere; as the second engine of the process that ran the 65 536-env batch
+    // 0.162-0.165 (r06_experiments.txt 1g, 4, 5).  An 8-GPU run is as fast as its slowest rank: 4 096 envs and below.
+    bool rollout_auto(int n) const override { return n <= 4096; }
     int rollout_step(tbx_engine* e, const ActionSource& src, uint32_t flags, int k, int q, uint64_t* packed, size_t stride, hipStream_t s) override
     {
         if (recs_chunk_k[q] < k) {                             // (the caller has made sure nothing reads the old buffer any more)
