@@ -2020,8 +2020,8 @@ struct BreakoutOps : GameOps {
     // gather up to 8 192 (0.1572 / 0.1479)
     // ... in single-engine probes.  In bench.py's own arms and in processes that hold several engines the same comparisons came out
     // between -7 % and +30 % at 8 192 envs and above (r06_experiments.txt, "what did not reproduce"): the engine's choice is the
-    // one size where every run agreed, 4 096 envs and below (8-13 % faster with or without a gather)
-    bool fused_overlap_auto(int n, int /*gather_kind*/) const override { return n <= 4096; }
+    // one case where every run agreed, 4 096 envs and below without a record gather (8-13 % faster)
+    bool fused_overlap_auto(int n, int gather_kind) const override { return gather_kind == 0 && n <= 4096; }
     // the next launch is released as soon as this one's step blocks are through (lead = the whole grid): leads of 128 ... 8 192
     // blocks were 1-6 points behind at every size up to 16 384 envs (r06_overlap_lead.txt)
     static constexpr int FUSED_LEAD_BLOCKS = 1 << 20;
@@ -2076,7 +2076,9 @@ struct BreakoutOps : GameOps {
     // a process of its own 0.152-0.156 ms on five boxes (0.96-0.98 of linear for the 1/8 batch) and 0.170-0.173 on two (all ten runs
     // of one box), against 0.160-0.161 in stream order everywhere; as the second engine of the process that ran the 65 536-env batch
     // 0.162-0.165 (r06_experiments.txt 1g, 4, 5).  An 8-GPU run is as fast as its slowest rank: 4 096 envs and below.
-    bool rollout_auto(int n) const override { return n <= 4096; }
+    // With a record ring on the device the 4 096-env chunks were -13 %, -2 %, +3 % and +11 % on four boxes (without a gather: -10 % on
+    // every one): the engine's choice is the case that never lost.
+    bool rollout_auto(int n, int gather_kind) const override { return gather_kind == 0 && n <= 4096; }
     int rollout_step(tbx_engine* e, const ActionSource& src, uint32_t flags, int k, int q, uint64_t* packed, size_t stride, hipStream_t s) override
     {
         if (recs_chunk_k[q] < k) {                             // (the caller has made sure nothing reads the old buffer any more)

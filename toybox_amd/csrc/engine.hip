@@ -875,7 +875,7 @@ static bool rollout_chunks_on(const tbx_engine* e, int channels)
     const int v = e->opt[TBX_OPT_ROLLOUT_CHUNKS];
     if (v == 2 || !e->ops->rollout_ok(channels)) return false;
     if (e->gather && !e->gather_ring) return false;              // one collective per step: k collectives cannot ride on one launch
-    return v == 1 || e->ops->rollout_auto(e->n);
+    return v == 1 || e->ops->rollout_auto(e->n, !e->gather ? 0 : e->gather_ring ? 2 : 1);
 }
 
 static int chunk_buffers(tbx_engine* e, int q, int k, size_t frame_bytes, bool want_packed, hipStream_t sync_a, hipStream_t sync_b)

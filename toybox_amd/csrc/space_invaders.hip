@@ -2016,7 +2016,7 @@ struct SiOps : GameOps {
     // (the engine's choice, off under a record ring) / chunks; no gather | K = 4 ring (r06_rollout_ab_si.txt): 2 048 envs 0.0918 / 0.0793 /
     // 0.0736 | 0.0972 / 0.0972 / 0.0809; 4 096: 0.1614 / 0.1481 / 0.1439 | 0.1658 / 0.1658 / 0.1487; 8 192: 0.3080 / 0.2966 / 0.2950 |
     // 0.3124 / 0.3119 / 0.2950; 16 384: 0.5943 / 0.5987 / 0.5950 | 0.6010 / 0.6026 / 0.6301
-    bool rollout_auto(int n) const override { return n <= 8192; }
+    bool rollout_auto(int n, int /*gather_kind*/) const override { return n <= 8192; }
     int rollout_step(tbx_engine* e, const ActionSource& src, uint32_t flags, int k, int q, uint64_t* packed, size_t stride, hipStream_t s) override
     {
         const size_t N = (size_t)e->n;

@@ -646,7 +646,7 @@ struct GameOps {
     // render record j (the state BEFORE frame j) into the chunk's record buffer of parity q, step record j into packed + j * stride,
     // the last frame's outputs into tbx_engine::reward / ...; rollout_render(): the rasteriser of record j of parity q into out.
     virtual bool rollout_ok(int /*channels*/) const { return false; }
-    virtual bool rollout_auto(int /*n*/) const { return false; }
+    virtual bool rollout_auto(int /*n*/, int /*gather_kind*/) const { return false; }
     virtual int rollout_step(tbx_engine*, const ActionSource&, uint32_t /*flags*/, int /*k*/, int /*q*/, uint64_t* /*packed*/, size_t /*stride*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
     virtual int rollout_render(tbx_engine*, uint8_t* /*out*/, int /*channels*/, int /*q*/, int /*j*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
     // batched interventions (include/toybox_amd.h, tbx_edit / tbx_reduce): one kernel over the selected envs
