@@ -2,7 +2,7 @@
 """Long soak of the overlapped rollout forms (GPU box): rollout chunks (tbx_rollout_synthetic, K = 4 record ring) and overlapped
 fused launches (the device-side ticket) against the CPU restatement over tens of thousands of frames without a synchronisation in
 between -- every chunk's step records compared through the gathered block, full states and frames at checkpoints, and tbx_sync's
-report at the end (a ticket time-out of the wait kernel would show there).  usage: soak_rollout.py [frames] [envs]"""
+report at the end (a ticket time-out of the wait kernel would show there).  usage: soak_rollout.py [frames] [envs] [game:form,...]"""
 import ctypes as C
 import os
 import sys
@@ -22,7 +22,9 @@ K = 4
 os.environ.setdefault("TBX_ORACLE_THREADS", "16")
 olib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
 _abi.bind(olib)
-for game, form in (("breakout", "chunks"), ("space_invaders", "chunks"), ("breakout", "ticket")):
+runs = [tuple(r.split(":")) for r in sys.argv[3].split(",")] if len(sys.argv) > 3 else \
+    [("breakout", "chunks"), ("space_invaders", "chunks"), ("breakout", "ticket")]
+for game, form in runs:
     g, o = Engine(game, n), Engine(game, n, lib=olib)
     for e in (g, o):
         e.seed(777)
@@ -41,7 +43,9 @@ for game, form in (("breakout", "chunks"), ("space_invaders", "chunks"), ("break
             for j in range(K):
                 g.render_step_synthetic(4242, t + j, channels=3, auto_reset=True, stream=st.ptr)
                 g.gather(stream=st.ptr)
-        o.rollout_synthetic(4242, t, K, channels=1, auto_reset=True)        # (the checker's frames are not needed: gray is cheapest)
+        for j in range(K):                                                    # (the checker steps only: its frames are compared at the checkpoints)
+            o.step_synthetic(4242, t + j, auto_reset=True)
+            o.gather()
         if (t // K) % 50 == 49:                                               # every 200 frames: the last K steps' records of every env
             if not np.array_equal(g.gather_host().reshape(K, -1)[:, :n], o.gather_host().reshape(K, -1)[:, :n]):
                 print("%s %s: step records differ in the chunk that ends at frame %d" % (game, form, t + K))
