@@ -448,9 +448,11 @@ int tbx_render_step_synthetic(tbx_engine* engine, uint8_t* out_dev, int channels
  *   TBX_BUF_REWARD / DONE / LIVES / SCORE / PACKED and the state: those of the chunk's LAST step; TBX_BUF_FRAME: its last frame.
  * Where the rasteriser reads step-written records (Breakout, canonical wall, RGB / RGBA; TBX_OPT_ROLLOUT_CHUNKS) a chunk is ONE step
  * launch on an internal stream -- every env k frames with its state in registers, writing k render records, the k step records and
- * the state once -- and k plain rasteriser launches that alternate between two more internal streams and depend on that step
- * launch alone: consecutive rasteriser launches overlap freely, the next chunk's step launch runs beside this chunk's
- * rasterisers (a whole chunk ahead of its own), and with a ring the collective waits for the step launch only.  That is what N
+ * the state once -- and rasteriser launches that depend on that step launch alone, in one of two forms: ONE launch for the chunk's
+ * k x N frames (the records and the frames of a chunk lie one behind the other), chunk behind chunk on a second internal stream --
+ * a render-only loop of launches k times as long as a frame's --, or k launches of one frame each that alternate between two
+ * internal streams and overlap freely.  Either way the next chunk's step launch runs beside this chunk's rasterisers (a whole
+ * chunk ahead of its own), and with a ring the collective waits for the step launch only.  That is what N
  * worker processes stepping independently of each other give the reference (baselines/baselines/common/vec_env/subproc_vec_env.py:49-74),
  * and what the per-GPU share of a strong-scaled batch (8 192 envs) loses to ramp-up and tail between launches in stream order.
  * Contract in that form: as for overlapped fused launches (TBX_OPT_FUSED_OVERLAP) -- two chunk buffers alternate; ask
@@ -831,8 +833,10 @@ int tbx_device_buffer(tbx_engine* engine, int which, void** out_ptr, size_t* out
  * as soon as the step blocks are through (both launches then run side by side for most of their length -- measured slower,
  * profiles/r06_experiments.txt). */
 #define TBX_OPT_FUSED_OVERLAP_LEAD 8
-/* tbx_rollout_synthetic as ONE step launch + k overlapped rasteriser launches per chunk (see there): 0 (default) = the engine's
- * choice by batch size, 1 = wherever the engine can, 2 = never (the k single calls in stream order) */
+/* tbx_rollout_synthetic as ONE step launch + the chunk's rasteriser launches on internal streams (see there): 0 (default) = the
+ * engine's choice by batch size, 1 = wherever the engine can (the rasteriser form its choice), 2 = never (the k single calls in
+ * stream order); 3 / 4 = as 1 with the rasteriser form named -- 3 a launch per frame on two streams, 4 one launch per chunk on one
+ * (games without that form: as 3) */
 #define TBX_OPT_ROLLOUT_CHUNKS 9
 #define TBX_OPT_COUNT         10
 /* read-only (tbx_get_option): what TBX_OPT_PIPELINE resolves to on this engine right now -- 0, 2 or 3 */

@@ -1179,7 +1179,7 @@ int tbx_gather_reduce_max(tbx_engine* e, double* inout)
 /* launch-time choices of the device engine: stored and reported, without effect on a scalar CPU restatement */
 int tbx_set_option(tbx_engine* e, int option, int value)
 {
-    static const int hi[TBX_OPT_COUNT] = {3, 2, 64, 1, 1, 64, 1, 2, 1 << 20, 2};
+    static const int hi[TBX_OPT_COUNT] = {3, 2, 64, 1, 1, 64, 1, 2, 1 << 20, 4};
     if (!e) return TBX_E_INVALID;
     if (option < 0 || option >= TBX_OPT_COUNT) return fail(e, TBX_E_INVALID, "unknown option");
     if (value < (option == TBX_OPT_GATHER_EVERY ? 1 : 0) || value > hi[option]) return fail(e, TBX_E_INVALID, "option value out of range");

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One engine, one loop form, N iterations -- the thing to put under rocprofv3 --kernel-trace when the question is what happens
 BETWEEN the kernels of the loop.   python scripts/loop_once.py game envs pair|fused|chunks|render|step iterations
-env LO_OVERLAP = TBX_OPT_FUSED_OVERLAP (0 engine's choice, 1 overlapped, 2 stream order), LO_GATHER = K of a 1-rank record gather (0: none)"""
+env LO_OVERLAP = TBX_OPT_FUSED_OVERLAP (0 engine's choice, 1 overlapped, 2 stream order), LO_GATHER = K of a 1-rank record gather (0: none),
+LO_CHUNKS = TBX_OPT_ROLLOUT_CHUNKS (0 engine's choice, 1 on, 2 off)"""
 import os
 import sys
 
@@ -12,6 +13,7 @@ game, n, form, iters = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[
 e = Engine(game, n)
 e.seed(1234); e.new_game()
 e.set_option(_abi.OPT_FUSED_OVERLAP, int(os.environ.get("LO_OVERLAP", "0")))
+e.set_option(_abi.OPT_ROLLOUT_CHUNKS, int(os.environ.get("LO_CHUNKS", "0")))
 G = int(os.environ.get("LO_GATHER", "0"))
 if G:
     e.set_option(_abi.OPT_GATHER_EVERY, G)

@@ -31,7 +31,7 @@ for game, form in runs:
         e.new_game()
         e.set_option(_abi.OPT_GATHER_EVERY, K)
         e.gather_init(1, 0, e.gather_unique_id())
-    g.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_ON)
+    g.set_option(_abi.OPT_ROLLOUT_CHUNKS, int(os.environ.get("SR_FORM", _abi.ROLLOUT_CHUNKS_ON)))   # (3 / 4 / 5: the rasteriser forms by name)
     g.set_option(_abi.OPT_FUSED_OVERLAP, _abi.FUSED_OVERLAP_ON if form == "ticket" else _abi.FUSED_OVERLAP_OFF)
     st = hip.Stream()
     t0 = time.time()

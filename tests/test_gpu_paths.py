@@ -1025,11 +1025,15 @@ def test_rollout_synthetic_call_contract(game, lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("game,n,channels,K,ring", [("breakout", 8192, 3, 4, True), ("breakout", 4096, 4, 4, False), ("breakout", 700, 3, 3, True),
-                                                    ("breakout", 20000, 3, 5, True), ("breakout", 3000, 3, 2, False),
-                                                    ("space_invaders", 4096, 3, 4, True), ("space_invaders", 900, 1, 3, False), ("space_invaders", 9000, 4, 2, True)])
-def test_rollout_chunks_equal_oracle(game, n, channels, K, ring, hip_lib, oracle_lib):
-    """Rollout chunks on the device (one step launch on the step lane + k rasteriser launches on two lanes, TBX_OPT_ROLLOUT_CHUNKS)
+@pytest.mark.parametrize("game,n,channels,K,ring,form", [
+    ("breakout", 8192, 3, 4, True, 1), ("breakout", 4096, 4, 4, False, 1), ("breakout", 700, 3, 3, True, 1), ("breakout", 20000, 3, 5, True, 1),
+    ("breakout", 3000, 3, 2, False, 1), ("breakout", 8192, 3, 4, True, 3), ("breakout", 3000, 4, 3, False, 4), ("breakout", 40000, 3, 3, True, 4),
+    ("space_invaders", 4096, 3, 4, True, 1), ("space_invaders", 900, 1, 3, False, 1), ("space_invaders", 9000, 4, 2, True, 1),
+    ("space_invaders", 5000, 3, 4, True, 4)])
+def test_rollout_chunks_equal_oracle(game, n, channels, K, ring, form, hip_lib, oracle_lib):
+    """Rollout chunks on the device (one step launch on the step lane + the chunk's rasteriser launches, TBX_OPT_ROLLOUT_CHUNKS: form 1 =
+    the engine's choice of rasteriser form, 3 = a launch per frame on two lanes, 4 = one launch for the chunk's k x n frames -- at most
+    65 536 per launch, so 20 000 x 5 and 40 000 x 3 take several -- on one lane; chunk 12 of every case runs in the OTHER form)
     against the oracle's k single calls (Breakout: one multi-frame step launch per chunk; SpaceInvaders: the record of the current state
     and the k single-frame step launches back to back on the step lane): EVERY chunk's step records (all envs), last-step outputs and sampled frames, read by
     copies queued on the caller's stream right behind tbx_device_buffer (the lazy join) and therefore before the next chunk is
@@ -1040,7 +1044,7 @@ def test_rollout_chunks_equal_oracle(game, n, channels, K, ring, hip_lib, oracle
     g, o = _pair(game, n, hip_lib, oracle_lib, seed=33)
     H, W = g.height, g.width
     fb = H * W * channels
-    g.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_ON)
+    g.set_option(_abi.OPT_ROLLOUT_CHUNKS, form)
     if ring:
         for e in (g, o):
             e.set_option(_abi.OPT_GATHER_EVERY, K)
@@ -1067,7 +1071,8 @@ def test_rollout_chunks_equal_oracle(game, n, channels, K, ring, hip_lib, oracle
             g.render_step_synthetic(1337, t, channels=channels, auto_reset=True, stream=s.ptr)
             o.render_step_synthetic(1337, t, channels=channels, auto_reset=True)
             t += 1
-        g.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_OFF if c == 10 else _abi.ROLLOUT_CHUNKS_ON)
+        other = _abi.ROLLOUT_CHUNKS_PER_FRAME if form == _abi.ROLLOUT_CHUNKS_SPAN else _abi.ROLLOUT_CHUNKS_SPAN
+        g.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_OFF if c == 10 else other if c == 12 else form)
         g.rollout_synthetic(1337, t, K, channels=channels, auto_reset=True, stream=s.ptr)
         f, nb = g.device_buffer(_abi.BUF_ROLLOUT_FRAMES)
         assert nb == K * n * fb

@@ -2077,8 +2077,11 @@ struct BreakoutOps : GameOps {
     // of one box), against 0.160-0.161 in stream order everywhere; as the second engine of the process that ran the 65 536-env batch
     // 0.162-0.165 (r06_experiments.txt 1g, 4, 5).  An 8-GPU run is as fast as its slowest rank: 4 096 envs and below.
     // With a record ring on the device the 4 096-env chunks were -13 %, -2 %, +3 % and +11 % on four boxes (without a gather: -10 % on
-    // every one): the engine's choice is the case that never lost.
-    bool rollout_auto(int n, int gather_kind) const override { return gather_kind == 0 && n <= 4096; }
+    // every one).  All of that is the form with a rasteriser launch per frame on two lanes; its spread is a lottery of where the buffers
+    // lie (r06_experiments item 6), the form with ONE rasteriser launch per chunk (rollout_render_span) has none and gains 7.5 % at
+    // 4 096 envs with the ring, 4 % at 8 192, 2 % at 16 384, 0-0.5 % at 65 536: the engine's choice is chunks up to 16 384 envs, per-frame
+    // launches only where they never lost (no gather, 4 096 envs and below).
+    bool rollout_auto(int n, int /*gather_kind*/) const override { return n <= 16384; }
     int rollout_step(tbx_engine* e, const ActionSource& src, uint32_t flags, int k, int q, uint64_t* packed, size_t stride, hipStream_t s) override
     {
         if (recs_chunk_k[q] < k) {                             // (the caller has made sure nothing reads the old buffer any more)
@@ -2099,6 +2102,23 @@ struct BreakoutOps : GameOps {
         const BrkRenderRec* rr = recs_chunk[q] + (size_t)j * (size_t)e->n;
         if (channels == 3) launch_render<3>(out, 0, e->n, s, rr);
         else launch_render<4>(out, 0, e->n, s, rr);
+        TBX_HIP(hipGetLastError());
+        return TBX_OK;
+    }
+
+    bool rollout_span_ok() const override { return true; }
+    // one launch per chunk on one lane / a launch per frame on two (scripts/box_probe.py, k = 4, same process, ms per step; r06_experiments
+    // item 6): K = 4 ring 4 096 envs 0.0792 / 0.0817-0.0843, 8 192: 0.1535 / 0.151-0.164 BY PLACEMENT, 16 384: 0.302 / 0.295-0.354; without a
+    // gather 4 096: 0.0789 / 0.0748, 8 192: 0.1527 / 0.1533-0.1543
+    bool rollout_span_auto(int n, int gather_kind) const override { return gather_kind != 0 || n > 4096; }
+    int rollout_render_span(tbx_engine* e, uint8_t* out, int channels, int q, int j0, int count, bool behind_rasteriser, hipStream_t s) override
+    {
+        // behind another rasteriser launch: one part, no staggered first waves (what those two are for -- first waves that start
+        // together into an idle memory system -- does not happen there); 8 192 envs x 4 frames 0.1533-0.1536 ms per step against
+        // 0.1553 with the two-part launch, 4 096: 0.0792 / 0.0813, 16 384: 0.3022 / 0.3035 (three processes each, r06_experiments item 6)
+        const BrkRenderRec* rr = recs_chunk[q] + (size_t)j0 * (size_t)e->n;
+        if (channels == 3) launch_render<3>(out, 0, count * e->n, s, rr, nullptr, nullptr, behind_rasteriser);
+        else launch_render<4>(out, 0, count * e->n, s, rr, nullptr, nullptr, behind_rasteriser);
         TBX_HIP(hipGetLastError());
         return TBX_OK;
     }
@@ -2153,9 +2173,9 @@ struct BreakoutOps : GameOps {
         // Launches of 16 384 .. 32 767 blocks (6 554 .. 13 107 envs) keep the staggered first waves instead: there the second
         // kernel boundary costs as much as it saves (scripts/pipeline_sweep.py, 8 192 envs: 0.172 / 0.169-0.173 ms per step two
         // parts / stagger, with a per-step gather 0.179 / 0.175).
-        // (overlapped = true was tried for the rasteriser launches of a rollout chunk -- one part, no stagger, like the rasteriser blocks
-        // of the fused launch: 8 192 envs 0.193 against 0.156 ms per step, 16 384: 0.363 against 0.314; they keep the launch forms of
-        // the stream-order loop)
+        // overlapped = true: one part, no stagger -- a launch that starts behind another rasteriser launch on its stream (a rollout chunk's
+        // span launch, rollout_render_span).  (Tried for the per-frame rasteriser launches of a chunk on two lanes, which start side by
+        // side: 8 192 envs 0.193 against 0.156 ms per step, 16 384: 0.363 against 0.314; those keep the launch forms of the stream-order loop)
         const bool two_parts = !overlapped && C == 3 && grid_for(count * split).x >= 32768u;
         const int split_arg = split | (two_parts || overlapped ? 1 << 16 : 0);          // bit 16: no stagger (this is one of two parts)
         auto launch_part = [&](int f0, int n) {                           // envs first + f0 .. first + f0 + n - 1 into their frames

@@ -875,7 +875,7 @@ static bool rollout_chunks_on(const tbx_engine* e, int channels)
     const int v = e->opt[TBX_OPT_ROLLOUT_CHUNKS];
     if (v == 2 || !e->ops->rollout_ok(channels)) return false;
     if (e->gather && !e->gather_ring) return false;              // one collective per step: k collectives cannot ride on one launch
-    return v == 1 || e->ops->rollout_auto(e->n, !e->gather ? 0 : e->gather_ring ? 2 : 1);
+    return v == 1 || v >= 3 || e->ops->rollout_auto(e->n, !e->gather ? 0 : e->gather_ring ? 2 : 1);
 }
 
 static int chunk_buffers(tbx_engine* e, int q, int k, size_t frame_bytes, bool want_packed, hipStream_t sync_a, hipStream_t sync_b)
@@ -940,16 +940,42 @@ static int rollout_chunked(tbx_engine* e, int channels, const ActionSource& src,
     EHIP(hipEventRecord(p.chunk_step_ev[q], ss));
     p.chunk_step_rec[q] = true;
     bool lane_used[2] = {false, false};
-    for (int j = 0; j < k; j++) {
-        const int l = j & 1;
-        hipStream_t ls = p.lane[l];
+    auto lane_for = [&](int l) -> int {
         if (!lane_used[l]) {
-            EHIP(hipStreamWaitEvent(ls, p.chunk_step_ev[q], 0));
-            if (fenced) EHIP(hipStreamWaitEvent(ls, p.user_step_ev[q], 0));
+            EHIP(hipStreamWaitEvent(p.lane[l], p.chunk_step_ev[q], 0));
+            if (fenced) EHIP(hipStreamWaitEvent(p.lane[l], p.user_step_ev[q], 0));
             lane_used[l] = true;
         }
-        rc = e->ops->rollout_render(e, p.chunk_frames[q] + (size_t)j * fb, channels, q, j, ls);
+        return TBX_OK;
+    };
+    const int form = e->opt[TBX_OPT_ROLLOUT_CHUNKS];
+    const bool span = e->ops->rollout_span_ok() && (form == 4 || (form != 3 && e->ops->rollout_span_auto(e->n, !e->gather ? 0 : 2)));
+    if (span) {
+        // The chunk's frames in ONE rasteriser launch (k x n frames; at most 65 536 frames per launch), chunk behind chunk on ONE internal
+        // stream: rasteriser launches back to back as in a render-only loop, k times as long as a frame's, the next chunk's step launch
+        // beside them on the step lane.  Nothing runs beside a rasteriser launch but that step launch, so the rate does not depend on where
+        // the frame buffers lie (two rasteriser launches side by side: 0.151-0.164 ms per step at 8 192 envs from process to process,
+        // this form 0.1533-0.1536 in every one; profiles/r06_experiments.txt item 6).
+        const int l = 0;
+        // is the previous chunk's launch still running on that stream?  Then this one starts like a launch of a render-only loop
+        bool behind = p.chunk_raster_rec[cur][l] && hipEventQuery(p.chunk_raster_ev[cur][l]) == hipErrorNotReady;
+        (void)hipGetLastError();                                // (hipErrorNotReady is an answer, not an error to keep)
+        rc = lane_for(l);
         if (rc) return rc;
+        const int per = std::max(1, std::min(k, 65536 / std::max(1, e->n)));
+        for (int j0 = 0; j0 < k; j0 += per) {
+            rc = e->ops->rollout_render_span(e, p.chunk_frames[q] + (size_t)j0 * fb, channels, q, j0, std::min(per, k - j0), behind, p.lane[l]);
+            if (rc) return rc;
+            behind = true;
+        }
+    } else {
+        for (int j = 0; j < k; j++) {
+            const int l = j & 1;
+            rc = lane_for(l);
+            if (rc) return rc;
+            rc = e->ops->rollout_render(e, p.chunk_frames[q] + (size_t)j * fb, channels, q, j, p.lane[l]);
+            if (rc) return rc;
+        }
     }
     for (int l = 0; l < 2; l++) {
         p.chunk_raster_rec[q][l] = lane_used[l];
@@ -1797,7 +1823,7 @@ int tbx_set_option(tbx_engine* e, int option, int value)
     case TBX_OPT_GATHER_EVERY: ok = value >= 1 && value <= 64; break;
     case TBX_OPT_FUSED_OVERLAP: ok = value >= 0 && value <= 2; break;
     case TBX_OPT_FUSED_OVERLAP_LEAD: ok = value >= 0 && value <= (1 << 20); break;
-    case TBX_OPT_ROLLOUT_CHUNKS: ok = value >= 0 && value <= 2; break;
+    case TBX_OPT_ROLLOUT_CHUNKS: ok = value >= 0 && value <= 4; break;
     default: return e->fail(TBX_E_INVALID, "unknown option");
     }
     if (!ok) return e->fail(TBX_E_INVALID, "option value out of range");

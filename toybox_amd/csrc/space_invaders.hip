@@ -2047,6 +2047,13 @@ struct SiOps : GameOps {
         return launch_rec_render(e, recs_chunk[q] + (size_t)j * (size_t)e->n, out, channels, 0, e->n, s);
     }
 
+    bool rollout_span_ok() const override { return true; }
+    bool rollout_span_auto(int /*n*/, int /*gather_kind*/) const override { return false; }
+    int rollout_render_span(tbx_engine* e, uint8_t* out, int channels, int q, int j0, int count, bool /*behind_rasteriser*/, hipStream_t s) override
+    {
+        return launch_rec_render(e, recs_chunk[q] + (size_t)j0 * (size_t)e->n, out, channels, 0, count * e->n, s);
+    }
+
     int launch_rec_render(tbx_engine* e, const SiRenderRec* rr, uint8_t* out_dev, int channels, int first_env, int n_envs, hipStream_t s)
     {
         // waves per frame: the set-up is light (a record, ~300 instructions), so RGB frames are cut finer than the

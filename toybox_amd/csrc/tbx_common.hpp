@@ -649,6 +649,13 @@ struct GameOps {
     virtual bool rollout_auto(int /*n*/, int /*gather_kind*/) const { return false; }
     virtual int rollout_step(tbx_engine*, const ActionSource&, uint32_t /*flags*/, int /*k*/, int /*q*/, uint64_t* /*packed*/, size_t /*stride*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
     virtual int rollout_render(tbx_engine*, uint8_t* /*out*/, int /*channels*/, int /*q*/, int /*j*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
+    // rollout_render_span(): records j0 .. j0 + count - 1 of parity q in ONE rasteriser launch (they lie one behind the other, and so do
+    // their frames: count x n "envs" to the rasteriser; behind_rasteriser: another rasteriser launch is still running in front of it on
+    // s, so its first waves start against draining stores -- raster.hpp); rollout_span_auto(): the engine's choice between one such
+    // launch per chunk on one internal stream and a launch per frame on two
+    virtual bool rollout_span_ok() const { return false; }
+    virtual bool rollout_span_auto(int /*n*/, int /*gather_kind*/) const { return false; }
+    virtual int rollout_render_span(tbx_engine*, uint8_t* /*out*/, int /*channels*/, int /*q*/, int /*j0*/, int /*count*/, bool /*behind_rasteriser*/, hipStream_t) { return TBX_E_UNSUPPORTED; }
     // batched interventions (include/toybox_amd.h, tbx_edit / tbx_reduce): one kernel over the selected envs
     virtual int edit(tbx_engine* e, int /*op*/, const TbxEditArgs&, const uint8_t* /*mask_dev*/, hipStream_t) { return e->fail(TBX_E_INVALID, "this game has no such edit"); }
     virtual int reduce(tbx_engine* e, int /*query*/, const TbxEditArgs&, double* /*out_dev*/, int /*width*/, hipStream_t) { return e->fail(TBX_E_INVALID, "this game has no such query"); }
