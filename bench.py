@@ -110,7 +110,7 @@ def parse():
                          "(auto = the engine's choice: up to 4 096 envs; rollout chunks take precedence where both apply)")
     ap.add_argument("--rollout-chunks", default="auto", choices=["auto", "on", "off"],
                     help="TBX_OPT_ROLLOUT_CHUNKS: the fused loop as tbx_rollout_synthetic chunks of --gather-every steps (one step launch + "
-                         "k overlapped rasteriser launches); auto = the engine's choice: Breakout and SpaceInvaders up to 8 192 envs")
+                         "the chunk's rasteriser launches); auto = the engine's choice: Breakout up to 32 768 envs (from 2 048 under a record ring), SpaceInvaders up to 8 192")
     ap.add_argument("--gather-every", type=int, default=4,
                     help="K of the record ring (TBX_OPT_GATHER_EVERY): one RCCL all-gather per K steps (1 = every step)")
     ap.add_argument("--game", default="breakout")
@@ -1380,8 +1380,10 @@ def baseline_configs(args, hip):
 def probe_arm(args, key, extra, hip):
     """one arm of the strong-scaling probe: n envs (1/8 of the batch) with the record gather on"""
     from toybox_amd import Engine, _abi
+    global CHUNK_K
     game, C, n, every, want_fused = extra["game"], extra["C"], extra["n"], extra["every"], extra["fused"]
     K = max(args.steps, 200)
+    chunk_k_before, CHUNK_K = CHUNK_K, max(1, every)          # (a rollout chunk under a record ring is the ring's K steps)
     eng = Engine(game, n, device=0)
     eng.seed(SEED_BASE)
     eng.new_game()
@@ -1402,6 +1404,7 @@ def probe_arm(args, key, extra, hip):
            "gather_every": eng.gather_every(), "pipeline_resolved": mode, "avg_launch_ms": launch["avg_ms"] if launch else None}
     eng.close()
     st.close()
+    CHUNK_K = chunk_k_before
     return out
 
 
@@ -1413,11 +1416,13 @@ def strong_share_probe(args, game, C, n_single, single_value, single_pair_value,
     n = n_single // 8
     res = {"envs_per_gpu": n, "gpus": 8, "unit": "env-steps/s per GPU",
            "note": "1/8 of the batch on one GPU with the record gather queued (1-rank RCCL communicator)"}
-    arms = (("main", args.gather_every, args.loop != "pair"), ("policy_loop", args.gather_every, False), ("pair_gather_every_step", 1, False))
+    # (ring_of_8: the main arm with twice the ring -- a chunk's rasteriser launch is then as long as the whole batch's)
+    arms = (("main", args.gather_every, args.loop != "pair"), ("policy_loop", args.gather_every, False), ("pair_gather_every_step", 1, False)) + \
+           ((("ring_of_8", 8, True),) if args.loop != "pair" and args.gather_every != 8 and max(args.steps, 200) % 8 == 0 else ())
     for key, every, want_fused in arms:
         r = run_arm("probe", key, args, {"game": game, "C": C, "n": n, "every": every, "fused": want_fused}, hip)
-        r["share_of_linear"] = r["value"] / (single_value if key == "main" else single_pair_value)
-        r["share_of"] = "value" if key == "main" else "serialised (the two-launch loop on the whole batch)"
+        r["share_of_linear"] = r["value"] / (single_value if want_fused else single_pair_value)
+        r["share_of"] = "value" if want_fused else "serialised (the two-launch loop on the whole batch)"
         res[key] = r
     res["value"] = res["main"]["value"]
     res["share_of_linear"] = res["main"]["share_of_linear"]

@@ -112,17 +112,19 @@ def main():
         clk.clkp_stop.argtypes = [C.POINTER(C.c_double), C.c_int]
     mhz = (C.c_double * 4096)()
 
+    CK = G if G else int(os.environ.get("BP_K", "4"))        # frames per chunk (with a ring: its K)
+
     def loop(form, k):
         nonlocal t
-        for _ in range(0, k, 4):
+        for _ in range(0, k, CK):
             if form != "order":
-                e.rollout_synthetic(1337, t, 4, channels=3, auto_reset=True, stream=st.ptr)
+                e.rollout_synthetic(1337, t, CK, channels=3, auto_reset=True, stream=st.ptr)
             else:
-                for j in range(4):
+                for j in range(CK):
                     e.render_step_synthetic(1337, t + j, channels=3, auto_reset=True, stream=st.ptr)
                     if G:
                         e.gather(stream=st.ptr)
-            t += 4
+            t += CK
         if form != "order":
             e.device_buffer(_abi.BUF_ROLLOUT_FRAMES)     # (the lazy join: the caller's stream behind the chunk's lanes)
         if G:

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The random-rollout loop in its three forms on ONE engine, interleaved on one box: single fused calls in stream order
 (`order`), single fused calls overlapped behind the device-side ticket (`ticket`, TBX_OPT_FUSED_OVERLAP), and rollout chunks of
-k steps (`chunks`; tbx_rollout_synthetic / TBX_OPT_ROLLOUT_CHUNKS; `pair` / `pipe` = the two-launch
+k steps (`chunks`; tbx_rollout_synthetic / TBX_OPT_ROLLOUT_CHUNKS with the rasteriser form the engine's choice; `frames` / `span`: the
+form named -- a rasteriser launch per frame on two lanes / one per chunk on one; `pair` / `pipe` = the two-launch
 loop in stream order / with TBX_OPT_PIPELINE = the engine's choice) -- ms per step, with the K = k record ring (1-rank
 communicator) or without a gather.   python scripts/rollout_ab.py [sizes ...]   (env RA_ROUNDS, RA_K, RA_GATHER = 0 / 1, RA_FORMS)"""
 import json
@@ -20,7 +21,7 @@ if os.environ.get("RA_LIB"):                       # another build (the DIAG bui
 
 sizes = [int(v) for v in sys.argv[1:]] or [4096, 8192]
 rounds, k, G = int(os.environ.get("RA_ROUNDS", "5")), int(os.environ.get("RA_K", "4")), int(os.environ.get("RA_GATHER", "1"))
-forms = os.environ.get("RA_FORMS", "order,ticket,chunks").split(",")
+forms = os.environ.get("RA_FORMS", "order,ticket,frames,span").split(",")
 GAME = os.environ.get("RA_GAME", "breakout")
 for n in sizes:
     K = max(40, min(400, 40 * 65536 // n // 4)) * k              # steps per timed region, a multiple of k
@@ -43,7 +44,7 @@ for n in sizes:
                 if G:
                     e.gather(stream=st.ptr)
                 e.render_device(0, 3, stream=st.ptr)
-        elif form == "chunks":
+        elif form in ("chunks", "frames", "span"):
             for _ in range(steps // k):
                 e.rollout_synthetic(1337, t, k, channels=3, auto_reset=True, stream=st.ptr); t += k
         else:
@@ -55,7 +56,7 @@ for n in sizes:
     for r in range(rounds):
         for form in forms:
             e.set_option(_abi.OPT_FUSED_OVERLAP, _abi.FUSED_OVERLAP_ON if form == "ticket" else _abi.FUSED_OVERLAP_OFF)
-            e.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_ON)
+            e.set_option(_abi.OPT_ROLLOUT_CHUNKS, {"frames": _abi.ROLLOUT_CHUNKS_PER_FRAME, "span": _abi.ROLLOUT_CHUNKS_SPAN}.get(form, _abi.ROLLOUT_CHUNKS_ON))
             e.set_option(_abi.OPT_PIPELINE, 1 if form == "pipe" else 0)
             run(form, 10 * k)
             hip.synchronize()

@@ -711,6 +711,9 @@ def test_gpu_bench_default_line_carries_every_arm():
     assert cfg["5_mixed_262144_one_gpu"]["segment_sizes"] == [87382, 87381, 87381] and 0.3 < cfg["5_mixed_262144_one_gpu"]["whole_step_frac"] < 1.0
     assert cfg["2_breakout_4096"]["loop"].startswith("rollout chunks") and cfg["3_space_invaders_4096"]["loop"].startswith("rollout chunks")   # (the engines' choice at 4 096 envs)
     assert j["scaling_strong"]["main"]["process"] == "own" and cfg["2_breakout_4096"]["process"] == "own"      # every arm a process of its own (run_arm)
+    ss = j["scaling_strong"]
+    assert ss["main"]["loop"] == "rollout chunks of 4" and ss["ring_of_8"]["loop"] == "rollout chunks of 8" and ss["ring_of_8"]["gather_every"] == 8
+    assert ss["main"]["share_of_linear"] > 0.9 and ss["ring_of_8"]["share_of_linear"] > 0.9      # (measured 0.98 / 0.99-1.0; the bar here only catches a broken arm)
     assert len(j["ranks"]) == 1 and j["ranks"][0]["arch"].startswith("gfx950") and j["ranks"][0]["pci"] and j["ranks"][0]["rank"] == 0
     ap = j["agent_path"]
     for game in ("breakout", "space_invaders", "amidar", "gridworld"):

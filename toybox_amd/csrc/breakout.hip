@@ -2079,9 +2079,12 @@ struct BreakoutOps : GameOps {
     // With a record ring on the device the 4 096-env chunks were -13 %, -2 %, +3 % and +11 % on four boxes (without a gather: -10 % on
     // every one).  All of that is the form with a rasteriser launch per frame on two lanes; its spread is a lottery of where the buffers
     // lie (r06_experiments item 6), the form with ONE rasteriser launch per chunk (rollout_render_span) has none and gains 7.5 % at
-    // 4 096 envs with the ring, 4 % at 8 192, 2 % at 16 384, 0-0.5 % at 65 536: the engine's choice is chunks up to 16 384 envs, per-frame
-    // launches only where they never lost (no gather, 4 096 envs and below).
-    bool rollout_auto(int n, int /*gather_kind*/) const override { return n <= 16384; }
+    // 4 096 envs with the ring, 4 % at 8 192 (6 % with K = 8, 6.5 % with 16), 2 % at 16 384, 1 % at 32 768, 0.3-0.8 % at 65 536 -- and loses
+    // 45 % at 1 024 with the ring (the next chunk's step launch rewrites the ring's rows and so waits for this chunk's collective: step
+    // launch and collective in series, 160 us per chunk, longer than 4 x 1 024 frames take to paint; 2 048: -3 %).  The engine's choice:
+    // chunks up to 32 768 envs, under a ring from 2 048; per-frame launches only where they never lost (no gather, 4 096 envs and
+    // below: -15 % at 1 024, -7 % at 2 048, -10 % at 4 096).
+    bool rollout_auto(int n, int gather_kind) const override { return n <= 32768 && (gather_kind == 0 || n >= 2048); }
     int rollout_step(tbx_engine* e, const ActionSource& src, uint32_t flags, int k, int q, uint64_t* packed, size_t stride, hipStream_t s) override
     {
         if (recs_chunk_k[q] < k) {                             // (the caller has made sure nothing reads the old buffer any more)
