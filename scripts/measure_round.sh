@@ -46,6 +46,12 @@ for g in 1 0; do RA_GATHER=$g timeout 300 python scripts/rollout_ab.py 2048 4096
 $B --envs 4096 --steps 400 --rollout-chunks off --fused-overlap off --no-extras > "$OUT/bench_breakout_4096_stream_order.json" 2>/dev/null
 $B --envs 4096 --steps 400 --rollout-chunks off --fused-overlap on --no-extras > "$OUT/bench_breakout_4096_ticket.json" 2>/dev/null
 $B --envs 8192 --with-gather --no-extras --steps 400 --rollout-chunks on > "$OUT/bench_breakout_8192_gather_chunks.json" 2>/dev/null
+$B --envs 8192 --with-gather --no-extras --steps 400 --rollout-chunks off > "$OUT/bench_breakout_8192_gather_stream_order.json" 2>/dev/null
+# ... the placement lottery of side-by-side rasteriser launches on THIS box (order / per frame on two lanes / one launch per chunk, processes that
+# differ in one allocation in front of the engine), chunk lengths, and the shader clock while the loops run
+BP_FORMS=order,3,4 AL_ROUNDS=1 AL_SIZES="8192 16384" AL_SHIFTS="0 4 2052 1048576" bash scripts/gpu_addr_lottery.sh > "$OUT/addr_lottery.txt" 2>&1
+bash scripts/gpu_chunk_lengths.sh > "$OUT/chunk_lengths.txt" 2>&1
+make -C scripts/ubench libclock_probe.so > /dev/null 2>&1; BP_FORMS=order,3,4 timeout 200 python scripts/box_probe.py 8192 16000 2 2>&1 | grep "^box id\|^round\|VBIOS\|^0 " > "$OUT/box_probe.txt"
 # ... and this build against the previous round's on the headline loop (stream order at 65 536 envs)
 timeout 300 python scripts/fused_lib_ab.py scripts/ab/lib_prev.so toybox_amd/csrc/libtoybox_amd.so 65536 4096 2>&1 | grep '^{' > "$OUT/fused_lib_ab.txt"
 # ---- the rasterisers (and [step ; render]) against the previous round's build, interleaved
