@@ -992,6 +992,10 @@ def test_rollout_synthetic_call_contract(game, lib):
             a.render_step_synthetic(1337, t, channels=3, auto_reset=True)
             b.render_device(0, 3); b.step_synthetic(1337, t, auto_reset=True)
             t += 1
+        if c == 2:
+            a.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_SPAN)            # one rasteriser launch for the chunk's k x n frames
+        if c == 4:
+            a.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_PER_FRAME)
         if c == 6:
             a.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_OFF)
         if c == 7:
@@ -1197,9 +1201,13 @@ def test_options_are_validated_and_reported(hip_lib, oracle_lib):
         assert [e.get_option(k) for k in range(5)] == [0, 0, 0, 0, 1]
         e.set_option(_abi.OPT_RENDER_SPLIT, 7)
         assert e.get_option(_abi.OPT_RENDER_SPLIT) == 7
-        for opt, val in ((_abi.OPT_PIPELINE, 4), (_abi.OPT_STEP_FORM, 3), (_abi.OPT_RENDER_SPLIT, -1), (99, 0), (_abi.OPT_AGENT_GENERIC, 2)):
+        for opt, val in ((_abi.OPT_PIPELINE, 4), (_abi.OPT_STEP_FORM, 3), (_abi.OPT_RENDER_SPLIT, -1), (99, 0), (_abi.OPT_AGENT_GENERIC, 2),
+                         (_abi.OPT_ROLLOUT_CHUNKS, 5), (_abi.OPT_ROLLOUT_CHUNKS, -1), (_abi.OPT_FUSED_OVERLAP, 3)):
             with pytest.raises(ToyboxAmdError):
                 e.set_option(opt, val)
+        for val in (_abi.ROLLOUT_CHUNKS_PER_FRAME, _abi.ROLLOUT_CHUNKS_SPAN, _abi.ROLLOUT_CHUNKS_AUTO):     # (the rasteriser forms by name)
+            e.set_option(_abi.OPT_ROLLOUT_CHUNKS, val)
+            assert e.get_option(_abi.OPT_ROLLOUT_CHUNKS) == val
         e.close()
 
 
