@@ -18,10 +18,10 @@ slice arrived) and the line says so (`rccl.verified`).  A communicator that cann
 Loop forms.  The north star's loop is a random-action rollout: actions come from the device, step t+1 does not need frame t.
 `fused` (default where the engine fuses: Breakout RGB / RGBA) is one tbx_render_step_synthetic per iteration -- the rasteriser
 of frame t and the step to frame t+1 as ONE launch; `pair` is tbx_step_synthetic ; tbx_render_device, two launches in stream
-order, the rate a policy-driven loop gets.  `chunks` (round 6; where the engine runs them: Breakout and SpaceInvaders up to 8 192
-envs, --rollout-chunks) is one tbx_rollout_synthetic per --gather-every steps -- step launches on a step lane, the chunk's
-rasteriser launches overlapped on two more, the ring's collective queued by the call -- when the timed region is a whole number
-of chunks.  Whenever `value` is not the pair form in stream order, that is measured on the same engine and reported beside it
+order, the rate a policy-driven loop gets.  `chunks` (round 6; where the engine runs them: Breakout up to 32 768 envs,
+SpaceInvaders up to 8 192, --rollout-chunks) is one tbx_rollout_synthetic per --gather-every steps -- step launches on a step
+lane, the chunk's rasteriser launches on other internal streams (Breakout: ONE launch over the chunk's frames, chunk behind
+chunk), the ring's collective queued by the call -- when the timed region is a whole number of chunks.  Whenever `value` is not the pair form in stream order, that is measured on the same engine and reported beside it
 as `serialised`.
 
 Protocol (mirroring the repeat-and-summarise shape of the reference's test/benchmark.py:119-148): an untimed
@@ -660,7 +660,7 @@ class Loop:
         if self.overlapped and self.K > 1:
             self.run = self.K - self.skip
         # rollout chunks (tbx_rollout_synthetic / TBX_OPT_ROLLOUT_CHUNKS): the fused loop in chunks of `chunk_k` steps -- one step launch
-        # + chunk_k overlapped rasteriser launches per call, the ring's collective queued by the call itself.  Only when every phase of the
+        # + the chunk's rasteriser launches (one over its chunk_k x n frames, or one per frame on two lanes) per call, the ring's collective queued by the call itself.  Only when every phase of the
         # loop is a whole number of chunks (a K-step ring cannot be left partly filled)
         self.chunk_k = 0
         self._rollout_ids = (_abi.BUF_ROLLOUT_FRAMES,)

@@ -132,7 +132,7 @@ def main():
         st.synchronize()                               # (not a device-wide wait: the clock probe's kernel is still running)
 
     # the forms: "order" = the fused launch in stream order; a number = tbx_rollout_synthetic with TBX_OPT_ROLLOUT_CHUNKS set to it
-    # (1 on, 3 a rasteriser launch per frame on two lanes, 4 one per chunk on one lane, 5 one per chunk, lanes alternating)
+    # (1 on, 3 a rasteriser launch per frame on two lanes, 4 one per chunk on one lane)
     forms = os.environ.get("BP_FORMS", "order,1").split(",")
     for form in forms:
         e.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_OFF if form == "order" else int(form))

@@ -38,7 +38,7 @@ OPT_PIPELINE_ACTIVE = 100          # read-only: what OPT_PIPELINE resolves to on
 OPT_RECORDS_ACTIVE = 101           # read-only: the rasteriser reads step-written render records
 OPT_RENDER_STEP_FUSED = 102        # read-only: tbx_render_step_synthetic is one launch on this engine
 OPT_FUSED_OVERLAP_ACTIVE = 103     # read-only: such launches would be overlapped right now
-OPT_ROLLOUT_CHUNKS = 9             # tbx_rollout_synthetic as one step launch + k overlapped rasteriser launches: 0 engine's choice, 1 on, 2 off
+OPT_ROLLOUT_CHUNKS = 9             # tbx_rollout_synthetic as one step launch + the chunk's rasteriser launches on internal streams: 0 engine's choice, 1 on, 2 off
 ROLLOUT_CHUNKS_AUTO, ROLLOUT_CHUNKS_ON, ROLLOUT_CHUNKS_OFF = 0, 1, 2
 ROLLOUT_CHUNKS_PER_FRAME, ROLLOUT_CHUNKS_SPAN = 3, 4   # on, with the rasteriser form named: a launch per frame on two lanes, one per chunk on one
 OPT_ROLLOUT_CHUNKS_ACTIVE = 104    # read-only: it would run that way right now

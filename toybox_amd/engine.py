@@ -481,7 +481,7 @@ class Engine:
     def rollout_synthetic(self, action_seed, t0, k, channels=3, env_offset=0, auto_reset=True, stream=0):
         """tbx_rollout_synthetic: k consecutive render_step_synthetic calls (each followed by gather() under a K-step record ring, K = k)
         as one -- frames in BUF_ROLLOUT_FRAMES [k, N, H, W, C], step records in BUF_ROLLOUT_PACKED [k, stride].  Where the engine can
-        (Breakout RGB / RGBA) one step launch + k rasteriser launches overlapped on internal streams."""
+        (Breakout, SpaceInvaders; RGB / RGBA) the chunk's steps on an internal stream + its rasteriser launches on others (OPT_ROLLOUT_CHUNKS)."""
         flags = _abi.STEP_AUTO_RESET if auto_reset else 0
         self._check(self._lib.tbx_rollout_synthetic(self._h, int(channels), int(action_seed), int(t0), int(k), int(env_offset), flags,
                                                     C.c_void_p(int(stream))))
