@@ -113,6 +113,7 @@ def main():
     mhz = (C.c_double * 4096)()
 
     CK = G if G else int(os.environ.get("BP_K", "4"))        # frames per chunk (with a ring: its K)
+    issued = [0.0]
 
     def loop(form, k):
         nonlocal t
@@ -125,6 +126,7 @@ def main():
                     if G:
                         e.gather(stream=st.ptr)
             t += CK
+        issued[0] = time.perf_counter()                 # (every call is queued: the host's share of the loop ends here)
         if form != "order":
             e.device_buffer(_abi.BUF_ROLLOUT_FRAMES)     # (the lazy join: the caller's stream behind the chunk's lanes)
         if G:
@@ -154,7 +156,8 @@ def main():
                 k = clk.clkp_stop(mhz, 4096)
                 v = sorted(mhz[i] for i in range(max(k, 0)))
                 note = "shader clock over %d intervals of 20 ms: min %.0f med %.0f max %.0f MHz;  " % (k, v[0], v[len(v) // 2], v[-1]) if v else "(no clock samples: %d)  " % k
-            print("round %d  %-6s  %.4f ms/step   %s%s" % (r, form, dt / steps * 1e3, note, s.summary() if os.environ.get("BP_HWMON") else ""), flush=True)
+            print("round %d  %-6s  %.4f ms/step   (the host had queued everything after %.4f ms/step)   %s%s"
+                  % (r, form, dt / steps * 1e3, (issued[0] - t0) / steps * 1e3, note, s.summary() if os.environ.get("BP_HWMON") else ""), flush=True)
     if os.environ.get("BP_ADDR"):
         print("addresses: " + ", ".join("%s %#x" % (k, e.device_buffer(v)[0]) for k, v in (("frames", _abi.BUF_ROLLOUT_FRAMES), ("packed", _abi.BUF_ROLLOUT_PACKED))))
     e.sync()

@@ -2080,8 +2080,9 @@ struct BreakoutOps : GameOps {
     // every one).  All of that is the form with a rasteriser launch per frame on two lanes; its spread is a lottery of where the buffers
     // lie (r06_experiments item 6), the form with ONE rasteriser launch per chunk (rollout_render_span) has none and gains 7.5 % at
     // 4 096 envs with the ring, 4 % at 8 192 (6 % with K = 8, 6.5 % with 16), 2 % at 16 384, 1 % at 32 768, 0.3-0.8 % at 65 536 -- and loses
-    // 45 % at 1 024 with the ring (the next chunk's step launch rewrites the ring's rows and so waits for this chunk's collective: step
-    // launch and collective in series, 160 us per chunk, longer than 4 x 1 024 frames take to paint; 2 048: -3 %).  The engine's choice:
+    // 45 % at 1 024 with the ring (165-175 us per chunk where the launches add up to less: the host queues a chunk in 28 us and the clock
+    // is the same, but the step launch takes 60-105 us there against 32-48 without the ring and starts 70 us after the one before it
+    // ended -- r06_chunk_timelines_3.txt; cause not established; 2 048: -3 %).  The engine's choice:
     // chunks up to 32 768 envs, under a ring from 2 048; per-frame launches only where they never lost (no gather, 4 096 envs and
     // below: -15 % at 1 024, -7 % at 2 048, -10 % at 4 096).
     bool rollout_auto(int n, int gather_kind) const override { return n <= 32768 && (gather_kind == 0 || n >= 2048); }

@@ -864,8 +864,9 @@ static int fused_overlapped(tbx_engine* e, int channels, const ActionSource& src
 //               (record j = the state before frame j), the k step records (straight into a ring of the gather, or an engine-owned
 //               [k][N] array) and the state.  It is ordered behind T_{c-1} by the lane, behind the rasterisers of chunk c-2 (they read
 //               R[q]), behind the collective that last read the ring, behind the caller's readers of output set q.
-//   lanes 0, 1  k plain rasteriser launches, launch j on lane j & 1: R[q][j] -> F[q][j].  They wait for T_c and for nothing else --
-//               and T_{c+1} has the whole length of these k launches to finish beside them.  No launch ever waits for a step that is
+//   lanes 0, 1  the rasteriser launches R[q][j] -> F[q][j]: k plain ones, launch j on lane j & 1, or ONE over the chunk's k x N frames
+//               on lane 0 (GameOps::rollout_render_span; below).  They wait for T_c and for nothing else -- and T_{c+1} has the whole
+//               length of these launches to finish beside them.  No launch ever waits for a step that is
 //               running beside a rasteriser (a Breakout step kernel that takes 10 us alone takes 100-250 us there -- what made the
 //               device-side ticket of overlapped fused launches wait for most of the launch before it).
 //   collective  (K-step ring, K = k) behind T_c alone: it runs beside the chunk's rasterisers.

@@ -2009,8 +2009,8 @@ struct SiOps : GameOps {
     }
 
     // ---- rollout chunks (engine.hip, rollout_chunked): the step lane runs the record of the current state and then the k single-frame
-    // step launches of the chunk back to back, step j leaving the record of frame j + 1 in the chunk's buffer; the k rasteriser
-    // launches on the two lanes read them.  (No multi-frame kernel: the wave-per-env step keeps its state in HBM rows anyway.)
+    // step launches of the chunk back to back, step j leaving the record of frame j + 1 in the chunk's buffer; the chunk's rasteriser
+    // launches (engine.hip: per frame on the two lanes, or one over the chunk) read them.  (No multi-frame kernel: the wave-per-env step keeps its state in HBM rows anyway.)
     bool rollout_ok(int) const override { return pipeline_ok(); }
     // scripts/rollout_ab.py (RA_GAME=space_invaders), k = 4, ms per step, single calls in stream order / the pipelined two-launch loop
     // (the engine's choice, off under a record ring) / chunks; no gather | K = 4 ring (r06_rollout_ab_si.txt): 2 048 envs 0.0918 / 0.0793 /

@@ -344,8 +344,8 @@ struct TbxPipe {
     // for by a one-wave kernel in front of launch N+1 (tbx_ticket_wait_kernel) -- not behind its rasteriser blocks.
     bool fused = false;                              // the calls since the pipeline was entered are such launches (pipe_enter joins before the kind of call changes)
     // Rollout chunks (tbx_rollout_synthetic; engine.hip, rollout_chunked): k frames per call.  ONE step launch on the step lane
-    // writes the k render records, the k step records and the state; k plain rasteriser launches alternate between the two lanes,
-    // dependent on that step launch alone -- and the step launch of chunk c+1 runs beside them, a whole chunk ahead of its own
+    // writes the k render records, the k step records and the state; the rasteriser launches (k, alternating between the two lanes, or
+    // one over the chunk's k x N frames on lane 0) depend on that step launch alone -- and the step launch of chunk c+1 runs beside them, a whole chunk ahead of its own
     // rasterisers: no launch waits for a step that runs beside a rasteriser (what kept overlapped fused launches unstable).
     bool rollout = false;                            // the calls since the pipeline was entered are rollout chunks
     hipStream_t step_lane = nullptr;
