@@ -838,10 +838,12 @@ CHUNK_K = 4                    # --gather-every: the ring depth is the chunk len
 LAST_LOOP_FORM = {"chunk_k": 0, "overlapped": False}    # what timed_arm's loop resolved to (read right after the call)
 CHUNK_NOTE = ("tbx_rollout_synthetic: the fused loop in chunks of %d steps -- per chunk ONE step launch on an internal stream (every env %d "
               "frames with its state in registers: %d render records, the %d step records straight into the record ring, the state once) and "
-              "%d plain rasteriser launches alternating between two more internal streams, dependent on that step launch alone; the next chunk's "
-              "step launch runs beside this chunk's rasterisers and the ring's collective waits for the step launch only (TBX_OPT_ROLLOUT_CHUNKS; "
-              "the engines' choice up to 8 192 envs).  avg_launch_ms: the time from one rasteriser launch's end to the next one's -- what a "
-              "frame costs in steady state -- not a kernel's own duration")
+              "the rasteriser launches of its %d frames, dependent on that step launch alone -- ONE launch over the chunk's frames, chunk behind "
+              "chunk on a second internal stream (Breakout under a record ring or above 4 096 envs), or a launch per frame alternating between "
+              "two; the next chunk's step launch runs beside this chunk's rasterisers and the ring's collective waits for the step launch only "
+              "(TBX_OPT_ROLLOUT_CHUNKS; the engines' choice: Breakout up to 32 768 envs, SpaceInvaders up to 8 192).  avg_launch_ms: the "
+              "time per frame between the ends of the first and the last chunk of a region -- what a frame costs in steady state -- not a "
+              "kernel's own duration")
 OVERLAP_NOTE = ("consecutive fused launches alternate between two internal streams, output sets and frame buffers; launch N+1 is ordered "
                 "behind the STEP BLOCKS of launch N only (a device-side counter they bump once their agent-scope stores are out, awaited by "
                 "a one-wave kernel in front of launch N+1), so it ramps up while launch N still paints (TBX_OPT_FUSED_OVERLAP; the engine's "
