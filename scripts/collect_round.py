@@ -124,7 +124,10 @@ def host_rates(tag):
 
 def rehearsal(tag):
     out = ["# bench.py --gpus N --gather host --one-device: the whole N-process flow on ONE GPU (every rank on device 0, the record gather over the",
-           "# host transport): what it exercises is the flow, not a scaling figure -- N ranks share one GPU", ""]
+           "# host transport): what it exercises is the flow, not a scaling figure -- N ranks share one GPU.  Round 6: with --steps 20 every rank",
+           "# runs its share as rollout chunks (step lane + rasteriser lane per process); eight such processes on ONE GPU take 9.1 ms per step where",
+           "# eight processes of fused launches in stream order took 3.1 (--steps 50, not a whole number of chunks: the pass before) -- an artefact of",
+           "# eight processes' internal streams sharing one GPU; the 2-rank runs are chunks too (49.5 M env-steps/s for the pair)", ""]
     for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, "rehearsal_*.json"))):
         try:
             j = json.loads([ln for ln in open(f) if ln.startswith("{")][-1])

@@ -23,7 +23,7 @@ $B --envs 8192 --with-gather --no-extras --steps 400 --loop pair > "$OUT/bench_b
 $B --envs 8192 --with-gather --no-extras --steps 400 --loop pair --gather-every 1 > "$OUT/bench_breakout_8192_gather_pair_k1.json" 2>/dev/null
 # ---- the N-process flow on ONE GPU: 2 and 8 ranks on device 0, host transport of the gather (no RCCL between two ranks of one device)
 python bench.py --gpus 2 --gather host --one-device --cpu-seconds 4 > "$OUT/rehearsal_2ranks_host_transport.json" 2> "$OUT/rehearsal_2ranks.err"
-python bench.py --gpus 8 --gather host --one-device --cpu-seconds 4 --steps 50 > "$OUT/rehearsal_8ranks_host_transport.json" 2> "$OUT/rehearsal_8ranks.err"
+python bench.py --gpus 8 --gather host --one-device --cpu-seconds 4 --steps 20 --warmup 5 > "$OUT/rehearsal_8ranks_host_transport.json" 2> "$OUT/rehearsal_8ranks.err"
 # ... and under the driver's own launch line for N > 1 (torch.distributed.run exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --gather host --one-device --cpu-seconds 4 > "$OUT/rehearsal_2ranks_torch_distributed_run.json" 2> "$OUT/rehearsal_2ranks_tdr.err"
 for g in breakout space_invaders amidar gridworld; do
