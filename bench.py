@@ -113,6 +113,8 @@ def parse():
                          "the chunk's rasteriser launches); auto = the engine's choice: Breakout up to 32 768 envs (from 2 048 under a record ring), SpaceInvaders up to 8 192")
     ap.add_argument("--gather-every", type=int, default=4,
                     help="K of the record ring (TBX_OPT_GATHER_EVERY): one RCCL all-gather per K steps (1 = every step)")
+    ap.add_argument("--mixed-streams", type=int, default=3, choices=[1, 3],
+                    help="--game mixed: one stream per segment (3: their rasterisers run side by side) or all three segments on ONE stream")
     ap.add_argument("--game", default="breakout")
     ap.add_argument("--envs", type=int, default=65536)
     ap.add_argument("--channels", type=int, default=3)
@@ -309,8 +311,8 @@ def mixed_reading(args, world, rank, local_rank, envs, K, Wm, R, gather, cpu_sec
     games = ["breakout", "amidar", "space_invaders"]
     sizes = MixedBatch.split_sizes(envs, len(games))
     mb = MixedBatch(games, sizes, device=local_rank, global_offset=rank * envs)
-    streams = [hip.Stream() for _ in games]
-    mb.attach_streams([s.ptr for s in streams])
+    streams = [hip.Stream() for _ in range(1 if args.mixed_streams == 1 else len(games))]
+    mb.attach_streams([streams[i % len(streams)].ptr for i in range(len(games))])
     if gather:
         with quiet_stdout():
             mb.gather_init(rank, world, gather_every=args.gather_every, transport=GATHER_TRANSPORT)
