@@ -125,9 +125,11 @@ def host_rates(tag):
 def rehearsal(tag):
     out = ["# bench.py --gpus N --gather host --one-device: the whole N-process flow on ONE GPU (every rank on device 0, the record gather over the",
            "# host transport): what it exercises is the flow, not a scaling figure -- N ranks share one GPU.  Round 6: with --steps 20 every rank",
-           "# runs its share as rollout chunks (step lane + rasteriser lane per process); eight such processes on ONE GPU take 9.1 ms per step where",
-           "# eight processes of fused launches in stream order took 3.1 (--steps 50, not a whole number of chunks: the pass before) -- an artefact of",
-           "# eight processes' internal streams sharing one GPU; the 2-rank runs are chunks too (49.5 M env-steps/s for the pair)", ""]
+           "# runs its share as rollout chunks (a step lane and a rasteriser lane per process).  On ONE shared GPU that form degrades with the number",
+           "# of processes -- 2 ranks 1.32 ms per step (49.5 M env-steps/s for the pair), 4 ranks 4.49 ms, 8 ranks 9.13 ms, against 3.53 ms for 8 ranks",
+           "# of fused launches in stream order (--rollout-chunks off) -- presumably because every exchange of the host transport is a barrier among",
+           "# the ranks' STEP launches, and on a shared GPU a process's step launch queues behind the other processes' rasteriser launches; with a GPU",
+           "# per rank nothing of another rank runs in front of it.  Not a figure of merit either way: the exchange is verified in every run.", ""]
     for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, "rehearsal_*.json"))):
         try:
             j = json.loads([ln for ln in open(f) if ln.startswith("{")][-1])
