@@ -1233,6 +1233,38 @@ def test_engines_choice_of_pipelined_mode(hip_lib):
 
 
 @pytest.mark.gpu
+def test_engines_choice_of_rollout_chunks(hip_lib):
+    """TBX_OPT_ROLLOUT_CHUNKS = 0: what the engines choose by game, batch size and gather (breakout.hip / space_invaders.hip,
+    rollout_auto), read back through TBX_OPT_ROLLOUT_CHUNKS_ACTIVE: Breakout chunks up to 32 768 envs, under a K-step
+    record ring only from 2 048; SpaceInvaders up to 8 192; never with a collective per step, never for Amidar / GridWorld; 1 / 3 / 4
+    switch them on wherever the engine can, 2 off."""
+    want = {("breakout", 1024): (1, 0), ("breakout", 2048): (1, 1), ("breakout", 8192): (1, 1), ("breakout", 32768): (1, 1), ("breakout", 40000): (0, 0),
+            ("space_invaders", 4096): (1, 1), ("space_invaders", 8192): (1, 1), ("space_invaders", 12000): (0, 0), ("amidar", 4096): (0, 0),
+            ("gridworld", 4096): (0, 0)}
+    for (game, n), (plain, ring) in want.items():
+        e = Engine(game, n, lib=hip_lib)
+        assert e.get_option(_abi.OPT_ROLLOUT_CHUNKS_ACTIVE) == plain, (game, n)
+        can = game in ("breakout", "space_invaders")
+        for v in (_abi.ROLLOUT_CHUNKS_ON, _abi.ROLLOUT_CHUNKS_PER_FRAME, _abi.ROLLOUT_CHUNKS_SPAN):
+            e.set_option(_abi.OPT_ROLLOUT_CHUNKS, v)
+            assert e.get_option(_abi.OPT_ROLLOUT_CHUNKS_ACTIVE) == (1 if can else 0), (game, n, v)
+        e.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_OFF)
+        assert e.get_option(_abi.OPT_ROLLOUT_CHUNKS_ACTIVE) == 0
+        e.set_option(_abi.OPT_ROLLOUT_CHUNKS, _abi.ROLLOUT_CHUNKS_AUTO)
+        e.close()
+        for every, expect in ((4, ring), (1, 0)):                                # a K-step ring / a collective per step
+            e = Engine(game, n, lib=hip_lib)
+            e.set_option(_abi.OPT_GATHER_EVERY, every)
+            try:
+                e.gather_init(1, 0, e.gather_unique_id())
+            except ToyboxAmdError:
+                e.close()
+                break                                                            # no librccl on this box
+            assert e.get_option(_abi.OPT_ROLLOUT_CHUNKS_ACTIVE) == expect, (game, n, every)
+            e.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("game", GAMES)
 def test_step1_frame_resident_kernel_paints(game, hip_lib, oracle_lib):
     """tbx_step1_frame = ToyboxBaseEnv.step in one call (envs/atari/base.py:126,109): on a one-env engine the resident kernel
